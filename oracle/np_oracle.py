@@ -1,0 +1,295 @@
+"""numpy/scipy CPU restatement of the g2o Gauss-Newton SE(2) pose-graph path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under ``sparse_gslam_amd/`` may import this
+module; only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s
+``cpu_baseline`` leg do, and only as the checker.
+
+PARITY UNPINNED: the arithmetic restated here lives in g2o (ros-gbp/libg2o-release,
+noetic branch = g2o 2020.5.29), an un-vendored third-party dependency of the
+reference that is absent from /root/reference and cannot be built in this image
+(no Eigen, no network).  The reference repo holds no tests / golden vectors for
+this path, so this restatement is anchored on the
+reference's call sites and on the published g2o algorithm, and is cross-checked
+against the independent C++ restatement in ``oracle/sgo_oracle.cpp`` and against
+hand-derived known answers (tests/test_oracle_kat.py).
+
+What is restated, and which reference call site binds it
+--------------------------------------------------------
+* ``normalize_theta``, SE2 compose / inverse      g2o/stuff/misc.h, types/slam2d/se2.h
+      used at src/sparse_gslam/src/submap_loop_closer.cpp:217-219,275
+* ``edge_error``      EdgeSE2::computeError       submap_loop_closer.cpp:214-217,273-276;
+                                                  log_runner.cpp:183-184
+* ``edge_jacobians``  EdgeSE2::linearizeOplus     (same edges)
+* ``dcs_rho``         RobustKernelDCS::robustify  submap_loop_closer.cpp:41,57,283
+* ``linearize``       BaseBinaryEdge::constructQuadraticForm + BlockSolver<3,3>::buildSystem
+                                                  src/sparse_gslam/src/graphs.cpp:17-20
+* ``solve_direct``    LinearSolverEigen (SimplicialLDLT); here SuperLU, both exact
+                      sparse direct factorisations in fp64           graphs.cpp:19
+* ``gauss_newton``    OptimizationAlgorithmGaussNewton::solve x n, VertexSE2::oplusImpl
+                                                  submap_loop_closer.cpp:286-288;
+                                                  log_runner.cpp:203-204
+
+Array conventions (shared with the C-ABI in include/sgo.h)
+----------------------------------------------------------
+poses (V,3) f64 [x,y,theta]; fixed (V,) bool; ei,ej (E,) int; meas (E,3) f64;
+info (E,6) f64 upper triangle [o11,o12,o13,o22,o23,o33]; phi (E,) f64, < 0 means
+"no robust kernel" (odometry edges), >= 0 is the DCS parameter of that edge.
+"""
+from __future__ import annotations
+
+import numpy as np
+import scipy.sparse as sp
+import scipy.sparse.linalg as spla
+
+TWO_PI = 2.0 * np.pi
+
+
+# ----------------------------------------------------------------------------- SE2
+def normalize_theta(t):
+    """g2o::normalize_theta: result in [-pi, pi).  Branch structure kept literal."""
+    t = np.asarray(t, dtype=np.float64)
+    inside = (t >= -np.pi) & (t < np.pi)
+    m = np.floor(t / TWO_PI)
+    u = t - m * TWO_PI
+    u = np.where(u >= np.pi, u - TWO_PI, u)
+    u = np.where(u < -np.pi, u + TWO_PI, u)
+    return np.where(inside, t, u)
+
+
+def se2_mul(a, b):
+    """a*b for (...,3) arrays: t = ta + R(tha) tb ; th = normalize(tha + thb)."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    c, s = np.cos(a[..., 2]), np.sin(a[..., 2])
+    out = np.empty(np.broadcast(a, b).shape, dtype=np.float64)
+    out[..., 0] = a[..., 0] + c * b[..., 0] - s * b[..., 1]
+    out[..., 1] = a[..., 1] + s * b[..., 0] + c * b[..., 1]
+    out[..., 2] = normalize_theta(a[..., 2] + b[..., 2])
+    return out
+
+
+def se2_inv(a):
+    """a^-1: th' = normalize(-th); t' = R(th') (-t)."""
+    a = np.asarray(a, dtype=np.float64)
+    th = normalize_theta(-a[..., 2])
+    c, s = np.cos(th), np.sin(th)
+    out = np.empty_like(a)
+    out[..., 0] = c * (-a[..., 0]) - s * (-a[..., 1])
+    out[..., 1] = s * (-a[..., 0]) + c * (-a[..., 1])
+    out[..., 2] = th
+    return out
+
+
+# ----------------------------------------------------------------------------- edges
+def info_full(info6):
+    """(E,6) upper triangle -> (E,3,3) symmetric."""
+    info6 = np.asarray(info6, dtype=np.float64)
+    O = np.empty(info6.shape[:-1] + (3, 3))
+    O[..., 0, 0] = info6[..., 0]
+    O[..., 0, 1] = O[..., 1, 0] = info6[..., 1]
+    O[..., 0, 2] = O[..., 2, 0] = info6[..., 2]
+    O[..., 1, 1] = info6[..., 3]
+    O[..., 1, 2] = O[..., 2, 1] = info6[..., 4]
+    O[..., 2, 2] = info6[..., 5]
+    return O
+
+
+def edge_error(xi, xj, meas):
+    """EdgeSE2::computeError: e = toVector( Z^-1 * (Xi^-1 * Xj) )."""
+    zinv = se2_inv(meas)
+    return se2_mul(zinv, se2_mul(se2_inv(xi), xj))
+
+
+def edge_jacobians(xi, xj, meas):
+    """EdgeSE2::linearizeOplus (analytic).  Returns A = de/dXi, B = de/dXj, (E,3,3)."""
+    xi = np.asarray(xi, dtype=np.float64)
+    xj = np.asarray(xj, dtype=np.float64)
+    zinv = se2_inv(meas)
+    si, ci = np.sin(xi[..., 2]), np.cos(xi[..., 2])
+    dx = xj[..., 0] - xi[..., 0]
+    dy = xj[..., 1] - xi[..., 1]
+    n = xi.shape[:-1]
+    A = np.zeros(n + (3, 3))
+    B = np.zeros(n + (3, 3))
+    A[..., 0, 0] = -ci
+    A[..., 0, 1] = -si
+    A[..., 0, 2] = -si * dx + ci * dy
+    A[..., 1, 0] = si
+    A[..., 1, 1] = -ci
+    A[..., 1, 2] = -ci * dx - si * dy
+    A[..., 2, 2] = -1.0
+    B[..., 0, 0] = ci
+    B[..., 0, 1] = si
+    B[..., 1, 0] = -si
+    B[..., 1, 1] = ci
+    B[..., 2, 2] = 1.0
+    Rz = np.zeros(n + (3, 3))
+    cz, sz = np.cos(zinv[..., 2]), np.sin(zinv[..., 2])
+    Rz[..., 0, 0] = cz
+    Rz[..., 0, 1] = -sz
+    Rz[..., 1, 0] = sz
+    Rz[..., 1, 1] = cz
+    Rz[..., 2, 2] = 1.0
+    return Rz @ A, Rz @ B
+
+
+def dcs_rho(e2, phi):
+    """RobustKernelDCS::robustify.  Returns (rho0, rho1); rho2 is 0 upstream.
+
+    phi < 0 => no kernel on that edge (rho0 = e2, rho1 = 1)."""
+    e2 = np.asarray(e2, dtype=np.float64)
+    phi = np.broadcast_to(np.asarray(phi, dtype=np.float64), e2.shape)
+    has = phi >= 0
+    with np.errstate(divide="ignore", invalid="ignore"):
+        scale = np.where(has, (2.0 * phi) / (phi + e2), 1.0)
+    sat = (~has) | (scale >= 1.0)
+    rho0 = np.where(sat, e2, scale * e2 * scale)
+    rho1 = np.where(sat, 1.0, scale * scale)
+    return rho0, rho1
+
+
+def chi2(poses, ei, ej, meas, info, phi):
+    """computeActiveErrors + activeChi2 / activeRobustChi2 -> (plain, robust, per-edge e2)."""
+    e = edge_error(poses[ei], poses[ej], meas)
+    O = info_full(info)
+    e2 = np.einsum("ni,nij,nj->n", e, O, e)
+    rho0, _ = dcs_rho(e2, phi)
+    return float(e2.sum()), float(rho0.sum()), e2
+
+
+# ----------------------------------------------------------------------------- system
+def hessian_index(fixed):
+    """BlockSolver::buildStructure index map: non-fixed vertices in ascending id."""
+    fixed = np.asarray(fixed, dtype=bool)
+    hidx = np.full(fixed.shape[0], -1, dtype=np.int64)
+    free = np.flatnonzero(~fixed)
+    hidx[free] = np.arange(free.size)
+    return hidx, free
+
+
+def linearize(poses, fixed, ei, ej, meas, info, phi):
+    """buildSystem: returns (H csc (3n x 3n, full symmetric), b (3n,), plain chi2, robust chi2).
+
+    b = -J^T (rho1 Omega) e ; H = J^T (rho1 Omega) J  (second-order robust term disabled
+    upstream).  Blocks of fixed vertices are skipped."""
+    hidx, free = hessian_index(fixed)
+    n = free.size
+    xi, xj = poses[ei], poses[ej]
+    e = edge_error(xi, xj, meas)
+    A, B = edge_jacobians(xi, xj, meas)
+    O = info_full(info)
+    e2 = np.einsum("ni,nij,nj->n", e, O, e)
+    rho0, rho1 = dcs_rho(e2, phi)
+    Ow = O * rho1[:, None, None]
+    Oe = np.einsum("nij,nj->ni", Ow, e)
+    At = np.swapaxes(A, 1, 2)
+    Bt = np.swapaxes(B, 1, 2)
+    bi = -np.einsum("nij,nj->ni", At, Oe)
+    bj = -np.einsum("nij,nj->ni", Bt, Oe)
+    Hii = At @ Ow @ A
+    Hjj = Bt @ Ow @ B
+    Hij = At @ Ow @ B
+    hi, hj = hidx[ei], hidx[ej]
+    fi, fj = hi >= 0, hj >= 0
+    b = np.zeros(3 * n)
+    np.add.at(b, (3 * hi[fi])[:, None] + np.arange(3)[None, :], bi[fi])
+    np.add.at(b, (3 * hj[fj])[:, None] + np.arange(3)[None, :], bj[fj])
+    rr = np.arange(3)[None, :, None]
+    cc = np.arange(3)[None, None, :]
+    rows, cols, vals = [], [], []
+
+    def put(mask, r, c, blk):
+        rows.append(np.broadcast_to(3 * r[mask][:, None, None] + rr, blk[mask].shape).ravel())
+        cols.append(np.broadcast_to(3 * c[mask][:, None, None] + cc, blk[mask].shape).ravel())
+        vals.append(blk[mask].ravel())
+
+    put(fi, hi, hi, Hii)
+    put(fj, hj, hj, Hjj)
+    both = fi & fj
+    put(both, hi, hj, Hij)
+    put(both, hj, hi, np.swapaxes(Hij, 1, 2))
+    if rows:
+        H = sp.coo_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))),
+                          shape=(3 * n, 3 * n)).tocsc()
+    else:
+        H = sp.csc_matrix((3 * n, 3 * n))
+    return H, b, float(e2.sum()), float(rho0.sum())
+
+
+def solve_direct(H, b):
+    """Exact sparse direct solve (SuperLU, symmetric-mode ordering)."""
+    lu = spla.splu(H.tocsc(), permc_spec="MMD_AT_PLUS_A", diag_pivot_thresh=0.0,
+                   options=dict(SymmetricMode=True))
+    return lu.solve(b)
+
+
+def solve_pcg(H, b, tol=1e-10, maxit=100000):
+    """Block-Jacobi preconditioned CG on the assembled system (reference for the GPU PCG)."""
+    n = b.size // 3
+    Hr = H.tocsr()
+    D = np.zeros((n, 3, 3))
+    Hb = Hr.tobsr(blocksize=(3, 3))
+    for r in range(n):
+        lo, hi = Hb.indptr[r], Hb.indptr[r + 1]
+        k = np.searchsorted(Hb.indices[lo:hi], r)
+        D[r] = Hb.data[lo + k]
+    Dinv = np.linalg.inv(D)
+    x = np.zeros_like(b)
+    r = b.copy()
+    z = np.einsum("nij,nj->ni", Dinv, r.reshape(n, 3)).ravel()
+    p = z.copy()
+    rz = r @ z
+    bn = np.sqrt(b @ b)
+    it = 0
+    while it < maxit and np.sqrt(r @ r) > tol * bn:
+        q = Hr @ p
+        alpha = rz / (p @ q)
+        x += alpha * p
+        r -= alpha * q
+        z = np.einsum("nij,nj->ni", Dinv, r.reshape(n, 3)).ravel()
+        rz_new = r @ z
+        p = z + (rz_new / rz) * p
+        rz = rz_new
+        it += 1
+    return x, it
+
+
+def oplus(poses, fixed, dx):
+    """SparseOptimizer::update -> VertexSE2::oplusImpl: additive t, wrapped theta."""
+    hidx, free = hessian_index(fixed)
+    out = np.array(poses, dtype=np.float64, copy=True)
+    d = dx.reshape(-1, 3)
+    out[free, 0] += d[:, 0]
+    out[free, 1] += d[:, 1]
+    out[free, 2] = normalize_theta(out[free, 2] + d[:, 2])
+    return out
+
+
+def gauss_newton(poses, fixed, ei, ej, meas, info, phi, iters=20, solver="direct",
+                 pcg_tol=1e-10, trace=None):
+    """optimize(iters): iters x { computeActiveErrors; buildSystem; solve; update }.
+
+    No damping, no convergence test (OptimizationAlgorithmGaussNewton).  Returns
+    (poses, stats) where stats['chi2'][k] / ['robust_chi2'][k] are the values at the START
+    of iteration k and entry [iters] is the final computeActiveErrors()."""
+    poses = np.array(poses, dtype=np.float64, copy=True)
+    stats = dict(chi2=[], robust_chi2=[], pcg_iters=[])
+    for _ in range(iters):
+        H, b, c2, rc2 = linearize(poses, fixed, ei, ej, meas, info, phi)
+        stats["chi2"].append(c2)
+        stats["robust_chi2"].append(rc2)
+        if solver == "direct":
+            dx = solve_direct(H, b)
+            stats["pcg_iters"].append(0)
+        else:
+            dx, k = solve_pcg(H, b, tol=pcg_tol)
+            stats["pcg_iters"].append(k)
+        if not np.all(np.isfinite(dx)):
+            break
+        poses = oplus(poses, fixed, dx)
+        if trace is not None:
+            trace.append(poses.copy())
+    c2, rc2, _ = chi2(poses, ei, ej, meas, info, phi)
+    stats["chi2"].append(c2)
+    stats["robust_chi2"].append(rc2)
+    return poses, stats
