@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""bench.py -- edge-Jacobians/s per Gauss-Newton iteration on a synthetic SE(2) pose graph.
+
+    python bench.py --gpus N --steps K --warmup W [--config C4] [--iters 20]
+
+A *step* is one ``optimize(20)`` call of the hot path (what the reference runs per accepted loop
+closure: src/sparse_gslam/src/submap_loop_closer.cpp:286-287) from the same initial poses, i.e.
+20 x { chi2, linearise + assemble, PCG solve, pose update } over all E edges.  ``value`` =
+steps x iters x E / time = edge-Jacobian evaluations per second per GN iteration, with the graph
+(structure + edge arrays) already resident in HBM when the timed region starts; the only upload in
+the timed region is the 24*V-byte pose reset at the start of each step.
+
+N > 1: launched by ``python -m torch.distributed.run``; one rank per GPU; the edge set is sharded
+(contiguous ranges after sorting by min(vi,vj)), poses are replicated, and the per-vertex
+(block-diagonal H, b) partials and the per-PCG-step Hessian-product partials are all-reduced with
+RCCL inside libsgo.  Total work is fixed => "scaling": "strong".
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 measured copy)
+
+
+def shard_edges(g, nranks: int, rank: int):
+    """Contiguous edge ranges after sorting by min(vi, vj) (compact vertex footprint per shard)."""
+    if nranks == 1:
+        return g
+    order = np.argsort(np.minimum(g.ei, g.ej), kind="stable")
+    lo = (g.E * rank) // nranks
+    hi = (g.E * (rank + 1)) // nranks
+    mask = np.zeros(g.E, dtype=bool)
+    mask[order[lo:hi]] = True
+    return g.subset(mask)
+
+
+def cpu_baseline(g, iters: int, budget_s: float = 25.0):
+    """The C++ oracle (single thread, sparse direct LDL^T -- the reference's solver class) timed on
+    a bounded sample: a prefix sub-graph (first Vs poses and the edges among them) sized so the
+    run stays within the budget."""
+    from oracle import c_oracle
+
+    Vs = min(g.V, 10_000)
+    keep = (g.ei < Vs) & (g.ej < Vs)
+    args = (g.poses[:Vs], g.fixed[:Vs], g.ei[keep], g.ej[keep], g.meas[keep], g.info[keep], g.phi[keep])
+    Es = int(keep.sum())
+    t0 = time.perf_counter()
+    n_it = 0
+    secs = []
+    while n_it < iters and (time.perf_counter() - t0) < budget_s:
+        # one GN iteration per call keeps the sample bounded; the symbolic analysis is redone each
+        # call (g2o redoes it once per optimize()), so time only the per-iteration figure it reports
+        _, st = c_oracle.gauss_newton(*args, iters=2, solver="direct")
+        secs.append(st["seconds"][1])  # iteration 1: numeric factorisation only (analysis done in 0)
+        n_it += 1
+        if n_it >= 3:
+            break
+    med = float(np.median(secs))
+    return dict(value=Es / med, unit="edge-Jacobians/s per GN iter", cores=1, kind="port",
+                sample=f"CPU restatement of g2o GN (not g2o itself: g2o/Eigen are not in the image): "
+                       f"single-thread C++ oracle, sparse direct LDL^T + min-degree ordering, on the "
+                       f"first {Vs} poses / {Es} edges of the workload, median of {n_it} GN iterations "
+                       f"(numeric factorisation + solve, symbolic analysis excluded)")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="C4")
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--solver", default=None, help="pcg | amg (default: library default)")
+    ap.add_argument("--tol", type=float, default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with python -m torch.distributed.run")
+        args.gpus = world
+
+    import torch
+    import torch.distributed as dist
+
+    from sparse_gslam_amd import capi, synth
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    g = synth.config(args.config)
+    shard = shard_edges(g, world, rank)
+
+    opts = {}
+    if args.solver:
+        opts["solver"] = dict(pcg=capi.SOLVER_PCG_BJ, bj=capi.SOLVER_PCG_BJ, amg=capi.SOLVER_PCG_AMG)[args.solver]
+    if args.tol:
+        opts["pcg_tol"] = args.tol
+    opt = capi.Optimizer(local_rank, **opts)
+    if world > 1:
+        uid = [capi.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        opt.comm_init(world, rank, uid[0])
+    opt.set_graph(*shard.arrays())
+
+    def step():
+        opt.set_poses(g.poses)
+        done, st = opt.optimize(args.iters)
+        if done != args.iters:
+            raise SystemExit(f"optimize stopped after {done} iterations: {st}")
+        return st
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    st = None
+    for _ in range(args.steps):
+        st = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    out = None
+    if rank == 0:
+        value = args.steps * args.iters * g.E / dt
+        o = capi.default_opts()
+        out = {
+            "metric": "edge-Jacobians/sec per GN iter on SE(2) graph; final chi2 vs g2o",
+            "value": value, "unit": "edge-Jacobians/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{args.config}: manhattan(V={g.V}, E={g.E}, seed={g.meta['seed']}, "
+                                   f"p_random={g.meta['p_random']}), init={g.meta['init']}, "
+                                   f"optimize({args.iters}) per step",
+                       "V": g.V, "E": g.E, "gn_iters_per_step": args.iters,
+                       "solver": {0: "pcg_block_jacobi", 1: "pcg_amg"}[opts.get("solver", o.solver)],
+                       "pcg_tol": opts.get("pcg_tol", o.pcg_tol), "parallelism": f"edge-shard x{world}"},
+            "final_chi2": st["chi2"][-1], "final_robust_chi2": st["robust_chi2"][-1],
+            "pcg_iters_per_gn_iter": float(np.mean(st["pcg_iters"])),
+            "gn_iter_ms_median": 1e3 * float(np.median(st["seconds"])),
+            "linearize_ms_median": 1e3 * float(np.median(st["seconds_linearize"])),
+        }
+    opt.close()
+
+    if rank == 0 and not args.no_roofline:
+        # roofline leg: same workload, every launch bracketed by HIP events on the ctx stream
+        popts = dict(opts)
+        popts["profile"] = 1
+        with capi.Optimizer(local_rank, **popts) as p:
+            if world == 1:
+                p.set_graph(*g.arrays())
+                p.optimize(min(args.iters, 3))
+                prof = p.kernel_profile()
+                name, k = max(prof.items(), key=lambda kv: kv[1]["ms"])
+                achieved = k["bytes"] / (k["ms"] * 1e-3) / 1e9
+                out["roofline"] = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS,
+                                   "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                                   "avg_launch_us": 1e3 * k["ms"] / k["launches"], "launches": k["launches"],
+                                   "algorithmic_bytes_per_launch": k["bytes"] / k["launches"],
+                                   "kernels": {n: {"launches": v["launches"], "ms": round(v["ms"], 3),
+                                                   "GB/s": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)}
+                                               for n, v in prof.items() if v["ms"] > 0}}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(g, args.iters)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,170 @@
+/* sgo.h -- C-ABI of the MI355X-native SE(2) pose-graph optimiser (libsgo.so).
+ *
+ * This is the drop-in boundary under sparse-gslam's g2o call sites.  The reference drives a
+ * g2o::SparseOptimizer (src/sparse_gslam/include/graphs.h:31-40) configured as
+ *   OptimizationAlgorithmGaussNewton + BlockSolver<BlockSolverTraits<3,3>> + LinearSolverEigen
+ * (src/sparse_gslam/src/graphs.cpp:17-23) through
+ *   initializeOptimization(); optimize(20); computeActiveErrors();
+ * (src/sparse_gslam/src/submap_loop_closer.cpp:286-288, src/sparse_gslam/src/log_runner.cpp:203-204).
+ * The C++ mirror of that API (include/g2o/...) marshals the pointer graph into the flat arrays
+ * below at initializeOptimization() and calls these entry points; INTEGRATION.md shows the
+ * binding a maintainer adds.
+ *
+ * Conventions
+ *   - plain pointers and sizes, caller-owned buffers, no exceptions, no torch types;
+ *   - every function returning int returns >= 0 on success and a negative SGO_E* code on
+ *     failure; sgo_last_error() gives the text;
+ *   - one sgo_ctx is thread-compatible (one thread at a time, like one g2o::SparseOptimizer,
+ *     serialised by the caller's boost::shared_mutex, graphs.h:21,32); different contexts are
+ *     independent (own HIP stream and device buffers, no global mutable state);
+ *   - all arithmetic is fp64 (g2o number_t = double).
+ *
+ * Array layout at the boundary (host memory)
+ *   poses[V][3]  x, y, theta of vertex id v (ids dense from 0: drone.cpp:64,121; slc.cpp:212)
+ *   fixed[V]     1 = VertexSE2::setFixed(true) (drone.cpp:66,75) -> excluded from the system
+ *   ei[E], ej[E] vertex ids of EdgeSE2::vertices()[0], [1]   (slc.cpp:214-215, 279-280)
+ *   meas[E][3]   EdgeSE2::setMeasurement(SE2(x,y,theta))      (slc.cpp:217, 275)
+ *   info[E][6]   EdgeSE2::information(), upper triangle o11,o12,o13,o22,o23,o33 (slc.cpp:216, 276)
+ *   phi[E]       DCS parameter of the edge's robust kernel (RobustKernelDCS::setDelta,
+ *                slc.cpp:57; attached slc.cpp:283); < 0 = no robust kernel (odometry edges)
+ */
+#ifndef SGO_H_
+#define SGO_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SGO_VERSION 100          /* 0.1.0 */
+#define SGO_MAX_ITERS 256        /* capacity of the per-iteration arrays in sgo_stats */
+
+/* error codes (negative).  -1 mirrors g2o's optimize() "nothing to optimise". */
+#define SGO_OK 0
+#define SGO_ENOTHING (-1)
+#define SGO_EINVAL (-2)
+#define SGO_EHIP (-3)
+#define SGO_ENOGRAPH (-4)
+#define SGO_ECOMM (-5)
+#define SGO_ENOMEM (-6)
+
+/* linear solver behind BlockSolver::solve (replaces LinearSolverEigen, graphs.cpp:19) */
+#define SGO_SOLVER_PCG_BJ 0      /* block-Jacobi preconditioned CG */
+#define SGO_SOLVER_PCG_AMG 1     /* CG preconditioned by a rigid-body aggregation multigrid V-cycle
+                                    with block-Jacobi smoothing */
+
+typedef struct sgo_ctx sgo_ctx;
+
+typedef struct sgo_opts {
+  int32_t struct_size;     /* = sizeof(sgo_opts); lets the struct grow compatibly */
+  int32_t solver;          /* SGO_SOLVER_*; env SGO_SOLVER={pcg,amg} overrides the default */
+  double pcg_tol;          /* stop when ||r|| <= pcg_tol * ||b||   (env SGO_PCG_TOL) */
+  int32_t pcg_maxit;       /* cap on PCG iterations per GN iteration (env SGO_PCG_MAXIT) */
+  int32_t pcg_chunk;       /* PCG iterations replayed per hipGraph launch between host checks */
+  int32_t use_graph;       /* 1: replay the PCG loop from a hipGraph; 0: plain stream launches */
+  int32_t profile;         /* 1: bracket every kernel launch with HIP events (forces use_graph=0)
+                              and report per-kernel totals through sgo_kernel_profile() */
+  int32_t verbose;         /* mirrors SparseOptimizer::setVerbose (graphs.cpp:21) */
+  int32_t reserved[8];
+} sgo_opts;
+
+/* Defaults (also applied when opts == NULL):
+ * solver = PCG_AMG, pcg_tol = 1e-8, pcg_maxit = 20000, pcg_chunk = 16, use_graph = 1. */
+void sgo_default_opts(sgo_opts* o);
+
+typedef struct sgo_stats {
+  int32_t iters_requested;
+  int32_t iters_done;                        /* as g2o optimize(): 0 = first solve failed */
+  double chi2[SGO_MAX_ITERS + 1];            /* activeChi2 at the START of iteration k; [iters_done] = final */
+  double robust_chi2[SGO_MAX_ITERS + 1];     /* activeRobustChi2, same indexing */
+  int32_t pcg_iters[SGO_MAX_ITERS];          /* PCG iterations of GN iteration k */
+  int32_t pcg_converged[SGO_MAX_ITERS];      /* 1 = reached pcg_tol */
+  double pcg_relres[SGO_MAX_ITERS];          /* final ||r|| / ||b|| (recurrence residual) */
+  double seconds[SGO_MAX_ITERS];             /* device time of GN iteration k (HIP events) */
+  double seconds_linearize[SGO_MAX_ITERS];   /* ... of which error/Jacobian/assembly */
+  double seconds_solve[SGO_MAX_ITERS];       /* ... of which the linear solve */
+  double seconds_total;                      /* wall time of the whole call (host clock) */
+  double seconds_setup;                      /* host structure build + upload of the last set_graph */
+} sgo_stats;
+
+int sgo_version(void);
+
+/* Replaces: new g2o::SparseOptimizer + setup_pose_opt() (graphs.cpp:17-23, graphs.h:38).
+ * device = HIP device ordinal (env SGO_DEVICE overrides when device < 0).  NULL on failure
+ * (sgo_last_error(NULL) has the reason). */
+sgo_ctx* sgo_create(int device, const sgo_opts* opts);
+/* Replaces: ~SparseOptimizer.  Never frees caller memory (README.md:22-23). */
+void sgo_destroy(sgo_ctx* ctx);
+
+/* Replaces: SparseOptimizer::initializeOptimization() (slc.cpp:286, log_runner.cpp:203): takes
+ * the active vertices/edges, builds the hessian index map (non-fixed vertices in ascending id),
+ * the block-CSR structure and the device-resident SoA edge arrays.  Edges whose endpoints are
+ * both fixed stay active for chi2 only.  E may be this rank's shard of the edge set when a
+ * communicator is attached (sgo_comm_init). */
+int sgo_set_graph_se2(sgo_ctx* ctx, int32_t V, const double* poses, const uint8_t* fixed, int32_t E,
+                      const int32_t* ei, const int32_t* ej, const double* meas, const double* info,
+                      const double* phi);
+
+/* Replaces: VertexSE2::setEstimate on every vertex (slc.cpp:219) without a structure rebuild. */
+int sgo_set_poses(sgo_ctx* ctx, const double* poses);
+/* Replaces: reading VertexSE2::estimate() after optimize() (slc.cpp:144-148, log_runner.cpp:258-267). */
+int sgo_get_poses(sgo_ctx* ctx, double* poses);
+
+/* Replaces: SparseOptimizer::optimize(iters) with OptimizationAlgorithmGaussNewton (slc.cpp:287,
+ * log_runner.cpp:204): iters x { computeActiveErrors; buildSystem; solve; update }, no damping, no
+ * convergence test.  Returns iterations done (0 = the first linear solve failed, estimates
+ * untouched), SGO_ENOTHING (-1) when there is no free active vertex, or another negative code.
+ * `out` may be NULL. */
+int sgo_optimize_gn(sgo_ctx* ctx, int32_t iters, sgo_stats* out);
+
+/* Replaces: computeActiveErrors(); activeChi2(); activeRobustChi2() (slc.cpp:288, drone.cpp:162-165). */
+int sgo_chi2(sgo_ctx* ctx, double* plain, double* robust);
+/* Replaces: EdgeSE2::computeError(); chi2() per edge (log_runner.cpp:183-184, the 11.345 gate).
+ * e2[E] in the edge order given to sgo_set_graph_se2. */
+int sgo_edge_chi2(sgo_ctx* ctx, double* e2);
+
+/* ---- single-step entry points (what BlockSolver::buildSystem / solve expose inside g2o);
+ *      used by the parity tests to check each kernel against the oracle. ---------------------- */
+/* number of free (non-fixed, active) vertices n; hessian index h -> vertex id in free_ids[n] */
+int sgo_num_free(sgo_ctx* ctx);
+int sgo_free_ids(sgo_ctx* ctx, int32_t* free_ids);
+/* buildSystem at the current poses: b[n][3], diag[n][9] (row-major 3x3), chi2 values. */
+int sgo_linearize(sgo_ctx* ctx, double* b, double* diag, double* plain, double* robust);
+/* y = H x with the Hessian of the last sgo_linearize (x, y: [n][3]). */
+int sgo_hessian_apply(sgo_ctx* ctx, const double* x, double* y);
+/* solve H x = b of the last sgo_linearize; returns PCG iterations (>= 0). */
+int sgo_solve(sgo_ctx* ctx, double* x, double* relres);
+/* z = M^-1 r with the configured preconditioner of the last sgo_linearize (r, z: [n][3]). */
+int sgo_precondition(sgo_ctx* ctx, const double* r, double* z);
+
+/* ---- profiling (opts.profile = 1) ---------------------------------------------------------- */
+/* Per-kernel totals accumulated since the last sgo_profile_reset: for kernel slot k,
+ * name (static string), launches, total milliseconds (HIP events on the ctx stream), and the
+ * algorithmic bytes those launches were specified to move.
+ * Returns the number of slots; fills up to cap entries. */
+typedef struct sgo_kernel_stat {
+  const char* name;
+  int64_t launches;
+  double ms;
+  double bytes;
+} sgo_kernel_stat;
+int sgo_kernel_profile(sgo_ctx* ctx, sgo_kernel_stat* out, int cap);
+int sgo_profile_reset(sgo_ctx* ctx);
+
+/* ---- multi-GPU: edge-sharded, one process per GPU, RCCL over xGMI -------------------------- */
+/* 128-byte unique id for rendezvous (wraps ncclGetUniqueId); rank 0 creates it, the host layer
+ * broadcasts it (torch.distributed / MPI / a file), every rank passes it to sgo_comm_init. */
+#define SGO_UNIQUE_ID_BYTES 128
+int sgo_comm_unique_id(void* id_out);
+int sgo_comm_init(sgo_ctx* ctx, int nranks, int rank, const void* unique_id);
+int sgo_comm_size(sgo_ctx* ctx);
+
+/* Text of the last error on this context (or, with ctx == NULL, of the last failed sgo_create /
+ * context-free call on this thread).  Never NULL. */
+const char* sgo_last_error(sgo_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SGO_H_ */

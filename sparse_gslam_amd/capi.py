@@ -1,0 +1,283 @@
+"""ctypes binding of libsgo.so (include/sgo.h) -- the only way Python reaches the optimiser.
+
+There is no CPU fallback: if the HIP library is missing or no GPU is present, calls fail
+loudly (``SgoError``).  The oracle under ``oracle/`` is never imported from here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libsgo.so")
+
+SGO_MAX_ITERS = 256
+SOLVER_PCG_BJ = 0
+SOLVER_PCG_AMG = 1
+UNIQUE_ID_BYTES = 128
+
+# every symbol include/sgo.h declares (checked by tests/test_abi.py)
+SYMBOLS = [
+    "sgo_version", "sgo_default_opts", "sgo_create", "sgo_destroy", "sgo_set_graph_se2",
+    "sgo_set_poses", "sgo_get_poses", "sgo_optimize_gn", "sgo_chi2", "sgo_edge_chi2",
+    "sgo_num_free", "sgo_free_ids", "sgo_linearize", "sgo_hessian_apply", "sgo_solve",
+    "sgo_precondition", "sgo_kernel_profile", "sgo_profile_reset", "sgo_comm_unique_id",
+    "sgo_comm_init", "sgo_comm_size", "sgo_last_error",
+]
+
+
+class SgoError(RuntimeError):
+    pass
+
+
+class Opts(C.Structure):
+    _fields_ = [("struct_size", C.c_int32), ("solver", C.c_int32), ("pcg_tol", C.c_double),
+                ("pcg_maxit", C.c_int32), ("pcg_chunk", C.c_int32), ("use_graph", C.c_int32),
+                ("profile", C.c_int32), ("verbose", C.c_int32), ("reserved", C.c_int32 * 8)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("iters_requested", C.c_int32), ("iters_done", C.c_int32),
+                ("chi2", C.c_double * (SGO_MAX_ITERS + 1)),
+                ("robust_chi2", C.c_double * (SGO_MAX_ITERS + 1)),
+                ("pcg_iters", C.c_int32 * SGO_MAX_ITERS),
+                ("pcg_converged", C.c_int32 * SGO_MAX_ITERS),
+                ("pcg_relres", C.c_double * SGO_MAX_ITERS),
+                ("seconds", C.c_double * SGO_MAX_ITERS),
+                ("seconds_linearize", C.c_double * SGO_MAX_ITERS),
+                ("seconds_solve", C.c_double * SGO_MAX_ITERS),
+                ("seconds_total", C.c_double), ("seconds_setup", C.c_double)]
+
+
+class KernelStat(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("launches", C.c_int64), ("ms", C.c_double),
+                ("bytes", C.c_double)]
+
+
+_LIB = None
+
+
+def build(force: bool = False) -> str:
+    """Compile libsgo.so in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC)
+            if f.endswith((".hip", ".cpp", ".h"))] + [os.path.join(_HERE, "..", "include", "sgo.h")]
+    stale = (not os.path.exists(LIB_PATH) or
+             any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs))
+    if force or stale:
+        subprocess.check_call(["make", "-s", "-C", CSRC, "libsgo.so"])
+    return LIB_PATH
+
+
+def lib():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise SgoError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; "
+                       "g.build()'` (there is no CPU fallback)")
+    L = C.CDLL(LIB_PATH)
+    d = C.POINTER(C.c_double)
+    i32 = C.POINTER(C.c_int32)
+    u8 = C.POINTER(C.c_uint8)
+    vp = C.c_void_p
+    L.sgo_version.restype = C.c_int
+    L.sgo_default_opts.argtypes = [C.POINTER(Opts)]
+    L.sgo_create.restype = vp
+    L.sgo_create.argtypes = [C.c_int, C.POINTER(Opts)]
+    L.sgo_destroy.argtypes = [vp]
+    L.sgo_set_graph_se2.argtypes = [vp, C.c_int32, d, u8, C.c_int32, i32, i32, d, d, d]
+    L.sgo_set_poses.argtypes = [vp, d]
+    L.sgo_get_poses.argtypes = [vp, d]
+    L.sgo_optimize_gn.argtypes = [vp, C.c_int32, C.POINTER(Stats)]
+    L.sgo_chi2.argtypes = [vp, d, d]
+    L.sgo_edge_chi2.argtypes = [vp, d]
+    L.sgo_num_free.argtypes = [vp]
+    L.sgo_free_ids.argtypes = [vp, i32]
+    L.sgo_linearize.argtypes = [vp, d, d, d, d]
+    L.sgo_hessian_apply.argtypes = [vp, d, d]
+    L.sgo_solve.argtypes = [vp, d, d]
+    L.sgo_precondition.argtypes = [vp, d, d]
+    L.sgo_kernel_profile.argtypes = [vp, C.POINTER(KernelStat), C.c_int]
+    L.sgo_profile_reset.argtypes = [vp]
+    L.sgo_comm_unique_id.argtypes = [vp]
+    L.sgo_comm_init.argtypes = [vp, C.c_int, C.c_int, vp]
+    L.sgo_comm_size.argtypes = [vp]
+    L.sgo_last_error.restype = C.c_char_p
+    L.sgo_last_error.argtypes = [vp]
+    _LIB = L
+    return L
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+def default_opts() -> Opts:
+    o = Opts()
+    lib().sgo_default_opts(C.byref(o))
+    return o
+
+
+def comm_unique_id() -> bytes:
+    buf = C.create_string_buffer(UNIQUE_ID_BYTES)
+    rc = lib().sgo_comm_unique_id(C.cast(buf, C.c_void_p))
+    if rc != 0:
+        raise SgoError("sgo_comm_unique_id: " + lib().sgo_last_error(None).decode())
+    return buf.raw
+
+
+class Optimizer:
+    """One ``sgo_ctx``: the device-side stand-in for the reference's pose-graph
+    ``g2o::SparseOptimizer`` (src/sparse_gslam/include/graphs.h:31-40)."""
+
+    def __init__(self, device: int = 0, **opts):
+        L = lib()
+        o = default_opts()
+        for k, v in opts.items():
+            if not hasattr(o, k):
+                raise TypeError(f"unknown option {k}")
+            setattr(o, k, v)
+        self._h = L.sgo_create(device, C.byref(o))
+        if not self._h:
+            raise SgoError("sgo_create: " + L.sgo_last_error(None).decode())
+        self.V = self.E = 0
+        self.last_stats = None
+
+    # -- lifetime
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().sgo_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _check(self, rc, what):
+        if rc < 0 and rc != -1:
+            raise SgoError(f"{what}: rc={rc}: " + lib().sgo_last_error(self._h).decode())
+        return rc
+
+    # -- multi-GPU
+    def comm_init(self, nranks: int, rank: int, unique_id: bytes):
+        buf = C.create_string_buffer(unique_id, UNIQUE_ID_BYTES)
+        self._check(lib().sgo_comm_init(self._h, nranks, rank, C.cast(buf, C.c_void_p)), "sgo_comm_init")
+
+    # -- graph
+    def set_graph(self, poses, fixed, ei, ej, meas, info, phi):
+        p = np.ascontiguousarray(poses, dtype=np.float64).reshape(-1, 3)
+        f = np.ascontiguousarray(fixed, dtype=np.uint8)
+        a = np.ascontiguousarray(ei, dtype=np.int32)
+        b = np.ascontiguousarray(ej, dtype=np.int32)
+        m = np.ascontiguousarray(meas, dtype=np.float64).reshape(-1, 3)
+        o = np.ascontiguousarray(info, dtype=np.float64).reshape(-1, 6)
+        ph = np.ascontiguousarray(phi, dtype=np.float64)
+        if not (f.shape[0] == p.shape[0] and a.size == b.size == m.shape[0] == o.shape[0] == ph.size):
+            raise ValueError("inconsistent array sizes")
+        self._check(lib().sgo_set_graph_se2(self._h, p.shape[0], _dp(p), f.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                            a.size, _ip(a), _ip(b), _dp(m), _dp(o), _dp(ph)),
+                    "sgo_set_graph_se2")
+        self.V, self.E = p.shape[0], a.size
+
+    def set_poses(self, poses):
+        p = np.ascontiguousarray(poses, dtype=np.float64).reshape(self.V, 3)
+        self._check(lib().sgo_set_poses(self._h, _dp(p)), "sgo_set_poses")
+
+    def get_poses(self):
+        p = np.empty((self.V, 3))
+        self._check(lib().sgo_get_poses(self._h, _dp(p)), "sgo_get_poses")
+        return p
+
+    @property
+    def n_free(self):
+        return self._check(lib().sgo_num_free(self._h), "sgo_num_free")
+
+    def free_ids(self):
+        out = np.empty(self.n_free, dtype=np.int32)
+        self._check(lib().sgo_free_ids(self._h, _ip(out)), "sgo_free_ids")
+        return out
+
+    # -- optimisation
+    def optimize(self, iters: int = 20):
+        """optimize(iters) -> (iterations done, stats dict)."""
+        st = Stats()
+        rc = self._check(lib().sgo_optimize_gn(self._h, iters, C.byref(st)), "sgo_optimize_gn")
+        d = max(st.iters_done, 0)
+        stats = dict(
+            rc=rc, iters_done=st.iters_done, chi2=list(st.chi2[: d + 1]),
+            robust_chi2=list(st.robust_chi2[: d + 1]), pcg_iters=list(st.pcg_iters[:iters]),
+            pcg_converged=list(st.pcg_converged[:iters]), pcg_relres=list(st.pcg_relres[:iters]),
+            seconds=list(st.seconds[:iters]), seconds_linearize=list(st.seconds_linearize[:iters]),
+            seconds_solve=list(st.seconds_solve[:iters]), seconds_total=st.seconds_total,
+            seconds_setup=st.seconds_setup)
+        self.last_stats = stats
+        return rc, stats
+
+    def chi2(self):
+        a = C.c_double()
+        b = C.c_double()
+        self._check(lib().sgo_chi2(self._h, C.byref(a), C.byref(b)), "sgo_chi2")
+        return a.value, b.value
+
+    def edge_chi2(self):
+        out = np.empty(self.E)
+        self._check(lib().sgo_edge_chi2(self._h, _dp(out)), "sgo_edge_chi2")
+        return out
+
+    # -- single steps (parity tests)
+    def linearize(self):
+        n = self.n_free
+        b = np.empty((n, 3))
+        diag = np.empty((n, 3, 3))
+        c = C.c_double()
+        r = C.c_double()
+        self._check(lib().sgo_linearize(self._h, _dp(b), _dp(diag), C.byref(c), C.byref(r)), "sgo_linearize")
+        return b, diag, c.value, r.value
+
+    def hessian_apply(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64).reshape(self.n_free, 3)
+        y = np.empty_like(x)
+        self._check(lib().sgo_hessian_apply(self._h, _dp(x), _dp(y)), "sgo_hessian_apply")
+        return y
+
+    def precondition(self, r):
+        r = np.ascontiguousarray(r, dtype=np.float64).reshape(self.n_free, 3)
+        z = np.empty_like(r)
+        self._check(lib().sgo_precondition(self._h, _dp(r), _dp(z)), "sgo_precondition")
+        return z
+
+    def solve(self):
+        x = np.empty((self.n_free, 3))
+        rr = C.c_double()
+        it = self._check(lib().sgo_solve(self._h, _dp(x), C.byref(rr)), "sgo_solve")
+        return x, it, rr.value
+
+    # -- profiling
+    def kernel_profile(self):
+        arr = (KernelStat * 64)()
+        n = self._check(lib().sgo_kernel_profile(self._h, arr, 64), "sgo_kernel_profile")
+        out = {}
+        for k in range(min(n, 64)):
+            if arr[k].launches:
+                out[arr[k].name.decode()] = dict(launches=int(arr[k].launches), ms=arr[k].ms,
+                                                 bytes=arr[k].bytes)
+        return out
+
+    def profile_reset(self):
+        self._check(lib().sgo_profile_reset(self._h), "sgo_profile_reset")

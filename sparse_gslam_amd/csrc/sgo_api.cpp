@@ -1,0 +1,853 @@
+// sgo_api.cpp -- host side of libsgo: the C-ABI of include/sgo.h over the HIP kernels.
+//
+// Mirrors the control flow of g2o's SparseOptimizer::optimize() with
+// OptimizationAlgorithmGaussNewton as sparse-gslam configures it
+// (src/sparse_gslam/src/graphs.cpp:17-23; called at submap_loop_closer.cpp:286-288 and
+// log_runner.cpp:203-204):
+//     for k in 0..iters:  computeActiveErrors; buildSystem; solve; update
+// with the linear solve done by preconditioned CG on the device instead of LinearSolverEigen.
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "sgo_comm.h"
+#include "sgo_internal.h"
+
+using namespace sgo;
+
+namespace {
+
+thread_local std::string g_err;  // for ctx == NULL
+
+double wall_s() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+constexpr double kPi = 3.14159265358979323846;
+double normalize_theta_h(double t) {
+  if (t >= -kPi && t < kPi) return t;
+  double m = std::floor(t / (2 * kPi));
+  t = t - m * 2 * kPi;
+  if (t >= kPi) t -= 2 * kPi;
+  if (t < -kPi) t += 2 * kPi;
+  return t;
+}
+
+}  // namespace
+
+struct sgo_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  sgo_opts opts{};
+  std::string err;
+  Comm comm;
+
+  // graph (host)
+  bool has_graph = false;
+  int V = 0, E = 0, n = 0;
+  std::vector<int> free_id;
+  double setup_seconds = 0.0;
+
+  // device
+  std::vector<void*> allocs;
+  double* d_poses = nullptr;
+  int* d_free_id = nullptr;
+  EdgeListDev el;
+  BsrDev A;
+  EdgeSlotsDev es;
+  double *d_dgb = nullptr, *d_b = nullptr, *d_x = nullptr, *d_r = nullptr, *d_z = nullptr, *d_p = nullptr,
+         *d_q = nullptr, *d_s1 = nullptr, *d_s2 = nullptr, *d_e2 = nullptr;
+  double* d_partials = nullptr;   // [3][kMaxPartials]
+  double* d_hist = nullptr;       // [SGO_MAX_ITERS + 2][2] chi2 history
+  PcgScalars* d_S = nullptr;
+  PcgScalars* h_S = nullptr;      // pinned
+  double* h_hist = nullptr;       // pinned
+  bool linearized = false;
+
+  hipGraphExec_t pcg_exec = nullptr;
+  int pcg_exec_chunk = 0;
+
+  // profiling
+  struct Rec { int kid; hipEvent_t a, b; };
+  std::vector<hipEvent_t> ev_pool;
+  std::vector<Rec> pending;
+  double prof_ms[K_COUNT] = {0};
+  int64_t prof_launches[K_COUNT] = {0};
+  double prof_bytes[K_COUNT] = {0};
+  int cur_kid = -1;
+  hipEvent_t cur_a = nullptr;
+};
+
+namespace {
+
+#define HIP_TRY(ctx, expr)                                                                     \
+  do {                                                                                         \
+    hipError_t e_ = (expr);                                                                    \
+    if (e_ != hipSuccess) {                                                                    \
+      (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                          \
+      return SGO_EHIP;                                                                         \
+    }                                                                                          \
+  } while (0)
+
+template <class T>
+int dalloc(sgo_ctx* c, T** p, size_t count) {
+  void* q = nullptr;
+  size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+  hipError_t e = hipMalloc(&q, bytes);
+  if (e != hipSuccess) {
+    c->err = std::string("hipMalloc(") + std::to_string(bytes) + "): " + hipGetErrorString(e);
+    return SGO_ENOMEM;
+  }
+  c->allocs.push_back(q);
+  *p = (T*)q;
+  return SGO_OK;
+}
+
+template <class T>
+int upload(sgo_ctx* c, T** p, const std::vector<T>& v) {
+  int rc = dalloc(c, p, v.size());
+  if (rc) return rc;
+  if (!v.empty()) HIP_TRY(c, hipMemcpyAsync(*p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, c->stream));
+  return SGO_OK;
+}
+
+void free_graph(sgo_ctx* c) {
+  if (c->pcg_exec) {
+    hipGraphExecDestroy(c->pcg_exec);
+    c->pcg_exec = nullptr;
+  }
+  for (void* p : c->allocs) hipFree(p);
+  c->allocs.clear();
+  c->has_graph = false;
+  c->linearized = false;
+}
+
+// ---- profiling: HIP events around each launch on the ctx stream ---------------------------
+hipEvent_t get_event(sgo_ctx* c) {
+  if (!c->ev_pool.empty()) {
+    hipEvent_t e = c->ev_pool.back();
+    c->ev_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e;
+  hipEventCreate(&e);
+  return e;
+}
+void prof_flush(sgo_ctx* c) {
+  if (c->pending.empty()) return;
+  hipStreamSynchronize(c->stream);
+  for (auto& r : c->pending) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) c->prof_ms[r.kid] += ms;
+    c->ev_pool.push_back(r.a);
+    c->ev_pool.push_back(r.b);
+  }
+  c->pending.clear();
+}
+struct Scope {
+  sgo_ctx* c;
+  int kid;
+  hipEvent_t a = nullptr;
+  Scope(sgo_ctx* c_, int kid_, double bytes) : c(c_), kid(kid_) {
+    if (!c->opts.profile) return;
+    c->prof_launches[kid]++;
+    c->prof_bytes[kid] += bytes;
+    a = get_event(c);
+    hipEventRecord(a, c->stream);
+  }
+  ~Scope() {
+    if (!a) return;
+    hipEvent_t b = get_event(c);
+    hipEventRecord(b, c->stream);
+    c->pending.push_back({kid, a, b});
+    if (c->pending.size() >= 2048) prof_flush(c);
+  }
+};
+
+// ---- algorithmic bytes per launch ------------------------------------
+double bytes_spmv(const BsrDev& A) { return 80.0 * A.nslot + 48.0 * A.n; }
+double bytes_linearize(const sgo_ctx* c) {
+  return 96.0 * c->A.nslot + 72.0 * (c->A.nslot - c->A.n) + 24.0 * c->V + 72.0 * c->A.n;
+}
+double bytes_chi2(const sgo_ctx* c) { return 96.0 * c->E + 24.0 * c->V; }
+
+// ---- structure build: SparseOptimizer::initializeOptimization + BlockSolver::buildStructure -
+int build_structure(sgo_ctx* c, int V, const double* poses, const uint8_t* fixed, int E, const int32_t* ei,
+                    const int32_t* ej, const double* meas, const double* info, const double* phi) {
+  // active vertices: those incident to at least one edge (initializeOptimization);
+  // with a communicator the degree is summed over ranks so every rank agrees on the rows.
+  std::vector<int> deg(V, 0);
+  for (int e = 0; e < E; ++e) {
+    int a = ei[e], b = ej[e];
+    if (a < 0 || a >= V || b < 0 || b >= V) {
+      c->err = "edge " + std::to_string(e) + " references a vertex outside [0, V)";
+      return SGO_EINVAL;
+    }
+    if (a == b) {
+      c->err = "edge " + std::to_string(e) + " is a self edge";
+      return SGO_EINVAL;
+    }
+    deg[a]++;
+    deg[b]++;
+  }
+  if (c->comm.nranks > 1) {
+    int* d_deg = nullptr;
+    int rc = upload(c, &d_deg, deg);
+    if (rc) return rc;
+    if (!c->comm.allreduce_i32(d_deg, V, c->stream, &c->err)) return SGO_ECOMM;
+    HIP_TRY(c, hipMemcpyAsync(deg.data(), d_deg, sizeof(int) * V, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+  }
+  std::vector<int> hidx(V, -1);
+  c->free_id.clear();
+  for (int v = 0; v < V; ++v)
+    if (!fixed[v] && deg[v] > 0) {
+      hidx[v] = (int)c->free_id.size();
+      c->free_id.push_back(v);
+    }
+  const int n = (int)c->free_id.size();
+  c->V = V;
+  c->E = E;
+  c->n = n;
+
+  // slots: one diagonal slot per row, then the row's directed edges in edge order
+  std::vector<int> rowptr(n + 1, 0);
+  for (int r = 0; r < n; ++r) rowptr[r + 1] = 1;
+  for (int e = 0; e < E; ++e) {
+    int hi = hidx[ei[e]], hj = hidx[ej[e]];
+    if (hi >= 0) rowptr[hi + 1]++;
+    if (hj >= 0) rowptr[hj + 1]++;
+  }
+  for (int r = 0; r < n; ++r) rowptr[r + 1] += rowptr[r];
+  const int ns = rowptr[n];
+  std::vector<int> row(ns), col(ns), svi(ns, 0), svj(ns, 0), flags(ns, 0), fill(rowptr.begin(), rowptr.end() - 1);
+  std::vector<double> zinv(3 * (size_t)ns, 0.0), sinfo(6 * (size_t)ns, 0.0), sphi(ns, -1.0);
+  for (int r = 0; r < n; ++r) {
+    int k = fill[r]++;
+    row[k] = r;
+    col[k] = r;
+    flags[k] = kSlotDiag;
+  }
+  // EdgeSE2::setMeasurement caches the inverse measurement on the host (computed once)
+  std::vector<double> ezinv(3 * (size_t)E);
+  for (int e = 0; e < E; ++e) {
+    const double* z = meas + 3 * (size_t)e;
+    double th = normalize_theta_h(-z[2]);
+    double cs = std::cos(th), sn = std::sin(th);
+    ezinv[e] = cs * (-z[0]) - sn * (-z[1]);
+    ezinv[(size_t)E + e] = sn * (-z[0]) + cs * (-z[1]);
+    ezinv[2 * (size_t)E + e] = th;
+  }
+  for (int e = 0; e < E; ++e) {
+    int hi = hidx[ei[e]], hj = hidx[ej[e]];
+    for (int side = 0; side < 2; ++side) {
+      int hr = side ? hj : hi, hc = side ? hi : hj;
+      if (hr < 0) continue;
+      int k = fill[hr]++;
+      row[k] = hr;
+      col[k] = hc >= 0 ? hc : hr;
+      flags[k] = (side ? kSlotDir : 0) | (hc < 0 ? kSlotColFixed : 0);
+      svi[k] = ei[e];
+      svj[k] = ej[e];
+      for (int q = 0; q < 3; ++q) zinv[q * (size_t)ns + k] = ezinv[q * (size_t)E + e];
+      for (int q = 0; q < 6; ++q) sinfo[q * (size_t)ns + k] = info[6 * (size_t)e + q];
+      sphi[k] = phi[e];
+    }
+  }
+  // wave groups: whole rows packed up to 64 slots; a longer row is its own group
+  std::vector<int> grp;
+  grp.push_back(0);
+  {
+    int cur = 0;
+    for (int r = 0; r < n; ++r) {
+      int len = rowptr[r + 1] - rowptr[r];
+      if (cur > 0 && cur + len > 64) {
+        grp.push_back(rowptr[r]);
+        cur = 0;
+      }
+      cur += len;
+      if (cur >= 64) {  // full (or a long row): close the group here
+        grp.push_back(rowptr[r + 1]);
+        cur = 0;
+      }
+    }
+    if (grp.back() != ns) grp.push_back(ns);
+  }
+  const int ngrp = (int)grp.size() - 1;
+
+  // edge list (original order) for chi2
+  std::vector<int> evi(ei, ei + E), evj(ej, ej + E);
+  std::vector<double> einfo(6 * (size_t)E), ephi(phi, phi + E);
+  for (int e = 0; e < E; ++e)
+    for (int q = 0; q < 6; ++q) einfo[q * (size_t)E + e] = info[6 * (size_t)e + q];
+
+  int rc;
+  c->A.n = n;
+  c->A.nslot = ns;
+  c->A.ngrp = ngrp;
+  if ((rc = upload(c, &c->A.row, row))) return rc;
+  if ((rc = upload(c, &c->A.col, col))) return rc;
+  if ((rc = upload(c, &c->A.grp, grp))) return rc;
+  if ((rc = upload(c, &c->A.rowptr, rowptr))) return rc;
+  if ((rc = dalloc(c, &c->A.blk, 9 * (size_t)ns))) return rc;
+  if ((rc = dalloc(c, &c->A.dinv, 6 * (size_t)n))) return rc;
+  if ((rc = upload(c, &c->es.vi, svi))) return rc;
+  if ((rc = upload(c, &c->es.vj, svj))) return rc;
+  if ((rc = upload(c, &c->es.flags, flags))) return rc;
+  if ((rc = upload(c, &c->es.zinv, zinv))) return rc;
+  if ((rc = upload(c, &c->es.info, sinfo))) return rc;
+  if ((rc = upload(c, &c->es.phi, sphi))) return rc;
+  c->el.E = E;
+  if ((rc = upload(c, &c->el.vi, evi))) return rc;
+  if ((rc = upload(c, &c->el.vj, evj))) return rc;
+  if ((rc = upload(c, &c->el.zinv, ezinv))) return rc;
+  if ((rc = upload(c, &c->el.info, einfo))) return rc;
+  if ((rc = upload(c, &c->el.phi, ephi))) return rc;
+  if ((rc = upload(c, &c->d_free_id, c->free_id))) return rc;
+  if ((rc = dalloc(c, &c->d_poses, 3 * (size_t)V))) return rc;
+  HIP_TRY(c, hipMemcpyAsync(c->d_poses, poses, sizeof(double) * 3 * (size_t)V, hipMemcpyHostToDevice, c->stream));
+  const size_t n3 = 3 * (size_t)n;
+  if ((rc = dalloc(c, &c->d_dgb, 9 * (size_t)n))) return rc;
+  if ((rc = dalloc(c, &c->d_b, n3))) return rc;
+  if ((rc = dalloc(c, &c->d_x, n3))) return rc;
+  if ((rc = dalloc(c, &c->d_r, n3))) return rc;
+  if ((rc = dalloc(c, &c->d_z, n3))) return rc;
+  if ((rc = dalloc(c, &c->d_p, n3))) return rc;
+  if ((rc = dalloc(c, &c->d_q, n3))) return rc;
+  if ((rc = dalloc(c, &c->d_s1, n3))) return rc;
+  if ((rc = dalloc(c, &c->d_s2, n3))) return rc;
+  if ((rc = dalloc(c, &c->d_e2, (size_t)E))) return rc;
+  if ((rc = dalloc(c, &c->d_partials, 3 * (size_t)kMaxPartials))) return rc;
+  if ((rc = dalloc(c, &c->d_hist, 2 * (size_t)(SGO_MAX_ITERS + 2)))) return rc;
+  if ((rc = dalloc(c, &c->d_S, 1))) return rc;
+  HIP_TRY(c, hipMemsetAsync(c->d_partials, 0, sizeof(double) * 3 * kMaxPartials, c->stream));
+  HIP_TRY(c, hipMemsetAsync(c->d_S, 0, sizeof(PcgScalars), c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));  // host staging vectors die at return
+  return SGO_OK;
+}
+
+// ---- one GN building block each ------------------------------------------------------------
+int do_chi2(sgo_ctx* c, double* d_out2, double* d_e2) {
+  int grid = 0;
+  {
+    Scope sc(c, K_CHI2, bytes_chi2(c));
+    launch_chi2(c->stream, c->el, c->d_poses, d_e2, c->d_partials, &grid);
+  }
+  {
+    Scope sc(c, K_REDUCE, 16.0 * grid);
+    launch_reduce2(c->stream, c->d_partials, grid, d_out2);
+  }
+  if (c->comm.nranks > 1 && !c->comm.allreduce_f64(d_out2, 2, c->stream, &c->err)) return SGO_ECOMM;
+  return SGO_OK;
+}
+
+// buildSystem + preconditioner + PCG start state
+int do_linearize(sgo_ctx* c) {
+  {
+    Scope sc(c, K_LINEARIZE, bytes_linearize(c));
+    launch_linearize(c->stream, c->A, c->es, c->d_poses, c->d_dgb);
+  }
+  if (c->comm.nranks > 1 && !c->comm.allreduce_f64(c->d_dgb, 9 * (size_t)c->n, c->stream, &c->err)) return SGO_ECOMM;
+  int grid = 0;
+  {
+    Scope sc(c, K_FINALIZE, (72.0 + 72.0 + 48.0 + 5 * 24.0) * c->n);
+    launch_finalize(c->stream, c->A, c->d_dgb, c->comm.rank == 0 ? 1 : 0, c->d_b, c->d_x, c->d_r, c->d_z, c->d_p,
+                    c->d_partials, &grid);
+  }
+  {
+    Scope sc(c, K_REDUCE, 16.0 * grid);
+    launch_init_scalars(c->stream, c->d_S, c->d_partials, grid, c->opts.pcg_tol, c->opts.pcg_maxit);
+  }
+  c->linearized = true;
+  return SGO_OK;
+}
+
+// y = H x  (+ optional x.y partials); all-reduces y over ranks
+int do_spmv(sgo_ctx* c, const double* x, double* y, bool dot, const PcgScalars* S, int* grid_out) {
+  const bool multi = c->comm.nranks > 1;
+  {
+    Scope sc(c, K_SPMV, bytes_spmv(c->A));
+    launch_spmv(c->stream, c->A, x, y, (dot && !multi) ? c->d_partials : nullptr, S, grid_out);
+  }
+  if (multi) {
+    if (!c->comm.allreduce_f64(y, 3 * (size_t)c->n, c->stream, &c->err)) return SGO_ECOMM;
+    if (dot) {
+      Scope sc(c, K_AMG_MISC, 48.0 * c->n);
+      launch_dot(c->stream, 3 * c->n, x, y, c->d_partials, S, grid_out);
+    }
+  }
+  return SGO_OK;
+}
+
+int pcg_iteration(sgo_ctx* c) {
+  int g1 = 0, g2 = 0, rc;
+  if ((rc = do_spmv(c, c->d_p, c->d_q, true, c->d_S, &g1))) return rc;
+  {
+    Scope sc(c, K_ALPHA, 8.0 * g1);
+    launch_alpha(c->stream, c->d_S, c->d_partials, g1);
+  }
+  {
+    Scope sc(c, K_UPDATE_XR, (7 * 24.0 + 48.0) * c->n);
+    launch_update_xr(c->stream, c->n, c->d_S, c->A.dinv, c->d_p, c->d_q, c->d_x, c->d_r, c->d_z,
+                     c->d_partials + kMaxPartials, &g2);
+  }
+  {
+    Scope sc(c, K_BETA, 16.0 * g2);
+    launch_beta(c->stream, c->d_S, c->d_partials + kMaxPartials, g2);
+  }
+  {
+    Scope sc(c, K_UPDATE_P, 3 * 24.0 * c->n);
+    launch_update_p(c->stream, c->n, c->d_S, c->d_z, c->d_p);
+  }
+  return SGO_OK;
+}
+
+int ensure_pcg_graph(sgo_ctx* c, int chunk) {
+  if (c->pcg_exec && c->pcg_exec_chunk == chunk) return SGO_OK;
+  if (c->pcg_exec) {
+    hipGraphExecDestroy(c->pcg_exec);
+    c->pcg_exec = nullptr;
+  }
+  hipGraph_t graph = nullptr;
+  HIP_TRY(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+  int rc = SGO_OK;
+  for (int k = 0; k < chunk && rc == SGO_OK; ++k) rc = pcg_iteration(c);
+  hipError_t e = hipStreamEndCapture(c->stream, &graph);
+  if (rc != SGO_OK) {
+    if (graph) hipGraphDestroy(graph);
+    return rc;
+  }
+  if (e != hipSuccess) {
+    c->err = std::string("hipStreamEndCapture: ") + hipGetErrorString(e);
+    return SGO_EHIP;
+  }
+  e = hipGraphInstantiate(&c->pcg_exec, graph, nullptr, nullptr, 0);
+  hipGraphDestroy(graph);
+  if (e != hipSuccess) {
+    c->pcg_exec = nullptr;
+    c->err = std::string("hipGraphInstantiate: ") + hipGetErrorString(e);
+    return SGO_EHIP;
+  }
+  c->pcg_exec_chunk = chunk;
+  return SGO_OK;
+}
+
+// Runs PCG from the state k_finalize left (x = 0, r = b, ...) until S.stop != 0.
+int run_pcg(sgo_ctx* c) {
+  const int chunk = std::max(1, c->opts.pcg_chunk);
+  const bool graph = c->opts.use_graph && !c->opts.profile && c->comm.nranks == 1;
+  if (graph) {
+    int rc = ensure_pcg_graph(c, chunk);
+    if (rc) return rc;
+  }
+  for (;;) {
+    HIP_TRY(c, hipMemcpyAsync(c->h_S, c->d_S, sizeof(PcgScalars), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->h_S->stop) break;
+    if (graph) {
+      HIP_TRY(c, hipGraphLaunch(c->pcg_exec, c->stream));
+    } else {
+      for (int k = 0; k < chunk; ++k) {
+        int rc = pcg_iteration(c);
+        if (rc) return rc;
+      }
+    }
+  }
+  return SGO_OK;
+}
+
+int check_graph(sgo_ctx* c) {
+  if (!c) return SGO_EINVAL;
+  if (!c->has_graph) {
+    c->err = "no graph: call sgo_set_graph_se2 first";
+    return SGO_ENOGRAPH;
+  }
+  hipError_t e = hipSetDevice(c->device);
+  if (e != hipSuccess) {
+    c->err = std::string("hipSetDevice: ") + hipGetErrorString(e);
+    return SGO_EHIP;
+  }
+  return SGO_OK;
+}
+
+}  // namespace
+
+// =============================================================================== C-ABI
+extern "C" {
+
+int sgo_version(void) { return SGO_VERSION; }
+
+void sgo_default_opts(sgo_opts* o) {
+  if (!o) return;
+  std::memset(o, 0, sizeof(*o));
+  o->struct_size = (int32_t)sizeof(sgo_opts);
+  o->solver = SGO_SOLVER_PCG_BJ;
+  o->pcg_tol = 1e-8;
+  o->pcg_maxit = 20000;
+  o->pcg_chunk = 16;
+  o->use_graph = 1;
+  o->profile = 0;
+  o->verbose = 0;
+  if (const char* s = std::getenv("SGO_SOLVER")) {
+    if (!std::strcmp(s, "pcg") || !std::strcmp(s, "bj")) o->solver = SGO_SOLVER_PCG_BJ;
+    else if (!std::strcmp(s, "amg")) o->solver = SGO_SOLVER_PCG_AMG;
+  }
+  if (const char* s = std::getenv("SGO_PCG_TOL")) o->pcg_tol = std::atof(s);
+  if (const char* s = std::getenv("SGO_PCG_MAXIT")) o->pcg_maxit = std::atoi(s);
+  if (const char* s = std::getenv("SGO_PCG_CHUNK")) o->pcg_chunk = std::atoi(s);
+  if (const char* s = std::getenv("SGO_USE_GRAPH")) o->use_graph = std::atoi(s);
+  if (const char* s = std::getenv("SGO_PROFILE")) o->profile = std::atoi(s);
+}
+
+sgo_ctx* sgo_create(int device, const sgo_opts* opts) {
+  if (device < 0) {
+    const char* s = std::getenv("SGO_DEVICE");
+    device = s ? std::atoi(s) : 0;
+  }
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0) {
+    g_err = std::string("no HIP device available: ") + hipGetErrorString(e);
+    return nullptr;
+  }
+  if (device >= count) {
+    g_err = "device ordinal " + std::to_string(device) + " out of range (" + std::to_string(count) + " devices)";
+    return nullptr;
+  }
+  if ((e = hipSetDevice(device)) != hipSuccess) {
+    g_err = std::string("hipSetDevice: ") + hipGetErrorString(e);
+    return nullptr;
+  }
+  sgo_ctx* c = new (std::nothrow) sgo_ctx();
+  if (!c) {
+    g_err = "out of host memory";
+    return nullptr;
+  }
+  c->device = device;
+  sgo_default_opts(&c->opts);
+  if (opts) {
+    size_t sz = std::min<size_t>(sizeof(sgo_opts), opts->struct_size > 0 ? (size_t)opts->struct_size : sizeof(sgo_opts));
+    std::memcpy(&c->opts, opts, sz);
+    c->opts.struct_size = (int32_t)sizeof(sgo_opts);
+  }
+  if (c->opts.pcg_tol <= 0) c->opts.pcg_tol = 1e-8;
+  if (c->opts.pcg_maxit <= 0) c->opts.pcg_maxit = 20000;
+  if (c->opts.pcg_chunk <= 0) c->opts.pcg_chunk = 16;
+  if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
+      (e = hipHostMalloc((void**)&c->h_S, sizeof(PcgScalars))) != hipSuccess ||
+      (e = hipHostMalloc((void**)&c->h_hist, sizeof(double) * 2 * (SGO_MAX_ITERS + 2))) != hipSuccess) {
+    g_err = std::string("context setup: ") + hipGetErrorString(e);
+    sgo_destroy(c);
+    return nullptr;
+  }
+  return c;
+}
+
+void sgo_destroy(sgo_ctx* c) {
+  if (!c) return;
+  hipSetDevice(c->device);
+  if (c->stream) hipStreamSynchronize(c->stream);
+  prof_flush(c);
+  free_graph(c);
+  c->comm.destroy();
+  for (hipEvent_t e : c->ev_pool) hipEventDestroy(e);
+  if (c->h_S) hipHostFree(c->h_S);
+  if (c->h_hist) hipHostFree(c->h_hist);
+  if (c->stream) hipStreamDestroy(c->stream);
+  delete c;
+}
+
+const char* sgo_last_error(sgo_ctx* c) { return c ? c->err.c_str() : g_err.c_str(); }
+
+int sgo_set_graph_se2(sgo_ctx* c, int32_t V, const double* poses, const uint8_t* fixed, int32_t E, const int32_t* ei,
+                      const int32_t* ej, const double* meas, const double* info, const double* phi) {
+  if (!c) return SGO_EINVAL;
+  if (V <= 0 || E < 0 || !poses || !fixed || (E > 0 && (!ei || !ej || !meas || !info || !phi))) {
+    c->err = "sgo_set_graph_se2: bad argument";
+    return SGO_EINVAL;
+  }
+  hipError_t e = hipSetDevice(c->device);
+  if (e != hipSuccess) {
+    c->err = std::string("hipSetDevice: ") + hipGetErrorString(e);
+    return SGO_EHIP;
+  }
+  const double t0 = wall_s();
+  hipStreamSynchronize(c->stream);
+  free_graph(c);
+  int rc = build_structure(c, V, poses, fixed, E, ei, ej, meas, info, phi);
+  if (rc != SGO_OK) {
+    free_graph(c);
+    return rc;
+  }
+  c->has_graph = true;
+  c->setup_seconds = wall_s() - t0;
+  return SGO_OK;
+}
+
+int sgo_set_poses(sgo_ctx* c, const double* poses) {
+  int rc = check_graph(c);
+  if (rc) return rc;
+  if (!poses) return SGO_EINVAL;
+  HIP_TRY(c, hipMemcpyAsync(c->d_poses, poses, sizeof(double) * 3 * (size_t)c->V, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  c->linearized = false;
+  return SGO_OK;
+}
+
+int sgo_get_poses(sgo_ctx* c, double* poses) {
+  int rc = check_graph(c);
+  if (rc) return rc;
+  if (!poses) return SGO_EINVAL;
+  HIP_TRY(c, hipMemcpyAsync(poses, c->d_poses, sizeof(double) * 3 * (size_t)c->V, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return SGO_OK;
+}
+
+int sgo_num_free(sgo_ctx* c) {
+  int rc = check_graph(c);
+  return rc ? rc : c->n;
+}
+
+int sgo_free_ids(sgo_ctx* c, int32_t* out) {
+  int rc = check_graph(c);
+  if (rc) return rc;
+  if (!out) return SGO_EINVAL;
+  std::copy(c->free_id.begin(), c->free_id.end(), out);
+  return c->n;
+}
+
+int sgo_chi2(sgo_ctx* c, double* plain, double* robust) {
+  int rc = check_graph(c);
+  if (rc) return rc;
+  if ((rc = do_chi2(c, c->d_hist, nullptr))) return rc;
+  HIP_TRY(c, hipMemcpyAsync(c->h_hist, c->d_hist, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (plain) *plain = c->h_hist[0];
+  if (robust) *robust = c->h_hist[1];
+  return SGO_OK;
+}
+
+int sgo_edge_chi2(sgo_ctx* c, double* e2) {
+  int rc = check_graph(c);
+  if (rc) return rc;
+  if (!e2) return SGO_EINVAL;
+  if ((rc = do_chi2(c, c->d_hist, c->d_e2))) return rc;
+  HIP_TRY(c, hipMemcpyAsync(e2, c->d_e2, sizeof(double) * (size_t)c->E, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return SGO_OK;
+}
+
+int sgo_linearize(sgo_ctx* c, double* b, double* diag, double* plain, double* robust) {
+  int rc = check_graph(c);
+  if (rc) return rc;
+  if (c->n == 0) return SGO_ENOTHING;
+  if ((rc = do_chi2(c, c->d_hist, nullptr))) return rc;
+  if ((rc = do_linearize(c))) return rc;
+  std::vector<double> dgb(9 * (size_t)c->n);
+  HIP_TRY(c, hipMemcpyAsync(dgb.data(), c->d_dgb, sizeof(double) * dgb.size(), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->h_hist, c->d_hist, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  for (int i = 0; i < c->n; ++i) {
+    const double* d = &dgb[9 * (size_t)i];
+    if (diag) {
+      double* D = diag + 9 * (size_t)i;
+      D[0] = d[0]; D[1] = d[1]; D[2] = d[2];
+      D[3] = d[1]; D[4] = d[3]; D[5] = d[4];
+      D[6] = d[2]; D[7] = d[4]; D[8] = d[5];
+    }
+    if (b) {
+      b[3 * (size_t)i] = d[6];
+      b[3 * (size_t)i + 1] = d[7];
+      b[3 * (size_t)i + 2] = d[8];
+    }
+  }
+  if (plain) *plain = c->h_hist[0];
+  if (robust) *robust = c->h_hist[1];
+  return SGO_OK;
+}
+
+int sgo_hessian_apply(sgo_ctx* c, const double* x, double* y) {
+  int rc = check_graph(c);
+  if (rc) return rc;
+  if (!x || !y) return SGO_EINVAL;
+  if (!c->linearized) {
+    c->err = "sgo_hessian_apply: call sgo_linearize first";
+    return SGO_EINVAL;
+  }
+  const size_t bytes = sizeof(double) * 3 * (size_t)c->n;
+  HIP_TRY(c, hipMemcpyAsync(c->d_s1, x, bytes, hipMemcpyHostToDevice, c->stream));
+  if ((rc = do_spmv(c, c->d_s1, c->d_s2, false, nullptr, nullptr))) return rc;
+  HIP_TRY(c, hipMemcpyAsync(y, c->d_s2, bytes, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return SGO_OK;
+}
+
+int sgo_precondition(sgo_ctx* c, const double* r, double* z) {
+  int rc = check_graph(c);
+  if (rc) return rc;
+  if (!r || !z) return SGO_EINVAL;
+  if (!c->linearized) {
+    c->err = "sgo_precondition: call sgo_linearize first";
+    return SGO_EINVAL;
+  }
+  const size_t bytes = sizeof(double) * 3 * (size_t)c->n;
+  HIP_TRY(c, hipMemcpyAsync(c->d_s1, r, bytes, hipMemcpyHostToDevice, c->stream));
+  launch_precond_bj(c->stream, c->n, c->A.dinv, c->d_s1, c->d_s2);
+  HIP_TRY(c, hipMemcpyAsync(z, c->d_s2, bytes, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return SGO_OK;
+}
+
+int sgo_solve(sgo_ctx* c, double* x, double* relres) {
+  int rc = check_graph(c);
+  if (rc) return rc;
+  if (!c->linearized) {
+    c->err = "sgo_solve: call sgo_linearize first";
+    return SGO_EINVAL;
+  }
+  // restart from the state of the last linearisation (idempotent re-finalize)
+  int grid = 0;
+  launch_finalize(c->stream, c->A, c->d_dgb, c->comm.rank == 0 ? 1 : 0, c->d_b, c->d_x, c->d_r, c->d_z, c->d_p,
+                  c->d_partials, &grid);
+  launch_init_scalars(c->stream, c->d_S, c->d_partials, grid, c->opts.pcg_tol, c->opts.pcg_maxit);
+  if ((rc = run_pcg(c))) return rc;
+  if (x) {
+    HIP_TRY(c, hipMemcpyAsync(x, c->d_x, sizeof(double) * 3 * (size_t)c->n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+  }
+  if (relres) *relres = c->h_S->bb > 0 ? std::sqrt(c->h_S->rr / c->h_S->bb) : 0.0;
+  if (c->h_S->stop == 3) {
+    c->err = "PCG breakdown (p.Hp <= 0 or non-finite): Hessian not positive definite";
+    return SGO_EINVAL;
+  }
+  return c->h_S->iter;
+}
+
+int sgo_optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
+  int rc = check_graph(c);
+  if (rc) return rc;
+  if (iters < 0 || iters > SGO_MAX_ITERS) {
+    c->err = "sgo_optimize_gn: iters must be in [0, SGO_MAX_ITERS]";
+    return SGO_EINVAL;
+  }
+  if (out) {
+    std::memset(out, 0, sizeof(*out));
+    out->iters_requested = iters;
+    out->seconds_setup = c->setup_seconds;
+  }
+  if (c->n == 0) return SGO_ENOTHING;
+  const double t0 = wall_s();
+  std::vector<hipEvent_t> ev(3 * (size_t)iters + 1);
+  for (auto& e : ev) HIP_TRY(c, hipEventCreate(&e));
+  auto cleanup = [&]() {
+    for (auto& e : ev) hipEventDestroy(e);
+  };
+  int done = 0;
+  for (int it = 0; it < iters; ++it) {
+    hipEventRecord(ev[3 * it], c->stream);
+    if ((rc = do_chi2(c, c->d_hist + 2 * it, nullptr)) || (rc = do_linearize(c))) {
+      cleanup();
+      return rc;
+    }
+    hipEventRecord(ev[3 * it + 1], c->stream);
+    if ((rc = run_pcg(c))) {
+      cleanup();
+      return rc;
+    }
+    const PcgScalars S = *c->h_S;
+    if (out) {
+      out->pcg_iters[it] = S.iter;
+      out->pcg_converged[it] = S.stop == 1;
+      out->pcg_relres[it] = S.bb > 0 ? std::sqrt(S.rr / S.bb) : 0.0;
+    }
+    if (S.stop == 3) {  // solver failure: estimates stay at the last successful update
+      c->err = "PCG breakdown in GN iteration " + std::to_string(it) + " (Hessian not positive definite)";
+      hipEventRecord(ev[3 * it + 2], c->stream);
+      break;
+    }
+    {
+      Scope sc(c, K_POSE_UPDATE, 72.0 * c->n);
+      launch_pose_update(c->stream, c->n, c->d_free_id, c->d_x, c->d_poses);
+    }
+    hipEventRecord(ev[3 * it + 2], c->stream);
+    c->linearized = false;
+    ++done;
+    if (c->opts.verbose)
+      std::fprintf(stderr, "[sgo] iteration= %d\t pcg= %d\t relres= %.3e\n", it, S.iter,
+                   S.bb > 0 ? std::sqrt(S.rr / S.bb) : 0.0);
+  }
+  if ((rc = do_chi2(c, c->d_hist + 2 * done, nullptr))) {
+    cleanup();
+    return rc;
+  }
+  HIP_TRY(c, hipMemcpyAsync(c->h_hist, c->d_hist, sizeof(double) * 2 * (size_t)(done + 1), hipMemcpyDeviceToHost,
+                            c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  prof_flush(c);
+  if (out) {
+    out->iters_done = done;
+    for (int k = 0; k <= done; ++k) {
+      out->chi2[k] = c->h_hist[2 * k];
+      out->robust_chi2[k] = c->h_hist[2 * k + 1];
+    }
+    const int timed = std::min(iters, done + 1);
+    for (int k = 0; k < timed; ++k) {
+      float a = 0.f, b = 0.f;
+      hipEventElapsedTime(&a, ev[3 * k], ev[3 * k + 1]);
+      hipEventElapsedTime(&b, ev[3 * k + 1], ev[3 * k + 2]);
+      out->seconds_linearize[k] = a * 1e-3;
+      out->seconds_solve[k] = b * 1e-3;
+      out->seconds[k] = (a + b) * 1e-3;
+    }
+    out->seconds_total = wall_s() - t0;
+  }
+  cleanup();
+  return done;
+}
+
+int sgo_kernel_profile(sgo_ctx* c, sgo_kernel_stat* out, int cap) {
+  if (!c) return SGO_EINVAL;
+  prof_flush(c);
+  for (int k = 0; k < K_COUNT && k < cap; ++k) {
+    out[k].name = kKernelNames[k];
+    out[k].launches = c->prof_launches[k];
+    out[k].ms = c->prof_ms[k];
+    out[k].bytes = c->prof_bytes[k];
+  }
+  return K_COUNT;
+}
+
+int sgo_profile_reset(sgo_ctx* c) {
+  if (!c) return SGO_EINVAL;
+  prof_flush(c);
+  for (int k = 0; k < K_COUNT; ++k) {
+    c->prof_ms[k] = 0;
+    c->prof_launches[k] = 0;
+    c->prof_bytes[k] = 0;
+  }
+  return SGO_OK;
+}
+
+int sgo_comm_unique_id(void* id_out) {
+  if (!id_out) return SGO_EINVAL;
+  return comm_unique_id(id_out, &g_err) ? SGO_OK : SGO_ECOMM;
+}
+
+int sgo_comm_init(sgo_ctx* c, int nranks, int rank, const void* unique_id) {
+  if (!c || nranks < 1 || rank < 0 || rank >= nranks || !unique_id) return SGO_EINVAL;
+  hipSetDevice(c->device);
+  if (c->has_graph) {
+    c->err = "sgo_comm_init must precede sgo_set_graph_se2";
+    return SGO_EINVAL;
+  }
+  return c->comm.init(nranks, rank, unique_id, &c->err) ? SGO_OK : SGO_ECOMM;
+}
+
+int sgo_comm_size(sgo_ctx* c) { return c ? c->comm.nranks : SGO_EINVAL; }
+
+}  // extern "C"

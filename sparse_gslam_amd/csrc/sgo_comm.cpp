@@ -1,0 +1,130 @@
+// sgo_comm.cpp -- RCCL binding for the edge-sharded multi-GPU mode (one process per GPU).
+//
+// librccl is dlopen'ed on first use so that the single-GPU product path carries no RCCL
+// dependency.  Only ncclAllReduce(sum) is used: after linearisation on the per-vertex
+// (block-diagonal H, b) partials, and once per PCG step on the partial Hessian product
+// (BASELINE.json north_star).
+#include <dlfcn.h>
+
+#include <cstdlib>
+#include <cstring>
+#include <string>
+
+#include "sgo_comm.h"
+
+namespace sgo {
+namespace {
+
+struct NcclUniqueId { char internal[128]; };
+using ncclComm_t = void*;
+constexpr int kNcclSum = 0;
+constexpr int kNcclInt32 = 2;
+constexpr int kNcclFloat64 = 8;
+
+struct Api {
+  void* handle = nullptr;
+  int (*GetUniqueId)(NcclUniqueId*) = nullptr;
+  int (*CommInitRank)(ncclComm_t*, int, NcclUniqueId, int) = nullptr;
+  int (*CommDestroy)(ncclComm_t) = nullptr;
+  int (*AllReduce)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+  std::string err;
+};
+
+Api& api() {
+  static Api a;
+  return a;
+}
+
+bool load(std::string* err) {
+  Api& a = api();
+  if (a.handle) return true;
+  const char* env = std::getenv("SGO_RCCL_LIB");
+  const char* names[] = {env, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  for (const char* n : names) {
+    if (!n || !*n) continue;
+    a.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+    if (a.handle) break;
+  }
+  if (!a.handle) {
+    *err = std::string("cannot load librccl: ") + (dlerror() ? dlerror() : "?");
+    return false;
+  }
+  a.GetUniqueId = (decltype(a.GetUniqueId))dlsym(a.handle, "ncclGetUniqueId");
+  a.CommInitRank = (decltype(a.CommInitRank))dlsym(a.handle, "ncclCommInitRank");
+  a.CommDestroy = (decltype(a.CommDestroy))dlsym(a.handle, "ncclCommDestroy");
+  a.AllReduce = (decltype(a.AllReduce))dlsym(a.handle, "ncclAllReduce");
+  a.GetErrorString = (decltype(a.GetErrorString))dlsym(a.handle, "ncclGetErrorString");
+  if (!a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.AllReduce) {
+    *err = "librccl lacks a required symbol";
+    dlclose(a.handle);
+    a.handle = nullptr;
+    return false;
+  }
+  return true;
+}
+
+std::string nccl_err(int rc) {
+  Api& a = api();
+  return a.GetErrorString ? a.GetErrorString(rc) : ("nccl error " + std::to_string(rc));
+}
+
+}  // namespace
+
+bool comm_unique_id(void* out128, std::string* err) {
+  if (!load(err)) return false;
+  NcclUniqueId id;
+  int rc = api().GetUniqueId(&id);
+  if (rc != 0) {
+    *err = "ncclGetUniqueId: " + nccl_err(rc);
+    return false;
+  }
+  std::memcpy(out128, id.internal, 128);
+  return true;
+}
+
+bool Comm::init(int nranks_, int rank_, const void* id128, std::string* err) {
+  if (!load(err)) return false;
+  destroy();
+  NcclUniqueId id;
+  std::memcpy(id.internal, id128, 128);
+  ncclComm_t c = nullptr;
+  int rc = api().CommInitRank(&c, nranks_, id, rank_);
+  if (rc != 0) {
+    *err = "ncclCommInitRank: " + nccl_err(rc);
+    return false;
+  }
+  handle = c;
+  nranks = nranks_;
+  rank = rank_;
+  return true;
+}
+
+void Comm::destroy() {
+  if (handle) api().CommDestroy((ncclComm_t)handle);
+  handle = nullptr;
+  nranks = 1;
+  rank = 0;
+}
+
+bool Comm::allreduce_f64(double* buf, size_t count, hipStream_t s, std::string* err) {
+  if (!handle || nranks <= 1) return true;
+  int rc = api().AllReduce(buf, buf, count, kNcclFloat64, kNcclSum, (ncclComm_t)handle, s);
+  if (rc != 0) {
+    *err = "ncclAllReduce(f64): " + nccl_err(rc);
+    return false;
+  }
+  return true;
+}
+
+bool Comm::allreduce_i32(int* buf, size_t count, hipStream_t s, std::string* err) {
+  if (!handle || nranks <= 1) return true;
+  int rc = api().AllReduce(buf, buf, count, kNcclInt32, kNcclSum, (ncclComm_t)handle, s);
+  if (rc != 0) {
+    *err = "ncclAllReduce(i32): " + nccl_err(rc);
+    return false;
+  }
+  return true;
+}
+
+}  // namespace sgo

@@ -1,0 +1,133 @@
+// sgo_internal.h -- shared declarations of libsgo (host side <-> HIP kernels).
+// Not part of the public ABI (that is include/sgo.h).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "sgo.h"
+
+namespace sgo {
+
+// ----------------------------------------------------------------------------------------
+// Block-CSR matrix with 3x3 fp64 blocks in "slot list sorted by row" form.
+//   * slot k belongs to block row row[k] and multiplies column col[k];
+//   * the FIRST slot of every row is that row's diagonal block;
+//   * blk is SoA over slots: blk[c * nslot + k] is component c (row-major 3x3) of slot k, so
+//     a wave reading 64 consecutive slots issues nine fully coalesced 512-byte loads;
+//   * grp[g] .. grp[g+1] is the slot range of wave-group g.  Groups are row aligned: a group
+//     holds whole rows (<= 64 slots) or exactly one long row (> 64 slots), so the segmented
+//     reduction of a row never leaves the wave and needs neither LDS hand-off nor atomics.
+// ----------------------------------------------------------------------------------------
+struct BsrDev {
+  int n = 0;          // block rows
+  int nslot = 0;      // slots (diagonal slots included)
+  int ngrp = 0;       // wave groups
+  int* row = nullptr;
+  int* col = nullptr;
+  int* grp = nullptr;     // [ngrp + 1]
+  int* rowptr = nullptr;  // [n + 1]
+  double* blk = nullptr;  // [9][nslot]
+  double* dinv = nullptr; // [n][6] inverse of the diagonal block, symmetric packing
+};
+
+// Directed-edge operands aligned with the level-0 slots (SoA over slots).  For a slot of row
+// r that came from edge e = (i, j):  dir = 0 when r is the i side (row Jacobian A), 1 when r is
+// the j side (row Jacobian B).  Diagonal slots carry flag kSlotDiag and no edge data.
+enum : int { kSlotDir = 1, kSlotColFixed = 2, kSlotDiag = 4 };
+struct EdgeSlotsDev {
+  int* vi = nullptr;      // vertex id of EdgeSE2::vertices()[0]
+  int* vj = nullptr;      // vertex id of EdgeSE2::vertices()[1]
+  int* flags = nullptr;
+  double* zinv = nullptr; // [3][nslot] cached inverse measurement (EdgeSE2::setMeasurement)
+  double* info = nullptr; // [6][nslot]
+  double* phi = nullptr;  // [nslot]
+};
+
+// Original edge list (edge order of sgo_set_graph_se2), SoA, for chi2 / per-edge chi2.
+struct EdgeListDev {
+  int E = 0;
+  int* vi = nullptr;
+  int* vj = nullptr;
+  double* zinv = nullptr; // [3][E]
+  double* info = nullptr; // [6][E]
+  double* phi = nullptr;  // [E]
+};
+
+// Device-resident scalars of the PCG recurrence (one cache line; read uniformly by kernels).
+struct PcgScalars {
+  double rz;      // r.z of the current iterate
+  double pq;      // p.Hp
+  double rr;      // r.r
+  double bb;      // b.b
+  double alpha;
+  double beta;
+  double tol2;    // pcg_tol^2
+  int iter;
+  int maxit;
+  int stop;       // 0 run, 1 converged, 2 maxit, 3 breakdown (pq <= 0 or non-finite)
+  int pad;
+};
+
+enum KernelId : int {
+  K_CHI2 = 0,
+  K_LINEARIZE,
+  K_FINALIZE,
+  K_SPMV,
+  K_ALPHA,
+  K_UPDATE_XR,
+  K_BETA,
+  K_UPDATE_P,
+  K_POSE_UPDATE,
+  K_REDUCE,
+  K_AMG_GALERKIN,
+  K_AMG_SMOOTH,
+  K_AMG_RESIDUAL,
+  K_AMG_RESTRICT,
+  K_AMG_PROLONG,
+  K_AMG_COARSE,
+  K_AMG_MISC,
+  K_COUNT
+};
+extern const char* const kKernelNames[K_COUNT];
+
+// Launch geometry shared by host and kernels.
+constexpr int kBlock = 256;          // 4 waves
+constexpr int kWavesPerBlock = kBlock / 64;
+constexpr int kMaxGrid = 2048;       // 256 CUs x 8 blocks
+constexpr int kMaxPartials = kMaxGrid;
+
+inline int grid_for(long long work_items, int per_block) {
+  long long g = (work_items + per_block - 1) / per_block;
+  if (g < 8) g = 8;
+  if (g > kMaxGrid) g = kMaxGrid;
+  g = (g + 7) / 8 * 8;  // multiple of 8: one contiguous band of groups per XCD
+  return (int)g;
+}
+
+// ---- kernel launchers (sgo_kernels.hip) --------------------------------------------------
+// All take the stream; none allocates or synchronises (hipGraph-capturable).
+void launch_chi2(hipStream_t s, const EdgeListDev& el, const double* poses, double* e2_out,
+                 double* partials /*[2][kMaxPartials]*/, int* grid_out);
+void launch_reduce2(hipStream_t s, const double* partials, int nparts, double* out2);
+void launch_linearize(hipStream_t s, const BsrDev& A, const EdgeSlotsDev& es, const double* poses,
+                      double* dgb /*[n][9]*/);
+void launch_finalize(hipStream_t s, const BsrDev& A, const double* dgb, int write_diag, double* b,
+                     double* x, double* r, double* z, double* p, double* partials, int* grid_out);
+void launch_init_scalars(hipStream_t s, PcgScalars* S, const double* partials, int nparts, double tol,
+                         int maxit);
+void launch_spmv(hipStream_t s, const BsrDev& A, const double* x, double* y, double* dot_partials,
+                 const PcgScalars* S, int* grid_out);
+void launch_alpha(hipStream_t s, PcgScalars* S, const double* partials, int nparts);
+void launch_update_xr(hipStream_t s, int n, const PcgScalars* S, const double* dinv, const double* p,
+                      const double* q, double* x, double* r, double* z, double* partials, int* grid_out);
+void launch_beta(hipStream_t s, PcgScalars* S, const double* partials, int nparts);
+void launch_update_p(hipStream_t s, int n, const PcgScalars* S, const double* z, double* p);
+void launch_pose_update(hipStream_t s, int n, const int* free_id, const double* x, double* poses);
+void launch_dot(hipStream_t s, int n3, const double* a, const double* b, double* partials, const PcgScalars* S,
+                int* grid_out);
+void launch_precond_bj(hipStream_t s, int n, const double* dinv, const double* r, double* z);
+
+}  // namespace sgo

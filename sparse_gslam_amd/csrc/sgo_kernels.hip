@@ -1,0 +1,543 @@
+// sgo_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the Gauss-Newton inner loop.
+//
+// What each kernel replaces in the reference's g2o path:
+//   k_chi2        computeActiveErrors + activeChi2/activeRobustChi2      (slc.cpp:288)
+//   k_linearize   EdgeSE2::computeError + linearizeOplus +
+//                 BaseBinaryEdge::constructQuadraticForm (+ RobustKernelDCS) over all edges
+//                 = BlockSolver<3,3>::buildSystem                         (graphs.cpp:18-20)
+//   k_finalize    block-diagonal inverse (preconditioner) + PCG start vectors
+//   k_spmv        the Hessian product inside the linear solve that replaces
+//                 LinearSolverEigen::solve                                (graphs.cpp:19)
+//   k_update_*    PCG vector recurrences
+//   k_pose_update SparseOptimizer::update -> VertexSE2::oplusImpl
+//
+// All of it is HBM-/cache-bound fp64 gather + stream work on 3x3 blocks: no MFMA (a 3x3 block is
+// not a dense contraction).  Design rules used (cdna_hip_programming.md G2, G11, G12, G13,
+// Appendix B scatter/gather): SoA slot arrays so every wave load is one contiguous 512-B
+// segment; per-row sums by a wavefront segmented scan over row-aligned slot groups (no atomics,
+// bitwise reproducible); grids capped at 2048 blocks and mapped so that each XCD walks one
+// contiguous band of rows (its L2 then holds that band's vector entries).
+#include "sgo_internal.h"
+
+namespace sgo {
+
+const char* const kKernelNames[K_COUNT] = {
+    "k_chi2",       "k_linearize",   "k_finalize",     "k_spmv",       "k_alpha",       "k_update_xr",
+    "k_beta",       "k_update_p",    "k_pose_update",  "k_reduce",     "k_amg_galerkin", "k_amg_smooth",
+    "k_amg_residual", "k_amg_restrict", "k_amg_prolong", "k_amg_coarse", "k_amg_misc"};
+
+namespace {
+
+constexpr double kPi = 3.14159265358979323846;
+
+// g2o::normalize_theta, branch structure kept literal (result in [-pi, pi)).
+__device__ __forceinline__ double norm_theta(double t) {
+  if (t >= -kPi && t < kPi) return t;
+  double m = floor(t / (2 * kPi));
+  t = t - m * 2 * kPi;
+  if (t >= kPi) t -= 2 * kPi;
+  if (t < -kPi) t += 2 * kPi;
+  return t;
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+  return v;  // lane 0
+}
+
+// Block-wide sums of N values; thread 0 stores them to out[i * stride + blockIdx.x].
+template <int N>
+__device__ __forceinline__ void block_sum_store(double (&v)[N], double* out, int stride) {
+  __shared__ double sm[N][kWavesPerBlock];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    double s = wave_sum(v[i]);
+    if (lane == 0) sm[i][w] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      double s = sm[i][0];
+#pragma unroll
+      for (int k = 1; k < kWavesPerBlock; ++k) s += sm[i][k];
+      out[(size_t)i * stride + blockIdx.x] = s;
+    }
+  }
+}
+
+// Deterministic sum of nparts partials by one block (fixed order), result in every thread.
+__device__ __forceinline__ double block_reduce_parts(const double* parts, int nparts) {
+  __shared__ double sm2[kWavesPerBlock];
+  __shared__ double res;
+  double s = 0.0;
+  for (int i = threadIdx.x; i < nparts; i += kBlock) s += parts[i];
+  s = wave_sum(s);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sm2[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = sm2[0];
+#pragma unroll
+    for (int k = 1; k < kWavesPerBlock; ++k) t += sm2[k];
+    res = t;
+  }
+  __syncthreads();
+  return res;
+}
+
+// Inclusive segmented scan over the wave: lanes with equal `row` that are contiguous form a
+// segment; after the scan the LAST lane of a segment holds the segment sum.
+template <int N>
+__device__ __forceinline__ void seg_scan(int row, double (&v)[N], int lane) {
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int r2 = __shfl_up(row, off);
+    const bool take = (lane >= off) && (r2 == row);
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const double u = __shfl_up(v[i], off);
+      if (take) v[i] += u;
+    }
+  }
+}
+
+// Map (block, wave) -> first group and stride so that XCD x (blocks with blockIdx % 8 == x under
+// the observed round-robin dispatch; speed only, never correctness) walks the contiguous band
+// [x * ngrp / 8, (x + 1) * ngrp / 8) of groups.
+__device__ __forceinline__ void group_walk(int ngrp, int* first, int* last, int* stride) {
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
+  const int lo = (int)(((long long)ngrp * xcd) >> 3), hi = (int)(((long long)ngrp * (xcd + 1)) >> 3);
+  *first = lo + slot * kWavesPerBlock + (threadIdx.x >> 6);
+  *last = hi;
+  *stride = per_xcd * kWavesPerBlock;
+}
+
+struct EdgeLin {
+  double e[3];
+  double e2, rho0, rho1;
+};
+
+// EdgeSE2::computeError with the cached inverse measurement Zi:
+//   e = toVector( Zi * (Xi^-1 * Xj) ),  SE2 algebra literal (g2o SE2::operator* / inverse).
+__device__ __forceinline__ void edge_error(double xi, double yi, double ti, double xj, double yj, double tj,
+                                           double zx, double zy, double zt, double sz, double cz,
+                                           double (&e)[3]) {
+  const double tin = norm_theta(-ti);
+  double s1, c1;
+  sincos(tin, &s1, &c1);
+  const double ix = c1 * (-xi) - s1 * (-yi);
+  const double iy = s1 * (-xi) + c1 * (-yi);
+  const double dx = ix + c1 * xj - s1 * yj;
+  const double dy = iy + s1 * xj + c1 * yj;
+  const double dth = norm_theta(tin + tj);
+  e[0] = zx + cz * dx - sz * dy;
+  e[1] = zy + sz * dx + cz * dy;
+  e[2] = norm_theta(zt + dth);
+}
+
+// RobustKernelDCS::robustify; phi < 0: no kernel.
+__device__ __forceinline__ void dcs(double e2, double phi, double* rho0, double* rho1) {
+  double r0 = e2, r1 = 1.0;
+  if (phi >= 0.0) {
+    const double scale = (2.0 * phi) / (phi + e2);
+    if (!(scale >= 1.0)) {
+      r0 = scale * e2 * scale;
+      r1 = scale * scale;
+    }
+  }
+  *rho0 = r0;
+  *rho1 = r1;
+}
+
+// ---------------------------------------------------------------------------- k_chi2
+__global__ __launch_bounds__(kBlock) void k_chi2(EdgeListDev el, const double* __restrict__ poses,
+                                                 double* __restrict__ e2_out, double* __restrict__ partials) {
+  double acc[2] = {0.0, 0.0};
+  const int E = el.E;
+  for (int k = blockIdx.x * kBlock + threadIdx.x; k < E; k += gridDim.x * kBlock) {
+    const int vi = el.vi[k], vj = el.vj[k];
+    const double xi = poses[3 * (size_t)vi], yi = poses[3 * (size_t)vi + 1], ti = poses[3 * (size_t)vi + 2];
+    const double xj = poses[3 * (size_t)vj], yj = poses[3 * (size_t)vj + 1], tj = poses[3 * (size_t)vj + 2];
+    const double zx = el.zinv[k], zy = el.zinv[(size_t)E + k], zt = el.zinv[2 * (size_t)E + k];
+    double sz, cz;
+    sincos(zt, &sz, &cz);
+    double e[3];
+    edge_error(xi, yi, ti, xj, yj, tj, zx, zy, zt, sz, cz, e);
+    const double o00 = el.info[k], o01 = el.info[(size_t)E + k], o02 = el.info[2 * (size_t)E + k];
+    const double o11 = el.info[3 * (size_t)E + k], o12 = el.info[4 * (size_t)E + k], o22 = el.info[5 * (size_t)E + k];
+    const double oe0 = o00 * e[0] + o01 * e[1] + o02 * e[2];
+    const double oe1 = o01 * e[0] + o11 * e[1] + o12 * e[2];
+    const double oe2 = o02 * e[0] + o12 * e[1] + o22 * e[2];
+    const double e2 = e[0] * oe0 + e[1] * oe1 + e[2] * oe2;
+    double r0, r1;
+    dcs(e2, el.phi[k], &r0, &r1);
+    if (e2_out) e2_out[k] = e2;
+    acc[0] += e2;
+    acc[1] += r0;
+  }
+  block_sum_store<2>(acc, partials, kMaxPartials);
+}
+
+// out2[i] = sum(partials[i][0..nparts))
+__global__ __launch_bounds__(kBlock) void k_reduce2(const double* __restrict__ partials, int nparts,
+                                                    double* __restrict__ out2) {
+  const double a = block_reduce_parts(partials, nparts);
+  const double b = block_reduce_parts(partials + kMaxPartials, nparts);
+  if (threadIdx.x == 0) {
+    out2[0] = a;
+    out2[1] = b;
+  }
+}
+
+// ---------------------------------------------------------------------------- k_linearize
+// One lane per slot.  For a directed slot (row r, edge (i,j)): row Jacobian Jr = A (dir 0) or B
+// (dir 1), column Jacobian Jc the other one;  writes the off-diagonal block Jr^T Ow Jc into the
+// slot, and segment-sums Jr^T Ow Jr (6 unique) and -Jr^T Ow e (3) over the row; the row's last
+// lane stores them to dgb[r][0..8].
+__global__ __launch_bounds__(kBlock) void k_linearize(BsrDev A, EdgeSlotsDev es, const double* __restrict__ poses,
+                                                      double* __restrict__ dgb) {
+  const int lane = threadIdx.x & 63;
+  const size_t ns = (size_t)A.nslot;
+  int g, gend, gstride;
+  group_walk(A.ngrp, &g, &gend, &gstride);
+  for (; g < gend; g += gstride) {
+    const int gb = A.grp[g], ge = A.grp[g + 1];
+    double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    int row = -1 - lane;  // inactive lanes: unique negative keys (never merge)
+    for (int k = gb + lane; k < ge; k += 64) {
+      row = A.row[k];
+      const int fl = es.flags[k];
+      if (fl & kSlotDiag) continue;
+      const int vi = es.vi[k], vj = es.vj[k];
+      const double xi = poses[3 * (size_t)vi], yi = poses[3 * (size_t)vi + 1], ti = poses[3 * (size_t)vi + 2];
+      const double xj = poses[3 * (size_t)vj], yj = poses[3 * (size_t)vj + 1], tj = poses[3 * (size_t)vj + 2];
+      const double zx = es.zinv[k], zy = es.zinv[ns + k], zt = es.zinv[2 * ns + k];
+      double sz, cz;
+      sincos(zt, &sz, &cz);
+      double e[3];
+      edge_error(xi, yi, ti, xj, yj, tj, zx, zy, zt, sz, cz, e);
+      const double o00 = es.info[k], o01 = es.info[ns + k], o02 = es.info[2 * ns + k];
+      const double o11 = es.info[3 * ns + k], o12 = es.info[4 * ns + k], o22 = es.info[5 * ns + k];
+      double oe0 = o00 * e[0] + o01 * e[1] + o02 * e[2];
+      double oe1 = o01 * e[0] + o11 * e[1] + o12 * e[2];
+      double oe2 = o02 * e[0] + o12 * e[1] + o22 * e[2];
+      const double e2 = e[0] * oe0 + e[1] * oe1 + e[2] * oe2;
+      double r0, w;
+      dcs(e2, es.phi[k], &r0, &w);
+      // robustInformation: Ow = rho1 * Omega ; omega_r scaled by rho1
+      const double w00 = w * o00, w01 = w * o01, w02 = w * o02, w11 = w * o11, w12 = w * o12, w22 = w * o22;
+      oe0 *= w; oe1 *= w; oe2 *= w;
+      // EdgeSE2::linearizeOplus: A = Rz a, B = Rz b  (third rows (0,0,-1) and (0,0,1))
+      double si, ci;
+      sincos(ti, &si, &ci);
+      const double ddx = xj - xi, ddy = yj - yi;
+      const double a02 = -si * ddx + ci * ddy, a12 = -ci * ddx - si * ddy;
+      const double A00 = cz * (-ci) - sz * si, A01 = cz * (-si) - sz * (-ci), A02 = cz * a02 - sz * a12;
+      const double A10 = sz * (-ci) + cz * si, A11 = sz * (-si) + cz * (-ci), A12 = sz * a02 + cz * a12;
+      const double B00 = cz * ci - sz * (-si), B01 = cz * si - sz * ci;
+      const double B10 = sz * ci + cz * (-si), B11 = sz * si + cz * ci;
+      const bool dir = fl & kSlotDir;
+      // row / column Jacobians (row-major), third row is (0,0,s3)
+      const double R00 = dir ? B00 : A00, R01 = dir ? B01 : A01, R02 = dir ? 0.0 : A02;
+      const double R10 = dir ? B10 : A10, R11 = dir ? B11 : A11, R12 = dir ? 0.0 : A12;
+      const double R22 = dir ? 1.0 : -1.0;
+      const double C00 = dir ? A00 : B00, C01 = dir ? A01 : B01, C02 = dir ? A02 : 0.0;
+      const double C10 = dir ? A10 : B10, C11 = dir ? A11 : B11, C12 = dir ? A12 : 0.0;
+      const double C22 = dir ? -1.0 : 1.0;
+      // T = Ow * R  (3x3), R has zero entries (2,0),(2,1)
+      const double T00 = w00 * R00 + w01 * R10, T01 = w00 * R01 + w01 * R11, T02 = w00 * R02 + w01 * R12 + w02 * R22;
+      const double T10 = w01 * R00 + w11 * R10, T11 = w01 * R01 + w11 * R11, T12 = w01 * R02 + w11 * R12 + w12 * R22;
+      const double T20 = w02 * R00 + w12 * R10, T21 = w02 * R01 + w12 * R11, T22 = w02 * R02 + w12 * R12 + w22 * R22;
+      // D = R^T T (symmetric): d00 d01 d02 d11 d12 d22
+      acc[0] += R00 * T00 + R10 * T10;
+      acc[1] += R00 * T01 + R10 * T11;
+      acc[2] += R00 * T02 + R10 * T12;
+      acc[3] += R01 * T01 + R11 * T11;
+      acc[4] += R01 * T02 + R11 * T12;
+      acc[5] += R02 * T02 + R12 * T12 + R22 * T22;
+      // b = -R^T (Ow e)
+      acc[6] -= R00 * oe0 + R10 * oe1;
+      acc[7] -= R01 * oe0 + R11 * oe1;
+      acc[8] -= R02 * oe0 + R12 * oe1 + R22 * oe2;
+      // off-diagonal block  R^T Ow C = T^T C   (T^T because Ow is symmetric: R^T Ow = (Ow R)^T)
+      double h[9];
+      if (fl & kSlotColFixed) {
+#pragma unroll
+        for (int c = 0; c < 9; ++c) h[c] = 0.0;
+      } else {
+        h[0] = T00 * C00 + T10 * C10;
+        h[1] = T00 * C01 + T10 * C11;
+        h[2] = T00 * C02 + T10 * C12 + T20 * C22;
+        h[3] = T01 * C00 + T11 * C10;
+        h[4] = T01 * C01 + T11 * C11;
+        h[5] = T01 * C02 + T11 * C12 + T21 * C22;
+        h[6] = T02 * C00 + T12 * C10;
+        h[7] = T02 * C01 + T12 * C11;
+        h[8] = T02 * C02 + T12 * C12 + T22 * C22;
+      }
+#pragma unroll
+      for (int c = 0; c < 9; ++c) A.blk[c * ns + k] = h[c];
+    }
+    seg_scan<9>(row, acc, lane);
+    const int rn = __shfl_down(row, 1);
+    if (row >= 0 && (lane == 63 || rn != row)) {
+      double* d = dgb + 9 * (size_t)row;
+#pragma unroll
+      for (int c = 0; c < 9; ++c) d[c] = acc[c];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------- k_finalize
+// Per row: diagonal slot, block-diagonal inverse, and the PCG start state
+//   x = 0, r = b, z = Dinv b, p = z ; partials[0][blk] = r.z, partials[1][blk] = b.b
+__global__ __launch_bounds__(kBlock) void k_finalize(BsrDev A, const double* __restrict__ dgb, int write_diag,
+                                                     double* __restrict__ b, double* __restrict__ x,
+                                                     double* __restrict__ r, double* __restrict__ z,
+                                                     double* __restrict__ p, double* __restrict__ partials) {
+  double acc[2] = {0.0, 0.0};
+  const size_t ns = (size_t)A.nslot;
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < A.n; i += gridDim.x * kBlock) {
+    const double* d = dgb + 9 * (size_t)i;
+    const double d00 = d[0], d01 = d[1], d02 = d[2], d11 = d[3], d12 = d[4], d22 = d[5];
+    const double b0 = d[6], b1 = d[7], b2 = d[8];
+    const int k0 = A.rowptr[i];
+    const double s = write_diag ? 1.0 : 0.0;
+    A.blk[0 * ns + k0] = s * d00; A.blk[1 * ns + k0] = s * d01; A.blk[2 * ns + k0] = s * d02;
+    A.blk[3 * ns + k0] = s * d01; A.blk[4 * ns + k0] = s * d11; A.blk[5 * ns + k0] = s * d12;
+    A.blk[6 * ns + k0] = s * d02; A.blk[7 * ns + k0] = s * d12; A.blk[8 * ns + k0] = s * d22;
+    // symmetric 3x3 inverse by cofactors
+    const double c00 = d11 * d22 - d12 * d12, c01 = d02 * d12 - d01 * d22, c02 = d01 * d12 - d02 * d11;
+    const double c11 = d00 * d22 - d02 * d02, c12 = d01 * d02 - d00 * d12, c22 = d00 * d11 - d01 * d01;
+    const double det = d00 * c00 + d01 * c01 + d02 * c02;
+    const double id = (det != 0.0 && isfinite(det)) ? 1.0 / det : 0.0;
+    const double i00 = c00 * id, i01 = c01 * id, i02 = c02 * id, i11 = c11 * id, i12 = c12 * id, i22 = c22 * id;
+    double* di = A.dinv + 6 * (size_t)i;
+    di[0] = i00; di[1] = i01; di[2] = i02; di[3] = i11; di[4] = i12; di[5] = i22;
+    const double z0 = i00 * b0 + i01 * b1 + i02 * b2;
+    const double z1 = i01 * b0 + i11 * b1 + i12 * b2;
+    const double z2 = i02 * b0 + i12 * b1 + i22 * b2;
+    const size_t o = 3 * (size_t)i;
+    b[o] = b0; b[o + 1] = b1; b[o + 2] = b2;
+    if (x) {
+      x[o] = 0.0; x[o + 1] = 0.0; x[o + 2] = 0.0;
+      r[o] = b0; r[o + 1] = b1; r[o + 2] = b2;
+      z[o] = z0; z[o + 1] = z1; z[o + 2] = z2;
+      p[o] = z0; p[o + 1] = z1; p[o + 2] = z2;
+    }
+    acc[0] += b0 * z0 + b1 * z1 + b2 * z2;
+    acc[1] += b0 * b0 + b1 * b1 + b2 * b2;
+  }
+  block_sum_store<2>(acc, partials, kMaxPartials);
+}
+
+__global__ __launch_bounds__(kBlock) void k_init_scalars(PcgScalars* S, const double* __restrict__ partials,
+                                                         int nparts, double tol, int maxit) {
+  const double rz = block_reduce_parts(partials, nparts);
+  const double bb = block_reduce_parts(partials + kMaxPartials, nparts);
+  if (threadIdx.x == 0) {
+    S->rz = rz;
+    S->bb = bb;
+    S->rr = bb;
+    S->pq = 0.0;
+    S->alpha = 0.0;
+    S->beta = 0.0;
+    S->tol2 = tol * tol;
+    S->iter = 0;
+    S->maxit = maxit;
+    S->stop = (bb == 0.0) ? 1 : (isfinite(bb) && isfinite(rz) ? 0 : 3);
+  }
+}
+
+// ---------------------------------------------------------------------------- k_spmv
+// y = A x, one lane per slot, wavefront segmented scan per row; optional partial of x.y.
+__global__ __launch_bounds__(kBlock) void k_spmv(BsrDev A, const double* __restrict__ x, double* __restrict__ y,
+                                                 double* __restrict__ dot_partials, const PcgScalars* S) {
+  if (S && S->stop) return;
+  const int lane = threadIdx.x & 63;
+  const size_t ns = (size_t)A.nslot;
+  double dotacc[1] = {0.0};
+  int g, gend, gstride;
+  group_walk(A.ngrp, &g, &gend, &gstride);
+  for (; g < gend; g += gstride) {
+    const int gb = A.grp[g], ge = A.grp[g + 1];
+    double acc[3] = {0.0, 0.0, 0.0};
+    int row = -1 - lane;
+    for (int k = gb + lane; k < ge; k += 64) {
+      row = A.row[k];
+      const int c = A.col[k];
+      const double x0 = x[3 * (size_t)c], x1 = x[3 * (size_t)c + 1], x2 = x[3 * (size_t)c + 2];
+      acc[0] += A.blk[k] * x0 + A.blk[ns + k] * x1 + A.blk[2 * ns + k] * x2;
+      acc[1] += A.blk[3 * ns + k] * x0 + A.blk[4 * ns + k] * x1 + A.blk[5 * ns + k] * x2;
+      acc[2] += A.blk[6 * ns + k] * x0 + A.blk[7 * ns + k] * x1 + A.blk[8 * ns + k] * x2;
+    }
+    seg_scan<3>(row, acc, lane);
+    const int rn = __shfl_down(row, 1);
+    if (row >= 0 && (lane == 63 || rn != row)) {
+      const size_t o = 3 * (size_t)row;
+      y[o] = acc[0]; y[o + 1] = acc[1]; y[o + 2] = acc[2];
+      if (dot_partials) dotacc[0] += x[o] * acc[0] + x[o + 1] * acc[1] + x[o + 2] * acc[2];
+    }
+  }
+  if (dot_partials) block_sum_store<1>(dotacc, dot_partials, kMaxPartials);
+}
+
+__global__ __launch_bounds__(kBlock) void k_alpha(PcgScalars* S, const double* __restrict__ partials, int nparts) {
+  if (S->stop) return;
+  const double pq = block_reduce_parts(partials, nparts);
+  if (threadIdx.x == 0) {
+    S->pq = pq;
+    if (!(pq > 0.0) || !isfinite(pq)) S->stop = 3;
+    else S->alpha = S->rz / pq;
+  }
+}
+
+// x += alpha p ; r -= alpha q ; z = Dinv r ; partials: r.z, r.r
+__global__ __launch_bounds__(kBlock) void k_update_xr(int n, const PcgScalars* S, const double* __restrict__ dinv,
+                                                      const double* __restrict__ p, const double* __restrict__ q,
+                                                      double* __restrict__ x, double* __restrict__ r,
+                                                      double* __restrict__ z, double* __restrict__ partials) {
+  if (S->stop) return;
+  const double alpha = S->alpha;
+  double acc[2] = {0.0, 0.0};
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    const size_t o = 3 * (size_t)i;
+    const double r0 = r[o] - alpha * q[o], r1 = r[o + 1] - alpha * q[o + 1], r2 = r[o + 2] - alpha * q[o + 2];
+    x[o] += alpha * p[o]; x[o + 1] += alpha * p[o + 1]; x[o + 2] += alpha * p[o + 2];
+    r[o] = r0; r[o + 1] = r1; r[o + 2] = r2;
+    if (dinv) {
+      const double* di = dinv + 6 * (size_t)i;
+      const double z0 = di[0] * r0 + di[1] * r1 + di[2] * r2;
+      const double z1 = di[1] * r0 + di[3] * r1 + di[4] * r2;
+      const double z2 = di[2] * r0 + di[4] * r1 + di[5] * r2;
+      z[o] = z0; z[o + 1] = z1; z[o + 2] = z2;
+      acc[0] += r0 * z0 + r1 * z1 + r2 * z2;
+    }
+    acc[1] += r0 * r0 + r1 * r1 + r2 * r2;
+  }
+  block_sum_store<2>(acc, partials, kMaxPartials);
+}
+
+__global__ __launch_bounds__(kBlock) void k_beta(PcgScalars* S, const double* __restrict__ partials, int nparts) {
+  if (S->stop) return;
+  const double rz = block_reduce_parts(partials, nparts);
+  const double rr = block_reduce_parts(partials + kMaxPartials, nparts);
+  if (threadIdx.x == 0) {
+    S->beta = rz / S->rz;
+    S->rz = rz;
+    S->rr = rr;
+    const int it = S->iter + 1;
+    S->iter = it;
+    if (!isfinite(rz) || !isfinite(rr)) S->stop = 3;
+    else if (rr <= S->tol2 * S->bb) S->stop = 1;
+    else if (it >= S->maxit) S->stop = 2;
+  }
+}
+
+// p = z + beta p   (flat over 3n)
+__global__ __launch_bounds__(kBlock) void k_update_p(int n3, const PcgScalars* S, const double* __restrict__ z,
+                                                     double* __restrict__ p) {
+  if (S->stop) return;
+  const double beta = S->beta;
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n3; i += gridDim.x * kBlock) p[i] = z[i] + beta * p[i];
+}
+
+// partials[blk] = sum a[i] * b[i]   (flat; used when the product had to be all-reduced first)
+__global__ __launch_bounds__(kBlock) void k_dot(int n3, const double* __restrict__ a, const double* __restrict__ b,
+                                                double* __restrict__ partials, const PcgScalars* S) {
+  if (S && S->stop) return;
+  double acc[1] = {0.0};
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n3; i += gridDim.x * kBlock) acc[0] += a[i] * b[i];
+  block_sum_store<1>(acc, partials, kMaxPartials);
+}
+
+// z = Dinv r
+__global__ __launch_bounds__(kBlock) void k_precond_bj(int n, const double* __restrict__ dinv,
+                                                       const double* __restrict__ r, double* __restrict__ z) {
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    const size_t o = 3 * (size_t)i;
+    const double* di = dinv + 6 * (size_t)i;
+    const double r0 = r[o], r1 = r[o + 1], r2 = r[o + 2];
+    z[o] = di[0] * r0 + di[1] * r1 + di[2] * r2;
+    z[o + 1] = di[1] * r0 + di[3] * r1 + di[4] * r2;
+    z[o + 2] = di[2] * r0 + di[4] * r1 + di[5] * r2;
+  }
+}
+
+// SparseOptimizer::update -> VertexSE2::oplusImpl: t += d[0:2]; theta = normalize(theta + d[2])
+__global__ __launch_bounds__(kBlock) void k_pose_update(int n, const int* __restrict__ free_id,
+                                                        const double* __restrict__ x, double* __restrict__ poses) {
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    const size_t v = 3 * (size_t)free_id[i], o = 3 * (size_t)i;
+    poses[v] += x[o];
+    poses[v + 1] += x[o + 1];
+    poses[v + 2] = norm_theta(poses[v + 2] + x[o + 2]);
+  }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------- launchers
+void launch_chi2(hipStream_t s, const EdgeListDev& el, const double* poses, double* e2_out, double* partials,
+                 int* grid_out) {
+  const int grid = grid_for(el.E, kBlock);
+  hipLaunchKernelGGL(k_chi2, dim3(grid), dim3(kBlock), 0, s, el, poses, e2_out, partials);
+  *grid_out = grid;
+}
+void launch_reduce2(hipStream_t s, const double* partials, int nparts, double* out2) {
+  hipLaunchKernelGGL(k_reduce2, dim3(1), dim3(kBlock), 0, s, partials, nparts, out2);
+}
+void launch_linearize(hipStream_t s, const BsrDev& A, const EdgeSlotsDev& es, const double* poses, double* dgb) {
+  const int grid = grid_for(A.ngrp, kWavesPerBlock);
+  hipLaunchKernelGGL(k_linearize, dim3(grid), dim3(kBlock), 0, s, A, es, poses, dgb);
+}
+void launch_finalize(hipStream_t s, const BsrDev& A, const double* dgb, int write_diag, double* b, double* x,
+                     double* r, double* z, double* p, double* partials, int* grid_out) {
+  const int grid = grid_for(A.n, kBlock);
+  hipLaunchKernelGGL(k_finalize, dim3(grid), dim3(kBlock), 0, s, A, dgb, write_diag, b, x, r, z, p, partials);
+  *grid_out = grid;
+}
+void launch_init_scalars(hipStream_t s, PcgScalars* S, const double* partials, int nparts, double tol, int maxit) {
+  hipLaunchKernelGGL(k_init_scalars, dim3(1), dim3(kBlock), 0, s, S, partials, nparts, tol, maxit);
+}
+void launch_spmv(hipStream_t s, const BsrDev& A, const double* x, double* y, double* dot_partials,
+                 const PcgScalars* S, int* grid_out) {
+  const int grid = grid_for(A.ngrp, kWavesPerBlock);
+  hipLaunchKernelGGL(k_spmv, dim3(grid), dim3(kBlock), 0, s, A, x, y, dot_partials, S);
+  if (grid_out) *grid_out = grid;
+}
+void launch_alpha(hipStream_t s, PcgScalars* S, const double* partials, int nparts) {
+  hipLaunchKernelGGL(k_alpha, dim3(1), dim3(kBlock), 0, s, S, partials, nparts);
+}
+void launch_update_xr(hipStream_t s, int n, const PcgScalars* S, const double* dinv, const double* p,
+                      const double* q, double* x, double* r, double* z, double* partials, int* grid_out) {
+  const int grid = grid_for(n, kBlock);
+  hipLaunchKernelGGL(k_update_xr, dim3(grid), dim3(kBlock), 0, s, n, S, dinv, p, q, x, r, z, partials);
+  if (grid_out) *grid_out = grid;
+}
+void launch_beta(hipStream_t s, PcgScalars* S, const double* partials, int nparts) {
+  hipLaunchKernelGGL(k_beta, dim3(1), dim3(kBlock), 0, s, S, partials, nparts);
+}
+void launch_update_p(hipStream_t s, int n, const PcgScalars* S, const double* z, double* p) {
+  const int grid = grid_for(3LL * n, kBlock);
+  hipLaunchKernelGGL(k_update_p, dim3(grid), dim3(kBlock), 0, s, 3 * n, S, z, p);
+}
+void launch_pose_update(hipStream_t s, int n, const int* free_id, const double* x, double* poses) {
+  const int grid = grid_for(n, kBlock);
+  hipLaunchKernelGGL(k_pose_update, dim3(grid), dim3(kBlock), 0, s, n, free_id, x, poses);
+}
+void launch_dot(hipStream_t s, int n3, const double* a, const double* b, double* partials, const PcgScalars* S,
+                int* grid_out) {
+  const int grid = grid_for(n3, kBlock);
+  hipLaunchKernelGGL(k_dot, dim3(grid), dim3(kBlock), 0, s, n3, a, b, partials, S);
+  if (grid_out) *grid_out = grid;
+}
+void launch_precond_bj(hipStream_t s, int n, const double* dinv, const double* r, double* z) {
+  const int grid = grid_for(n, kBlock);
+  hipLaunchKernelGGL(k_precond_bj, dim3(grid), dim3(kBlock), 0, s, n, dinv, r, z);
+}
+
+}  // namespace sgo

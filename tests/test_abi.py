@@ -1,0 +1,41 @@
+"""The C-ABI library loads on a CPU-only host and exports every symbol include/sgo.h declares."""
+import ctypes
+import os
+import re
+
+from sparse_gslam_amd import capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    src = open(os.path.join(ROOT, "include", "sgo.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(sgo_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_and_binding_agree():
+    assert _declared_symbols() == sorted(capi.SYMBOLS)
+
+
+def test_library_exports_every_declared_symbol(sgo_lib):
+    for name in _declared_symbols():
+        assert hasattr(sgo_lib, name), name
+    assert sgo_lib.sgo_version() == 100
+
+
+def test_struct_sizes_match_header(sgo_lib):
+    o = capi.default_opts()
+    assert o.struct_size == ctypes.sizeof(capi.Opts)
+    assert o.pcg_tol > 0 and o.pcg_maxit > 0 and o.pcg_chunk > 0
+
+
+def test_no_oracle_in_product():
+    """The product never imports, links or loads anything under oracle/."""
+    pkg = os.path.join(ROOT, "sparse_gslam_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h", "Makefile")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "import oracle" not in text and "from oracle" not in text, f
+                assert "sgo_oracle" not in text and "np_oracle" not in text, f
