@@ -178,10 +178,13 @@ def manhattan(V: int, E: int, seed: int, p_random: float = 0.0, *, info_mode: st
     rel = _rel(truth[ei], truth[ej])
     sig = np.array([sigma_xy, sigma_xy, sigma_th])
     noise = rng.standard_normal((Etot, 3)) * sig
+    # information matrices of noise-free graphs (sigma = 0) use the nominal sigmas
+    isig = np.array([sigma_xy if sigma_xy > 0 else SIGMA_XY, sigma_xy if sigma_xy > 0 else SIGMA_XY,
+                     sigma_th if sigma_th > 0 else SIGMA_TH])
     info = np.zeros((Etot, 6))
     if info_mode == "diag":
-        info[:, 0] = info[:, 3] = 1.0 / sigma_xy**2
-        info[:, 5] = 1.0 / sigma_th**2
+        info[:, 0] = info[:, 3] = 1.0 / isig[0]**2
+        info[:, 5] = 1.0 / isig[2]**2
     elif info_mode == "full":
         # random rotation Q = Rz(a) Ry(b) Rx(c), small b,c so that theta stays the stiff axis
         a = rng.uniform(-np.pi, np.pi, Etot)
@@ -189,7 +192,7 @@ def manhattan(V: int, E: int, seed: int, p_random: float = 0.0, *, info_mode: st
         c = rng.uniform(-0.2, 0.2, Etot)
         Q = _euler(a, b, c)
         noise = np.einsum("nij,nj->ni", Q, noise)
-        O = np.einsum("nij,j,nkj->nik", Q, 1.0 / sig**2, Q)
+        O = np.einsum("nij,j,nkj->nik", Q, 1.0 / isig**2, Q)
         info[:, 0], info[:, 1], info[:, 2] = O[:, 0, 0], O[:, 0, 1], O[:, 0, 2]
         info[:, 3], info[:, 4], info[:, 5] = O[:, 1, 1], O[:, 1, 2], O[:, 2, 2]
     else:
