@@ -161,7 +161,7 @@ def main():
                        "solver": {0: "pcg_block_jacobi", 1: "pcg_amg"}[opts.get("solver", o.solver)],
                        "pcg_tol": opts.get("pcg_tol", o.pcg_tol), "parallelism": f"edge-shard x{world}"},
             "final_chi2": st["chi2"][-1], "final_robust_chi2": st["robust_chi2"][-1],
-            "pcg_iters_per_gn_iter": float(np.mean(st["pcg_iters"])),
+            "pcg_iters_per_gn_iter": float(np.mean(st["pcg_iters"])), "pcg_iters": st["pcg_iters"],
             "gn_iter_ms_median": 1e3 * float(np.median(st["seconds"])),
             "linearize_ms_median": 1e3 * float(np.median(st["seconds_linearize"])),
         }

@@ -1,0 +1,44 @@
+// sgo_amg.h -- rigid-body aggregation multigrid preconditioner (K-cycle) for the block-CSR
+// Gauss-Newton Hessian.  See sgo_amg.hip for the algorithm and DESIGN.md section 5.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+
+#include "sgo_internal.h"
+
+namespace sgo {
+
+struct AmgConfig {
+  double theta = 0.02;     // strength-of-connection threshold (env SGO_AMG_THETA)
+  double omega = 0.7;      // block-Jacobi damping (env SGO_AMG_OMEGA)
+  int max_levels = 10;
+  int coarsest_nodes = 100; // stop coarsening at or below this many nodes (dense inverse of 3x that)
+};
+
+// profiling hook supplied by the context (brackets a launch with HIP events when enabled)
+struct AmgProf {
+  void* user = nullptr;
+  void (*begin)(void* user, int kid, double bytes) = nullptr;
+  void (*end)(void* user) = nullptr;
+};
+
+struct Amg;  // opaque
+
+// Build the hierarchy for the level-0 matrix A0, whose values (blk, dinv) must hold the
+// linearisation at the initial poses (they provide the strength of connection).  `pos_src` /
+// `free_id` give the positions of the level-0 nodes: pos of row h = poses[3*free_id[h] + 0..1].
+Amg* amg_create(hipStream_t s, const BsrDev& A0, const double* d_poses, const int* d_free_id,
+                const AmgConfig& cfg, const AmgProf& prof, std::string* err);
+void amg_destroy(Amg* m);
+// Recompute the coarse operators for the current level-0 values and poses (once per GN iteration).
+int amg_update(Amg* m, hipStream_t s, std::string* err);
+// z = M^-1 r (one K-cycle).  If dotvec != nullptr, partials[0..nparts) receive the per-block
+// partial sums of dotvec . z; returns nparts (the grid of the last kernel).
+// dotvec2 (optional) adds partials[kMaxPartials + ..] = dotvec2 . z.
+int amg_apply(Amg* m, hipStream_t s, const double* r, double* z, const double* dotvec, double* partials,
+              const PcgScalars* S, const double* dotvec2 = nullptr);
+int amg_num_levels(const Amg* m);
+void amg_describe(const Amg* m, std::string* out);
+
+}  // namespace sgo

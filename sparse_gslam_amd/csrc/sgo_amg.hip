@@ -1,0 +1,722 @@
+// sgo_amg.hip -- rigid-body aggregation multigrid preconditioner for the GN Hessian.
+//
+// Why it exists: the block-Jacobi PCG that BASELINE.json's north_star names needs 8 000+
+// iterations per GN iteration on the 10k-pose graph and does not reach 1e-8 in 20 000 on the
+// 100k-pose graph (profiles/r01_bj_c4_kernel_stats.csv), because the pose-graph Hessian is a
+// vector-Laplacian-like operator whose low-energy modes are near-rigid motions of large parts
+// of the trajectory.  This preconditioner keeps block-Jacobi as the smoother and adds a
+// coarse-grid hierarchy that represents exactly those modes:
+//   * nodes are aggregated by strength of connection (greedy root-node aggregation on
+//     Frobenius norms of the 3x3 blocks, threshold theta) -- structure built on the host once
+//     per sgo_set_graph_se2 (like g2o's symbolic analysis, once per optimize());
+//   * the prolongator is the tentative rigid-body one: an aggregate moves as a rigid body
+//     (u_x, u_y, w) about its centre c, so node i at p_i gets T(p_i - c) u with
+//     T(d) = [[1,0,-d_y],[0,1,d_x],[0,0,1]] -- the three rigid motions of SE(2) are represented
+//     exactly on every level (they are the null space of every edge's Jacobian pair);
+//   * coarse operators are Galerkin products P^T H P, recomputed on the device every GN
+//     iteration (values change, structure does not): one lane per fine slot in coarse-slot
+//     order, wavefront segmented scan per coarse slot -- no atomics, bitwise reproducible;
+//   * cycle: K-cycle (two flexible-CG steps per intermediate level, Notay's AGMG scheme) with
+//     one damped block-Jacobi sweep before and after; the coarsest level (<= ~100 nodes) is
+//     solved with an explicit dense inverse computed once per GN iteration.
+// All launches go to the caller's stream with fixed pointers, so a whole PCG iteration
+// including the cycle is captured into one hipGraph.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <numeric>
+#include <vector>
+
+#include "sgo_amg.h"
+#include "sgo_device.h"
+
+namespace sgo {
+
+namespace {
+
+// --------------------------------------------------------------------------------- kernels
+// Frobenius norm of every slot's block (strength of connection input).
+__global__ __launch_bounds__(kBlock) void k_block_norms(BsrDev A, double* __restrict__ w) {
+  const size_t ns = (size_t)A.nslot;
+  for (int k = blockIdx.x * kBlock + threadIdx.x; k < A.nslot; k += gridDim.x * kBlock) {
+    double s = 0.0;
+#pragma unroll
+    for (int c = 0; c < 9; ++c) {
+      const double v = A.blk[c * ns + k];
+      s += v * v;
+    }
+    w[k] = sqrt(s);
+  }
+}
+
+// Level-0 node positions from the pose array: pos[h] = poses[free_id[h]].xy
+__global__ __launch_bounds__(kBlock) void k_positions0(int n, const int* __restrict__ free_id,
+                                                       const double* __restrict__ poses, double* __restrict__ pos) {
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    const size_t v = 3 * (size_t)free_id[i];
+    pos[2 * (size_t)i] = poses[v];
+    pos[2 * (size_t)i + 1] = poses[v + 1];
+  }
+}
+
+// Aggregate centres and lever arms: one thread per aggregate (members are few).
+__global__ __launch_bounds__(kBlock) void k_centres(int nc, const int* __restrict__ mem_ptr, const int* __restrict__ mem,
+                                                    const double* __restrict__ pos, double* __restrict__ cpos,
+                                                    double* __restrict__ d) {
+  for (int a = blockIdx.x * kBlock + threadIdx.x; a < nc; a += gridDim.x * kBlock) {
+    const int lo = mem_ptr[a], hi = mem_ptr[a + 1];
+    double sx = 0.0, sy = 0.0;
+    for (int t = lo; t < hi; ++t) {
+      const int i = mem[t];
+      sx += pos[2 * (size_t)i];
+      sy += pos[2 * (size_t)i + 1];
+    }
+    const double inv = 1.0 / (double)(hi - lo);
+    const double cx = sx * inv, cy = sy * inv;
+    cpos[2 * (size_t)a] = cx;
+    cpos[2 * (size_t)a + 1] = cy;
+    for (int t = lo; t < hi; ++t) {
+      const int i = mem[t];
+      d[2 * (size_t)i] = pos[2 * (size_t)i] - cx;
+      d[2 * (size_t)i + 1] = pos[2 * (size_t)i + 1] - cy;
+    }
+  }
+}
+
+// Galerkin product: coarse slot s gets sum over its fine slots k=(i,j) of T_i^T B_k T_j.
+// One lane per contribution, contributions sorted by coarse slot, segmented scan by coarse slot.
+struct GalerkinMap {
+  int n = 0;              // contributions (= fine slots)
+  int ngrp = 0;
+  const int* src = nullptr;  // fine slot of contribution t
+  const int* tgt = nullptr;  // coarse slot of contribution t
+  const int* grp = nullptr;  // wave groups aligned to coarse-slot boundaries
+};
+__global__ __launch_bounds__(kBlock) void k_galerkin(BsrDev F, BsrDev C, GalerkinMap g, const double* __restrict__ d) {
+  const int lane = threadIdx.x & 63;
+  const size_t nf = (size_t)F.nslot, ncs = (size_t)C.nslot;
+  int gi, gend, gstride;
+  group_walk(g.ngrp, &gi, &gend, &gstride);
+  for (; gi < gend; gi += gstride) {
+    const int gb = g.grp[gi], ge = g.grp[gi + 1];
+    double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    int key = -1 - lane;
+    for (int t = gb + lane; t < ge; t += 64) {
+      key = g.tgt[t];
+      const int k = g.src[t];
+      const int i = F.row[k], j = F.col[k];
+      const double dxi = d[2 * (size_t)i], dyi = d[2 * (size_t)i + 1];
+      const double dxj = d[2 * (size_t)j], dyj = d[2 * (size_t)j + 1];
+      double b[9];
+#pragma unroll
+      for (int c = 0; c < 9; ++c) b[c] = F.blk[c * nf + k];
+      // M = B T_j : third column = -dy_j * col0 + dx_j * col1 + col2
+      const double m02 = -dyj * b[0] + dxj * b[1] + b[2];
+      const double m12 = -dyj * b[3] + dxj * b[4] + b[5];
+      const double m22 = -dyj * b[6] + dxj * b[7] + b[8];
+      // C = T_i^T M : third row = -dy_i * row0 + dx_i * row1 + row2
+      acc[0] += b[0];
+      acc[1] += b[1];
+      acc[2] += m02;
+      acc[3] += b[3];
+      acc[4] += b[4];
+      acc[5] += m12;
+      acc[6] += -dyi * b[0] + dxi * b[3] + b[6];
+      acc[7] += -dyi * b[1] + dxi * b[4] + b[7];
+      acc[8] += -dyi * m02 + dxi * m12 + m22;
+    }
+    seg_scan<9>(key, acc, lane);
+    const int kn = __shfl_down(key, 1);
+    if (key >= 0 && (lane == 63 || kn != key)) {
+#pragma unroll
+      for (int c = 0; c < 9; ++c) C.blk[c * ncs + key] = acc[c];
+    }
+  }
+}
+
+// dinv of a coarse level from its diagonal slots (first slot of each row)
+__global__ __launch_bounds__(kBlock) void k_level_dinv(BsrDev A) {
+  const size_t ns = (size_t)A.nslot;
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < A.n; i += gridDim.x * kBlock) {
+    const int k0 = A.rowptr[i];
+    // symmetrise (the Galerkin sum is symmetric up to rounding)
+    const double d00 = A.blk[k0], d01 = 0.5 * (A.blk[ns + k0] + A.blk[3 * ns + k0]);
+    const double d02 = 0.5 * (A.blk[2 * ns + k0] + A.blk[6 * ns + k0]), d11 = A.blk[4 * ns + k0];
+    const double d12 = 0.5 * (A.blk[5 * ns + k0] + A.blk[7 * ns + k0]), d22 = A.blk[8 * ns + k0];
+    const double c00 = d11 * d22 - d12 * d12, c01 = d02 * d12 - d01 * d22, c02 = d01 * d12 - d02 * d11;
+    const double c11 = d00 * d22 - d02 * d02, c12 = d01 * d02 - d00 * d12, c22 = d00 * d11 - d01 * d01;
+    const double det = d00 * c00 + d01 * c01 + d02 * c02;
+    const double id = (det != 0.0 && isfinite(det)) ? 1.0 / det : 0.0;
+    double* di = A.dinv + 6 * (size_t)i;
+    di[0] = c00 * id; di[1] = c01 * id; di[2] = c02 * id; di[3] = c11 * id; di[4] = c12 * id; di[5] = c22 * id;
+  }
+}
+
+// rc[a] = sum_{i in a} T_i^T r_i     (one thread per aggregate)
+__global__ __launch_bounds__(kBlock) void k_restrict(int nc, const int* __restrict__ mem_ptr, const int* __restrict__ mem,
+                                                     const double* __restrict__ d, const double* __restrict__ r,
+                                                     double* __restrict__ rc, const PcgScalars* S) {
+  if (S && S->stop) return;
+  for (int a = blockIdx.x * kBlock + threadIdx.x; a < nc; a += gridDim.x * kBlock) {
+    const int lo = mem_ptr[a], hi = mem_ptr[a + 1];
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    for (int t = lo; t < hi; ++t) {
+      const int i = mem[t];
+      const double r0 = r[3 * (size_t)i], r1 = r[3 * (size_t)i + 1], r2 = r[3 * (size_t)i + 2];
+      s0 += r0;
+      s1 += r1;
+      s2 += -d[2 * (size_t)i + 1] * r0 + d[2 * (size_t)i] * r1 + r2;
+    }
+    rc[3 * (size_t)a] = s0;
+    rc[3 * (size_t)a + 1] = s1;
+    rc[3 * (size_t)a + 2] = s2;
+  }
+}
+
+// x_i += T_i xc[agg(i)]
+__global__ __launch_bounds__(kBlock) void k_prolong_add(int n, const int* __restrict__ agg, const double* __restrict__ d,
+                                                        const double* __restrict__ xc, double* __restrict__ x,
+                                                        const PcgScalars* S) {
+  if (S && S->stop) return;
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    const size_t a = 3 * (size_t)agg[i], o = 3 * (size_t)i;
+    const double u0 = xc[a], u1 = xc[a + 1], w = xc[a + 2];
+    x[o] += u0 - d[2 * (size_t)i + 1] * w;
+    x[o + 1] += u1 + d[2 * (size_t)i] * w;
+    x[o + 2] += w;
+  }
+}
+
+// Flexible-CG updates of the K-cycle.  Scalars come from per-block partials reduced by every
+// block in the same fixed order (deterministic, no extra launch).
+//   mode 0: alpha = pB/pA; xk = alpha p ; bk -= alpha q
+//   mode 1: beta = pC/pA ; z2 -= beta z1                      (p2 = z2 - (z2.q1 / z1.q1) z1)
+//   mode 2: alpha = pB/pA; xk += alpha p
+__global__ __launch_bounds__(kBlock) void k_fcg(int mode, int n3, const double* __restrict__ partsA, int nA,
+                                                const double* __restrict__ partsB, int nB, const double* __restrict__ p,
+                                                const double* __restrict__ q, double* __restrict__ xk,
+                                                double* __restrict__ bk, const PcgScalars* S) {
+  if (S && S->stop) return;
+  const double den = block_reduce_parts(partsA, nA);
+  const double num = block_reduce_parts(partsB, nB);
+  const double a = (den > 0.0 && isfinite(den) && isfinite(num)) ? num / den : 0.0;
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n3; i += gridDim.x * kBlock) {
+    if (mode == 0) {
+      xk[i] = a * p[i];
+      bk[i] -= a * q[i];
+    } else if (mode == 1) {
+      xk[i] -= a * p[i];
+    } else {
+      xk[i] += a * p[i];
+    }
+  }
+}
+
+// Coarsest level: dense matrix from the slots, inverted in place by Gauss-Jordan (SPD, no
+// pivoting), one workgroup.  N = 3 n.  inv is N x N row-major in global memory.
+constexpr int kDenseThreads = 1024;
+__global__ __launch_bounds__(kDenseThreads) void k_dense_invert(BsrDev A, double* __restrict__ inv, int* __restrict__ fail) {
+  const int N = 3 * A.n;
+  const size_t ns = (size_t)A.nslot;
+  extern __shared__ double sh[];  // [2N]: scaled pivot row, pivot column
+  double* prow = sh;
+  double* pcol = sh + N;
+  for (int t = threadIdx.x; t < N * N; t += kDenseThreads) inv[t] = 0.0;
+  __syncthreads();
+  for (int k = threadIdx.x; k < A.nslot; k += kDenseThreads) {
+    const int r = A.row[k], c = A.col[k];
+#pragma unroll
+    for (int e = 0; e < 9; ++e) inv[(size_t)(3 * r + e / 3) * N + 3 * c + e % 3] = A.blk[e * ns + k];
+  }
+  __syncthreads();
+  __shared__ double piv;
+  for (int k = 0; k < N; ++k) {
+    if (threadIdx.x == 0) {
+      const double v = inv[(size_t)k * N + k];
+      if (!(v > 0.0) || !isfinite(v)) *fail = 1;
+      piv = (v != 0.0) ? 1.0 / v : 0.0;
+    }
+    __syncthreads();
+    const double p = piv;
+    for (int j = threadIdx.x; j < N; j += kDenseThreads) {
+      prow[j] = (j == k) ? 0.0 : inv[(size_t)k * N + j] * p;
+      pcol[j] = (j == k) ? 0.0 : inv[(size_t)j * N + k];
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < N * N; t += kDenseThreads) {
+      const int i = t / N, j = t - i * N;
+      double v;
+      if (i == k) v = (j == k) ? p : prow[j];
+      else if (j == k) v = -pcol[i] * p;
+      else v = inv[t] - pcol[i] * prow[j];
+      inv[t] = v;
+    }
+    __syncthreads();
+  }
+}
+
+// x = inv * b  (one workgroup; inv symmetric, so column reads are coalesced row reads)
+__global__ __launch_bounds__(kDenseThreads) void k_dense_apply(int N, const double* __restrict__ inv,
+                                                              const double* __restrict__ b, double* __restrict__ x,
+                                                              const PcgScalars* S) {
+  if (S && S->stop) return;
+  extern __shared__ double sb[];
+  for (int j = threadIdx.x; j < N; j += kDenseThreads) sb[j] = b[j];
+  __syncthreads();
+  for (int i = threadIdx.x; i < N; i += kDenseThreads) {
+    double s = 0.0;
+    for (int j = 0; j < N; ++j) s += inv[(size_t)j * N + i] * sb[j];
+    x[i] = s;
+  }
+}
+
+// --------------------------------------------------------------------------------- host
+template <class T>
+T* dev_alloc(std::vector<void*>& pool, size_t count) {
+  void* p = nullptr;
+  if (hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T)) != hipSuccess) return nullptr;
+  pool.push_back(p);
+  return (T*)p;
+}
+template <class T>
+T* dev_upload(std::vector<void*>& pool, const std::vector<T>& v, hipStream_t s) {
+  T* p = dev_alloc<T>(pool, v.size());
+  if (p && !v.empty()) hipMemcpyAsync(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s);
+  return p;
+}
+
+// wave groups over segments [ptr[i], ptr[i+1]): whole segments packed up to 64 items; a longer
+// segment is its own group (same rule as the level-0 row groups in sgo_api.cpp)
+std::vector<int> make_groups(const std::vector<int>& ptr) {
+  std::vector<int> grp;
+  grp.push_back(0);
+  const int nseg = (int)ptr.size() - 1;
+  int cur = 0;
+  for (int r = 0; r < nseg; ++r) {
+    const int len = ptr[r + 1] - ptr[r];
+    if (cur > 0 && cur + len > 64) {
+      grp.push_back(ptr[r]);
+      cur = 0;
+    }
+    cur += len;
+    if (cur >= 64) {
+      grp.push_back(ptr[r + 1]);
+      cur = 0;
+    }
+  }
+  if (grp.back() != ptr[nseg]) grp.push_back(ptr[nseg]);
+  return grp;
+}
+
+struct HostLevel {
+  int n = 0, nslot = 0;
+  std::vector<int> rowptr, row, col;
+};
+
+// Greedy root-node aggregation (Vanek et al.) on the strength graph
+//   strong(i,j)  <=>  w_ij >= theta * sqrt(w_ii w_jj)
+int aggregate(const HostLevel& L, const std::vector<double>& w, double theta, std::vector<int>& agg) {
+  const int n = L.n;
+  agg.assign(n, -1);
+  auto strong = [&](int i, int k) {
+    const int j = L.col[k];
+    if (j == i) return false;
+    const double di = w[L.rowptr[i]], dj = w[L.rowptr[j]];
+    return w[k] >= theta * std::sqrt(di * dj) && w[k] > 0.0;
+  };
+  int nc = 0;
+  // pass 1: a node all of whose strong neighbours are free roots a new aggregate
+  for (int i = 0; i < n; ++i) {
+    if (agg[i] >= 0) continue;
+    bool any = false, ok = true;
+    for (int k = L.rowptr[i] + 1; k < L.rowptr[i + 1] && ok; ++k)
+      if (strong(i, k)) {
+        any = true;
+        if (agg[L.col[k]] >= 0) ok = false;
+      }
+    if (!any || !ok) continue;
+    agg[i] = nc;
+    for (int k = L.rowptr[i] + 1; k < L.rowptr[i + 1]; ++k)
+      if (strong(i, k)) agg[L.col[k]] = nc;
+    ++nc;
+  }
+  // pass 2: leftovers join the aggregate of their strongest aggregated strong neighbour
+  std::vector<int> agg1(agg);
+  for (int i = 0; i < n; ++i) {
+    if (agg1[i] >= 0) continue;
+    double best = -1.0;
+    int ba = -1;
+    for (int k = L.rowptr[i] + 1; k < L.rowptr[i + 1]; ++k)
+      if (strong(i, k) && agg1[L.col[k]] >= 0 && w[k] > best) {
+        best = w[k];
+        ba = agg1[L.col[k]];
+      }
+    if (ba >= 0) agg[i] = ba;
+  }
+  // pass 3: whatever is left forms aggregates with its free strong neighbours
+  for (int i = 0; i < n; ++i) {
+    if (agg[i] >= 0) continue;
+    agg[i] = nc;
+    for (int k = L.rowptr[i] + 1; k < L.rowptr[i + 1]; ++k)
+      if (strong(i, k) && agg[L.col[k]] < 0) agg[L.col[k]] = nc;
+    ++nc;
+  }
+  return nc;
+}
+
+}  // namespace
+
+// one level of the hierarchy on the device
+struct AmgLevel {
+  BsrDev A;                 // operator of this level (level 0 aliases the context's matrix)
+  int spmv_grid = 0;
+  // transfer to the next level (absent on the coarsest)
+  int nc = 0;
+  int* agg = nullptr;
+  int* mem_ptr = nullptr;
+  int* mem = nullptr;
+  double* pos = nullptr;    // [n][2]
+  double* d = nullptr;      // [n][2] lever arms
+  GalerkinMap gal;
+  // work vectors [n][3]
+  double *xs = nullptr, *rs = nullptr;                     // smoother state of cycle()
+  double *bk = nullptr, *xk = nullptr, *z1 = nullptr, *z2 = nullptr, *q = nullptr;  // K-cycle FCG (levels >= 1)
+  double *pA = nullptr, *pB = nullptr, *pC = nullptr;      // [2][kMaxPartials] each
+};
+
+struct Amg {
+  AmgConfig cfg;
+  AmgProf prof;
+  std::vector<void*> pool;
+  std::vector<AmgLevel> lv;
+  const double* d_poses = nullptr;
+  const int* d_free_id = nullptr;
+  // coarsest dense inverse
+  int N = 0;
+  double* inv = nullptr;
+  int* d_fail = nullptr;
+  std::string desc;
+};
+
+namespace {
+
+struct Scope {
+  const AmgProf& p;
+  Scope(const AmgProf& p_, int kid, double bytes) : p(p_) {
+    if (p.begin) p.begin(p.user, kid, bytes);
+  }
+  ~Scope() {
+    if (p.end) p.end(p.user);
+  }
+};
+
+double bytes_spmv(const BsrDev& A) { return 80.0 * A.nslot + 48.0 * A.n; }
+
+// z = cycle(l, rhs): pre-smooth from zero + residual (fused), restrict, coarse solve (dense or
+// two FCG steps), prolong, post-smooth.  Optional partials of dotvec . out.  Returns grid of the
+// last kernel.
+int cycle(Amg* m, hipStream_t s, int l, const double* rhs, double* out, const double* dotvec, double* dotparts,
+          const PcgScalars* S, const double* dotvec2 = nullptr);
+
+// two flexible-CG steps on level l for A xk = bk (bk is overwritten by the residual)
+void fcg(Amg* m, hipStream_t s, int l, const PcgScalars* S) {
+  AmgLevel& L = m->lv[l];
+  const int n3 = 3 * L.A.n;
+  const int vgrid = grid_for(n3, kBlock);
+  cycle(m, s, l, L.bk, L.z1, nullptr, nullptr, S);
+  int gA;
+  {
+    SpmvArgs a{};
+    a.x = L.z1; a.y = L.q; a.dotA = L.z1; a.dotB = L.z1; a.dotC = L.bk; a.partials = L.pA; a.S = S;
+    Scope sc(m->prof, K_AMG_COARSE, bytes_spmv(L.A));
+    gA = launch_spmv_ex(s, L.A, SPMV_AX, a);
+  }
+  {
+    Scope sc(m->prof, K_AMG_MISC, 5 * 8.0 * n3);
+    hipLaunchKernelGGL(k_fcg, dim3(vgrid), dim3(kBlock), 0, s, 0, n3, L.pA, gA, L.pA + kMaxPartials, gA, L.z1, L.q,
+                       L.xk, L.bk, S);
+  }
+  const int gC = cycle(m, s, l, L.bk, L.z2, L.q, L.pC, S);
+  {
+    Scope sc(m->prof, K_AMG_MISC, 3 * 8.0 * n3);
+    hipLaunchKernelGGL(k_fcg, dim3(vgrid), dim3(kBlock), 0, s, 1, n3, L.pA, gA, L.pC, gC, L.z1, (const double*)nullptr,
+                       L.z2, (double*)nullptr, S);
+  }
+  int gB;
+  {
+    SpmvArgs a{};
+    a.x = L.z2; a.y = L.q; a.dotA = L.z2; a.dotB = L.z2; a.dotC = L.bk; a.partials = L.pB; a.S = S;
+    Scope sc(m->prof, K_AMG_COARSE, bytes_spmv(L.A));
+    gB = launch_spmv_ex(s, L.A, SPMV_AX, a);
+  }
+  {
+    Scope sc(m->prof, K_AMG_MISC, 3 * 8.0 * n3);
+    hipLaunchKernelGGL(k_fcg, dim3(vgrid), dim3(kBlock), 0, s, 2, n3, L.pB, gB, L.pB + kMaxPartials, gB, L.z2,
+                       (const double*)nullptr, L.xk, (double*)nullptr, S);
+  }
+}
+
+int cycle(Amg* m, hipStream_t s, int l, const double* rhs, double* out, const double* dotvec, double* dotparts,
+          const PcgScalars* S, const double* dotvec2) {
+  AmgLevel& L = m->lv[l];
+  AmgLevel& C = m->lv[l + 1];
+  const int last = (int)m->lv.size() - 1;
+  {
+    SpmvArgs a{};
+    a.b = rhs; a.y = L.rs; a.y2 = L.xs; a.omega = m->cfg.omega; a.S = S;
+    Scope sc(m->prof, l == 0 ? K_AMG_RESIDUAL : K_AMG_COARSE, bytes_spmv(L.A) + 72.0 * L.A.nslot);
+    launch_spmv_ex(s, L.A, SPMV_PRE_RESID, a);
+  }
+  {
+    Scope sc(m->prof, K_AMG_RESTRICT, 40.0 * L.A.n + 24.0 * L.nc);
+    hipLaunchKernelGGL(k_restrict, dim3(grid_for(L.nc, kBlock)), dim3(kBlock), 0, s, L.nc, L.mem_ptr, L.mem, L.d, L.rs,
+                       C.bk, S);
+  }
+  if (l + 1 == last) {
+    Scope sc(m->prof, K_AMG_COARSE, 8.0 * m->N * m->N);
+    hipLaunchKernelGGL(k_dense_apply, dim3(1), dim3(kDenseThreads), sizeof(double) * m->N, s, m->N, m->inv, C.bk, C.xk, S);
+  } else {
+    fcg(m, s, l + 1, S);
+  }
+  {
+    Scope sc(m->prof, K_AMG_PROLONG, 68.0 * L.A.n);
+    hipLaunchKernelGGL(k_prolong_add, dim3(grid_for(L.A.n, kBlock)), dim3(kBlock), 0, s, L.A.n, L.agg, L.d, C.xk, L.xs, S);
+  }
+  SpmvArgs a{};
+  a.x = L.xs; a.b = rhs; a.y = out; a.omega = m->cfg.omega; a.S = S;
+  if (dotvec) {
+    a.dotA = dotvec;
+    a.dotA2 = dotvec2;
+    a.partials = dotparts;
+  }
+  Scope sc(m->prof, l == 0 ? K_AMG_SMOOTH : K_AMG_COARSE, bytes_spmv(L.A) + 72.0 * L.A.n);
+  return launch_spmv_ex(s, L.A, SPMV_JACOBI, a);
+}
+
+}  // namespace
+
+int amg_num_levels(const Amg* m) { return m ? (int)m->lv.size() : 0; }
+void amg_describe(const Amg* m, std::string* out) { *out = m ? m->desc : ""; }
+
+void amg_destroy(Amg* m) {
+  if (!m) return;
+  for (void* p : m->pool) hipFree(p);
+  delete m;
+}
+
+int amg_update(Amg* m, hipStream_t s, std::string* err) {
+  const int last = (int)m->lv.size() - 1;
+  {
+    AmgLevel& L0 = m->lv[0];
+    Scope sc(m->prof, K_AMG_MISC, 40.0 * L0.A.n);
+    hipLaunchKernelGGL(k_positions0, dim3(grid_for(L0.A.n, kBlock)), dim3(kBlock), 0, s, L0.A.n, m->d_free_id, m->d_poses,
+                       L0.pos);
+  }
+  for (int l = 0; l < last; ++l) {
+    AmgLevel& L = m->lv[l];
+    AmgLevel& C = m->lv[l + 1];
+    {
+      Scope sc(m->prof, K_AMG_MISC, 36.0 * L.A.n);
+      hipLaunchKernelGGL(k_centres, dim3(grid_for(L.nc, kBlock)), dim3(kBlock), 0, s, L.nc, L.mem_ptr, L.mem, L.pos, C.pos, L.d);
+    }
+    {
+      Scope sc(m->prof, K_AMG_GALERKIN, (72.0 + 16.0 + 32.0) * L.A.nslot + 72.0 * C.A.nslot);
+      hipLaunchKernelGGL(k_galerkin, dim3(grid_for(L.gal.ngrp, kWavesPerBlock)), dim3(kBlock), 0, s, L.A, C.A, L.gal, L.d);
+    }
+    {
+      Scope sc(m->prof, K_AMG_MISC, 120.0 * C.A.n);
+      hipLaunchKernelGGL(k_level_dinv, dim3(grid_for(C.A.n, kBlock)), dim3(kBlock), 0, s, C.A);
+    }
+  }
+  {
+    Scope sc(m->prof, K_AMG_MISC, 8.0 * m->N * m->N);
+    hipLaunchKernelGGL(k_dense_invert, dim3(1), dim3(kDenseThreads), sizeof(double) * 2 * m->N, s, m->lv[last].A, m->inv, m->d_fail);
+  }
+  if (hipGetLastError() != hipSuccess) {
+    if (err) *err = "amg_update: kernel launch failed";
+    return SGO_EHIP;
+  }
+  return SGO_OK;
+}
+
+int amg_apply(Amg* m, hipStream_t s, const double* r, double* z, const double* dotvec, double* partials,
+              const PcgScalars* S, const double* dotvec2) {
+  return cycle(m, s, 0, r, z, dotvec, partials, S, dotvec2);
+}
+
+Amg* amg_create(hipStream_t s, const BsrDev& A0, const double* d_poses, const int* d_free_id, const AmgConfig& cfg_in,
+                const AmgProf& prof, std::string* err) {
+  Amg* m = new Amg();
+  m->cfg = cfg_in;
+  if (const char* e = std::getenv("SGO_AMG_THETA")) m->cfg.theta = std::atof(e);
+  if (const char* e = std::getenv("SGO_AMG_OMEGA")) m->cfg.omega = std::atof(e);
+  m->prof = prof;
+  m->d_poses = d_poses;
+  m->d_free_id = d_free_id;
+  auto fail = [&](const std::string& msg) -> Amg* {
+    if (err) *err = msg;
+    amg_destroy(m);
+    return nullptr;
+  };
+
+  // level 0 structure to the host
+  HostLevel H;
+  H.n = A0.n;
+  H.nslot = A0.nslot;
+  H.rowptr.resize(H.n + 1);
+  H.row.resize(H.nslot);
+  H.col.resize(H.nslot);
+  hipMemcpyAsync(H.rowptr.data(), A0.rowptr, sizeof(int) * (H.n + 1), hipMemcpyDeviceToHost, s);
+  hipMemcpyAsync(H.row.data(), A0.row, sizeof(int) * H.nslot, hipMemcpyDeviceToHost, s);
+  hipMemcpyAsync(H.col.data(), A0.col, sizeof(int) * H.nslot, hipMemcpyDeviceToHost, s);
+  if (hipStreamSynchronize(s) != hipSuccess) return fail("amg_create: copy of the level-0 structure failed");
+
+  AmgLevel L0;
+  L0.A = A0;
+  m->lv.push_back(L0);
+  char line[160];
+  for (int l = 0;; ++l) {
+    AmgLevel& L = m->lv[l];
+    const int n = L.A.n, n3 = 3 * n;
+    L.spmv_grid = grid_for(L.A.ngrp, kWavesPerBlock);
+    std::snprintf(line, sizeof line, "L%d n=%d slots=%d; ", l, n, L.A.nslot);
+    m->desc += line;
+    L.xs = dev_alloc<double>(m->pool, n3);
+    L.rs = dev_alloc<double>(m->pool, n3);
+    if (!L.pos) L.pos = dev_alloc<double>(m->pool, 2 * (size_t)n);
+    if (l > 0) {
+      L.bk = dev_alloc<double>(m->pool, n3);
+      L.xk = dev_alloc<double>(m->pool, n3);
+      L.z1 = dev_alloc<double>(m->pool, n3);
+      L.z2 = dev_alloc<double>(m->pool, n3);
+      L.q = dev_alloc<double>(m->pool, n3);
+      L.pA = dev_alloc<double>(m->pool, 2 * (size_t)kMaxPartials);
+      L.pB = dev_alloc<double>(m->pool, 2 * (size_t)kMaxPartials);
+      L.pC = dev_alloc<double>(m->pool, 2 * (size_t)kMaxPartials);
+      if (!L.pC) return fail("amg_create: out of device memory");
+      hipMemsetAsync(L.pA, 0, sizeof(double) * 2 * kMaxPartials, s);
+      hipMemsetAsync(L.pB, 0, sizeof(double) * 2 * kMaxPartials, s);
+      hipMemsetAsync(L.pC, 0, sizeof(double) * 2 * kMaxPartials, s);
+    }
+    if (!L.xs || !L.rs || !L.pos) return fail("amg_create: out of device memory");
+    if (n <= m->cfg.coarsest_nodes || l + 1 >= m->cfg.max_levels) break;
+
+    // strength of connection from the current values of this level
+    std::vector<double> w(H.nslot);
+    {
+      double* d_w = dev_alloc<double>(m->pool, H.nslot);
+      if (!d_w) return fail("amg_create: out of device memory");
+      hipLaunchKernelGGL(k_block_norms, dim3(grid_for(H.nslot, kBlock)), dim3(kBlock), 0, s, L.A, d_w);
+      hipMemcpyAsync(w.data(), d_w, sizeof(double) * H.nslot, hipMemcpyDeviceToHost, s);
+      if (hipStreamSynchronize(s) != hipSuccess) return fail("amg_create: strength kernel failed");
+    }
+    std::vector<int> agg;
+    int nc = aggregate(H, w, m->cfg.theta, agg);
+    if (nc > 0.9 * n) nc = aggregate(H, w, 0.0, agg);  // stalled: treat every connection as strong
+    if (nc > 0.9 * n || nc < 1) break;                   // cannot coarsen further
+
+    // members by aggregate
+    std::vector<int> mem_ptr(nc + 1, 0), mem(n);
+    for (int i = 0; i < n; ++i) mem_ptr[agg[i] + 1]++;
+    for (int a = 0; a < nc; ++a) mem_ptr[a + 1] += mem_ptr[a];
+    {
+      std::vector<int> fill(mem_ptr.begin(), mem_ptr.end() - 1);
+      for (int i = 0; i < n; ++i) mem[fill[agg[i]]++] = i;
+    }
+    // coarse slots: unique (agg[row], agg[col]); diagonal first in each row
+    const int ns = H.nslot;
+    std::vector<uint64_t> key(ns);
+    for (int k = 0; k < ns; ++k) {
+      const uint64_t cr = (uint64_t)agg[H.row[k]], cc = (uint64_t)agg[H.col[k]];
+      const uint64_t ccs = (cc == cr) ? 0 : cc + 1;  // diagonal sorts first
+      key[k] = (cr << 32) | ccs;
+    }
+    std::vector<int> order(ns);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return key[a] < key[b]; });
+    HostLevel Hc;
+    Hc.n = nc;
+    std::vector<int> tgt(ns), cptr;  // contribution -> coarse slot; coarse slot -> contribution range
+    {
+      uint64_t prev = ~0ull;
+      int cs = -1;
+      for (int t = 0; t < ns; ++t) {
+        const uint64_t kk = key[order[t]];
+        if (kk != prev) {
+          ++cs;
+          prev = kk;
+          cptr.push_back(t);
+          const int cr = (int)(kk >> 32);
+          const uint64_t ccs = kk & 0xffffffffull;
+          Hc.row.push_back(cr);
+          Hc.col.push_back(ccs == 0 ? cr : (int)(ccs - 1));
+        }
+        tgt[t] = cs;
+      }
+      cptr.push_back(ns);
+    }
+    Hc.nslot = (int)Hc.row.size();
+    Hc.rowptr.assign(nc + 1, 0);
+    for (int k = 0; k < Hc.nslot; ++k) Hc.rowptr[Hc.row[k] + 1]++;
+    for (int a = 0; a < nc; ++a) Hc.rowptr[a + 1] += Hc.rowptr[a];
+    for (int a = 0; a < nc; ++a)
+      if (Hc.col[Hc.rowptr[a]] != a) return fail("amg_create: internal error (coarse diagonal slot missing)");
+    std::vector<int> grp_c = make_groups(Hc.rowptr);
+    std::vector<int> grp_g = make_groups(cptr);
+
+    // upload transfer data of level l and the structure of level l+1
+    L.nc = nc;
+    L.agg = dev_upload(m->pool, agg, s);
+    L.mem_ptr = dev_upload(m->pool, mem_ptr, s);
+    L.mem = dev_upload(m->pool, mem, s);
+    L.d = dev_alloc<double>(m->pool, 2 * (size_t)n);
+    L.gal.n = ns;
+    L.gal.src = dev_upload(m->pool, order, s);
+    L.gal.tgt = dev_upload(m->pool, tgt, s);
+    L.gal.grp = dev_upload(m->pool, grp_g, s);
+    L.gal.ngrp = (int)grp_g.size() - 1;
+    AmgLevel C;
+    C.A.n = nc;
+    C.A.nslot = Hc.nslot;
+    C.A.ngrp = (int)grp_c.size() - 1;
+    C.A.row = dev_upload(m->pool, Hc.row, s);
+    C.A.col = dev_upload(m->pool, Hc.col, s);
+    C.A.grp = dev_upload(m->pool, grp_c, s);
+    C.A.rowptr = dev_upload(m->pool, Hc.rowptr, s);
+    C.A.blk = dev_alloc<double>(m->pool, 9 * (size_t)Hc.nslot);
+    C.A.dinv = dev_alloc<double>(m->pool, 6 * (size_t)nc);
+    if (!L.agg || !L.mem_ptr || !L.mem || !L.d || !L.gal.src || !L.gal.tgt || !L.gal.grp || !C.A.row || !C.A.col ||
+        !C.A.grp || !C.A.rowptr || !C.A.blk || !C.A.dinv)
+      return fail("amg_create: out of device memory");
+    if (hipStreamSynchronize(s) != hipSuccess) return fail("amg_create: upload failed");  // host vectors die below
+    m->lv.push_back(C);  // invalidates L
+    // values of level l+1 (needed for the next level's strengths): positions, centres, Galerkin
+    {
+      AmgLevel& Lr = m->lv[l];
+      AmgLevel& Cr = m->lv[l + 1];
+      Cr.pos = dev_alloc<double>(m->pool, 2 * (size_t)nc);
+      if (!Cr.pos) return fail("amg_create: out of device memory");
+      if (l == 0)
+        hipLaunchKernelGGL(k_positions0, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, s, n, d_free_id, d_poses, Lr.pos);
+      hipLaunchKernelGGL(k_centres, dim3(grid_for(nc, kBlock)), dim3(kBlock), 0, s, nc, Lr.mem_ptr, Lr.mem, Lr.pos, Cr.pos, Lr.d);
+      hipLaunchKernelGGL(k_galerkin, dim3(grid_for(Lr.gal.ngrp, kWavesPerBlock)), dim3(kBlock), 0, s, Lr.A, Cr.A, Lr.gal, Lr.d);
+      if (hipStreamSynchronize(s) != hipSuccess) return fail("amg_create: Galerkin kernel failed");
+    }
+    H = std::move(Hc);
+  }
+  const int last = (int)m->lv.size() - 1;
+  if (last == 0) return fail("amg_create: graph too small or not coarsenable; use the block-Jacobi solver");
+  m->N = 3 * m->lv[last].A.n;
+  if (m->N > 1536) return fail("amg_create: coarsest level too large (" + std::to_string(m->N) + " unknowns)");
+  if (sizeof(double) * 2 * m->N > 64 * 1024) return fail("amg_create: coarsest level exceeds the LDS staging buffer");
+  m->inv = dev_alloc<double>(m->pool, (size_t)m->N * m->N);
+  m->d_fail = dev_alloc<int>(m->pool, 1);
+  if (!m->inv || !m->d_fail) return fail("amg_create: out of device memory");
+  hipMemsetAsync(m->d_fail, 0, sizeof(int), s);
+  std::snprintf(line, sizeof line, "coarsest dense N=%d; theta=%.3g omega=%.2f", m->N, m->cfg.theta, m->cfg.omega);
+  m->desc += line;
+  return m;
+}
+
+}  // namespace sgo

@@ -15,6 +15,7 @@
 #include <string>
 #include <vector>
 
+#include "sgo_amg.h"
 #include "sgo_comm.h"
 #include "sgo_internal.h"
 
@@ -69,6 +70,10 @@ struct sgo_ctx {
   double* h_hist = nullptr;       // pinned
   bool linearized = false;
 
+  Amg* amg = nullptr;             // non-null when the AMG preconditioner is active
+  double* d_zparts = nullptr;     // [2][kMaxPartials] partials of r.z from the cycle's last kernel
+  std::string solver_desc;
+
   hipGraphExec_t pcg_exec = nullptr;
   int pcg_exec_chunk = 0;
 
@@ -79,8 +84,7 @@ struct sgo_ctx {
   double prof_ms[K_COUNT] = {0};
   int64_t prof_launches[K_COUNT] = {0};
   double prof_bytes[K_COUNT] = {0};
-  int cur_kid = -1;
-  hipEvent_t cur_a = nullptr;
+  void* amg_scope = nullptr;  // Scope* of the AMG launch being bracketed
 };
 
 namespace {
@@ -120,6 +124,10 @@ void free_graph(sgo_ctx* c) {
   if (c->pcg_exec) {
     hipGraphExecDestroy(c->pcg_exec);
     c->pcg_exec = nullptr;
+  }
+  if (c->amg) {
+    amg_destroy(c->amg);
+    c->amg = nullptr;
   }
   for (void* p : c->allocs) hipFree(p);
   c->allocs.clear();
@@ -323,6 +331,7 @@ int build_structure(sgo_ctx* c, int V, const double* poses, const uint8_t* fixed
   if ((rc = dalloc(c, &c->d_s2, n3))) return rc;
   if ((rc = dalloc(c, &c->d_e2, (size_t)E))) return rc;
   if ((rc = dalloc(c, &c->d_partials, 3 * (size_t)kMaxPartials))) return rc;
+  if ((rc = dalloc(c, &c->d_zparts, 2 * (size_t)kMaxPartials))) return rc;
   if ((rc = dalloc(c, &c->d_hist, 2 * (size_t)(SGO_MAX_ITERS + 2)))) return rc;
   if ((rc = dalloc(c, &c->d_S, 1))) return rc;
   HIP_TRY(c, hipMemsetAsync(c->d_partials, 0, sizeof(double) * 3 * kMaxPartials, c->stream));
@@ -346,6 +355,25 @@ int do_chi2(sgo_ctx* c, double* d_out2, double* d_e2) {
   return SGO_OK;
 }
 
+// PCG start state after k_finalize (x = 0, r = b, z = Dinv b, p = z; partials rz / bb with `grid`
+// entries).  With the AMG preconditioner: refresh the coarse operators, z = M^-1 b, p = z.
+int start_pcg(sgo_ctx* c, int grid) {
+  if (c->amg) {
+    int rc = amg_update(c->amg, c->stream, &c->err);
+    if (rc) return rc;
+    const int gz = amg_apply(c->amg, c->stream, c->d_r, c->d_z, c->d_r, c->d_zparts, nullptr);
+    HIP_TRY(c, hipMemcpyAsync(c->d_p, c->d_z, sizeof(double) * 3 * (size_t)c->n, hipMemcpyDeviceToDevice, c->stream));
+    Scope sc(c, K_REDUCE, 8.0 * (gz + grid));
+    launch_init_scalars(c->stream, c->d_S, c->d_zparts, gz, c->d_partials + kMaxPartials, grid, c->opts.pcg_tol,
+                        c->opts.pcg_maxit);
+  } else {
+    Scope sc(c, K_REDUCE, 16.0 * grid);
+    launch_init_scalars(c->stream, c->d_S, c->d_partials, grid, c->d_partials + kMaxPartials, grid, c->opts.pcg_tol,
+                        c->opts.pcg_maxit);
+  }
+  return SGO_OK;
+}
+
 // buildSystem + preconditioner + PCG start state
 int do_linearize(sgo_ctx* c) {
   {
@@ -359,10 +387,8 @@ int do_linearize(sgo_ctx* c) {
     launch_finalize(c->stream, c->A, c->d_dgb, c->comm.rank == 0 ? 1 : 0, c->d_b, c->d_x, c->d_r, c->d_z, c->d_p,
                     c->d_partials, &grid);
   }
-  {
-    Scope sc(c, K_REDUCE, 16.0 * grid);
-    launch_init_scalars(c->stream, c->d_S, c->d_partials, grid, c->opts.pcg_tol, c->opts.pcg_maxit);
-  }
+  int rc = start_pcg(c, grid);
+  if (rc) return rc;
   c->linearized = true;
   return SGO_OK;
 }
@@ -391,14 +417,20 @@ int pcg_iteration(sgo_ctx* c) {
     Scope sc(c, K_ALPHA, 8.0 * g1);
     launch_alpha(c->stream, c->d_S, c->d_partials, g1);
   }
+  double* parts2 = c->d_partials + kMaxPartials;  // [0] = r.z (block-Jacobi only), [1] = r.r
   {
     Scope sc(c, K_UPDATE_XR, (7 * 24.0 + 48.0) * c->n);
-    launch_update_xr(c->stream, c->n, c->d_S, c->A.dinv, c->d_p, c->d_q, c->d_x, c->d_r, c->d_z,
-                     c->d_partials + kMaxPartials, &g2);
+    launch_update_xr(c->stream, c->n, c->d_S, c->amg ? nullptr : c->A.dinv, c->d_p, c->d_q, c->d_x, c->d_r, c->d_z,
+                     parts2, &g2);
   }
-  {
+  if (c->amg) {
+    // the K-cycle is a (mildly) variable preconditioner: flexible beta from z.q
+    const int gz = amg_apply(c->amg, c->stream, c->d_r, c->d_z, c->d_r, c->d_zparts, c->d_S, c->d_q);
+    Scope sc(c, K_BETA, 8.0 * (2 * gz + g2));
+    launch_beta(c->stream, c->d_S, c->d_zparts, gz, parts2 + kMaxPartials, g2, c->d_zparts + kMaxPartials);
+  } else {
     Scope sc(c, K_BETA, 16.0 * g2);
-    launch_beta(c->stream, c->d_S, c->d_partials + kMaxPartials, g2);
+    launch_beta(c->stream, c->d_S, parts2, g2, parts2 + kMaxPartials, g2);
   }
   {
     Scope sc(c, K_UPDATE_P, 3 * 24.0 * c->n);
@@ -585,6 +617,37 @@ int sgo_set_graph_se2(sgo_ctx* c, int32_t V, const double* poses, const uint8_t*
     return rc;
   }
   c->has_graph = true;
+  c->solver_desc = "pcg_block_jacobi";
+  if (c->opts.solver == SGO_SOLVER_PCG_AMG && c->comm.nranks == 1 && c->n > 64) {
+    // the hierarchy is built from the Hessian at the initial poses (strength of connection)
+    if ((rc = do_linearize(c)) != SGO_OK) {
+      free_graph(c);
+      return rc;
+    }
+    AmgConfig cfg;
+    AmgProf prof;
+    prof.user = c;
+    prof.begin = [](void* u, int kid, double bytes) {
+      sgo_ctx* cc = (sgo_ctx*)u;
+      cc->amg_scope = new Scope(cc, kid, bytes);
+    };
+    prof.end = [](void* u) {
+      sgo_ctx* cc = (sgo_ctx*)u;
+      delete (Scope*)cc->amg_scope;
+      cc->amg_scope = nullptr;
+    };
+    std::string aerr;
+    c->amg = amg_create(c->stream, c->A, c->d_poses, c->d_free_id, cfg, prof, &aerr);
+    if (c->amg) {
+      amg_describe(c->amg, &c->solver_desc);
+      c->solver_desc = "pcg_amg: " + c->solver_desc;
+    } else {
+      c->solver_desc = "pcg_block_jacobi (AMG unavailable: " + aerr + ")";
+      if (c->opts.verbose) std::fprintf(stderr, "[sgo] %s\n", c->solver_desc.c_str());
+    }
+    c->linearized = false;
+  }
+  if (c->opts.verbose) std::fprintf(stderr, "[sgo] solver: %s\n", c->solver_desc.c_str());
   c->setup_seconds = wall_s() - t0;
   return SGO_OK;
 }
@@ -697,7 +760,8 @@ int sgo_precondition(sgo_ctx* c, const double* r, double* z) {
   }
   const size_t bytes = sizeof(double) * 3 * (size_t)c->n;
   HIP_TRY(c, hipMemcpyAsync(c->d_s1, r, bytes, hipMemcpyHostToDevice, c->stream));
-  launch_precond_bj(c->stream, c->n, c->A.dinv, c->d_s1, c->d_s2);
+  if (c->amg) amg_apply(c->amg, c->stream, c->d_s1, c->d_s2, nullptr, nullptr, nullptr);
+  else launch_precond_bj(c->stream, c->n, c->A.dinv, c->d_s1, c->d_s2);
   HIP_TRY(c, hipMemcpyAsync(z, c->d_s2, bytes, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   return SGO_OK;
@@ -714,7 +778,7 @@ int sgo_solve(sgo_ctx* c, double* x, double* relres) {
   int grid = 0;
   launch_finalize(c->stream, c->A, c->d_dgb, c->comm.rank == 0 ? 1 : 0, c->d_b, c->d_x, c->d_r, c->d_z, c->d_p,
                   c->d_partials, &grid);
-  launch_init_scalars(c->stream, c->d_S, c->d_partials, grid, c->opts.pcg_tol, c->opts.pcg_maxit);
+  if ((rc = start_pcg(c, grid))) return rc;
   if ((rc = run_pcg(c))) return rc;
   if (x) {
     HIP_TRY(c, hipMemcpyAsync(x, c->d_x, sizeof(double) * 3 * (size_t)c->n, hipMemcpyDeviceToHost, c->stream));

@@ -1,0 +1,97 @@
+// sgo_device.h -- device-side helpers shared by the HIP translation units (wave64 reductions,
+// the wavefront segmented scan, the XCD-aware group walk).
+#pragma once
+#include "sgo_internal.h"
+
+namespace sgo {
+namespace {
+
+constexpr double kPi = 3.14159265358979323846;
+
+// g2o::normalize_theta, branch structure kept literal (result in [-pi, pi)).
+__device__ __forceinline__ double norm_theta(double t) {
+  if (t >= -kPi && t < kPi) return t;
+  double m = floor(t / (2 * kPi));
+  t = t - m * 2 * kPi;
+  if (t >= kPi) t -= 2 * kPi;
+  if (t < -kPi) t += 2 * kPi;
+  return t;
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+  return v;  // lane 0
+}
+
+// Block-wide sums of N values; thread 0 stores them to out[i * stride + blockIdx.x].
+template <int N>
+__device__ __forceinline__ void block_sum_store(double (&v)[N], double* out, int stride) {
+  __shared__ double sm[N][kWavesPerBlock];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    double s = wave_sum(v[i]);
+    if (lane == 0) sm[i][w] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      double s = sm[i][0];
+#pragma unroll
+      for (int k = 1; k < kWavesPerBlock; ++k) s += sm[i][k];
+      out[(size_t)i * stride + blockIdx.x] = s;
+    }
+  }
+}
+
+// Deterministic sum of nparts partials by one block (fixed order), result in every thread.
+__device__ __forceinline__ double block_reduce_parts(const double* parts, int nparts) {
+  __shared__ double sm2[kWavesPerBlock];
+  __shared__ double res;
+  double s = 0.0;
+  for (int i = threadIdx.x; i < nparts; i += kBlock) s += parts[i];
+  s = wave_sum(s);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sm2[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = sm2[0];
+#pragma unroll
+    for (int k = 1; k < kWavesPerBlock; ++k) t += sm2[k];
+    res = t;
+  }
+  __syncthreads();
+  return res;
+}
+
+// Inclusive segmented scan over the wave: lanes with equal `row` that are contiguous form a
+// segment; after the scan the LAST lane of a segment holds the segment sum.
+template <int N>
+__device__ __forceinline__ void seg_scan(int row, double (&v)[N], int lane) {
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int r2 = __shfl_up(row, off);
+    const bool take = (lane >= off) && (r2 == row);
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const double u = __shfl_up(v[i], off);
+      if (take) v[i] += u;
+    }
+  }
+}
+
+// Map (block, wave) -> first group and stride so that XCD x (blocks with blockIdx % 8 == x under
+// the observed round-robin dispatch; speed only, never correctness) walks the contiguous band
+// [x * ngrp / 8, (x + 1) * ngrp / 8) of groups.
+__device__ __forceinline__ void group_walk(int ngrp, int* first, int* last, int* stride) {
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
+  const int lo = (int)(((long long)ngrp * xcd) >> 3), hi = (int)(((long long)ngrp * (xcd + 1)) >> 3);
+  *first = lo + slot * kWavesPerBlock + (threadIdx.x >> 6);
+  *last = hi;
+  *stride = per_xcd * kWavesPerBlock;
+}
+
+}  // namespace
+}  // namespace sgo

@@ -71,6 +71,22 @@ struct PcgScalars {
   int pad;
 };
 
+// k_spmv modes and arguments (see sgo_kernels.hip)
+enum : int { SPMV_AX = 0, SPMV_RESID = 1, SPMV_JACOBI = 2, SPMV_PRE_RESID = 3 };
+struct SpmvArgs {
+  const double* x = nullptr;     // gathered operand (unused by SPMV_PRE_RESID)
+  double* y = nullptr;           // output
+  const double* b = nullptr;     // right-hand side (modes != AX)
+  double* y2 = nullptr;          // SPMV_PRE_RESID: omega Dinv b
+  double omega = 0.0;
+  const double* dotA = nullptr;  // partials[0] += dotA . out
+  const double* dotA2 = nullptr; // partials[1] += dotA2 . out   (takes precedence over dotB . dotC)
+  const double* dotB = nullptr;  // partials[1] += dotB . dotC
+  const double* dotC = nullptr;
+  double* partials = nullptr;    // [2][kMaxPartials]
+  const PcgScalars* S = nullptr; // optional early-out flag
+};
+
 enum KernelId : int {
   K_CHI2 = 0,
   K_LINEARIZE,
@@ -116,14 +132,17 @@ void launch_linearize(hipStream_t s, const BsrDev& A, const EdgeSlotsDev& es, co
                       double* dgb /*[n][9]*/);
 void launch_finalize(hipStream_t s, const BsrDev& A, const double* dgb, int write_diag, double* b,
                      double* x, double* r, double* z, double* p, double* partials, int* grid_out);
-void launch_init_scalars(hipStream_t s, PcgScalars* S, const double* partials, int nparts, double tol,
-                         int maxit);
+void launch_init_scalars(hipStream_t s, PcgScalars* S, const double* rz_parts, int n_rz, const double* bb_parts,
+                         int n_bb, double tol, int maxit);
 void launch_spmv(hipStream_t s, const BsrDev& A, const double* x, double* y, double* dot_partials,
                  const PcgScalars* S, int* grid_out);
+int launch_spmv_ex(hipStream_t s, const BsrDev& A, int mode, const SpmvArgs& a);  // returns grid
 void launch_alpha(hipStream_t s, PcgScalars* S, const double* partials, int nparts);
 void launch_update_xr(hipStream_t s, int n, const PcgScalars* S, const double* dinv, const double* p,
                       const double* q, double* x, double* r, double* z, double* partials, int* grid_out);
-void launch_beta(hipStream_t s, PcgScalars* S, const double* partials, int nparts);
+// zq_parts != nullptr selects the flexible (Polak-Ribiere) beta = -alpha (z.q) / rz_old
+void launch_beta(hipStream_t s, PcgScalars* S, const double* rz_parts, int n_rz, const double* rr_parts, int n_rr,
+                 const double* zq_parts = nullptr);
 void launch_update_p(hipStream_t s, int n, const PcgScalars* S, const double* z, double* p);
 void launch_pose_update(hipStream_t s, int n, const int* free_id, const double* x, double* poses);
 void launch_dot(hipStream_t s, int n3, const double* a, const double* b, double* partials, const PcgScalars* S,

@@ -17,6 +17,7 @@
 // segment; per-row sums by a wavefront segmented scan over row-aligned slot groups (no atomics,
 // bitwise reproducible); grids capped at 2048 blocks and mapped so that each XCD walks one
 // contiguous band of rows (its L2 then holds that band's vector entries).
+#include "sgo_device.h"
 #include "sgo_internal.h"
 
 namespace sgo {
@@ -27,93 +28,6 @@ const char* const kKernelNames[K_COUNT] = {
     "k_amg_residual", "k_amg_restrict", "k_amg_prolong", "k_amg_coarse", "k_amg_misc"};
 
 namespace {
-
-constexpr double kPi = 3.14159265358979323846;
-
-// g2o::normalize_theta, branch structure kept literal (result in [-pi, pi)).
-__device__ __forceinline__ double norm_theta(double t) {
-  if (t >= -kPi && t < kPi) return t;
-  double m = floor(t / (2 * kPi));
-  t = t - m * 2 * kPi;
-  if (t >= kPi) t -= 2 * kPi;
-  if (t < -kPi) t += 2 * kPi;
-  return t;
-}
-
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
-  return v;  // lane 0
-}
-
-// Block-wide sums of N values; thread 0 stores them to out[i * stride + blockIdx.x].
-template <int N>
-__device__ __forceinline__ void block_sum_store(double (&v)[N], double* out, int stride) {
-  __shared__ double sm[N][kWavesPerBlock];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-#pragma unroll
-  for (int i = 0; i < N; ++i) {
-    double s = wave_sum(v[i]);
-    if (lane == 0) sm[i][w] = s;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-      double s = sm[i][0];
-#pragma unroll
-      for (int k = 1; k < kWavesPerBlock; ++k) s += sm[i][k];
-      out[(size_t)i * stride + blockIdx.x] = s;
-    }
-  }
-}
-
-// Deterministic sum of nparts partials by one block (fixed order), result in every thread.
-__device__ __forceinline__ double block_reduce_parts(const double* parts, int nparts) {
-  __shared__ double sm2[kWavesPerBlock];
-  __shared__ double res;
-  double s = 0.0;
-  for (int i = threadIdx.x; i < nparts; i += kBlock) s += parts[i];
-  s = wave_sum(s);
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) sm2[threadIdx.x >> 6] = s;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double t = sm2[0];
-#pragma unroll
-    for (int k = 1; k < kWavesPerBlock; ++k) t += sm2[k];
-    res = t;
-  }
-  __syncthreads();
-  return res;
-}
-
-// Inclusive segmented scan over the wave: lanes with equal `row` that are contiguous form a
-// segment; after the scan the LAST lane of a segment holds the segment sum.
-template <int N>
-__device__ __forceinline__ void seg_scan(int row, double (&v)[N], int lane) {
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const int r2 = __shfl_up(row, off);
-    const bool take = (lane >= off) && (r2 == row);
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-      const double u = __shfl_up(v[i], off);
-      if (take) v[i] += u;
-    }
-  }
-}
-
-// Map (block, wave) -> first group and stride so that XCD x (blocks with blockIdx % 8 == x under
-// the observed round-robin dispatch; speed only, never correctness) walks the contiguous band
-// [x * ngrp / 8, (x + 1) * ngrp / 8) of groups.
-__device__ __forceinline__ void group_walk(int ngrp, int* first, int* last, int* stride) {
-  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
-  const int lo = (int)(((long long)ngrp * xcd) >> 3), hi = (int)(((long long)ngrp * (xcd + 1)) >> 3);
-  *first = lo + slot * kWavesPerBlock + (threadIdx.x >> 6);
-  *last = hi;
-  *stride = per_xcd * kWavesPerBlock;
-}
 
 struct EdgeLin {
   double e[3];
@@ -334,10 +248,11 @@ __global__ __launch_bounds__(kBlock) void k_finalize(BsrDev A, const double* __r
   block_sum_store<2>(acc, partials, kMaxPartials);
 }
 
-__global__ __launch_bounds__(kBlock) void k_init_scalars(PcgScalars* S, const double* __restrict__ partials,
-                                                         int nparts, double tol, int maxit) {
-  const double rz = block_reduce_parts(partials, nparts);
-  const double bb = block_reduce_parts(partials + kMaxPartials, nparts);
+__global__ __launch_bounds__(kBlock) void k_init_scalars(PcgScalars* S, const double* __restrict__ rz_parts, int n_rz,
+                                                         const double* __restrict__ bb_parts, int n_bb, double tol,
+                                                         int maxit) {
+  const double rz = block_reduce_parts(rz_parts, n_rz);
+  const double bb = block_reduce_parts(bb_parts, n_bb);
   if (threadIdx.x == 0) {
     S->rz = rz;
     S->bb = bb;
@@ -353,13 +268,20 @@ __global__ __launch_bounds__(kBlock) void k_init_scalars(PcgScalars* S, const do
 }
 
 // ---------------------------------------------------------------------------- k_spmv
-// y = A x, one lane per slot, wavefront segmented scan per row; optional partial of x.y.
-__global__ __launch_bounds__(kBlock) void k_spmv(BsrDev A, const double* __restrict__ x, double* __restrict__ y,
-                                                 double* __restrict__ dot_partials, const PcgScalars* S) {
-  if (S && S->stop) return;
+// One lane per slot, wavefront segmented scan per row.  MODE selects the row epilogue:
+//   SPMV_AX         y = A x
+//   SPMV_RESID      y = b - A x
+//   SPMV_JACOBI     y = x + omega Dinv (b - A x)                 (damped block-Jacobi sweep)
+//   SPMV_PRE_RESID  y2 = omega Dinv b ; y = b - A y2              (first sweep from x = 0 fused
+//                   with the residual: the gathered operand is omega Dinv[col] b[col])
+// Optional dot partials (row epilogue): partials[0] += dotA[row].out[row],
+// partials[1] += dotB[row].dotC[row].
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void k_spmv(BsrDev A, SpmvArgs a) {
+  if (a.S && a.S->stop) return;
   const int lane = threadIdx.x & 63;
   const size_t ns = (size_t)A.nslot;
-  double dotacc[1] = {0.0};
+  double dotacc[2] = {0.0, 0.0};
   int g, gend, gstride;
   group_walk(A.ngrp, &g, &gend, &gstride);
   for (; g < gend; g += gstride) {
@@ -369,7 +291,16 @@ __global__ __launch_bounds__(kBlock) void k_spmv(BsrDev A, const double* __restr
     for (int k = gb + lane; k < ge; k += 64) {
       row = A.row[k];
       const int c = A.col[k];
-      const double x0 = x[3 * (size_t)c], x1 = x[3 * (size_t)c + 1], x2 = x[3 * (size_t)c + 2];
+      double x0, x1, x2;
+      if (MODE == SPMV_PRE_RESID) {
+        const double* di = A.dinv + 6 * (size_t)c;
+        const double b0 = a.b[3 * (size_t)c], b1 = a.b[3 * (size_t)c + 1], b2 = a.b[3 * (size_t)c + 2];
+        x0 = a.omega * (di[0] * b0 + di[1] * b1 + di[2] * b2);
+        x1 = a.omega * (di[1] * b0 + di[3] * b1 + di[4] * b2);
+        x2 = a.omega * (di[2] * b0 + di[4] * b1 + di[5] * b2);
+      } else {
+        x0 = a.x[3 * (size_t)c]; x1 = a.x[3 * (size_t)c + 1]; x2 = a.x[3 * (size_t)c + 2];
+      }
       acc[0] += A.blk[k] * x0 + A.blk[ns + k] * x1 + A.blk[2 * ns + k] * x2;
       acc[1] += A.blk[3 * ns + k] * x0 + A.blk[4 * ns + k] * x1 + A.blk[5 * ns + k] * x2;
       acc[2] += A.blk[6 * ns + k] * x0 + A.blk[7 * ns + k] * x1 + A.blk[8 * ns + k] * x2;
@@ -378,11 +309,32 @@ __global__ __launch_bounds__(kBlock) void k_spmv(BsrDev A, const double* __restr
     const int rn = __shfl_down(row, 1);
     if (row >= 0 && (lane == 63 || rn != row)) {
       const size_t o = 3 * (size_t)row;
-      y[o] = acc[0]; y[o + 1] = acc[1]; y[o + 2] = acc[2];
-      if (dot_partials) dotacc[0] += x[o] * acc[0] + x[o + 1] * acc[1] + x[o + 2] * acc[2];
+      double o0 = acc[0], o1 = acc[1], o2 = acc[2];
+      if (MODE != SPMV_AX) {
+        const double r0 = a.b[o] - acc[0], r1 = a.b[o + 1] - acc[1], r2 = a.b[o + 2] - acc[2];
+        if (MODE == SPMV_JACOBI) {
+          const double* di = A.dinv + 6 * (size_t)row;
+          o0 = a.x[o] + a.omega * (di[0] * r0 + di[1] * r1 + di[2] * r2);
+          o1 = a.x[o + 1] + a.omega * (di[1] * r0 + di[3] * r1 + di[4] * r2);
+          o2 = a.x[o + 2] + a.omega * (di[2] * r0 + di[4] * r1 + di[5] * r2);
+        } else {
+          o0 = r0; o1 = r1; o2 = r2;
+        }
+        if (MODE == SPMV_PRE_RESID) {
+          const double* di = A.dinv + 6 * (size_t)row;
+          const double b0 = a.b[o], b1 = a.b[o + 1], b2 = a.b[o + 2];
+          a.y2[o] = a.omega * (di[0] * b0 + di[1] * b1 + di[2] * b2);
+          a.y2[o + 1] = a.omega * (di[1] * b0 + di[3] * b1 + di[4] * b2);
+          a.y2[o + 2] = a.omega * (di[2] * b0 + di[4] * b1 + di[5] * b2);
+        }
+      }
+      a.y[o] = o0; a.y[o + 1] = o1; a.y[o + 2] = o2;
+      if (a.dotA) dotacc[0] += a.dotA[o] * o0 + a.dotA[o + 1] * o1 + a.dotA[o + 2] * o2;
+      if (a.dotA2) dotacc[1] += a.dotA2[o] * o0 + a.dotA2[o + 1] * o1 + a.dotA2[o + 2] * o2;
+      else if (a.dotB) dotacc[1] += a.dotB[o] * a.dotC[o] + a.dotB[o + 1] * a.dotC[o + 1] + a.dotB[o + 2] * a.dotC[o + 2];
     }
   }
-  if (dot_partials) block_sum_store<1>(dotacc, dot_partials, kMaxPartials);
+  if (a.partials) block_sum_store<2>(dotacc, a.partials, kMaxPartials);
 }
 
 __global__ __launch_bounds__(kBlock) void k_alpha(PcgScalars* S, const double* __restrict__ partials, int nparts) {
@@ -421,12 +373,16 @@ __global__ __launch_bounds__(kBlock) void k_update_xr(int n, const PcgScalars* S
   block_sum_store<2>(acc, partials, kMaxPartials);
 }
 
-__global__ __launch_bounds__(kBlock) void k_beta(PcgScalars* S, const double* __restrict__ partials, int nparts) {
+__global__ __launch_bounds__(kBlock) void k_beta(PcgScalars* S, const double* __restrict__ rz_parts, int n_rz,
+                                                 const double* __restrict__ rr_parts, int n_rr,
+                                                 const double* __restrict__ zq_parts) {
   if (S->stop) return;
-  const double rz = block_reduce_parts(partials, nparts);
-  const double rr = block_reduce_parts(partials + kMaxPartials, nparts);
+  const double rz = block_reduce_parts(rz_parts, n_rz);
+  const double rr = block_reduce_parts(rr_parts, n_rr);
+  // flexible CG (variable preconditioner, e.g. the K-cycle): z_new.(r_new - r_old) = -alpha z_new.q
+  const double zq = zq_parts ? block_reduce_parts(zq_parts, n_rz) : 0.0;
   if (threadIdx.x == 0) {
-    S->beta = rz / S->rz;
+    S->beta = zq_parts ? -S->alpha * zq / S->rz : rz / S->rz;
     S->rz = rz;
     S->rr = rr;
     const int it = S->iter + 1;
@@ -500,13 +456,31 @@ void launch_finalize(hipStream_t s, const BsrDev& A, const double* dgb, int writ
   hipLaunchKernelGGL(k_finalize, dim3(grid), dim3(kBlock), 0, s, A, dgb, write_diag, b, x, r, z, p, partials);
   *grid_out = grid;
 }
-void launch_init_scalars(hipStream_t s, PcgScalars* S, const double* partials, int nparts, double tol, int maxit) {
-  hipLaunchKernelGGL(k_init_scalars, dim3(1), dim3(kBlock), 0, s, S, partials, nparts, tol, maxit);
+void launch_init_scalars(hipStream_t s, PcgScalars* S, const double* rz_parts, int n_rz, const double* bb_parts,
+                         int n_bb, double tol, int maxit) {
+  hipLaunchKernelGGL(k_init_scalars, dim3(1), dim3(kBlock), 0, s, S, rz_parts, n_rz, bb_parts, n_bb, tol, maxit);
+}
+int launch_spmv_ex(hipStream_t s, const BsrDev& A, int mode, const SpmvArgs& a) {
+  const int grid = grid_for(A.ngrp, kWavesPerBlock);
+  switch (mode) {
+    case SPMV_AX: hipLaunchKernelGGL(k_spmv<SPMV_AX>, dim3(grid), dim3(kBlock), 0, s, A, a); break;
+    case SPMV_RESID: hipLaunchKernelGGL(k_spmv<SPMV_RESID>, dim3(grid), dim3(kBlock), 0, s, A, a); break;
+    case SPMV_JACOBI: hipLaunchKernelGGL(k_spmv<SPMV_JACOBI>, dim3(grid), dim3(kBlock), 0, s, A, a); break;
+    default: hipLaunchKernelGGL(k_spmv<SPMV_PRE_RESID>, dim3(grid), dim3(kBlock), 0, s, A, a); break;
+  }
+  return grid;
 }
 void launch_spmv(hipStream_t s, const BsrDev& A, const double* x, double* y, double* dot_partials,
                  const PcgScalars* S, int* grid_out) {
-  const int grid = grid_for(A.ngrp, kWavesPerBlock);
-  hipLaunchKernelGGL(k_spmv, dim3(grid), dim3(kBlock), 0, s, A, x, y, dot_partials, S);
+  SpmvArgs a{};
+  a.x = x;
+  a.y = y;
+  a.S = S;
+  if (dot_partials) {
+    a.dotA = x;
+    a.partials = dot_partials;
+  }
+  const int grid = launch_spmv_ex(s, A, SPMV_AX, a);
   if (grid_out) *grid_out = grid;
 }
 void launch_alpha(hipStream_t s, PcgScalars* S, const double* partials, int nparts) {
@@ -518,8 +492,9 @@ void launch_update_xr(hipStream_t s, int n, const PcgScalars* S, const double* d
   hipLaunchKernelGGL(k_update_xr, dim3(grid), dim3(kBlock), 0, s, n, S, dinv, p, q, x, r, z, partials);
   if (grid_out) *grid_out = grid;
 }
-void launch_beta(hipStream_t s, PcgScalars* S, const double* partials, int nparts) {
-  hipLaunchKernelGGL(k_beta, dim3(1), dim3(kBlock), 0, s, S, partials, nparts);
+void launch_beta(hipStream_t s, PcgScalars* S, const double* rz_parts, int n_rz, const double* rr_parts, int n_rr,
+                 const double* zq_parts) {
+  hipLaunchKernelGGL(k_beta, dim3(1), dim3(kBlock), 0, s, S, rz_parts, n_rz, rr_parts, n_rr, zq_parts);
 }
 void launch_update_p(hipStream_t s, int n, const PcgScalars* S, const double* z, double* p) {
   const int grid = grid_for(3LL * n, kBlock);

@@ -79,3 +79,53 @@ def test_gauss_newton_matches_direct_oracle(opt, name):
         assert abs(st["chi2"][k] - ost["chi2"][k]) <= 1e-6 * ost["chi2"][k], k
         assert abs(st["robust_chi2"][k] - ost["robust_chi2"][k]) <= 1e-6 * ost["robust_chi2"][k], k
     assert np.abs(P - oP).max() <= 1e-5
+
+
+# ------------------------------------------------------------------ AMG-preconditioned solver
+@pytest.fixture(scope="module")
+def opt_amg():
+    o = capi.Optimizer(0, solver=capi.SOLVER_PCG_AMG, pcg_tol=1e-10, pcg_maxit=5000)
+    yield o
+    o.close()
+
+
+def test_amg_preconditioner_is_positive_and_contracts(opt_amg):
+    """The K-cycle is a variable preconditioner (inner flexible CG), so <u, M v> == <M u, v> holds
+    only approximately; the outer flexible PCG needs <u, M u> > 0 and M ~ H^-1."""
+    g = synth.config("C2", info_mode="full")
+    opt_amg.set_graph(*g.arrays())
+    b, _, _, _ = opt_amg.linearize()
+    rng = np.random.default_rng(5)
+    u = rng.standard_normal((opt_amg.n_free, 3))
+    v = rng.standard_normal((opt_amg.n_free, 3))
+    Mu, Mv = opt_amg.precondition(u), opt_amg.precondition(v)
+    assert (u * Mu).sum() > 0 and (v * Mv).sum() > 0
+    assert abs((u * Mv).sum() - (Mu * v).sum()) <= 0.1 * abs((u * Mv).sum())
+    # one preconditioned step on the actual right-hand side reduces the M-norm of the residual
+    x1 = opt_amg.precondition(b)
+    r1 = b - opt_amg.hessian_apply(x1)
+    assert (r1 * opt_amg.precondition(r1)).sum() < (b * x1).sum()
+
+
+def test_amg_pcg_solves_the_normal_equations(opt_amg):
+    g = synth.config("C2", info_mode="full")
+    opt_amg.set_graph(*g.arrays())
+    b, _, _, _ = opt_amg.linearize()
+    x, it, relres = opt_amg.solve()
+    assert 0 < it < 400 and relres <= 1e-10
+    r = b - opt_amg.hessian_apply(x)
+    assert np.linalg.norm(r) <= 1e-8 * np.linalg.norm(b)
+
+
+@pytest.mark.parametrize("name", ["C1", "C2"])
+def test_amg_gauss_newton_matches_direct_oracle(opt_amg, name):
+    g = synth.config(name, info_mode="full")
+    opt_amg.set_graph(*g.arrays())
+    done, st = opt_amg.optimize(20)
+    P = opt_amg.get_poses()
+    oP, ost = _oracle().gauss_newton(*g.arrays(), iters=20, solver="direct")
+    assert done == 20 == ost["iters_done"]
+    for k in range(21):
+        assert abs(st["chi2"][k] - ost["chi2"][k]) <= 1e-6 * ost["chi2"][k], k
+        assert abs(st["robust_chi2"][k] - ost["robust_chi2"][k]) <= 1e-6 * ost["robust_chi2"][k], k
+    assert np.abs(P - oP).max() <= 1e-5
