@@ -70,7 +70,8 @@ typedef struct sgo_opts {
 } sgo_opts;
 
 /* Defaults (also applied when opts == NULL):
- * solver = PCG_AMG, pcg_tol = 1e-8, pcg_maxit = 20000, pcg_chunk = 16, use_graph = 1. */
+ * solver = PCG_AMG (falls back to PCG_BJ for graphs with <= 64 free poses and in multi-GPU
+ * mode), pcg_tol = 1e-8, pcg_maxit = 20000, pcg_chunk = 16, use_graph = 1. */
 void sgo_default_opts(sgo_opts* o);
 
 typedef struct sgo_stats {

@@ -244,13 +244,16 @@ __global__ __launch_bounds__(kDenseThreads) void k_dense_invert(BsrDev A, double
       pcol[j] = (j == k) ? 0.0 : inv[(size_t)j * N + k];
     }
     __syncthreads();
-    for (int t = threadIdx.x; t < N * N; t += kDenseThreads) {
-      const int i = t / N, j = t - i * N;
-      double v;
-      if (i == k) v = (j == k) ? p : prow[j];
-      else if (j == k) v = -pcol[i] * p;
-      else v = inv[t] - pcol[i] * prow[j];
-      inv[t] = v;
+    for (int i = threadIdx.x / 64; i < N; i += kDenseThreads / 64) {  // one wave per row
+      const double f = pcol[i];
+      double* Mi = inv + (size_t)i * N;
+      for (int j = threadIdx.x & 63; j < N; j += 64) {
+        double v;
+        if (i == k) v = (j == k) ? p : prow[j];
+        else if (j == k) v = -f * p;
+        else v = Mi[j] - f * prow[j];
+        Mi[j] = v;
+      }
     }
     __syncthreads();
   }
@@ -269,6 +272,273 @@ __global__ __launch_bounds__(kDenseThreads) void k_dense_apply(int N, const doub
     for (int j = 0; j < N; ++j) s += inv[(size_t)j * N + i] * sb[j];
     x[i] = s;
   }
+}
+
+// --------------------------------------------------------------------------------- fused coarse tree
+// Every level below `tree_start` is small (<= 2048 rows): run as separate launches, each of its
+// ~10 kernels per visit costs ~5-6 us of launch + cache write-back latency while moving a few KB,
+// and the K-cycle visits level l 2^l times.  k_coarse_tree runs the whole K-cycle recursion of
+// those levels inside ONE workgroup (16 waves): phases are separated by __syncthreads()
+// (workgroup-scope visibility is enough, all waves share the CU's L1), data stays in the CU's
+// L1 / the XCD's L2.  Same arithmetic, same order as the multi-launch path.
+constexpr int kTreeThreads = 1024;
+constexpr int kTreeWaves = kTreeThreads / 64;
+constexpr int kTreeMaxLevels = 6;
+struct TreeLevel {
+  BsrDev A;
+  int nc = 0;
+  const int* agg = nullptr;
+  const int* mem_ptr = nullptr;
+  const int* mem = nullptr;
+  const double* d = nullptr;
+  double *xs = nullptr, *rs = nullptr, *bk = nullptr, *xk = nullptr, *z1 = nullptr, *z2 = nullptr, *q = nullptr;
+};
+struct CoarseTree {
+  int nlev = 0;   // levels in the tree; the last one is the dense coarsest level
+  int N = 0;      // dense dimension
+  const double* inv = nullptr;
+  double omega = 0.0;
+  TreeLevel lv[kTreeMaxLevels];
+};
+
+// all-reduce two doubles over the workgroup (every thread gets the sums, fixed order)
+__device__ __forceinline__ void blk_allreduce2(double& a, double& b, double* sm) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  a = wave_sum(a);
+  b = wave_sum(b);
+  if (lane == 0) {
+    sm[w] = a;
+    sm[kTreeWaves + w] = b;
+  }
+  __syncthreads();
+  double sa = 0.0, sb = 0.0;
+#pragma unroll
+  for (int k = 0; k < kTreeWaves; ++k) {
+    sa += sm[k];
+    sb += sm[kTreeWaves + k];
+  }
+  __syncthreads();
+  a = sa;
+  b = sb;
+}
+
+// workgroup-wide version of k_spmv<MODE> (same row epilogues); ends with a barrier
+template <int MODE>
+__device__ __forceinline__ void blk_spmv(const BsrDev& A, const SpmvArgs& a, bool dots, double& d0, double& d1,
+                                         double* sm) {
+  const int lane = threadIdx.x & 63;
+  const size_t ns = (size_t)A.nslot;
+  double acc0 = 0.0, acc1 = 0.0;
+  for (int g = threadIdx.x >> 6; g < A.ngrp; g += kTreeWaves) {
+    const int gb = A.grp[g], ge = A.grp[g + 1];
+    double acc[3] = {0.0, 0.0, 0.0};
+    int row = -1 - lane;
+    for (int k = gb + lane; k < ge; k += 64) {
+      row = A.row[k];
+      const int c = A.col[k];
+      double x0, x1, x2;
+      if (MODE == SPMV_PRE_RESID) {
+        const double* di = A.dinv + 6 * (size_t)c;
+        const double b0 = a.b[3 * (size_t)c], b1 = a.b[3 * (size_t)c + 1], b2 = a.b[3 * (size_t)c + 2];
+        x0 = a.omega * (di[0] * b0 + di[1] * b1 + di[2] * b2);
+        x1 = a.omega * (di[1] * b0 + di[3] * b1 + di[4] * b2);
+        x2 = a.omega * (di[2] * b0 + di[4] * b1 + di[5] * b2);
+      } else {
+        x0 = a.x[3 * (size_t)c]; x1 = a.x[3 * (size_t)c + 1]; x2 = a.x[3 * (size_t)c + 2];
+      }
+      acc[0] += A.blk[k] * x0 + A.blk[ns + k] * x1 + A.blk[2 * ns + k] * x2;
+      acc[1] += A.blk[3 * ns + k] * x0 + A.blk[4 * ns + k] * x1 + A.blk[5 * ns + k] * x2;
+      acc[2] += A.blk[6 * ns + k] * x0 + A.blk[7 * ns + k] * x1 + A.blk[8 * ns + k] * x2;
+    }
+    seg_scan<3>(row, acc, lane);
+    const int rn = __shfl_down(row, 1);
+    if (row >= 0 && (lane == 63 || rn != row)) {
+      const size_t o = 3 * (size_t)row;
+      double o0 = acc[0], o1 = acc[1], o2 = acc[2];
+      if (MODE != SPMV_AX) {
+        const double r0 = a.b[o] - acc[0], r1 = a.b[o + 1] - acc[1], r2 = a.b[o + 2] - acc[2];
+        if (MODE == SPMV_JACOBI) {
+          const double* di = A.dinv + 6 * (size_t)row;
+          o0 = a.x[o] + a.omega * (di[0] * r0 + di[1] * r1 + di[2] * r2);
+          o1 = a.x[o + 1] + a.omega * (di[1] * r0 + di[3] * r1 + di[4] * r2);
+          o2 = a.x[o + 2] + a.omega * (di[2] * r0 + di[4] * r1 + di[5] * r2);
+        } else {
+          o0 = r0; o1 = r1; o2 = r2;
+        }
+        if (MODE == SPMV_PRE_RESID) {
+          const double* di = A.dinv + 6 * (size_t)row;
+          const double b0 = a.b[o], b1 = a.b[o + 1], b2 = a.b[o + 2];
+          a.y2[o] = a.omega * (di[0] * b0 + di[1] * b1 + di[2] * b2);
+          a.y2[o + 1] = a.omega * (di[1] * b0 + di[3] * b1 + di[4] * b2);
+          a.y2[o + 2] = a.omega * (di[2] * b0 + di[4] * b1 + di[5] * b2);
+        }
+      }
+      a.y[o] = o0; a.y[o + 1] = o1; a.y[o + 2] = o2;
+      if (a.dotA) acc0 += a.dotA[o] * o0 + a.dotA[o + 1] * o1 + a.dotA[o + 2] * o2;
+      if (a.dotB) acc1 += a.dotB[o] * a.dotC[o] + a.dotB[o + 1] * a.dotC[o + 1] + a.dotB[o + 2] * a.dotC[o + 2];
+    }
+  }
+  if (dots) {
+    blk_allreduce2(acc0, acc1, sm);
+    d0 = acc0;
+    d1 = acc1;
+  } else {
+    __syncthreads();
+  }
+}
+
+__device__ __forceinline__ void blk_dense_apply(int N, const double* __restrict__ inv, const double* __restrict__ b,
+                                                double* __restrict__ x, double* sb) {
+  for (int j = threadIdx.x; j < N; j += kTreeThreads) sb[j] = b[j];
+  __syncthreads();
+  const int s = threadIdx.x & 3;
+  for (int base = 0; base < N; base += kTreeThreads / 4) {
+    const int i = base + (threadIdx.x >> 2);
+    double acc = 0.0;
+    if (i < N)
+      for (int j = s; j < N; j += 4) acc += inv[(size_t)j * N + i] * sb[j];
+    acc += __shfl_xor(acc, 1);
+    acc += __shfl_xor(acc, 2);
+    if (i < N && s == 0) x[i] = acc;
+  }
+  __syncthreads();
+}
+
+template <int L>
+__device__ void tree_fcg(const CoarseTree& T, double* sm, double* sb);
+
+// out = cycle(level L of the tree, rhs); dot = dotvec . out when dotvec != nullptr
+template <int L>
+__device__ void tree_cycle(const CoarseTree& T, const double* rhs, double* out, const double* dotvec, double& dot,
+                           double* sm, double* sb) {
+  if constexpr (L + 1 < kTreeMaxLevels) {
+    const TreeLevel& X = T.lv[L];
+    const TreeLevel& C = T.lv[L + 1];
+    double u0, u1;
+    {
+      SpmvArgs a{};
+      a.b = rhs; a.y = X.rs; a.y2 = X.xs; a.omega = T.omega;
+      blk_spmv<SPMV_PRE_RESID>(X.A, a, false, u0, u1, sm);
+    }
+    for (int ag = threadIdx.x; ag < X.nc; ag += kTreeThreads) {
+      const int lo = X.mem_ptr[ag], hi = X.mem_ptr[ag + 1];
+      double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+      for (int t = lo; t < hi; ++t) {
+        const int i = X.mem[t];
+        const double r0 = X.rs[3 * (size_t)i], r1 = X.rs[3 * (size_t)i + 1], r2 = X.rs[3 * (size_t)i + 2];
+        s0 += r0;
+        s1 += r1;
+        s2 += -X.d[2 * (size_t)i + 1] * r0 + X.d[2 * (size_t)i] * r1 + r2;
+      }
+      C.bk[3 * (size_t)ag] = s0;
+      C.bk[3 * (size_t)ag + 1] = s1;
+      C.bk[3 * (size_t)ag + 2] = s2;
+    }
+    __syncthreads();
+    if (L + 1 == T.nlev - 1) blk_dense_apply(T.N, T.inv, C.bk, C.xk, sb);
+    else tree_fcg<L + 1>(T, sm, sb);
+    for (int i = threadIdx.x; i < X.A.n; i += kTreeThreads) {
+      const size_t ca = 3 * (size_t)X.agg[i], o = 3 * (size_t)i;
+      const double c0 = C.xk[ca], c1 = C.xk[ca + 1], w = C.xk[ca + 2];
+      X.xs[o] += c0 - X.d[2 * (size_t)i + 1] * w;
+      X.xs[o + 1] += c1 + X.d[2 * (size_t)i] * w;
+      X.xs[o + 2] += w;
+    }
+    __syncthreads();
+    SpmvArgs a{};
+    a.x = X.xs; a.b = rhs; a.y = out; a.omega = T.omega; a.dotA = dotvec;
+    blk_spmv<SPMV_JACOBI>(X.A, a, dotvec != nullptr, dot, u1, sm);
+  }
+}
+
+// two flexible-CG steps for A_L xk = bk (same recurrences as the host-driven fcg())
+template <int L>
+__device__ void tree_fcg(const CoarseTree& T, double* sm, double* sb) {
+  if constexpr (L + 1 < kTreeMaxLevels) {
+    const TreeLevel& X = T.lv[L];
+    const int n3 = 3 * X.A.n;
+    double dummy = 0.0;
+    tree_cycle<L>(T, X.bk, X.z1, nullptr, dummy, sm, sb);
+    double den = 0.0, num = 0.0;
+    {
+      SpmvArgs a{};
+      a.x = X.z1; a.y = X.q; a.dotA = X.z1; a.dotB = X.z1; a.dotC = X.bk;
+      blk_spmv<SPMV_AX>(X.A, a, true, den, num, sm);
+    }
+    const bool ok = den > 0.0 && isfinite(den);
+    const double al = (ok && isfinite(num)) ? num / den : 0.0;
+    for (int i = threadIdx.x; i < n3; i += kTreeThreads) {
+      X.xk[i] = al * X.z1[i];
+      X.bk[i] -= al * X.q[i];
+    }
+    __syncthreads();
+    double c = 0.0;
+    tree_cycle<L>(T, X.bk, X.z2, X.q, c, sm, sb);
+    const double be = (ok && isfinite(c)) ? c / den : 0.0;
+    for (int i = threadIdx.x; i < n3; i += kTreeThreads) X.z2[i] -= be * X.z1[i];
+    __syncthreads();
+    double den2 = 0.0, num2 = 0.0;
+    {
+      SpmvArgs a{};
+      a.x = X.z2; a.y = X.q; a.dotA = X.z2; a.dotB = X.z2; a.dotC = X.bk;
+      blk_spmv<SPMV_AX>(X.A, a, true, den2, num2, sm);
+    }
+    const double al2 = (den2 > 0.0 && isfinite(den2) && isfinite(num2)) ? num2 / den2 : 0.0;
+    for (int i = threadIdx.x; i < n3; i += kTreeThreads) X.xk[i] += al2 * X.z2[i];
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(kTreeThreads) void k_coarse_tree(const CoarseTree* __restrict__ T, const PcgScalars* S) {
+  if (S && S->stop) return;
+  __shared__ double sm[2 * kTreeWaves];
+  extern __shared__ double sb[];
+  tree_fcg<0>(*T, sm, sb);
+}
+
+// Coarsest-level inverse with the matrix held in LDS (N <= 140): Gauss-Jordan, one workgroup.
+__global__ __launch_bounds__(kDenseThreads) void k_dense_invert_lds(BsrDev A, double* __restrict__ inv, int* __restrict__ fail) {
+  const int N = 3 * A.n;
+  const size_t ns = (size_t)A.nslot;
+  extern __shared__ double sh[];  // [N*N] matrix, [N] pivot row, [N] pivot column
+  double* M = sh;
+  double* prow = sh + (size_t)N * N;
+  double* pcol = prow + N;
+  __shared__ double piv;
+  for (int t = threadIdx.x; t < N * N; t += kDenseThreads) M[t] = 0.0;
+  __syncthreads();
+  for (int k = threadIdx.x; k < A.nslot; k += kDenseThreads) {
+    const int r = A.row[k], c = A.col[k];
+#pragma unroll
+    for (int e = 0; e < 9; ++e) M[(3 * r + e / 3) * N + 3 * c + e % 3] = A.blk[e * ns + k];
+  }
+  __syncthreads();
+  for (int k = 0; k < N; ++k) {
+    if (threadIdx.x == 0) {
+      const double v = M[k * N + k];
+      if (!(v > 0.0) || !isfinite(v)) *fail = 1;
+      piv = (v != 0.0) ? 1.0 / v : 0.0;
+    }
+    __syncthreads();
+    const double p = piv;
+    for (int j = threadIdx.x; j < N; j += kDenseThreads) {
+      prow[j] = (j == k) ? 0.0 : M[k * N + j] * p;
+      pcol[j] = (j == k) ? 0.0 : M[j * N + k];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x / 64; i < N; i += kDenseThreads / 64) {   // one wave per row: no division
+      const double f = pcol[i];
+      for (int j = threadIdx.x & 63; j < N; j += 64) {
+        double v;
+        if (i == k) v = (j == k) ? p : prow[j];
+        else if (j == k) v = -f * p;
+        else v = M[i * N + j] - f * prow[j];
+        M[i * N + j] = v;
+      }
+    }
+    __syncthreads();
+  }
+  for (int t = threadIdx.x; t < N * N; t += kDenseThreads) inv[t] = M[t];
 }
 
 // --------------------------------------------------------------------------------- host
@@ -392,6 +662,9 @@ struct Amg {
   std::vector<AmgLevel> lv;
   const double* d_poses = nullptr;
   const int* d_free_id = nullptr;
+  int tree_start = -1;  // first level handled by k_coarse_tree (-1: none)
+  CoarseTree tree;
+  CoarseTree* d_tree = nullptr;
   // coarsest dense inverse
   int N = 0;
   double* inv = nullptr;
@@ -429,17 +702,17 @@ void fcg(Amg* m, hipStream_t s, int l, const PcgScalars* S) {
   {
     SpmvArgs a{};
     a.x = L.z1; a.y = L.q; a.dotA = L.z1; a.dotB = L.z1; a.dotC = L.bk; a.partials = L.pA; a.S = S;
-    Scope sc(m->prof, K_AMG_COARSE, bytes_spmv(L.A));
+    Scope sc(m->prof, K_SPMV_AX, bytes_spmv(L.A));
     gA = launch_spmv_ex(s, L.A, SPMV_AX, a);
   }
   {
-    Scope sc(m->prof, K_AMG_MISC, 5 * 8.0 * n3);
+    Scope sc(m->prof, K_FCG, 5 * 8.0 * n3);
     hipLaunchKernelGGL(k_fcg, dim3(vgrid), dim3(kBlock), 0, s, 0, n3, L.pA, gA, L.pA + kMaxPartials, gA, L.z1, L.q,
                        L.xk, L.bk, S);
   }
   const int gC = cycle(m, s, l, L.bk, L.z2, L.q, L.pC, S);
   {
-    Scope sc(m->prof, K_AMG_MISC, 3 * 8.0 * n3);
+    Scope sc(m->prof, K_FCG, 3 * 8.0 * n3);
     hipLaunchKernelGGL(k_fcg, dim3(vgrid), dim3(kBlock), 0, s, 1, n3, L.pA, gA, L.pC, gC, L.z1, (const double*)nullptr,
                        L.z2, (double*)nullptr, S);
   }
@@ -447,11 +720,11 @@ void fcg(Amg* m, hipStream_t s, int l, const PcgScalars* S) {
   {
     SpmvArgs a{};
     a.x = L.z2; a.y = L.q; a.dotA = L.z2; a.dotB = L.z2; a.dotC = L.bk; a.partials = L.pB; a.S = S;
-    Scope sc(m->prof, K_AMG_COARSE, bytes_spmv(L.A));
+    Scope sc(m->prof, K_SPMV_AX, bytes_spmv(L.A));
     gB = launch_spmv_ex(s, L.A, SPMV_AX, a);
   }
   {
-    Scope sc(m->prof, K_AMG_MISC, 3 * 8.0 * n3);
+    Scope sc(m->prof, K_FCG, 3 * 8.0 * n3);
     hipLaunchKernelGGL(k_fcg, dim3(vgrid), dim3(kBlock), 0, s, 2, n3, L.pB, gB, L.pB + kMaxPartials, gB, L.z2,
                        (const double*)nullptr, L.xk, (double*)nullptr, S);
   }
@@ -465,22 +738,25 @@ int cycle(Amg* m, hipStream_t s, int l, const double* rhs, double* out, const do
   {
     SpmvArgs a{};
     a.b = rhs; a.y = L.rs; a.y2 = L.xs; a.omega = m->cfg.omega; a.S = S;
-    Scope sc(m->prof, l == 0 ? K_AMG_RESIDUAL : K_AMG_COARSE, bytes_spmv(L.A) + 72.0 * L.A.nslot);
+    Scope sc(m->prof, K_SPMV_PRE_RESID, bytes_spmv(L.A) + 72.0 * L.A.nslot);
     launch_spmv_ex(s, L.A, SPMV_PRE_RESID, a);
   }
   {
-    Scope sc(m->prof, K_AMG_RESTRICT, 40.0 * L.A.n + 24.0 * L.nc);
+    Scope sc(m->prof, K_RESTRICT, 40.0 * L.A.n + 24.0 * L.nc);
     hipLaunchKernelGGL(k_restrict, dim3(grid_for(L.nc, kBlock)), dim3(kBlock), 0, s, L.nc, L.mem_ptr, L.mem, L.d, L.rs,
                        C.bk, S);
   }
   if (l + 1 == last) {
-    Scope sc(m->prof, K_AMG_COARSE, 8.0 * m->N * m->N);
+    Scope sc(m->prof, K_DENSE_APPLY, 8.0 * m->N * m->N);
     hipLaunchKernelGGL(k_dense_apply, dim3(1), dim3(kDenseThreads), sizeof(double) * m->N, s, m->N, m->inv, C.bk, C.xk, S);
+  } else if (m->tree_start >= 0 && l + 1 >= m->tree_start) {
+    Scope sc(m->prof, K_COARSE_TREE, 0.0);
+    hipLaunchKernelGGL(k_coarse_tree, dim3(1), dim3(kTreeThreads), sizeof(double) * m->N, s, (const CoarseTree*)m->d_tree, S);
   } else {
     fcg(m, s, l + 1, S);
   }
   {
-    Scope sc(m->prof, K_AMG_PROLONG, 68.0 * L.A.n);
+    Scope sc(m->prof, K_PROLONG, 68.0 * L.A.n);
     hipLaunchKernelGGL(k_prolong_add, dim3(grid_for(L.A.n, kBlock)), dim3(kBlock), 0, s, L.A.n, L.agg, L.d, C.xk, L.xs, S);
   }
   SpmvArgs a{};
@@ -490,7 +766,7 @@ int cycle(Amg* m, hipStream_t s, int l, const double* rhs, double* out, const do
     a.dotA2 = dotvec2;
     a.partials = dotparts;
   }
-  Scope sc(m->prof, l == 0 ? K_AMG_SMOOTH : K_AMG_COARSE, bytes_spmv(L.A) + 72.0 * L.A.n);
+  Scope sc(m->prof, K_SPMV_JACOBI, bytes_spmv(L.A) + 72.0 * L.A.n);
   return launch_spmv_ex(s, L.A, SPMV_JACOBI, a);
 }
 
@@ -509,7 +785,7 @@ int amg_update(Amg* m, hipStream_t s, std::string* err) {
   const int last = (int)m->lv.size() - 1;
   {
     AmgLevel& L0 = m->lv[0];
-    Scope sc(m->prof, K_AMG_MISC, 40.0 * L0.A.n);
+    Scope sc(m->prof, K_POSITIONS0, 40.0 * L0.A.n);
     hipLaunchKernelGGL(k_positions0, dim3(grid_for(L0.A.n, kBlock)), dim3(kBlock), 0, s, L0.A.n, m->d_free_id, m->d_poses,
                        L0.pos);
   }
@@ -517,21 +793,25 @@ int amg_update(Amg* m, hipStream_t s, std::string* err) {
     AmgLevel& L = m->lv[l];
     AmgLevel& C = m->lv[l + 1];
     {
-      Scope sc(m->prof, K_AMG_MISC, 36.0 * L.A.n);
+      Scope sc(m->prof, K_CENTRES, 36.0 * L.A.n);
       hipLaunchKernelGGL(k_centres, dim3(grid_for(L.nc, kBlock)), dim3(kBlock), 0, s, L.nc, L.mem_ptr, L.mem, L.pos, C.pos, L.d);
     }
     {
-      Scope sc(m->prof, K_AMG_GALERKIN, (72.0 + 16.0 + 32.0) * L.A.nslot + 72.0 * C.A.nslot);
+      Scope sc(m->prof, K_GALERKIN, (72.0 + 16.0 + 32.0) * L.A.nslot + 72.0 * C.A.nslot);
       hipLaunchKernelGGL(k_galerkin, dim3(grid_for(L.gal.ngrp, kWavesPerBlock)), dim3(kBlock), 0, s, L.A, C.A, L.gal, L.d);
     }
     {
-      Scope sc(m->prof, K_AMG_MISC, 120.0 * C.A.n);
+      Scope sc(m->prof, K_LEVEL_DINV, 120.0 * C.A.n);
       hipLaunchKernelGGL(k_level_dinv, dim3(grid_for(C.A.n, kBlock)), dim3(kBlock), 0, s, C.A);
     }
   }
   {
-    Scope sc(m->prof, K_AMG_MISC, 8.0 * m->N * m->N);
-    hipLaunchKernelGGL(k_dense_invert, dim3(1), dim3(kDenseThreads), sizeof(double) * 2 * m->N, s, m->lv[last].A, m->inv, m->d_fail);
+    Scope sc(m->prof, K_DENSE_INVERT, 8.0 * m->N * m->N);
+    const size_t lds = sizeof(double) * ((size_t)m->N * m->N + 2 * m->N);
+    if (lds <= 150 * 1024)
+      hipLaunchKernelGGL(k_dense_invert_lds, dim3(1), dim3(kDenseThreads), lds, s, m->lv[last].A, m->inv, m->d_fail);
+    else
+      hipLaunchKernelGGL(k_dense_invert, dim3(1), dim3(kDenseThreads), sizeof(double) * 2 * m->N, s, m->lv[last].A, m->inv, m->d_fail);
   }
   if (hipGetLastError() != hipSuccess) {
     if (err) *err = "amg_update: kernel launch failed";
@@ -551,6 +831,8 @@ Amg* amg_create(hipStream_t s, const BsrDev& A0, const double* d_poses, const in
   m->cfg = cfg_in;
   if (const char* e = std::getenv("SGO_AMG_THETA")) m->cfg.theta = std::atof(e);
   if (const char* e = std::getenv("SGO_AMG_OMEGA")) m->cfg.omega = std::atof(e);
+  if (const char* e = std::getenv("SGO_AMG_THETA_COARSE")) m->cfg.theta_coarse = std::atof(e);
+  if (const char* e = std::getenv("SGO_AMG_COARSEST")) m->cfg.coarsest_nodes = std::atoi(e);
   m->prof = prof;
   m->d_poses = d_poses;
   m->d_free_id = d_free_id;
@@ -612,7 +894,7 @@ Amg* amg_create(hipStream_t s, const BsrDev& A0, const double* d_poses, const in
       if (hipStreamSynchronize(s) != hipSuccess) return fail("amg_create: strength kernel failed");
     }
     std::vector<int> agg;
-    int nc = aggregate(H, w, m->cfg.theta, agg);
+    int nc = aggregate(H, w, l == 0 ? m->cfg.theta : m->cfg.theta_coarse, agg);
     if (nc > 0.9 * n) nc = aggregate(H, w, 0.0, agg);  // stalled: treat every connection as strong
     if (nc > 0.9 * n || nc < 1) break;                   // cannot coarsen further
 
@@ -714,7 +996,36 @@ Amg* amg_create(hipStream_t s, const BsrDev& A0, const double* d_poses, const in
   m->d_fail = dev_alloc<int>(m->pool, 1);
   if (!m->inv || !m->d_fail) return fail("amg_create: out of device memory");
   hipMemsetAsync(m->d_fail, 0, sizeof(int), s);
-  std::snprintf(line, sizeof line, "coarsest dense N=%d; theta=%.3g omega=%.2f", m->N, m->cfg.theta, m->cfg.omega);
+  // levels small enough for the single-workgroup tree kernel
+  for (int l = 1; l < last; ++l)
+    if (m->lv[l].A.n <= 2048 && m->lv[l].A.nslot <= 40000 && last - l + 1 <= kTreeMaxLevels) {
+      m->tree_start = l;
+      break;
+    }
+  // measured on MI355X (round 1): with the level data in global memory the single-workgroup tree
+  // is latency-bound (16 waves, ~3 us per dependent-load phase) and slower than separate
+  // launches; it stays opt-in until the small levels are staged in LDS.
+  if (!std::getenv("SGO_AMG_TREE")) m->tree_start = -1;
+  if (m->tree_start >= 0) {
+    CoarseTree& T = m->tree;
+    T.nlev = last - m->tree_start + 1;
+    T.N = m->N;
+    T.inv = m->inv;
+    T.omega = m->cfg.omega;
+    for (int k = 0; k < T.nlev; ++k) {
+      const AmgLevel& L = m->lv[m->tree_start + k];
+      TreeLevel& X = T.lv[k];
+      X.A = L.A; X.nc = L.nc; X.agg = L.agg; X.mem_ptr = L.mem_ptr; X.mem = L.mem; X.d = L.d;
+      X.xs = L.xs; X.rs = L.rs; X.bk = L.bk; X.xk = L.xk; X.z1 = L.z1; X.z2 = L.z2; X.q = L.q;
+    }
+    m->d_tree = dev_alloc<CoarseTree>(m->pool, 1);
+    if (!m->d_tree) return fail("amg_create: out of device memory");
+    hipMemcpyAsync(m->d_tree, &m->tree, sizeof(CoarseTree), hipMemcpyHostToDevice, s);
+    if (hipStreamSynchronize(s) != hipSuccess) return fail("amg_create: tree upload failed");
+  }
+  hipFuncSetAttribute((const void*)k_dense_invert_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+  std::snprintf(line, sizeof line, "coarsest dense N=%d; tree from L%d; theta=%.3g omega=%.2f", m->N, m->tree_start,
+                m->cfg.theta, m->cfg.omega);
   m->desc += line;
   return m;
 }

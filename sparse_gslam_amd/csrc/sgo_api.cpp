@@ -348,7 +348,7 @@ int do_chi2(sgo_ctx* c, double* d_out2, double* d_e2) {
     launch_chi2(c->stream, c->el, c->d_poses, d_e2, c->d_partials, &grid);
   }
   {
-    Scope sc(c, K_REDUCE, 16.0 * grid);
+    Scope sc(c, K_REDUCE2, 16.0 * grid);
     launch_reduce2(c->stream, c->d_partials, grid, d_out2);
   }
   if (c->comm.nranks > 1 && !c->comm.allreduce_f64(d_out2, 2, c->stream, &c->err)) return SGO_ECOMM;
@@ -363,11 +363,11 @@ int start_pcg(sgo_ctx* c, int grid) {
     if (rc) return rc;
     const int gz = amg_apply(c->amg, c->stream, c->d_r, c->d_z, c->d_r, c->d_zparts, nullptr);
     HIP_TRY(c, hipMemcpyAsync(c->d_p, c->d_z, sizeof(double) * 3 * (size_t)c->n, hipMemcpyDeviceToDevice, c->stream));
-    Scope sc(c, K_REDUCE, 8.0 * (gz + grid));
+    Scope sc(c, K_INIT_SCALARS, 8.0 * (gz + grid));
     launch_init_scalars(c->stream, c->d_S, c->d_zparts, gz, c->d_partials + kMaxPartials, grid, c->opts.pcg_tol,
                         c->opts.pcg_maxit);
   } else {
-    Scope sc(c, K_REDUCE, 16.0 * grid);
+    Scope sc(c, K_INIT_SCALARS, 16.0 * grid);
     launch_init_scalars(c->stream, c->d_S, c->d_partials, grid, c->d_partials + kMaxPartials, grid, c->opts.pcg_tol,
                         c->opts.pcg_maxit);
   }
@@ -397,13 +397,13 @@ int do_linearize(sgo_ctx* c) {
 int do_spmv(sgo_ctx* c, const double* x, double* y, bool dot, const PcgScalars* S, int* grid_out) {
   const bool multi = c->comm.nranks > 1;
   {
-    Scope sc(c, K_SPMV, bytes_spmv(c->A));
+    Scope sc(c, K_SPMV_AX, bytes_spmv(c->A));
     launch_spmv(c->stream, c->A, x, y, (dot && !multi) ? c->d_partials : nullptr, S, grid_out);
   }
   if (multi) {
     if (!c->comm.allreduce_f64(y, 3 * (size_t)c->n, c->stream, &c->err)) return SGO_ECOMM;
     if (dot) {
-      Scope sc(c, K_AMG_MISC, 48.0 * c->n);
+      Scope sc(c, K_DOT, 48.0 * c->n);
       launch_dot(c->stream, 3 * c->n, x, y, c->d_partials, S, grid_out);
     }
   }
@@ -518,7 +518,7 @@ void sgo_default_opts(sgo_opts* o) {
   if (!o) return;
   std::memset(o, 0, sizeof(*o));
   o->struct_size = (int32_t)sizeof(sgo_opts);
-  o->solver = SGO_SOLVER_PCG_BJ;
+  o->solver = SGO_SOLVER_PCG_AMG;
   o->pcg_tol = 1e-8;
   o->pcg_maxit = 20000;
   o->pcg_chunk = 16;

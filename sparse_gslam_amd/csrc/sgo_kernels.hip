@@ -23,9 +23,10 @@
 namespace sgo {
 
 const char* const kKernelNames[K_COUNT] = {
-    "k_chi2",       "k_linearize",   "k_finalize",     "k_spmv",       "k_alpha",       "k_update_xr",
-    "k_beta",       "k_update_p",    "k_pose_update",  "k_reduce",     "k_amg_galerkin", "k_amg_smooth",
-    "k_amg_residual", "k_amg_restrict", "k_amg_prolong", "k_amg_coarse", "k_amg_misc"};
+    "k_chi2",        "k_reduce2",  "k_linearize",   "k_finalize",   "k_init_scalars", "k_spmv<0>",  "k_spmv<1>",
+    "k_spmv<2>",     "k_spmv<3>",  "k_alpha",       "k_update_xr",  "k_beta",         "k_update_p", "k_dot",
+    "k_pose_update", "k_positions0", "k_centres",   "k_galerkin",   "k_level_dinv",   "k_restrict", "k_prolong_add",
+    "k_fcg",         "k_dense_invert", "k_dense_apply", "k_coarse_tree"};
 
 namespace {
 
