@@ -153,24 +153,35 @@ __global__ __launch_bounds__(kBlock) void k_level_dinv(BsrDev A) {
   }
 }
 
-// rc[a] = sum_{i in a} T_i^T r_i     (one thread per aggregate)
-__global__ __launch_bounds__(kBlock) void k_restrict(int nc, const int* __restrict__ mem_ptr, const int* __restrict__ mem,
-                                                     const double* __restrict__ d, const double* __restrict__ r,
-                                                     double* __restrict__ rc, const PcgScalars* S) {
+// rc[a] = sum_{i in a} T_i^T r_i : one lane per member (members sorted by aggregate), wavefront
+// segmented scan per aggregate -- one dependent load chain instead of a serial member loop.
+__global__ __launch_bounds__(kBlock) void k_restrict(int ngrp, const int* __restrict__ grp, const int* __restrict__ mem,
+                                                     const int* __restrict__ agg, const double* __restrict__ d,
+                                                     const double* __restrict__ r, double* __restrict__ rc,
+                                                     const PcgScalars* S) {
   if (S && S->stop) return;
-  for (int a = blockIdx.x * kBlock + threadIdx.x; a < nc; a += gridDim.x * kBlock) {
-    const int lo = mem_ptr[a], hi = mem_ptr[a + 1];
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-    for (int t = lo; t < hi; ++t) {
+  const int lane = threadIdx.x & 63;
+  int g, gend, gstride;
+  group_walk(ngrp, &g, &gend, &gstride);
+  for (; g < gend; g += gstride) {
+    const int gb = grp[g], ge = grp[g + 1];
+    double acc[3] = {0.0, 0.0, 0.0};
+    int key = -1 - lane;
+    for (int t = gb + lane; t < ge; t += 64) {
       const int i = mem[t];
+      key = agg[i];
       const double r0 = r[3 * (size_t)i], r1 = r[3 * (size_t)i + 1], r2 = r[3 * (size_t)i + 2];
-      s0 += r0;
-      s1 += r1;
-      s2 += -d[2 * (size_t)i + 1] * r0 + d[2 * (size_t)i] * r1 + r2;
+      acc[0] += r0;
+      acc[1] += r1;
+      acc[2] += -d[2 * (size_t)i + 1] * r0 + d[2 * (size_t)i] * r1 + r2;
     }
-    rc[3 * (size_t)a] = s0;
-    rc[3 * (size_t)a + 1] = s1;
-    rc[3 * (size_t)a + 2] = s2;
+    seg_scan<3>(key, acc, lane);
+    const int kn = __shfl_down(key, 1);
+    if (key >= 0 && (lane == 63 || kn != key)) {
+      rc[3 * (size_t)key] = acc[0];
+      rc[3 * (size_t)key + 1] = acc[1];
+      rc[3 * (size_t)key + 2] = acc[2];
+    }
   }
 }
 
@@ -646,6 +657,8 @@ struct AmgLevel {
   int* agg = nullptr;
   int* mem_ptr = nullptr;
   int* mem = nullptr;
+  int* mem_grp = nullptr;   // wave groups over the member list, aligned to aggregates
+  int mem_ngrp = 0;
   double* pos = nullptr;    // [n][2]
   double* d = nullptr;      // [n][2] lever arms
   GalerkinMap gal;
@@ -743,8 +756,8 @@ int cycle(Amg* m, hipStream_t s, int l, const double* rhs, double* out, const do
   }
   {
     Scope sc(m->prof, K_RESTRICT, 40.0 * L.A.n + 24.0 * L.nc);
-    hipLaunchKernelGGL(k_restrict, dim3(grid_for(L.nc, kBlock)), dim3(kBlock), 0, s, L.nc, L.mem_ptr, L.mem, L.d, L.rs,
-                       C.bk, S);
+    hipLaunchKernelGGL(k_restrict, dim3(grid_for(L.mem_ngrp, kWavesPerBlock)), dim3(kBlock), 0, s, L.mem_ngrp, L.mem_grp,
+                       L.mem, L.agg, L.d, L.rs, C.bk, S);
   }
   if (l + 1 == last) {
     Scope sc(m->prof, K_DENSE_APPLY, 8.0 * m->N * m->N);
@@ -952,6 +965,9 @@ Amg* amg_create(hipStream_t s, const BsrDev& A0, const double* d_poses, const in
     L.agg = dev_upload(m->pool, agg, s);
     L.mem_ptr = dev_upload(m->pool, mem_ptr, s);
     L.mem = dev_upload(m->pool, mem, s);
+    std::vector<int> grp_m = make_groups(mem_ptr);
+    L.mem_grp = dev_upload(m->pool, grp_m, s);
+    L.mem_ngrp = (int)grp_m.size() - 1;
     L.d = dev_alloc<double>(m->pool, 2 * (size_t)n);
     L.gal.n = ns;
     L.gal.src = dev_upload(m->pool, order, s);
@@ -968,7 +984,7 @@ Amg* amg_create(hipStream_t s, const BsrDev& A0, const double* d_poses, const in
     C.A.rowptr = dev_upload(m->pool, Hc.rowptr, s);
     C.A.blk = dev_alloc<double>(m->pool, 9 * (size_t)Hc.nslot);
     C.A.dinv = dev_alloc<double>(m->pool, 6 * (size_t)nc);
-    if (!L.agg || !L.mem_ptr || !L.mem || !L.d || !L.gal.src || !L.gal.tgt || !L.gal.grp || !C.A.row || !C.A.col ||
+    if (!L.agg || !L.mem_ptr || !L.mem || !L.mem_grp || !L.d || !L.gal.src || !L.gal.tgt || !L.gal.grp || !C.A.row || !C.A.col ||
         !C.A.grp || !C.A.rowptr || !C.A.blk || !C.A.dinv)
       return fail("amg_create: out of device memory");
     if (hipStreamSynchronize(s) != hipSuccess) return fail("amg_create: upload failed");  // host vectors die below
