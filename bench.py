@@ -10,10 +10,11 @@ steps x iters x E / time = edge-Jacobian evaluations per second per GN iteration
 (structure + edge arrays) already resident in HBM when the timed region starts; the only upload in
 the timed region is the 24*V-byte pose reset at the start of each step.
 
-N > 1: launched by ``python -m torch.distributed.run``; one rank per GPU; the edge set is sharded
-(contiguous ranges after sorting by min(vi,vj)), poses are replicated, and the per-vertex
-(block-diagonal H, b) partials and the per-PCG-step Hessian-product partials are all-reduced with
-RCCL inside libsgo.  Total work is fixed => "scaling": "strong".
+N > 1: launched by ``python -m torch.distributed.run``; one rank per GPU.  Every rank holds the full
+graph; per GN iteration rank r evaluates the edge Jacobians of its contiguous band of Hessian rows
+and the per-vertex (block-diagonal H, b) contributions plus the off-diagonal blocks are all-reduced
+with RCCL inside libsgo; the linear solve then runs replicated (DESIGN.md section 6 says why).
+Total work is fixed => "scaling": "strong".
 """
 from __future__ import annotations
 
@@ -29,18 +30,6 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 measured copy)
-
-
-def shard_edges(g, nranks: int, rank: int):
-    """Contiguous edge ranges after sorting by min(vi, vj) (compact vertex footprint per shard)."""
-    if nranks == 1:
-        return g
-    order = np.argsort(np.minimum(g.ei, g.ej), kind="stable")
-    lo = (g.E * rank) // nranks
-    hi = (g.E * (rank + 1)) // nranks
-    mask = np.zeros(g.E, dtype=bool)
-    mask[order[lo:hi]] = True
-    return g.subset(mask)
 
 
 def cpu_baseline(g, iters: int, budget_s: float = 25.0):
@@ -109,8 +98,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    g = synth.config(args.config)
-    shard = shard_edges(g, world, rank)
+    g = synth.config(args.config)   # every rank builds the same graph (deterministic generator)
 
     opts = {}
     if args.solver:
@@ -122,7 +110,7 @@ def main():
         uid = [capi.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
         opt.comm_init(world, rank, uid[0])
-    opt.set_graph(*shard.arrays())
+    opt.set_graph(*g.arrays())
 
     def step():
         opt.set_poses(g.poses)
@@ -159,7 +147,7 @@ def main():
                                    f"optimize({args.iters}) per step",
                        "V": g.V, "E": g.E, "gn_iters_per_step": args.iters,
                        "solver": {0: "pcg_block_jacobi", 1: "pcg_amg"}[opts.get("solver", o.solver)],
-                       "pcg_tol": opts.get("pcg_tol", o.pcg_tol), "parallelism": f"edge-shard x{world}"},
+                       "pcg_tol": opts.get("pcg_tol", o.pcg_tol), "parallelism": f"row-band sharded linearisation x{world}, replicated solve"},
             "final_chi2": st["chi2"][-1], "final_robust_chi2": st["robust_chi2"][-1],
             "pcg_iters_per_gn_iter": float(np.mean(st["pcg_iters"])), "pcg_iters": st["pcg_iters"],
             "gn_iter_ms_median": 1e3 * float(np.median(st["seconds"])),

@@ -101,8 +101,8 @@ void sgo_destroy(sgo_ctx* ctx);
 /* Replaces: SparseOptimizer::initializeOptimization() (slc.cpp:286, log_runner.cpp:203): takes
  * the active vertices/edges, builds the hessian index map (non-fixed vertices in ascending id),
  * the block-CSR structure and the device-resident SoA edge arrays.  Edges whose endpoints are
- * both fixed stay active for chi2 only.  E may be this rank's shard of the edge set when a
- * communicator is attached (sgo_comm_init). */
+ * both fixed stay active for chi2 only.  With a communicator attached (sgo_comm_init) every
+ * rank passes the same full graph. */
 int sgo_set_graph_se2(sgo_ctx* ctx, int32_t V, const double* poses, const uint8_t* fixed, int32_t E,
                       const int32_t* ei, const int32_t* ej, const double* meas, const double* info,
                       const double* phi);
@@ -153,13 +153,28 @@ typedef struct sgo_kernel_stat {
 int sgo_kernel_profile(sgo_ctx* ctx, sgo_kernel_stat* out, int cap);
 int sgo_profile_reset(sgo_ctx* ctx);
 
-/* ---- multi-GPU: edge-sharded, one process per GPU, RCCL over xGMI -------------------------- */
+/* ---- multi-GPU: one process per GPU, RCCL over xGMI ------------------------------------------
+ * Every rank is given the SAME full graph.  Per GN iteration rank r evaluates the edge
+ * Jacobians of its contiguous band of Hessian rows (sgo_shard_range over the row groups), the
+ * per-vertex (block-diagonal H, b) contributions and the off-diagonal blocks are summed over
+ * ranks with ncclAllReduce (every value has exactly one non-zero contributor, so the result is
+ * bit-identical to the single-GPU arrays), and the linear solve then runs replicated. */
 /* 128-byte unique id for rendezvous (wraps ncclGetUniqueId); rank 0 creates it, the host layer
  * broadcasts it (torch.distributed / MPI / a file), every rank passes it to sgo_comm_init. */
 #define SGO_UNIQUE_ID_BYTES 128
 int sgo_comm_unique_id(void* id_out);
 int sgo_comm_init(sgo_ctx* ctx, int nranks, int rank, const void* unique_id);
 int sgo_comm_size(sgo_ctx* ctx);
+/* The contiguous range [begin, end) of `count` work units (row groups, edges) that rank `rank` of
+ * `nranks` evaluates.  Pure function (no GPU needed); exposed so the host layer and the CPU tests
+ * can reproduce the partition. */
+void sgo_shard_range(int32_t count, int32_t nranks, int32_t rank, int32_t* begin, int32_t* end);
+
+/* Test hook: make this context evaluate the band of rank `rank` of `nranks` WITHOUT a
+ * communicator (collectives are skipped), so that the per-rank partial arrays can be inspected on
+ * a single GPU: summing sgo_linearize's b / diag over rank = 0..nranks-1 must reproduce the
+ * single-rank result exactly.  Must precede sgo_set_graph_se2. */
+int sgo_debug_set_shard(sgo_ctx* ctx, int nranks, int rank);
 
 /* Text of the last error on this context (or, with ctx == NULL, of the last failed sgo_create /
  * context-free call on this thread).  Never NULL. */

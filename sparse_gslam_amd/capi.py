@@ -26,7 +26,7 @@ SYMBOLS = [
     "sgo_set_poses", "sgo_get_poses", "sgo_optimize_gn", "sgo_chi2", "sgo_edge_chi2",
     "sgo_num_free", "sgo_free_ids", "sgo_linearize", "sgo_hessian_apply", "sgo_solve",
     "sgo_precondition", "sgo_kernel_profile", "sgo_profile_reset", "sgo_comm_unique_id",
-    "sgo_comm_init", "sgo_comm_size", "sgo_last_error",
+    "sgo_comm_init", "sgo_comm_size", "sgo_shard_range", "sgo_debug_set_shard", "sgo_last_error",
 ]
 
 
@@ -106,6 +106,9 @@ def lib():
     L.sgo_comm_unique_id.argtypes = [vp]
     L.sgo_comm_init.argtypes = [vp, C.c_int, C.c_int, vp]
     L.sgo_comm_size.argtypes = [vp]
+    L.sgo_shard_range.restype = None
+    L.sgo_shard_range.argtypes = [C.c_int32, C.c_int32, C.c_int32, i32, i32]
+    L.sgo_debug_set_shard.argtypes = [vp, C.c_int, C.c_int]
     L.sgo_last_error.restype = C.c_char_p
     L.sgo_last_error.argtypes = [vp]
     _LIB = L
@@ -124,6 +127,14 @@ def default_opts() -> Opts:
     o = Opts()
     lib().sgo_default_opts(C.byref(o))
     return o
+
+
+def shard_range(count: int, nranks: int, rank: int):
+    """[begin, end) of the work units rank `rank` evaluates (sgo_shard_range; needs no GPU)."""
+    a = C.c_int32()
+    b = C.c_int32()
+    lib().sgo_shard_range(count, nranks, rank, C.byref(a), C.byref(b))
+    return a.value, b.value
 
 
 def comm_unique_id() -> bytes:
@@ -178,6 +189,9 @@ class Optimizer:
     def comm_init(self, nranks: int, rank: int, unique_id: bytes):
         buf = C.create_string_buffer(unique_id, UNIQUE_ID_BYTES)
         self._check(lib().sgo_comm_init(self._h, nranks, rank, C.cast(buf, C.c_void_p)), "sgo_comm_init")
+
+    def debug_set_shard(self, nranks: int, rank: int):
+        self._check(lib().sgo_debug_set_shard(self._h, nranks, rank), "sgo_debug_set_shard")
 
     # -- graph
     def set_graph(self, poses, fixed, ei, ej, meas, info, phi):

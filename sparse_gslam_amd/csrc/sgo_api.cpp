@@ -187,8 +187,7 @@ double bytes_chi2(const sgo_ctx* c) { return 96.0 * c->E + 24.0 * c->V; }
 // ---- structure build: SparseOptimizer::initializeOptimization + BlockSolver::buildStructure -
 int build_structure(sgo_ctx* c, int V, const double* poses, const uint8_t* fixed, int E, const int32_t* ei,
                     const int32_t* ej, const double* meas, const double* info, const double* phi) {
-  // active vertices: those incident to at least one edge (initializeOptimization);
-  // with a communicator the degree is summed over ranks so every rank agrees on the rows.
+  // active vertices: those incident to at least one edge (initializeOptimization)
   std::vector<int> deg(V, 0);
   for (int e = 0; e < E; ++e) {
     int a = ei[e], b = ej[e];
@@ -202,14 +201,6 @@ int build_structure(sgo_ctx* c, int V, const double* poses, const uint8_t* fixed
     }
     deg[a]++;
     deg[b]++;
-  }
-  if (c->comm.nranks > 1) {
-    int* d_deg = nullptr;
-    int rc = upload(c, &d_deg, deg);
-    if (rc) return rc;
-    if (!c->comm.allreduce_i32(d_deg, V, c->stream, &c->err)) return SGO_ECOMM;
-    HIP_TRY(c, hipMemcpyAsync(deg.data(), d_deg, sizeof(int) * V, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
   }
   std::vector<int> hidx(V, -1);
   c->free_id.clear();
@@ -345,13 +336,15 @@ int do_chi2(sgo_ctx* c, double* d_out2, double* d_e2) {
   int grid = 0;
   {
     Scope sc(c, K_CHI2, bytes_chi2(c));
-    launch_chi2(c->stream, c->el, c->d_poses, d_e2, c->d_partials, &grid);
+    int e0 = 0, e1 = c->E;
+    if (c->comm.nranks > 1 && !d_e2) sgo_shard_range(c->E, c->comm.nranks, c->comm.rank, &e0, &e1);
+    launch_chi2(c->stream, c->el, e0, e1, c->d_poses, d_e2, c->d_partials, &grid);
   }
   {
     Scope sc(c, K_REDUCE2, 16.0 * grid);
     launch_reduce2(c->stream, c->d_partials, grid, d_out2);
   }
-  if (c->comm.nranks > 1 && !c->comm.allreduce_f64(d_out2, 2, c->stream, &c->err)) return SGO_ECOMM;
+  if (c->comm.nranks > 1 && !d_e2 && !c->comm.allreduce_f64(d_out2, 2, c->stream, &c->err)) return SGO_ECOMM;
   return SGO_OK;
 }
 
@@ -376,15 +369,27 @@ int start_pcg(sgo_ctx* c, int grid) {
 
 // buildSystem + preconditioner + PCG start state
 int do_linearize(sgo_ctx* c) {
-  {
-    Scope sc(c, K_LINEARIZE, bytes_linearize(c));
-    launch_linearize(c->stream, c->A, c->es, c->d_poses, c->d_dgb);
+  // Multi-GPU: rank r evaluates the edges of its contiguous band of row groups (whole rows, so
+  // every value is produced by exactly one rank); the other bands stay zero and the all-reduce
+  // (sum with exact zeros) reproduces the single-GPU arrays bit for bit on every rank.
+  int g0 = 0, g1 = c->A.ngrp;
+  if (c->comm.nranks > 1) {
+    sgo_shard_range(c->A.ngrp, c->comm.nranks, c->comm.rank, &g0, &g1);
+    HIP_TRY(c, hipMemsetAsync(c->A.blk, 0, sizeof(double) * 9 * (size_t)c->A.nslot, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_dgb, 0, sizeof(double) * 9 * (size_t)c->n, c->stream));
   }
-  if (c->comm.nranks > 1 && !c->comm.allreduce_f64(c->d_dgb, 9 * (size_t)c->n, c->stream, &c->err)) return SGO_ECOMM;
+  {
+    Scope sc(c, K_LINEARIZE, bytes_linearize(c) * (double)(g1 - g0) / std::max(1, c->A.ngrp));
+    launch_linearize(c->stream, c->A, g0, g1, c->es, c->d_poses, c->d_dgb);
+  }
+  if (c->comm.nranks > 1) {
+    if (!c->comm.allreduce_f64(c->A.blk, 9 * (size_t)c->A.nslot, c->stream, &c->err)) return SGO_ECOMM;
+    if (!c->comm.allreduce_f64(c->d_dgb, 9 * (size_t)c->n, c->stream, &c->err)) return SGO_ECOMM;
+  }
   int grid = 0;
   {
     Scope sc(c, K_FINALIZE, (72.0 + 72.0 + 48.0 + 5 * 24.0) * c->n);
-    launch_finalize(c->stream, c->A, c->d_dgb, c->comm.rank == 0 ? 1 : 0, c->d_b, c->d_x, c->d_r, c->d_z, c->d_p,
+    launch_finalize(c->stream, c->A, c->d_dgb, 1, c->d_b, c->d_x, c->d_r, c->d_z, c->d_p,
                     c->d_partials, &grid);
   }
   int rc = start_pcg(c, grid);
@@ -393,20 +398,11 @@ int do_linearize(sgo_ctx* c) {
   return SGO_OK;
 }
 
-// y = H x  (+ optional x.y partials); all-reduces y over ranks
+// y = H x  (+ optional x.y partials).  The solve is replicated on every rank (identical H after
+// the all-reduce in do_linearize), so no collective is needed here.
 int do_spmv(sgo_ctx* c, const double* x, double* y, bool dot, const PcgScalars* S, int* grid_out) {
-  const bool multi = c->comm.nranks > 1;
-  {
-    Scope sc(c, K_SPMV_AX, bytes_spmv(c->A));
-    launch_spmv(c->stream, c->A, x, y, (dot && !multi) ? c->d_partials : nullptr, S, grid_out);
-  }
-  if (multi) {
-    if (!c->comm.allreduce_f64(y, 3 * (size_t)c->n, c->stream, &c->err)) return SGO_ECOMM;
-    if (dot) {
-      Scope sc(c, K_DOT, 48.0 * c->n);
-      launch_dot(c->stream, 3 * c->n, x, y, c->d_partials, S, grid_out);
-    }
-  }
+  Scope sc(c, K_SPMV_AX, bytes_spmv(c->A));
+  launch_spmv(c->stream, c->A, x, y, dot ? c->d_partials : nullptr, S, grid_out);
   return SGO_OK;
 }
 
@@ -472,7 +468,7 @@ int ensure_pcg_graph(sgo_ctx* c, int chunk) {
 // Runs PCG from the state k_finalize left (x = 0, r = b, ...) until S.stop != 0.
 int run_pcg(sgo_ctx* c) {
   const int chunk = std::max(1, c->opts.pcg_chunk);
-  const bool graph = c->opts.use_graph && !c->opts.profile && c->comm.nranks == 1;
+  const bool graph = c->opts.use_graph && !c->opts.profile;
   if (graph) {
     int rc = ensure_pcg_graph(c, chunk);
     if (rc) return rc;
@@ -618,7 +614,7 @@ int sgo_set_graph_se2(sgo_ctx* c, int32_t V, const double* poses, const uint8_t*
   }
   c->has_graph = true;
   c->solver_desc = "pcg_block_jacobi";
-  if (c->opts.solver == SGO_SOLVER_PCG_AMG && c->comm.nranks == 1 && c->n > 64) {
+  if (c->opts.solver == SGO_SOLVER_PCG_AMG && c->n > 64 && (c->comm.nranks == 1 || c->comm.handle)) {
     // the hierarchy is built from the Hessian at the initial poses (strength of connection)
     if ((rc = do_linearize(c)) != SGO_OK) {
       free_graph(c);
@@ -776,7 +772,7 @@ int sgo_solve(sgo_ctx* c, double* x, double* relres) {
   }
   // restart from the state of the last linearisation (idempotent re-finalize)
   int grid = 0;
-  launch_finalize(c->stream, c->A, c->d_dgb, c->comm.rank == 0 ? 1 : 0, c->d_b, c->d_x, c->d_r, c->d_z, c->d_p,
+  launch_finalize(c->stream, c->A, c->d_dgb, 1, c->d_b, c->d_x, c->d_r, c->d_z, c->d_p,
                   c->d_partials, &grid);
   if ((rc = start_pcg(c, grid))) return rc;
   if ((rc = run_pcg(c))) return rc;
@@ -913,5 +909,26 @@ int sgo_comm_init(sgo_ctx* c, int nranks, int rank, const void* unique_id) {
 }
 
 int sgo_comm_size(sgo_ctx* c) { return c ? c->comm.nranks : SGO_EINVAL; }
+
+int sgo_debug_set_shard(sgo_ctx* c, int nranks, int rank) {
+  if (!c || nranks < 1 || rank < 0 || rank >= nranks) return SGO_EINVAL;
+  if (c->has_graph) {
+    c->err = "sgo_debug_set_shard must precede sgo_set_graph_se2";
+    return SGO_EINVAL;
+  }
+  c->comm.destroy();
+  c->comm.nranks = nranks;  // no handle: Comm::allreduce_* are no-ops
+  c->comm.rank = rank;
+  return SGO_OK;
+}
+
+void sgo_shard_range(int32_t count, int32_t nranks, int32_t rank, int32_t* begin, int32_t* end) {
+  if (nranks < 1) nranks = 1;
+  if (rank < 0) rank = 0;
+  if (rank >= nranks) rank = nranks - 1;
+  const long long lo = (long long)count * rank / nranks, hi = (long long)count * (rank + 1) / nranks;
+  if (begin) *begin = (int32_t)lo;
+  if (end) *end = (int32_t)hi;
+}
 
 }  // extern "C"

@@ -136,10 +136,10 @@ inline int grid_for(long long work_items, int per_block) {
 
 // ---- kernel launchers (sgo_kernels.hip) --------------------------------------------------
 // All take the stream; none allocates or synchronises (hipGraph-capturable).
-void launch_chi2(hipStream_t s, const EdgeListDev& el, const double* poses, double* e2_out,
+void launch_chi2(hipStream_t s, const EdgeListDev& el, int e0, int e1, const double* poses, double* e2_out,
                  double* partials /*[2][kMaxPartials]*/, int* grid_out);
 void launch_reduce2(hipStream_t s, const double* partials, int nparts, double* out2);
-void launch_linearize(hipStream_t s, const BsrDev& A, const EdgeSlotsDev& es, const double* poses,
+void launch_linearize(hipStream_t s, const BsrDev& A, int g0, int g1, const EdgeSlotsDev& es, const double* poses,
                       double* dgb /*[n][9]*/);
 void launch_finalize(hipStream_t s, const BsrDev& A, const double* dgb, int write_diag, double* b,
                      double* x, double* r, double* z, double* p, double* partials, int* grid_out);

@@ -68,11 +68,11 @@ __device__ __forceinline__ void dcs(double e2, double phi, double* rho0, double*
 }
 
 // ---------------------------------------------------------------------------- k_chi2
-__global__ __launch_bounds__(kBlock) void k_chi2(EdgeListDev el, const double* __restrict__ poses,
+__global__ __launch_bounds__(kBlock) void k_chi2(EdgeListDev el, int e0, int e1, const double* __restrict__ poses,
                                                  double* __restrict__ e2_out, double* __restrict__ partials) {
   double acc[2] = {0.0, 0.0};
   const int E = el.E;
-  for (int k = blockIdx.x * kBlock + threadIdx.x; k < E; k += gridDim.x * kBlock) {
+  for (int k = e0 + blockIdx.x * kBlock + threadIdx.x; k < e1; k += gridDim.x * kBlock) {
     const int vi = el.vi[k], vj = el.vj[k];
     const double xi = poses[3 * (size_t)vi], yi = poses[3 * (size_t)vi + 1], ti = poses[3 * (size_t)vi + 2];
     const double xj = poses[3 * (size_t)vj], yj = poses[3 * (size_t)vj + 1], tj = poses[3 * (size_t)vj + 2];
@@ -112,12 +112,14 @@ __global__ __launch_bounds__(kBlock) void k_reduce2(const double* __restrict__ p
 // (dir 1), column Jacobian Jc the other one;  writes the off-diagonal block Jr^T Ow Jc into the
 // slot, and segment-sums Jr^T Ow Jr (6 unique) and -Jr^T Ow e (3) over the row; the row's last
 // lane stores them to dgb[r][0..8].
-__global__ __launch_bounds__(kBlock) void k_linearize(BsrDev A, EdgeSlotsDev es, const double* __restrict__ poses,
-                                                      double* __restrict__ dgb) {
+__global__ __launch_bounds__(kBlock) void k_linearize(BsrDev A, int g0, int g1, EdgeSlotsDev es,
+                                                      const double* __restrict__ poses, double* __restrict__ dgb) {
   const int lane = threadIdx.x & 63;
   const size_t ns = (size_t)A.nslot;
   int g, gend, gstride;
-  group_walk(A.ngrp, &g, &gend, &gstride);
+  group_walk(g1 - g0, &g, &gend, &gstride);   // this rank's band of row groups [g0, g1)
+  g += g0;
+  gend += g0;
   for (; g < gend; g += gstride) {
     const int gb = A.grp[g], ge = A.grp[g + 1];
     double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -438,18 +440,19 @@ __global__ __launch_bounds__(kBlock) void k_pose_update(int n, const int* __rest
 }  // namespace
 
 // ---------------------------------------------------------------------------- launchers
-void launch_chi2(hipStream_t s, const EdgeListDev& el, const double* poses, double* e2_out, double* partials,
-                 int* grid_out) {
-  const int grid = grid_for(el.E, kBlock);
-  hipLaunchKernelGGL(k_chi2, dim3(grid), dim3(kBlock), 0, s, el, poses, e2_out, partials);
+void launch_chi2(hipStream_t s, const EdgeListDev& el, int e0, int e1, const double* poses, double* e2_out,
+                 double* partials, int* grid_out) {
+  const int grid = grid_for(e1 - e0, kBlock);
+  hipLaunchKernelGGL(k_chi2, dim3(grid), dim3(kBlock), 0, s, el, e0, e1, poses, e2_out, partials);
   *grid_out = grid;
 }
 void launch_reduce2(hipStream_t s, const double* partials, int nparts, double* out2) {
   hipLaunchKernelGGL(k_reduce2, dim3(1), dim3(kBlock), 0, s, partials, nparts, out2);
 }
-void launch_linearize(hipStream_t s, const BsrDev& A, const EdgeSlotsDev& es, const double* poses, double* dgb) {
-  const int grid = grid_for(A.ngrp, kWavesPerBlock);
-  hipLaunchKernelGGL(k_linearize, dim3(grid), dim3(kBlock), 0, s, A, es, poses, dgb);
+void launch_linearize(hipStream_t s, const BsrDev& A, int g0, int g1, const EdgeSlotsDev& es, const double* poses,
+                      double* dgb) {
+  const int grid = grid_for(g1 - g0, kWavesPerBlock);
+  hipLaunchKernelGGL(k_linearize, dim3(grid), dim3(kBlock), 0, s, A, g0, g1, es, poses, dgb);
 }
 void launch_finalize(hipStream_t s, const BsrDev& A, const double* dgb, int write_diag, double* b, double* x,
                      double* r, double* z, double* p, double* partials, int* grid_out) {
