@@ -1,0 +1,140 @@
+"""Edge cases of the reference's call sites, through the C-ABI on the GPU."""
+import numpy as np
+import pytest
+
+from sparse_gslam_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle():
+    from oracle import c_oracle
+    return c_oracle
+
+
+def _check_against_oracle(opt, args, iters=10, tol=1e-6):
+    opt.set_graph(*args)
+    done, st = opt.optimize(iters)
+    P = opt.get_poses()
+    oP, ost = _oracle().gauss_newton(*args, iters=iters)
+    assert done == ost["iters_done"] == iters
+    assert abs(st["chi2"][-1] - ost["chi2"][-1]) <= tol * ost["chi2"][-1] + 1e-12
+    assert np.abs(P - oP).max() <= 1e-5
+    return P
+
+
+@pytest.fixture(scope="module")
+def opt():
+    o = capi.Optimizer(0, pcg_tol=1e-10, pcg_maxit=100000)
+    yield o
+    o.close()
+
+
+def test_duplicate_edges_and_edges_to_fixed_vertices(opt):
+    """Two closures on the same pair accumulate into one H block; several fixed vertices, edges
+    between fixed vertices stay in chi2 only (SURVEY 8(b) notes 2, 3)."""
+    g = synth.manhattan(150, 300, seed=41, info_mode="full")
+    dup = np.arange(160, 200)
+    args = [g.poses, g.fixed.copy(), np.concatenate([g.ei, g.ei[dup]]), np.concatenate([g.ej, g.ej[dup]]),
+            np.concatenate([g.meas, g.meas[dup] + 0.01]), np.concatenate([g.info, g.info[dup]]),
+            np.concatenate([g.phi, g.phi[dup]])]
+    args[1][[0, 1, 2, 75]] = True          # edges (0,1), (1,2) now join two fixed vertices
+    P = _check_against_oracle(opt, args)
+    assert np.array_equal(P[[0, 1, 2, 75]], g.poses[[0, 1, 2, 75]])
+
+
+def test_vertex_without_edges_is_inactive_and_untouched(opt):
+    g = synth.manhattan(80, 150, seed=42)
+    poses = np.vstack([g.poses, [[123.0, -45.0, 0.7]]])     # vertex 80: no edges, not fixed
+    fixed = np.append(g.fixed, False)
+    args = [poses, fixed, g.ei, g.ej, g.meas, g.info, g.phi]
+    opt.set_graph(*args)
+    assert opt.n_free == 79
+    done, _ = opt.optimize(5)
+    assert done == 5 and np.array_equal(opt.get_poses()[80], poses[80])
+
+
+def test_nothing_to_optimise_returns_minus_one(opt):
+    g = synth.manhattan(20, 30, seed=43)
+    opt.set_graph(g.poses, np.ones(20, dtype=bool), g.ei, g.ej, g.meas, g.info, g.phi)
+    rc, st = opt.optimize(5)
+    assert rc == -1
+    c, r = opt.chi2()      # chi2 of the (all fixed) graph is still defined
+    oc, orc = _oracle().chi2(g.poses, np.ones(20, bool), g.ei, g.ej, g.meas, g.info, g.phi)
+    assert abs(c - oc) <= 1e-12 * oc and abs(r - orc) <= 1e-12 * orc
+
+
+def test_indefinite_information_fails_cleanly_and_keeps_estimates(opt):
+    """g2o stops when the factorisation fails and leaves estimates at the last good update; here the
+    PCG breakdown test (p.Hp <= 0) plays that role: optimize returns 0, poses untouched."""
+    g = synth.manhattan(60, 100, seed=44)
+    info = g.info.copy()
+    info[:, [0, 3, 5]] *= -1.0
+    opt.set_graph(g.poses, g.fixed, g.ei, g.ej, g.meas, info, g.phi)
+    rc, st = opt.optimize(5)
+    assert rc == 0 and st["iters_done"] == 0
+    assert np.array_equal(opt.get_poses(), g.poses)
+
+
+def test_invalid_arguments_are_rejected(opt):
+    g = synth.manhattan(20, 30, seed=45)
+    bad = g.ej.copy()
+    bad[3] = 20                      # vertex id out of range
+    with pytest.raises(capi.SgoError):
+        opt.set_graph(g.poses, g.fixed, g.ei, bad, g.meas, g.info, g.phi)
+    bad = g.ej.copy()
+    bad[3] = g.ei[3]                 # self edge
+    with pytest.raises(capi.SgoError):
+        opt.set_graph(g.poses, g.fixed, g.ei, bad, g.meas, g.info, g.phi)
+    with pytest.raises(capi.SgoError):
+        capi.Optimizer(0).optimize(1)   # no graph
+
+
+def test_hub_vertex_with_a_row_longer_than_one_wave(opt):
+    """A vertex with > 64 incident edges: its Hessian row spans several wave passes."""
+    g = synth.manhattan(400, 700, seed=46, info_mode="full")
+    hub = 200
+    others = np.setdiff1d(np.arange(0, 400, 2), [hub])[:150]
+    rel = np.stack([g.truth[others, 0] - g.truth[hub, 0], g.truth[others, 1] - g.truth[hub, 1],
+                    g.truth[others, 2] - g.truth[hub, 2]], axis=1)
+    c, s = np.cos(g.truth[hub, 2]), np.sin(g.truth[hub, 2])
+    meas = np.stack([c * rel[:, 0] + s * rel[:, 1], -s * rel[:, 0] + c * rel[:, 1], rel[:, 2]], axis=1)
+    args = [g.poses, g.fixed, np.concatenate([g.ei, np.full(150, hub, np.int32)]),
+            np.concatenate([g.ej, others.astype(np.int32)]), np.concatenate([g.meas, meas]),
+            np.concatenate([g.info, np.tile(g.info[0], (150, 1))]), np.concatenate([g.phi, np.full(150, 1.0)])]
+    _check_against_oracle(opt, args)
+
+
+def test_closure_gate_matches_reference_rule(opt):
+    """log_runner.cpp:183-184: per-edge chi2 after computeError(), threshold 11.345."""
+    g = synth.manhattan(200, 500, seed=47, info_mode="full")
+    opt.set_graph(*g.arrays())
+    e2 = opt.edge_chi2()
+    oe2 = _oracle().edges(g.poses[g.ei], g.poses[g.ej], g.meas, g.info, g.phi)[3]
+    assert np.array_equal(e2 > 11.345, oe2 > 11.345)
+    c, _ = opt.chi2()
+    assert abs(c - e2.sum()) <= 1e-12 * c
+
+
+def test_two_contexts_are_independent():
+    """lm_graph.opt and pose_graph.opt may be inside optimize() concurrently (log_runner.cpp:217-238):
+    per-context stream and buffers, no shared mutable state."""
+    import threading
+    g1 = synth.manhattan(300, 700, seed=48)
+    g2 = synth.manhattan(350, 800, seed=49, info_mode="full")
+    res = {}
+
+    def run(tag, g):
+        with capi.Optimizer(0) as o:
+            o.set_graph(*g.arrays())
+            res[tag] = (o.optimize(10), o.get_poses())
+    ts = [threading.Thread(target=run, args=(k, g)) for k, g in (("a", g1), ("b", g2))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    for tag, g in (("a", g1), ("b", g2)):
+        oP, ost = _oracle().gauss_newton(*g.arrays(), iters=10)
+        (done, st), P = res[tag]
+        assert done == 10 and abs(st["chi2"][-1] - ost["chi2"][-1]) <= 1e-6 * ost["chi2"][-1]
+        assert np.abs(P - oP).max() <= 1e-5
