@@ -224,64 +224,132 @@ __global__ __launch_bounds__(kBlock) void k_fcg(int mode, int n3, const double* 
   }
 }
 
-// Coarsest level: dense matrix from the slots, inverted in place by Gauss-Jordan (SPD, no
-// pivoting), one workgroup.  N = 3 n.  inv is N x N row-major in global memory.
+// Coarsest level: explicit dense inverse, recomputed every GN iteration by a blocked in-place
+// Gauss-Jordan (SPD, no pivoting) spread over many workgroups: for pivot block K (32 x 32)
+//   P = inv(A_KK);  A_Kj <- P A_Kj (j != K);  A_ij <- A_ij - A_iK A_Kj (i, j != K);
+//   A_iK <- -A_iK P (i != K);  A_KK <- P.
+// The matrix is stored row-major with leading dimension Np = N rounded up to 32 and an identity
+// on the padding, so every tile is full.  4 launches per pivot block.
+constexpr int kGjB = 32;
 constexpr int kDenseThreads = 1024;
-__global__ __launch_bounds__(kDenseThreads) void k_dense_invert(BsrDev A, double* __restrict__ inv, int* __restrict__ fail) {
-  const int N = 3 * A.n;
+
+__global__ __launch_bounds__(kBlock) void k_dense_fill(BsrDev A, int Np, double* __restrict__ M) {
   const size_t ns = (size_t)A.nslot;
-  extern __shared__ double sh[];  // [2N]: scaled pivot row, pivot column
-  double* prow = sh;
-  double* pcol = sh + N;
-  for (int t = threadIdx.x; t < N * N; t += kDenseThreads) inv[t] = 0.0;
-  __syncthreads();
-  for (int k = threadIdx.x; k < A.nslot; k += kDenseThreads) {
+  const int N = 3 * A.n;
+  for (int k = blockIdx.x * kBlock + threadIdx.x; k < A.nslot; k += gridDim.x * kBlock) {
     const int r = A.row[k], c = A.col[k];
 #pragma unroll
-    for (int e = 0; e < 9; ++e) inv[(size_t)(3 * r + e / 3) * N + 3 * c + e % 3] = A.blk[e * ns + k];
+    for (int e = 0; e < 9; ++e) M[(size_t)(3 * r + e / 3) * Np + 3 * c + e % 3] = A.blk[e * ns + k];
   }
-  __syncthreads();
+  for (int i = N + blockIdx.x * kBlock + threadIdx.x; i < Np; i += gridDim.x * kBlock) M[(size_t)i * Np + i] = 1.0;
+}
+
+// P = inv(A_KK) by scalar Gauss-Jordan in LDS (one workgroup)
+__global__ __launch_bounds__(kBlock) void k_gj_pivot(double* __restrict__ M, int Np, int kb, double* __restrict__ P,
+                                                     int* __restrict__ fail) {
+  __shared__ double a[kGjB][kGjB + 1];
+  __shared__ double prow[kGjB], pcol[kGjB];
   __shared__ double piv;
-  for (int k = 0; k < N; ++k) {
-    if (threadIdx.x == 0) {
-      const double v = inv[(size_t)k * N + k];
+  const int t = threadIdx.x, base = kb * kGjB;
+  for (int e = t; e < kGjB * kGjB; e += kBlock) a[e / kGjB][e % kGjB] = M[(size_t)(base + e / kGjB) * Np + base + e % kGjB];
+  __syncthreads();
+  for (int k = 0; k < kGjB; ++k) {
+    if (t == 0) {
+      const double v = a[k][k];
       if (!(v > 0.0) || !isfinite(v)) *fail = 1;
       piv = (v != 0.0) ? 1.0 / v : 0.0;
     }
     __syncthreads();
     const double p = piv;
-    for (int j = threadIdx.x; j < N; j += kDenseThreads) {
-      prow[j] = (j == k) ? 0.0 : inv[(size_t)k * N + j] * p;
-      pcol[j] = (j == k) ? 0.0 : inv[(size_t)j * N + k];
+    if (t < kGjB) {
+      prow[t] = (t == k) ? 0.0 : a[k][t] * p;
+      pcol[t] = (t == k) ? 0.0 : a[t][k];
     }
     __syncthreads();
-    for (int i = threadIdx.x / 64; i < N; i += kDenseThreads / 64) {  // one wave per row
-      const double f = pcol[i];
-      double* Mi = inv + (size_t)i * N;
-      for (int j = threadIdx.x & 63; j < N; j += 64) {
-        double v;
-        if (i == k) v = (j == k) ? p : prow[j];
-        else if (j == k) v = -f * p;
-        else v = Mi[j] - f * prow[j];
-        Mi[j] = v;
-      }
+    for (int e = t; e < kGjB * kGjB; e += kBlock) {
+      const int i = e / kGjB, j = e % kGjB;
+      double v;
+      if (i == k) v = (j == k) ? p : prow[j];
+      else if (j == k) v = -pcol[i] * p;
+      else v = a[i][j] - pcol[i] * prow[j];
+      a[i][j] = v;
     }
     __syncthreads();
   }
+  for (int e = t; e < kGjB * kGjB; e += kBlock) P[e] = a[e / kGjB][e % kGjB];
 }
 
-// x = inv * b  (one workgroup; inv symmetric, so column reads are coalesced row reads)
-__global__ __launch_bounds__(kDenseThreads) void k_dense_apply(int N, const double* __restrict__ inv,
-                                                              const double* __restrict__ b, double* __restrict__ x,
-                                                              const PcgScalars* S) {
-  if (S && S->stop) return;
-  extern __shared__ double sb[];
-  for (int j = threadIdx.x; j < N; j += kDenseThreads) sb[j] = b[j];
+// C = alpha * X * Y for 32x32 tiles held in LDS; each of the 256 threads produces 4 entries
+__device__ __forceinline__ void tile_mm(const double (*X)[kGjB + 1], const double (*Y)[kGjB + 1], double (&out)[4]) {
+  const int r = threadIdx.x >> 3, c0 = (threadIdx.x & 7) * 4;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) out[q] = 0.0;
+  for (int k = 0; k < kGjB; ++k) {
+    const double x = X[r][k];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) out[q] += x * Y[k][c0 + q];
+  }
+}
+
+// mode 0: row panel    A_Kj <- P A_Kj          (block j = blockIdx.x, skipped when j == kb)
+// mode 1: trailing     A_ij <- A_ij - A_iK A_Kj (blockIdx.x = j, blockIdx.y = i; i, j != kb)
+// mode 2: column panel A_iK <- -A_iK P (i != kb), A_KK <- P
+__global__ __launch_bounds__(kBlock) void k_gj_step(int mode, double* __restrict__ M, int Np, int kb,
+                                                    const double* __restrict__ P) {
+  __shared__ double X[kGjB][kGjB + 1], Y[kGjB][kGjB + 1];
+  const int t = threadIdx.x, K0 = kb * kGjB;
+  const int bj = blockIdx.x, bi = (mode == 1) ? blockIdx.y : blockIdx.x;
+  if (mode == 0 && bj == kb) return;
+  if (mode == 1 && (bi == kb || bj == kb)) return;
+  const int r = t >> 3, c0 = (t & 7) * 4;
+  if (mode == 2 && bi == kb) {
+    for (int e = t; e < kGjB * kGjB; e += kBlock) M[(size_t)(K0 + e / kGjB) * Np + K0 + e % kGjB] = P[e];
+    return;
+  }
+  // load operands
+  for (int e = t; e < kGjB * kGjB; e += kBlock) {
+    const int i = e / kGjB, j = e % kGjB;
+    if (mode == 0) {
+      X[i][j] = P[e];
+      Y[i][j] = M[(size_t)(K0 + i) * Np + bj * kGjB + j];
+    } else if (mode == 1) {
+      X[i][j] = M[(size_t)(bi * kGjB + i) * Np + K0 + j];
+      Y[i][j] = M[(size_t)(K0 + i) * Np + bj * kGjB + j];
+    } else {
+      X[i][j] = M[(size_t)(bi * kGjB + i) * Np + K0 + j];
+      Y[i][j] = P[e];
+    }
+  }
   __syncthreads();
-  for (int i = threadIdx.x; i < N; i += kDenseThreads) {
+  double o[4];
+  tile_mm(X, Y, o);
+  if (mode == 0) {
+    double* dst = M + (size_t)(K0 + r) * Np + bj * kGjB + c0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) dst[q] = o[q];
+  } else if (mode == 1) {
+    double* dst = M + (size_t)(bi * kGjB + r) * Np + bj * kGjB + c0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) dst[q] -= o[q];
+  } else {
+    double* dst = M + (size_t)(bi * kGjB + r) * Np + K0 + c0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) dst[q] = -o[q];
+  }
+}
+
+// x = inv * b : one wave per row (inv is symmetric; row reads are coalesced)
+__global__ __launch_bounds__(kBlock) void k_dense_apply(int N, int Np, const double* __restrict__ inv,
+                                                       const double* __restrict__ b, double* __restrict__ x,
+                                                       const PcgScalars* S) {
+  if (S && S->stop) return;
+  const int lane = threadIdx.x & 63;
+  for (int i = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6); i < N; i += gridDim.x * kWavesPerBlock) {
+    const double* row = inv + (size_t)i * Np;
     double s = 0.0;
-    for (int j = 0; j < N; ++j) s += inv[(size_t)j * N + i] * sb[j];
-    x[i] = s;
+    for (int j = lane; j < N; j += 64) s += row[j] * b[j];
+    s = wave_sum(s);
+    if (lane == 0) x[i] = s;
   }
 }
 
@@ -307,6 +375,7 @@ struct TreeLevel {
 struct CoarseTree {
   int nlev = 0;   // levels in the tree; the last one is the dense coarsest level
   int N = 0;      // dense dimension
+  int Np = 0;     // leading dimension of inv
   const double* inv = nullptr;
   double omega = 0.0;
   TreeLevel lv[kTreeMaxLevels];
@@ -398,8 +467,8 @@ __device__ __forceinline__ void blk_spmv(const BsrDev& A, const SpmvArgs& a, boo
   }
 }
 
-__device__ __forceinline__ void blk_dense_apply(int N, const double* __restrict__ inv, const double* __restrict__ b,
-                                                double* __restrict__ x, double* sb) {
+__device__ __forceinline__ void blk_dense_apply(int N, int Np, const double* __restrict__ inv,
+                                                const double* __restrict__ b, double* __restrict__ x, double* sb) {
   for (int j = threadIdx.x; j < N; j += kTreeThreads) sb[j] = b[j];
   __syncthreads();
   const int s = threadIdx.x & 3;
@@ -407,7 +476,7 @@ __device__ __forceinline__ void blk_dense_apply(int N, const double* __restrict_
     const int i = base + (threadIdx.x >> 2);
     double acc = 0.0;
     if (i < N)
-      for (int j = s; j < N; j += 4) acc += inv[(size_t)j * N + i] * sb[j];
+      for (int j = s; j < N; j += 4) acc += inv[(size_t)j * Np + i] * sb[j];
     acc += __shfl_xor(acc, 1);
     acc += __shfl_xor(acc, 2);
     if (i < N && s == 0) x[i] = acc;
@@ -446,7 +515,7 @@ __device__ void tree_cycle(const CoarseTree& T, const double* rhs, double* out, 
       C.bk[3 * (size_t)ag + 2] = s2;
     }
     __syncthreads();
-    if (L + 1 == T.nlev - 1) blk_dense_apply(T.N, T.inv, C.bk, C.xk, sb);
+    if (L + 1 == T.nlev - 1) blk_dense_apply(T.N, T.Np, T.inv, C.bk, C.xk, sb);
     else tree_fcg<L + 1>(T, sm, sb);
     for (int i = threadIdx.x; i < X.A.n; i += kTreeThreads) {
       const size_t ca = 3 * (size_t)X.agg[i], o = 3 * (size_t)i;
@@ -505,51 +574,6 @@ __global__ __launch_bounds__(kTreeThreads) void k_coarse_tree(const CoarseTree* 
   __shared__ double sm[2 * kTreeWaves];
   extern __shared__ double sb[];
   tree_fcg<0>(*T, sm, sb);
-}
-
-// Coarsest-level inverse with the matrix held in LDS (N <= 140): Gauss-Jordan, one workgroup.
-__global__ __launch_bounds__(kDenseThreads) void k_dense_invert_lds(BsrDev A, double* __restrict__ inv, int* __restrict__ fail) {
-  const int N = 3 * A.n;
-  const size_t ns = (size_t)A.nslot;
-  extern __shared__ double sh[];  // [N*N] matrix, [N] pivot row, [N] pivot column
-  double* M = sh;
-  double* prow = sh + (size_t)N * N;
-  double* pcol = prow + N;
-  __shared__ double piv;
-  for (int t = threadIdx.x; t < N * N; t += kDenseThreads) M[t] = 0.0;
-  __syncthreads();
-  for (int k = threadIdx.x; k < A.nslot; k += kDenseThreads) {
-    const int r = A.row[k], c = A.col[k];
-#pragma unroll
-    for (int e = 0; e < 9; ++e) M[(3 * r + e / 3) * N + 3 * c + e % 3] = A.blk[e * ns + k];
-  }
-  __syncthreads();
-  for (int k = 0; k < N; ++k) {
-    if (threadIdx.x == 0) {
-      const double v = M[k * N + k];
-      if (!(v > 0.0) || !isfinite(v)) *fail = 1;
-      piv = (v != 0.0) ? 1.0 / v : 0.0;
-    }
-    __syncthreads();
-    const double p = piv;
-    for (int j = threadIdx.x; j < N; j += kDenseThreads) {
-      prow[j] = (j == k) ? 0.0 : M[k * N + j] * p;
-      pcol[j] = (j == k) ? 0.0 : M[j * N + k];
-    }
-    __syncthreads();
-    for (int i = threadIdx.x / 64; i < N; i += kDenseThreads / 64) {   // one wave per row: no division
-      const double f = pcol[i];
-      for (int j = threadIdx.x & 63; j < N; j += 64) {
-        double v;
-        if (i == k) v = (j == k) ? p : prow[j];
-        else if (j == k) v = -f * p;
-        else v = M[i * N + j] - f * prow[j];
-        M[i * N + j] = v;
-      }
-    }
-    __syncthreads();
-  }
-  for (int t = threadIdx.x; t < N * N; t += kDenseThreads) inv[t] = M[t];
 }
 
 // --------------------------------------------------------------------------------- host
@@ -678,9 +702,10 @@ struct Amg {
   int tree_start = -1;  // first level handled by k_coarse_tree (-1: none)
   CoarseTree tree;
   CoarseTree* d_tree = nullptr;
-  // coarsest dense inverse
-  int N = 0;
+  // coarsest dense inverse (row-major, leading dimension Np = N rounded up to 32)
+  int N = 0, Np = 0;
   double* inv = nullptr;
+  double* gjP = nullptr;   // [32][32] inverse of the current pivot block
   int* d_fail = nullptr;
   std::string desc;
 };
@@ -761,7 +786,8 @@ int cycle(Amg* m, hipStream_t s, int l, const double* rhs, double* out, const do
   }
   if (l + 1 == last) {
     Scope sc(m->prof, K_DENSE_APPLY, 8.0 * m->N * m->N);
-    hipLaunchKernelGGL(k_dense_apply, dim3(1), dim3(kDenseThreads), sizeof(double) * m->N, s, m->N, m->inv, C.bk, C.xk, S);
+    hipLaunchKernelGGL(k_dense_apply, dim3(grid_for(m->N, kWavesPerBlock)), dim3(kBlock), 0, s, m->N, m->Np, m->inv, C.bk,
+                       C.xk, S);
   } else if (m->tree_start >= 0 && l + 1 >= m->tree_start) {
     Scope sc(m->prof, K_COARSE_TREE, 0.0);
     hipLaunchKernelGGL(k_coarse_tree, dim3(1), dim3(kTreeThreads), sizeof(double) * m->N, s, (const CoarseTree*)m->d_tree, S);
@@ -819,12 +845,16 @@ int amg_update(Amg* m, hipStream_t s, std::string* err) {
     }
   }
   {
-    Scope sc(m->prof, K_DENSE_INVERT, 8.0 * m->N * m->N);
-    const size_t lds = sizeof(double) * ((size_t)m->N * m->N + 2 * m->N);
-    if (lds <= 150 * 1024)
-      hipLaunchKernelGGL(k_dense_invert_lds, dim3(1), dim3(kDenseThreads), lds, s, m->lv[last].A, m->inv, m->d_fail);
-    else
-      hipLaunchKernelGGL(k_dense_invert, dim3(1), dim3(kDenseThreads), sizeof(double) * 2 * m->N, s, m->lv[last].A, m->inv, m->d_fail);
+    Scope sc(m->prof, K_DENSE_INVERT, 8.0 * m->Np * m->Np);
+    const int nb = m->Np / kGjB;
+    hipMemsetAsync(m->inv, 0, sizeof(double) * (size_t)m->Np * m->Np, s);
+    hipLaunchKernelGGL(k_dense_fill, dim3(grid_for(m->lv[last].A.nslot, kBlock)), dim3(kBlock), 0, s, m->lv[last].A, m->Np, m->inv);
+    for (int kb = 0; kb < nb; ++kb) {
+      hipLaunchKernelGGL(k_gj_pivot, dim3(1), dim3(kBlock), 0, s, m->inv, m->Np, kb, m->gjP, m->d_fail);
+      hipLaunchKernelGGL(k_gj_step, dim3(nb), dim3(kBlock), 0, s, 0, m->inv, m->Np, kb, (const double*)m->gjP);
+      hipLaunchKernelGGL(k_gj_step, dim3(nb, nb), dim3(kBlock), 0, s, 1, m->inv, m->Np, kb, (const double*)m->gjP);
+      hipLaunchKernelGGL(k_gj_step, dim3(nb), dim3(kBlock), 0, s, 2, m->inv, m->Np, kb, (const double*)m->gjP);
+    }
   }
   if (hipGetLastError() != hipSuccess) {
     if (err) *err = "amg_update: kernel launch failed";
@@ -1006,15 +1036,18 @@ Amg* amg_create(hipStream_t s, const BsrDev& A0, const double* d_poses, const in
   const int last = (int)m->lv.size() - 1;
   if (last == 0) return fail("amg_create: graph too small or not coarsenable; use the block-Jacobi solver");
   m->N = 3 * m->lv[last].A.n;
-  if (m->N > 1536) return fail("amg_create: coarsest level too large (" + std::to_string(m->N) + " unknowns)");
-  if (sizeof(double) * 2 * m->N > 64 * 1024) return fail("amg_create: coarsest level exceeds the LDS staging buffer");
-  m->inv = dev_alloc<double>(m->pool, (size_t)m->N * m->N);
+  m->Np = (m->N + kGjB - 1) / kGjB * kGjB;
+  if (m->N > 3072) return fail("amg_create: coarsest level too large (" + std::to_string(m->N) + " unknowns)");
+  m->inv = dev_alloc<double>(m->pool, (size_t)m->Np * m->Np);
+  m->gjP = dev_alloc<double>(m->pool, kGjB * kGjB);
   m->d_fail = dev_alloc<int>(m->pool, 1);
-  if (!m->inv || !m->d_fail) return fail("amg_create: out of device memory");
+  if (!m->inv || !m->d_fail || !m->gjP) return fail("amg_create: out of device memory");
   hipMemsetAsync(m->d_fail, 0, sizeof(int), s);
   // levels small enough for the single-workgroup tree kernel
+  int tree_rows = 2048;
+  if (const char* e = std::getenv("SGO_AMG_TREE_ROWS")) tree_rows = std::atoi(e);
   for (int l = 1; l < last; ++l)
-    if (m->lv[l].A.n <= 2048 && m->lv[l].A.nslot <= 40000 && last - l + 1 <= kTreeMaxLevels) {
+    if (m->lv[l].A.n <= tree_rows && m->lv[l].A.nslot <= 40000 && last - l + 1 <= kTreeMaxLevels) {
       m->tree_start = l;
       break;
     }
@@ -1026,6 +1059,7 @@ Amg* amg_create(hipStream_t s, const BsrDev& A0, const double* d_poses, const in
     CoarseTree& T = m->tree;
     T.nlev = last - m->tree_start + 1;
     T.N = m->N;
+    T.Np = m->Np;
     T.inv = m->inv;
     T.omega = m->cfg.omega;
     for (int k = 0; k < T.nlev; ++k) {
@@ -1039,7 +1073,6 @@ Amg* amg_create(hipStream_t s, const BsrDev& A0, const double* d_poses, const in
     hipMemcpyAsync(m->d_tree, &m->tree, sizeof(CoarseTree), hipMemcpyHostToDevice, s);
     if (hipStreamSynchronize(s) != hipSuccess) return fail("amg_create: tree upload failed");
   }
-  hipFuncSetAttribute((const void*)k_dense_invert_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
   std::snprintf(line, sizeof line, "coarsest dense N=%d; tree from L%d; theta=%.3g omega=%.2f", m->N, m->tree_start,
                 m->cfg.theta, m->cfg.omega);
   m->desc += line;
