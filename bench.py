@@ -167,13 +167,22 @@ def main():
             prof = p.kernel_profile()
         name, k = max(prof.items(), key=lambda kv: kv[1]["ms"])
         achieved = k["bytes"] / (k["ms"] * 1e-3) / 1e9
+        # HBM traffic of the same kernel from the separate rocprofv3 --pmc passes (FETCH_SIZE x2,
+        # WRITE_SIZE; scripts/pmc_summary.py), committed per round under profiles/
+        traffic, traffic_src = None, None
+        solver_name = {0: "bj", 1: "amg"}[opts.get("solver", capi.default_opts().solver)]
+        for cand in sorted(__import__("glob").glob(os.path.join(ROOT, "profiles", f"r*_pmc_traffic_{solver_name}_{args.config.lower()}.json"))):
+            kk = json.load(open(cand))["kernels"].get(name)
+            if kk:
+                traffic, traffic_src = kk["hbm_bytes_per_launch"], os.path.relpath(cand, ROOT)
         out["roofline"] = {
             "bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
             "avg_launch_us": 1e3 * k["ms"] / k["launches"], "launches": k["launches"],
             "algorithmic_bytes_per_launch": k["bytes"] / k["launches"],
             "note": "achieved = algorithmic bytes of all launches of this kernel (all multigrid levels) / their "
-                    "summed HIP-event time; per-kernel table below uses rocprofv3's kernel names",
+                    "summed HIP-event time (empty-bracket time calibrated and subtracted); traffic = mean HBM "
+                    "bytes per launch from rocprofv3 --pmc passes; per-kernel table uses rocprofv3's kernel names",
             "kernels": {n: {"launches": v["launches"], "ms": round(v["ms"], 3),
                             "avg_us": round(1e3 * v["ms"] / v["launches"], 2),
                             "GB/s": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)}
