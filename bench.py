@@ -106,9 +106,11 @@ def main():
     if args.tol:
         opts["pcg_tol"] = args.tol
     opt = capi.Optimizer(local_rank, **opts)
-    if world > 1:
+    if world > 1 or os.environ.get("SGO_BENCH_FORCE_COMM"):
+        # rendezvous for libsgo's own RCCL communicator: rank 0 makes the id, torch broadcasts it
         uid = [capi.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
+        if world > 1:
+            dist.broadcast_object_list(uid, src=0)
         opt.comm_init(world, rank, uid[0])
     opt.set_graph(*g.arrays())
 

@@ -12,7 +12,7 @@ namespace sgo {
 struct AmgConfig {
   double theta = 0.02;     // strength-of-connection threshold on level 0 (env SGO_AMG_THETA)
   double theta_coarse = 0.02;  // ... on the coarser levels (env SGO_AMG_THETA_COARSE)
-  double omega = 0.7;      // block-Jacobi damping (env SGO_AMG_OMEGA)
+  double omega = 0.8;      // block-Jacobi damping (env SGO_AMG_OMEGA)
   int max_levels = 10;
   int coarsest_nodes = 400;  // stop coarsening at or below this many nodes (dense inverse of 3x that
                            // fits the LDS-resident Gauss-Jordan up to N = 138)

@@ -185,16 +185,29 @@ __global__ __launch_bounds__(kBlock) void k_restrict(int ngrp, const int* __rest
   }
 }
 
-// x_i += T_i xc[agg(i)]
+// x_i += T_i (c1 u1 + c2 u2)[agg(i)]   (u2 may be null; scalars as in k_spmv's fused modes)
 __global__ __launch_bounds__(kBlock) void k_prolong_add(int n, const int* __restrict__ agg, const double* __restrict__ d,
-                                                        const double* __restrict__ xc, double* __restrict__ x,
-                                                        const PcgScalars* S) {
+                                                        const double* __restrict__ u1, SpmvRatio r1,
+                                                        const double* __restrict__ u2, SpmvRatio r2,
+                                                        double* __restrict__ x, const PcgScalars* S) {
   if (S && S->stop) return;
+  double c1 = 1.0, c2 = 0.0;
+  if (r1.num) {
+    const double den = block_reduce_parts(r1.den, r1.n_den), num = block_reduce_parts(r1.num, r1.n_num);
+    c1 = (den > 0.0 && isfinite(den) && isfinite(num)) ? num / den : 0.0;
+  }
+  if (u2) {
+    const double den = block_reduce_parts(r2.den, r2.n_den), num = block_reduce_parts(r2.num, r2.n_num);
+    c2 = (den > 0.0 && isfinite(den) && isfinite(num)) ? num / den : 0.0;
+  }
   for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
     const size_t a = 3 * (size_t)agg[i], o = 3 * (size_t)i;
-    const double u0 = xc[a], u1 = xc[a + 1], w = xc[a + 2];
-    x[o] += u0 - d[2 * (size_t)i + 1] * w;
-    x[o + 1] += u1 + d[2 * (size_t)i] * w;
+    double w0 = c1 * u1[a], w1 = c1 * u1[a + 1], w = c1 * u1[a + 2];
+    if (u2) {
+      w0 += c2 * u2[a]; w1 += c2 * u2[a + 1]; w += c2 * u2[a + 2];
+    }
+    x[o] += w0 - d[2 * (size_t)i + 1] * w;
+    x[o + 1] += w1 + d[2 * (size_t)i] * w;
     x[o + 2] += w;
   }
 }
@@ -689,6 +702,7 @@ struct AmgLevel {
   // work vectors [n][3]
   double *xs = nullptr, *rs = nullptr;                     // smoother state of cycle()
   double *bk = nullptr, *xk = nullptr, *z1 = nullptr, *z2 = nullptr, *q = nullptr;  // K-cycle FCG (levels >= 1)
+  double *bk2 = nullptr, *p2 = nullptr, *q2 = nullptr;     // residual after the first FCG step; second direction; A p2
   double *pA = nullptr, *pB = nullptr, *pC = nullptr;      // [2][kMaxPartials] each
 };
 
@@ -724,18 +738,29 @@ struct Scope {
 
 double bytes_spmv(const BsrDev& A) { return 80.0 * A.nslot + 48.0 * A.n; }
 
-// z = cycle(l, rhs): pre-smooth from zero + residual (fused), restrict, coarse solve (dense or
-// two FCG steps), prolong, post-smooth.  Optional partials of dotvec . out.  Returns grid of the
-// last kernel.
-int cycle(Amg* m, hipStream_t s, int l, const double* rhs, double* out, const double* dotvec, double* dotparts,
-          const PcgScalars* S, const double* dotvec2 = nullptr);
+// The coarse solution of level l as seen by its parent: xk (dense level) or the flexible-CG
+// combination c1 z1 + c2 p2 whose scalars are ratios of the partial sums the FCG SpMVs left
+// in pA / pB (never materialised: the consumers apply it on the fly).
+struct CoarseSol {
+  const double* u1 = nullptr;
+  const double* u2 = nullptr;
+  SpmvRatio c1, c2;
+};
 
-// two flexible-CG steps on level l for A xk = bk (bk is overwritten by the residual)
-void fcg(Amg* m, hipStream_t s, int l, const PcgScalars* S) {
+int cycle(Amg* m, hipStream_t s, int l, const double* rhs, const double* rhs_sub, const SpmvRatio& rhs_c,
+          double* rhs_out, double* out, const double* dotvec, double* dotparts, const PcgScalars* S,
+          const double* dotvec2 = nullptr);
+
+// Two flexible-CG steps on level l for A x = bk (Notay's K-cycle), with the vector updates
+// fused into the neighbouring SpMV-type launches:
+//   z1 = cycle(bk);               q = A z1            -> pA = (z1.q, z1.bk)     a1 = pA[1]/pA[0]
+//   z2 = cycle(bk - a1 q) [bk2];  q = A (z2 - b z1)   -> pC = (q.z2), b = pC[0]/pA[0]; p2 = z2 - b z1
+//                                                        pB = (p2.q, p2.bk2)      a2 = pB[1]/pB[0]
+//   x = a1 z1 + a2 p2   (returned as a CoarseSol)
+CoarseSol fcg(Amg* m, hipStream_t s, int l, const PcgScalars* S) {
   AmgLevel& L = m->lv[l];
-  const int n3 = 3 * L.A.n;
-  const int vgrid = grid_for(n3, kBlock);
-  cycle(m, s, l, L.bk, L.z1, nullptr, nullptr, S);
+  SpmvRatio none;
+  cycle(m, s, l, L.bk, nullptr, none, nullptr, L.z1, nullptr, nullptr, S);
   int gA;
   {
     SpmvArgs a{};
@@ -743,70 +768,86 @@ void fcg(Amg* m, hipStream_t s, int l, const PcgScalars* S) {
     Scope sc(m->prof, K_SPMV_AX, bytes_spmv(L.A));
     gA = launch_spmv_ex(s, L.A, SPMV_AX, a);
   }
-  {
-    Scope sc(m->prof, K_FCG, 5 * 8.0 * n3);
-    hipLaunchKernelGGL(k_fcg, dim3(vgrid), dim3(kBlock), 0, s, 0, n3, L.pA, gA, L.pA + kMaxPartials, gA, L.z1, L.q,
-                       L.xk, L.bk, S);
-  }
-  const int gC = cycle(m, s, l, L.bk, L.z2, L.q, L.pC, S);
-  {
-    Scope sc(m->prof, K_FCG, 3 * 8.0 * n3);
-    hipLaunchKernelGGL(k_fcg, dim3(vgrid), dim3(kBlock), 0, s, 1, n3, L.pA, gA, L.pC, gC, L.z1, (const double*)nullptr,
-                       L.z2, (double*)nullptr, S);
-  }
+  SpmvRatio a1{L.pA + kMaxPartials, gA, L.pA, gA};
+  const int gC = cycle(m, s, l, L.bk, L.q, a1, L.bk2, L.z2, L.q, L.pC, S);
   int gB;
   {
     SpmvArgs a{};
-    a.x = L.z2; a.y = L.q; a.dotA = L.z2; a.dotB = L.z2; a.dotC = L.bk; a.partials = L.pB; a.S = S;
-    Scope sc(m->prof, K_SPMV_AX, bytes_spmv(L.A));
-    gB = launch_spmv_ex(s, L.A, SPMV_AX, a);
+    a.x = L.z2; a.x2 = L.z1; a.x_out = L.p2; a.y = L.q2; a.dotC = L.bk2; a.partials = L.pB; a.S = S;
+    a.c1 = SpmvRatio{L.pC, gC, L.pA, gA};
+    Scope sc(m->prof, K_SPMV_AX_C, bytes_spmv(L.A) + 48.0 * L.A.nslot);
+    gB = launch_spmv_ex(s, L.A, SPMV_AX_C, a);
   }
-  {
-    Scope sc(m->prof, K_FCG, 3 * 8.0 * n3);
-    hipLaunchKernelGGL(k_fcg, dim3(vgrid), dim3(kBlock), 0, s, 2, n3, L.pB, gB, L.pB + kMaxPartials, gB, L.z2,
-                       (const double*)nullptr, L.xk, (double*)nullptr, S);
-  }
+  CoarseSol cs;
+  cs.u1 = L.z1;
+  cs.c1 = a1;
+  cs.u2 = L.p2;
+  cs.c2 = SpmvRatio{L.pB + kMaxPartials, gB, L.pB, gB};
+  return cs;
 }
 
-int cycle(Amg* m, hipStream_t s, int l, const double* rhs, double* out, const double* dotvec, double* dotparts,
-          const PcgScalars* S, const double* dotvec2) {
+// out = cycle(l, rhs'): rhs' = rhs - c rhs_sub when rhs_sub != nullptr (stored to rhs_out).
+// pre-smooth from zero + residual (one launch), restrict, coarse solve (dense inverse or two FCG
+// steps), prolongation fused into the post-smoothing launch on levels >= 1 (separate launch on
+// level 0, where the extra gathers would cost more than the launch).  Optional partials of
+// dotvec . out (and dotvec2 . out).  Returns the grid of the last kernel.
+int cycle(Amg* m, hipStream_t s, int l, const double* rhs, const double* rhs_sub, const SpmvRatio& rhs_c,
+          double* rhs_out, double* out, const double* dotvec, double* dotparts, const PcgScalars* S,
+          const double* dotvec2) {
   AmgLevel& L = m->lv[l];
   AmgLevel& C = m->lv[l + 1];
   const int last = (int)m->lv.size() - 1;
+  const double* rhs_eff = rhs;
   {
     SpmvArgs a{};
     a.b = rhs; a.y = L.rs; a.y2 = L.xs; a.omega = m->cfg.omega; a.S = S;
-    Scope sc(m->prof, K_SPMV_PRE_RESID, bytes_spmv(L.A) + 72.0 * L.A.nslot);
-    launch_spmv_ex(s, L.A, SPMV_PRE_RESID, a);
+    if (rhs_sub) {
+      a.bsub = rhs_sub; a.c1 = rhs_c; a.b_out = rhs_out;
+      rhs_eff = rhs_out;
+      Scope sc(m->prof, K_SPMV_PRE_RESID_S, bytes_spmv(L.A) + 120.0 * L.A.nslot);
+      launch_spmv_ex(s, L.A, SPMV_PRE_RESID_S, a);
+    } else {
+      Scope sc(m->prof, K_SPMV_PRE_RESID, bytes_spmv(L.A) + 72.0 * L.A.nslot);
+      launch_spmv_ex(s, L.A, SPMV_PRE_RESID, a);
+    }
   }
   {
     Scope sc(m->prof, K_RESTRICT, 40.0 * L.A.n + 24.0 * L.nc);
     hipLaunchKernelGGL(k_restrict, dim3(grid_for(L.mem_ngrp, kWavesPerBlock)), dim3(kBlock), 0, s, L.mem_ngrp, L.mem_grp,
                        L.mem, L.agg, L.d, L.rs, C.bk, S);
   }
+  CoarseSol cs;
   if (l + 1 == last) {
     Scope sc(m->prof, K_DENSE_APPLY, 8.0 * m->N * m->N);
     hipLaunchKernelGGL(k_dense_apply, dim3(grid_for(m->N, kWavesPerBlock)), dim3(kBlock), 0, s, m->N, m->Np, m->inv, C.bk,
                        C.xk, S);
+    cs.u1 = C.xk;
   } else if (m->tree_start >= 0 && l + 1 >= m->tree_start) {
     Scope sc(m->prof, K_COARSE_TREE, 0.0);
     hipLaunchKernelGGL(k_coarse_tree, dim3(1), dim3(kTreeThreads), sizeof(double) * m->N, s, (const CoarseTree*)m->d_tree, S);
+    cs.u1 = C.xk;
   } else {
-    fcg(m, s, l + 1, S);
-  }
-  {
-    Scope sc(m->prof, K_PROLONG, 68.0 * L.A.n);
-    hipLaunchKernelGGL(k_prolong_add, dim3(grid_for(L.A.n, kBlock)), dim3(kBlock), 0, s, L.A.n, L.agg, L.d, C.xk, L.xs, S);
+    cs = fcg(m, s, l + 1, S);
   }
   SpmvArgs a{};
-  a.x = L.xs; a.b = rhs; a.y = out; a.omega = m->cfg.omega; a.S = S;
+  a.x = L.xs; a.b = rhs_eff; a.y = out; a.omega = m->cfg.omega; a.S = S;
   if (dotvec) {
     a.dotA = dotvec;
     a.dotA2 = dotvec2;
     a.partials = dotparts;
   }
-  Scope sc(m->prof, K_SPMV_JACOBI, bytes_spmv(L.A) + 72.0 * L.A.n);
-  return launch_spmv_ex(s, L.A, SPMV_JACOBI, a);
+  if (l == 0) {
+    {
+      Scope sc(m->prof, K_PROLONG, 68.0 * L.A.n);
+      hipLaunchKernelGGL(k_prolong_add, dim3(grid_for(L.A.n, kBlock)), dim3(kBlock), 0, s, L.A.n, L.agg, L.d, cs.u1, cs.c1,
+                         cs.u2, cs.c2, L.xs, S);
+    }
+    Scope sc(m->prof, K_SPMV_JACOBI, bytes_spmv(L.A) + 72.0 * L.A.n);
+    return launch_spmv_ex(s, L.A, SPMV_JACOBI, a);
+  }
+  a.agg = L.agg; a.d = L.d; a.u1 = cs.u1; a.u2 = cs.u2; a.c1 = cs.c1; a.c2 = cs.c2;
+  Scope sc(m->prof, K_SPMV_JACOBI_P, bytes_spmv(L.A) + 72.0 * L.A.n + 68.0 * L.A.nslot);
+  return launch_spmv_ex(s, L.A, SPMV_JACOBI_P, a);
 }
 
 }  // namespace
@@ -865,7 +906,8 @@ int amg_update(Amg* m, hipStream_t s, std::string* err) {
 
 int amg_apply(Amg* m, hipStream_t s, const double* r, double* z, const double* dotvec, double* partials,
               const PcgScalars* S, const double* dotvec2) {
-  return cycle(m, s, 0, r, z, dotvec, partials, S, dotvec2);
+  SpmvRatio none;
+  return cycle(m, s, 0, r, nullptr, none, nullptr, z, dotvec, partials, S, dotvec2);
 }
 
 Amg* amg_create(hipStream_t s, const BsrDev& A0, const double* d_poses, const int* d_free_id, const AmgConfig& cfg_in,
@@ -916,10 +958,13 @@ Amg* amg_create(hipStream_t s, const BsrDev& A0, const double* d_poses, const in
       L.z1 = dev_alloc<double>(m->pool, n3);
       L.z2 = dev_alloc<double>(m->pool, n3);
       L.q = dev_alloc<double>(m->pool, n3);
+      L.bk2 = dev_alloc<double>(m->pool, n3);
+      L.p2 = dev_alloc<double>(m->pool, n3);
+      L.q2 = dev_alloc<double>(m->pool, n3);
       L.pA = dev_alloc<double>(m->pool, 2 * (size_t)kMaxPartials);
       L.pB = dev_alloc<double>(m->pool, 2 * (size_t)kMaxPartials);
       L.pC = dev_alloc<double>(m->pool, 2 * (size_t)kMaxPartials);
-      if (!L.pC) return fail("amg_create: out of device memory");
+      if (!L.pC || !L.bk2 || !L.p2 || !L.q2) return fail("amg_create: out of device memory");
       hipMemsetAsync(L.pA, 0, sizeof(double) * 2 * kMaxPartials, s);
       hipMemsetAsync(L.pB, 0, sizeof(double) * 2 * kMaxPartials, s);
       hipMemsetAsync(L.pC, 0, sizeof(double) * 2 * kMaxPartials, s);

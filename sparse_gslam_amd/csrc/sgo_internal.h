@@ -72,7 +72,17 @@ struct PcgScalars {
 };
 
 // k_spmv modes and arguments (see sgo_kernels.hip)
-enum : int { SPMV_AX = 0, SPMV_RESID = 1, SPMV_JACOBI = 2, SPMV_PRE_RESID = 3 };
+enum : int {
+  SPMV_AX = 0, SPMV_RESID = 1, SPMV_JACOBI = 2, SPMV_PRE_RESID = 3,
+  SPMV_JACOBI_P = 4, SPMV_PRE_RESID_S = 5, SPMV_AX_C = 6
+};
+// scalar = sum(num[0..n_num)) / sum(den[0..n_den)); num == den == nullptr means 1
+struct SpmvRatio {
+  const double* num = nullptr;
+  int n_num = 0;
+  const double* den = nullptr;
+  int n_den = 0;
+};
 struct SpmvArgs {
   const double* x = nullptr;     // gathered operand (unused by SPMV_PRE_RESID)
   double* y = nullptr;           // output
@@ -85,6 +95,16 @@ struct SpmvArgs {
   const double* dotC = nullptr;
   double* partials = nullptr;    // [2][kMaxPartials]
   const PcgScalars* S = nullptr; // optional early-out flag
+  // fused coarse-level variants
+  SpmvRatio c1, c2;
+  const int* agg = nullptr;      // JACOBI_P: aggregate of each vertex, lever arms d, coarse vectors u1, u2
+  const double* d = nullptr;
+  const double* u1 = nullptr;
+  const double* u2 = nullptr;
+  const double* bsub = nullptr;  // PRE_RESID_S: b' = b - c1 bsub, stored to b_out
+  double* b_out = nullptr;
+  const double* x2 = nullptr;    // AX_C: x' = x - c1 x2, stored to x_out
+  double* x_out = nullptr;
 };
 
 // One profiling slot per __global__ symbol (template instantiations separately), named as
@@ -100,6 +120,9 @@ enum KernelId : int {
   K_SPMV_RESID,
   K_SPMV_JACOBI,
   K_SPMV_PRE_RESID,
+  K_SPMV_JACOBI_P,
+  K_SPMV_PRE_RESID_S,
+  K_SPMV_AX_C,
   K_ALPHA,
   K_UPDATE_XR,
   K_BETA,

@@ -24,7 +24,7 @@ namespace sgo {
 
 const char* const kKernelNames[K_COUNT] = {
     "k_chi2",        "k_reduce2",  "k_linearize",   "k_finalize",   "k_init_scalars", "k_spmv<0>",  "k_spmv<1>",
-    "k_spmv<2>",     "k_spmv<3>",  "k_alpha",       "k_update_xr",  "k_beta",         "k_update_p", "k_dot",
+    "k_spmv<2>",     "k_spmv<3>",  "k_spmv<4>",     "k_spmv<5>",    "k_spmv<6>",      "k_alpha",       "k_update_xr",  "k_beta",         "k_update_p", "k_dot",
     "k_pose_update", "k_positions0", "k_centres",   "k_galerkin",   "k_level_dinv",   "k_restrict", "k_prolong_add",
     "k_fcg",         "k_gj_pivot+k_gj_step (dense inverse)", "k_dense_apply", "k_coarse_tree"};
 
@@ -271,19 +271,66 @@ __global__ __launch_bounds__(kBlock) void k_init_scalars(PcgScalars* S, const do
 }
 
 // ---------------------------------------------------------------------------- k_spmv
-// One lane per slot, wavefront segmented scan per row.  MODE selects the row epilogue:
-//   SPMV_AX         y = A x
-//   SPMV_RESID      y = b - A x
-//   SPMV_JACOBI     y = x + omega Dinv (b - A x)                 (damped block-Jacobi sweep)
-//   SPMV_PRE_RESID  y2 = omega Dinv b ; y = b - A y2              (first sweep from x = 0 fused
-//                   with the residual: the gathered operand is omega Dinv[col] b[col])
+// One lane per slot, wavefront segmented scan per row.  MODE selects operand and row epilogue:
+//   SPMV_AX           y = A x
+//   SPMV_RESID        y = b - A x
+//   SPMV_JACOBI       y = x + omega Dinv (b - A x)               (damped block-Jacobi sweep)
+//   SPMV_PRE_RESID    y2 = omega Dinv b ; y = b - A y2            (first sweep from x = 0 fused with
+//                     the residual: the gathered operand is omega Dinv[col] b[col])
+// Fused variants used on the coarse multigrid levels, where a launch costs more than its data
+// (DESIGN.md section 7); scalars c1, c2 are ratios of per-block partial sums that every block
+// reduces itself in a fixed order:
+//   SPMV_JACOBI_P     as JACOBI with x' = x + P (c1 u1 + c2 u2)   (prolongation of the coarse
+//                     correction, itself the FCG combination of the child level, fused in)
+//   SPMV_PRE_RESID_S  as PRE_RESID with b' = b - c1 bsub ; b_out = b'   (FCG residual update fused in)
+//   SPMV_AX_C         as AX with x' = x - c1 x2 ; x_out = x'       (FCG direction update fused in);
+//                     dots: partials[0] = x'.y, partials[1] = x'.dotC
 // Optional dot partials (row epilogue): partials[0] += dotA[row].out[row],
-// partials[1] += dotB[row].dotC[row].
+// partials[1] += dotA2[row].out[row]  or  dotB[row].dotC[row].
+__device__ __forceinline__ double ratio_of(const SpmvRatio& r) {
+  if (!r.num) return r.den ? 0.0 : 1.0;
+  const double den = block_reduce_parts(r.den, r.n_den);
+  const double num = block_reduce_parts(r.num, r.n_num);
+  return (den > 0.0 && isfinite(den) && isfinite(num)) ? num / den : 0.0;
+}
+
 template <int MODE>
 __global__ __launch_bounds__(kBlock) void k_spmv(BsrDev A, SpmvArgs a) {
   if (a.S && a.S->stop) return;
   const int lane = threadIdx.x & 63;
   const size_t ns = (size_t)A.nslot;
+  double c1 = 1.0, c2 = 0.0;
+  if (MODE == SPMV_JACOBI_P || MODE == SPMV_PRE_RESID_S || MODE == SPMV_AX_C) {
+    c1 = ratio_of(a.c1);
+    if (MODE == SPMV_JACOBI_P && a.u2) c2 = ratio_of(a.c2);
+  }
+  // operand of vertex v (3 doubles) under the mode's transformation
+  auto operand = [&](size_t v, double& x0, double& x1, double& x2) {
+    if (MODE == SPMV_PRE_RESID || MODE == SPMV_PRE_RESID_S) {
+      const double* di = A.dinv + 6 * v;
+      double b0 = a.b[3 * v], b1 = a.b[3 * v + 1], b2 = a.b[3 * v + 2];
+      if (MODE == SPMV_PRE_RESID_S) {
+        b0 -= c1 * a.bsub[3 * v]; b1 -= c1 * a.bsub[3 * v + 1]; b2 -= c1 * a.bsub[3 * v + 2];
+      }
+      x0 = a.omega * (di[0] * b0 + di[1] * b1 + di[2] * b2);
+      x1 = a.omega * (di[1] * b0 + di[3] * b1 + di[4] * b2);
+      x2 = a.omega * (di[2] * b0 + di[4] * b1 + di[5] * b2);
+    } else {
+      x0 = a.x[3 * v]; x1 = a.x[3 * v + 1]; x2 = a.x[3 * v + 2];
+      if (MODE == SPMV_JACOBI_P) {
+        const size_t ag = 3 * (size_t)a.agg[v];
+        double w0 = c1 * a.u1[ag], w1 = c1 * a.u1[ag + 1], w2 = c1 * a.u1[ag + 2];
+        if (a.u2) {
+          w0 += c2 * a.u2[ag]; w1 += c2 * a.u2[ag + 1]; w2 += c2 * a.u2[ag + 2];
+        }
+        x0 += w0 - a.d[2 * v + 1] * w2;
+        x1 += w1 + a.d[2 * v] * w2;
+        x2 += w2;
+      } else if (MODE == SPMV_AX_C) {
+        x0 -= c1 * a.x2[3 * v]; x1 -= c1 * a.x2[3 * v + 1]; x2 -= c1 * a.x2[3 * v + 2];
+      }
+    }
+  };
   double dotacc[2] = {0.0, 0.0};
   int g, gend, gstride;
   group_walk(A.ngrp, &g, &gend, &gstride);
@@ -293,17 +340,8 @@ __global__ __launch_bounds__(kBlock) void k_spmv(BsrDev A, SpmvArgs a) {
     int row = -1 - lane;
     for (int k = gb + lane; k < ge; k += 64) {
       row = A.row[k];
-      const int c = A.col[k];
       double x0, x1, x2;
-      if (MODE == SPMV_PRE_RESID) {
-        const double* di = A.dinv + 6 * (size_t)c;
-        const double b0 = a.b[3 * (size_t)c], b1 = a.b[3 * (size_t)c + 1], b2 = a.b[3 * (size_t)c + 2];
-        x0 = a.omega * (di[0] * b0 + di[1] * b1 + di[2] * b2);
-        x1 = a.omega * (di[1] * b0 + di[3] * b1 + di[4] * b2);
-        x2 = a.omega * (di[2] * b0 + di[4] * b1 + di[5] * b2);
-      } else {
-        x0 = a.x[3 * (size_t)c]; x1 = a.x[3 * (size_t)c + 1]; x2 = a.x[3 * (size_t)c + 2];
-      }
+      operand((size_t)A.col[k], x0, x1, x2);
       acc[0] += A.blk[k] * x0 + A.blk[ns + k] * x1 + A.blk[2 * ns + k] * x2;
       acc[1] += A.blk[3 * ns + k] * x0 + A.blk[4 * ns + k] * x1 + A.blk[5 * ns + k] * x2;
       acc[2] += A.blk[6 * ns + k] * x0 + A.blk[7 * ns + k] * x1 + A.blk[8 * ns + k] * x2;
@@ -313,28 +351,42 @@ __global__ __launch_bounds__(kBlock) void k_spmv(BsrDev A, SpmvArgs a) {
     if (row >= 0 && (lane == 63 || rn != row)) {
       const size_t o = 3 * (size_t)row;
       double o0 = acc[0], o1 = acc[1], o2 = acc[2];
-      if (MODE != SPMV_AX) {
-        const double r0 = a.b[o] - acc[0], r1 = a.b[o + 1] - acc[1], r2 = a.b[o + 2] - acc[2];
-        if (MODE == SPMV_JACOBI) {
+      if (MODE == SPMV_AX_C) {
+        double s0, s1, s2;
+        operand((size_t)row, s0, s1, s2);
+        a.x_out[o] = s0; a.x_out[o + 1] = s1; a.x_out[o + 2] = s2;
+        dotacc[0] += s0 * o0 + s1 * o1 + s2 * o2;
+        dotacc[1] += s0 * a.dotC[o] + s1 * a.dotC[o + 1] + s2 * a.dotC[o + 2];
+      } else if (MODE != SPMV_AX) {
+        double b0 = a.b[o], b1 = a.b[o + 1], b2 = a.b[o + 2];
+        if (MODE == SPMV_PRE_RESID_S) {
+          b0 -= c1 * a.bsub[o]; b1 -= c1 * a.bsub[o + 1]; b2 -= c1 * a.bsub[o + 2];
+          a.b_out[o] = b0; a.b_out[o + 1] = b1; a.b_out[o + 2] = b2;
+        }
+        const double r0 = b0 - acc[0], r1 = b1 - acc[1], r2 = b2 - acc[2];
+        if (MODE == SPMV_JACOBI || MODE == SPMV_JACOBI_P) {
           const double* di = A.dinv + 6 * (size_t)row;
-          o0 = a.x[o] + a.omega * (di[0] * r0 + di[1] * r1 + di[2] * r2);
-          o1 = a.x[o + 1] + a.omega * (di[1] * r0 + di[3] * r1 + di[4] * r2);
-          o2 = a.x[o + 2] + a.omega * (di[2] * r0 + di[4] * r1 + di[5] * r2);
+          double s0, s1, s2;
+          operand((size_t)row, s0, s1, s2);
+          o0 = s0 + a.omega * (di[0] * r0 + di[1] * r1 + di[2] * r2);
+          o1 = s1 + a.omega * (di[1] * r0 + di[3] * r1 + di[4] * r2);
+          o2 = s2 + a.omega * (di[2] * r0 + di[4] * r1 + di[5] * r2);
         } else {
           o0 = r0; o1 = r1; o2 = r2;
         }
-        if (MODE == SPMV_PRE_RESID) {
+        if (MODE == SPMV_PRE_RESID || MODE == SPMV_PRE_RESID_S) {
           const double* di = A.dinv + 6 * (size_t)row;
-          const double b0 = a.b[o], b1 = a.b[o + 1], b2 = a.b[o + 2];
           a.y2[o] = a.omega * (di[0] * b0 + di[1] * b1 + di[2] * b2);
           a.y2[o + 1] = a.omega * (di[1] * b0 + di[3] * b1 + di[4] * b2);
           a.y2[o + 2] = a.omega * (di[2] * b0 + di[4] * b1 + di[5] * b2);
         }
       }
       a.y[o] = o0; a.y[o + 1] = o1; a.y[o + 2] = o2;
-      if (a.dotA) dotacc[0] += a.dotA[o] * o0 + a.dotA[o + 1] * o1 + a.dotA[o + 2] * o2;
-      if (a.dotA2) dotacc[1] += a.dotA2[o] * o0 + a.dotA2[o + 1] * o1 + a.dotA2[o + 2] * o2;
-      else if (a.dotB) dotacc[1] += a.dotB[o] * a.dotC[o] + a.dotB[o + 1] * a.dotC[o + 1] + a.dotB[o + 2] * a.dotC[o + 2];
+      if (MODE != SPMV_AX_C) {
+        if (a.dotA) dotacc[0] += a.dotA[o] * o0 + a.dotA[o + 1] * o1 + a.dotA[o + 2] * o2;
+        if (a.dotA2) dotacc[1] += a.dotA2[o] * o0 + a.dotA2[o + 1] * o1 + a.dotA2[o + 2] * o2;
+        else if (a.dotB) dotacc[1] += a.dotB[o] * a.dotC[o] + a.dotB[o + 1] * a.dotC[o + 1] + a.dotB[o + 2] * a.dotC[o + 2];
+      }
     }
   }
   if (a.partials) block_sum_store<2>(dotacc, a.partials, kMaxPartials);
@@ -470,6 +522,9 @@ int launch_spmv_ex(hipStream_t s, const BsrDev& A, int mode, const SpmvArgs& a) 
     case SPMV_AX: hipLaunchKernelGGL(k_spmv<SPMV_AX>, dim3(grid), dim3(kBlock), 0, s, A, a); break;
     case SPMV_RESID: hipLaunchKernelGGL(k_spmv<SPMV_RESID>, dim3(grid), dim3(kBlock), 0, s, A, a); break;
     case SPMV_JACOBI: hipLaunchKernelGGL(k_spmv<SPMV_JACOBI>, dim3(grid), dim3(kBlock), 0, s, A, a); break;
+    case SPMV_JACOBI_P: hipLaunchKernelGGL(k_spmv<SPMV_JACOBI_P>, dim3(grid), dim3(kBlock), 0, s, A, a); break;
+    case SPMV_PRE_RESID_S: hipLaunchKernelGGL(k_spmv<SPMV_PRE_RESID_S>, dim3(grid), dim3(kBlock), 0, s, A, a); break;
+    case SPMV_AX_C: hipLaunchKernelGGL(k_spmv<SPMV_AX_C>, dim3(grid), dim3(kBlock), 0, s, A, a); break;
     default: hipLaunchKernelGGL(k_spmv<SPMV_PRE_RESID>, dim3(grid), dim3(kBlock), 0, s, A, a); break;
   }
   return grid;
