@@ -19,9 +19,13 @@
 //
 // Backend: a graph whose active vertices are all VertexSE2 and whose active edges are all EdgeSE2
 // (robust kernel: none or RobustKernelDCS) optimised with OptimizationAlgorithmGaussNewton -- the
-// reference's pose graph (graphs.cpp:17-23) -- runs on the GPU through sgo_optimize_gn.  Any other
-// combination (the landmark graph: Levenberg + VertexRhoTheta / EdgeSE2RhoTheta) is not executed
-// by this backend yet: optimize() reports it on std::cerr and returns -1 (no silent CPU path).
+// reference's pose graph (graphs.cpp:17-23), the hot path -- ALWAYS runs on the GPU through
+// sgo_optimize_gn; if the device or libsgo is unavailable optimize() fails loudly, there is no
+// CPU fallback for it.  Every other combination (the reference's landmark graph: Levenberg,
+// BlockSolverTraits<-1,2>, VertexRhoTheta / EdgeSE2RhoTheta with numeric Jacobians, graphs.cpp:9-15,
+// drone.cpp:146-187) is a tiny, latency-bound problem (pruned to one pose at every loop closure,
+// slc.cpp:257-262) and is solved by the small dense host solver at the end of this file
+// ("CPU path of the new backend suffices").
 #pragma once
 
 #if defined(__has_include)
@@ -41,6 +45,7 @@
 #include <cmath>
 #include <cstdint>
 #include <iostream>
+#include <limits>
 #include <map>
 #include <memory>
 #include <set>
@@ -182,6 +187,8 @@ class OptimizableGraph : public HyperGraph {
     void setFixed(bool f) { _fixed = f; }
     int hessianIndex() const { return _hessianIndex; }
     void setHessianIndex(int i) { _hessianIndex = i; }
+    int colInHessian() const { return _colInHessian; }
+    void setColInHessian(int c) { _colInHessian = c; }
     virtual int dimension() const = 0;
     virtual void oplus(const double* v) = 0;
     virtual void push() = 0;
@@ -192,6 +199,7 @@ class OptimizableGraph : public HyperGraph {
    protected:
     bool _fixed = false;
     int _hessianIndex = -1;
+    int _colInHessian = -1;
   };
   class Edge : public HyperGraph::Edge {
    public:
@@ -199,6 +207,9 @@ class OptimizableGraph : public HyperGraph {
     virtual int dimension() const = 0;
     virtual void computeError() = 0;
     virtual double chi2() const = 0;
+    virtual void linearizeOplus() = 0;
+    // adds this edge's J^T W J / -J^T W e into the dense normal equations (row-major H, ld = n)
+    virtual void constructQuadraticForm(double* H, int n, double* b) = 0;
     RobustKernel* robustKernel() const { return _robustKernel; }
     void setRobustKernel(RobustKernel* k) { _robustKernel = k; }
     int level() const { return _level; }
@@ -309,7 +320,7 @@ class BaseBinaryEdge : public OptimizableGraph::Edge {
 
   // numeric Jacobian by central differences (g2o's default when a subclass only defines
   // computeError, e.g. src/sparse_gslam/src/g2o_bindings/edge_se2_rhotheta.cpp:9-16)
-  virtual void linearizeOplus() {
+  void linearizeOplus() override {
     const double delta = 1e-9, scalar = 1.0 / (2 * delta);
     ErrorVector errorBak = _error;
     for (int side = 0; side < 2; ++side) {
@@ -339,6 +350,57 @@ class BaseBinaryEdge : public OptimizableGraph::Edge {
       }
     }
     _error = errorBak;
+  }
+  // BaseBinaryEdge::constructQuadraticForm (+ robustInformation with the second-order term
+  // disabled, as upstream): b -= J^T (rho1 Omega) e ; H += J^T (rho1 Omega) J
+  void constructQuadraticForm(double* H, int n, double* b) override {
+    OptimizableGraph::Vertex* from = static_cast<OptimizableGraph::Vertex*>(_vertices[0]);
+    OptimizableGraph::Vertex* to = static_cast<OptimizableGraph::Vertex*>(_vertices[1]);
+    const bool fromNotFixed = !from->fixed(), toNotFixed = !to->fixed();
+    if (!fromNotFixed && !toNotFixed) return;
+    double w = 1.0;
+    if (robustKernel()) {
+      Vector3 rho;
+      robustKernel()->robustify(chi2(), rho);
+      w = rho[1];
+    }
+    const int Di = VertexXi::Dimension, Dj = VertexXj::Dimension;
+    double Oe[D];
+    for (int r = 0; r < D; ++r) {
+      double s = 0;
+      for (int c = 0; c < D; ++c) s += _information(r, c) * _error[c];
+      Oe[r] = w * s;
+    }
+    const int ci = from->colInHessian(), cj = to->colInHessian();
+    auto JtOJ = [&](auto& Ja, int da, int ca, auto& Jb, int db, int cb) {
+      for (int p = 0; p < da; ++p)
+        for (int q = 0; q < db; ++q) {
+          double s = 0;
+          for (int r = 0; r < D; ++r)
+            for (int c = 0; c < D; ++c) s += Ja(r, p) * w * _information(r, c) * Jb(c, q);
+          H[(size_t)(ca + p) * n + cb + q] += s;
+        }
+    };
+    if (fromNotFixed) {
+      for (int p = 0; p < Di; ++p) {
+        double s = 0;
+        for (int r = 0; r < D; ++r) s += _jacobianOplusXi(r, p) * Oe[r];
+        b[ci + p] -= s;
+      }
+      JtOJ(_jacobianOplusXi, Di, ci, _jacobianOplusXi, Di, ci);
+    }
+    if (toNotFixed) {
+      for (int p = 0; p < Dj; ++p) {
+        double s = 0;
+        for (int r = 0; r < D; ++r) s += _jacobianOplusXj(r, p) * Oe[r];
+        b[cj + p] -= s;
+      }
+      JtOJ(_jacobianOplusXj, Dj, cj, _jacobianOplusXj, Dj, cj);
+    }
+    if (fromNotFixed && toNotFixed) {
+      JtOJ(_jacobianOplusXi, Di, ci, _jacobianOplusXj, Dj, cj);
+      JtOJ(_jacobianOplusXj, Dj, cj, _jacobianOplusXi, Di, ci);
+    }
   }
   virtual bool read(std::istream& is) = 0;
   virtual bool write(std::ostream& os) const = 0;
@@ -565,11 +627,7 @@ class SparseOptimizer : public OptimizableGraph {
     bool anyFree = false;
     for (auto* v : _activeVertices) anyFree = anyFree || !v->fixed();
     if (_activeVertices.empty() || !anyFree) return -1;
-    if (!gpuEligible()) {
-      std::cerr << "SparseOptimizer::optimize: this graph (vertex/edge types or algorithm) is not the SE(2) "
-                   "Gauss-Newton pose-graph path; the sgo backend does not execute it yet" << std::endl;
-      return -1;
-    }
+    if (!gpuEligible()) return hostOptimize(iterations, online);
     if (!uploadGraph()) return 0;
     sgo_stats* st = new sgo_stats();
     int done = sgo_optimize_gn(_ctx, iterations, st);
@@ -625,6 +683,122 @@ class SparseOptimizer : public OptimizableGraph {
   }
 
  private:
+  // ---- small dense host solver for graphs that are not the SE(2) GN pose graph -----------------
+  // OptimizationAlgorithmGaussNewton::solve / OptimizationAlgorithmLevenberg::solve of g2o
+  // 2020.5.29 on dense normal equations (the landmark graph has <= a few hundred unknowns).
+  bool hostBuildSystem(std::vector<double>& H, std::vector<double>& b, int n) {
+    std::fill(H.begin(), H.end(), 0.0);
+    std::fill(b.begin(), b.end(), 0.0);
+    for (auto* e : _activeEdges) {
+      e->linearizeOplus();
+      e->constructQuadraticForm(H.data(), n, b.data());
+    }
+    return true;
+  }
+  static bool hostCholeskySolve(std::vector<double> A, const std::vector<double>& b, int n, std::vector<double>& x) {
+    for (int j = 0; j < n; ++j) {                     // in-place lower Cholesky
+      double d = A[(size_t)j * n + j];
+      for (int k = 0; k < j; ++k) d -= A[(size_t)j * n + k] * A[(size_t)j * n + k];
+      if (!(d > 0.0) || !std::isfinite(d)) return false;
+      d = std::sqrt(d);
+      A[(size_t)j * n + j] = d;
+      for (int i = j + 1; i < n; ++i) {
+        double s = A[(size_t)i * n + j];
+        for (int k = 0; k < j; ++k) s -= A[(size_t)i * n + k] * A[(size_t)j * n + k];
+        A[(size_t)i * n + j] = s / d;
+      }
+    }
+    x = b;
+    for (int i = 0; i < n; ++i) {
+      double s = x[i];
+      for (int k = 0; k < i; ++k) s -= A[(size_t)i * n + k] * x[k];
+      x[i] = s / A[(size_t)i * n + i];
+    }
+    for (int i = n - 1; i >= 0; --i) {
+      double s = x[i];
+      for (int k = i + 1; k < n; ++k) s -= A[(size_t)k * n + i] * x[k];
+      x[i] = s / A[(size_t)i * n + i];
+    }
+    for (double v : x)
+      if (!std::isfinite(v)) return false;
+    return true;
+  }
+  void hostUpdate(const std::vector<double>& x) {
+    for (auto* v : _activeVertices)
+      if (!v->fixed()) v->oplus(x.data() + v->colInHessian());
+  }
+  int hostOptimize(int iterations, bool online) {
+    (void)online;
+    int n = 0;
+    for (auto* v : _activeVertices) {
+      v->setColInHessian(v->fixed() ? -1 : n);
+      if (!v->fixed()) n += v->dimension();
+    }
+    if (n == 0) return -1;
+    const bool lm = _algorithm->kind() == OptimizationAlgorithm::Levenberg;
+    std::vector<double> H((size_t)n * n), b(n), x(n);
+    int cjIterations = 0;
+    bool ok = true, failed = false;
+    for (int it = 0; it < iterations && ok; ++it) {
+      computeActiveErrors();
+      double currentChi = activeRobustChi2();
+      hostBuildSystem(H, b, n);
+      if (!lm) {  // Gauss-Newton: one undamped step
+        if (!hostCholeskySolve(H, b, n, x)) {
+          std::cerr << "SparseOptimizer::optimize: Cholesky failure, solving failed" << std::endl;
+          failed = true;
+          break;
+        }
+        hostUpdate(x);
+        ++cjIterations;
+        continue;
+      }
+      if (it == 0) {  // computeLambdaInit: tau * max diagonal, tau = 1e-5
+        double maxDiag = 0;
+        for (int j = 0; j < n; ++j) maxDiag = std::max(std::fabs(H[(size_t)j * n + j]), maxDiag);
+        _lmLambda = 1e-5 * maxDiag;
+        _lmNi = 2.0;
+      }
+      double rho = 0;
+      int qmax = 0;
+      do {
+        push();
+        std::vector<double> Hl(H);
+        for (int j = 0; j < n; ++j) Hl[(size_t)j * n + j] += _lmLambda;
+        const bool ok2 = hostCholeskySolve(Hl, b, n, x);
+        double tempChi = std::numeric_limits<double>::max();
+        double scale = 1e-3;
+        if (ok2) {
+          hostUpdate(x);
+          computeActiveErrors();
+          tempChi = activeRobustChi2();
+          for (int j = 0; j < n; ++j) scale += x[j] * (_lmLambda * x[j] + b[j]);
+        }
+        rho = (currentChi - tempChi) / scale;
+        if (rho > 0 && std::isfinite(tempChi) && ok2) {  // accept
+          double alpha = 1. - std::pow((2 * rho - 1), 3);
+          alpha = std::min(alpha, 2. / 3.);
+          const double scaleFactor = std::max(1. / 3., alpha);
+          _lmLambda *= scaleFactor;
+          _lmNi = 2;
+          currentChi = tempChi;
+          discardTop();
+        } else {  // reject: restore and increase the damping
+          _lmLambda *= _lmNi;
+          _lmNi *= 2;
+          pop();
+          if (!std::isfinite(_lmLambda)) break;
+        }
+        qmax++;
+      } while (rho < 0 && qmax < 10);
+      ++cjIterations;
+      if (qmax == 10 || rho == 0 || !std::isfinite(_lmLambda)) ok = false;  // Terminate
+    }
+    if (failed) return 0;
+    return cjIterations;
+  }
+  double _lmLambda = 0.0, _lmNi = 2.0;
+
   bool gpuEligible() const {
     if (_algorithm->kind() != OptimizationAlgorithm::GaussNewton) return false;
     for (auto* v : _activeVertices)

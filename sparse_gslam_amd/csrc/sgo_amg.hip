@@ -17,8 +17,10 @@
 //     iteration (values change, structure does not): one lane per fine slot in coarse-slot
 //     order, wavefront segmented scan per coarse slot -- no atomics, bitwise reproducible;
 //   * cycle: K-cycle (two flexible-CG steps per intermediate level, Notay's AGMG scheme) with
-//     one damped block-Jacobi sweep before and after; the coarsest level (<= ~100 nodes) is
-//     solved with an explicit dense inverse computed once per GN iteration.
+//     one damped block-Jacobi sweep before and after; the coarsest level (<= 400 nodes) is
+//     solved with an explicit dense inverse recomputed every GN iteration (blocked Gauss-Jordan);
+//     on the coarse levels the prolongation and the FCG vector updates are fused into the
+//     SpMV-type launches (k_spmv<4..6>) because a launch there costs more than its data.
 // All launches go to the caller's stream with fixed pointers, so a whole PCG iteration
 // including the cycle is captured into one hipGraph.
 #include <algorithm>
@@ -209,31 +211,6 @@ __global__ __launch_bounds__(kBlock) void k_prolong_add(int n, const int* __rest
     x[o] += w0 - d[2 * (size_t)i + 1] * w;
     x[o + 1] += w1 + d[2 * (size_t)i] * w;
     x[o + 2] += w;
-  }
-}
-
-// Flexible-CG updates of the K-cycle.  Scalars come from per-block partials reduced by every
-// block in the same fixed order (deterministic, no extra launch).
-//   mode 0: alpha = pB/pA; xk = alpha p ; bk -= alpha q
-//   mode 1: beta = pC/pA ; z2 -= beta z1                      (p2 = z2 - (z2.q1 / z1.q1) z1)
-//   mode 2: alpha = pB/pA; xk += alpha p
-__global__ __launch_bounds__(kBlock) void k_fcg(int mode, int n3, const double* __restrict__ partsA, int nA,
-                                                const double* __restrict__ partsB, int nB, const double* __restrict__ p,
-                                                const double* __restrict__ q, double* __restrict__ xk,
-                                                double* __restrict__ bk, const PcgScalars* S) {
-  if (S && S->stop) return;
-  const double den = block_reduce_parts(partsA, nA);
-  const double num = block_reduce_parts(partsB, nB);
-  const double a = (den > 0.0 && isfinite(den) && isfinite(num)) ? num / den : 0.0;
-  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n3; i += gridDim.x * kBlock) {
-    if (mode == 0) {
-      xk[i] = a * p[i];
-      bk[i] -= a * q[i];
-    } else if (mode == 1) {
-      xk[i] -= a * p[i];
-    } else {
-      xk[i] += a * p[i];
-    }
   }
 }
 

@@ -135,7 +135,6 @@ enum KernelId : int {
   K_LEVEL_DINV,
   K_RESTRICT,
   K_PROLONG,
-  K_FCG,
   K_DENSE_INVERT,
   K_DENSE_APPLY,
   K_COARSE_TREE,

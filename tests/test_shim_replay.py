@@ -67,3 +67,18 @@ def test_call_site_replay_matches_oracle(tmp_path):
     assert abs(float(c2) - s2["chi2"][-1]) <= 1e-6 * s2["chi2"][-1]
     assert abs(float(r2) - s2["robust_chi2"][-1]) <= 1e-6 * s2["robust_chi2"][-1]
     assert np.abs(P - P2).max() <= 1e-6
+
+
+def test_landmark_graph_types_run_on_the_host_solver():
+    """The non-hot-path half of the surface (drone.cpp:146-187, graphs.cpp:9-15): user-defined 2-dof
+    vertex + computeError-only edge (numeric Jacobians), Levenberg-Marquardt, push/pop/discardTop,
+    updateInitialization.  Exact measurements => LM returns to the ground truth; an inconsistent
+    observation raises chi2 and pop() restores the accepted estimates.  No GPU involved."""
+    subprocess.check_call(["make", "-s", "-C", CPP, "landmark_graph"])
+    out = subprocess.run([os.path.join(CPP, "landmark_graph")], capture_output=True, text=True, check=True).stdout.split()
+    chi2_before, chi2_after, its, perr, lerr, chi2_bad, chi2_restored, dof = map(float, out)
+    assert chi2_before > 10 and chi2_after < 1e-18 and 1 <= its <= 15
+    assert perr < 1e-9 and lerr < 1e-9
+    assert chi2_bad > 100 * max(chi2_after, 1e-20) and chi2_bad > 10
+    assert chi2_restored < 1e-18
+    assert dof == 7 * 3 + 20 * 2
