@@ -167,6 +167,7 @@ def main():
             p.profile_reset()
             p.optimize(min(args.iters, 4))
             prof = p.kernel_profile()
+            overhead_us = 1e3 * p.profile_overhead_ms()
         name, k = max(prof.items(), key=lambda kv: kv[1]["ms"])
         achieved = k["bytes"] / (k["ms"] * 1e-3) / 1e9
         # HBM traffic of the same kernel from the separate rocprofv3 --pmc passes (FETCH_SIZE x2,
@@ -181,9 +182,11 @@ def main():
             "bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
             "avg_launch_us": 1e3 * k["ms"] / k["launches"], "launches": k["launches"],
+            "event_bracket_overhead_us": overhead_us,
             "algorithmic_bytes_per_launch": k["bytes"] / k["launches"],
             "note": "achieved = algorithmic bytes of all launches of this kernel (all multigrid levels) / their "
-                    "summed HIP-event time (empty-bracket time calibrated and subtracted); traffic = mean HBM "
+                    "summed HIP-event time (an empty event bracket alone measures event_bracket_overhead_us, so "
+                    "avg_launch_us exceeds rocprofv3's kernel duration by up to that much); traffic = mean HBM "
                     "bytes per launch from rocprofv3 --pmc passes; per-kernel table uses rocprofv3's kernel names",
             "kernels": {n: {"launches": v["launches"], "ms": round(v["ms"], 3),
                             "avg_us": round(1e3 * v["ms"] / v["launches"], 2),

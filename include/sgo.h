@@ -152,6 +152,9 @@ typedef struct sgo_kernel_stat {
 } sgo_kernel_stat;
 int sgo_kernel_profile(sgo_ctx* ctx, sgo_kernel_stat* out, int cap);
 int sgo_profile_reset(sgo_ctx* ctx);
+/* Milliseconds an EMPTY event bracket measures on this context's stream: the upper bound of the
+ * per-launch bias of sgo_kernel_profile's times relative to rocprofv3 kernel durations. */
+double sgo_profile_overhead_ms(sgo_ctx* ctx);
 
 /* ---- multi-GPU: one process per GPU, RCCL over xGMI ------------------------------------------
  * Every rank is given the SAME full graph.  Per GN iteration rank r evaluates the edge

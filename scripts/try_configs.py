@@ -25,5 +25,5 @@ for name in names:
         o.set_graph(*g.arrays())
         ts = time.time() - t
         done, st = o.optimize(iters)
-    print(f"{name}: gen {tg:.1f}s setup {ts:.2f}s done={done} pcg={st['pcg_iters']} conv={st['pcg_converged']} "
+    print(f"{name}: gen {tg:.1f}s setup {ts:.2f}s done={done} pcg={st['pcg_iters']} "
           f"gn_ms={[round(1e3 * s, 1) for s in st['seconds']]} chi2={st['chi2'][0]:.6g}->{st['chi2'][-1]:.6g}", flush=True)

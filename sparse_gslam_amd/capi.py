@@ -25,7 +25,7 @@ SYMBOLS = [
     "sgo_version", "sgo_default_opts", "sgo_create", "sgo_destroy", "sgo_set_graph_se2",
     "sgo_set_poses", "sgo_get_poses", "sgo_optimize_gn", "sgo_chi2", "sgo_edge_chi2",
     "sgo_num_free", "sgo_free_ids", "sgo_linearize", "sgo_hessian_apply", "sgo_solve",
-    "sgo_precondition", "sgo_kernel_profile", "sgo_profile_reset", "sgo_comm_unique_id",
+    "sgo_precondition", "sgo_kernel_profile", "sgo_profile_reset", "sgo_profile_overhead_ms", "sgo_comm_unique_id",
     "sgo_comm_init", "sgo_comm_size", "sgo_shard_range", "sgo_debug_set_shard", "sgo_last_error",
 ]
 
@@ -103,6 +103,8 @@ def lib():
     L.sgo_precondition.argtypes = [vp, d, d]
     L.sgo_kernel_profile.argtypes = [vp, C.POINTER(KernelStat), C.c_int]
     L.sgo_profile_reset.argtypes = [vp]
+    L.sgo_profile_overhead_ms.restype = C.c_double
+    L.sgo_profile_overhead_ms.argtypes = [vp]
     L.sgo_comm_unique_id.argtypes = [vp]
     L.sgo_comm_init.argtypes = [vp, C.c_int, C.c_int, vp]
     L.sgo_comm_size.argtypes = [vp]
@@ -292,6 +294,9 @@ class Optimizer:
                 out[arr[k].name.decode()] = dict(launches=int(arr[k].launches), ms=arr[k].ms,
                                                  bytes=arr[k].bytes)
         return out
+
+    def profile_overhead_ms(self):
+        return lib().sgo_profile_overhead_ms(self._h)
 
     def profile_reset(self):
         self._check(lib().sgo_profile_reset(self._h), "sgo_profile_reset")

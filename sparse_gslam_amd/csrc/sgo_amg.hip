@@ -234,39 +234,27 @@ __global__ __launch_bounds__(kBlock) void k_dense_fill(BsrDev A, int Np, double*
   for (int i = N + blockIdx.x * kBlock + threadIdx.x; i < Np; i += gridDim.x * kBlock) M[(size_t)i * Np + i] = 1.0;
 }
 
-// P = inv(A_KK) by scalar Gauss-Jordan in LDS (one workgroup)
-__global__ __launch_bounds__(kBlock) void k_gj_pivot(double* __restrict__ M, int Np, int kb, double* __restrict__ P,
-                                                     int* __restrict__ fail) {
+// P = inv(A_KK) by scalar Gauss-Jordan (one workgroup, one thread per matrix element: the element
+// lives in a register, only the pivot row / column travel through LDS; 2 barriers per step)
+__global__ __launch_bounds__(kGjB * kGjB) void k_gj_pivot(double* __restrict__ M, int Np, int kb, double* __restrict__ P,
+                                                          int* __restrict__ fail) {
   __shared__ double a[kGjB][kGjB + 1];
-  __shared__ double prow[kGjB], pcol[kGjB];
-  __shared__ double piv;
-  const int t = threadIdx.x, base = kb * kGjB;
-  for (int e = t; e < kGjB * kGjB; e += kBlock) a[e / kGjB][e % kGjB] = M[(size_t)(base + e / kGjB) * Np + base + e % kGjB];
+  const int i = threadIdx.x / kGjB, j = threadIdx.x % kGjB, base = kb * kGjB;
+  double v = M[(size_t)(base + i) * Np + base + j];
+  a[i][j] = v;
   __syncthreads();
   for (int k = 0; k < kGjB; ++k) {
-    if (t == 0) {
-      const double v = a[k][k];
-      if (!(v > 0.0) || !isfinite(v)) *fail = 1;
-      piv = (v != 0.0) ? 1.0 / v : 0.0;
-    }
+    const double akk = a[k][k], akj = a[k][j], aik = a[i][k];
+    if (threadIdx.x == 0 && (!(akk > 0.0) || !isfinite(akk))) *fail = 1;
+    const double p = (akk != 0.0) ? 1.0 / akk : 0.0;
+    if (i == k) v = (j == k) ? p : akj * p;
+    else if (j == k) v = -aik * p;
+    else v = v - aik * (akj * p);
     __syncthreads();
-    const double p = piv;
-    if (t < kGjB) {
-      prow[t] = (t == k) ? 0.0 : a[k][t] * p;
-      pcol[t] = (t == k) ? 0.0 : a[t][k];
-    }
-    __syncthreads();
-    for (int e = t; e < kGjB * kGjB; e += kBlock) {
-      const int i = e / kGjB, j = e % kGjB;
-      double v;
-      if (i == k) v = (j == k) ? p : prow[j];
-      else if (j == k) v = -pcol[i] * p;
-      else v = a[i][j] - pcol[i] * prow[j];
-      a[i][j] = v;
-    }
+    a[i][j] = v;
     __syncthreads();
   }
-  for (int e = t; e < kGjB * kGjB; e += kBlock) P[e] = a[e / kGjB][e % kGjB];
+  P[threadIdx.x] = v;
 }
 
 // C = alpha * X * Y for 32x32 tiles held in LDS; each of the 256 threads produces 4 entries
@@ -752,7 +740,7 @@ CoarseSol fcg(Amg* m, hipStream_t s, int l, const PcgScalars* S) {
     SpmvArgs a{};
     a.x = L.z2; a.x2 = L.z1; a.x_out = L.p2; a.y = L.q2; a.dotC = L.bk2; a.partials = L.pB; a.S = S;
     a.c1 = SpmvRatio{L.pC, gC, L.pA, gA};
-    Scope sc(m->prof, K_SPMV_AX_C, bytes_spmv(L.A) + 48.0 * L.A.nslot);
+    Scope sc(m->prof, K_SPMV_AX_C, 80.0 * L.A.nslot + 120.0 * L.A.n);
     gB = launch_spmv_ex(s, L.A, SPMV_AX_C, a);
   }
   CoarseSol cs;
@@ -778,13 +766,14 @@ int cycle(Amg* m, hipStream_t s, int l, const double* rhs, const double* rhs_sub
   {
     SpmvArgs a{};
     a.b = rhs; a.y = L.rs; a.y2 = L.xs; a.omega = m->cfg.omega; a.S = S;
+    a.smoother_f32 = true;
     if (rhs_sub) {
       a.bsub = rhs_sub; a.c1 = rhs_c; a.b_out = rhs_out;
       rhs_eff = rhs_out;
-      Scope sc(m->prof, K_SPMV_PRE_RESID_S, bytes_spmv(L.A) + 120.0 * L.A.nslot);
+      Scope sc(m->prof, K_SPMV_PRE_RESID_S, 80.0 * L.A.nslot + 168.0 * L.A.n);
       launch_spmv_ex(s, L.A, SPMV_PRE_RESID_S, a);
     } else {
-      Scope sc(m->prof, K_SPMV_PRE_RESID, bytes_spmv(L.A) + 72.0 * L.A.nslot);
+      Scope sc(m->prof, K_SPMV_PRE_RESID, (L.A.blkf ? 44.0 : 80.0) * L.A.nslot + 120.0 * L.A.n);
       launch_spmv_ex(s, L.A, SPMV_PRE_RESID, a);
     }
   }
@@ -808,6 +797,7 @@ int cycle(Amg* m, hipStream_t s, int l, const double* rhs, const double* rhs_sub
   }
   SpmvArgs a{};
   a.x = L.xs; a.b = rhs_eff; a.y = out; a.omega = m->cfg.omega; a.S = S;
+  a.smoother_f32 = true;
   if (dotvec) {
     a.dotA = dotvec;
     a.dotA2 = dotvec2;
@@ -819,11 +809,11 @@ int cycle(Amg* m, hipStream_t s, int l, const double* rhs, const double* rhs_sub
       hipLaunchKernelGGL(k_prolong_add, dim3(grid_for(L.A.n, kBlock)), dim3(kBlock), 0, s, L.A.n, L.agg, L.d, cs.u1, cs.c1,
                          cs.u2, cs.c2, L.xs, S);
     }
-    Scope sc(m->prof, K_SPMV_JACOBI, bytes_spmv(L.A) + 72.0 * L.A.n);
+    Scope sc(m->prof, K_SPMV_JACOBI, (L.A.blkf ? 44.0 : 80.0) * L.A.nslot + 120.0 * L.A.n);
     return launch_spmv_ex(s, L.A, SPMV_JACOBI, a);
   }
   a.agg = L.agg; a.d = L.d; a.u1 = cs.u1; a.u2 = cs.u2; a.c1 = cs.c1; a.c2 = cs.c2;
-  Scope sc(m->prof, K_SPMV_JACOBI_P, bytes_spmv(L.A) + 72.0 * L.A.n + 68.0 * L.A.nslot);
+  Scope sc(m->prof, K_SPMV_JACOBI_P, 80.0 * L.A.nslot + 140.0 * L.A.n + 48.0 * L.nc);
   return launch_spmv_ex(s, L.A, SPMV_JACOBI_P, a);
 }
 
@@ -868,7 +858,7 @@ int amg_update(Amg* m, hipStream_t s, std::string* err) {
     hipMemsetAsync(m->inv, 0, sizeof(double) * (size_t)m->Np * m->Np, s);
     hipLaunchKernelGGL(k_dense_fill, dim3(grid_for(m->lv[last].A.nslot, kBlock)), dim3(kBlock), 0, s, m->lv[last].A, m->Np, m->inv);
     for (int kb = 0; kb < nb; ++kb) {
-      hipLaunchKernelGGL(k_gj_pivot, dim3(1), dim3(kBlock), 0, s, m->inv, m->Np, kb, m->gjP, m->d_fail);
+      hipLaunchKernelGGL(k_gj_pivot, dim3(1), dim3(kGjB * kGjB), 0, s, m->inv, m->Np, kb, m->gjP, m->d_fail);
       hipLaunchKernelGGL(k_gj_step, dim3(nb), dim3(kBlock), 0, s, 0, m->inv, m->Np, kb, (const double*)m->gjP);
       hipLaunchKernelGGL(k_gj_step, dim3(nb, nb), dim3(kBlock), 0, s, 1, m->inv, m->Np, kb, (const double*)m->gjP);
       hipLaunchKernelGGL(k_gj_step, dim3(nb), dim3(kBlock), 0, s, 2, m->inv, m->Np, kb, (const double*)m->gjP);

@@ -132,6 +132,9 @@ void free_graph(sgo_ctx* c) {
   }
   for (void* p : c->allocs) hipFree(p);
   c->allocs.clear();
+  c->A = BsrDev();
+  c->es = EdgeSlotsDev();
+  c->el = EdgeListDev();
   c->has_graph = false;
   c->linearized = false;
 }
@@ -147,9 +150,9 @@ hipEvent_t get_event(sgo_ctx* c) {
   hipEventCreate(&e);
   return e;
 }
-// An event pair with nothing between them still measures ~2-3 us on the queue; calibrate it once
-// (median of 33 empty brackets) and subtract it per launch so that the per-kernel averages are
-// comparable with rocprofv3's kernel durations.
+// An event pair with nothing between them still measures a few us on the queue; it is measured
+// once (median of 33 empty brackets) and REPORTED (sgo_profile_overhead_ms) as the bias bound of
+// the per-kernel averages relative to rocprofv3's kernel durations -- it is not subtracted.
 void prof_calibrate(sgo_ctx* c) {
   if (c->prof_null_ms >= 0.0) return;
   std::vector<float> v;
@@ -171,7 +174,7 @@ void prof_flush(sgo_ctx* c) {
   hipStreamSynchronize(c->stream);
   for (auto& r : c->pending) {
     float ms = 0.f;
-    if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) c->prof_ms[r.kid] += std::max(0.0, (double)ms - c->prof_null_ms);
+    if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) c->prof_ms[r.kid] += ms;
     c->ev_pool.push_back(r.a);
     c->ev_pool.push_back(r.b);
   }
@@ -315,6 +318,10 @@ int build_structure(sgo_ctx* c, int V, const double* poses, const uint8_t* fixed
   if ((rc = upload(c, &c->A.grp, grp))) return rc;
   if ((rc = upload(c, &c->A.rowptr, rowptr))) return rc;
   if ((rc = dalloc(c, &c->A.blk, 9 * (size_t)ns))) return rc;
+  // measured (round 1): the fp32 smoother copy halves the bytes of two level-0 passes but its 4-byte
+  // SoA loads run no faster than the 8-byte ones (18.2 vs 17.6 ms per GN iteration on C4): opt-in.
+  if (c->opts.solver == SGO_SOLVER_PCG_AMG && std::getenv("SGO_AMG_SMOOTHER_F32"))
+    if ((rc = dalloc(c, &c->A.blkf, 9 * (size_t)ns))) return rc;
   if ((rc = dalloc(c, &c->A.dinv, 6 * (size_t)n))) return rc;
   if ((rc = upload(c, &c->es.vi, svi))) return rc;
   if ((rc = upload(c, &c->es.vj, svj))) return rc;
@@ -397,6 +404,7 @@ int do_linearize(sgo_ctx* c) {
   if (c->comm.nranks > 1) {
     sgo_shard_range(c->A.ngrp, c->comm.nranks, c->comm.rank, &g0, &g1);
     HIP_TRY(c, hipMemsetAsync(c->A.blk, 0, sizeof(double) * 9 * (size_t)c->A.nslot, c->stream));
+    if (c->A.blkf) HIP_TRY(c, hipMemsetAsync(c->A.blkf, 0, sizeof(float) * 9 * (size_t)c->A.nslot, c->stream));
     HIP_TRY(c, hipMemsetAsync(c->d_dgb, 0, sizeof(double) * 9 * (size_t)c->n, c->stream));
   }
   {
@@ -406,6 +414,7 @@ int do_linearize(sgo_ctx* c) {
   if (c->comm.nranks > 1) {
     if (!c->comm.allreduce_f64(c->A.blk, 9 * (size_t)c->A.nslot, c->stream, &c->err)) return SGO_ECOMM;
     if (!c->comm.allreduce_f64(c->d_dgb, 9 * (size_t)c->n, c->stream, &c->err)) return SGO_ECOMM;
+    if (c->A.blkf) launch_blk_to_f32(c->stream, c->A);   // refresh the smoother's fp32 copy for all bands
   }
   int grid = 0;
   {
@@ -506,6 +515,41 @@ int run_pcg(sgo_ctx* c) {
         if (rc) return rc;
       }
     }
+  }
+  return SGO_OK;
+}
+
+// (Re)build the multigrid hierarchy from the CURRENT level-0 values (requires do_linearize).
+int build_amg(sgo_ctx* c) {
+  if (c->pcg_exec) {  // the captured PCG iteration references the old hierarchy's buffers
+    hipGraphExecDestroy(c->pcg_exec);
+    c->pcg_exec = nullptr;
+  }
+  if (c->amg) {
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    amg_destroy(c->amg);
+    c->amg = nullptr;
+  }
+  AmgConfig cfg;
+  AmgProf prof;
+  prof.user = c;
+  prof.begin = [](void* u, int kid, double bytes) {
+    sgo_ctx* cc = (sgo_ctx*)u;
+    cc->amg_scope = new Scope(cc, kid, bytes);
+  };
+  prof.end = [](void* u) {
+    sgo_ctx* cc = (sgo_ctx*)u;
+    delete (Scope*)cc->amg_scope;
+    cc->amg_scope = nullptr;
+  };
+  std::string aerr;
+  c->amg = amg_create(c->stream, c->A, c->d_poses, c->d_free_id, cfg, prof, &aerr);
+  if (c->amg) {
+    amg_describe(c->amg, &c->solver_desc);
+    c->solver_desc = "pcg_amg: " + c->solver_desc;
+  } else {
+    c->solver_desc = "pcg_block_jacobi (AMG unavailable: " + aerr + ")";
+    if (c->opts.verbose) std::fprintf(stderr, "[sgo] %s\n", c->solver_desc.c_str());
   }
   return SGO_OK;
 }
@@ -637,30 +681,9 @@ int sgo_set_graph_se2(sgo_ctx* c, int32_t V, const double* poses, const uint8_t*
   c->solver_desc = "pcg_block_jacobi";
   if (c->opts.solver == SGO_SOLVER_PCG_AMG && c->n > 64 && (c->comm.nranks == 1 || c->comm.handle)) {
     // the hierarchy is built from the Hessian at the initial poses (strength of connection)
-    if ((rc = do_linearize(c)) != SGO_OK) {
+    if ((rc = do_linearize(c)) != SGO_OK || (rc = build_amg(c)) != SGO_OK) {
       free_graph(c);
       return rc;
-    }
-    AmgConfig cfg;
-    AmgProf prof;
-    prof.user = c;
-    prof.begin = [](void* u, int kid, double bytes) {
-      sgo_ctx* cc = (sgo_ctx*)u;
-      cc->amg_scope = new Scope(cc, kid, bytes);
-    };
-    prof.end = [](void* u) {
-      sgo_ctx* cc = (sgo_ctx*)u;
-      delete (Scope*)cc->amg_scope;
-      cc->amg_scope = nullptr;
-    };
-    std::string aerr;
-    c->amg = amg_create(c->stream, c->A, c->d_poses, c->d_free_id, cfg, prof, &aerr);
-    if (c->amg) {
-      amg_describe(c->amg, &c->solver_desc);
-      c->solver_desc = "pcg_amg: " + c->solver_desc;
-    } else {
-      c->solver_desc = "pcg_block_jacobi (AMG unavailable: " + aerr + ")";
-      if (c->opts.verbose) std::fprintf(stderr, "[sgo] %s\n", c->solver_desc.c_str());
     }
     c->linearized = false;
   }
@@ -829,11 +852,26 @@ int sgo_optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
     for (auto& e : ev) hipEventDestroy(e);
   };
   int done = 0;
+  int best_pcg = 0, rebuilds = 0;
+  bool rebuild_next = false;
   for (int it = 0; it < iters; ++it) {
     hipEventRecord(ev[3 * it], c->stream);
     if ((rc = do_chi2(c, c->d_hist + 2 * it, nullptr)) || (rc = do_linearize(c))) {
       cleanup();
       return rc;
+    }
+    if (rebuild_next && c->amg) {
+      // The aggregation was made from the Hessian of an earlier linearisation; robust-kernel
+      // re-weighting has changed the strength of connection enough to more than double the PCG
+      // iterations: redo the set-up from the current values (same cost as in sgo_set_graph_se2).
+      if ((rc = build_amg(c)) || (rc = do_linearize(c))) {
+        cleanup();
+        return rc;
+      }
+      rebuild_next = false;
+      ++rebuilds;
+      best_pcg = 0;
+      if (c->opts.verbose) std::fprintf(stderr, "[sgo] multigrid hierarchy rebuilt before iteration %d\n", it);
     }
     hipEventRecord(ev[3 * it + 1], c->stream);
     if ((rc = run_pcg(c))) {
@@ -841,6 +879,10 @@ int sgo_optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
       return rc;
     }
     const PcgScalars S = *c->h_S;
+    if (c->amg && S.stop != 3) {
+      if (best_pcg == 0 || S.iter < best_pcg) best_pcg = S.iter;
+      if (S.iter > 2 * best_pcg + 10 && rebuilds < 3) rebuild_next = true;
+    }
     if (out) {
       out->pcg_iters[it] = S.iter;
       out->pcg_converged[it] = S.stop == 1;
@@ -901,6 +943,12 @@ int sgo_kernel_profile(sgo_ctx* c, sgo_kernel_stat* out, int cap) {
     out[k].bytes = c->prof_bytes[k];
   }
   return K_COUNT;
+}
+
+double sgo_profile_overhead_ms(sgo_ctx* c) {
+  if (!c) return -1.0;
+  if (c->prof_null_ms < 0.0) prof_calibrate(c);
+  return c->prof_null_ms;
 }
 
 int sgo_profile_reset(sgo_ctx* c) {

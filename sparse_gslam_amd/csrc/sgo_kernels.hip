@@ -197,6 +197,10 @@ __global__ __launch_bounds__(kBlock) void k_linearize(BsrDev A, int g0, int g1, 
       }
 #pragma unroll
       for (int c = 0; c < 9; ++c) A.blk[c * ns + k] = h[c];
+      if (A.blkf) {
+#pragma unroll
+        for (int c = 0; c < 9; ++c) A.blkf[c * ns + k] = (float)h[c];
+      }
     }
     seg_scan<9>(row, acc, lane);
     const int rn = __shfl_down(row, 1);
@@ -206,6 +210,12 @@ __global__ __launch_bounds__(kBlock) void k_linearize(BsrDev A, int g0, int g1, 
       for (int c = 0; c < 9; ++c) d[c] = acc[c];
     }
   }
+}
+
+// fp32 copy of all blocks (multi-GPU: after the all-reduce filled in the other ranks' bands)
+__global__ __launch_bounds__(kBlock) void k_blk_to_f32(BsrDev A) {
+  const size_t n = 9 * (size_t)A.nslot;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) A.blkf[i] = (float)A.blk[i];
 }
 
 // ---------------------------------------------------------------------------- k_finalize
@@ -226,6 +236,11 @@ __global__ __launch_bounds__(kBlock) void k_finalize(BsrDev A, const double* __r
     A.blk[0 * ns + k0] = s * d00; A.blk[1 * ns + k0] = s * d01; A.blk[2 * ns + k0] = s * d02;
     A.blk[3 * ns + k0] = s * d01; A.blk[4 * ns + k0] = s * d11; A.blk[5 * ns + k0] = s * d12;
     A.blk[6 * ns + k0] = s * d02; A.blk[7 * ns + k0] = s * d12; A.blk[8 * ns + k0] = s * d22;
+    if (A.blkf) {
+      A.blkf[0 * ns + k0] = (float)(s * d00); A.blkf[1 * ns + k0] = (float)(s * d01); A.blkf[2 * ns + k0] = (float)(s * d02);
+      A.blkf[3 * ns + k0] = (float)(s * d01); A.blkf[4 * ns + k0] = (float)(s * d11); A.blkf[5 * ns + k0] = (float)(s * d12);
+      A.blkf[6 * ns + k0] = (float)(s * d02); A.blkf[7 * ns + k0] = (float)(s * d12); A.blkf[8 * ns + k0] = (float)(s * d22);
+    }
     // symmetric 3x3 inverse by cofactors
     const double c00 = d11 * d22 - d12 * d12, c01 = d02 * d12 - d01 * d22, c02 = d01 * d12 - d02 * d11;
     const double c11 = d00 * d22 - d02 * d02, c12 = d01 * d02 - d00 * d12, c22 = d00 * d11 - d01 * d01;
@@ -294,11 +309,12 @@ __device__ __forceinline__ double ratio_of(const SpmvRatio& r) {
   return (den > 0.0 && isfinite(den) && isfinite(num)) ? num / den : 0.0;
 }
 
-template <int MODE>
+template <int MODE, typename BlkT>
 __global__ __launch_bounds__(kBlock) void k_spmv(BsrDev A, SpmvArgs a) {
   if (a.S && a.S->stop) return;
   const int lane = threadIdx.x & 63;
   const size_t ns = (size_t)A.nslot;
+  const BlkT* __restrict__ blk = sizeof(BlkT) == 4 ? (const BlkT*)A.blkf : (const BlkT*)A.blk;
   double c1 = 1.0, c2 = 0.0;
   if (MODE == SPMV_JACOBI_P || MODE == SPMV_PRE_RESID_S || MODE == SPMV_AX_C) {
     c1 = ratio_of(a.c1);
@@ -342,9 +358,9 @@ __global__ __launch_bounds__(kBlock) void k_spmv(BsrDev A, SpmvArgs a) {
       row = A.row[k];
       double x0, x1, x2;
       operand((size_t)A.col[k], x0, x1, x2);
-      acc[0] += A.blk[k] * x0 + A.blk[ns + k] * x1 + A.blk[2 * ns + k] * x2;
-      acc[1] += A.blk[3 * ns + k] * x0 + A.blk[4 * ns + k] * x1 + A.blk[5 * ns + k] * x2;
-      acc[2] += A.blk[6 * ns + k] * x0 + A.blk[7 * ns + k] * x1 + A.blk[8 * ns + k] * x2;
+      acc[0] += (double)blk[k] * x0 + (double)blk[ns + k] * x1 + (double)blk[2 * ns + k] * x2;
+      acc[1] += (double)blk[3 * ns + k] * x0 + (double)blk[4 * ns + k] * x1 + (double)blk[5 * ns + k] * x2;
+      acc[2] += (double)blk[6 * ns + k] * x0 + (double)blk[7 * ns + k] * x1 + (double)blk[8 * ns + k] * x2;
     }
     seg_scan<3>(row, acc, lane);
     const int rn = __shfl_down(row, 1);
@@ -506,6 +522,9 @@ void launch_linearize(hipStream_t s, const BsrDev& A, int g0, int g1, const Edge
   const int grid = grid_for(g1 - g0, kWavesPerBlock);
   hipLaunchKernelGGL(k_linearize, dim3(grid), dim3(kBlock), 0, s, A, g0, g1, es, poses, dgb);
 }
+void launch_blk_to_f32(hipStream_t s, const BsrDev& A) {
+  hipLaunchKernelGGL(k_blk_to_f32, dim3(grid_for(9LL * A.nslot, kBlock)), dim3(kBlock), 0, s, A);
+}
 void launch_finalize(hipStream_t s, const BsrDev& A, const double* dgb, int write_diag, double* b, double* x,
                      double* r, double* z, double* p, double* partials, int* grid_out) {
   const int grid = grid_for(A.n, kBlock);
@@ -518,14 +537,21 @@ void launch_init_scalars(hipStream_t s, PcgScalars* S, const double* rz_parts, i
 }
 int launch_spmv_ex(hipStream_t s, const BsrDev& A, int mode, const SpmvArgs& a) {
   const int grid = grid_for(A.ngrp, kWavesPerBlock);
+  const bool f32 = A.blkf != nullptr && a.smoother_f32;
   switch (mode) {
-    case SPMV_AX: hipLaunchKernelGGL(k_spmv<SPMV_AX>, dim3(grid), dim3(kBlock), 0, s, A, a); break;
-    case SPMV_RESID: hipLaunchKernelGGL(k_spmv<SPMV_RESID>, dim3(grid), dim3(kBlock), 0, s, A, a); break;
-    case SPMV_JACOBI: hipLaunchKernelGGL(k_spmv<SPMV_JACOBI>, dim3(grid), dim3(kBlock), 0, s, A, a); break;
-    case SPMV_JACOBI_P: hipLaunchKernelGGL(k_spmv<SPMV_JACOBI_P>, dim3(grid), dim3(kBlock), 0, s, A, a); break;
-    case SPMV_PRE_RESID_S: hipLaunchKernelGGL(k_spmv<SPMV_PRE_RESID_S>, dim3(grid), dim3(kBlock), 0, s, A, a); break;
-    case SPMV_AX_C: hipLaunchKernelGGL(k_spmv<SPMV_AX_C>, dim3(grid), dim3(kBlock), 0, s, A, a); break;
-    default: hipLaunchKernelGGL(k_spmv<SPMV_PRE_RESID>, dim3(grid), dim3(kBlock), 0, s, A, a); break;
+    case SPMV_AX: hipLaunchKernelGGL((k_spmv<SPMV_AX, double>), dim3(grid), dim3(kBlock), 0, s, A, a); break;
+    case SPMV_RESID: hipLaunchKernelGGL((k_spmv<SPMV_RESID, double>), dim3(grid), dim3(kBlock), 0, s, A, a); break;
+    case SPMV_JACOBI:
+      if (f32) hipLaunchKernelGGL((k_spmv<SPMV_JACOBI, float>), dim3(grid), dim3(kBlock), 0, s, A, a);
+      else hipLaunchKernelGGL((k_spmv<SPMV_JACOBI, double>), dim3(grid), dim3(kBlock), 0, s, A, a);
+      break;
+    case SPMV_JACOBI_P: hipLaunchKernelGGL((k_spmv<SPMV_JACOBI_P, double>), dim3(grid), dim3(kBlock), 0, s, A, a); break;
+    case SPMV_PRE_RESID_S: hipLaunchKernelGGL((k_spmv<SPMV_PRE_RESID_S, double>), dim3(grid), dim3(kBlock), 0, s, A, a); break;
+    case SPMV_AX_C: hipLaunchKernelGGL((k_spmv<SPMV_AX_C, double>), dim3(grid), dim3(kBlock), 0, s, A, a); break;
+    default:
+      if (f32) hipLaunchKernelGGL((k_spmv<SPMV_PRE_RESID, float>), dim3(grid), dim3(kBlock), 0, s, A, a);
+      else hipLaunchKernelGGL((k_spmv<SPMV_PRE_RESID, double>), dim3(grid), dim3(kBlock), 0, s, A, a);
+      break;
   }
   return grid;
 }
