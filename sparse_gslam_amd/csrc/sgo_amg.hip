@@ -678,6 +678,7 @@ struct Amg {
   std::vector<AmgLevel> lv;
   const double* d_poses = nullptr;
   const int* d_free_id = nullptr;
+  int kdepth = 1 << 20;  // levels <= kdepth use the K-cycle (two FCG steps), deeper ones a V-cycle
   int tree_start = -1;  // first level handled by k_coarse_tree (-1: none)
   CoarseTree tree;
   CoarseTree* d_tree = nullptr;
@@ -792,6 +793,10 @@ int cycle(Amg* m, hipStream_t s, int l, const double* rhs, const double* rhs_sub
     Scope sc(m->prof, K_COARSE_TREE, 0.0);
     hipLaunchKernelGGL(k_coarse_tree, dim3(1), dim3(kTreeThreads), sizeof(double) * m->N, s, (const CoarseTree*)m->d_tree, S);
     cs.u1 = C.xk;
+  } else if (l + 1 > m->kdepth) {  // plain V-cycle below the K-cycle depth
+    SpmvRatio none;
+    cycle(m, s, l + 1, C.bk, nullptr, none, nullptr, C.xk, nullptr, nullptr, S);
+    cs.u1 = C.xk;
   } else {
     cs = fcg(m, s, l + 1, S);
   }
@@ -884,6 +889,7 @@ Amg* amg_create(hipStream_t s, const BsrDev& A0, const double* d_poses, const in
   if (const char* e = std::getenv("SGO_AMG_THETA")) m->cfg.theta = std::atof(e);
   if (const char* e = std::getenv("SGO_AMG_OMEGA")) m->cfg.omega = std::atof(e);
   if (const char* e = std::getenv("SGO_AMG_THETA_COARSE")) m->cfg.theta_coarse = std::atof(e);
+  if (const char* e = std::getenv("SGO_AMG_KDEPTH")) m->kdepth = std::atoi(e);
   if (const char* e = std::getenv("SGO_AMG_COARSEST")) m->cfg.coarsest_nodes = std::atoi(e);
   m->prof = prof;
   m->d_poses = d_poses;

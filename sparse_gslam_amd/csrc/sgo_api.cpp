@@ -76,6 +76,9 @@ struct sgo_ctx {
 
   hipGraphExec_t pcg_exec = nullptr;
   int pcg_exec_chunk = 0;
+  int pcg_pred = 0;               // PCG iterations of the previous solve (prediction for the next)
+  PcgScalars* h_S2 = nullptr;     // pinned [2]: pipelined read-back of the stop flag
+  hipEvent_t ev_S[2] = {nullptr, nullptr};
 
   // profiling
   struct Rec { int kid; hipEvent_t a, b; };
@@ -132,6 +135,7 @@ void free_graph(sgo_ctx* c) {
   }
   for (void* p : c->allocs) hipFree(p);
   c->allocs.clear();
+  c->pcg_pred = 0;
   c->A = BsrDev();
   c->es = EdgeSlotsDev();
   c->el = EdgeListDev();
@@ -496,26 +500,46 @@ int ensure_pcg_graph(sgo_ctx* c, int chunk) {
 }
 
 // Runs PCG from the state k_finalize left (x = 0, r = b, ...) until S.stop != 0.
+// Runs PCG from the state k_finalize / start_pcg left (x = 0, r = b, ...) until S.stop != 0.
+// Graph mode: a 2-iteration hipGraph is replayed; the first (predicted - 8) iterations -- predicted
+// = the count of the previous solve -- go out without any host check, after that one 4-iteration
+// chunk is always in flight while the host waits for the stop flag copied out after the previous
+// chunk (kernels of iterations past convergence exit on the flag), so the GPU never idles on a
+// host round trip and at most one chunk of early-exit launches is wasted.
 int run_pcg(sgo_ctx* c) {
-  const int chunk = std::max(1, c->opts.pcg_chunk);
   const bool graph = c->opts.use_graph && !c->opts.profile;
-  if (graph) {
-    int rc = ensure_pcg_graph(c, chunk);
-    if (rc) return rc;
-  }
-  for (;;) {
-    HIP_TRY(c, hipMemcpyAsync(c->h_S, c->d_S, sizeof(PcgScalars), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (c->h_S->stop) break;
-    if (graph) {
-      HIP_TRY(c, hipGraphLaunch(c->pcg_exec, c->stream));
-    } else {
+  if (!graph) {
+    const int chunk = std::max(1, c->opts.pcg_chunk);
+    for (;;) {
+      HIP_TRY(c, hipMemcpyAsync(c->h_S, c->d_S, sizeof(PcgScalars), hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(c, hipStreamSynchronize(c->stream));
+      if (c->h_S->stop) break;
       for (int k = 0; k < chunk; ++k) {
         int rc = pcg_iteration(c);
         if (rc) return rc;
       }
     }
+    c->pcg_pred = c->h_S->iter;
+    return SGO_OK;
   }
+  constexpr int kUnit = 2;   // iterations per graph replay
+  int rc = ensure_pcg_graph(c, kUnit);
+  if (rc) return rc;
+  const int chunk_launches = std::max(1, c->opts.pcg_chunk / (4 * kUnit) * 2);  // default 16 -> 4 iterations
+  for (int k = 0; k < std::max(0, c->pcg_pred - 8) / kUnit; ++k) HIP_TRY(c, hipGraphLaunch(c->pcg_exec, c->stream));
+  int slot = 0;
+  HIP_TRY(c, hipMemcpyAsync(&c->h_S2[slot], c->d_S, sizeof(PcgScalars), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipEventRecord(c->ev_S[slot], c->stream));
+  for (;;) {
+    for (int k = 0; k < chunk_launches; ++k) HIP_TRY(c, hipGraphLaunch(c->pcg_exec, c->stream));  // speculative
+    HIP_TRY(c, hipMemcpyAsync(&c->h_S2[slot ^ 1], c->d_S, sizeof(PcgScalars), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipEventRecord(c->ev_S[slot ^ 1], c->stream));
+    HIP_TRY(c, hipEventSynchronize(c->ev_S[slot]));
+    if (c->h_S2[slot].stop) break;
+    slot ^= 1;
+  }
+  *c->h_S = c->h_S2[slot];
+  c->pcg_pred = c->h_S->iter;
   return SGO_OK;
 }
 
@@ -633,6 +657,9 @@ sgo_ctx* sgo_create(int device, const sgo_opts* opts) {
   if (c->opts.pcg_chunk <= 0) c->opts.pcg_chunk = 16;
   if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
       (e = hipHostMalloc((void**)&c->h_S, sizeof(PcgScalars))) != hipSuccess ||
+      (e = hipHostMalloc((void**)&c->h_S2, 2 * sizeof(PcgScalars))) != hipSuccess ||
+      (e = hipEventCreateWithFlags(&c->ev_S[0], hipEventDisableTiming)) != hipSuccess ||
+      (e = hipEventCreateWithFlags(&c->ev_S[1], hipEventDisableTiming)) != hipSuccess ||
       (e = hipHostMalloc((void**)&c->h_hist, sizeof(double) * 2 * (SGO_MAX_ITERS + 2))) != hipSuccess) {
     g_err = std::string("context setup: ") + hipGetErrorString(e);
     sgo_destroy(c);
@@ -650,6 +677,9 @@ void sgo_destroy(sgo_ctx* c) {
   c->comm.destroy();
   for (hipEvent_t e : c->ev_pool) hipEventDestroy(e);
   if (c->h_S) hipHostFree(c->h_S);
+  if (c->h_S2) hipHostFree(c->h_S2);
+  for (hipEvent_t ev : c->ev_S)
+    if (ev) hipEventDestroy(ev);
   if (c->h_hist) hipHostFree(c->h_hist);
   if (c->stream) hipStreamDestroy(c->stream);
   delete c;
