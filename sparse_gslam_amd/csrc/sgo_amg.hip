@@ -221,7 +221,6 @@ __global__ __launch_bounds__(kBlock) void k_prolong_add(int n, const int* __rest
 // The matrix is stored row-major with leading dimension Np = N rounded up to 32 and an identity
 // on the padding, so every tile is full.  4 launches per pivot block.
 constexpr int kGjB = 32;
-constexpr int kDenseThreads = 1024;
 
 __global__ __launch_bounds__(kBlock) void k_dense_fill(BsrDev A, int Np, double* __restrict__ M) {
   const size_t ns = (size_t)A.nslot;
