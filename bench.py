@@ -32,33 +32,28 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 measured copy)
 
 
-def cpu_baseline(g, iters: int, budget_s: float = 25.0):
-    """The C++ oracle (single thread, sparse direct LDL^T -- the reference's solver class) timed on
-    a bounded sample: a prefix sub-graph (first Vs poses and the edges among them) sized so the
-    run stays within the budget."""
+def cpu_baseline(g, iters: int):
+    """The C++ oracle (single thread, sparse direct LDL^T = the reference's solver class) timed on a
+    bounded sample of the workload: the sub-graph of the first 30 000 poses (about 15 s of CPU).  The
+    direct solver's cost is super-linear in the graph size (fill-in), so the rate on the sample is an
+    UPPER bound of the rate on the full graph; the full C4 graph was timed once offline while the
+    golden fixture was generated (scripts/make_golden_large.py: 781 s for 20 iterations)."""
     from oracle import c_oracle
 
-    Vs = min(g.V, 10_000)
+    Vs = min(g.V, 30_000)
     keep = (g.ei < Vs) & (g.ej < Vs)
     args = (g.poses[:Vs], g.fixed[:Vs], g.ei[keep], g.ej[keep], g.meas[keep], g.info[keep], g.phi[keep])
     Es = int(keep.sum())
-    t0 = time.perf_counter()
-    n_it = 0
-    secs = []
-    while n_it < iters and (time.perf_counter() - t0) < budget_s:
-        # one GN iteration per call keeps the sample bounded; the symbolic analysis is redone each
-        # call (g2o redoes it once per optimize()), so time only the per-iteration figure it reports
-        _, st = c_oracle.gauss_newton(*args, iters=2, solver="direct")
-        secs.append(st["seconds"][1])  # iteration 1: numeric factorisation only (analysis done in 0)
-        n_it += 1
-        if n_it >= 3:
-            break
-    med = float(np.median(secs))
+    _, st = c_oracle.gauss_newton(*args, iters=3, solver="direct")
+    med = float(np.median(st["seconds"][1:]))   # iteration 0 also pays the symbolic analysis (once per optimize())
+    note = ""
+    if g.V == 100_000 and g.E == 1_000_000:
+        note = "; full graph measured offline: 39 s per GN iteration = 25.6 k edge-Jacobians/s"
     return dict(value=Es / med, unit="edge-Jacobians/s per GN iter", cores=1, kind="port",
                 sample=f"CPU restatement of g2o GN (not g2o itself: g2o/Eigen are not in the image): "
                        f"single-thread C++ oracle, sparse direct LDL^T + min-degree ordering, on the "
-                       f"first {Vs} poses / {Es} edges of the workload, median of {n_it} GN iterations "
-                       f"(numeric factorisation + solve, symbolic analysis excluded)")
+                       f"first {Vs} poses / {Es} edges of the workload, median of GN iterations 2-3 "
+                       f"(numeric factorisation + solve; symbolic analysis excluded){note}")
 
 
 def main():
