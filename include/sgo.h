@@ -51,8 +51,8 @@ extern "C" {
 
 /* linear solver behind BlockSolver::solve (replaces LinearSolverEigen, graphs.cpp:19) */
 #define SGO_SOLVER_PCG_BJ 0      /* block-Jacobi preconditioned CG */
-#define SGO_SOLVER_PCG_AMG 1     /* CG preconditioned by a rigid-body aggregation multigrid V-cycle
-                                    with block-Jacobi smoothing */
+#define SGO_SOLVER_PCG_AMG 1     /* (flexible) CG preconditioned by a rigid-body aggregation multigrid
+                                    K-cycle with block-Jacobi smoothing */
 
 typedef struct sgo_ctx sgo_ctx;
 
@@ -70,8 +70,9 @@ typedef struct sgo_opts {
 } sgo_opts;
 
 /* Defaults (also applied when opts == NULL):
- * solver = PCG_AMG (falls back to PCG_BJ for graphs with <= 64 free poses and in multi-GPU
- * mode), pcg_tol = 1e-8, pcg_maxit = 20000, pcg_chunk = 16, use_graph = 1. */
+ * solver = PCG_AMG (graphs with <= 400 free poses are preconditioned by an explicit dense inverse,
+ * i.e. solved directly; falls back to PCG_BJ only when a larger graph cannot be coarsened),
+ * pcg_tol = 1e-8, pcg_maxit = 20000, pcg_chunk = 16, use_graph = 1. */
 void sgo_default_opts(sgo_opts* o);
 
 typedef struct sgo_stats {

@@ -223,12 +223,18 @@ __global__ __launch_bounds__(kBlock) void k_prolong_add(int n, const int* __rest
 constexpr int kGjB = 32;
 
 __global__ __launch_bounds__(kBlock) void k_dense_fill(BsrDev A, int Np, double* __restrict__ M) {
+  // one thread per block row, slots added in order: level 0 can hold several slots for the same
+  // (row, col) -- duplicate edges, and the zero blocks of fixed-column slots that alias the
+  // diagonal -- so the fill must accumulate, and a row-exclusive sequential sum keeps it
+  // deterministic.  M was zeroed by the caller.
   const size_t ns = (size_t)A.nslot;
   const int N = 3 * A.n;
-  for (int k = blockIdx.x * kBlock + threadIdx.x; k < A.nslot; k += gridDim.x * kBlock) {
-    const int r = A.row[k], c = A.col[k];
+  for (int r = blockIdx.x * kBlock + threadIdx.x; r < A.n; r += gridDim.x * kBlock) {
+    for (int k = A.rowptr[r]; k < A.rowptr[r + 1]; ++k) {
+      const int c = A.col[k];
 #pragma unroll
-    for (int e = 0; e < 9; ++e) M[(size_t)(3 * r + e / 3) * Np + 3 * c + e % 3] = A.blk[e * ns + k];
+      for (int e = 0; e < 9; ++e) M[(size_t)(3 * r + e / 3) * Np + 3 * c + e % 3] += A.blk[e * ns + k];
+    }
   }
   for (int i = N + blockIdx.x * kBlock + threadIdx.x; i < Np; i += gridDim.x * kBlock) M[(size_t)i * Np + i] = 1.0;
 }
@@ -328,6 +334,19 @@ __global__ __launch_bounds__(kBlock) void k_dense_apply(int N, int Np, const dou
     s = wave_sum(s);
     if (lane == 0) x[i] = s;
   }
+}
+
+// partials[0][blk] = sum z.a ; partials[1][blk] = sum z.b (b optional)
+__global__ __launch_bounds__(kBlock) void k_dots2(int n, const double* __restrict__ z, const double* __restrict__ a,
+                                                  const double* __restrict__ b, double* __restrict__ partials,
+                                                  const PcgScalars* S) {
+  if (S && S->stop) return;
+  double acc[2] = {0.0, 0.0};
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    acc[0] += z[i] * a[i];
+    if (b) acc[1] += z[i] * b[i];
+  }
+  block_sum_store<2>(acc, partials, kMaxPartials);
 }
 
 // --------------------------------------------------------------------------------- fused coarse tree
@@ -860,7 +879,7 @@ int amg_update(Amg* m, hipStream_t s, std::string* err) {
     Scope sc(m->prof, K_DENSE_INVERT, 8.0 * m->Np * m->Np);
     const int nb = m->Np / kGjB;
     hipMemsetAsync(m->inv, 0, sizeof(double) * (size_t)m->Np * m->Np, s);
-    hipLaunchKernelGGL(k_dense_fill, dim3(grid_for(m->lv[last].A.nslot, kBlock)), dim3(kBlock), 0, s, m->lv[last].A, m->Np, m->inv);
+    hipLaunchKernelGGL(k_dense_fill, dim3(grid_for(m->lv[last].A.n, kBlock)), dim3(kBlock), 0, s, m->lv[last].A, m->Np, m->inv);
     for (int kb = 0; kb < nb; ++kb) {
       hipLaunchKernelGGL(k_gj_pivot, dim3(1), dim3(kGjB * kGjB), 0, s, m->inv, m->Np, kb, m->gjP, m->d_fail);
       hipLaunchKernelGGL(k_gj_step, dim3(nb), dim3(kBlock), 0, s, 0, m->inv, m->Np, kb, (const double*)m->gjP);
@@ -877,6 +896,17 @@ int amg_update(Amg* m, hipStream_t s, std::string* err) {
 
 int amg_apply(Amg* m, hipStream_t s, const double* r, double* z, const double* dotvec, double* partials,
               const PcgScalars* S, const double* dotvec2) {
+  if (m->lv.size() == 1) {  // single (dense) level: z = H^-1 r
+    {
+      Scope sc(m->prof, K_DENSE_APPLY, 8.0 * m->N * m->N);
+      hipLaunchKernelGGL(k_dense_apply, dim3(grid_for(m->N, kWavesPerBlock)), dim3(kBlock), 0, s, m->N, m->Np, m->inv, r, z, S);
+    }
+    if (!dotvec) return 0;
+    const int grid = grid_for(m->N, kBlock);
+    Scope sc(m->prof, K_DOT, 24.0 * m->N);
+    hipLaunchKernelGGL(k_dots2, dim3(grid), dim3(kBlock), 0, s, m->N, (const double*)z, dotvec, dotvec2, partials, S);
+    return grid;
+  }
   SpmvRatio none;
   return cycle(m, s, 0, r, nullptr, none, nullptr, z, dotvec, partials, S, dotvec2);
 }
@@ -1051,7 +1081,9 @@ Amg* amg_create(hipStream_t s, const BsrDev& A0, const double* d_poses, const in
     H = std::move(Hc);
   }
   const int last = (int)m->lv.size() - 1;
-  if (last == 0) return fail("amg_create: graph too small or not coarsenable; use the block-Jacobi solver");
+  // last == 0: the whole graph is at most coarsest_nodes large (or cannot be coarsened) and is
+  // "solved" by the dense inverse directly -- the preconditioner is then exact (1-2 PCG iterations)
+  if (last == 0 && m->lv[0].A.n > 1024) return fail("amg_create: graph not coarsenable; use the block-Jacobi solver");
   m->N = 3 * m->lv[last].A.n;
   m->Np = (m->N + kGjB - 1) / kGjB * kGjB;
   if (m->N > 3072) return fail("amg_create: coarsest level too large (" + std::to_string(m->N) + " unknowns)");

@@ -709,7 +709,7 @@ int sgo_set_graph_se2(sgo_ctx* c, int32_t V, const double* poses, const uint8_t*
   }
   c->has_graph = true;
   c->solver_desc = "pcg_block_jacobi";
-  if (c->opts.solver == SGO_SOLVER_PCG_AMG && c->n > 64 && (c->comm.nranks == 1 || c->comm.handle)) {
+  if (c->opts.solver == SGO_SOLVER_PCG_AMG && c->n > 0 && (c->comm.nranks == 1 || c->comm.handle)) {
     // the hierarchy is built from the Hessian at the initial poses (strength of connection)
     if ((rc = do_linearize(c)) != SGO_OK || (rc = build_amg(c)) != SGO_OK) {
       free_graph(c);
