@@ -180,8 +180,8 @@ def main():
             "event_bracket_overhead_us": overhead_us,
             "algorithmic_bytes_per_launch": k["bytes"] / k["launches"],
             "note": "achieved = algorithmic bytes of all launches of this kernel (all multigrid levels) / their "
-                    "summed HIP-event time (an empty event bracket alone measures event_bracket_overhead_us, so "
-                    "avg_launch_us exceeds rocprofv3's kernel duration by up to that much); traffic = mean HBM "
+                    "summed HIP-event time; the events are the dispatch's own start/stop stamps "
+                    "(hipExtLaunchKernelGGL), comparable with rocprofv3 kernel durations; traffic = mean HBM "
                     "bytes per launch from rocprofv3 --pmc passes; per-kernel table uses rocprofv3's kernel names",
             "kernels": {n: {"launches": v["launches"], "ms": round(v["ms"], 3),
                             "avg_us": round(1e3 * v["ms"] / v["launches"], 2),

@@ -798,18 +798,18 @@ int cycle(Amg* m, hipStream_t s, int l, const double* rhs, const double* rhs_sub
   }
   {
     Scope sc(m->prof, K_RESTRICT, 40.0 * L.A.n + 24.0 * L.nc);
-    hipLaunchKernelGGL(k_restrict, dim3(grid_for(L.mem_ngrp, kWavesPerBlock)), dim3(kBlock), 0, s, L.mem_ngrp, L.mem_grp,
+    SGO_LAUNCH(k_restrict, dim3(grid_for(L.mem_ngrp, kWavesPerBlock)), dim3(kBlock), 0, s, L.mem_ngrp, L.mem_grp,
                        L.mem, L.agg, L.d, L.rs, C.bk, S);
   }
   CoarseSol cs;
   if (l + 1 == last) {
     Scope sc(m->prof, K_DENSE_APPLY, 8.0 * m->N * m->N);
-    hipLaunchKernelGGL(k_dense_apply, dim3(grid_for(m->N, kWavesPerBlock)), dim3(kBlock), 0, s, m->N, m->Np, m->inv, C.bk,
+    SGO_LAUNCH(k_dense_apply, dim3(grid_for(m->N, kWavesPerBlock)), dim3(kBlock), 0, s, m->N, m->Np, m->inv, C.bk,
                        C.xk, S);
     cs.u1 = C.xk;
   } else if (m->tree_start >= 0 && l + 1 >= m->tree_start) {
     Scope sc(m->prof, K_COARSE_TREE, 0.0);
-    hipLaunchKernelGGL(k_coarse_tree, dim3(1), dim3(kTreeThreads), sizeof(double) * m->N, s, (const CoarseTree*)m->d_tree, S);
+    SGO_LAUNCH(k_coarse_tree, dim3(1), dim3(kTreeThreads), sizeof(double) * m->N, s, (const CoarseTree*)m->d_tree, S);
     cs.u1 = C.xk;
   } else if (l + 1 > m->kdepth) {  // plain V-cycle below the K-cycle depth
     SpmvRatio none;
@@ -829,7 +829,7 @@ int cycle(Amg* m, hipStream_t s, int l, const double* rhs, const double* rhs_sub
   if (l == 0) {
     {
       Scope sc(m->prof, K_PROLONG, 68.0 * L.A.n);
-      hipLaunchKernelGGL(k_prolong_add, dim3(grid_for(L.A.n, kBlock)), dim3(kBlock), 0, s, L.A.n, L.agg, L.d, cs.u1, cs.c1,
+      SGO_LAUNCH(k_prolong_add, dim3(grid_for(L.A.n, kBlock)), dim3(kBlock), 0, s, L.A.n, L.agg, L.d, cs.u1, cs.c1,
                          cs.u2, cs.c2, L.xs, S);
     }
     Scope sc(m->prof, K_SPMV_JACOBI, (L.A.blkf ? 44.0 : 80.0) * L.A.nslot + 120.0 * L.A.n);
@@ -856,7 +856,7 @@ int amg_update(Amg* m, hipStream_t s, std::string* err) {
   {
     AmgLevel& L0 = m->lv[0];
     Scope sc(m->prof, K_POSITIONS0, 40.0 * L0.A.n);
-    hipLaunchKernelGGL(k_positions0, dim3(grid_for(L0.A.n, kBlock)), dim3(kBlock), 0, s, L0.A.n, m->d_free_id, m->d_poses,
+    SGO_LAUNCH(k_positions0, dim3(grid_for(L0.A.n, kBlock)), dim3(kBlock), 0, s, L0.A.n, m->d_free_id, m->d_poses,
                        L0.pos);
   }
   for (int l = 0; l < last; ++l) {
@@ -864,27 +864,27 @@ int amg_update(Amg* m, hipStream_t s, std::string* err) {
     AmgLevel& C = m->lv[l + 1];
     {
       Scope sc(m->prof, K_CENTRES, 36.0 * L.A.n);
-      hipLaunchKernelGGL(k_centres, dim3(grid_for(L.nc, kBlock)), dim3(kBlock), 0, s, L.nc, L.mem_ptr, L.mem, L.pos, C.pos, L.d);
+      SGO_LAUNCH(k_centres, dim3(grid_for(L.nc, kBlock)), dim3(kBlock), 0, s, L.nc, L.mem_ptr, L.mem, L.pos, C.pos, L.d);
     }
     {
       Scope sc(m->prof, K_GALERKIN, (72.0 + 16.0 + 32.0) * L.A.nslot + 72.0 * C.A.nslot);
-      hipLaunchKernelGGL(k_galerkin, dim3(grid_for(L.gal.ngrp, kWavesPerBlock)), dim3(kBlock), 0, s, L.A, C.A, L.gal, L.d);
+      SGO_LAUNCH(k_galerkin, dim3(grid_for(L.gal.ngrp, kWavesPerBlock)), dim3(kBlock), 0, s, L.A, C.A, L.gal, L.d);
     }
     {
       Scope sc(m->prof, K_LEVEL_DINV, 120.0 * C.A.n);
-      hipLaunchKernelGGL(k_level_dinv, dim3(grid_for(C.A.n, kBlock)), dim3(kBlock), 0, s, C.A);
+      SGO_LAUNCH(k_level_dinv, dim3(grid_for(C.A.n, kBlock)), dim3(kBlock), 0, s, C.A);
     }
   }
   {
     Scope sc(m->prof, K_DENSE_INVERT, 8.0 * m->Np * m->Np);
     const int nb = m->Np / kGjB;
     hipMemsetAsync(m->inv, 0, sizeof(double) * (size_t)m->Np * m->Np, s);
-    hipLaunchKernelGGL(k_dense_fill, dim3(grid_for(m->lv[last].A.n, kBlock)), dim3(kBlock), 0, s, m->lv[last].A, m->Np, m->inv);
+    SGO_LAUNCH(k_dense_fill, dim3(grid_for(m->lv[last].A.n, kBlock)), dim3(kBlock), 0, s, m->lv[last].A, m->Np, m->inv);
     for (int kb = 0; kb < nb; ++kb) {
-      hipLaunchKernelGGL(k_gj_pivot, dim3(1), dim3(kGjB * kGjB), 0, s, m->inv, m->Np, kb, m->gjP, m->d_fail);
-      hipLaunchKernelGGL(k_gj_step, dim3(nb), dim3(kBlock), 0, s, 0, m->inv, m->Np, kb, (const double*)m->gjP);
-      hipLaunchKernelGGL(k_gj_step, dim3(nb, nb), dim3(kBlock), 0, s, 1, m->inv, m->Np, kb, (const double*)m->gjP);
-      hipLaunchKernelGGL(k_gj_step, dim3(nb), dim3(kBlock), 0, s, 2, m->inv, m->Np, kb, (const double*)m->gjP);
+      SGO_LAUNCH(k_gj_pivot, dim3(1), dim3(kGjB * kGjB), 0, s, m->inv, m->Np, kb, m->gjP, m->d_fail);
+      SGO_LAUNCH(k_gj_step, dim3(nb), dim3(kBlock), 0, s, 0, m->inv, m->Np, kb, (const double*)m->gjP);
+      SGO_LAUNCH(k_gj_step, dim3(nb, nb), dim3(kBlock), 0, s, 1, m->inv, m->Np, kb, (const double*)m->gjP);
+      SGO_LAUNCH(k_gj_step, dim3(nb), dim3(kBlock), 0, s, 2, m->inv, m->Np, kb, (const double*)m->gjP);
     }
   }
   if (hipGetLastError() != hipSuccess) {
@@ -899,12 +899,12 @@ int amg_apply(Amg* m, hipStream_t s, const double* r, double* z, const double* d
   if (m->lv.size() == 1) {  // single (dense) level: z = H^-1 r
     {
       Scope sc(m->prof, K_DENSE_APPLY, 8.0 * m->N * m->N);
-      hipLaunchKernelGGL(k_dense_apply, dim3(grid_for(m->N, kWavesPerBlock)), dim3(kBlock), 0, s, m->N, m->Np, m->inv, r, z, S);
+      SGO_LAUNCH(k_dense_apply, dim3(grid_for(m->N, kWavesPerBlock)), dim3(kBlock), 0, s, m->N, m->Np, m->inv, r, z, S);
     }
     if (!dotvec) return 0;
     const int grid = grid_for(m->N, kBlock);
     Scope sc(m->prof, K_DOT, 24.0 * m->N);
-    hipLaunchKernelGGL(k_dots2, dim3(grid), dim3(kBlock), 0, s, m->N, (const double*)z, dotvec, dotvec2, partials, S);
+    SGO_LAUNCH(k_dots2, dim3(grid), dim3(kBlock), 0, s, m->N, (const double*)z, dotvec, dotvec2, partials, S);
     return grid;
   }
   SpmvRatio none;
@@ -979,7 +979,7 @@ Amg* amg_create(hipStream_t s, const BsrDev& A0, const double* d_poses, const in
     {
       double* d_w = dev_alloc<double>(m->pool, H.nslot);
       if (!d_w) return fail("amg_create: out of device memory");
-      hipLaunchKernelGGL(k_block_norms, dim3(grid_for(H.nslot, kBlock)), dim3(kBlock), 0, s, L.A, d_w);
+      SGO_LAUNCH(k_block_norms, dim3(grid_for(H.nslot, kBlock)), dim3(kBlock), 0, s, L.A, d_w);
       hipMemcpyAsync(w.data(), d_w, sizeof(double) * H.nslot, hipMemcpyDeviceToHost, s);
       if (hipStreamSynchronize(s) != hipSuccess) return fail("amg_create: strength kernel failed");
     }
@@ -1073,9 +1073,9 @@ Amg* amg_create(hipStream_t s, const BsrDev& A0, const double* d_poses, const in
       Cr.pos = dev_alloc<double>(m->pool, 2 * (size_t)nc);
       if (!Cr.pos) return fail("amg_create: out of device memory");
       if (l == 0)
-        hipLaunchKernelGGL(k_positions0, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, s, n, d_free_id, d_poses, Lr.pos);
-      hipLaunchKernelGGL(k_centres, dim3(grid_for(nc, kBlock)), dim3(kBlock), 0, s, nc, Lr.mem_ptr, Lr.mem, Lr.pos, Cr.pos, Lr.d);
-      hipLaunchKernelGGL(k_galerkin, dim3(grid_for(Lr.gal.ngrp, kWavesPerBlock)), dim3(kBlock), 0, s, Lr.A, Cr.A, Lr.gal, Lr.d);
+        SGO_LAUNCH(k_positions0, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, s, n, d_free_id, d_poses, Lr.pos);
+      SGO_LAUNCH(k_centres, dim3(grid_for(nc, kBlock)), dim3(kBlock), 0, s, nc, Lr.mem_ptr, Lr.mem, Lr.pos, Cr.pos, Lr.d);
+      SGO_LAUNCH(k_galerkin, dim3(grid_for(Lr.gal.ngrp, kWavesPerBlock)), dim3(kBlock), 0, s, Lr.A, Cr.A, Lr.gal, Lr.d);
       if (hipStreamSynchronize(s) != hipSuccess) return fail("amg_create: Galerkin kernel failed");
     }
     H = std::move(Hc);

@@ -184,22 +184,40 @@ void prof_flush(sgo_ctx* c) {
   }
   c->pending.clear();
 }
+// Brackets ONE kernel launch (default): the launch itself carries the events (SGO_LAUNCH ->
+// hipExtLaunchKernelGGL), so the measured time is the kernel's dispatch-to-completion time, as in
+// rocprofv3's kernel trace.  multi = true brackets a whole launch sequence with two event records.
 struct Scope {
   sgo_ctx* c;
   int kid;
-  hipEvent_t a = nullptr;
-  Scope(sgo_ctx* c_, int kid_, double bytes) : c(c_), kid(kid_) {
+  bool multi;
+  hipEvent_t a = nullptr, b = nullptr;
+  Scope(sgo_ctx* c_, int kid_, double bytes, bool multi_ = false) : c(c_), kid(kid_), multi(multi_) {
     if (!c->opts.profile) return;
     if (c->prof_null_ms < 0.0) prof_calibrate(c);
     c->prof_launches[kid]++;
     c->prof_bytes[kid] += bytes;
     a = get_event(c);
-    hipEventRecord(a, c->stream);
+    if (multi) {
+      hipEventRecord(a, c->stream);
+    } else {
+      b = get_event(c);
+      tl_launch_ev.start = a;
+      tl_launch_ev.stop = b;
+    }
   }
   ~Scope() {
     if (!a) return;
-    hipEvent_t b = get_event(c);
-    hipEventRecord(b, c->stream);
+    if (multi) {
+      b = get_event(c);
+      hipEventRecord(b, c->stream);
+    } else if (tl_launch_ev.start == a) {  // no launch consumed the events: drop the sample
+      tl_launch_ev = LaunchEvents();
+      c->prof_launches[kid]--;
+      c->ev_pool.push_back(a);
+      c->ev_pool.push_back(b);
+      return;
+    }
     c->pending.push_back({kid, a, b});
     if (c->pending.size() >= 2048) prof_flush(c);
   }
@@ -559,7 +577,7 @@ int build_amg(sgo_ctx* c) {
   prof.user = c;
   prof.begin = [](void* u, int kid, double bytes) {
     sgo_ctx* cc = (sgo_ctx*)u;
-    cc->amg_scope = new Scope(cc, kid, bytes);
+    cc->amg_scope = new Scope(cc, kid, bytes, kid == K_DENSE_INVERT);
   };
   prof.end = [](void* u) {
     sgo_ctx* cc = (sgo_ctx*)u;

@@ -2,6 +2,7 @@
 // Not part of the public ABI (that is include/sgo.h).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cstdint>
 #include <string>
@@ -159,6 +160,23 @@ inline int grid_for(long long work_items, int per_block) {
   g = (g + 7) / 8 * 8;  // multiple of 8: one contiguous band of groups per XCD
   return (int)g;
 }
+
+// ---- launch macro -------------------------------------------------------------------------
+// In profile mode (sgo_opts.profile) the bracket of the NEXT single launch is the kernel's own
+// dispatch: hipExtLaunchKernelGGL stamps the start/stop events from the dispatch packet, which is
+// what rocprofv3 --kernel-trace reports, instead of two extra event packets around it.
+struct LaunchEvents {
+  hipEvent_t start = nullptr;
+  hipEvent_t stop = nullptr;
+};
+extern thread_local LaunchEvents tl_launch_ev;
+#define SGO_LAUNCH(kernel, grid, block, shmem, stream, ...)                                              \
+  do {                                                                                                   \
+    const ::sgo::LaunchEvents ev_ = ::sgo::tl_launch_ev;                                                 \
+    ::sgo::tl_launch_ev = ::sgo::LaunchEvents();                                                         \
+    if (ev_.start) hipExtLaunchKernelGGL(kernel, grid, block, shmem, stream, ev_.start, ev_.stop, 0, __VA_ARGS__); \
+    else hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);                            \
+  } while (0)
 
 // ---- kernel launchers (sgo_kernels.hip) --------------------------------------------------
 // All take the stream; none allocates or synchronises (hipGraph-capturable).

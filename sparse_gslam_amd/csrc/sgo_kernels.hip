@@ -22,6 +22,8 @@
 
 namespace sgo {
 
+thread_local LaunchEvents tl_launch_ev;
+
 const char* const kKernelNames[K_COUNT] = {
     "k_chi2",        "k_reduce2",  "k_linearize",   "k_finalize",   "k_init_scalars", "k_spmv<0, double>",  "k_spmv<1, double>",
     "k_spmv<2, double>", "k_spmv<3, double>", "k_spmv<4, double>", "k_spmv<5, double>", "k_spmv<6, double>",      "k_alpha",       "k_update_xr",  "k_beta",         "k_update_p", "k_dot",
@@ -511,46 +513,46 @@ __global__ __launch_bounds__(kBlock) void k_pose_update(int n, const int* __rest
 void launch_chi2(hipStream_t s, const EdgeListDev& el, int e0, int e1, const double* poses, double* e2_out,
                  double* partials, int* grid_out) {
   const int grid = grid_for(e1 - e0, kBlock);
-  hipLaunchKernelGGL(k_chi2, dim3(grid), dim3(kBlock), 0, s, el, e0, e1, poses, e2_out, partials);
+  SGO_LAUNCH(k_chi2, dim3(grid), dim3(kBlock), 0, s, el, e0, e1, poses, e2_out, partials);
   *grid_out = grid;
 }
 void launch_reduce2(hipStream_t s, const double* partials, int nparts, double* out2) {
-  hipLaunchKernelGGL(k_reduce2, dim3(1), dim3(kBlock), 0, s, partials, nparts, out2);
+  SGO_LAUNCH(k_reduce2, dim3(1), dim3(kBlock), 0, s, partials, nparts, out2);
 }
 void launch_linearize(hipStream_t s, const BsrDev& A, int g0, int g1, const EdgeSlotsDev& es, const double* poses,
                       double* dgb) {
   const int grid = grid_for(g1 - g0, kWavesPerBlock);
-  hipLaunchKernelGGL(k_linearize, dim3(grid), dim3(kBlock), 0, s, A, g0, g1, es, poses, dgb);
+  SGO_LAUNCH(k_linearize, dim3(grid), dim3(kBlock), 0, s, A, g0, g1, es, poses, dgb);
 }
 void launch_blk_to_f32(hipStream_t s, const BsrDev& A) {
-  hipLaunchKernelGGL(k_blk_to_f32, dim3(grid_for(9LL * A.nslot, kBlock)), dim3(kBlock), 0, s, A);
+  SGO_LAUNCH(k_blk_to_f32, dim3(grid_for(9LL * A.nslot, kBlock)), dim3(kBlock), 0, s, A);
 }
 void launch_finalize(hipStream_t s, const BsrDev& A, const double* dgb, int write_diag, double* b, double* x,
                      double* r, double* z, double* p, double* partials, int* grid_out) {
   const int grid = grid_for(A.n, kBlock);
-  hipLaunchKernelGGL(k_finalize, dim3(grid), dim3(kBlock), 0, s, A, dgb, write_diag, b, x, r, z, p, partials);
+  SGO_LAUNCH(k_finalize, dim3(grid), dim3(kBlock), 0, s, A, dgb, write_diag, b, x, r, z, p, partials);
   *grid_out = grid;
 }
 void launch_init_scalars(hipStream_t s, PcgScalars* S, const double* rz_parts, int n_rz, const double* bb_parts,
                          int n_bb, double tol, int maxit) {
-  hipLaunchKernelGGL(k_init_scalars, dim3(1), dim3(kBlock), 0, s, S, rz_parts, n_rz, bb_parts, n_bb, tol, maxit);
+  SGO_LAUNCH(k_init_scalars, dim3(1), dim3(kBlock), 0, s, S, rz_parts, n_rz, bb_parts, n_bb, tol, maxit);
 }
 int launch_spmv_ex(hipStream_t s, const BsrDev& A, int mode, const SpmvArgs& a) {
   const int grid = grid_for(A.ngrp, kWavesPerBlock);
   const bool f32 = A.blkf != nullptr && a.smoother_f32;
   switch (mode) {
-    case SPMV_AX: hipLaunchKernelGGL((k_spmv<SPMV_AX, double>), dim3(grid), dim3(kBlock), 0, s, A, a); break;
-    case SPMV_RESID: hipLaunchKernelGGL((k_spmv<SPMV_RESID, double>), dim3(grid), dim3(kBlock), 0, s, A, a); break;
+    case SPMV_AX: SGO_LAUNCH((k_spmv<SPMV_AX, double>), dim3(grid), dim3(kBlock), 0, s, A, a); break;
+    case SPMV_RESID: SGO_LAUNCH((k_spmv<SPMV_RESID, double>), dim3(grid), dim3(kBlock), 0, s, A, a); break;
     case SPMV_JACOBI:
-      if (f32) hipLaunchKernelGGL((k_spmv<SPMV_JACOBI, float>), dim3(grid), dim3(kBlock), 0, s, A, a);
-      else hipLaunchKernelGGL((k_spmv<SPMV_JACOBI, double>), dim3(grid), dim3(kBlock), 0, s, A, a);
+      if (f32) SGO_LAUNCH((k_spmv<SPMV_JACOBI, float>), dim3(grid), dim3(kBlock), 0, s, A, a);
+      else SGO_LAUNCH((k_spmv<SPMV_JACOBI, double>), dim3(grid), dim3(kBlock), 0, s, A, a);
       break;
-    case SPMV_JACOBI_P: hipLaunchKernelGGL((k_spmv<SPMV_JACOBI_P, double>), dim3(grid), dim3(kBlock), 0, s, A, a); break;
-    case SPMV_PRE_RESID_S: hipLaunchKernelGGL((k_spmv<SPMV_PRE_RESID_S, double>), dim3(grid), dim3(kBlock), 0, s, A, a); break;
-    case SPMV_AX_C: hipLaunchKernelGGL((k_spmv<SPMV_AX_C, double>), dim3(grid), dim3(kBlock), 0, s, A, a); break;
+    case SPMV_JACOBI_P: SGO_LAUNCH((k_spmv<SPMV_JACOBI_P, double>), dim3(grid), dim3(kBlock), 0, s, A, a); break;
+    case SPMV_PRE_RESID_S: SGO_LAUNCH((k_spmv<SPMV_PRE_RESID_S, double>), dim3(grid), dim3(kBlock), 0, s, A, a); break;
+    case SPMV_AX_C: SGO_LAUNCH((k_spmv<SPMV_AX_C, double>), dim3(grid), dim3(kBlock), 0, s, A, a); break;
     default:
-      if (f32) hipLaunchKernelGGL((k_spmv<SPMV_PRE_RESID, float>), dim3(grid), dim3(kBlock), 0, s, A, a);
-      else hipLaunchKernelGGL((k_spmv<SPMV_PRE_RESID, double>), dim3(grid), dim3(kBlock), 0, s, A, a);
+      if (f32) SGO_LAUNCH((k_spmv<SPMV_PRE_RESID, float>), dim3(grid), dim3(kBlock), 0, s, A, a);
+      else SGO_LAUNCH((k_spmv<SPMV_PRE_RESID, double>), dim3(grid), dim3(kBlock), 0, s, A, a);
       break;
   }
   return grid;
@@ -569,35 +571,35 @@ void launch_spmv(hipStream_t s, const BsrDev& A, const double* x, double* y, dou
   if (grid_out) *grid_out = grid;
 }
 void launch_alpha(hipStream_t s, PcgScalars* S, const double* partials, int nparts) {
-  hipLaunchKernelGGL(k_alpha, dim3(1), dim3(kBlock), 0, s, S, partials, nparts);
+  SGO_LAUNCH(k_alpha, dim3(1), dim3(kBlock), 0, s, S, partials, nparts);
 }
 void launch_update_xr(hipStream_t s, int n, const PcgScalars* S, const double* dinv, const double* p,
                       const double* q, double* x, double* r, double* z, double* partials, int* grid_out) {
   const int grid = grid_for(n, kBlock);
-  hipLaunchKernelGGL(k_update_xr, dim3(grid), dim3(kBlock), 0, s, n, S, dinv, p, q, x, r, z, partials);
+  SGO_LAUNCH(k_update_xr, dim3(grid), dim3(kBlock), 0, s, n, S, dinv, p, q, x, r, z, partials);
   if (grid_out) *grid_out = grid;
 }
 void launch_beta(hipStream_t s, PcgScalars* S, const double* rz_parts, int n_rz, const double* rr_parts, int n_rr,
                  const double* zq_parts) {
-  hipLaunchKernelGGL(k_beta, dim3(1), dim3(kBlock), 0, s, S, rz_parts, n_rz, rr_parts, n_rr, zq_parts);
+  SGO_LAUNCH(k_beta, dim3(1), dim3(kBlock), 0, s, S, rz_parts, n_rz, rr_parts, n_rr, zq_parts);
 }
 void launch_update_p(hipStream_t s, int n, const PcgScalars* S, const double* z, double* p) {
   const int grid = grid_for(3LL * n, kBlock);
-  hipLaunchKernelGGL(k_update_p, dim3(grid), dim3(kBlock), 0, s, 3 * n, S, z, p);
+  SGO_LAUNCH(k_update_p, dim3(grid), dim3(kBlock), 0, s, 3 * n, S, z, p);
 }
 void launch_pose_update(hipStream_t s, int n, const int* free_id, const double* x, double* poses) {
   const int grid = grid_for(n, kBlock);
-  hipLaunchKernelGGL(k_pose_update, dim3(grid), dim3(kBlock), 0, s, n, free_id, x, poses);
+  SGO_LAUNCH(k_pose_update, dim3(grid), dim3(kBlock), 0, s, n, free_id, x, poses);
 }
 void launch_dot(hipStream_t s, int n3, const double* a, const double* b, double* partials, const PcgScalars* S,
                 int* grid_out) {
   const int grid = grid_for(n3, kBlock);
-  hipLaunchKernelGGL(k_dot, dim3(grid), dim3(kBlock), 0, s, n3, a, b, partials, S);
+  SGO_LAUNCH(k_dot, dim3(grid), dim3(kBlock), 0, s, n3, a, b, partials, S);
   if (grid_out) *grid_out = grid;
 }
 void launch_precond_bj(hipStream_t s, int n, const double* dinv, const double* r, double* z) {
   const int grid = grid_for(n, kBlock);
-  hipLaunchKernelGGL(k_precond_bj, dim3(grid), dim3(kBlock), 0, s, n, dinv, r, z);
+  SGO_LAUNCH(k_precond_bj, dim3(grid), dim3(kBlock), 0, s, n, dinv, r, z);
 }
 
 }  // namespace sgo
