@@ -594,17 +594,25 @@ class SparseOptimizer : public OptimizableGraph {
     (void)level;
     _activeVertices.clear();
     _activeEdges.clear();
+    // upstream rule: walk the edge sets OF THE VERTICES that are in the graph (not the graph's own
+    // edge container) and activate every edge all of whose vertices are in the graph.  After
+    // clear() a re-added vertex still lists its old edges (slc.cpp:259-261); they come back to
+    // life only if every endpoint is back in the graph too.
     std::set<HyperGraph::Vertex*> vs;
+    std::set<HyperGraph::Edge*> seen;
     std::vector<HyperGraph::Edge*> es;
-    for (auto* e : _edges) {
-      bool all = true;
-      for (auto* v : e->vertices()) {
-        auto it = _vertices.find(v->id());
-        if (it == _vertices.end() || it->second != v) all = false;
+    for (auto& kv : _vertices) {
+      for (auto* e : kv.second->edges()) {
+        if (!seen.insert(e).second) continue;
+        bool all = true;
+        for (auto* v : e->vertices()) {
+          auto it = v ? _vertices.find(v->id()) : _vertices.end();
+          if (it == _vertices.end() || it->second != v) all = false;
+        }
+        if (!all) continue;
+        es.push_back(e);
+        for (auto* v : e->vertices()) vs.insert(v);
       }
-      if (!all) continue;
-      es.push_back(e);
-      for (auto* v : e->vertices()) vs.insert(v);
     }
     std::sort(es.begin(), es.end(), [](HyperGraph::Edge* a, HyperGraph::Edge* b) { return a->internalId() < b->internalId(); });
     for (auto* e : es) _activeEdges.push_back(static_cast<OptimizableGraph::Edge*>(e));

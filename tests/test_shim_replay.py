@@ -82,3 +82,11 @@ def test_landmark_graph_types_run_on_the_host_solver():
     assert chi2_bad > 100 * max(chi2_after, 1e-20) and chi2_bad > 10
     assert chi2_restored < 1e-18
     assert dof == 7 * 3 + 20 * 2
+
+
+def test_shim_container_semantics():
+    """addVertex/addEdge/removeEdge/removeVertex return values, hessian order by id, upstream clear()
+    semantics, push/pop, ownership -- SURVEY.md section 8(b) semantic notes (host only)."""
+    subprocess.check_call(["make", "-s", "-C", CPP, "shim_semantics"])
+    out = subprocess.run([os.path.join(CPP, "shim_semantics")], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.strip() == "ok", out.stderr
