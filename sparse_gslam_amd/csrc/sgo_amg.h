@@ -14,6 +14,9 @@ struct AmgConfig {
   double theta_coarse = 0.02;  // ... on the coarser levels (env SGO_AMG_THETA_COARSE)
   double omega = 0.8;      // block-Jacobi damping (env SGO_AMG_OMEGA)
   int max_levels = 10;
+  bool double_pass = false; // aggregate twice per level when the coarsening ratio is below 4 (env
+                            // SGO_AMG_DOUBLE_PASS=1): fewer levels but ~2x the PCG iterations on
+                            // chain-dominated graphs -- measured a wash, kept off
   int coarsest_nodes = 400;  // stop coarsening at or below this many nodes (dense inverse of 3x that
                            // fits the LDS-resident Gauss-Jordan up to N = 138)
 };

@@ -919,6 +919,7 @@ Amg* amg_create(hipStream_t s, const BsrDev& A0, const double* d_poses, const in
   if (const char* e = std::getenv("SGO_AMG_OMEGA")) m->cfg.omega = std::atof(e);
   if (const char* e = std::getenv("SGO_AMG_THETA_COARSE")) m->cfg.theta_coarse = std::atof(e);
   if (const char* e = std::getenv("SGO_AMG_KDEPTH")) m->kdepth = std::atoi(e);
+  if (const char* e = std::getenv("SGO_AMG_DOUBLE_PASS")) m->cfg.double_pass = std::atoi(e) != 0;
   if (const char* e = std::getenv("SGO_AMG_COARSEST")) m->cfg.coarsest_nodes = std::atoi(e);
   m->prof = prof;
   m->d_poses = d_poses;
@@ -984,9 +985,54 @@ Amg* amg_create(hipStream_t s, const BsrDev& A0, const double* d_poses, const in
       if (hipStreamSynchronize(s) != hipSuccess) return fail("amg_create: strength kernel failed");
     }
     std::vector<int> agg;
-    int nc = aggregate(H, w, l == 0 ? m->cfg.theta : m->cfg.theta_coarse, agg);
+    const double theta_l = l == 0 ? m->cfg.theta : m->cfg.theta_coarse;
+    int nc = aggregate(H, w, theta_l, agg);
     if (nc > 0.9 * n) nc = aggregate(H, w, 0.0, agg);  // stalled: treat every connection as strong
     if (nc > 0.9 * n || nc < 1) break;                   // cannot coarsen further
+    // Chain-dominated graphs (few strong neighbours per node) give aggregates of ~3 nodes and a deep
+    // hierarchy, which the K-cycle pays for exponentially.  When the coarsening ratio is below 4,
+    // aggregate the aggregates once more over the strong inter-aggregate connections.
+    if (m->cfg.double_pass && nc > n / 4 && nc > m->cfg.coarsest_nodes) {
+      HostLevel G;   // graph of aggregates: one "diagonal" slot per aggregate, then strong neighbours
+      G.n = nc;
+      std::vector<std::pair<uint64_t, double>> ed;
+      for (int i = 0; i < n; ++i) {
+        const double di = w[H.rowptr[i]];
+        for (int k = H.rowptr[i] + 1; k < H.rowptr[i + 1]; ++k) {
+          const int j = H.col[k];
+          if (j == i || agg[i] == agg[j]) continue;
+          if (w[k] >= theta_l * std::sqrt(di * w[H.rowptr[j]]) && w[k] > 0.0)
+            ed.emplace_back(((uint64_t)agg[i] << 32) | (uint32_t)agg[j], w[k]);
+        }
+      }
+      std::sort(ed.begin(), ed.end());
+      G.rowptr.assign(nc + 1, 0);
+      std::vector<double> gw;
+      {
+        size_t t = 0;
+        for (int a = 0; a < nc; ++a) {
+          G.row.push_back(a);
+          G.col.push_back(a);
+          gw.push_back(1.0);   // placeholder; with theta = 0 only positivity of the weights matters
+          while (t < ed.size() && (int)(ed[t].first >> 32) == a) {
+            const int b = (int)(ed[t].first & 0xffffffffu);
+            double sum = 0.0;
+            while (t < ed.size() && (int)(ed[t].first >> 32) == a && (int)(ed[t].first & 0xffffffffu) == b) sum += ed[t++].second;
+            G.row.push_back(a);
+            G.col.push_back(b);
+            gw.push_back(sum);
+          }
+          G.rowptr[a + 1] = (int)G.row.size();
+        }
+      }
+      G.nslot = (int)G.row.size();
+      std::vector<int> agg2;
+      const int nc2 = aggregate(G, gw, 0.0, agg2);
+      if (nc2 >= 1 && nc2 < nc) {
+        for (int i = 0; i < n; ++i) agg[i] = agg2[agg[i]];
+        nc = nc2;
+      }
+    }
 
     // members by aggregate
     std::vector<int> mem_ptr(nc + 1, 0), mem(n);
