@@ -544,7 +544,10 @@ int run_pcg(sgo_ctx* c) {
   int rc = ensure_pcg_graph(c, kUnit);
   if (rc) return rc;
   const int chunk_launches = std::max(1, c->opts.pcg_chunk / (4 * kUnit) * 2);  // default 16 -> 4 iterations
-  for (int k = 0; k < std::max(0, c->pcg_pred - 8) / kUnit; ++k) HIP_TRY(c, hipGraphLaunch(c->pcg_exec, c->stream));
+  // unchecked prefix: 80 % of the previous count minus a margin (a solve that converges earlier
+  // than that only wastes ~1 us per early-exit launch)
+  const int unchecked = std::max(0, (int)(0.8 * c->pcg_pred) - 4) / kUnit;
+  for (int k = 0; k < unchecked; ++k) HIP_TRY(c, hipGraphLaunch(c->pcg_exec, c->stream));
   int slot = 0;
   HIP_TRY(c, hipMemcpyAsync(&c->h_S2[slot], c->d_S, sizeof(PcgScalars), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipEventRecord(c->ev_S[slot], c->stream));
@@ -567,6 +570,7 @@ int build_amg(sgo_ctx* c) {
     hipGraphExecDestroy(c->pcg_exec);
     c->pcg_exec = nullptr;
   }
+  c->pcg_pred = 0;  // the iteration count of the old hierarchy predicts nothing about the new one
   if (c->amg) {
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     amg_destroy(c->amg);
