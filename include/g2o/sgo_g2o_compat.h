@@ -189,6 +189,8 @@ class OptimizableGraph : public HyperGraph {
     void setHessianIndex(int i) { _hessianIndex = i; }
     int colInHessian() const { return _colInHessian; }
     void setColInHessian(int c) { _colInHessian = c; }
+    int tempIndex() const { return _tempIndex; }
+    void setTempIndex(int t) { _tempIndex = t; }
     virtual int dimension() const = 0;
     virtual void oplus(const double* v) = 0;
     virtual void push() = 0;
@@ -200,6 +202,7 @@ class OptimizableGraph : public HyperGraph {
     bool _fixed = false;
     int _hessianIndex = -1;
     int _colInHessian = -1;
+    int _tempIndex = -1;
   };
   class Edge : public HyperGraph::Edge {
    public:
@@ -829,13 +832,12 @@ class SparseOptimizer : public OptimizableGraph {
     }
     const int V = (int)_activeVertices.size(), E = (int)_activeEdges.size();
     std::vector<double> poses(3 * (size_t)V);
-    std::unordered_map<const HyperGraph::Vertex*, int> index;
     for (int k = 0; k < V; ++k) {
-      const VertexSE2* v = static_cast<const VertexSE2*>(_activeVertices[k]);
+      VertexSE2* v = static_cast<VertexSE2*>(_activeVertices[k]);
       poses[3 * k] = v->estimate()[0];
       poses[3 * k + 1] = v->estimate()[1];
       poses[3 * k + 2] = v->estimate()[2];
-      index[v] = k;
+      v->setTempIndex(k);   // compact numbering in ascending id (the array index sgo uses)
     }
     if (_graphOnDevice) {
       if (sgo_set_poses(_ctx, poses.data()) == SGO_OK) return true;
@@ -848,8 +850,8 @@ class SparseOptimizer : public OptimizableGraph {
     std::vector<double> meas(3 * (size_t)E), info(6 * (size_t)E), phi(E);
     for (int k = 0; k < E; ++k) {
       const EdgeSE2* e = static_cast<const EdgeSE2*>(_activeEdges[k]);
-      ei[k] = index[e->vertex(0)];
-      ej[k] = index[e->vertex(1)];
+      ei[k] = static_cast<const OptimizableGraph::Vertex*>(e->vertex(0))->tempIndex();
+      ej[k] = static_cast<const OptimizableGraph::Vertex*>(e->vertex(1))->tempIndex();
       for (int q = 0; q < 3; ++q) meas[3 * k + q] = e->measurement()[q];
       const auto& O = e->information();
       double* o = &info[6 * (size_t)k];

@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "sgo_amg.h"
@@ -27,6 +28,23 @@ thread_local std::string g_err;  // for ctx == NULL
 
 double wall_s() {
   return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// Static-partition parallel loop over [0, n) on up to 8 host threads (structure build only).
+template <class F>
+void parallel_for(int n, F&& fn) {
+  const int hw = (int)std::thread::hardware_concurrency();
+  const int T = std::max(1, std::min({8, hw > 0 ? hw : 1, n / 20000}));
+  if (T == 1) {
+    fn(0, n);
+    return;
+  }
+  std::vector<std::thread> th;
+  for (int t = 0; t < T; ++t) {
+    const int lo = (int)((long long)n * t / T), hi = (int)((long long)n * (t + 1) / T);
+    th.emplace_back([&fn, lo, hi]() { fn(lo, hi); });
+  }
+  for (auto& x : th) x.join();
 }
 
 constexpr double kPi = 3.14159265358979323846;
@@ -234,6 +252,7 @@ double bytes_chi2(const sgo_ctx* c) { return 96.0 * c->E + 24.0 * c->V; }
 int build_structure(sgo_ctx* c, int V, const double* poses, const uint8_t* fixed, int E, const int32_t* ei,
                     const int32_t* ej, const double* meas, const double* info, const double* phi) {
   // active vertices: those incident to at least one edge (initializeOptimization)
+  const double tb0 = wall_s();
   std::vector<int> deg(V, 0);
   for (int e = 0; e < E; ++e) {
     int a = ei[e], b = ej[e];
@@ -270,40 +289,53 @@ int build_structure(sgo_ctx* c, int V, const double* poses, const uint8_t* fixed
   }
   for (int r = 0; r < n; ++r) rowptr[r + 1] += rowptr[r];
   const int ns = rowptr[n];
-  std::vector<int> row(ns), col(ns), svi(ns, 0), svj(ns, 0), flags(ns, 0), fill(rowptr.begin(), rowptr.end() - 1);
-  std::vector<double> zinv(3 * (size_t)ns, 0.0), sinfo(6 * (size_t)ns, 0.0), sphi(ns, -1.0);
-  for (int r = 0; r < n; ++r) {
-    int k = fill[r]++;
-    row[k] = r;
-    col[k] = r;
-    flags[k] = kSlotDiag;
-  }
-  // EdgeSE2::setMeasurement caches the inverse measurement on the host (computed once)
-  std::vector<double> ezinv(3 * (size_t)E);
-  for (int e = 0; e < E; ++e) {
-    const double* z = meas + 3 * (size_t)e;
-    double th = normalize_theta_h(-z[2]);
-    double cs = std::cos(th), sn = std::sin(th);
-    ezinv[e] = cs * (-z[0]) - sn * (-z[1]);
-    ezinv[(size_t)E + e] = sn * (-z[0]) + cs * (-z[1]);
-    ezinv[2 * (size_t)E + e] = th;
-  }
-  for (int e = 0; e < E; ++e) {
-    int hi = hidx[ei[e]], hj = hidx[ej[e]];
-    for (int side = 0; side < 2; ++side) {
-      int hr = side ? hj : hi, hc = side ? hi : hj;
-      if (hr < 0) continue;
-      int k = fill[hr]++;
-      row[k] = hr;
-      col[k] = hc >= 0 ? hc : hr;
-      flags[k] = (side ? kSlotDir : 0) | (hc < 0 ? kSlotColFixed : 0);
-      svi[k] = ei[e];
-      svj[k] = ej[e];
-      for (int q = 0; q < 3; ++q) zinv[q * (size_t)ns + k] = ezinv[q * (size_t)E + e];
-      for (int q = 0; q < 6; ++q) sinfo[q * (size_t)ns + k] = info[6 * (size_t)e + q];
-      sphi[k] = phi[e];
+  // slot position of each edge's two directed copies (serial: keeps edge order within a row)
+  std::vector<int> pos_i(E, -1), pos_j(E, -1);
+  {
+    std::vector<int> fill(rowptr.begin(), rowptr.end() - 1);
+    for (int r = 0; r < n; ++r) fill[r]++;  // slot 0 of every row is the diagonal
+    for (int e = 0; e < E; ++e) {
+      int hi = hidx[ei[e]], hj = hidx[ej[e]];
+      if (hi >= 0) pos_i[e] = fill[hi]++;
+      if (hj >= 0) pos_j[e] = fill[hj]++;
     }
   }
+  std::vector<int> row(ns), col(ns), svi(ns, 0), svj(ns, 0), flags(ns, 0);
+  std::vector<double> zinv(3 * (size_t)ns, 0.0), sinfo(6 * (size_t)ns, 0.0), sphi(ns, -1.0);
+  std::vector<double> ezinv(3 * (size_t)E);
+  // the fills below are independent per row / per edge: spread them over the host cores
+  parallel_for(n, [&](int r0, int r1) {
+    for (int r = r0; r < r1; ++r) {
+      const int k = rowptr[r];
+      row[k] = r;
+      col[k] = r;
+      flags[k] = kSlotDiag;
+    }
+  });
+  parallel_for(E, [&](int e0, int e1) {
+    for (int e = e0; e < e1; ++e) {
+      // EdgeSE2::setMeasurement caches the inverse measurement on the host (computed once)
+      const double* z = meas + 3 * (size_t)e;
+      const double th = normalize_theta_h(-z[2]);
+      const double cs = std::cos(th), sn = std::sin(th);
+      const double zi[3] = {cs * (-z[0]) - sn * (-z[1]), sn * (-z[0]) + cs * (-z[1]), th};
+      for (int q = 0; q < 3; ++q) ezinv[q * (size_t)E + e] = zi[q];
+      const int hi = hidx[ei[e]], hj = hidx[ej[e]];
+      for (int side = 0; side < 2; ++side) {
+        const int hr = side ? hj : hi, hc = side ? hi : hj;
+        if (hr < 0) continue;
+        const int k = side ? pos_j[e] : pos_i[e];
+        row[k] = hr;
+        col[k] = hc >= 0 ? hc : hr;
+        flags[k] = (side ? kSlotDir : 0) | (hc < 0 ? kSlotColFixed : 0);
+        svi[k] = ei[e];
+        svj[k] = ej[e];
+        for (int q = 0; q < 3; ++q) zinv[q * (size_t)ns + k] = zi[q];
+        for (int q = 0; q < 6; ++q) sinfo[q * (size_t)ns + k] = info[6 * (size_t)e + q];
+        sphi[k] = phi[e];
+      }
+    }
+  });
   // wave groups: whole rows packed up to 64 slots; a longer row is its own group
   std::vector<int> grp;
   grp.push_back(0);
@@ -328,9 +360,12 @@ int build_structure(sgo_ctx* c, int V, const double* poses, const uint8_t* fixed
   // edge list (original order) for chi2
   std::vector<int> evi(ei, ei + E), evj(ej, ej + E);
   std::vector<double> einfo(6 * (size_t)E), ephi(phi, phi + E);
-  for (int e = 0; e < E; ++e)
-    for (int q = 0; q < 6; ++q) einfo[q * (size_t)E + e] = info[6 * (size_t)e + q];
+  parallel_for(E, [&](int e0, int e1) {
+    for (int e = e0; e < e1; ++e)
+      for (int q = 0; q < 6; ++q) einfo[q * (size_t)E + e] = info[6 * (size_t)e + q];
+  });
 
+  const double tb1 = wall_s();
   int rc;
   c->A.n = n;
   c->A.nslot = ns;
@@ -378,6 +413,9 @@ int build_structure(sgo_ctx* c, int V, const double* poses, const uint8_t* fixed
   HIP_TRY(c, hipMemsetAsync(c->d_partials, 0, sizeof(double) * 3 * kMaxPartials, c->stream));
   HIP_TRY(c, hipMemsetAsync(c->d_S, 0, sizeof(PcgScalars), c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));  // host staging vectors die at return
+  if (c->opts.verbose)
+    std::fprintf(stderr, "[sgo] set_graph: host structure %.1f ms, alloc+upload %.1f ms\n", 1e3 * (tb1 - tb0),
+                 1e3 * (wall_s() - tb1));
   return SGO_OK;
 }
 
@@ -641,6 +679,7 @@ void sgo_default_opts(sgo_opts* o) {
   if (const char* s = std::getenv("SGO_PCG_CHUNK")) o->pcg_chunk = std::atoi(s);
   if (const char* s = std::getenv("SGO_USE_GRAPH")) o->use_graph = std::atoi(s);
   if (const char* s = std::getenv("SGO_PROFILE")) o->profile = std::atoi(s);
+  if (const char* s = std::getenv("SGO_VERBOSE")) o->verbose = std::atoi(s);
 }
 
 sgo_ctx* sgo_create(int device, const sgo_opts* opts) {
@@ -733,10 +772,12 @@ int sgo_set_graph_se2(sgo_ctx* c, int32_t V, const double* poses, const uint8_t*
   c->solver_desc = "pcg_block_jacobi";
   if (c->opts.solver == SGO_SOLVER_PCG_AMG && c->n > 0 && (c->comm.nranks == 1 || c->comm.handle)) {
     // the hierarchy is built from the Hessian at the initial poses (strength of connection)
+    const double ta0 = wall_s();
     if ((rc = do_linearize(c)) != SGO_OK || (rc = build_amg(c)) != SGO_OK) {
       free_graph(c);
       return rc;
     }
+    if (c->opts.verbose) std::fprintf(stderr, "[sgo] set_graph: multigrid set-up %.1f ms\n", 1e3 * (wall_s() - ta0));
     c->linearized = false;
   }
   if (c->opts.verbose) std::fprintf(stderr, "[sgo] solver: %s\n", c->solver_desc.c_str());
