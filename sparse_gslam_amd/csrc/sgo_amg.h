@@ -17,6 +17,8 @@ struct AmgConfig {
   bool double_pass = false; // aggregate twice per level when the coarsening ratio is below 4 (env
                             // SGO_AMG_DOUBLE_PASS=1): fewer levels but ~2x the PCG iterations on
                             // chain-dominated graphs -- measured a wash, kept off
+  double double_ratio = 4.0;   // ... when n / nc < double_ratio (env SGO_AMG_DOUBLE_RATIO)
+  int double_from_level = 0;   // ... on levels >= this (env SGO_AMG_DOUBLE_FROM)
   int coarsest_nodes = 400;  // stop coarsening at or below this many nodes (dense inverse of 3x that
                            // fits the LDS-resident Gauss-Jordan up to N = 138)
 };

@@ -926,6 +926,8 @@ Amg* amg_create(hipStream_t s, const BsrDev& A0, const double* d_poses, const in
   if (const char* e = std::getenv("SGO_AMG_THETA_COARSE")) m->cfg.theta_coarse = std::atof(e);
   if (const char* e = std::getenv("SGO_AMG_KDEPTH")) m->kdepth = std::atoi(e);
   if (const char* e = std::getenv("SGO_AMG_DOUBLE_PASS")) m->cfg.double_pass = std::atoi(e) != 0;
+  if (const char* e = std::getenv("SGO_AMG_DOUBLE_RATIO")) m->cfg.double_ratio = std::atof(e);
+  if (const char* e = std::getenv("SGO_AMG_DOUBLE_FROM")) m->cfg.double_from_level = std::atoi(e);
   if (const char* e = std::getenv("SGO_AMG_COARSEST")) m->cfg.coarsest_nodes = std::atoi(e);
   m->prof = prof;
   m->d_poses = d_poses;
@@ -999,7 +1001,8 @@ Amg* amg_create(hipStream_t s, const BsrDev& A0, const double* d_poses, const in
     // Chain-dominated graphs (few strong neighbours per node) give aggregates of ~3 nodes and a deep
     // hierarchy, which the K-cycle pays for exponentially.  When the coarsening ratio is below 4,
     // aggregate the aggregates once more over the strong inter-aggregate connections.
-    if (m->cfg.double_pass && nc > n / 4 && nc > m->cfg.coarsest_nodes) {
+    if (m->cfg.double_pass && (double)nc * m->cfg.double_ratio > (double)n && nc > m->cfg.coarsest_nodes &&
+        l >= m->cfg.double_from_level) {
       HostLevel G;   // graph of aggregates: one "diagonal" slot per aggregate, then strong neighbours
       G.n = nc;
       std::vector<std::pair<uint64_t, double>> ed;
