@@ -703,6 +703,7 @@ struct Amg {
   const double* d_poses = nullptr;
   const int* d_free_id = nullptr;
   int kdepth = 1 << 20;  // levels <= kdepth use the K-cycle (two FCG steps), deeper ones a V-cycle
+  int fcg2_depth = 1 << 20;  // levels <= this take two FCG steps, deeper K-cycle levels one
   int tree_start = -1;  // first level handled by k_coarse_tree (-1: none)
   CoarseTree tree;
   CoarseTree* d_tree = nullptr;
@@ -759,6 +760,12 @@ CoarseSol fcg(Amg* m, hipStream_t s, int l, const PcgScalars* S) {
     gA = launch_spmv_ex(s, L.A, SPMV_AX, a);
   }
   SpmvRatio a1{L.pA + kMaxPartials, gA, L.pA, gA};
+  if (l > m->fcg2_depth) {  // one FCG step only (steepest descent in the cycle's direction)
+    CoarseSol one;
+    one.u1 = L.z1;
+    one.c1 = a1;
+    return one;
+  }
   const int gC = cycle(m, s, l, L.bk, L.q, a1, L.bk2, L.z2, L.q, L.pC, S);
   int gB;
   {
@@ -925,6 +932,7 @@ Amg* amg_create(hipStream_t s, const BsrDev& A0, const double* d_poses, const in
   if (const char* e = std::getenv("SGO_AMG_OMEGA")) m->cfg.omega = std::atof(e);
   if (const char* e = std::getenv("SGO_AMG_THETA_COARSE")) m->cfg.theta_coarse = std::atof(e);
   if (const char* e = std::getenv("SGO_AMG_KDEPTH")) m->kdepth = std::atoi(e);
+  if (const char* e = std::getenv("SGO_AMG_FCG2_DEPTH")) m->fcg2_depth = std::atoi(e);
   if (const char* e = std::getenv("SGO_AMG_DOUBLE_PASS")) m->cfg.double_pass = std::atoi(e) != 0;
   if (const char* e = std::getenv("SGO_AMG_DOUBLE_RATIO")) m->cfg.double_ratio = std::atof(e);
   if (const char* e = std::getenv("SGO_AMG_DOUBLE_FROM")) m->cfg.double_from_level = std::atoi(e);
