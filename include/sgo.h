@@ -61,10 +61,14 @@ typedef struct sgo_opts {
   int32_t solver;          /* SGO_SOLVER_*; env SGO_SOLVER={pcg,amg} overrides the default */
   double pcg_tol;          /* stop when ||r|| <= pcg_tol * ||b||   (env SGO_PCG_TOL) */
   int32_t pcg_maxit;       /* cap on PCG iterations per GN iteration (env SGO_PCG_MAXIT) */
-  int32_t pcg_chunk;       /* PCG iterations replayed per hipGraph launch between host checks */
-  int32_t use_graph;       /* 1: replay the PCG loop from a hipGraph; 0: plain stream launches */
-  int32_t profile;         /* 1: bracket every kernel launch with HIP events (forces use_graph=0)
-                              and report per-kernel totals through sgo_kernel_profile() */
+  int32_t pcg_chunk;       /* graph mode: pcg_chunk / 4 iterations are kept in flight speculatively
+                              between checks of the device-side stop flag; plain mode: iterations
+                              launched between two host checks */
+  int32_t use_graph;       /* 1: replay PCG iterations (incl. the multigrid cycle) from a hipGraph;
+                              0: plain stream launches */
+  int32_t profile;         /* 1: every launch carries its own start/stop HIP events
+                              (hipExtLaunchKernelGGL; forces use_graph=0); per-kernel totals through
+                              sgo_kernel_profile() */
   int32_t verbose;         /* mirrors SparseOptimizer::setVerbose (graphs.cpp:21) */
   int32_t reserved[8];
 } sgo_opts;
