@@ -936,6 +936,9 @@ Amg* amg_create(hipStream_t s, const BsrDev& A0, const double* d_poses, const in
   if (const char* e = std::getenv("SGO_AMG_DOUBLE_PASS")) m->cfg.double_pass = std::atoi(e) != 0;
   if (const char* e = std::getenv("SGO_AMG_DOUBLE_RATIO")) m->cfg.double_ratio = std::atof(e);
   if (const char* e = std::getenv("SGO_AMG_DOUBLE_FROM")) m->cfg.double_from_level = std::atoi(e);
+  // larger graphs afford a larger dense coarsest level (its inverse costs O(N^3) once per GN
+  // iteration, one K-cycle level less halves the coarse-level launches of every PCG iteration)
+  m->cfg.coarsest_nodes = std::min(1000, std::max(m->cfg.coarsest_nodes, A0.n / 1500));
   if (const char* e = std::getenv("SGO_AMG_COARSEST")) m->cfg.coarsest_nodes = std::atoi(e);
   m->prof = prof;
   m->d_poses = d_poses;
