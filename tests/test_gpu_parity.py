@@ -172,3 +172,36 @@ def test_single_rank_rccl_communicator_gives_identical_results():
         Pb = b.get_poses()
     assert da == db == 5
     assert np.array_equal(Pa, Pb) and sa["chi2"] == sb["chi2"]
+
+
+# ------------------------------------------------------------------ execution modes agree
+def test_graph_replay_plain_launches_and_profile_mode_agree_bitwise():
+    """hipGraph replay, plain stream launches and the event-bracketed profile mode run the same
+    kernels in the same order: identical poses, chi2 history and PCG iteration counts."""
+    g = synth.config("C2", info_mode="full")
+    res = []
+    for kw in (dict(use_graph=1), dict(use_graph=0), dict(profile=1)):
+        with capi.Optimizer(0, **kw) as o:
+            o.set_graph(*g.arrays())
+            done, st = o.optimize(6)
+            res.append((done, st["chi2"], st["pcg_iters"], o.get_poses()))
+            if kw.get("profile"):
+                prof = o.kernel_profile()
+                # 6 GN iterations + the linearisation of the multigrid set-up
+                assert prof["k_linearize"]["launches"] in (6, 7) and prof["k_spmv<0, double>"]["ms"] > 0
+                assert 0 <= o.profile_overhead_ms() < 0.1
+    for r in res[1:]:
+        assert r[0] == res[0][0] == 6 and r[1] == res[0][1] and r[2] == res[0][2]
+        assert np.array_equal(r[3], res[0][3])
+
+
+def test_both_solvers_reach_the_same_solution(opt, opt_amg):
+    g = synth.config("C1", info_mode="full")
+    xs = []
+    for o in (opt, opt_amg):
+        o.set_graph(*g.arrays())
+        o.linearize()
+        x, it, relres = o.solve()
+        assert it > 0 and relres <= 1e-10
+        xs.append(x)
+    assert np.abs(xs[0] - xs[1]).max() <= 1e-7 * np.abs(xs[0]).max()
