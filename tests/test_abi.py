@@ -39,3 +39,13 @@ def test_no_oracle_in_product():
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "import oracle" not in text and "from oracle" not in text, f
                 assert "sgo_oracle" not in text and "np_oracle" not in text, f
+
+
+def test_header_compiles_as_plain_c(tmp_path):
+    """include/sgo.h is a C header (the boundary is a C-ABI): the C99 example builds against it."""
+    import subprocess
+    exe = tmp_path / "c_api_demo"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "c_api_demo.c"), "-L" + capi.CSRC, "-lsgo", "-L/opt/rocm/lib",
+                           "-Wl,-rpath," + capi.CSRC, "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)])
+    assert exe.exists()

@@ -138,3 +138,17 @@ def test_two_contexts_are_independent():
         (done, st), P = res[tag]
         assert done == 10 and abs(st["chi2"][-1] - ost["chi2"][-1]) <= 1e-6 * ost["chi2"][-1]
         assert np.abs(P - oP).max() <= 1e-5
+
+
+def test_c99_example_runs(tmp_path):
+    """examples/c_api_demo.c: the ABI driven from plain C; a consistent square loop closes to chi2 = 0."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "c_api_demo"
+    subprocess.check_call(["gcc", "-std=c99", "-I" + os.path.join(root, "include"),
+                           os.path.join(root, "examples", "c_api_demo.c"), "-L" + capi.CSRC, "-lsgo", "-L/opt/rocm/lib",
+                           "-Wl,-rpath," + capi.CSRC, "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)])
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "iterations 10" in out.stdout
