@@ -46,7 +46,7 @@ __global__ __launch_bounds__(kBlock) void k_block_norms(BsrDev A, double* __rest
     double s = 0.0;
 #pragma unroll
     for (int c = 0; c < 9; ++c) {
-      const double v = A.blk[c * ns + k];
+      const double v = A.blk[blk_at(c, k, ns)];
       s += v * v;
     }
     w[k] = sqrt(s);
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(kBlock) void k_galerkin(BsrDev F, BsrDev C, Galerki
       const double dxj = d[2 * (size_t)j], dyj = d[2 * (size_t)j + 1];
       double b[9];
 #pragma unroll
-      for (int c = 0; c < 9; ++c) b[c] = F.blk[c * nf + k];
+      for (int c = 0; c < 9; ++c) b[c] = F.blk[blk_at(c, k, nf)];
       // M = B T_j : third column = -dy_j * col0 + dx_j * col1 + col2
       const double m02 = -dyj * b[0] + dxj * b[1] + b[2];
       const double m12 = -dyj * b[3] + dxj * b[4] + b[5];
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(kBlock) void k_galerkin(BsrDev F, BsrDev C, Galerki
     const int kn = __shfl_down(key, 1);
     if (key >= 0 && (lane == 63 || kn != key)) {
 #pragma unroll
-      for (int c = 0; c < 9; ++c) C.blk[c * ncs + key] = acc[c];
+      for (int c = 0; c < 9; ++c) C.blk[blk_at(c, key, ncs)] = acc[c];
     }
   }
 }
@@ -144,9 +144,9 @@ __global__ __launch_bounds__(kBlock) void k_level_dinv(BsrDev A) {
   for (int i = blockIdx.x * kBlock + threadIdx.x; i < A.n; i += gridDim.x * kBlock) {
     const int k0 = A.rowptr[i];
     // symmetrise (the Galerkin sum is symmetric up to rounding)
-    const double d00 = A.blk[k0], d01 = 0.5 * (A.blk[ns + k0] + A.blk[3 * ns + k0]);
-    const double d02 = 0.5 * (A.blk[2 * ns + k0] + A.blk[6 * ns + k0]), d11 = A.blk[4 * ns + k0];
-    const double d12 = 0.5 * (A.blk[5 * ns + k0] + A.blk[7 * ns + k0]), d22 = A.blk[8 * ns + k0];
+    const double d00 = A.blk[blk_at(0, k0, ns)], d01 = 0.5 * (A.blk[blk_at(1, k0, ns)] + A.blk[blk_at(3, k0, ns)]);
+    const double d02 = 0.5 * (A.blk[blk_at(2, k0, ns)] + A.blk[blk_at(6, k0, ns)]), d11 = A.blk[blk_at(4, k0, ns)];
+    const double d12 = 0.5 * (A.blk[blk_at(5, k0, ns)] + A.blk[blk_at(7, k0, ns)]), d22 = A.blk[blk_at(8, k0, ns)];
     const double c00 = d11 * d22 - d12 * d12, c01 = d02 * d12 - d01 * d22, c02 = d01 * d12 - d02 * d11;
     const double c11 = d00 * d22 - d02 * d02, c12 = d01 * d02 - d00 * d12, c22 = d00 * d11 - d01 * d01;
     const double det = d00 * c00 + d01 * c01 + d02 * c02;
@@ -234,7 +234,7 @@ __global__ __launch_bounds__(kBlock) void k_dense_fill(BsrDev A, int Np, double*
     for (int k = A.rowptr[r]; k < A.rowptr[r + 1]; ++k) {
       const int c = A.col[k];
 #pragma unroll
-      for (int e = 0; e < 9; ++e) M[(size_t)(3 * r + e / 3) * Np + 3 * c + e % 3] += A.blk[e * ns + k];
+      for (int e = 0; e < 9; ++e) M[(size_t)(3 * r + e / 3) * Np + 3 * c + e % 3] += A.blk[blk_at(e, k, ns)];
     }
   }
   for (int i = N + blockIdx.x * kBlock + threadIdx.x; i < Np; i += gridDim.x * kBlock) M[(size_t)i * Np + i] = 1.0;
@@ -423,9 +423,9 @@ __device__ __forceinline__ void blk_spmv(const BsrDev& A, const SpmvArgs& a, boo
       } else {
         x0 = a.x[3 * (size_t)c]; x1 = a.x[3 * (size_t)c + 1]; x2 = a.x[3 * (size_t)c + 2];
       }
-      acc[0] += A.blk[k] * x0 + A.blk[ns + k] * x1 + A.blk[2 * ns + k] * x2;
-      acc[1] += A.blk[3 * ns + k] * x0 + A.blk[4 * ns + k] * x1 + A.blk[5 * ns + k] * x2;
-      acc[2] += A.blk[6 * ns + k] * x0 + A.blk[7 * ns + k] * x1 + A.blk[8 * ns + k] * x2;
+      acc[0] += A.blk[blk_at(0, k, ns)] * x0 + A.blk[blk_at(1, k, ns)] * x1 + A.blk[blk_at(2, k, ns)] * x2;
+      acc[1] += A.blk[blk_at(3, k, ns)] * x0 + A.blk[blk_at(4, k, ns)] * x1 + A.blk[blk_at(5, k, ns)] * x2;
+      acc[2] += A.blk[blk_at(6, k, ns)] * x0 + A.blk[blk_at(7, k, ns)] * x1 + A.blk[blk_at(8, k, ns)] * x2;
     }
     seg_scan<3>(row, acc, lane);
     const int rn = __shfl_down(row, 1);

@@ -16,8 +16,9 @@ namespace sgo {
 // Block-CSR matrix with 3x3 fp64 blocks in "slot list sorted by row" form.
 //   * slot k belongs to block row row[k] and multiplies column col[k];
 //   * the FIRST slot of every row is that row's diagonal block;
-//   * blk is SoA over slots: blk[c * nslot + k] is component c (row-major 3x3) of slot k, so
-//     a wave reading 64 consecutive slots issues nine fully coalesced 512-byte loads;
+//   * blk is SoA over slots in component pairs (blk_at below): component c (row-major 3x3) of
+//     slot k is blk[blk_at(c, k, nslot)], so a wave reading 64 consecutive slots issues four
+//     fully coalesced 1-KiB loads (16 B per lane) and one 512-byte load;
 //   * grp[g] .. grp[g+1] is the slot range of wave-group g.  Groups are row aligned: a group
 //     holds whole rows (<= 64 slots) or exactly one long row (> 64 slots), so the segmented
 //     reduction of a row never leaves the wave and needs neither LDS hand-off nor atomics.
@@ -30,12 +31,20 @@ struct BsrDev {
   int* col = nullptr;
   int* grp = nullptr;     // [ngrp + 1]
   int* rowptr = nullptr;  // [n + 1]
-  double* blk = nullptr;  // [9][nslot]
+  double* blk = nullptr;  // 9 * nslot doubles, layout blk_at()
   float* blkf = nullptr;  // [9][nslot] fp32 copy of blk read by the multigrid SMOOTHER on level 0 only
                           // (the smoother is part of the preconditioner, which need not be exact;
                           // the CG operator product always reads the fp64 blocks)
   double* dinv = nullptr; // [n][6] inverse of the diagonal block, symmetric packing
 };
+
+// Block storage ("pair-SoA"): components (0,1), (2,3), (4,5), (6,7) of slot k are adjacent pairs --
+// pair p of slot k sits at double offset 2 * (p * nslot + k) -- and component 8 is at 8 * nslot + k.
+// A wave reading 64 consecutive slots issues four 16-byte-per-lane loads of one contiguous KiB
+// each plus one 512-B load, instead of nine 8-byte-per-lane loads.
+__host__ __device__ inline size_t blk_at(int c, size_t k, size_t ns) {
+  return c < 8 ? 2 * ((size_t)(c >> 1) * ns + k) + (size_t)(c & 1) : 8 * ns + k;
+}
 
 // Directed-edge operands aligned with the level-0 slots (SoA over slots).  For a slot of row
 // r that came from edge e = (i, j):  dir = 0 when r is the i side (row Jacobian A), 1 when r is

@@ -13,8 +13,8 @@
 //
 // All of it is HBM-/cache-bound fp64 gather + stream work on 3x3 blocks: no MFMA (a 3x3 block is
 // not a dense contraction).  Design rules used (cdna_hip_programming.md G2, G11, G12, G13,
-// Appendix B scatter/gather): SoA slot arrays so every wave load is one contiguous 512-B
-// segment; per-row sums by a wavefront segmented scan over row-aligned slot groups (no atomics,
+// Appendix B scatter/gather): SoA slot arrays (blocks in component pairs) so every wave load is
+// one contiguous 512-B or 1-KiB segment; per-row sums by a wavefront segmented scan over row-aligned slot groups (no atomics,
 // bitwise reproducible); grids capped at 2048 blocks and mapped so that each XCD walks one
 // contiguous band of rows (its L2 then holds that band's vector entries).
 #include "sgo_device.h"
@@ -198,10 +198,10 @@ __global__ __launch_bounds__(kBlock) void k_linearize(BsrDev A, int g0, int g1, 
         h[8] = T02 * C02 + T12 * C12 + T22 * C22;
       }
 #pragma unroll
-      for (int c = 0; c < 9; ++c) A.blk[c * ns + k] = h[c];
+      for (int c = 0; c < 9; ++c) A.blk[blk_at(c, k, ns)] = h[c];
       if (A.blkf) {
 #pragma unroll
-        for (int c = 0; c < 9; ++c) A.blkf[c * ns + k] = (float)h[c];
+        for (int c = 0; c < 9; ++c) A.blkf[blk_at(c, k, ns)] = (float)h[c];
       }
     }
     seg_scan<9>(row, acc, lane);
@@ -235,13 +235,13 @@ __global__ __launch_bounds__(kBlock) void k_finalize(BsrDev A, const double* __r
     const double b0 = d[6], b1 = d[7], b2 = d[8];
     const int k0 = A.rowptr[i];
     const double s = write_diag ? 1.0 : 0.0;
-    A.blk[0 * ns + k0] = s * d00; A.blk[1 * ns + k0] = s * d01; A.blk[2 * ns + k0] = s * d02;
-    A.blk[3 * ns + k0] = s * d01; A.blk[4 * ns + k0] = s * d11; A.blk[5 * ns + k0] = s * d12;
-    A.blk[6 * ns + k0] = s * d02; A.blk[7 * ns + k0] = s * d12; A.blk[8 * ns + k0] = s * d22;
+    A.blk[blk_at(0, k0, ns)] = s * d00; A.blk[blk_at(1, k0, ns)] = s * d01; A.blk[blk_at(2, k0, ns)] = s * d02;
+    A.blk[blk_at(3, k0, ns)] = s * d01; A.blk[blk_at(4, k0, ns)] = s * d11; A.blk[blk_at(5, k0, ns)] = s * d12;
+    A.blk[blk_at(6, k0, ns)] = s * d02; A.blk[blk_at(7, k0, ns)] = s * d12; A.blk[blk_at(8, k0, ns)] = s * d22;
     if (A.blkf) {
-      A.blkf[0 * ns + k0] = (float)(s * d00); A.blkf[1 * ns + k0] = (float)(s * d01); A.blkf[2 * ns + k0] = (float)(s * d02);
-      A.blkf[3 * ns + k0] = (float)(s * d01); A.blkf[4 * ns + k0] = (float)(s * d11); A.blkf[5 * ns + k0] = (float)(s * d12);
-      A.blkf[6 * ns + k0] = (float)(s * d02); A.blkf[7 * ns + k0] = (float)(s * d12); A.blkf[8 * ns + k0] = (float)(s * d22);
+      A.blkf[blk_at(0, k0, ns)] = (float)(s * d00); A.blkf[blk_at(1, k0, ns)] = (float)(s * d01); A.blkf[blk_at(2, k0, ns)] = (float)(s * d02);
+      A.blkf[blk_at(3, k0, ns)] = (float)(s * d01); A.blkf[blk_at(4, k0, ns)] = (float)(s * d11); A.blkf[blk_at(5, k0, ns)] = (float)(s * d12);
+      A.blkf[blk_at(6, k0, ns)] = (float)(s * d02); A.blkf[blk_at(7, k0, ns)] = (float)(s * d12); A.blkf[blk_at(8, k0, ns)] = (float)(s * d22);
     }
     // symmetric 3x3 inverse by cofactors
     const double c00 = d11 * d22 - d12 * d12, c01 = d02 * d12 - d01 * d22, c02 = d01 * d12 - d02 * d11;
@@ -360,9 +360,20 @@ __global__ __launch_bounds__(kBlock) void k_spmv(BsrDev A, SpmvArgs a) {
       row = A.row[k];
       double x0, x1, x2;
       operand((size_t)A.col[k], x0, x1, x2);
-      acc[0] += (double)blk[k] * x0 + (double)blk[ns + k] * x1 + (double)blk[2 * ns + k] * x2;
-      acc[1] += (double)blk[3 * ns + k] * x0 + (double)blk[4 * ns + k] * x1 + (double)blk[5 * ns + k] * x2;
-      acc[2] += (double)blk[6 * ns + k] * x0 + (double)blk[7 * ns + k] * x1 + (double)blk[8 * ns + k] * x2;
+      double b0, b1, b2, b3, b4, b5, b6, b7;
+      if (sizeof(BlkT) == 8) {  // four 16-byte loads (component pairs) + one 8-byte load
+        const double2* __restrict__ bp = reinterpret_cast<const double2*>(A.blk);
+        const double2 p0 = bp[k], p1 = bp[ns + k], p2 = bp[2 * ns + k], p3 = bp[3 * ns + k];
+        b0 = p0.x; b1 = p0.y; b2 = p1.x; b3 = p1.y; b4 = p2.x; b5 = p2.y; b6 = p3.x; b7 = p3.y;
+      } else {
+        b0 = (double)blk[blk_at(0, k, ns)]; b1 = (double)blk[blk_at(1, k, ns)]; b2 = (double)blk[blk_at(2, k, ns)];
+        b3 = (double)blk[blk_at(3, k, ns)]; b4 = (double)blk[blk_at(4, k, ns)]; b5 = (double)blk[blk_at(5, k, ns)];
+        b6 = (double)blk[blk_at(6, k, ns)]; b7 = (double)blk[blk_at(7, k, ns)];
+      }
+      const double b8 = (double)blk[8 * ns + k];
+      acc[0] += b0 * x0 + b1 * x1 + b2 * x2;
+      acc[1] += b3 * x0 + b4 * x1 + b5 * x2;
+      acc[2] += b6 * x0 + b7 * x1 + b8 * x2;
     }
     seg_scan<3>(row, acc, lane);
     const int rn = __shfl_down(row, 1);
