@@ -14,8 +14,8 @@
 // All of it is HBM-/cache-bound fp64 gather + stream work on 3x3 blocks: no MFMA (a 3x3 block is
 // not a dense contraction).  Design rules used (cdna_hip_programming.md G2, G11, G12, G13,
 // Appendix B scatter/gather): SoA slot arrays (blocks in component pairs) so every wave load is
-// one contiguous 512-B or 1-KiB segment; per-row sums by a wavefront segmented scan over row-aligned slot groups (no atomics,
-// bitwise reproducible); grids capped at 2048 blocks and mapped so that each XCD walks one
+// one contiguous 512-B or 1-KiB segment; per-row sums by a wavefront segmented scan over
+// row-aligned slot groups (no atomics, bitwise reproducible); grids capped at 2048 blocks and mapped so that each XCD walks one
 // contiguous band of rows (its L2 then holds that band's vector entries).
 #include "sgo_device.h"
 #include "sgo_internal.h"
