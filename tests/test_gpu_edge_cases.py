@@ -152,3 +152,30 @@ def test_c99_example_runs(tmp_path):
     out = subprocess.run([str(exe)], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "iterations 10" in out.stdout
+
+
+def test_repeated_set_graph_and_optimize_do_not_leak_device_memory():
+    """The reference re-runs initializeOptimization + optimize(20) after every accepted loop closure
+    on a growing graph (slc.cpp:286-287): hundreds of set_graph / optimize cycles per run."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    free = ctypes.c_size_t()
+    total = ctypes.c_size_t()
+
+    def used():
+        assert hip.hipMemGetInfo(ctypes.byref(free), ctypes.byref(total)) == 0
+        return total.value - free.value
+
+    graphs = [synth.manhattan(400 + 40 * k, 900 + 90 * k, seed=50 + k) for k in range(4)]
+    with capi.Optimizer(0) as o:
+        for g in graphs:          # warm the allocator / code objects
+            o.set_graph(*g.arrays())
+            o.optimize(2)
+        base = used()
+        for rep in range(40):
+            g = graphs[rep % 4]
+            o.set_graph(*g.arrays())
+            done, _ = o.optimize(3)
+            assert done == 3
+        grown = used() - base
+    assert grown < 64 << 20, f"device memory grew by {grown / 2**20:.1f} MiB over 40 set_graph/optimize cycles"
