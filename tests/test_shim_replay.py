@@ -90,3 +90,19 @@ def test_shim_container_semantics():
     subprocess.check_call(["make", "-s", "-C", CPP, "shim_semantics"])
     out = subprocess.run([os.path.join(CPP, "shim_semantics")], capture_output=True, text=True)
     assert out.returncode == 0 and out.stdout.strip() == "ok", out.stderr
+
+
+def test_cmake_find_module_resolves_g2o_to_this_backend(tmp_path):
+    """cmake/FindG2O.cmake defines the variables sparse-gslam's CMakeLists consumes
+    (find_package(G2O REQUIRED); G2O_*_LIBRARY list at src/sparse_gslam/CMakeLists.txt:235-243)."""
+    import shutil
+    if shutil.which("cmake") is None:
+        pytest.skip("cmake not installed")
+    build = tmp_path / "b"
+    subprocess.check_call(["cmake", "-S", os.path.join(ROOT, "tests", "cmake_project"), "-B", str(build),
+                           f"-DSGO_ROOT={ROOT}"], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["cmake", "--build", str(build)], stdout=subprocess.DEVNULL)
+    exe = build / "replay"
+    assert exe.exists()
+    out = subprocess.run(["ldd", str(exe)], capture_output=True, text=True).stdout
+    assert "libsgo.so" in out and "not found" not in out
