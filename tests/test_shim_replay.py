@@ -106,3 +106,23 @@ def test_cmake_find_module_resolves_g2o_to_this_backend(tmp_path):
     assert exe.exists()
     out = subprocess.run(["ldd", str(exe)], capture_output=True, text=True).stdout
     assert "libsgo.so" in out and "not found" not in out
+
+
+REF_INC = "/root/reference/src/sparse_gslam/include"
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_INC), reason="reference checkout not present (GPU box)")
+def test_reference_custom_type_headers_compile_against_the_shim(tmp_path):
+    """The reference's own g2o_bindings/{vertex_rhotheta,edge_se2_rhotheta}.h (included from the
+    read-only checkout, not copied) are accepted by the compat headers: subclass ABI of SURVEY.md
+    section 2 row 6.  tests/eigen_stub/ only forwards <Eigen/...> to the compat layer's stand-in."""
+    exe = tmp_path / "ref_check"
+    subprocess.check_call(["g++", "-std=c++14", "-Wall", "-I" + os.path.join(ROOT, "include"),
+                           "-I" + os.path.join(ROOT, "tests", "eigen_stub"), "-I" + REF_INC,
+                           os.path.join(CPP, "ref_headers_check.cpp"), "-L" + os.path.join(ROOT, "sparse_gslam_amd", "csrc"),
+                           "-lsgo", "-L/opt/rocm/lib", "-Wl,-rpath," + os.path.join(ROOT, "sparse_gslam_amd", "csrc"),
+                           "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)])
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    its, chi2 = out.stdout.split()[:2]
+    assert int(its) >= 1 and float(chi2) < 1e-12
