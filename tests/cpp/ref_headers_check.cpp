@@ -14,6 +14,7 @@
 #include "g2o/core/sparse_optimizer.h"
 #include "g2o/solvers/eigen/linear_solver_eigen.h"
 #include "g2o/stuff/macros.h"
+#include "delta_vector.h"   // reference header: struct Delta { double dt; g2o::SE2 dpose; } in an aligned vector
 #include "g2o_bindings/edge_se2_rhotheta.h"
 #include "g2o_bindings/vertex_rhotheta.h"
 
@@ -70,6 +71,9 @@ int main() {
   opt.computeActiveErrors();
   const double chi2 = opt.activeChi2();
   opt.discardTop();
+  DeltaVector dv;
+  dv.push_back({0.1, p1.estimate()});
+  if (dv.size() != 1 || dv[0].dpose[0] != p1.estimate()[0]) return 2;
   std::cout << its << " " << chi2 << " " << lm.estimate()[0] << " " << p1.estimate()[0] << std::endl;
   delete opt.algorithm();
   return (its >= 1 && chi2 < 1e-12) ? 0 : 1;
