@@ -202,3 +202,39 @@ def test_generator_is_deterministic_and_matches_committed_digest():
         for a in g.arrays():
             h.update(np.ascontiguousarray(a).tobytes())
         assert h.hexdigest() == str(np.load(big)["digest"])
+
+
+def test_jacobians_match_symbolic_derivation():
+    """EdgeSE2::linearizeOplus re-derived symbolically (sympy): e = toVector(Z^-1 * (Xi^-1 * Xj)) with
+    the additive vertex update t += d[0:2], theta += d[2] (VertexSE2::oplusImpl), differentiated at
+    d = 0 ignoring the wrap.  Pins both restatements' analytic A = de/dXi, B = de/dXj."""
+    sp = pytest.importorskip("sympy")
+    xi, yi, ti, xj, yj, tj, zx, zy, zt = sp.symbols("xi yi ti xj yj tj zx zy zt", real=True)
+
+    def R(t):
+        return sp.Matrix([[sp.cos(t), -sp.sin(t)], [sp.sin(t), sp.cos(t)]])
+
+    def inv(x, y, t):
+        p = R(-t) * sp.Matrix([-x, -y])
+        return p[0], p[1], -t
+
+    def mul(a, b):
+        p = sp.Matrix([a[0], a[1]]) + R(a[2]) * sp.Matrix([b[0], b[1]])
+        return p[0], p[1], a[2] + b[2]
+
+    e = mul(inv(zx, zy, zt), mul(inv(xi, yi, ti), (xj, yj, tj)))
+    E = sp.Matrix(e)
+    A = E.jacobian([xi, yi, ti])
+    B = E.jacobian([xj, yj, tj])
+    fA = sp.lambdify([xi, yi, ti, xj, yj, tj, zx, zy, zt], A, "numpy")
+    fB = sp.lambdify([xi, yi, ti, xj, yj, tj, zx, zy, zt], B, "numpy")
+    rng = np.random.default_rng(11)
+    for _ in range(25):
+        v = rng.uniform(-3, 3, 9)
+        v[[2, 5, 8]] = rng.uniform(-PI, PI, 3)
+        Xi, Xj, Z = v[0:3], v[3:6], v[6:9]
+        An, Bn = no.edge_jacobians(Xi[None], Xj[None], Z[None])
+        _, Ac, Bc, _, _, _ = co.edges(Xi, Xj, Z, I6, -1.0)
+        As, Bs = np.array(fA(*v), dtype=float), np.array(fB(*v), dtype=float)
+        assert np.abs(An[0] - As).max() < 1e-12 and np.abs(Bn[0] - Bs).max() < 1e-12
+        assert np.abs(Ac[0] - As).max() < 1e-12 and np.abs(Bc[0] - Bs).max() < 1e-12
