@@ -148,6 +148,7 @@ def main():
             "final_chi2": st["chi2"][-1], "final_robust_chi2": st["robust_chi2"][-1],
             "pcg_iters_per_gn_iter": float(np.mean(st["pcg_iters"])), "pcg_iters": st["pcg_iters"],
             "gn_iter_ms_median": 1e3 * float(np.median(st["seconds"])),
+            "set_graph_ms": 1e3 * st["seconds_setup"],   # host structure build + upload + multigrid set-up (not in value)
             "linearize_ms_median": 1e3 * float(np.median(st["seconds_linearize"])),
         }
     opt.close()
