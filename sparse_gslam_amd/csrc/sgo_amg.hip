@@ -275,51 +275,96 @@ __device__ __forceinline__ void tile_mm(const double (*X)[kGjB + 1], const doubl
   }
 }
 
-// mode 0: row panel    A_Kj <- P A_Kj          (block j = blockIdx.x, skipped when j == kb)
-// mode 1: trailing     A_ij <- A_ij - A_iK A_Kj (blockIdx.x = j, blockIdx.y = i; i, j != kb)
-// mode 2: column panel A_iK <- -A_iK P (i != kb), A_KK <- P
-__global__ __launch_bounds__(kBlock) void k_gj_step(int mode, double* __restrict__ M, int Np, int kb,
-                                                    const double* __restrict__ P) {
+// One Gauss-Jordan block step K = kb is two launches:
+//   k_gj_panels  row panel A_Kj <- P A_Kj (j != K), A_KK <- P, and column panel A_iK <- -A_iK P
+//                (i != K) with the ORIGINAL A_iK saved to Xs[i] for the trailing update;
+//   k_gj_trail   A_ij <- A_ij - Xs_i A_Kj (i, j != K); the workgroup that finishes the next
+//                diagonal block (K+1, K+1) inverts it in LDS straight away and leaves it in P,
+//                so no separate pivot launch sits on the critical path.
+__global__ __launch_bounds__(kBlock) void k_gj_panels(double* __restrict__ M, int Np, int kb, const double* __restrict__ P,
+                                                      double* __restrict__ Xs) {
   __shared__ double X[kGjB][kGjB + 1], Y[kGjB][kGjB + 1];
-  const int t = threadIdx.x, K0 = kb * kGjB;
-  const int bj = blockIdx.x, bi = (mode == 1) ? blockIdx.y : blockIdx.x;
-  if (mode == 0 && bj == kb) return;
-  if (mode == 1 && (bi == kb || bj == kb)) return;
-  const int r = t >> 3, c0 = (t & 7) * 4;
-  if (mode == 2 && bi == kb) {
-    for (int e = t; e < kGjB * kGjB; e += kBlock) M[(size_t)(K0 + e / kGjB) * Np + K0 + e % kGjB] = P[e];
+  const int t = threadIdx.x, K0 = kb * kGjB, nb = Np / kGjB;
+  const bool rowp = (int)blockIdx.x < nb;
+  const int b = rowp ? blockIdx.x : blockIdx.x - nb;
+  if (b == kb) {
+    if (rowp)
+      for (int e = t; e < kGjB * kGjB; e += kBlock) M[(size_t)(K0 + e / kGjB) * Np + K0 + e % kGjB] = P[e];
     return;
   }
-  // load operands
   for (int e = t; e < kGjB * kGjB; e += kBlock) {
     const int i = e / kGjB, j = e % kGjB;
-    if (mode == 0) {
+    if (rowp) {
       X[i][j] = P[e];
-      Y[i][j] = M[(size_t)(K0 + i) * Np + bj * kGjB + j];
-    } else if (mode == 1) {
-      X[i][j] = M[(size_t)(bi * kGjB + i) * Np + K0 + j];
-      Y[i][j] = M[(size_t)(K0 + i) * Np + bj * kGjB + j];
+      Y[i][j] = M[(size_t)(K0 + i) * Np + b * kGjB + j];
     } else {
-      X[i][j] = M[(size_t)(bi * kGjB + i) * Np + K0 + j];
+      const double v = M[(size_t)(b * kGjB + i) * Np + K0 + j];
+      X[i][j] = v;
+      Xs[(size_t)b * kGjB * kGjB + e] = v;
       Y[i][j] = P[e];
     }
   }
   __syncthreads();
   double o[4];
   tile_mm(X, Y, o);
-  if (mode == 0) {
-    double* dst = M + (size_t)(K0 + r) * Np + bj * kGjB + c0;
+  const int r = t >> 3, c0 = (t & 7) * 4;
+  if (rowp) {
+    double* dst = M + (size_t)(K0 + r) * Np + b * kGjB + c0;
 #pragma unroll
     for (int q = 0; q < 4; ++q) dst[q] = o[q];
-  } else if (mode == 1) {
-    double* dst = M + (size_t)(bi * kGjB + r) * Np + bj * kGjB + c0;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) dst[q] -= o[q];
   } else {
-    double* dst = M + (size_t)(bi * kGjB + r) * Np + K0 + c0;
+    double* dst = M + (size_t)(b * kGjB + r) * Np + K0 + c0;
 #pragma unroll
     for (int q = 0; q < 4; ++q) dst[q] = -o[q];
   }
+}
+
+__global__ __launch_bounds__(kBlock) void k_gj_trail(double* __restrict__ M, int Np, int kb, const double* __restrict__ Xs,
+                                                     double* __restrict__ P, int* __restrict__ fail) {
+  __shared__ double X[kGjB][kGjB + 1], Y[kGjB][kGjB + 1];
+  const int t = threadIdx.x, K0 = kb * kGjB;
+  const int bj = blockIdx.x, bi = blockIdx.y;
+  if (bi == kb || bj == kb) return;
+  for (int e = t; e < kGjB * kGjB; e += kBlock) {
+    const int i = e / kGjB, j = e % kGjB;
+    X[i][j] = Xs[(size_t)bi * kGjB * kGjB + e];
+    Y[i][j] = M[(size_t)(K0 + i) * Np + bj * kGjB + j];
+  }
+  __syncthreads();
+  double o[4];
+  tile_mm(X, Y, o);
+  const int r = t >> 3, c0 = (t & 7) * 4;
+  double* dst = M + (size_t)(bi * kGjB + r) * Np + bj * kGjB + c0;
+  double v[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) dst[q] = v[q] = dst[q] - o[q];
+  if (bi != kb + 1 || bj != kb + 1) return;
+  // next pivot block: P = inv(A_K'K') by the same scalar Gauss-Jordan as k_gj_pivot
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 4; ++q) X[r][c0 + q] = v[q];
+  __syncthreads();
+  for (int k = 0; k < kGjB; ++k) {
+    const double akk = X[k][k], aik = X[r][k];
+    double akj[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) akj[q] = X[k][c0 + q];
+    if (t == 0 && (!(akk > 0.0) || !isfinite(akk))) *fail = 1;
+    const double p = (akk != 0.0) ? 1.0 / akk : 0.0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int c = c0 + q;
+      if (r == k) v[q] = (c == k) ? p : akj[q] * p;
+      else if (c == k) v[q] = -aik * p;
+      else v[q] = v[q] - aik * (akj[q] * p);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) X[r][c0 + q] = v[q];
+    __syncthreads();
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) P[r * kGjB + c0 + q] = v[q];
 }
 
 // x = inv * b : one wave per row (inv is symmetric; row reads are coalesced)
@@ -711,6 +756,7 @@ struct Amg {
   int N = 0, Np = 0;
   double* inv = nullptr;
   double* gjP = nullptr;   // [32][32] inverse of the current pivot block
+  double* gjX = nullptr;   // [Np/32][32][32] column panel of the current step before its update
   int* d_fail = nullptr;
   std::string desc;
 };
@@ -893,11 +939,10 @@ int amg_update(Amg* m, hipStream_t s, std::string* err) {
     const int nb = m->Np / kGjB;
     hipMemsetAsync(m->inv, 0, sizeof(double) * (size_t)m->Np * m->Np, s);
     SGO_LAUNCH(k_dense_fill, dim3(grid_for(m->lv[last].A.n, kBlock)), dim3(kBlock), 0, s, m->lv[last].A, m->Np, m->inv);
+    SGO_LAUNCH(k_gj_pivot, dim3(1), dim3(kGjB * kGjB), 0, s, m->inv, m->Np, 0, m->gjP, m->d_fail);
     for (int kb = 0; kb < nb; ++kb) {
-      SGO_LAUNCH(k_gj_pivot, dim3(1), dim3(kGjB * kGjB), 0, s, m->inv, m->Np, kb, m->gjP, m->d_fail);
-      SGO_LAUNCH(k_gj_step, dim3(nb), dim3(kBlock), 0, s, 0, m->inv, m->Np, kb, (const double*)m->gjP);
-      SGO_LAUNCH(k_gj_step, dim3(nb, nb), dim3(kBlock), 0, s, 1, m->inv, m->Np, kb, (const double*)m->gjP);
-      SGO_LAUNCH(k_gj_step, dim3(nb), dim3(kBlock), 0, s, 2, m->inv, m->Np, kb, (const double*)m->gjP);
+      SGO_LAUNCH(k_gj_panels, dim3(2 * nb), dim3(kBlock), 0, s, m->inv, m->Np, kb, (const double*)m->gjP, m->gjX);
+      SGO_LAUNCH(k_gj_trail, dim3(nb, nb), dim3(kBlock), 0, s, m->inv, m->Np, kb, (const double*)m->gjX, m->gjP, m->d_fail);
     }
   }
   if (hipGetLastError() != hipSuccess) {
@@ -1172,8 +1217,9 @@ Amg* amg_create(hipStream_t s, const BsrDev& A0, const double* d_poses, const in
   if (m->N > 3072) return fail("amg_create: coarsest level too large (" + std::to_string(m->N) + " unknowns)");
   m->inv = dev_alloc<double>(m->pool, (size_t)m->Np * m->Np);
   m->gjP = dev_alloc<double>(m->pool, kGjB * kGjB);
+  m->gjX = dev_alloc<double>(m->pool, (size_t)m->Np * kGjB);
   m->d_fail = dev_alloc<int>(m->pool, 1);
-  if (!m->inv || !m->d_fail || !m->gjP) return fail("amg_create: out of device memory");
+  if (!m->inv || !m->d_fail || !m->gjP || !m->gjX) return fail("amg_create: out of device memory");
   hipMemsetAsync(m->d_fail, 0, sizeof(int), s);
   // levels small enough for the single-workgroup tree kernel
   int tree_rows = 2048;
