@@ -499,28 +499,21 @@ int do_spmv(sgo_ctx* c, const double* x, double* y, bool dot, const PcgScalars* 
 int pcg_iteration(sgo_ctx* c) {
   int g1 = 0, g2 = 0, rc;
   if ((rc = do_spmv(c, c->d_p, c->d_q, true, c->d_S, &g1))) return rc;
-  {
-    Scope sc(c, K_ALPHA, 8.0 * g1);
-    launch_alpha(c->stream, c->d_S, c->d_partials, g1);
-  }
   double* parts2 = c->d_partials + kMaxPartials;  // [0] = r.z (block-Jacobi only), [1] = r.r
   {
     Scope sc(c, K_UPDATE_XR, (7 * 24.0 + 48.0) * c->n);
-    launch_update_xr(c->stream, c->n, c->d_S, c->amg ? nullptr : c->A.dinv, c->d_p, c->d_q, c->d_x, c->d_r, c->d_z,
-                     parts2, &g2);
+    launch_update_xr(c->stream, c->n, c->d_S, c->d_partials, g1, c->amg ? nullptr : c->A.dinv, c->d_p, c->d_q, c->d_x,
+                     c->d_r, c->d_z, parts2, &g2);
   }
   if (c->amg) {
     // the K-cycle is a (mildly) variable preconditioner: flexible beta from z.q
     const int gz = amg_apply(c->amg, c->stream, c->d_r, c->d_z, c->d_r, c->d_zparts, c->d_S, c->d_q);
-    Scope sc(c, K_BETA, 8.0 * (2 * gz + g2));
-    launch_beta(c->stream, c->d_S, c->d_zparts, gz, parts2 + kMaxPartials, g2, c->d_zparts + kMaxPartials);
-  } else {
-    Scope sc(c, K_BETA, 16.0 * g2);
-    launch_beta(c->stream, c->d_S, parts2, g2, parts2 + kMaxPartials, g2);
-  }
-  {
     Scope sc(c, K_UPDATE_P, 3 * 24.0 * c->n);
-    launch_update_p(c->stream, c->n, c->d_S, c->d_z, c->d_p);
+    launch_update_p(c->stream, c->n, c->d_S, c->d_zparts, gz, parts2 + kMaxPartials, g2, c->d_zparts + kMaxPartials,
+                    c->d_z, c->d_p);
+  } else {
+    Scope sc(c, K_UPDATE_P, 3 * 24.0 * c->n);
+    launch_update_p(c->stream, c->n, c->d_S, parts2, g2, parts2 + kMaxPartials, g2, nullptr, c->d_z, c->d_p);
   }
   return SGO_OK;
 }

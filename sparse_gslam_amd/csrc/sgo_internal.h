@@ -78,10 +78,11 @@ struct PcgScalars {
   double alpha;
   double beta;
   double tol2;    // pcg_tol^2
+  double rz_prev; // r.z before this iteration's update (recorded by k_update_xr for k_update_p)
   int iter;
   int maxit;
   int stop;       // 0 run, 1 converged, 2 maxit, 3 breakdown (pq <= 0 or non-finite)
-  int pad;
+  int iter_prev;  // iter as k_update_xr saw it
 };
 
 // k_spmv modes and arguments (see sgo_kernels.hip)
@@ -202,13 +203,11 @@ void launch_init_scalars(hipStream_t s, PcgScalars* S, const double* rz_parts, i
 void launch_spmv(hipStream_t s, const BsrDev& A, const double* x, double* y, double* dot_partials,
                  const PcgScalars* S, int* grid_out);
 int launch_spmv_ex(hipStream_t s, const BsrDev& A, int mode, const SpmvArgs& a);  // returns grid
-void launch_alpha(hipStream_t s, PcgScalars* S, const double* partials, int nparts);
-void launch_update_xr(hipStream_t s, int n, const PcgScalars* S, const double* dinv, const double* p,
-                      const double* q, double* x, double* r, double* z, double* partials, int* grid_out);
-// zq_parts != nullptr selects the flexible (Polak-Ribiere) beta = -alpha (z.q) / rz_old
-void launch_beta(hipStream_t s, PcgScalars* S, const double* rz_parts, int n_rz, const double* rr_parts, int n_rr,
-                 const double* zq_parts = nullptr);
-void launch_update_p(hipStream_t s, int n, const PcgScalars* S, const double* z, double* p);
+void launch_update_xr(hipStream_t s, int n, PcgScalars* S, const double* pq_parts, int n_pq, const double* dinv,
+                      const double* p, const double* q, double* x, double* r, double* z, double* partials,
+                      int* grid_out);
+void launch_update_p(hipStream_t s, int n, PcgScalars* S, const double* rz_parts, int n_rz, const double* rr_parts,
+                     int n_rr, const double* zq_parts, const double* z, double* p);
 void launch_pose_update(hipStream_t s, int n, const int* free_id, const double* x, double* poses);
 void launch_dot(hipStream_t s, int n3, const double* a, const double* b, double* partials, const PcgScalars* S,
                 int* grid_out);

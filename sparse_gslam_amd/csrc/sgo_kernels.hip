@@ -281,7 +281,9 @@ __global__ __launch_bounds__(kBlock) void k_init_scalars(PcgScalars* S, const do
     S->alpha = 0.0;
     S->beta = 0.0;
     S->tol2 = tol * tol;
+    S->rz_prev = rz;
     S->iter = 0;
+    S->iter_prev = 0;
     S->maxit = maxit;
     S->stop = (bb == 0.0) ? 1 : (isfinite(bb) && isfinite(rz) ? 0 : 3);
   }
@@ -421,23 +423,28 @@ __global__ __launch_bounds__(kBlock) void k_spmv(BsrDev A, SpmvArgs a) {
   if (a.partials) block_sum_store<2>(dotacc, a.partials, kMaxPartials);
 }
 
-__global__ __launch_bounds__(kBlock) void k_alpha(PcgScalars* S, const double* __restrict__ partials, int nparts) {
-  if (S->stop) return;
-  const double pq = block_reduce_parts(partials, nparts);
-  if (threadIdx.x == 0) {
-    S->pq = pq;
-    if (!(pq > 0.0) || !isfinite(pq)) S->stop = 3;
-    else S->alpha = S->rz / pq;
-  }
-}
-
+// alpha = r.z / p.q from the partials of p.q (every workgroup re-reduces them in the same fixed
+// order, so all agree bit for bit and no single-workgroup scalar kernel sits between the product
+// and the update; workgroup 0 records the scalars), then
 // x += alpha p ; r -= alpha q ; z = Dinv r ; partials: r.z, r.r
-__global__ __launch_bounds__(kBlock) void k_update_xr(int n, const PcgScalars* S, const double* __restrict__ dinv,
-                                                      const double* __restrict__ p, const double* __restrict__ q,
-                                                      double* __restrict__ x, double* __restrict__ r,
-                                                      double* __restrict__ z, double* __restrict__ partials) {
+__global__ __launch_bounds__(kBlock) void k_update_xr(int n, PcgScalars* S, const double* __restrict__ pq_parts, int n_pq,
+                                                      const double* __restrict__ dinv, const double* __restrict__ p,
+                                                      const double* __restrict__ q, double* __restrict__ x,
+                                                      double* __restrict__ r, double* __restrict__ z,
+                                                      double* __restrict__ partials) {
   if (S->stop) return;
-  const double alpha = S->alpha;
+  const double pq = block_reduce_parts(pq_parts, n_pq);
+  const double rz = S->rz;
+  const bool bad = !(pq > 0.0) || !isfinite(pq);
+  const double alpha = rz / pq;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    S->pq = pq;
+    S->rz_prev = rz;
+    S->iter_prev = S->iter;
+    if (bad) S->stop = 3;
+    else S->alpha = alpha;
+  }
+  if (bad) return;
   double acc[2] = {0.0, 0.0};
   for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
     const size_t o = 3 * (size_t)i;
@@ -457,31 +464,32 @@ __global__ __launch_bounds__(kBlock) void k_update_xr(int n, const PcgScalars* S
   block_sum_store<2>(acc, partials, kMaxPartials);
 }
 
-__global__ __launch_bounds__(kBlock) void k_beta(PcgScalars* S, const double* __restrict__ rz_parts, int n_rz,
-                                                 const double* __restrict__ rr_parts, int n_rr,
-                                                 const double* __restrict__ zq_parts) {
+// beta and the stopping test from the partials of r.z, r.r (and z.q), re-reduced by every
+// workgroup as above, then p = z + beta p (flat over 3n).  Reads rz_prev / alpha, which the
+// k_update_xr of this iteration recorded, so workgroup 0 can overwrite S->rz while the others
+// are still running.
+__global__ __launch_bounds__(kBlock) void k_update_p(int n3, PcgScalars* S, const double* __restrict__ rz_parts, int n_rz,
+                                                     const double* __restrict__ rr_parts, int n_rr,
+                                                     const double* __restrict__ zq_parts, const double* __restrict__ z,
+                                                     double* __restrict__ p) {
   if (S->stop) return;
   const double rz = block_reduce_parts(rz_parts, n_rz);
   const double rr = block_reduce_parts(rr_parts, n_rr);
   // flexible CG (variable preconditioner, e.g. the K-cycle): z_new.(r_new - r_old) = -alpha z_new.q
   const double zq = zq_parts ? block_reduce_parts(zq_parts, n_rz) : 0.0;
-  if (threadIdx.x == 0) {
-    S->beta = zq_parts ? -S->alpha * zq / S->rz : rz / S->rz;
+  const double beta = zq_parts ? -S->alpha * zq / S->rz_prev : rz / S->rz_prev;
+  int stop = 0;
+  if (!isfinite(rz) || !isfinite(rr)) stop = 3;
+  else if (rr <= S->tol2 * S->bb) stop = 1;
+  else if (S->iter_prev + 1 >= S->maxit) stop = 2;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    S->beta = beta;
     S->rz = rz;
     S->rr = rr;
-    const int it = S->iter + 1;
-    S->iter = it;
-    if (!isfinite(rz) || !isfinite(rr)) S->stop = 3;
-    else if (rr <= S->tol2 * S->bb) S->stop = 1;
-    else if (it >= S->maxit) S->stop = 2;
+    S->iter = S->iter_prev + 1;
+    if (stop) S->stop = stop;
   }
-}
-
-// p = z + beta p   (flat over 3n)
-__global__ __launch_bounds__(kBlock) void k_update_p(int n3, const PcgScalars* S, const double* __restrict__ z,
-                                                     double* __restrict__ p) {
-  if (S->stop) return;
-  const double beta = S->beta;
+  if (stop) return;
   for (int i = blockIdx.x * kBlock + threadIdx.x; i < n3; i += gridDim.x * kBlock) p[i] = z[i] + beta * p[i];
 }
 
@@ -581,22 +589,17 @@ void launch_spmv(hipStream_t s, const BsrDev& A, const double* x, double* y, dou
   const int grid = launch_spmv_ex(s, A, SPMV_AX, a);
   if (grid_out) *grid_out = grid;
 }
-void launch_alpha(hipStream_t s, PcgScalars* S, const double* partials, int nparts) {
-  SGO_LAUNCH(k_alpha, dim3(1), dim3(kBlock), 0, s, S, partials, nparts);
-}
-void launch_update_xr(hipStream_t s, int n, const PcgScalars* S, const double* dinv, const double* p,
-                      const double* q, double* x, double* r, double* z, double* partials, int* grid_out) {
+void launch_update_xr(hipStream_t s, int n, PcgScalars* S, const double* pq_parts, int n_pq, const double* dinv,
+                      const double* p, const double* q, double* x, double* r, double* z, double* partials,
+                      int* grid_out) {
   const int grid = grid_for(n, kBlock);
-  SGO_LAUNCH(k_update_xr, dim3(grid), dim3(kBlock), 0, s, n, S, dinv, p, q, x, r, z, partials);
+  SGO_LAUNCH(k_update_xr, dim3(grid), dim3(kBlock), 0, s, n, S, pq_parts, n_pq, dinv, p, q, x, r, z, partials);
   if (grid_out) *grid_out = grid;
 }
-void launch_beta(hipStream_t s, PcgScalars* S, const double* rz_parts, int n_rz, const double* rr_parts, int n_rr,
-                 const double* zq_parts) {
-  SGO_LAUNCH(k_beta, dim3(1), dim3(kBlock), 0, s, S, rz_parts, n_rz, rr_parts, n_rr, zq_parts);
-}
-void launch_update_p(hipStream_t s, int n, const PcgScalars* S, const double* z, double* p) {
+void launch_update_p(hipStream_t s, int n, PcgScalars* S, const double* rz_parts, int n_rz, const double* rr_parts,
+                     int n_rr, const double* zq_parts, const double* z, double* p) {
   const int grid = grid_for(3LL * n, kBlock);
-  SGO_LAUNCH(k_update_p, dim3(grid), dim3(kBlock), 0, s, 3 * n, S, z, p);
+  SGO_LAUNCH(k_update_p, dim3(grid), dim3(kBlock), 0, s, 3 * n, S, rz_parts, n_rz, rr_parts, n_rr, zq_parts, z, p);
 }
 void launch_pose_update(hipStream_t s, int n, const int* free_id, const double* x, double* poses) {
   const int grid = grid_for(n, kBlock);
