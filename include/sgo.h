@@ -130,6 +130,31 @@ int sgo_chi2(sgo_ctx* ctx, double* plain, double* robust);
  * e2[E] in the edge order given to sgo_set_graph_se2. */
 int sgo_edge_chi2(sgo_ctx* ctx, double* e2);
 
+/* Replaces: the covariance producer of a loop closure and its use as the edge information
+ * (src/sparse_gslam/src/cartographer_bindings/fast_correlative_scan_matcher_2d.cc:537-561,
+ * submap_loop_closer.cpp:276), batched: for match q the scores of the
+ * (2 w + 1) x (2 w + 1) x (2 scan_window + 1) window around the best candidate, in the reference's
+ * loop order (x offset i outermost, y offset j, scan index k fastest), give
+ *     x(i,j,k) = (-j res, -i res, (k - num_angular_perturbations) angular_step)
+ *                 (include/cartographer_bindings/correlative_scan_matcher_2d.h:78-82)
+ *     K = sum score x x^T, u = sum score x, s = sum score,   cov = K / s - u u^T / s^2,
+ * and information = cov^-1 (3x3 row-major, cofactors / determinant as Eigen's fixed-size inverse).
+ * A window with s == 0 or a singular covariance yields non-finite entries, as the reference's
+ * arithmetic does.  Needs no graph.  scores are addressed from win[q].score_offset. */
+typedef struct sgo_match_window {
+  int32_t x_index_offset;   /* best candidate (cells) */
+  int32_t y_index_offset;
+  int32_t scan_index;
+  int32_t scan_window;      /* min(w, scan_index, n_scans - 1 - scan_index) at the call site */
+  int32_t w_size;           /* 5 in the reference */
+  int32_t num_angular_perturbations;
+  double resolution;        /* SearchParameters::resolution */
+  double angular_step;      /* SearchParameters::angular_perturbation_step_size */
+  int64_t score_offset;     /* first score of this window in scores[] */
+} sgo_match_window;
+int sgo_closure_information(sgo_ctx* ctx, int32_t n, const sgo_match_window* win, const float* scores,
+                            int64_t n_scores, double* cov /*[n][9]*/, double* info /*[n][9]*/);
+
 /* ---- single-step entry points (what BlockSolver::buildSystem / solve expose inside g2o);
  *      used by the parity tests to check each kernel against the oracle. ---------------------- */
 /* number of free (non-fixed, active) vertices n; hessian index h -> vertex id in free_ids[n] */

@@ -293,3 +293,39 @@ def gauss_newton(poses, fixed, ei, ej, meas, info, phi, iters=20, solver="direct
     stats["chi2"].append(c2)
     stats["robust_chi2"].append(rc2)
     return poses, stats
+
+
+def closure_information(win, scores):
+    """Covariance of one scan-match window and the information matrix made from it.
+
+    Follows src/sparse_gslam/src/cartographer_bindings/fast_correlative_scan_matcher_2d.cc:537-561
+    (K, u, s accumulated in double over i, j, k in that loop order, scores are float;
+    cov = K / s - u u^T / s^2), the pose of a cell from
+    include/cartographer_bindings/correlative_scan_matcher_2d.h:78-82, and
+    submap_loop_closer.cpp:276 (information = covariance.inverse()).
+    `win`: dict with x_index_offset, y_index_offset, scan_index, scan_window, w_size,
+    num_angular_perturbations, resolution, angular_step; `scores`: the window's scores, k fastest."""
+    w, sw = win["w_size"], win["scan_window"]
+    sc = np.asarray(scores, dtype=np.float32).reshape(2 * w + 1, 2 * w + 1, 2 * sw + 1)
+    K = np.zeros((3, 3))
+    u = np.zeros(3)
+    s = 0.0
+    for a, i in enumerate(range(win["x_index_offset"] - w, win["x_index_offset"] + w + 1)):
+        for b, j in enumerate(range(win["y_index_offset"] - w, win["y_index_offset"] + w + 1)):
+            for c, k in enumerate(range(win["scan_index"] - sw, win["scan_index"] + sw + 1)):
+                x = np.array([-j * win["resolution"], -i * win["resolution"],
+                              (k - win["num_angular_perturbations"]) * win["angular_step"]])
+                score = float(sc[a, b, c])
+                K += np.outer(x, x) * score
+                u += x * score
+                s += score
+    with np.errstate(divide="ignore", invalid="ignore"):
+        d = np.float64(1.0) / np.float64(s)
+        cov = d * K - d * d * np.outer(u, u)
+        c = cov
+        cof = np.array([[c[1, 1] * c[2, 2] - c[1, 2] * c[2, 1], c[0, 2] * c[2, 1] - c[0, 1] * c[2, 2], c[0, 1] * c[1, 2] - c[0, 2] * c[1, 1]],
+                        [c[1, 2] * c[2, 0] - c[1, 0] * c[2, 2], c[0, 0] * c[2, 2] - c[0, 2] * c[2, 0], c[0, 2] * c[1, 0] - c[0, 0] * c[1, 2]],
+                        [c[1, 0] * c[2, 1] - c[1, 1] * c[2, 0], c[0, 1] * c[2, 0] - c[0, 0] * c[2, 1], c[0, 0] * c[1, 1] - c[0, 1] * c[1, 0]]])
+        det = c[0, 0] * cof[0, 0] + c[0, 1] * cof[1, 0] + c[0, 2] * cof[2, 0]
+        info = cof * (np.float64(1.0) / det)
+    return cov, info

@@ -27,6 +27,7 @@ SYMBOLS = [
     "sgo_num_free", "sgo_free_ids", "sgo_linearize", "sgo_hessian_apply", "sgo_solve",
     "sgo_precondition", "sgo_kernel_profile", "sgo_profile_reset", "sgo_profile_overhead_ms", "sgo_comm_unique_id",
     "sgo_comm_init", "sgo_comm_size", "sgo_shard_range", "sgo_debug_set_shard", "sgo_last_error",
+    "sgo_closure_information",
 ]
 
 
@@ -51,6 +52,13 @@ class Stats(C.Structure):
                 ("seconds_linearize", C.c_double * SGO_MAX_ITERS),
                 ("seconds_solve", C.c_double * SGO_MAX_ITERS),
                 ("seconds_total", C.c_double), ("seconds_setup", C.c_double)]
+
+
+class MatchWindow(C.Structure):
+    """sgo_match_window (include/sgo.h): one scan-match score window."""
+    _fields_ = [("x_index_offset", C.c_int32), ("y_index_offset", C.c_int32), ("scan_index", C.c_int32),
+                ("scan_window", C.c_int32), ("w_size", C.c_int32), ("num_angular_perturbations", C.c_int32),
+                ("resolution", C.c_double), ("angular_step", C.c_double), ("score_offset", C.c_int64)]
 
 
 class KernelStat(C.Structure):
@@ -111,6 +119,7 @@ def lib():
     L.sgo_shard_range.restype = None
     L.sgo_shard_range.argtypes = [C.c_int32, C.c_int32, C.c_int32, i32, i32]
     L.sgo_debug_set_shard.argtypes = [vp, C.c_int, C.c_int]
+    L.sgo_closure_information.argtypes = [vp, C.c_int32, C.POINTER(MatchWindow), C.POINTER(C.c_float), C.c_int64, d, d]
     L.sgo_last_error.restype = C.c_char_p
     L.sgo_last_error.argtypes = [vp]
     _LIB = L
@@ -255,6 +264,27 @@ class Optimizer:
         out = np.empty(self.E)
         self._check(lib().sgo_edge_chi2(self._h, _dp(out)), "sgo_edge_chi2")
         return out
+
+    def closure_information(self, windows, scores):
+        """Covariance and information of a batch of scan-match windows (sgo_closure_information).
+
+        windows: sequence of dicts with the sgo_match_window fields except score_offset, which is
+        assigned here (the windows' scores are laid out back to back in `scores`) unless given."""
+        n = len(windows)
+        arr = (MatchWindow * max(n, 1))()
+        off = 0
+        for q, w in enumerate(windows):
+            for k in ("x_index_offset", "y_index_offset", "scan_index", "scan_window", "w_size",
+                      "num_angular_perturbations", "resolution", "angular_step"):
+                setattr(arr[q], k, w[k])
+            arr[q].score_offset = w.get("score_offset", off)
+            off += (2 * w["w_size"] + 1) ** 2 * (2 * w["scan_window"] + 1)
+        sc = np.ascontiguousarray(scores, dtype=np.float32)
+        cov = np.empty((n, 3, 3))
+        info = np.empty((n, 3, 3))
+        self._check(lib().sgo_closure_information(self._h, n, arr, sc.ctypes.data_as(C.POINTER(C.c_float)),
+                                                  sc.size, _dp(cov), _dp(info)), "sgo_closure_information")
+        return cov, info
 
     # -- single steps (parity tests)
     def linearize(self):

@@ -831,6 +831,62 @@ int sgo_edge_chi2(sgo_ctx* c, double* e2) {
   return SGO_OK;
 }
 
+int sgo_closure_information(sgo_ctx* c, int32_t n, const sgo_match_window* win, const float* scores, int64_t n_scores,
+                            double* cov, double* info) {
+  if (!c) return SGO_EINVAL;
+  if (n < 0 || n_scores < 0 || (n > 0 && (!win || !scores || !cov || !info))) {
+    c->err = "sgo_closure_information: null buffer or negative count";
+    return SGO_EINVAL;
+  }
+  if (n == 0) return SGO_OK;
+  // every window must lie inside scores[]: the kernel trusts these bounds
+  for (int q = 0; q < n; ++q) {
+    const sgo_match_window& W = win[q];
+    if (W.w_size < 0 || W.w_size > 1024 || W.scan_window < 0 || W.scan_window > 1024 || W.score_offset < 0) {
+      c->err = "sgo_closure_information: window " + std::to_string(q) + " has a negative or oversized extent";
+      return SGO_EINVAL;
+    }
+    const int64_t nw = 2 * (int64_t)W.w_size + 1, total = nw * nw * (2 * (int64_t)W.scan_window + 1);
+    if (total > INT32_MAX || W.score_offset + total > n_scores) {
+      c->err = "sgo_closure_information: window " + std::to_string(q) + " reaches past scores[n_scores]";
+      return SGO_EINVAL;
+    }
+  }
+  HIP_TRY(c, hipSetDevice(c->device));
+  sgo_match_window* d_win = nullptr;
+  float* d_sc = nullptr;
+  double* d_out = nullptr;
+  auto release = [&]() {
+    if (d_win) hipFree(d_win);
+    if (d_sc) hipFree(d_sc);
+    if (d_out) hipFree(d_out);
+  };
+  if (hipMalloc(&d_win, sizeof(sgo_match_window) * (size_t)n) != hipSuccess ||
+      hipMalloc(&d_sc, sizeof(float) * (size_t)std::max<int64_t>(n_scores, 1)) != hipSuccess ||
+      hipMalloc(&d_out, sizeof(double) * 18 * (size_t)n) != hipSuccess) {
+    release();
+    c->err = "sgo_closure_information: out of device memory";
+    return SGO_ENOMEM;
+  }
+  hipError_t e = hipMemcpyAsync(d_win, win, sizeof(sgo_match_window) * (size_t)n, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess)
+    e = hipMemcpyAsync(d_sc, scores, sizeof(float) * (size_t)n_scores, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) {
+    launch_closure_cov(c->stream, n, d_win, d_sc, d_out, d_out + 9 * (size_t)n);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(cov, d_out, sizeof(double) * 9 * (size_t)n, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess)
+    e = hipMemcpyAsync(info, d_out + 9 * (size_t)n, sizeof(double) * 9 * (size_t)n, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  release();
+  if (e != hipSuccess) {
+    c->err = std::string("sgo_closure_information: ") + hipGetErrorString(e);
+    return SGO_EHIP;
+  }
+  return SGO_OK;
+}
+
 int sgo_linearize(sgo_ctx* c, double* b, double* diag, double* plain, double* robust) {
   int rc = check_graph(c);
   if (rc) return rc;
@@ -987,8 +1043,8 @@ int sgo_optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
     c->linearized = false;
     ++done;
     if (c->opts.verbose)
-      std::fprintf(stderr, "[sgo] iteration= %d\t pcg= %d\t relres= %.3e\n", it, S.iter,
-                   S.bb > 0 ? std::sqrt(S.rr / S.bb) : 0.0);
+      std::fprintf(stderr, "[sgo] iteration= %d\t pcg= %d\t relres= %.3e\t |b|= %.3e\n", it, S.iter,
+                   S.bb > 0 ? std::sqrt(S.rr / S.bb) : 0.0, std::sqrt(S.bb));
   }
   if ((rc = do_chi2(c, c->d_hist + 2 * done, nullptr))) {
     cleanup();

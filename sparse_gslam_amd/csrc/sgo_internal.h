@@ -209,6 +209,8 @@ void launch_update_xr(hipStream_t s, int n, PcgScalars* S, const double* pq_part
 void launch_update_p(hipStream_t s, int n, PcgScalars* S, const double* rz_parts, int n_rz, const double* rr_parts,
                      int n_rr, const double* zq_parts, const double* z, double* p);
 void launch_pose_update(hipStream_t s, int n, const int* free_id, const double* x, double* poses);
+void launch_closure_cov(hipStream_t s, int n, const sgo_match_window* win, const float* scores, double* cov,
+                        double* info);
 void launch_dot(hipStream_t s, int n3, const double* a, const double* b, double* partials, const PcgScalars* S,
                 int* grid_out);
 void launch_precond_bj(hipStream_t s, int n, const double* dinv, const double* r, double* z);

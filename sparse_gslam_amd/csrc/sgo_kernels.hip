@@ -601,6 +601,57 @@ void launch_update_p(hipStream_t s, int n, PcgScalars* S, const double* rz_parts
   const int grid = grid_for(3LL * n, kBlock);
   SGO_LAUNCH(k_update_p, dim3(grid), dim3(kBlock), 0, s, 3 * n, S, rz_parts, n_rz, rr_parts, n_rr, zq_parts, z, p);
 }
+// Score-weighted sample covariance of a scan-match window and its inverse: one wave per match,
+// lanes stride over the window's samples (k fastest, as the reference's loops), ten fp64 sums
+// combined by a fixed-shape wave reduction.
+__global__ __launch_bounds__(kBlock) void k_closure_cov(int n, const sgo_match_window* __restrict__ win,
+                                                        const float* __restrict__ scores, double* __restrict__ cov,
+                                                        double* __restrict__ info) {
+  const int lane = threadIdx.x & 63;
+  for (int q = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6); q < n; q += gridDim.x * kWavesPerBlock) {
+    const sgo_match_window W = win[q];
+    const int nw = 2 * W.w_size + 1, nk = 2 * W.scan_window + 1, total = nw * nw * nk;
+    const float* sc = scores + W.score_offset;
+    double a[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // Kxx Kxy Kxt Kyy Kyt Ktt ux uy ut s
+    for (int e = lane; e < total; e += 64) {
+      const int kk = e % nk, jj = (e / nk) % nw, ii = e / (nk * nw);
+      const int i = W.x_index_offset - W.w_size + ii, j = W.y_index_offset - W.w_size + jj;
+      const int k = W.scan_index - W.scan_window + kk;
+      const double x = -j * W.resolution, y = -i * W.resolution;
+      const double t = (k - W.num_angular_perturbations) * W.angular_step;
+      const double w = (double)sc[e];
+      a[0] += x * x * w; a[1] += x * y * w; a[2] += x * t * w;
+      a[3] += y * y * w; a[4] += y * t * w; a[5] += t * t * w;
+      a[6] += x * w; a[7] += y * w; a[8] += t * w;
+      a[9] += w;
+    }
+#pragma unroll
+    for (int c = 0; c < 10; ++c) a[c] = wave_sum(a[c]);
+    if (lane == 0) {
+      const double d = 1.0 / a[9], d2 = d * d;
+      const double c00 = d * a[0] - d2 * a[6] * a[6], c01 = d * a[1] - d2 * a[6] * a[7], c02 = d * a[2] - d2 * a[6] * a[8];
+      const double c11 = d * a[3] - d2 * a[7] * a[7], c12 = d * a[4] - d2 * a[7] * a[8], c22 = d * a[5] - d2 * a[8] * a[8];
+      double* C = cov + 9 * (size_t)q;
+      C[0] = c00; C[1] = c01; C[2] = c02;
+      C[3] = c01; C[4] = c11; C[5] = c12;
+      C[6] = c02; C[7] = c12; C[8] = c22;
+      // inverse by cofactors / determinant
+      const double k00 = c11 * c22 - c12 * c12, k01 = c02 * c12 - c01 * c22, k02 = c01 * c12 - c02 * c11;
+      const double k11 = c00 * c22 - c02 * c02, k12 = c01 * c02 - c00 * c12, k22 = c00 * c11 - c01 * c01;
+      const double id = 1.0 / (c00 * k00 + c01 * k01 + c02 * k02);
+      double* I = info + 9 * (size_t)q;
+      I[0] = k00 * id; I[1] = k01 * id; I[2] = k02 * id;
+      I[3] = k01 * id; I[4] = k11 * id; I[5] = k12 * id;
+      I[6] = k02 * id; I[7] = k12 * id; I[8] = k22 * id;
+    }
+  }
+}
+
+void launch_closure_cov(hipStream_t s, int n, const sgo_match_window* win, const float* scores, double* cov,
+                        double* info) {
+  const int grid = grid_for(n, kWavesPerBlock);
+  SGO_LAUNCH(k_closure_cov, dim3(grid), dim3(kBlock), 0, s, n, win, scores, cov, info);
+}
 void launch_pose_update(hipStream_t s, int n, const int* free_id, const double* x, double* poses) {
   const int grid = grid_for(n, kBlock);
   SGO_LAUNCH(k_pose_update, dim3(grid), dim3(kBlock), 0, s, n, free_id, x, poses);
