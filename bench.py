@@ -101,12 +101,30 @@ def main():
     if args.tol:
         opts["pcg_tol"] = args.tol
     opt = capi.Optimizer(local_rank, **opts)
+    sharding = f"row-band sharded linearisation x{world}, replicated solve"
     if world > 1 or os.environ.get("SGO_BENCH_FORCE_COMM"):
         # rendezvous for libsgo's own RCCL communicator: rank 0 makes the id, torch broadcasts it
         uid = [capi.comm_unique_id() if rank == 0 else None]
         if world > 1:
             dist.broadcast_object_list(uid, src=0)
-        opt.comm_init(world, rank, uid[0])
+        comm_error = None
+        try:
+            opt.comm_init(world, rank, uid[0])
+        except capi.SgoError as e:   # e.g. librccl not loadable: agree on it across ranks, then run replicated
+            comm_error = str(e)
+        if world > 1:
+            ok = torch.tensor([0 if comm_error else 1], dtype=torch.int32, device="cuda")
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                if comm_error is None:   # this rank has a communicator the others lack: start over without it
+                    opt.close()
+                    opt = capi.Optimizer(local_rank, **opts)
+                    comm_error = "sgo_comm_init failed on another rank"
+                sharding = f"replicated on {world} GPUs (no sharding: {comm_error})"
+                if rank == 0:
+                    print(f"[bench] {sharding}", file=sys.stderr)
+        elif comm_error:
+            raise SystemExit(comm_error)
     opt.set_graph(*g.arrays())
 
     def step():
@@ -144,7 +162,7 @@ def main():
                                    f"optimize({args.iters}) per step",
                        "V": g.V, "E": g.E, "gn_iters_per_step": args.iters,
                        "solver": {0: "pcg_block_jacobi", 1: "pcg_amg"}[opts.get("solver", o.solver)],
-                       "pcg_tol": opts.get("pcg_tol", o.pcg_tol), "parallelism": f"row-band sharded linearisation x{world}, replicated solve"},
+                       "pcg_tol": opts.get("pcg_tol", o.pcg_tol), "parallelism": sharding},
             "final_chi2": st["chi2"][-1], "final_robust_chi2": st["robust_chi2"][-1],
             "pcg_iters_per_gn_iter": float(np.mean(st["pcg_iters"])), "pcg_iters": st["pcg_iters"],
             "gn_iter_ms_median": 1e3 * float(np.median(st["seconds"])),
