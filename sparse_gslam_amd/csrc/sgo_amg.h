@@ -19,8 +19,8 @@ struct AmgConfig {
                             // chain-dominated graphs -- measured a wash, kept off
   double double_ratio = 4.0;   // ... when n / nc < double_ratio (env SGO_AMG_DOUBLE_RATIO)
   int double_from_level = 0;   // ... on levels >= this (env SGO_AMG_DOUBLE_FROM)
-  int coarsest_nodes = 400;  // stop coarsening at or below this many nodes (dense inverse of 3x that
-                           // fits the LDS-resident Gauss-Jordan up to N = 138)
+  int coarsest_nodes = 400;  // stop coarsening at or below this many nodes; that level is inverted densely
+                             // (blocked Gauss-Jordan over 3x that many unknowns) once per GN iteration
 };
 
 // profiling hook supplied by the context (brackets a launch with HIP events when enabled)
@@ -45,6 +45,8 @@ int amg_update(Amg* m, hipStream_t s, std::string* err);
 // dotvec2 (optional) adds partials[kMaxPartials + ..] = dotvec2 . z.
 int amg_apply(Amg* m, hipStream_t s, const double* r, double* z, const double* dotvec, double* partials,
               const PcgScalars* S, const double* dotvec2 = nullptr);
+// true when the last amg_update met a non-positive pivot in the coarsest operator (synchronises `s`)
+bool amg_coarsest_not_spd(Amg* m, hipStream_t s);
 int amg_num_levels(const Amg* m);
 void amg_describe(const Amg* m, std::string* out);
 

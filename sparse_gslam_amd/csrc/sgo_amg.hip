@@ -927,6 +927,13 @@ int cycle(Amg* m, hipStream_t s, int l, const double* rhs, const double* rhs_sub
 }  // namespace
 
 int amg_num_levels(const Amg* m) { return m ? (int)m->lv.size() : 0; }
+bool amg_coarsest_not_spd(Amg* m, hipStream_t s) {
+  int f = 0;
+  if (!m || !m->d_fail) return false;
+  if (hipMemcpyAsync(&f, m->d_fail, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess) return false;
+  if (hipStreamSynchronize(s) != hipSuccess) return false;
+  return f != 0;
+}
 void amg_describe(const Amg* m, std::string* out) { *out = m ? m->desc : ""; }
 
 void amg_destroy(Amg* m) {
@@ -963,6 +970,7 @@ int amg_update(Amg* m, hipStream_t s, std::string* err) {
     Scope sc(m->prof, K_DENSE_INVERT, 8.0 * m->Np * m->Np);
     const int nb = m->Np / kGjB;
     hipMemsetAsync(m->inv, 0, sizeof(double) * (size_t)m->Np * m->Np, s);
+    hipMemsetAsync(m->d_fail, 0, sizeof(int), s);
     SGO_LAUNCH(k_dense_fill, dim3(grid_for(m->lv[last].A.n, kBlock)), dim3(kBlock), 0, s, m->lv[last].A, m->Np, m->inv);
     SGO_LAUNCH(k_gj_pivot, dim3(1), dim3(kGjB * kGjB), 0, s, m->inv, m->Np, 0, m->gjP, m->d_fail);
     for (int kb = 0; kb < nb; ++kb) {
@@ -1071,11 +1079,14 @@ Amg* amg_create(hipStream_t s, const BsrDev& A0, const double* d_poses, const in
     // strength of connection from the current values of this level
     std::vector<double> w(H.nslot);
     {
-      double* d_w = dev_alloc<double>(m->pool, H.nslot);
-      if (!d_w) return fail("amg_create: out of device memory");
+      double* d_w = nullptr;   // scratch of this step only: not kept in the pool
+      if (hipMalloc((void**)&d_w, sizeof(double) * std::max(H.nslot, 1)) != hipSuccess)
+        return fail("amg_create: out of device memory");
       SGO_LAUNCH(k_block_norms, dim3(grid_for(H.nslot, kBlock)), dim3(kBlock), 0, s, L.A, d_w);
       hipMemcpyAsync(w.data(), d_w, sizeof(double) * H.nslot, hipMemcpyDeviceToHost, s);
-      if (hipStreamSynchronize(s) != hipSuccess) return fail("amg_create: strength kernel failed");
+      const hipError_t e = hipStreamSynchronize(s);
+      hipFree(d_w);
+      if (e != hipSuccess) return fail("amg_create: strength kernel failed");
     }
     std::vector<int> agg;
     const double theta_l = l == 0 ? m->cfg.theta : m->cfg.theta_coarse;

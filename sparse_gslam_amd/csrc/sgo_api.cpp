@@ -748,6 +748,10 @@ int sgo_set_graph_se2(sgo_ctx* c, int32_t V, const double* poses, const uint8_t*
     c->err = "sgo_set_graph_se2: bad argument";
     return SGO_EINVAL;
   }
+  if (2 * (int64_t)E + (int64_t)V > (int64_t)INT32_MAX / 2) {  // slot indices are 32-bit (2E + n slots)
+    c->err = "sgo_set_graph_se2: graph too large for 32-bit slot indices";
+    return SGO_EINVAL;
+  }
   hipError_t e = hipSetDevice(c->device);
   if (e != hipSuccess) {
     c->err = std::string("hipSetDevice: ") + hipGetErrorString(e);
@@ -988,28 +992,29 @@ int sgo_optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
   }
   if (c->n == 0) return SGO_ENOTHING;
   const double t0 = wall_s();
-  std::vector<hipEvent_t> ev(3 * (size_t)iters + 1);
-  for (auto& e : ev) HIP_TRY(c, hipEventCreate(&e));
-  auto cleanup = [&]() {
-    for (auto& e : ev) hipEventDestroy(e);
-  };
+  struct Events {  // per-iteration time stamps; destroyed on every return path
+    std::vector<hipEvent_t> v;
+    ~Events() {
+      for (hipEvent_t e : v)
+        if (e) hipEventDestroy(e);
+    }
+  } evs;
+  evs.v.assign(3 * (size_t)iters + 1, nullptr);
+  for (auto& e : evs.v) HIP_TRY(c, hipEventCreate(&e));
+  std::vector<hipEvent_t>& ev = evs.v;
   int done = 0;
   int best_pcg = 0, rebuilds = 0;
   bool rebuild_next = false;
   for (int it = 0; it < iters; ++it) {
     hipEventRecord(ev[3 * it], c->stream);
     if ((rc = do_chi2(c, c->d_hist + 2 * it, nullptr)) || (rc = do_linearize(c))) {
-      cleanup();
       return rc;
     }
     if (rebuild_next && c->amg) {
       // The aggregation was made from the Hessian of an earlier linearisation; robust-kernel
       // re-weighting has changed the strength of connection enough to more than double the PCG
       // iterations: redo the set-up from the current values (same cost as in sgo_set_graph_se2).
-      if ((rc = build_amg(c)) || (rc = do_linearize(c))) {
-        cleanup();
-        return rc;
-      }
+      if ((rc = build_amg(c)) || (rc = do_linearize(c))) return rc;
       rebuild_next = false;
       ++rebuilds;
       best_pcg = 0;
@@ -1017,7 +1022,6 @@ int sgo_optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
     }
     hipEventRecord(ev[3 * it + 1], c->stream);
     if ((rc = run_pcg(c))) {
-      cleanup();
       return rc;
     }
     const PcgScalars S = *c->h_S;
@@ -1031,7 +1035,9 @@ int sgo_optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
       out->pcg_relres[it] = S.bb > 0 ? std::sqrt(S.rr / S.bb) : 0.0;
     }
     if (S.stop == 3) {  // solver failure: estimates stay at the last successful update
-      c->err = "PCG breakdown in GN iteration " + std::to_string(it) + " (Hessian not positive definite)";
+      c->err = "PCG breakdown in GN iteration " + std::to_string(it) + " (Hessian not positive definite";
+      if (c->amg && amg_coarsest_not_spd(c->amg, c->stream)) c->err += "; its coarsest Galerkin operator has a non-positive pivot";
+      c->err += ")";
       hipEventRecord(ev[3 * it + 2], c->stream);
       break;
     }
@@ -1047,7 +1053,6 @@ int sgo_optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
                    S.bb > 0 ? std::sqrt(S.rr / S.bb) : 0.0, std::sqrt(S.bb));
   }
   if ((rc = do_chi2(c, c->d_hist + 2 * done, nullptr))) {
-    cleanup();
     return rc;
   }
   HIP_TRY(c, hipMemcpyAsync(c->h_hist, c->d_hist, sizeof(double) * 2 * (size_t)(done + 1), hipMemcpyDeviceToHost,
@@ -1071,12 +1076,11 @@ int sgo_optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
     }
     out->seconds_total = wall_s() - t0;
   }
-  cleanup();
   return done;
 }
 
 int sgo_kernel_profile(sgo_ctx* c, sgo_kernel_stat* out, int cap) {
-  if (!c) return SGO_EINVAL;
+  if (!c || (cap > 0 && !out)) return SGO_EINVAL;
   prof_flush(c);
   for (int k = 0; k < K_COUNT && k < cap; ++k) {
     out[k].name = kKernelNames[k];
