@@ -196,13 +196,14 @@ __global__ __launch_bounds__(kBlock) void k_prolong_add(int n, const int* __rest
                                                         const double* __restrict__ xadd) {
   if (S && S->stop) return;
   double c1 = 1.0, c2 = 0.0;
-  if (r1.num) {
-    const double den = block_reduce_parts(r1.den, r1.n_den), num = block_reduce_parts(r1.num, r1.n_num);
-    c1 = (den > 0.0 && isfinite(den) && isfinite(num)) ? num / den : 0.0;
-  }
-  if (u2) {
-    const double den = block_reduce_parts(r2.den, r2.n_den), num = block_reduce_parts(r2.num, r2.n_num);
-    c2 = (den > 0.0 && isfinite(den) && isfinite(num)) ? num / den : 0.0;
+  {
+    const double* const parts[4] = {r1.num ? r1.den : nullptr, r1.num, (u2 && r2.num) ? r2.den : nullptr,
+                                    u2 ? r2.num : nullptr};
+    const int cnt[4] = {r1.n_den, r1.n_num, r2.n_den, r2.n_num};
+    double v[4];
+    block_reduce_parts_n<4>(parts, cnt, v);
+    if (r1.num) c1 = (v[0] > 0.0 && isfinite(v[0]) && isfinite(v[1])) ? v[1] / v[0] : 0.0;
+    if (u2) c2 = (v[2] > 0.0 && isfinite(v[2]) && isfinite(v[3])) ? v[3] / v[2] : 0.0;
   }
   for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
     const size_t a = 3 * (size_t)agg[i], o = 3 * (size_t)i;

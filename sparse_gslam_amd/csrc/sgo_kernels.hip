@@ -273,8 +273,11 @@ __global__ __launch_bounds__(kBlock) void k_finalize(BsrDev A, const double* __r
 __global__ __launch_bounds__(kBlock) void k_init_scalars(PcgScalars* S, const double* __restrict__ rz_parts, int n_rz,
                                                          const double* __restrict__ bb_parts, int n_bb, double tol,
                                                          int maxit) {
-  const double rz = block_reduce_parts(rz_parts, n_rz);
-  const double bb = block_reduce_parts(bb_parts, n_bb);
+  const double* const parts[2] = {rz_parts, bb_parts};
+  const int cnt[2] = {n_rz, n_bb};
+  double v[2];
+  block_reduce_parts_n<2>(parts, cnt, v);
+  const double rz = v[0], bb = v[1];
   if (threadIdx.x == 0) {
     S->rz = rz;
     S->bb = bb;
@@ -308,11 +311,19 @@ __global__ __launch_bounds__(kBlock) void k_init_scalars(PcgScalars* S, const do
 //                     dots: partials[0] = x'.y, partials[1] = x'.dotC
 // Optional dot partials (row epilogue): partials[0] += dotA[row].out[row],
 // partials[1] += dotA2[row].out[row]  or  dotB[row].dotC[row].
-__device__ __forceinline__ double ratio_of(const SpmvRatio& r) {
+__device__ __forceinline__ double ratio_value(const SpmvRatio& r, double den, double num) {
   if (!r.num) return r.den ? 0.0 : 1.0;
-  const double den = block_reduce_parts(r.den, r.n_den);
-  const double num = block_reduce_parts(r.num, r.n_num);
   return (den > 0.0 && isfinite(den) && isfinite(num)) ? num / den : 0.0;
+}
+// c1 = ratio r1, c2 = ratio r2 (only when use2): all partial sums in one block reduction
+__device__ __forceinline__ void ratios2(const SpmvRatio& r1, const SpmvRatio& r2, bool use2, double& c1, double& c2) {
+  const double* const parts[4] = {r1.num ? r1.den : nullptr, r1.num, (use2 && r2.num) ? r2.den : nullptr,
+                                  use2 ? r2.num : nullptr};
+  const int cnt[4] = {r1.n_den, r1.n_num, r2.n_den, r2.n_num};
+  double v[4];
+  block_reduce_parts_n<4>(parts, cnt, v);
+  c1 = ratio_value(r1, v[0], v[1]);
+  if (use2) c2 = ratio_value(r2, v[2], v[3]);
 }
 
 // The two level-0 sweeps (JACOBI, PRE_RESID) would take 84 / 76 VGPRs = 5 / 6 waves per SIMD, which
@@ -327,8 +338,7 @@ void k_spmv(BsrDev A, SpmvArgs a) {
   const BlkT* __restrict__ blk = sizeof(BlkT) == 4 ? (const BlkT*)A.blkf : (const BlkT*)A.blk;
   double c1 = 1.0, c2 = 0.0;
   if (MODE == SPMV_JACOBI_P || MODE == SPMV_PRE_RESID_S || MODE == SPMV_AX_C) {
-    c1 = ratio_of(a.c1);
-    if (MODE == SPMV_JACOBI_P && a.u2) c2 = ratio_of(a.c2);
+    ratios2(a.c1, a.c2, MODE == SPMV_JACOBI_P && a.u2 != nullptr, c1, c2);
   }
   // operand of vertex v (3 doubles) under the mode's transformation
   auto operand = [&](size_t v, double& x0, double& x1, double& x2) {
@@ -438,15 +448,17 @@ __global__ __launch_bounds__(kBlock) void k_update_xr(int n, PcgScalars* S, cons
                                                       const double* __restrict__ q, double* __restrict__ x,
                                                       double* __restrict__ r, double* __restrict__ z,
                                                       double* __restrict__ partials) {
-  if (S->stop) return;
-  const double pq = block_reduce_parts(pq_parts, n_pq);
+  // the scalars of the previous launches in one go, before the reduction's barriers
+  const int stop0 = S->stop, iter0 = S->iter;
   const double rz = S->rz;
+  if (stop0) return;
+  const double pq = block_reduce_parts(pq_parts, n_pq);
   const bool bad = !(pq > 0.0) || !isfinite(pq);
   const double alpha = rz / pq;
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     S->pq = pq;
     S->rz_prev = rz;
-    S->iter_prev = S->iter;
+    S->iter_prev = iter0;
     if (bad) S->stop = 3;
     else S->alpha = alpha;
   }
@@ -478,21 +490,26 @@ __global__ __launch_bounds__(kBlock) void k_update_p(int n3, PcgScalars* S, cons
                                                      const double* __restrict__ rr_parts, int n_rr,
                                                      const double* __restrict__ zq_parts, const double* __restrict__ z,
                                                      double* __restrict__ p) {
-  if (S->stop) return;
-  const double rz = block_reduce_parts(rz_parts, n_rz);
-  const double rr = block_reduce_parts(rr_parts, n_rr);
+  // the scalars of the previous launches in one go, before the reduction's barriers
+  const int stop0 = S->stop, iter_prev = S->iter_prev, maxit = S->maxit;
+  const double alpha = S->alpha, rz_prev = S->rz_prev, tol2 = S->tol2, bb = S->bb;
+  if (stop0) return;
   // flexible CG (variable preconditioner, e.g. the K-cycle): z_new.(r_new - r_old) = -alpha z_new.q
-  const double zq = zq_parts ? block_reduce_parts(zq_parts, n_rz) : 0.0;
-  const double beta = zq_parts ? -S->alpha * zq / S->rz_prev : rz / S->rz_prev;
+  const double* const parts[3] = {rz_parts, rr_parts, zq_parts};
+  const int cnt[3] = {n_rz, n_rr, n_rz};
+  double v[3];
+  block_reduce_parts_n<3>(parts, cnt, v);
+  const double rz = v[0], rr = v[1], zq = v[2];
+  const double beta = zq_parts ? -alpha * zq / rz_prev : rz / rz_prev;
   int stop = 0;
   if (!isfinite(rz) || !isfinite(rr)) stop = 3;
-  else if (rr <= S->tol2 * S->bb) stop = 1;
-  else if (S->iter_prev + 1 >= S->maxit) stop = 2;
+  else if (rr <= tol2 * bb) stop = 1;
+  else if (iter_prev + 1 >= maxit) stop = 2;
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     S->beta = beta;
     S->rz = rz;
     S->rr = rr;
-    S->iter = S->iter_prev + 1;
+    S->iter = iter_prev + 1;
     if (stop) S->stop = stop;
   }
   if (stop) return;
