@@ -1,0 +1,24 @@
+#!/bin/bash
+# Regenerates the rocprofv3 artifacts under profiles/ on the GPU box (run through gpurun from the
+# repo root: `gpurun -- bash scripts/profile_round.sh r01`); outputs land in gpurun_out/.
+# rocprofv3 wants cwd and TMPDIR under /tmp; --pmc passes are separate from the --stats pass.
+set -u
+tag=${1:-r01}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+cd /tmp; export TMPDIR=/tmp
+O=$R/gpurun_out
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_amg_c4 -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > $O/prof_amg_c4.log 2>&1
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$c -- python3 $R/bench.py --steps 1 --warmup 0 --iters 4 --no-cpu-baseline --no-roofline > $O/pmc_$c.log 2>&1
+done
+python3 $R/scripts/pmc_summary.py $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE > $O/${tag}_pmc_traffic_amg_c4.json
+cp $(find $O/prof_amg_c4 -name "*kernel_stats.csv" | head -1) $O/${tag}_amg_c4_kernel_stats.csv
+# per-dispatch traces are large: keep only the summaries
+find $O -name "*kernel_trace.csv" -delete; find $O -name "*counter_collection.csv" -delete
+# bench lines (the roofline leg reads the PMC summary: make it visible under profiles/ first)
+cp $O/${tag}_pmc_traffic_amg_c4.json $R/profiles/${tag}_pmc_traffic_amg_c4.json
+cd $R
+python3 bench.py 2>/dev/null | tail -1 > $O/${tag}_bench_c4.json
+python3 bench.py --config C2 2>/dev/null | tail -1 > $O/${tag}_bench_c2.json
+python3 scripts/short.py < $O/${tag}_bench_c4.json; python3 scripts/short.py < $O/${tag}_bench_c2.json
+python3 scripts/robustness.py > $O/${tag}_robustness_raw.txt 2>/dev/null; cat $O/${tag}_robustness_raw.txt
