@@ -1,13 +1,15 @@
 // sgo_comm.cpp -- RCCL binding for the edge-sharded multi-GPU mode (one process per GPU).
 //
 // librccl is dlopen'ed on first use so that the single-GPU product path carries no RCCL
-// dependency.  Only ncclAllReduce(sum) is used: after linearisation on the per-vertex
-// (block-diagonal H, b) partials, and once per PCG step on the partial Hessian product
-// (BASELINE.json north_star).
+// dependency.  Only ncclAllReduce(sum) is used, once per GN iteration after the band-sharded
+// linearisation: on the Hessian blocks, on the per-vertex (block-diagonal H, b) array and on the
+// two chi2 partial sums (BASELINE.json north_star).
+// The linear solve runs replicated, so no collective sits inside the PCG loop.
 #include <dlfcn.h>
 
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 
 #include "sgo_comm.h"
@@ -37,6 +39,8 @@ Api& api() {
 }
 
 bool load(std::string* err) {
+  static std::mutex mu;   // contexts on different threads may initialise their communicators at once
+  std::lock_guard<std::mutex> lock(mu);
   Api& a = api();
   if (a.handle) return true;
   const char* env = std::getenv("SGO_RCCL_LIB");
