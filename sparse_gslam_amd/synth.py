@@ -149,6 +149,27 @@ def manhattan(V: int, E: int, seed: int, p_random: float = 0.0, *, info_mode: st
         raise ValueError("E must be >= V-1 (the odometry chain)")
     rng = np.random.default_rng(seed)
     truth = _walk(V, rng)
+    return _build(truth, E, rng, seed, p_random, info_mode, phi, init, tail, sigma_xy, sigma_th, 2.0, 10)
+
+
+def trajectory_graph(truth: np.ndarray, E: int, seed: int, *, info_mode: str = "full", phi: float = 10.0,
+                     init: str = "incremental", tail: int = 200, sigma_xy: float = SIGMA_XY,
+                     sigma_th: float = SIGMA_TH, closure_radius: float = 1.0, min_sep: int = 40) -> Graph:
+    """The same construction on a GIVEN trajectory (e.g. the intel-lab keyframe trajectory the
+    reference ships as a result file, tests/golden/ref_trajectories.npz): odometry chain plus
+    ``E - (V-1)`` closures between poses that revisit the same place (within ``closure_radius``
+    metres, at least ``min_sep`` keyframes apart), DCS delta ``phi`` on the closures
+    (datasets/intel-lab/slam-11.yaml:38 uses 10)."""
+    truth = np.asarray(truth, dtype=np.float64).copy()
+    truth[:, 2] = _wrap(truth[:, 2])
+    if E < truth.shape[0] - 1:
+        raise ValueError("E must be >= V-1 (the odometry chain)")
+    rng = np.random.default_rng(seed)
+    return _build(truth, E, rng, seed, 0.0, info_mode, phi, init, tail, sigma_xy, sigma_th, closure_radius, min_sep)
+
+
+def _build(truth, E, rng, seed, p_random, info_mode, phi, init, tail, sigma_xy, sigma_th, radius, min_sep) -> Graph:
+    V = truth.shape[0]
     n_close = E - (V - 1)
     n_rand = int(round(E * p_random))
     n_rand = min(n_rand, n_close)
@@ -159,7 +180,7 @@ def manhattan(V: int, E: int, seed: int, p_random: float = 0.0, *, info_mode: st
     li = lj = np.empty(0, dtype=np.int64)
     r_used = 0.0
     if n_local > 0:
-        ci, cj, r_used = _closure_candidates(truth, n_local)
+        ci, cj, r_used = _closure_candidates(truth, n_local, radius, min_sep)
         if ci.size < n_local:  # not enough revisits: top up with random pairs
             n_rand += n_local - ci.size
             n_local = ci.size
@@ -250,8 +271,26 @@ def _euler(a, b, c):
     return Q
 
 
+def reference_trajectory(name: str) -> np.ndarray:
+    """Keyframe trajectory (V,3) of one of the reference's shipped result files
+    (src/sparse_gslam/datasets/<name>/*30pts.txt, CARMEN FLASER lines sorted by time stamp),
+    from the committed fixture tests/golden/ref_trajectories.npz (scripts/make_traj_fixture.py)."""
+    import os
+
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden",
+                        "ref_trajectories.npz")
+    with np.load(path) as z:
+        return z[name].copy()
+
+
 def config(name: str, **overrides) -> Graph:
-    """Instantiate one of BASELINE.json's synthetic configs (C1, C2, C4, C4r, C5)."""
+    """Instantiate one of BASELINE.json's synthetic configs (C1, C2, C4, C4r, C5), or "C1i" /
+    "C1a": the C1-sized graph on the reference's own intel-lab / aces keyframe trajectory."""
+    if name in ("C1i", "C1a"):
+        truth = reference_trajectory("intel_lab" if name == "C1i" else "aces")
+        kw = dict(E=truth.shape[0] - 1 + (60 if name == "C1i" else 30), seed=11)
+        kw.update(overrides)
+        return trajectory_graph(truth, **kw)
     kw = dict(CONFIGS[name])
     kw.update(overrides)
     return manhattan(**kw)
