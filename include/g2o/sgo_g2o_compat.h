@@ -746,6 +746,15 @@ class SparseOptimizer : public OptimizableGraph {
       if (!v->fixed()) n += v->dimension();
     }
     if (n == 0) return -1;
+    // This dense host solver exists for the landmark graph (<= a few hundred unknowns).  It is not a
+    // fallback for pose graphs: a large graph that is not (VertexSE2, EdgeSE2, no kernel or DCS,
+    // Gauss-Newton) is refused instead of being solved in O(n^3) on the host.
+    if (n > kHostSolverMaxUnknowns) {
+      std::cerr << "SparseOptimizer::optimize: " << n << " unknowns in a graph the device path does not cover "
+                << "(only VertexSE2 / EdgeSE2 with no kernel or RobustKernelDCS under Gauss-Newton is); refusing"
+                << std::endl;
+      return 0;
+    }
     const bool lm = _algorithm->kind() == OptimizationAlgorithm::Levenberg;
     std::vector<double> H((size_t)n * n), b(n), x(n);
     int cjIterations = 0;
@@ -809,6 +818,7 @@ class SparseOptimizer : public OptimizableGraph {
     return cjIterations;
   }
   double _lmLambda = 0.0, _lmNi = 2.0;
+  static constexpr int kHostSolverMaxUnknowns = 3000;
 
   bool gpuEligible() const {
     if (_algorithm->kind() != OptimizationAlgorithm::GaussNewton) return false;
