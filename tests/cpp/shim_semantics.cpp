@@ -1,6 +1,7 @@
 // shim_semantics.cpp -- container / bookkeeping semantics of the g2o-compat SparseOptimizer that the
 // reference relies on (SURVEY.md section 8(b) "semantic notes"); host only, no GPU call is made.
 // Prints "ok" and returns 0 when every check holds.
+#include <deque>
 #include <iostream>
 
 #include "g2o/core/block_solver.h"
@@ -97,6 +98,36 @@ int main() {
   k.robustify(0.5, rho);
   CHECK(rho[0] == 0.5 && rho[1] == 1.0);
   CHECK(normalize_theta(3 * const_pi()) == -const_pi());
+  {
+    // A large pose graph in a configuration the device path does not cover (Levenberg-Marquardt)
+    // is refused (optimize() == 0, estimates untouched): the dense host solver serves the
+    // landmark graph only and must never become a silent fallback for pose graphs.
+    const int N = 1200;
+    std::deque<VertexSE2> pv(N);
+    std::deque<EdgeSE2> pe(N - 1);
+    SparseOptimizer big;
+    auto* alg = new OptimizationAlgorithmLevenberg(
+        g2o::make_unique<BlockSolver<BlockSolverTraits<3, 3>>>(
+            g2o::make_unique<LinearSolverEigen<BlockSolver<BlockSolverTraits<3, 3>>::PoseMatrixType>>()));
+    big.setAlgorithm(alg);
+    for (int k = 0; k < N; ++k) {
+      pv[k].setId(k);
+      pv[k].setEstimate(SE2(k, 0, 0));
+      pv[k].setFixed(k == 0);
+      big.addVertex(&pv[k]);
+    }
+    for (int k = 0; k + 1 < N; ++k) {
+      pe[k].vertices()[0] = &pv[k];
+      pe[k].vertices()[1] = &pv[k + 1];
+      pe[k].setMeasurement(SE2(1.1, 0, 0));
+      pe[k].information().setIdentity();
+      big.addEdge(&pe[k]);
+    }
+    big.initializeOptimization();
+    CHECK(big.optimize(5) == 0);
+    CHECK(pv[N - 1].estimate()[0] == double(N - 1));
+    delete alg;
+  }
   std::cout << "ok" << std::endl;
   return 0;
 }
