@@ -1092,9 +1092,14 @@ Amg* amg_create(hipStream_t s, const BsrDev& A0, const double* d_poses, const in
     std::vector<int> agg;
     const double theta_l = l == 0 ? m->cfg.theta : m->cfg.theta_coarse;
     const auto tA = std::chrono::steady_clock::now();
+    auto ms_since = [](std::chrono::steady_clock::time_point t) {
+      return 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count();
+    };
+    double t_agg = 0, t_sort = 0;
     int nc = aggregate(H, w, theta_l, agg);
     if (nc > 0.9 * n) nc = aggregate(H, w, 0.0, agg);  // stalled: treat every connection as strong
     if (nc > 0.9 * n || nc < 1) break;                   // cannot coarsen further
+    t_agg = ms_since(tA);
     // Chain-dominated graphs (few strong neighbours per node) give aggregates of ~3 nodes and a deep
     // hierarchy, which the K-cycle pays for exponentially.  When the coarsening ratio is below 4,
     // aggregate the aggregates once more over the strong inter-aggregate connections.
@@ -1173,6 +1178,7 @@ Amg* amg_create(hipStream_t s, const BsrDev& A0, const double* d_poses, const in
         order[cnt[(size_t)(key[k] >> 32)]++] = k;
       }
     }
+    t_sort = ms_since(tA) - t_agg;
     HostLevel Hc;
     Hc.n = nc;
     std::vector<int> tgt(ns), cptr;  // contribution -> coarse slot; coarse slot -> contribution range
@@ -1203,8 +1209,8 @@ Amg* amg_create(hipStream_t s, const BsrDev& A0, const double* d_poses, const in
     std::vector<int> grp_c = make_groups(Hc.rowptr);
     std::vector<int> grp_g = make_groups(cptr);
     if (std::getenv("SGO_VERBOSE"))
-      std::fprintf(stderr, "[sgo] amg level %d: host aggregation + coarse structure %.1f ms (n=%d -> %d)\n", l,
-                   1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - tA).count(), n, nc);
+      std::fprintf(stderr, "[sgo] amg level %d: host aggregation + coarse structure %.1f ms (aggregate %.1f, sort %.1f; n=%d -> %d)\n",
+                   l, ms_since(tA), t_agg, t_sort, n, nc);
 
     // upload transfer data of level l and the structure of level l+1
     L.nc = nc;

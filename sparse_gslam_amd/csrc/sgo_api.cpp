@@ -12,6 +12,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
+#include <new>
 #include <string>
 #include <thread>
 #include <vector>
@@ -59,8 +61,28 @@ double normalize_theta_h(double t) {
 
 }  // namespace
 
+// Bump allocator over one host block that only ever grows (uninitialised memory, 64-byte aligned).
+struct HostArena {
+  std::unique_ptr<char[]> mem;
+  size_t cap = 0, used = 0;
+  void reserve(size_t bytes) {   // invalidates earlier take()s
+    used = 0;
+    if (bytes <= cap) return;
+    mem.reset();
+    cap = bytes + bytes / 4;
+    mem.reset(new char[cap + 64]);
+  }
+  void* take(size_t bytes) {
+    char* base = (char*)(((uintptr_t)mem.get() + 63) & ~(uintptr_t)63);
+    void* q = base + used;
+    used += (bytes + 63) & ~(size_t)63;
+    return used <= cap ? q : nullptr;
+  }
+};
+
 struct sgo_ctx {
   int device = 0;
+  HostArena stage;
   hipStream_t stream = nullptr;
   sgo_opts opts{};
   std::string err;
@@ -139,6 +161,29 @@ int upload(sgo_ctx* c, T** p, const std::vector<T>& v) {
   int rc = dalloc(c, p, v.size());
   if (rc) return rc;
   if (!v.empty()) HIP_TRY(c, hipMemcpyAsync(*p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, c->stream));
+  return SGO_OK;
+}
+
+// Host staging buffer WITHOUT value-initialisation: the structure build writes every element it
+// later reads, and zero-filling ~300 MB of std::vector storage was a third of its time on C4.
+// The memory comes from the context's staging arena, which is kept between sgo_set_graph_se2 calls
+// (the reference re-initialises a slowly growing graph before every optimize(20)): no mmap / page
+// faults / munmap of ~300 MB per call.
+template <class T>
+struct HostBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  HostBuf(HostArena& a, size_t count) : p((T*)a.take(count * sizeof(T))), n(count) {}
+  T& operator[](size_t i) { return p[i]; }
+  const T& operator[](size_t i) const { return p[i]; }
+  T* data() { return p; }
+  size_t size() const { return n; }
+};
+template <class T>
+int upload(sgo_ctx* c, T** p, const HostBuf<T>& v) {
+  int rc = dalloc(c, p, v.n);
+  if (rc) return rc;
+  if (v.n) HIP_TRY(c, hipMemcpyAsync(*p, v.p, v.n * sizeof(T), hipMemcpyHostToDevice, c->stream));
   return SGO_OK;
 }
 
@@ -300,16 +345,32 @@ int build_structure(sgo_ctx* c, int V, const double* poses, const uint8_t* fixed
       if (hj >= 0) pos_j[e] = fill[hj]++;
     }
   }
-  std::vector<int> row(ns), col(ns), svi(ns, 0), svj(ns, 0), flags(ns, 0);
-  std::vector<double> zinv(3 * (size_t)ns, 0.0), sinfo(6 * (size_t)ns, 0.0), sphi(ns, -1.0);
-  std::vector<double> ezinv(3 * (size_t)E);
-  // the fills below are independent per row / per edge: spread them over the host cores
+  HostArena& ar = c->stage;
+  try {
+    ar.reserve((size_t)ns * (5 * sizeof(int) + 10 * sizeof(double)) + (size_t)E * 9 * sizeof(double) + 16 * 64);
+  } catch (const std::bad_alloc&) {
+    c->err = "sgo_set_graph_se2: out of host memory for the staging buffers";
+    return SGO_ENOMEM;
+  }
+  HostBuf<int> row(ar, ns), col(ar, ns), svi(ar, ns), svj(ar, ns), flags(ar, ns);
+  HostBuf<double> zinv(ar, 3 * (size_t)ns), sinfo(ar, 6 * (size_t)ns), sphi(ar, ns);
+  HostBuf<double> ezinv(ar, 3 * (size_t)E), einfo(ar, 6 * (size_t)E);
+  if (!einfo.p) {
+    c->err = "sgo_set_graph_se2: internal error (staging arena too small)";
+    return SGO_EINVAL;
+  }
+  // the fills below are independent per row / per edge: spread them over the host cores.  Every
+  // slot is written exactly once: the diagonal slots here, the directed-edge slots below.
   parallel_for(n, [&](int r0, int r1) {
     for (int r = r0; r < r1; ++r) {
       const int k = rowptr[r];
       row[k] = r;
       col[k] = r;
       flags[k] = kSlotDiag;
+      svi[k] = svj[k] = 0;      // operands of a diagonal slot are never read (k_linearize skips it)
+      for (int q = 0; q < 3; ++q) zinv[q * (size_t)ns + k] = 0.0;
+      for (int q = 0; q < 6; ++q) sinfo[q * (size_t)ns + k] = 0.0;
+      sphi[k] = -1.0;
     }
   });
   parallel_for(E, [&](int e0, int e1) {
@@ -358,8 +419,6 @@ int build_structure(sgo_ctx* c, int V, const double* poses, const uint8_t* fixed
   const int ngrp = (int)grp.size() - 1;
 
   // edge list (original order) for chi2
-  std::vector<int> evi(ei, ei + E), evj(ej, ej + E);
-  std::vector<double> einfo(6 * (size_t)E), ephi(phi, phi + E);
   parallel_for(E, [&](int e0, int e1) {
     for (int e = e0; e < e1; ++e)
       for (int q = 0; q < 6; ++q) einfo[q * (size_t)E + e] = info[6 * (size_t)e + q];
@@ -387,11 +446,17 @@ int build_structure(sgo_ctx* c, int V, const double* poses, const uint8_t* fixed
   if ((rc = upload(c, &c->es.info, sinfo))) return rc;
   if ((rc = upload(c, &c->es.phi, sphi))) return rc;
   c->el.E = E;
-  if ((rc = upload(c, &c->el.vi, evi))) return rc;
-  if ((rc = upload(c, &c->el.vj, evj))) return rc;
+  // caller-order index / kernel arrays go up straight from the caller's buffers
+  if ((rc = dalloc(c, &c->el.vi, (size_t)E)) || (rc = dalloc(c, &c->el.vj, (size_t)E)) ||
+      (rc = dalloc(c, &c->el.phi, (size_t)E)))
+    return rc;
+  if (E > 0) {
+    HIP_TRY(c, hipMemcpyAsync(c->el.vi, ei, sizeof(int32_t) * (size_t)E, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->el.vj, ej, sizeof(int32_t) * (size_t)E, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->el.phi, phi, sizeof(double) * (size_t)E, hipMemcpyHostToDevice, c->stream));
+  }
   if ((rc = upload(c, &c->el.zinv, ezinv))) return rc;
   if ((rc = upload(c, &c->el.info, einfo))) return rc;
-  if ((rc = upload(c, &c->el.phi, ephi))) return rc;
   if ((rc = upload(c, &c->d_free_id, c->free_id))) return rc;
   if ((rc = dalloc(c, &c->d_poses, 3 * (size_t)V))) return rc;
   HIP_TRY(c, hipMemcpyAsync(c->d_poses, poses, sizeof(double) * 3 * (size_t)V, hipMemcpyHostToDevice, c->stream));
@@ -760,6 +825,7 @@ int sgo_set_graph_se2(sgo_ctx* c, int32_t V, const double* poses, const uint8_t*
   const double t0 = wall_s();
   hipStreamSynchronize(c->stream);
   free_graph(c);
+  if (c->opts.verbose) std::fprintf(stderr, "[sgo] set_graph: release of the previous graph %.1f ms\n", 1e3 * (wall_s() - t0));
   int rc = build_structure(c, V, poses, fixed, E, ei, ej, meas, info, phi);
   if (rc != SGO_OK) {
     free_graph(c);
@@ -777,8 +843,9 @@ int sgo_set_graph_se2(sgo_ctx* c, int32_t V, const double* poses, const uint8_t*
     if (c->opts.verbose) std::fprintf(stderr, "[sgo] set_graph: multigrid set-up %.1f ms\n", 1e3 * (wall_s() - ta0));
     c->linearized = false;
   }
-  if (c->opts.verbose) std::fprintf(stderr, "[sgo] solver: %s\n", c->solver_desc.c_str());
   c->setup_seconds = wall_s() - t0;
+  if (c->opts.verbose)
+    std::fprintf(stderr, "[sgo] solver: %s\n[sgo] set_graph: total %.1f ms\n", c->solver_desc.c_str(), 1e3 * c->setup_seconds);
   return SGO_OK;
 }
 
