@@ -117,6 +117,8 @@ struct sgo_ctx {
   hipGraphExec_t pcg_exec = nullptr;
   int pcg_exec_chunk = 0;
   int pcg_pred = 0;               // PCG iterations of the previous solve (prediction for the next)
+  int amg_best = 0;               // fewest PCG iterations seen with the current hierarchy (0: none yet);
+                                  // kept across optimize() calls so that a hierarchy adapted to other poses is noticed
   PcgScalars* h_S2 = nullptr;     // pinned [2]: pipelined read-back of the stop flag
   hipEvent_t ev_S[2] = {nullptr, nullptr};
 
@@ -667,6 +669,7 @@ int build_amg(sgo_ctx* c) {
     c->pcg_exec = nullptr;
   }
   c->pcg_pred = 0;  // the iteration count of the old hierarchy predicts nothing about the new one
+  c->amg_best = 0;
   if (c->amg) {
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     amg_destroy(c->amg);
@@ -1070,7 +1073,8 @@ int sgo_optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
   for (auto& e : evs.v) HIP_TRY(c, hipEventCreate(&e));
   std::vector<hipEvent_t>& ev = evs.v;
   int done = 0;
-  int best_pcg = 0, rebuilds = 0;
+  int rebuilds = 0;
+  int& best_pcg = c->amg_best;
   bool rebuild_next = false;
   for (int it = 0; it < iters; ++it) {
     hipEventRecord(ev[3 * it], c->stream);
@@ -1078,13 +1082,12 @@ int sgo_optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
       return rc;
     }
     if (rebuild_next && c->amg) {
-      // The aggregation was made from the Hessian of an earlier linearisation; robust-kernel
-      // re-weighting has changed the strength of connection enough to more than double the PCG
-      // iterations: redo the set-up from the current values (same cost as in sgo_set_graph_se2).
+      // The aggregation was made from the Hessian of an earlier linearisation and robust-kernel
+      // re-weighting has changed the strength of connection since (see the rule below): redo the
+      // set-up from the current values (same cost as in sgo_set_graph_se2).
       if ((rc = build_amg(c)) || (rc = do_linearize(c))) return rc;
       rebuild_next = false;
       ++rebuilds;
-      best_pcg = 0;
       if (c->opts.verbose) std::fprintf(stderr, "[sgo] multigrid hierarchy rebuilt before iteration %d\n", it);
     }
     hipEventRecord(ev[3 * it + 1], c->stream);
@@ -1094,7 +1097,15 @@ int sgo_optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
     const PcgScalars S = *c->h_S;
     if (c->amg && S.stop != 3) {
       if (best_pcg == 0 || S.iter < best_pcg) best_pcg = S.iter;
-      if (S.iter > 2 * best_pcg + 10 && rebuilds < 3) rebuild_next = true;
+      // Redo the aggregation from the current values when that pays: always when the count has more
+      // than doubled, and when it is > 25 % above the best while the PCG iterations it would save
+      // over the remaining GN iterations exceed the set-up's cost (~150 PCG iterations' worth: host
+      // aggregation + one more linearisation).  Counts only -- no clocks -- so that every rank of a
+      // multi-GPU run takes the same decision.
+      const int left = iters - it - 1;
+      const bool doubled = S.iter > 2 * best_pcg + 10;
+      const bool pays = 4 * S.iter > 5 * best_pcg && (long long)(S.iter - best_pcg) * left > 150;
+      if (rebuilds < 3 && (doubled || pays)) rebuild_next = true;
     }
     if (out) {
       out->pcg_iters[it] = S.iter;
