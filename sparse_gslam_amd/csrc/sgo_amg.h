@@ -19,6 +19,8 @@ struct AmgConfig {
                             // chain-dominated graphs -- measured a wash, kept off
   double double_ratio = 4.0;   // ... when n / nc < double_ratio (env SGO_AMG_DOUBLE_RATIO)
   int double_from_level = 0;   // ... on levels >= this (env SGO_AMG_DOUBLE_FROM)
+  bool smooth = true;          // smoothed aggregation: P = (I - omega_p D^-1 A) T (env SGO_AMG_SMOOTH=0: tentative P)
+  double omega_p = 0.66;       // damping of the prolongator smoothing step (env SGO_AMG_OMEGA_P)
   int coarsest_nodes = 400;  // stop coarsening at or below this many nodes; that level is inverted densely
                              // (blocked Gauss-Jordan over 3x that many unknowns) once per GN iteration
 };

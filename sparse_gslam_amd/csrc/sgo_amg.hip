@@ -138,6 +138,222 @@ __global__ __launch_bounds__(kBlock) void k_galerkin(BsrDev F, BsrDev C, Galerki
   }
 }
 
+// ------------------------------------------------------------------ smoothed aggregation
+// Prolongator smoothed by one damped block-Jacobi step, P = (I - w D^-1 A) T, and the Galerkin
+// operator A_c = P^T A P formed in two sparse products (AP = A P, then P^T AP).  The sparsity of
+// P, AP and A_c and the list of block products behind every entry are fixed by the graph and the
+// aggregation: the host lists them once (amg_create), sorted by target entry, and the numeric
+// phase of every GN iteration is three segmented-sum kernels of the k_galerkin kind.
+struct ProdMap {
+  int n = 0;                 // products
+  int ngrp = 0;
+  const int* a = nullptr;    // left operand of product t
+  const int* b = nullptr;    // right operand
+  const int* tgt = nullptr;  // target entry (non-decreasing in t)
+  const int* grp = nullptr;  // wave groups aligned to target boundaries
+};
+struct PDev {
+  int np = 0;                // blocks of P
+  int* rowptr = nullptr;     // [n + 1] entries of fine row i: [rowptr[i], rowptr[i+1]), coarse cols ascending
+  int* row = nullptr;        // [np]
+  int* col = nullptr;        // [np]
+  double* blk = nullptr;     // [np][9]: blocks are mostly GATHERED (products), so one 72-byte record each
+  int* r_grp = nullptr;      // wave groups over the entries aligned to fine rows (prolongation)
+  int r_ngrp = 0;
+  ProdMap val;               // a = fine slot k = (i, j), tgt = entry (i, agg(j))
+  // the same entries grouped by coarse column, with their own copy of the blocks, so that the
+  // restriction streams too: position t holds entry t_idx[t]
+  int* t_pos = nullptr;      // [np] position of entry e in column order
+  int* t_row = nullptr;      // [np] fine row at position t
+  int* t_col = nullptr;      // [np] coarse column at position t
+  double* t_blk = nullptr;   // [np][9]
+  int* t_grp = nullptr;      // wave groups over the positions aligned to columns
+  int t_ngrp = 0;
+  int nap = 0;               // blocks of AP
+  double* apblk = nullptr;   // [nap][9]
+  ProdMap ap;                // a = fine slot (i, j), b = P entry (j, c), tgt = AP entry (i, c)
+  ProdMap rap;               // a = P entry (i, a), b = AP entry (i, c), tgt = coarse slot (a, c)
+};
+
+__device__ __forceinline__ void load9(const double* __restrict__ base, size_t e, double (&v)[9]) {
+#pragma unroll
+  for (int c = 0; c < 9; ++c) v[c] = base[9 * e + c];
+}
+
+// P_e = [e is the own-aggregate entry] T_i - w D_i^-1 sum_{k in e} A_k T_col(k)
+__global__ __launch_bounds__(kBlock) void k_p_values(BsrDev F, PDev P, const int* __restrict__ agg,
+                                                     const double* __restrict__ d, double omega_p) {
+  const int lane = threadIdx.x & 63;
+  const size_t nf = (size_t)F.nslot;
+  int gi, gend, gstride;
+  group_walk(P.val.ngrp, &gi, &gend, &gstride);
+  for (; gi < gend; gi += gstride) {
+    const int gb = P.val.grp[gi], ge = P.val.grp[gi + 1];
+    double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    int key = -1 - lane;
+    for (int t = gb + lane; t < ge; t += 64) {
+      key = P.val.tgt[t];
+      const int k = P.val.a[t];
+      const int j = F.col[k];
+      const double dxj = d[2 * (size_t)j], dyj = d[2 * (size_t)j + 1];
+      double b[9];
+#pragma unroll
+      for (int c = 0; c < 9; ++c) b[c] = F.blk[blk_at(c, k, nf)];
+      acc[0] += b[0]; acc[1] += b[1]; acc[2] += -dyj * b[0] + dxj * b[1] + b[2];
+      acc[3] += b[3]; acc[4] += b[4]; acc[5] += -dyj * b[3] + dxj * b[4] + b[5];
+      acc[6] += b[6]; acc[7] += b[7]; acc[8] += -dyj * b[6] + dxj * b[7] + b[8];
+    }
+    seg_scan<9>(key, acc, lane);
+    const int kn = __shfl_down(key, 1);
+    if (key >= 0 && (lane == 63 || kn != key)) {
+      const size_t i = (size_t)P.row[key];
+      const double* di = F.dinv + 6 * i;
+      double o[9];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        o[c] = -omega_p * (di[0] * acc[c] + di[1] * acc[3 + c] + di[2] * acc[6 + c]);
+        o[3 + c] = -omega_p * (di[1] * acc[c] + di[3] * acc[3 + c] + di[4] * acc[6 + c]);
+        o[6 + c] = -omega_p * (di[2] * acc[c] + di[4] * acc[3 + c] + di[5] * acc[6 + c]);
+      }
+      if (P.col[key] == agg[i]) {
+        o[0] += 1.0; o[4] += 1.0; o[8] += 1.0;
+        o[2] += -d[2 * i + 1];
+        o[5] += d[2 * i];
+      }
+      const size_t tp = (size_t)P.t_pos[key];
+#pragma unroll
+      for (int c = 0; c < 9; ++c) {
+        P.blk[9 * (size_t)key + c] = o[c];
+        P.t_blk[9 * tp + c] = o[c];
+      }
+    }
+  }
+}
+
+// out_t = sum over the products of target t of  X(a) * Y(b)   (TRANSPOSE_X: X(a)^T * Y(b))
+// X blocks: pair-SoA BsrDev values (xb_bsr) or plain [9][nx]; Y plain [9][ny]; out plain or BsrDev.
+template <bool X_BSR, bool TRANSPOSE_X, bool OUT_BSR>
+__global__ __launch_bounds__(kBlock) void k_block_products(ProdMap mp, const double* __restrict__ X, size_t nx,
+                                                           const double* __restrict__ Y, size_t ny,
+                                                           double* __restrict__ out, size_t nout) {
+  const int lane = threadIdx.x & 63;
+  int gi, gend, gstride;
+  group_walk(mp.ngrp, &gi, &gend, &gstride);
+  for (; gi < gend; gi += gstride) {
+    const int gb = mp.grp[gi], ge = mp.grp[gi + 1];
+    double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    int key = -1 - lane;
+    for (int t = gb + lane; t < ge; t += 64) {
+      key = mp.tgt[t];
+      const size_t ia = (size_t)mp.a[t], ib = (size_t)mp.b[t];
+      double x[9], y[9];
+      if (X_BSR) {
+#pragma unroll
+        for (int c = 0; c < 9; ++c) x[c] = X[blk_at(c, ia, nx)];
+      } else {
+        load9(X, ia, x);
+      }
+      load9(Y, ib, y);
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          if (TRANSPOSE_X) acc[3 * r + c] += x[r] * y[c] + x[3 + r] * y[3 + c] + x[6 + r] * y[6 + c];
+          else acc[3 * r + c] += x[3 * r] * y[c] + x[3 * r + 1] * y[3 + c] + x[3 * r + 2] * y[6 + c];
+        }
+    }
+    seg_scan<9>(key, acc, lane);
+    const int kn = __shfl_down(key, 1);
+    if (key >= 0 && (lane == 63 || kn != key)) {
+#pragma unroll
+      for (int c = 0; c < 9; ++c) {
+        if (OUT_BSR) out[blk_at(c, (size_t)key, nout)] = acc[c];
+        else out[9 * (size_t)key + c] = acc[c];
+      }
+    }
+  }
+}
+
+// rc[a] = sum over the entries e of column a of P_e^T r[row(e)]   (column-ordered copy of P)
+__global__ __launch_bounds__(kBlock) void k_restrict_p(PDev P, const double* __restrict__ r, double* __restrict__ rc,
+                                                       const PcgScalars* S) {
+  if (S && S->stop) return;
+  const int lane = threadIdx.x & 63;
+  int g, gend, gstride;
+  group_walk(P.t_ngrp, &g, &gend, &gstride);
+  for (; g < gend; g += gstride) {
+    const int gb = P.t_grp[g], ge = P.t_grp[g + 1];
+    double acc[3] = {0.0, 0.0, 0.0};
+    int key = -1 - lane;
+    for (int t = gb + lane; t < ge; t += 64) {
+      key = P.t_col[t];
+      const size_t i = (size_t)P.t_row[t];
+      const double r0 = r[3 * i], r1 = r[3 * i + 1], r2 = r[3 * i + 2];
+      double b[9];
+      load9(P.t_blk, (size_t)t, b);
+      acc[0] += b[0] * r0 + b[3] * r1 + b[6] * r2;
+      acc[1] += b[1] * r0 + b[4] * r1 + b[7] * r2;
+      acc[2] += b[2] * r0 + b[5] * r1 + b[8] * r2;
+    }
+    seg_scan<3>(key, acc, lane);
+    const int kn = __shfl_down(key, 1);
+    if (key >= 0 && (lane == 63 || kn != key)) {
+      rc[3 * (size_t)key] = acc[0];
+      rc[3 * (size_t)key + 1] = acc[1];
+      rc[3 * (size_t)key + 2] = acc[2];
+    }
+  }
+}
+
+// x_i += sum over the entries e of row i of P_e (c1 u1 + c2 u2)[col(e)]  (+ xadd_i)
+__global__ __launch_bounds__(kBlock) void k_prolong_p(int n, PDev P, const double* __restrict__ u1, SpmvRatio r1,
+                                                      const double* __restrict__ u2, SpmvRatio r2,
+                                                      double* __restrict__ x, const PcgScalars* S,
+                                                      const double* __restrict__ xadd) {
+  if (S && S->stop) return;
+  double c1 = 1.0, c2 = 0.0;
+  {
+    const double* const parts[4] = {r1.num ? r1.den : nullptr, r1.num, (u2 && r2.num) ? r2.den : nullptr,
+                                    u2 ? r2.num : nullptr};
+    const int cnt[4] = {r1.n_den, r1.n_num, r2.n_den, r2.n_num};
+    double v[4];
+    block_reduce_parts_n<4>(parts, cnt, v);
+    if (r1.num) c1 = (v[0] > 0.0 && isfinite(v[0]) && isfinite(v[1])) ? v[1] / v[0] : 0.0;
+    if (u2) c2 = (v[2] > 0.0 && isfinite(v[2]) && isfinite(v[3])) ? v[3] / v[2] : 0.0;
+  }
+  // one lane per entry (entries are sorted by fine row), wavefront segmented sum per row
+  const int lane = threadIdx.x & 63;
+  int g, gend, gstride;
+  group_walk(P.r_ngrp, &g, &gend, &gstride);
+  for (; g < gend; g += gstride) {
+    const int gb = P.r_grp[g], ge = P.r_grp[g + 1];
+    double acc[3] = {0.0, 0.0, 0.0};
+    int key = -1 - lane;
+    for (int e = gb + lane; e < ge; e += 64) {
+      key = P.row[e];
+      const size_t a = 3 * (size_t)P.col[e];
+      double w0 = c1 * u1[a], w1 = c1 * u1[a + 1], w2 = c1 * u1[a + 2];
+      if (u2) {
+        w0 += c2 * u2[a]; w1 += c2 * u2[a + 1]; w2 += c2 * u2[a + 2];
+      }
+      double b[9];
+      load9(P.blk, (size_t)e, b);
+      acc[0] += b[0] * w0 + b[1] * w1 + b[2] * w2;
+      acc[1] += b[3] * w0 + b[4] * w1 + b[5] * w2;
+      acc[2] += b[6] * w0 + b[7] * w1 + b[8] * w2;
+    }
+    seg_scan<3>(key, acc, lane);
+    const int kn = __shfl_down(key, 1);
+    if (key >= 0 && (lane == 63 || kn != key)) {
+      const size_t o = 3 * (size_t)key;
+      if (xadd) {
+        acc[0] += xadd[o]; acc[1] += xadd[o + 1]; acc[2] += xadd[o + 2];
+      }
+      x[o] += acc[0]; x[o + 1] += acc[1]; x[o + 2] += acc[2];
+    }
+  }
+}
+
 // dinv of a coarse level from its diagonal slots (first slot of each row)
 __global__ __launch_bounds__(kBlock) void k_level_dinv(BsrDev A) {
   const size_t ns = (size_t)A.nslot;
@@ -723,6 +939,249 @@ int aggregate(const HostLevel& L, const std::vector<double>& w, double theta, st
   return nc;
 }
 
+// Host side of the smoothed-aggregation set-up: patterns of P, AP = A P and A_c = P^T AP and, for
+// every entry of each, the block products that make it up, listed in target order (all sorting is
+// per row -- a counting sort over the row's few distinct columns -- so the rows run in parallel).
+struct SaHost {
+  std::vector<int> p_rowptr, p_row, p_col, val_src, val_tgt, val_grp;
+  std::vector<int> r_grp, t_pos, t_row, t_col, t_grp;
+  int nap = 0;
+  std::vector<int> ap_a, ap_b, ap_tgt, ap_grp;
+  HostLevel Hc;
+  std::vector<int> rap_a, rap_b, rap_tgt, rap_grp;
+};
+
+// Orders `items` products of one row by their target's local index q (counting sort, stable) and
+// writes them to out_*[base ...]; ptr[first_target + q] receives the start of target q.
+struct RowSorter {
+  std::vector<int> cnt, qa, qb, qq;
+  void begin(int ntargets) {
+    cnt.assign((size_t)ntargets + 1, 0);
+    qa.clear(); qb.clear(); qq.clear();
+  }
+  void add(int a, int b, int q) {
+    qa.push_back(a); qb.push_back(b); qq.push_back(q);
+    cnt[(size_t)q + 1]++;
+  }
+  void flush(int base, int first_target, int* out_a, int* out_b, int* out_tgt, int* ptr) {
+    const int nt = (int)cnt.size() - 1;
+    for (int q = 0; q < nt; ++q) cnt[q + 1] += cnt[q];
+    for (int q = 0; q < nt; ++q) ptr[first_target + q] = base + cnt[q];
+    for (size_t t = 0; t < qq.size(); ++t) {
+      const int dst = base + cnt[qq[t]]++;
+      out_a[dst] = qa[t];
+      if (out_b) out_b[dst] = qb[t];
+      out_tgt[dst] = first_target + qq[t];
+    }
+  }
+};
+
+void sa_symbolic(const HostLevel& H, const std::vector<int>& agg, int nc, SaHost& o) {
+  const int n = H.n;
+  // ---- P: row i holds the aggregates of the columns of row i (its own among them: diagonal slot)
+  o.p_rowptr.assign((size_t)n + 1, 0);
+  host_parallel_for(n, 4096, [&](int lo, int hi, int) {
+    std::vector<int> mark((size_t)nc, -1);
+    for (int i = lo; i < hi; ++i) {
+      int cnt = 0;
+      for (int k = H.rowptr[i]; k < H.rowptr[i + 1]; ++k) {
+        const int a = agg[H.col[k]];
+        if (mark[a] != i) {
+          mark[a] = i;
+          ++cnt;
+        }
+      }
+      o.p_rowptr[i + 1] = cnt;
+    }
+  });
+  for (int i = 0; i < n; ++i) o.p_rowptr[i + 1] += o.p_rowptr[i];
+  const int np = o.p_rowptr[n];
+  o.p_row.resize(np);
+  o.p_col.resize(np);
+  o.val_src.resize(H.nslot);
+  o.val_tgt.resize(H.nslot);
+  std::vector<int> val_ptr((size_t)np + 1);
+  host_parallel_for(n, 4096, [&](int lo, int hi, int) {
+    std::vector<int> mark((size_t)nc, -1), pos((size_t)nc, 0), uniq;
+    RowSorter rs;
+    for (int i = lo; i < hi; ++i) {
+      uniq.clear();
+      for (int k = H.rowptr[i]; k < H.rowptr[i + 1]; ++k) {
+        const int a = agg[H.col[k]];
+        if (mark[a] != i) {
+          mark[a] = i;
+          uniq.push_back(a);
+        }
+      }
+      std::sort(uniq.begin(), uniq.end());
+      const int e0 = o.p_rowptr[i];
+      for (size_t q = 0; q < uniq.size(); ++q) {
+        pos[uniq[q]] = (int)q;
+        o.p_row[e0 + q] = i;
+        o.p_col[e0 + q] = uniq[q];
+      }
+      rs.begin((int)uniq.size());
+      for (int k = H.rowptr[i]; k < H.rowptr[i + 1]; ++k) rs.add(k, 0, pos[agg[H.col[k]]]);
+      rs.flush(H.rowptr[i], e0, o.val_src.data(), nullptr, o.val_tgt.data(), val_ptr.data());
+    }
+  });
+  val_ptr[np] = H.nslot;
+  o.val_grp = make_groups(val_ptr);
+  // ---- entries by coarse column (restriction walks P^T)
+  std::vector<int> t_ptr((size_t)nc + 1, 0);
+  for (int e = 0; e < np; ++e) t_ptr[(size_t)o.p_col[e] + 1]++;
+  for (int a = 0; a < nc; ++a) t_ptr[a + 1] += t_ptr[a];
+  std::vector<int> t_idx(np);
+  o.t_pos.resize(np);
+  o.t_row.resize(np);
+  o.t_col.resize(np);
+  {
+    std::vector<int> fill(t_ptr.begin(), t_ptr.end() - 1);
+    for (int e = 0; e < np; ++e) {
+      const int t = fill[o.p_col[e]]++;
+      t_idx[t] = e;
+      o.t_pos[e] = t;
+      o.t_row[t] = o.p_row[e];
+      o.t_col[t] = o.p_col[e];
+    }
+  }
+  o.t_grp = make_groups(t_ptr);
+  o.r_grp = make_groups(o.p_rowptr);
+  // ---- AP: row i holds the union of the P rows of the columns of row i
+  std::vector<int> ap_rowptr((size_t)n + 1, 0), app((size_t)n + 1, 0);
+  host_parallel_for(n, 4096, [&](int lo, int hi, int) {
+    std::vector<int> mark((size_t)nc, -1);
+    for (int i = lo; i < hi; ++i) {
+      int cnt = 0, prod = 0;
+      for (int k = H.rowptr[i]; k < H.rowptr[i + 1]; ++k) {
+        const int j = H.col[k];
+        prod += o.p_rowptr[j + 1] - o.p_rowptr[j];
+        for (int e = o.p_rowptr[j]; e < o.p_rowptr[j + 1]; ++e) {
+          const int c = o.p_col[e];
+          if (mark[c] != i) {
+            mark[c] = i;
+            ++cnt;
+          }
+        }
+      }
+      ap_rowptr[i + 1] = cnt;
+      app[i + 1] = prod;
+    }
+  });
+  for (int i = 0; i < n; ++i) {
+    ap_rowptr[i + 1] += ap_rowptr[i];
+    app[i + 1] += app[i];
+  }
+  o.nap = ap_rowptr[n];
+  const int nprod_ap = app[n];
+  std::vector<int> ap_col((size_t)o.nap), ap_ptr((size_t)o.nap + 1);
+  o.ap_a.resize(nprod_ap);
+  o.ap_b.resize(nprod_ap);
+  o.ap_tgt.resize(nprod_ap);
+  host_parallel_for(n, 2048, [&](int lo, int hi, int) {
+    std::vector<int> mark((size_t)nc, -1), pos((size_t)nc, 0), uniq;
+    RowSorter rs;
+    for (int i = lo; i < hi; ++i) {
+      uniq.clear();
+      for (int k = H.rowptr[i]; k < H.rowptr[i + 1]; ++k) {
+        const int j = H.col[k];
+        for (int e = o.p_rowptr[j]; e < o.p_rowptr[j + 1]; ++e) {
+          const int c = o.p_col[e];
+          if (mark[c] != i) {
+            mark[c] = i;
+            uniq.push_back(c);
+          }
+        }
+      }
+      std::sort(uniq.begin(), uniq.end());
+      const int f0 = ap_rowptr[i];
+      for (size_t q = 0; q < uniq.size(); ++q) {
+        pos[uniq[q]] = (int)q;
+        ap_col[f0 + q] = uniq[q];
+      }
+      rs.begin((int)uniq.size());
+      for (int k = H.rowptr[i]; k < H.rowptr[i + 1]; ++k) {
+        const int j = H.col[k];
+        for (int e = o.p_rowptr[j]; e < o.p_rowptr[j + 1]; ++e) rs.add(k, e, pos[o.p_col[e]]);
+      }
+      rs.flush(app[i], f0, o.ap_a.data(), o.ap_b.data(), o.ap_tgt.data(), ap_ptr.data());
+    }
+  });
+  ap_ptr[o.nap] = nprod_ap;
+  o.ap_grp = make_groups(ap_ptr);
+  // ---- A_c = P^T AP: coarse row a collects, over the entries (i, a) of column a of P, row i of AP
+  HostLevel& C = o.Hc;
+  C.n = nc;
+  C.rowptr.assign((size_t)nc + 1, 0);
+  std::vector<int> rpp((size_t)nc + 1, 0);
+  host_parallel_for(nc, 256, [&](int lo, int hi, int) {
+    std::vector<int> mark((size_t)nc, -1);
+    for (int a = lo; a < hi; ++a) {
+      int cnt = 0, prod = 0;
+      for (int t = t_ptr[a]; t < t_ptr[a + 1]; ++t) {
+        const int i = o.t_row[t];
+        prod += ap_rowptr[i + 1] - ap_rowptr[i];
+        for (int f = ap_rowptr[i]; f < ap_rowptr[i + 1]; ++f) {
+          const int c = ap_col[f];
+          if (mark[c] != a) {
+            mark[c] = a;
+            ++cnt;
+          }
+        }
+      }
+      C.rowptr[a + 1] = cnt;
+      rpp[a + 1] = prod;
+    }
+  });
+  for (int a = 0; a < nc; ++a) {
+    C.rowptr[a + 1] += C.rowptr[a];
+    rpp[a + 1] += rpp[a];
+  }
+  C.nslot = C.rowptr[nc];
+  const int nprod_rap = rpp[nc];
+  C.row.resize(C.nslot);
+  C.col.resize(C.nslot);
+  std::vector<int> rap_ptr((size_t)C.nslot + 1);
+  o.rap_a.resize(nprod_rap);
+  o.rap_b.resize(nprod_rap);
+  o.rap_tgt.resize(nprod_rap);
+  host_parallel_for(nc, 256, [&](int lo, int hi, int) {
+    std::vector<int> mark((size_t)nc, -1), pos((size_t)nc, 0), uniq;
+    RowSorter rs;
+    for (int a = lo; a < hi; ++a) {
+      uniq.clear();
+      for (int t = t_ptr[a]; t < t_ptr[a + 1]; ++t) {
+        const int i = o.t_row[t];
+        for (int f = ap_rowptr[i]; f < ap_rowptr[i + 1]; ++f) {
+          const int c = ap_col[f];
+          if (mark[c] != a) {
+            mark[c] = a;
+            if (c != a) uniq.push_back(c);
+          }
+        }
+      }
+      std::sort(uniq.begin(), uniq.end());
+      const int s0 = C.rowptr[a];   // diagonal slot first (BsrDev convention), then ascending columns
+      C.row[s0] = a;
+      C.col[s0] = a;
+      pos[a] = 0;
+      for (size_t q = 0; q < uniq.size(); ++q) {
+        pos[uniq[q]] = (int)q + 1;
+        C.row[s0 + 1 + q] = a;
+        C.col[s0 + 1 + q] = uniq[q];
+      }
+      rs.begin((int)uniq.size() + 1);
+      for (int t = t_ptr[a]; t < t_ptr[a + 1]; ++t) {
+        const int e = t_idx[t], i = o.t_row[t];
+        for (int f = ap_rowptr[i]; f < ap_rowptr[i + 1]; ++f) rs.add(e, f, pos[ap_col[f]]);
+      }
+      rs.flush(rpp[a], s0, o.rap_a.data(), o.rap_b.data(), o.rap_tgt.data(), rap_ptr.data());
+    }
+  });
+  rap_ptr[C.nslot] = nprod_rap;
+  o.rap_grp = make_groups(rap_ptr);
+}
+
 }  // namespace
 
 // one level of the hierarchy on the device
@@ -739,6 +1198,8 @@ struct AmgLevel {
   double* pos = nullptr;    // [n][2]
   double* d = nullptr;      // [n][2] lever arms
   GalerkinMap gal;
+  bool smoothed = false;    // transfer by the smoothed prolongator P (below) instead of the tentative one
+  PDev P;
   // work vectors [n][3]
   double *xs = nullptr, *rs = nullptr;                     // smoother state of cycle()
   double *tX = nullptr, *tR = nullptr;                     // second pre-smoothing sweep (level 0, nu0 = 2)
@@ -781,6 +1242,34 @@ struct Scope {
 };
 
 double bytes_spmv(const BsrDev& A) { return 80.0 * A.nslot + 48.0 * A.n; }
+
+// Values of the operator of level l+1 from those of level l (lever arms L.d must be current):
+// tentative prolongator: one Galerkin pass; smoothed: P values, AP = A P, A_c = P^T AP.
+void launch_coarse_operator(Amg* m, hipStream_t s, AmgLevel& L, AmgLevel& C) {
+  if (!L.smoothed) {
+    Scope sc(m->prof, K_GALERKIN, (72.0 + 16.0 + 32.0) * L.A.nslot + 72.0 * C.A.nslot);
+    SGO_LAUNCH(k_galerkin, dim3(grid_for(L.gal.ngrp, kWavesPerBlock)), dim3(kBlock), 0, s, L.A, C.A, L.gal, L.d);
+    return;
+  }
+  PDev& P = L.P;
+  {
+    Scope sc(m->prof, K_SA_P, (72.0 + 12.0 + 16.0) * L.A.nslot + 80.0 * P.np);
+    SGO_LAUNCH(k_p_values, dim3(grid_for(P.val.ngrp, kWavesPerBlock)), dim3(kBlock), 0, s, L.A, P, (const int*)L.agg,
+               (const double*)L.d, m->cfg.omega_p);
+  }
+  {
+    Scope sc(m->prof, K_SA_AP, 156.0 * P.ap.n + 72.0 * P.nap);
+    SGO_LAUNCH((k_block_products<true, false, false>), dim3(grid_for(P.ap.ngrp, kWavesPerBlock)), dim3(kBlock), 0, s,
+               P.ap, (const double*)L.A.blk, (size_t)L.A.nslot, (const double*)P.blk, (size_t)P.np, P.apblk,
+               (size_t)P.nap);
+  }
+  {
+    Scope sc(m->prof, K_SA_RAP, 156.0 * P.rap.n + 72.0 * C.A.nslot);
+    SGO_LAUNCH((k_block_products<false, true, true>), dim3(grid_for(P.rap.ngrp, kWavesPerBlock)), dim3(kBlock), 0, s,
+               P.rap, (const double*)P.blk, (size_t)P.np, (const double*)P.apblk, (size_t)P.nap, C.A.blk,
+               (size_t)C.A.nslot);
+  }
+}
 
 // The coarse solution of level l as seen by its parent: xk (dense level) or the flexible-CG
 // combination c1 z1 + c2 p2 whose scalars are ratios of the partial sums the FCG SpMVs left
@@ -872,7 +1361,11 @@ int cycle(Amg* m, hipStream_t s, int l, const double* rhs, const double* rhs_sub
     Scope sc(m->prof, K_SPMV_PRE_RESID, 80.0 * L.A.nslot + 120.0 * L.A.n);
     launch_spmv_ex(s, L.A, SPMV_PRE_RESID, a);
   }
-  {
+  if (L.smoothed) {
+    Scope sc(m->prof, K_RESTRICT_P, 84.0 * L.P.np + 24.0 * L.A.n + 24.0 * L.nc);
+    SGO_LAUNCH(k_restrict_p, dim3(grid_for(L.P.t_ngrp, kWavesPerBlock)), dim3(kBlock), 0, s, L.P,
+               (const double*)(two ? L.tR : L.rs), C.bk, S);
+  } else {
     Scope sc(m->prof, K_RESTRICT, 40.0 * L.A.n + 24.0 * L.nc);
     SGO_LAUNCH(k_restrict, dim3(grid_for(L.mem_ngrp, kWavesPerBlock)), dim3(kBlock), 0, s, L.mem_ngrp, L.mem_grp,
                        L.mem, L.agg, L.d, two ? L.tR : L.rs, C.bk, S);
@@ -902,8 +1395,12 @@ int cycle(Amg* m, hipStream_t s, int l, const double* rhs, const double* rhs_sub
     a.dotA2 = dotvec2;
     a.partials = dotparts;
   }
-  if (l == 0) {
-    {
+  if (l == 0 || L.smoothed) {
+    if (L.smoothed) {
+      Scope sc(m->prof, K_PROLONG_P, 80.0 * L.P.np + 52.0 * L.A.n);
+      SGO_LAUNCH(k_prolong_p, dim3(grid_for(L.P.r_ngrp, kWavesPerBlock)), dim3(kBlock), 0, s, L.A.n, L.P, cs.u1, cs.c1, cs.u2, cs.c2,
+                 L.xs, S, two ? (const double*)L.tX : nullptr);
+    } else {
       Scope sc(m->prof, K_PROLONG, 68.0 * L.A.n);
       SGO_LAUNCH(k_prolong_add, dim3(grid_for(L.A.n, kBlock)), dim3(kBlock), 0, s, L.A.n, L.agg, L.d, cs.u1, cs.c1,
                          cs.u2, cs.c2, L.xs, S, two ? (const double*)L.tX : nullptr);
@@ -958,10 +1455,7 @@ int amg_update(Amg* m, hipStream_t s, std::string* err) {
       Scope sc(m->prof, K_CENTRES, 36.0 * L.A.n);
       SGO_LAUNCH(k_centres, dim3(grid_for(L.nc, kBlock)), dim3(kBlock), 0, s, L.nc, L.mem_ptr, L.mem, L.pos, C.pos, L.d);
     }
-    {
-      Scope sc(m->prof, K_GALERKIN, (72.0 + 16.0 + 32.0) * L.A.nslot + 72.0 * C.A.nslot);
-      SGO_LAUNCH(k_galerkin, dim3(grid_for(L.gal.ngrp, kWavesPerBlock)), dim3(kBlock), 0, s, L.A, C.A, L.gal, L.d);
-    }
+    launch_coarse_operator(m, s, L, C);
     {
       Scope sc(m->prof, K_LEVEL_DINV, 120.0 * C.A.n);
       SGO_LAUNCH(k_level_dinv, dim3(grid_for(C.A.n, kBlock)), dim3(kBlock), 0, s, C.A);
@@ -1010,6 +1504,11 @@ Amg* amg_create(hipStream_t s, const BsrDev& A0, const double* d_poses, const in
   if (const char* e = std::getenv("SGO_AMG_THETA")) m->cfg.theta = std::atof(e);
   if (const char* e = std::getenv("SGO_AMG_OMEGA")) m->cfg.omega = std::atof(e);
   if (const char* e = std::getenv("SGO_AMG_THETA_COARSE")) m->cfg.theta_coarse = std::atof(e);
+  if (const char* e = std::getenv("SGO_AMG_SMOOTH")) m->cfg.smooth = std::atoi(e) != 0;
+  if (const char* e = std::getenv("SGO_AMG_OMEGA_P")) m->cfg.omega_p = std::atof(e);
+  // With the smoothed prolongator a V-cycle needs ~1.4x the PCG iterations of the K-cycle (C4: 39 vs
+  // 27) at less than half the launches per iteration: V is the default there, K for the tentative one.
+  if (m->cfg.smooth) m->kdepth = 0;
   if (const char* e = std::getenv("SGO_AMG_KDEPTH")) m->kdepth = std::atoi(e);
   if (const char* e = std::getenv("SGO_AMG_FCG2_DEPTH")) m->fcg2_depth = std::atoi(e);
   if (const char* e = std::getenv("SGO_AMG_DOUBLE_PASS")) m->cfg.double_pass = std::atoi(e) != 0;
@@ -1154,6 +1653,15 @@ Amg* amg_create(hipStream_t s, const BsrDev& A0, const double* d_poses, const in
       std::vector<int> fill(mem_ptr.begin(), mem_ptr.end() - 1);
       for (int i = 0; i < n; ++i) mem[fill[agg[i]]++] = i;
     }
+    HostLevel Hc;
+    std::vector<int> order, tgt, cptr, grp_g;
+    SaHost sa;
+    const bool smooth = m->cfg.smooth;
+    if (smooth) {
+      sa_symbolic(H, agg, nc, sa);
+      Hc = std::move(sa.Hc);
+      t_sort = ms_since(tA) - t_agg;
+    } else {
     // coarse slots: unique (agg[row], agg[col]); diagonal first in each row
     const int ns = H.nslot;
     std::vector<uint64_t> key(ns);
@@ -1164,7 +1672,7 @@ Amg* amg_create(hipStream_t s, const BsrDev& A0, const double* d_poses, const in
     }
     // stable order by key = two stable counting sorts (low word = column code, then high word = row):
     // O(ns), a few ms for 2M slots where std::stable_sort with an indirect key took > 100 ms
-    std::vector<int> order(ns);
+    order.resize(ns);
     {
       std::vector<int> tmp(ns), cnt((size_t)nc + 2, 0);
       for (int k = 0; k < ns; ++k) cnt[(size_t)(key[k] & 0xffffffffull) + 1]++;
@@ -1179,9 +1687,8 @@ Amg* amg_create(hipStream_t s, const BsrDev& A0, const double* d_poses, const in
       }
     }
     t_sort = ms_since(tA) - t_agg;
-    HostLevel Hc;
     Hc.n = nc;
-    std::vector<int> tgt(ns), cptr;  // contribution -> coarse slot; coarse slot -> contribution range
+    tgt.resize(ns);   // contribution -> coarse slot; cptr: coarse slot -> contribution range
     {
       uint64_t prev = ~0ull;
       int cs = -1;
@@ -1206,8 +1713,9 @@ Amg* amg_create(hipStream_t s, const BsrDev& A0, const double* d_poses, const in
     for (int a = 0; a < nc; ++a) Hc.rowptr[a + 1] += Hc.rowptr[a];
     for (int a = 0; a < nc; ++a)
       if (Hc.col[Hc.rowptr[a]] != a) return fail("amg_create: internal error (coarse diagonal slot missing)");
+    grp_g = make_groups(cptr);
+    }
     std::vector<int> grp_c = make_groups(Hc.rowptr);
-    std::vector<int> grp_g = make_groups(cptr);
     if (std::getenv("SGO_VERBOSE"))
       std::fprintf(stderr, "[sgo] amg level %d: host aggregation + coarse structure %.1f ms (aggregate %.1f, sort %.1f; n=%d -> %d)\n",
                    l, ms_since(tA), t_agg, t_sort, n, nc);
@@ -1221,11 +1729,54 @@ Amg* amg_create(hipStream_t s, const BsrDev& A0, const double* d_poses, const in
     L.mem_grp = dev_upload(m->pool, grp_m, s);
     L.mem_ngrp = (int)grp_m.size() - 1;
     L.d = dev_alloc<double>(m->pool, 2 * (size_t)n);
-    L.gal.n = ns;
-    L.gal.src = dev_upload(m->pool, order, s);
-    L.gal.tgt = dev_upload(m->pool, tgt, s);
-    L.gal.grp = dev_upload(m->pool, grp_g, s);
-    L.gal.ngrp = (int)grp_g.size() - 1;
+    if (smooth) {
+      PDev& P = L.P;
+      L.smoothed = true;
+      P.np = (int)sa.p_row.size();
+      P.rowptr = dev_upload(m->pool, sa.p_rowptr, s);
+      P.row = dev_upload(m->pool, sa.p_row, s);
+      P.col = dev_upload(m->pool, sa.p_col, s);
+      P.blk = dev_alloc<double>(m->pool, 9 * (size_t)P.np);
+      P.val.n = H.nslot;
+      P.val.a = dev_upload(m->pool, sa.val_src, s);
+      P.val.tgt = dev_upload(m->pool, sa.val_tgt, s);
+      P.val.grp = dev_upload(m->pool, sa.val_grp, s);
+      P.val.ngrp = (int)sa.val_grp.size() - 1;
+      P.r_grp = dev_upload(m->pool, sa.r_grp, s);
+      P.r_ngrp = (int)sa.r_grp.size() - 1;
+      P.t_pos = dev_upload(m->pool, sa.t_pos, s);
+      P.t_row = dev_upload(m->pool, sa.t_row, s);
+      P.t_col = dev_upload(m->pool, sa.t_col, s);
+      P.t_blk = dev_alloc<double>(m->pool, 9 * (size_t)P.np);
+      P.t_grp = dev_upload(m->pool, sa.t_grp, s);
+      P.t_ngrp = (int)sa.t_grp.size() - 1;
+      P.nap = sa.nap;
+      P.apblk = dev_alloc<double>(m->pool, 9 * (size_t)P.nap);
+      P.ap.n = (int)sa.ap_a.size();
+      P.ap.a = dev_upload(m->pool, sa.ap_a, s);
+      P.ap.b = dev_upload(m->pool, sa.ap_b, s);
+      P.ap.tgt = dev_upload(m->pool, sa.ap_tgt, s);
+      P.ap.grp = dev_upload(m->pool, sa.ap_grp, s);
+      P.ap.ngrp = (int)sa.ap_grp.size() - 1;
+      P.rap.n = (int)sa.rap_a.size();
+      P.rap.a = dev_upload(m->pool, sa.rap_a, s);
+      P.rap.b = dev_upload(m->pool, sa.rap_b, s);
+      P.rap.tgt = dev_upload(m->pool, sa.rap_tgt, s);
+      P.rap.grp = dev_upload(m->pool, sa.rap_grp, s);
+      P.rap.ngrp = (int)sa.rap_grp.size() - 1;
+      if (!P.rowptr || !P.row || !P.col || !P.blk || !P.val.a || !P.val.tgt || !P.val.grp || !P.r_grp || !P.t_pos || !P.t_row || !P.t_col || !P.t_blk || !P.t_grp ||
+          !P.apblk || !P.ap.a || !P.ap.b || !P.ap.tgt || !P.ap.grp || !P.rap.a || !P.rap.b || !P.rap.tgt || !P.rap.grp)
+        return fail("amg_create: out of device memory");
+      std::snprintf(line, sizeof line, "(P %d, AP %d blocks; %d + %d products) ", P.np, P.nap, P.ap.n, P.rap.n);
+      m->desc += line;
+    } else {
+      L.gal.n = H.nslot;
+      L.gal.src = dev_upload(m->pool, order, s);
+      L.gal.tgt = dev_upload(m->pool, tgt, s);
+      L.gal.grp = dev_upload(m->pool, grp_g, s);
+      L.gal.ngrp = (int)grp_g.size() - 1;
+      if (!L.gal.src || !L.gal.tgt || !L.gal.grp) return fail("amg_create: out of device memory");
+    }
     AmgLevel C;
     C.A.n = nc;
     C.A.nslot = Hc.nslot;
@@ -1236,7 +1787,7 @@ Amg* amg_create(hipStream_t s, const BsrDev& A0, const double* d_poses, const in
     C.A.rowptr = dev_upload(m->pool, Hc.rowptr, s);
     C.A.blk = dev_alloc<double>(m->pool, 9 * (size_t)Hc.nslot);
     C.A.dinv = dev_alloc<double>(m->pool, 6 * (size_t)nc);
-    if (!L.agg || !L.mem_ptr || !L.mem || !L.mem_grp || !L.d || !L.gal.src || !L.gal.tgt || !L.gal.grp || !C.A.row || !C.A.col ||
+    if (!L.agg || !L.mem_ptr || !L.mem || !L.mem_grp || !L.d || !C.A.row || !C.A.col ||
         !C.A.grp || !C.A.rowptr || !C.A.blk || !C.A.dinv)
       return fail("amg_create: out of device memory");
     if (hipStreamSynchronize(s) != hipSuccess) return fail("amg_create: upload failed");  // host vectors die below
@@ -1250,7 +1801,8 @@ Amg* amg_create(hipStream_t s, const BsrDev& A0, const double* d_poses, const in
       if (l == 0)
         SGO_LAUNCH(k_positions0, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, s, n, d_free_id, d_poses, Lr.pos);
       SGO_LAUNCH(k_centres, dim3(grid_for(nc, kBlock)), dim3(kBlock), 0, s, nc, Lr.mem_ptr, Lr.mem, Lr.pos, Cr.pos, Lr.d);
-      SGO_LAUNCH(k_galerkin, dim3(grid_for(Lr.gal.ngrp, kWavesPerBlock)), dim3(kBlock), 0, s, Lr.A, Cr.A, Lr.gal, Lr.d);
+      launch_coarse_operator(m, s, Lr, Cr);
+      if (l + 1 < m->cfg.max_levels) SGO_LAUNCH(k_level_dinv, dim3(grid_for(Cr.A.n, kBlock)), dim3(kBlock), 0, s, Cr.A);
       if (hipStreamSynchronize(s) != hipSuccess) return fail("amg_create: Galerkin kernel failed");
     }
     H = std::move(Hc);
@@ -1279,7 +1831,7 @@ Amg* amg_create(hipStream_t s, const BsrDev& A0, const double* d_poses, const in
   // measured on MI355X (round 1): with the level data in global memory the single-workgroup tree
   // is latency-bound (16 waves, ~3 us per dependent-load phase) and slower than separate
   // launches; it stays opt-in until the small levels are staged in LDS.
-  if (!std::getenv("SGO_AMG_TREE")) m->tree_start = -1;
+  if (!std::getenv("SGO_AMG_TREE") || m->cfg.smooth) m->tree_start = -1;   // (the tree kernel knows the tentative transfer only)
   if (m->tree_start >= 0) {
     CoarseTree& T = m->tree;
     T.nlev = last - m->tree_start + 1;

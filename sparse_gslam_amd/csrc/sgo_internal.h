@@ -5,7 +5,9 @@
 #include <hip/hip_ext.h>
 
 #include <cstdint>
+#include <algorithm>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "sgo.h"
@@ -153,6 +155,11 @@ enum KernelId : int {
   K_DENSE_INVERT,
   K_DENSE_APPLY,
   K_COARSE_TREE,
+  K_SA_P,
+  K_SA_AP,
+  K_SA_RAP,
+  K_RESTRICT_P,
+  K_PROLONG_P,
   K_COUNT
 };
 extern const char* const kKernelNames[K_COUNT];
@@ -169,6 +176,23 @@ inline int grid_for(long long work_items, int per_block) {
   if (g > kMaxGrid) g = kMaxGrid;
   g = (g + 7) / 8 * 8;  // multiple of 8: one contiguous band of groups per XCD
   return (int)g;
+}
+
+// Static-partition parallel loop over [0, n) on up to 8 host threads (structure builds only).
+template <class F>
+inline void host_parallel_for(int n, int grain, F&& fn) {
+  const int hw = (int)std::thread::hardware_concurrency();
+  const int T = std::max(1, std::min({8, hw > 0 ? hw : 1, n / std::max(1, grain)}));
+  if (T == 1) {
+    fn(0, n, 0);
+    return;
+  }
+  std::vector<std::thread> th;
+  for (int t = 0; t < T; ++t) {
+    const int lo = (int)((long long)n * t / T), hi = (int)((long long)n * (t + 1) / T);
+    th.emplace_back([&fn, lo, hi, t]() { fn(lo, hi, t); });
+  }
+  for (auto& x : th) x.join();
 }
 
 // ---- launch macro -------------------------------------------------------------------------
