@@ -942,42 +942,59 @@ int aggregate(const HostLevel& L, const std::vector<double>& w, double theta, st
 // Host side of the smoothed-aggregation set-up: patterns of P, AP = A P and A_c = P^T AP and, for
 // every entry of each, the block products that make it up, listed in target order (all sorting is
 // per row -- a counting sort over the row's few distinct columns -- so the rows run in parallel).
+// int array without value-initialisation (the product lists are 10^7 entries and fully overwritten)
+struct UVec {
+  std::unique_ptr<int[]> p;
+  size_t n = 0;
+  void resize(size_t count) {
+    p.reset(new int[std::max<size_t>(count, 1)]);
+    n = count;
+  }
+  int* data() { return p.get(); }
+  size_t size() const { return n; }
+};
+int* dev_upload(std::vector<void*>& pool, const UVec& v, hipStream_t s) {
+  int* d = dev_alloc<int>(pool, v.n);
+  if (d && v.n) hipMemcpyAsync(d, v.p.get(), v.n * sizeof(int), hipMemcpyHostToDevice, s);
+  return d;
+}
 struct SaHost {
   std::vector<int> p_rowptr, p_row, p_col, val_src, val_tgt, val_grp;
   std::vector<int> r_grp, t_pos, t_row, t_col, t_grp;
   int nap = 0;
-  std::vector<int> ap_a, ap_b, ap_tgt, ap_grp;
+  UVec ap_a, ap_b, ap_tgt;
+  std::vector<int> ap_grp;
   HostLevel Hc;
-  std::vector<int> rap_a, rap_b, rap_tgt, rap_grp;
+  UVec rap_a, rap_b, rap_tgt;
+  std::vector<int> rap_grp;
 };
 
-// Orders `items` products of one row by their target's local index q (counting sort, stable) and
-// writes them to out_*[base ...]; ptr[first_target + q] receives the start of target q.
+// Per-row counting sort of products by the local index q of their target: count(q) for every
+// product, then start(), then place() returns each product's destination (stable).
 struct RowSorter {
-  std::vector<int> cnt, qa, qb, qq;
-  void begin(int ntargets) {
-    cnt.assign((size_t)ntargets + 1, 0);
-    qa.clear(); qb.clear(); qq.clear();
-  }
-  void add(int a, int b, int q) {
-    qa.push_back(a); qb.push_back(b); qq.push_back(q);
-    cnt[(size_t)q + 1]++;
-  }
-  void flush(int base, int first_target, int* out_a, int* out_b, int* out_tgt, int* ptr) {
-    const int nt = (int)cnt.size() - 1;
-    for (int q = 0; q < nt; ++q) cnt[q + 1] += cnt[q];
-    for (int q = 0; q < nt; ++q) ptr[first_target + q] = base + cnt[q];
-    for (size_t t = 0; t < qq.size(); ++t) {
-      const int dst = base + cnt[qq[t]]++;
-      out_a[dst] = qa[t];
-      if (out_b) out_b[dst] = qb[t];
-      out_tgt[dst] = first_target + qq[t];
+  std::vector<int> off;
+  void begin(int ntargets) { off.assign((size_t)ntargets + 1, 0); }
+  void count(int q) { off[(size_t)q + 1]++; }
+  void start(int base, int first_target, int* ptr) {
+    const int nt = (int)off.size() - 1;
+    for (int q = 0; q < nt; ++q) off[q + 1] += off[q];
+    for (int q = 0; q < nt; ++q) {
+      off[q] += base;
+      ptr[first_target + q] = off[q];
     }
   }
+  int place(int q) { return off[q]++; }
 };
 
 void sa_symbolic(const HostLevel& H, const std::vector<int>& agg, int nc, SaHost& o) {
   const int n = H.n;
+  const bool verbose = std::getenv("SGO_VERBOSE") != nullptr;
+  auto t0 = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    const auto t1 = std::chrono::steady_clock::now();
+    if (verbose && n > 20000) std::fprintf(stderr, "[sgo]   sa_symbolic %-12s %.1f ms\n", what, 1e3 * std::chrono::duration<double>(t1 - t0).count());
+    t0 = t1;
+  };
   // ---- P: row i holds the aggregates of the columns of row i (its own among them: diagonal slot)
   o.p_rowptr.assign((size_t)n + 1, 0);
   host_parallel_for(n, 4096, [&](int lo, int hi, int) {
@@ -1021,12 +1038,18 @@ void sa_symbolic(const HostLevel& H, const std::vector<int>& agg, int nc, SaHost
         o.p_col[e0 + q] = uniq[q];
       }
       rs.begin((int)uniq.size());
-      for (int k = H.rowptr[i]; k < H.rowptr[i + 1]; ++k) rs.add(k, 0, pos[agg[H.col[k]]]);
-      rs.flush(H.rowptr[i], e0, o.val_src.data(), nullptr, o.val_tgt.data(), val_ptr.data());
+      for (int k = H.rowptr[i]; k < H.rowptr[i + 1]; ++k) rs.count(pos[agg[H.col[k]]]);
+      rs.start(H.rowptr[i], e0, val_ptr.data());
+      for (int k = H.rowptr[i]; k < H.rowptr[i + 1]; ++k) {
+        const int q = pos[agg[H.col[k]]], dst = rs.place(q);
+        o.val_src[dst] = k;
+        o.val_tgt[dst] = e0 + q;
+      }
     }
   });
   val_ptr[np] = H.nslot;
   o.val_grp = make_groups(val_ptr);
+  lap("P");
   // ---- entries by coarse column (restriction walks P^T)
   std::vector<int> t_ptr((size_t)nc + 1, 0);
   for (int e = 0; e < np; ++e) t_ptr[(size_t)o.p_col[e] + 1]++;
@@ -1047,6 +1070,7 @@ void sa_symbolic(const HostLevel& H, const std::vector<int>& agg, int nc, SaHost
   }
   o.t_grp = make_groups(t_ptr);
   o.r_grp = make_groups(o.p_rowptr);
+  lap("P^T lists");
   // ---- AP: row i holds the union of the P rows of the columns of row i
   std::vector<int> ap_rowptr((size_t)n + 1, 0), app((size_t)n + 1, 0);
   host_parallel_for(n, 4096, [&](int lo, int hi, int) {
@@ -1072,6 +1096,7 @@ void sa_symbolic(const HostLevel& H, const std::vector<int>& agg, int nc, SaHost
     ap_rowptr[i + 1] += ap_rowptr[i];
     app[i + 1] += app[i];
   }
+  lap("AP count");
   o.nap = ap_rowptr[n];
   const int nprod_ap = app[n];
   std::vector<int> ap_col((size_t)o.nap), ap_ptr((size_t)o.nap + 1);
@@ -1102,13 +1127,24 @@ void sa_symbolic(const HostLevel& H, const std::vector<int>& agg, int nc, SaHost
       rs.begin((int)uniq.size());
       for (int k = H.rowptr[i]; k < H.rowptr[i + 1]; ++k) {
         const int j = H.col[k];
-        for (int e = o.p_rowptr[j]; e < o.p_rowptr[j + 1]; ++e) rs.add(k, e, pos[o.p_col[e]]);
+        for (int e = o.p_rowptr[j]; e < o.p_rowptr[j + 1]; ++e) rs.count(pos[o.p_col[e]]);
       }
-      rs.flush(app[i], f0, o.ap_a.data(), o.ap_b.data(), o.ap_tgt.data(), ap_ptr.data());
+      rs.start(app[i], f0, ap_ptr.data());
+      int *pa = o.ap_a.data(), *pb = o.ap_b.data(), *pt = o.ap_tgt.data();
+      for (int k = H.rowptr[i]; k < H.rowptr[i + 1]; ++k) {
+        const int j = H.col[k];
+        for (int e = o.p_rowptr[j]; e < o.p_rowptr[j + 1]; ++e) {
+          const int q = pos[o.p_col[e]], dst = rs.place(q);
+          pa[dst] = k;
+          pb[dst] = e;
+          pt[dst] = f0 + q;
+        }
+      }
     }
   });
   ap_ptr[o.nap] = nprod_ap;
   o.ap_grp = make_groups(ap_ptr);
+  lap("AP fill");
   // ---- A_c = P^T AP: coarse row a collects, over the entries (i, a) of column a of P, row i of AP
   HostLevel& C = o.Hc;
   C.n = nc;
@@ -1137,6 +1173,7 @@ void sa_symbolic(const HostLevel& H, const std::vector<int>& agg, int nc, SaHost
     C.rowptr[a + 1] += C.rowptr[a];
     rpp[a + 1] += rpp[a];
   }
+  lap("RAP count");
   C.nslot = C.rowptr[nc];
   const int nprod_rap = rpp[nc];
   C.row.resize(C.nslot);
@@ -1172,14 +1209,25 @@ void sa_symbolic(const HostLevel& H, const std::vector<int>& agg, int nc, SaHost
       }
       rs.begin((int)uniq.size() + 1);
       for (int t = t_ptr[a]; t < t_ptr[a + 1]; ++t) {
-        const int e = t_idx[t], i = o.t_row[t];
-        for (int f = ap_rowptr[i]; f < ap_rowptr[i + 1]; ++f) rs.add(e, f, pos[ap_col[f]]);
+        const int i = o.t_row[t];
+        for (int f = ap_rowptr[i]; f < ap_rowptr[i + 1]; ++f) rs.count(pos[ap_col[f]]);
       }
-      rs.flush(rpp[a], s0, o.rap_a.data(), o.rap_b.data(), o.rap_tgt.data(), rap_ptr.data());
+      rs.start(rpp[a], s0, rap_ptr.data());
+      int *pa = o.rap_a.data(), *pb = o.rap_b.data(), *pt = o.rap_tgt.data();
+      for (int t = t_ptr[a]; t < t_ptr[a + 1]; ++t) {
+        const int e = t_idx[t], i = o.t_row[t];
+        for (int f = ap_rowptr[i]; f < ap_rowptr[i + 1]; ++f) {
+          const int q = pos[ap_col[f]], dst = rs.place(q);
+          pa[dst] = e;
+          pb[dst] = f;
+          pt[dst] = s0 + q;
+        }
+      }
     }
   });
   rap_ptr[C.nslot] = nprod_rap;
   o.rap_grp = make_groups(rap_ptr);
+  lap("RAP fill");
 }
 
 }  // namespace
