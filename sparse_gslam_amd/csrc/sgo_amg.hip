@@ -986,7 +986,10 @@ struct RowSorter {
   int place(int q) { return off[q]++; }
 };
 
-void sa_symbolic(const HostLevel& H, const std::vector<int>& agg, int nc, SaHost& o) {
+// Returns false (nothing usable in `o`) when the product lists would exceed `budget` products: graphs
+// with many long-range edges make the smoothed coarse operators nearly dense, and the caller then
+// keeps the tentative prolongator for this level.
+bool sa_symbolic(const HostLevel& H, const std::vector<int>& agg, int nc, long long budget, SaHost& o) {
   const int n = H.n;
   const bool verbose = std::getenv("SGO_VERBOSE") != nullptr;
   auto t0 = std::chrono::steady_clock::now();
@@ -1072,11 +1075,13 @@ void sa_symbolic(const HostLevel& H, const std::vector<int>& agg, int nc, SaHost
   o.r_grp = make_groups(o.p_rowptr);
   lap("P^T lists");
   // ---- AP: row i holds the union of the P rows of the columns of row i
-  std::vector<int> ap_rowptr((size_t)n + 1, 0), app((size_t)n + 1, 0);
+  std::vector<int> ap_rowptr((size_t)n + 1, 0);
+  std::vector<long long> app((size_t)n + 1, 0);
   host_parallel_for(n, 4096, [&](int lo, int hi, int) {
     std::vector<int> mark((size_t)nc, -1);
     for (int i = lo; i < hi; ++i) {
-      int cnt = 0, prod = 0;
+      int cnt = 0;
+      long long prod = 0;
       for (int k = H.rowptr[i]; k < H.rowptr[i + 1]; ++k) {
         const int j = H.col[k];
         prod += o.p_rowptr[j + 1] - o.p_rowptr[j];
@@ -1097,8 +1102,9 @@ void sa_symbolic(const HostLevel& H, const std::vector<int>& agg, int nc, SaHost
     app[i + 1] += app[i];
   }
   lap("AP count");
+  if (app[n] > budget || ap_rowptr[n] < 0) return false;
   o.nap = ap_rowptr[n];
-  const int nprod_ap = app[n];
+  const int nprod_ap = (int)app[n];
   std::vector<int> ap_col((size_t)o.nap), ap_ptr((size_t)o.nap + 1);
   o.ap_a.resize(nprod_ap);
   o.ap_b.resize(nprod_ap);
@@ -1129,7 +1135,7 @@ void sa_symbolic(const HostLevel& H, const std::vector<int>& agg, int nc, SaHost
         const int j = H.col[k];
         for (int e = o.p_rowptr[j]; e < o.p_rowptr[j + 1]; ++e) rs.count(pos[o.p_col[e]]);
       }
-      rs.start(app[i], f0, ap_ptr.data());
+      rs.start((int)app[i], f0, ap_ptr.data());
       int *pa = o.ap_a.data(), *pb = o.ap_b.data(), *pt = o.ap_tgt.data();
       for (int k = H.rowptr[i]; k < H.rowptr[i + 1]; ++k) {
         const int j = H.col[k];
@@ -1149,11 +1155,12 @@ void sa_symbolic(const HostLevel& H, const std::vector<int>& agg, int nc, SaHost
   HostLevel& C = o.Hc;
   C.n = nc;
   C.rowptr.assign((size_t)nc + 1, 0);
-  std::vector<int> rpp((size_t)nc + 1, 0);
+  std::vector<long long> rpp((size_t)nc + 1, 0);
   host_parallel_for(nc, 256, [&](int lo, int hi, int) {
     std::vector<int> mark((size_t)nc, -1);
     for (int a = lo; a < hi; ++a) {
-      int cnt = 0, prod = 0;
+      int cnt = 0;
+      long long prod = 0;
       for (int t = t_ptr[a]; t < t_ptr[a + 1]; ++t) {
         const int i = o.t_row[t];
         prod += ap_rowptr[i + 1] - ap_rowptr[i];
@@ -1174,8 +1181,9 @@ void sa_symbolic(const HostLevel& H, const std::vector<int>& agg, int nc, SaHost
     rpp[a + 1] += rpp[a];
   }
   lap("RAP count");
+  if (app[n] + rpp[nc] > budget || C.rowptr[nc] > std::max(H.nslot / 2, 4096)) return false;
   C.nslot = C.rowptr[nc];
-  const int nprod_rap = rpp[nc];
+  const int nprod_rap = (int)rpp[nc];
   C.row.resize(C.nslot);
   C.col.resize(C.nslot);
   std::vector<int> rap_ptr((size_t)C.nslot + 1);
@@ -1212,7 +1220,7 @@ void sa_symbolic(const HostLevel& H, const std::vector<int>& agg, int nc, SaHost
         const int i = o.t_row[t];
         for (int f = ap_rowptr[i]; f < ap_rowptr[i + 1]; ++f) rs.count(pos[ap_col[f]]);
       }
-      rs.start(rpp[a], s0, rap_ptr.data());
+      rs.start((int)rpp[a], s0, rap_ptr.data());
       int *pa = o.rap_a.data(), *pb = o.rap_b.data(), *pt = o.rap_tgt.data();
       for (int t = t_ptr[a]; t < t_ptr[a + 1]; ++t) {
         const int e = t_idx[t], i = o.t_row[t];
@@ -1228,6 +1236,7 @@ void sa_symbolic(const HostLevel& H, const std::vector<int>& agg, int nc, SaHost
   rap_ptr[C.nslot] = nprod_rap;
   o.rap_grp = make_groups(rap_ptr);
   lap("RAP fill");
+  return true;
 }
 
 }  // namespace
@@ -1428,7 +1437,8 @@ int cycle(Amg* m, hipStream_t s, int l, const double* rhs, const double* rhs_sub
     Scope sc(m->prof, K_COARSE_TREE, 0.0);
     SGO_LAUNCH(k_coarse_tree, dim3(1), dim3(kTreeThreads), sizeof(double) * m->N, s, (const CoarseTree*)m->d_tree, S);
     cs.u1 = C.xk;
-  } else if (l + 1 > m->kdepth) {  // plain V-cycle below the K-cycle depth
+  } else if (l + 1 > m->kdepth && m->lv[l + 1].smoothed) {  // V-cycle below the K-cycle depth; a level whose own
+                                                             // transfer is the tentative one always gets the K-cycle
     SpmvRatio none;
     cycle(m, s, l + 1, C.bk, nullptr, none, nullptr, C.xk, nullptr, nullptr, S);
     cs.u1 = C.xk;
@@ -1704,12 +1714,23 @@ Amg* amg_create(hipStream_t s, const BsrDev& A0, const double* d_poses, const in
     HostLevel Hc;
     std::vector<int> order, tgt, cptr, grp_g;
     SaHost sa;
-    const bool smooth = m->cfg.smooth;
+    bool smooth = m->cfg.smooth;
     if (smooth) {
-      sa_symbolic(H, agg, nc, sa);
-      Hc = std::move(sa.Hc);
+      // product lists of at most 16 per fine slot (C4 needs 9-11, chain-like graphs 4-6) and a coarse
+      // operator of at most half the fine one's blocks; beyond that the smoothed coarse operator is
+      // nearly dense (5 % random long-range closures on C4: 33 products per slot, 4.4x the blocks,
+      // 2x slower than the tentative hierarchy): this level keeps the tentative prolongator
+      const long long budget = std::min<long long>(1500000000LL, std::max<long long>(16LL * H.nslot, 2000000LL));
+      try {
+        smooth = sa_symbolic(H, agg, nc, budget, sa);
+      } catch (const std::bad_alloc&) {
+        smooth = false;
+      }
+      if (smooth) Hc = std::move(sa.Hc);
+      else sa = SaHost();
       t_sort = ms_since(tA) - t_agg;
-    } else {
+    }
+    if (!smooth) {
     // coarse slots: unique (agg[row], agg[col]); diagonal first in each row
     const int ns = H.nslot;
     std::vector<uint64_t> key(ns);

@@ -90,8 +90,10 @@ def opt_amg():
 
 
 def test_amg_preconditioner_is_positive_and_contracts(opt_amg):
-    """The K-cycle is a variable preconditioner (inner flexible CG), so <u, M v> == <M u, v> holds
-    only approximately; the outer flexible PCG needs <u, M u> > 0 and M ~ H^-1."""
+    """Default: smoothed aggregation, V-cycle -- a fixed symmetric operator (checked below).  With
+    SGO_AMG_KDEPTH > 0 the K-cycle's inner flexible CG makes it a variable preconditioner, for which
+    <u, M v> == <M u, v> holds only approximately; the outer flexible PCG needs <u, M u> > 0 and
+    M ~ H^-1 either way."""
     g = synth.config("C2", info_mode="full")
     opt_amg.set_graph(*g.arrays())
     b, _, _, _ = opt_amg.linearize()
@@ -105,6 +107,38 @@ def test_amg_preconditioner_is_positive_and_contracts(opt_amg):
     x1 = opt_amg.precondition(b)
     r1 = b - opt_amg.hessian_apply(x1)
     assert (r1 * opt_amg.precondition(r1)).sum() < (b * x1).sum()
+
+
+def test_smoothed_aggregation_v_cycle_is_a_symmetric_operator(opt_amg):
+    """P = (I - w D^-1 A) T, Galerkin coarse operators, one damped block-Jacobi sweep before and after
+    on every level, exact dense coarsest solve: M is symmetric positive definite and linear."""
+    g = synth.config("C2", info_mode="full")
+    opt_amg.set_graph(*g.arrays())
+    opt_amg.linearize()
+    rng = np.random.default_rng(7)
+    u = rng.standard_normal((opt_amg.n_free, 3))
+    v = rng.standard_normal((opt_amg.n_free, 3))
+    Mu, Mv = opt_amg.precondition(u), opt_amg.precondition(v)
+    assert abs((u * Mv).sum() - (Mu * v).sum()) <= 1e-9 * max(abs((u * Mv).sum()), np.linalg.norm(u) * np.linalg.norm(Mv) * 1e-3)
+    assert np.abs(opt_amg.precondition(2.0 * u - 3.0 * v) - (2.0 * Mu - 3.0 * Mv)).max() <= 1e-9 * np.abs(Mu).max()
+    assert (u * Mu).sum() > 0 and (v * Mv).sum() > 0
+
+
+def test_tentative_and_smoothed_hierarchies_solve_the_same_system(monkeypatch):
+    """SGO_AMG_SMOOTH=0 keeps the plain-aggregation K-cycle of the first milestone: same solution,
+    more PCG iterations."""
+    g = synth.config("C2", info_mode="full")
+    res = {}
+    for smooth in ("1", "0"):
+        monkeypatch.setenv("SGO_AMG_SMOOTH", smooth)
+        with capi.Optimizer(0, solver=capi.SOLVER_PCG_AMG, pcg_tol=1e-10, pcg_maxit=5000) as o:
+            o.set_graph(*g.arrays())
+            o.linearize()
+            res[smooth] = o.solve()
+    (x1, it1, rr1), (x0, it0, rr0) = res["1"], res["0"]
+    assert rr1 <= 1e-10 and rr0 <= 1e-10
+    assert np.abs(x1 - x0).max() <= 1e-7 * np.abs(x0).max()
+    assert it1 < it0 < 400
 
 
 def test_amg_pcg_solves_the_normal_equations(opt_amg):
