@@ -1181,7 +1181,7 @@ bool sa_symbolic(const HostLevel& H, const std::vector<int>& agg, int nc, long l
     rpp[a + 1] += rpp[a];
   }
   lap("RAP count");
-  if (app[n] + rpp[nc] > budget || C.rowptr[nc] > std::max(H.nslot / 2, 4096)) return false;
+  if (app[n] + rpp[nc] > budget || C.rowptr[nc] > std::max(H.nslot, 4096)) return false;
   C.nslot = C.rowptr[nc];
   const int nprod_rap = (int)rpp[nc];
   C.row.resize(C.nslot);
@@ -1717,7 +1717,7 @@ Amg* amg_create(hipStream_t s, const BsrDev& A0, const double* d_poses, const in
     bool smooth = m->cfg.smooth;
     if (smooth) {
       // product lists of at most 16 per fine slot (C4 needs 9-11, chain-like graphs 4-6) and a coarse
-      // operator of at most half the fine one's blocks; beyond that the smoothed coarse operator is
+      // operator with no more blocks than the fine one (C4 0.06x, chains 0.5x); beyond that the smoothed coarse operator is
       // nearly dense (5 % random long-range closures on C4: 33 products per slot, 4.4x the blocks,
       // 2x slower than the tentative hierarchy): this level keeps the tentative prolongator
       const long long budget = std::min<long long>(1500000000LL, std::max<long long>(16LL * H.nslot, 2000000LL));
