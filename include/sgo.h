@@ -51,8 +51,9 @@ extern "C" {
 
 /* linear solver behind BlockSolver::solve (replaces LinearSolverEigen, graphs.cpp:19) */
 #define SGO_SOLVER_PCG_BJ 0      /* block-Jacobi preconditioned CG */
-#define SGO_SOLVER_PCG_AMG 1     /* (flexible) CG preconditioned by a rigid-body aggregation multigrid
-                                    K-cycle with block-Jacobi smoothing */
+#define SGO_SOLVER_PCG_AMG 1     /* CG preconditioned by a rigid-body smoothed-aggregation multigrid V-cycle
+                                    with block-Jacobi smoothing (K-cycle on levels that keep the
+                                    tentative prolongator) */
 
 typedef struct sgo_ctx sgo_ctx;
 
