@@ -32,13 +32,16 @@ struct AmgProf {
   void (*end)(void* user) = nullptr;
 };
 
+struct ChunkArena;
 struct Amg;  // opaque
 
 // Build the hierarchy for the level-0 matrix A0, whose values (blk, dinv) must hold the
 // linearisation at the initial poses (they provide the strength of connection).  `pos_src` /
 // `free_id` give the positions of the level-0 nodes: pos of row h = poses[3*free_id[h] + 0..1].
+// `scratch` (optional) provides host memory for the set-up's large temporary lists; it is rewound here
+// and may be rewound again by the caller once amg_create has returned.
 Amg* amg_create(hipStream_t s, const BsrDev& A0, const double* d_poses, const int* d_free_id,
-                const AmgConfig& cfg, const AmgProf& prof, std::string* err);
+                const AmgConfig& cfg, const AmgProf& prof, std::string* err, ChunkArena* scratch = nullptr);
 void amg_destroy(Amg* m);
 // Recompute the coarse operators for the current level-0 values and poses (once per GN iteration).
 int amg_update(Amg* m, hipStream_t s, std::string* err);

@@ -944,18 +944,25 @@ int aggregate(const HostLevel& L, const std::vector<double>& w, double theta, st
 // per row -- a counting sort over the row's few distinct columns -- so the rows run in parallel).
 // int array without value-initialisation (the product lists are 10^7 entries and fully overwritten)
 struct UVec {
-  std::unique_ptr<int[]> p;
+  std::unique_ptr<int[]> own;
+  int* p = nullptr;
   size_t n = 0;
+  ChunkArena* arena = nullptr;   // when set, the memory is the arena's (kept for the next set-up)
   void resize(size_t count) {
-    p.reset(new int[std::max<size_t>(count, 1)]);
+    if (arena) {
+      p = (int*)arena->take(std::max<size_t>(count, 1) * sizeof(int));
+    } else {
+      own.reset(new int[std::max<size_t>(count, 1)]);
+      p = own.get();
+    }
     n = count;
   }
-  int* data() { return p.get(); }
+  int* data() { return p; }
   size_t size() const { return n; }
 };
 int* dev_upload(std::vector<void*>& pool, const UVec& v, hipStream_t s) {
   int* d = dev_alloc<int>(pool, v.n);
-  if (d && v.n) hipMemcpyAsync(d, v.p.get(), v.n * sizeof(int), hipMemcpyHostToDevice, s);
+  if (d && v.n) hipMemcpyAsync(d, v.p, v.n * sizeof(int), hipMemcpyHostToDevice, s);
   return d;
 }
 struct SaHost {
@@ -1556,7 +1563,7 @@ int amg_apply(Amg* m, hipStream_t s, const double* r, double* z, const double* d
 }
 
 Amg* amg_create(hipStream_t s, const BsrDev& A0, const double* d_poses, const int* d_free_id, const AmgConfig& cfg_in,
-                const AmgProf& prof, std::string* err) {
+                const AmgProf& prof, std::string* err, ChunkArena* scratch) {
   Amg* m = new Amg();
   m->cfg = cfg_in;
   if (const char* e = std::getenv("SGO_AMG_THETA")) m->cfg.theta = std::atof(e);
@@ -1714,6 +1721,11 @@ Amg* amg_create(hipStream_t s, const BsrDev& A0, const double* d_poses, const in
     HostLevel Hc;
     std::vector<int> order, tgt, cptr, grp_g;
     SaHost sa;
+    if (scratch) {   // everything of the previous level has been uploaded (stream synchronised below)
+      scratch->rewind();
+      sa.ap_a.arena = sa.ap_b.arena = sa.ap_tgt.arena = scratch;
+      sa.rap_a.arena = sa.rap_b.arena = sa.rap_tgt.arena = scratch;
+    }
     bool smooth = m->cfg.smooth;
     if (smooth) {
       // product lists of at most 16 per fine slot (C4 needs 9-11, chain-like graphs 4-6) and a coarse
@@ -1790,6 +1802,7 @@ Amg* amg_create(hipStream_t s, const BsrDev& A0, const double* d_poses, const in
                    l, ms_since(tA), t_agg, t_sort, n, nc);
 
     // upload transfer data of level l and the structure of level l+1
+    const auto tU = std::chrono::steady_clock::now();
     L.nc = nc;
     L.agg = dev_upload(m->pool, agg, s);
     L.mem_ptr = dev_upload(m->pool, mem_ptr, s);
@@ -1860,6 +1873,7 @@ Amg* amg_create(hipStream_t s, const BsrDev& A0, const double* d_poses, const in
         !C.A.grp || !C.A.rowptr || !C.A.blk || !C.A.dinv)
       return fail("amg_create: out of device memory");
     if (hipStreamSynchronize(s) != hipSuccess) return fail("amg_create: upload failed");  // host vectors die below
+    const double t_up = ms_since(tU);
     m->lv.push_back(C);  // invalidates L
     // values of level l+1 (needed for the next level's strengths): positions, centres, Galerkin
     {
@@ -1873,6 +1887,8 @@ Amg* amg_create(hipStream_t s, const BsrDev& A0, const double* d_poses, const in
       launch_coarse_operator(m, s, Lr, Cr);
       if (l + 1 < m->cfg.max_levels) SGO_LAUNCH(k_level_dinv, dim3(grid_for(Cr.A.n, kBlock)), dim3(kBlock), 0, s, Cr.A);
       if (hipStreamSynchronize(s) != hipSuccess) return fail("amg_create: Galerkin kernel failed");
+      if (std::getenv("SGO_VERBOSE") && n > 20000)
+        std::fprintf(stderr, "[sgo] amg level %d: alloc + upload %.1f ms, first values %.1f ms\n", l, t_up, ms_since(tU) - t_up);
     }
     H = std::move(Hc);
   }

@@ -83,6 +83,7 @@ struct HostArena {
 struct sgo_ctx {
   int device = 0;
   HostArena stage;
+  ChunkArena amg_scratch;   // host lists of the multigrid set-up, reused across set-ups
   hipStream_t stream = nullptr;
   sgo_opts opts{};
   std::string err;
@@ -688,7 +689,7 @@ int build_amg(sgo_ctx* c) {
     cc->amg_scope = nullptr;
   };
   std::string aerr;
-  c->amg = amg_create(c->stream, c->A, c->d_poses, c->d_free_id, cfg, prof, &aerr);
+  c->amg = amg_create(c->stream, c->A, c->d_poses, c->d_free_id, cfg, prof, &aerr, &c->amg_scratch);
   if (c->amg) {
     amg_describe(c->amg, &c->solver_desc);
     c->solver_desc = "pcg_amg: " + c->solver_desc;

@@ -178,6 +178,43 @@ inline int grid_for(long long work_items, int per_block) {
   return (int)g;
 }
 
+// Host scratch that survives between set-ups: blocks are kept and handed out again after rewind(),
+// so the 10^8-byte product lists of the multigrid set-up are not re-mapped, page-faulted and
+// unmapped on every sgo_set_graph_se2 (uninitialised memory, 64-byte aligned, single-threaded use).
+struct ChunkArena {
+  struct Block {
+    char* raw = nullptr;   // as allocated
+    char* base = nullptr;  // 64-byte aligned start
+    size_t cap = 0, used = 0;
+  };
+  std::vector<Block> blocks;
+  ChunkArena() = default;
+  ChunkArena(const ChunkArena&) = delete;
+  ChunkArena& operator=(const ChunkArena&) = delete;
+  ~ChunkArena() {
+    for (Block& b : blocks) delete[] b.raw;
+  }
+  void rewind() {
+    for (Block& b : blocks) b.used = 0;
+  }
+  void* take(size_t bytes) {
+    bytes = (bytes + 63) & ~(size_t)63;
+    for (Block& b : blocks)
+      if (b.cap - b.used >= bytes) {
+        void* q = b.base + b.used;
+        b.used += bytes;
+        return q;
+      }
+    Block nb;
+    nb.cap = std::max<size_t>(bytes, (size_t)64 << 20);
+    nb.raw = new char[nb.cap + 64];
+    nb.base = (char*)(((uintptr_t)nb.raw + 63) & ~(uintptr_t)63);
+    nb.used = bytes;
+    blocks.push_back(nb);
+    return nb.base;
+  }
+};
+
 // Static-partition parallel loop over [0, n) on up to 8 host threads (structure builds only).
 template <class F>
 inline void host_parallel_for(int n, int grain, F&& fn) {
