@@ -1,4 +1,4 @@
-// sgo_amg.h -- rigid-body aggregation multigrid preconditioner (K-cycle) for the block-CSR
+// sgo_amg.h -- rigid-body smoothed-aggregation multigrid preconditioner for the block-CSR
 // Gauss-Newton Hessian.  See sgo_amg.hip for the algorithm and DESIGN.md section 5.
 #pragma once
 #include <hip/hip_runtime.h>

@@ -1,4 +1,4 @@
-// sgo_amg.hip -- rigid-body aggregation multigrid preconditioner for the GN Hessian.
+// sgo_amg.hip -- rigid-body smoothed-aggregation multigrid preconditioner for the GN Hessian.
 //
 // Why it exists: the block-Jacobi PCG that BASELINE.json's north_star names needs 8 000+
 // iterations per GN iteration on the 10k-pose graph and does not reach 1e-8 in 20 000 on the
@@ -9,18 +9,20 @@
 //   * nodes are aggregated by strength of connection (greedy root-node aggregation on
 //     Frobenius norms of the 3x3 blocks, threshold theta) -- structure built on the host once
 //     per sgo_set_graph_se2 (like g2o's symbolic analysis, once per optimize());
-//   * the prolongator is the tentative rigid-body one: an aggregate moves as a rigid body
+//   * the tentative prolongator T is the rigid-body one: an aggregate moves as a rigid body
 //     (u_x, u_y, w) about its centre c, so node i at p_i gets T(p_i - c) u with
 //     T(d) = [[1,0,-d_y],[0,1,d_x],[0,0,1]] -- the three rigid motions of SE(2) are represented
 //     exactly on every level (they are the null space of every edge's Jacobian pair);
+//   * the prolongator used is T smoothed by one damped block-Jacobi step, P = (I - w D^-1 H) T
+//     (smoothed aggregation); a level whose smoothed coarse operator would be too dense keeps T;
 //   * coarse operators are Galerkin products P^T H P, recomputed on the device every GN
-//     iteration (values change, structure does not): one lane per fine slot in coarse-slot
-//     order, wavefront segmented scan per coarse slot -- no atomics, bitwise reproducible;
-//   * cycle: K-cycle (two flexible-CG steps per intermediate level, Notay's AGMG scheme) with
-//     one damped block-Jacobi sweep before and after; the coarsest level (<= 400 nodes) is
-//     solved with an explicit dense inverse recomputed every GN iteration (blocked Gauss-Jordan);
-//     on the coarse levels the prolongation and the FCG vector updates are fused into the
-//     SpMV-type launches (k_spmv<4..6>) because a launch there costs more than its data.
+//     iteration (values change, structure does not) from product lists the host made at set-up:
+//     one lane per block product in target order, wavefront segmented scan per target block --
+//     no atomics, bitwise reproducible;
+//   * cycle: V-cycle with one damped block-Jacobi sweep before and after (levels that keep T: K-cycle,
+//     two flexible-CG steps per level, Notay's AGMG scheme, with the prolongation and the FCG vector
+//     updates fused into the SpMV-type launches k_spmv<4..6>); the coarsest level (<= 400 nodes) is
+//     solved with an explicit dense inverse recomputed every GN iteration (blocked Gauss-Jordan).
 // All launches go to the caller's stream with fixed pointers, so a whole PCG iteration
 // including the cycle is captured into one hipGraph.
 #include <algorithm>
