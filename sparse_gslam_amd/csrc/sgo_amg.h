@@ -19,6 +19,9 @@ struct AmgConfig {
                             // chain-dominated graphs -- measured a wash, kept off
   double double_ratio = 4.0;   // ... when n / nc < double_ratio (env SGO_AMG_DOUBLE_RATIO)
   int double_from_level = 0;   // ... on levels >= this (env SGO_AMG_DOUBLE_FROM)
+  int nu0 = 1;                 // damped block-Jacobi sweeps before and after on level 0 (env SGO_AMG_NU0)
+  int nu_coarse = 1;           // ... on the coarser V-cycle levels (env SGO_AMG_NU_COARSE); amg_create picks 2 for
+                               // graphs with >= 10^6 level-0 blocks, where a coarse sweep is cheap next to level 0
   bool smooth = true;          // smoothed aggregation: P = (I - omega_p D^-1 A) T (env SGO_AMG_SMOOTH=0: tentative P)
   double omega_p = 0.66;       // damping of the prolongator smoothing step (env SGO_AMG_OMEGA_P)
   int coarsest_nodes = 400;  // stop coarsening at or below this many nodes; that level is inverted densely

@@ -1268,7 +1268,7 @@ struct AmgLevel {
   PDev P;
   // work vectors [n][3]
   double *xs = nullptr, *rs = nullptr;                     // smoother state of cycle()
-  double *tX = nullptr, *tR = nullptr;                     // second pre-smoothing sweep (level 0, nu0 = 2)
+  double* tR = nullptr;                                    // second residual buffer of multi-sweep smoothing
   double *bk = nullptr, *xk = nullptr, *z1 = nullptr, *z2 = nullptr, *q = nullptr;  // K-cycle FCG (levels >= 1)
   double *bk2 = nullptr, *p2 = nullptr, *q2 = nullptr;     // residual after the first FCG step; second direction; A p2
   double *pA = nullptr, *pB = nullptr, *pC = nullptr;      // [2][kMaxPartials] each
@@ -1417,24 +1417,26 @@ int cycle(Amg* m, hipStream_t s, int l, const double* rhs, const double* rhs_sub
       launch_spmv_ex(s, L.A, SPMV_PRE_RESID, a);
     }
   }
-  // SGO_AMG_NU0=2: two damped-Jacobi sweeps before and after on level 0 (opt-in; measured on C4:
-  // 46 instead of 51.5 PCG iterations but 18.9 instead of 17.0 ms per GN iteration)
-  static const int nu0 = std::getenv("SGO_AMG_NU0") ? std::atoi(std::getenv("SGO_AMG_NU0")) : 1;
-  const bool two = (l == 0 && nu0 >= 2 && L.tX && L.tR);
-  if (two) {  // second pre-smoothing sweep: tX = omega Dinv rs, tR = rs - A tX
+  // further pre-smoothing sweeps (levels walked by the V-cycle only): sweep s applied to the residual
+  // of sweep s-1 gives the next correction (accumulated into xs) and the next residual (rs <-> tR)
+  const int nu = (L.tR && (L.smoothed || l == 0)) ? std::max(1, l == 0 ? m->cfg.nu0 : m->cfg.nu_coarse) : 1;
+  double* res = L.rs;
+  for (int sw = 1; sw < nu; ++sw) {
+    double* nxt = (res == L.rs) ? L.tR : L.rs;
     SpmvArgs a{};
-    a.b = L.rs; a.y = L.tR; a.y2 = L.tX; a.omega = m->cfg.omega; a.S = S;
-    Scope sc(m->prof, K_SPMV_PRE_RESID, 80.0 * L.A.nslot + 120.0 * L.A.n);
-    launch_spmv_ex(s, L.A, SPMV_PRE_RESID, a);
+    a.b = res; a.y = nxt; a.y2 = L.xs; a.omega = m->cfg.omega; a.S = S;
+    Scope sc(m->prof, K_SPMV_PRE_RESID_ACC, 80.0 * L.A.nslot + 144.0 * L.A.n);
+    launch_spmv_ex(s, L.A, SPMV_PRE_RESID_ACC, a);
+    res = nxt;
   }
   if (L.smoothed) {
     Scope sc(m->prof, K_RESTRICT_P, 84.0 * L.P.np + 24.0 * L.A.n + 24.0 * L.nc);
     SGO_LAUNCH(k_restrict_p, dim3(grid_for(L.P.t_ngrp, kWavesPerBlock)), dim3(kBlock), 0, s, L.P,
-               (const double*)(two ? L.tR : L.rs), C.bk, S);
+               (const double*)res, C.bk, S);
   } else {
     Scope sc(m->prof, K_RESTRICT, 40.0 * L.A.n + 24.0 * L.nc);
     SGO_LAUNCH(k_restrict, dim3(grid_for(L.mem_ngrp, kWavesPerBlock)), dim3(kBlock), 0, s, L.mem_ngrp, L.mem_grp,
-                       L.mem, L.agg, L.d, two ? L.tR : L.rs, C.bk, S);
+                       L.mem, L.agg, L.d, res, C.bk, S);
   }
   CoarseSol cs;
   if (l + 1 == last) {
@@ -1466,20 +1468,22 @@ int cycle(Amg* m, hipStream_t s, int l, const double* rhs, const double* rhs_sub
     if (L.smoothed) {
       Scope sc(m->prof, K_PROLONG_P, 80.0 * L.P.np + 52.0 * L.A.n);
       SGO_LAUNCH(k_prolong_p, dim3(grid_for(L.P.r_ngrp, kWavesPerBlock)), dim3(kBlock), 0, s, L.A.n, L.P, cs.u1, cs.c1, cs.u2, cs.c2,
-                 L.xs, S, two ? (const double*)L.tX : nullptr);
+                 L.xs, S, (const double*)nullptr);
     } else {
       Scope sc(m->prof, K_PROLONG, 68.0 * L.A.n);
       SGO_LAUNCH(k_prolong_add, dim3(grid_for(L.A.n, kBlock)), dim3(kBlock), 0, s, L.A.n, L.agg, L.d, cs.u1, cs.c1,
-                         cs.u2, cs.c2, L.xs, S, two ? (const double*)L.tX : nullptr);
+                         cs.u2, cs.c2, L.xs, S, (const double*)nullptr);
     }
-    if (two) {  // second post-smoothing sweep, the mirror image of the second pre-sweep (rs is free here)
+    // post-smoothing: nu sweeps, the first nu - 1 through the two residual buffers (free by now)
+    for (int sw = 1; sw < nu; ++sw) {
+      double* dst = (a.x == L.rs) ? L.tR : L.rs;
       SpmvArgs b = a;
-      b.y = L.rs; b.dotA = nullptr; b.dotA2 = nullptr; b.partials = nullptr;
+      b.y = dst; b.dotA = nullptr; b.dotA2 = nullptr; b.partials = nullptr;
       {
         Scope sc(m->prof, K_SPMV_JACOBI, (L.A.blkf ? 44.0 : 80.0) * L.A.nslot + 120.0 * L.A.n);
         launch_spmv_ex(s, L.A, SPMV_JACOBI, b);
       }
-      a.x = L.rs;
+      a.x = dst;
     }
     Scope sc(m->prof, K_SPMV_JACOBI, (L.A.blkf ? 44.0 : 80.0) * L.A.nslot + 120.0 * L.A.n);
     return launch_spmv_ex(s, L.A, SPMV_JACOBI, a);
@@ -1571,6 +1575,12 @@ Amg* amg_create(hipStream_t s, const BsrDev& A0, const double* d_poses, const in
   if (const char* e = std::getenv("SGO_AMG_THETA")) m->cfg.theta = std::atof(e);
   if (const char* e = std::getenv("SGO_AMG_OMEGA")) m->cfg.omega = std::atof(e);
   if (const char* e = std::getenv("SGO_AMG_THETA_COARSE")) m->cfg.theta_coarse = std::atof(e);
+  if (const char* e = std::getenv("SGO_AMG_NU0")) m->cfg.nu0 = std::atoi(e);
+  // A sweep on a coarse level is a 5-10 us launch whatever the graph; it pays when a PCG iteration is
+  // dominated by level 0 (C4: 31 instead of 39 iterations, 9.7 instead of 10.6 ms) and costs a few
+  // per cent on graphs whose level 0 is itself launch-bound (10k / 40k: 2.67 instead of 2.51 ms).
+  m->cfg.nu_coarse = A0.nslot >= 1000000 ? 2 : 1;
+  if (const char* e = std::getenv("SGO_AMG_NU_COARSE")) m->cfg.nu_coarse = std::atoi(e);
   if (const char* e = std::getenv("SGO_AMG_SMOOTH")) m->cfg.smooth = std::atoi(e) != 0;
   if (const char* e = std::getenv("SGO_AMG_OMEGA_P")) m->cfg.omega_p = std::atof(e);
   // With the smoothed prolongator a V-cycle needs ~1.4x the PCG iterations of the K-cycle (C4: 39 vs
@@ -1618,10 +1628,7 @@ Amg* amg_create(hipStream_t s, const BsrDev& A0, const double* d_poses, const in
     m->desc += line;
     L.xs = dev_alloc<double>(m->pool, n3);
     L.rs = dev_alloc<double>(m->pool, n3);
-    if (l == 0) {
-      L.tX = dev_alloc<double>(m->pool, n3);
-      L.tR = dev_alloc<double>(m->pool, n3);
-    }
+    L.tR = dev_alloc<double>(m->pool, n3);
     if (!L.pos) L.pos = dev_alloc<double>(m->pool, 2 * (size_t)n);
     if (l > 0) {
       L.bk = dev_alloc<double>(m->pool, n3);

@@ -90,7 +90,8 @@ struct PcgScalars {
 // k_spmv modes and arguments (see sgo_kernels.hip)
 enum : int {
   SPMV_AX = 0, SPMV_RESID = 1, SPMV_JACOBI = 2, SPMV_PRE_RESID = 3,
-  SPMV_JACOBI_P = 4, SPMV_PRE_RESID_S = 5, SPMV_AX_C = 6
+  SPMV_JACOBI_P = 4, SPMV_PRE_RESID_S = 5, SPMV_AX_C = 6,
+  SPMV_PRE_RESID_ACC = 7   // PRE_RESID whose correction is ADDED to y2 (second and later pre-smoothing sweeps)
 };
 // scalar = sum(num[0..n_num)) / sum(den[0..n_den)); num == den == nullptr means 1
 struct SpmvRatio {
@@ -160,6 +161,7 @@ enum KernelId : int {
   K_SA_RAP,
   K_RESTRICT_P,
   K_PROLONG_P,
+  K_SPMV_PRE_RESID_ACC,
   K_COUNT
 };
 extern const char* const kKernelNames[K_COUNT];

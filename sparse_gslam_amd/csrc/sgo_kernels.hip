@@ -31,7 +31,7 @@ const char* const kKernelNames[K_COUNT] = {
     "k_spmv<2, double>", "k_spmv<3, double>", "k_spmv<4, double>", "k_spmv<5, double>", "k_spmv<6, double>",      "k_alpha",       "k_update_xr",  "k_beta",         "k_update_p", "k_dot",
     "k_pose_update", "k_positions0", "k_centres",   "k_galerkin",   "k_level_dinv",   "k_restrict", "k_prolong_add",
     "k_gj_panels+k_gj_trail (dense inverse)", "k_dense_apply", "k_coarse_tree", "k_p_values", "k_block_products<1, 0, 0>",
-    "k_block_products<0, 1, 1>", "k_restrict_p", "k_prolong_p"};
+    "k_block_products<0, 1, 1>", "k_restrict_p", "k_prolong_p", "k_spmv<7, double>"};
 
 namespace {
 
@@ -308,6 +308,7 @@ __global__ __launch_bounds__(kBlock) void k_init_scalars(PcgScalars* S, const do
 //   SPMV_JACOBI_P     as JACOBI with x' = x + P (c1 u1 + c2 u2)   (prolongation of the coarse
 //                     correction, itself the FCG combination of the child level, fused in)
 //   SPMV_PRE_RESID_S  as PRE_RESID with b' = b - c1 bsub ; b_out = b'   (FCG residual update fused in)
+//   SPMV_PRE_RESID_ACC as PRE_RESID with y2 += omega Dinv b         (pre-smoothing sweeps after the first)
 //   SPMV_AX_C         as AX with x' = x - c1 x2 ; x_out = x'       (FCG direction update fused in);
 //                     dots: partials[0] = x'.y, partials[1] = x'.dotC
 // Optional dot partials (row epilogue): partials[0] += dotA[row].out[row],
@@ -343,7 +344,7 @@ void k_spmv(BsrDev A, SpmvArgs a) {
   }
   // operand of vertex v (3 doubles) under the mode's transformation
   auto operand = [&](size_t v, double& x0, double& x1, double& x2) {
-    if (MODE == SPMV_PRE_RESID || MODE == SPMV_PRE_RESID_S) {
+    if (MODE == SPMV_PRE_RESID || MODE == SPMV_PRE_RESID_S || MODE == SPMV_PRE_RESID_ACC) {
       const double* di = A.dinv + 6 * v;
       double b0 = a.b[3 * v], b1 = a.b[3 * v + 1], b2 = a.b[3 * v + 2];
       if (MODE == SPMV_PRE_RESID_S) {
@@ -422,11 +423,15 @@ void k_spmv(BsrDev A, SpmvArgs a) {
         } else {
           o0 = r0; o1 = r1; o2 = r2;
         }
-        if (MODE == SPMV_PRE_RESID || MODE == SPMV_PRE_RESID_S) {
+        if (MODE == SPMV_PRE_RESID || MODE == SPMV_PRE_RESID_S || MODE == SPMV_PRE_RESID_ACC) {
           const double* di = A.dinv + 6 * (size_t)row;
-          a.y2[o] = a.omega * (di[0] * b0 + di[1] * b1 + di[2] * b2);
-          a.y2[o + 1] = a.omega * (di[1] * b0 + di[3] * b1 + di[4] * b2);
-          a.y2[o + 2] = a.omega * (di[2] * b0 + di[4] * b1 + di[5] * b2);
+          double v0 = a.omega * (di[0] * b0 + di[1] * b1 + di[2] * b2);
+          double v1 = a.omega * (di[1] * b0 + di[3] * b1 + di[4] * b2);
+          double v2 = a.omega * (di[2] * b0 + di[4] * b1 + di[5] * b2);
+          if (MODE == SPMV_PRE_RESID_ACC) {
+            v0 += a.y2[o]; v1 += a.y2[o + 1]; v2 += a.y2[o + 2];
+          }
+          a.y2[o] = v0; a.y2[o + 1] = v1; a.y2[o + 2] = v2;
         }
       }
       a.y[o] = o0; a.y[o + 1] = o1; a.y[o + 2] = o2;
@@ -592,6 +597,7 @@ int launch_spmv_ex(hipStream_t s, const BsrDev& A, int mode, const SpmvArgs& a) 
       break;
     case SPMV_JACOBI_P: SGO_LAUNCH((k_spmv<SPMV_JACOBI_P, double>), dim3(grid), dim3(kBlock), 0, s, A, a); break;
     case SPMV_PRE_RESID_S: SGO_LAUNCH((k_spmv<SPMV_PRE_RESID_S, double>), dim3(grid), dim3(kBlock), 0, s, A, a); break;
+    case SPMV_PRE_RESID_ACC: SGO_LAUNCH((k_spmv<SPMV_PRE_RESID_ACC, double>), dim3(grid), dim3(kBlock), 0, s, A, a); break;
     case SPMV_AX_C: SGO_LAUNCH((k_spmv<SPMV_AX_C, double>), dim3(grid), dim3(kBlock), 0, s, A, a); break;
     default:
       if (f32) SGO_LAUNCH((k_spmv<SPMV_PRE_RESID, float>), dim3(grid), dim3(kBlock), 0, s, A, a);
