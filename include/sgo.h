@@ -174,6 +174,9 @@ int sgo_precondition(sgo_ctx* ctx, const double* r, double* z);
 /* Per-kernel totals accumulated since the last sgo_profile_reset: for kernel slot k,
  * name (static string), launches, total milliseconds (HIP events on the ctx stream), and the
  * algorithmic bytes those launches were specified to move.
+ * Slots are named as rocprofv3 prints the kernel; the launches of the three block-stream kernels on the
+ * finest multigrid level are kept in slots of their own, named "<kernel> @level0" (the same kernels'
+ * coarse-level launches sit on the launch-latency floor and would blur the bandwidth figure).
  * Returns the number of slots; fills up to cap entries. */
 typedef struct sgo_kernel_stat {
   const char* name;

@@ -1413,7 +1413,7 @@ int cycle(Amg* m, hipStream_t s, int l, const double* rhs, const double* rhs_sub
       Scope sc(m->prof, K_SPMV_PRE_RESID_S, 80.0 * L.A.nslot + 168.0 * L.A.n);
       launch_spmv_ex(s, L.A, SPMV_PRE_RESID_S, a);
     } else {
-      Scope sc(m->prof, K_SPMV_PRE_RESID, (L.A.blkf ? 44.0 : 80.0) * L.A.nslot + 120.0 * L.A.n);
+      Scope sc(m->prof, l == 0 ? K_SPMV_PRE_RESID_L0 : K_SPMV_PRE_RESID, (L.A.blkf ? 44.0 : 80.0) * L.A.nslot + 120.0 * L.A.n);
       launch_spmv_ex(s, L.A, SPMV_PRE_RESID, a);
     }
   }
@@ -1480,12 +1480,12 @@ int cycle(Amg* m, hipStream_t s, int l, const double* rhs, const double* rhs_sub
       SpmvArgs b = a;
       b.y = dst; b.dotA = nullptr; b.dotA2 = nullptr; b.partials = nullptr;
       {
-        Scope sc(m->prof, K_SPMV_JACOBI, (L.A.blkf ? 44.0 : 80.0) * L.A.nslot + 120.0 * L.A.n);
+        Scope sc(m->prof, l == 0 ? K_SPMV_JACOBI_L0 : K_SPMV_JACOBI, (L.A.blkf ? 44.0 : 80.0) * L.A.nslot + 120.0 * L.A.n);
         launch_spmv_ex(s, L.A, SPMV_JACOBI, b);
       }
       a.x = dst;
     }
-    Scope sc(m->prof, K_SPMV_JACOBI, (L.A.blkf ? 44.0 : 80.0) * L.A.nslot + 120.0 * L.A.n);
+    Scope sc(m->prof, l == 0 ? K_SPMV_JACOBI_L0 : K_SPMV_JACOBI, (L.A.blkf ? 44.0 : 80.0) * L.A.nslot + 120.0 * L.A.n);
     return launch_spmv_ex(s, L.A, SPMV_JACOBI, a);
   }
   a.agg = L.agg; a.d = L.d; a.u1 = cs.u1; a.u2 = cs.u2; a.c1 = cs.c1; a.c2 = cs.c2;

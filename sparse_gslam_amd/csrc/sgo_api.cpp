@@ -559,7 +559,7 @@ int do_linearize(sgo_ctx* c) {
 // y = H x  (+ optional x.y partials).  The solve is replicated on every rank (identical H after
 // the all-reduce in do_linearize), so no collective is needed here.
 int do_spmv(sgo_ctx* c, const double* x, double* y, bool dot, const PcgScalars* S, int* grid_out) {
-  Scope sc(c, K_SPMV_AX, bytes_spmv(c->A));
+  Scope sc(c, K_SPMV_AX_L0, bytes_spmv(c->A));
   launch_spmv(c->stream, c->A, x, y, dot ? c->d_partials : nullptr, S, grid_out);
   return SGO_OK;
 }

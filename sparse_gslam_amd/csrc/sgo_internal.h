@@ -162,6 +162,9 @@ enum KernelId : int {
   K_RESTRICT_P,
   K_PROLONG_P,
   K_SPMV_PRE_RESID_ACC,
+  K_SPMV_AX_L0,         // the level-0 launches of the three block-stream kernels, kept apart from
+  K_SPMV_JACOBI_L0,     // the same kernels' launches on coarse levels (names end in " @level0")
+  K_SPMV_PRE_RESID_L0,
   K_COUNT
 };
 extern const char* const kKernelNames[K_COUNT];

@@ -31,7 +31,8 @@ const char* const kKernelNames[K_COUNT] = {
     "k_spmv<2, double>", "k_spmv<3, double>", "k_spmv<4, double>", "k_spmv<5, double>", "k_spmv<6, double>",      "k_alpha",       "k_update_xr",  "k_beta",         "k_update_p", "k_dot",
     "k_pose_update", "k_positions0", "k_centres",   "k_galerkin",   "k_level_dinv",   "k_restrict", "k_prolong_add",
     "k_gj_panels+k_gj_trail (dense inverse)", "k_dense_apply", "k_coarse_tree", "k_p_values", "k_block_products<1, 0, 0>",
-    "k_block_products<0, 1, 1>", "k_restrict_p", "k_prolong_p", "k_spmv<7, double>"};
+    "k_block_products<0, 1, 1>", "k_restrict_p", "k_prolong_p", "k_spmv<7, double>",
+    "k_spmv<0, double> @level0", "k_spmv<2, double> @level0", "k_spmv<3, double> @level0"};
 
 namespace {
 
