@@ -6,6 +6,10 @@ set -u
 tag=${1:-r01}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp; export TMPDIR=/tmp
+# Plain stream launches (no hipGraph) for the profiled passes, as in bench.py's own roofline leg: graph
+# replay keeps up to two 4-iteration chunks in flight past convergence, whose early-exit launches
+# (0.6 us each) would pull the per-kernel averages of the summary 10-20 % below the working launches'.
+export SGO_USE_GRAPH=0
 O=$R/gpurun_out
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_amg_c4 -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > $O/prof_amg_c4.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
@@ -16,6 +20,7 @@ cp $(find $O/prof_amg_c4 -name "*kernel_stats.csv" | head -1) $O/${tag}_amg_c4_k
 # per-dispatch traces are large: keep only the summaries
 find $O -name "*kernel_trace.csv" -delete; find $O -name "*counter_collection.csv" -delete
 # bench lines (the roofline leg reads the PMC summary: make it visible under profiles/ first)
+unset SGO_USE_GRAPH
 cp $O/${tag}_pmc_traffic_amg_c4.json $R/profiles/${tag}_pmc_traffic_amg_c4.json
 cd $R
 python3 bench.py 2>/dev/null | tail -1 > $O/${tag}_bench_c4.json
