@@ -62,9 +62,9 @@ typedef struct sgo_opts {
   int32_t solver;          /* SGO_SOLVER_*; env SGO_SOLVER={pcg,amg} overrides the default */
   double pcg_tol;          /* stop when ||r|| <= pcg_tol * ||b||   (env SGO_PCG_TOL) */
   int32_t pcg_maxit;       /* cap on PCG iterations per GN iteration (env SGO_PCG_MAXIT) */
-  int32_t pcg_chunk;       /* graph mode: pcg_chunk / 4 iterations are kept in flight speculatively
-                              between checks of the device-side stop flag; plain mode: iterations
-                              launched between two host checks */
+  int32_t pcg_chunk;       /* graph mode: pcg_chunk / 16 replays of the 2-iteration hipGraph are kept in
+                              flight speculatively between checks of the device-side stop flag;
+                              plain mode: iterations launched between two host checks */
   int32_t use_graph;       /* 1: replay PCG iterations (incl. the multigrid cycle) from a hipGraph;
                               0: plain stream launches */
   int32_t profile;         /* 1: every launch carries its own start/stop HIP events
