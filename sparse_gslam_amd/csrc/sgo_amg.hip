@@ -159,7 +159,9 @@ struct PDev {
   int* rowptr = nullptr;     // [n + 1] entries of fine row i: [rowptr[i], rowptr[i+1]), coarse cols ascending
   int* row = nullptr;        // [np]
   int* col = nullptr;        // [np]
-  double* blk = nullptr;     // [np][9]: blocks are mostly GATHERED (products), so one 72-byte record each
+  double* blk = nullptr;     // [np][9]: the copy the block products GATHER from (one 72-byte record each)
+  double* r_blk = nullptr;   // [9][np]: the copy the prolongation STREAMS (row order, one array per component,
+                             // non-temporal loads: read once per cycle, must not push the level-0 matrix out of the MALL)
   int* r_grp = nullptr;      // wave groups over the entries aligned to fine rows (prolongation)
   int r_ngrp = 0;
   ProdMap val;               // a = fine slot k = (i, j), tgt = entry (i, agg(j))
@@ -168,7 +170,7 @@ struct PDev {
   int* t_pos = nullptr;      // [np] position of entry e in column order
   int* t_row = nullptr;      // [np] fine row at position t
   int* t_col = nullptr;      // [np] coarse column at position t
-  double* t_blk = nullptr;   // [np][9]
+  double* t_blk = nullptr;   // [9][np]: column order, streamed by the restriction (non-temporal loads)
   int* t_grp = nullptr;      // wave groups over the positions aligned to columns
   int t_ngrp = 0;
   int nap = 0;               // blocks of AP
@@ -222,11 +224,12 @@ __global__ __launch_bounds__(kBlock) void k_p_values(BsrDev F, PDev P, const int
         o[2] += -d[2 * i + 1];
         o[5] += d[2 * i];
       }
-      const size_t tp = (size_t)P.t_pos[key];
+      const size_t tp = (size_t)P.t_pos[key], np = (size_t)P.np;
 #pragma unroll
       for (int c = 0; c < 9; ++c) {
         P.blk[9 * (size_t)key + c] = o[c];
-        P.t_blk[9 * tp + c] = o[c];
+        P.r_blk[c * np + key] = o[c];
+        P.t_blk[c * np + tp] = o[c];
       }
     }
   }
@@ -281,6 +284,7 @@ __global__ __launch_bounds__(kBlock) void k_restrict_p(PDev P, const double* __r
                                                        const PcgScalars* S) {
   if (S && S->stop) return;
   const int lane = threadIdx.x & 63;
+  const size_t np = (size_t)P.np;
   int g, gend, gstride;
   group_walk(P.t_ngrp, &g, &gend, &gstride);
   for (; g < gend; g += gstride) {
@@ -292,7 +296,8 @@ __global__ __launch_bounds__(kBlock) void k_restrict_p(PDev P, const double* __r
       const size_t i = (size_t)P.t_row[t];
       const double r0 = r[3 * i], r1 = r[3 * i + 1], r2 = r[3 * i + 2];
       double b[9];
-      load9(P.t_blk, (size_t)t, b);
+#pragma unroll
+      for (int c = 0; c < 9; ++c) b[c] = __builtin_nontemporal_load(P.t_blk + c * np + t);
       acc[0] += b[0] * r0 + b[3] * r1 + b[6] * r2;
       acc[1] += b[1] * r0 + b[4] * r1 + b[7] * r2;
       acc[2] += b[2] * r0 + b[5] * r1 + b[8] * r2;
@@ -325,6 +330,7 @@ __global__ __launch_bounds__(kBlock) void k_prolong_p(int n, PDev P, const doubl
   }
   // one lane per entry (entries are sorted by fine row), wavefront segmented sum per row
   const int lane = threadIdx.x & 63;
+  const size_t np = (size_t)P.np;
   int g, gend, gstride;
   group_walk(P.r_ngrp, &g, &gend, &gstride);
   for (; g < gend; g += gstride) {
@@ -339,7 +345,8 @@ __global__ __launch_bounds__(kBlock) void k_prolong_p(int n, PDev P, const doubl
         w0 += c2 * u2[a]; w1 += c2 * u2[a + 1]; w2 += c2 * u2[a + 2];
       }
       double b[9];
-      load9(P.blk, (size_t)e, b);
+#pragma unroll
+      for (int c = 0; c < 9; ++c) b[c] = __builtin_nontemporal_load(P.r_blk + c * np + e);
       acc[0] += b[0] * w0 + b[1] * w1 + b[2] * w2;
       acc[1] += b[3] * w0 + b[4] * w1 + b[5] * w2;
       acc[2] += b[6] * w0 + b[7] * w1 + b[8] * w2;
@@ -1839,6 +1846,7 @@ Amg* amg_create(hipStream_t s, const BsrDev& A0, const double* d_poses, const in
       P.t_row = dev_upload(m->pool, sa.t_row, s);
       P.t_col = dev_upload(m->pool, sa.t_col, s);
       P.t_blk = dev_alloc<double>(m->pool, 9 * (size_t)P.np);
+      P.r_blk = dev_alloc<double>(m->pool, 9 * (size_t)P.np);
       P.t_grp = dev_upload(m->pool, sa.t_grp, s);
       P.t_ngrp = (int)sa.t_grp.size() - 1;
       P.nap = sa.nap;
@@ -1855,7 +1863,7 @@ Amg* amg_create(hipStream_t s, const BsrDev& A0, const double* d_poses, const in
       P.rap.tgt = dev_upload(m->pool, sa.rap_tgt, s);
       P.rap.grp = dev_upload(m->pool, sa.rap_grp, s);
       P.rap.ngrp = (int)sa.rap_grp.size() - 1;
-      if (!P.rowptr || !P.row || !P.col || !P.blk || !P.val.a || !P.val.tgt || !P.val.grp || !P.r_grp || !P.t_pos || !P.t_row || !P.t_col || !P.t_blk || !P.t_grp ||
+      if (!P.rowptr || !P.row || !P.col || !P.blk || !P.val.a || !P.val.tgt || !P.val.grp || !P.r_grp || !P.t_pos || !P.t_row || !P.t_col || !P.t_blk || !P.r_blk || !P.t_grp ||
           !P.apblk || !P.ap.a || !P.ap.b || !P.ap.tgt || !P.ap.grp || !P.rap.a || !P.rap.b || !P.rap.tgt || !P.rap.grp)
         return fail("amg_create: out of device memory");
       std::snprintf(line, sizeof line, "(P %d, AP %d blocks; %d + %d products) ", P.np, P.nap, P.ap.n, P.rap.n);
