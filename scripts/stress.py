@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Randomised soak test of the C-ABI on the GPU: graphs of random size / density / long-range share /
+information shape through one context (set_graph, optimize, read-back), compared with the CPU oracle
+when small.  Prints one line per case and a summary; exits non-zero on any disagreement."""
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
+from oracle import c_oracle  # noqa: E402
+from sparse_gslam_amd import capi, synth  # noqa: E402
+
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+bad = 0
+t0 = time.time()
+with capi.Optimizer(0) as opt:
+    for case in range(n_cases):
+        V = int(rng.choice([60, 300, 450, 1200, 3000, 8000, 20000]))
+        dens = float(rng.choice([1.0, 1.05, 1.5, 3.0, 6.0]))
+        E = max(V - 1, int(dens * V))
+        kw = dict(V=V, E=E, seed=int(rng.integers(1, 10**6)), p_random=float(rng.choice([0.0, 0.0, 0.05, 0.3])),
+                  info_mode=str(rng.choice(["diag", "full"])), phi=float(rng.choice([1.0, 10.0])),
+                  init=str(rng.choice(["incremental", "incremental", "odom"])) if V <= 1200 else "incremental")
+        g = synth.manhattan(**kw)
+        if rng.random() < 0.3:      # a few more fixed vertices / an isolated tail vertex
+            g.fixed[rng.integers(0, V, 3)] = True
+        iters = 6
+        opt.set_graph(*g.arrays())
+        done, st = opt.optimize(iters)
+        P = opt.get_poses()
+        line = f"{case:3d} V={V:6d} E={E:6d} {kw['info_mode']:4s} p_rand={kw['p_random']:.2f} init={kw['init']:11s} done={done} pcg={st['pcg_iters']}"
+        ok = np.isfinite(P).all() and done in (0, iters)
+        if V <= 3000:
+            oP, ost = c_oracle.gauss_newton(*g.arrays(), iters=iters)
+            if ost["iters_done"] == iters and done == iters:
+                rel = max(abs(a - b) / max(b, 1e-30) for a, b in zip(st["chi2"], ost["chi2"]))
+                line += f" rel={rel:.1e}"
+                ok = ok and rel < 1e-6
+            else:
+                line += f" oracle_done={ost['iters_done']}"
+                ok = ok and (done == ost["iters_done"] or done == 0)
+        print(line + ("" if ok else "   <-- MISMATCH"), flush=True)
+        bad += 0 if ok else 1
+print(f"{n_cases} cases, {bad} bad, {time.time() - t0:.0f} s")
+sys.exit(1 if bad else 0)
