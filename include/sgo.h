@@ -60,7 +60,9 @@ typedef struct sgo_ctx sgo_ctx;
 typedef struct sgo_opts {
   int32_t struct_size;     /* = sizeof(sgo_opts); lets the struct grow compatibly */
   int32_t solver;          /* SGO_SOLVER_*; env SGO_SOLVER={pcg,amg} overrides the default */
-  double pcg_tol;          /* stop when ||r|| <= pcg_tol * ||b||   (env SGO_PCG_TOL) */
+  double pcg_tol;          /* stop when ||r|| <= pcg_tol * ||b||   (env SGO_PCG_TOL); chain-like graphs
+                              (< 4 Hessian blocks per free pose, i.e. ill-conditioned and cheap to
+                              iterate on) use pcg_tol / 10 */
   int32_t pcg_maxit;       /* cap on PCG iterations per GN iteration (env SGO_PCG_MAXIT) */
   int32_t pcg_chunk;       /* graph mode: pcg_chunk / 16 replays of the 2-iteration hipGraph are kept in
                               flight speculatively between checks of the device-side stop flag;

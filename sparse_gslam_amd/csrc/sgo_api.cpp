@@ -118,6 +118,7 @@ struct sgo_ctx {
   hipGraphExec_t pcg_exec = nullptr;
   int pcg_exec_chunk = 0;
   int pcg_pred = 0;               // PCG iterations of the previous solve (prediction for the next)
+  double tol_scale = 1.0;         // < 1 on chain-like graphs (see sgo_set_graph_se2)
   int amg_best = 0;               // fewest PCG iterations seen with the current hierarchy (0: none yet);
                                   // kept across optimize() calls so that a hierarchy adapted to other poses is noticed
   PcgScalars* h_S2 = nullptr;     // pinned [2]: pipelined read-back of the stop flag
@@ -513,11 +514,11 @@ int start_pcg(sgo_ctx* c, int grid) {
     const int gz = amg_apply(c->amg, c->stream, c->d_r, c->d_z, c->d_r, c->d_zparts, nullptr);
     HIP_TRY(c, hipMemcpyAsync(c->d_p, c->d_z, sizeof(double) * 3 * (size_t)c->n, hipMemcpyDeviceToDevice, c->stream));
     Scope sc(c, K_INIT_SCALARS, 8.0 * (gz + grid));
-    launch_init_scalars(c->stream, c->d_S, c->d_zparts, gz, c->d_partials + kMaxPartials, grid, c->opts.pcg_tol,
+    launch_init_scalars(c->stream, c->d_S, c->d_zparts, gz, c->d_partials + kMaxPartials, grid, c->opts.pcg_tol * c->tol_scale,
                         c->opts.pcg_maxit);
   } else {
     Scope sc(c, K_INIT_SCALARS, 16.0 * grid);
-    launch_init_scalars(c->stream, c->d_S, c->d_partials, grid, c->d_partials + kMaxPartials, grid, c->opts.pcg_tol,
+    launch_init_scalars(c->stream, c->d_S, c->d_partials, grid, c->d_partials + kMaxPartials, grid, c->opts.pcg_tol * c->tol_scale,
                         c->opts.pcg_maxit);
   }
   return SGO_OK;
@@ -839,6 +840,12 @@ int sgo_set_graph_se2(sgo_ctx* c, int32_t V, const double* poses, const uint8_t*
     return rc;
   }
   c->has_graph = true;
+  // Chain-like graphs (fewer than ~1.5 edges per free pose: under 4 Hessian blocks per row) are the
+  // ill-conditioned ones -- kappa(H) grows with the square of the chain length -- and a relative
+  // residual of 1e-8 then leaves errors that show in chi2 (3000 poses / 3150 edges: iterates 3e-6 and
+  // poses 7e-5 m from the direct-solver oracle at 1e-8, 1.4e-8 at 1e-9).  Their PCG iterations are the
+  // cheap ones, so they get a 10x tighter tolerance than opts.pcg_tol.
+  c->tol_scale = (c->n > 0 && (long long)c->A.nslot < 4LL * c->n) ? 0.1 : 1.0;
   c->solver_desc = "pcg_block_jacobi";
   if (c->opts.solver == SGO_SOLVER_PCG_AMG && c->n > 0 && (c->comm.nranks == 1 || c->comm.handle)) {
     // the hierarchy is built from the Hessian at the initial poses (strength of connection)
