@@ -119,6 +119,7 @@ struct sgo_ctx {
   int pcg_exec_chunk = 0;
   int pcg_pred = 0;               // PCG iterations of the previous solve (prediction for the next)
   double tol_scale = 1.0;         // < 1 on chain-like graphs (see sgo_set_graph_se2)
+  int pcg_softcap = 0;            // > 0: iteration cap of the next solve (sgo_optimize_gn: stale-hierarchy bail-out)
   int amg_best = 0;               // fewest PCG iterations seen with the current hierarchy (0: none yet);
                                   // kept across optimize() calls so that a hierarchy adapted to other poses is noticed
   PcgScalars* h_S2 = nullptr;     // pinned [2]: pipelined read-back of the stop flag
@@ -515,11 +516,11 @@ int start_pcg(sgo_ctx* c, int grid) {
     HIP_TRY(c, hipMemcpyAsync(c->d_p, c->d_z, sizeof(double) * 3 * (size_t)c->n, hipMemcpyDeviceToDevice, c->stream));
     Scope sc(c, K_INIT_SCALARS, 8.0 * (gz + grid));
     launch_init_scalars(c->stream, c->d_S, c->d_zparts, gz, c->d_partials + kMaxPartials, grid, c->opts.pcg_tol * c->tol_scale,
-                        c->opts.pcg_maxit);
+                        c->pcg_softcap > 0 ? std::min(c->pcg_softcap, c->opts.pcg_maxit) : c->opts.pcg_maxit);
   } else {
     Scope sc(c, K_INIT_SCALARS, 16.0 * grid);
     launch_init_scalars(c->stream, c->d_S, c->d_partials, grid, c->d_partials + kMaxPartials, grid, c->opts.pcg_tol * c->tol_scale,
-                        c->opts.pcg_maxit);
+                        c->pcg_softcap > 0 ? std::min(c->pcg_softcap, c->opts.pcg_maxit) : c->opts.pcg_maxit);
   }
   return SGO_OK;
 }
@@ -1083,12 +1084,17 @@ int sgo_optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
   evs.v.assign(3 * (size_t)iters + 1, nullptr);
   for (auto& e : evs.v) HIP_TRY(c, hipEventCreate(&e));
   std::vector<hipEvent_t>& ev = evs.v;
+  struct SoftcapGuard {   // the bail-out cap applies to solves inside this call only
+    sgo_ctx* c;
+    ~SoftcapGuard() { c->pcg_softcap = 0; }
+  } softcap_guard{c};
   int done = 0;
   int rebuilds = 0;
   int& best_pcg = c->amg_best;
   bool rebuild_next = false;
   for (int it = 0; it < iters; ++it) {
     hipEventRecord(ev[3 * it], c->stream);
+    c->pcg_softcap = (c->amg && c->amg_best > 0 && rebuilds < 3 && !rebuild_next) ? 4 * c->amg_best + 40 : 0;
     if ((rc = do_chi2(c, c->d_hist + 2 * it, nullptr)) || (rc = do_linearize(c))) {
       return rc;
     }
@@ -1102,8 +1108,21 @@ int sgo_optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
       if (c->opts.verbose) std::fprintf(stderr, "[sgo] multigrid hierarchy rebuilt before iteration %d\n", it);
     }
     hipEventRecord(ev[3 * it + 1], c->stream);
+    int wasted = 0;
     if ((rc = run_pcg(c))) {
       return rc;
+    }
+    if (c->pcg_softcap > 0 && c->h_S->stop == 2 && c->h_S->iter < c->opts.pcg_maxit && c->amg) {
+      // The solve ran into the bail-out cap (4x the best count of this hierarchy): the aggregation no
+      // longer fits the re-weighted Hessian.  Redo the set-up from the current values and solve again
+      // from x = 0 instead of grinding on (seen: 735 iterations where the rebuilt hierarchy needs 16).
+      wasted = c->h_S->iter;
+      c->pcg_softcap = 0;
+      if ((rc = build_amg(c)) || (rc = do_linearize(c)) || (rc = run_pcg(c))) return rc;
+      ++rebuilds;
+      rebuild_next = false;
+      if (c->opts.verbose)
+        std::fprintf(stderr, "[sgo] iteration %d: solve abandoned after %d PCG iterations, hierarchy rebuilt\n", it, wasted);
     }
     const PcgScalars S = *c->h_S;
     if (c->amg && S.stop != 3) {
@@ -1119,7 +1138,7 @@ int sgo_optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
       if (rebuilds < 3 && (doubled || pays)) rebuild_next = true;
     }
     if (out) {
-      out->pcg_iters[it] = S.iter;
+      out->pcg_iters[it] = S.iter + wasted;   // an abandoned solve's iterations count too
       out->pcg_converged[it] = S.stop == 1;
       out->pcg_relres[it] = S.bb > 0 ? std::sqrt(S.rr / S.bb) : 0.0;
     }
@@ -1141,6 +1160,7 @@ int sgo_optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
       std::fprintf(stderr, "[sgo] iteration= %d\t pcg= %d\t relres= %.3e\t |b|= %.3e\n", it, S.iter,
                    S.bb > 0 ? std::sqrt(S.rr / S.bb) : 0.0, std::sqrt(S.bb));
   }
+  c->pcg_softcap = 0;
   if ((rc = do_chi2(c, c->d_hist + 2 * done, nullptr))) {
     return rc;
   }
