@@ -44,6 +44,7 @@
 #include <cassert>
 #include <cmath>
 #include <cstdint>
+#include <cstring>
 #include <iostream>
 #include <limits>
 #include <map>
@@ -613,6 +614,11 @@ class SparseOptimizer : public OptimizableGraph {
           if (it == _vertices.end() || it->second != v) all = false;
         }
         if (!all) continue;
+        // upstream: `allVerticesOK && !e->allVerticesFixed()` -- an edge between fixed vertices is not
+        // active (it would count in activeChi2 / activeEdges, drone.cpp:162-165, and nowhere else)
+        bool allFixed = true;
+        for (auto* v : e->vertices()) allFixed = allFixed && static_cast<OptimizableGraph::Vertex*>(v)->fixed();
+        if (allFixed) continue;
         es.push_back(e);
         for (auto* v : e->vertices()) vs.insert(v);
       }
@@ -645,9 +651,9 @@ class SparseOptimizer : public OptimizableGraph {
     if (done < 0 && done != SGO_ENOTHING) {
       std::cerr << "SparseOptimizer::optimize: " << sgo_last_error(_ctx) << std::endl;
       done = 0;
-    } else if (done >= 0 && done < iterations) {
-      std::cerr << "SparseOptimizer::optimize: linear solve failed in iteration " << done << ": " << sgo_last_error(_ctx)
-                << std::endl;
+    } else if (done == 0 && iterations > 0) {   // OptimizationAlgorithm::Fail: optimize() returns 0 upstream too
+      std::cerr << "SparseOptimizer::optimize: linear solve failed after " << st->iters_done << " iterations: "
+                << sgo_last_error(_ctx) << std::endl;
     }
     if (_verbose)
       for (int k = 0; k < st->iters_done; ++k)
@@ -831,7 +837,21 @@ class SparseOptimizer : public OptimizableGraph {
     return true;
   }
   // marshal the pointer graph into the flat arrays of sgo_set_graph_se2 (compact vertex numbering
-  // in ascending id) and upload; later optimize() calls on an unchanged structure only refresh poses
+  // in ascending id) and upload.  g2o rebuilds the system from the edge objects on every optimize(),
+  // so measurement / information / fixed / kernel-delta changes made between two optimize() calls
+  // without an initializeOptimization() must be seen: the arrays are marshalled every time and only
+  // when they hash equal to what the device holds is the upload reduced to the poses.
+  static uint64_t hashBytes(uint64_t h, const void* p, size_t n) {   // FNV-1a over 8-byte words + tail
+    const unsigned char* c = static_cast<const unsigned char*>(p);
+    size_t i = 0;
+    for (; i + 8 <= n; i += 8) {
+      uint64_t w;
+      std::memcpy(&w, c + i, 8);
+      h = (h ^ w) * 1099511628211ull;
+    }
+    for (; i < n; ++i) h = (h ^ c[i]) * 1099511628211ull;
+    return h;
+  }
   bool uploadGraph() {
     if (!_ctx) {
       _ctx = sgo_create(-1, nullptr);
@@ -849,11 +869,6 @@ class SparseOptimizer : public OptimizableGraph {
       poses[3 * k + 2] = v->estimate()[2];
       v->setTempIndex(k);   // compact numbering in ascending id (the array index sgo uses)
     }
-    if (_graphOnDevice) {
-      if (sgo_set_poses(_ctx, poses.data()) == SGO_OK) return true;
-      std::cerr << "SparseOptimizer: " << sgo_last_error(_ctx) << std::endl;
-      return false;
-    }
     std::vector<uint8_t> fixed(V);
     for (int k = 0; k < V; ++k) fixed[k] = _activeVertices[k]->fixed() ? 1 : 0;
     std::vector<int32_t> ei(E), ej(E);
@@ -868,6 +883,19 @@ class SparseOptimizer : public OptimizableGraph {
       o[0] = O(0, 0); o[1] = O(0, 1); o[2] = O(0, 2); o[3] = O(1, 1); o[4] = O(1, 2); o[5] = O(2, 2);
       phi[k] = e->robustKernel() ? e->robustKernel()->delta() : -1.0;
     }
+    uint64_t h = 1469598103934665603ull;
+    h = hashBytes(h, fixed.data(), fixed.size());
+    h = hashBytes(h, ei.data(), sizeof(int32_t) * ei.size());
+    h = hashBytes(h, ej.data(), sizeof(int32_t) * ej.size());
+    h = hashBytes(h, meas.data(), sizeof(double) * meas.size());
+    h = hashBytes(h, info.data(), sizeof(double) * info.size());
+    h = hashBytes(h, phi.data(), sizeof(double) * phi.size());
+    if (_graphOnDevice && h == _deviceGraphHash && V == _deviceV && E == _deviceE) {
+      if (sgo_set_poses(_ctx, poses.data()) == SGO_OK) return true;
+      std::cerr << "SparseOptimizer: " << sgo_last_error(_ctx) << std::endl;
+      return false;
+    }
+    _graphOnDevice = false;
     int rc = sgo_set_graph_se2(_ctx, V, poses.data(), fixed.data(), E, ei.data(), ej.data(), meas.data(), info.data(),
                                phi.data());
     if (rc != SGO_OK) {
@@ -875,6 +903,9 @@ class SparseOptimizer : public OptimizableGraph {
       return false;
     }
     _graphOnDevice = true;
+    _deviceGraphHash = h;
+    _deviceV = V;
+    _deviceE = E;
     return true;
   }
   void downloadEstimates() {
@@ -899,6 +930,8 @@ class SparseOptimizer : public OptimizableGraph {
   std::vector<OptimizableGraph::Edge*> _activeEdges;
   sgo_ctx* _ctx = nullptr;
   bool _graphOnDevice = false;
+  uint64_t _deviceGraphHash = 0;
+  int _deviceV = 0, _deviceE = 0;
   std::unique_ptr<sgo_stats> _lastStats;
 };
 

@@ -84,7 +84,9 @@ void sgo_default_opts(sgo_opts* o);
 
 typedef struct sgo_stats {
   int32_t iters_requested;
-  int32_t iters_done;                        /* as g2o optimize(): 0 = first solve failed */
+  int32_t iters_done;                        /* GN updates actually applied (the return value is 0 whenever a
+                                                linear solve failed, as g2o's optimize(); this still counts the
+                                                updates applied before the failure) */
   double chi2[SGO_MAX_ITERS + 1];            /* activeChi2 at the START of iteration k; [iters_done] = final */
   double robust_chi2[SGO_MAX_ITERS + 1];     /* activeRobustChi2, same indexing */
   int32_t pcg_iters[SGO_MAX_ITERS];          /* PCG iterations of GN iteration k */
@@ -122,8 +124,11 @@ int sgo_get_poses(sgo_ctx* ctx, double* poses);
 
 /* Replaces: SparseOptimizer::optimize(iters) with OptimizationAlgorithmGaussNewton (slc.cpp:287,
  * log_runner.cpp:204): iters x { computeActiveErrors; buildSystem; solve; update }, no damping, no
- * convergence test.  Returns iterations done (0 = the first linear solve failed, estimates
- * untouched), SGO_ENOTHING (-1) when there is no free active vertex, or another negative code.
+ * convergence test.  Returns iterations done; 0 when a linear solve failed -- PCG breakdown (H not
+ * positive definite) or pcg_maxit reached without pcg_tol: that step is not applied, the estimates stay
+ * at the last applied update (out->iters_done of them) and sgo_last_error has the reason, as
+ * g2o::SparseOptimizer::optimize returns 0 on OptimizationAlgorithm::Fail; SGO_ENOTHING (-1) when
+ * there is no free active vertex; or another negative code.
  * `out` may be NULL. */
 int sgo_optimize_gn(sgo_ctx* ctx, int32_t iters, sgo_stats* out);
 

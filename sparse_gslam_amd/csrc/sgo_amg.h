@@ -14,11 +14,6 @@ struct AmgConfig {
   double theta_coarse = 0.02;  // ... on the coarser levels (env SGO_AMG_THETA_COARSE)
   double omega = 0.8;      // block-Jacobi damping (env SGO_AMG_OMEGA)
   int max_levels = 10;
-  bool double_pass = false; // aggregate twice per level when the coarsening ratio is below 4 (env
-                            // SGO_AMG_DOUBLE_PASS=1): fewer levels but ~2x the PCG iterations on
-                            // chain-dominated graphs -- measured a wash, kept off
-  double double_ratio = 4.0;   // ... when n / nc < double_ratio (env SGO_AMG_DOUBLE_RATIO)
-  int double_from_level = 0;   // ... on levels >= this (env SGO_AMG_DOUBLE_FROM)
   int nu0 = 1;                 // damped block-Jacobi sweeps before and after on level 0 (env SGO_AMG_NU0)
   int nu_coarse = 1;           // ... on the coarser V-cycle levels (env SGO_AMG_NU_COARSE); amg_create picks 2 for
                                // graphs with >= 10^6 level-0 blocks, where a coarse sweep is cheap next to level 0

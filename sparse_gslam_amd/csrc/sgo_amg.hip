@@ -626,229 +626,6 @@ __global__ __launch_bounds__(kBlock) void k_dots2(int n, const double* __restric
   block_sum_store<2>(acc, partials, kMaxPartials);
 }
 
-// --------------------------------------------------------------------------------- fused coarse tree
-// Every level below `tree_start` is small (<= 2048 rows): run as separate launches, each of its
-// ~10 kernels per visit costs ~5-6 us of launch + cache write-back latency while moving a few KB,
-// and the K-cycle visits level l 2^l times.  k_coarse_tree runs the whole K-cycle recursion of
-// those levels inside ONE workgroup (16 waves): phases are separated by __syncthreads()
-// (workgroup-scope visibility is enough, all waves share the CU's L1), data stays in the CU's
-// L1 / the XCD's L2.  Same arithmetic, same order as the multi-launch path.
-constexpr int kTreeThreads = 1024;
-constexpr int kTreeWaves = kTreeThreads / 64;
-constexpr int kTreeMaxLevels = 6;
-struct TreeLevel {
-  BsrDev A;
-  int nc = 0;
-  const int* agg = nullptr;
-  const int* mem_ptr = nullptr;
-  const int* mem = nullptr;
-  const double* d = nullptr;
-  double *xs = nullptr, *rs = nullptr, *bk = nullptr, *xk = nullptr, *z1 = nullptr, *z2 = nullptr, *q = nullptr;
-};
-struct CoarseTree {
-  int nlev = 0;   // levels in the tree; the last one is the dense coarsest level
-  int N = 0;      // dense dimension
-  int Np = 0;     // leading dimension of inv
-  const double* inv = nullptr;
-  double omega = 0.0;
-  TreeLevel lv[kTreeMaxLevels];
-};
-
-// all-reduce two doubles over the workgroup (every thread gets the sums, fixed order)
-__device__ __forceinline__ void blk_allreduce2(double& a, double& b, double* sm) {
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  a = wave_sum(a);
-  b = wave_sum(b);
-  if (lane == 0) {
-    sm[w] = a;
-    sm[kTreeWaves + w] = b;
-  }
-  __syncthreads();
-  double sa = 0.0, sb = 0.0;
-#pragma unroll
-  for (int k = 0; k < kTreeWaves; ++k) {
-    sa += sm[k];
-    sb += sm[kTreeWaves + k];
-  }
-  __syncthreads();
-  a = sa;
-  b = sb;
-}
-
-// workgroup-wide version of k_spmv<MODE> (same row epilogues); ends with a barrier
-template <int MODE>
-__device__ __forceinline__ void blk_spmv(const BsrDev& A, const SpmvArgs& a, bool dots, double& d0, double& d1,
-                                         double* sm) {
-  const int lane = threadIdx.x & 63;
-  const size_t ns = (size_t)A.nslot;
-  double acc0 = 0.0, acc1 = 0.0;
-  for (int g = threadIdx.x >> 6; g < A.ngrp; g += kTreeWaves) {
-    const int gb = A.grp[g], ge = A.grp[g + 1];
-    double acc[3] = {0.0, 0.0, 0.0};
-    int row = -1 - lane;
-    for (int k = gb + lane; k < ge; k += 64) {
-      row = A.row[k];
-      const int c = A.col[k];
-      double x0, x1, x2;
-      if (MODE == SPMV_PRE_RESID) {
-        const double* di = A.dinv + 6 * (size_t)c;
-        const double b0 = a.b[3 * (size_t)c], b1 = a.b[3 * (size_t)c + 1], b2 = a.b[3 * (size_t)c + 2];
-        x0 = a.omega * (di[0] * b0 + di[1] * b1 + di[2] * b2);
-        x1 = a.omega * (di[1] * b0 + di[3] * b1 + di[4] * b2);
-        x2 = a.omega * (di[2] * b0 + di[4] * b1 + di[5] * b2);
-      } else {
-        x0 = a.x[3 * (size_t)c]; x1 = a.x[3 * (size_t)c + 1]; x2 = a.x[3 * (size_t)c + 2];
-      }
-      acc[0] += A.blk[blk_at(0, k, ns)] * x0 + A.blk[blk_at(1, k, ns)] * x1 + A.blk[blk_at(2, k, ns)] * x2;
-      acc[1] += A.blk[blk_at(3, k, ns)] * x0 + A.blk[blk_at(4, k, ns)] * x1 + A.blk[blk_at(5, k, ns)] * x2;
-      acc[2] += A.blk[blk_at(6, k, ns)] * x0 + A.blk[blk_at(7, k, ns)] * x1 + A.blk[blk_at(8, k, ns)] * x2;
-    }
-    seg_scan<3>(row, acc, lane);
-    const int rn = __shfl_down(row, 1);
-    if (row >= 0 && (lane == 63 || rn != row)) {
-      const size_t o = 3 * (size_t)row;
-      double o0 = acc[0], o1 = acc[1], o2 = acc[2];
-      if (MODE != SPMV_AX) {
-        const double r0 = a.b[o] - acc[0], r1 = a.b[o + 1] - acc[1], r2 = a.b[o + 2] - acc[2];
-        if (MODE == SPMV_JACOBI) {
-          const double* di = A.dinv + 6 * (size_t)row;
-          o0 = a.x[o] + a.omega * (di[0] * r0 + di[1] * r1 + di[2] * r2);
-          o1 = a.x[o + 1] + a.omega * (di[1] * r0 + di[3] * r1 + di[4] * r2);
-          o2 = a.x[o + 2] + a.omega * (di[2] * r0 + di[4] * r1 + di[5] * r2);
-        } else {
-          o0 = r0; o1 = r1; o2 = r2;
-        }
-        if (MODE == SPMV_PRE_RESID) {
-          const double* di = A.dinv + 6 * (size_t)row;
-          const double b0 = a.b[o], b1 = a.b[o + 1], b2 = a.b[o + 2];
-          a.y2[o] = a.omega * (di[0] * b0 + di[1] * b1 + di[2] * b2);
-          a.y2[o + 1] = a.omega * (di[1] * b0 + di[3] * b1 + di[4] * b2);
-          a.y2[o + 2] = a.omega * (di[2] * b0 + di[4] * b1 + di[5] * b2);
-        }
-      }
-      a.y[o] = o0; a.y[o + 1] = o1; a.y[o + 2] = o2;
-      if (a.dotA) acc0 += a.dotA[o] * o0 + a.dotA[o + 1] * o1 + a.dotA[o + 2] * o2;
-      if (a.dotB) acc1 += a.dotB[o] * a.dotC[o] + a.dotB[o + 1] * a.dotC[o + 1] + a.dotB[o + 2] * a.dotC[o + 2];
-    }
-  }
-  if (dots) {
-    blk_allreduce2(acc0, acc1, sm);
-    d0 = acc0;
-    d1 = acc1;
-  } else {
-    __syncthreads();
-  }
-}
-
-__device__ __forceinline__ void blk_dense_apply(int N, int Np, const double* __restrict__ inv,
-                                                const double* __restrict__ b, double* __restrict__ x, double* sb) {
-  for (int j = threadIdx.x; j < N; j += kTreeThreads) sb[j] = b[j];
-  __syncthreads();
-  const int s = threadIdx.x & 3;
-  for (int base = 0; base < N; base += kTreeThreads / 4) {
-    const int i = base + (threadIdx.x >> 2);
-    double acc = 0.0;
-    if (i < N)
-      for (int j = s; j < N; j += 4) acc += inv[(size_t)j * Np + i] * sb[j];
-    acc += __shfl_xor(acc, 1);
-    acc += __shfl_xor(acc, 2);
-    if (i < N && s == 0) x[i] = acc;
-  }
-  __syncthreads();
-}
-
-template <int L>
-__device__ void tree_fcg(const CoarseTree& T, double* sm, double* sb);
-
-// out = cycle(level L of the tree, rhs); dot = dotvec . out when dotvec != nullptr
-template <int L>
-__device__ void tree_cycle(const CoarseTree& T, const double* rhs, double* out, const double* dotvec, double& dot,
-                           double* sm, double* sb) {
-  if constexpr (L + 1 < kTreeMaxLevels) {
-    const TreeLevel& X = T.lv[L];
-    const TreeLevel& C = T.lv[L + 1];
-    double u0, u1;
-    {
-      SpmvArgs a{};
-      a.b = rhs; a.y = X.rs; a.y2 = X.xs; a.omega = T.omega;
-      blk_spmv<SPMV_PRE_RESID>(X.A, a, false, u0, u1, sm);
-    }
-    for (int ag = threadIdx.x; ag < X.nc; ag += kTreeThreads) {
-      const int lo = X.mem_ptr[ag], hi = X.mem_ptr[ag + 1];
-      double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-      for (int t = lo; t < hi; ++t) {
-        const int i = X.mem[t];
-        const double r0 = X.rs[3 * (size_t)i], r1 = X.rs[3 * (size_t)i + 1], r2 = X.rs[3 * (size_t)i + 2];
-        s0 += r0;
-        s1 += r1;
-        s2 += -X.d[2 * (size_t)i + 1] * r0 + X.d[2 * (size_t)i] * r1 + r2;
-      }
-      C.bk[3 * (size_t)ag] = s0;
-      C.bk[3 * (size_t)ag + 1] = s1;
-      C.bk[3 * (size_t)ag + 2] = s2;
-    }
-    __syncthreads();
-    if (L + 1 == T.nlev - 1) blk_dense_apply(T.N, T.Np, T.inv, C.bk, C.xk, sb);
-    else tree_fcg<L + 1>(T, sm, sb);
-    for (int i = threadIdx.x; i < X.A.n; i += kTreeThreads) {
-      const size_t ca = 3 * (size_t)X.agg[i], o = 3 * (size_t)i;
-      const double c0 = C.xk[ca], c1 = C.xk[ca + 1], w = C.xk[ca + 2];
-      X.xs[o] += c0 - X.d[2 * (size_t)i + 1] * w;
-      X.xs[o + 1] += c1 + X.d[2 * (size_t)i] * w;
-      X.xs[o + 2] += w;
-    }
-    __syncthreads();
-    SpmvArgs a{};
-    a.x = X.xs; a.b = rhs; a.y = out; a.omega = T.omega; a.dotA = dotvec;
-    blk_spmv<SPMV_JACOBI>(X.A, a, dotvec != nullptr, dot, u1, sm);
-  }
-}
-
-// two flexible-CG steps for A_L xk = bk (same recurrences as the host-driven fcg())
-template <int L>
-__device__ void tree_fcg(const CoarseTree& T, double* sm, double* sb) {
-  if constexpr (L + 1 < kTreeMaxLevels) {
-    const TreeLevel& X = T.lv[L];
-    const int n3 = 3 * X.A.n;
-    double dummy = 0.0;
-    tree_cycle<L>(T, X.bk, X.z1, nullptr, dummy, sm, sb);
-    double den = 0.0, num = 0.0;
-    {
-      SpmvArgs a{};
-      a.x = X.z1; a.y = X.q; a.dotA = X.z1; a.dotB = X.z1; a.dotC = X.bk;
-      blk_spmv<SPMV_AX>(X.A, a, true, den, num, sm);
-    }
-    const bool ok = den > 0.0 && isfinite(den);
-    const double al = (ok && isfinite(num)) ? num / den : 0.0;
-    for (int i = threadIdx.x; i < n3; i += kTreeThreads) {
-      X.xk[i] = al * X.z1[i];
-      X.bk[i] -= al * X.q[i];
-    }
-    __syncthreads();
-    double c = 0.0;
-    tree_cycle<L>(T, X.bk, X.z2, X.q, c, sm, sb);
-    const double be = (ok && isfinite(c)) ? c / den : 0.0;
-    for (int i = threadIdx.x; i < n3; i += kTreeThreads) X.z2[i] -= be * X.z1[i];
-    __syncthreads();
-    double den2 = 0.0, num2 = 0.0;
-    {
-      SpmvArgs a{};
-      a.x = X.z2; a.y = X.q; a.dotA = X.z2; a.dotB = X.z2; a.dotC = X.bk;
-      blk_spmv<SPMV_AX>(X.A, a, true, den2, num2, sm);
-    }
-    const double al2 = (den2 > 0.0 && isfinite(den2) && isfinite(num2)) ? num2 / den2 : 0.0;
-    for (int i = threadIdx.x; i < n3; i += kTreeThreads) X.xk[i] += al2 * X.z2[i];
-    __syncthreads();
-  }
-}
-
-__global__ __launch_bounds__(kTreeThreads) void k_coarse_tree(const CoarseTree* __restrict__ T, const PcgScalars* S) {
-  if (S && S->stop) return;
-  __shared__ double sm[2 * kTreeWaves];
-  extern __shared__ double sb[];
-  tree_fcg<0>(*T, sm, sb);
-}
-
 // --------------------------------------------------------------------------------- host
 template <class T>
 T* dev_alloc(std::vector<void*>& pool, size_t count) {
@@ -1290,9 +1067,6 @@ struct Amg {
   const int* d_free_id = nullptr;
   int kdepth = 1 << 20;  // levels <= kdepth use the K-cycle (two FCG steps), deeper ones a V-cycle
   int fcg2_depth = 1 << 20;  // levels <= this take two FCG steps, deeper K-cycle levels one
-  int tree_start = -1;  // first level handled by k_coarse_tree (-1: none)
-  CoarseTree tree;
-  CoarseTree* d_tree = nullptr;
   // coarsest dense inverse (row-major, leading dimension Np = N rounded up to 32)
   int N = 0, Np = 0;
   double* inv = nullptr;
@@ -1413,14 +1187,13 @@ int cycle(Amg* m, hipStream_t s, int l, const double* rhs, const double* rhs_sub
   {
     SpmvArgs a{};
     a.b = rhs; a.y = L.rs; a.y2 = L.xs; a.omega = m->cfg.omega; a.S = S;
-    a.smoother_f32 = true;
     if (rhs_sub) {
       a.bsub = rhs_sub; a.c1 = rhs_c; a.b_out = rhs_out;
       rhs_eff = rhs_out;
       Scope sc(m->prof, K_SPMV_PRE_RESID_S, 80.0 * L.A.nslot + 168.0 * L.A.n);
       launch_spmv_ex(s, L.A, SPMV_PRE_RESID_S, a);
     } else {
-      Scope sc(m->prof, l == 0 ? K_SPMV_PRE_RESID_L0 : K_SPMV_PRE_RESID, (L.A.blkf ? 44.0 : 80.0) * L.A.nslot + 120.0 * L.A.n);
+      Scope sc(m->prof, l == 0 ? K_SPMV_PRE_RESID_L0 : K_SPMV_PRE_RESID, 80.0 * L.A.nslot + 120.0 * L.A.n);
       launch_spmv_ex(s, L.A, SPMV_PRE_RESID, a);
     }
   }
@@ -1451,10 +1224,6 @@ int cycle(Amg* m, hipStream_t s, int l, const double* rhs, const double* rhs_sub
     SGO_LAUNCH(k_dense_apply, dim3(grid_for(m->N, kWavesPerBlock)), dim3(kBlock), 0, s, m->N, m->Np, m->inv, C.bk,
                        C.xk, S);
     cs.u1 = C.xk;
-  } else if (m->tree_start >= 0 && l + 1 >= m->tree_start) {
-    Scope sc(m->prof, K_COARSE_TREE, 0.0);
-    SGO_LAUNCH(k_coarse_tree, dim3(1), dim3(kTreeThreads), sizeof(double) * m->N, s, (const CoarseTree*)m->d_tree, S);
-    cs.u1 = C.xk;
   } else if (l + 1 > m->kdepth && m->lv[l + 1].smoothed) {  // V-cycle below the K-cycle depth; a level whose own
                                                              // transfer is the tentative one always gets the K-cycle
     SpmvRatio none;
@@ -1465,7 +1234,6 @@ int cycle(Amg* m, hipStream_t s, int l, const double* rhs, const double* rhs_sub
   }
   SpmvArgs a{};
   a.x = L.xs; a.b = rhs_eff; a.y = out; a.omega = m->cfg.omega; a.S = S;
-  a.smoother_f32 = true;
   if (dotvec) {
     a.dotA = dotvec;
     a.dotA2 = dotvec2;
@@ -1487,12 +1255,12 @@ int cycle(Amg* m, hipStream_t s, int l, const double* rhs, const double* rhs_sub
       SpmvArgs b = a;
       b.y = dst; b.dotA = nullptr; b.dotA2 = nullptr; b.partials = nullptr;
       {
-        Scope sc(m->prof, l == 0 ? K_SPMV_JACOBI_L0 : K_SPMV_JACOBI, (L.A.blkf ? 44.0 : 80.0) * L.A.nslot + 120.0 * L.A.n);
+        Scope sc(m->prof, l == 0 ? K_SPMV_JACOBI_L0 : K_SPMV_JACOBI, 80.0 * L.A.nslot + 120.0 * L.A.n);
         launch_spmv_ex(s, L.A, SPMV_JACOBI, b);
       }
       a.x = dst;
     }
-    Scope sc(m->prof, l == 0 ? K_SPMV_JACOBI_L0 : K_SPMV_JACOBI, (L.A.blkf ? 44.0 : 80.0) * L.A.nslot + 120.0 * L.A.n);
+    Scope sc(m->prof, l == 0 ? K_SPMV_JACOBI_L0 : K_SPMV_JACOBI, 80.0 * L.A.nslot + 120.0 * L.A.n);
     return launch_spmv_ex(s, L.A, SPMV_JACOBI, a);
   }
   a.agg = L.agg; a.d = L.d; a.u1 = cs.u1; a.u2 = cs.u2; a.c1 = cs.c1; a.c2 = cs.c2;
@@ -1595,9 +1363,6 @@ Amg* amg_create(hipStream_t s, const BsrDev& A0, const double* d_poses, const in
   if (m->cfg.smooth) m->kdepth = 0;
   if (const char* e = std::getenv("SGO_AMG_KDEPTH")) m->kdepth = std::atoi(e);
   if (const char* e = std::getenv("SGO_AMG_FCG2_DEPTH")) m->fcg2_depth = std::atoi(e);
-  if (const char* e = std::getenv("SGO_AMG_DOUBLE_PASS")) m->cfg.double_pass = std::atoi(e) != 0;
-  if (const char* e = std::getenv("SGO_AMG_DOUBLE_RATIO")) m->cfg.double_ratio = std::atof(e);
-  if (const char* e = std::getenv("SGO_AMG_DOUBLE_FROM")) m->cfg.double_from_level = std::atoi(e);
   // larger graphs afford a larger dense coarsest level (its inverse costs O(N^3) once per GN
   // iteration, one K-cycle level less halves the coarse-level launches of every PCG iteration)
   m->cfg.coarsest_nodes = std::min(1000, std::max(m->cfg.coarsest_nodes, A0.n / 1500));
@@ -1680,51 +1445,6 @@ Amg* amg_create(hipStream_t s, const BsrDev& A0, const double* d_poses, const in
     if (nc > 0.9 * n) nc = aggregate(H, w, 0.0, agg);  // stalled: treat every connection as strong
     if (nc > 0.9 * n || nc < 1) break;                   // cannot coarsen further
     t_agg = ms_since(tA);
-    // Chain-dominated graphs (few strong neighbours per node) give aggregates of ~3 nodes and a deep
-    // hierarchy, which the K-cycle pays for exponentially.  When the coarsening ratio is below 4,
-    // aggregate the aggregates once more over the strong inter-aggregate connections.
-    if (m->cfg.double_pass && (double)nc * m->cfg.double_ratio > (double)n && nc > m->cfg.coarsest_nodes &&
-        l >= m->cfg.double_from_level) {
-      HostLevel G;   // graph of aggregates: one "diagonal" slot per aggregate, then strong neighbours
-      G.n = nc;
-      std::vector<std::pair<uint64_t, double>> ed;
-      for (int i = 0; i < n; ++i) {
-        const double di = w[H.rowptr[i]];
-        for (int k = H.rowptr[i] + 1; k < H.rowptr[i + 1]; ++k) {
-          const int j = H.col[k];
-          if (j == i || agg[i] == agg[j]) continue;
-          if (w[k] >= theta_l * std::sqrt(di * w[H.rowptr[j]]) && w[k] > 0.0)
-            ed.emplace_back(((uint64_t)agg[i] << 32) | (uint32_t)agg[j], w[k]);
-        }
-      }
-      std::sort(ed.begin(), ed.end());
-      G.rowptr.assign(nc + 1, 0);
-      std::vector<double> gw;
-      {
-        size_t t = 0;
-        for (int a = 0; a < nc; ++a) {
-          G.row.push_back(a);
-          G.col.push_back(a);
-          gw.push_back(1.0);   // placeholder; with theta = 0 only positivity of the weights matters
-          while (t < ed.size() && (int)(ed[t].first >> 32) == a) {
-            const int b = (int)(ed[t].first & 0xffffffffu);
-            double sum = 0.0;
-            while (t < ed.size() && (int)(ed[t].first >> 32) == a && (int)(ed[t].first & 0xffffffffu) == b) sum += ed[t++].second;
-            G.row.push_back(a);
-            G.col.push_back(b);
-            gw.push_back(sum);
-          }
-          G.rowptr[a + 1] = (int)G.row.size();
-        }
-      }
-      G.nslot = (int)G.row.size();
-      std::vector<int> agg2;
-      const int nc2 = aggregate(G, gw, 0.0, agg2);
-      if (nc2 >= 1 && nc2 < nc) {
-        for (int i = 0; i < n; ++i) agg[i] = agg2[agg[i]];
-        nc = nc2;
-      }
-    }
 
     // members by aggregate
     std::vector<int> mem_ptr(nc + 1, 0), mem(n);
@@ -1922,37 +1642,7 @@ Amg* amg_create(hipStream_t s, const BsrDev& A0, const double* d_poses, const in
   m->d_fail = dev_alloc<int>(m->pool, 1);
   if (!m->inv || !m->d_fail || !m->gjP || !m->gjX) return fail("amg_create: out of device memory");
   hipMemsetAsync(m->d_fail, 0, sizeof(int), s);
-  // levels small enough for the single-workgroup tree kernel
-  int tree_rows = 2048;
-  if (const char* e = std::getenv("SGO_AMG_TREE_ROWS")) tree_rows = std::atoi(e);
-  for (int l = 1; l < last; ++l)
-    if (m->lv[l].A.n <= tree_rows && m->lv[l].A.nslot <= 40000 && last - l + 1 <= kTreeMaxLevels) {
-      m->tree_start = l;
-      break;
-    }
-  // measured on MI355X (round 1): with the level data in global memory the single-workgroup tree
-  // is latency-bound (16 waves, ~3 us per dependent-load phase) and slower than separate
-  // launches; it stays opt-in until the small levels are staged in LDS.
-  if (!std::getenv("SGO_AMG_TREE") || m->cfg.smooth) m->tree_start = -1;   // (the tree kernel knows the tentative transfer only)
-  if (m->tree_start >= 0) {
-    CoarseTree& T = m->tree;
-    T.nlev = last - m->tree_start + 1;
-    T.N = m->N;
-    T.Np = m->Np;
-    T.inv = m->inv;
-    T.omega = m->cfg.omega;
-    for (int k = 0; k < T.nlev; ++k) {
-      const AmgLevel& L = m->lv[m->tree_start + k];
-      TreeLevel& X = T.lv[k];
-      X.A = L.A; X.nc = L.nc; X.agg = L.agg; X.mem_ptr = L.mem_ptr; X.mem = L.mem; X.d = L.d;
-      X.xs = L.xs; X.rs = L.rs; X.bk = L.bk; X.xk = L.xk; X.z1 = L.z1; X.z2 = L.z2; X.q = L.q;
-    }
-    m->d_tree = dev_alloc<CoarseTree>(m->pool, 1);
-    if (!m->d_tree) return fail("amg_create: out of device memory");
-    hipMemcpyAsync(m->d_tree, &m->tree, sizeof(CoarseTree), hipMemcpyHostToDevice, s);
-    if (hipStreamSynchronize(s) != hipSuccess) return fail("amg_create: tree upload failed");
-  }
-  std::snprintf(line, sizeof line, "coarsest dense N=%d; tree from L%d; theta=%.3g omega=%.2f", m->N, m->tree_start,
+  std::snprintf(line, sizeof line, "coarsest dense N=%d; theta=%.3g omega=%.2f", m->N,
                 m->cfg.theta, m->cfg.omega);
   m->desc += line;
   return m;

@@ -439,10 +439,6 @@ int build_structure(sgo_ctx* c, int V, const double* poses, const uint8_t* fixed
   if ((rc = upload(c, &c->A.grp, grp))) return rc;
   if ((rc = upload(c, &c->A.rowptr, rowptr))) return rc;
   if ((rc = dalloc(c, &c->A.blk, 9 * (size_t)ns))) return rc;
-  // measured (round 1): the fp32 smoother copy halves the bytes of two level-0 passes but its 4-byte
-  // SoA loads run no faster than the 8-byte ones (18.2 vs 17.6 ms per GN iteration on C4): opt-in.
-  if (c->opts.solver == SGO_SOLVER_PCG_AMG && std::getenv("SGO_AMG_SMOOTHER_F32"))
-    if ((rc = dalloc(c, &c->A.blkf, 9 * (size_t)ns))) return rc;
   if ((rc = dalloc(c, &c->A.dinv, 6 * (size_t)n))) return rc;
   if ((rc = upload(c, &c->es.vi, svi))) return rc;
   if ((rc = upload(c, &c->es.vj, svj))) return rc;
@@ -534,7 +530,6 @@ int do_linearize(sgo_ctx* c) {
   if (c->comm.nranks > 1) {
     sgo_shard_range(c->A.ngrp, c->comm.nranks, c->comm.rank, &g0, &g1);
     HIP_TRY(c, hipMemsetAsync(c->A.blk, 0, sizeof(double) * 9 * (size_t)c->A.nslot, c->stream));
-    if (c->A.blkf) HIP_TRY(c, hipMemsetAsync(c->A.blkf, 0, sizeof(float) * 9 * (size_t)c->A.nslot, c->stream));
     HIP_TRY(c, hipMemsetAsync(c->d_dgb, 0, sizeof(double) * 9 * (size_t)c->n, c->stream));
   }
   {
@@ -544,7 +539,6 @@ int do_linearize(sgo_ctx* c) {
   if (c->comm.nranks > 1) {
     if (!c->comm.allreduce_f64(c->A.blk, 9 * (size_t)c->A.nslot, c->stream, &c->err)) return SGO_ECOMM;
     if (!c->comm.allreduce_f64(c->d_dgb, 9 * (size_t)c->n, c->stream, &c->err)) return SGO_ECOMM;
-    if (c->A.blkf) launch_blk_to_f32(c->stream, c->A);   // refresh the smoother's fp32 copy for all bands
   }
   int grid = 0;
   {
@@ -591,6 +585,7 @@ int pcg_iteration(sgo_ctx* c) {
 int ensure_pcg_graph(sgo_ctx* c, int chunk) {
   if (c->pcg_exec && c->pcg_exec_chunk == chunk) return SGO_OK;
   if (c->pcg_exec) {
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
     hipGraphExecDestroy(c->pcg_exec);
     c->pcg_exec = nullptr;
   }
@@ -670,6 +665,9 @@ int run_pcg(sgo_ctx* c) {
 
 // (Re)build the multigrid hierarchy from the CURRENT level-0 values (requires do_linearize).
 int build_amg(sgo_ctx* c) {
+  // speculative replays of the captured PCG iteration (and the launches queued behind them) may still be
+  // in flight: drain the stream before the exec and the old hierarchy's buffers go away
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
   if (c->pcg_exec) {  // the captured PCG iteration references the old hierarchy's buffers
     hipGraphExecDestroy(c->pcg_exec);
     c->pcg_exec = nullptr;
@@ -677,7 +675,6 @@ int build_amg(sgo_ctx* c) {
   c->pcg_pred = 0;  // the iteration count of the old hierarchy predicts nothing about the new one
   c->amg_best = 0;
   if (c->amg) {
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
     amg_destroy(c->amg);
     c->amg = nullptr;
   }
@@ -1089,6 +1086,7 @@ int sgo_optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
     ~SoftcapGuard() { c->pcg_softcap = 0; }
   } softcap_guard{c};
   int done = 0;
+  bool failed = false;
   int rebuilds = 0;
   int& best_pcg = c->amg_best;
   bool rebuild_next = false;
@@ -1142,10 +1140,21 @@ int sgo_optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
       out->pcg_converged[it] = S.stop == 1;
       out->pcg_relres[it] = S.bb > 0 ? std::sqrt(S.rr / S.bb) : 0.0;
     }
-    if (S.stop == 3) {  // solver failure: estimates stay at the last successful update
-      c->err = "PCG breakdown in GN iteration " + std::to_string(it) + " (Hessian not positive definite";
-      if (c->amg && amg_coarsest_not_spd(c->amg, c->stream)) c->err += "; its coarsest Galerkin operator has a non-positive pivot";
-      c->err += ")";
+    if (S.stop != 1) {
+      // Solver failure, as LinearSolverEigen::solve returning false (OptimizationAlgorithm::Fail): the
+      // step is NOT applied, estimates stay at the last successful update and the call returns 0 like
+      // g2o::SparseOptimizer::optimize.  stop == 3: p.Hp <= 0 or non-finite (H not positive definite);
+      // stop == 2: pcg_maxit iterations without reaching pcg_tol (an inexact step is never applied).
+      if (S.stop == 3) {
+        c->err = "PCG breakdown in GN iteration " + std::to_string(it) + " (Hessian not positive definite";
+        if (c->amg && amg_coarsest_not_spd(c->amg, c->stream)) c->err += "; its coarsest Galerkin operator has a non-positive pivot";
+        c->err += ")";
+      } else {
+        c->err = "PCG did not reach pcg_tol within pcg_maxit = " + std::to_string(c->opts.pcg_maxit) +
+                 " iterations in GN iteration " + std::to_string(it) + " (relative residual " +
+                 std::to_string(S.bb > 0 ? std::sqrt(S.rr / S.bb) : 0.0) + "); the step was not applied";
+      }
+      failed = true;
       hipEventRecord(ev[3 * it + 2], c->stream);
       break;
     }
@@ -1185,7 +1194,7 @@ int sgo_optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
     }
     out->seconds_total = wall_s() - t0;
   }
-  return done;
+  return failed ? 0 : done;   // g2o: optimize() returns 0 when the algorithm reported Fail
 }
 
 int sgo_kernel_profile(sgo_ctx* c, sgo_kernel_stat* out, int cap) {

@@ -34,9 +34,6 @@ struct BsrDev {
   int* grp = nullptr;     // [ngrp + 1]
   int* rowptr = nullptr;  // [n + 1]
   double* blk = nullptr;  // 9 * nslot doubles, layout blk_at()
-  float* blkf = nullptr;  // [9][nslot] fp32 copy of blk read by the multigrid SMOOTHER on level 0 only
-                          // (the smoother is part of the preconditioner, which need not be exact;
-                          // the CG operator product always reads the fp64 blocks)
   double* dinv = nullptr; // [n][6] inverse of the diagonal block, symmetric packing
 };
 
@@ -112,7 +109,6 @@ struct SpmvArgs {
   const double* dotC = nullptr;
   double* partials = nullptr;    // [2][kMaxPartials]
   const PcgScalars* S = nullptr; // optional early-out flag
-  bool smoother_f32 = false;     // JACOBI / PRE_RESID: read the fp32 block copy when the matrix has one
   // fused coarse-level variants
   SpmvRatio c1, c2;
   const int* agg = nullptr;      // JACOBI_P: aggregate of each vertex, lever arms d, coarse vectors u1, u2
@@ -155,7 +151,6 @@ enum KernelId : int {
   K_PROLONG,
   K_DENSE_INVERT,
   K_DENSE_APPLY,
-  K_COARSE_TREE,
   K_SA_P,
   K_SA_AP,
   K_SA_RAP,
@@ -261,7 +256,6 @@ void launch_chi2(hipStream_t s, const EdgeListDev& el, int e0, int e1, const dou
 void launch_reduce2(hipStream_t s, const double* partials, int nparts, double* out2);
 void launch_linearize(hipStream_t s, const BsrDev& A, int g0, int g1, const EdgeSlotsDev& es, const double* poses,
                       double* dgb /*[n][9]*/);
-void launch_blk_to_f32(hipStream_t s, const BsrDev& A);
 void launch_finalize(hipStream_t s, const BsrDev& A, const double* dgb, int write_diag, double* b,
                      double* x, double* r, double* z, double* p, double* partials, int* grid_out);
 void launch_init_scalars(hipStream_t s, PcgScalars* S, const double* rz_parts, int n_rz, const double* bb_parts,

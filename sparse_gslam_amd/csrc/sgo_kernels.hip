@@ -27,12 +27,12 @@ namespace sgo {
 thread_local LaunchEvents tl_launch_ev;
 
 const char* const kKernelNames[K_COUNT] = {
-    "k_chi2",        "k_reduce2",  "k_linearize",   "k_finalize",   "k_init_scalars", "k_spmv<0, double>",  "k_spmv<1, double>",
-    "k_spmv<2, double>", "k_spmv<3, double>", "k_spmv<4, double>", "k_spmv<5, double>", "k_spmv<6, double>",      "k_alpha",       "k_update_xr",  "k_beta",         "k_update_p", "k_dot",
+    "k_chi2",        "k_reduce2",  "k_linearize",   "k_finalize",   "k_init_scalars", "k_spmv<0>",  "k_spmv<1>",
+    "k_spmv<2>", "k_spmv<3>", "k_spmv<4>", "k_spmv<5>", "k_spmv<6>",      "k_alpha",       "k_update_xr",  "k_beta",         "k_update_p", "k_dot",
     "k_pose_update", "k_positions0", "k_centres",   "k_galerkin",   "k_level_dinv",   "k_restrict", "k_prolong_add",
-    "k_gj_panels+k_gj_trail (dense inverse)", "k_dense_apply", "k_coarse_tree", "k_p_values", "k_block_products<1, 0, 0>",
-    "k_block_products<0, 1, 1>", "k_restrict_p", "k_prolong_p", "k_spmv<7, double>",
-    "k_spmv<0, double> @level0", "k_spmv<2, double> @level0", "k_spmv<3, double> @level0"};
+    "k_gj_panels+k_gj_trail (dense inverse)", "k_dense_apply", "k_p_values", "k_block_products<1, 0, 0>",
+    "k_block_products<0, 1, 1>", "k_restrict_p", "k_prolong_p", "k_spmv<7>",
+    "k_spmv<0> @level0", "k_spmv<2> @level0", "k_spmv<3> @level0"};
 
 namespace {
 
@@ -203,10 +203,6 @@ __global__ __launch_bounds__(kBlock) void k_linearize(BsrDev A, int g0, int g1, 
       }
 #pragma unroll
       for (int c = 0; c < 9; ++c) A.blk[blk_at(c, k, ns)] = h[c];
-      if (A.blkf) {
-#pragma unroll
-        for (int c = 0; c < 9; ++c) A.blkf[blk_at(c, k, ns)] = (float)h[c];
-      }
     }
     seg_scan<9>(row, acc, lane);
     const int rn = __shfl_down(row, 1);
@@ -216,12 +212,6 @@ __global__ __launch_bounds__(kBlock) void k_linearize(BsrDev A, int g0, int g1, 
       for (int c = 0; c < 9; ++c) d[c] = acc[c];
     }
   }
-}
-
-// fp32 copy of all blocks (multi-GPU: after the all-reduce filled in the other ranks' bands)
-__global__ __launch_bounds__(kBlock) void k_blk_to_f32(BsrDev A) {
-  const size_t n = 9 * (size_t)A.nslot;
-  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) A.blkf[i] = (float)A.blk[i];
 }
 
 // ---------------------------------------------------------------------------- k_finalize
@@ -242,11 +232,6 @@ __global__ __launch_bounds__(kBlock) void k_finalize(BsrDev A, const double* __r
     A.blk[blk_at(0, k0, ns)] = s * d00; A.blk[blk_at(1, k0, ns)] = s * d01; A.blk[blk_at(2, k0, ns)] = s * d02;
     A.blk[blk_at(3, k0, ns)] = s * d01; A.blk[blk_at(4, k0, ns)] = s * d11; A.blk[blk_at(5, k0, ns)] = s * d12;
     A.blk[blk_at(6, k0, ns)] = s * d02; A.blk[blk_at(7, k0, ns)] = s * d12; A.blk[blk_at(8, k0, ns)] = s * d22;
-    if (A.blkf) {
-      A.blkf[blk_at(0, k0, ns)] = (float)(s * d00); A.blkf[blk_at(1, k0, ns)] = (float)(s * d01); A.blkf[blk_at(2, k0, ns)] = (float)(s * d02);
-      A.blkf[blk_at(3, k0, ns)] = (float)(s * d01); A.blkf[blk_at(4, k0, ns)] = (float)(s * d11); A.blkf[blk_at(5, k0, ns)] = (float)(s * d12);
-      A.blkf[blk_at(6, k0, ns)] = (float)(s * d02); A.blkf[blk_at(7, k0, ns)] = (float)(s * d12); A.blkf[blk_at(8, k0, ns)] = (float)(s * d22);
-    }
     // symmetric 3x3 inverse by cofactors
     const double c00 = d11 * d22 - d12 * d12, c01 = d02 * d12 - d01 * d22, c02 = d01 * d12 - d02 * d11;
     const double c11 = d00 * d22 - d02 * d02, c12 = d01 * d02 - d00 * d12, c22 = d00 * d11 - d01 * d01;
@@ -332,13 +317,12 @@ __device__ __forceinline__ void ratios2(const SpmvRatio& r1, const SpmvRatio& r2
 // The two level-0 sweeps (JACOBI, PRE_RESID) would take 84 / 76 VGPRs = 5 / 6 waves per SIMD, which
 // leaves part of the 2048-block grid waiting for a second round; bounding them to 8 blocks per CU
 // (<= 64 VGPRs, no spills) keeps the whole grid resident: 37 -> 30 us per sweep on C4 (6.0 TB/s).
-template <int MODE, typename BlkT>
+template <int MODE>
 __global__ __launch_bounds__(kBlock, ((MODE == SPMV_JACOBI || MODE == SPMV_PRE_RESID) ? 8 : 1))
 void k_spmv(BsrDev A, SpmvArgs a) {
   if (a.S && a.S->stop) return;
   const int lane = threadIdx.x & 63;
   const size_t ns = (size_t)A.nslot;
-  const BlkT* __restrict__ blk = sizeof(BlkT) == 4 ? (const BlkT*)A.blkf : (const BlkT*)A.blk;
   double c1 = 1.0, c2 = 0.0;
   if (MODE == SPMV_JACOBI_P || MODE == SPMV_PRE_RESID_S || MODE == SPMV_AX_C) {
     ratios2(a.c1, a.c2, MODE == SPMV_JACOBI_P && a.u2 != nullptr, c1, c2);
@@ -381,17 +365,11 @@ void k_spmv(BsrDev A, SpmvArgs a) {
       row = A.row[k];
       double x0, x1, x2;
       operand((size_t)A.col[k], x0, x1, x2);
-      double b0, b1, b2, b3, b4, b5, b6, b7;
-      if (sizeof(BlkT) == 8) {  // four 16-byte loads (component pairs) + one 8-byte load
-        const double2* __restrict__ bp = reinterpret_cast<const double2*>(A.blk);
-        const double2 p0 = bp[k], p1 = bp[ns + k], p2 = bp[2 * ns + k], p3 = bp[3 * ns + k];
-        b0 = p0.x; b1 = p0.y; b2 = p1.x; b3 = p1.y; b4 = p2.x; b5 = p2.y; b6 = p3.x; b7 = p3.y;
-      } else {
-        b0 = (double)blk[blk_at(0, k, ns)]; b1 = (double)blk[blk_at(1, k, ns)]; b2 = (double)blk[blk_at(2, k, ns)];
-        b3 = (double)blk[blk_at(3, k, ns)]; b4 = (double)blk[blk_at(4, k, ns)]; b5 = (double)blk[blk_at(5, k, ns)];
-        b6 = (double)blk[blk_at(6, k, ns)]; b7 = (double)blk[blk_at(7, k, ns)];
-      }
-      const double b8 = (double)blk[8 * ns + k];
+      // four 16-byte loads (component pairs) + one 8-byte load
+      const double2* __restrict__ bp = reinterpret_cast<const double2*>(A.blk);
+      const double2 p0 = bp[k], p1 = bp[ns + k], p2 = bp[2 * ns + k], p3 = bp[3 * ns + k];
+      const double b0 = p0.x, b1 = p0.y, b2 = p1.x, b3 = p1.y, b4 = p2.x, b5 = p2.y, b6 = p3.x, b7 = p3.y;
+      const double b8 = A.blk[8 * ns + k];
       acc[0] += b0 * x0 + b1 * x1 + b2 * x2;
       acc[1] += b3 * x0 + b4 * x1 + b5 * x2;
       acc[2] += b6 * x0 + b7 * x1 + b8 * x2;
@@ -573,9 +551,6 @@ void launch_linearize(hipStream_t s, const BsrDev& A, int g0, int g1, const Edge
   const int grid = grid_for(g1 - g0, kWavesPerBlock);
   SGO_LAUNCH(k_linearize, dim3(grid), dim3(kBlock), 0, s, A, g0, g1, es, poses, dgb);
 }
-void launch_blk_to_f32(hipStream_t s, const BsrDev& A) {
-  SGO_LAUNCH(k_blk_to_f32, dim3(grid_for(9LL * A.nslot, kBlock)), dim3(kBlock), 0, s, A);
-}
 void launch_finalize(hipStream_t s, const BsrDev& A, const double* dgb, int write_diag, double* b, double* x,
                      double* r, double* z, double* p, double* partials, int* grid_out) {
   const int grid = grid_for(A.n, kBlock);
@@ -588,21 +563,18 @@ void launch_init_scalars(hipStream_t s, PcgScalars* S, const double* rz_parts, i
 }
 int launch_spmv_ex(hipStream_t s, const BsrDev& A, int mode, const SpmvArgs& a) {
   const int grid = grid_for(A.ngrp, kWavesPerBlock);
-  const bool f32 = A.blkf != nullptr && a.smoother_f32;
   switch (mode) {
-    case SPMV_AX: SGO_LAUNCH((k_spmv<SPMV_AX, double>), dim3(grid), dim3(kBlock), 0, s, A, a); break;
-    case SPMV_RESID: SGO_LAUNCH((k_spmv<SPMV_RESID, double>), dim3(grid), dim3(kBlock), 0, s, A, a); break;
+    case SPMV_AX: SGO_LAUNCH((k_spmv<SPMV_AX>), dim3(grid), dim3(kBlock), 0, s, A, a); break;
+    case SPMV_RESID: SGO_LAUNCH((k_spmv<SPMV_RESID>), dim3(grid), dim3(kBlock), 0, s, A, a); break;
     case SPMV_JACOBI:
-      if (f32) SGO_LAUNCH((k_spmv<SPMV_JACOBI, float>), dim3(grid), dim3(kBlock), 0, s, A, a);
-      else SGO_LAUNCH((k_spmv<SPMV_JACOBI, double>), dim3(grid), dim3(kBlock), 0, s, A, a);
+      SGO_LAUNCH((k_spmv<SPMV_JACOBI>), dim3(grid), dim3(kBlock), 0, s, A, a);
       break;
-    case SPMV_JACOBI_P: SGO_LAUNCH((k_spmv<SPMV_JACOBI_P, double>), dim3(grid), dim3(kBlock), 0, s, A, a); break;
-    case SPMV_PRE_RESID_S: SGO_LAUNCH((k_spmv<SPMV_PRE_RESID_S, double>), dim3(grid), dim3(kBlock), 0, s, A, a); break;
-    case SPMV_PRE_RESID_ACC: SGO_LAUNCH((k_spmv<SPMV_PRE_RESID_ACC, double>), dim3(grid), dim3(kBlock), 0, s, A, a); break;
-    case SPMV_AX_C: SGO_LAUNCH((k_spmv<SPMV_AX_C, double>), dim3(grid), dim3(kBlock), 0, s, A, a); break;
+    case SPMV_JACOBI_P: SGO_LAUNCH((k_spmv<SPMV_JACOBI_P>), dim3(grid), dim3(kBlock), 0, s, A, a); break;
+    case SPMV_PRE_RESID_S: SGO_LAUNCH((k_spmv<SPMV_PRE_RESID_S>), dim3(grid), dim3(kBlock), 0, s, A, a); break;
+    case SPMV_PRE_RESID_ACC: SGO_LAUNCH((k_spmv<SPMV_PRE_RESID_ACC>), dim3(grid), dim3(kBlock), 0, s, A, a); break;
+    case SPMV_AX_C: SGO_LAUNCH((k_spmv<SPMV_AX_C>), dim3(grid), dim3(kBlock), 0, s, A, a); break;
     default:
-      if (f32) SGO_LAUNCH((k_spmv<SPMV_PRE_RESID, float>), dim3(grid), dim3(kBlock), 0, s, A, a);
-      else SGO_LAUNCH((k_spmv<SPMV_PRE_RESID, double>), dim3(grid), dim3(kBlock), 0, s, A, a);
+      SGO_LAUNCH((k_spmv<SPMV_PRE_RESID>), dim3(grid), dim3(kBlock), 0, s, A, a);
       break;
   }
   return grid;

@@ -30,7 +30,7 @@ def test_random_graphs_match_oracle_through_one_context():
             assert done == ost["iters_done"] == 6, (case, V, E)
             floor = 1e-9 * ost["chi2"][0]
             rel = max(abs(a - b) / max(b, floor) for a, b in zip(st["chi2"], ost["chi2"]))
-            # 1e-6 is BASELINE.json's bound; chain-like graphs of thousands of poses are ill-conditioned
-            # enough for two direct solvers to differ by 2e-7 on a transient iterate
-            assert rel < 2e-6, (case, V, E, rel)
+            # 1e-6 relative is BASELINE.json's bound and holds for every iterate, also on the chain-like
+            # graphs of thousands of poses (kappa(H) beyond 1e10), which run at a tightened PCG tolerance
+            assert rel <= 1e-6, (case, V, E, rel)
             assert np.isfinite(P).all() and np.abs(P - oP).max() < 1e-4, (case, V, E)
