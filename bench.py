@@ -182,17 +182,7 @@ def main():
             p.optimize(min(args.iters, 4))
             raw = p.kernel_profile()
             overhead_us = 1e3 * p.profile_overhead_ms()
-        # libsgo keeps the level-0 launches of the three block-stream kernels in slots of their own
-        # ("<name> @level0"): fold them back under the kernel's rocprofv3 name for the table and the
-        # headline figure, and keep the level-0 share for the extra "level0" entry below
-        prof, level0 = {}, {}
-        for n, v in raw.items():
-            base = n.replace(" @level0", "")
-            t = prof.setdefault(base, dict(launches=0, ms=0.0, bytes=0.0))
-            for f in ("launches", "ms", "bytes"):
-                t[f] += v[f]
-            if n.endswith(" @level0"):
-                level0[base] = v
+        prof = raw
         name, k = max(prof.items(), key=lambda kv: kv[1]["ms"])
         achieved = k["bytes"] / (k["ms"] * 1e-3) / 1e9
         # HBM traffic of the same kernel from the separate rocprofv3 --pmc passes (FETCH_SIZE x2,
@@ -203,23 +193,25 @@ def main():
             kk = json.load(open(cand))["kernels"].get(name)
             if kk:
                 traffic, traffic_src = kk["hbm_bytes_per_launch"], os.path.relpath(cand, ROOT)
+        # whole-iteration figure of SURVEY.md section 8(d): B_GN = B_lin + K B_pcg + 48 V over the median
+        # GN iteration time, B_lin = 200 E + 72 V, B_pcg = 76 E + 430 V, K = PCG iterations per GN iteration
+        K = float(np.mean(st["pcg_iters"]))
+        b_gn = (200.0 * g.E + 72.0 * g.V) + K * (76.0 * g.E + 430.0 * g.V) + 48.0 * g.V
+        t_gn = float(np.median(st["seconds"]))
         out["roofline"] = {
             "bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
             "avg_launch_us": 1e3 * k["ms"] / k["launches"], "launches": k["launches"],
             "event_bracket_overhead_us": overhead_us,
             "algorithmic_bytes_per_launch": k["bytes"] / k["launches"],
-            "level0": ({"launches": level0[name]["launches"],
-                        "avg_launch_us": 1e3 * level0[name]["ms"] / level0[name]["launches"],
-                        "algorithmic_bytes_per_launch": level0[name]["bytes"] / level0[name]["launches"],
-                        "achieved": level0[name]["bytes"] / (level0[name]["ms"] * 1e-3) / 1e9,
-                        "frac": level0[name]["bytes"] / (level0[name]["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS}
-                       if name in level0 and level0[name]["launches"] else None),
-            "note": "achieved = algorithmic bytes of all launches of this kernel (all multigrid levels) / their "
-                    "summed HIP-event time; level0 = the same for its launches on the finest level only (the "
-                    "coarse-level launches move KBs-MBs and sit on the launch-latency floor); the events are the dispatch's own start/stop stamps "
+            "gn_iteration": {"bytes": b_gn, "seconds": t_gn, "pcg_iters": K, "achieved": b_gn / t_gn / 1e9,
+                             "frac": b_gn / t_gn / 1e9 / HBM_PEAK_GBS},
+            "note": "achieved = algorithmic bytes (SURVEY.md section 8(d): every stored block once with one index, "
+                    "76 B per edge, + the per-row vectors; DESIGN.md section 4) of all launches of this kernel / their "
+                    "summed HIP-event time; the events are the dispatch's own start/stop stamps "
                     "(hipExtLaunchKernelGGL), comparable with rocprofv3 kernel durations; traffic = mean HBM "
-                    "bytes per launch from rocprofv3 --pmc passes; per-kernel table uses rocprofv3's kernel names",
+                    "bytes per launch from rocprofv3 --pmc passes; gn_iteration = B_GN / t_GN of section 8(d); "
+                    "per-kernel table uses rocprofv3's kernel names",
             "kernels": {n: {"launches": v["launches"], "ms": round(v["ms"], 3),
                             "avg_us": round(1e3 * v["ms"] / v["launches"], 2),
                             "GB/s": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)}

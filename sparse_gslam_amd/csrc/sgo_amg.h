@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <string>
+#include <vector>
 
 #include "sgo_internal.h"
 
@@ -14,7 +15,6 @@ struct AmgConfig {
   double theta_coarse = 0.02;  // ... on the coarser levels (env SGO_AMG_THETA_COARSE)
   double omega = 0.8;      // block-Jacobi damping (env SGO_AMG_OMEGA)
   int max_levels = 10;
-  int nu0 = 1;                 // damped block-Jacobi sweeps before and after on level 0 (env SGO_AMG_NU0)
   int nu_coarse = 1;           // ... on the coarser V-cycle levels (env SGO_AMG_NU_COARSE); amg_create picks 2 for
                                // graphs with >= 10^6 level-0 blocks, where a coarse sweep is cheap next to level 0
   bool smooth = true;          // smoothed aggregation: P = (I - omega_p D^-1 A) T (env SGO_AMG_SMOOTH=0: tentative P)
@@ -33,21 +33,33 @@ struct AmgProf {
 struct ChunkArena;
 struct Amg;  // opaque
 
-// Build the hierarchy for the level-0 matrix A0, whose values (blk, dinv) must hold the
-// linearisation at the initial poses (they provide the strength of connection).  `pos_src` /
-// `free_id` give the positions of the level-0 nodes: pos of row h = poses[3*free_id[h] + 0..1].
-// `scratch` (optional) provides host memory for the set-up's large temporary lists; it is rewound here
-// and may be rewound again by the caller once amg_create has returned.
-Amg* amg_create(hipStream_t s, const BsrDev& A0, const double* d_poses, const int* d_free_id,
-                const AmgConfig& cfg, const AmgProf& prof, std::string* err, ChunkArena* scratch = nullptr);
+// logical structure of a level's operator on the host (slot list sorted by row, diagonal slot first)
+struct HostLevel {
+  int n = 0, nslot = 0;
+  std::vector<int> rowptr, row, col;
+};
+
+// Build the hierarchy for the level-0 matrix: S0 is its symmetric storage (the cycle's level-0 products
+// run on it), A0 its logical view (set-up kernels) and H0 the same structure on the host.  The values
+// (S0.ublk, dblk, dinv) must hold the linearisation at the initial poses (they provide the strength of
+// connection).  `d_poses` / `d_free_id` give the positions of the level-0 nodes: pos of row h =
+// poses[3*free_id[h] + 0..1].  `scratch` (optional) provides host memory for the set-up's large temporary
+// lists; it is rewound here and may be rewound again by the caller once amg_create has returned.
+Amg* amg_create(hipStream_t s, const BsrDev& A0, const Sym0Dev& S0, const HostLevel& H0, const double* d_poses,
+                const int* d_free_id, const AmgConfig& cfg, const AmgProf& prof, std::string* err,
+                ChunkArena* scratch = nullptr);
 void amg_destroy(Amg* m);
 // Recompute the coarse operators for the current level-0 values and poses (once per GN iteration).
 int amg_update(Amg* m, hipStream_t s, std::string* err);
-// z = M^-1 r (one K-cycle).  If dotvec != nullptr, partials[0..nparts) receive the per-block
+// z = M^-1 r (one cycle).  If dotvec != nullptr, partials[0..nparts) receive the per-block
 // partial sums of dotvec . z; returns nparts (the grid of the last kernel).
 // dotvec2 (optional) adds partials[kMaxPartials + ..] = dotvec2 . z.
+// xs0_ready: the producer of r has already left omega Dinv r in amg_xs0() (k_finalize, k_update_xr) --
+// the cycle's first level-0 smoothing sweep from zero -- otherwise the cycle computes it first.
 int amg_apply(Amg* m, hipStream_t s, const double* r, double* z, const double* dotvec, double* partials,
-              const PcgScalars* S, const double* dotvec2 = nullptr);
+              const PcgScalars* S, const double* dotvec2 = nullptr, bool xs0_ready = false);
+double* amg_xs0(Amg* m);     // [n][3] on the device; nullptr for a single-level (dense) hierarchy
+double amg_omega(const Amg* m);
 // true when the last amg_update met a non-positive pivot in the coarsest operator (synchronises `s`)
 bool amg_coarsest_not_spd(Amg* m, hipStream_t s);
 int amg_num_levels(const Amg* m);

@@ -43,14 +43,12 @@ namespace {
 // --------------------------------------------------------------------------------- kernels
 // Frobenius norm of every slot's block (strength of connection input).
 __global__ __launch_bounds__(kBlock) void k_block_norms(BsrDev A, double* __restrict__ w) {
-  const size_t ns = (size_t)A.nslot;
   for (int k = blockIdx.x * kBlock + threadIdx.x; k < A.nslot; k += gridDim.x * kBlock) {
+    double b[9];
+    load_block(A, (size_t)k, b);
     double s = 0.0;
 #pragma unroll
-    for (int c = 0; c < 9; ++c) {
-      const double v = A.blk[blk_at(c, k, ns)];
-      s += v * v;
-    }
+    for (int c = 0; c < 9; ++c) s += b[c] * b[c];
     w[k] = sqrt(s);
   }
 }
@@ -100,7 +98,7 @@ struct GalerkinMap {
 };
 __global__ __launch_bounds__(kBlock) void k_galerkin(BsrDev F, BsrDev C, GalerkinMap g, const double* __restrict__ d) {
   const int lane = threadIdx.x & 63;
-  const size_t nf = (size_t)F.nslot, ncs = (size_t)C.nslot;
+  const size_t ncs = (size_t)C.nslot;
   int gi, gend, gstride;
   group_walk(g.ngrp, &gi, &gend, &gstride);
   for (; gi < gend; gi += gstride) {
@@ -114,8 +112,7 @@ __global__ __launch_bounds__(kBlock) void k_galerkin(BsrDev F, BsrDev C, Galerki
       const double dxi = d[2 * (size_t)i], dyi = d[2 * (size_t)i + 1];
       const double dxj = d[2 * (size_t)j], dyj = d[2 * (size_t)j + 1];
       double b[9];
-#pragma unroll
-      for (int c = 0; c < 9; ++c) b[c] = F.blk[blk_at(c, k, nf)];
+      load_block(F, (size_t)k, b);
       // M = B T_j : third column = -dy_j * col0 + dx_j * col1 + col2
       const double m02 = -dyj * b[0] + dxj * b[1] + b[2];
       const double m12 = -dyj * b[3] + dxj * b[4] + b[5];
@@ -188,7 +185,6 @@ __device__ __forceinline__ void load9(const double* __restrict__ base, size_t e,
 __global__ __launch_bounds__(kBlock) void k_p_values(BsrDev F, PDev P, const int* __restrict__ agg,
                                                      const double* __restrict__ d, double omega_p) {
   const int lane = threadIdx.x & 63;
-  const size_t nf = (size_t)F.nslot;
   int gi, gend, gstride;
   group_walk(P.val.ngrp, &gi, &gend, &gstride);
   for (; gi < gend; gi += gstride) {
@@ -201,8 +197,7 @@ __global__ __launch_bounds__(kBlock) void k_p_values(BsrDev F, PDev P, const int
       const int j = F.col[k];
       const double dxj = d[2 * (size_t)j], dyj = d[2 * (size_t)j + 1];
       double b[9];
-#pragma unroll
-      for (int c = 0; c < 9; ++c) b[c] = F.blk[blk_at(c, k, nf)];
+      load_block(F, (size_t)k, b);
       acc[0] += b[0]; acc[1] += b[1]; acc[2] += -dyj * b[0] + dxj * b[1] + b[2];
       acc[3] += b[3]; acc[4] += b[4]; acc[5] += -dyj * b[3] + dxj * b[4] + b[5];
       acc[6] += b[6]; acc[7] += b[7]; acc[8] += -dyj * b[6] + dxj * b[7] + b[8];
@@ -236,10 +231,11 @@ __global__ __launch_bounds__(kBlock) void k_p_values(BsrDev F, PDev P, const int
 }
 
 // out_t = sum over the products of target t of  X(a) * Y(b)   (TRANSPOSE_X: X(a)^T * Y(b))
-// X blocks: pair-SoA BsrDev values (xb_bsr) or plain [9][nx]; Y plain [9][ny]; out plain or BsrDev.
+// X blocks: the logical slots of a level's operator XA (X_BSR; load_block) or plain records X[nx][9];
+// Y plain [ny][9]; out plain or pair-SoA (a BsrDev's blk).
 template <bool X_BSR, bool TRANSPOSE_X, bool OUT_BSR>
-__global__ __launch_bounds__(kBlock) void k_block_products(ProdMap mp, const double* __restrict__ X, size_t nx,
-                                                           const double* __restrict__ Y, size_t ny,
+__global__ __launch_bounds__(kBlock) void k_block_products(ProdMap mp, BsrDev XA, const double* __restrict__ X,
+                                                           const double* __restrict__ Y,
                                                            double* __restrict__ out, size_t nout) {
   const int lane = threadIdx.x & 63;
   int gi, gend, gstride;
@@ -252,12 +248,8 @@ __global__ __launch_bounds__(kBlock) void k_block_products(ProdMap mp, const dou
       key = mp.tgt[t];
       const size_t ia = (size_t)mp.a[t], ib = (size_t)mp.b[t];
       double x[9], y[9];
-      if (X_BSR) {
-#pragma unroll
-        for (int c = 0; c < 9; ++c) x[c] = X[blk_at(c, ia, nx)];
-      } else {
-        load9(X, ia, x);
-      }
+      if (X_BSR) load_block(XA, ia, x);
+      else load9(X, ia, x);
       load9(Y, ib, y);
 #pragma unroll
       for (int r = 0; r < 3; ++r)
@@ -459,13 +451,14 @@ __global__ __launch_bounds__(kBlock) void k_dense_fill(BsrDev A, int Np, double*
   // (row, col) -- duplicate edges, and the zero blocks of fixed-column slots that alias the
   // diagonal -- so the fill must accumulate, and a row-exclusive sequential sum keeps it
   // deterministic.  M was zeroed by the caller.
-  const size_t ns = (size_t)A.nslot;
   const int N = 3 * A.n;
   for (int r = blockIdx.x * kBlock + threadIdx.x; r < A.n; r += gridDim.x * kBlock) {
     for (int k = A.rowptr[r]; k < A.rowptr[r + 1]; ++k) {
       const int c = A.col[k];
+      double b[9];
+      load_block(A, (size_t)k, b);
 #pragma unroll
-      for (int e = 0; e < 9; ++e) M[(size_t)(3 * r + e / 3) * Np + 3 * c + e % 3] += A.blk[blk_at(e, k, ns)];
+      for (int e = 0; e < 9; ++e) M[(size_t)(3 * r + e / 3) * Np + 3 * c + e % 3] += b[e];
     }
   }
   for (int i = N + blockIdx.x * kBlock + threadIdx.x; i < Np; i += gridDim.x * kBlock) M[(size_t)i * Np + i] = 1.0;
@@ -663,11 +656,6 @@ std::vector<int> make_groups(const std::vector<int>& ptr) {
   if (grp.back() != ptr[nseg]) grp.push_back(ptr[nseg]);
   return grp;
 }
-
-struct HostLevel {
-  int n = 0, nslot = 0;
-  std::vector<int> rowptr, row, col;
-};
 
 // Greedy root-node aggregation (Vanek et al.) on the strength graph
 //   strong(i,j)  <=>  w_ij >= theta * sqrt(w_ii w_jj)
@@ -1061,6 +1049,7 @@ struct AmgLevel {
 struct Amg {
   AmgConfig cfg;
   AmgProf prof;
+  Sym0Dev S0;               // level-0 operator in symmetric storage (lv[0].A is its logical view)
   std::vector<void*> pool;
   std::vector<AmgLevel> lv;
   const double* d_poses = nullptr;
@@ -1107,14 +1096,12 @@ void launch_coarse_operator(Amg* m, hipStream_t s, AmgLevel& L, AmgLevel& C) {
   {
     Scope sc(m->prof, K_SA_AP, 156.0 * P.ap.n + 72.0 * P.nap);
     SGO_LAUNCH((k_block_products<true, false, false>), dim3(grid_for(P.ap.ngrp, kWavesPerBlock)), dim3(kBlock), 0, s,
-               P.ap, (const double*)L.A.blk, (size_t)L.A.nslot, (const double*)P.blk, (size_t)P.np, P.apblk,
-               (size_t)P.nap);
+               P.ap, L.A, (const double*)nullptr, (const double*)P.blk, P.apblk, (size_t)P.nap);
   }
   {
     Scope sc(m->prof, K_SA_RAP, 156.0 * P.rap.n + 72.0 * C.A.nslot);
     SGO_LAUNCH((k_block_products<false, true, true>), dim3(grid_for(P.rap.ngrp, kWavesPerBlock)), dim3(kBlock), 0, s,
-               P.rap, (const double*)P.blk, (size_t)P.np, (const double*)P.apblk, (size_t)P.nap, C.A.blk,
-               (size_t)C.A.nslot);
+               P.rap, BsrDev(), (const double*)P.blk, (const double*)P.apblk, C.A.blk, (size_t)C.A.nslot);
   }
 }
 
@@ -1129,7 +1116,7 @@ struct CoarseSol {
 
 int cycle(Amg* m, hipStream_t s, int l, const double* rhs, const double* rhs_sub, const SpmvRatio& rhs_c,
           double* rhs_out, double* out, const double* dotvec, double* dotparts, const PcgScalars* S,
-          const double* dotvec2 = nullptr);
+          const double* dotvec2 = nullptr, bool xs0_ready = false);
 
 // Two flexible-CG steps on level l for A x = bk (Notay's K-cycle), with the vector updates
 // fused into the neighbouring SpMV-type launches:
@@ -1179,12 +1166,23 @@ CoarseSol fcg(Amg* m, hipStream_t s, int l, const PcgScalars* S) {
 // dotvec . out (and dotvec2 . out).  Returns the grid of the last kernel.
 int cycle(Amg* m, hipStream_t s, int l, const double* rhs, const double* rhs_sub, const SpmvRatio& rhs_c,
           double* rhs_out, double* out, const double* dotvec, double* dotparts, const PcgScalars* S,
-          const double* dotvec2) {
+          const double* dotvec2, bool xs0_ready) {
   AmgLevel& L = m->lv[l];
   AmgLevel& C = m->lv[l + 1];
   const int last = (int)m->lv.size() - 1;
   const double* rhs_eff = rhs;
-  {
+  if (l == 0) {
+    // finest level, symmetric storage: xs = omega Dinv rhs (first sweep from zero; normally left by the
+    // producer of rhs), then the residual rs = rhs - H xs in one pass over the stored blocks
+    if (!xs0_ready) {
+      Scope sc(m->prof, K_DOT, 96.0 * L.A.n);
+      launch_precond_bj(s, L.A.n, m->S0.dinv, rhs, L.xs, m->cfg.omega);
+    }
+    Spmv0Args a{};
+    a.x = L.xs; a.b = rhs; a.y = L.rs; a.S = S;
+    Scope sc(m->prof, K_SPMV0_RESID, 76.0 * m->S0.nu + 120.0 * m->S0.n);
+    launch_spmv0(s, m->S0, S0_RESID, a);
+  } else {
     SpmvArgs a{};
     a.b = rhs; a.y = L.rs; a.y2 = L.xs; a.omega = m->cfg.omega; a.S = S;
     if (rhs_sub) {
@@ -1193,13 +1191,13 @@ int cycle(Amg* m, hipStream_t s, int l, const double* rhs, const double* rhs_sub
       Scope sc(m->prof, K_SPMV_PRE_RESID_S, 80.0 * L.A.nslot + 168.0 * L.A.n);
       launch_spmv_ex(s, L.A, SPMV_PRE_RESID_S, a);
     } else {
-      Scope sc(m->prof, l == 0 ? K_SPMV_PRE_RESID_L0 : K_SPMV_PRE_RESID, 80.0 * L.A.nslot + 120.0 * L.A.n);
+      Scope sc(m->prof, K_SPMV_PRE_RESID, 80.0 * L.A.nslot + 120.0 * L.A.n);
       launch_spmv_ex(s, L.A, SPMV_PRE_RESID, a);
     }
   }
   // further pre-smoothing sweeps (levels walked by the V-cycle only): sweep s applied to the residual
   // of sweep s-1 gives the next correction (accumulated into xs) and the next residual (rs <-> tR)
-  const int nu = (L.tR && (L.smoothed || l == 0)) ? std::max(1, l == 0 ? m->cfg.nu0 : m->cfg.nu_coarse) : 1;
+  const int nu = (l > 0 && L.tR && L.smoothed) ? std::max(1, m->cfg.nu_coarse) : 1;
   double* res = L.rs;
   for (int sw = 1; sw < nu; ++sw) {
     double* nxt = (res == L.rs) ? L.tR : L.rs;
@@ -1239,7 +1237,27 @@ int cycle(Amg* m, hipStream_t s, int l, const double* rhs, const double* rhs_sub
     a.dotA2 = dotvec2;
     a.partials = dotparts;
   }
-  if (l == 0 || L.smoothed) {
+  if (l == 0) {   // prolongation, then the post-smoothing sweep on the symmetric storage
+    if (L.smoothed) {
+      Scope sc(m->prof, K_PROLONG_P, 80.0 * L.P.np + 52.0 * L.A.n);
+      SGO_LAUNCH(k_prolong_p, dim3(grid_for(L.P.r_ngrp, kWavesPerBlock)), dim3(kBlock), 0, s, L.A.n, L.P, cs.u1, cs.c1, cs.u2, cs.c2,
+                 L.xs, S, (const double*)nullptr);
+    } else {
+      Scope sc(m->prof, K_PROLONG, 68.0 * L.A.n);
+      SGO_LAUNCH(k_prolong_add, dim3(grid_for(L.A.n, kBlock)), dim3(kBlock), 0, s, L.A.n, L.agg, L.d, cs.u1, cs.c1,
+                         cs.u2, cs.c2, L.xs, S, (const double*)nullptr);
+    }
+    Spmv0Args b{};
+    b.x = L.xs; b.b = rhs; b.y = out; b.omega = m->cfg.omega; b.S = S;
+    if (dotvec) {
+      b.dotA = dotvec;
+      b.dotA2 = dotvec2;
+      b.partials = dotparts;
+    }
+    Scope sc(m->prof, K_SPMV0_JACOBI, 76.0 * m->S0.nu + 168.0 * m->S0.n);
+    return launch_spmv0(s, m->S0, S0_JACOBI, b);
+  }
+  if (L.smoothed) {
     if (L.smoothed) {
       Scope sc(m->prof, K_PROLONG_P, 80.0 * L.P.np + 52.0 * L.A.n);
       SGO_LAUNCH(k_prolong_p, dim3(grid_for(L.P.r_ngrp, kWavesPerBlock)), dim3(kBlock), 0, s, L.A.n, L.P, cs.u1, cs.c1, cs.u2, cs.c2,
@@ -1255,12 +1273,12 @@ int cycle(Amg* m, hipStream_t s, int l, const double* rhs, const double* rhs_sub
       SpmvArgs b = a;
       b.y = dst; b.dotA = nullptr; b.dotA2 = nullptr; b.partials = nullptr;
       {
-        Scope sc(m->prof, l == 0 ? K_SPMV_JACOBI_L0 : K_SPMV_JACOBI, 80.0 * L.A.nslot + 120.0 * L.A.n);
+        Scope sc(m->prof, K_SPMV_JACOBI, 80.0 * L.A.nslot + 120.0 * L.A.n);
         launch_spmv_ex(s, L.A, SPMV_JACOBI, b);
       }
       a.x = dst;
     }
-    Scope sc(m->prof, l == 0 ? K_SPMV_JACOBI_L0 : K_SPMV_JACOBI, 80.0 * L.A.nslot + 120.0 * L.A.n);
+    Scope sc(m->prof, K_SPMV_JACOBI, 80.0 * L.A.nslot + 120.0 * L.A.n);
     return launch_spmv_ex(s, L.A, SPMV_JACOBI, a);
   }
   a.agg = L.agg; a.d = L.d; a.u1 = cs.u1; a.u2 = cs.u2; a.c1 = cs.c1; a.c2 = cs.c2;
@@ -1326,8 +1344,11 @@ int amg_update(Amg* m, hipStream_t s, std::string* err) {
   return SGO_OK;
 }
 
+double* amg_xs0(Amg* m) { return (m && m->lv.size() > 1) ? m->lv[0].xs : nullptr; }
+double amg_omega(const Amg* m) { return m ? m->cfg.omega : 0.0; }
+
 int amg_apply(Amg* m, hipStream_t s, const double* r, double* z, const double* dotvec, double* partials,
-              const PcgScalars* S, const double* dotvec2) {
+              const PcgScalars* S, const double* dotvec2, bool xs0_ready) {
   if (m->lv.size() == 1) {  // single (dense) level: z = H^-1 r
     {
       Scope sc(m->prof, K_DENSE_APPLY, 8.0 * m->N * m->N);
@@ -1340,17 +1361,18 @@ int amg_apply(Amg* m, hipStream_t s, const double* r, double* z, const double* d
     return grid;
   }
   SpmvRatio none;
-  return cycle(m, s, 0, r, nullptr, none, nullptr, z, dotvec, partials, S, dotvec2);
+  return cycle(m, s, 0, r, nullptr, none, nullptr, z, dotvec, partials, S, dotvec2, xs0_ready);
 }
 
-Amg* amg_create(hipStream_t s, const BsrDev& A0, const double* d_poses, const int* d_free_id, const AmgConfig& cfg_in,
-                const AmgProf& prof, std::string* err, ChunkArena* scratch) {
+Amg* amg_create(hipStream_t s, const BsrDev& A0, const Sym0Dev& S0, const HostLevel& H0, const double* d_poses,
+                const int* d_free_id, const AmgConfig& cfg_in, const AmgProf& prof, std::string* err,
+                ChunkArena* scratch) {
   Amg* m = new Amg();
   m->cfg = cfg_in;
+  m->S0 = S0;
   if (const char* e = std::getenv("SGO_AMG_THETA")) m->cfg.theta = std::atof(e);
   if (const char* e = std::getenv("SGO_AMG_OMEGA")) m->cfg.omega = std::atof(e);
   if (const char* e = std::getenv("SGO_AMG_THETA_COARSE")) m->cfg.theta_coarse = std::atof(e);
-  if (const char* e = std::getenv("SGO_AMG_NU0")) m->cfg.nu0 = std::atoi(e);
   // A sweep on a coarse level is a 5-10 us launch whatever the graph; it pays when a PCG iteration is
   // dominated by level 0 (C4: 31 instead of 39 iterations, 9.7 instead of 10.6 ms) and costs a few
   // per cent on graphs whose level 0 is itself launch-bound (10k / 40k: 2.67 instead of 2.51 ms).
@@ -1376,17 +1398,8 @@ Amg* amg_create(hipStream_t s, const BsrDev& A0, const double* d_poses, const in
     return nullptr;
   };
 
-  // level 0 structure to the host
-  HostLevel H;
-  H.n = A0.n;
-  H.nslot = A0.nslot;
-  H.rowptr.resize(H.n + 1);
-  H.row.resize(H.nslot);
-  H.col.resize(H.nslot);
-  hipMemcpyAsync(H.rowptr.data(), A0.rowptr, sizeof(int) * (H.n + 1), hipMemcpyDeviceToHost, s);
-  hipMemcpyAsync(H.row.data(), A0.row, sizeof(int) * H.nslot, hipMemcpyDeviceToHost, s);
-  hipMemcpyAsync(H.col.data(), A0.col, sizeof(int) * H.nslot, hipMemcpyDeviceToHost, s);
-  if (hipStreamSynchronize(s) != hipSuccess) return fail("amg_create: copy of the level-0 structure failed");
+  HostLevel Hown;              // structure of the level being coarsened: H0 first, then the level built last
+  const HostLevel* Hp = &H0;
 
   AmgLevel L0;
   L0.A = A0;
@@ -1394,6 +1407,7 @@ Amg* amg_create(hipStream_t s, const BsrDev& A0, const double* d_poses, const in
   char line[160];
   for (int l = 0;; ++l) {
     AmgLevel& L = m->lv[l];
+    const HostLevel& H = *Hp;
     const int n = L.A.n, n3 = 3 * n;
     L.spmv_grid = grid_for(L.A.ngrp, kWavesPerBlock);
     std::snprintf(line, sizeof line, "L%d n=%d slots=%d; ", l, n, L.A.nslot);
@@ -1627,7 +1641,8 @@ Amg* amg_create(hipStream_t s, const BsrDev& A0, const double* d_poses, const in
       if (std::getenv("SGO_VERBOSE") && n > 20000)
         std::fprintf(stderr, "[sgo] amg level %d: alloc + upload %.1f ms, first values %.1f ms\n", l, t_up, ms_since(tU) - t_up);
     }
-    H = std::move(Hc);
+    Hown = std::move(Hc);
+    Hp = &Hown;
   }
   const int last = (int)m->lv.size() - 1;
   // last == 0: the whole graph is at most coarsest_nodes large (or cannot be coarsened) and is

@@ -92,7 +92,9 @@ struct sgo_ctx {
   // graph (host)
   bool has_graph = false;
   int V = 0, E = 0, n = 0;
-  std::vector<int> free_id;
+  std::vector<int> free_id;      // hessian index (g2o order: free active vertices in ascending id) -> vertex id
+  std::vector<int> row_of_asc;   // hessian index -> internal row (Hilbert order, build_structure)
+  HostLevel H0;                  // logical level-0 structure on the host (multigrid set-up input)
   double setup_seconds = 0.0;
 
   // device
@@ -100,7 +102,8 @@ struct sgo_ctx {
   double* d_poses = nullptr;
   int* d_free_id = nullptr;
   EdgeListDev el;
-  BsrDev A;
+  Sym0Dev S0;                    // level-0 Hessian, symmetric storage (the solve's products run on this)
+  BsrDev A;                      // its logical view (multigrid set-up kernels)
   EdgeSlotsDev es;
   double *d_dgb = nullptr, *d_b = nullptr, *d_x = nullptr, *d_r = nullptr, *d_z = nullptr, *d_p = nullptr,
          *d_q = nullptr, *d_s1 = nullptr, *d_s2 = nullptr, *d_e2 = nullptr;
@@ -205,6 +208,7 @@ void free_graph(sgo_ctx* c) {
   c->allocs.clear();
   c->pcg_pred = 0;
   c->A = BsrDev();
+  c->S0 = Sym0Dev();
   c->es = EdgeSlotsDev();
   c->el = EdgeListDev();
   c->has_graph = false;
@@ -291,17 +295,51 @@ struct Scope {
   }
 };
 
-// ---- algorithmic bytes per launch ------------------------------------
-double bytes_spmv(const BsrDev& A) { return 80.0 * A.nslot + 48.0 * A.n; }
-double bytes_linearize(const sgo_ctx* c) {
-  return 96.0 * c->A.nslot + 72.0 * (c->A.nslot - c->A.n) + 24.0 * c->V + 72.0 * c->A.n;
+// ---- algorithmic bytes per launch ------------
+// Level-0 product: every stored off-diagonal block once with one index (76 B per edge), the diagonal
+// block (48 B), the operand and the result (24 B each) per row; + the right-hand side (RESID, JACOBI)
+// and the block-diagonal inverse (JACOBI).
+double bytes_spmv0(const Sym0Dev& A, int mode) {
+  return 76.0 * A.nu + (96.0 + (mode != S0_AX ? 24.0 : 0.0) + (mode == S0_JACOBI ? 48.0 : 0.0)) * A.n;
 }
+// linearise + assemble: the row-parallel design reads each edge's operands once per endpoint row
+// (2 x 128 B: indices, inverse measurement, information, two poses), writes the off-diagonal block once
+// (72 B) and 72 B of (diagonal block, b) per row
+double bytes_linearize(const sgo_ctx* c) { return 128.0 * c->S0.ncs + 72.0 * c->S0.nu + 72.0 * c->n; }
 double bytes_chi2(const sgo_ctx* c) { return 96.0 * c->E + 24.0 * c->V; }
 
+// Hilbert-curve index of the cell (x, y) of a 2^order x 2^order grid.
+uint32_t hilbert_index(uint32_t x, uint32_t y, int order) {
+  uint32_t d = 0;
+  for (uint32_t s = 1u << (order - 1); s > 0; s >>= 1) {
+    const uint32_t rx = (x & s) ? 1u : 0u, ry = (y & s) ? 1u : 0u;
+    d += s * s * ((3u * rx) ^ ry);
+    if (ry == 0) {   // rotate the quadrant
+      if (rx == 1) {
+        x = s - 1 - (x & (s - 1));
+        y = s - 1 - (y & (s - 1));
+      } else {
+        x &= s - 1;
+        y &= s - 1;
+      }
+      const uint32_t t = x;
+      x = y;
+      y = t;
+    } else {
+      x &= s - 1;
+      y &= s - 1;
+    }
+  }
+  return d;
+}
+
 // ---- structure build: SparseOptimizer::initializeOptimization + BlockSolver::buildStructure -
+// The hessian index map of g2o -- free active vertices in ascending id -- is what the API speaks
+// (c->free_id, sgo_free_ids, sgo_linearize, ...).  Internally the rows are numbered along a Hilbert
+// curve through the initial poses (c->row_of_asc maps one to the other), which makes the symmetric
+// storage of Sym0Dev work: the endpoints of almost every edge end up a few hundred rows apart.
 int build_structure(sgo_ctx* c, int V, const double* poses, const uint8_t* fixed, int E, const int32_t* ei,
                     const int32_t* ej, const double* meas, const double* info, const double* phi) {
-  // active vertices: those incident to at least one edge (initializeOptimization)
   const double tb0 = wall_s();
   std::vector<int> deg(V, 0);
   for (int e = 0; e < E; ++e) {
@@ -317,67 +355,83 @@ int build_structure(sgo_ctx* c, int V, const double* poses, const uint8_t* fixed
     deg[a]++;
     deg[b]++;
   }
-  std::vector<int> hidx(V, -1);
+  // active free vertices in ascending id = g2o's hessian order (initializeOptimization)
   c->free_id.clear();
   for (int v = 0; v < V; ++v)
-    if (!fixed[v] && deg[v] > 0) {
-      hidx[v] = (int)c->free_id.size();
-      c->free_id.push_back(v);
-    }
+    if (!fixed[v] && deg[v] > 0) c->free_id.push_back(v);
   const int n = (int)c->free_id.size();
   c->V = V;
   c->E = E;
   c->n = n;
+  // internal row order: Hilbert index of the initial position (ties and non-finite poses: by id)
+  std::vector<int> hpos(V, -1);          // vertex id -> internal row
+  std::vector<int> row_vertex(n);        // internal row -> vertex id
+  c->row_of_asc.assign(n, 0);
+  {
+    double lo[2] = {1e300, 1e300}, hi[2] = {-1e300, -1e300};
+    for (int h = 0; h < n; ++h) {
+      const double* q = poses + 3 * (size_t)c->free_id[h];
+      for (int d = 0; d < 2; ++d)
+        if (std::isfinite(q[d])) {
+          lo[d] = std::min(lo[d], q[d]);
+          hi[d] = std::max(hi[d], q[d]);
+        }
+    }
+    const double ext = std::max(hi[0] - lo[0], hi[1] - lo[1]);
+    const double scale = (ext > 0.0 && std::isfinite(ext)) ? 65535.0 / ext : 0.0;
+    std::vector<uint64_t> key(n);
+    parallel_for(n, [&](int h0, int h1) {
+      for (int h = h0; h < h1; ++h) {
+        const double* q = poses + 3 * (size_t)c->free_id[h];
+        uint32_t d = 0;
+        if (std::isfinite(q[0]) && std::isfinite(q[1]) && scale > 0.0)
+          d = hilbert_index((uint32_t)((q[0] - lo[0]) * scale), (uint32_t)((q[1] - lo[1]) * scale), 16);
+        key[h] = ((uint64_t)d << 32) | (uint32_t)h;
+      }
+    });
+    std::sort(key.begin(), key.end());
+    for (int r = 0; r < n; ++r) {
+      const int h = (int)(key[r] & 0xffffffffu);
+      c->row_of_asc[h] = r;
+      row_vertex[r] = c->free_id[h];
+      hpos[c->free_id[h]] = r;
+    }
+  }
 
-  // slots: one diagonal slot per row, then the row's directed edges in edge order
+  // compact slots: per row one slot per incident edge (edge order within the row)
   std::vector<int> rowptr(n + 1, 0);
-  for (int r = 0; r < n; ++r) rowptr[r + 1] = 1;
   for (int e = 0; e < E; ++e) {
-    int hi = hidx[ei[e]], hj = hidx[ej[e]];
+    const int hi = hpos[ei[e]], hj = hpos[ej[e]];
     if (hi >= 0) rowptr[hi + 1]++;
     if (hj >= 0) rowptr[hj + 1]++;
   }
   for (int r = 0; r < n; ++r) rowptr[r + 1] += rowptr[r];
   const int ns = rowptr[n];
-  // slot position of each edge's two directed copies (serial: keeps edge order within a row)
   std::vector<int> pos_i(E, -1), pos_j(E, -1);
   {
     std::vector<int> fill(rowptr.begin(), rowptr.end() - 1);
-    for (int r = 0; r < n; ++r) fill[r]++;  // slot 0 of every row is the diagonal
     for (int e = 0; e < E; ++e) {
-      int hi = hidx[ei[e]], hj = hidx[ej[e]];
+      const int hi = hpos[ei[e]], hj = hpos[ej[e]];
       if (hi >= 0) pos_i[e] = fill[hi]++;
       if (hj >= 0) pos_j[e] = fill[hj]++;
     }
   }
   HostArena& ar = c->stage;
   try {
-    ar.reserve((size_t)ns * (5 * sizeof(int) + 10 * sizeof(double)) + (size_t)E * 9 * sizeof(double) + 16 * 64);
+    ar.reserve((size_t)ns * (4 * sizeof(int) + 3 + 10 * sizeof(double)) + (size_t)E * 9 * sizeof(double) + 32 * 64);
   } catch (const std::bad_alloc&) {
     c->err = "sgo_set_graph_se2: out of host memory for the staging buffers";
     return SGO_ENOMEM;
   }
-  HostBuf<int> row(ar, ns), col(ar, ns), svi(ar, ns), svj(ar, ns), flags(ar, ns);
+  HostBuf<int> col(ar, ns), svi(ar, ns), svj(ar, ns), own(ar, (size_t)ns + 1);
+  HostBuf<unsigned char> type(ar, ns), meta(ar, ns), flags(ar, ns);
   HostBuf<double> zinv(ar, 3 * (size_t)ns), sinfo(ar, 6 * (size_t)ns), sphi(ar, ns);
   HostBuf<double> ezinv(ar, 3 * (size_t)E), einfo(ar, 6 * (size_t)E);
   if (!einfo.p) {
     c->err = "sgo_set_graph_se2: internal error (staging arena too small)";
     return SGO_EINVAL;
   }
-  // the fills below are independent per row / per edge: spread them over the host cores.  Every
-  // slot is written exactly once: the diagonal slots here, the directed-edge slots below.
-  parallel_for(n, [&](int r0, int r1) {
-    for (int r = r0; r < r1; ++r) {
-      const int k = rowptr[r];
-      row[k] = r;
-      col[k] = r;
-      flags[k] = kSlotDiag;
-      svi[k] = svj[k] = 0;      // operands of a diagonal slot are never read (k_linearize skips it)
-      for (int q = 0; q < 3; ++q) zinv[q * (size_t)ns + k] = 0.0;
-      for (int q = 0; q < 6; ++q) sinfo[q * (size_t)ns + k] = 0.0;
-      sphi[k] = -1.0;
-    }
-  });
+  // every slot is written exactly once (each edge fills its one or two slots)
   parallel_for(E, [&](int e0, int e1) {
     for (int e = e0; e < e1; ++e) {
       // EdgeSE2::setMeasurement caches the inverse measurement on the host (computed once)
@@ -386,14 +440,16 @@ int build_structure(sgo_ctx* c, int V, const double* poses, const uint8_t* fixed
       const double cs = std::cos(th), sn = std::sin(th);
       const double zi[3] = {cs * (-z[0]) - sn * (-z[1]), sn * (-z[0]) + cs * (-z[1]), th};
       for (int q = 0; q < 3; ++q) ezinv[q * (size_t)E + e] = zi[q];
-      const int hi = hidx[ei[e]], hj = hidx[ej[e]];
+      for (int q = 0; q < 6; ++q) einfo[q * (size_t)E + e] = info[6 * (size_t)e + q];
+      const int hi = hpos[ei[e]], hj = hpos[ej[e]];
       for (int side = 0; side < 2; ++side) {
         const int hr = side ? hj : hi, hc = side ? hi : hj;
         if (hr < 0) continue;
         const int k = side ? pos_j[e] : pos_i[e];
-        row[k] = hr;
         col[k] = hc >= 0 ? hc : hr;
-        flags[k] = (side ? kSlotDir : 0) | (hc < 0 ? kSlotColFixed : 0);
+        // the block lives with the lower row; an edge to a fixed vertex has none
+        type[k] = (unsigned char)(hc < 0 ? kSlotNoBlock : (hr < hc ? kSlotOwned : kSlotTransposed));
+        flags[k] = (unsigned char)(side ? kSlotDir : 0);
         svi[k] = ei[e];
         svj[k] = ej[e];
         for (int q = 0; q < 3; ++q) zinv[q * (size_t)ns + k] = zi[q];
@@ -402,44 +458,141 @@ int build_structure(sgo_ctx* c, int V, const double* poses, const uint8_t* fixed
       }
     }
   });
+  // storage index of every owned slot = its rank among the owned slots (own[k]: exclusive count)
+  int nu = 0, ntr = 0;
+  for (int k = 0; k < ns; ++k) {
+    own[k] = nu;
+    nu += type[k] == kSlotOwned;
+    ntr += type[k] == kSlotTransposed;
+  }
+  own[ns] = nu;
   // wave groups: whole rows packed up to 64 slots; a longer row is its own group
-  std::vector<int> grp;
+  std::vector<int> grp, grow;
   grp.push_back(0);
   {
-    int cur = 0;
+    int cur = 0, first = 0;
     for (int r = 0; r < n; ++r) {
-      int len = rowptr[r + 1] - rowptr[r];
+      const int len = rowptr[r + 1] - rowptr[r];
       if (cur > 0 && cur + len > 64) {
         grp.push_back(rowptr[r]);
+        grow.push_back(first);
+        first = r;
         cur = 0;
       }
       cur += len;
       if (cur >= 64) {  // full (or a long row): close the group here
         grp.push_back(rowptr[r + 1]);
+        grow.push_back(first);
+        first = r + 1;
         cur = 0;
       }
     }
-    if (grp.back() != ns) grp.push_back(ns);
+    if (grp.back() != ns) {
+      grp.push_back(ns);
+      grow.push_back(first);
+    }
   }
   const int ngrp = (int)grp.size() - 1;
-
-  // edge list (original order) for chi2
+  std::vector<int> gown(ngrp), gtr(ngrp), tref((size_t)std::max(ntr, 1));
+  {
+    int t = 0;
+    for (int g = 0; g < ngrp; ++g) {
+      gown[g] = own[grp[g]];
+      gtr[g] = t;
+      for (int k = grp[g]; k < grp[g + 1]; ++k) t += type[k] == kSlotTransposed;
+    }
+  }
+  // meta bytes; transposed slots' references (the owner's slot of the same edge); logical structure for
+  // the multigrid set-up (diagonal slot first, then the row's block slots)
+  HostLevel& H = c->H0;
+  H.n = n;
+  H.rowptr.assign((size_t)n + 1, 0);
+  for (int r = 0; r < n; ++r) {
+    int nb = 1;
+    for (int k = rowptr[r]; k < rowptr[r + 1]; ++k) nb += type[k] != kSlotNoBlock;
+    H.rowptr[r + 1] = H.rowptr[r] + nb;
+  }
+  H.nslot = H.rowptr[n];
+  H.row.resize(H.nslot);
+  H.col.resize(H.nslot);
+  std::vector<int> lref(H.nslot);
+  std::vector<int> tslot((size_t)ns);   // compact slot -> position among the transposed slots
+  {
+    int t = 0;
+    for (int k = 0; k < ns; ++k) {
+      tslot[k] = t;
+      t += type[k] == kSlotTransposed;
+    }
+  }
   parallel_for(E, [&](int e0, int e1) {
-    for (int e = e0; e < e1; ++e)
-      for (int q = 0; q < 6; ++q) einfo[q * (size_t)E + e] = info[6 * (size_t)e + q];
+    for (int e = e0; e < e1; ++e) {
+      const int ki = pos_i[e], kj = pos_j[e];
+      if (ki < 0 || kj < 0) continue;
+      if (type[ki] == kSlotOwned) tref[tslot[kj]] = own[ki];
+      else tref[tslot[ki]] = own[kj];
+    }
+  });
+  parallel_for(ngrp, [&](int g0, int g1) {
+    for (int g = g0; g < g1; ++g) {
+      int r = grow[g];
+      for (int k = grp[g]; k < grp[g + 1]; ++k) {
+        while (k >= rowptr[r + 1]) ++r;
+        const int off = (grp[g + 1] - grp[g] > 64) ? 0 : r - grow[g];
+        meta[k] = (unsigned char)(off | (type[k] << 6));
+      }
+    }
+  });
+  parallel_for(n, [&](int r0, int r1) {
+    for (int r = r0; r < r1; ++r) {
+      int q = H.rowptr[r];
+      H.row[q] = r;
+      H.col[q] = r;
+      lref[q] = ~r;
+      ++q;
+      for (int k = rowptr[r]; k < rowptr[r + 1]; ++k) {
+        if (type[k] == kSlotNoBlock) continue;
+        H.row[q] = r;
+        H.col[q] = col[k];
+        lref[q] = type[k] == kSlotOwned ? (own[k] << 1) : ((tref[tslot[k]] << 1) | 1);
+        ++q;
+      }
+    }
   });
 
   const double tb1 = wall_s();
   int rc;
-  c->A.n = n;
-  c->A.nslot = ns;
-  c->A.ngrp = ngrp;
-  if ((rc = upload(c, &c->A.row, row))) return rc;
-  if ((rc = upload(c, &c->A.col, col))) return rc;
-  if ((rc = upload(c, &c->A.grp, grp))) return rc;
-  if ((rc = upload(c, &c->A.rowptr, rowptr))) return rc;
-  if ((rc = dalloc(c, &c->A.blk, 9 * (size_t)ns))) return rc;
-  if ((rc = dalloc(c, &c->A.dinv, 6 * (size_t)n))) return rc;
+  Sym0Dev& S = c->S0;
+  S.n = n;
+  S.nu = nu;
+  S.ncs = ns;
+  S.ngrp = ngrp;
+  if ((rc = upload(c, &S.col, col))) return rc;
+  if ((rc = upload(c, &S.meta, meta))) return rc;
+  if ((rc = upload(c, &S.tref, tref))) return rc;
+  if ((rc = upload(c, &S.grp, grp))) return rc;
+  if ((rc = upload(c, &S.grow, grow))) return rc;
+  if ((rc = upload(c, &S.gown, gown))) return rc;
+  if ((rc = upload(c, &S.gtr, gtr))) return rc;
+  if ((rc = dalloc(c, &S.ublk, 9 * (size_t)nu))) return rc;
+  if ((rc = dalloc(c, &S.dblk, 6 * (size_t)n))) return rc;
+  if ((rc = dalloc(c, &S.dinv, 6 * (size_t)n))) return rc;
+  // logical view for the multigrid set-up kernels
+  BsrDev& A = c->A;
+  A.n = n;
+  A.nslot = H.nslot;
+  A.ngrp = 0;
+  if ((rc = upload(c, &A.row, H.row))) return rc;
+  if ((rc = upload(c, &A.col, H.col))) return rc;
+  if ((rc = upload(c, &A.rowptr, H.rowptr))) return rc;
+  {
+    int* d_ref = nullptr;
+    if ((rc = upload(c, &d_ref, lref))) return rc;
+    A.ref = d_ref;
+  }
+  A.ublk = S.ublk;
+  A.nu = (size_t)nu;
+  A.dblk = S.dblk;
+  A.dinv = S.dinv;
   if ((rc = upload(c, &c->es.vi, svi))) return rc;
   if ((rc = upload(c, &c->es.vj, svj))) return rc;
   if ((rc = upload(c, &c->es.flags, flags))) return rc;
@@ -458,7 +611,7 @@ int build_structure(sgo_ctx* c, int V, const double* poses, const uint8_t* fixed
   }
   if ((rc = upload(c, &c->el.zinv, ezinv))) return rc;
   if ((rc = upload(c, &c->el.info, einfo))) return rc;
-  if ((rc = upload(c, &c->d_free_id, c->free_id))) return rc;
+  if ((rc = upload(c, &c->d_free_id, row_vertex))) return rc;
   if ((rc = dalloc(c, &c->d_poses, 3 * (size_t)V))) return rc;
   HIP_TRY(c, hipMemcpyAsync(c->d_poses, poses, sizeof(double) * 3 * (size_t)V, hipMemcpyHostToDevice, c->stream));
   const size_t n3 = 3 * (size_t)n;
@@ -480,8 +633,8 @@ int build_structure(sgo_ctx* c, int V, const double* poses, const uint8_t* fixed
   HIP_TRY(c, hipMemsetAsync(c->d_S, 0, sizeof(PcgScalars), c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));  // host staging vectors die at return
   if (c->opts.verbose)
-    std::fprintf(stderr, "[sgo] set_graph: host structure %.1f ms, alloc+upload %.1f ms\n", 1e3 * (tb1 - tb0),
-                 1e3 * (wall_s() - tb1));
+    std::fprintf(stderr, "[sgo] set_graph: host structure %.1f ms, alloc+upload %.1f ms (%d rows, %d stored blocks, %d slots)\n",
+                 1e3 * (tb1 - tb0), 1e3 * (wall_s() - tb1), n, nu, ns);
   return SGO_OK;
 }
 
@@ -508,7 +661,7 @@ int start_pcg(sgo_ctx* c, int grid) {
   if (c->amg) {
     int rc = amg_update(c->amg, c->stream, &c->err);
     if (rc) return rc;
-    const int gz = amg_apply(c->amg, c->stream, c->d_r, c->d_z, c->d_r, c->d_zparts, nullptr);
+    const int gz = amg_apply(c->amg, c->stream, c->d_r, c->d_z, c->d_r, c->d_zparts, nullptr, nullptr, true);
     HIP_TRY(c, hipMemcpyAsync(c->d_p, c->d_z, sizeof(double) * 3 * (size_t)c->n, hipMemcpyDeviceToDevice, c->stream));
     Scope sc(c, K_INIT_SCALARS, 8.0 * (gz + grid));
     launch_init_scalars(c->stream, c->d_S, c->d_zparts, gz, c->d_partials + kMaxPartials, grid, c->opts.pcg_tol * c->tol_scale,
@@ -526,25 +679,25 @@ int do_linearize(sgo_ctx* c) {
   // Multi-GPU: rank r evaluates the edges of its contiguous band of row groups (whole rows, so
   // every value is produced by exactly one rank); the other bands stay zero and the all-reduce
   // (sum with exact zeros) reproduces the single-GPU arrays bit for bit on every rank.
-  int g0 = 0, g1 = c->A.ngrp;
+  int g0 = 0, g1 = c->S0.ngrp;
   if (c->comm.nranks > 1) {
-    sgo_shard_range(c->A.ngrp, c->comm.nranks, c->comm.rank, &g0, &g1);
-    HIP_TRY(c, hipMemsetAsync(c->A.blk, 0, sizeof(double) * 9 * (size_t)c->A.nslot, c->stream));
+    sgo_shard_range(c->S0.ngrp, c->comm.nranks, c->comm.rank, &g0, &g1);
+    HIP_TRY(c, hipMemsetAsync(c->S0.ublk, 0, sizeof(double) * 9 * (size_t)c->S0.nu, c->stream));
     HIP_TRY(c, hipMemsetAsync(c->d_dgb, 0, sizeof(double) * 9 * (size_t)c->n, c->stream));
   }
   {
-    Scope sc(c, K_LINEARIZE, bytes_linearize(c) * (double)(g1 - g0) / std::max(1, c->A.ngrp));
-    launch_linearize(c->stream, c->A, g0, g1, c->es, c->d_poses, c->d_dgb);
+    Scope sc(c, K_LINEARIZE, bytes_linearize(c) * (double)(g1 - g0) / std::max(1, c->S0.ngrp));
+    launch_linearize(c->stream, c->S0, g0, g1, c->es, c->d_poses, c->d_dgb);
   }
   if (c->comm.nranks > 1) {
-    if (!c->comm.allreduce_f64(c->A.blk, 9 * (size_t)c->A.nslot, c->stream, &c->err)) return SGO_ECOMM;
+    if (!c->comm.allreduce_f64(c->S0.ublk, 9 * (size_t)c->S0.nu, c->stream, &c->err)) return SGO_ECOMM;
     if (!c->comm.allreduce_f64(c->d_dgb, 9 * (size_t)c->n, c->stream, &c->err)) return SGO_ECOMM;
   }
   int grid = 0;
   {
-    Scope sc(c, K_FINALIZE, (72.0 + 72.0 + 48.0 + 5 * 24.0) * c->n);
-    launch_finalize(c->stream, c->A, c->d_dgb, 1, c->d_b, c->d_x, c->d_r, c->d_z, c->d_p,
-                    c->d_partials, &grid);
+    Scope sc(c, K_FINALIZE, (72.0 + 48.0 + 48.0 + 6 * 24.0) * c->n);
+    launch_finalize(c->stream, c->S0, c->d_dgb, c->d_b, c->d_x, c->d_r, c->d_z, c->d_p,
+                    c->amg ? amg_xs0(c->amg) : nullptr, c->amg ? amg_omega(c->amg) : 0.0, c->d_partials, &grid);
   }
   int rc = start_pcg(c, grid);
   if (rc) return rc;
@@ -555,8 +708,17 @@ int do_linearize(sgo_ctx* c) {
 // y = H x  (+ optional x.y partials).  The solve is replicated on every rank (identical H after
 // the all-reduce in do_linearize), so no collective is needed here.
 int do_spmv(sgo_ctx* c, const double* x, double* y, bool dot, const PcgScalars* S, int* grid_out) {
-  Scope sc(c, K_SPMV_AX_L0, bytes_spmv(c->A));
-  launch_spmv(c->stream, c->A, x, y, dot ? c->d_partials : nullptr, S, grid_out);
+  Scope sc(c, K_SPMV0_AX, bytes_spmv0(c->S0, S0_AX));
+  Spmv0Args a{};
+  a.x = x;
+  a.y = y;
+  a.S = S;
+  if (dot) {
+    a.dotA = x;
+    a.partials = c->d_partials;
+  }
+  const int grid = launch_spmv0(c->stream, c->S0, S0_AX, a);
+  if (grid_out) *grid_out = grid;
   return SGO_OK;
 }
 
@@ -565,13 +727,14 @@ int pcg_iteration(sgo_ctx* c) {
   if ((rc = do_spmv(c, c->d_p, c->d_q, true, c->d_S, &g1))) return rc;
   double* parts2 = c->d_partials + kMaxPartials;  // [0] = r.z (block-Jacobi only), [1] = r.r
   {
+    // block-Jacobi: z = Dinv r; multigrid: xs = omega Dinv r, the cycle's first level-0 sweep from zero
     Scope sc(c, K_UPDATE_XR, (7 * 24.0 + 48.0) * c->n);
-    launch_update_xr(c->stream, c->n, c->d_S, c->d_partials, g1, c->amg ? nullptr : c->A.dinv, c->d_p, c->d_q, c->d_x,
-                     c->d_r, c->d_z, parts2, &g2);
+    launch_update_xr(c->stream, c->n, c->d_S, c->d_partials, g1, c->S0.dinv, c->d_p, c->d_q, c->d_x, c->d_r, c->d_z,
+                     c->amg ? amg_xs0(c->amg) : nullptr, c->amg ? amg_omega(c->amg) : 0.0, parts2, &g2);
   }
   if (c->amg) {
     // the K-cycle is a (mildly) variable preconditioner: flexible beta from z.q
-    const int gz = amg_apply(c->amg, c->stream, c->d_r, c->d_z, c->d_r, c->d_zparts, c->d_S, c->d_q);
+    const int gz = amg_apply(c->amg, c->stream, c->d_r, c->d_z, c->d_r, c->d_zparts, c->d_S, c->d_q, true);
     Scope sc(c, K_UPDATE_P, 3 * 24.0 * c->n);
     launch_update_p(c->stream, c->n, c->d_S, c->d_zparts, gz, parts2 + kMaxPartials, g2, c->d_zparts + kMaxPartials,
                     c->d_z, c->d_p);
@@ -691,7 +854,7 @@ int build_amg(sgo_ctx* c) {
     cc->amg_scope = nullptr;
   };
   std::string aerr;
-  c->amg = amg_create(c->stream, c->A, c->d_poses, c->d_free_id, cfg, prof, &aerr, &c->amg_scratch);
+  c->amg = amg_create(c->stream, c->A, c->S0, c->H0, c->d_poses, c->d_free_id, cfg, prof, &aerr, &c->amg_scratch);
   if (c->amg) {
     amg_describe(c->amg, &c->solver_desc);
     c->solver_desc = "pcg_amg: " + c->solver_desc;
@@ -699,6 +862,25 @@ int build_amg(sgo_ctx* c) {
     c->solver_desc = "pcg_block_jacobi (AMG unavailable: " + aerr + ")";
     if (c->opts.verbose) std::fprintf(stderr, "[sgo] %s\n", c->solver_desc.c_str());
   }
+  return SGO_OK;
+}
+
+// Vectors over the free vertices cross the API in g2o's hessian order and live on the device in the
+// internal (Hilbert) row order: permute on the way (test / single-step entry points only).
+int vec_to_device(sgo_ctx* c, const double* host_asc, double* dev) {
+  std::vector<double> tmp(3 * (size_t)c->n);
+  for (int i = 0; i < c->n; ++i)
+    for (int q = 0; q < 3; ++q) tmp[3 * (size_t)c->row_of_asc[i] + q] = host_asc[3 * (size_t)i + q];
+  HIP_TRY(c, hipMemcpyAsync(dev, tmp.data(), sizeof(double) * tmp.size(), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return SGO_OK;
+}
+int vec_from_device(sgo_ctx* c, const double* dev, double* host_asc) {
+  std::vector<double> tmp(3 * (size_t)c->n);
+  HIP_TRY(c, hipMemcpyAsync(tmp.data(), dev, sizeof(double) * tmp.size(), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  for (int i = 0; i < c->n; ++i)
+    for (int q = 0; q < 3; ++q) host_asc[3 * (size_t)i + q] = tmp[3 * (size_t)c->row_of_asc[i] + q];
   return SGO_OK;
 }
 
@@ -843,7 +1025,7 @@ int sgo_set_graph_se2(sgo_ctx* c, int32_t V, const double* poses, const uint8_t*
   // residual of 1e-8 then leaves errors that show in chi2 (3000 poses / 3150 edges: iterates 3e-6 and
   // poses 7e-5 m from the direct-solver oracle at 1e-8, 1.4e-8 at 1e-9).  Their PCG iterations are the
   // cheap ones, so they get a 10x tighter tolerance than opts.pcg_tol.
-  c->tol_scale = (c->n > 0 && (long long)c->A.nslot < 4LL * c->n) ? 0.1 : 1.0;
+  c->tol_scale = (c->n > 0 && (long long)c->A.nslot < 4LL * c->n) ? 0.1 : 1.0;   // logical slots: 2 per edge + 1 per row
   c->solver_desc = "pcg_block_jacobi";
   if (c->opts.solver == SGO_SOLVER_PCG_AMG && c->n > 0 && (c->comm.nranks == 1 || c->comm.handle)) {
     // the hierarchy is built from the Hessian at the initial poses (strength of connection)
@@ -980,8 +1162,8 @@ int sgo_linearize(sgo_ctx* c, double* b, double* diag, double* plain, double* ro
   HIP_TRY(c, hipMemcpyAsync(dgb.data(), c->d_dgb, sizeof(double) * dgb.size(), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipMemcpyAsync(c->h_hist, c->d_hist, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
-  for (int i = 0; i < c->n; ++i) {
-    const double* d = &dgb[9 * (size_t)i];
+  for (int i = 0; i < c->n; ++i) {   // i: hessian index (g2o order); its values sit in internal row row_of_asc[i]
+    const double* d = &dgb[9 * (size_t)c->row_of_asc[i]];
     if (diag) {
       double* D = diag + 9 * (size_t)i;
       D[0] = d[0]; D[1] = d[1]; D[2] = d[2];
@@ -1007,12 +1189,9 @@ int sgo_hessian_apply(sgo_ctx* c, const double* x, double* y) {
     c->err = "sgo_hessian_apply: call sgo_linearize first";
     return SGO_EINVAL;
   }
-  const size_t bytes = sizeof(double) * 3 * (size_t)c->n;
-  HIP_TRY(c, hipMemcpyAsync(c->d_s1, x, bytes, hipMemcpyHostToDevice, c->stream));
+  if ((rc = vec_to_device(c, x, c->d_s1))) return rc;
   if ((rc = do_spmv(c, c->d_s1, c->d_s2, false, nullptr, nullptr))) return rc;
-  HIP_TRY(c, hipMemcpyAsync(y, c->d_s2, bytes, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
-  return SGO_OK;
+  return vec_from_device(c, c->d_s2, y);
 }
 
 int sgo_precondition(sgo_ctx* c, const double* r, double* z) {
@@ -1023,13 +1202,10 @@ int sgo_precondition(sgo_ctx* c, const double* r, double* z) {
     c->err = "sgo_precondition: call sgo_linearize first";
     return SGO_EINVAL;
   }
-  const size_t bytes = sizeof(double) * 3 * (size_t)c->n;
-  HIP_TRY(c, hipMemcpyAsync(c->d_s1, r, bytes, hipMemcpyHostToDevice, c->stream));
+  if ((rc = vec_to_device(c, r, c->d_s1))) return rc;
   if (c->amg) amg_apply(c->amg, c->stream, c->d_s1, c->d_s2, nullptr, nullptr, nullptr);
-  else launch_precond_bj(c->stream, c->n, c->A.dinv, c->d_s1, c->d_s2);
-  HIP_TRY(c, hipMemcpyAsync(z, c->d_s2, bytes, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
-  return SGO_OK;
+  else launch_precond_bj(c->stream, c->n, c->S0.dinv, c->d_s1, c->d_s2, 1.0);
+  return vec_from_device(c, c->d_s2, z);
 }
 
 int sgo_solve(sgo_ctx* c, double* x, double* relres) {
@@ -1041,14 +1217,11 @@ int sgo_solve(sgo_ctx* c, double* x, double* relres) {
   }
   // restart from the state of the last linearisation (idempotent re-finalize)
   int grid = 0;
-  launch_finalize(c->stream, c->A, c->d_dgb, 1, c->d_b, c->d_x, c->d_r, c->d_z, c->d_p,
-                  c->d_partials, &grid);
+  launch_finalize(c->stream, c->S0, c->d_dgb, c->d_b, c->d_x, c->d_r, c->d_z, c->d_p,
+                  c->amg ? amg_xs0(c->amg) : nullptr, c->amg ? amg_omega(c->amg) : 0.0, c->d_partials, &grid);
   if ((rc = start_pcg(c, grid))) return rc;
   if ((rc = run_pcg(c))) return rc;
-  if (x) {
-    HIP_TRY(c, hipMemcpyAsync(x, c->d_x, sizeof(double) * 3 * (size_t)c->n, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-  }
+  if (x && (rc = vec_from_device(c, c->d_x, x))) return rc;
   if (relres) *relres = c->h_S->bb > 0 ? std::sqrt(c->h_S->rr / c->h_S->bb) : 0.0;
   if (c->h_S->stop == 3) {
     c->err = "PCG breakdown (p.Hp <= 0 or non-finite): Hessian not positive definite";

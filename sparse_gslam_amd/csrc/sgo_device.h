@@ -112,6 +112,35 @@ __device__ __forceinline__ void seg_scan(int row, double (&v)[N], int lane) {
   }
 }
 
+// Row-major 3x3 block of LOGICAL slot k of a level's operator: from the slot-indexed pair-SoA array on
+// the coarse levels; on level 0 through ref[] from the symmetric storage (diagonal blocks in symmetric
+// packing, off-diagonal blocks stored once and transposed for the other endpoint's row).
+__device__ __forceinline__ void load_block(const BsrDev& A, size_t k, double (&b)[9]) {
+  if (A.ref == nullptr) {
+    const size_t ns = (size_t)A.nslot;
+#pragma unroll
+    for (int c = 0; c < 9; ++c) b[c] = A.blk[blk_at(c, k, ns)];
+    return;
+  }
+  const int r = A.ref[k];
+  if (r < 0) {
+    const double* d = A.dblk + 6 * (size_t)(~r);
+    b[0] = d[0]; b[1] = d[1]; b[2] = d[2];
+    b[3] = d[1]; b[4] = d[3]; b[5] = d[4];
+    b[6] = d[2]; b[7] = d[4]; b[8] = d[5];
+    return;
+  }
+  const size_t u = (size_t)(r >> 1);
+  double t[9];
+#pragma unroll
+  for (int c = 0; c < 9; ++c) t[c] = A.ublk[blk_at(c, u, A.nu)];
+  const bool tr = r & 1;
+  b[0] = t[0]; b[4] = t[4]; b[8] = t[8];
+  b[1] = tr ? t[3] : t[1]; b[3] = tr ? t[1] : t[3];
+  b[2] = tr ? t[6] : t[2]; b[6] = tr ? t[2] : t[6];
+  b[5] = tr ? t[7] : t[5]; b[7] = tr ? t[5] : t[7];
+}
+
 // Map (block, wave) -> first group and stride so that XCD x (blocks with blockIdx % 8 == x under
 // the observed round-robin dispatch; speed only, never correctness) walks the contiguous band
 // [x * ngrp / 8, (x + 1) * ngrp / 8) of groups.

@@ -15,7 +15,8 @@
 namespace sgo {
 
 // ----------------------------------------------------------------------------------------
-// Block-CSR matrix with 3x3 fp64 blocks in "slot list sorted by row" form.
+// Block-CSR matrix with 3x3 fp64 blocks in "slot list sorted by row" form (the LOGICAL view of a
+// multigrid level's operator, and the storage of every level but the finest):
 //   * slot k belongs to block row row[k] and multiplies column col[k];
 //   * the FIRST slot of every row is that row's diagonal block;
 //   * blk is SoA over slots in component pairs (blk_at below): component c (row-major 3x3) of
@@ -24,6 +25,12 @@ namespace sgo {
 //   * grp[g] .. grp[g+1] is the slot range of wave-group g.  Groups are row aligned: a group
 //     holds whole rows (<= 64 slots) or exactly one long row (> 64 slots), so the segmented
 //     reduction of a row never leaves the wave and needs neither LDS hand-off nor atomics.
+// The finest level keeps its VALUES in the symmetric storage of Sym0Dev (every off-diagonal block
+// once); its logical view then has blk == nullptr and ref[k] says where slot k's block lives:
+//   ref[k] < 0   diagonal block of row ~ref[k]  (dblk, symmetric packing)
+//   ref[k] >= 0  off-diagonal block ublk[ref[k] >> 1], transposed when ref[k] & 1.
+// Only the per-GN-iteration set-up kernels of the multigrid hierarchy read level 0 through this
+// view (load_block in sgo_device.h); the products of the solve run on Sym0Dev directly.
 // ----------------------------------------------------------------------------------------
 struct BsrDev {
   int n = 0;          // block rows
@@ -33,8 +40,13 @@ struct BsrDev {
   int* col = nullptr;
   int* grp = nullptr;     // [ngrp + 1]
   int* rowptr = nullptr;  // [n + 1]
-  double* blk = nullptr;  // 9 * nslot doubles, layout blk_at()
+  double* blk = nullptr;  // 9 * nslot doubles, layout blk_at()   (nullptr on level 0)
   double* dinv = nullptr; // [n][6] inverse of the diagonal block, symmetric packing
+  // level 0 only: references into the symmetric storage
+  const int* ref = nullptr;     // [nslot]
+  const double* ublk = nullptr; // pair-SoA over nu stored off-diagonal blocks
+  size_t nu = 0;
+  const double* dblk = nullptr; // [n][6]
 };
 
 // Block storage ("pair-SoA"): components (0,1), (2,3), (4,5), (6,7) of slot k are adjacent pairs --
@@ -45,17 +57,57 @@ __host__ __device__ inline size_t blk_at(int c, size_t k, size_t ns) {
   return c < 8 ? 2 * ((size_t)(c >> 1) * ns + k) + (size_t)(c & 1) : 8 * ns + k;
 }
 
-// Directed-edge operands aligned with the level-0 slots (SoA over slots).  For a slot of row
-// r that came from edge e = (i, j):  dir = 0 when r is the i side (row Jacobian A), 1 when r is
-// the j side (row Jacobian B).  Diagonal slots carry flag kSlotDiag and no edge data.
-enum : int { kSlotDir = 1, kSlotColFixed = 2, kSlotDiag = 4 };
+// ----------------------------------------------------------------------------------------
+// Level-0 Hessian in SYMMETRIC storage: H is symmetric, so every off-diagonal block is stored once
+// (72 B + indices per edge) and serves both y_i += B x_j and y_j += B^T x_i.
+//   * rows are numbered in Hilbert-curve order of the poses (sgo_api.cpp), which puts the two
+//     endpoints of almost every edge -- odometry steps and closures between nearby poses alike --
+//     a few hundred rows apart;
+//   * the compact slot list has, per row, one slot per incident off-diagonal block: the slot is
+//     OWNED (the block is stored with this row; owned slots of consecutive rows are consecutive in
+//     ublk, so their loads stream) or TRANSPOSED (the block is stored with the other endpoint's row;
+//     the lane fetches it through tref and multiplies by its transpose).  Thanks to the ordering the
+//     owner's row was streamed moments earlier by a neighbouring wave of the same XCD, so the second
+//     read is an L2 hit: HBM / Infinity-Cache traffic is that of the symmetric storage, and no
+//     atomics or scatter are needed -- every row is still summed by a wavefront segmented scan in a
+//     fixed order (bitwise reproducible);
+//   * an edge to a FIXED vertex has a slot without a block (it contributes to the row's diagonal
+//     block and right-hand side only), a row without any edge to a free vertex gets one such slot;
+//   * diagonal blocks live apart in symmetric packing (dblk, 48 B per row) and are applied by the
+//     row's last lane.
+// Per slot: col (4 B) and meta (1 B: row - grow[g] in bits 0..5, type in bits 6..7); per transposed
+// slot: tref (4 B).  The storage index of an owned slot is gown[g] + its rank among the group's owned
+// slots (ballot + popcount), that of a transposed slot tref[gtr[g] + rank].
+// ----------------------------------------------------------------------------------------
+enum : int { kSlotOwned = 0, kSlotTransposed = 1, kSlotNoBlock = 2 };
+struct Sym0Dev {
+  int n = 0;        // rows
+  int nu = 0;       // stored off-diagonal blocks
+  int ncs = 0;      // compact slots
+  int ngrp = 0;
+  int* col = nullptr;            // [ncs]
+  unsigned char* meta = nullptr; // [ncs]
+  int* tref = nullptr;           // [number of transposed slots]
+  int* grp = nullptr;            // [ngrp + 1] slot range of wave group g (whole rows)
+  int* grow = nullptr;           // [ngrp] first row of group g
+  int* gown = nullptr;           // [ngrp] storage index of the group's first owned slot
+  int* gtr = nullptr;            // [ngrp] position in tref of the group's first transposed slot
+  double* ublk = nullptr;        // pair-SoA [nu]
+  double* dblk = nullptr;        // [n][6]
+  double* dinv = nullptr;        // [n][6]
+};
+
+// Edge operands aligned with the level-0 compact slots (SoA over slots).  For a slot of row r that
+// came from edge e = (i, j):  dir = 0 when r is the i side (row Jacobian A), 1 when r is the j side
+// (row Jacobian B).
+enum : int { kSlotDir = 1, kSlotNoEdge = 2 };
 struct EdgeSlotsDev {
   int* vi = nullptr;      // vertex id of EdgeSE2::vertices()[0]
   int* vj = nullptr;      // vertex id of EdgeSE2::vertices()[1]
-  int* flags = nullptr;
-  double* zinv = nullptr; // [3][nslot] cached inverse measurement (EdgeSE2::setMeasurement)
-  double* info = nullptr; // [6][nslot]
-  double* phi = nullptr;  // [nslot]
+  unsigned char* flags = nullptr;
+  double* zinv = nullptr; // [3][ncs] cached inverse measurement (EdgeSE2::setMeasurement)
+  double* info = nullptr; // [6][ncs]
+  double* phi = nullptr;  // [ncs]
 };
 
 // Original edge list (edge order of sgo_set_graph_se2), SoA, for chi2 / per-edge chi2.
@@ -121,6 +173,19 @@ struct SpmvArgs {
   double* x_out = nullptr;
 };
 
+// k_spmv0 (level 0, symmetric storage) modes and arguments
+enum : int { S0_AX = 0, S0_RESID = 1, S0_JACOBI = 2 };
+struct Spmv0Args {
+  const double* x = nullptr;     // gathered operand
+  double* y = nullptr;           // output
+  const double* b = nullptr;     // right-hand side (RESID, JACOBI)
+  double omega = 0.0;
+  const double* dotA = nullptr;  // partials[0] += dotA . y
+  const double* dotA2 = nullptr; // partials[1] += dotA2 . y
+  double* partials = nullptr;    // [2][kMaxPartials]
+  const PcgScalars* S = nullptr; // optional early-out flag
+};
+
 // One profiling slot per __global__ symbol (template instantiations separately), named as
 // rocprofv3 --kernel-trace prints them, so bench.py's event timings can be checked 1:1 against
 // the committed rocprof summaries.
@@ -157,9 +222,9 @@ enum KernelId : int {
   K_RESTRICT_P,
   K_PROLONG_P,
   K_SPMV_PRE_RESID_ACC,
-  K_SPMV_AX_L0,         // the level-0 launches of the three block-stream kernels, kept apart from
-  K_SPMV_JACOBI_L0,     // the same kernels' launches on coarse levels (names end in " @level0")
-  K_SPMV_PRE_RESID_L0,
+  K_SPMV0_AX,           // the level-0 products on the symmetric storage
+  K_SPMV0_RESID,
+  K_SPMV0_JACOBI,
   K_COUNT
 };
 extern const char* const kKernelNames[K_COUNT];
@@ -254,18 +319,17 @@ extern thread_local LaunchEvents tl_launch_ev;
 void launch_chi2(hipStream_t s, const EdgeListDev& el, int e0, int e1, const double* poses, double* e2_out,
                  double* partials /*[2][kMaxPartials]*/, int* grid_out);
 void launch_reduce2(hipStream_t s, const double* partials, int nparts, double* out2);
-void launch_linearize(hipStream_t s, const BsrDev& A, int g0, int g1, const EdgeSlotsDev& es, const double* poses,
+void launch_linearize(hipStream_t s, const Sym0Dev& A, int g0, int g1, const EdgeSlotsDev& es, const double* poses,
                       double* dgb /*[n][9]*/);
-void launch_finalize(hipStream_t s, const BsrDev& A, const double* dgb, int write_diag, double* b,
-                     double* x, double* r, double* z, double* p, double* partials, int* grid_out);
+void launch_finalize(hipStream_t s, const Sym0Dev& A, const double* dgb, double* b, double* x, double* r, double* z,
+                     double* p, double* xs, double omega, double* partials, int* grid_out);
 void launch_init_scalars(hipStream_t s, PcgScalars* S, const double* rz_parts, int n_rz, const double* bb_parts,
                          int n_bb, double tol, int maxit);
-void launch_spmv(hipStream_t s, const BsrDev& A, const double* x, double* y, double* dot_partials,
-                 const PcgScalars* S, int* grid_out);
+int launch_spmv0(hipStream_t s, const Sym0Dev& A, int mode, const Spmv0Args& a);   // returns grid
 int launch_spmv_ex(hipStream_t s, const BsrDev& A, int mode, const SpmvArgs& a);  // returns grid
 void launch_update_xr(hipStream_t s, int n, PcgScalars* S, const double* pq_parts, int n_pq, const double* dinv,
-                      const double* p, const double* q, double* x, double* r, double* z, double* partials,
-                      int* grid_out);
+                      const double* p, const double* q, double* x, double* r, double* z, double* xs, double omega,
+                      double* partials, int* grid_out);
 void launch_update_p(hipStream_t s, int n, PcgScalars* S, const double* rz_parts, int n_rz, const double* rr_parts,
                      int n_rr, const double* zq_parts, const double* z, double* p);
 void launch_pose_update(hipStream_t s, int n, const int* free_id, const double* x, double* poses);
@@ -273,6 +337,6 @@ void launch_closure_cov(hipStream_t s, int n, const sgo_match_window* win, const
                         double* info);
 void launch_dot(hipStream_t s, int n3, const double* a, const double* b, double* partials, const PcgScalars* S,
                 int* grid_out);
-void launch_precond_bj(hipStream_t s, int n, const double* dinv, const double* r, double* z);
+void launch_precond_bj(hipStream_t s, int n, const double* dinv, const double* r, double* z, double scale);
 
 }  // namespace sgo

@@ -32,7 +32,7 @@ const char* const kKernelNames[K_COUNT] = {
     "k_pose_update", "k_positions0", "k_centres",   "k_galerkin",   "k_level_dinv",   "k_restrict", "k_prolong_add",
     "k_gj_panels+k_gj_trail (dense inverse)", "k_dense_apply", "k_p_values", "k_block_products<1, 0, 0>",
     "k_block_products<0, 1, 1>", "k_restrict_p", "k_prolong_p", "k_spmv<7>",
-    "k_spmv<0> @level0", "k_spmv<2> @level0", "k_spmv<3> @level0"};
+    "k_spmv0<0>", "k_spmv0<1>", "k_spmv0<2>"};
 
 namespace {
 
@@ -114,26 +114,37 @@ __global__ __launch_bounds__(kBlock) void k_reduce2(const double* __restrict__ p
 }
 
 // ---------------------------------------------------------------------------- k_linearize
-// One lane per slot.  For a directed slot (row r, edge (i,j)): row Jacobian Jr = A (dir 0) or B
-// (dir 1), column Jacobian Jc the other one;  writes the off-diagonal block Jr^T Ow Jc into the
-// slot, and segment-sums Jr^T Ow Jr (6 unique) and -Jr^T Ow e (3) over the row; the row's last
-// lane stores them to dgb[r][0..8].
-__global__ __launch_bounds__(kBlock) void k_linearize(BsrDev A, int g0, int g1, EdgeSlotsDev es,
+// One lane per compact slot of the level-0 matrix (Sym0Dev).  For a slot of row r that came from edge
+// (i,j): row Jacobian Jr = A (dir 0) or B (dir 1), column Jacobian Jc the other one; the lane
+// segment-sums Jr^T Ow Jr (6 unique) and -Jr^T Ow e (3) over the row -- the row's last lane stores them
+// to dgb[r][0..8] -- and, when the slot OWNS the block, writes the off-diagonal block Jr^T Ow Jc into the
+// symmetric storage (the transposed slot of the other endpoint's row evaluates the same edge for its
+// own row sums and writes nothing: recompute instead of scatter).
+__global__ __launch_bounds__(kBlock) void k_linearize(Sym0Dev A, int g0, int g1, EdgeSlotsDev es,
                                                       const double* __restrict__ poses, double* __restrict__ dgb) {
   const int lane = threadIdx.x & 63;
-  const size_t ns = (size_t)A.nslot;
+  const size_t ns = (size_t)A.ncs, nu = (size_t)A.nu;
   int g, gend, gstride;
   group_walk(g1 - g0, &g, &gend, &gstride);   // this rank's band of row groups [g0, g1)
   g += g0;
   gend += g0;
   for (; g < gend; g += gstride) {
-    const int gb = A.grp[g], ge = A.grp[g + 1];
+    const int gb = A.grp[g], ge = A.grp[g + 1], r0 = A.grow[g];
+    int ob = A.gown[g];
     double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     int row = -1 - lane;  // inactive lanes: unique negative keys (never merge)
-    for (int k = gb + lane; k < ge; k += 64) {
-      row = A.row[k];
+    for (int kb = gb; kb < ge; kb += 64) {
+      const int k = kb + lane;
+      const bool active = k < ge;
+      const int m = active ? (int)A.meta[k] : (kSlotNoBlock << 6);
+      const bool owned = active && (m >> 6) == kSlotOwned;
+      const unsigned long long omask = __ballot(owned);
+      const int idx = ob + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(omask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)omask, 0u));
+      ob += __popcll(omask);
+      if (!active) continue;
+      row = r0 + (m & 63);
       const int fl = es.flags[k];
-      if (fl & kSlotDiag) continue;
+      if (fl & kSlotNoEdge) continue;
       const int vi = es.vi[k], vj = es.vj[k];
       const double xi = poses[3 * (size_t)vi], yi = poses[3 * (size_t)vi + 1], ti = poses[3 * (size_t)vi + 2];
       const double xj = poses[3 * (size_t)vj], yj = poses[3 * (size_t)vj + 1], tj = poses[3 * (size_t)vj + 2];
@@ -148,8 +159,8 @@ __global__ __launch_bounds__(kBlock) void k_linearize(BsrDev A, int g0, int g1, 
       double oe1 = o01 * e[0] + o11 * e[1] + o12 * e[2];
       double oe2 = o02 * e[0] + o12 * e[1] + o22 * e[2];
       const double e2 = e[0] * oe0 + e[1] * oe1 + e[2] * oe2;
-      double r0, w;
-      dcs(e2, es.phi[k], &r0, &w);
+      double r0_, w;
+      dcs(e2, es.phi[k], &r0_, &w);
       // robustInformation: Ow = rho1 * Omega ; omega_r scaled by rho1
       const double w00 = w * o00, w01 = w * o01, w02 = w * o02, w11 = w * o11, w12 = w * o12, w22 = w * o22;
       oe0 *= w; oe1 *= w; oe2 *= w;
@@ -167,9 +178,6 @@ __global__ __launch_bounds__(kBlock) void k_linearize(BsrDev A, int g0, int g1, 
       const double R00 = dir ? B00 : A00, R01 = dir ? B01 : A01, R02 = dir ? 0.0 : A02;
       const double R10 = dir ? B10 : A10, R11 = dir ? B11 : A11, R12 = dir ? 0.0 : A12;
       const double R22 = dir ? 1.0 : -1.0;
-      const double C00 = dir ? A00 : B00, C01 = dir ? A01 : B01, C02 = dir ? A02 : 0.0;
-      const double C10 = dir ? A10 : B10, C11 = dir ? A11 : B11, C12 = dir ? A12 : 0.0;
-      const double C22 = dir ? -1.0 : 1.0;
       // T = Ow * R  (3x3), R has zero entries (2,0),(2,1)
       const double T00 = w00 * R00 + w01 * R10, T01 = w00 * R01 + w01 * R11, T02 = w00 * R02 + w01 * R12 + w02 * R22;
       const double T10 = w01 * R00 + w11 * R10, T11 = w01 * R01 + w11 * R11, T12 = w01 * R02 + w11 * R12 + w12 * R22;
@@ -185,24 +193,18 @@ __global__ __launch_bounds__(kBlock) void k_linearize(BsrDev A, int g0, int g1, 
       acc[6] -= R00 * oe0 + R10 * oe1;
       acc[7] -= R01 * oe0 + R11 * oe1;
       acc[8] -= R02 * oe0 + R12 * oe1 + R22 * oe2;
-      // off-diagonal block  R^T Ow C = T^T C   (T^T because Ow is symmetric: R^T Ow = (Ow R)^T)
-      double h[9];
-      if (fl & kSlotColFixed) {
-#pragma unroll
-        for (int c = 0; c < 9; ++c) h[c] = 0.0;
-      } else {
-        h[0] = T00 * C00 + T10 * C10;
-        h[1] = T00 * C01 + T10 * C11;
-        h[2] = T00 * C02 + T10 * C12 + T20 * C22;
-        h[3] = T01 * C00 + T11 * C10;
-        h[4] = T01 * C01 + T11 * C11;
-        h[5] = T01 * C02 + T11 * C12 + T21 * C22;
-        h[6] = T02 * C00 + T12 * C10;
-        h[7] = T02 * C01 + T12 * C11;
-        h[8] = T02 * C02 + T12 * C12 + T22 * C22;
+      if (owned) {
+        // off-diagonal block  R^T Ow C = T^T C   (T^T because Ow is symmetric: R^T Ow = (Ow R)^T)
+        const double C00 = dir ? A00 : B00, C01 = dir ? A01 : B01, C02 = dir ? A02 : 0.0;
+        const double C10 = dir ? A10 : B10, C11 = dir ? A11 : B11, C12 = dir ? A12 : 0.0;
+        const double C22 = dir ? -1.0 : 1.0;
+        double2* __restrict__ bp = reinterpret_cast<double2*>(A.ublk);
+        bp[idx] = make_double2(T00 * C00 + T10 * C10, T00 * C01 + T10 * C11);
+        bp[nu + idx] = make_double2(T00 * C02 + T10 * C12 + T20 * C22, T01 * C00 + T11 * C10);
+        bp[2 * nu + idx] = make_double2(T01 * C01 + T11 * C11, T01 * C02 + T11 * C12 + T21 * C22);
+        bp[3 * nu + idx] = make_double2(T02 * C00 + T12 * C10, T02 * C01 + T12 * C11);
+        A.ublk[8 * nu + idx] = T02 * C02 + T12 * C12 + T22 * C22;
       }
-#pragma unroll
-      for (int c = 0; c < 9; ++c) A.blk[blk_at(c, k, ns)] = h[c];
     }
     seg_scan<9>(row, acc, lane);
     const int rn = __shfl_down(row, 1);
@@ -215,23 +217,21 @@ __global__ __launch_bounds__(kBlock) void k_linearize(BsrDev A, int g0, int g1, 
 }
 
 // ---------------------------------------------------------------------------- k_finalize
-// Per row: diagonal slot, block-diagonal inverse, and the PCG start state
+// Per row: diagonal block (symmetric packing), block-diagonal inverse, and the PCG start state
 //   x = 0, r = b, z = Dinv b, p = z ; partials[0][blk] = r.z, partials[1][blk] = b.b
-__global__ __launch_bounds__(kBlock) void k_finalize(BsrDev A, const double* __restrict__ dgb, int write_diag,
+// and, for the multigrid cycle's first smoothing sweep from zero, xs = omega Dinv b.
+__global__ __launch_bounds__(kBlock) void k_finalize(Sym0Dev A, const double* __restrict__ dgb,
                                                      double* __restrict__ b, double* __restrict__ x,
                                                      double* __restrict__ r, double* __restrict__ z,
-                                                     double* __restrict__ p, double* __restrict__ partials) {
+                                                     double* __restrict__ p, double* __restrict__ xs, double omega,
+                                                     double* __restrict__ partials) {
   double acc[2] = {0.0, 0.0};
-  const size_t ns = (size_t)A.nslot;
   for (int i = blockIdx.x * kBlock + threadIdx.x; i < A.n; i += gridDim.x * kBlock) {
     const double* d = dgb + 9 * (size_t)i;
     const double d00 = d[0], d01 = d[1], d02 = d[2], d11 = d[3], d12 = d[4], d22 = d[5];
     const double b0 = d[6], b1 = d[7], b2 = d[8];
-    const int k0 = A.rowptr[i];
-    const double s = write_diag ? 1.0 : 0.0;
-    A.blk[blk_at(0, k0, ns)] = s * d00; A.blk[blk_at(1, k0, ns)] = s * d01; A.blk[blk_at(2, k0, ns)] = s * d02;
-    A.blk[blk_at(3, k0, ns)] = s * d01; A.blk[blk_at(4, k0, ns)] = s * d11; A.blk[blk_at(5, k0, ns)] = s * d12;
-    A.blk[blk_at(6, k0, ns)] = s * d02; A.blk[blk_at(7, k0, ns)] = s * d12; A.blk[blk_at(8, k0, ns)] = s * d22;
+    double* dd = A.dblk + 6 * (size_t)i;
+    dd[0] = d00; dd[1] = d01; dd[2] = d02; dd[3] = d11; dd[4] = d12; dd[5] = d22;
     // symmetric 3x3 inverse by cofactors
     const double c00 = d11 * d22 - d12 * d12, c01 = d02 * d12 - d01 * d22, c02 = d01 * d12 - d02 * d11;
     const double c11 = d00 * d22 - d02 * d02, c12 = d01 * d02 - d00 * d12, c22 = d00 * d11 - d01 * d01;
@@ -250,6 +250,9 @@ __global__ __launch_bounds__(kBlock) void k_finalize(BsrDev A, const double* __r
       r[o] = b0; r[o + 1] = b1; r[o + 2] = b2;
       z[o] = z0; z[o + 1] = z1; z[o + 2] = z2;
       p[o] = z0; p[o + 1] = z1; p[o + 2] = z2;
+    }
+    if (xs) {
+      xs[o] = omega * z0; xs[o + 1] = omega * z1; xs[o + 2] = omega * z2;
     }
     acc[0] += b0 * z0 + b1 * z1 + b2 * z2;
     acc[1] += b0 * b0 + b1 * b1 + b2 * b2;
@@ -424,14 +427,99 @@ void k_spmv(BsrDev A, SpmvArgs a) {
   if (a.partials) block_sum_store<2>(dotacc, a.partials, kMaxPartials);
 }
 
+// ---------------------------------------------------------------------------- k_spmv0
+// The level-0 (finest) Hessian product on the SYMMETRIC storage (Sym0Dev, sgo_internal.h): one lane
+// per compact slot; an owned slot streams its block, a transposed slot fetches the block stored with
+// the other endpoint's row (an L2 hit thanks to the Hilbert row order) and multiplies by its transpose;
+// wavefront segmented scan per row; the row's last lane adds the diagonal block's product and applies
+// the mode's epilogue:
+//   S0_AX      y = H x
+//   S0_RESID   y = b - H x                           (x = omega Dinv b was made by the producer of b:
+//                                                     first smoothing sweep from zero + residual)
+//   S0_JACOBI  y = x + omega Dinv (b - H x)          (damped block-Jacobi sweep)
+// Optional dot partials: partials[0] += dotA[row].y[row], partials[1] += dotA2[row].y[row].
+// Bounded to 8 workgroups per CU (<= 64 VGPRs) so that the whole 2048-block grid is resident.
+template <int MODE>
+__global__ __launch_bounds__(kBlock, 8) void k_spmv0(Sym0Dev A, Spmv0Args a) {
+  if (a.S && a.S->stop) return;
+  const int lane = threadIdx.x & 63;
+  const size_t nu = (size_t)A.nu;
+  const double2* __restrict__ bp = reinterpret_cast<const double2*>(A.ublk);
+  double dotacc[2] = {0.0, 0.0};
+  int g, gend, gstride;
+  group_walk(A.ngrp, &g, &gend, &gstride);
+  for (; g < gend; g += gstride) {
+    const int gb = A.grp[g], ge = A.grp[g + 1], r0 = A.grow[g];
+    int ob = A.gown[g], tb = A.gtr[g];
+    double acc[3] = {0.0, 0.0, 0.0};
+    int row = -1 - lane;
+    for (int kb = gb; kb < ge; kb += 64) {
+      const int k = kb + lane;
+      const bool active = k < ge;
+      const int m = active ? (int)A.meta[k] : (kSlotNoBlock << 6);
+      const int type = m >> 6;
+      const unsigned long long omask = __ballot(type == kSlotOwned), tmask = __ballot(type == kSlotTransposed);
+      const int orank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(omask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)omask, 0u));
+      const int trank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(tmask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)tmask, 0u));
+      int idx = ob + orank;
+      const bool tr = type == kSlotTransposed;
+      if (tr) idx = A.tref[tb + trank];
+      ob += __popcll(omask);
+      tb += __popcll(tmask);
+      if (active) row = r0 + (m & 63);
+      if (type != kSlotNoBlock) {
+        const size_t c = 3 * (size_t)A.col[k];
+        const double x0 = a.x[c], x1 = a.x[c + 1], x2 = a.x[c + 2];
+        const double2 p0 = bp[idx], p1 = bp[nu + idx], p2 = bp[2 * nu + idx], p3 = bp[3 * nu + idx];
+        const double b8 = A.ublk[8 * nu + idx];
+        // row-major b0..b8 = p0.x p0.y p1.x | p1.y p2.x p2.y | p3.x p3.y b8 ; transposed: swap (1,3) (2,6) (5,7)
+        const double m01 = tr ? p1.y : p0.y, m02 = tr ? p3.x : p1.x;
+        const double m10 = tr ? p0.y : p1.y, m12 = tr ? p3.y : p2.y;
+        const double m20 = tr ? p1.x : p3.x, m21 = tr ? p2.y : p3.y;
+        acc[0] += p0.x * x0 + m01 * x1 + m02 * x2;
+        acc[1] += m10 * x0 + p2.x * x1 + m12 * x2;
+        acc[2] += m20 * x0 + m21 * x1 + b8 * x2;
+      }
+    }
+    seg_scan<3>(row, acc, lane);
+    const int rn = __shfl_down(row, 1);
+    if (row >= 0 && (lane == 63 || rn != row)) {
+      const size_t o = 3 * (size_t)row;
+      const double* dd = A.dblk + 6 * (size_t)row;
+      const double s0 = a.x[o], s1 = a.x[o + 1], s2 = a.x[o + 2];
+      double o0 = acc[0] + dd[0] * s0 + dd[1] * s1 + dd[2] * s2;
+      double o1 = acc[1] + dd[1] * s0 + dd[3] * s1 + dd[4] * s2;
+      double o2 = acc[2] + dd[2] * s0 + dd[4] * s1 + dd[5] * s2;
+      if (MODE != S0_AX) {
+        const double t0 = a.b[o] - o0, t1 = a.b[o + 1] - o1, t2 = a.b[o + 2] - o2;
+        if (MODE == S0_JACOBI) {
+          const double* di = A.dinv + 6 * (size_t)row;
+          o0 = s0 + a.omega * (di[0] * t0 + di[1] * t1 + di[2] * t2);
+          o1 = s1 + a.omega * (di[1] * t0 + di[3] * t1 + di[4] * t2);
+          o2 = s2 + a.omega * (di[2] * t0 + di[4] * t1 + di[5] * t2);
+        } else {
+          o0 = t0; o1 = t1; o2 = t2;
+        }
+      }
+      a.y[o] = o0; a.y[o + 1] = o1; a.y[o + 2] = o2;
+      if (a.dotA) dotacc[0] += a.dotA[o] * o0 + a.dotA[o + 1] * o1 + a.dotA[o + 2] * o2;
+      if (a.dotA2) dotacc[1] += a.dotA2[o] * o0 + a.dotA2[o + 1] * o1 + a.dotA2[o + 2] * o2;
+    }
+  }
+  if (a.partials) block_sum_store<2>(dotacc, a.partials, kMaxPartials);
+}
+
 // alpha = r.z / p.q from the partials of p.q (every workgroup re-reduces them in the same fixed
 // order, so all agree bit for bit and no single-workgroup scalar kernel sits between the product
 // and the update; workgroup 0 records the scalars), then
 // x += alpha p ; r -= alpha q ; z = Dinv r ; partials: r.z, r.r
+// With the multigrid preconditioner (xs != nullptr) the update also leaves xs = omega Dinv r, the cycle's
+// first level-0 smoothing sweep from zero, so that the level-0 residual pass gathers a plain vector.
 __global__ __launch_bounds__(kBlock) void k_update_xr(int n, PcgScalars* S, const double* __restrict__ pq_parts, int n_pq,
                                                       const double* __restrict__ dinv, const double* __restrict__ p,
                                                       const double* __restrict__ q, double* __restrict__ x,
                                                       double* __restrict__ r, double* __restrict__ z,
+                                                      double* __restrict__ xs, double omega,
                                                       double* __restrict__ partials) {
   // the scalars of the previous launches in one go, before the reduction's barriers
   const int stop0 = S->stop, iter0 = S->iter;
@@ -459,8 +547,12 @@ __global__ __launch_bounds__(kBlock) void k_update_xr(int n, PcgScalars* S, cons
       const double z0 = di[0] * r0 + di[1] * r1 + di[2] * r2;
       const double z1 = di[1] * r0 + di[3] * r1 + di[4] * r2;
       const double z2 = di[2] * r0 + di[4] * r1 + di[5] * r2;
-      z[o] = z0; z[o + 1] = z1; z[o + 2] = z2;
-      acc[0] += r0 * z0 + r1 * z1 + r2 * z2;
+      if (xs) {
+        xs[o] = omega * z0; xs[o + 1] = omega * z1; xs[o + 2] = omega * z2;
+      } else {
+        z[o] = z0; z[o + 1] = z1; z[o + 2] = z2;
+        acc[0] += r0 * z0 + r1 * z1 + r2 * z2;
+      }
     }
     acc[1] += r0 * r0 + r1 * r1 + r2 * r2;
   }
@@ -510,16 +602,16 @@ __global__ __launch_bounds__(kBlock) void k_dot(int n3, const double* __restrict
   block_sum_store<1>(acc, partials, kMaxPartials);
 }
 
-// z = Dinv r
+// z = scale Dinv r
 __global__ __launch_bounds__(kBlock) void k_precond_bj(int n, const double* __restrict__ dinv,
-                                                       const double* __restrict__ r, double* __restrict__ z) {
+                                                       const double* __restrict__ r, double* __restrict__ z, double scale) {
   for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
     const size_t o = 3 * (size_t)i;
     const double* di = dinv + 6 * (size_t)i;
     const double r0 = r[o], r1 = r[o + 1], r2 = r[o + 2];
-    z[o] = di[0] * r0 + di[1] * r1 + di[2] * r2;
-    z[o + 1] = di[1] * r0 + di[3] * r1 + di[4] * r2;
-    z[o + 2] = di[2] * r0 + di[4] * r1 + di[5] * r2;
+    z[o] = scale * (di[0] * r0 + di[1] * r1 + di[2] * r2);
+    z[o + 1] = scale * (di[1] * r0 + di[3] * r1 + di[4] * r2);
+    z[o + 2] = scale * (di[2] * r0 + di[4] * r1 + di[5] * r2);
   }
 }
 
@@ -546,15 +638,15 @@ void launch_chi2(hipStream_t s, const EdgeListDev& el, int e0, int e1, const dou
 void launch_reduce2(hipStream_t s, const double* partials, int nparts, double* out2) {
   SGO_LAUNCH(k_reduce2, dim3(1), dim3(kBlock), 0, s, partials, nparts, out2);
 }
-void launch_linearize(hipStream_t s, const BsrDev& A, int g0, int g1, const EdgeSlotsDev& es, const double* poses,
+void launch_linearize(hipStream_t s, const Sym0Dev& A, int g0, int g1, const EdgeSlotsDev& es, const double* poses,
                       double* dgb) {
   const int grid = grid_for(g1 - g0, kWavesPerBlock);
   SGO_LAUNCH(k_linearize, dim3(grid), dim3(kBlock), 0, s, A, g0, g1, es, poses, dgb);
 }
-void launch_finalize(hipStream_t s, const BsrDev& A, const double* dgb, int write_diag, double* b, double* x,
-                     double* r, double* z, double* p, double* partials, int* grid_out) {
+void launch_finalize(hipStream_t s, const Sym0Dev& A, const double* dgb, double* b, double* x, double* r, double* z,
+                     double* p, double* xs, double omega, double* partials, int* grid_out) {
   const int grid = grid_for(A.n, kBlock);
-  SGO_LAUNCH(k_finalize, dim3(grid), dim3(kBlock), 0, s, A, dgb, write_diag, b, x, r, z, p, partials);
+  SGO_LAUNCH(k_finalize, dim3(grid), dim3(kBlock), 0, s, A, dgb, b, x, r, z, p, xs, omega, partials);
   *grid_out = grid;
 }
 void launch_init_scalars(hipStream_t s, PcgScalars* S, const double* rz_parts, int n_rz, const double* bb_parts,
@@ -579,24 +671,20 @@ int launch_spmv_ex(hipStream_t s, const BsrDev& A, int mode, const SpmvArgs& a) 
   }
   return grid;
 }
-void launch_spmv(hipStream_t s, const BsrDev& A, const double* x, double* y, double* dot_partials,
-                 const PcgScalars* S, int* grid_out) {
-  SpmvArgs a{};
-  a.x = x;
-  a.y = y;
-  a.S = S;
-  if (dot_partials) {
-    a.dotA = x;
-    a.partials = dot_partials;
+int launch_spmv0(hipStream_t s, const Sym0Dev& A, int mode, const Spmv0Args& a) {
+  const int grid = grid_for(A.ngrp, kWavesPerBlock);
+  switch (mode) {
+    case S0_AX: SGO_LAUNCH((k_spmv0<S0_AX>), dim3(grid), dim3(kBlock), 0, s, A, a); break;
+    case S0_RESID: SGO_LAUNCH((k_spmv0<S0_RESID>), dim3(grid), dim3(kBlock), 0, s, A, a); break;
+    default: SGO_LAUNCH((k_spmv0<S0_JACOBI>), dim3(grid), dim3(kBlock), 0, s, A, a); break;
   }
-  const int grid = launch_spmv_ex(s, A, SPMV_AX, a);
-  if (grid_out) *grid_out = grid;
+  return grid;
 }
 void launch_update_xr(hipStream_t s, int n, PcgScalars* S, const double* pq_parts, int n_pq, const double* dinv,
-                      const double* p, const double* q, double* x, double* r, double* z, double* partials,
-                      int* grid_out) {
+                      const double* p, const double* q, double* x, double* r, double* z, double* xs, double omega,
+                      double* partials, int* grid_out) {
   const int grid = grid_for(n, kBlock);
-  SGO_LAUNCH(k_update_xr, dim3(grid), dim3(kBlock), 0, s, n, S, pq_parts, n_pq, dinv, p, q, x, r, z, partials);
+  SGO_LAUNCH(k_update_xr, dim3(grid), dim3(kBlock), 0, s, n, S, pq_parts, n_pq, dinv, p, q, x, r, z, xs, omega, partials);
   if (grid_out) *grid_out = grid;
 }
 void launch_update_p(hipStream_t s, int n, PcgScalars* S, const double* rz_parts, int n_rz, const double* rr_parts,
@@ -665,9 +753,9 @@ void launch_dot(hipStream_t s, int n3, const double* a, const double* b, double*
   SGO_LAUNCH(k_dot, dim3(grid), dim3(kBlock), 0, s, n3, a, b, partials, S);
   if (grid_out) *grid_out = grid;
 }
-void launch_precond_bj(hipStream_t s, int n, const double* dinv, const double* r, double* z) {
+void launch_precond_bj(hipStream_t s, int n, const double* dinv, const double* r, double* z, double scale) {
   const int grid = grid_for(n, kBlock);
-  SGO_LAUNCH(k_precond_bj, dim3(grid), dim3(kBlock), 0, s, n, dinv, r, z);
+  SGO_LAUNCH(k_precond_bj, dim3(grid), dim3(kBlock), 0, s, n, dinv, r, z, scale);
 }
 
 }  // namespace sgo
