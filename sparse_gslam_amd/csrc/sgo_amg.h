@@ -45,7 +45,7 @@ struct HostLevel {
 // connection).  `d_poses` / `d_free_id` give the positions of the level-0 nodes: pos of row h =
 // poses[3*free_id[h] + 0..1].  `scratch` (optional) provides host memory for the set-up's large temporary
 // lists; it is rewound here and may be rewound again by the caller once amg_create has returned.
-Amg* amg_create(hipStream_t s, const BsrDev& A0, const Sym0Dev& S0, const HostLevel& H0, const double* d_poses,
+Amg* amg_create(hipStream_t s, const BsrDev& A0, const Sym0Dev& S0, const Tile0Dev& T0, const HostLevel& H0, const double* d_poses,
                 const int* d_free_id, const AmgConfig& cfg, const AmgProf& prof, std::string* err,
                 ChunkArena* scratch = nullptr);
 void amg_destroy(Amg* m);

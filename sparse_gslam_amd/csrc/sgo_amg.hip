@@ -1050,6 +1050,7 @@ struct Amg {
   AmgConfig cfg;
   AmgProf prof;
   Sym0Dev S0;               // level-0 operator in symmetric storage (lv[0].A is its logical view)
+  Tile0Dev T0;              // ... and its tile view
   std::vector<void*> pool;
   std::vector<AmgLevel> lv;
   const double* d_poses = nullptr;
@@ -1181,7 +1182,7 @@ int cycle(Amg* m, hipStream_t s, int l, const double* rhs, const double* rhs_sub
     Spmv0Args a{};
     a.x = L.xs; a.b = rhs; a.y = L.rs; a.S = S;
     Scope sc(m->prof, K_SPMV0_RESID, 76.0 * m->S0.nu + 120.0 * m->S0.n);
-    launch_spmv0(s, m->S0, S0_RESID, a);
+    launch_spmv0_any(s, m->S0, m->T0, S0_RESID, a);
   } else {
     SpmvArgs a{};
     a.b = rhs; a.y = L.rs; a.y2 = L.xs; a.omega = m->cfg.omega; a.S = S;
@@ -1255,7 +1256,7 @@ int cycle(Amg* m, hipStream_t s, int l, const double* rhs, const double* rhs_sub
       b.partials = dotparts;
     }
     Scope sc(m->prof, K_SPMV0_JACOBI, 76.0 * m->S0.nu + 168.0 * m->S0.n);
-    return launch_spmv0(s, m->S0, S0_JACOBI, b);
+    return launch_spmv0_any(s, m->S0, m->T0, S0_JACOBI, b);
   }
   if (L.smoothed) {
     if (L.smoothed) {
@@ -1364,12 +1365,13 @@ int amg_apply(Amg* m, hipStream_t s, const double* r, double* z, const double* d
   return cycle(m, s, 0, r, nullptr, none, nullptr, z, dotvec, partials, S, dotvec2, xs0_ready);
 }
 
-Amg* amg_create(hipStream_t s, const BsrDev& A0, const Sym0Dev& S0, const HostLevel& H0, const double* d_poses,
+Amg* amg_create(hipStream_t s, const BsrDev& A0, const Sym0Dev& S0, const Tile0Dev& T0, const HostLevel& H0, const double* d_poses,
                 const int* d_free_id, const AmgConfig& cfg_in, const AmgProf& prof, std::string* err,
                 ChunkArena* scratch) {
   Amg* m = new Amg();
   m->cfg = cfg_in;
   m->S0 = S0;
+  m->T0 = T0;
   if (const char* e = std::getenv("SGO_AMG_THETA")) m->cfg.theta = std::atof(e);
   if (const char* e = std::getenv("SGO_AMG_OMEGA")) m->cfg.omega = std::atof(e);
   if (const char* e = std::getenv("SGO_AMG_THETA_COARSE")) m->cfg.theta_coarse = std::atof(e);

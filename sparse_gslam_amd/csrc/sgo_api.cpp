@@ -103,6 +103,7 @@ struct sgo_ctx {
   int* d_free_id = nullptr;
   EdgeListDev el;
   Sym0Dev S0;                    // level-0 Hessian, symmetric storage (the solve's products run on this)
+  Tile0Dev T0;                   // ... its tile view (ntile == 0: no tile view, products use the wave-group kernel)
   BsrDev A;                      // its logical view (multigrid set-up kernels)
   EdgeSlotsDev es;
   double *d_dgb = nullptr, *d_b = nullptr, *d_x = nullptr, *d_r = nullptr, *d_z = nullptr, *d_p = nullptr,
@@ -209,6 +210,7 @@ void free_graph(sgo_ctx* c) {
   c->pcg_pred = 0;
   c->A = BsrDev();
   c->S0 = Sym0Dev();
+  c->T0 = Tile0Dev();
   c->es = EdgeSlotsDev();
   c->el = EdgeListDev();
   c->has_graph = false;
@@ -418,20 +420,21 @@ int build_structure(sgo_ctx* c, int V, const double* poses, const uint8_t* fixed
   }
   HostArena& ar = c->stage;
   try {
-    ar.reserve((size_t)ns * (4 * sizeof(int) + 3 + 10 * sizeof(double)) + (size_t)E * 9 * sizeof(double) + 32 * 64);
+    ar.reserve((size_t)ns * (5 * sizeof(int) + 4 + 10 * sizeof(double)) + (size_t)E * 9 * sizeof(double) + 64 * 64);
   } catch (const std::bad_alloc&) {
     c->err = "sgo_set_graph_se2: out of host memory for the staging buffers";
     return SGO_ENOMEM;
   }
   HostBuf<int> col(ar, ns), svi(ar, ns), svj(ar, ns), own(ar, (size_t)ns + 1);
-  HostBuf<unsigned char> type(ar, ns), meta(ar, ns), flags(ar, ns);
+  HostBuf<unsigned char> type(ar, ns), meta(ar, ns), flags(ar, ns), off1(ar, (size_t)std::max(ns, 1));
+  HostBuf<unsigned int> cv(ar, (size_t)std::max(ns, 1));
   HostBuf<double> zinv(ar, 3 * (size_t)ns), sinfo(ar, 6 * (size_t)ns), sphi(ar, ns);
   HostBuf<double> ezinv(ar, 3 * (size_t)E), einfo(ar, 6 * (size_t)E);
   if (!einfo.p) {
     c->err = "sgo_set_graph_se2: internal error (staging arena too small)";
     return SGO_EINVAL;
   }
-  // every slot is written exactly once (each edge fills its one or two slots)
+  // every slot is written exactly once (each edge fills its one or two slots); col < 0: fixed column
   parallel_for(E, [&](int e0, int e1) {
     for (int e = e0; e < e1; ++e) {
       // EdgeSE2::setMeasurement caches the inverse measurement on the host (computed once)
@@ -446,9 +449,7 @@ int build_structure(sgo_ctx* c, int V, const double* poses, const uint8_t* fixed
         const int hr = side ? hj : hi, hc = side ? hi : hj;
         if (hr < 0) continue;
         const int k = side ? pos_j[e] : pos_i[e];
-        col[k] = hc >= 0 ? hc : hr;
-        // the block lives with the lower row; an edge to a fixed vertex has none
-        type[k] = (unsigned char)(hc < 0 ? kSlotNoBlock : (hr < hc ? kSlotOwned : kSlotTransposed));
+        col[k] = hc;
         flags[k] = (unsigned char)(side ? kSlotDir : 0);
         svi[k] = ei[e];
         svj[k] = ej[e];
@@ -458,15 +459,100 @@ int build_structure(sgo_ctx* c, int V, const double* poses, const uint8_t* fixed
       }
     }
   });
-  // storage index of every owned slot = its rank among the owned slots (own[k]: exclusive count)
+
+  // ---- tiles (Tile0Dev): consecutive rows, cut so that the blocks are spread evenly over ~2 tiles per CU
+  // and a tile's LDS -- operand slice + halo, owned sums, one staging slot per intra-tile transposed slot --
+  // fits kTileLdsMax.  A pair inside a tile stores its block with the lower row only (the other row's slot
+  // is TRANSPOSED); every other slot with a free column is OWNED.
+  std::vector<TileDesc> tiles;
+  std::vector<int> tile_of_row(std::max(n, 1)), hcol;
+  int tile_lds = 0;
+  bool tiles_ok = true;
+  {
+    const int lds_budget = kTileLdsMax - 1024;
+    long long nblk = 0;
+    for (int k = 0; k < ns; ++k) nblk += col[k] >= 0;
+    long long target = std::max<long long>(512, (nblk / 2 + 511) / 512);   // slots per tile (both directions counted)
+    std::vector<int> mark(std::max(n, 1), -1);
+    for (int attempt = 0; attempt < 6; ++attempt) {
+      tiles.clear();
+      tile_lds = 0;
+      int r = 0;
+      while (r < n) {
+        TileDesc T{};
+        T.row0 = r;
+        long long slots = 0;
+        while (r < n && (r == T.row0 || (slots < 2 * target && r - T.row0 < 4096))) {
+          slots += rowptr[r + 1] - rowptr[r];
+          ++r;
+        }
+        T.row1 = r;
+        for (int q = T.row0; q < T.row1; ++q) tile_of_row[q] = (int)tiles.size();
+        tiles.push_back(T);
+      }
+      // exact LDS need per tile: rows + halo columns + rows + staged entries, 24 B each
+      bool fits = true;
+      for (size_t t = 0; t < tiles.size() && fits; ++t) {
+        const TileDesc& T = tiles[t];
+        long long halo = 0, staged = 0;
+        for (int k = rowptr[T.row0]; k < rowptr[T.row1]; ++k) {
+          const int cc = col[k];
+          if (cc < 0) continue;
+          if (cc >= T.row0 && cc < T.row1) {
+            staged += 1;   // each intra-tile pair has two slots, one of them staged: count halves below
+          } else if (mark[cc] != (int)t) {
+            mark[cc] = (int)t;
+            ++halo;
+          }
+        }
+        staged /= 2;
+        const long long rows = T.row1 - T.row0;
+        const long long need = 24 * (2 * rows + halo + staged);
+        if (need > lds_budget || rows + halo > 65000 || staged > 65000) fits = false;
+        tile_lds = std::max<long long>(tile_lds, need);
+      }
+      std::fill(mark.begin(), mark.end(), -1);
+      if (fits) break;
+      if (target <= 64) {
+        tiles_ok = false;   // e.g. a hub vertex whose row alone overflows the LDS: no tile view
+        break;
+      }
+      target = std::max<long long>(64, target / 2);
+      if (attempt == 5) tiles_ok = false;
+    }
+  }
+  if (const char* e = std::getenv("SGO_SPMV0"))
+    if (!std::strcmp(e, "group")) tiles_ok = false;   // experiments: force the wave-group kernel
+  if (!tiles_ok) {   // one "tile" per row range of nothing: every pair stored once, with the lower row
+    tiles.clear();
+    for (int r = 0; r < n; ++r) tile_of_row[r] = 0;
+  }
+  // slot types
+  parallel_for(n, [&](int r0, int r1) {
+    for (int r = r0; r < r1; ++r)
+      for (int k = rowptr[r]; k < rowptr[r + 1]; ++k) {
+        const int cc = col[k];
+        if (cc < 0) {
+          type[k] = kSlotNoBlock;
+          col[k] = r;   // never dereferenced as a column; keeps the index in range
+        } else {
+          type[k] = (unsigned char)((tile_of_row[cc] == tile_of_row[r] && cc < r) ? kSlotTransposed : kSlotOwned);
+        }
+      }
+  });
+  // storage index of every owned slot = its rank among the owned slots (own[k]: exclusive count);
+  // tslot[k]: rank among the transposed slots
+  std::vector<int> tslot((size_t)ns + 1);
   int nu = 0, ntr = 0;
   for (int k = 0; k < ns; ++k) {
     own[k] = nu;
+    tslot[k] = ntr;
     nu += type[k] == kSlotOwned;
     ntr += type[k] == kSlotTransposed;
   }
   own[ns] = nu;
-  // wave groups: whole rows packed up to 64 slots; a longer row is its own group
+  tslot[ns] = ntr;
+  // wave groups over the compact slots: whole rows packed up to 64 slots; a longer row is its own group
   std::vector<int> grp, grow;
   grp.push_back(0);
   {
@@ -494,42 +580,17 @@ int build_structure(sgo_ctx* c, int V, const double* poses, const uint8_t* fixed
   }
   const int ngrp = (int)grp.size() - 1;
   std::vector<int> gown(ngrp), gtr(ngrp), tref((size_t)std::max(ntr, 1));
-  {
-    int t = 0;
-    for (int g = 0; g < ngrp; ++g) {
-      gown[g] = own[grp[g]];
-      gtr[g] = t;
-      for (int k = grp[g]; k < grp[g + 1]; ++k) t += type[k] == kSlotTransposed;
-    }
+  for (int g = 0; g < ngrp; ++g) {
+    gown[g] = own[grp[g]];
+    gtr[g] = tslot[grp[g]];
   }
-  // meta bytes; transposed slots' references (the owner's slot of the same edge); logical structure for
-  // the multigrid set-up (diagonal slot first, then the row's block slots)
-  HostLevel& H = c->H0;
-  H.n = n;
-  H.rowptr.assign((size_t)n + 1, 0);
-  for (int r = 0; r < n; ++r) {
-    int nb = 1;
-    for (int k = rowptr[r]; k < rowptr[r + 1]; ++k) nb += type[k] != kSlotNoBlock;
-    H.rowptr[r + 1] = H.rowptr[r] + nb;
-  }
-  H.nslot = H.rowptr[n];
-  H.row.resize(H.nslot);
-  H.col.resize(H.nslot);
-  std::vector<int> lref(H.nslot);
-  std::vector<int> tslot((size_t)ns);   // compact slot -> position among the transposed slots
-  {
-    int t = 0;
-    for (int k = 0; k < ns; ++k) {
-      tslot[k] = t;
-      t += type[k] == kSlotTransposed;
-    }
-  }
+  // transposed slots' references (the owner's slot of the same edge); meta bytes
   parallel_for(E, [&](int e0, int e1) {
     for (int e = e0; e < e1; ++e) {
       const int ki = pos_i[e], kj = pos_j[e];
       if (ki < 0 || kj < 0) continue;
-      if (type[ki] == kSlotOwned) tref[tslot[kj]] = own[ki];
-      else tref[tslot[ki]] = own[kj];
+      if (type[ki] == kSlotTransposed) tref[tslot[ki]] = own[kj];
+      else if (type[kj] == kSlotTransposed) tref[tslot[kj]] = own[ki];
     }
   });
   parallel_for(ngrp, [&](int g0, int g1) {
@@ -542,6 +603,19 @@ int build_structure(sgo_ctx* c, int V, const double* poses, const uint8_t* fixed
       }
     }
   });
+  // logical structure for the multigrid set-up (diagonal slot first, then the row's block slots)
+  HostLevel& H = c->H0;
+  H.n = n;
+  H.rowptr.assign((size_t)n + 1, 0);
+  for (int r = 0; r < n; ++r) {
+    int nb = 1;
+    for (int k = rowptr[r]; k < rowptr[r + 1]; ++k) nb += type[k] != kSlotNoBlock;
+    H.rowptr[r + 1] = H.rowptr[r] + nb;
+  }
+  H.nslot = H.rowptr[n];
+  H.row.resize(H.nslot);
+  H.col.resize(H.nslot);
+  std::vector<int> lref(H.nslot);
   parallel_for(n, [&](int r0, int r1) {
     for (int r = r0; r < r1; ++r) {
       int q = H.rowptr[r];
@@ -558,6 +632,91 @@ int build_structure(sgo_ctx* c, int V, const double* poses, const uint8_t* fixed
       }
     }
   });
+  // tile arrays: phase-1 groups over the owned slots (numbered like the storage), operand index and twin's
+  // staging slot per owned slot, halo columns, staged-entry ranges per row
+  std::vector<int> trowptr((size_t)n + 1), grp1, grow1;
+  if (tiles_ok) {
+    for (int r = 0; r <= n; ++r) trowptr[r] = tslot[rowptr[std::min(r, n)]];
+    std::vector<int> hidx(std::max(n, 1), -1), hmark(std::max(n, 1), -1);
+    grp1.push_back(0);
+    for (size_t t = 0; t < tiles.size(); ++t) {
+      TileDesc& T = tiles[t];
+      const int nr = T.row1 - T.row0;
+      T.e0 = trowptr[T.row0];
+      T.nstaged = trowptr[T.row1] - T.e0;
+      T.h0 = (int)hcol.size();
+      T.g0 = (int)grow1.size();
+      int cur = 0, first = T.row0;
+      for (int r = T.row0; r < T.row1; ++r) {
+        const int len = own[rowptr[r + 1]] - own[rowptr[r]];
+        // operand index of the row's owned slots; halo numbering in first-seen order
+        for (int k = rowptr[r]; k < rowptr[r + 1]; ++k) {
+          if (type[k] != kSlotOwned) continue;
+          const int cc = col[k];
+          unsigned ci;
+          if (cc >= T.row0 && cc < T.row1) {
+            ci = (unsigned)(cc - T.row0);
+          } else {
+            if (hmark[cc] != (int)t) {
+              hmark[cc] = (int)t;
+              hidx[cc] = (int)hcol.size() - T.h0;
+              hcol.push_back(cc);
+            }
+            ci = (unsigned)(nr + hidx[cc]);
+          }
+          cv[own[k]] = ci | 0xFFFF0000u;   // twin's staging slot filled in below
+        }
+        if (len == 0) continue;
+        if (cur > 0 && cur + len > 64) {
+          grp1.push_back(own[rowptr[r]]);
+          grow1.push_back(first);
+          cur = 0;
+        }
+        if (cur == 0) first = r;
+        cur += len;
+        if (cur >= 64) {
+          grp1.push_back(own[rowptr[r + 1]]);
+          grow1.push_back(first);
+          cur = 0;
+        }
+      }
+      if (cur > 0) {
+        grp1.push_back(own[rowptr[T.row1]]);
+        grow1.push_back(first);
+      }
+      T.g1 = (int)grow1.size();
+      T.h1 = (int)hcol.size();
+    }
+    const int ng1 = (int)grow1.size();
+    for (int g = 0; g < ng1 && tiles_ok; ++g) {
+      int r = grow1[g];
+      const bool longrow = grp1[g + 1] - grp1[g] > 64;
+      for (int u = grp1[g]; u < grp1[g + 1]; ++u) {
+        while (own[rowptr[r + 1]] <= u) ++r;
+        if (!longrow && r - grow1[g] > 255) tiles_ok = false;   // hundreds of rows in a row that own nothing
+        off1[u] = (unsigned char)(longrow ? 0 : r - grow1[g]);
+      }
+    }
+    // twins: the owned slot of an intra-tile pair hands B^T x to the transposed slot's staging entry
+    parallel_for(E, [&](int e0, int e1) {
+      for (int e = e0; e < e1; ++e) {
+        const int ki = pos_i[e], kj = pos_j[e];
+        if (ki < 0 || kj < 0) continue;
+        int ko, kt;
+        if (type[ki] == kSlotTransposed) { kt = ki; ko = kj; }
+        else if (type[kj] == kSlotTransposed) { kt = kj; ko = ki; }
+        else continue;
+        const int trow = col[ko];
+        const unsigned vp = (unsigned)(tslot[kt] - tiles[tile_of_row[trow]].e0);
+        cv[own[ko]] = (cv[own[ko]] & 0xFFFFu) | (vp << 16);
+      }
+    });
+    if (!tiles_ok) {
+      // cannot happen for tiles that fit the LDS unless rows own nothing en masse; the types were already
+      // chosen for these tiles, and the wave-group kernel handles any mix of owned / transposed slots
+      tiles.clear();
+    }
+  }
 
   const double tb1 = wall_s();
   int rc;
@@ -576,6 +735,23 @@ int build_structure(sgo_ctx* c, int V, const double* poses, const uint8_t* fixed
   if ((rc = dalloc(c, &S.ublk, 9 * (size_t)nu))) return rc;
   if ((rc = dalloc(c, &S.dblk, 6 * (size_t)n))) return rc;
   if ((rc = dalloc(c, &S.dinv, 6 * (size_t)n))) return rc;
+  Tile0Dev& TL = c->T0;
+  TL = Tile0Dev();
+  if (tiles_ok && !tiles.empty()) {
+    TL.ntile = (int)tiles.size();
+    TL.lds_bytes = tile_lds;
+    if (hcol.empty()) hcol.push_back(0);
+    if ((rc = upload(c, &TL.tile, tiles))) return rc;
+    if ((rc = upload(c, &TL.cv, cv))) return rc;
+    if ((rc = upload(c, &TL.off1, off1))) return rc;
+    if ((rc = upload(c, &TL.grp1, grp1))) return rc;
+    if ((rc = upload(c, &TL.grow1, grow1))) return rc;
+    if ((rc = upload(c, &TL.trowptr, trowptr))) return rc;
+    if ((rc = upload(c, &TL.hcol, hcol))) return rc;
+    if (c->opts.verbose)
+      std::fprintf(stderr, "[sgo] level-0 tiles: %d tiles, %d B LDS, %d stored blocks for %d pairs (%.1f %% stored with both rows), %zu halo columns\n",
+                   TL.ntile, TL.lds_bytes, nu, (nu + ntr) / 2, (nu + ntr) > 0 ? 100.0 * (nu - ntr) / (nu + ntr) : 0.0, hcol.size());
+  }
   // logical view for the multigrid set-up kernels
   BsrDev& A = c->A;
   A.n = n;
@@ -717,7 +893,7 @@ int do_spmv(sgo_ctx* c, const double* x, double* y, bool dot, const PcgScalars* 
     a.dotA = x;
     a.partials = c->d_partials;
   }
-  const int grid = launch_spmv0(c->stream, c->S0, S0_AX, a);
+  const int grid = launch_spmv0_any(c->stream, c->S0, c->T0, S0_AX, a);
   if (grid_out) *grid_out = grid;
   return SGO_OK;
 }
@@ -854,7 +1030,7 @@ int build_amg(sgo_ctx* c) {
     cc->amg_scope = nullptr;
   };
   std::string aerr;
-  c->amg = amg_create(c->stream, c->A, c->S0, c->H0, c->d_poses, c->d_free_id, cfg, prof, &aerr, &c->amg_scratch);
+  c->amg = amg_create(c->stream, c->A, c->S0, c->T0, c->H0, c->d_poses, c->d_free_id, cfg, prof, &aerr, &c->amg_scratch);
   if (c->amg) {
     amg_describe(c->amg, &c->solver_desc);
     c->solver_desc = "pcg_amg: " + c->solver_desc;
@@ -1368,6 +1544,37 @@ int sgo_optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
     out->seconds_total = wall_s() - t0;
   }
   return failed ? 0 : done;   // g2o: optimize() returns 0 when the algorithm reported Fail
+}
+
+// Micro-benchmark of the level-0 product on the resident graph: `reps` back-to-back launches of
+// k_spmv0<mode> (operand = the PCG direction buffer, whatever it holds), HIP events around them on the
+// context's stream; returns the mean microseconds per launch (< 0 on error).  variant = Spmv0Args::dbg.
+double sgo_debug_spmv0_us(sgo_ctx* c, int mode, int variant, int reps) {
+  if (check_graph(c) != SGO_OK || reps < 1 || c->n == 0) return -1.0;
+  hipEvent_t a, b;
+  if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return -1.0;
+  Spmv0Args args{};
+  args.x = c->d_p;
+  args.y = c->d_s2;
+  args.b = c->d_b;
+  args.omega = 0.8;
+  args.dbg = variant;
+  const bool tiled = c->T0.ntile > 0 && !(variant & 16);   // variant 16: the wave-group kernel
+  args.dbg = variant & 15;
+  if (tiled) launch_spmv0t(c->stream, c->S0, c->T0, mode, args);
+  else launch_spmv0(c->stream, c->S0, mode, args);
+  hipEventRecord(a, c->stream);
+  for (int k = 0; k < reps; ++k) {
+    if (tiled) launch_spmv0t(c->stream, c->S0, c->T0, mode, args);
+    else launch_spmv0(c->stream, c->S0, mode, args);
+  }
+  hipEventRecord(b, c->stream);
+  hipStreamSynchronize(c->stream);
+  float ms = 0.f;
+  hipEventElapsedTime(&ms, a, b);
+  hipEventDestroy(a);
+  hipEventDestroy(b);
+  return 1e3 * ms / reps;
 }
 
 int sgo_kernel_profile(sgo_ctx* c, sgo_kernel_stat* out, int cap) {

@@ -64,13 +64,12 @@ __host__ __device__ inline size_t blk_at(int c, size_t k, size_t ns) {
 //     endpoints of almost every edge -- odometry steps and closures between nearby poses alike --
 //     a few hundred rows apart;
 //   * the compact slot list has, per row, one slot per incident off-diagonal block: the slot is
-//     OWNED (the block is stored with this row; owned slots of consecutive rows are consecutive in
-//     ublk, so their loads stream) or TRANSPOSED (the block is stored with the other endpoint's row;
-//     the lane fetches it through tref and multiplies by its transpose).  Thanks to the ordering the
-//     owner's row was streamed moments earlier by a neighbouring wave of the same XCD, so the second
-//     read is an L2 hit: HBM / Infinity-Cache traffic is that of the symmetric storage, and no
-//     atomics or scatter are needed -- every row is still summed by a wavefront segmented scan in a
-//     fixed order (bitwise reproducible);
+//     OWNED (a block oriented for this row is stored with it; owned slots of consecutive rows are
+//     consecutive in ublk, so their loads stream) or TRANSPOSED (the block is stored only with the other
+//     endpoint's row, which lies in the same tile -- Tile0Dev below -- and has the lower index).  Pairs of
+//     rows in different tiles own a copy each.  The tile kernel serves a transposed slot through LDS;
+//     the wave-group kernel k_spmv0 (graphs without a tile view) fetches the owner's block through tref
+//     and multiplies by its transpose;
 //   * an edge to a FIXED vertex has a slot without a block (it contributes to the row's diagonal
 //     block and right-hand side only), a row without any edge to a free vertex gets one such slot;
 //   * diagonal blocks live apart in symmetric packing (dblk, 48 B per row) and are applied by the
@@ -95,6 +94,44 @@ struct Sym0Dev {
   double* ublk = nullptr;        // pair-SoA [nu]
   double* dblk = nullptr;        // [n][6]
   double* dinv = nullptr;        // [n][6]
+};
+
+// ----------------------------------------------------------------------------------------
+// Tile view of the level-0 storage for the products of the solve (k_spmv0t).  Measured on MI355X
+// (scripts/micro/ta_micro.hip): a wave64 global load costs >= 26 cycles of its CU's address path whatever
+// it moves, and ~2.4 cycles per lane when the lanes hit different cache lines, even on L2 hits -- gathers,
+// not bytes, bound this kernel class.  So the rows are cut into TILES of consecutive (Hilbert-ordered)
+// rows, one workgroup per tile at a time, and every global access of the hot loop is a coalesced stream:
+//   * a pair of rows INSIDE one tile stores its block once (with the lower row); the other row receives
+//     B^T x through an LDS staging slot: symmetric storage, 72 B per edge;
+//   * a pair that straddles two tiles (10-30 % in Hilbert order) stores the block with BOTH rows, each
+//     copy oriented for its row, so that no block is ever gathered;
+//   * phase 0  the tile's slice of the operand and its HALO (the distinct columns outside the tile, each
+//              fetched once per tile instead of once per slot) go to LDS;
+//     phase 1  one lane per stored block of the tile's rows: block streamed (5 coalesced loads), operand
+//              from LDS, u = B x_c segment-summed per row, v = B^T x_r to the twin's staging slot (vpos);
+//     phase 2  one thread per row sums the row's staged entries in a fixed order, adds the owned part and
+//              the diagonal block's product, applies the mode's epilogue and stores the row (coalesced).
+// No atomics, every sum in a fixed order (bitwise reproducible).
+// ----------------------------------------------------------------------------------------
+struct TileDesc {
+  int row0, row1;   // rows [row0, row1)
+  int g0, g1;       // phase-1 wave groups (whole rows of owned slots, <= 64 slots or one long row)
+  int h0, h1;       // halo columns hcol[h0 .. h1)
+  int e0;           // first staged entry (transposed slot number) of the tile
+  int nstaged;      // staged entries
+};
+struct Tile0Dev {
+  int ntile = 0;
+  int lds_bytes = 0;          // dynamic LDS per workgroup (largest tile)
+  TileDesc* tile = nullptr;
+  unsigned int* cv = nullptr;       // [nu] owned slot u: LDS operand index (local row, or rows + halo number) in
+                                    // bits 0..15, tile-relative staging slot of its twin in bits 16..31 (0xFFFF: none)
+  unsigned char* off1 = nullptr;    // [nu] row - grow1[g]
+  int* grp1 = nullptr;              // [ng1 + 1]
+  int* grow1 = nullptr;             // [ng1]
+  int* trowptr = nullptr;           // [n + 1] staged entries of row r: [trowptr[r], trowptr[r+1])  (global numbering)
+  int* hcol = nullptr;              // halo columns (global rows) of all tiles
 };
 
 // Edge operands aligned with the level-0 compact slots (SoA over slots).  For a slot of row r that
@@ -184,6 +221,8 @@ struct Spmv0Args {
   const double* dotA2 = nullptr; // partials[1] += dotA2 . y
   double* partials = nullptr;    // [2][kMaxPartials]
   const PcgScalars* S = nullptr; // optional early-out flag
+  int dbg = 0;                   // timing experiments only (wrong results): 1 transposed lanes read contiguous blocks,
+                                 // 2 operand gathered by row instead of column, 4 no block loads, 8 no operand loads
 };
 
 // One profiling slot per __global__ symbol (template instantiations separately), named as
@@ -326,6 +365,13 @@ void launch_finalize(hipStream_t s, const Sym0Dev& A, const double* dgb, double*
 void launch_init_scalars(hipStream_t s, PcgScalars* S, const double* rz_parts, int n_rz, const double* bb_parts,
                          int n_bb, double tol, int maxit);
 int launch_spmv0(hipStream_t s, const Sym0Dev& A, int mode, const Spmv0Args& a);   // returns grid
+int launch_spmv0t(hipStream_t s, const Sym0Dev& A, const Tile0Dev& T, int mode, const Spmv0Args& a);   // returns grid
+// tile kernel when the graph has a tile view, the wave-group kernel otherwise
+inline int launch_spmv0_any(hipStream_t s, const Sym0Dev& A, const Tile0Dev& T, int mode, const Spmv0Args& a) {
+  return T.ntile > 0 ? launch_spmv0t(s, A, T, mode, a) : launch_spmv0(s, A, mode, a);
+}
+constexpr int kTileThreads = 512;
+constexpr int kTileLdsMax = 64 * 1024;   // two workgroups per CU
 int launch_spmv_ex(hipStream_t s, const BsrDev& A, int mode, const SpmvArgs& a);  // returns grid
 void launch_update_xr(hipStream_t s, int n, PcgScalars* S, const double* pq_parts, int n_pq, const double* dinv,
                       const double* p, const double* q, double* x, double* r, double* z, double* xs, double omega,

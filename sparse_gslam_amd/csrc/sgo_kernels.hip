@@ -17,6 +17,7 @@
 // one contiguous 512-B or 1-KiB segment; per-row sums by a wavefront segmented scan over
 // row-aligned slot groups (no atomics, bitwise reproducible); grids capped at 2048 blocks and mapped so that each XCD walks one
 // contiguous band of rows (its L2 then holds that band's vector entries).
+#include <algorithm>
 #include <cstdlib>
 
 #include "sgo_device.h"
@@ -463,15 +464,22 @@ __global__ __launch_bounds__(kBlock, 8) void k_spmv0(Sym0Dev A, Spmv0Args a) {
       const int trank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(tmask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)tmask, 0u));
       int idx = ob + orank;
       const bool tr = type == kSlotTransposed;
-      if (tr) idx = A.tref[tb + trank];
+      if (tr) idx = (a.dbg & 1) ? min(ob + trank, A.nu - 1) : A.tref[tb + trank];
       ob += __popcll(omask);
       tb += __popcll(tmask);
       if (active) row = r0 + (m & 63);
       if (type != kSlotNoBlock) {
-        const size_t c = 3 * (size_t)A.col[k];
-        const double x0 = a.x[c], x1 = a.x[c + 1], x2 = a.x[c + 2];
-        const double2 p0 = bp[idx], p1 = bp[nu + idx], p2 = bp[2 * nu + idx], p3 = bp[3 * nu + idx];
-        const double b8 = A.ublk[8 * nu + idx];
+        const size_t c = (a.dbg & 2) ? 3 * (size_t)row : 3 * (size_t)A.col[k];
+        double x0 = 1.0, x1 = 2.0, x2 = 3.0;
+        if (!(a.dbg & 8)) {
+          x0 = a.x[c]; x1 = a.x[c + 1]; x2 = a.x[c + 2];
+        }
+        double2 p0 = make_double2(1, 2), p1 = p0, p2 = p0, p3 = p0;
+        double b8 = 1.0;
+        if (!(a.dbg & 4)) {
+          p0 = bp[idx]; p1 = bp[nu + idx]; p2 = bp[2 * nu + idx]; p3 = bp[3 * nu + idx];
+          b8 = A.ublk[8 * nu + idx];
+        }
         // row-major b0..b8 = p0.x p0.y p1.x | p1.y p2.x p2.y | p3.x p3.y b8 ; transposed: swap (1,3) (2,6) (5,7)
         const double m01 = tr ? p1.y : p0.y, m02 = tr ? p3.x : p1.x;
         const double m10 = tr ? p0.y : p1.y, m12 = tr ? p3.y : p2.y;
@@ -507,6 +515,124 @@ __global__ __launch_bounds__(kBlock, 8) void k_spmv0(Sym0Dev A, Spmv0Args a) {
     }
   }
   if (a.partials) block_sum_store<2>(dotacc, a.partials, kMaxPartials);
+}
+
+// ---------------------------------------------------------------------------- k_spmv0t
+// The level-0 product on the TILE view (Tile0Dev, sgo_internal.h): every stored block is streamed by
+// exactly one lane, operands come from LDS (the tile's slice + its halo, fetched once per tile), transposed
+// contributions of intra-tile pairs travel through LDS staging.  Modes and epilogues as k_spmv0.  One
+// workgroup works on one tile at a time; workgroups of XCD x walk the x-th contiguous eighth of the tiles.
+template <int MODE>
+__global__ __launch_bounds__(kTileThreads) void k_spmv0t(Sym0Dev A, Tile0Dev TL, Spmv0Args a) {
+  if (a.S && a.S->stop) return;
+  extern __shared__ double lds[];
+  constexpr int NW = kTileThreads / 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const size_t nu = (size_t)A.nu;
+  const double2* __restrict__ bp = reinterpret_cast<const double2*>(A.ublk);
+  double dotacc[2] = {0.0, 0.0};
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
+  const int tlo = (int)(((long long)TL.ntile * xcd) >> 3), thi = (int)(((long long)TL.ntile * (xcd + 1)) >> 3);
+  for (int t = tlo + slot; t < thi; t += per_xcd) {
+    const TileDesc T = TL.tile[t];
+    const int nr = T.row1 - T.row0, nh = T.h1 - T.h0;
+    double* xs = lds;                    // [nr + nh][3] operand: the tile's rows, then its halo columns
+    double* ys = xs + 3 * (nr + nh);     // [nr][3] owned part of the row sums
+    double* vst = ys + 3 * nr;           // [nstaged][3]
+    // ---- phase 0: operand slice and halo to LDS, owned sums cleared
+    for (int i = tid; i < 3 * nr; i += kTileThreads) {
+      xs[i] = a.x[3 * (size_t)T.row0 + i];
+      ys[i] = 0.0;
+    }
+    for (int i = tid; i < nh; i += kTileThreads) {
+      const size_t c3 = 3 * (size_t)TL.hcol[T.h0 + i];
+      const double h0 = a.x[c3], h1 = a.x[c3 + 1], h2 = a.x[c3 + 2];
+      double* d = xs + 3 * (nr + i);
+      d[0] = h0; d[1] = h1; d[2] = h2;
+    }
+    __syncthreads();
+    // ---- phase 1: one lane per stored block; groups hold whole rows
+    for (int g = T.g0 + wave; g < T.g1; g += NW) {
+      const int gb = TL.grp1[g], ge = TL.grp1[g + 1], r0 = TL.grow1[g];
+      double acc[3] = {0.0, 0.0, 0.0};
+      int row = -1 - lane;
+      for (int k = gb + lane; k < ge; k += 64) {
+        const unsigned cw = TL.cv[k];
+        row = r0 + TL.off1[k];
+        const double2 p0 = bp[k], p1 = bp[nu + k], p2 = bp[2 * nu + k], p3 = bp[3 * nu + k];
+        const double b8 = A.ublk[8 * nu + k];
+        const double* xc = xs + 3 * (cw & 0xFFFFu);
+        const double x0 = xc[0], x1 = xc[1], x2 = xc[2];
+        acc[0] += p0.x * x0 + p0.y * x1 + p1.x * x2;
+        acc[1] += p1.y * x0 + p2.x * x1 + p2.y * x2;
+        acc[2] += p3.x * x0 + p3.y * x1 + b8 * x2;
+        const unsigned vp = cw >> 16;
+        if (vp != 0xFFFFu) {   // the twin row is in this tile: hand it B^T x_row through LDS
+          const double* xr = xs + 3 * (row - T.row0);
+          const double s0 = xr[0], s1 = xr[1], s2 = xr[2];
+          double* v = vst + 3 * vp;
+          v[0] = p0.x * s0 + p1.y * s1 + p3.x * s2;
+          v[1] = p0.y * s0 + p2.x * s1 + p3.y * s2;
+          v[2] = p1.x * s0 + p2.y * s1 + b8 * s2;
+        }
+      }
+      seg_scan<3>(row, acc, lane);
+      const int rn = __shfl_down(row, 1);
+      if (row >= 0 && (lane == 63 || rn != row)) {   // a row's owned slots sit in exactly one group: single writer
+        double* d = ys + 3 * (row - T.row0);
+        d[0] = acc[0]; d[1] = acc[1]; d[2] = acc[2];
+      }
+    }
+    __syncthreads();
+    // ---- phase 2: one thread per row: staged entries in order, owned part, diagonal block, epilogue
+    for (int i = tid; i < nr; i += kTileThreads) {
+      const int r = T.row0 + i;
+      const int e0 = TL.trowptr[r] - T.e0, e1 = TL.trowptr[r + 1] - T.e0;
+      const double s0 = xs[3 * i], s1 = xs[3 * i + 1], s2 = xs[3 * i + 2];
+      const double* dd = A.dblk + 6 * (size_t)r;
+      double o0 = ys[3 * i], o1 = ys[3 * i + 1], o2 = ys[3 * i + 2];
+      for (int e = e0; e < e1; ++e) {
+        o0 += vst[3 * e]; o1 += vst[3 * e + 1]; o2 += vst[3 * e + 2];
+      }
+      o0 += dd[0] * s0 + dd[1] * s1 + dd[2] * s2;
+      o1 += dd[1] * s0 + dd[3] * s1 + dd[4] * s2;
+      o2 += dd[2] * s0 + dd[4] * s1 + dd[5] * s2;
+      const size_t o = 3 * (size_t)r;
+      if (MODE != S0_AX) {
+        const double t0 = a.b[o] - o0, t1 = a.b[o + 1] - o1, t2 = a.b[o + 2] - o2;
+        if (MODE == S0_JACOBI) {
+          const double* di = A.dinv + 6 * (size_t)r;
+          o0 = s0 + a.omega * (di[0] * t0 + di[1] * t1 + di[2] * t2);
+          o1 = s1 + a.omega * (di[1] * t0 + di[3] * t1 + di[4] * t2);
+          o2 = s2 + a.omega * (di[2] * t0 + di[4] * t1 + di[5] * t2);
+        } else {
+          o0 = t0; o1 = t1; o2 = t2;
+        }
+      }
+      a.y[o] = o0; a.y[o + 1] = o1; a.y[o + 2] = o2;
+      if (a.dotA) dotacc[0] += a.dotA[o] * o0 + a.dotA[o + 1] * o1 + a.dotA[o + 2] * o2;
+      if (a.dotA2) dotacc[1] += a.dotA2[o] * o0 + a.dotA2[o + 1] * o1 + a.dotA2[o + 2] * o2;
+    }
+    __syncthreads();   // the next tile reuses the LDS
+  }
+  if (a.partials) {
+    __shared__ double sm[2][NW];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const double sum = wave_sum(dotacc[i]);
+      if (lane == 0) sm[i][wave] = sum;
+    }
+    __syncthreads();
+    if (tid == 0) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        double sum = sm[i][0];
+#pragma unroll
+        for (int k = 1; k < NW; ++k) sum += sm[i][k];
+        a.partials[(size_t)i * kMaxPartials + blockIdx.x] = sum;
+      }
+    }
+  }
 }
 
 // alpha = r.z / p.q from the partials of p.q (every workgroup re-reduces them in the same fixed
@@ -677,6 +803,18 @@ int launch_spmv0(hipStream_t s, const Sym0Dev& A, int mode, const Spmv0Args& a) 
     case S0_AX: SGO_LAUNCH((k_spmv0<S0_AX>), dim3(grid), dim3(kBlock), 0, s, A, a); break;
     case S0_RESID: SGO_LAUNCH((k_spmv0<S0_RESID>), dim3(grid), dim3(kBlock), 0, s, A, a); break;
     default: SGO_LAUNCH((k_spmv0<S0_JACOBI>), dim3(grid), dim3(kBlock), 0, s, A, a); break;
+  }
+  return grid;
+}
+int launch_spmv0t(hipStream_t s, const Sym0Dev& A, const Tile0Dev& T, int mode, const Spmv0Args& a) {
+  // at most two tile workgroups fit a CU (LDS): 512 resident; more tiles are walked in a loop
+  long long g = std::min<long long>(T.ntile, 2LL * 256);
+  if (g < 8) g = 8;
+  const int grid = (int)((g + 7) / 8 * 8);
+  switch (mode) {
+    case S0_AX: SGO_LAUNCH((k_spmv0t<S0_AX>), dim3(grid), dim3(kTileThreads), (size_t)T.lds_bytes, s, A, T, a); break;
+    case S0_RESID: SGO_LAUNCH((k_spmv0t<S0_RESID>), dim3(grid), dim3(kTileThreads), (size_t)T.lds_bytes, s, A, T, a); break;
+    default: SGO_LAUNCH((k_spmv0t<S0_JACOBI>), dim3(grid), dim3(kTileThreads), (size_t)T.lds_bytes, s, A, T, a); break;
   }
   return grid;
 }
