@@ -16,7 +16,7 @@ with capi.Optimizer(0) as o:
     o.linearize()
     import os
     reps = int(os.environ.get("SGO_PROBE_REPS", "200"))
-    variants = [int(v) for v in os.environ.get("SGO_PROBE_VARIANTS", "0,16").split(",")]
+    variants = [int(v) for v in os.environ.get("SGO_PROBE_VARIANTS", "0").split(",")]
     for variant in variants:
         t = [L.sgo_debug_spmv0_us(o._h, mode, variant, reps) for mode in (0, 1, 2)]
         print(f"variant {variant:2d}: AX {t[0]:.1f} us  RESID {t[1]:.1f} us  JACOBI {t[2]:.1f} us", flush=True)

@@ -37,6 +37,9 @@ struct Amg;  // opaque
 struct HostLevel {
   int n = 0, nslot = 0;
   std::vector<int> rowptr, row, col;
+  std::vector<int> visit;   // order in which the greedy aggregation visits the nodes (empty: 0, 1, 2, ...).  Level 0
+                            // is visited along the trajectory (ascending vertex id) although its rows are numbered
+                            // along a Hilbert curve: chains of odometry edges then pair up regularly
 };
 
 // Build the hierarchy for the level-0 matrix: S0 is its symmetric storage (the cycle's level-0 products

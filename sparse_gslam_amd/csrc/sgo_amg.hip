@@ -662,6 +662,7 @@ std::vector<int> make_groups(const std::vector<int>& ptr) {
 int aggregate(const HostLevel& L, const std::vector<double>& w, double theta, std::vector<int>& agg) {
   const int n = L.n;
   agg.assign(n, -1);
+  const int* visit = L.visit.size() == (size_t)n ? L.visit.data() : nullptr;
   std::vector<uint8_t> sflag(L.nslot, 0);   // strength of every slot, evaluated once
   for (int i = 0; i < n; ++i) {
     const double di = w[L.rowptr[i]];
@@ -675,7 +676,8 @@ int aggregate(const HostLevel& L, const std::vector<double>& w, double theta, st
   auto strong = [&](int, int k) { return sflag[k] != 0; };
   int nc = 0;
   // pass 1: a node all of whose strong neighbours are free roots a new aggregate
-  for (int i = 0; i < n; ++i) {
+  for (int t = 0; t < n; ++t) {
+    const int i = visit ? visit[t] : t;
     if (agg[i] >= 0) continue;
     bool any = false, ok = true;
     for (int k = L.rowptr[i] + 1; k < L.rowptr[i + 1] && ok; ++k)
@@ -691,7 +693,8 @@ int aggregate(const HostLevel& L, const std::vector<double>& w, double theta, st
   }
   // pass 2: leftovers join the aggregate of their strongest aggregated strong neighbour
   std::vector<int> agg1(agg);
-  for (int i = 0; i < n; ++i) {
+  for (int t = 0; t < n; ++t) {
+    const int i = visit ? visit[t] : t;
     if (agg1[i] >= 0) continue;
     double best = -1.0;
     int ba = -1;
@@ -703,7 +706,8 @@ int aggregate(const HostLevel& L, const std::vector<double>& w, double theta, st
     if (ba >= 0) agg[i] = ba;
   }
   // pass 3: whatever is left forms aggregates with its free strong neighbours
-  for (int i = 0; i < n; ++i) {
+  for (int t = 0; t < n; ++t) {
+    const int i = visit ? visit[t] : t;
     if (agg[i] >= 0) continue;
     agg[i] = nc;
     for (int k = L.rowptr[i] + 1; k < L.rowptr[i + 1]; ++k)
@@ -711,6 +715,18 @@ int aggregate(const HostLevel& L, const std::vector<double>& w, double theta, st
     ++nc;
   }
   return nc;
+}
+
+// Renumber the aggregates in the order in which they first appear along the rows (the coarse level then
+// inherits the fine level's locality); `visit_c` receives the new ids in creation order, i.e. the order in
+// which the next level's aggregation should visit them to continue along the trajectory.
+void renumber_aggregates(std::vector<int>& agg, int nc, std::vector<int>& visit_c) {
+  std::vector<int> newid((size_t)nc, -1);
+  int next = 0;
+  for (size_t i = 0; i < agg.size(); ++i)
+    if (newid[agg[i]] < 0) newid[agg[i]] = next++;
+  for (size_t i = 0; i < agg.size(); ++i) agg[i] = newid[agg[i]];
+  visit_c.assign(newid.begin(), newid.end());
 }
 
 // Host side of the smoothed-aggregation set-up: patterns of P, AP = A P and A_c = P^T AP and, for
@@ -1181,7 +1197,7 @@ int cycle(Amg* m, hipStream_t s, int l, const double* rhs, const double* rhs_sub
     }
     Spmv0Args a{};
     a.x = L.xs; a.b = rhs; a.y = L.rs; a.S = S;
-    Scope sc(m->prof, K_SPMV0_RESID, 76.0 * m->S0.nu + 120.0 * m->S0.n);
+    Scope sc(m->prof, m->T0.ntile > 0 ? K_SPMV0T_RESID : K_SPMV0_RESID, 76.0 * m->S0.npairs + 120.0 * m->S0.n);
     launch_spmv0_any(s, m->S0, m->T0, S0_RESID, a);
   } else {
     SpmvArgs a{};
@@ -1255,7 +1271,7 @@ int cycle(Amg* m, hipStream_t s, int l, const double* rhs, const double* rhs_sub
       b.dotA2 = dotvec2;
       b.partials = dotparts;
     }
-    Scope sc(m->prof, K_SPMV0_JACOBI, 76.0 * m->S0.nu + 168.0 * m->S0.n);
+    Scope sc(m->prof, m->T0.ntile > 0 ? K_SPMV0T_JACOBI : K_SPMV0_JACOBI, 76.0 * m->S0.npairs + 168.0 * m->S0.n);
     return launch_spmv0_any(s, m->S0, m->T0, S0_JACOBI, b);
   }
   if (L.smoothed) {
@@ -1460,6 +1476,8 @@ Amg* amg_create(hipStream_t s, const BsrDev& A0, const Sym0Dev& S0, const Tile0D
     int nc = aggregate(H, w, theta_l, agg);
     if (nc > 0.9 * n) nc = aggregate(H, w, 0.0, agg);  // stalled: treat every connection as strong
     if (nc > 0.9 * n || nc < 1) break;                   // cannot coarsen further
+    std::vector<int> visit_c;
+    if (!H.visit.empty()) renumber_aggregates(agg, nc, visit_c);
     t_agg = ms_since(tA);
 
     // members by aggregate
@@ -1644,6 +1662,7 @@ Amg* amg_create(hipStream_t s, const BsrDev& A0, const Sym0Dev& S0, const Tile0D
         std::fprintf(stderr, "[sgo] amg level %d: alloc + upload %.1f ms, first values %.1f ms\n", l, t_up, ms_since(tU) - t_up);
     }
     Hown = std::move(Hc);
+    Hown.visit = std::move(visit_c);
     Hp = &Hown;
   }
   const int last = (int)m->lv.size() - 1;

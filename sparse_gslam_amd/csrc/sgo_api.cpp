@@ -302,7 +302,7 @@ struct Scope {
 // block (48 B), the operand and the result (24 B each) per row; + the right-hand side (RESID, JACOBI)
 // and the block-diagonal inverse (JACOBI).
 double bytes_spmv0(const Sym0Dev& A, int mode) {
-  return 76.0 * A.nu + (96.0 + (mode != S0_AX ? 24.0 : 0.0) + (mode == S0_JACOBI ? 48.0 : 0.0)) * A.n;
+  return 76.0 * A.npairs + (96.0 + (mode != S0_AX ? 24.0 : 0.0) + (mode == S0_JACOBI ? 48.0 : 0.0)) * A.n;
 }
 // linearise + assemble: the row-parallel design reads each edge's operands once per endpoint row
 // (2 x 128 B: indices, inverse measurement, information, two poses), writes the off-diagonal block once
@@ -469,10 +469,18 @@ int build_structure(sgo_ctx* c, int V, const double* poses, const uint8_t* fixed
   int tile_lds = 0;
   bool tiles_ok = true;
   {
-    const int lds_budget = kTileLdsMax - 1024;
+    int lds_budget = kTileLdsMax - 1024;
+    if (const char* e = std::getenv("SGO_TILE_LDS")) lds_budget = std::atoi(e);
+    int tile_div = 512;   // two tiles per CU
+    {
+      hipDeviceProp_t prop;
+      if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0)
+        tile_div = 2 * prop.multiProcessorCount;
+    }
+    if (const char* e = std::getenv("SGO_TILE_DIV")) tile_div = std::max(1, std::atoi(e));
     long long nblk = 0;
     for (int k = 0; k < ns; ++k) nblk += col[k] >= 0;
-    long long target = std::max<long long>(512, (nblk / 2 + 511) / 512);   // slots per tile (both directions counted)
+    long long target = std::max<long long>(512, (nblk / 2 + tile_div - 1) / tile_div);   // pairs per tile
     std::vector<int> mark(std::max(n, 1), -1);
     for (int attempt = 0; attempt < 6; ++attempt) {
       tiles.clear();
@@ -606,6 +614,7 @@ int build_structure(sgo_ctx* c, int V, const double* poses, const uint8_t* fixed
   // logical structure for the multigrid set-up (diagonal slot first, then the row's block slots)
   HostLevel& H = c->H0;
   H.n = n;
+  H.visit = c->row_of_asc;   // the multigrid aggregation walks level 0 along the trajectory (ascending vertex id)
   H.rowptr.assign((size_t)n + 1, 0);
   for (int r = 0; r < n; ++r) {
     int nb = 1;
@@ -723,6 +732,7 @@ int build_structure(sgo_ctx* c, int V, const double* poses, const uint8_t* fixed
   Sym0Dev& S = c->S0;
   S.n = n;
   S.nu = nu;
+  S.npairs = (nu + ntr) / 2;   // owned = intra pairs + 2 x inter pairs, transposed = intra pairs
   S.ncs = ns;
   S.ngrp = ngrp;
   if ((rc = upload(c, &S.col, col))) return rc;
@@ -740,6 +750,7 @@ int build_structure(sgo_ctx* c, int V, const double* poses, const uint8_t* fixed
   if (tiles_ok && !tiles.empty()) {
     TL.ntile = (int)tiles.size();
     TL.lds_bytes = tile_lds;
+    if (const char* e = std::getenv("SGO_TILE_THREADS")) TL.threads = std::atoi(e) == 1024 ? 1024 : 512;
     if (hcol.empty()) hcol.push_back(0);
     if ((rc = upload(c, &TL.tile, tiles))) return rc;
     if ((rc = upload(c, &TL.cv, cv))) return rc;
@@ -884,7 +895,7 @@ int do_linearize(sgo_ctx* c) {
 // y = H x  (+ optional x.y partials).  The solve is replicated on every rank (identical H after
 // the all-reduce in do_linearize), so no collective is needed here.
 int do_spmv(sgo_ctx* c, const double* x, double* y, bool dot, const PcgScalars* S, int* grid_out) {
-  Scope sc(c, K_SPMV0_AX, bytes_spmv0(c->S0, S0_AX));
+  Scope sc(c, c->T0.ntile > 0 ? K_SPMV0T_AX : K_SPMV0_AX, bytes_spmv0(c->S0, S0_AX));
   Spmv0Args a{};
   a.x = x;
   a.y = y;

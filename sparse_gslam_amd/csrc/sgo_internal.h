@@ -81,7 +81,8 @@ __host__ __device__ inline size_t blk_at(int c, size_t k, size_t ns) {
 enum : int { kSlotOwned = 0, kSlotTransposed = 1, kSlotNoBlock = 2 };
 struct Sym0Dev {
   int n = 0;        // rows
-  int nu = 0;       // stored off-diagonal blocks
+  int npairs = 0;   // connected pairs of free rows = the blocks a fully symmetric storage holds (SURVEY 8(d)'s E)
+  int nu = 0;       // stored off-diagonal blocks (pairs inside a tile once, pairs across tiles twice)
   int ncs = 0;      // compact slots
   int ngrp = 0;
   int* col = nullptr;            // [ncs]
@@ -124,6 +125,7 @@ struct TileDesc {
 struct Tile0Dev {
   int ntile = 0;
   int lds_bytes = 0;          // dynamic LDS per workgroup (largest tile)
+  int threads = 512;          // workgroup size (512 or 1024)
   TileDesc* tile = nullptr;
   unsigned int* cv = nullptr;       // [nu] owned slot u: LDS operand index (local row, or rows + halo number) in
                                     // bits 0..15, tile-relative staging slot of its twin in bits 16..31 (0xFFFF: none)
@@ -261,9 +263,12 @@ enum KernelId : int {
   K_RESTRICT_P,
   K_PROLONG_P,
   K_SPMV_PRE_RESID_ACC,
-  K_SPMV0_AX,           // the level-0 products on the symmetric storage
+  K_SPMV0_AX,           // the level-0 products, wave-group kernel (graphs without a tile view)
   K_SPMV0_RESID,
   K_SPMV0_JACOBI,
+  K_SPMV0T_AX,          // the level-0 products, tile kernel
+  K_SPMV0T_RESID,
+  K_SPMV0T_JACOBI,
   K_COUNT
 };
 extern const char* const kKernelNames[K_COUNT];
@@ -370,8 +375,7 @@ int launch_spmv0t(hipStream_t s, const Sym0Dev& A, const Tile0Dev& T, int mode, 
 inline int launch_spmv0_any(hipStream_t s, const Sym0Dev& A, const Tile0Dev& T, int mode, const Spmv0Args& a) {
   return T.ntile > 0 ? launch_spmv0t(s, A, T, mode, a) : launch_spmv0(s, A, mode, a);
 }
-constexpr int kTileThreads = 512;
-constexpr int kTileLdsMax = 64 * 1024;   // two workgroups per CU
+constexpr int kTileLdsMax = 79 * 1024;   // two tile workgroups per CU (160 KiB of LDS)
 int launch_spmv_ex(hipStream_t s, const BsrDev& A, int mode, const SpmvArgs& a);  // returns grid
 void launch_update_xr(hipStream_t s, int n, PcgScalars* S, const double* pq_parts, int n_pq, const double* dinv,
                       const double* p, const double* q, double* x, double* r, double* z, double* xs, double omega,

@@ -33,7 +33,7 @@ const char* const kKernelNames[K_COUNT] = {
     "k_pose_update", "k_positions0", "k_centres",   "k_galerkin",   "k_level_dinv",   "k_restrict", "k_prolong_add",
     "k_gj_panels+k_gj_trail (dense inverse)", "k_dense_apply", "k_p_values", "k_block_products<1, 0, 0>",
     "k_block_products<0, 1, 1>", "k_restrict_p", "k_prolong_p", "k_spmv<7>",
-    "k_spmv0<0>", "k_spmv0<1>", "k_spmv0<2>"};
+    "k_spmv0<0>", "k_spmv0<1>", "k_spmv0<2>", "k_spmv0t<0, 512>", "k_spmv0t<1, 512>", "k_spmv0t<2, 512>"};
 
 namespace {
 
@@ -522,7 +522,7 @@ __global__ __launch_bounds__(kBlock, 8) void k_spmv0(Sym0Dev A, Spmv0Args a) {
 // exactly one lane, operands come from LDS (the tile's slice + its halo, fetched once per tile), transposed
 // contributions of intra-tile pairs travel through LDS staging.  Modes and epilogues as k_spmv0.  One
 // workgroup works on one tile at a time; workgroups of XCD x walk the x-th contiguous eighth of the tiles.
-template <int MODE>
+template <int MODE, int kTileThreads>
 __global__ __launch_bounds__(kTileThreads) void k_spmv0t(Sym0Dev A, Tile0Dev TL, Spmv0Args a) {
   if (a.S && a.S->stop) return;
   extern __shared__ double lds[];
@@ -806,15 +806,33 @@ int launch_spmv0(hipStream_t s, const Sym0Dev& A, int mode, const Spmv0Args& a) 
   }
   return grid;
 }
+template <int MODE, int NT>
+void launch_spmv0t_inst(hipStream_t s, const Sym0Dev& A, const Tile0Dev& T, const Spmv0Args& a, int grid) {
+  static int lds_allowed = 0;   // dynamic LDS beyond 64 KB needs the attribute once per kernel
+  if (T.lds_bytes > 65536 && T.lds_bytes > lds_allowed) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spmv0t<MODE, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+    lds_allowed = 160 * 1024 - 256;
+  }
+  SGO_LAUNCH((k_spmv0t<MODE, NT>), dim3(grid), dim3(NT), (size_t)T.lds_bytes, s, A, T, a);
+}
 int launch_spmv0t(hipStream_t s, const Sym0Dev& A, const Tile0Dev& T, int mode, const Spmv0Args& a) {
-  // at most two tile workgroups fit a CU (LDS): 512 resident; more tiles are walked in a loop
-  long long g = std::min<long long>(T.ntile, 2LL * 256);
+  // as many tile workgroups as fit the CUs' LDS are resident; more tiles are walked in a loop
+  const int per_cu = std::max(1, std::min(T.threads == 1024 ? 2 : 4, (160 * 1024) / std::max(T.lds_bytes + 512, 1)));
+  long long g = std::min<long long>(T.ntile, 256LL * per_cu);
   if (g < 8) g = 8;
   const int grid = (int)((g + 7) / 8 * 8);
-  switch (mode) {
-    case S0_AX: SGO_LAUNCH((k_spmv0t<S0_AX>), dim3(grid), dim3(kTileThreads), (size_t)T.lds_bytes, s, A, T, a); break;
-    case S0_RESID: SGO_LAUNCH((k_spmv0t<S0_RESID>), dim3(grid), dim3(kTileThreads), (size_t)T.lds_bytes, s, A, T, a); break;
-    default: SGO_LAUNCH((k_spmv0t<S0_JACOBI>), dim3(grid), dim3(kTileThreads), (size_t)T.lds_bytes, s, A, T, a); break;
+  if (T.threads == 1024) {
+    switch (mode) {
+      case S0_AX: launch_spmv0t_inst<S0_AX, 1024>(s, A, T, a, grid); break;
+      case S0_RESID: launch_spmv0t_inst<S0_RESID, 1024>(s, A, T, a, grid); break;
+      default: launch_spmv0t_inst<S0_JACOBI, 1024>(s, A, T, a, grid); break;
+    }
+  } else {
+    switch (mode) {
+      case S0_AX: launch_spmv0t_inst<S0_AX, 512>(s, A, T, a, grid); break;
+      case S0_RESID: launch_spmv0t_inst<S0_RESID, 512>(s, A, T, a, grid); break;
+      default: launch_spmv0t_inst<S0_JACOBI, 512>(s, A, T, a, grid); break;
+    }
   }
   return grid;
 }
