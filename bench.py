@@ -11,10 +11,9 @@ steps x iters x E / time = edge-Jacobian evaluations per second per GN iteration
 the timed region is the 24*V-byte pose reset at the start of each step.
 
 N > 1: launched by ``python -m torch.distributed.run``; one rank per GPU.  Every rank holds the full
-graph; per GN iteration rank r evaluates the edge Jacobians of its contiguous band of Hessian rows
-and the per-vertex (block-diagonal H, b) contributions plus the off-diagonal blocks are all-reduced
-with RCCL inside libsgo; the linear solve then runs replicated (DESIGN.md section 6 says why).
-Total work is fixed => "scaling": "strong".
+graph; every level-0 Hessian product of the solve (each pass over the edges' blocks: three per PCG
+iteration) is evaluated by rank r for the rows of its range of tiles and the product vector is
+all-reduced with RCCL inside libsgo.  Total work is fixed => "scaling": "strong".
 """
 from __future__ import annotations
 
@@ -54,6 +53,21 @@ def cpu_baseline(g, iters: int):
                        f"single-thread C++ oracle, sparse direct LDL^T + min-degree ordering, on the "
                        f"first {Vs} poses / {Es} edges of the workload, median of GN iterations 2-3 "
                        f"(numeric factorisation + solve; symbolic analysis excluded){note}")
+
+
+def golden_rel_err(config, iters, st):
+    """Relative error of the final chi2 against the committed CPU-oracle fixture of this workload
+    (tests/golden/<config>_{direct,pcg}.npz: sparse direct LDL^T, or the oracle's PCG for graphs with random
+    closures), None when there is no fixture for (config, iters)."""
+    for kind in ("direct", "pcg"):
+        path = os.path.join(ROOT, "tests", "golden", f"{config}_{kind}.npz")
+        if os.path.exists(path):
+            f = np.load(path)
+            if int(f["iters"]) == iters:
+                ref = float(f["chi2"][-1])
+                return {"value": abs(st["chi2"][-1] - ref) / ref, "reference": f"{config}_{kind}.npz (CPU oracle, {kind})",
+                        "bound": 1e-6}
+    return None
 
 
 def main():
@@ -101,28 +115,29 @@ def main():
     if args.tol:
         opts["pcg_tol"] = args.tol
     opt = capi.Optimizer(local_rank, **opts)
-    sharding = f"row-band sharded linearisation x{world}, replicated solve"
+    sharding = "single GPU" if world == 1 else (
+        f"level-0 Hessian products sharded over {world} tile ranges + ncclAllReduce of the product vector per PCG "
+        f"step; linearisation, coarse multigrid levels and vector recurrences replicated")
     if world > 1 or os.environ.get("SGO_BENCH_FORCE_COMM"):
-        # rendezvous for libsgo's own RCCL communicator: rank 0 makes the id, torch broadcasts it
+        # rendezvous for libsgo's own RCCL communicator: rank 0 makes the id, torch broadcasts it.  No
+        # communicator, no multi-GPU number: a failure on any rank ends the run with a non-zero exit code
+        # instead of silently benchmarking N replicas.
         uid = [capi.comm_unique_id() if rank == 0 else None]
         if world > 1:
             dist.broadcast_object_list(uid, src=0)
         comm_error = None
         try:
             opt.comm_init(world, rank, uid[0])
-        except capi.SgoError as e:   # e.g. librccl not loadable: agree on it across ranks, then run replicated
+        except capi.SgoError as e:
             comm_error = str(e)
         if world > 1:
             ok = torch.tensor([0 if comm_error else 1], dtype=torch.int32, device="cuda")
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
             if int(ok.item()) == 0:
-                if comm_error is None:   # this rank has a communicator the others lack: start over without it
-                    opt.close()
-                    opt = capi.Optimizer(local_rank, **opts)
-                    comm_error = "sgo_comm_init failed on another rank"
-                sharding = f"replicated on {world} GPUs (no sharding: {comm_error})"
-                if rank == 0:
-                    print(f"[bench] {sharding}", file=sys.stderr)
+                opt.close()
+                dist.destroy_process_group()
+                raise SystemExit(f"[bench] rank {rank}: RCCL communicator unavailable ({comm_error or 'failed on another rank'}); "
+                                 "no multi-GPU measurement")
         elif comm_error:
             raise SystemExit(comm_error)
     opt.set_graph(*g.arrays())
@@ -164,6 +179,7 @@ def main():
                        "solver": {0: "pcg_block_jacobi", 1: "pcg_amg"}[opts.get("solver", o.solver)],
                        "pcg_tol": opts.get("pcg_tol", o.pcg_tol), "parallelism": sharding},
             "final_chi2": st["chi2"][-1], "final_robust_chi2": st["robust_chi2"][-1],
+            "final_chi2_rel_err_vs_oracle": golden_rel_err(args.config, args.iters, st),
             "pcg_iters_per_gn_iter": float(np.mean(st["pcg_iters"])), "pcg_iters": st["pcg_iters"],
             "gn_iter_ms_median": 1e3 * float(np.median(st["seconds"])),
             "set_graph_ms": 1e3 * st["seconds_setup"],   # host structure build + upload + multigrid set-up (not in value)

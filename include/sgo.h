@@ -110,9 +110,10 @@ void sgo_destroy(sgo_ctx* ctx);
 
 /* Replaces: SparseOptimizer::initializeOptimization() (slc.cpp:286, log_runner.cpp:203): takes
  * the active vertices/edges, builds the hessian index map (non-fixed vertices in ascending id),
- * the block-CSR structure and the device-resident SoA edge arrays.  Edges whose endpoints are
- * both fixed stay active for chi2 only.  With a communicator attached (sgo_comm_init) every
- * rank passes the same full graph. */
+ * the block-sparse structure (rows numbered internally along a Hilbert curve through the poses, every
+ * off-diagonal block stored once inside a tile of rows) and the device-resident SoA edge arrays.  Edges
+ * whose endpoints are both fixed stay active for chi2 only.  With a communicator attached
+ * (sgo_comm_init) every rank passes the same full graph. */
 int sgo_set_graph_se2(sgo_ctx* ctx, int32_t V, const double* poses, const uint8_t* fixed, int32_t E,
                       const int32_t* ei, const int32_t* ej, const double* meas, const double* info,
                       const double* phi);
@@ -198,26 +199,38 @@ int sgo_profile_reset(sgo_ctx* ctx);
 double sgo_profile_overhead_ms(sgo_ctx* ctx);
 
 /* ---- multi-GPU: one process per GPU, RCCL over xGMI ------------------------------------------
- * Every rank is given the SAME full graph.  Per GN iteration rank r evaluates the edge
- * Jacobians of its contiguous band of Hessian rows (sgo_shard_range over the row groups), the
- * per-vertex (block-diagonal H, b) contributions and the off-diagonal blocks are summed over
- * ranks with ncclAllReduce (every value has exactly one non-zero contributor, so the result is
- * bit-identical to the single-GPU arrays), and the linear solve then runs replicated. */
+ * Every rank is given the SAME full graph (sgo_set_graph_se2 with identical arguments).  The rows of the
+ * level-0 Hessian are cut into tiles of consecutive rows (Hilbert order of the poses); rank r owns the
+ * contiguous range of tiles sgo_shard_range(ntiles, nranks, r).  Every level-0 Hessian product of the solve
+ * -- H p of the CG recurrence and the two smoothing passes of the multigrid cycle, i.e. every pass over
+ * the edges' blocks -- is evaluated by each rank for the rows of its tiles only, zeros elsewhere, and the
+ * product vector is summed over ranks with ncclAllReduce (one non-zero contributor per row: the sum is
+ * exact), the per-PCG-step exchange BASELINE.json's north_star names.  chi2 is summed over edge ranges the
+ * same way.  Linearisation (1.5 % of an iteration), the coarse multigrid levels and the vector recurrences
+ * run replicated, on bit-identical data, so every rank takes the same decisions. */
 /* 128-byte unique id for rendezvous (wraps ncclGetUniqueId); rank 0 creates it, the host layer
  * broadcasts it (torch.distributed / MPI / a file), every rank passes it to sgo_comm_init. */
 #define SGO_UNIQUE_ID_BYTES 128
 int sgo_comm_unique_id(void* id_out);
 int sgo_comm_init(sgo_ctx* ctx, int nranks, int rank, const void* unique_id);
 int sgo_comm_size(sgo_ctx* ctx);
-/* The contiguous range [begin, end) of `count` work units (row groups, edges) that rank `rank` of
+/* The contiguous range [begin, end) of `count` work units (tiles, edges) that rank `rank` of
  * `nranks` evaluates.  Pure function (no GPU needed); exposed so the host layer and the CPU tests
  * can reproduce the partition. */
 void sgo_shard_range(int32_t count, int32_t nranks, int32_t rank, int32_t* begin, int32_t* end);
+/* The row plan sgo_set_graph_se2 makes for a graph, computed on the host alone (no GPU, no context): the
+ * number of free active vertices n, the vertex id of every internal row (row_vertex[n], Hilbert order), the
+ * tiles (tile_row_begin[ntiles + 1], capacity tile_cap) and the first row of every rank's tile range
+ * (rank_row_begin[nranks + 1]).  Output pointers may be NULL.  Lets multi-process callers and the CPU tests
+ * see which rows of a level-0 product each rank contributes. */
+int sgo_plan_rows(int32_t V, const double* poses, const uint8_t* fixed, int32_t E, const int32_t* ei, const int32_t* ej,
+                  int32_t nranks, int32_t* n_free, int32_t* row_vertex, int32_t* ntiles, int32_t* tile_row_begin,
+                  int32_t tile_cap, int32_t* rank_row_begin);
 
-/* Test hook: make this context evaluate the band of rank `rank` of `nranks` WITHOUT a
- * communicator (collectives are skipped), so that the per-rank partial arrays can be inspected on
- * a single GPU: summing sgo_linearize's b / diag over rank = 0..nranks-1 must reproduce the
- * single-rank result exactly.  Must precede sgo_set_graph_se2. */
+/* Test hook: make this context evaluate the tile range of rank `rank` of `nranks` WITHOUT a
+ * communicator (collectives are skipped), so that the per-rank partial products can be inspected on
+ * a single GPU: summing sgo_hessian_apply's result over rank = 0..nranks-1 must reproduce the
+ * single-rank product exactly.  Must precede sgo_set_graph_se2. */
 int sgo_debug_set_shard(sgo_ctx* ctx, int nranks, int rank);
 
 /* Text of the last error on this context (or, with ctx == NULL, of the last failed sgo_create /

@@ -27,7 +27,7 @@ SYMBOLS = [
     "sgo_num_free", "sgo_free_ids", "sgo_linearize", "sgo_hessian_apply", "sgo_solve",
     "sgo_precondition", "sgo_kernel_profile", "sgo_profile_reset", "sgo_profile_overhead_ms", "sgo_comm_unique_id",
     "sgo_comm_init", "sgo_comm_size", "sgo_shard_range", "sgo_debug_set_shard", "sgo_last_error",
-    "sgo_closure_information",
+    "sgo_closure_information", "sgo_plan_rows",
 ]
 
 
@@ -120,6 +120,7 @@ def lib():
     L.sgo_shard_range.argtypes = [C.c_int32, C.c_int32, C.c_int32, i32, i32]
     L.sgo_debug_set_shard.argtypes = [vp, C.c_int, C.c_int]
     L.sgo_closure_information.argtypes = [vp, C.c_int32, C.POINTER(MatchWindow), C.POINTER(C.c_float), C.c_int64, d, d]
+    L.sgo_plan_rows.argtypes = [C.c_int32, d, u8, C.c_int32, i32, i32, C.c_int32, i32, i32, i32, i32, C.c_int32, i32]
     L.sgo_last_error.restype = C.c_char_p
     L.sgo_last_error.argtypes = [vp]
     _LIB = L
@@ -146,6 +147,27 @@ def shard_range(count: int, nranks: int, rank: int):
     b = C.c_int32()
     lib().sgo_shard_range(count, nranks, rank, C.byref(a), C.byref(b))
     return a.value, b.value
+
+
+def plan_rows(poses, fixed, ei, ej, nranks: int = 1):
+    """Host-only row plan of a graph (sgo_plan_rows; needs no GPU): dict with n, row_vertex (n,),
+    tile_row_begin (ntiles + 1,), rank_row_begin (nranks + 1,)."""
+    p = np.ascontiguousarray(poses, dtype=np.float64).reshape(-1, 3)
+    f = np.ascontiguousarray(fixed, dtype=np.uint8)
+    a = np.ascontiguousarray(ei, dtype=np.int32)
+    b = np.ascontiguousarray(ej, dtype=np.int32)
+    V = p.shape[0]
+    n = C.c_int32()
+    nt = C.c_int32()
+    rv = np.empty(V, dtype=np.int32)
+    tb = np.empty(V + 2, dtype=np.int32)
+    rb = np.empty(nranks + 1, dtype=np.int32)
+    rc = lib().sgo_plan_rows(V, _dp(p), f.ctypes.data_as(C.POINTER(C.c_uint8)), a.size, _ip(a), _ip(b), nranks,
+                             C.byref(n), _ip(rv), C.byref(nt), _ip(tb), tb.size, _ip(rb))
+    if rc != 0:
+        raise SgoError(f"sgo_plan_rows: rc={rc}: " + lib().sgo_last_error(None).decode())
+    return dict(n=n.value, row_vertex=rv[: n.value].copy(), tile_row_begin=tb[: nt.value + 1].copy(),
+                rank_row_begin=rb.copy())
 
 
 def comm_unique_id() -> bytes:

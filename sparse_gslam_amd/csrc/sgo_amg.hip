@@ -34,6 +34,7 @@
 #include <vector>
 
 #include "sgo_amg.h"
+#include "sgo_comm.h"
 #include "sgo_device.h"
 
 namespace sgo {
@@ -1067,6 +1068,9 @@ struct Amg {
   AmgProf prof;
   Sym0Dev S0;               // level-0 operator in symmetric storage (lv[0].A is its logical view)
   Tile0Dev T0;              // ... and its tile view
+  Comm* comm = nullptr;     // multi-GPU: level-0 products over the units [u0, u1) + all-reduce
+  int u0 = 0, u1 = 0;
+  bool comm_failed = false;
   std::vector<void*> pool;
   std::vector<AmgLevel> lv;
   const double* d_poses = nullptr;
@@ -1197,8 +1201,18 @@ int cycle(Amg* m, hipStream_t s, int l, const double* rhs, const double* rhs_sub
     }
     Spmv0Args a{};
     a.x = L.xs; a.b = rhs; a.y = L.rs; a.S = S;
-    Scope sc(m->prof, m->T0.ntile > 0 ? K_SPMV0T_RESID : K_SPMV0_RESID, 76.0 * m->S0.npairs + 120.0 * m->S0.n);
-    launch_spmv0_any(s, m->S0, m->T0, S0_RESID, a);
+    if (m->comm) {
+      a.u0 = m->u0; a.u1 = m->u1;
+      hipMemsetAsync(L.rs, 0, sizeof(double) * 3 * (size_t)L.A.n, s);
+    }
+    if (!m->comm || a.u1 > a.u0) {
+      Scope sc(m->prof, m->T0.ntile > 0 ? K_SPMV0T_RESID : K_SPMV0_RESID, 76.0 * m->S0.npairs + 120.0 * m->S0.n);
+      launch_spmv0_any(s, m->S0, m->T0, S0_RESID, a);
+    }
+    if (m->comm) {
+      std::string e;
+      if (!m->comm->allreduce_f64(L.rs, 3 * (size_t)L.A.n, s, &e)) m->comm_failed = true;
+    }
   } else {
     SpmvArgs a{};
     a.b = rhs; a.y = L.rs; a.y2 = L.xs; a.omega = m->cfg.omega; a.S = S;
@@ -1270,6 +1284,23 @@ int cycle(Amg* m, hipStream_t s, int l, const double* rhs, const double* rhs_sub
       b.dotA = dotvec;
       b.dotA2 = dotvec2;
       b.partials = dotparts;
+    }
+    if (m->comm) {
+      // this rank's rows, zeros elsewhere, all-reduce, then the dot products on the full vector (replicated)
+      b.u0 = m->u0; b.u1 = m->u1;
+      b.dotA = nullptr; b.dotA2 = nullptr; b.partials = nullptr;
+      hipMemsetAsync(out, 0, sizeof(double) * 3 * (size_t)L.A.n, s);
+      if (b.u1 > b.u0) {
+        Scope sc(m->prof, m->T0.ntile > 0 ? K_SPMV0T_JACOBI : K_SPMV0_JACOBI, 76.0 * m->S0.npairs + 168.0 * m->S0.n);
+        launch_spmv0_any(s, m->S0, m->T0, S0_JACOBI, b);
+      }
+      std::string e;
+      if (!m->comm->allreduce_f64(out, 3 * (size_t)L.A.n, s, &e)) m->comm_failed = true;
+      if (!dotvec) return 0;
+      const int grid = grid_for(3LL * L.A.n, kBlock);
+      Scope sc(m->prof, K_DOT, 72.0 * L.A.n);
+      SGO_LAUNCH(k_dots2, dim3(grid), dim3(kBlock), 0, s, 3 * L.A.n, (const double*)out, dotvec, dotvec2, dotparts, S);
+      return grid;
     }
     Scope sc(m->prof, m->T0.ntile > 0 ? K_SPMV0T_JACOBI : K_SPMV0_JACOBI, 76.0 * m->S0.npairs + 168.0 * m->S0.n);
     return launch_spmv0_any(s, m->S0, m->T0, S0_JACOBI, b);
@@ -1361,6 +1392,12 @@ int amg_update(Amg* m, hipStream_t s, std::string* err) {
   return SGO_OK;
 }
 
+void amg_set_shard(Amg* m, Comm* comm, int u0, int u1) {
+  m->comm = comm;
+  m->u0 = u0;
+  m->u1 = u1;
+}
+bool amg_comm_failed(const Amg* m) { return m && m->comm_failed; }
 double* amg_xs0(Amg* m) { return (m && m->lv.size() > 1) ? m->lv[0].xs : nullptr; }
 double amg_omega(const Amg* m) { return m ? m->cfg.omega : 0.0; }
 

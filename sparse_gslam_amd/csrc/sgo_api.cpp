@@ -88,6 +88,7 @@ struct sgo_ctx {
   sgo_opts opts{};
   std::string err;
   Comm comm;
+  int shard_u0 = 0, shard_u1 = 0, shard_units = 0;   // multi-GPU: this rank's range of level-0 work units (tiles)
 
   // graph (host)
   bool has_graph = false;
@@ -340,39 +341,52 @@ uint32_t hilbert_index(uint32_t x, uint32_t y, int order) {
 // (c->free_id, sgo_free_ids, sgo_linearize, ...).  Internally the rows are numbered along a Hilbert
 // curve through the initial poses (c->row_of_asc maps one to the other), which makes the symmetric
 // storage of Sym0Dev work: the endpoints of almost every edge end up a few hundred rows apart.
-int build_structure(sgo_ctx* c, int V, const double* poses, const uint8_t* fixed, int E, const int32_t* ei,
-                    const int32_t* ej, const double* meas, const double* info, const double* phi) {
-  const double tb0 = wall_s();
+// Host-only plan of the level-0 rows (no GPU involved; also behind sgo_plan_rows for the multi-process tests):
+// g2o's hessian order, the internal Hilbert row order, the compact slot positions of every edge and the tiles.
+struct RowPlan {
+  int n = 0, ns = 0;
+  std::vector<int> free_id;      // hessian index (free active vertices in ascending id) -> vertex id
+  std::vector<int> row_of_asc;   // hessian index -> internal row
+  std::vector<int> row_vertex;   // internal row -> vertex id
+  std::vector<int> hpos;         // vertex id -> internal row (-1: fixed or inactive)
+  std::vector<int> rowptr;       // [n + 1] compact slots of row r
+  std::vector<int> pos_i, pos_j; // [E] slot of edge e in the row of its first / second endpoint (-1: none)
+  std::vector<int> col;          // [ns] column (internal row) of the slot, -1: fixed column
+  std::vector<TileDesc> tiles;   // row0 / row1 filled in
+  std::vector<int> tile_of_row;
+  int tile_lds = 0;
+  bool tiles_ok = true;
+};
+
+int plan_rows(int V, const double* poses, const uint8_t* fixed, int E, const int32_t* ei, const int32_t* ej, int tile_div,
+              std::string* err, RowPlan& P) {
   std::vector<int> deg(V, 0);
   for (int e = 0; e < E; ++e) {
     int a = ei[e], b = ej[e];
     if (a < 0 || a >= V || b < 0 || b >= V) {
-      c->err = "edge " + std::to_string(e) + " references a vertex outside [0, V)";
+      *err = "edge " + std::to_string(e) + " references a vertex outside [0, V)";
       return SGO_EINVAL;
     }
     if (a == b) {
-      c->err = "edge " + std::to_string(e) + " is a self edge";
+      *err = "edge " + std::to_string(e) + " is a self edge";
       return SGO_EINVAL;
     }
     deg[a]++;
     deg[b]++;
   }
   // active free vertices in ascending id = g2o's hessian order (initializeOptimization)
-  c->free_id.clear();
+  P.free_id.clear();
   for (int v = 0; v < V; ++v)
-    if (!fixed[v] && deg[v] > 0) c->free_id.push_back(v);
-  const int n = (int)c->free_id.size();
-  c->V = V;
-  c->E = E;
-  c->n = n;
+    if (!fixed[v] && deg[v] > 0) P.free_id.push_back(v);
+  const int n = P.n = (int)P.free_id.size();
   // internal row order: Hilbert index of the initial position (ties and non-finite poses: by id)
-  std::vector<int> hpos(V, -1);          // vertex id -> internal row
-  std::vector<int> row_vertex(n);        // internal row -> vertex id
-  c->row_of_asc.assign(n, 0);
+  P.hpos.assign(V, -1);
+  P.row_vertex.assign(n, 0);
+  P.row_of_asc.assign(n, 0);
   {
     double lo[2] = {1e300, 1e300}, hi[2] = {-1e300, -1e300};
     for (int h = 0; h < n; ++h) {
-      const double* q = poses + 3 * (size_t)c->free_id[h];
+      const double* q = poses + 3 * (size_t)P.free_id[h];
       for (int d = 0; d < 2; ++d)
         if (std::isfinite(q[d])) {
           lo[d] = std::min(lo[d], q[d]);
@@ -384,7 +398,7 @@ int build_structure(sgo_ctx* c, int V, const double* poses, const uint8_t* fixed
     std::vector<uint64_t> key(n);
     parallel_for(n, [&](int h0, int h1) {
       for (int h = h0; h < h1; ++h) {
-        const double* q = poses + 3 * (size_t)c->free_id[h];
+        const double* q = poses + 3 * (size_t)P.free_id[h];
         uint32_t d = 0;
         if (std::isfinite(q[0]) && std::isfinite(q[1]) && scale > 0.0)
           d = hilbert_index((uint32_t)((q[0] - lo[0]) * scale), (uint32_t)((q[1] - lo[1]) * scale), 16);
@@ -394,89 +408,51 @@ int build_structure(sgo_ctx* c, int V, const double* poses, const uint8_t* fixed
     std::sort(key.begin(), key.end());
     for (int r = 0; r < n; ++r) {
       const int h = (int)(key[r] & 0xffffffffu);
-      c->row_of_asc[h] = r;
-      row_vertex[r] = c->free_id[h];
-      hpos[c->free_id[h]] = r;
+      P.row_of_asc[h] = r;
+      P.row_vertex[r] = P.free_id[h];
+      P.hpos[P.free_id[h]] = r;
     }
   }
-
+  const std::vector<int>& hpos = P.hpos;
   // compact slots: per row one slot per incident edge (edge order within the row)
-  std::vector<int> rowptr(n + 1, 0);
+  std::vector<int>& rowptr = P.rowptr;
+  rowptr.assign((size_t)n + 1, 0);
   for (int e = 0; e < E; ++e) {
     const int hi = hpos[ei[e]], hj = hpos[ej[e]];
     if (hi >= 0) rowptr[hi + 1]++;
     if (hj >= 0) rowptr[hj + 1]++;
   }
   for (int r = 0; r < n; ++r) rowptr[r + 1] += rowptr[r];
-  const int ns = rowptr[n];
-  std::vector<int> pos_i(E, -1), pos_j(E, -1);
+  const int ns = P.ns = rowptr[n];
+  P.pos_i.assign(E, -1);
+  P.pos_j.assign(E, -1);
+  P.col.resize((size_t)std::max(ns, 1));
   {
     std::vector<int> fill(rowptr.begin(), rowptr.end() - 1);
     for (int e = 0; e < E; ++e) {
       const int hi = hpos[ei[e]], hj = hpos[ej[e]];
-      if (hi >= 0) pos_i[e] = fill[hi]++;
-      if (hj >= 0) pos_j[e] = fill[hj]++;
-    }
-  }
-  HostArena& ar = c->stage;
-  try {
-    ar.reserve((size_t)ns * (5 * sizeof(int) + 4 + 10 * sizeof(double)) + (size_t)E * 9 * sizeof(double) + 64 * 64);
-  } catch (const std::bad_alloc&) {
-    c->err = "sgo_set_graph_se2: out of host memory for the staging buffers";
-    return SGO_ENOMEM;
-  }
-  HostBuf<int> col(ar, ns), svi(ar, ns), svj(ar, ns), own(ar, (size_t)ns + 1);
-  HostBuf<unsigned char> type(ar, ns), meta(ar, ns), flags(ar, ns), off1(ar, (size_t)std::max(ns, 1));
-  HostBuf<unsigned int> cv(ar, (size_t)std::max(ns, 1));
-  HostBuf<double> zinv(ar, 3 * (size_t)ns), sinfo(ar, 6 * (size_t)ns), sphi(ar, ns);
-  HostBuf<double> ezinv(ar, 3 * (size_t)E), einfo(ar, 6 * (size_t)E);
-  if (!einfo.p) {
-    c->err = "sgo_set_graph_se2: internal error (staging arena too small)";
-    return SGO_EINVAL;
-  }
-  // every slot is written exactly once (each edge fills its one or two slots); col < 0: fixed column
-  parallel_for(E, [&](int e0, int e1) {
-    for (int e = e0; e < e1; ++e) {
-      // EdgeSE2::setMeasurement caches the inverse measurement on the host (computed once)
-      const double* z = meas + 3 * (size_t)e;
-      const double th = normalize_theta_h(-z[2]);
-      const double cs = std::cos(th), sn = std::sin(th);
-      const double zi[3] = {cs * (-z[0]) - sn * (-z[1]), sn * (-z[0]) + cs * (-z[1]), th};
-      for (int q = 0; q < 3; ++q) ezinv[q * (size_t)E + e] = zi[q];
-      for (int q = 0; q < 6; ++q) einfo[q * (size_t)E + e] = info[6 * (size_t)e + q];
-      const int hi = hpos[ei[e]], hj = hpos[ej[e]];
-      for (int side = 0; side < 2; ++side) {
-        const int hr = side ? hj : hi, hc = side ? hi : hj;
-        if (hr < 0) continue;
-        const int k = side ? pos_j[e] : pos_i[e];
-        col[k] = hc;
-        flags[k] = (unsigned char)(side ? kSlotDir : 0);
-        svi[k] = ei[e];
-        svj[k] = ej[e];
-        for (int q = 0; q < 3; ++q) zinv[q * (size_t)ns + k] = zi[q];
-        for (int q = 0; q < 6; ++q) sinfo[q * (size_t)ns + k] = info[6 * (size_t)e + q];
-        sphi[k] = phi[e];
+      if (hi >= 0) {
+        P.col[fill[hi]] = hj;
+        P.pos_i[e] = fill[hi]++;
+      }
+      if (hj >= 0) {
+        P.col[fill[hj]] = hi;
+        P.pos_j[e] = fill[hj]++;
       }
     }
-  });
-
+  }
+  const std::vector<int>& col = P.col;
   // ---- tiles (Tile0Dev): consecutive rows, cut so that the blocks are spread evenly over ~2 tiles per CU
   // and a tile's LDS -- operand slice + halo, owned sums, one staging slot per intra-tile transposed slot --
   // fits kTileLdsMax.  A pair inside a tile stores its block with the lower row only (the other row's slot
   // is TRANSPOSED); every other slot with a free column is OWNED.
-  std::vector<TileDesc> tiles;
-  std::vector<int> tile_of_row(std::max(n, 1)), hcol;
-  int tile_lds = 0;
-  bool tiles_ok = true;
+  std::vector<TileDesc>& tiles = P.tiles;
+  std::vector<int>& tile_of_row = P.tile_of_row;
+  tile_of_row.assign(std::max(n, 1), 0);
+  P.tiles_ok = true;
   {
     int lds_budget = kTileLdsMax - 1024;
     if (const char* e = std::getenv("SGO_TILE_LDS")) lds_budget = std::atoi(e);
-    int tile_div = 512;   // two tiles per CU
-    {
-      hipDeviceProp_t prop;
-      if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0)
-        tile_div = 2 * prop.multiProcessorCount;
-    }
     if (const char* e = std::getenv("SGO_TILE_DIV")) tile_div = std::max(1, std::atoi(e));
     long long nblk = 0;
     for (int k = 0; k < ns; ++k) nblk += col[k] >= 0;
@@ -484,7 +460,7 @@ int build_structure(sgo_ctx* c, int V, const double* poses, const uint8_t* fixed
     std::vector<int> mark(std::max(n, 1), -1);
     for (int attempt = 0; attempt < 6; ++attempt) {
       tiles.clear();
-      tile_lds = 0;
+      long long lds = 0;
       int r = 0;
       while (r < n) {
         TileDesc T{};
@@ -517,24 +493,95 @@ int build_structure(sgo_ctx* c, int V, const double* poses, const uint8_t* fixed
         const long long rows = T.row1 - T.row0;
         const long long need = 24 * (2 * rows + halo + staged);
         if (need > lds_budget || rows + halo > 65000 || staged > 65000) fits = false;
-        tile_lds = std::max<long long>(tile_lds, need);
+        lds = std::max(lds, need);
       }
       std::fill(mark.begin(), mark.end(), -1);
+      P.tile_lds = (int)lds;
       if (fits) break;
       if (target <= 64) {
-        tiles_ok = false;   // e.g. a hub vertex whose row alone overflows the LDS: no tile view
+        P.tiles_ok = false;   // e.g. a hub vertex whose row alone overflows the LDS: no tile view
         break;
       }
       target = std::max<long long>(64, target / 2);
-      if (attempt == 5) tiles_ok = false;
+      if (attempt == 5) P.tiles_ok = false;
     }
   }
   if (const char* e = std::getenv("SGO_SPMV0"))
-    if (!std::strcmp(e, "group")) tiles_ok = false;   // experiments: force the wave-group kernel
-  if (!tiles_ok) {   // one "tile" per row range of nothing: every pair stored once, with the lower row
+    if (!std::strcmp(e, "group")) P.tiles_ok = false;   // experiments: force the wave-group kernel
+  if (!P.tiles_ok) {   // one "tile" per row range of nothing: every pair stored once, with the lower row
     tiles.clear();
     for (int r = 0; r < n; ++r) tile_of_row[r] = 0;
   }
+  return SGO_OK;
+}
+
+int build_structure(sgo_ctx* c, int V, const double* poses, const uint8_t* fixed, int E, const int32_t* ei,
+                    const int32_t* ej, const double* meas, const double* info, const double* phi) {
+  const double tb0 = wall_s();
+  RowPlan P;
+  int tile_div = 512;   // two tiles per CU
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0)
+      tile_div = 2 * prop.multiProcessorCount;
+  }
+  {
+    const int prc = plan_rows(V, poses, fixed, E, ei, ej, tile_div, &c->err, P);
+    if (prc != SGO_OK) return prc;
+  }
+  c->free_id = P.free_id;
+  c->row_of_asc = P.row_of_asc;
+  const int n = P.n, ns = P.ns;
+  c->V = V;
+  c->E = E;
+  c->n = n;
+  const std::vector<int>&hpos = P.hpos, &row_vertex = P.row_vertex, &rowptr = P.rowptr, &pos_i = P.pos_i, &pos_j = P.pos_j;
+  std::vector<int>& col = P.col;
+  std::vector<TileDesc>& tiles = P.tiles;
+  std::vector<int>& tile_of_row = P.tile_of_row;
+  std::vector<int> hcol;
+  const int tile_lds = P.tile_lds;
+  bool tiles_ok = P.tiles_ok;
+  HostArena& ar = c->stage;
+  try {
+    ar.reserve((size_t)ns * (4 * sizeof(int) + 4 + 10 * sizeof(double)) + (size_t)E * 9 * sizeof(double) + 64 * 64);
+  } catch (const std::bad_alloc&) {
+    c->err = "sgo_set_graph_se2: out of host memory for the staging buffers";
+    return SGO_ENOMEM;
+  }
+  HostBuf<int> svi(ar, ns), svj(ar, ns), own(ar, (size_t)ns + 1);
+  HostBuf<unsigned char> type(ar, ns), meta(ar, ns), flags(ar, ns), off1(ar, (size_t)std::max(ns, 1));
+  HostBuf<unsigned int> cv(ar, (size_t)std::max(ns, 1));
+  HostBuf<double> zinv(ar, 3 * (size_t)ns), sinfo(ar, 6 * (size_t)ns), sphi(ar, ns);
+  HostBuf<double> ezinv(ar, 3 * (size_t)E), einfo(ar, 6 * (size_t)E);
+  if (!einfo.p) {
+    c->err = "sgo_set_graph_se2: internal error (staging arena too small)";
+    return SGO_EINVAL;
+  }
+  // every slot is written exactly once (each edge fills its one or two slots)
+  parallel_for(E, [&](int e0, int e1) {
+    for (int e = e0; e < e1; ++e) {
+      // EdgeSE2::setMeasurement caches the inverse measurement on the host (computed once)
+      const double* z = meas + 3 * (size_t)e;
+      const double th = normalize_theta_h(-z[2]);
+      const double cs = std::cos(th), sn = std::sin(th);
+      const double zi[3] = {cs * (-z[0]) - sn * (-z[1]), sn * (-z[0]) + cs * (-z[1]), th};
+      for (int q = 0; q < 3; ++q) ezinv[q * (size_t)E + e] = zi[q];
+      for (int q = 0; q < 6; ++q) einfo[q * (size_t)E + e] = info[6 * (size_t)e + q];
+      const int hi = hpos[ei[e]], hj = hpos[ej[e]];
+      for (int side = 0; side < 2; ++side) {
+        const int hr = side ? hj : hi;
+        if (hr < 0) continue;
+        const int k = side ? pos_j[e] : pos_i[e];
+        flags[k] = (unsigned char)(side ? kSlotDir : 0);
+        svi[k] = ei[e];
+        svj[k] = ej[e];
+        for (int q = 0; q < 3; ++q) zinv[q * (size_t)ns + k] = zi[q];
+        for (int q = 0; q < 6; ++q) sinfo[q * (size_t)ns + k] = info[6 * (size_t)e + q];
+        sphi[k] = phi[e];
+      }
+    }
+  });
   // slot types
   parallel_for(n, [&](int r0, int r1) {
     for (int r = r0; r < r1; ++r)
@@ -861,24 +908,12 @@ int start_pcg(sgo_ctx* c, int grid) {
   return SGO_OK;
 }
 
-// buildSystem + preconditioner + PCG start state
+// buildSystem + preconditioner + PCG start state.  Multi-GPU: every rank linearises the whole graph (1.5 % of
+// a GN iteration; sharding it would mean all-reducing the blocks, 72 B per edge, to save it).
 int do_linearize(sgo_ctx* c) {
-  // Multi-GPU: rank r evaluates the edges of its contiguous band of row groups (whole rows, so
-  // every value is produced by exactly one rank); the other bands stay zero and the all-reduce
-  // (sum with exact zeros) reproduces the single-GPU arrays bit for bit on every rank.
-  int g0 = 0, g1 = c->S0.ngrp;
-  if (c->comm.nranks > 1) {
-    sgo_shard_range(c->S0.ngrp, c->comm.nranks, c->comm.rank, &g0, &g1);
-    HIP_TRY(c, hipMemsetAsync(c->S0.ublk, 0, sizeof(double) * 9 * (size_t)c->S0.nu, c->stream));
-    HIP_TRY(c, hipMemsetAsync(c->d_dgb, 0, sizeof(double) * 9 * (size_t)c->n, c->stream));
-  }
   {
-    Scope sc(c, K_LINEARIZE, bytes_linearize(c) * (double)(g1 - g0) / std::max(1, c->S0.ngrp));
-    launch_linearize(c->stream, c->S0, g0, g1, c->es, c->d_poses, c->d_dgb);
-  }
-  if (c->comm.nranks > 1) {
-    if (!c->comm.allreduce_f64(c->S0.ublk, 9 * (size_t)c->S0.nu, c->stream, &c->err)) return SGO_ECOMM;
-    if (!c->comm.allreduce_f64(c->d_dgb, 9 * (size_t)c->n, c->stream, &c->err)) return SGO_ECOMM;
+    Scope sc(c, K_LINEARIZE, bytes_linearize(c));
+    launch_linearize(c->stream, c->S0, 0, c->S0.ngrp, c->es, c->d_poses, c->d_dgb);
   }
   int grid = 0;
   {
@@ -895,11 +930,31 @@ int do_linearize(sgo_ctx* c) {
 // y = H x  (+ optional x.y partials).  The solve is replicated on every rank (identical H after
 // the all-reduce in do_linearize), so no collective is needed here.
 int do_spmv(sgo_ctx* c, const double* x, double* y, bool dot, const PcgScalars* S, int* grid_out) {
-  Scope sc(c, c->T0.ntile > 0 ? K_SPMV0T_AX : K_SPMV0_AX, bytes_spmv0(c->S0, S0_AX));
   Spmv0Args a{};
   a.x = x;
   a.y = y;
   a.S = S;
+  if (c->comm.nranks > 1 || c->comm.handle) {
+    // multi-GPU: this rank's range of tiles only, zeros elsewhere, all-reduce of the product vector (every row
+    // has exactly one non-zero contributor: the sum is exact), then the dot product on the full vectors --
+    // the same arithmetic on every rank, so the replicated PCG recurrences stay bit-identical across ranks
+    a.u0 = c->shard_u0;
+    a.u1 = c->shard_u1;
+    HIP_TRY(c, hipMemsetAsync(y, 0, sizeof(double) * 3 * (size_t)c->n, c->stream));
+    if (a.u1 > a.u0) {
+      Scope sc(c, c->T0.ntile > 0 ? K_SPMV0T_AX : K_SPMV0_AX, bytes_spmv0(c->S0, S0_AX) * (a.u1 - a.u0) / std::max(1, c->shard_units));
+      launch_spmv0_any(c->stream, c->S0, c->T0, S0_AX, a);
+    }
+    if (!c->comm.allreduce_f64(y, 3 * (size_t)c->n, c->stream, &c->err)) return SGO_ECOMM;
+    if (dot) {
+      int grid = 0;
+      Scope sc(c, K_DOT, 48.0 * c->n);
+      launch_dot(c->stream, 3 * c->n, x, y, c->d_partials, S, &grid);
+      if (grid_out) *grid_out = grid;
+    }
+    return SGO_OK;
+  }
+  Scope sc(c, c->T0.ntile > 0 ? K_SPMV0T_AX : K_SPMV0_AX, bytes_spmv0(c->S0, S0_AX));
   if (dot) {
     a.dotA = x;
     a.partials = c->d_partials;
@@ -922,6 +977,10 @@ int pcg_iteration(sgo_ctx* c) {
   if (c->amg) {
     // the K-cycle is a (mildly) variable preconditioner: flexible beta from z.q
     const int gz = amg_apply(c->amg, c->stream, c->d_r, c->d_z, c->d_r, c->d_zparts, c->d_S, c->d_q, true);
+    if (amg_comm_failed(c->amg)) {
+      c->err = "collective failed inside the multigrid cycle";
+      return SGO_ECOMM;
+    }
     Scope sc(c, K_UPDATE_P, 3 * 24.0 * c->n);
     launch_update_p(c->stream, c->n, c->d_S, c->d_zparts, gz, parts2 + kMaxPartials, g2, c->d_zparts + kMaxPartials,
                     c->d_z, c->d_p);
@@ -971,7 +1030,8 @@ int ensure_pcg_graph(sgo_ctx* c, int chunk) {
 // iterations past convergence exit on the flag), so the GPU never idles on a host round trip and at
 // most two replays of early-exit launches are wasted.
 int run_pcg(sgo_ctx* c) {
-  const bool graph = c->opts.use_graph && !c->opts.profile;
+  // collectives inside the loop: plain stream launches (RCCL calls are not captured into the hipGraph)
+  const bool graph = c->opts.use_graph && !c->opts.profile && !(c->comm.nranks > 1 || c->comm.handle);
   if (!graph) {
     const int chunk = std::max(1, c->opts.pcg_chunk);
     for (;;) {
@@ -1043,6 +1103,7 @@ int build_amg(sgo_ctx* c) {
   std::string aerr;
   c->amg = amg_create(c->stream, c->A, c->S0, c->T0, c->H0, c->d_poses, c->d_free_id, cfg, prof, &aerr, &c->amg_scratch);
   if (c->amg) {
+    if (c->comm.nranks > 1 || c->comm.handle) amg_set_shard(c->amg, &c->comm, c->shard_u0, c->shard_u1);
     amg_describe(c->amg, &c->solver_desc);
     c->solver_desc = "pcg_amg: " + c->solver_desc;
   } else {
@@ -1207,6 +1268,8 @@ int sgo_set_graph_se2(sgo_ctx* c, int32_t V, const double* poses, const uint8_t*
     return rc;
   }
   c->has_graph = true;
+  c->shard_units = c->T0.ntile > 0 ? c->T0.ntile : c->S0.ngrp;
+  sgo_shard_range(c->shard_units, c->comm.nranks, c->comm.rank, &c->shard_u0, &c->shard_u1);
   // Chain-like graphs (fewer than ~1.5 edges per free pose: under 4 Hessian blocks per row) are the
   // ill-conditioned ones -- kappa(H) grows with the square of the chain length -- and a relative
   // residual of 1e-8 then leaves errors that show in chi2 (3000 poses / 3150 edges: iterates 3e-6 and
@@ -1559,7 +1622,7 @@ int sgo_optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
 
 // Micro-benchmark of the level-0 product on the resident graph: `reps` back-to-back launches of
 // k_spmv0<mode> (operand = the PCG direction buffer, whatever it holds), HIP events around them on the
-// context's stream; returns the mean microseconds per launch (< 0 on error).  variant = Spmv0Args::dbg.
+// context's stream; returns the mean microseconds per launch (< 0 on error).  variant 16: the wave-group kernel even when the graph has a tile view.
 double sgo_debug_spmv0_us(sgo_ctx* c, int mode, int variant, int reps) {
   if (check_graph(c) != SGO_OK || reps < 1 || c->n == 0) return -1.0;
   hipEvent_t a, b;
@@ -1569,9 +1632,7 @@ double sgo_debug_spmv0_us(sgo_ctx* c, int mode, int variant, int reps) {
   args.y = c->d_s2;
   args.b = c->d_b;
   args.omega = 0.8;
-  args.dbg = variant;
   const bool tiled = c->T0.ntile > 0 && !(variant & 16);   // variant 16: the wave-group kernel
-  args.dbg = variant & 15;
   if (tiled) launch_spmv0t(c->stream, c->S0, c->T0, mode, args);
   else launch_spmv0(c->stream, c->S0, mode, args);
   hipEventRecord(a, c->stream);
@@ -1644,6 +1705,49 @@ int sgo_debug_set_shard(sgo_ctx* c, int nranks, int rank) {
   c->comm.nranks = nranks;  // no handle: Comm::allreduce_* are no-ops
   c->comm.rank = rank;
   return SGO_OK;
+}
+
+int sgo_plan_rows(int32_t V, const double* poses, const uint8_t* fixed, int32_t E, const int32_t* ei, const int32_t* ej,
+                  int32_t nranks, int32_t* n_free, int32_t* row_vertex, int32_t* ntiles, int32_t* tile_row_begin,
+                  int32_t tile_cap, int32_t* rank_row_begin) {
+  if (V <= 0 || E < 0 || !poses || !fixed || (E > 0 && (!ei || !ej)) || nranks < 1 || !n_free) return SGO_EINVAL;
+  try {
+    RowPlan P;
+    std::string err;
+    const int rc = plan_rows(V, poses, fixed, E, ei, ej, 512, &err, P);
+    if (rc != SGO_OK) {
+      g_err = err;
+      return rc;
+    }
+    *n_free = P.n;
+    if (row_vertex) std::copy(P.row_vertex.begin(), P.row_vertex.end(), row_vertex);
+    const int nt = (int)P.tiles.size();
+    if (ntiles) *ntiles = nt;
+    if (tile_row_begin) {
+      if (tile_cap < nt + 1) {
+        g_err = "sgo_plan_rows: tile_cap too small";
+        return SGO_EINVAL;
+      }
+      for (int t = 0; t < nt; ++t) tile_row_begin[t] = P.tiles[t].row0;
+      tile_row_begin[nt] = P.n;
+    }
+    if (rank_row_begin) {
+      for (int r = 0; r <= nranks; ++r) {
+        if (nt == 0) {   // no tile view: the wave-group kernel is sharded by row groups; report an even row split
+          rank_row_begin[r] = (int32_t)((long long)P.n * r / nranks);
+          continue;
+        }
+        int32_t b = 0, e = 0;
+        sgo_shard_range(nt, nranks, std::min(r, nranks - 1), &b, &e);
+        rank_row_begin[r] = r == nranks ? P.n : P.tiles[b].row0;
+        (void)e;
+      }
+    }
+    return SGO_OK;
+  } catch (const std::bad_alloc&) {
+    g_err = "sgo_plan_rows: out of host memory";
+    return SGO_ENOMEM;
+  }
 }
 
 void sgo_shard_range(int32_t count, int32_t nranks, int32_t rank, int32_t* begin, int32_t* end) {

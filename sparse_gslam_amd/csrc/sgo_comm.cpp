@@ -1,10 +1,11 @@
 // sgo_comm.cpp -- RCCL binding for the edge-sharded multi-GPU mode (one process per GPU).
 //
 // librccl is dlopen'ed on first use so that the single-GPU product path carries no RCCL
-// dependency.  Only ncclAllReduce(sum) is used, once per GN iteration after the band-sharded
-// linearisation: on the Hessian blocks, on the per-vertex (block-diagonal H, b) array and on the
-// two chi2 partial sums (BASELINE.json north_star).
-// The linear solve runs replicated, so no collective sits inside the PCG loop.
+// dependency.  Only ncclAllReduce(sum) is used: on the product vector of every level-0 Hessian
+// product of the solve -- each rank evaluates the rows of its range of tiles and writes zeros
+// elsewhere, so the sum reproduces the full vector exactly -- and on the two chi2 partial sums
+// (BASELINE.json north_star).  A communicator of ONE
+// rank still calls ncclAllReduce (the single-GPU test of this path).
 #include <dlfcn.h>
 
 #include <cstdlib>
@@ -112,7 +113,7 @@ void Comm::destroy() {
 }
 
 bool Comm::allreduce_f64(double* buf, size_t count, hipStream_t s, std::string* err) {
-  if (!handle || nranks <= 1) return true;
+  if (!handle) return true;   // no communicator (single GPU, or the rank-emulation test hook)
   int rc = api().AllReduce(buf, buf, count, kNcclFloat64, kNcclSum, (ncclComm_t)handle, s);
   if (rc != 0) {
     *err = "ncclAllReduce(f64): " + nccl_err(rc);
@@ -122,7 +123,7 @@ bool Comm::allreduce_f64(double* buf, size_t count, hipStream_t s, std::string* 
 }
 
 bool Comm::allreduce_i32(int* buf, size_t count, hipStream_t s, std::string* err) {
-  if (!handle || nranks <= 1) return true;
+  if (!handle) return true;
   int rc = api().AllReduce(buf, buf, count, kNcclInt32, kNcclSum, (ncclComm_t)handle, s);
   if (rc != 0) {
     *err = "ncclAllReduce(i32): " + nccl_err(rc);

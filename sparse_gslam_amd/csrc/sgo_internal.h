@@ -223,8 +223,8 @@ struct Spmv0Args {
   const double* dotA2 = nullptr; // partials[1] += dotA2 . y
   double* partials = nullptr;    // [2][kMaxPartials]
   const PcgScalars* S = nullptr; // optional early-out flag
-  int dbg = 0;                   // timing experiments only (wrong results): 1 transposed lanes read contiguous blocks,
-                                 // 2 operand gathered by row instead of column, 4 no block loads, 8 no operand loads
+  int u0 = 0, u1 = 0;            // multi-GPU: only the work units [u0, u1) -- tiles (k_spmv0t) or wave groups (k_spmv0) --
+                                 // are evaluated, i.e. only their rows of y are written (u1 == 0: all)
 };
 
 // One profiling slot per __global__ symbol (template instantiations separately), named as

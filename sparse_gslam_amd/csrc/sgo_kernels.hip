@@ -447,8 +447,11 @@ __global__ __launch_bounds__(kBlock, 8) void k_spmv0(Sym0Dev A, Spmv0Args a) {
   const size_t nu = (size_t)A.nu;
   const double2* __restrict__ bp = reinterpret_cast<const double2*>(A.ublk);
   double dotacc[2] = {0.0, 0.0};
+  const int ulo = a.u1 > 0 ? a.u0 : 0, uhi = a.u1 > 0 ? a.u1 : A.ngrp;
   int g, gend, gstride;
-  group_walk(A.ngrp, &g, &gend, &gstride);
+  group_walk(uhi - ulo, &g, &gend, &gstride);
+  g += ulo;
+  gend += ulo;
   for (; g < gend; g += gstride) {
     const int gb = A.grp[g], ge = A.grp[g + 1], r0 = A.grow[g];
     int ob = A.gown[g], tb = A.gtr[g];
@@ -464,22 +467,15 @@ __global__ __launch_bounds__(kBlock, 8) void k_spmv0(Sym0Dev A, Spmv0Args a) {
       const int trank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(tmask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)tmask, 0u));
       int idx = ob + orank;
       const bool tr = type == kSlotTransposed;
-      if (tr) idx = (a.dbg & 1) ? min(ob + trank, A.nu - 1) : A.tref[tb + trank];
+      if (tr) idx = A.tref[tb + trank];
       ob += __popcll(omask);
       tb += __popcll(tmask);
       if (active) row = r0 + (m & 63);
       if (type != kSlotNoBlock) {
-        const size_t c = (a.dbg & 2) ? 3 * (size_t)row : 3 * (size_t)A.col[k];
-        double x0 = 1.0, x1 = 2.0, x2 = 3.0;
-        if (!(a.dbg & 8)) {
-          x0 = a.x[c]; x1 = a.x[c + 1]; x2 = a.x[c + 2];
-        }
-        double2 p0 = make_double2(1, 2), p1 = p0, p2 = p0, p3 = p0;
-        double b8 = 1.0;
-        if (!(a.dbg & 4)) {
-          p0 = bp[idx]; p1 = bp[nu + idx]; p2 = bp[2 * nu + idx]; p3 = bp[3 * nu + idx];
-          b8 = A.ublk[8 * nu + idx];
-        }
+        const size_t c = 3 * (size_t)A.col[k];
+        const double x0 = a.x[c], x1 = a.x[c + 1], x2 = a.x[c + 2];
+        const double2 p0 = bp[idx], p1 = bp[nu + idx], p2 = bp[2 * nu + idx], p3 = bp[3 * nu + idx];
+        const double b8 = A.ublk[8 * nu + idx];
         // row-major b0..b8 = p0.x p0.y p1.x | p1.y p2.x p2.y | p3.x p3.y b8 ; transposed: swap (1,3) (2,6) (5,7)
         const double m01 = tr ? p1.y : p0.y, m02 = tr ? p3.x : p1.x;
         const double m10 = tr ? p0.y : p1.y, m12 = tr ? p3.y : p2.y;
@@ -532,7 +528,8 @@ __global__ __launch_bounds__(kTileThreads) void k_spmv0t(Sym0Dev A, Tile0Dev TL,
   const double2* __restrict__ bp = reinterpret_cast<const double2*>(A.ublk);
   double dotacc[2] = {0.0, 0.0};
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
-  const int tlo = (int)(((long long)TL.ntile * xcd) >> 3), thi = (int)(((long long)TL.ntile * (xcd + 1)) >> 3);
+  const int ulo = a.u1 > 0 ? a.u0 : 0, nun = (a.u1 > 0 ? a.u1 : TL.ntile) - ulo;
+  const int tlo = ulo + (int)(((long long)nun * xcd) >> 3), thi = ulo + (int)(((long long)nun * (xcd + 1)) >> 3);
   for (int t = tlo + slot; t < thi; t += per_xcd) {
     const TileDesc T = TL.tile[t];
     const int nr = T.row1 - T.row0, nh = T.h1 - T.h0;

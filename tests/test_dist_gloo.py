@@ -1,8 +1,9 @@
 """N > 1 path on CPU: world_size-2 gloo processes emulate the multi-GPU scheme of libsgo
-(DESIGN.md section 6): every rank holds the full graph, evaluates only its contiguous band of
-Hessian rows, and an all-reduce(sum) of the zero-padded partial arrays must reproduce the
-single-rank system exactly (each value has one non-zero contributor).  The band partition is the
-library's own sgo_shard_range (pure function, no GPU)."""
+(DESIGN.md section 6): every rank holds the full graph, evaluates the level-0 Hessian product only for the
+rows of its range of tiles (zeros elsewhere), and an all-reduce(sum) of the product vectors must reproduce
+the full product exactly (one non-zero contributor per row).  The partition is libsgo's own: the host-only
+row plan sgo_plan_rows (Hilbert row order, tiles, tile range per rank -- the code sgo_set_graph_se2 runs) and
+sgo_shard_range; the arithmetic of the rows comes from the numpy oracle (no GPU here)."""
 import os
 import socket
 
@@ -31,8 +32,9 @@ def test_shard_range_is_a_balanced_partition():
             assert max(sizes) - min(sizes) <= 1
 
 
-def _band_system(g, lo, hi):
-    """b (n,3) and block diagonal (n,3,3) contributions of Hessian rows [lo, hi) only."""
+def _rows_product(g, x, vertex_rows):
+    """(H x) restricted to the Hessian rows of the vertices `vertex_rows`, zeros elsewhere; H from the numpy
+    oracle, x and the result in g2o's hessian order (free vertices in ascending id)."""
     from oracle import np_oracle as no
     hidx, free = no.hessian_index(g.fixed)
     n = free.size
@@ -43,15 +45,16 @@ def _band_system(g, lo, hi):
     e2 = np.einsum("ni,nij,nj->n", e, O, e)
     _, rho1 = no.dcs_rho(e2, g.phi)
     Ow = O * rho1[:, None, None]
-    Oe = np.einsum("nij,nj->ni", Ow, e)
-    b = np.zeros((n, 3))
-    D = np.zeros((n, 3, 3))
-    for J, h in ((A, hidx[g.ei]), (B, hidx[g.ej])):
-        m = (h >= lo) & (h < hi)
-        Jt = np.swapaxes(J[m], 1, 2)
-        np.add.at(b, h[m], -np.einsum("nij,nj->ni", Jt, Oe[m]))
-        np.add.at(D, h[m], Jt @ Ow[m] @ J[m])
-    return b, D
+    mine = np.zeros(g.poses.shape[0], dtype=bool)
+    mine[vertex_rows] = True
+    y = np.zeros((n, 3))
+    hi, hj = hidx[g.ei], hidx[g.ej]
+    At, Bt = np.swapaxes(A, 1, 2), np.swapaxes(B, 1, 2)
+    for Jr_t, Jc, hr, hc, vr in ((At, A, hi, hi, g.ei), (Bt, B, hj, hj, g.ej), (At, B, hi, hj, g.ei), (Bt, A, hj, hi, g.ej)):
+        m = (hr >= 0) & (hc >= 0) & mine[vr]
+        blk = Jr_t[m] @ Ow[m] @ Jc[m]
+        np.add.at(y, hr[m], np.einsum("nij,nj->ni", blk, x[hc[m]]))
+    return y
 
 
 def _worker(rank, world, port, q):
@@ -65,15 +68,22 @@ def _worker(rank, world, port, q):
         uid = [os.urandom(capi.UNIQUE_ID_BYTES) if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
         assert isinstance(uid[0], bytes) and len(uid[0]) == capi.UNIQUE_ID_BYTES
-        g = synth.manhattan(400, 1100, seed=21, info_mode="full")      # same graph on every rank
+        g = synth.manhattan(3000, 12000, seed=21, info_mode="full")      # same graph on every rank
         n = int((~g.fixed).sum())
-        lo, hi = capi.shard_range(n, world, rank)
-        b, D = _band_system(g, lo, hi)
-        tb, tD = torch.from_numpy(b.copy()), torch.from_numpy(D.copy())
-        dist.all_reduce(tb)
-        dist.all_reduce(tD)
-        fb, fD = _band_system(g, 0, n)
-        ok = bool(np.array_equal(tb.numpy(), fb) and np.array_equal(tD.numpy(), fD))
+        # libsgo's own host-side plan (no GPU): which rows of a level-0 product this rank contributes
+        plan = capi.plan_rows(g.poses, g.fixed, g.ei, g.ej, world)
+        rb = plan["rank_row_begin"]
+        ok = plan["n"] == n and rb[0] == 0 and rb[-1] == n and all(rb[k] < rb[k + 1] for k in range(world))
+        ok = ok and sorted(plan["row_vertex"].tolist()) == np.flatnonzero(~g.fixed).tolist()
+        tb = plan["tile_row_begin"]
+        ok = ok and all(int(b) in set(tb.tolist()) for b in rb)           # rank boundaries are tile boundaries
+        x = np.random.default_rng(5).standard_normal((n, 3))
+        mine = plan["row_vertex"][rb[rank]:rb[rank + 1]]
+        y = _rows_product(g, x, mine)
+        ty = torch.from_numpy(y.copy())
+        dist.all_reduce(ty)                                                # the per-product exchange of the scheme
+        full = _rows_product(g, x, np.flatnonzero(~g.fixed))
+        ok = ok and bool(np.array_equal(ty.numpy(), full))                 # one contributor per row: exact
         # chi2: per-rank partial sums over an edge range, all-reduced (rounding-level agreement)
         from oracle import np_oracle as no
         e0, e1 = capi.shard_range(g.E, world, rank)
@@ -82,13 +92,12 @@ def _worker(rank, world, port, q):
         dist.all_reduce(t)
         fc, frc, _ = no.chi2(g.poses, g.ei, g.ej, g.meas, g.info, g.phi)
         ok = ok and abs(t[0].item() - fc) <= 1e-12 * fc and abs(t[1].item() - frc) <= 1e-12 * frc
-        ok = ok and hi > lo and (rank > 0 or lo == 0)
-        q.put((rank, ok, uid[0].hex()))
+        q.put((rank, bool(ok), uid[0].hex()))
     finally:
         dist.destroy_process_group()
 
 
-def test_two_rank_band_partition_reproduces_the_full_system():
+def test_two_rank_row_partition_reproduces_the_full_product():
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -102,3 +111,12 @@ def test_two_rank_band_partition_reproduces_the_full_system():
         assert p.exitcode == 0
     assert all(ok for _, ok, _ in res), res
     assert res[0][2] == res[1][2]     # both ranks saw the same rendezvous id
+
+
+def test_plan_rows_is_a_partition_for_every_world_size():
+    g = synth.manhattan(2000, 9000, seed=4)
+    for world in (1, 2, 3, 8):
+        plan = capi.plan_rows(g.poses, g.fixed, g.ei, g.ej, world)
+        rb = plan["rank_row_begin"]
+        assert rb[0] == 0 and rb[-1] == plan["n"] and np.all(np.diff(rb) >= 0)
+        assert np.array_equal(np.sort(plan["row_vertex"]), np.flatnonzero(~g.fixed))

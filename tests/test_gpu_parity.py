@@ -166,35 +166,44 @@ def test_amg_gauss_newton_matches_direct_oracle(opt_amg, name):
 
 
 # ------------------------------------------------------------------ multi-GPU logic on one GPU
-def test_band_partials_sum_to_the_single_rank_system_bitwise():
-    """Each emulated rank evaluates its band of Hessian rows; the sum over ranks (what
-    ncclAllReduce computes) must equal the single-rank arrays bit for bit."""
+def test_rank_partial_products_sum_to_the_single_rank_product_bitwise():
+    """Multi-GPU scheme on one GPU: each emulated rank evaluates the level-0 product for the rows of its tile
+    range only (zeros elsewhere); the sum over ranks -- what ncclAllReduce computes -- must equal the
+    single-rank product bit for bit, and every row must have exactly one contributing rank."""
     g = synth.config("C2", info_mode="full")
+    x = np.random.default_rng(3).standard_normal((int((~g.fixed).sum()), 3))
     with capi.Optimizer(0, solver=capi.SOLVER_PCG_BJ) as full:
         full.set_graph(*g.arrays())
-        fb, fd, fc, frc = full.linearize()
+        full.linearize()
+        fy = full.hessian_apply(x)
     for world in (2, 3, 8):
-        sb = np.zeros_like(fb)
-        sd = np.zeros_like(fd)
-        sc = src = 0.0
+        sy = np.zeros_like(fy)
+        owners = np.zeros(fy.shape[0], dtype=int)
+        plan = capi.plan_rows(g.poses, g.fixed, g.ei, g.ej, world)
         for r in range(world):
             with capi.Optimizer(0, solver=capi.SOLVER_PCG_BJ) as o:
                 o.debug_set_shard(world, r)
                 o.set_graph(*g.arrays())
-                b, d, c, rc = o.linearize()
-                assert np.count_nonzero(b) < b.size      # really a partial
-                sb += b
-                sd += d
-                sc += c
-                src += rc
-        assert np.array_equal(sb, fb) and np.array_equal(sd, fd), world
-        assert abs(sc - fc) <= 1e-12 * fc and abs(src - frc) <= 1e-12 * frc
+                o.linearize()
+                y = o.hessian_apply(x)
+            nz = np.any(y != 0.0, axis=1)
+            assert 0 < nz.sum() < y.shape[0]            # really a partial
+            # the rows this rank wrote are the rows the host-only plan assigns to it
+            free = np.flatnonzero(~g.fixed)
+            mine = np.isin(free, plan["row_vertex"][plan["rank_row_begin"][r]:plan["rank_row_begin"][r + 1]])
+            assert not np.any(nz & ~mine)
+            owners += nz
+            sy += y
+        assert np.array_equal(sy, fy), world
+        assert owners.max() == 1
 
 
-def test_single_rank_rccl_communicator_gives_identical_results():
-    """Exercises the RCCL binding (dlopen, ncclCommInitRank, ncclAllReduce inside the GN loop and
-    around the hipGraph) with a 1-rank communicator."""
-    g = synth.config("C1", info_mode="full")
+def test_single_rank_rccl_communicator_runs_the_collective_path():
+    """Exercises the RCCL binding with a 1-rank communicator: dlopen, ncclCommInitRank and a real
+    ncclAllReduce after every level-0 product of the solve and on chi2 (the multi-GPU code path: sharded
+    products, zero fill, all-reduce, dot products on the full vectors).  The PCG scalars are summed in another
+    order than on the single-GPU path, so agreement is to rounding, not bitwise."""
+    g = synth.config("C2", info_mode="full")
     with capi.Optimizer(0) as a:
         a.set_graph(*g.arrays())
         da, sa = a.optimize(5)
@@ -205,7 +214,10 @@ def test_single_rank_rccl_communicator_gives_identical_results():
         db, sb = b.optimize(5)
         Pb = b.get_poses()
     assert da == db == 5
-    assert np.array_equal(Pa, Pb) and sa["chi2"] == sb["chi2"]
+    assert np.abs(Pa - Pb).max() <= 1e-7
+    for ca, cb in zip(sa["chi2"], sb["chi2"]):
+        assert abs(ca - cb) <= 1e-9 * ca
+    assert max(abs(x - y) for x, y in zip(sa["pcg_iters"], sb["pcg_iters"])) <= 2
 
 
 # ------------------------------------------------------------------ execution modes agree
