@@ -32,11 +32,18 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s 
 
 
 def cpu_baseline(g, iters: int):
-    """The C++ oracle (single thread, sparse direct LDL^T = the reference's solver class) timed on a
-    bounded sample of the workload: the sub-graph of the first 30 000 poses (about 15 s of CPU).  The
-    direct solver's cost is super-linear in the graph size (fill-in), so the rate on the sample is an
-    UPPER bound of the rate on the full graph; the full C4 graph was timed once offline while the
-    golden fixture was generated (scripts/make_golden_large.py: 781 s for 20 iterations)."""
+    """CPU restatement of g2o's GN (not g2o itself: g2o / Eigen are not in the image) on the host cores, the three
+    variants of SURVEY.md section 8(d), each on a BOUNDED sample of the workload:
+    A  single thread, sparse direct LDL^T (the reference's solver class) on the sub-graph of the first 30 000
+       poses -- the direct solver's cost is super-linear in the graph size (fill-in), so the rate on the sample
+       is an UPPER bound of the rate on the full graph (full C4: 39 s per GN iteration, measured once offline
+       while the golden fixture was generated, scripts/make_golden_large.py);
+    B  single thread, block-Jacobi PCG on the FULL graph: linearise + assemble, then a bounded number of PCG
+       iterations; block-Jacobi PCG needs thousands of iterations per solve on these graphs (7 764 on C2, more
+       than 20 000 on C4, profiles/r01_bj_c4_bench.json), so the figure is seconds per PCG iteration and the
+       rate it bounds;
+    C  the same on all host cores (OpenMP).
+    `value` is variant A's rate (the fastest CPU path on graphs it can factorise)."""
     from oracle import c_oracle
 
     Vs = min(g.V, 30_000)
@@ -48,11 +55,25 @@ def cpu_baseline(g, iters: int):
     note = ""
     if g.V == 100_000 and g.E == 1_000_000:
         note = "; full graph measured offline: 39 s per GN iteration = 25.6 k edge-Jacobians/s"
-    return dict(value=Es / med, unit="edge-Jacobians/s per GN iter", cores=1, kind="port",
-                sample=f"CPU restatement of g2o GN (not g2o itself: g2o/Eigen are not in the image): "
+    ncores = os.cpu_count() or 1
+    variants = {}
+    for tag, threads, maxit in (("B_pcg_1_thread", 1, 60), ("C_pcg_openmp_all_cores", ncores, 200)):
+        r = c_oracle.pcg_timing(*g.arrays(), threads=threads, pcg_tol=1e-8, pcg_maxit=maxit)
+        per_it = r["seconds_pcg"] / max(r["pcg_iters"], 1)
+        k_needed = 20000 if g.V >= 100_000 else 7764
+        variants[tag] = dict(threads=threads, seconds_linearize=r["seconds_linearize"], pcg_iterations_timed=r["pcg_iters"],
+                             converged_within_sample=r["converged"], seconds_per_pcg_iteration=per_it,
+                             sample=f"full graph, {r['pcg_iters']} PCG iterations",
+                             rate_bound=dict(value=g.E / (r["seconds_linearize"] + k_needed * per_it), unit="edge-Jacobians/s per GN iter",
+                                             assumes_pcg_iterations=k_needed,
+                                             note="block-Jacobi PCG iterations per solve measured on the GPU path with the same "
+                                                  "preconditioner (lower bound where it did not converge)"))
+    return dict(value=Es / med, unit="edge-Jacobians/s per GN iter", cores=1, kind="port", host_cores=ncores,
+                sample=f"variant A: CPU restatement of g2o GN (not g2o itself: g2o/Eigen are not in the image): "
                        f"single-thread C++ oracle, sparse direct LDL^T + min-degree ordering, on the "
                        f"first {Vs} poses / {Es} edges of the workload, median of GN iterations 2-3 "
-                       f"(numeric factorisation + solve; symbolic analysis excluded){note}")
+                       f"(numeric factorisation + solve; symbolic analysis excluded){note}",
+                variants=variants)
 
 
 def golden_rel_err(config, iters, st):

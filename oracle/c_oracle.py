@@ -45,6 +45,8 @@ def lib():
         L.sgo_oracle_gn.restype = C.c_int
         L.sgo_oracle_gn.argtypes = [C.c_int, _d, _u, C.c_int, _i, _i, _d, _d, _d, C.c_int, C.c_int,
                                     C.c_double, C.c_int, _d, _d, _i, _d]
+        L.sgo_oracle_pcg_timing.restype = C.c_int
+        L.sgo_oracle_pcg_timing.argtypes = [C.c_int, _d, _u, C.c_int, _i, _i, _d, _d, _d, C.c_double, C.c_int, C.c_int, _d]
         _LIB = L
     return _LIB
 
@@ -127,3 +129,12 @@ def gauss_newton(poses, fixed, ei, ej, meas, info, phi, iters=20, solver="direct
     d = max(done, 0)
     return p, dict(chi2=list(c[: d + 1]), robust_chi2=list(r[: d + 1]), pcg_iters=list(k[:d]),
                    seconds=list(s[:d]), iters_done=done)
+
+
+def pcg_timing(poses, fixed, ei, ej, meas, info, phi, threads=1, pcg_tol=1e-8, pcg_maxit=200):
+    """One GN iteration's cost with the block-Jacobi PCG on `threads` OpenMP threads (CPU-baseline variants
+    B / C): dict(seconds_linearize, seconds_pcg, pcg_iters, converged)."""
+    p, f, a, b, m, o, ph = _prep(poses, fixed, ei, ej, meas, info, phi)
+    out = np.zeros(4)
+    k = lib().sgo_oracle_pcg_timing(p.shape[0], p, f, a.size, a, b, m, o, ph, pcg_tol, pcg_maxit, threads, out)
+    return dict(seconds_linearize=float(out[0]), seconds_pcg=float(out[1]), pcg_iters=int(k), converged=bool(out[3]))

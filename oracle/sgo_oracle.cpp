@@ -490,6 +490,109 @@ double now_s() {
   return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
+// ---------------------------------------------------------------- threaded PCG (CPU-baseline variants B / C)
+// The same block-Jacobi PCG on a row-wise copy of H (both triangles, CSR of 3x3 blocks) so that the product
+// is a gather per row and the rows can be split over OpenMP threads ("CPU PCG ...
+// plus an OpenMP all-cores variant").  Runs at most maxit iterations; returns the iterations done.
+struct RowCsr {
+  std::vector<int> ptr, col;
+  std::vector<double> blk;   // 9 per entry, diagonal first
+};
+void to_rows(const System& S, RowCsr& R) {
+  const int n = S.n;
+  R.ptr.assign((size_t)n + 1, 0);
+  for (int i = 0; i < n; ++i) R.ptr[i + 1] = 1;
+  for (auto& pr : S.pairs) {
+    R.ptr[pr.first + 1]++;
+    R.ptr[pr.second + 1]++;
+  }
+  for (int i = 0; i < n; ++i) R.ptr[i + 1] += R.ptr[i];
+  R.col.resize(R.ptr[n]);
+  R.blk.resize((size_t)R.ptr[n] * 9);
+  std::vector<int> fill(R.ptr.begin(), R.ptr.end() - 1);
+  for (int i = 0; i < n; ++i) {
+    R.col[fill[i]] = i;
+    std::copy(&S.diag[(size_t)i * 9], &S.diag[(size_t)i * 9] + 9, &R.blk[(size_t)fill[i] * 9]);
+    fill[i]++;
+  }
+  for (size_t k = 0; k < S.pairs.size(); ++k) {
+    const int r0 = S.pairs[k].first, c0 = S.pairs[k].second;
+    const double* B = &S.off[k * 9];
+    R.col[fill[r0]] = c0;
+    std::copy(B, B + 9, &R.blk[(size_t)fill[r0] * 9]);
+    fill[r0]++;
+    R.col[fill[c0]] = r0;
+    double* T = &R.blk[(size_t)fill[c0] * 9];
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) T[3 * r + c] = B[3 * c + r];
+    fill[c0]++;
+  }
+}
+int pcg_rows(const System& S, const RowCsr& R, std::vector<double>& x, double tol, int maxit, int threads, bool* converged) {
+  const int n = S.n, N = 3 * n;
+  std::vector<double> Dinv((size_t)n * 9), r(S.b), z(N), p(N), q(N);
+  for (int i = 0; i < n; ++i)
+    if (!inv3(&S.diag[(size_t)i * 9], &Dinv[(size_t)i * 9])) return -1;
+  x.assign(N, 0.0);
+  double rz = 0, bb = 0;
+#pragma omp parallel for num_threads(threads) reduction(+ : rz, bb) schedule(static)
+  for (int i = 0; i < n; ++i) {
+    const double* M = &Dinv[(size_t)i * 9];
+    for (int k = 0; k < 3; ++k) {
+      z[3 * i + k] = M[3 * k] * r[3 * i] + M[3 * k + 1] * r[3 * i + 1] + M[3 * k + 2] * r[3 * i + 2];
+      p[3 * i + k] = z[3 * i + k];
+      rz += r[3 * i + k] * z[3 * i + k];
+      bb += r[3 * i + k] * r[3 * i + k];
+    }
+  }
+  double rr = bb;
+  int it = 0;
+  *converged = false;
+  while (it < maxit) {
+    if (rr <= tol * tol * bb) {
+      *converged = true;
+      break;
+    }
+    double pq = 0;
+#pragma omp parallel for num_threads(threads) reduction(+ : pq) schedule(static)
+    for (int i = 0; i < n; ++i) {
+      double a0 = 0, a1 = 0, a2 = 0;
+      for (int k = R.ptr[i]; k < R.ptr[i + 1]; ++k) {
+        const double* B = &R.blk[(size_t)k * 9];
+        const double* v = &p[3 * (size_t)R.col[k]];
+        a0 += B[0] * v[0] + B[1] * v[1] + B[2] * v[2];
+        a1 += B[3] * v[0] + B[4] * v[1] + B[5] * v[2];
+        a2 += B[6] * v[0] + B[7] * v[1] + B[8] * v[2];
+      }
+      q[3 * i] = a0; q[3 * i + 1] = a1; q[3 * i + 2] = a2;
+      pq += p[3 * i] * a0 + p[3 * i + 1] * a1 + p[3 * i + 2] * a2;
+    }
+    if (!(pq > 0)) return -1;
+    const double alpha = rz / pq;
+    double rzn = 0;
+    rr = 0;
+#pragma omp parallel for num_threads(threads) reduction(+ : rzn, rr) schedule(static)
+    for (int i = 0; i < n; ++i) {
+      const double* M = &Dinv[(size_t)i * 9];
+      for (int k = 0; k < 3; ++k) {
+        x[3 * i + k] += alpha * p[3 * i + k];
+        r[3 * i + k] -= alpha * q[3 * i + k];
+      }
+      for (int k = 0; k < 3; ++k) {
+        z[3 * i + k] = M[3 * k] * r[3 * i] + M[3 * k + 1] * r[3 * i + 1] + M[3 * k + 2] * r[3 * i + 2];
+        rzn += r[3 * i + k] * z[3 * i + k];
+        rr += r[3 * i + k] * r[3 * i + k];
+      }
+    }
+    const double beta = rzn / rz;
+#pragma omp parallel for num_threads(threads) schedule(static)
+    for (int i = 0; i < N; ++i) p[i] = z[i] + beta * p[i];
+    rz = rzn;
+    ++it;
+  }
+  return it;
+}
+
 }  // namespace
 
 extern "C" {
@@ -574,6 +677,33 @@ int sgo_oracle_hessian_apply(int V, const double* poses, const uint8_t* fixed, i
   build_system(g, poses, S, &c, &rc);
   sym_spmv(S, x, y);
   return S.n;
+}
+
+// CPU-baseline timing of ONE Gauss-Newton iteration with the block-Jacobi PCG on `threads` OpenMP threads
+// (1 = variant B of SURVEY.md section 8(d), all cores = variant C): linearise + assemble at `poses`, then at
+// most pcg_maxit PCG iterations.  out[0] = seconds of linearise + assemble (single thread, as the GN loop
+// above), out[1] = seconds of the PCG iterations, out[2] = iterations run, out[3] = 1 if pcg_tol was reached.
+int sgo_oracle_pcg_timing(int V, const double* poses, const uint8_t* fixed, int E, const int32_t* ei, const int32_t* ej,
+                          const double* meas, const double* info, const double* phi, double pcg_tol, int pcg_maxit,
+                          int threads, double* out) {
+  Graph g{V, E, fixed, ei, ej, meas, info, phi};
+  System S;
+  build_structure(g, S);
+  if (S.n == 0) return -1;
+  double c2, rc2;
+  double t0 = now_s();
+  build_system(g, poses, S, &c2, &rc2);
+  out[0] = now_s() - t0;
+  RowCsr R;
+  to_rows(S, R);
+  std::vector<double> x;
+  bool conv = false;
+  t0 = now_s();
+  const int k = pcg_rows(S, R, x, pcg_tol, pcg_maxit, threads < 1 ? 1 : threads, &conv);
+  out[1] = now_s() - t0;
+  out[2] = (double)k;
+  out[3] = conv ? 1.0 : 0.0;
+  return k;
 }
 
 // SparseOptimizer::optimize(iters) with OptimizationAlgorithmGaussNewton (slc.cpp:286-288,
