@@ -633,8 +633,50 @@ class SparseOptimizer : public OptimizableGraph {
     _graphOnDevice = false;
     return true;
   }
-  bool updateInitialization(HyperGraph::VertexSet&, HyperGraph::EdgeSet&) { return initializeOptimization(); }
+  // upstream appends the new vertices / edges to the active sets (new vertices get the next hessian indices)
+  // and extends the solver's structure; vertices and edges already active keep their place
+  bool updateInitialization(HyperGraph::VertexSet& vset, HyperGraph::EdgeSet& eset) {
+    std::vector<OptimizableGraph::Vertex*> nv;
+    for (auto* hv : vset) {
+      auto* v = static_cast<OptimizableGraph::Vertex*>(hv);
+      if (std::find(_activeVertices.begin(), _activeVertices.end(), v) == _activeVertices.end()) nv.push_back(v);
+    }
+    std::vector<OptimizableGraph::Edge*> ne;
+    for (auto* he : eset) {
+      auto* e = static_cast<OptimizableGraph::Edge*>(he);
+      bool all = true, allFixed = true;
+      for (auto* v : e->vertices()) {
+        auto it = v ? _vertices.find(v->id()) : _vertices.end();
+        if (it == _vertices.end() || it->second != v) all = false;
+        else allFixed = allFixed && static_cast<OptimizableGraph::Vertex*>(v)->fixed();
+      }
+      if (!all || allFixed) continue;
+      if (std::find(_activeEdges.begin(), _activeEdges.end(), e) == _activeEdges.end()) ne.push_back(e);
+      for (auto* v : e->vertices()) {   // an edge activates its vertices (upstream asserts they are in vset)
+        auto* ov = static_cast<OptimizableGraph::Vertex*>(v);
+        if (std::find(_activeVertices.begin(), _activeVertices.end(), ov) == _activeVertices.end() &&
+            std::find(nv.begin(), nv.end(), ov) == nv.end())
+          nv.push_back(ov);
+      }
+    }
+    std::sort(nv.begin(), nv.end(), [](OptimizableGraph::Vertex* a, OptimizableGraph::Vertex* b) { return a->id() < b->id(); });
+    std::sort(ne.begin(), ne.end(), [](OptimizableGraph::Edge* a, OptimizableGraph::Edge* b) { return a->internalId() < b->internalId(); });
+    int h = 0;
+    for (auto* v : _activeVertices) h += v->fixed() ? 0 : 1;
+    for (auto* v : nv) {
+      v->setHessianIndex(v->fixed() ? -1 : h++);
+      _activeVertices.push_back(v);
+    }
+    for (auto* e : ne) _activeEdges.push_back(e);
+    _graphOnDevice = false;
+    return true;
+  }
 
+  // `online` (drone.cpp:155 passes true after updateInitialization): upstream it only decides whether the block
+  // structure is rebuilt (BlockSolver::init / buildStructure at iteration 0) or was already extended by
+  // updateInitialization -> updateStructure; the numbers are the same either way -- lambda is re-initialised from
+  // the diagonal at iteration 0 of every optimize() call in both modes (OptimizationAlgorithmLevenberg::solve).
+  // This backend marshals / assembles from the active sets on every call, so the flag has nothing left to select.
   int optimize(int iterations, bool online = false) {
     (void)online;
     if (!_algorithm) {
@@ -664,6 +706,14 @@ class SparseOptimizer : public OptimizableGraph {
     return done;
   }
   const sgo_stats* lastStats() const { return _lastStats.get(); }
+  // Levenberg-Marquardt bookkeeping of the last optimize() on the host solver (extension for the tests; g2o
+  // exposes the same numbers through OptimizationAlgorithmLevenberg::currentLambda() / levenbergIterations()
+  // and its verbose output): damping after the iteration, robust chi2 after it, trials it took.
+  struct LmIteration {
+    double lambda, chi2;
+    int trials;
+  };
+  const std::vector<LmIteration>& lmTrace() const { return _lmTrace; }
 
   void computeActiveErrors() {
     for (auto* e : _activeEdges) e->computeError();
@@ -762,6 +812,7 @@ class SparseOptimizer : public OptimizableGraph {
       return 0;
     }
     const bool lm = _algorithm->kind() == OptimizationAlgorithm::Levenberg;
+    _lmTrace.clear();
     std::vector<double> H((size_t)n * n), b(n), x(n);
     int cjIterations = 0;
     bool ok = true, failed = false;
@@ -818,12 +869,14 @@ class SparseOptimizer : public OptimizableGraph {
         qmax++;
       } while (rho < 0 && qmax < 10);
       ++cjIterations;
+      _lmTrace.push_back({_lmLambda, currentChi, qmax});
       if (qmax == 10 || rho == 0 || !std::isfinite(_lmLambda)) ok = false;  // Terminate
     }
     if (failed) return 0;
     return cjIterations;
   }
   double _lmLambda = 0.0, _lmNi = 2.0;
+  std::vector<LmIteration> _lmTrace;
   static constexpr int kHostSolverMaxUnknowns = 3000;
 
   bool gpuEligible() const {

@@ -133,6 +133,7 @@ struct sgo_ctx {
   // profiling
   struct Rec { int kid; hipEvent_t a, b; };
   std::vector<hipEvent_t> ev_pool;
+  std::vector<hipEvent_t> iter_events;   // time stamps of sgo_optimize_gn, reused across calls
   std::vector<Rec> pending;
   double prof_ms[K_COUNT] = {0};
   int64_t prof_launches[K_COUNT] = {0};
@@ -1148,6 +1149,22 @@ int check_graph(sgo_ctx* c) {
 
 }  // namespace
 
+// include/sgo.h promises that no exception crosses the C boundary: host allocations (std::vector, std::string, new)
+// inside an entry point are caught here and reported as SGO_ENOMEM / SGO_EINVAL
+#define SGO_CATCH(ctx)                                                              \
+  catch (const std::bad_alloc&) {                                                   \
+    if (ctx) (ctx)->err = "out of host memory";                                     \
+    return SGO_ENOMEM;                                                              \
+  }                                                                                 \
+  catch (const std::exception& e_) {                                                \
+    if (ctx) (ctx)->err = std::string("internal error: ") + e_.what();              \
+    return SGO_EINVAL;                                                              \
+  }                                                                                 \
+  catch (...) {                                                                     \
+    if (ctx) (ctx)->err = "internal error (unknown exception)";                     \
+    return SGO_EINVAL;                                                              \
+  }
+
 // =============================================================================== C-ABI
 extern "C" {
 
@@ -1231,6 +1248,7 @@ void sgo_destroy(sgo_ctx* c) {
   free_graph(c);
   c->comm.destroy();
   for (hipEvent_t e : c->ev_pool) hipEventDestroy(e);
+  for (hipEvent_t e : c->iter_events) hipEventDestroy(e);
   if (c->h_S) hipHostFree(c->h_S);
   if (c->h_S2) hipHostFree(c->h_S2);
   for (hipEvent_t ev : c->ev_S)
@@ -1244,72 +1262,78 @@ const char* sgo_last_error(sgo_ctx* c) { return c ? c->err.c_str() : g_err.c_str
 
 int sgo_set_graph_se2(sgo_ctx* c, int32_t V, const double* poses, const uint8_t* fixed, int32_t E, const int32_t* ei,
                       const int32_t* ej, const double* meas, const double* info, const double* phi) {
-  if (!c) return SGO_EINVAL;
-  if (V <= 0 || E < 0 || !poses || !fixed || (E > 0 && (!ei || !ej || !meas || !info || !phi))) {
-    c->err = "sgo_set_graph_se2: bad argument";
-    return SGO_EINVAL;
-  }
-  if (2 * (int64_t)E + (int64_t)V > (int64_t)INT32_MAX / 2) {  // slot indices are 32-bit (2E + n slots)
-    c->err = "sgo_set_graph_se2: graph too large for 32-bit slot indices";
-    return SGO_EINVAL;
-  }
-  hipError_t e = hipSetDevice(c->device);
-  if (e != hipSuccess) {
-    c->err = std::string("hipSetDevice: ") + hipGetErrorString(e);
-    return SGO_EHIP;
-  }
-  const double t0 = wall_s();
-  hipStreamSynchronize(c->stream);
-  free_graph(c);
-  if (c->opts.verbose) std::fprintf(stderr, "[sgo] set_graph: release of the previous graph %.1f ms\n", 1e3 * (wall_s() - t0));
-  int rc = build_structure(c, V, poses, fixed, E, ei, ej, meas, info, phi);
-  if (rc != SGO_OK) {
+  try {
+    if (!c) return SGO_EINVAL;
+    if (V <= 0 || E < 0 || !poses || !fixed || (E > 0 && (!ei || !ej || !meas || !info || !phi))) {
+      c->err = "sgo_set_graph_se2: bad argument";
+      return SGO_EINVAL;
+    }
+    if (2 * (int64_t)E + (int64_t)V > (int64_t)INT32_MAX / 2) {  // slot indices are 32-bit (2E + n slots)
+      c->err = "sgo_set_graph_se2: graph too large for 32-bit slot indices";
+      return SGO_EINVAL;
+    }
+    hipError_t e = hipSetDevice(c->device);
+    if (e != hipSuccess) {
+      c->err = std::string("hipSetDevice: ") + hipGetErrorString(e);
+      return SGO_EHIP;
+    }
+    const double t0 = wall_s();
+    hipStreamSynchronize(c->stream);
     free_graph(c);
-    return rc;
-  }
-  c->has_graph = true;
-  c->shard_units = c->T0.ntile > 0 ? c->T0.ntile : c->S0.ngrp;
-  sgo_shard_range(c->shard_units, c->comm.nranks, c->comm.rank, &c->shard_u0, &c->shard_u1);
-  // Chain-like graphs (fewer than ~1.5 edges per free pose: under 4 Hessian blocks per row) are the
-  // ill-conditioned ones -- kappa(H) grows with the square of the chain length -- and a relative
-  // residual of 1e-8 then leaves errors that show in chi2 (3000 poses / 3150 edges: iterates 3e-6 and
-  // poses 7e-5 m from the direct-solver oracle at 1e-8, 1.4e-8 at 1e-9).  Their PCG iterations are the
-  // cheap ones, so they get a 10x tighter tolerance than opts.pcg_tol.
-  c->tol_scale = (c->n > 0 && (long long)c->A.nslot < 4LL * c->n) ? 0.1 : 1.0;   // logical slots: 2 per edge + 1 per row
-  c->solver_desc = "pcg_block_jacobi";
-  if (c->opts.solver == SGO_SOLVER_PCG_AMG && c->n > 0 && (c->comm.nranks == 1 || c->comm.handle)) {
-    // the hierarchy is built from the Hessian at the initial poses (strength of connection)
-    const double ta0 = wall_s();
-    if ((rc = do_linearize(c)) != SGO_OK || (rc = build_amg(c)) != SGO_OK) {
+    if (c->opts.verbose) std::fprintf(stderr, "[sgo] set_graph: release of the previous graph %.1f ms\n", 1e3 * (wall_s() - t0));
+    int rc = build_structure(c, V, poses, fixed, E, ei, ej, meas, info, phi);
+    if (rc != SGO_OK) {
       free_graph(c);
       return rc;
     }
-    if (c->opts.verbose) std::fprintf(stderr, "[sgo] set_graph: multigrid set-up %.1f ms\n", 1e3 * (wall_s() - ta0));
-    c->linearized = false;
-  }
-  c->setup_seconds = wall_s() - t0;
-  if (c->opts.verbose)
-    std::fprintf(stderr, "[sgo] solver: %s\n[sgo] set_graph: total %.1f ms\n", c->solver_desc.c_str(), 1e3 * c->setup_seconds);
-  return SGO_OK;
+    c->has_graph = true;
+    c->shard_units = c->T0.ntile > 0 ? c->T0.ntile : c->S0.ngrp;
+    sgo_shard_range(c->shard_units, c->comm.nranks, c->comm.rank, &c->shard_u0, &c->shard_u1);
+    // Chain-like graphs (fewer than ~1.5 edges per free pose: under 4 Hessian blocks per row) are the
+    // ill-conditioned ones -- kappa(H) grows with the square of the chain length -- and a relative
+    // residual of 1e-8 then leaves errors that show in chi2 (3000 poses / 3150 edges: iterates 3e-6 and
+    // poses 7e-5 m from the direct-solver oracle at 1e-8, 1.4e-8 at 1e-9).  Their PCG iterations are the
+    // cheap ones, so they get a 10x tighter tolerance than opts.pcg_tol.
+    c->tol_scale = (c->n > 0 && (long long)c->A.nslot < 4LL * c->n) ? 0.1 : 1.0;   // logical slots: 2 per edge + 1 per row
+    c->solver_desc = "pcg_block_jacobi";
+    if (c->opts.solver == SGO_SOLVER_PCG_AMG && c->n > 0 && (c->comm.nranks == 1 || c->comm.handle)) {
+      // the hierarchy is built from the Hessian at the initial poses (strength of connection)
+      const double ta0 = wall_s();
+      if ((rc = do_linearize(c)) != SGO_OK || (rc = build_amg(c)) != SGO_OK) {
+        free_graph(c);
+        return rc;
+      }
+      if (c->opts.verbose) std::fprintf(stderr, "[sgo] set_graph: multigrid set-up %.1f ms\n", 1e3 * (wall_s() - ta0));
+      c->linearized = false;
+    }
+    c->setup_seconds = wall_s() - t0;
+    if (c->opts.verbose)
+      std::fprintf(stderr, "[sgo] solver: %s\n[sgo] set_graph: total %.1f ms\n", c->solver_desc.c_str(), 1e3 * c->setup_seconds);
+    return SGO_OK;
+  } SGO_CATCH(c)
 }
 
 int sgo_set_poses(sgo_ctx* c, const double* poses) {
-  int rc = check_graph(c);
-  if (rc) return rc;
-  if (!poses) return SGO_EINVAL;
-  HIP_TRY(c, hipMemcpyAsync(c->d_poses, poses, sizeof(double) * 3 * (size_t)c->V, hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
-  c->linearized = false;
-  return SGO_OK;
+  try {
+    int rc = check_graph(c);
+    if (rc) return rc;
+    if (!poses) return SGO_EINVAL;
+    HIP_TRY(c, hipMemcpyAsync(c->d_poses, poses, sizeof(double) * 3 * (size_t)c->V, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->linearized = false;
+    return SGO_OK;
+  } SGO_CATCH(c)
 }
 
 int sgo_get_poses(sgo_ctx* c, double* poses) {
-  int rc = check_graph(c);
-  if (rc) return rc;
-  if (!poses) return SGO_EINVAL;
-  HIP_TRY(c, hipMemcpyAsync(poses, c->d_poses, sizeof(double) * 3 * (size_t)c->V, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
-  return SGO_OK;
+  try {
+    int rc = check_graph(c);
+    if (rc) return rc;
+    if (!poses) return SGO_EINVAL;
+    HIP_TRY(c, hipMemcpyAsync(poses, c->d_poses, sizeof(double) * 3 * (size_t)c->V, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return SGO_OK;
+  } SGO_CATCH(c)
 }
 
 int sgo_num_free(sgo_ctx* c) {
@@ -1318,306 +1342,321 @@ int sgo_num_free(sgo_ctx* c) {
 }
 
 int sgo_free_ids(sgo_ctx* c, int32_t* out) {
-  int rc = check_graph(c);
-  if (rc) return rc;
-  if (!out) return SGO_EINVAL;
-  std::copy(c->free_id.begin(), c->free_id.end(), out);
-  return c->n;
+  try {
+    int rc = check_graph(c);
+    if (rc) return rc;
+    if (!out) return SGO_EINVAL;
+    std::copy(c->free_id.begin(), c->free_id.end(), out);
+    return c->n;
+  } SGO_CATCH(c)
 }
 
 int sgo_chi2(sgo_ctx* c, double* plain, double* robust) {
-  int rc = check_graph(c);
-  if (rc) return rc;
-  if ((rc = do_chi2(c, c->d_hist, nullptr))) return rc;
-  HIP_TRY(c, hipMemcpyAsync(c->h_hist, c->d_hist, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
-  if (plain) *plain = c->h_hist[0];
-  if (robust) *robust = c->h_hist[1];
-  return SGO_OK;
+  try {
+    int rc = check_graph(c);
+    if (rc) return rc;
+    if ((rc = do_chi2(c, c->d_hist, nullptr))) return rc;
+    HIP_TRY(c, hipMemcpyAsync(c->h_hist, c->d_hist, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (plain) *plain = c->h_hist[0];
+    if (robust) *robust = c->h_hist[1];
+    return SGO_OK;
+  } SGO_CATCH(c)
 }
 
 int sgo_edge_chi2(sgo_ctx* c, double* e2) {
-  int rc = check_graph(c);
-  if (rc) return rc;
-  if (!e2) return SGO_EINVAL;
-  if ((rc = do_chi2(c, c->d_hist, c->d_e2))) return rc;
-  HIP_TRY(c, hipMemcpyAsync(e2, c->d_e2, sizeof(double) * (size_t)c->E, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
-  return SGO_OK;
+  try {
+    int rc = check_graph(c);
+    if (rc) return rc;
+    if (!e2) return SGO_EINVAL;
+    if ((rc = do_chi2(c, c->d_hist, c->d_e2))) return rc;
+    HIP_TRY(c, hipMemcpyAsync(e2, c->d_e2, sizeof(double) * (size_t)c->E, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return SGO_OK;
+  } SGO_CATCH(c)
 }
 
 int sgo_closure_information(sgo_ctx* c, int32_t n, const sgo_match_window* win, const float* scores, int64_t n_scores,
                             double* cov, double* info) {
-  if (!c) return SGO_EINVAL;
-  if (n < 0 || n_scores < 0 || (n > 0 && (!win || !scores || !cov || !info))) {
-    c->err = "sgo_closure_information: null buffer or negative count";
-    return SGO_EINVAL;
-  }
-  if (n == 0) return SGO_OK;
-  // every window must lie inside scores[]: the kernel trusts these bounds
-  for (int q = 0; q < n; ++q) {
-    const sgo_match_window& W = win[q];
-    if (W.w_size < 0 || W.w_size > 1024 || W.scan_window < 0 || W.scan_window > 1024 || W.score_offset < 0) {
-      c->err = "sgo_closure_information: window " + std::to_string(q) + " has a negative or oversized extent";
+  try {
+    if (!c) return SGO_EINVAL;
+    if (n < 0 || n_scores < 0 || (n > 0 && (!win || !scores || !cov || !info))) {
+      c->err = "sgo_closure_information: null buffer or negative count";
       return SGO_EINVAL;
     }
-    const int64_t nw = 2 * (int64_t)W.w_size + 1, total = nw * nw * (2 * (int64_t)W.scan_window + 1);
-    if (total > INT32_MAX || W.score_offset + total > n_scores) {
-      c->err = "sgo_closure_information: window " + std::to_string(q) + " reaches past scores[n_scores]";
-      return SGO_EINVAL;
+    if (n == 0) return SGO_OK;
+    // every window must lie inside scores[]: the kernel trusts these bounds
+    for (int q = 0; q < n; ++q) {
+      const sgo_match_window& W = win[q];
+      if (W.w_size < 0 || W.w_size > 1024 || W.scan_window < 0 || W.scan_window > 1024 || W.score_offset < 0) {
+        c->err = "sgo_closure_information: window " + std::to_string(q) + " has a negative or oversized extent";
+        return SGO_EINVAL;
+      }
+      const int64_t nw = 2 * (int64_t)W.w_size + 1, total = nw * nw * (2 * (int64_t)W.scan_window + 1);
+      if (total > INT32_MAX || W.score_offset + total > n_scores) {
+        c->err = "sgo_closure_information: window " + std::to_string(q) + " reaches past scores[n_scores]";
+        return SGO_EINVAL;
+      }
     }
-  }
-  HIP_TRY(c, hipSetDevice(c->device));
-  sgo_match_window* d_win = nullptr;
-  float* d_sc = nullptr;
-  double* d_out = nullptr;
-  auto release = [&]() {
-    if (d_win) hipFree(d_win);
-    if (d_sc) hipFree(d_sc);
-    if (d_out) hipFree(d_out);
-  };
-  if (hipMalloc(&d_win, sizeof(sgo_match_window) * (size_t)n) != hipSuccess ||
-      hipMalloc(&d_sc, sizeof(float) * (size_t)std::max<int64_t>(n_scores, 1)) != hipSuccess ||
-      hipMalloc(&d_out, sizeof(double) * 18 * (size_t)n) != hipSuccess) {
+    HIP_TRY(c, hipSetDevice(c->device));
+    sgo_match_window* d_win = nullptr;
+    float* d_sc = nullptr;
+    double* d_out = nullptr;
+    auto release = [&]() {
+      if (d_win) hipFree(d_win);
+      if (d_sc) hipFree(d_sc);
+      if (d_out) hipFree(d_out);
+    };
+    if (hipMalloc(&d_win, sizeof(sgo_match_window) * (size_t)n) != hipSuccess ||
+        hipMalloc(&d_sc, sizeof(float) * (size_t)std::max<int64_t>(n_scores, 1)) != hipSuccess ||
+        hipMalloc(&d_out, sizeof(double) * 18 * (size_t)n) != hipSuccess) {
+      release();
+      c->err = "sgo_closure_information: out of device memory";
+      return SGO_ENOMEM;
+    }
+    hipError_t e = hipMemcpyAsync(d_win, win, sizeof(sgo_match_window) * (size_t)n, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess)
+      e = hipMemcpyAsync(d_sc, scores, sizeof(float) * (size_t)n_scores, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+      launch_closure_cov(c->stream, n, d_win, d_sc, d_out, d_out + 9 * (size_t)n);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(cov, d_out, sizeof(double) * 9 * (size_t)n, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess)
+      e = hipMemcpyAsync(info, d_out + 9 * (size_t)n, sizeof(double) * 9 * (size_t)n, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     release();
-    c->err = "sgo_closure_information: out of device memory";
-    return SGO_ENOMEM;
-  }
-  hipError_t e = hipMemcpyAsync(d_win, win, sizeof(sgo_match_window) * (size_t)n, hipMemcpyHostToDevice, c->stream);
-  if (e == hipSuccess)
-    e = hipMemcpyAsync(d_sc, scores, sizeof(float) * (size_t)n_scores, hipMemcpyHostToDevice, c->stream);
-  if (e == hipSuccess) {
-    launch_closure_cov(c->stream, n, d_win, d_sc, d_out, d_out + 9 * (size_t)n);
-    e = hipGetLastError();
-  }
-  if (e == hipSuccess) e = hipMemcpyAsync(cov, d_out, sizeof(double) * 9 * (size_t)n, hipMemcpyDeviceToHost, c->stream);
-  if (e == hipSuccess)
-    e = hipMemcpyAsync(info, d_out + 9 * (size_t)n, sizeof(double) * 9 * (size_t)n, hipMemcpyDeviceToHost, c->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-  release();
-  if (e != hipSuccess) {
-    c->err = std::string("sgo_closure_information: ") + hipGetErrorString(e);
-    return SGO_EHIP;
-  }
-  return SGO_OK;
+    if (e != hipSuccess) {
+      c->err = std::string("sgo_closure_information: ") + hipGetErrorString(e);
+      return SGO_EHIP;
+    }
+    return SGO_OK;
+  } SGO_CATCH(c)
 }
 
 int sgo_linearize(sgo_ctx* c, double* b, double* diag, double* plain, double* robust) {
-  int rc = check_graph(c);
-  if (rc) return rc;
-  if (c->n == 0) return SGO_ENOTHING;
-  if ((rc = do_chi2(c, c->d_hist, nullptr))) return rc;
-  if ((rc = do_linearize(c))) return rc;
-  std::vector<double> dgb(9 * (size_t)c->n);
-  HIP_TRY(c, hipMemcpyAsync(dgb.data(), c->d_dgb, sizeof(double) * dgb.size(), hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipMemcpyAsync(c->h_hist, c->d_hist, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
-  for (int i = 0; i < c->n; ++i) {   // i: hessian index (g2o order); its values sit in internal row row_of_asc[i]
-    const double* d = &dgb[9 * (size_t)c->row_of_asc[i]];
-    if (diag) {
-      double* D = diag + 9 * (size_t)i;
-      D[0] = d[0]; D[1] = d[1]; D[2] = d[2];
-      D[3] = d[1]; D[4] = d[3]; D[5] = d[4];
-      D[6] = d[2]; D[7] = d[4]; D[8] = d[5];
+  try {
+    int rc = check_graph(c);
+    if (rc) return rc;
+    if (c->n == 0) return SGO_ENOTHING;
+    if ((rc = do_chi2(c, c->d_hist, nullptr))) return rc;
+    if ((rc = do_linearize(c))) return rc;
+    std::vector<double> dgb(9 * (size_t)c->n);
+    HIP_TRY(c, hipMemcpyAsync(dgb.data(), c->d_dgb, sizeof(double) * dgb.size(), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->h_hist, c->d_hist, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (int i = 0; i < c->n; ++i) {   // i: hessian index (g2o order); its values sit in internal row row_of_asc[i]
+      const double* d = &dgb[9 * (size_t)c->row_of_asc[i]];
+      if (diag) {
+        double* D = diag + 9 * (size_t)i;
+        D[0] = d[0]; D[1] = d[1]; D[2] = d[2];
+        D[3] = d[1]; D[4] = d[3]; D[5] = d[4];
+        D[6] = d[2]; D[7] = d[4]; D[8] = d[5];
+      }
+      if (b) {
+        b[3 * (size_t)i] = d[6];
+        b[3 * (size_t)i + 1] = d[7];
+        b[3 * (size_t)i + 2] = d[8];
+      }
     }
-    if (b) {
-      b[3 * (size_t)i] = d[6];
-      b[3 * (size_t)i + 1] = d[7];
-      b[3 * (size_t)i + 2] = d[8];
-    }
-  }
-  if (plain) *plain = c->h_hist[0];
-  if (robust) *robust = c->h_hist[1];
-  return SGO_OK;
+    if (plain) *plain = c->h_hist[0];
+    if (robust) *robust = c->h_hist[1];
+    return SGO_OK;
+  } SGO_CATCH(c)
 }
 
 int sgo_hessian_apply(sgo_ctx* c, const double* x, double* y) {
-  int rc = check_graph(c);
-  if (rc) return rc;
-  if (!x || !y) return SGO_EINVAL;
-  if (!c->linearized) {
-    c->err = "sgo_hessian_apply: call sgo_linearize first";
-    return SGO_EINVAL;
-  }
-  if ((rc = vec_to_device(c, x, c->d_s1))) return rc;
-  if ((rc = do_spmv(c, c->d_s1, c->d_s2, false, nullptr, nullptr))) return rc;
-  return vec_from_device(c, c->d_s2, y);
+  try {
+    int rc = check_graph(c);
+    if (rc) return rc;
+    if (!x || !y) return SGO_EINVAL;
+    if (!c->linearized) {
+      c->err = "sgo_hessian_apply: call sgo_linearize first";
+      return SGO_EINVAL;
+    }
+    if ((rc = vec_to_device(c, x, c->d_s1))) return rc;
+    if ((rc = do_spmv(c, c->d_s1, c->d_s2, false, nullptr, nullptr))) return rc;
+    return vec_from_device(c, c->d_s2, y);
+  } SGO_CATCH(c)
 }
 
 int sgo_precondition(sgo_ctx* c, const double* r, double* z) {
-  int rc = check_graph(c);
-  if (rc) return rc;
-  if (!r || !z) return SGO_EINVAL;
-  if (!c->linearized) {
-    c->err = "sgo_precondition: call sgo_linearize first";
-    return SGO_EINVAL;
-  }
-  if ((rc = vec_to_device(c, r, c->d_s1))) return rc;
-  if (c->amg) amg_apply(c->amg, c->stream, c->d_s1, c->d_s2, nullptr, nullptr, nullptr);
-  else launch_precond_bj(c->stream, c->n, c->S0.dinv, c->d_s1, c->d_s2, 1.0);
-  return vec_from_device(c, c->d_s2, z);
+  try {
+    int rc = check_graph(c);
+    if (rc) return rc;
+    if (!r || !z) return SGO_EINVAL;
+    if (!c->linearized) {
+      c->err = "sgo_precondition: call sgo_linearize first";
+      return SGO_EINVAL;
+    }
+    if ((rc = vec_to_device(c, r, c->d_s1))) return rc;
+    if (c->amg) amg_apply(c->amg, c->stream, c->d_s1, c->d_s2, nullptr, nullptr, nullptr);
+    else launch_precond_bj(c->stream, c->n, c->S0.dinv, c->d_s1, c->d_s2, 1.0);
+    return vec_from_device(c, c->d_s2, z);
+  } SGO_CATCH(c)
 }
 
 int sgo_solve(sgo_ctx* c, double* x, double* relres) {
-  int rc = check_graph(c);
-  if (rc) return rc;
-  if (!c->linearized) {
-    c->err = "sgo_solve: call sgo_linearize first";
-    return SGO_EINVAL;
-  }
-  // restart from the state of the last linearisation (idempotent re-finalize)
-  int grid = 0;
-  launch_finalize(c->stream, c->S0, c->d_dgb, c->d_b, c->d_x, c->d_r, c->d_z, c->d_p,
-                  c->amg ? amg_xs0(c->amg) : nullptr, c->amg ? amg_omega(c->amg) : 0.0, c->d_partials, &grid);
-  if ((rc = start_pcg(c, grid))) return rc;
-  if ((rc = run_pcg(c))) return rc;
-  if (x && (rc = vec_from_device(c, c->d_x, x))) return rc;
-  if (relres) *relres = c->h_S->bb > 0 ? std::sqrt(c->h_S->rr / c->h_S->bb) : 0.0;
-  if (c->h_S->stop == 3) {
-    c->err = "PCG breakdown (p.Hp <= 0 or non-finite): Hessian not positive definite";
-    return SGO_EINVAL;
-  }
-  return c->h_S->iter;
+  try {
+    int rc = check_graph(c);
+    if (rc) return rc;
+    if (!c->linearized) {
+      c->err = "sgo_solve: call sgo_linearize first";
+      return SGO_EINVAL;
+    }
+    // restart from the state of the last linearisation (idempotent re-finalize)
+    int grid = 0;
+    launch_finalize(c->stream, c->S0, c->d_dgb, c->d_b, c->d_x, c->d_r, c->d_z, c->d_p,
+                    c->amg ? amg_xs0(c->amg) : nullptr, c->amg ? amg_omega(c->amg) : 0.0, c->d_partials, &grid);
+    if ((rc = start_pcg(c, grid))) return rc;
+    if ((rc = run_pcg(c))) return rc;
+    if (x && (rc = vec_from_device(c, c->d_x, x))) return rc;
+    if (relres) *relres = c->h_S->bb > 0 ? std::sqrt(c->h_S->rr / c->h_S->bb) : 0.0;
+    if (c->h_S->stop == 3) {
+      c->err = "PCG breakdown (p.Hp <= 0 or non-finite): Hessian not positive definite";
+      return SGO_EINVAL;
+    }
+    return c->h_S->iter;
+  } SGO_CATCH(c)
 }
 
 int sgo_optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
-  int rc = check_graph(c);
-  if (rc) return rc;
-  if (iters < 0 || iters > SGO_MAX_ITERS) {
-    c->err = "sgo_optimize_gn: iters must be in [0, SGO_MAX_ITERS]";
-    return SGO_EINVAL;
-  }
-  if (out) {
-    std::memset(out, 0, sizeof(*out));
-    out->iters_requested = iters;
-    out->seconds_setup = c->setup_seconds;
-  }
-  if (c->n == 0) return SGO_ENOTHING;
-  const double t0 = wall_s();
-  struct Events {  // per-iteration time stamps; destroyed on every return path
-    std::vector<hipEvent_t> v;
-    ~Events() {
-      for (hipEvent_t e : v)
-        if (e) hipEventDestroy(e);
-    }
-  } evs;
-  evs.v.assign(3 * (size_t)iters + 1, nullptr);
-  for (auto& e : evs.v) HIP_TRY(c, hipEventCreate(&e));
-  std::vector<hipEvent_t>& ev = evs.v;
-  struct SoftcapGuard {   // the bail-out cap applies to solves inside this call only
-    sgo_ctx* c;
-    ~SoftcapGuard() { c->pcg_softcap = 0; }
-  } softcap_guard{c};
-  int done = 0;
-  bool failed = false;
-  int rebuilds = 0;
-  int& best_pcg = c->amg_best;
-  bool rebuild_next = false;
-  for (int it = 0; it < iters; ++it) {
-    hipEventRecord(ev[3 * it], c->stream);
-    c->pcg_softcap = (c->amg && c->amg_best > 0 && rebuilds < 3 && !rebuild_next) ? 4 * c->amg_best + 40 : 0;
-    if ((rc = do_chi2(c, c->d_hist + 2 * it, nullptr)) || (rc = do_linearize(c))) {
-      return rc;
-    }
-    if (rebuild_next && c->amg) {
-      // The aggregation was made from the Hessian of an earlier linearisation and robust-kernel
-      // re-weighting has changed the strength of connection since (see the rule below): redo the
-      // set-up from the current values (same cost as in sgo_set_graph_se2).
-      if ((rc = build_amg(c)) || (rc = do_linearize(c))) return rc;
-      rebuild_next = false;
-      ++rebuilds;
-      if (c->opts.verbose) std::fprintf(stderr, "[sgo] multigrid hierarchy rebuilt before iteration %d\n", it);
-    }
-    hipEventRecord(ev[3 * it + 1], c->stream);
-    int wasted = 0;
-    if ((rc = run_pcg(c))) {
-      return rc;
-    }
-    if (c->pcg_softcap > 0 && c->h_S->stop == 2 && c->h_S->iter < c->opts.pcg_maxit && c->amg) {
-      // The solve ran into the bail-out cap (4x the best count of this hierarchy): the aggregation no
-      // longer fits the re-weighted Hessian.  Redo the set-up from the current values and solve again
-      // from x = 0 instead of grinding on (seen: 735 iterations where the rebuilt hierarchy needs 16).
-      wasted = c->h_S->iter;
-      c->pcg_softcap = 0;
-      if ((rc = build_amg(c)) || (rc = do_linearize(c)) || (rc = run_pcg(c))) return rc;
-      ++rebuilds;
-      rebuild_next = false;
-      if (c->opts.verbose)
-        std::fprintf(stderr, "[sgo] iteration %d: solve abandoned after %d PCG iterations, hierarchy rebuilt\n", it, wasted);
-    }
-    const PcgScalars S = *c->h_S;
-    if (c->amg && S.stop != 3) {
-      if (best_pcg == 0 || S.iter < best_pcg) best_pcg = S.iter;
-      // Redo the aggregation from the current values when that pays: always when the count has more
-      // than doubled, and when it is > 25 % above the best while the PCG iterations it would save
-      // over the remaining GN iterations exceed the set-up's cost (~150 PCG iterations' worth: host
-      // aggregation + one more linearisation).  Counts only -- no clocks -- so that every rank of a
-      // multi-GPU run takes the same decision.
-      const int left = iters - it - 1;
-      const bool doubled = S.iter > 2 * best_pcg + 10;
-      const bool pays = 4 * S.iter > 5 * best_pcg && (long long)(S.iter - best_pcg) * left > 150;
-      if (rebuilds < 3 && (doubled || pays)) rebuild_next = true;
+  try {
+    int rc = check_graph(c);
+    if (rc) return rc;
+    if (iters < 0 || iters > SGO_MAX_ITERS) {
+      c->err = "sgo_optimize_gn: iters must be in [0, SGO_MAX_ITERS]";
+      return SGO_EINVAL;
     }
     if (out) {
-      out->pcg_iters[it] = S.iter + wasted;   // an abandoned solve's iterations count too
-      out->pcg_converged[it] = S.stop == 1;
-      out->pcg_relres[it] = S.bb > 0 ? std::sqrt(S.rr / S.bb) : 0.0;
+      std::memset(out, 0, sizeof(*out));
+      out->iters_requested = iters;
+      out->seconds_setup = c->setup_seconds;
     }
-    if (S.stop != 1) {
-      // Solver failure, as LinearSolverEigen::solve returning false (OptimizationAlgorithm::Fail): the
-      // step is NOT applied, estimates stay at the last successful update and the call returns 0 like
-      // g2o::SparseOptimizer::optimize.  stop == 3: p.Hp <= 0 or non-finite (H not positive definite);
-      // stop == 2: pcg_maxit iterations without reaching pcg_tol (an inexact step is never applied).
-      if (S.stop == 3) {
-        c->err = "PCG breakdown in GN iteration " + std::to_string(it) + " (Hessian not positive definite";
-        if (c->amg && amg_coarsest_not_spd(c->amg, c->stream)) c->err += "; its coarsest Galerkin operator has a non-positive pivot";
-        c->err += ")";
-      } else {
-        c->err = "PCG did not reach pcg_tol within pcg_maxit = " + std::to_string(c->opts.pcg_maxit) +
-                 " iterations in GN iteration " + std::to_string(it) + " (relative residual " +
-                 std::to_string(S.bb > 0 ? std::sqrt(S.rr / S.bb) : 0.0) + "); the step was not applied";
+    if (c->n == 0) return SGO_ENOTHING;
+    const double t0 = wall_s();
+    // per-iteration time stamps: events are kept in the context and reused by later calls
+    while (c->iter_events.size() < 3 * (size_t)iters + 1) {
+      hipEvent_t e = nullptr;
+      HIP_TRY(c, hipEventCreate(&e));
+      c->iter_events.push_back(e);
+    }
+    std::vector<hipEvent_t>& ev = c->iter_events;
+    struct SoftcapGuard {   // the bail-out cap applies to solves inside this call only
+      sgo_ctx* c;
+      ~SoftcapGuard() { c->pcg_softcap = 0; }
+    } softcap_guard{c};
+    int done = 0;
+    bool failed = false;
+    int rebuilds = 0;
+    int& best_pcg = c->amg_best;
+    bool rebuild_next = false;
+    for (int it = 0; it < iters; ++it) {
+      hipEventRecord(ev[3 * it], c->stream);
+      c->pcg_softcap = (c->amg && c->amg_best > 0 && rebuilds < 3 && !rebuild_next) ? 4 * c->amg_best + 40 : 0;
+      if ((rc = do_chi2(c, c->d_hist + 2 * it, nullptr)) || (rc = do_linearize(c))) {
+        return rc;
       }
-      failed = true;
+      if (rebuild_next && c->amg) {
+        // The aggregation was made from the Hessian of an earlier linearisation and robust-kernel
+        // re-weighting has changed the strength of connection since (see the rule below): redo the
+        // set-up from the current values (same cost as in sgo_set_graph_se2).
+        if ((rc = build_amg(c)) || (rc = do_linearize(c))) return rc;
+        rebuild_next = false;
+        ++rebuilds;
+        if (c->opts.verbose) std::fprintf(stderr, "[sgo] multigrid hierarchy rebuilt before iteration %d\n", it);
+      }
+      hipEventRecord(ev[3 * it + 1], c->stream);
+      int wasted = 0;
+      if ((rc = run_pcg(c))) {
+        return rc;
+      }
+      if (c->pcg_softcap > 0 && c->h_S->stop == 2 && c->h_S->iter < c->opts.pcg_maxit && c->amg) {
+        // The solve ran into the bail-out cap (4x the best count of this hierarchy): the aggregation no
+        // longer fits the re-weighted Hessian.  Redo the set-up from the current values and solve again
+        // from x = 0 instead of grinding on (seen: 735 iterations where the rebuilt hierarchy needs 16).
+        wasted = c->h_S->iter;
+        c->pcg_softcap = 0;
+        if ((rc = build_amg(c)) || (rc = do_linearize(c)) || (rc = run_pcg(c))) return rc;
+        ++rebuilds;
+        rebuild_next = false;
+        if (c->opts.verbose)
+          std::fprintf(stderr, "[sgo] iteration %d: solve abandoned after %d PCG iterations, hierarchy rebuilt\n", it, wasted);
+      }
+      const PcgScalars S = *c->h_S;
+      if (c->amg && S.stop != 3) {
+        if (best_pcg == 0 || S.iter < best_pcg) best_pcg = S.iter;
+        // Redo the aggregation from the current values when that pays: always when the count has more
+        // than doubled, and when it is > 25 % above the best while the PCG iterations it would save
+        // over the remaining GN iterations exceed the set-up's cost (~150 PCG iterations' worth: host
+        // aggregation + one more linearisation).  Counts only -- no clocks -- so that every rank of a
+        // multi-GPU run takes the same decision.
+        const int left = iters - it - 1;
+        const bool doubled = S.iter > 2 * best_pcg + 10;
+        const bool pays = 4 * S.iter > 5 * best_pcg && (long long)(S.iter - best_pcg) * left > 150;
+        if (rebuilds < 3 && (doubled || pays)) rebuild_next = true;
+      }
+      if (out) {
+        out->pcg_iters[it] = S.iter + wasted;   // an abandoned solve's iterations count too
+        out->pcg_converged[it] = S.stop == 1;
+        out->pcg_relres[it] = S.bb > 0 ? std::sqrt(S.rr / S.bb) : 0.0;
+      }
+      if (S.stop != 1) {
+        // Solver failure, as LinearSolverEigen::solve returning false (OptimizationAlgorithm::Fail): the
+        // step is NOT applied, estimates stay at the last successful update and the call returns 0 like
+        // g2o::SparseOptimizer::optimize.  stop == 3: p.Hp <= 0 or non-finite (H not positive definite);
+        // stop == 2: pcg_maxit iterations without reaching pcg_tol (an inexact step is never applied).
+        if (S.stop == 3) {
+          c->err = "PCG breakdown in GN iteration " + std::to_string(it) + " (Hessian not positive definite";
+          if (c->amg && amg_coarsest_not_spd(c->amg, c->stream)) c->err += "; its coarsest Galerkin operator has a non-positive pivot";
+          c->err += ")";
+        } else {
+          c->err = "PCG did not reach pcg_tol within pcg_maxit = " + std::to_string(c->opts.pcg_maxit) +
+                   " iterations in GN iteration " + std::to_string(it) + " (relative residual " +
+                   std::to_string(S.bb > 0 ? std::sqrt(S.rr / S.bb) : 0.0) + "); the step was not applied";
+        }
+        failed = true;
+        hipEventRecord(ev[3 * it + 2], c->stream);
+        break;
+      }
+      {
+        Scope sc(c, K_POSE_UPDATE, 72.0 * c->n);
+        launch_pose_update(c->stream, c->n, c->d_free_id, c->d_x, c->d_poses);
+      }
       hipEventRecord(ev[3 * it + 2], c->stream);
-      break;
+      c->linearized = false;
+      ++done;
+      if (c->opts.verbose)
+        std::fprintf(stderr, "[sgo] iteration= %d\t pcg= %d\t relres= %.3e\t |b|= %.3e\n", it, S.iter,
+                     S.bb > 0 ? std::sqrt(S.rr / S.bb) : 0.0, std::sqrt(S.bb));
     }
-    {
-      Scope sc(c, K_POSE_UPDATE, 72.0 * c->n);
-      launch_pose_update(c->stream, c->n, c->d_free_id, c->d_x, c->d_poses);
+    c->pcg_softcap = 0;
+    if ((rc = do_chi2(c, c->d_hist + 2 * done, nullptr))) {
+      return rc;
     }
-    hipEventRecord(ev[3 * it + 2], c->stream);
-    c->linearized = false;
-    ++done;
-    if (c->opts.verbose)
-      std::fprintf(stderr, "[sgo] iteration= %d\t pcg= %d\t relres= %.3e\t |b|= %.3e\n", it, S.iter,
-                   S.bb > 0 ? std::sqrt(S.rr / S.bb) : 0.0, std::sqrt(S.bb));
-  }
-  c->pcg_softcap = 0;
-  if ((rc = do_chi2(c, c->d_hist + 2 * done, nullptr))) {
-    return rc;
-  }
-  HIP_TRY(c, hipMemcpyAsync(c->h_hist, c->d_hist, sizeof(double) * 2 * (size_t)(done + 1), hipMemcpyDeviceToHost,
-                            c->stream));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
-  prof_flush(c);
-  if (out) {
-    out->iters_done = done;
-    for (int k = 0; k <= done; ++k) {
-      out->chi2[k] = c->h_hist[2 * k];
-      out->robust_chi2[k] = c->h_hist[2 * k + 1];
+    HIP_TRY(c, hipMemcpyAsync(c->h_hist, c->d_hist, sizeof(double) * 2 * (size_t)(done + 1), hipMemcpyDeviceToHost,
+                              c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    prof_flush(c);
+    if (out) {
+      out->iters_done = done;
+      for (int k = 0; k <= done; ++k) {
+        out->chi2[k] = c->h_hist[2 * k];
+        out->robust_chi2[k] = c->h_hist[2 * k + 1];
+      }
+      const int timed = std::min(iters, done + 1);
+      for (int k = 0; k < timed; ++k) {
+        float a = 0.f, b = 0.f;
+        hipEventElapsedTime(&a, ev[3 * k], ev[3 * k + 1]);
+        hipEventElapsedTime(&b, ev[3 * k + 1], ev[3 * k + 2]);
+        out->seconds_linearize[k] = a * 1e-3;
+        out->seconds_solve[k] = b * 1e-3;
+        out->seconds[k] = (a + b) * 1e-3;
+      }
+      out->seconds_total = wall_s() - t0;
     }
-    const int timed = std::min(iters, done + 1);
-    for (int k = 0; k < timed; ++k) {
-      float a = 0.f, b = 0.f;
-      hipEventElapsedTime(&a, ev[3 * k], ev[3 * k + 1]);
-      hipEventElapsedTime(&b, ev[3 * k + 1], ev[3 * k + 2]);
-      out->seconds_linearize[k] = a * 1e-3;
-      out->seconds_solve[k] = b * 1e-3;
-      out->seconds[k] = (a + b) * 1e-3;
-    }
-    out->seconds_total = wall_s() - t0;
-  }
-  return failed ? 0 : done;   // g2o: optimize() returns 0 when the algorithm reported Fail
+    return failed ? 0 : done;   // g2o: optimize() returns 0 when the algorithm reported Fail
+  } SGO_CATCH(c)
 }
 
 // Micro-benchmark of the level-0 product on the resident graph: `reps` back-to-back launches of
@@ -1650,15 +1689,17 @@ double sgo_debug_spmv0_us(sgo_ctx* c, int mode, int variant, int reps) {
 }
 
 int sgo_kernel_profile(sgo_ctx* c, sgo_kernel_stat* out, int cap) {
-  if (!c || (cap > 0 && !out)) return SGO_EINVAL;
-  prof_flush(c);
-  for (int k = 0; k < K_COUNT && k < cap; ++k) {
-    out[k].name = kKernelNames[k];
-    out[k].launches = c->prof_launches[k];
-    out[k].ms = c->prof_ms[k];
-    out[k].bytes = c->prof_bytes[k];
-  }
-  return K_COUNT;
+  try {
+    if (!c || (cap > 0 && !out)) return SGO_EINVAL;
+    prof_flush(c);
+    for (int k = 0; k < K_COUNT && k < cap; ++k) {
+      out[k].name = kKernelNames[k];
+      out[k].launches = c->prof_launches[k];
+      out[k].ms = c->prof_ms[k];
+      out[k].bytes = c->prof_bytes[k];
+    }
+    return K_COUNT;
+  } SGO_CATCH(c)
 }
 
 double sgo_profile_overhead_ms(sgo_ctx* c) {
@@ -1668,14 +1709,16 @@ double sgo_profile_overhead_ms(sgo_ctx* c) {
 }
 
 int sgo_profile_reset(sgo_ctx* c) {
-  if (!c) return SGO_EINVAL;
-  prof_flush(c);
-  for (int k = 0; k < K_COUNT; ++k) {
-    c->prof_ms[k] = 0;
-    c->prof_launches[k] = 0;
-    c->prof_bytes[k] = 0;
-  }
-  return SGO_OK;
+  try {
+    if (!c) return SGO_EINVAL;
+    prof_flush(c);
+    for (int k = 0; k < K_COUNT; ++k) {
+      c->prof_ms[k] = 0;
+      c->prof_launches[k] = 0;
+      c->prof_bytes[k] = 0;
+    }
+    return SGO_OK;
+  } SGO_CATCH(c)
 }
 
 int sgo_comm_unique_id(void* id_out) {
@@ -1684,13 +1727,15 @@ int sgo_comm_unique_id(void* id_out) {
 }
 
 int sgo_comm_init(sgo_ctx* c, int nranks, int rank, const void* unique_id) {
-  if (!c || nranks < 1 || rank < 0 || rank >= nranks || !unique_id) return SGO_EINVAL;
-  hipSetDevice(c->device);
-  if (c->has_graph) {
-    c->err = "sgo_comm_init must precede sgo_set_graph_se2";
-    return SGO_EINVAL;
-  }
-  return c->comm.init(nranks, rank, unique_id, &c->err) ? SGO_OK : SGO_ECOMM;
+  try {
+    if (!c || nranks < 1 || rank < 0 || rank >= nranks || !unique_id) return SGO_EINVAL;
+    hipSetDevice(c->device);
+    if (c->has_graph) {
+      c->err = "sgo_comm_init must precede sgo_set_graph_se2";
+      return SGO_EINVAL;
+    }
+    return c->comm.init(nranks, rank, unique_id, &c->err) ? SGO_OK : SGO_ECOMM;
+  } SGO_CATCH(c)
 }
 
 int sgo_comm_size(sgo_ctx* c) { return c ? c->comm.nranks : SGO_EINVAL; }
