@@ -45,6 +45,11 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <deque>
+#include <fstream>
+#include <iomanip>
+#include <sstream>
+#include <string>
 #include <iostream>
 #include <limits>
 #include <map>
@@ -472,8 +477,27 @@ class EdgeSE2 : public BaseBinaryEdge<3, SE2, VertexSE2, VertexSE2> {
     _jacobianOplusXi = z * a;
     _jacobianOplusXj = z * b;
   }
-  bool read(std::istream&) override { return true; }
-  bool write(std::ostream& os) const override { return os.good(); }
+  // g2o text format of EDGE_SE2 (after the tag and the two vertex ids): dx dy dtheta, then the upper triangle
+  // of the information matrix row by row (o11 o12 o13 o22 o23 o33)
+  bool read(std::istream& is) override {
+    double x, y, t;
+    is >> x >> y >> t;
+    setMeasurement(SE2(x, y, t));
+    for (int i = 0; i < 3; ++i)
+      for (int j = i; j < 3; ++j) {
+        double v;
+        is >> v;
+        _information(i, j) = v;
+        if (i != j) _information(j, i) = v;
+      }
+    return !is.fail();
+  }
+  bool write(std::ostream& os) const override {
+    os << _measurement[0] << " " << _measurement[1] << " " << _measurement[2];
+    for (int i = 0; i < 3; ++i)
+      for (int j = i; j < 3; ++j) os << " " << _information(i, j);
+    return os.good();
+  }
 
  protected:
   SE2 _inverseMeasurement;
@@ -705,6 +729,85 @@ class SparseOptimizer : public OptimizableGraph {
     downloadEstimates();
     return done;
   }
+  // ---- graph files (OptimizableGraph::load / save of g2o, for the types of this backend's device path):
+  //   VERTEX_SE2 id x y theta | EDGE_SE2 i j dx dy dtheta o11 o12 o13 o22 o23 o33 | FIX id...
+  // load() creates the objects and keeps them alive for the optimiser's lifetime (everything the CALLER adds
+  // stays caller-owned, README.md:22-23); records of other types are skipped with a note on std::cerr, as
+  // upstream does for unregistered tags.  save() writes the vertices in ascending id, FIX lines, then the edges
+  // in insertion order, with max_digits10 precision (a load / save / load round trip is exact).
+  bool load(std::istream& is) {
+    std::string line;
+    int skipped = 0;
+    while (std::getline(is, line)) {
+      std::istringstream ls(line);
+      std::string tag;
+      if (!(ls >> tag) || tag[0] == '#') continue;
+      if (tag == "VERTEX_SE2") {
+        int id;
+        if (!(ls >> id)) return false;
+        _loadedVertices.emplace_back();
+        VertexSE2& v = _loadedVertices.back();
+        v.setId(id);
+        if (!v.read(ls) || ls.fail() || !addVertex(&v)) return false;
+      } else if (tag == "EDGE_SE2") {
+        int i, j;
+        if (!(ls >> i >> j)) return false;
+        auto* vi = vertex(i);
+        auto* vj = vertex(j);
+        if (!vi || !vj) {
+          std::cerr << "SparseOptimizer::load: EDGE_SE2 " << i << " " << j << " references an unknown vertex" << std::endl;
+          return false;
+        }
+        _loadedEdges.emplace_back();
+        EdgeSE2& e = _loadedEdges.back();
+        e.vertices()[0] = vi;
+        e.vertices()[1] = vj;
+        if (!e.read(ls) || !addEdge(&e)) return false;
+      } else if (tag == "FIX") {
+        int id;
+        while (ls >> id)
+          if (auto* v = vertex(id)) v->setFixed(true);
+      } else {
+        ++skipped;
+      }
+    }
+    if (skipped) std::cerr << "SparseOptimizer::load: skipped " << skipped << " records of types this backend does not read" << std::endl;
+    return true;
+  }
+  bool load(const char* filename) {
+    std::ifstream f(filename);
+    return f.good() && load(f);
+  }
+  bool save(std::ostream& os, int level = 0) const {
+    (void)level;
+    os << std::setprecision(17);
+    std::vector<const OptimizableGraph::Vertex*> vs;
+    for (auto& kv : _vertices) vs.push_back(static_cast<const OptimizableGraph::Vertex*>(kv.second));
+    std::sort(vs.begin(), vs.end(), [](const OptimizableGraph::Vertex* a, const OptimizableGraph::Vertex* b) { return a->id() < b->id(); });
+    for (auto* v : vs) {
+      if (typeid(*v) != typeid(VertexSE2)) continue;
+      os << "VERTEX_SE2 " << v->id() << " ";
+      static_cast<const VertexSE2*>(v)->write(os);
+      os << "\n";
+    }
+    for (auto* v : vs)
+      if (v->fixed()) os << "FIX " << v->id() << "\n";
+    std::vector<const HyperGraph::Edge*> es(_edges.begin(), _edges.end());
+    std::sort(es.begin(), es.end(), [](const HyperGraph::Edge* a, const HyperGraph::Edge* b) { return a->internalId() < b->internalId(); });
+    for (auto* he : es) {
+      auto* e = static_cast<const OptimizableGraph::Edge*>(he);
+      if (typeid(*e) != typeid(EdgeSE2)) continue;
+      os << "EDGE_SE2 " << e->vertices()[0]->id() << " " << e->vertices()[1]->id() << " ";
+      static_cast<const EdgeSE2*>(e)->write(os);
+      os << "\n";
+    }
+    return os.good();
+  }
+  bool save(const char* filename, int level = 0) const {
+    std::ofstream f(filename);
+    return f.good() && save(f, level);
+  }
+
   const sgo_stats* lastStats() const { return _lastStats.get(); }
   // Levenberg-Marquardt bookkeeping of the last optimize() on the host solver (extension for the tests; g2o
   // exposes the same numbers through OptimizationAlgorithmLevenberg::currentLambda() / levenbergIterations()
@@ -986,6 +1089,17 @@ class SparseOptimizer : public OptimizableGraph {
   uint64_t _deviceGraphHash = 0;
   int _deviceV = 0, _deviceE = 0;
   std::unique_ptr<sgo_stats> _lastStats;
+  std::deque<VertexSE2> _loadedVertices;   // objects created by load(): the optimiser's own
+  std::deque<EdgeSE2> _loadedEdges;
 };
+
+// One line of the CARMEN-style trajectory file the reference writes for the external metricEvaluator
+// (src/sparse_gslam/src/log_runner.cpp:18-23, :258-268; datasets/eval.sh:2-3):
+//   FLASER 0 x y theta x y theta t myhost t
+inline void write_carmen_result_line(std::ostream& os, const SE2& estimate, double time) {
+  const double x = estimate[0], y = estimate[1], theta = estimate[2];
+  os << "FLASER 0 " << x << ' ' << y << ' ' << theta << ' ' << x << ' ' << y << ' ' << theta << ' ' << time << " myhost " << time
+     << '\n';
+}
 
 }  // namespace g2o

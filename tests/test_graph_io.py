@@ -36,3 +36,61 @@ def test_carmen_result_round_trip(tmp_path):
     assert first == "FLASER 0 1.5 -2.25 0.5 1.5 -2.25 0.5 0.5 myhost 0.5"
     Q, S = graph_io.read_carmen_result(str(p))
     assert np.allclose(Q, P) and np.allclose(S, T)
+
+
+# ---------------------------------------------------------------- the C++ side (compat header)
+import os  # noqa: E402
+import subprocess  # noqa: E402
+
+import pytest  # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CPP = os.path.join(ROOT, "tests", "cpp")
+
+
+def test_cpp_load_save_round_trip_is_exact(tmp_path):
+    """SparseOptimizer::load / save and EdgeSE2::read / write of the compat header (the reference's own
+    read / write members are stubs, src/sparse_gslam/src/g2o_bindings/edge_se2_rhotheta.cpp:18-23): a file
+    written by the Python writer is loaded and saved by the C++ side and read back value for value, ids and
+    FIX records included; unknown record types are skipped.  No GPU involved."""
+    g = synth.manhattan(80, 150, seed=5, info_mode="full")
+    g.fixed[7] = True
+    a, b = tmp_path / "a.g2o", tmp_path / "b.g2o"
+    graph_io.write_g2o(str(a), g)
+    with open(a, "a") as f:
+        f.write("VERTEX_XY 900 1.0 2.0\n# a comment\n")
+    subprocess.check_call(["make", "-s", "-C", CPP, "graph_io"])
+    out = subprocess.run([os.path.join(CPP, "graph_io"), str(a), str(b)], capture_output=True, text=True, check=True)
+    V, E, nfixed = map(int, out.stdout.split())
+    assert (V, E, nfixed) == (g.V, g.E, int(g.fixed.sum()))
+    assert "skipped 1 records" in out.stderr
+    h = graph_io.read_g2o(str(b), loop_phi=1.0, fix_first=False)
+    for x, y in zip(g.arrays(), h.arrays()):
+        assert np.array_equal(np.asarray(x), np.asarray(y))
+
+
+@pytest.mark.gpu
+def test_cpp_loaded_graph_optimises_like_the_c_abi(tmp_path):
+    """A .g2o file through the compat header's load + initializeOptimization + optimize(20) on the GPU equals
+    the same graph through the C-ABI; the CARMEN result file has the reference's line format."""
+    from sparse_gslam_amd import capi
+    g = synth.manhattan(1500, 4000, seed=9, info_mode="full", phi=1.0)
+    a, b, r = tmp_path / "a.g2o", tmp_path / "b.g2o", tmp_path / "t.result"
+    graph_io.write_g2o(str(a), g)
+    subprocess.check_call(["make", "-s", "-C", CPP, "graph_io"])
+    out = subprocess.run([os.path.join(CPP, "graph_io"), str(a), str(b), "optimize", str(r)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    lines = out.stdout.splitlines()
+    its, chi2, rchi2 = lines[1].split()
+    gg = graph_io.read_g2o(str(a), loop_phi=1.0)
+    with capi.Optimizer(0) as o:
+        o.set_graph(*gg.arrays())
+        done, st = o.optimize(20)
+        P = o.get_poses()
+    assert int(its) == done == 20
+    assert abs(float(chi2) - st["chi2"][-1]) <= 1e-9 * st["chi2"][-1]
+    assert abs(float(rchi2) - st["robust_chi2"][-1]) <= 1e-9 * st["robust_chi2"][-1]
+    Q, T = graph_io.read_carmen_result(str(r))
+    assert Q.shape == P.shape and np.abs(Q - P).max() <= 1e-5 and T[1] == 1.0   # 6 significant digits in the file
+    saved = graph_io.read_g2o(str(b), loop_phi=1.0)
+    assert np.abs(saved.poses - P).max() <= 1e-12
