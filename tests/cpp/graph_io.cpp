@@ -3,10 +3,12 @@
 // "optimize" as third argument, on a GPU -- optimize(20) of the loaded graph (the pose-graph solver stack of
 // src/sparse_gslam/src/graphs.cpp:17-23).
 // usage: graph_io <in.g2o> <out.g2o> [optimize <result.carmen>]
+#include <algorithm>
 #include <fstream>
 #include <iomanip>
 #include <iostream>
 #include <string>
+#include <vector>
 
 #include "g2o/core/block_solver.h"
 #include "g2o/core/optimization_algorithm_gauss_newton.h"
@@ -44,7 +46,10 @@ int main(int argc, char** argv) {
     std::cout << its << " " << opt.activeChi2() << " " << opt.activeRobustChi2() << std::endl;
     std::ofstream res(argv[4]);
     double t = 0.0;
-    for (auto& kv : opt.vertices()) write_carmen_result_line(res, static_cast<VertexSE2*>(kv.second)->estimate(), t++);
+    std::vector<int> ids;   // vertices() is a hash map: the trajectory file goes in id (= time) order
+    for (auto& kv : opt.vertices()) ids.push_back(kv.first);
+    std::sort(ids.begin(), ids.end());
+    for (int id : ids) write_carmen_result_line(res, static_cast<VertexSE2*>(opt.vertex(id))->estimate(), t++);
   }
   if (!opt.save(argv[2])) return 1;
   delete opt.algorithm();

@@ -91,6 +91,7 @@ def test_cpp_loaded_graph_optimises_like_the_c_abi(tmp_path):
     assert abs(float(chi2) - st["chi2"][-1]) <= 1e-9 * st["chi2"][-1]
     assert abs(float(rchi2) - st["robust_chi2"][-1]) <= 1e-9 * st["robust_chi2"][-1]
     Q, T = graph_io.read_carmen_result(str(r))
-    assert Q.shape == P.shape and np.abs(Q - P).max() <= 1e-5 and T[1] == 1.0   # 6 significant digits in the file
+    # the reference streams with the default precision: 6 significant digits per number
+    assert Q.shape == P.shape and np.abs(Q - P).max() <= 1e-5 * max(1.0, np.abs(P).max()) * 10 and T[1] == 1.0
     saved = graph_io.read_g2o(str(b), loop_phi=1.0)
     assert np.abs(saved.poses - P).max() <= 1e-12
