@@ -98,18 +98,42 @@ __device__ __forceinline__ void block_reduce_parts_n(const double* const (&parts
 
 // Inclusive segmented scan over the wave: lanes with equal `row` that are contiguous form a
 // segment; after the scan the LAST lane of a segment holds the segment sum.
-template <int N>
-__device__ __forceinline__ void seg_scan(int row, double (&v)[N], int lane) {
+//
+// Cross-lane traffic goes through DPP moves on the vector ALU, not through ds_bpermute: the LDS crossbar
+// is what the tile kernel's staging and the 40-odd permutes of a shuffle-based scan would otherwise
+// share (measured: SQ_WAIT_INST_LDS 18 % of the wave cycles of k_spmv0t with __shfl_up).  Steps 1, 2, 4, 8
+// stay inside a row of 16 lanes (row_shr); the carries into rows 1 / 3 and then 2 / 3 come from lane 15 / 47
+// and lane 31 (row_bcast15 / row_bcast31).  The two carry steps rely on what every caller guarantees:
+// the keys of the ACTIVE lanes are non-decreasing along the wave (slots sorted by target), so a lane whose
+// key equals that of the last lane of the previous row(s) belongs to a segment that spans everything in
+// between.  Inactive lanes carry unique negative keys and never match.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_int(int old, int v) {
+  return __builtin_amdgcn_update_dpp(old, v, CTRL, ROW_MASK, 0xF, false);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_double(double v) {
+  const int lo = dpp_int<CTRL, ROW_MASK>(0, __double2loint(v)), hi = dpp_int<CTRL, ROW_MASK>(0, __double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+template <int N, int CTRL, int ROW_MASK>
+__device__ __forceinline__ void seg_scan_step(int row, double (&v)[N]) {
+  constexpr int kNoKey = (int)0x80000000;   // lanes without a source lane see a key no lane has
+  const bool take = dpp_int<CTRL, ROW_MASK>(kNoKey, row) == row;
 #pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const int r2 = __shfl_up(row, off);
-    const bool take = (lane >= off) && (r2 == row);
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-      const double u = __shfl_up(v[i], off);
-      if (take) v[i] += u;
-    }
+  for (int i = 0; i < N; ++i) {
+    const double u = dpp_double<CTRL, ROW_MASK>(v[i]);
+    if (take) v[i] += u;
   }
+}
+template <int N>
+__device__ __forceinline__ void seg_scan(int row, double (&v)[N], int /*lane*/) {
+  seg_scan_step<N, 0x111, 0xF>(row, v);   // row_shr:1
+  seg_scan_step<N, 0x112, 0xF>(row, v);   // row_shr:2
+  seg_scan_step<N, 0x114, 0xF>(row, v);   // row_shr:4
+  seg_scan_step<N, 0x118, 0xF>(row, v);   // row_shr:8
+  seg_scan_step<N, 0x142, 0xA>(row, v);   // row_bcast15 into rows 1 and 3
+  seg_scan_step<N, 0x143, 0xC>(row, v);   // row_bcast31 into rows 2 and 3
 }
 
 // Row-major 3x3 block of LOGICAL slot k of a level's operator: from the slot-indexed pair-SoA array on

@@ -518,6 +518,49 @@ __global__ __launch_bounds__(kBlock, 8) void k_spmv0(Sym0Dev A, Spmv0Args a) {
 // exactly one lane, operands come from LDS (the tile's slice + its halo, fetched once per tile), transposed
 // contributions of intra-tile pairs travel through LDS staging.  Modes and epilogues as k_spmv0.  One
 // workgroup works on one tile at a time; workgroups of XCD x walk the x-th contiguous eighth of the tiles.
+// one wave's loads for the first 64 slots of a phase-1 group, issued a whole group ahead of their use
+struct TileGroupLoad {
+  int gb, ge, r0;
+  bool valid;
+  unsigned cw;
+  int off;
+  double2 p0, p1, p2, p3;
+  double b8;
+};
+__device__ __forceinline__ void tile_group_load(const Sym0Dev& A, const Tile0Dev& TL, const double2* __restrict__ bp, size_t nu,
+                                                int g, int lane, TileGroupLoad& L) {
+  L.gb = TL.grp1[g];
+  L.ge = TL.grp1[g + 1];
+  L.r0 = TL.grow1[g];
+  const int k = L.gb + lane;
+  L.valid = k < L.ge;
+  if (L.valid) {
+    L.cw = TL.cv[k];
+    L.off = TL.off1[k];
+    L.p0 = bp[k]; L.p1 = bp[nu + k]; L.p2 = bp[2 * nu + k]; L.p3 = bp[3 * nu + k];
+    L.b8 = A.ublk[8 * nu + k];
+  }
+}
+// u = B x_col into acc, v = B^T x_row to the twin's staging slot
+__device__ __forceinline__ void tile_slot(const double* __restrict__ xs, double* __restrict__ vst, int rowl, unsigned cw,
+                                          const double2& p0, const double2& p1, const double2& p2, const double2& p3, double b8,
+                                          double (&acc)[3]) {
+  const double* xc = xs + 3 * (cw & 0xFFFFu);
+  const double x0 = xc[0], x1 = xc[1], x2 = xc[2];
+  acc[0] += p0.x * x0 + p0.y * x1 + p1.x * x2;
+  acc[1] += p1.y * x0 + p2.x * x1 + p2.y * x2;
+  acc[2] += p3.x * x0 + p3.y * x1 + b8 * x2;
+  const unsigned vp = cw >> 16;
+  if (vp != 0xFFFFu) {   // the twin row is in this tile: hand it B^T x_row through LDS
+    const double* xr = xs + 3 * rowl;
+    const double s0 = xr[0], s1 = xr[1], s2 = xr[2];
+    double* v = vst + 3 * vp;
+    v[0] = p0.x * s0 + p1.y * s1 + p3.x * s2;
+    v[1] = p0.y * s0 + p2.x * s1 + p3.y * s2;
+    v[2] = p1.x * s0 + p2.y * s1 + b8 * s2;
+  }
+}
+
 template <int MODE, int kTileThreads>
 __global__ __launch_bounds__(kTileThreads) void k_spmv0t(Sym0Dev A, Tile0Dev TL, Spmv0Args a) {
   if (a.S && a.S->stop) return;
@@ -536,6 +579,22 @@ __global__ __launch_bounds__(kTileThreads) void k_spmv0t(Sym0Dev A, Tile0Dev TL,
     double* xs = lds;                    // [nr + nh][3] operand: the tile's rows, then its halo columns
     double* ys = xs + 3 * (nr + nh);     // [nr][3] owned part of the row sums
     double* vst = ys + 3 * nr;           // [nstaged][3]
+    // ---- the loads that do not depend on LDS go out first: this wave's first phase-1 group, and (threads that own
+    // a row in phase 2) the row's staged range and diagonal block; they are in flight while phase 0 fills the LDS
+    int g = T.g0 + wave;
+    bool has = g < T.g1;
+    TileGroupLoad cur;
+    cur.valid = false;
+    if (has) tile_group_load(A, TL, bp, nu, g, lane, cur);
+    int e0 = 0, e1 = 0;
+    double dd0 = 0, dd1 = 0, dd2 = 0, dd3 = 0, dd4 = 0, dd5 = 0;
+    if (tid < nr) {
+      const int r = T.row0 + tid;
+      e0 = TL.trowptr[r] - T.e0;
+      e1 = TL.trowptr[r + 1] - T.e0;
+      const double* dd = A.dblk + 6 * (size_t)r;
+      dd0 = dd[0]; dd1 = dd[1]; dd2 = dd[2]; dd3 = dd[3]; dd4 = dd[4]; dd5 = dd[5];
+    }
     // ---- phase 0: operand slice and halo to LDS, owned sums cleared
     for (int i = tid; i < 3 * nr; i += kTileThreads) {
       xs[i] = a.x[3 * (size_t)T.row0 + i];
@@ -548,30 +607,26 @@ __global__ __launch_bounds__(kTileThreads) void k_spmv0t(Sym0Dev A, Tile0Dev TL,
       d[0] = h0; d[1] = h1; d[2] = h2;
     }
     __syncthreads();
-    // ---- phase 1: one lane per stored block; groups hold whole rows
-    for (int g = T.g0 + wave; g < T.g1; g += NW) {
-      const int gb = TL.grp1[g], ge = TL.grp1[g + 1], r0 = TL.grow1[g];
+    // ---- phase 1: one lane per stored block; groups hold whole rows; the next group's loads are issued before
+    // the current one is worked on
+    while (has) {
+      const int gn = g + NW;
+      const bool hasn = gn < T.g1;
+      TileGroupLoad nxt;
+      nxt.valid = false;
+      if (hasn) tile_group_load(A, TL, bp, nu, gn, lane, nxt);
       double acc[3] = {0.0, 0.0, 0.0};
       int row = -1 - lane;
-      for (int k = gb + lane; k < ge; k += 64) {
+      if (cur.valid) {
+        row = cur.r0 + cur.off;
+        tile_slot(xs, vst, row - T.row0, cur.cw, cur.p0, cur.p1, cur.p2, cur.p3, cur.b8, acc);
+      }
+      for (int k = cur.gb + 64 + lane; k < cur.ge; k += 64) {   // a row longer than one wave
         const unsigned cw = TL.cv[k];
-        row = r0 + TL.off1[k];
+        row = cur.r0 + TL.off1[k];
         const double2 p0 = bp[k], p1 = bp[nu + k], p2 = bp[2 * nu + k], p3 = bp[3 * nu + k];
         const double b8 = A.ublk[8 * nu + k];
-        const double* xc = xs + 3 * (cw & 0xFFFFu);
-        const double x0 = xc[0], x1 = xc[1], x2 = xc[2];
-        acc[0] += p0.x * x0 + p0.y * x1 + p1.x * x2;
-        acc[1] += p1.y * x0 + p2.x * x1 + p2.y * x2;
-        acc[2] += p3.x * x0 + p3.y * x1 + b8 * x2;
-        const unsigned vp = cw >> 16;
-        if (vp != 0xFFFFu) {   // the twin row is in this tile: hand it B^T x_row through LDS
-          const double* xr = xs + 3 * (row - T.row0);
-          const double s0 = xr[0], s1 = xr[1], s2 = xr[2];
-          double* v = vst + 3 * vp;
-          v[0] = p0.x * s0 + p1.y * s1 + p3.x * s2;
-          v[1] = p0.y * s0 + p2.x * s1 + p3.y * s2;
-          v[2] = p1.x * s0 + p2.y * s1 + b8 * s2;
-        }
+        tile_slot(xs, vst, row - T.row0, cw, p0, p1, p2, p3, b8, acc);
       }
       seg_scan<3>(row, acc, lane);
       const int rn = __shfl_down(row, 1);
@@ -579,21 +634,28 @@ __global__ __launch_bounds__(kTileThreads) void k_spmv0t(Sym0Dev A, Tile0Dev TL,
         double* d = ys + 3 * (row - T.row0);
         d[0] = acc[0]; d[1] = acc[1]; d[2] = acc[2];
       }
+      cur = nxt;
+      g = gn;
+      has = hasn;
     }
     __syncthreads();
     // ---- phase 2: one thread per row: staged entries in order, owned part, diagonal block, epilogue
     for (int i = tid; i < nr; i += kTileThreads) {
       const int r = T.row0 + i;
-      const int e0 = TL.trowptr[r] - T.e0, e1 = TL.trowptr[r + 1] - T.e0;
+      if (i >= kTileThreads) {   // tiles of more rows than threads (rare): the later rows load here
+        e0 = TL.trowptr[r] - T.e0;
+        e1 = TL.trowptr[r + 1] - T.e0;
+        const double* dd = A.dblk + 6 * (size_t)r;
+        dd0 = dd[0]; dd1 = dd[1]; dd2 = dd[2]; dd3 = dd[3]; dd4 = dd[4]; dd5 = dd[5];
+      }
       const double s0 = xs[3 * i], s1 = xs[3 * i + 1], s2 = xs[3 * i + 2];
-      const double* dd = A.dblk + 6 * (size_t)r;
       double o0 = ys[3 * i], o1 = ys[3 * i + 1], o2 = ys[3 * i + 2];
       for (int e = e0; e < e1; ++e) {
         o0 += vst[3 * e]; o1 += vst[3 * e + 1]; o2 += vst[3 * e + 2];
       }
-      o0 += dd[0] * s0 + dd[1] * s1 + dd[2] * s2;
-      o1 += dd[1] * s0 + dd[3] * s1 + dd[4] * s2;
-      o2 += dd[2] * s0 + dd[4] * s1 + dd[5] * s2;
+      o0 += dd0 * s0 + dd1 * s1 + dd2 * s2;
+      o1 += dd1 * s0 + dd3 * s1 + dd4 * s2;
+      o2 += dd2 * s0 + dd4 * s1 + dd5 * s2;
       const size_t o = 3 * (size_t)r;
       if (MODE != S0_AX) {
         const double t0 = a.b[o] - o0, t1 = a.b[o + 1] - o1, t2 = a.b[o + 2] - o2;
