@@ -158,7 +158,7 @@ struct PDev {
   int* row = nullptr;        // [np]
   int* col = nullptr;        // [np]
   double* blk = nullptr;     // [np][9]: the copy the block products GATHER from (one 72-byte record each)
-  double* r_blk = nullptr;   // [9][np]: the copy the prolongation STREAMS (row order, one array per component,
+  double* r_blk = nullptr;   // pair-SoA [np] (blk_at): the copy the prolongation STREAMS (row order,
                              // non-temporal loads: read once per cycle, must not push the level-0 matrix out of the MALL)
   int* r_grp = nullptr;      // wave groups over the entries aligned to fine rows (prolongation)
   int r_ngrp = 0;
@@ -168,7 +168,7 @@ struct PDev {
   int* t_pos = nullptr;      // [np] position of entry e in column order
   int* t_row = nullptr;      // [np] fine row at position t
   int* t_col = nullptr;      // [np] coarse column at position t
-  double* t_blk = nullptr;   // [9][np]: column order, streamed by the restriction (non-temporal loads)
+  double* t_blk = nullptr;   // pair-SoA [np]: column order, streamed by the restriction (non-temporal loads)
   int* t_grp = nullptr;      // wave groups over the positions aligned to columns
   int t_ngrp = 0;
   int nap = 0;               // blocks of AP
@@ -177,6 +177,16 @@ struct PDev {
   ProdMap rap;               // a = P entry (i, a), b = AP entry (i, c), tgt = coarse slot (a, c)
 };
 
+// block e of a pair-SoA array (blk_at) that is read once per cycle: four 16-byte and one 8-byte non-temporal
+// loads per lane (the stream must not push the level-0 matrix out of the Infinity Cache)
+typedef double sgo_d2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void load9_stream(const double* __restrict__ base, size_t e, size_t n, double (&v)[9]) {
+  const sgo_d2* __restrict__ bp = reinterpret_cast<const sgo_d2*>(base);
+  const sgo_d2 p0 = __builtin_nontemporal_load(bp + e), p1 = __builtin_nontemporal_load(bp + n + e);
+  const sgo_d2 p2 = __builtin_nontemporal_load(bp + 2 * n + e), p3 = __builtin_nontemporal_load(bp + 3 * n + e);
+  v[0] = p0.x; v[1] = p0.y; v[2] = p1.x; v[3] = p1.y; v[4] = p2.x; v[5] = p2.y; v[6] = p3.x; v[7] = p3.y;
+  v[8] = __builtin_nontemporal_load(base + 8 * n + e);
+}
 __device__ __forceinline__ void load9(const double* __restrict__ base, size_t e, double (&v)[9]) {
 #pragma unroll
   for (int c = 0; c < 9; ++c) v[c] = base[9 * e + c];
@@ -224,8 +234,8 @@ __global__ __launch_bounds__(kBlock) void k_p_values(BsrDev F, PDev P, const int
 #pragma unroll
       for (int c = 0; c < 9; ++c) {
         P.blk[9 * (size_t)key + c] = o[c];
-        P.r_blk[c * np + key] = o[c];
-        P.t_blk[c * np + tp] = o[c];
+        P.r_blk[blk_at(c, key, np)] = o[c];
+        P.t_blk[blk_at(c, tp, np)] = o[c];
       }
     }
   }
@@ -289,8 +299,7 @@ __global__ __launch_bounds__(kBlock) void k_restrict_p(PDev P, const double* __r
       const size_t i = (size_t)P.t_row[t];
       const double r0 = r[3 * i], r1 = r[3 * i + 1], r2 = r[3 * i + 2];
       double b[9];
-#pragma unroll
-      for (int c = 0; c < 9; ++c) b[c] = __builtin_nontemporal_load(P.t_blk + c * np + t);
+      load9_stream(P.t_blk, (size_t)t, np, b);
       acc[0] += b[0] * r0 + b[3] * r1 + b[6] * r2;
       acc[1] += b[1] * r0 + b[4] * r1 + b[7] * r2;
       acc[2] += b[2] * r0 + b[5] * r1 + b[8] * r2;
@@ -338,8 +347,7 @@ __global__ __launch_bounds__(kBlock) void k_prolong_p(int n, PDev P, const doubl
         w0 += c2 * u2[a]; w1 += c2 * u2[a + 1]; w2 += c2 * u2[a + 2];
       }
       double b[9];
-#pragma unroll
-      for (int c = 0; c < 9; ++c) b[c] = __builtin_nontemporal_load(P.r_blk + c * np + e);
+      load9_stream(P.r_blk, (size_t)e, np, b);
       acc[0] += b[0] * w0 + b[1] * w1 + b[2] * w2;
       acc[1] += b[3] * w0 + b[4] * w1 + b[5] * w2;
       acc[2] += b[6] * w0 + b[7] * w1 + b[8] * w2;
