@@ -31,6 +31,7 @@ struct AmgProf {
 };
 
 struct ChunkArena;
+struct DevArena;   // device memory of the hierarchy: owned by the caller, rewound by it after amg_destroy
 struct Amg;  // opaque
 
 // logical structure of a level's operator on the host (slot list sorted by row, diagonal slot first)
@@ -50,7 +51,7 @@ struct HostLevel {
 // lists; it is rewound here and may be rewound again by the caller once amg_create has returned.
 Amg* amg_create(hipStream_t s, const BsrDev& A0, const Sym0Dev& S0, const Tile0Dev& T0, const HostLevel& H0, const double* d_poses,
                 const int* d_free_id, const AmgConfig& cfg, const AmgProf& prof, std::string* err,
-                ChunkArena* scratch = nullptr);
+                ChunkArena* scratch, DevArena* arena);
 void amg_destroy(Amg* m);
 // Recompute the coarse operators for the current level-0 values and poses (once per GN iteration).
 int amg_update(Amg* m, hipStream_t s, std::string* err);

@@ -452,9 +452,22 @@ __global__ __launch_bounds__(kBlock) void k_prolong_add(int n, const int* __rest
 //   P = inv(A_KK);  A_Kj <- P A_Kj (j != K);  A_ij <- A_ij - A_iK A_Kj (i, j != K);
 //   A_iK <- -A_iK P (i != K);  A_KK <- P.
 // The matrix is stored row-major with leading dimension Np = N rounded up to 32 and an identity
-// on the padding, so every tile is full.  4 launches per pivot block.
+// on the padding, so every tile is full.  One launch per pivot block (k_gj_step).
 constexpr int kGjB = 32;
 
+// The coarse levels' slots are unique per (row, col) (the host lists them so): one thread per slot stores its
+// 3x3 block, no accumulation.  M was zeroed by the caller.
+__global__ __launch_bounds__(kBlock) void k_dense_fill_unique(BsrDev A, int Np, double* __restrict__ M) {
+  const int N = 3 * A.n;
+  for (int k = blockIdx.x * kBlock + threadIdx.x; k < A.nslot; k += gridDim.x * kBlock) {
+    const int r = A.row[k], c = A.col[k];
+    double b[9];
+    load_block(A, (size_t)k, b);
+#pragma unroll
+    for (int e = 0; e < 9; ++e) M[(size_t)(3 * r + e / 3) * Np + 3 * c + e % 3] = b[e];
+  }
+  for (int i = N + blockIdx.x * kBlock + threadIdx.x; i < Np; i += gridDim.x * kBlock) M[(size_t)i * Np + i] = 1.0;
+}
 __global__ __launch_bounds__(kBlock) void k_dense_fill(BsrDev A, int Np, double* __restrict__ M) {
   // one thread per block row, slots added in order: level 0 can hold several slots for the same
   // (row, col) -- duplicate edges, and the zero blocks of fixed-column slots that alias the
@@ -477,20 +490,20 @@ __global__ __launch_bounds__(kBlock) void k_dense_fill(BsrDev A, int Np, double*
 // lives in a register, only the pivot row / column travel through LDS; 2 barriers per step)
 __global__ __launch_bounds__(kGjB * kGjB) void k_gj_pivot(double* __restrict__ M, int Np, int kb, double* __restrict__ P,
                                                           int* __restrict__ fail) {
-  __shared__ double a[kGjB][kGjB + 1];
+  __shared__ double a2[2][kGjB][kGjB + 1];   // ping-pong: one barrier per elimination step
   const int i = threadIdx.x / kGjB, j = threadIdx.x % kGjB, base = kb * kGjB;
   double v = M[(size_t)(base + i) * Np + base + j];
-  a[i][j] = v;
+  a2[0][i][j] = v;
   __syncthreads();
   for (int k = 0; k < kGjB; ++k) {
+    double (*a)[kGjB + 1] = a2[k & 1];
     const double akk = a[k][k], akj = a[k][j], aik = a[i][k];
     if (threadIdx.x == 0 && (!(akk > 0.0) || !isfinite(akk))) *fail = 1;
     const double p = (akk != 0.0) ? 1.0 / akk : 0.0;
     if (i == k) v = (j == k) ? p : akj * p;
     else if (j == k) v = -aik * p;
     else v = v - aik * (akj * p);
-    __syncthreads();
-    a[i][j] = v;
+    a2[(k + 1) & 1][i][j] = v;
     __syncthreads();
   }
   P[threadIdx.x] = v;
@@ -508,80 +521,79 @@ __device__ __forceinline__ void tile_mm(const double (*X)[kGjB + 1], const doubl
   }
 }
 
-// One Gauss-Jordan block step K = kb is two launches:
-//   k_gj_panels  row panel A_Kj <- P A_Kj (j != K), A_KK <- P, and column panel A_iK <- -A_iK P
-//                (i != K) with the ORIGINAL A_iK saved to Xs[i] for the trailing update;
-//   k_gj_trail   A_ij <- A_ij - Xs_i A_Kj (i, j != K); the workgroup that finishes the next
-//                diagonal block (K+1, K+1) inverts it in LDS straight away and leaves it in P,
-//                so no separate pivot launch sits on the critical path.
-__global__ __launch_bounds__(kBlock) void k_gj_panels(double* __restrict__ M, int Np, int kb, const double* __restrict__ P,
-                                                      double* __restrict__ Xs) {
+// One Gauss-Jordan block step K = kb is ONE launch over all 32x32 tiles, reading the matrix of the previous
+// step (Min) and writing the next one (Mout) -- ping-pong, so that no tile is read after another workgroup
+// has overwritten it and no panel kernel has to run first:
+//   (K, K)            <- P                       (P = inv(A_KK), made by the previous launch)
+//   (K, j), j != K    <- P A_Kj
+//   (i, K), i != K    <- -A_iK P
+//   (i, j) elsewhere  <- A_ij - A_iK (P A_Kj)    (the row-panel product recomputed per tile: two tile
+//                                                 products instead of one buy half the launches)
+// and the workgroup that finishes the next diagonal block (K+1, K+1) inverts it in LDS straight away and
+// leaves it in Pout.  The 32 elimination steps of that inverse are the critical path of the whole inversion
+// (one sequential 32x32 inverse per block step), so they ping-pong between two LDS tiles: step k reads tile
+// k & 1 and writes the other one, ONE barrier per step.
+__global__ __launch_bounds__(kBlock) void k_gj_step(const double* __restrict__ Min, double* __restrict__ Mout, int Np, int kb,
+                                                    const double* __restrict__ Pin, double* __restrict__ Pout,
+                                                    int* __restrict__ fail) {
   __shared__ double X[kGjB][kGjB + 1], Y[kGjB][kGjB + 1];
-  const int t = threadIdx.x, K0 = kb * kGjB, nb = Np / kGjB;
-  const bool rowp = (int)blockIdx.x < nb;
-  const int b = rowp ? blockIdx.x : blockIdx.x - nb;
-  if (b == kb) {
-    if (rowp)
-      for (int e = t; e < kGjB * kGjB; e += kBlock) M[(size_t)(K0 + e / kGjB) * Np + K0 + e % kGjB] = P[e];
+  const int t = threadIdx.x, K0 = kb * kGjB;
+  const int bj = blockIdx.x, bi = blockIdx.y;
+  const int r = t >> 3, c0 = (t & 7) * 4;
+  double v[4];
+  double* dst = Mout + (size_t)(bi * kGjB + r) * Np + bj * kGjB + c0;
+  if (bi == kb && bj == kb) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) dst[q] = Pin[r * kGjB + c0 + q];
     return;
   }
+  // first product: P A_Kj (row panel and general tiles) or A_iK P (column panel)
   for (int e = t; e < kGjB * kGjB; e += kBlock) {
     const int i = e / kGjB, j = e % kGjB;
-    if (rowp) {
-      X[i][j] = P[e];
-      Y[i][j] = M[(size_t)(K0 + i) * Np + b * kGjB + j];
+    if (bj == kb) {
+      X[i][j] = Min[(size_t)(bi * kGjB + i) * Np + K0 + j];
+      Y[i][j] = Pin[e];
     } else {
-      const double v = M[(size_t)(b * kGjB + i) * Np + K0 + j];
-      X[i][j] = v;
-      Xs[(size_t)b * kGjB * kGjB + e] = v;
-      Y[i][j] = P[e];
+      X[i][j] = Pin[e];
+      Y[i][j] = Min[(size_t)(K0 + i) * Np + bj * kGjB + j];
     }
   }
   __syncthreads();
   double o[4];
   tile_mm(X, Y, o);
-  const int r = t >> 3, c0 = (t & 7) * 4;
-  if (rowp) {
-    double* dst = M + (size_t)(K0 + r) * Np + b * kGjB + c0;
+  if (bi == kb) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) dst[q] = o[q];
-  } else {
-    double* dst = M + (size_t)(b * kGjB + r) * Np + K0 + c0;
+    return;
+  }
+  if (bj == kb) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) dst[q] = -o[q];
+    return;
   }
-}
-
-__global__ __launch_bounds__(kBlock) void k_gj_trail(double* __restrict__ M, int Np, int kb, const double* __restrict__ Xs,
-                                                     double* __restrict__ P, int* __restrict__ fail) {
-  __shared__ double X[kGjB][kGjB + 1], Y[kGjB][kGjB + 1];
-  const int t = threadIdx.x, K0 = kb * kGjB;
-  const int bj = blockIdx.x, bi = blockIdx.y;
-  if (bi == kb || bj == kb) return;
-  for (int e = t; e < kGjB * kGjB; e += kBlock) {
-    const int i = e / kGjB, j = e % kGjB;
-    X[i][j] = Xs[(size_t)bi * kGjB * kGjB + e];
-    Y[i][j] = M[(size_t)(K0 + i) * Np + bj * kGjB + j];
-  }
-  __syncthreads();
-  double o[4];
-  tile_mm(X, Y, o);
-  const int r = t >> 3, c0 = (t & 7) * 4;
-  double* dst = M + (size_t)(bi * kGjB + r) * Np + bj * kGjB + c0;
-  double v[4];
+  // general tile: A_ij - A_iK (P A_Kj)
+  __syncthreads();   // everyone is done reading X / Y
 #pragma unroll
-  for (int q = 0; q < 4; ++q) dst[q] = v[q] = dst[q] - o[q];
+  for (int q = 0; q < 4; ++q) Y[r][c0 + q] = o[q];
+  for (int e = t; e < kGjB * kGjB; e += kBlock) X[e / kGjB][e % kGjB] = Min[(size_t)(bi * kGjB + e / kGjB) * Np + K0 + e % kGjB];
+  __syncthreads();
+  tile_mm(X, Y, o);
+  const double* src = Min + (size_t)(bi * kGjB + r) * Np + bj * kGjB + c0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) dst[q] = v[q] = src[q] - o[q];
   if (bi != kb + 1 || bj != kb + 1) return;
-  // next pivot block: P = inv(A_K'K') by the same scalar Gauss-Jordan as k_gj_pivot
+  // next pivot block: Pout = inv(A_K'K') by scalar Gauss-Jordan
   __syncthreads();
 #pragma unroll
   for (int q = 0; q < 4; ++q) X[r][c0 + q] = v[q];
   __syncthreads();
   for (int k = 0; k < kGjB; ++k) {
-    const double akk = X[k][k], aik = X[r][k];
+    double (*rd)[kGjB + 1] = (k & 1) ? Y : X;
+    double (*wr)[kGjB + 1] = (k & 1) ? X : Y;
+    const double akk = rd[k][k], aik = rd[r][k];
     double akj[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) akj[q] = X[k][c0 + q];
+    for (int q = 0; q < 4; ++q) akj[q] = rd[k][c0 + q];
     if (t == 0 && (!(akk > 0.0) || !isfinite(akk))) *fail = 1;
     const double p = (akk != 0.0) ? 1.0 / akk : 0.0;
 #pragma unroll
@@ -590,14 +602,12 @@ __global__ __launch_bounds__(kBlock) void k_gj_trail(double* __restrict__ M, int
       if (r == k) v[q] = (c == k) ? p : akj[q] * p;
       else if (c == k) v[q] = -aik * p;
       else v[q] = v[q] - aik * (akj[q] * p);
+      wr[r][c0 + q] = v[q];
     }
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < 4; ++q) X[r][c0 + q] = v[q];
     __syncthreads();
   }
 #pragma unroll
-  for (int q = 0; q < 4; ++q) P[r * kGjB + c0 + q] = v[q];
+  for (int q = 0; q < 4; ++q) Pout[r * kGjB + c0 + q] = v[q];
 }
 
 // x = inv * b : one wave per row (inv is symmetric; row reads are coalesced)
@@ -630,14 +640,11 @@ __global__ __launch_bounds__(kBlock) void k_dots2(int n, const double* __restric
 
 // --------------------------------------------------------------------------------- host
 template <class T>
-T* dev_alloc(std::vector<void*>& pool, size_t count) {
-  void* p = nullptr;
-  if (hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T)) != hipSuccess) return nullptr;
-  pool.push_back(p);
-  return (T*)p;
+T* dev_alloc(DevArena* pool, size_t count) {
+  return (T*)pool->take(std::max<size_t>(count, 1) * sizeof(T));
 }
 template <class T>
-T* dev_upload(std::vector<void*>& pool, const std::vector<T>& v, hipStream_t s) {
+T* dev_upload(DevArena* pool, const std::vector<T>& v, hipStream_t s) {
   T* p = dev_alloc<T>(pool, v.size());
   if (p && !v.empty()) hipMemcpyAsync(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s);
   return p;
@@ -759,7 +766,7 @@ struct UVec {
   int* data() { return p; }
   size_t size() const { return n; }
 };
-int* dev_upload(std::vector<void*>& pool, const UVec& v, hipStream_t s) {
+int* dev_upload(DevArena* pool, const UVec& v, hipStream_t s) {
   int* d = dev_alloc<int>(pool, v.n);
   if (d && v.n) hipMemcpyAsync(d, v.p, v.n * sizeof(int), hipMemcpyHostToDevice, s);
   return d;
@@ -1079,7 +1086,7 @@ struct Amg {
   Comm* comm = nullptr;     // multi-GPU: level-0 products over the units [u0, u1) + all-reduce
   int u0 = 0, u1 = 0;
   bool comm_failed = false;
-  std::vector<void*> pool;
+  DevArena* pool = nullptr;   // the caller's arena (not owned)
   std::vector<AmgLevel> lv;
   const double* d_poses = nullptr;
   const int* d_free_id = nullptr;
@@ -1088,8 +1095,9 @@ struct Amg {
   // coarsest dense inverse (row-major, leading dimension Np = N rounded up to 32)
   int N = 0, Np = 0;
   double* inv = nullptr;
-  double* gjP = nullptr;   // [32][32] inverse of the current pivot block
-  double* gjX = nullptr;   // [Np/32][32][32] column panel of the current step before its update
+  double* inv0 = nullptr;  // ping-pong buffers of the block Gauss-Jordan; `inv` is the one the last step writes
+  double* inv1 = nullptr;
+  double* gjP[2] = {nullptr, nullptr};   // [32][32] inverse of the current / next pivot block
   int* d_fail = nullptr;
   std::string desc;
 };
@@ -1356,8 +1364,7 @@ void amg_describe(const Amg* m, std::string* out) { *out = m ? m->desc : ""; }
 
 void amg_destroy(Amg* m) {
   if (!m) return;
-  for (void* p : m->pool) hipFree(p);
-  delete m;
+  delete m;   // the device memory belongs to the caller's arena
 }
 
 int amg_update(Amg* m, hipStream_t s, std::string* err) {
@@ -1384,13 +1391,18 @@ int amg_update(Amg* m, hipStream_t s, std::string* err) {
   {
     Scope sc(m->prof, K_DENSE_INVERT, 8.0 * m->Np * m->Np);
     const int nb = m->Np / kGjB;
-    hipMemsetAsync(m->inv, 0, sizeof(double) * (size_t)m->Np * m->Np, s);
+    hipMemsetAsync(m->inv0, 0, sizeof(double) * (size_t)m->Np * m->Np, s);
     hipMemsetAsync(m->d_fail, 0, sizeof(int), s);
-    SGO_LAUNCH(k_dense_fill, dim3(grid_for(m->lv[last].A.n, kBlock)), dim3(kBlock), 0, s, m->lv[last].A, m->Np, m->inv);
-    SGO_LAUNCH(k_gj_pivot, dim3(1), dim3(kGjB * kGjB), 0, s, m->inv, m->Np, 0, m->gjP, m->d_fail);
-    for (int kb = 0; kb < nb; ++kb) {
-      SGO_LAUNCH(k_gj_panels, dim3(2 * nb), dim3(kBlock), 0, s, m->inv, m->Np, kb, (const double*)m->gjP, m->gjX);
-      SGO_LAUNCH(k_gj_trail, dim3(nb, nb), dim3(kBlock), 0, s, m->inv, m->Np, kb, (const double*)m->gjX, m->gjP, m->d_fail);
+    if (last > 0)
+      SGO_LAUNCH(k_dense_fill_unique, dim3(grid_for(m->lv[last].A.nslot, kBlock)), dim3(kBlock), 0, s, m->lv[last].A, m->Np, m->inv0);
+    else   // level 0 can hold several slots per (row, col): duplicate edges
+      SGO_LAUNCH(k_dense_fill, dim3(grid_for(m->lv[last].A.n, kBlock)), dim3(kBlock), 0, s, m->lv[last].A, m->Np, m->inv0);
+    SGO_LAUNCH(k_gj_pivot, dim3(1), dim3(kGjB * kGjB), 0, s, m->inv0, m->Np, 0, m->gjP[0], m->d_fail);
+    for (int kb = 0; kb < nb; ++kb) {   // the result of step kb lands in buffer (kb + 1) & 1: m->inv after the last one
+      const double* src = (kb & 1) ? m->inv1 : m->inv0;
+      double* dst = (kb & 1) ? m->inv0 : m->inv1;
+      SGO_LAUNCH(k_gj_step, dim3(nb, nb), dim3(kBlock), 0, s, src, dst, m->Np, kb, (const double*)m->gjP[kb & 1],
+                 m->gjP[(kb + 1) & 1], m->d_fail);
     }
   }
   if (hipGetLastError() != hipSuccess) {
@@ -1428,8 +1440,9 @@ int amg_apply(Amg* m, hipStream_t s, const double* r, double* z, const double* d
 
 Amg* amg_create(hipStream_t s, const BsrDev& A0, const Sym0Dev& S0, const Tile0Dev& T0, const HostLevel& H0, const double* d_poses,
                 const int* d_free_id, const AmgConfig& cfg_in, const AmgProf& prof, std::string* err,
-                ChunkArena* scratch) {
+                ChunkArena* scratch, DevArena* arena) {
   Amg* m = new Amg();
+  m->pool = arena;
   m->cfg = cfg_in;
   m->S0 = S0;
   m->T0 = T0;
@@ -1502,13 +1515,11 @@ Amg* amg_create(hipStream_t s, const BsrDev& A0, const Sym0Dev& S0, const Tile0D
     // strength of connection from the current values of this level
     std::vector<double> w(H.nslot);
     {
-      double* d_w = nullptr;   // scratch of this step only: not kept in the pool
-      if (hipMalloc((void**)&d_w, sizeof(double) * std::max(H.nslot, 1)) != hipSuccess)
-        return fail("amg_create: out of device memory");
+      double* d_w = dev_alloc<double>(m->pool, (size_t)std::max(H.nslot, 1));   // (stays in the arena until its rewind)
+      if (!d_w) return fail("amg_create: out of device memory");
       SGO_LAUNCH(k_block_norms, dim3(grid_for(H.nslot, kBlock)), dim3(kBlock), 0, s, L.A, d_w);
       hipMemcpyAsync(w.data(), d_w, sizeof(double) * H.nslot, hipMemcpyDeviceToHost, s);
       const hipError_t e = hipStreamSynchronize(s);
-      hipFree(d_w);
       if (e != hipSuccess) return fail("amg_create: strength kernel failed");
     }
     std::vector<int> agg;
@@ -1717,11 +1728,13 @@ Amg* amg_create(hipStream_t s, const BsrDev& A0, const Sym0Dev& S0, const Tile0D
   m->N = 3 * m->lv[last].A.n;
   m->Np = (m->N + kGjB - 1) / kGjB * kGjB;
   if (m->N > 3072) return fail("amg_create: coarsest level too large (" + std::to_string(m->N) + " unknowns)");
-  m->inv = dev_alloc<double>(m->pool, (size_t)m->Np * m->Np);
-  m->gjP = dev_alloc<double>(m->pool, kGjB * kGjB);
-  m->gjX = dev_alloc<double>(m->pool, (size_t)m->Np * kGjB);
+  m->inv0 = dev_alloc<double>(m->pool, (size_t)m->Np * m->Np);
+  m->inv1 = dev_alloc<double>(m->pool, (size_t)m->Np * m->Np);
+  m->gjP[0] = dev_alloc<double>(m->pool, kGjB * kGjB);
+  m->gjP[1] = dev_alloc<double>(m->pool, kGjB * kGjB);
+  m->inv = ((m->Np / kGjB) & 1) ? m->inv1 : m->inv0;
   m->d_fail = dev_alloc<int>(m->pool, 1);
-  if (!m->inv || !m->d_fail || !m->gjP || !m->gjX) return fail("amg_create: out of device memory");
+  if (!m->inv0 || !m->inv1 || !m->d_fail || !m->gjP[0] || !m->gjP[1]) return fail("amg_create: out of device memory");
   hipMemsetAsync(m->d_fail, 0, sizeof(int), s);
   std::snprintf(line, sizeof line, "coarsest dense N=%d; theta=%.3g omega=%.2f", m->N,
                 m->cfg.theta, m->cfg.omega);

@@ -99,7 +99,8 @@ struct sgo_ctx {
   double setup_seconds = 0.0;
 
   // device
-  std::vector<void*> allocs;
+  DevArena graph_arena;           // device arrays of the resident graph (rewound by the next set_graph)
+  DevArena amg_arena;             // ... of the multigrid hierarchy (rewound when the hierarchy is rebuilt)
   double* d_poses = nullptr;
   int* d_free_id = nullptr;
   EdgeListDev el;
@@ -155,14 +156,12 @@ namespace {
 
 template <class T>
 int dalloc(sgo_ctx* c, T** p, size_t count) {
-  void* q = nullptr;
-  size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
-  hipError_t e = hipMalloc(&q, bytes);
-  if (e != hipSuccess) {
-    c->err = std::string("hipMalloc(") + std::to_string(bytes) + "): " + hipGetErrorString(e);
+  const size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+  void* q = c->graph_arena.take(bytes);
+  if (!q) {
+    c->err = "out of device memory (" + std::to_string(bytes) + " bytes)";
     return SGO_ENOMEM;
   }
-  c->allocs.push_back(q);
   *p = (T*)q;
   return SGO_OK;
 }
@@ -207,8 +206,8 @@ void free_graph(sgo_ctx* c) {
     amg_destroy(c->amg);
     c->amg = nullptr;
   }
-  for (void* p : c->allocs) hipFree(p);
-  c->allocs.clear();
+  c->amg_arena.rewind();
+  c->graph_arena.rewind();   // the caller has synchronised the stream: nothing in flight reads these arrays
   c->pcg_pred = 0;
   c->A = BsrDev();
   c->S0 = Sym0Dev();
@@ -361,6 +360,13 @@ struct RowPlan {
 
 int plan_rows(int V, const double* poses, const uint8_t* fixed, int E, const int32_t* ei, const int32_t* ej, int tile_div,
               std::string* err, RowPlan& P) {
+  const bool verbose = std::getenv("SGO_VERBOSE") != nullptr && E > 200000;
+  double tl = wall_s();
+  auto lap = [&](const char* what) {
+    const double t = wall_s();
+    if (verbose) std::fprintf(stderr, "[sgo]   plan %-18s %.1f ms\n", what, 1e3 * (t - tl));
+    tl = t;
+  };
   std::vector<int> deg(V, 0);
   for (int e = 0; e < E; ++e) {
     int a = ei[e], b = ej[e];
@@ -380,6 +386,7 @@ int plan_rows(int V, const double* poses, const uint8_t* fixed, int E, const int
   for (int v = 0; v < V; ++v)
     if (!fixed[v] && deg[v] > 0) P.free_id.push_back(v);
   const int n = P.n = (int)P.free_id.size();
+  lap("degrees");
   // internal row order: Hilbert index of the initial position (ties and non-finite poses: by id)
   P.hpos.assign(V, -1);
   P.row_vertex.assign(n, 0);
@@ -415,6 +422,7 @@ int plan_rows(int V, const double* poses, const uint8_t* fixed, int E, const int
     }
   }
   const std::vector<int>& hpos = P.hpos;
+  lap("hilbert order");
   // compact slots: per row one slot per incident edge (edge order within the row)
   std::vector<int>& rowptr = P.rowptr;
   rowptr.assign((size_t)n + 1, 0);
@@ -443,6 +451,7 @@ int plan_rows(int V, const double* poses, const uint8_t* fixed, int E, const int
     }
   }
   const std::vector<int>& col = P.col;
+  lap("slot positions");
   // ---- tiles (Tile0Dev): consecutive rows, cut so that the blocks are spread evenly over ~2 tiles per CU
   // and a tile's LDS -- operand slice + halo, owned sums, one staging slot per intra-tile transposed slot --
   // fits kTileLdsMax.  A pair inside a tile stores its block with the lower row only (the other row's slot
@@ -507,6 +516,7 @@ int plan_rows(int V, const double* poses, const uint8_t* fixed, int E, const int
       if (attempt == 5) P.tiles_ok = false;
     }
   }
+  lap("tiles");
   if (const char* e = std::getenv("SGO_SPMV0"))
     if (!std::strcmp(e, "group")) P.tiles_ok = false;   // experiments: force the wave-group kernel
   if (!P.tiles_ok) {   // one "tile" per row range of nothing: every pair stored once, with the lower row
@@ -530,6 +540,13 @@ int build_structure(sgo_ctx* c, int V, const double* poses, const uint8_t* fixed
     const int prc = plan_rows(V, poses, fixed, E, ei, ej, tile_div, &c->err, P);
     if (prc != SGO_OK) return prc;
   }
+  const bool verbose = c->opts.verbose && E > 200000;
+  double tl = wall_s();
+  auto lap = [&](const char* what) {
+    const double t = wall_s();
+    if (verbose) std::fprintf(stderr, "[sgo]   build %-17s %.1f ms\n", what, 1e3 * (t - tl));
+    tl = t;
+  };
   c->free_id = P.free_id;
   c->row_of_asc = P.row_of_asc;
   const int n = P.n, ns = P.ns;
@@ -583,6 +600,7 @@ int build_structure(sgo_ctx* c, int V, const double* poses, const uint8_t* fixed
       }
     }
   });
+  lap("edge operands");
   // slot types
   parallel_for(n, [&](int r0, int r1) {
     for (int r = r0; r < r1; ++r)
@@ -608,6 +626,7 @@ int build_structure(sgo_ctx* c, int V, const double* poses, const uint8_t* fixed
   }
   own[ns] = nu;
   tslot[ns] = ntr;
+  lap("types + ranks");
   // wave groups over the compact slots: whole rows packed up to 64 slots; a longer row is its own group
   std::vector<int> grp, grow;
   grp.push_back(0);
@@ -659,6 +678,7 @@ int build_structure(sgo_ctx* c, int V, const double* poses, const uint8_t* fixed
       }
     }
   });
+  lap("groups tref meta");
   // logical structure for the multigrid set-up (diagonal slot first, then the row's block slots)
   HostLevel& H = c->H0;
   H.n = n;
@@ -689,6 +709,7 @@ int build_structure(sgo_ctx* c, int V, const double* poses, const uint8_t* fixed
       }
     }
   });
+  lap("logical view");
   // tile arrays: phase-1 groups over the owned slots (numbered like the storage), operand index and twin's
   // staging slot per owned slot, halo columns, staged-entry ranges per row
   std::vector<int> trowptr((size_t)n + 1), grp1, grow1;
@@ -775,6 +796,7 @@ int build_structure(sgo_ctx* c, int V, const double* poses, const uint8_t* fixed
     }
   }
 
+  lap("tile arrays");
   const double tb1 = wall_s();
   int rc;
   Sym0Dev& S = c->S0;
@@ -1089,6 +1111,7 @@ int build_amg(sgo_ctx* c) {
     amg_destroy(c->amg);
     c->amg = nullptr;
   }
+  c->amg_arena.rewind();
   AmgConfig cfg;
   AmgProf prof;
   prof.user = c;
@@ -1102,7 +1125,8 @@ int build_amg(sgo_ctx* c) {
     cc->amg_scope = nullptr;
   };
   std::string aerr;
-  c->amg = amg_create(c->stream, c->A, c->S0, c->T0, c->H0, c->d_poses, c->d_free_id, cfg, prof, &aerr, &c->amg_scratch);
+  c->amg = amg_create(c->stream, c->A, c->S0, c->T0, c->H0, c->d_poses, c->d_free_id, cfg, prof, &aerr, &c->amg_scratch,
+                      &c->amg_arena);
   if (c->amg) {
     if (c->comm.nranks > 1 || c->comm.handle) amg_set_shard(c->amg, &c->comm, c->shard_u0, c->shard_u1);
     amg_describe(c->amg, &c->solver_desc);
@@ -1246,6 +1270,8 @@ void sgo_destroy(sgo_ctx* c) {
   if (c->stream) hipStreamSynchronize(c->stream);
   prof_flush(c);
   free_graph(c);
+  c->graph_arena.release();
+  c->amg_arena.release();
   c->comm.destroy();
   for (hipEvent_t e : c->ev_pool) hipEventDestroy(e);
   for (hipEvent_t e : c->iter_events) hipEventDestroy(e);

@@ -324,6 +324,50 @@ struct ChunkArena {
   }
 };
 
+// Device memory that survives between set-ups: a graph's ~60 arrays (and the multigrid hierarchy's ~100) are
+// carved out of a few large hipMalloc'ed chunks that are rewound, not freed, when the next graph arrives --
+// the reference re-initialises its slowly growing graph before every optimize(20), and 60 hipFree + 60
+// hipMalloc calls cost 15-20 ms per set-up on C4.  Single-threaded use (one context = one thread at a time).
+struct DevArena {
+  struct Chunk {
+    char* base = nullptr;
+    size_t cap = 0, used = 0;
+  };
+  std::vector<Chunk> chunks;
+  size_t next_chunk = (size_t)8 << 20;
+  DevArena() = default;
+  DevArena(const DevArena&) = delete;
+  DevArena& operator=(const DevArena&) = delete;
+  void* take(size_t bytes) {   // nullptr when the device is out of memory
+    bytes = (std::max<size_t>(bytes, 1) + 255) & ~(size_t)255;
+    for (Chunk& c : chunks)
+      if (c.cap - c.used >= bytes) {
+        void* q = c.base + c.used;
+        c.used += bytes;
+        return q;
+      }
+    Chunk n;
+    n.cap = std::max(bytes, next_chunk);
+    void* q = nullptr;
+    if (hipMalloc(&q, n.cap) != hipSuccess) {
+      n.cap = bytes;
+      if (hipMalloc(&q, n.cap) != hipSuccess) return nullptr;
+    }
+    next_chunk = std::min<size_t>(next_chunk * 2, (size_t)1 << 30);
+    n.base = (char*)q;
+    n.used = bytes;
+    chunks.push_back(n);
+    return q;
+  }
+  void rewind() {
+    for (Chunk& c : chunks) c.used = 0;
+  }
+  void release() {
+    for (Chunk& c : chunks) hipFree(c.base);
+    chunks.clear();
+  }
+};
+
 // Static-partition parallel loop over [0, n) on up to 8 host threads (structure builds only).
 template <class F>
 inline void host_parallel_for(int n, int grain, F&& fn) {

@@ -31,7 +31,7 @@ const char* const kKernelNames[K_COUNT] = {
     "k_chi2",        "k_reduce2",  "k_linearize",   "k_finalize",   "k_init_scalars", "k_spmv<0>",  "k_spmv<1>",
     "k_spmv<2>", "k_spmv<3>", "k_spmv<4>", "k_spmv<5>", "k_spmv<6>",      "k_alpha",       "k_update_xr",  "k_beta",         "k_update_p", "k_dot",
     "k_pose_update", "k_positions0", "k_centres",   "k_galerkin",   "k_level_dinv",   "k_restrict", "k_prolong_add",
-    "k_gj_panels+k_gj_trail (dense inverse)", "k_dense_apply", "k_p_values", "k_block_products<1, 0, 0>",
+    "k_gj_step (dense inverse, all block steps)", "k_dense_apply", "k_p_values", "k_block_products<1, 0, 0>",
     "k_block_products<0, 1, 1>", "k_restrict_p", "k_prolong_p", "k_spmv<7>",
     "k_spmv0<0>", "k_spmv0<1>", "k_spmv0<2>", "k_spmv0t<0, 512>", "k_spmv0t<1, 512>", "k_spmv0t<2, 512>"};
 
