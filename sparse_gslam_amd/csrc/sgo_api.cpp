@@ -7,6 +7,7 @@
 //     for k in 0..iters:  computeActiveErrors; buildSystem; solve; update
 // with the linear solve done by preconditioned CG on the device instead of LinearSolverEigen.
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -553,7 +554,7 @@ int build_structure(sgo_ctx* c, int V, const double* poses, const uint8_t* fixed
   c->V = V;
   c->E = E;
   c->n = n;
-  const std::vector<int>&hpos = P.hpos, &row_vertex = P.row_vertex, &rowptr = P.rowptr, &pos_i = P.pos_i, &pos_j = P.pos_j;
+  const std::vector<int>&row_vertex = P.row_vertex, &rowptr = P.rowptr, &pos_i = P.pos_i, &pos_j = P.pos_j;
   std::vector<int>& col = P.col;
   std::vector<TileDesc>& tiles = P.tiles;
   std::vector<int>& tile_of_row = P.tile_of_row;
@@ -562,41 +563,30 @@ int build_structure(sgo_ctx* c, int V, const double* poses, const uint8_t* fixed
   bool tiles_ok = P.tiles_ok;
   HostArena& ar = c->stage;
   try {
-    ar.reserve((size_t)ns * (4 * sizeof(int) + 4 + 10 * sizeof(double)) + (size_t)E * 9 * sizeof(double) + 64 * 64);
+    ar.reserve((size_t)ns * (3 * sizeof(int) + 4 + sizeof(unsigned int)) + 64 * 64);
   } catch (const std::bad_alloc&) {
     c->err = "sgo_set_graph_se2: out of host memory for the staging buffers";
     return SGO_ENOMEM;
   }
-  HostBuf<int> svi(ar, ns), svj(ar, ns), own(ar, (size_t)ns + 1);
+  HostBuf<int> eidx(ar, ns), own(ar, (size_t)ns + 1);
   HostBuf<unsigned char> type(ar, ns), meta(ar, ns), flags(ar, ns), off1(ar, (size_t)std::max(ns, 1));
   HostBuf<unsigned int> cv(ar, (size_t)std::max(ns, 1));
-  HostBuf<double> zinv(ar, 3 * (size_t)ns), sinfo(ar, 6 * (size_t)ns), sphi(ar, ns);
-  HostBuf<double> ezinv(ar, 3 * (size_t)E), einfo(ar, 6 * (size_t)E);
-  if (!einfo.p) {
+  if (!cv.p) {
     c->err = "sgo_set_graph_se2: internal error (staging arena too small)";
     return SGO_EINVAL;
   }
-  // every slot is written exactly once (each edge fills its one or two slots)
+  // every slot is written exactly once (each edge fills its one or two slots): the edge it came from and the
+  // side; the operand arrays themselves are expanded on the device (k_slot_expand)
   parallel_for(E, [&](int e0, int e1) {
     for (int e = e0; e < e1; ++e) {
-      // EdgeSE2::setMeasurement caches the inverse measurement on the host (computed once)
-      const double* z = meas + 3 * (size_t)e;
-      const double th = normalize_theta_h(-z[2]);
-      const double cs = std::cos(th), sn = std::sin(th);
-      const double zi[3] = {cs * (-z[0]) - sn * (-z[1]), sn * (-z[0]) + cs * (-z[1]), th};
-      for (int q = 0; q < 3; ++q) ezinv[q * (size_t)E + e] = zi[q];
-      for (int q = 0; q < 6; ++q) einfo[q * (size_t)E + e] = info[6 * (size_t)e + q];
-      const int hi = hpos[ei[e]], hj = hpos[ej[e]];
-      for (int side = 0; side < 2; ++side) {
-        const int hr = side ? hj : hi;
-        if (hr < 0) continue;
-        const int k = side ? pos_j[e] : pos_i[e];
-        flags[k] = (unsigned char)(side ? kSlotDir : 0);
-        svi[k] = ei[e];
-        svj[k] = ej[e];
-        for (int q = 0; q < 3; ++q) zinv[q * (size_t)ns + k] = zi[q];
-        for (int q = 0; q < 6; ++q) sinfo[q * (size_t)ns + k] = info[6 * (size_t)e + q];
-        sphi[k] = phi[e];
+      const int ki = pos_i[e], kj = pos_j[e];
+      if (ki >= 0) {
+        eidx[ki] = e;
+        flags[ki] = 0;
+      }
+      if (kj >= 0) {
+        eidx[kj] = e;
+        flags[kj] = (unsigned char)kSlotDir;
       }
     }
   });
@@ -715,66 +705,89 @@ int build_structure(sgo_ctx* c, int V, const double* poses, const uint8_t* fixed
   std::vector<int> trowptr((size_t)n + 1), grp1, grow1;
   if (tiles_ok) {
     for (int r = 0; r <= n; ++r) trowptr[r] = tslot[rowptr[std::min(r, n)]];
-    std::vector<int> hidx(std::max(n, 1), -1), hmark(std::max(n, 1), -1);
+    // per tile, on the host threads: halo numbering in first-seen order, operand index of every owned slot,
+    // phase-1 groups; then the per-tile lists are strung together
+    const int nt = (int)tiles.size();
+    std::vector<std::vector<int>> t_hcol(nt), t_grp(nt), t_grow(nt);
+    {
+      const int hw = (int)std::thread::hardware_concurrency();
+      const int T = std::max(1, std::min({8, hw > 0 ? hw : 1, nt}));
+      std::vector<std::thread> th;
+      for (int w = 0; w < T; ++w)
+        th.emplace_back([&, w]() {
+          std::vector<int> hidx(std::max(n, 1), -1), hmark(std::max(n, 1), -1);
+          for (int t = (int)((long long)nt * w / T); t < (int)((long long)nt * (w + 1) / T); ++t) {
+            const TileDesc& TT = tiles[t];
+            const int nr = TT.row1 - TT.row0;
+            std::vector<int>&hc = t_hcol[t], &tg = t_grp[t], &tw = t_grow[t];
+            int cur = 0, first = TT.row0;
+            for (int r = TT.row0; r < TT.row1; ++r) {
+              const int len = own[rowptr[r + 1]] - own[rowptr[r]];
+              for (int k = rowptr[r]; k < rowptr[r + 1]; ++k) {
+                if (type[k] != kSlotOwned) continue;
+                const int cc = col[k];
+                unsigned ci;
+                if (cc >= TT.row0 && cc < TT.row1) {
+                  ci = (unsigned)(cc - TT.row0);
+                } else {
+                  if (hmark[cc] != t) {
+                    hmark[cc] = t;
+                    hidx[cc] = (int)hc.size();
+                    hc.push_back(cc);
+                  }
+                  ci = (unsigned)(nr + hidx[cc]);
+                }
+                cv[own[k]] = ci | 0xFFFF0000u;   // twin's staging slot filled in below
+              }
+              if (len == 0) continue;
+              if (cur > 0 && cur + len > 64) {   // group boundaries are recorded as END positions (owned-slot numbers)
+                tg.push_back(own[rowptr[r]]);
+                tw.push_back(first);
+                cur = 0;
+              }
+              if (cur == 0) first = r;
+              cur += len;
+              if (cur >= 64) {
+                tg.push_back(own[rowptr[r + 1]]);
+                tw.push_back(first);
+                cur = 0;
+              }
+            }
+            if (cur > 0) {
+              tg.push_back(own[rowptr[TT.row1]]);
+              tw.push_back(first);
+            }
+          }
+        });
+      for (auto& x : th) x.join();
+    }
     grp1.push_back(0);
-    for (size_t t = 0; t < tiles.size(); ++t) {
+    for (int t = 0; t < nt; ++t) {
       TileDesc& T = tiles[t];
-      const int nr = T.row1 - T.row0;
       T.e0 = trowptr[T.row0];
       T.nstaged = trowptr[T.row1] - T.e0;
       T.h0 = (int)hcol.size();
       T.g0 = (int)grow1.size();
-      int cur = 0, first = T.row0;
-      for (int r = T.row0; r < T.row1; ++r) {
-        const int len = own[rowptr[r + 1]] - own[rowptr[r]];
-        // operand index of the row's owned slots; halo numbering in first-seen order
-        for (int k = rowptr[r]; k < rowptr[r + 1]; ++k) {
-          if (type[k] != kSlotOwned) continue;
-          const int cc = col[k];
-          unsigned ci;
-          if (cc >= T.row0 && cc < T.row1) {
-            ci = (unsigned)(cc - T.row0);
-          } else {
-            if (hmark[cc] != (int)t) {
-              hmark[cc] = (int)t;
-              hidx[cc] = (int)hcol.size() - T.h0;
-              hcol.push_back(cc);
-            }
-            ci = (unsigned)(nr + hidx[cc]);
-          }
-          cv[own[k]] = ci | 0xFFFF0000u;   // twin's staging slot filled in below
-        }
-        if (len == 0) continue;
-        if (cur > 0 && cur + len > 64) {
-          grp1.push_back(own[rowptr[r]]);
-          grow1.push_back(first);
-          cur = 0;
-        }
-        if (cur == 0) first = r;
-        cur += len;
-        if (cur >= 64) {
-          grp1.push_back(own[rowptr[r + 1]]);
-          grow1.push_back(first);
-          cur = 0;
-        }
-      }
-      if (cur > 0) {
-        grp1.push_back(own[rowptr[T.row1]]);
-        grow1.push_back(first);
-      }
+      hcol.insert(hcol.end(), t_hcol[t].begin(), t_hcol[t].end());
+      grp1.insert(grp1.end(), t_grp[t].begin(), t_grp[t].end());
+      grow1.insert(grow1.end(), t_grow[t].begin(), t_grow[t].end());
       T.g1 = (int)grow1.size();
       T.h1 = (int)hcol.size();
     }
     const int ng1 = (int)grow1.size();
-    for (int g = 0; g < ng1 && tiles_ok; ++g) {
-      int r = grow1[g];
-      const bool longrow = grp1[g + 1] - grp1[g] > 64;
-      for (int u = grp1[g]; u < grp1[g + 1]; ++u) {
-        while (own[rowptr[r + 1]] <= u) ++r;
-        if (!longrow && r - grow1[g] > 255) tiles_ok = false;   // hundreds of rows in a row that own nothing
-        off1[u] = (unsigned char)(longrow ? 0 : r - grow1[g]);
+    std::atomic<bool> span_ok{true};
+    parallel_for(ng1, [&](int ga, int gb) {
+      for (int g = ga; g < gb; ++g) {
+        int r = grow1[g];
+        const bool longrow = grp1[g + 1] - grp1[g] > 64;
+        for (int u = grp1[g]; u < grp1[g + 1]; ++u) {
+          while (own[rowptr[r + 1]] <= u) ++r;
+          if (!longrow && r - grow1[g] > 255) span_ok = false;   // hundreds of rows in a row that own nothing
+          off1[u] = (unsigned char)(longrow ? 0 : r - grow1[g]);
+        }
       }
-    }
+    });
+    if (!span_ok) tiles_ok = false;
     // twins: the owned slot of an intra-tile pair hands B^T x to the transposed slot's staging entry
     parallel_for(E, [&](int e0, int e1) {
       for (int e = e0; e < e1; ++e) {
@@ -850,24 +863,30 @@ int build_structure(sgo_ctx* c, int V, const double* poses, const uint8_t* fixed
   A.nu = (size_t)nu;
   A.dblk = S.dblk;
   A.dinv = S.dinv;
-  if ((rc = upload(c, &c->es.vi, svi))) return rc;
-  if ((rc = upload(c, &c->es.vj, svj))) return rc;
-  if ((rc = upload(c, &c->es.flags, flags))) return rc;
-  if ((rc = upload(c, &c->es.zinv, zinv))) return rc;
-  if ((rc = upload(c, &c->es.info, sinfo))) return rc;
-  if ((rc = upload(c, &c->es.phi, sphi))) return rc;
+  // edge arrays in caller order: indices / kernel parameter straight from the caller's buffers; the inverse
+  // measurements and the SoA information are made on the device from the raw rows, and the per-slot operand
+  // arrays of k_linearize are expanded there too
   c->el.E = E;
-  // caller-order index / kernel arrays go up straight from the caller's buffers
-  if ((rc = dalloc(c, &c->el.vi, (size_t)E)) || (rc = dalloc(c, &c->el.vj, (size_t)E)) ||
-      (rc = dalloc(c, &c->el.phi, (size_t)E)))
+  int* d_eidx = nullptr;
+  double *d_meas = nullptr, *d_info = nullptr;
+  if ((rc = upload(c, &d_eidx, eidx))) return rc;
+  if ((rc = upload(c, &c->es.flags, flags))) return rc;
+  if ((rc = dalloc(c, &c->es.vi, (size_t)ns)) || (rc = dalloc(c, &c->es.vj, (size_t)ns)) || (rc = dalloc(c, &c->es.zinv, 3 * (size_t)ns)) ||
+      (rc = dalloc(c, &c->es.info, 6 * (size_t)ns)) || (rc = dalloc(c, &c->es.phi, (size_t)ns)))
+    return rc;
+  if ((rc = dalloc(c, &c->el.vi, (size_t)E)) || (rc = dalloc(c, &c->el.vj, (size_t)E)) || (rc = dalloc(c, &c->el.phi, (size_t)E)) ||
+      (rc = dalloc(c, &c->el.zinv, 3 * (size_t)E)) || (rc = dalloc(c, &c->el.info, 6 * (size_t)E)) ||
+      (rc = dalloc(c, &d_meas, 3 * (size_t)E)) || (rc = dalloc(c, &d_info, 6 * (size_t)E)))
     return rc;
   if (E > 0) {
     HIP_TRY(c, hipMemcpyAsync(c->el.vi, ei, sizeof(int32_t) * (size_t)E, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(c->el.vj, ej, sizeof(int32_t) * (size_t)E, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(c->el.phi, phi, sizeof(double) * (size_t)E, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(d_meas, meas, sizeof(double) * 3 * (size_t)E, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(d_info, info, sizeof(double) * 6 * (size_t)E, hipMemcpyHostToDevice, c->stream));
+    launch_edge_prepare(c->stream, E, d_meas, d_info, c->el.zinv, c->el.info);
+    if (ns > 0) launch_slot_expand(c->stream, ns, d_eidx, c->el, c->es);
   }
-  if ((rc = upload(c, &c->el.zinv, ezinv))) return rc;
-  if ((rc = upload(c, &c->el.info, einfo))) return rc;
   if ((rc = upload(c, &c->d_free_id, row_vertex))) return rc;
   if ((rc = dalloc(c, &c->d_poses, 3 * (size_t)V))) return rc;
   HIP_TRY(c, hipMemcpyAsync(c->d_poses, poses, sizeof(double) * 3 * (size_t)V, hipMemcpyHostToDevice, c->stream));

@@ -407,6 +407,8 @@ extern thread_local LaunchEvents tl_launch_ev;
 void launch_chi2(hipStream_t s, const EdgeListDev& el, int e0, int e1, const double* poses, double* e2_out,
                  double* partials /*[2][kMaxPartials]*/, int* grid_out);
 void launch_reduce2(hipStream_t s, const double* partials, int nparts, double* out2);
+void launch_edge_prepare(hipStream_t s, int E, const double* meas, const double* info, double* zinv, double* info_soa);
+void launch_slot_expand(hipStream_t s, int ncs, const int* eidx, const EdgeListDev& el, const EdgeSlotsDev& es);
 void launch_linearize(hipStream_t s, const Sym0Dev& A, int g0, int g1, const EdgeSlotsDev& es, const double* poses,
                       double* dgb /*[n][9]*/);
 void launch_finalize(hipStream_t s, const Sym0Dev& A, const double* dgb, double* b, double* x, double* r, double* z,

@@ -114,6 +114,39 @@ __global__ __launch_bounds__(kBlock) void k_reduce2(const double* __restrict__ p
   }
 }
 
+// ---------------------------------------------------------------------------- set-up kernels
+// EdgeSE2::setMeasurement caches the inverse measurement (computed once per set_graph): zinv = Z^-1 in SoA,
+// and the information's upper triangle from the caller's AoS rows to SoA.
+__global__ __launch_bounds__(kBlock) void k_edge_prepare(int E, const double* __restrict__ meas, const double* __restrict__ info,
+                                                         double* __restrict__ zinv, double* __restrict__ info_soa) {
+  for (int e = blockIdx.x * kBlock + threadIdx.x; e < E; e += gridDim.x * kBlock) {
+    const double zx = meas[3 * (size_t)e], zy = meas[3 * (size_t)e + 1], zt = meas[3 * (size_t)e + 2];
+    const double th = norm_theta(-zt);
+    double sn, cs;
+    sincos(th, &sn, &cs);
+    zinv[e] = cs * (-zx) - sn * (-zy);
+    zinv[(size_t)E + e] = sn * (-zx) + cs * (-zy);
+    zinv[2 * (size_t)E + e] = th;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) info_soa[q * (size_t)E + e] = info[6 * (size_t)e + q];
+  }
+}
+// The per-slot operand arrays of k_linearize (coalesced per slot) from the per-edge arrays: slot k came from
+// edge eidx[k]; the host only lists that index and the side (4 + 1 B per slot instead of 96 B).
+__global__ __launch_bounds__(kBlock) void k_slot_expand(int ncs, const int* __restrict__ eidx, EdgeListDev el, EdgeSlotsDev es) {
+  const size_t ns = (size_t)ncs, E = (size_t)el.E;
+  for (int k = blockIdx.x * kBlock + threadIdx.x; k < ncs; k += gridDim.x * kBlock) {
+    const size_t e = (size_t)eidx[k];
+    es.vi[k] = el.vi[e];
+    es.vj[k] = el.vj[e];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) es.zinv[q * ns + k] = el.zinv[q * E + e];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) es.info[q * ns + k] = el.info[q * E + e];
+    es.phi[k] = el.phi[e];
+  }
+}
+
 // ---------------------------------------------------------------------------- k_linearize
 // One lane per compact slot of the level-0 matrix (Sym0Dev).  For a slot of row r that came from edge
 // (i,j): row Jacobian Jr = A (dir 0) or B (dir 1), column Jacobian Jc the other one; the lane
@@ -837,6 +870,12 @@ void launch_finalize(hipStream_t s, const Sym0Dev& A, const double* dgb, double*
 void launch_init_scalars(hipStream_t s, PcgScalars* S, const double* rz_parts, int n_rz, const double* bb_parts,
                          int n_bb, double tol, int maxit) {
   SGO_LAUNCH(k_init_scalars, dim3(1), dim3(kBlock), 0, s, S, rz_parts, n_rz, bb_parts, n_bb, tol, maxit);
+}
+void launch_edge_prepare(hipStream_t s, int E, const double* meas, const double* info, double* zinv, double* info_soa) {
+  SGO_LAUNCH(k_edge_prepare, dim3(grid_for(E, kBlock)), dim3(kBlock), 0, s, E, meas, info, zinv, info_soa);
+}
+void launch_slot_expand(hipStream_t s, int ncs, const int* eidx, const EdgeListDev& el, const EdgeSlotsDev& es) {
+  SGO_LAUNCH(k_slot_expand, dim3(grid_for(ncs, kBlock)), dim3(kBlock), 0, s, ncs, eidx, el, es);
 }
 int launch_spmv_ex(hipStream_t s, const BsrDev& A, int mode, const SpmvArgs& a) {
   const int grid = grid_for(A.ngrp, kWavesPerBlock);
