@@ -3,7 +3,7 @@
 # repo root: `gpurun -- bash scripts/profile_round.sh r01`); outputs land in gpurun_out/.
 # rocprofv3 wants cwd and TMPDIR under /tmp; --pmc passes are separate from the --stats pass.
 set -u
-tag=${1:-r01}
+tag=${1:-r02}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp; export TMPDIR=/tmp
 # Plain stream launches (no hipGraph) for the profiled passes, as in bench.py's own roofline leg: graph
