@@ -531,11 +531,11 @@ int build_structure(sgo_ctx* c, int V, const double* poses, const uint8_t* fixed
                     const int32_t* ej, const double* meas, const double* info, const double* phi) {
   const double tb0 = wall_s();
   RowPlan P;
-  int tile_div = 512;   // two tiles per CU
+  int tile_div = 256;   // one tile per CU: the larger the tiles, the fewer pairs straddle two of them
   {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0)
-      tile_div = 2 * prop.multiProcessorCount;
+      tile_div = prop.multiProcessorCount;
   }
   {
     const int prc = plan_rows(V, poses, fixed, E, ei, ej, tile_div, &c->err, P);
@@ -833,7 +833,7 @@ int build_structure(sgo_ctx* c, int V, const double* poses, const uint8_t* fixed
   if (tiles_ok && !tiles.empty()) {
     TL.ntile = (int)tiles.size();
     TL.lds_bytes = tile_lds;
-    if (const char* e = std::getenv("SGO_TILE_THREADS")) TL.threads = std::atoi(e) == 1024 ? 1024 : 512;
+    if (const char* e = std::getenv("SGO_TILE_THREADS")) TL.threads = std::atoi(e) == 512 ? 512 : 1024;
     if (hcol.empty()) hcol.push_back(0);
     if ((rc = upload(c, &TL.tile, tiles))) return rc;
     if ((rc = upload(c, &TL.cv, cv))) return rc;
@@ -1804,7 +1804,7 @@ int sgo_plan_rows(int32_t V, const double* poses, const uint8_t* fixed, int32_t 
   try {
     RowPlan P;
     std::string err;
-    const int rc = plan_rows(V, poses, fixed, E, ei, ej, 512, &err, P);
+    const int rc = plan_rows(V, poses, fixed, E, ei, ej, 256, &err, P);
     if (rc != SGO_OK) {
       g_err = err;
       return rc;

@@ -125,7 +125,7 @@ struct TileDesc {
 struct Tile0Dev {
   int ntile = 0;
   int lds_bytes = 0;          // dynamic LDS per workgroup (largest tile)
-  int threads = 512;          // workgroup size (512 or 1024)
+  int threads = 1024;         // workgroup size (512 or 1024)
   TileDesc* tile = nullptr;
   unsigned int* cv = nullptr;       // [nu] owned slot u: LDS operand index (local row, or rows + halo number) in
                                     // bits 0..15, tile-relative staging slot of its twin in bits 16..31 (0xFFFF: none)
@@ -421,7 +421,7 @@ int launch_spmv0t(hipStream_t s, const Sym0Dev& A, const Tile0Dev& T, int mode, 
 inline int launch_spmv0_any(hipStream_t s, const Sym0Dev& A, const Tile0Dev& T, int mode, const Spmv0Args& a) {
   return T.ntile > 0 ? launch_spmv0t(s, A, T, mode, a) : launch_spmv0(s, A, mode, a);
 }
-constexpr int kTileLdsMax = 79 * 1024;   // two tile workgroups per CU (160 KiB of LDS)
+constexpr int kTileLdsMax = 156 * 1024;   // one 1024-thread tile workgroup per CU (160 KiB of LDS)
 int launch_spmv_ex(hipStream_t s, const BsrDev& A, int mode, const SpmvArgs& a);  // returns grid
 void launch_update_xr(hipStream_t s, int n, PcgScalars* S, const double* pq_parts, int n_pq, const double* dinv,
                       const double* p, const double* q, double* x, double* r, double* z, double* xs, double omega,

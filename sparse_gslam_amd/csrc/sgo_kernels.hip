@@ -33,7 +33,7 @@ const char* const kKernelNames[K_COUNT] = {
     "k_pose_update", "k_positions0", "k_centres",   "k_galerkin",   "k_level_dinv",   "k_restrict", "k_prolong_add",
     "k_gj_step (dense inverse, all block steps)", "k_dense_apply", "k_p_values", "k_block_products<1, 0, 0>",
     "k_block_products<0, 1, 1>", "k_restrict_p", "k_prolong_p", "k_spmv<7>",
-    "k_spmv0<0>", "k_spmv0<1>", "k_spmv0<2>", "k_spmv0t<0, 512>", "k_spmv0t<1, 512>", "k_spmv0t<2, 512>"};
+    "k_spmv0<0>", "k_spmv0<1>", "k_spmv0<2>", "k_spmv0t<0, 1024>", "k_spmv0t<1, 1024>", "k_spmv0t<2, 1024>"};
 
 namespace {
 
