@@ -679,16 +679,18 @@ int aggregate(const HostLevel& L, const std::vector<double>& w, double theta, st
   const int n = L.n;
   agg.assign(n, -1);
   const int* visit = L.visit.size() == (size_t)n ? L.visit.data() : nullptr;
-  std::vector<uint8_t> sflag(L.nslot, 0);   // strength of every slot, evaluated once
-  for (int i = 0; i < n; ++i) {
-    const double di = w[L.rowptr[i]];
-    for (int k = L.rowptr[i] + 1; k < L.rowptr[i + 1]; ++k) {
-      const int j = L.col[k];
-      if (j == i) continue;
-      const double t = theta * theta * di * w[L.rowptr[j]];   // w_ij >= theta sqrt(d_i d_j), squared
-      sflag[k] = (w[k] > 0.0 && w[k] * w[k] >= t) ? 1 : 0;
+  std::vector<uint8_t> sflag(L.nslot, 0);   // strength of every slot, evaluated once (rows in parallel)
+  host_parallel_for(n, 2048, [&](int lo, int hi, int) {
+    for (int i = lo; i < hi; ++i) {
+      const double di = w[L.rowptr[i]];
+      for (int k = L.rowptr[i] + 1; k < L.rowptr[i + 1]; ++k) {
+        const int j = L.col[k];
+        if (j == i) continue;
+        const double t = theta * theta * di * w[L.rowptr[j]];   // w_ij >= theta sqrt(d_i d_j), squared
+        sflag[k] = (w[k] > 0.0 && w[k] * w[k] >= t) ? 1 : 0;
+      }
     }
-  }
+  });
   auto strong = [&](int, int k) { return sflag[k] != 0; };
   int nc = 0;
   // pass 1: a node all of whose strong neighbours are free roots a new aggregate
@@ -813,7 +815,7 @@ bool sa_symbolic(const HostLevel& H, const std::vector<int>& agg, int nc, long l
   };
   // ---- P: row i holds the aggregates of the columns of row i (its own among them: diagonal slot)
   o.p_rowptr.assign((size_t)n + 1, 0);
-  host_parallel_for(n, 4096, [&](int lo, int hi, int) {
+  host_parallel_for(n, 512, [&](int lo, int hi, int) {
     std::vector<int> mark((size_t)nc, -1);
     for (int i = lo; i < hi; ++i) {
       int cnt = 0;
@@ -834,7 +836,7 @@ bool sa_symbolic(const HostLevel& H, const std::vector<int>& agg, int nc, long l
   o.val_src.resize(H.nslot);
   o.val_tgt.resize(H.nslot);
   std::vector<int> val_ptr((size_t)np + 1);
-  host_parallel_for(n, 4096, [&](int lo, int hi, int) {
+  host_parallel_for(n, 512, [&](int lo, int hi, int) {
     std::vector<int> mark((size_t)nc, -1), pos((size_t)nc, 0), uniq;
     RowSorter rs;
     for (int i = lo; i < hi; ++i) {
@@ -890,7 +892,7 @@ bool sa_symbolic(const HostLevel& H, const std::vector<int>& agg, int nc, long l
   // ---- AP: row i holds the union of the P rows of the columns of row i
   std::vector<int> ap_rowptr((size_t)n + 1, 0);
   std::vector<long long> app((size_t)n + 1, 0);
-  host_parallel_for(n, 4096, [&](int lo, int hi, int) {
+  host_parallel_for(n, 512, [&](int lo, int hi, int) {
     std::vector<int> mark((size_t)nc, -1);
     for (int i = lo; i < hi; ++i) {
       int cnt = 0;
@@ -922,7 +924,7 @@ bool sa_symbolic(const HostLevel& H, const std::vector<int>& agg, int nc, long l
   o.ap_a.resize(nprod_ap);
   o.ap_b.resize(nprod_ap);
   o.ap_tgt.resize(nprod_ap);
-  host_parallel_for(n, 2048, [&](int lo, int hi, int) {
+  host_parallel_for(n, 256, [&](int lo, int hi, int) {
     std::vector<int> mark((size_t)nc, -1), pos((size_t)nc, 0), uniq;
     RowSorter rs;
     for (int i = lo; i < hi; ++i) {
@@ -969,7 +971,7 @@ bool sa_symbolic(const HostLevel& H, const std::vector<int>& agg, int nc, long l
   C.n = nc;
   C.rowptr.assign((size_t)nc + 1, 0);
   std::vector<long long> rpp((size_t)nc + 1, 0);
-  host_parallel_for(nc, 256, [&](int lo, int hi, int) {
+  host_parallel_for(nc, 64, [&](int lo, int hi, int) {
     std::vector<int> mark((size_t)nc, -1);
     for (int a = lo; a < hi; ++a) {
       int cnt = 0;
@@ -1003,7 +1005,7 @@ bool sa_symbolic(const HostLevel& H, const std::vector<int>& agg, int nc, long l
   o.rap_a.resize(nprod_rap);
   o.rap_b.resize(nprod_rap);
   o.rap_tgt.resize(nprod_rap);
-  host_parallel_for(nc, 256, [&](int lo, int hi, int) {
+  host_parallel_for(nc, 64, [&](int lo, int hi, int) {
     std::vector<int> mark((size_t)nc, -1), pos((size_t)nc, 0), uniq;
     RowSorter rs;
     for (int a = lo; a < hi; ++a) {

@@ -33,21 +33,10 @@ double wall_s() {
   return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
-// Static-partition parallel loop over [0, n) on up to 8 host threads (structure build only).
+// Static-partition parallel loop over [0, n) on the host pool (structure build only).
 template <class F>
 void parallel_for(int n, F&& fn) {
-  const int hw = (int)std::thread::hardware_concurrency();
-  const int T = std::max(1, std::min({8, hw > 0 ? hw : 1, n / 20000}));
-  if (T == 1) {
-    fn(0, n);
-    return;
-  }
-  std::vector<std::thread> th;
-  for (int t = 0; t < T; ++t) {
-    const int lo = (int)((long long)n * t / T), hi = (int)((long long)n * (t + 1) / T);
-    th.emplace_back([&fn, lo, hi]() { fn(lo, hi); });
-  }
-  for (auto& x : th) x.join();
+  host_parallel_for(n, 8192, [&fn](int lo, int hi, int) { fn(lo, hi); });
 }
 
 constexpr double kPi = 3.14159265358979323846;
@@ -710,11 +699,8 @@ int build_structure(sgo_ctx* c, int V, const double* poses, const uint8_t* fixed
     const int nt = (int)tiles.size();
     std::vector<std::vector<int>> t_hcol(nt), t_grp(nt), t_grow(nt);
     {
-      const int hw = (int)std::thread::hardware_concurrency();
-      const int T = std::max(1, std::min({8, hw > 0 ? hw : 1, nt}));
-      std::vector<std::thread> th;
-      for (int w = 0; w < T; ++w)
-        th.emplace_back([&, w]() {
+      const int T = std::max(1, std::min(HostPool::get().size(), nt));
+      HostPool::get().run(T, [&](int w) {
           std::vector<int> hidx(std::max(n, 1), -1), hmark(std::max(n, 1), -1);
           for (int t = (int)((long long)nt * w / T); t < (int)((long long)nt * (w + 1) / T); ++t) {
             const TileDesc& TT = tiles[t];
@@ -758,8 +744,7 @@ int build_structure(sgo_ctx* c, int V, const double* poses, const uint8_t* fixed
               tw.push_back(first);
             }
           }
-        });
-      for (auto& x : th) x.join();
+      });
     }
     grp1.push_back(0);
     for (int t = 0; t < nt; ++t) {
