@@ -1691,7 +1691,7 @@ int sgo_optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
 
 // Micro-benchmark of the level-0 product on the resident graph: `reps` back-to-back launches of
 // k_spmv0<mode> (operand = the PCG direction buffer, whatever it holds), HIP events around them on the
-// context's stream; returns the mean microseconds per launch (< 0 on error).  variant 16: the wave-group kernel even when the graph has a tile view.
+// context's stream; returns the mean microseconds per launch (< 0 on error).  variant 16: the wave-group kernel even when the graph has a tile view; variant 32: per-phase s_memtime stamps of the tile kernel on stderr (diagnostic).
 double sgo_debug_spmv0_us(sgo_ctx* c, int mode, int variant, int reps) {
   if (check_graph(c) != SGO_OK || reps < 1 || c->n == 0) return -1.0;
   hipEvent_t a, b;
@@ -1702,6 +1702,12 @@ double sgo_debug_spmv0_us(sgo_ctx* c, int mode, int variant, int reps) {
   args.b = c->d_b;
   args.omega = 0.8;
   const bool tiled = c->T0.ntile > 0 && !(variant & 16);   // variant 16: the wave-group kernel
+  long long* d_st = nullptr;
+  if ((variant & 32) && tiled) {
+    hipMalloc((void**)&d_st, sizeof(long long) * 8 * (size_t)c->T0.ntile);
+    hipMemset(d_st, 0, sizeof(long long) * 8 * (size_t)c->T0.ntile);
+    args.dbg_stamps = d_st;
+  }
   if (tiled) launch_spmv0t(c->stream, c->S0, c->T0, mode, args);
   else launch_spmv0(c->stream, c->S0, mode, args);
   hipEventRecord(a, c->stream);
@@ -1715,6 +1721,18 @@ double sgo_debug_spmv0_us(sgo_ctx* c, int mode, int variant, int reps) {
   hipEventElapsedTime(&ms, a, b);
   hipEventDestroy(a);
   hipEventDestroy(b);
+  if (d_st) {
+    std::vector<long long> st(8 * (size_t)c->T0.ntile);
+    hipMemcpy(st.data(), d_st, sizeof(long long) * st.size(), hipMemcpyDeviceToHost);
+    hipFree(d_st);
+    double ph[6] = {0, 0, 0, 0, 0, 0};
+    for (int t = 0; t < c->T0.ntile; ++t)
+      for (int q = 0; q < 6; ++q) ph[q] += (double)(st[8 * t + q + 1] - st[8 * t + q]);
+    std::fprintf(stderr, "[sgo] tile kernel phases, shader cycles of wave 0 (s_memtime), mean over %d tiles: phase 0 %.0f, barrier %.0f, "
+                 "phase 1 %.0f, barrier %.0f, phase 2 %.0f, barrier %.0f\n", c->T0.ntile,
+                 ph[0] / c->T0.ntile, ph[1] / c->T0.ntile, ph[2] / c->T0.ntile, ph[3] / c->T0.ntile, ph[4] / c->T0.ntile,
+                 ph[5] / c->T0.ntile);
+  }
   return 1e3 * ms / reps;
 }
 

@@ -230,6 +230,7 @@ struct Spmv0Args {
   const double* dotA2 = nullptr; // partials[1] += dotA2 . y
   double* partials = nullptr;    // [2][kMaxPartials]
   const PcgScalars* S = nullptr; // optional early-out flag
+  long long* dbg_stamps = nullptr;   // diagnostic builds: [ntile][8] s_memtime stamps of the tile kernel's phases
   int u0 = 0, u1 = 0;            // multi-GPU: only the work units [u0, u1) -- tiles (k_spmv0t) or wave groups (k_spmv0) --
                                  // are evaluated, i.e. only their rows of y are written (u1 == 0: all)
 };

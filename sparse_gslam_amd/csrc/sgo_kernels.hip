@@ -598,6 +598,8 @@ template <int MODE, int kTileThreads>
 __global__ __launch_bounds__(kTileThreads) void k_spmv0t(Sym0Dev A, Tile0Dev TL, Spmv0Args a) {
   if (a.S && a.S->stop) return;
   extern __shared__ double lds[];
+  __shared__ int next_group_cell;
+  int* next_group = &next_group_cell;
   constexpr int NW = kTileThreads / 64;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const size_t nu = (size_t)A.nu;
@@ -609,11 +611,22 @@ __global__ __launch_bounds__(kTileThreads) void k_spmv0t(Sym0Dev A, Tile0Dev TL,
   for (int t = tlo + slot; t < thi; t += per_xcd) {
     const TileDesc T = TL.tile[t];
     const int nr = T.row1 - T.row0, nh = T.h1 - T.h0;
+    long long* stamp = a.dbg_stamps ? a.dbg_stamps + 8 * (size_t)t : nullptr;
+    if (stamp && tid == 0) stamp[0] = __builtin_amdgcn_s_memtime();
     double* xs = lds;                    // [nr + nh][3] operand: the tile's rows, then its halo columns
     double* ys = xs + 3 * (nr + nh);     // [nr][3] owned part of the row sums
     double* vst = ys + 3 * nr;           // [nstaged][3]
-    // ---- the loads that do not depend on LDS go out first: this wave's first phase-1 group, and (threads that own
-    // a row in phase 2) the row's staged range and diagonal block; they are in flight while phase 0 fills the LDS
+    // ---- phase 0: operand slice and halo to LDS, owned sums cleared.  Order of issue matters (a wave's loads
+    // return in order): the operand slice and the halo column numbers first, then -- while those are in flight --
+    // this wave's first phase-1 group and the phase-2 row data, then the halo operands
+    double xsl[3] = {0.0, 0.0, 0.0};   // up to three slice elements per thread (3 * rows <= 3 * kTileThreads)
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const int i = tid + q * kTileThreads;
+      if (i < 3 * nr) xsl[q] = a.x[3 * (size_t)T.row0 + i];
+    }
+    const int hc0 = tid < nh ? TL.hcol[T.h0 + tid] : -1;
+    if (tid == 0) *next_group = T.g0 + NW;   // groups are handed out through an LDS counter (the first NW statically)
     int g = T.g0 + wave;
     bool has = g < T.g1;
     TileGroupLoad cur;
@@ -628,22 +641,40 @@ __global__ __launch_bounds__(kTileThreads) void k_spmv0t(Sym0Dev A, Tile0Dev TL,
       const double* dd = A.dblk + 6 * (size_t)r;
       dd0 = dd[0]; dd1 = dd[1]; dd2 = dd[2]; dd3 = dd[3]; dd4 = dd[4]; dd5 = dd[5];
     }
-    // ---- phase 0: operand slice and halo to LDS, owned sums cleared
-    for (int i = tid; i < 3 * nr; i += kTileThreads) {
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const int i = tid + q * kTileThreads;
+      if (i < 3 * nr) {
+        xs[i] = xsl[q];
+        ys[i] = 0.0;
+      }
+    }
+    for (int i = tid + 3 * kTileThreads; i < 3 * nr; i += kTileThreads) {   // tiles of more rows than threads (rare)
       xs[i] = a.x[3 * (size_t)T.row0 + i];
       ys[i] = 0.0;
     }
-    for (int i = tid; i < nh; i += kTileThreads) {
+    if (hc0 >= 0) {
+      const size_t c3 = 3 * (size_t)hc0;
+      const double h0 = a.x[c3], h1 = a.x[c3 + 1], h2 = a.x[c3 + 2];
+      double* d = xs + 3 * (nr + tid);
+      d[0] = h0; d[1] = h1; d[2] = h2;
+    }
+    for (int i = tid + kTileThreads; i < nh; i += kTileThreads) {
       const size_t c3 = 3 * (size_t)TL.hcol[T.h0 + i];
       const double h0 = a.x[c3], h1 = a.x[c3 + 1], h2 = a.x[c3 + 2];
       double* d = xs + 3 * (nr + i);
       d[0] = h0; d[1] = h1; d[2] = h2;
     }
+    if (stamp && tid == 0) stamp[1] = __builtin_amdgcn_s_memtime();
     __syncthreads();
-    // ---- phase 1: one lane per stored block; groups hold whole rows; the next group's loads are issued before
-    // the current one is worked on
+    if (stamp && tid == 0) stamp[2] = __builtin_amdgcn_s_memtime();
+    // ---- phase 1: one lane per stored block; groups hold whole rows.  A wave takes its next group from the LDS
+    // counter and issues that group's loads before it works on the current one (which wave sums which group does
+    // not change a single bit of the result: every group writes its own rows)
     while (has) {
-      const int gn = g + NW;
+      int gn = 0;
+      if (lane == 0) gn = atomicAdd(next_group, 1);
+      gn = __builtin_amdgcn_readfirstlane(gn);
       const bool hasn = gn < T.g1;
       TileGroupLoad nxt;
       nxt.valid = false;
@@ -671,7 +702,9 @@ __global__ __launch_bounds__(kTileThreads) void k_spmv0t(Sym0Dev A, Tile0Dev TL,
       g = gn;
       has = hasn;
     }
+    if (stamp && tid == 0) stamp[3] = __builtin_amdgcn_s_memtime();
     __syncthreads();
+    if (stamp && tid == 0) stamp[4] = __builtin_amdgcn_s_memtime();
     // ---- phase 2: one thread per row: staged entries in order, owned part, diagonal block, epilogue
     for (int i = tid; i < nr; i += kTileThreads) {
       const int r = T.row0 + i;
@@ -705,7 +738,9 @@ __global__ __launch_bounds__(kTileThreads) void k_spmv0t(Sym0Dev A, Tile0Dev TL,
       if (a.dotA) dotacc[0] += a.dotA[o] * o0 + a.dotA[o + 1] * o1 + a.dotA[o + 2] * o2;
       if (a.dotA2) dotacc[1] += a.dotA2[o] * o0 + a.dotA2[o + 1] * o1 + a.dotA2[o + 2] * o2;
     }
+    if (stamp && tid == 0) stamp[5] = __builtin_amdgcn_s_memtime();
     __syncthreads();   // the next tile reuses the LDS
+    if (stamp && tid == 0) stamp[6] = __builtin_amdgcn_s_memtime();
   }
   if (a.partials) {
     __shared__ double sm[2][NW];
