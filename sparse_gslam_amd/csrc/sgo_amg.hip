@@ -1407,8 +1407,9 @@ int amg_update(Amg* m, hipStream_t s, std::string* err) {
                  m->gjP[(kb + 1) & 1], m->d_fail);
     }
   }
-  if (hipGetLastError() != hipSuccess) {
-    if (err) *err = "amg_update: kernel launch failed";
+  const hipError_t le = hipGetLastError();
+  if (le != hipSuccess) {
+    if (err) *err = std::string("amg_update: a kernel launch failed: ") + hipGetErrorString(le);
     return SGO_EHIP;
   }
   return SGO_OK;

@@ -516,7 +516,7 @@ int launch_spmv0t(hipStream_t s, const Sym0Dev& A, const Tile0Dev& T, int mode, 
 inline int launch_spmv0_any(hipStream_t s, const Sym0Dev& A, const Tile0Dev& T, int mode, const Spmv0Args& a) {
   return T.ntile > 0 ? launch_spmv0t(s, A, T, mode, a) : launch_spmv0(s, A, mode, a);
 }
-constexpr int kTileLdsMax = 156 * 1024;   // one 1024-thread tile workgroup per CU (160 KiB of LDS)
+constexpr int kTileLdsMax = 157 * 1024;   // one 1024-thread tile workgroup per CU (160 KiB of LDS)
 int launch_spmv_ex(hipStream_t s, const BsrDev& A, int mode, const SpmvArgs& a);  // returns grid
 void launch_update_xr(hipStream_t s, int n, PcgScalars* S, const double* pq_parts, int n_pq, const double* dinv,
                       const double* p, const double* q, double* x, double* r, double* z, double* xs, double omega,

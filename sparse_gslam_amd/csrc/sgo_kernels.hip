@@ -943,8 +943,10 @@ template <int MODE, int NT>
 void launch_spmv0t_inst(hipStream_t s, const Sym0Dev& A, const Tile0Dev& T, const Spmv0Args& a, int grid) {
   static int lds_allowed = 0;   // dynamic LDS beyond 64 KB needs the attribute once per kernel
   if (T.lds_bytes > 65536 && T.lds_bytes > lds_allowed) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spmv0t<MODE, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
-    lds_allowed = 160 * 1024 - 256;
+    constexpr int kDynMax = 160 * 1024 - 2048;   // the kernel's static LDS (scalars, dot partials) comes on top
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spmv0t<MODE, NT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            kDynMax) == hipSuccess)
+      lds_allowed = kDynMax;
   }
   SGO_LAUNCH((k_spmv0t<MODE, NT>), dim3(grid), dim3(NT), (size_t)T.lds_bytes, s, A, T, a);
 }
