@@ -233,6 +233,17 @@ int sgo_plan_rows(int32_t V, const double* poses, const uint8_t* fixed, int32_t 
  * single-rank product exactly.  Must precede sgo_set_graph_se2. */
 int sgo_debug_set_shard(sgo_ctx* ctx, int nranks, int rank);
 
+/* Further test / measurement hooks (no g2o counterpart).
+ * sgo_debug_coarse_rhs: the coarse right-hand side the first half of a multigrid cycle makes from r ([n][3], hessian
+ *   order): first sweep from zero, level-0 residual pass, restriction; under sgo_debug_set_shard this rank's partial
+ *   (the partials of all ranks sum to the single-rank vector: the cycle's small all-reduce).  Returns its length,
+ *   0 without a multi-level hierarchy.  Requires sgo_linearize.
+ * sgo_debug_spmv0_us: mean microseconds of `reps` back-to-back launches of the level-0 Hessian product kernel on the
+ *   resident graph (mode 0 = H x, 1 = residual, 2 = Jacobi sweep); variant 16 selects the wave-group kernel,
+ *   variant 32 prints per-phase cycle stamps of the tile kernel. */
+int sgo_debug_coarse_rhs(sgo_ctx* ctx, const double* r, double* out, int cap);
+double sgo_debug_spmv0_us(sgo_ctx* ctx, int mode, int variant, int reps);
+
 /* Text of the last error on this context (or, with ctx == NULL, of the last failed sgo_create /
  * context-free call on this thread).  Never NULL. */
 const char* sgo_last_error(sgo_ctx* ctx);

@@ -27,7 +27,7 @@ SYMBOLS = [
     "sgo_num_free", "sgo_free_ids", "sgo_linearize", "sgo_hessian_apply", "sgo_solve",
     "sgo_precondition", "sgo_kernel_profile", "sgo_profile_reset", "sgo_profile_overhead_ms", "sgo_comm_unique_id",
     "sgo_comm_init", "sgo_comm_size", "sgo_shard_range", "sgo_debug_set_shard", "sgo_last_error",
-    "sgo_closure_information", "sgo_plan_rows",
+    "sgo_closure_information", "sgo_plan_rows", "sgo_debug_coarse_rhs", "sgo_debug_spmv0_us",
 ]
 
 

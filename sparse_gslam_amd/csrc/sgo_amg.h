@@ -62,11 +62,14 @@ int amg_update(Amg* m, hipStream_t s, std::string* err);
 // the cycle's first level-0 smoothing sweep from zero -- otherwise the cycle computes it first.
 int amg_apply(Amg* m, hipStream_t s, const double* r, double* z, const double* dotvec, double* partials,
               const PcgScalars* S, const double* dotvec2 = nullptr, bool xs0_ready = false);
-// Multi-GPU: the cycle's two level-0 products evaluate the work units [u0, u1) only (this rank's tiles) and
-// all-reduce their result over `comm` (everything else of the cycle runs replicated).
+// Multi-GPU: the cycle's two level-0 products evaluate the work units [u0, u1) only (this rank's tiles = the rows
+// [row0, row1)); the residual pass stays a per-rank partial that the restriction folds into a partial coarse
+// right-hand side, which is all-reduced over `comm` (3 n_c doubles); the post-smoothing pass's result is all-reduced
+// as a whole (3 n doubles).  Everything else of the cycle runs replicated.
 struct Comm;
-void amg_set_shard(Amg* m, Comm* comm, int u0, int u1);
+void amg_set_shard(Amg* m, Comm* comm, int u0, int u1, int row0, int row1);
 bool amg_comm_failed(const Amg* m);
+int amg_debug_coarse_rhs(Amg* m, hipStream_t s, const double* r, double* out_dev, int cap3);   // test hook, see sgo_amg.hip
 double* amg_xs0(Amg* m);     // [n][3] on the device; nullptr for a single-level (dense) hierarchy
 double amg_omega(const Amg* m);
 // true when the last amg_update met a non-positive pivot in the coarsest operator (synchronises `s`)

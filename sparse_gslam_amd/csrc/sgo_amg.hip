@@ -283,8 +283,10 @@ __global__ __launch_bounds__(kBlock) void k_block_products(ProdMap mp, BsrDev XA
 }
 
 // rc[a] = sum over the entries e of column a of P_e^T r[row(e)]   (column-ordered copy of P)
+// Multi-GPU: only the fine rows [row0, row1) contribute (row1 == 0: all) -- the partial coarse right-hand sides of
+// the ranks are then summed by an all-reduce of 3 n_c doubles instead of all-reducing the fine residual.
 __global__ __launch_bounds__(kBlock) void k_restrict_p(PDev P, const double* __restrict__ r, double* __restrict__ rc,
-                                                       const PcgScalars* S) {
+                                                       const PcgScalars* S, int row0, int row1) {
   if (S && S->stop) return;
   const int lane = threadIdx.x & 63;
   const size_t np = (size_t)P.np;
@@ -297,6 +299,7 @@ __global__ __launch_bounds__(kBlock) void k_restrict_p(PDev P, const double* __r
     for (int t = gb + lane; t < ge; t += 64) {
       key = P.t_col[t];
       const size_t i = (size_t)P.t_row[t];
+      if (row1 > 0 && ((int)i < row0 || (int)i >= row1)) continue;
       const double r0 = r[3 * i], r1 = r[3 * i + 1], r2 = r[3 * i + 2];
       double b[9];
       load9_stream(P.t_blk, (size_t)t, np, b);
@@ -387,7 +390,7 @@ __global__ __launch_bounds__(kBlock) void k_level_dinv(BsrDev A) {
 __global__ __launch_bounds__(kBlock) void k_restrict(int ngrp, const int* __restrict__ grp, const int* __restrict__ mem,
                                                      const int* __restrict__ agg, const double* __restrict__ d,
                                                      const double* __restrict__ r, double* __restrict__ rc,
-                                                     const PcgScalars* S) {
+                                                     const PcgScalars* S, int row0, int row1) {
   if (S && S->stop) return;
   const int lane = threadIdx.x & 63;
   int g, gend, gstride;
@@ -399,6 +402,7 @@ __global__ __launch_bounds__(kBlock) void k_restrict(int ngrp, const int* __rest
     for (int t = gb + lane; t < ge; t += 64) {
       const int i = mem[t];
       key = agg[i];
+      if (row1 > 0 && (i < row0 || i >= row1)) continue;
       const double r0 = r[3 * (size_t)i], r1 = r[3 * (size_t)i + 1], r2 = r[3 * (size_t)i + 2];
       acc[0] += r0;
       acc[1] += r1;
@@ -1085,8 +1089,8 @@ struct Amg {
   AmgProf prof;
   Sym0Dev S0;               // level-0 operator in symmetric storage (lv[0].A is its logical view)
   Tile0Dev T0;              // ... and its tile view
-  Comm* comm = nullptr;     // multi-GPU: level-0 products over the units [u0, u1) + all-reduce
-  int u0 = 0, u1 = 0;
+  Comm* comm = nullptr;     // multi-GPU: level-0 products over the units [u0, u1) (= rows [row0, row1)) + all-reduce
+  int u0 = 0, u1 = 0, row0 = 0, row1 = 0;
   bool comm_failed = false;
   DevArena* pool = nullptr;   // the caller's arena (not owned)
   std::vector<AmgLevel> lv;
@@ -1210,6 +1214,7 @@ int cycle(Amg* m, hipStream_t s, int l, const double* rhs, const double* rhs_sub
   AmgLevel& C = m->lv[l + 1];
   const int last = (int)m->lv.size() - 1;
   const double* rhs_eff = rhs;
+  const bool sharded0 = l == 0 && m->comm != nullptr;
   if (l == 0) {
     // finest level, symmetric storage: xs = omega Dinv rhs (first sweep from zero; normally left by the
     // producer of rhs), then the residual rs = rhs - H xs in one pass over the stored blocks
@@ -1227,10 +1232,8 @@ int cycle(Amg* m, hipStream_t s, int l, const double* rhs, const double* rhs_sub
       Scope sc(m->prof, m->T0.ntile > 0 ? K_SPMV0T_RESID : K_SPMV0_RESID, 76.0 * m->S0.npairs + 120.0 * m->S0.n);
       launch_spmv0_any(s, m->S0, m->T0, S0_RESID, a);
     }
-    if (m->comm) {
-      std::string e;
-      if (!m->comm->allreduce_f64(L.rs, 3 * (size_t)L.A.n, s, &e)) m->comm_failed = true;
-    }
+    // multi-GPU: the residual stays a per-rank partial (this rank's rows); the restriction below takes only those
+    // rows and the coarse right-hand side is what gets all-reduced (3 n_c doubles instead of 3 n)
   } else {
     SpmvArgs a{};
     a.b = rhs; a.y = L.rs; a.y2 = L.xs; a.omega = m->cfg.omega; a.S = S;
@@ -1259,11 +1262,15 @@ int cycle(Amg* m, hipStream_t s, int l, const double* rhs, const double* rhs_sub
   if (L.smoothed) {
     Scope sc(m->prof, K_RESTRICT_P, 84.0 * L.P.np + 24.0 * L.A.n + 24.0 * L.nc);
     SGO_LAUNCH(k_restrict_p, dim3(grid_for(L.P.t_ngrp, kWavesPerBlock)), dim3(kBlock), 0, s, L.P,
-               (const double*)res, C.bk, S);
+               (const double*)res, C.bk, S, sharded0 ? m->row0 : 0, sharded0 ? m->row1 : 0);
   } else {
     Scope sc(m->prof, K_RESTRICT, 40.0 * L.A.n + 24.0 * L.nc);
     SGO_LAUNCH(k_restrict, dim3(grid_for(L.mem_ngrp, kWavesPerBlock)), dim3(kBlock), 0, s, L.mem_ngrp, L.mem_grp,
-                       L.mem, L.agg, L.d, res, C.bk, S);
+                       L.mem, L.agg, L.d, res, C.bk, S, sharded0 ? m->row0 : 0, sharded0 ? m->row1 : 0);
+  }
+  if (sharded0) {   // the ranks' partial coarse right-hand sides (each from its own fine rows) -> their sum
+    std::string e;
+    if (!m->comm->allreduce_f64(C.bk, 3 * (size_t)C.A.n, s, &e)) m->comm_failed = true;
   }
   CoarseSol cs;
   if (l + 1 == last) {
@@ -1415,12 +1422,40 @@ int amg_update(Amg* m, hipStream_t s, std::string* err) {
   return SGO_OK;
 }
 
-void amg_set_shard(Amg* m, Comm* comm, int u0, int u1) {
+void amg_set_shard(Amg* m, Comm* comm, int u0, int u1, int row0, int row1) {
   m->comm = comm;
   m->u0 = u0;
   m->u1 = u1;
+  m->row0 = row0;
+  m->row1 = row1;
 }
 bool amg_comm_failed(const Amg* m) { return m && m->comm_failed; }
+// Test hook: the coarse right-hand side the first half of a level-0 cycle produces from r (first sweep from zero,
+// residual pass, restriction) -- with a shard set and no communicator, this rank's PARTIAL coarse right-hand side.
+int amg_debug_coarse_rhs(Amg* m, hipStream_t s, const double* r, double* out_dev, int cap3) {
+  if (!m || m->lv.size() < 2) return 0;
+  AmgLevel& L = m->lv[0];
+  AmgLevel& C = m->lv[1];
+  const int n3c = 3 * C.A.n;
+  if (cap3 < n3c) return -1;
+  launch_precond_bj(s, L.A.n, m->S0.dinv, r, L.xs, m->cfg.omega);
+  Spmv0Args a{};
+  a.x = L.xs; a.b = r; a.y = L.rs;
+  const bool sharded = m->comm != nullptr;
+  if (sharded) {
+    a.u0 = m->u0; a.u1 = m->u1;
+    hipMemsetAsync(L.rs, 0, sizeof(double) * 3 * (size_t)L.A.n, s);
+  }
+  if (!sharded || a.u1 > a.u0) launch_spmv0_any(s, m->S0, m->T0, S0_RESID, a);
+  if (L.smoothed)
+    SGO_LAUNCH(k_restrict_p, dim3(grid_for(L.P.t_ngrp, kWavesPerBlock)), dim3(kBlock), 0, s, L.P, (const double*)L.rs, C.bk,
+               (const PcgScalars*)nullptr, sharded ? m->row0 : 0, sharded ? m->row1 : 0);
+  else
+    SGO_LAUNCH(k_restrict, dim3(grid_for(L.mem_ngrp, kWavesPerBlock)), dim3(kBlock), 0, s, L.mem_ngrp, L.mem_grp, L.mem, L.agg,
+               L.d, (const double*)L.rs, C.bk, (const PcgScalars*)nullptr, sharded ? m->row0 : 0, sharded ? m->row1 : 0);
+  hipMemcpyAsync(out_dev, C.bk, sizeof(double) * n3c, hipMemcpyDeviceToDevice, s);
+  return n3c;
+}
 double* amg_xs0(Amg* m) { return (m && m->lv.size() > 1) ? m->lv[0].xs : nullptr; }
 double amg_omega(const Amg* m) { return m ? m->cfg.omega : 0.0; }
 

@@ -79,6 +79,8 @@ struct sgo_ctx {
   std::string err;
   Comm comm;
   int shard_u0 = 0, shard_u1 = 0, shard_units = 0;   // multi-GPU: this rank's range of level-0 work units (tiles)
+  int shard_row0 = 0, shard_row1 = 0;                //            = these rows
+  std::vector<int> unit_row0;                        // first row of every work unit (+ n at the end)
 
   // graph (host)
   bool has_graph = false;
@@ -813,6 +815,13 @@ int build_structure(sgo_ctx* c, int V, const double* poses, const uint8_t* fixed
   if ((rc = dalloc(c, &S.ublk, 9 * (size_t)nu))) return rc;
   if ((rc = dalloc(c, &S.dblk, 6 * (size_t)n))) return rc;
   if ((rc = dalloc(c, &S.dinv, 6 * (size_t)n))) return rc;
+  c->unit_row0.clear();   // first row of every level-0 work unit (tiles, or wave groups without a tile view)
+  if (tiles_ok && !tiles.empty()) {
+    for (const TileDesc& T : tiles) c->unit_row0.push_back(T.row0);
+  } else {
+    for (int g = 0; g < ngrp; ++g) c->unit_row0.push_back(grow[g]);
+  }
+  c->unit_row0.push_back(n);
   Tile0Dev& TL = c->T0;
   TL = Tile0Dev();
   if (tiles_ok && !tiles.empty()) {
@@ -1132,7 +1141,7 @@ int build_amg(sgo_ctx* c) {
   c->amg = amg_create(c->stream, c->A, c->S0, c->T0, c->H0, c->d_poses, c->d_free_id, cfg, prof, &aerr, &c->amg_scratch,
                       &c->amg_arena);
   if (c->amg) {
-    if (c->comm.nranks > 1 || c->comm.handle) amg_set_shard(c->amg, &c->comm, c->shard_u0, c->shard_u1);
+    if (c->comm.nranks > 1 || c->comm.handle) amg_set_shard(c->amg, &c->comm, c->shard_u0, c->shard_u1, c->shard_row0, c->shard_row1);
     amg_describe(c->amg, &c->solver_desc);
     c->solver_desc = "pcg_amg: " + c->solver_desc;
   } else {
@@ -1319,6 +1328,8 @@ int sgo_set_graph_se2(sgo_ctx* c, int32_t V, const double* poses, const uint8_t*
     c->has_graph = true;
     c->shard_units = c->T0.ntile > 0 ? c->T0.ntile : c->S0.ngrp;
     sgo_shard_range(c->shard_units, c->comm.nranks, c->comm.rank, &c->shard_u0, &c->shard_u1);
+    c->shard_row0 = c->unit_row0.empty() ? 0 : c->unit_row0[c->shard_u0];
+    c->shard_row1 = c->unit_row0.empty() ? c->n : c->unit_row0[c->shard_u1];
     // Chain-like graphs (fewer than ~1.5 edges per free pose: under 4 Hessian blocks per row) are the
     // ill-conditioned ones -- kappa(H) grows with the square of the chain length -- and a relative
     // residual of 1e-8 then leaves errors that show in chi2 (3000 poses / 3150 edges: iterates 3e-6 and
@@ -1326,7 +1337,7 @@ int sgo_set_graph_se2(sgo_ctx* c, int32_t V, const double* poses, const uint8_t*
     // cheap ones, so they get a 10x tighter tolerance than opts.pcg_tol.
     c->tol_scale = (c->n > 0 && (long long)c->A.nslot < 4LL * c->n) ? 0.1 : 1.0;   // logical slots: 2 per edge + 1 per row
     c->solver_desc = "pcg_block_jacobi";
-    if (c->opts.solver == SGO_SOLVER_PCG_AMG && c->n > 0 && (c->comm.nranks == 1 || c->comm.handle)) {
+    if (c->opts.solver == SGO_SOLVER_PCG_AMG && c->n > 0) {
       // the hierarchy is built from the Hessian at the initial poses (strength of connection)
       const double ta0 = wall_s();
       if ((rc = do_linearize(c)) != SGO_OK || (rc = build_amg(c)) != SGO_OK) {
@@ -1734,6 +1745,24 @@ double sgo_debug_spmv0_us(sgo_ctx* c, int mode, int variant, int reps) {
                  ph[5] / c->T0.ntile);
   }
   return 1e3 * ms / reps;
+}
+
+// Test hook for the multi-GPU scheme: the coarse right-hand side the first half of a multigrid cycle makes from r
+// (hessian order, [n][3]): first sweep from zero, level-0 residual pass, restriction.  Under sgo_debug_set_shard it
+// is this rank's partial; the partials of all ranks sum to the single-rank vector.  Returns its length (3 x coarse
+// nodes), 0 without a multi-level hierarchy, < 0 on error.  Requires sgo_linearize.
+int sgo_debug_coarse_rhs(sgo_ctx* c, const double* r, double* out, int cap) {
+  int rc = check_graph(c);
+  if (rc) return rc;
+  if (!r || !out || !c->linearized) return SGO_EINVAL;
+  if (!c->amg) return 0;
+  if ((rc = vec_to_device(c, r, c->d_s1))) return rc;
+  const int n3 = amg_debug_coarse_rhs(c->amg, c->stream, c->d_s1, c->d_s2, 3 * c->n);
+  if (n3 <= 0) return n3;
+  if (cap < n3) return SGO_EINVAL;
+  HIP_TRY(c, hipMemcpyAsync(out, c->d_s2, sizeof(double) * (size_t)n3, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return n3;
 }
 
 int sgo_kernel_profile(sgo_ctx* c, sgo_kernel_stat* out, int cap) {

@@ -198,6 +198,40 @@ def test_rank_partial_products_sum_to_the_single_rank_product_bitwise():
         assert owners.max() == 1
 
 
+def test_rank_partial_coarse_right_hand_sides_sum_to_the_single_rank_one():
+    """The other exchange of the multi-GPU cycle: each rank restricts the residual of ITS rows only and the
+    partial coarse right-hand sides are all-reduced (3 n_c doubles).  Emulated ranks on one GPU: the partials sum
+    to the single-rank vector (to rounding: the per-column sums are split differently)."""
+    import ctypes as C
+    L = capi.lib()
+    L.sgo_debug_coarse_rhs.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int]
+    g = synth.config("C2", info_mode="full")
+    n = int((~g.fixed).sum())
+    r = np.random.default_rng(4).standard_normal((n, 3))
+
+    def coarse(o):
+        out = np.zeros(3 * n)
+        k = L.sgo_debug_coarse_rhs(o._h, r.ctypes.data_as(C.POINTER(C.c_double)), out.ctypes.data_as(C.POINTER(C.c_double)), out.size)
+        assert k > 0
+        return out[:k].copy()
+
+    with capi.Optimizer(0) as full:
+        full.set_graph(*g.arrays())
+        full.linearize()
+        fc = coarse(full)
+    for world in (2, 5):
+        acc = np.zeros_like(fc)
+        for rk in range(world):
+            with capi.Optimizer(0) as o:
+                o.debug_set_shard(world, rk)
+                o.set_graph(*g.arrays())
+                o.linearize()
+                part = coarse(o)
+            assert np.abs(part).max() > 0 and not np.allclose(part, fc)
+            acc += part
+        assert np.abs(acc - fc).max() <= 1e-12 * np.abs(fc).max(), world
+
+
 def test_single_rank_rccl_communicator_runs_the_collective_path():
     """Exercises the RCCL binding with a 1-rank communicator: dlopen, ncclCommInitRank and a real
     ncclAllReduce after every level-0 product of the solve and on chi2 (the multi-GPU code path: sharded
