@@ -73,13 +73,18 @@ typedef struct sgo_opts {
                               (hipExtLaunchKernelGGL; forces use_graph=0); per-kernel totals through
                               sgo_kernel_profile() */
   int32_t verbose;         /* mirrors SparseOptimizer::setVerbose (graphs.cpp:21) */
-  int32_t reserved[8];
+  int32_t direct_rows;     /* small-graph path (solver PCG_AMG, one GPU): a graph with at most this many free poses
+                              whose elimination analysis fits -- trajectory chain + closures covered by <= 50
+                              separator poses -- runs sgo_optimize_gn as ONE kernel launch of a sparse block
+                              LDL^T (nested dissection of the chain, separators dense in LDS); 0 = never
+                              (env SGO_DIRECT_ROWS); the single-step entry points keep using the PCG path */
+  int32_t reserved[7];
 } sgo_opts;
 
 /* Defaults (also applied when opts == NULL):
  * solver = PCG_AMG (graphs with <= 400 free poses are preconditioned by an explicit dense inverse,
  * i.e. solved directly; falls back to PCG_BJ only when a larger graph cannot be coarsened),
- * pcg_tol = 1e-8, pcg_maxit = 20000, pcg_chunk = 16, use_graph = 1. */
+ * pcg_tol = 1e-8, pcg_maxit = 20000, pcg_chunk = 16, use_graph = 1, direct_rows = 2048. */
 void sgo_default_opts(sgo_opts* o);
 
 typedef struct sgo_stats {
@@ -89,7 +94,7 @@ typedef struct sgo_stats {
                                                 updates applied before the failure) */
   double chi2[SGO_MAX_ITERS + 1];            /* activeChi2 at the START of iteration k; [iters_done] = final */
   double robust_chi2[SGO_MAX_ITERS + 1];     /* activeRobustChi2, same indexing */
-  int32_t pcg_iters[SGO_MAX_ITERS];          /* PCG iterations of GN iteration k */
+  int32_t pcg_iters[SGO_MAX_ITERS];          /* PCG iterations of GN iteration k (0 on the direct small-graph path) */
   int32_t pcg_converged[SGO_MAX_ITERS];      /* 1 = reached pcg_tol */
   double pcg_relres[SGO_MAX_ITERS];          /* final ||r|| / ||b|| (recurrence residual) */
   double seconds[SGO_MAX_ITERS];             /* device time of GN iteration k (HIP events) */
@@ -243,6 +248,11 @@ int sgo_debug_set_shard(sgo_ctx* ctx, int nranks, int rank);
  *   variant 32 prints per-phase cycle stamps of the tile kernel. */
 int sgo_debug_coarse_rhs(sgo_ctx* ctx, const double* r, double* out, int cap);
 double sgo_debug_spmv0_us(sgo_ctx* ctx, int mode, int variant, int reps);
+
+/* One line naming the solver the resident graph's sgo_optimize_gn runs ("direct_ldlt: ...", "pcg_amg: L0 n=... ",
+ * "pcg_block_jacobi ..."): which path a graph took, and for the direct path's refusals the reason
+ * ("pcg_amg: ...; direct path not used: more separators than the dense block holds").  Never NULL. */
+const char* sgo_solver_description(sgo_ctx* ctx);
 
 /* Text of the last error on this context (or, with ctx == NULL, of the last failed sgo_create /
  * context-free call on this thread).  Never NULL. */

@@ -28,6 +28,7 @@ SYMBOLS = [
     "sgo_precondition", "sgo_kernel_profile", "sgo_profile_reset", "sgo_profile_overhead_ms", "sgo_comm_unique_id",
     "sgo_comm_init", "sgo_comm_size", "sgo_shard_range", "sgo_debug_set_shard", "sgo_last_error",
     "sgo_closure_information", "sgo_plan_rows", "sgo_debug_coarse_rhs", "sgo_debug_spmv0_us",
+    "sgo_solver_description",
 ]
 
 
@@ -38,7 +39,8 @@ class SgoError(RuntimeError):
 class Opts(C.Structure):
     _fields_ = [("struct_size", C.c_int32), ("solver", C.c_int32), ("pcg_tol", C.c_double),
                 ("pcg_maxit", C.c_int32), ("pcg_chunk", C.c_int32), ("use_graph", C.c_int32),
-                ("profile", C.c_int32), ("verbose", C.c_int32), ("reserved", C.c_int32 * 8)]
+                ("profile", C.c_int32), ("verbose", C.c_int32), ("direct_rows", C.c_int32),
+                ("reserved", C.c_int32 * 7)]
 
 
 class Stats(C.Structure):
@@ -110,6 +112,8 @@ def lib():
     L.sgo_solve.argtypes = [vp, d, d]
     L.sgo_precondition.argtypes = [vp, d, d]
     L.sgo_kernel_profile.argtypes = [vp, C.POINTER(KernelStat), C.c_int]
+    L.sgo_solver_description.restype = C.c_char_p
+    L.sgo_solver_description.argtypes = [vp]
     L.sgo_profile_reset.argtypes = [vp]
     L.sgo_profile_overhead_ms.restype = C.c_double
     L.sgo_profile_overhead_ms.argtypes = [vp]
@@ -335,6 +339,10 @@ class Optimizer:
         rr = C.c_double()
         it = self._check(lib().sgo_solve(self._h, _dp(x), C.byref(rr)), "sgo_solve")
         return x, it, rr.value
+
+    def solver_description(self) -> str:
+        """Which solver sgo_optimize_gn runs for the resident graph (sgo_solver_description)."""
+        return lib().sgo_solver_description(self._h).decode()
 
     # -- profiling
     def kernel_profile(self):

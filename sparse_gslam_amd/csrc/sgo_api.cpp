@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "sgo_amg.h"
+#include "sgo_direct.h"
 #include "sgo_comm.h"
 #include "sgo_internal.h"
 
@@ -110,8 +111,14 @@ struct sgo_ctx {
   bool linearized = false;
 
   Amg* amg = nullptr;             // non-null when the AMG preconditioner is active
+  bool amg_pending = false;       // the hierarchy is built on first use (graphs that optimize() through `direct`)
+  Direct* direct = nullptr;       // small-graph path: optimize() is one launch (sgo_direct.h)
+  std::string direct_why;         // why the last graph did not qualify for it
+  DirectResult* d_dres = nullptr;
+  DirectResult* h_dres = nullptr; // pinned
   double* d_zparts = nullptr;     // [2][kMaxPartials] partials of r.z from the cycle's last kernel
   std::string solver_desc;
+  std::string solver_text;        // what sgo_solver_description hands out
 
   hipGraphExec_t pcg_exec = nullptr;
   int pcg_exec_chunk = 0;
@@ -198,6 +205,11 @@ void free_graph(sgo_ctx* c) {
     amg_destroy(c->amg);
     c->amg = nullptr;
   }
+  if (c->direct) {
+    direct_destroy(c->direct);
+    c->direct = nullptr;
+  }
+  c->amg_pending = false;
   c->amg_arena.rewind();
   c->graph_arena.rewind();   // the caller has synchronised the stream: nothing in flight reads these arrays
   c->pcg_pred = 0;
@@ -1153,6 +1165,17 @@ int build_amg(sgo_ctx* c) {
 
 // Vectors over the free vertices cross the API in g2o's hessian order and live on the device in the
 // internal (Hilbert) row order: permute on the way (test / single-step entry points only).
+// Graphs that optimize() through the single-launch direct path build their multigrid hierarchy only when a
+// single-step entry point (sgo_solve, sgo_precondition) or the PCG fallback asks for it.
+int ensure_amg(sgo_ctx* c) {
+  if (!c->amg_pending) return SGO_OK;
+  c->amg_pending = false;
+  int rc;
+  if ((rc = do_linearize(c)) != SGO_OK || (rc = build_amg(c)) != SGO_OK) return rc;
+  c->linearized = false;
+  return SGO_OK;
+}
+
 int vec_to_device(sgo_ctx* c, const double* host_asc, double* dev) {
   std::vector<double> tmp(3 * (size_t)c->n);
   for (int i = 0; i < c->n; ++i)
@@ -1218,6 +1241,8 @@ void sgo_default_opts(sgo_opts* o) {
   o->use_graph = 1;
   o->profile = 0;
   o->verbose = 0;
+  o->direct_rows = 2048;
+  if (const char* s = std::getenv("SGO_DIRECT_ROWS")) o->direct_rows = std::atoi(s);
   if (const char* s = std::getenv("SGO_SOLVER")) {
     if (!std::strcmp(s, "pcg") || !std::strcmp(s, "bj")) o->solver = SGO_SOLVER_PCG_BJ;
     else if (!std::strcmp(s, "amg")) o->solver = SGO_SOLVER_PCG_AMG;
@@ -1269,7 +1294,9 @@ sgo_ctx* sgo_create(int device, const sgo_opts* opts) {
       (e = hipHostMalloc((void**)&c->h_S2, 2 * sizeof(PcgScalars))) != hipSuccess ||
       (e = hipEventCreateWithFlags(&c->ev_S[0], hipEventDisableTiming)) != hipSuccess ||
       (e = hipEventCreateWithFlags(&c->ev_S[1], hipEventDisableTiming)) != hipSuccess ||
-      (e = hipHostMalloc((void**)&c->h_hist, sizeof(double) * 2 * (SGO_MAX_ITERS + 2))) != hipSuccess) {
+      (e = hipHostMalloc((void**)&c->h_hist, sizeof(double) * 2 * (SGO_MAX_ITERS + 2))) != hipSuccess ||
+      (e = hipHostMalloc((void**)&c->h_dres, sizeof(DirectResult))) != hipSuccess ||
+      (e = hipMalloc((void**)&c->d_dres, sizeof(DirectResult))) != hipSuccess) {
     g_err = std::string("context setup: ") + hipGetErrorString(e);
     sgo_destroy(c);
     return nullptr;
@@ -1293,8 +1320,17 @@ void sgo_destroy(sgo_ctx* c) {
   for (hipEvent_t ev : c->ev_S)
     if (ev) hipEventDestroy(ev);
   if (c->h_hist) hipHostFree(c->h_hist);
+  if (c->h_dres) hipHostFree(c->h_dres);
+  if (c->d_dres) hipFree(c->d_dres);
   if (c->stream) hipStreamDestroy(c->stream);
   delete c;
+}
+
+const char* sgo_solver_description(sgo_ctx* c) {
+  if (!c || !c->has_graph) return "";
+  c->solver_text = c->solver_desc;
+  if (!c->direct && !c->direct_why.empty()) c->solver_text += "; direct path not used: " + c->direct_why;
+  return c->solver_text.c_str();
 }
 
 const char* sgo_last_error(sgo_ctx* c) { return c ? c->err.c_str() : g_err.c_str(); }
@@ -1337,7 +1373,30 @@ int sgo_set_graph_se2(sgo_ctx* c, int32_t V, const double* poses, const uint8_t*
     // cheap ones, so they get a 10x tighter tolerance than opts.pcg_tol.
     c->tol_scale = (c->n > 0 && (long long)c->A.nslot < 4LL * c->n) ? 0.1 : 1.0;   // logical slots: 2 per edge + 1 per row
     c->solver_desc = "pcg_block_jacobi";
-    if (c->opts.solver == SGO_SOLVER_PCG_AMG && c->n > 0) {
+    c->direct_why.clear();
+    if (c->opts.solver == SGO_SOLVER_PCG_AMG && c->n > 0 && c->opts.direct_rows > 0 && c->comm.nranks <= 1 && !c->comm.handle) {
+      // Small graphs (the reference's own sizes): optimize() as ONE launch of a sparse direct solver when the
+      // elimination analysis fits (sgo_direct.h); the multigrid hierarchy is then built only if a single-step
+      // entry point asks for it.
+      std::string derr;
+      c->direct = direct_create(c->stream, &c->graph_arena, V, c->n, c->free_id.data(), E, ei, ej, c->opts.direct_rows,
+                                &c->direct_why, &derr);
+      if (!c->direct && !derr.empty()) {
+        c->err = derr;
+        free_graph(c);
+        return SGO_EHIP;
+      }
+      if (c->direct) {
+        const DirectInfo& di = direct_info(c->direct);
+        c->solver_desc = "direct_ldlt: " + std::to_string(di.n_chain) + " chain poses in " + std::to_string(di.levels) +
+                         " levels + " + std::to_string(di.n_sep) + " separators (dense), " + std::to_string(di.slots) +
+                         " stored blocks, " + std::to_string(di.contributions) + " block products per factorisation; pcg_amg on demand";
+        c->amg_pending = true;
+      } else if (c->opts.verbose) {
+        std::fprintf(stderr, "[sgo] direct path not used: %s\n", c->direct_why.c_str());
+      }
+    }
+    if (c->opts.solver == SGO_SOLVER_PCG_AMG && c->n > 0 && !c->direct) {
       // the hierarchy is built from the Hessian at the initial poses (strength of connection)
       const double ta0 = wall_s();
       if ((rc = do_linearize(c)) != SGO_OK || (rc = build_amg(c)) != SGO_OK) {
@@ -1480,6 +1539,7 @@ int sgo_linearize(sgo_ctx* c, double* b, double* diag, double* plain, double* ro
     int rc = check_graph(c);
     if (rc) return rc;
     if (c->n == 0) return SGO_ENOTHING;
+    if ((rc = ensure_amg(c))) return rc;
     if ((rc = do_chi2(c, c->d_hist, nullptr))) return rc;
     if ((rc = do_linearize(c))) return rc;
     std::vector<double> dgb(9 * (size_t)c->n);
@@ -1576,6 +1636,50 @@ int sgo_optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
     }
     if (c->n == 0) return SGO_ENOTHING;
     const double t0 = wall_s();
+    if (c->direct) {
+      // ---- small-graph path: the whole call is one launch (sgo_direct.h)
+      {
+        Scope sc(c, K_DIRECT, direct_bytes(c->direct, c->E, iters));
+        hipError_t he = direct_optimize(c->direct, c->stream, c->el, c->d_poses, iters, c->d_hist, c->d_dres);
+        if (he != hipSuccess) {
+          c->err = std::string("k_direct launch: ") + hipGetErrorString(he);
+          return SGO_EHIP;
+        }
+      }
+      HIP_TRY(c, hipMemcpyAsync(c->h_hist, c->d_hist, sizeof(double) * 2 * (size_t)(iters + 1), hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(c, hipMemcpyAsync(c->h_dres, c->d_dres, sizeof(DirectResult), hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(c, hipStreamSynchronize(c->stream));
+      prof_flush(c);
+      c->linearized = false;
+      const DirectResult& R = *c->h_dres;
+      const int done = R.done;
+      if (R.fail) {
+        c->err = std::string("direct factorisation failed in GN iteration ") + std::to_string(done) +
+                 (R.fail == 1 ? " (a pivot block is not positive definite: Hessian not positive definite)"
+                              : " (non-finite update)") + "; the step was not applied";
+      }
+      if (out) {
+        out->iters_done = done;
+        for (int k = 0; k <= done; ++k) {
+          out->chi2[k] = c->h_hist[2 * k];
+          out->robust_chi2[k] = c->h_hist[2 * k + 1];
+        }
+        const int timed = std::min(iters, done + (R.fail ? 1 : 0));
+        for (int k = 0; k < timed; ++k) {
+          out->pcg_iters[k] = 0;
+          out->pcg_converged[k] = (k < done) ? 1 : 0;
+          out->seconds_linearize[k] = 1e-8 * (double)(R.stamp[2 * k + 1] - R.stamp[2 * k]);
+          out->seconds[k] = 1e-8 * (double)(R.stamp[2 * k + 2] - R.stamp[2 * k]);
+          out->seconds_solve[k] = out->seconds[k] - out->seconds_linearize[k];
+        }
+        out->seconds_total = wall_s() - t0;
+      }
+      if (c->opts.verbose)
+        for (int k = 0; k <= done; ++k)
+          std::fprintf(stderr, "[sgo] iteration= %d\t chi2= %.9e\t robust= %.9e\t (direct)\n", k, c->h_hist[2 * k], c->h_hist[2 * k + 1]);
+      return R.fail ? 0 : done;
+    }
+    if ((rc = ensure_amg(c))) return rc;
     // per-iteration time stamps: events are kept in the context and reused by later calls
     while (c->iter_events.size() < 3 * (size_t)iters + 1) {
       hipEvent_t e = nullptr;
@@ -1755,6 +1859,7 @@ int sgo_debug_coarse_rhs(sgo_ctx* c, const double* r, double* out, int cap) {
   int rc = check_graph(c);
   if (rc) return rc;
   if (!r || !out || !c->linearized) return SGO_EINVAL;
+  if (ensure_amg(c)) return 0;
   if (!c->amg) return 0;
   if ((rc = vec_to_device(c, r, c->d_s1))) return rc;
   const int n3 = amg_debug_coarse_rhs(c->amg, c->stream, c->d_s1, c->d_s2, 3 * c->n);

@@ -18,6 +18,38 @@ __device__ __forceinline__ double norm_theta(double t) {
   return t;
 }
 
+// EdgeSE2::computeError with the cached inverse measurement Zi:
+//   e = toVector( Zi * (Xi^-1 * Xj) ),  SE2 algebra literal (g2o SE2::operator* / inverse).
+__device__ __forceinline__ void edge_error(double xi, double yi, double ti, double xj, double yj, double tj,
+                                           double zx, double zy, double zt, double sz, double cz,
+                                           double (&e)[3]) {
+  const double tin = norm_theta(-ti);
+  double s1, c1;
+  sincos(tin, &s1, &c1);
+  const double ix = c1 * (-xi) - s1 * (-yi);
+  const double iy = s1 * (-xi) + c1 * (-yi);
+  const double dx = ix + c1 * xj - s1 * yj;
+  const double dy = iy + s1 * xj + c1 * yj;
+  const double dth = norm_theta(tin + tj);
+  e[0] = zx + cz * dx - sz * dy;
+  e[1] = zy + sz * dx + cz * dy;
+  e[2] = norm_theta(zt + dth);
+}
+
+// RobustKernelDCS::robustify; phi < 0: no kernel.
+__device__ __forceinline__ void dcs(double e2, double phi, double* rho0, double* rho1) {
+  double r0 = e2, r1 = 1.0;
+  if (phi >= 0.0) {
+    const double scale = (2.0 * phi) / (phi + e2);
+    if (!(scale >= 1.0)) {
+      r0 = scale * e2 * scale;
+      r1 = scale * scale;
+    }
+  }
+  *rho0 = r0;
+  *rho1 = r1;
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);

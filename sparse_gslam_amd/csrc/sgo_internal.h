@@ -277,6 +277,7 @@ enum KernelId : int {
   K_SPMV0T_AX,          // the level-0 products, tile kernel
   K_SPMV0T_RESID,
   K_SPMV0T_JACOBI,
+  K_DIRECT,
   K_COUNT
 };
 extern const char* const kKernelNames[K_COUNT];
