@@ -364,7 +364,7 @@ struct RowPlan {
 
 int plan_rows(int V, const double* poses, const uint8_t* fixed, int E, const int32_t* ei, const int32_t* ej, int tile_div,
               std::string* err, RowPlan& P) {
-  const bool verbose = std::getenv("SGO_VERBOSE") != nullptr && E > 200000;
+  const bool verbose = std::getenv("SGO_VERBOSE") != nullptr && (E > 200000 || std::atoi(std::getenv("SGO_VERBOSE")) > 1);
   double tl = wall_s();
   auto lap = [&](const char* what) {
     const double t = wall_s();
@@ -544,7 +544,7 @@ int build_structure(sgo_ctx* c, int V, const double* poses, const uint8_t* fixed
     const int prc = plan_rows(V, poses, fixed, E, ei, ej, tile_div, &c->err, P);
     if (prc != SGO_OK) return prc;
   }
-  const bool verbose = c->opts.verbose && E > 200000;
+  const bool verbose = c->opts.verbose && (E > 200000 || c->opts.verbose > 1);
   double tl = wall_s();
   auto lap = [&](const char* what) {
     const double t = wall_s();
@@ -1379,6 +1379,7 @@ int sgo_set_graph_se2(sgo_ctx* c, int32_t V, const double* poses, const uint8_t*
       // elimination analysis fits (sgo_direct.h); the multigrid hierarchy is then built only if a single-step
       // entry point asks for it.
       std::string derr;
+      const double td0 = wall_s();
       c->direct = direct_create(c->stream, &c->graph_arena, V, c->n, c->free_id.data(), E, ei, ej, c->opts.direct_rows,
                                 &c->direct_why, &derr);
       if (!c->direct && !derr.empty()) {
@@ -1386,6 +1387,7 @@ int sgo_set_graph_se2(sgo_ctx* c, int32_t V, const double* poses, const uint8_t*
         free_graph(c);
         return SGO_EHIP;
       }
+      if (c->opts.verbose) std::fprintf(stderr, "[sgo] set_graph: direct-path analysis %.2f ms\n", 1e3 * (wall_s() - td0));
       if (c->direct) {
         const DirectInfo& di = direct_info(c->direct);
         c->solver_desc = "direct_ldlt: " + std::to_string(di.n_chain) + " chain poses in " + std::to_string(di.levels) +
@@ -1674,7 +1676,15 @@ int sgo_optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
         }
         out->seconds_total = wall_s() - t0;
       }
-      if (c->opts.verbose)
+      if (c->opts.verbose && done > 0)
+        std::fprintf(stderr, "[sgo] direct: %.0f MHz shader clock during the call\n",
+                     (double)R.cycles / (1e-2 * (double)(R.stamp[R.fail ? 2 * done + 2 : 2 * iters + 1] - R.stamp[0])));
+      if (c->opts.verbose && done > 0)
+        std::fprintf(stderr, "[sgo] direct, last iteration [us]: edges %.1f, assembly %.1f, sparse forward %.1f, separators %.1f + %.1f, "
+                     "sparse backward %.1f, update %.1f\n", 1e-2 * (double)(R.phase[1] - R.phase[0]), 1e-2 * (double)(R.phase[2] - R.phase[1]),
+                     1e-2 * (double)(R.phase[3] - R.phase[2]), 1e-2 * (double)(R.phase[4] - R.phase[3]), 1e-2 * (double)(R.phase[5] - R.phase[4]),
+                     1e-2 * (double)(R.phase[6] - R.phase[5]), 1e-2 * (double)(R.phase[7] - R.phase[6]));
+      if (c->opts.verbose > 1)
         for (int k = 0; k <= done; ++k)
           std::fprintf(stderr, "[sgo] iteration= %d\t chi2= %.9e\t robust= %.9e\t (direct)\n", k, c->h_hist[2 * k], c->h_hist[2 * k + 1]);
       return R.fail ? 0 : done;

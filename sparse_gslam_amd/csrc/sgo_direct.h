@@ -30,6 +30,9 @@ struct DirectResult {
   int fail;          // 0 ok; 1 a pivot block was not positive definite; 2 non-finite update
   int fail_iter;
   int pad;
+  unsigned long long cycles;     // shader clock cycles (s_memtime) between the first and the last stamp
+  unsigned long long phase[8];   // wall_clock64 of the LAST iteration: start, edges done, assembled, sparse forward done,
+                                 // separators eliminated, separators solved, sparse backward done, poses updated
   unsigned long long stamp[2 * SGO_MAX_ITERS + 4];   // wall_clock64 (100 MHz) at the start of iteration k [2k] and
                                                      // after its assembly [2k + 1]; the closing chi2 pass starts at
                                                      // [2 iters] and ends at [2 iters + 1]; after a failure in

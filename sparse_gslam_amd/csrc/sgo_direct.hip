@@ -48,36 +48,42 @@ constexpr size_t kLdsBudget = 150 * 1024;
 enum : unsigned { T_OFF = 0, T_DIAG = 1, T_DENSE = 2, T_RHS = 3 };
 
 struct DirectDev {
-  int n, nI, ns, NL, E, NB, tri, nss;
-  const int* vertex_pos;      // [V] elimination position of a vertex, -1 fixed
-  const int* pos_vertex;      // [n]
-  const int* vptr;            // [n + 1] incident edges of a position ...
-  const int* vlist;           // ... (edge << 1 | side)
-  const int* slot_row;        // [NB] row position of a stored block (-1: dummy slot of an empty column)
-  const int* slot_col;        // [NB] column position (-1: padding)
-  const int* slot_edge;       // [NB] first edge of the pair (edge << 1 | transposed), -1 fill
+  int n, nI, ns, NL, E, NB, tri, nzero, nmulti;
+  const int* pos_vertex;      // [n] vertex id of an elimination position
+  const int4* vrec;           // [n] incident edges of a position, (edge << 1 | side), -1 none; w <= -2: more at vover[-2 - w]
+  const int* vover;           // overflow lists: count, entries
+  const unsigned* edge_tgt;   // [E] where the edge's off-diagonal block goes: kind << 30 | transposed << 29 | index
+                              //     kind 0 nowhere (a fixed endpoint), 1 stored block, 2 separator block (si << 12 | sj),
+                              //     3 the pair has several edges (summed afterwards: `multi`)
+  const int* zero_slots;      // [nzero] stored blocks that are pure fill
+  const int2* multi;          // [nmulti] pairs with several edges: {target as above (kind 1 / 2), first edge << 1 | transposed}
   const int* enext;           // [E] next edge of the same pair, same encoding
-  const int* ss_pair;         // [nss] separator pairs with edges: (si << 12 | sj), si > sj
-  const int* ss_edge;         // [nss]
-  const int* lslot;           // [NL + 1] slot range of a level (multiples of 64)
-  const int* ltask;           // [NL + 1] task range of a level
-  const unsigned* tk_target;  // kind << 28 | index
-  const int* tk_cptr;         // contributions of a task
-  const int* ca;              // slot of W_ik
-  const int* cb;              // slot of W_jk
+  const int2* slot_rc;        // [NB] {row position (-1: dummy slot of an empty column), column position (-1: padding)}
+  const int* lmeta;           // [2 (NL + 1)] slot range (multiples of 64) and task range of every level
+  const int4* tk;             // forward tasks: {kind << 28 | index, first contribution, end, 0}
+  const int4* ctr;            // contributions: {slot of W_ik, slot of W_jk, k, 0}
   const unsigned short* dpair;  // dense block pairs (bi << 8 | bj), bi >= bj, sorted by bj descending
   double* Wd;                 // [nI][9] diagonal blocks of the sparse columns
   double* Wo;                 // [NB][9] stored blocks
-  double* escr;               // [E][27] per-edge terms of the current linearisation
+  double* escr;               // [E][27] per-edge terms of the current linearisation: Hii(6) bi(3) Hjj(6) bj(3) [Hij(9)]
+  double* zsc;                // [2][E] sin / cos of the inverse measurement's angle (constant per edge)
 };
 
+// 1 / x by the hardware reciprocal + two Newton steps (the IEEE division sequence is 3x longer and sits on the
+// critical path of every pivot)
+__device__ __forceinline__ double fast_rcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = r * (2.0 - x * r);
+  r = r * (2.0 - x * r);
+  return r;
+}
 // inverse of a symmetric 3x3 (d00 d01 d02 d11 d12 d22); false when the block is not positive definite
 __device__ __forceinline__ bool inv_sym3(double d00, double d01, double d02, double d11, double d12, double d22,
                                          double (&iv)[6]) {
   const double c00 = d11 * d22 - d12 * d12, c01 = d02 * d12 - d01 * d22, c02 = d01 * d12 - d02 * d11;
   const double c11 = d00 * d22 - d02 * d02, c12 = d01 * d02 - d00 * d12, c22 = d00 * d11 - d01 * d01;
   const double det = d00 * c00 + d01 * c01 + d02 * c02;
-  const double id = 1.0 / det;
+  const double id = fast_rcp(det);
   iv[0] = c00 * id; iv[1] = c01 * id; iv[2] = c02 * id; iv[3] = c11 * id; iv[4] = c12 * id; iv[5] = c22 * id;
   return d00 > 0.0 && c22 > 0.0 && det > 0.0 && isfinite(det);
 }
@@ -91,45 +97,68 @@ __device__ __forceinline__ void mul_sym(const double (&W)[9], const double (&S)[
     T[3 * r + 2] = a * S[2] + b * S[4] + c * S[5];
   }
 }
+// Stored 3x3 blocks are 80-byte records (row-major, one double of padding): 16-byte aligned, so a gathered
+// block is four 16-byte loads + one 8-byte load per lane instead of nine 8-byte ones.
+constexpr int kBS = 10;
 __device__ __forceinline__ void load9g(const double* __restrict__ p, double (&v)[9]) {
-#pragma unroll
-  for (int c = 0; c < 9; ++c) v[c] = p[c];
+  const double2* __restrict__ q = reinterpret_cast<const double2*>(p);
+  const double2 a = q[0], b = q[1], c = q[2], d = q[3];
+  v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y; v[4] = c.x; v[5] = c.y; v[6] = d.x; v[7] = d.y;
+  v[8] = p[8];
 }
-__device__ __forceinline__ double readlane63(double v) {
-  const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63), hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+__device__ __forceinline__ void store9g(double* __restrict__ p, const double (&v)[9]) {
+  double2* __restrict__ q = reinterpret_cast<double2*>(p);
+  q[0] = make_double2(v[0], v[1]);
+  q[1] = make_double2(v[2], v[3]);
+  q[2] = make_double2(v[4], v[5]);
+  q[3] = make_double2(v[6], v[7]);
+  p[8] = v[8];
+}
+__device__ __forceinline__ double readlane_d(double v, int l) {   // l wave-uniform
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
   return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ int tri_at(int i, int j) { return i * (i + 1) / 2 + j; }   // i >= j
 
 // Everything an edge contributes at the current poses: rec = Hii(6) bi(3) Hjj(6) bj(3) Hij(9)
-// (EdgeSE2::computeError, linearizeOplus, RobustKernelDCS::robustify, constructQuadraticForm; same arithmetic as
-// k_linearize).  Returns e2 and rho0 for the chi2 sums.
-__device__ __forceinline__ void edge_terms(const EdgeListDev& el, int k, const double* __restrict__ poses, bool jac,
-                                           double* __restrict__ rec, double* e2_out, double* rho_out) {
+// (EdgeSE2::computeError, linearizeOplus, RobustKernelDCS::robustify, constructQuadraticForm; the arithmetic of
+// k_linearize, with sin / cos of the inverse measurement's angle taken from zsc and sin(-t_i) = -sin(t_i)).
+// Returns e2 and rho0 for the chi2 sums.
+__device__ __forceinline__ void edge_terms(const EdgeListDev& el, const double* __restrict__ zsc, int k,
+                                           const double* __restrict__ poses, bool jac, double* __restrict__ rec,
+                                           double (&hij)[9], double* e2_out, double* rho_out) {
   const size_t E = (size_t)el.E;
   const int vi = el.vi[k], vj = el.vj[k];
-  const double xi = poses[3 * (size_t)vi], yi = poses[3 * (size_t)vi + 1], ti = poses[3 * (size_t)vi + 2];
-  const double xj = poses[3 * (size_t)vj], yj = poses[3 * (size_t)vj + 1], tj = poses[3 * (size_t)vj + 2];
   const double zx = el.zinv[k], zy = el.zinv[E + k], zt = el.zinv[2 * E + k];
-  double sz, cz;
-  sincos(zt, &sz, &cz);
-  double e[3];
-  edge_error(xi, yi, ti, xj, yj, tj, zx, zy, zt, sz, cz, e);
+  const double sz = zsc[k], cz = zsc[E + k];
   const double o00 = el.info[k], o01 = el.info[E + k], o02 = el.info[2 * E + k];
   const double o11 = el.info[3 * E + k], o12 = el.info[4 * E + k], o22 = el.info[5 * E + k];
+  const double ph = el.phi[k];
+  const double xi = poses[3 * (size_t)vi], yi = poses[3 * (size_t)vi + 1], ti = poses[3 * (size_t)vi + 2];
+  const double xj = poses[3 * (size_t)vj], yj = poses[3 * (size_t)vj + 1], tj = poses[3 * (size_t)vj + 2];
+  double si, ci;
+  sincos(ti, &si, &ci);
+  // e = toVector(Zi * (Xi^-1 * Xj)), SE2 algebra as edge_error (sgo_device.h): Xi^-1 = (R(-ti), -R(-ti) t_i)
+  const double tin = norm_theta(-ti);
+  const double s1 = -si, c1 = ci;
+  const double ix = c1 * (-xi) - s1 * (-yi), iy = s1 * (-xi) + c1 * (-yi);
+  const double dx = ix + c1 * xj - s1 * yj, dy = iy + s1 * xj + c1 * yj;
+  const double dth = norm_theta(tin + tj);
+  double e[3];
+  e[0] = zx + cz * dx - sz * dy;
+  e[1] = zy + sz * dx + cz * dy;
+  e[2] = norm_theta(zt + dth);
   double oe0 = o00 * e[0] + o01 * e[1] + o02 * e[2];
   double oe1 = o01 * e[0] + o11 * e[1] + o12 * e[2];
   double oe2 = o02 * e[0] + o12 * e[1] + o22 * e[2];
   const double e2 = e[0] * oe0 + e[1] * oe1 + e[2] * oe2;
   double r0, w;
-  dcs(e2, el.phi[k], &r0, &w);
+  dcs(e2, ph, &r0, &w);
   *e2_out = e2;
   *rho_out = r0;
   if (!jac) return;
   const double w00 = w * o00, w01 = w * o01, w02 = w * o02, w11 = w * o11, w12 = w * o12, w22 = w * o22;
   oe0 *= w; oe1 *= w; oe2 *= w;
-  double si, ci;
-  sincos(ti, &si, &ci);
   const double ddx = xj - xi, ddy = yj - yi;
   const double a02 = -si * ddx + ci * ddy, a12 = -ci * ddx - si * ddy;
   const double A00 = cz * (-ci) - sz * si, A01 = cz * (-si) - sz * (-ci), A02 = cz * a02 - sz * a12;
@@ -144,37 +173,37 @@ __device__ __forceinline__ void edge_terms(const EdgeListDev& el, int k, const d
   const double TB10 = w01 * B00 + w11 * B10, TB11 = w01 * B01 + w11 * B11, TB12 = w12;
   const double TB22 = w22;
   // Hii = A^T TA
-  rec[0] = A00 * TA00 + A10 * TA10;
-  rec[1] = A00 * TA01 + A10 * TA11;
-  rec[2] = A00 * TA02 + A10 * TA12;
-  rec[3] = A01 * TA01 + A11 * TA11;
-  rec[4] = A01 * TA02 + A11 * TA12;
-  rec[5] = A02 * TA02 + A12 * TA12 - TA22;
+  rec[0 * E] = A00 * TA00 + A10 * TA10;
+  rec[1 * E] = A00 * TA01 + A10 * TA11;
+  rec[2 * E] = A00 * TA02 + A10 * TA12;
+  rec[3 * E] = A01 * TA01 + A11 * TA11;
+  rec[4 * E] = A01 * TA02 + A11 * TA12;
+  rec[5 * E] = A02 * TA02 + A12 * TA12 - TA22;
   // bi = -A^T (Ow e)
-  rec[6] = -(A00 * oe0 + A10 * oe1);
-  rec[7] = -(A01 * oe0 + A11 * oe1);
-  rec[8] = -(A02 * oe0 + A12 * oe1 - oe2);
+  rec[6 * E] = -(A00 * oe0 + A10 * oe1);
+  rec[7 * E] = -(A01 * oe0 + A11 * oe1);
+  rec[8 * E] = -(A02 * oe0 + A12 * oe1 - oe2);
   // Hjj = B^T TB
-  rec[9] = B00 * TB00 + B10 * TB10;
-  rec[10] = B00 * TB01 + B10 * TB11;
-  rec[11] = B00 * TB02 + B10 * TB12;
-  rec[12] = B01 * TB01 + B11 * TB11;
-  rec[13] = B01 * TB02 + B11 * TB12;
-  rec[14] = TB22;
+  rec[9 * E] = B00 * TB00 + B10 * TB10;
+  rec[10 * E] = B00 * TB01 + B10 * TB11;
+  rec[11 * E] = B00 * TB02 + B10 * TB12;
+  rec[12 * E] = B01 * TB01 + B11 * TB11;
+  rec[13 * E] = B01 * TB02 + B11 * TB12;
+  rec[14 * E] = TB22;
   // bj = -B^T (Ow e)
-  rec[15] = -(B00 * oe0 + B10 * oe1);
-  rec[16] = -(B01 * oe0 + B11 * oe1);
-  rec[17] = -oe2;
+  rec[15 * E] = -(B00 * oe0 + B10 * oe1);
+  rec[16 * E] = -(B01 * oe0 + B11 * oe1);
+  rec[17 * E] = -oe2;
   // Hij = A^T Ow B = TA^T B  (row vi, column vj)
-  rec[18] = TA00 * B00 + TA10 * B10;
-  rec[19] = TA00 * B01 + TA10 * B11;
-  rec[20] = TA20;
-  rec[21] = TA01 * B00 + TA11 * B10;
-  rec[22] = TA01 * B01 + TA11 * B11;
-  rec[23] = TA21;
-  rec[24] = TA02 * B00 + TA12 * B10;
-  rec[25] = TA02 * B01 + TA12 * B11;
-  rec[26] = TA22;
+  hij[0] = TA00 * B00 + TA10 * B10;
+  hij[1] = TA00 * B01 + TA10 * B11;
+  hij[2] = TA20;
+  hij[3] = TA01 * B00 + TA11 * B10;
+  hij[4] = TA01 * B01 + TA11 * B11;
+  hij[5] = TA21;
+  hij[6] = TA02 * B00 + TA12 * B10;
+  hij[7] = TA02 * B01 + TA12 * B11;
+  hij[8] = TA22;
 }
 
 // sum over the edges of a pair (linked through enext) of H[row][col], row-major
@@ -182,41 +211,180 @@ __device__ __forceinline__ void pair_block(const DirectDev& D, int first, double
 #pragma unroll
   for (int c = 0; c < 9; ++c) b[c] = 0.0;
   for (int t = first; t >= 0; t = D.enext[t >> 1]) {
-    const double* h = D.escr + 27 * (size_t)(t >> 1) + 18;
+    const size_t E = (size_t)D.E;
+    const double* h = D.escr + (size_t)(t >> 1) + 18 * E;
     if (t & 1) {
 #pragma unroll
       for (int r = 0; r < 3; ++r)
 #pragma unroll
-        for (int c = 0; c < 3; ++c) b[3 * r + c] += h[3 * c + r];
+        for (int c = 0; c < 3; ++c) b[3 * r + c] += h[(3 * c + r) * E];
     } else {
 #pragma unroll
-      for (int c = 0; c < 9; ++c) b[c] += h[c];
+      for (int c = 0; c < 9; ++c) b[c] += h[c * E];
     }
   }
 }
+// store an off-diagonal block h = H[row][col] (row-major; `tr`: h is the transpose of what the target wants)
+__device__ __forceinline__ void store_offdiag(const DirectDev& D, double* __restrict__ Sd, unsigned tgt, const double* h) {
+  const unsigned kind = tgt >> 30;
+  const bool tr = (tgt >> 29) & 1u;
+  const int idx = (int)(tgt & 0x1fffffffu);
+  if (kind == 1) {
+    double v[9];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) v[3 * r + c] = tr ? h[3 * c + r] : h[3 * r + c];
+    store9g(D.Wo + kBS * (size_t)idx, v);
+  } else if (kind == 2) {
+    const int si = idx >> 12, sj = idx & 4095;
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) Sd[tri_at(3 * si + r, 3 * sj + c)] = tr ? h[3 * c + r] : h[3 * r + c];
+  }
+}
+
+// One forward task: a target minus its contributions W_ik D_k^-1 W_jk^T.  A DIAGONAL target (sparse column or
+// separator) also owns its pose's right-hand side: both take a contribution from exactly the same columns k, so
+// W_ik and D_k are fetched once for the two.
+__device__ __forceinline__ void run_task(const DirectDev& D, double* __restrict__ xb, double* __restrict__ Sd, int4 tk, int4 c0) {
+  const unsigned kind = (unsigned)tk.x >> 28;
+  const int idx = tk.x & 0x0fffffff;
+  const int si = idx >> 12, sj = idx & 4095;   // T_DENSE
+  const bool diag = kind == T_DIAG || (kind == T_DENSE && si == sj);
+  // a9 = (old value) - sum of contributions: a stored target is fetched together with the sources
+  double a9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  double r3[3] = {0, 0, 0};
+  double* wt = (kind == T_DIAG ? D.Wd : D.Wo) + kBS * (size_t)idx;
+  if (kind == T_OFF || kind == T_DIAG) load9g(wt, a9);
+  for (int c = tk.y; c < tk.z; ++c) {
+    const int4 cr = c == tk.y ? c0 : D.ctr[c];
+    const int k = cr.z;
+    double Wa[9], iv[6], Tm[9];
+    load9g(D.Wo + kBS * (size_t)cr.x, Wa);
+    const double2* dk = reinterpret_cast<const double2*>(D.Wd + kBS * (size_t)k);
+    const double2 q0 = dk[0], q1 = dk[1], q2 = dk[2];
+    const double d22 = D.Wd[kBS * (size_t)k + 8];
+    inv_sym3(q0.x, q0.y, q1.x, q2.x, q2.y, d22, iv);
+    mul_sym(Wa, iv, Tm);
+    if (diag) {
+      const double b0 = xb[3 * k], b1 = xb[3 * k + 1], b2 = xb[3 * k + 2];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) r3[r] -= Tm[3 * r] * b0 + Tm[3 * r + 1] * b1 + Tm[3 * r + 2] * b2;
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+          a9[3 * r + q] -= Tm[3 * r] * Wa[3 * q] + Tm[3 * r + 1] * Wa[3 * q + 1] + Tm[3 * r + 2] * Wa[3 * q + 2];
+    } else {
+      double Wb[9];
+      load9g(D.Wo + kBS * (size_t)cr.y, Wb);
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+          a9[3 * r + q] -= Tm[3 * r] * Wb[3 * q] + Tm[3 * r + 1] * Wb[3 * q + 1] + Tm[3 * r + 2] * Wb[3 * q + 2];
+    }
+  }
+  if (diag) {
+    const int pos = kind == T_DIAG ? idx : D.nI + si;
+    xb[3 * pos] += r3[0];
+    xb[3 * pos + 1] += r3[1];
+    xb[3 * pos + 2] += r3[2];
+  }
+  if (kind == T_DENSE) {
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+        if (si != sj || r >= q) Sd[tri_at(3 * si + r, 3 * sj + q)] += a9[3 * r + q];
+  } else {
+    store9g(wt, a9);
+  }
+}
+
+constexpr int kPF = 1;   // forward tasks per thread whose records are fetched one level ahead
 
 __global__ __launch_bounds__(kDT) void k_direct(DirectDev D, EdgeListDev el, double* __restrict__ poses, int iters,
                                                 double* __restrict__ hist, DirectResult* __restrict__ res) {
   extern __shared__ double lds[];
   double* xb = lds;                       // [3 n] right-hand side, then the solution, by elimination position
   double* Sd = lds + 3 * (size_t)D.n;     // [tri] packed lower triangle of the separator block
-  double* red = Sd + D.tri;               // [2][16] chi2 partials
+  double* pinv = Sd + D.tri;              // [ns][6] inverses of the separators' pivot blocks
+  double* red = pinv + 6 * (size_t)D.ns;  // [2][16] chi2 partials
+  int* lmeta = reinterpret_cast<int*>(red + 32);   // [2 (NL + 1)]
   __shared__ int fail_flag;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int n = D.n, nI = D.nI, ns = D.ns;
+  const int n = D.n, nI = D.nI, ns = D.ns, NL = D.NL;
+  const size_t E = (size_t)D.E;
   if (tid == 0) fail_flag = 0;
+  for (int k = tid; k < 2 * (NL + 1); k += kDT) lmeta[k] = D.lmeta[k];
+  for (int k = tid; k < D.tri; k += kDT) Sd[k] = 0.0;
+  for (int k = tid; k < D.E; k += kDT) {
+    double sz, cz;
+    sincos(el.zinv[2 * E + k], &sz, &cz);
+    D.zsc[k] = sz;
+    D.zsc[E + k] = cz;
+  }
+  __syncthreads();
+  const int* lslot = lmeta;
+  const int* ltask = lmeta + NL + 1;
+  // records of this thread's first tasks of the next forward level (static data: fetched while the previous
+  // level computes, so that a level costs one round trip to the blocks instead of three)
+  int4 ntk[kPF], nc[kPF];
+#pragma unroll
+  for (int q = 0; q < kPF; ++q) ntk[q] = nc[q] = make_int4(0, 0, 0, 0);
+  auto prefetch = [&](int l) {
+    if (NL == 0) return;
+    const int t0 = ltask[l], t1 = ltask[l + 1];
+#pragma unroll
+    for (int q = 0; q < kPF; ++q) {
+      const int T = t0 + tid + q * kDT;
+      if (T < t1) {
+        ntk[q] = D.tk[T];
+        nc[q] = D.ctr[ntk[q].y];
+      }
+    }
+  };
+  prefetch(0);
+  const int mypair = D.dpair[tid < ns * (ns + 1) / 2 ? tid : 0];   // the dense block pair this thread updates (static)
+  const unsigned long long clk0 = __builtin_amdgcn_s_memtime();
   int done = 0, fail = 0;
   for (int it = 0; it <= iters; ++it) {
-    if (tid == 0) res->stamp[2 * it] = (unsigned long long)wall_clock64();
-    // ---- edges: chi2 sums, and (unless this is the closing pass) the terms of the linearisation
+    // per-thread addresses of 30-odd arrays are loop invariant; hoisted out of the GN loop they cost 50 spilled
+    // registers: an opaque copy of the thread index keeps them inside the phase that uses them
+    int tq = tid;
+    asm volatile("" : "+v"(tq));
+    if (tid == 0) {
+      res->stamp[2 * it] = (unsigned long long)wall_clock64();
+      if (it < iters) res->phase[0] = res->stamp[2 * it];
+    }
+    // ---- edges: chi2 sums, and (unless this is the closing pass) the terms of the linearisation; an edge
+    //      that is alone on its pair of poses writes its off-diagonal block straight to where it is stored
     const bool jac = it < iters;
     double acc[2] = {0.0, 0.0};
-    for (int k = tid; k < D.E; k += kDT) {
-      double e2, r0;
-      edge_terms(el, k, poses, jac, D.escr + 27 * (size_t)k, &e2, &r0);
+    for (int k = tq; k < D.E; k += kDT) {
+      double e2, r0, hij[9];
+      double* o = D.escr + k;   // SoA: component c of edge k at escr[c E + k] (coalesced stores)
+      edge_terms(el, D.zsc, k, poses, jac, o, hij, &e2, &r0);
       acc[0] += e2;
       acc[1] += r0;
+      if (jac) {
+        const unsigned tgt = D.edge_tgt[k];
+        if ((tgt >> 30) == 3) {
+#pragma unroll
+          for (int c = 0; c < 9; ++c) o[(18 + c) * E] = hij[c];
+        } else {
+          store_offdiag(D, Sd, tgt, hij);
+        }
+      }
     }
+    if (jac)
+      for (int q = tq; q < D.nzero; q += kDT) {
+        const double z9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        store9g(D.Wo + kBS * (size_t)D.zero_slots[q], z9);
+      }
     seg_scan<2>(0, acc, lane);
     if (lane == 63) {
       red[wave] = acc[0];
@@ -233,25 +401,31 @@ __global__ __launch_bounds__(kDT) void k_direct(DirectDev D, EdgeListDev el, dou
       hist[2 * it + 1] = b;
     }
     if (!jac) break;
-    // ---- assembly
-    for (int k = tid; k < D.tri; k += kDT) Sd[k] = 0.0;
-    __syncthreads();
-    for (int f = tid; f < n; f += kDT) {
+    if (tid == 0) res->phase[1] = (unsigned long long)wall_clock64();
+    // ---- assembly: diagonal blocks and right-hand sides (sums over a pose's incident edges), multi-edge pairs
+    for (int f = tq; f < n; f += kDT) {
+      const int4 vr = D.vrec[f];
       double d[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-      for (int q = D.vptr[f]; q < D.vptr[f + 1]; ++q) {
-        const int t = D.vlist[q];
-        const double* h = D.escr + 27 * (size_t)(t >> 1) + ((t & 1) ? 9 : 0);
+      auto add = [&](int t) {
+        const double* h = D.escr + (size_t)(t >> 1) + ((t & 1) ? 9 * E : 0);
 #pragma unroll
-        for (int c = 0; c < 9; ++c) d[c] += h[c];
+        for (int c = 0; c < 9; ++c) d[c] += h[c * E];
+      };
+      if (vr.x >= 0) add(vr.x);
+      if (vr.y >= 0) add(vr.y);
+      if (vr.z >= 0) add(vr.z);
+      if (vr.w >= 0) add(vr.w);
+      if (vr.w <= -2) {
+        const int* ov = D.vover + (-2 - vr.w);
+        const int cnt = ov[0];
+        for (int q = 1; q <= cnt; ++q) add(ov[q]);
       }
       xb[3 * f] = d[6];
       xb[3 * f + 1] = d[7];
       xb[3 * f + 2] = d[8];
       if (f < nI) {
-        double* w = D.Wd + 9 * (size_t)f;
-        w[0] = d[0]; w[1] = d[1]; w[2] = d[2];
-        w[3] = d[1]; w[4] = d[3]; w[5] = d[4];
-        w[6] = d[2]; w[7] = d[4]; w[8] = d[5];
+        const double w9[9] = {d[0], d[1], d[2], d[1], d[3], d[4], d[2], d[4], d[5]};
+        store9g(D.Wd + kBS * (size_t)f, w9);
       } else {
         const int r = 3 * (f - nI);
         Sd[tri_at(r, r)] = d[0];
@@ -262,86 +436,56 @@ __global__ __launch_bounds__(kDT) void k_direct(DirectDev D, EdgeListDev el, dou
         Sd[tri_at(r + 2, r + 2)] = d[5];
       }
     }
-    for (int s = tid; s < D.NB; s += kDT) {
-      if (D.slot_col[s] < 0 || D.slot_row[s] < 0) continue;
+    for (int q = tq; q < D.nmulti; q += kDT) {
+      const int2 m = D.multi[q];
       double b[9];
-      pair_block(D, D.slot_edge[s], b);
-      double* w = D.Wo + 9 * (size_t)s;
-#pragma unroll
-      for (int c = 0; c < 9; ++c) w[c] = b[c];
-    }
-    for (int q = tid; q < D.nss; q += kDT) {
-      const int pr = D.ss_pair[q], si = pr >> 12, sj = pr & 4095;
-      double b[9];
-      pair_block(D, D.ss_edge[q], b);
-#pragma unroll
-      for (int r = 0; r < 3; ++r)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) Sd[tri_at(3 * si + r, 3 * sj + c)] = b[3 * r + c];
+      pair_block(D, m.y, b);
+      store_offdiag(D, Sd, (unsigned)m.x, b);
     }
     __syncthreads();
-    if (tid == 0) res->stamp[2 * it + 1] = (unsigned long long)wall_clock64();
+    if (tid == 0) res->phase[2] = res->stamp[2 * it + 1] = (unsigned long long)wall_clock64();
     // ---- sparse levels, forward: Schur updates and right-hand sides of the level's columns
-    for (int l = 0; l < D.NL; ++l) {
-      const int t0 = D.ltask[l], t1 = D.ltask[l + 1];
-      for (int T = t0 + tid; T < t1; T += kDT) {
-        const unsigned tg = D.tk_target[T];
-        const unsigned kind = tg >> 28;
-        const int idx = (int)(tg & 0x0fffffffu);
-        double a9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-        for (int c = D.tk_cptr[T]; c < D.tk_cptr[T + 1]; ++c) {
-          const int sa = D.ca[c];
-          const int k = D.slot_col[sa];
-          double Wa[9], Dk[9], iv[6], Tm[9];
-          load9g(D.Wo + 9 * (size_t)sa, Wa);
-          load9g(D.Wd + 9 * (size_t)k, Dk);
-          inv_sym3(Dk[0], Dk[1], Dk[2], Dk[4], Dk[5], Dk[8], iv);
-          mul_sym(Wa, iv, Tm);
-          if (kind == T_RHS) {
-            const double b0 = xb[3 * k], b1 = xb[3 * k + 1], b2 = xb[3 * k + 2];
+    for (int l = 0; l < NL; ++l) {
+      const int t0 = ltask[l], t1 = ltask[l + 1];
+      int4 ctk[kPF], cc[kPF];
 #pragma unroll
-            for (int r = 0; r < 3; ++r) a9[r] += Tm[3 * r] * b0 + Tm[3 * r + 1] * b1 + Tm[3 * r + 2] * b2;
-          } else {
-            double Wb[9];
-            load9g(D.Wo + 9 * (size_t)D.cb[c], Wb);
+      for (int q = 0; q < kPF; ++q) {
+        ctk[q] = ntk[q];
+        cc[q] = nc[q];
+      }
+      prefetch(l + 1 < NL ? l + 1 : 0);
 #pragma unroll
-            for (int r = 0; r < 3; ++r)
-#pragma unroll
-              for (int q = 0; q < 3; ++q)
-                a9[3 * r + q] += Tm[3 * r] * Wb[3 * q] + Tm[3 * r + 1] * Wb[3 * q + 1] + Tm[3 * r + 2] * Wb[3 * q + 2];
-          }
-        }
-        if (kind == T_RHS) {
-          xb[3 * idx] -= a9[0];
-          xb[3 * idx + 1] -= a9[1];
-          xb[3 * idx + 2] -= a9[2];
-        } else if (kind == T_DENSE) {
-          const int si = idx >> 12, sj = idx & 4095;
-#pragma unroll
-          for (int r = 0; r < 3; ++r)
-#pragma unroll
-            for (int q = 0; q < 3; ++q)
-              if (si != sj || r >= q) Sd[tri_at(3 * si + r, 3 * sj + q)] -= a9[3 * r + q];
-        } else {
-          double* w = (kind == T_DIAG ? D.Wd : D.Wo) + 9 * (size_t)idx;
-#pragma unroll
-          for (int c = 0; c < 9; ++c) w[c] -= a9[c];
-        }
+      for (int q = 0; q < kPF; ++q)
+        if (t0 + tq + q * kDT < t1) run_task(D, xb, Sd, ctk[q], cc[q]);
+      for (int T = t0 + tq + kPF * kDT; T < t1; T += kDT) {
+        const int4 tk = D.tk[T];
+        run_task(D, xb, Sd, tk, D.ctr[tk.y]);
       }
       __syncthreads();
     }
-    // ---- separators: right-looking block LDL^T on the packed triangle, pivot block p; W form (panel kept)
+    if (tid == 0) res->phase[3] = (unsigned long long)wall_clock64();
+    // ---- separators: right-looking block LDL^T on the packed triangle, 3x3 pivots, W form (the panel stays);
+    //      the thread that finishes the next pivot block inverts it for everybody
+    if (tid == 0 && ns > 0) {
+      double iv[6];
+      const bool ok = inv_sym3(Sd[tri_at(0, 0)], Sd[tri_at(1, 0)], Sd[tri_at(2, 0)], Sd[tri_at(1, 1)], Sd[tri_at(2, 1)],
+                               Sd[tri_at(2, 2)], iv);
+#pragma unroll
+      for (int c = 0; c < 6; ++c) pinv[c] = iv[c];
+      if (!ok) atomicOr(&fail_flag, 1);
+    }
+    __syncthreads();
     double* bs = xb + 3 * (size_t)nI;
     for (int p = 0; p + 1 < ns; ++p) {
       const int m = ns - 1 - p, cnt = m * (m + 1) / 2;
       const int P = 3 * p;
       double iv[6];
-      inv_sym3(Sd[tri_at(P, P)], Sd[tri_at(P + 1, P)], Sd[tri_at(P + 2, P)], Sd[tri_at(P + 1, P + 1)],
-               Sd[tri_at(P + 2, P + 1)], Sd[tri_at(P + 2, P + 2)], iv);
-      for (int t = tid; t < cnt + m; t += kDT) {
+#pragma unroll
+      for (int c = 0; c < 6; ++c) iv[c] = pinv[6 * p + c];
+      for (int t = tq; t < cnt + m; t += kDT) {
         if (t < cnt) {
-          const int pr = D.dpair[t], bi = pr >> 8, bj = pr & 255;
-          double Wa[9], Wb[9], Tm[9];
+          const int pr = t < kDT ? mypair : (int)D.dpair[t], bi = pr >> 8, bj = pr & 255;
+          double Wa[9], Wb[9], Tm[9], nb[9];
 #pragma unroll
           for (int r = 0; r < 3; ++r)
 #pragma unroll
@@ -354,8 +498,18 @@ __global__ __launch_bounds__(kDT) void k_direct(DirectDev D, EdgeListDev el, dou
           for (int r = 0; r < 3; ++r)
 #pragma unroll
             for (int q = 0; q < 3; ++q)
-              if (bi != bj || r >= q)
-                Sd[tri_at(3 * bi + r, 3 * bj + q)] -= Tm[3 * r] * Wb[3 * q] + Tm[3 * r + 1] * Wb[3 * q + 1] + Tm[3 * r + 2] * Wb[3 * q + 2];
+              if (bi != bj || r >= q) {
+                nb[3 * r + q] = Sd[tri_at(3 * bi + r, 3 * bj + q)] -
+                                (Tm[3 * r] * Wb[3 * q] + Tm[3 * r + 1] * Wb[3 * q + 1] + Tm[3 * r + 2] * Wb[3 * q + 2]);
+                Sd[tri_at(3 * bi + r, 3 * bj + q)] = nb[3 * r + q];
+              }
+          if (bi == p + 1 && bj == p + 1) {
+            double nv[6];
+            const bool ok = inv_sym3(nb[0], nb[3], nb[6], nb[4], nb[7], nb[8], nv);
+#pragma unroll
+            for (int c = 0; c < 6; ++c) pinv[6 * (p + 1) + c] = nv[c];
+            if (!ok) atomicOr(&fail_flag, 1);
+          }
         } else {
           const int bi = p + 1 + (t - cnt);
           double Wa[9], Tm[9];
@@ -371,46 +525,64 @@ __global__ __launch_bounds__(kDT) void k_direct(DirectDev D, EdgeListDev el, dou
       }
       __syncthreads();
     }
-    // back substitution of the separators by ONE wave: x_p = D_p^-1 (b_p - sum_{i > p} W_ip^T x_i)
-    if (wave == 0) {
-      for (int p = ns - 1; p >= 0; --p) {
-        const int P = 3 * p;
-        double v[3] = {0.0, 0.0, 0.0};
-        for (int bi = p + 1 + lane; bi < ns; bi += 64) {
-          const double x0 = bs[3 * bi], x1 = bs[3 * bi + 1], x2 = bs[3 * bi + 2];
+    if (tid == 0) res->phase[4] = (unsigned long long)wall_clock64();
+    // back substitution of the separators by ONE wave, column oriented: lane p owns b_p; step i: x_i = D_i^-1 b_i is
+    // broadcast from lane i and every lane p < i takes W_ip^T x_i off its b_p.  No barriers, no reductions.
+    if (wave == 0 && ns > 0) {
+      double b0 = 0.0, b1 = 0.0, b2 = 0.0;
+      if (lane < ns) {
+        b0 = bs[3 * lane];
+        b1 = bs[3 * lane + 1];
+        b2 = bs[3 * lane + 2];
+      }
+      const int lp = lane < ns ? lane : 0;
+      for (int i = ns - 1; i >= 0; --i) {
+        double W[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        if (lane < i) {
 #pragma unroll
-          for (int q = 0; q < 3; ++q)
-            v[q] += Sd[tri_at(3 * bi, P + q)] * x0 + Sd[tri_at(3 * bi + 1, P + q)] * x1 + Sd[tri_at(3 * bi + 2, P + q)] * x2;
+          for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) W[3 * r + q] = Sd[tri_at(3 * i + r, 3 * lp + q)];
         }
-        seg_scan<3>(0, v, lane);
-        const double s0 = readlane63(v[0]), s1 = readlane63(v[1]), s2 = readlane63(v[2]);
-        double iv[6];
-        const bool ok = inv_sym3(Sd[tri_at(P, P)], Sd[tri_at(P + 1, P)], Sd[tri_at(P + 2, P)], Sd[tri_at(P + 1, P + 1)],
-                                 Sd[tri_at(P + 2, P + 1)], Sd[tri_at(P + 2, P + 2)], iv);
-        const double r0 = bs[P] - s0, r1 = bs[P + 1] - s1, r2 = bs[P + 2] - s2;
-        // (the LDS unit serves one wave's operations in issue order: every lane's read of b_p precedes this store,
-        // and the store precedes the next step's reads)
-        if (lane == 0) {
-          bs[P] = iv[0] * r0 + iv[1] * r1 + iv[2] * r2;
-          bs[P + 1] = iv[1] * r0 + iv[3] * r1 + iv[4] * r2;
-          bs[P + 2] = iv[2] * r0 + iv[4] * r1 + iv[5] * r2;
-          if (!ok) atomicOr(&fail_flag, 1);
+        const double* iv = pinv + 6 * i;
+        const double y0 = readlane_d(b0, i), y1 = readlane_d(b1, i), y2 = readlane_d(b2, i);
+        const double x0 = iv[0] * y0 + iv[1] * y1 + iv[2] * y2;
+        const double x1 = iv[1] * y0 + iv[3] * y1 + iv[4] * y2;
+        const double x2 = iv[2] * y0 + iv[4] * y1 + iv[5] * y2;
+        if (lane == i) {
+          bs[3 * i] = x0;
+          bs[3 * i + 1] = x1;
+          bs[3 * i + 2] = x2;
         }
-        __builtin_amdgcn_wave_barrier();
+        if (lane < i) {
+          b0 -= W[0] * x0 + W[3] * x1 + W[6] * x2;
+          b1 -= W[1] * x0 + W[4] * x1 + W[7] * x2;
+          b2 -= W[2] * x0 + W[5] * x1 + W[8] * x2;
+        }
       }
     }
     __syncthreads();
+    if (tid == 0) res->phase[5] = (unsigned long long)wall_clock64();
+    // the separator block is dead until the next linearisation writes into it: clear it now (the barriers of the
+    // backward levels / the update separate this from those writes)
+    for (int k = tq; k < D.tri; k += kDT) Sd[k] = 0.0;
     // ---- sparse levels, backward
-    for (int l = D.NL - 1; l >= 0; --l) {
-      const int s0 = D.lslot[l], s1 = D.lslot[l + 1];
-      for (int s = s0 + tid; s < s1; s += kDT) {
-        const int col = D.slot_col[s], row = D.slot_row[s];
+    for (int l = NL - 1; l >= 0; --l) {
+      const int s0 = lslot[l], s1 = lslot[l + 1];
+      for (int s = s0 + tq; s < s1; s += kDT) {
+        const int2 rc = D.slot_rc[s];
+        const int row = rc.x, col = rc.y;
         double v[3] = {0.0, 0.0, 0.0};
-        double Dk[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-        if (col >= 0) load9g(D.Wd + 9 * (size_t)col, Dk);
+        double d00 = 1, d01 = 0, d02 = 0, d11 = 1, d12 = 0, d22 = 1;
+        if (col >= 0) {
+          const double2* dk = reinterpret_cast<const double2*>(D.Wd + kBS * (size_t)col);
+          const double2 q0 = dk[0], q1 = dk[1], q2 = dk[2];
+          d00 = q0.x; d01 = q0.y; d02 = q1.x; d11 = q2.x; d12 = q2.y;
+          d22 = D.Wd[kBS * (size_t)col + 8];
+        }
         if (col >= 0 && row >= 0) {
           double W[9];
-          load9g(D.Wo + 9 * (size_t)s, W);
+          load9g(D.Wo + kBS * (size_t)s, W);
           const double x0 = xb[3 * row], x1 = xb[3 * row + 1], x2 = xb[3 * row + 2];
 #pragma unroll
           for (int q = 0; q < 3; ++q) v[q] = W[q] * x0 + W[3 + q] * x1 + W[6 + q] * x2;
@@ -420,7 +592,7 @@ __global__ __launch_bounds__(kDT) void k_direct(DirectDev D, EdgeListDev el, dou
         const int nk = __shfl_down(key, 1);
         if (col >= 0 && (lane == 63 || nk != key)) {
           double iv[6];
-          const bool ok = inv_sym3(Dk[0], Dk[1], Dk[2], Dk[4], Dk[5], Dk[8], iv);
+          const bool ok = inv_sym3(d00, d01, d02, d11, d12, d22, iv);
           const double r0 = xb[3 * col] - v[0], r1 = xb[3 * col + 1] - v[1], r2 = xb[3 * col + 2] - v[2];
           xb[3 * col] = iv[0] * r0 + iv[1] * r1 + iv[2] * r2;
           xb[3 * col + 1] = iv[1] * r0 + iv[3] * r1 + iv[4] * r2;
@@ -430,14 +602,15 @@ __global__ __launch_bounds__(kDT) void k_direct(DirectDev D, EdgeListDev el, dou
       }
       __syncthreads();
     }
+    if (tid == 0) res->phase[6] = (unsigned long long)wall_clock64();
     // ---- update (VertexSE2::oplusImpl) unless the factorisation failed or the step is not finite
     bool bad = false;
-    for (int f = tid; f < n; f += kDT) bad |= !(isfinite(xb[3 * f]) && isfinite(xb[3 * f + 1]) && isfinite(xb[3 * f + 2]));
+    for (int f = tq; f < n; f += kDT) bad |= !(isfinite(xb[3 * f]) && isfinite(xb[3 * f + 1]) && isfinite(xb[3 * f + 2]));
     if (bad) atomicOr(&fail_flag, 2);
     __syncthreads();
     fail = fail_flag;
     if (fail) break;
-    for (int f = tid; f < n; f += kDT) {
+    for (int f = tq; f < n; f += kDT) {
       const size_t v = 3 * (size_t)D.pos_vertex[f];
       poses[v] += xb[3 * f];
       poses[v + 1] += xb[3 * f + 1];
@@ -445,13 +618,12 @@ __global__ __launch_bounds__(kDT) void k_direct(DirectDev D, EdgeListDev el, dou
     }
     ++done;
     __syncthreads();
+    if (tid == 0) res->phase[7] = (unsigned long long)wall_clock64();
   }
   if (tid == 0) {
-    if (fail) {
-      // hist[2 done] already holds the chi2 at the poses that stay (the failed iteration's own start)
-      res->fail_iter = done;
-    }
+    if (fail) res->fail_iter = done;   // hist[2 done] holds the chi2 at the poses that stay
     res->done = done;
+    res->cycles = __builtin_amdgcn_s_memtime() - clk0;
     res->fail = (fail & 1) ? 1 : (fail ? 2 : 0);
     res->stamp[fail ? 2 * done + 2 : 2 * iters + 1] = (unsigned long long)wall_clock64();   // end of the call
   }
@@ -475,9 +647,10 @@ struct Direct {
   DirectDev dev{};
   DirectInfo info{};
   // host copies of the uploaded lists must outlive the asynchronous copies
-  std::vector<int> h_vertex_pos, h_pos_vertex, h_vptr, h_vlist, h_slot_row, h_slot_col, h_slot_edge, h_enext, h_ss_pair,
-      h_ss_edge, h_lslot, h_ltask, h_tk_cptr, h_ca, h_cb;
-  std::vector<unsigned> h_tk_target;
+  std::vector<int> h_pos_vertex, h_vover, h_zero, h_enext, h_lmeta;
+  std::vector<int4> h_vrec, h_tk, h_ctr;
+  std::vector<int2> h_multi, h_slot_rc;
+  std::vector<unsigned> h_edge_tgt;
   std::vector<unsigned short> h_dpair;
 };
 
@@ -590,7 +763,7 @@ Direct* direct_create(hipStream_t s, DevArena* arena, int V, int n, const int* f
   }
   if (NL > kMaxLevels) return no("elimination tree too deep");
   const int tri = 3 * ns * (3 * ns + 1) / 2;
-  const size_t lds_bytes = sizeof(double) * (3 * (size_t)n + (size_t)tri + 32);
+  const size_t lds_bytes = sizeof(double) * (3 * (size_t)n + (size_t)tri + 6 * (size_t)ns + 32) + sizeof(int) * 2 * ((size_t)NL + 1);
   if (lds_bytes > kLdsBudget) return no("right-hand side + separator block exceed the LDS");
 
   Direct* d = new Direct();
@@ -598,11 +771,9 @@ Direct* direct_create(hipStream_t s, DevArena* arena, int V, int n, const int* f
   for (int k = 0; k < nI; ++k) lcols[level[k]].push_back(k);
   // ---- slots: per level, per column (ascending), a column's blocks inside one wave
   std::vector<int> colbase((size_t)nI, 0);
-  auto& srow = d->h_slot_row;
-  auto& scol = d->h_slot_col;
-  d->h_lslot.assign((size_t)NL + 1, 0);
+  std::vector<int> srow, scol, lslot((size_t)NL + 1, 0), ltask((size_t)NL + 1, 0);
   for (int l = 0; l < NL; ++l) {
-    d->h_lslot[l] = (int)srow.size();
+    lslot[l] = (int)srow.size();
     for (int k : lcols[l]) {
       const int len = std::max<int>(1, (int)st[k].size());
       const int cur = (int)srow.size();
@@ -626,62 +797,96 @@ Direct* direct_create(hipStream_t s, DevArena* arena, int V, int n, const int* f
       scol.push_back(-1);
     }
   }
-  d->h_lslot[NL] = (int)srow.size();
+  lslot[NL] = (int)srow.size();
   const int NB = (int)srow.size();
+  d->h_slot_rc.resize((size_t)NB);
+  for (int q = 0; q < NB; ++q) d->h_slot_rc[q] = make_int2(srow[q], scol[q]);
   auto slot_of = [&](int i, int k) -> int {   // stored block (row i, column k), k < nI
     const std::vector<int>& v = st[k];
     const auto it = std::lower_bound(v.begin(), v.end(), i);
     return colbase[k] + (int)(it - v.begin());
   };
   // ---- assembly lists
-  d->h_vertex_pos.assign((size_t)V, -1);
+  std::vector<int> vertex_pos((size_t)V, -1);
   d->h_pos_vertex.resize((size_t)n);
   for (int p = 0; p < n; ++p) {
     d->h_pos_vertex[p] = free_id[order[p]];
-    d->h_vertex_pos[free_id[order[p]]] = p;
+    vertex_pos[free_id[order[p]]] = p;
   }
-  d->h_vptr.assign((size_t)n + 1, 0);
-  for (int e = 0; e < E; ++e) {
-    const int a = d->h_vertex_pos[ei[e]], b = d->h_vertex_pos[ej[e]];
-    if (a >= 0) ++d->h_vptr[a + 1];
-    if (b >= 0) ++d->h_vptr[b + 1];
-  }
-  for (int p = 0; p < n; ++p) d->h_vptr[p + 1] += d->h_vptr[p];
-  d->h_vlist.resize((size_t)d->h_vptr[n]);
-  {
-    std::vector<int> cur(d->h_vptr.begin(), d->h_vptr.end() - 1);
+  {   // incident edges of every position: four inline, the rest in an overflow list
+    std::vector<std::vector<int>> inc((size_t)n);
     for (int e = 0; e < E; ++e) {
-      const int a = d->h_vertex_pos[ei[e]], b = d->h_vertex_pos[ej[e]];
-      if (a >= 0) d->h_vlist[cur[a]++] = e << 1;
-      if (b >= 0) d->h_vlist[cur[b]++] = e << 1 | 1;
+      const int a = vertex_pos[ei[e]], b = vertex_pos[ej[e]];
+      if (a >= 0) inc[a].push_back(e << 1);
+      if (b >= 0) inc[b].push_back(e << 1 | 1);
+    }
+    d->h_vrec.resize((size_t)n);
+    for (int p = 0; p < n; ++p) {
+      const std::vector<int>& v = inc[p];
+      int4 r = make_int4(-1, -1, -1, -1);
+      const int inl = v.size() <= 4 ? (int)v.size() : 3;
+      if (inl > 0) r.x = v[0];
+      if (inl > 1) r.y = v[1];
+      if (inl > 2) r.z = v[2];
+      if (inl > 3) r.w = v[3];
+      if ((int)v.size() > inl) {
+        r.w = -2 - (int)d->h_vover.size();
+        d->h_vover.push_back((int)v.size() - inl);
+        for (size_t q = (size_t)inl; q < v.size(); ++q) d->h_vover.push_back(v[q]);
+      }
+      d->h_vrec[p] = r;
     }
   }
-  d->h_slot_edge.assign((size_t)NB, -1);
+  // off-diagonal blocks: the stored block is H[row = later position][col = earlier position]; an edge holds H[vi][vj]
+  std::vector<int> slot_first((size_t)NB, -1), slot_cnt((size_t)NB, 0), ss_first((size_t)ns * ns, -1), ss_cnt((size_t)ns * ns, 0);
   d->h_enext.assign((size_t)std::max(E, 1), -1);
-  std::vector<int> ss_first((size_t)ns * ns, -1);
+  d->h_edge_tgt.assign((size_t)std::max(E, 1), 0u);
+  std::vector<unsigned> tgt_of((size_t)std::max(E, 1), 0u);
   for (int e = E - 1; e >= 0; --e) {   // descending: the lists come out in ascending edge order
-    const int a = d->h_vertex_pos[ei[e]], b = d->h_vertex_pos[ej[e]];
+    const int a = vertex_pos[ei[e]], b = vertex_pos[ej[e]];
     if (a < 0 || b < 0) continue;
-    // the stored block is H[row = later position][col = earlier position]; the edge holds H[vi][vj]
     const int row = std::max(a, b), col = std::min(a, b);
-    const int enc = e << 1 | (row == a ? 0 : 1);
-    int* head = col < nI ? &d->h_slot_edge[slot_of(row, col)] : &ss_first[(size_t)(row - nI) * ns + (col - nI)];
+    const unsigned tr = row == a ? 0u : 1u;
+    int *head, *cnt;
+    unsigned tgt;
+    if (col < nI) {
+      const int sl = slot_of(row, col);
+      head = &slot_first[sl];
+      cnt = &slot_cnt[sl];
+      tgt = 1u << 30 | (unsigned)sl;
+    } else {
+      const size_t q = (size_t)(row - nI) * ns + (col - nI);
+      head = &ss_first[q];
+      cnt = &ss_cnt[q];
+      tgt = 2u << 30 | (unsigned)((row - nI) << 12 | (col - nI));
+    }
     d->h_enext[e] = *head;
-    *head = enc;
+    *head = (int)(e << 1 | (int)tr);
+    ++*cnt;
+    tgt_of[e] = tgt;
+    d->h_edge_tgt[e] = tgt | tr << 29;
   }
-  for (int si = 0; si < ns; ++si)
-    for (int sj = 0; sj < si; ++sj)
-      if (ss_first[(size_t)si * ns + sj] >= 0) {
-        d->h_ss_pair.push_back(si << 12 | sj);
-        d->h_ss_edge.push_back(ss_first[(size_t)si * ns + sj]);
-      }
+  for (int e = 0; e < E; ++e) {
+    const unsigned tgt = tgt_of[e];
+    if (!tgt) continue;
+    const bool dense = (tgt >> 30) == 2;
+    const int idx = (int)(tgt & 0x1fffffffu);
+    const size_t q = dense ? (size_t)(idx >> 12) * ns + (idx & 4095) : (size_t)idx;
+    const int cnt = dense ? ss_cnt[q] : slot_cnt[q];
+    if (cnt > 1) {
+      d->h_edge_tgt[e] = 3u << 30;
+      const int first = dense ? ss_first[q] : slot_first[q];
+      if ((first >> 1) == e) d->h_multi.push_back(make_int2((int)tgt, first));   // once per pair
+    }
+  }
+  for (int q = 0; q < NB; ++q)
+    if (srow[q] >= 0 && scol[q] >= 0 && slot_cnt[q] == 0) d->h_zero.push_back(q);
   // ---- forward tasks per level: (target, slot a, slot b) sorted by target
   struct Contrib {
     unsigned target;
-    int a, b;
+    int a, b, k;
   };
   std::vector<Contrib> cl;
-  d->h_ltask.assign((size_t)NL + 1, 0);
   long long total_contrib = 0;
   for (int l = 0; l < NL; ++l) {
     cl.clear();
@@ -689,14 +894,13 @@ Direct* direct_create(hipStream_t s, DevArena* arena, int V, int n, const int* f
       const std::vector<int>& v = st[k];
       for (size_t x = 0; x < v.size(); ++x) {
         const int i = v[x], sa = colbase[k] + (int)x;
-        cl.push_back({T_RHS << 28 | (unsigned)i, sa, sa});
         for (size_t y = 0; y <= x; ++y) {
           const int j = v[y], sb = colbase[k] + (int)y;   // i >= j
           unsigned tg;
           if (j >= nI) tg = T_DENSE << 28 | (unsigned)((i - nI) << 12 | (j - nI));
           else if (i == j) tg = T_DIAG << 28 | (unsigned)j;
           else tg = T_OFF << 28 | (unsigned)slot_of(i, j);
-          cl.push_back({tg, sa, sb});
+          cl.push_back({tg, sa, sb, k});
         }
       }
     }
@@ -706,46 +910,45 @@ Direct* direct_create(hipStream_t s, DevArena* arena, int V, int n, const int* f
       return no("too much fill");
     }
     std::stable_sort(cl.begin(), cl.end(), [](const Contrib& x, const Contrib& y) { return x.target < y.target; });
-    d->h_ltask[l] = (int)d->h_tk_target.size();
+    ltask[l] = (int)d->h_tk.size();
     for (size_t q = 0; q < cl.size(); ++q) {
       if (q == 0 || cl[q].target != cl[q - 1].target) {
-        d->h_tk_target.push_back(cl[q].target);
-        d->h_tk_cptr.push_back((int)d->h_ca.size());
+        if (!d->h_tk.empty() && (int)d->h_tk.size() > ltask[l]) d->h_tk.back().z = (int)d->h_ctr.size();
+        d->h_tk.push_back(make_int4((int)cl[q].target, (int)d->h_ctr.size(), 0, 0));
       }
-      d->h_ca.push_back(cl[q].a);
-      d->h_cb.push_back(cl[q].b);
+      d->h_ctr.push_back(make_int4(cl[q].a, cl[q].b, cl[q].k, 0));
     }
+    if ((int)d->h_tk.size() > ltask[l]) d->h_tk.back().z = (int)d->h_ctr.size();
   }
-  d->h_ltask[NL] = (int)d->h_tk_target.size();
-  d->h_tk_cptr.push_back((int)d->h_ca.size());
+  ltask[NL] = (int)d->h_tk.size();
+  d->h_lmeta = lslot;
+  d->h_lmeta.insert(d->h_lmeta.end(), ltask.begin(), ltask.end());
   // ---- dense pair table: bj descending so that the trailing blocks of pivot p are a prefix
   for (int bj = ns - 1; bj >= 0; --bj)
     for (int bi = bj; bi < ns; ++bi) d->h_dpair.push_back((unsigned short)(bi << 8 | bj));
 
   hipError_t e = hipSuccess;
   DirectDev& D = d->dev;
-  D.n = n; D.nI = nI; D.ns = ns; D.NL = NL; D.E = E; D.NB = NB; D.tri = tri; D.nss = (int)d->h_ss_pair.size();
-  D.vertex_pos = up(s, arena, d->h_vertex_pos, &e);
+  D.n = n; D.nI = nI; D.ns = ns; D.NL = NL; D.E = E; D.NB = NB; D.tri = tri;
+  D.nzero = (int)d->h_zero.size();
+  D.nmulti = (int)d->h_multi.size();
   D.pos_vertex = up(s, arena, d->h_pos_vertex, &e);
-  D.vptr = up(s, arena, d->h_vptr, &e);
-  D.vlist = up(s, arena, d->h_vlist, &e);
-  D.slot_row = up(s, arena, d->h_slot_row, &e);
-  D.slot_col = up(s, arena, d->h_slot_col, &e);
-  D.slot_edge = up(s, arena, d->h_slot_edge, &e);
+  D.vrec = up(s, arena, d->h_vrec, &e);
+  D.vover = up(s, arena, d->h_vover, &e);
+  D.edge_tgt = up(s, arena, d->h_edge_tgt, &e);
+  D.zero_slots = up(s, arena, d->h_zero, &e);
+  D.multi = up(s, arena, d->h_multi, &e);
   D.enext = up(s, arena, d->h_enext, &e);
-  D.ss_pair = up(s, arena, d->h_ss_pair, &e);
-  D.ss_edge = up(s, arena, d->h_ss_edge, &e);
-  D.lslot = up(s, arena, d->h_lslot, &e);
-  D.ltask = up(s, arena, d->h_ltask, &e);
-  D.tk_target = up(s, arena, d->h_tk_target, &e);
-  D.tk_cptr = up(s, arena, d->h_tk_cptr, &e);
-  D.ca = up(s, arena, d->h_ca, &e);
-  D.cb = up(s, arena, d->h_cb, &e);
+  D.slot_rc = up(s, arena, d->h_slot_rc, &e);
+  D.lmeta = up(s, arena, d->h_lmeta, &e);
+  D.tk = up(s, arena, d->h_tk, &e);
+  D.ctr = up(s, arena, d->h_ctr, &e);
   D.dpair = up(s, arena, d->h_dpair, &e);
-  D.Wd = (double*)arena->take(sizeof(double) * 9 * (size_t)std::max(nI, 1));
-  D.Wo = (double*)arena->take(sizeof(double) * 9 * (size_t)std::max(NB, 1));
+  D.Wd = (double*)arena->take(sizeof(double) * kBS * (size_t)std::max(nI, 1));
+  D.Wo = (double*)arena->take(sizeof(double) * kBS * (size_t)std::max(NB, 1));
   D.escr = (double*)arena->take(sizeof(double) * 27 * (size_t)std::max(E, 1));
-  if (e == hipSuccess && (!D.Wd || !D.Wo || !D.escr)) e = hipErrorOutOfMemory;
+  D.zsc = (double*)arena->take(sizeof(double) * 2 * (size_t)std::max(E, 1));
+  if (e == hipSuccess && (!D.Wd || !D.Wo || !D.escr || !D.zsc)) e = hipErrorOutOfMemory;
   if (e == hipSuccess)
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_direct), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget);
   if (e != hipSuccess) {
