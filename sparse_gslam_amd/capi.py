@@ -340,6 +340,10 @@ class Optimizer:
         it = self._check(lib().sgo_solve(self._h, _dp(x), C.byref(rr)), "sgo_solve")
         return x, it, rr.value
 
+    def last_error(self) -> str:
+        """Text of the last error on this context (sgo_last_error)."""
+        return lib().sgo_last_error(self._h).decode()
+
     def solver_description(self) -> str:
         """Which solver sgo_optimize_gn runs for the resident graph (sgo_solver_description)."""
         return lib().sgo_solver_description(self._h).decode()

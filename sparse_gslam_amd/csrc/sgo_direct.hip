@@ -37,7 +37,7 @@ namespace sgo {
 
 namespace {
 
-constexpr int kDT = 1024;               // threads of the workgroup
+constexpr int kDT = 512;                // threads of the workgroup
 constexpr int kMaxSep = 50;             // separators: 150 x 150 packed triangle = 91 KB of LDS
 constexpr int kMaxLevels = 24;
 constexpr int kMaxEdges = 1 << 15;
@@ -314,6 +314,7 @@ __global__ __launch_bounds__(kDT) void k_direct(DirectDev D, EdgeListDev el, dou
   double* pinv = Sd + D.tri;              // [ns][6] inverses of the separators' pivot blocks
   double* red = pinv + 6 * (size_t)D.ns;  // [2][16] chi2 partials
   int* lmeta = reinterpret_cast<int*>(red + 32);   // [2 (NL + 1)]
+  unsigned short* dpl = reinterpret_cast<unsigned short*>(lmeta + 2 * (D.NL + 1));   // [ns (ns + 1) / 2] dense block pairs
   __shared__ int fail_flag;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = D.n, nI = D.nI, ns = D.ns, NL = D.NL;
@@ -321,6 +322,7 @@ __global__ __launch_bounds__(kDT) void k_direct(DirectDev D, EdgeListDev el, dou
   if (tid == 0) fail_flag = 0;
   for (int k = tid; k < 2 * (NL + 1); k += kDT) lmeta[k] = D.lmeta[k];
   for (int k = tid; k < D.tri; k += kDT) Sd[k] = 0.0;
+  for (int k = tid; k < D.ns * (D.ns + 1) / 2; k += kDT) dpl[k] = D.dpair[k];
   for (int k = tid; k < D.E; k += kDT) {
     double sz, cz;
     sincos(el.zinv[2 * E + k], &sz, &cz);
@@ -348,7 +350,6 @@ __global__ __launch_bounds__(kDT) void k_direct(DirectDev D, EdgeListDev el, dou
     }
   };
   prefetch(0);
-  const int mypair = D.dpair[tid < ns * (ns + 1) / 2 ? tid : 0];   // the dense block pair this thread updates (static)
   const unsigned long long clk0 = __builtin_amdgcn_s_memtime();
   int done = 0, fail = 0;
   for (int it = 0; it <= iters; ++it) {
@@ -482,45 +483,64 @@ __global__ __launch_bounds__(kDT) void k_direct(DirectDev D, EdgeListDev el, dou
       double iv[6];
 #pragma unroll
       for (int c = 0; c < 6; ++c) iv[c] = pinv[6 * p + c];
-      for (int t = tq; t < cnt + m; t += kDT) {
-        if (t < cnt) {
-          const int pr = t < kDT ? mypair : (int)D.dpair[t], bi = pr >> 8, bj = pr & 255;
-          double Wa[9], Wb[9], Tm[9], nb[9];
+      // Work items: one ROW of a trailing block (three lanes per block) or of a right-hand-side entry, on all waves
+      // but the last; the last wave's first lane forms the NEXT pivot block whole and inverts it for everybody.
+      // With a handful of busy waves a step costs the instruction stream of its longest wave (~5 cycles per
+      // instruction), so the two jobs run side by side instead of one after the other in the same wave.
+      constexpr int kWorkers = kDT - 64;
+      if (tid >= kWorkers) {
+        if (tid == kWorkers) {
+          const int rb0 = tri_at(3 * (p + 1), 0), rb1 = rb0 + 3 * (p + 1) + 1, rb2 = rb1 + 3 * (p + 1) + 2;
+          double W[9], Tm[9];
 #pragma unroll
-          for (int r = 0; r < 3; ++r)
-#pragma unroll
-            for (int q = 0; q < 3; ++q) {
-              Wa[3 * r + q] = Sd[tri_at(3 * bi + r, P + q)];
-              Wb[3 * r + q] = Sd[tri_at(3 * bj + r, P + q)];
-            }
-          mul_sym(Wa, iv, Tm);
-#pragma unroll
-          for (int r = 0; r < 3; ++r)
-#pragma unroll
-            for (int q = 0; q < 3; ++q)
-              if (bi != bj || r >= q) {
-                nb[3 * r + q] = Sd[tri_at(3 * bi + r, 3 * bj + q)] -
-                                (Tm[3 * r] * Wb[3 * q] + Tm[3 * r + 1] * Wb[3 * q + 1] + Tm[3 * r + 2] * Wb[3 * q + 2]);
-                Sd[tri_at(3 * bi + r, 3 * bj + q)] = nb[3 * r + q];
-              }
-          if (bi == p + 1 && bj == p + 1) {
-            double nv[6];
-            const bool ok = inv_sym3(nb[0], nb[3], nb[6], nb[4], nb[7], nb[8], nv);
-#pragma unroll
-            for (int c = 0; c < 6; ++c) pinv[6 * (p + 1) + c] = nv[c];
-            if (!ok) atomicOr(&fail_flag, 1);
+          for (int q = 0; q < 3; ++q) {
+            W[q] = Sd[rb0 + P + q];
+            W[3 + q] = Sd[rb1 + P + q];
+            W[6 + q] = Sd[rb2 + P + q];
           }
-        } else {
-          const int bi = p + 1 + (t - cnt);
-          double Wa[9], Tm[9];
+          mul_sym(W, iv, Tm);
+          const int d0 = rb0 + 3 * (p + 1), d1 = rb1 + 3 * (p + 1), d2 = rb2 + 3 * (p + 1);
+          const double e00 = Sd[d0] - (Tm[0] * W[0] + Tm[1] * W[1] + Tm[2] * W[2]);
+          const double e10 = Sd[d1] - (Tm[3] * W[0] + Tm[4] * W[1] + Tm[5] * W[2]);
+          const double e11 = Sd[d1 + 1] - (Tm[3] * W[3] + Tm[4] * W[4] + Tm[5] * W[5]);
+          const double e20 = Sd[d2] - (Tm[6] * W[0] + Tm[7] * W[1] + Tm[8] * W[2]);
+          const double e21 = Sd[d2 + 1] - (Tm[6] * W[3] + Tm[7] * W[4] + Tm[8] * W[5]);
+          const double e22 = Sd[d2 + 2] - (Tm[6] * W[6] + Tm[7] * W[7] + Tm[8] * W[8]);
+          double nv[6];
+          const bool ok = inv_sym3(e00, e10, e20, e11, e21, e22, nv);
 #pragma unroll
-          for (int r = 0; r < 3; ++r)
-#pragma unroll
-            for (int q = 0; q < 3; ++q) Wa[3 * r + q] = Sd[tri_at(3 * bi + r, P + q)];
-          mul_sym(Wa, iv, Tm);
-          const double b0 = bs[P], b1 = bs[P + 1], b2 = bs[P + 2];
-#pragma unroll
-          for (int r = 0; r < 3; ++r) bs[3 * bi + r] -= Tm[3 * r] * b0 + Tm[3 * r + 1] * b1 + Tm[3 * r + 2] * b2;
+          for (int c = 0; c < 6; ++c) pinv[6 * (p + 1) + c] = nv[c];
+          Sd[d0] = e00;
+          Sd[d1] = e10;
+          Sd[d1 + 1] = e11;
+          Sd[d2] = e20;
+          Sd[d2 + 1] = e21;
+          Sd[d2 + 2] = e22;
+          if (!ok) atomicOr(&fail_flag, 1);
+        }
+      } else {
+        const double p0 = bs[P], p1 = bs[P + 1], p2 = bs[P + 2];
+        for (int u = tq; u < 3 * (cnt + m); u += kWorkers) {
+          const bool blk = u < 3 * cnt;
+          const int v = blk ? u : u - 3 * cnt;
+          const int g = v / 3, r = v - 3 * g;
+          const int pr = blk ? (int)dpl[g] : ((p + 1 + g) << 8), bi = pr >> 8, bj = pr & 255;
+          const int ra = tri_at(3 * bi + r, 0);
+          const double a0 = Sd[ra + P], a1 = Sd[ra + P + 1], a2 = Sd[ra + P + 2];
+          const double t0 = a0 * iv[0] + a1 * iv[1] + a2 * iv[2];
+          const double t1 = a0 * iv[1] + a1 * iv[3] + a2 * iv[4];
+          const double t2 = a0 * iv[2] + a1 * iv[4] + a2 * iv[5];
+          if (!blk) {
+            bs[3 * bi + r] -= t0 * p0 + t1 * p1 + t2 * p2;
+            continue;
+          }
+          const bool dg = bi == bj;
+          if (dg && bi == p + 1) continue;   // the next pivot block: the last wave's job
+          const int rb0 = tri_at(3 * bj, 0), rb1 = rb0 + 3 * bj + 1, rb2 = rb1 + 3 * bj + 2;
+          double* out = Sd + ra + 3 * bj;
+          out[0] -= t0 * Sd[rb0 + P] + t1 * Sd[rb0 + P + 1] + t2 * Sd[rb0 + P + 2];
+          if (!dg || r >= 1) out[1] -= t0 * Sd[rb1 + P] + t1 * Sd[rb1 + P + 1] + t2 * Sd[rb1 + P + 2];
+          if (!dg || r >= 2) out[2] -= t0 * Sd[rb2 + P] + t1 * Sd[rb2 + P + 1] + t2 * Sd[rb2 + P + 2];
         }
       }
       __syncthreads();
@@ -763,7 +783,8 @@ Direct* direct_create(hipStream_t s, DevArena* arena, int V, int n, const int* f
   }
   if (NL > kMaxLevels) return no("elimination tree too deep");
   const int tri = 3 * ns * (3 * ns + 1) / 2;
-  const size_t lds_bytes = sizeof(double) * (3 * (size_t)n + (size_t)tri + 6 * (size_t)ns + 32) + sizeof(int) * 2 * ((size_t)NL + 1);
+  const size_t lds_bytes = sizeof(double) * (3 * (size_t)n + (size_t)tri + 6 * (size_t)ns + 32) + sizeof(int) * 2 * ((size_t)NL + 1) +
+                           sizeof(unsigned short) * ((size_t)ns * (ns + 1) / 2 + 4);
   if (lds_bytes > kLdsBudget) return no("right-hand side + separator block exceed the LDS");
 
   Direct* d = new Direct();

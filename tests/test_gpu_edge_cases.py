@@ -23,9 +23,11 @@ def _check_against_oracle(opt, args, iters=10, tol=1e-6):
     return P
 
 
-@pytest.fixture(scope="module")
-def opt():
-    o = capi.Optimizer(0, pcg_tol=1e-10, pcg_maxit=100000)
+@pytest.fixture(scope="module", params=["auto", "pcg"])
+def opt(request):
+    """Both ways a small graph can run: the single-launch direct path where it qualifies (default), and the
+    multigrid PCG path alone (direct_rows = 0)."""
+    o = capi.Optimizer(0, pcg_tol=1e-10, pcg_maxit=100000, **({"direct_rows": 0} if request.param == "pcg" else {}))
     yield o
     o.close()
 

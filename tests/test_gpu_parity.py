@@ -19,7 +19,7 @@ def _oracle():
 
 @pytest.fixture(scope="module")
 def opt():
-    o = capi.Optimizer(0, pcg_tol=1e-10, pcg_maxit=200000)
+    o = capi.Optimizer(0, pcg_tol=1e-10, pcg_maxit=200000, direct_rows=0)   # the PCG path (tests/test_gpu_direct.py covers the other)
     yield o
     o.close()
 
@@ -84,7 +84,7 @@ def test_gauss_newton_matches_direct_oracle(opt, name):
 # ------------------------------------------------------------------ AMG-preconditioned solver
 @pytest.fixture(scope="module")
 def opt_amg():
-    o = capi.Optimizer(0, solver=capi.SOLVER_PCG_AMG, pcg_tol=1e-10, pcg_maxit=5000)
+    o = capi.Optimizer(0, solver=capi.SOLVER_PCG_AMG, pcg_tol=1e-10, pcg_maxit=5000, direct_rows=0)
     yield o
     o.close()
 
