@@ -650,17 +650,6 @@ __global__ __launch_bounds__(kDT) void k_direct(DirectDev D, EdgeListDev el, dou
 }
 
 // ------------------------------------------------------------------------------------------------ host
-template <typename T>
-T* up(hipStream_t s, DevArena* ar, const std::vector<T>& v, hipError_t* e) {
-  T* p = (T*)ar->take(sizeof(T) * std::max<size_t>(v.size(), 1));
-  if (!p) {
-    *e = hipErrorOutOfMemory;
-    return nullptr;
-  }
-  if (!v.empty() && *e == hipSuccess) *e = hipMemcpyAsync(p, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice, s);
-  return p;
-}
-
 }  // namespace
 
 struct Direct {
@@ -672,6 +661,7 @@ struct Direct {
   std::vector<int2> h_multi, h_slot_rc;
   std::vector<unsigned> h_edge_tgt;
   std::vector<unsigned short> h_dpair;
+  std::vector<char> h_blob;   // what is uploaded: must outlive the asynchronous copy
 };
 
 const DirectInfo& direct_info(const Direct* d) { return d->info; }
@@ -754,33 +744,55 @@ Direct* direct_create(hipStream_t s, DevArena* arena, int V, int n, const int* f
     if (is_sep[f]) order.push_back(f);
   std::vector<int> pos((size_t)n);
   for (int p = 0; p < n; ++p) pos[order[p]] = p;
-  // ---- symbolic factorisation of the sparse columns
-  std::vector<std::vector<int>> st((size_t)nI), kids((size_t)nI);
+  // ---- symbolic factorisation of the sparse columns (flat storage: this runs before every optimize(20) of the
+  //      reference's loop, slc.cpp:286, and a thousand small vectors cost more than the arithmetic)
+  struct Span {
+    const int *b, *e;
+    size_t size() const { return (size_t)(e - b); }
+    bool empty() const { return b == e; }
+    const int* begin() const { return b; }
+    const int* end() const { return e; }
+    int operator[](size_t q) const { return b[q]; }
+  };
+  std::vector<int> st_ptr((size_t)nI + 1, 0), st_idx, first_kid((size_t)std::max(nI, 1), -1), next_sib((size_t)std::max(nI, 1), -1),
+      level((size_t)std::max(nI, 1), 0);
+  st_idx.reserve(6 * (size_t)nI + 64);
+  int NL = 0;
   {
-    std::vector<std::vector<int>> later((size_t)nI);
+    std::vector<int> lptr((size_t)nI + 1, 0), lidx;
+    for (auto& pr : pairs) {
+      const int a = std::min(pos[pr.first], pos[pr.second]);
+      if (a < nI) ++lptr[a + 1];
+    }
+    for (int k = 0; k < nI; ++k) lptr[k + 1] += lptr[k];
+    lidx.resize((size_t)lptr[nI]);
+    std::vector<int> cur(lptr.begin(), lptr.end() - 1);
     for (auto& pr : pairs) {
       const int a = std::min(pos[pr.first], pos[pr.second]), b = std::max(pos[pr.first], pos[pr.second]);
-      if (a < nI) later[a].push_back(b);
+      if (a < nI) lidx[cur[a]++] = b;
     }
-    std::vector<int> tmp;
+    std::vector<int> v;
+    v.reserve(256);
     for (int k = 0; k < nI; ++k) {
-      std::vector<int>& v = later[k];
-      for (int c : kids[k])
-        for (int i : st[c])
-          if (i != k) v.push_back(i);
+      v.assign(lidx.begin() + lptr[k], lidx.begin() + lptr[k + 1]);
+      for (int c = first_kid[k]; c >= 0; c = next_sib[c]) {
+        for (int q = st_ptr[c]; q < st_ptr[c + 1]; ++q)
+          if (st_idx[q] != k) v.push_back(st_idx[q]);
+        level[k] = std::max(level[k], level[c] + 1);
+      }
       std::sort(v.begin(), v.end());
       v.erase(std::unique(v.begin(), v.end()), v.end());
       if ((int)v.size() > kMaxColumn) return no("a column has more blocks than a wave holds");
-      st[k] = v;
-      if (!v.empty() && v[0] < nI) kids[v[0]].push_back(k);
+      st_idx.insert(st_idx.end(), v.begin(), v.end());
+      st_ptr[k + 1] = (int)st_idx.size();
+      if (!v.empty() && v[0] < nI) {
+        next_sib[k] = first_kid[v[0]];
+        first_kid[v[0]] = k;
+      }
+      NL = std::max(NL, level[k] + 1);
     }
   }
-  std::vector<int> level((size_t)nI, 0);
-  int NL = 0;
-  for (int k = 0; k < nI; ++k) {
-    for (int c : kids[k]) level[k] = std::max(level[k], level[c] + 1);
-    NL = std::max(NL, level[k] + 1);
-  }
+  auto ST = [&](int k) { return Span{st_idx.data() + st_ptr[k], st_idx.data() + st_ptr[k + 1]}; };
   if (NL > kMaxLevels) return no("elimination tree too deep");
   const int tri = 3 * ns * (3 * ns + 1) / 2;
   const size_t lds_bytes = sizeof(double) * (3 * (size_t)n + (size_t)tri + 6 * (size_t)ns + 32) + sizeof(int) * 2 * ((size_t)NL + 1) +
@@ -796,7 +808,7 @@ Direct* direct_create(hipStream_t s, DevArena* arena, int V, int n, const int* f
   for (int l = 0; l < NL; ++l) {
     lslot[l] = (int)srow.size();
     for (int k : lcols[l]) {
-      const int len = std::max<int>(1, (int)st[k].size());
+      const int len = std::max<int>(1, (int)ST(k).size());
       const int cur = (int)srow.size();
       if ((cur & 63) + len > 64)
         for (int q = cur; q < ((cur + 63) & ~63); ++q) {
@@ -804,11 +816,11 @@ Direct* direct_create(hipStream_t s, DevArena* arena, int V, int n, const int* f
           scol.push_back(-1);
         }
       colbase[k] = (int)srow.size();
-      if (st[k].empty()) {
+      if (ST(k).empty()) {
         srow.push_back(-1);
         scol.push_back(k);
       }
-      for (int i : st[k]) {
+      for (int i : ST(k)) {
         srow.push_back(i);
         scol.push_back(k);
       }
@@ -823,7 +835,7 @@ Direct* direct_create(hipStream_t s, DevArena* arena, int V, int n, const int* f
   d->h_slot_rc.resize((size_t)NB);
   for (int q = 0; q < NB; ++q) d->h_slot_rc[q] = make_int2(srow[q], scol[q]);
   auto slot_of = [&](int i, int k) -> int {   // stored block (row i, column k), k < nI
-    const std::vector<int>& v = st[k];
+    const Span v = ST(k);
     const auto it = std::lower_bound(v.begin(), v.end(), i);
     return colbase[k] + (int)(it - v.begin());
   };
@@ -835,25 +847,34 @@ Direct* direct_create(hipStream_t s, DevArena* arena, int V, int n, const int* f
     vertex_pos[free_id[order[p]]] = p;
   }
   {   // incident edges of every position: four inline, the rest in an overflow list
-    std::vector<std::vector<int>> inc((size_t)n);
+    std::vector<int> iptr((size_t)n + 1, 0), iidx;
     for (int e = 0; e < E; ++e) {
       const int a = vertex_pos[ei[e]], b = vertex_pos[ej[e]];
-      if (a >= 0) inc[a].push_back(e << 1);
-      if (b >= 0) inc[b].push_back(e << 1 | 1);
+      if (a >= 0) ++iptr[a + 1];
+      if (b >= 0) ++iptr[b + 1];
+    }
+    for (int p = 0; p < n; ++p) iptr[p + 1] += iptr[p];
+    iidx.resize((size_t)iptr[n]);
+    std::vector<int> cur(iptr.begin(), iptr.end() - 1);
+    for (int e = 0; e < E; ++e) {
+      const int a = vertex_pos[ei[e]], b = vertex_pos[ej[e]];
+      if (a >= 0) iidx[cur[a]++] = e << 1;
+      if (b >= 0) iidx[cur[b]++] = e << 1 | 1;
     }
     d->h_vrec.resize((size_t)n);
     for (int p = 0; p < n; ++p) {
-      const std::vector<int>& v = inc[p];
+      const int* v = iidx.data() + iptr[p];
+      const int cnt = iptr[p + 1] - iptr[p];
       int4 r = make_int4(-1, -1, -1, -1);
-      const int inl = v.size() <= 4 ? (int)v.size() : 3;
+      const int inl = cnt <= 4 ? cnt : 3;
       if (inl > 0) r.x = v[0];
       if (inl > 1) r.y = v[1];
       if (inl > 2) r.z = v[2];
       if (inl > 3) r.w = v[3];
-      if ((int)v.size() > inl) {
+      if (cnt > inl) {
         r.w = -2 - (int)d->h_vover.size();
-        d->h_vover.push_back((int)v.size() - inl);
-        for (size_t q = (size_t)inl; q < v.size(); ++q) d->h_vover.push_back(v[q]);
+        d->h_vover.push_back(cnt - inl);
+        for (int q = inl; q < cnt; ++q) d->h_vover.push_back(v[q]);
       }
       d->h_vrec[p] = r;
     }
@@ -912,7 +933,7 @@ Direct* direct_create(hipStream_t s, DevArena* arena, int V, int n, const int* f
   for (int l = 0; l < NL; ++l) {
     cl.clear();
     for (int k : lcols[l]) {
-      const std::vector<int>& v = st[k];
+      const Span v = ST(k);
       for (size_t x = 0; x < v.size(); ++x) {
         const int i = v[x], sa = colbase[k] + (int)x;
         for (size_t y = 0; y <= x; ++y) {
@@ -953,25 +974,57 @@ Direct* direct_create(hipStream_t s, DevArena* arena, int V, int n, const int* f
   D.n = n; D.nI = nI; D.ns = ns; D.NL = NL; D.E = E; D.NB = NB; D.tri = tri;
   D.nzero = (int)d->h_zero.size();
   D.nmulti = (int)d->h_multi.size();
-  D.pos_vertex = up(s, arena, d->h_pos_vertex, &e);
-  D.vrec = up(s, arena, d->h_vrec, &e);
-  D.vover = up(s, arena, d->h_vover, &e);
-  D.edge_tgt = up(s, arena, d->h_edge_tgt, &e);
-  D.zero_slots = up(s, arena, d->h_zero, &e);
-  D.multi = up(s, arena, d->h_multi, &e);
-  D.enext = up(s, arena, d->h_enext, &e);
-  D.slot_rc = up(s, arena, d->h_slot_rc, &e);
-  D.lmeta = up(s, arena, d->h_lmeta, &e);
-  D.tk = up(s, arena, d->h_tk, &e);
-  D.ctr = up(s, arena, d->h_ctr, &e);
-  D.dpair = up(s, arena, d->h_dpair, &e);
+  {   // all lists in ONE host blob, one allocation, one copy (a dozen small pageable copies cost 0.1 ms)
+    std::vector<char>& blob = d->h_blob;
+    size_t off[12], total = 0;
+    int q = 0;
+    auto put = [&](const void* src, size_t bytes) {
+      total = (total + 15) & ~(size_t)15;
+      off[q++] = total;
+      blob.resize(total + bytes);
+      if (bytes) std::memcpy(blob.data() + total, src, bytes);
+      total += bytes;
+    };
+    put(d->h_pos_vertex.data(), sizeof(int) * d->h_pos_vertex.size());
+    put(d->h_vrec.data(), sizeof(int4) * d->h_vrec.size());
+    put(d->h_vover.data(), sizeof(int) * d->h_vover.size());
+    put(d->h_edge_tgt.data(), sizeof(unsigned) * d->h_edge_tgt.size());
+    put(d->h_zero.data(), sizeof(int) * d->h_zero.size());
+    put(d->h_multi.data(), sizeof(int2) * d->h_multi.size());
+    put(d->h_enext.data(), sizeof(int) * d->h_enext.size());
+    put(d->h_slot_rc.data(), sizeof(int2) * d->h_slot_rc.size());
+    put(d->h_lmeta.data(), sizeof(int) * d->h_lmeta.size());
+    put(d->h_tk.data(), sizeof(int4) * d->h_tk.size());
+    put(d->h_ctr.data(), sizeof(int4) * d->h_ctr.size());
+    put(d->h_dpair.data(), sizeof(unsigned short) * d->h_dpair.size());
+    char* base = (char*)arena->take(std::max<size_t>(total, 16));
+    if (!base) e = hipErrorOutOfMemory;
+    else e = hipMemcpyAsync(base, blob.data(), total, hipMemcpyHostToDevice, s);
+    if (base) {
+      D.pos_vertex = (const int*)(base + off[0]);
+      D.vrec = (const int4*)(base + off[1]);
+      D.vover = (const int*)(base + off[2]);
+      D.edge_tgt = (const unsigned*)(base + off[3]);
+      D.zero_slots = (const int*)(base + off[4]);
+      D.multi = (const int2*)(base + off[5]);
+      D.enext = (const int*)(base + off[6]);
+      D.slot_rc = (const int2*)(base + off[7]);
+      D.lmeta = (const int*)(base + off[8]);
+      D.tk = (const int4*)(base + off[9]);
+      D.ctr = (const int4*)(base + off[10]);
+      D.dpair = (const unsigned short*)(base + off[11]);
+    }
+  }
   D.Wd = (double*)arena->take(sizeof(double) * kBS * (size_t)std::max(nI, 1));
   D.Wo = (double*)arena->take(sizeof(double) * kBS * (size_t)std::max(NB, 1));
   D.escr = (double*)arena->take(sizeof(double) * 27 * (size_t)std::max(E, 1));
   D.zsc = (double*)arena->take(sizeof(double) * 2 * (size_t)std::max(E, 1));
   if (e == hipSuccess && (!D.Wd || !D.Wo || !D.escr || !D.zsc)) e = hipErrorOutOfMemory;
-  if (e == hipSuccess)
+  static bool attr_set = false;   // per process and device function: idempotent, so a race only repeats the call
+  if (e == hipSuccess && !attr_set) {
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_direct), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget);
+    attr_set = e == hipSuccess;
+  }
   if (e != hipSuccess) {
     *err = std::string("direct_create: ") + hipGetErrorString(e);
     delete d;
