@@ -470,24 +470,40 @@ int plan_rows(int V, const double* poses, const uint8_t* fixed, int E, const int
     if (const char* e = std::getenv("SGO_TILE_DIV")) tile_div = std::max(1, std::atoi(e));
     long long nblk = 0;
     for (int k = 0; k < ns; ++k) nblk += col[k] >= 0;
-    long long target = std::max<long long>(512, (nblk / 2 + tile_div - 1) / tile_div);   // pairs per tile
+    // A tile costs what it STORES (measured, C4: 4.8 cycles per stored block + 90 per wave group, against 20-47 k
+    // cycles per tile when tiles were cut by slot count): its slots with a free column minus its intra-tile pairs,
+    // which are stored once.  Tiles are cut greedily to a block target; the target is re-derived from the total
+    // the cut produced (pairs that straddle two tiles are stored twice, so the total depends on the cut) until
+    // the tiles number one per CU.
+    long long target = std::max<long long>(512, (nblk / 2 * 5 / 4 + tile_div - 1) / tile_div);   // stored blocks per tile
     std::vector<int> mark(std::max(n, 1), -1);
     for (int attempt = 0; attempt < 6; ++attempt) {
-      tiles.clear();
       long long lds = 0;
-      int r = 0;
-      while (r < n) {
-        TileDesc T{};
-        T.row0 = r;
-        long long slots = 0;
-        while (r < n && (r == T.row0 || (slots < 2 * target && r - T.row0 < 4096))) {
-          slots += rowptr[r + 1] - rowptr[r];
-          ++r;
+      for (int pass = 0; pass < 4; ++pass) {
+        tiles.clear();
+        long long total = 0;
+        int r = 0;
+        while (r < n) {
+          TileDesc T{};
+          T.row0 = r;
+          long long blocks = 0;
+          while (r < n && (r == T.row0 || (blocks < target && r - T.row0 < 4096))) {
+            for (int k = rowptr[r]; k < rowptr[r + 1]; ++k) {
+              const int cc = col[k];
+              blocks += cc >= 0 && !(cc >= T.row0 && cc < r);   // a pair inside the tile was counted with its earlier row
+            }
+            ++r;
+          }
+          T.row1 = r;
+          total += blocks;
+          tiles.push_back(T);
         }
-        T.row1 = r;
-        for (int q = T.row0; q < T.row1; ++q) tile_of_row[q] = (int)tiles.size();
-        tiles.push_back(T);
+        const int K = (int)tiles.size();
+        if (attempt > 0 || target <= 512 || (K <= tile_div && K >= tile_div - tile_div / 32)) break;
+        target = std::max<long long>(512, total / tile_div + (K > tile_div ? total / tile_div / 64 + 1 : 1));
       }
+      for (size_t t = 0; t < tiles.size(); ++t)
+        for (int q = tiles[t].row0; q < tiles[t].row1; ++q) tile_of_row[q] = (int)t;
       // exact LDS need per tile: rows + halo columns + rows + staged entries, 24 B each
       bool fits = true;
       for (size_t t = 0; t < tiles.size() && fits; ++t) {
@@ -1857,6 +1873,27 @@ double sgo_debug_spmv0_us(sgo_ctx* c, int mode, int variant, int reps) {
                  "phase 1 %.0f, barrier %.0f, phase 2 %.0f, barrier %.0f\n", c->T0.ntile,
                  ph[0] / c->T0.ntile, ph[1] / c->T0.ntile, ph[2] / c->T0.ntile, ph[3] / c->T0.ntile, ph[4] / c->T0.ntile,
                  ph[5] / c->T0.ntile);
+    if (std::getenv("SGO_TILE_DUMP")) {   // per tile: rows, groups, stored blocks, halo columns, staged entries, phase cycles
+      std::vector<TileDesc> td((size_t)c->T0.ntile);
+      hipMemcpy(td.data(), c->T0.tile, sizeof(TileDesc) * td.size(), hipMemcpyDeviceToHost);
+      int ng = 0;
+      for (const TileDesc& T : td) ng = std::max(ng, T.g1);
+      std::vector<int> g1((size_t)ng + 1);
+      hipMemcpy(g1.data(), c->T0.grp1, sizeof(int) * g1.size(), hipMemcpyDeviceToHost);
+      for (int t = 0; t < c->T0.ntile; ++t)
+        std::fprintf(stderr, "TILE %d %d %d %d %d %d %lld %lld %lld %lld %lld %lld\n", t, td[t].row1 - td[t].row0, td[t].g1 - td[t].g0,
+                     g1[td[t].g1] - g1[td[t].g0], td[t].h1 - td[t].h0, td[t].nstaged, st[8 * t + 1] - st[8 * t], st[8 * t + 2] - st[8 * t + 1],
+                     st[8 * t + 3] - st[8 * t + 2], st[8 * t + 4] - st[8 * t + 3], st[8 * t + 5] - st[8 * t + 4], st[8 * t + 6] - st[8 * t + 5]);
+    }
+    long long s0 = st[0], s1 = st[0], e0 = st[6], e1 = st[6], dmin = st[6] - st[0], dmax = dmin;
+    double dsum = 0.0;
+    for (int t = 0; t < c->T0.ntile; ++t) {
+      const long long a0 = st[8 * t], a6 = st[8 * t + 6], dd = a6 - a0;
+      s0 = std::min(s0, a0); s1 = std::max(s1, a0); e0 = std::min(e0, a6); e1 = std::max(e1, a6);
+      dmin = std::min(dmin, dd); dmax = std::max(dmax, dd); dsum += (double)dd;
+    }
+    std::fprintf(stderr, "[sgo] tile kernel, per tile (wave 0): cycles min %lld mean %.0f max %lld; first stamps spread over %lld cycles, "
+                 "last stamps over %lld; first start to last end %lld cycles\n", dmin, dsum / c->T0.ntile, dmax, s1 - s0, e1 - e0, e1 - s0);
   }
   return 1e3 * ms / reps;
 }
