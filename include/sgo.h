@@ -74,17 +74,19 @@ typedef struct sgo_opts {
                               sgo_kernel_profile() */
   int32_t verbose;         /* mirrors SparseOptimizer::setVerbose (graphs.cpp:21) */
   int32_t direct_rows;     /* small-graph path (solver PCG_AMG, one GPU): a graph with at most this many free poses
-                              whose elimination analysis fits -- trajectory chain + closures covered by <= 50
+                              whose elimination analysis fits -- trajectory chain + closures covered by <= 60
                               separator poses -- runs sgo_optimize_gn as ONE kernel launch of a sparse block
                               LDL^T (nested dissection of the chain, separators dense in LDS); 0 = never
-                              (env SGO_DIRECT_ROWS); the single-step entry points keep using the PCG path */
+                              (env SGO_DIRECT_ROWS); the single-step entry points keep using the PCG path.
+                              The path itself works (and wins) up to ~100k chain-like poses; the default stops
+                              where two backward-stable solvers stop agreeing to 1e-6 in chi2 (kappa ~ n^2) */
   int32_t reserved[7];
 } sgo_opts;
 
 /* Defaults (also applied when opts == NULL):
  * solver = PCG_AMG (graphs with <= 400 free poses are preconditioned by an explicit dense inverse,
  * i.e. solved directly; falls back to PCG_BJ only when a larger graph cannot be coarsened),
- * pcg_tol = 1e-8, pcg_maxit = 20000, pcg_chunk = 16, use_graph = 1, direct_rows = 2048. */
+ * pcg_tol = 1e-8, pcg_maxit = 20000, pcg_chunk = 16, use_graph = 1, direct_rows = 8192. */
 void sgo_default_opts(sgo_opts* o);
 
 typedef struct sgo_stats {

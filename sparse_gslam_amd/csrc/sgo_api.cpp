@@ -1257,7 +1257,7 @@ void sgo_default_opts(sgo_opts* o) {
   o->use_graph = 1;
   o->profile = 0;
   o->verbose = 0;
-  o->direct_rows = 2048;
+  o->direct_rows = 8192;
   if (const char* s = std::getenv("SGO_DIRECT_ROWS")) o->direct_rows = std::atoi(s);
   if (const char* s = std::getenv("SGO_SOLVER")) {
     if (!std::strcmp(s, "pcg") || !std::strcmp(s, "bj")) o->solver = SGO_SOLVER_PCG_BJ;

@@ -38,9 +38,9 @@ namespace sgo {
 namespace {
 
 constexpr int kDT = 512;                // threads of the workgroup
-constexpr int kMaxSep = 50;             // separators: 150 x 150 packed triangle = 91 KB of LDS
+constexpr int kMaxSep = 60;             // separators: 180 x 180 packed triangle = 130 KB of LDS
 constexpr int kMaxLevels = 24;
-constexpr int kMaxEdges = 1 << 15;
+constexpr int kMaxEdges = 1 << 18;
 constexpr int kMaxColumn = 63;          // stored blocks of one sparse column (a wave holds a column's segment)
 constexpr int kMaxContrib = 1 << 20;
 constexpr size_t kLdsBudget = 150 * 1024;
@@ -65,6 +65,7 @@ struct DirectDev {
   const unsigned short* dpair;  // dense block pairs (bi << 8 | bj), bi >= bj, sorted by bj descending
   double* Wd;                 // [nI][9] diagonal blocks of the sparse columns
   double* Wo;                 // [NB][9] stored blocks
+  double* xbg;                // [3 n] right-hand side / solution when it does not fit the LDS
   double* escr;               // [E][27] per-edge terms of the current linearisation: Hii(6) bi(3) Hjj(6) bj(3) [Hij(9)]
   double* zsc;                // [2][E] sin / cos of the inverse measurement's angle (constant per edge)
 };
@@ -77,25 +78,36 @@ __device__ __forceinline__ double fast_rcp(double x) {
   r = r * (2.0 - x * r);
   return r;
 }
-// inverse of a symmetric 3x3 (d00 d01 d02 d11 d12 d22); false when the block is not positive definite
+// Pivot blocks are applied through their 3x3 LDL^T factors, not through an explicit inverse: the pivots of the upper
+// elimination levels are Schur complements of long chain segments (kappa ~ 1e8 and more) and a factor solve is
+// backward stable whatever the block's conditioning, at the cost of two more reciprocals per pivot (5 % of the
+// kernel).  Its three pivots also ARE the positive-definiteness test (LinearSolverEigen's LDL^T failing).
+// f = {l10, l20, l21, 1/p0, 1/p1, 1/p2} of D = L diag(p) L^T (d00 d01 d02 d11 d12 d22); false when a pivot is not positive.
 __device__ __forceinline__ bool inv_sym3(double d00, double d01, double d02, double d11, double d12, double d22,
-                                         double (&iv)[6]) {
-  const double c00 = d11 * d22 - d12 * d12, c01 = d02 * d12 - d01 * d22, c02 = d01 * d12 - d02 * d11;
-  const double c11 = d00 * d22 - d02 * d02, c12 = d01 * d02 - d00 * d12, c22 = d00 * d11 - d01 * d01;
-  const double det = d00 * c00 + d01 * c01 + d02 * c02;
-  const double id = fast_rcp(det);
-  iv[0] = c00 * id; iv[1] = c01 * id; iv[2] = c02 * id; iv[3] = c11 * id; iv[4] = c12 * id; iv[5] = c22 * id;
-  return d00 > 0.0 && c22 > 0.0 && det > 0.0 && isfinite(det);
+                                         double (&f)[6]) {
+  const double r0 = fast_rcp(d00);
+  const double l10 = d01 * r0, l20 = d02 * r0;
+  const double p1 = d11 - l10 * d01;
+  const double r1 = fast_rcp(p1);
+  const double u21 = d12 - l20 * d01;
+  const double l21 = u21 * r1;
+  const double p2 = d22 - l20 * d02 - l21 * u21;
+  const double r2 = fast_rcp(p2);
+  f[0] = l10; f[1] = l20; f[2] = l21; f[3] = r0; f[4] = r1; f[5] = r2;
+  return d00 > 0.0 && p1 > 0.0 && p2 > 0.0 && isfinite(p2);
 }
-// T = W * S, W row-major 3x3, S symmetric (6)
-__device__ __forceinline__ void mul_sym(const double (&W)[9], const double (&S)[6], double (&T)[9]) {
+// x = D^-1 y through the factors
+__device__ __forceinline__ void solve3(const double* f, double y0, double y1, double y2, double& x0, double& x1, double& x2) {
+  const double z1 = y1 - f[0] * y0;
+  const double z2 = y2 - f[1] * y0 - f[2] * z1;
+  x2 = z2 * f[5];
+  x1 = z1 * f[4] - f[2] * x2;
+  x0 = y0 * f[3] - f[0] * x1 - f[1] * x2;
+}
+// T = W * D^-1 (D symmetric: row r of T solves D t = w_r)
+__device__ __forceinline__ void mul_sym(const double (&W)[9], const double (&F)[6], double (&T)[9]) {
 #pragma unroll
-  for (int r = 0; r < 3; ++r) {
-    const double a = W[3 * r], b = W[3 * r + 1], c = W[3 * r + 2];
-    T[3 * r] = a * S[0] + b * S[1] + c * S[2];
-    T[3 * r + 1] = a * S[1] + b * S[3] + c * S[4];
-    T[3 * r + 2] = a * S[2] + b * S[4] + c * S[5];
-  }
+  for (int r = 0; r < 3; ++r) solve3(F, W[3 * r], W[3 * r + 1], W[3 * r + 2], T[3 * r], T[3 * r + 1], T[3 * r + 2]);
 }
 // Stored 3x3 blocks are 80-byte records (row-major, one double of padding): 16-byte aligned, so a gathered
 // block is four 16-byte loads + one 8-byte load per lane instead of nine 8-byte ones.
@@ -306,13 +318,24 @@ __device__ __forceinline__ void run_task(const DirectDev& D, double* __restrict_
 
 constexpr int kPF = 1;   // forward tasks per thread whose records are fetched one level ahead
 
+// XG: the right-hand side / solution vector lives in global memory (graphs whose 24 n bytes do not fit the LDS
+// next to the separator block) instead of LDS.
+template <bool XG>
 __global__ __launch_bounds__(kDT) void k_direct(DirectDev D, EdgeListDev el, double* __restrict__ poses, int iters,
                                                 double* __restrict__ hist, DirectResult* __restrict__ res) {
   extern __shared__ double lds[];
-  double* xb = lds;                       // [3 n] right-hand side, then the solution, by elimination position
-  double* Sd = lds + 3 * (size_t)D.n;     // [tri] packed lower triangle of the separator block
+  double* xb;                             // [3 n] right-hand side, then the solution, by elimination position
+  double* Sd;                             // [tri] packed lower triangle of the separator block
+  if constexpr (XG) {
+    xb = D.xbg;
+    Sd = lds;
+  } else {
+    xb = lds;
+    Sd = lds + 3 * (size_t)D.n;
+  }
   double* pinv = Sd + D.tri;              // [ns][6] inverses of the separators' pivot blocks
-  double* red = pinv + 6 * (size_t)D.ns;  // [2][16] chi2 partials
+  double* bs = pinv + 6 * (size_t)D.ns;   // [3 ns] the separators' right-hand side / solution during the dense phase
+  double* red = bs + 3 * (size_t)D.ns;    // [2][16] chi2 partials
   int* lmeta = reinterpret_cast<int*>(red + 32);   // [2 (NL + 1)]
   unsigned short* dpl = reinterpret_cast<unsigned short*>(lmeta + 2 * (D.NL + 1));   // [ns (ns + 1) / 2] dense block pairs
   __shared__ int fail_flag;
@@ -475,8 +498,8 @@ __global__ __launch_bounds__(kDT) void k_direct(DirectDev D, EdgeListDev el, dou
       for (int c = 0; c < 6; ++c) pinv[c] = iv[c];
       if (!ok) atomicOr(&fail_flag, 1);
     }
+    for (int k = tq; k < 3 * ns; k += kDT) bs[k] = xb[3 * (size_t)nI + k];
     __syncthreads();
-    double* bs = xb + 3 * (size_t)nI;
     for (int p = 0; p + 1 < ns; ++p) {
       const int m = ns - 1 - p, cnt = m * (m + 1) / 2;
       const int P = 3 * p;
@@ -527,9 +550,8 @@ __global__ __launch_bounds__(kDT) void k_direct(DirectDev D, EdgeListDev el, dou
           const int pr = blk ? (int)dpl[g] : ((p + 1 + g) << 8), bi = pr >> 8, bj = pr & 255;
           const int ra = tri_at(3 * bi + r, 0);
           const double a0 = Sd[ra + P], a1 = Sd[ra + P + 1], a2 = Sd[ra + P + 2];
-          const double t0 = a0 * iv[0] + a1 * iv[1] + a2 * iv[2];
-          const double t1 = a0 * iv[1] + a1 * iv[3] + a2 * iv[4];
-          const double t2 = a0 * iv[2] + a1 * iv[4] + a2 * iv[5];
+          double t0, t1, t2;
+          solve3(iv, a0, a1, a2, t0, t1, t2);
           if (!blk) {
             bs[3 * bi + r] -= t0 * p0 + t1 * p1 + t2 * p2;
             continue;
@@ -566,13 +588,13 @@ __global__ __launch_bounds__(kDT) void k_direct(DirectDev D, EdgeListDev el, dou
         }
         const double* iv = pinv + 6 * i;
         const double y0 = readlane_d(b0, i), y1 = readlane_d(b1, i), y2 = readlane_d(b2, i);
-        const double x0 = iv[0] * y0 + iv[1] * y1 + iv[2] * y2;
-        const double x1 = iv[1] * y0 + iv[3] * y1 + iv[4] * y2;
-        const double x2 = iv[2] * y0 + iv[4] * y1 + iv[5] * y2;
+        double x0, x1, x2;
+        solve3(iv, y0, y1, y2, x0, x1, x2);
         if (lane == i) {
-          bs[3 * i] = x0;
-          bs[3 * i + 1] = x1;
-          bs[3 * i + 2] = x2;
+          double* xo = xb + 3 * (size_t)(nI + i);
+          xo[0] = x0;
+          xo[1] = x1;
+          xo[2] = x2;
         }
         if (lane < i) {
           b0 -= W[0] * x0 + W[3] * x1 + W[6] * x2;
@@ -614,9 +636,11 @@ __global__ __launch_bounds__(kDT) void k_direct(DirectDev D, EdgeListDev el, dou
           double iv[6];
           const bool ok = inv_sym3(d00, d01, d02, d11, d12, d22, iv);
           const double r0 = xb[3 * col] - v[0], r1 = xb[3 * col + 1] - v[1], r2 = xb[3 * col + 2] - v[2];
-          xb[3 * col] = iv[0] * r0 + iv[1] * r1 + iv[2] * r2;
-          xb[3 * col + 1] = iv[1] * r0 + iv[3] * r1 + iv[4] * r2;
-          xb[3 * col + 2] = iv[2] * r0 + iv[4] * r1 + iv[5] * r2;
+          double x0, x1, x2;
+          solve3(iv, r0, r1, r2, x0, x1, x2);
+          xb[3 * col] = x0;
+          xb[3 * col + 1] = x1;
+          xb[3 * col + 2] = x2;
           if (!ok) atomicOr(&fail_flag, 1);
         }
       }
@@ -662,6 +686,7 @@ struct Direct {
   std::vector<unsigned> h_edge_tgt;
   std::vector<unsigned short> h_dpair;
   std::vector<char> h_blob;   // what is uploaded: must outlive the asynchronous copy
+  bool xb_global = false;
 };
 
 const DirectInfo& direct_info(const Direct* d) { return d->info; }
@@ -795,9 +820,11 @@ Direct* direct_create(hipStream_t s, DevArena* arena, int V, int n, const int* f
   auto ST = [&](int k) { return Span{st_idx.data() + st_ptr[k], st_idx.data() + st_ptr[k + 1]}; };
   if (NL > kMaxLevels) return no("elimination tree too deep");
   const int tri = 3 * ns * (3 * ns + 1) / 2;
-  const size_t lds_bytes = sizeof(double) * (3 * (size_t)n + (size_t)tri + 6 * (size_t)ns + 32) + sizeof(int) * 2 * ((size_t)NL + 1) +
+  const size_t lds_fixed = sizeof(double) * ((size_t)tri + 9 * (size_t)ns + 32) + sizeof(int) * 2 * ((size_t)NL + 1) +
                            sizeof(unsigned short) * ((size_t)ns * (ns + 1) / 2 + 4);
-  if (lds_bytes > kLdsBudget) return no("right-hand side + separator block exceed the LDS");
+  const bool xb_global = lds_fixed + sizeof(double) * 3 * (size_t)n > kLdsBudget;   // the vector then lives in global memory
+  const size_t lds_bytes = lds_fixed + (xb_global ? 0 : sizeof(double) * 3 * (size_t)n);
+  if (lds_bytes > kLdsBudget) return no("separator block exceeds the LDS");
 
   Direct* d = new Direct();
   std::vector<std::vector<int>> lcols((size_t)NL);
@@ -1019,10 +1046,15 @@ Direct* direct_create(hipStream_t s, DevArena* arena, int V, int n, const int* f
   D.Wo = (double*)arena->take(sizeof(double) * kBS * (size_t)std::max(NB, 1));
   D.escr = (double*)arena->take(sizeof(double) * 27 * (size_t)std::max(E, 1));
   D.zsc = (double*)arena->take(sizeof(double) * 2 * (size_t)std::max(E, 1));
+  D.xbg = xb_global ? (double*)arena->take(sizeof(double) * 3 * (size_t)n) : nullptr;
+  if (xb_global && !D.xbg && e == hipSuccess) e = hipErrorOutOfMemory;
+  d->xb_global = xb_global;
   if (e == hipSuccess && (!D.Wd || !D.Wo || !D.escr || !D.zsc)) e = hipErrorOutOfMemory;
   static bool attr_set = false;   // per process and device function: idempotent, so a race only repeats the call
   if (e == hipSuccess && !attr_set) {
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_direct), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget);
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_direct<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_direct<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget);
     attr_set = e == hipSuccess;
   }
   if (e != hipSuccess) {
@@ -1042,7 +1074,8 @@ Direct* direct_create(hipStream_t s, DevArena* arena, int V, int n, const int* f
 
 hipError_t direct_optimize(Direct* d, hipStream_t s, const EdgeListDev& el, double* d_poses, int iters, double* d_hist,
                            DirectResult* d_res) {
-  SGO_LAUNCH(k_direct, dim3(1), dim3(kDT), d->info.lds_bytes, s, d->dev, el, d_poses, iters, d_hist, d_res);
+  if (d->xb_global) SGO_LAUNCH(k_direct<true>, dim3(1), dim3(kDT), d->info.lds_bytes, s, d->dev, el, d_poses, iters, d_hist, d_res);
+  else SGO_LAUNCH(k_direct<false>, dim3(1), dim3(kDT), d->info.lds_bytes, s, d->dev, el, d_poses, iters, d_hist, d_res);
   return hipGetLastError();
 }
 
