@@ -112,6 +112,46 @@ def golden_rel_err(config, iters, st):
     return None
 
 
+def reference_usage_session(device: int, V: int = 1000, closures: int = 30):
+    """The reference's own usage pattern at the reference's own size (slc.cpp:205-288): the graph grows along the
+    trajectory and after every accepted closure the WHOLE graph is re-initialised and optimised with optimize(20).
+    Latency per closure of libsgo (set_graph + optimize(20) + read-back; such graphs take the single-launch direct
+    path) and of the CPU oracle (analysis + 20 x sparse LDL^T, one thread) on the same graphs."""
+    from oracle import c_oracle
+    from sparse_gslam_amd import capi, synth
+    g = synth.manhattan(V, V - 1 + closures, seed=1, info_mode="full", init="odom", phi=10.0)
+    odo, clo = np.arange(V - 1), np.arange(V - 1, g.E)
+    clo = clo[np.argsort(np.maximum(g.ei[clo], g.ej[clo]))]
+    pg, pc = g.poses.copy(), g.poses.copy()
+    tg, tc, worst = [], [], 0.0
+    desc = ""
+    with capi.Optimizer(device) as opt:
+        for k, c in enumerate(clo):
+            last = int(max(g.ei[c], g.ej[c]))
+            edges = np.concatenate([odo[:last], clo[: k + 1]])
+            edges = edges[(g.ei[edges] <= last) & (g.ej[edges] <= last)]
+            sl = slice(0, last + 1)
+            a = lambda P: (P[sl], g.fixed[sl], g.ei[edges], g.ej[edges], g.meas[edges], g.info[edges], g.phi[edges])  # noqa: E731
+            t = time.perf_counter()
+            opt.set_graph(*a(pg))
+            done, st = opt.optimize(20)
+            pg[sl] = opt.get_poses()
+            tg.append(time.perf_counter() - t)
+            desc = opt.solver_description().split(":")[0]
+            t = time.perf_counter()
+            P, ost = c_oracle.gauss_newton(*a(pc), iters=20)
+            pc[sl] = P
+            tc.append(time.perf_counter() - t)
+            if ost["chi2"][-1] > 1e-9:
+                worst = max(worst, abs(st["chi2"][-1] - ost["chi2"][-1]) / ost["chi2"][-1])
+    tg, tc = 1e3 * np.array(tg[1:]), 1e3 * np.array(tc[1:])      # the first call carries one-time initialisation
+    return {"workload": f"manhattan chain of {V} poses, {closures} closures found along the way; optimize(20) after each",
+            "solver": desc, "closures_timed": int(tg.size), "ms_per_closure_median": float(np.median(tg)),
+            "ms_per_closure_mean": float(tg.mean()), "cpu_oracle_ms_per_closure_median": float(np.median(tc)),
+            "cpu_oracle_ms_per_closure_mean": float(tc.mean()), "cpu_oracle_threads": 1,
+            "final_chi2_rel_err_vs_oracle_max": worst}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -312,6 +352,7 @@ def main():
                         for n, v in prof.items() if v["ms"] > 0}}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(g, args.iters)
+        out["reference_usage_session"] = reference_usage_session(local_rank)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

@@ -476,31 +476,50 @@ int plan_rows(int V, const double* poses, const uint8_t* fixed, int E, const int
     // the cut produced (pairs that straddle two tiles are stored twice, so the total depends on the cut) until
     // the tiles number one per CU.
     long long target = std::max<long long>(512, (nblk / 2 * 5 / 4 + tile_div - 1) / tile_div);   // stored blocks per tile
+    long long starget = std::max<long long>(512, (nblk / 2 + tile_div - 1) / tile_div);          // pairs per tile (fallback)
     std::vector<int> mark(std::max(n, 1), -1);
-    for (int attempt = 0; attempt < 6; ++attempt) {
+    for (int attempt = 0; attempt < 7; ++attempt) {
       long long lds = 0;
-      for (int pass = 0; pass < 4; ++pass) {
+      if (attempt == 0) {
+        for (int pass = 0; pass < 4; ++pass) {
+          tiles.clear();
+          long long total = 0;
+          int r = 0;
+          while (r < n) {
+            TileDesc T{};
+            T.row0 = r;
+            long long blocks = 0;
+            while (r < n && (r == T.row0 || (blocks < target && r - T.row0 < 4096))) {
+              for (int k = rowptr[r]; k < rowptr[r + 1]; ++k) {
+                const int cc = col[k];
+                blocks += cc >= 0 && !(cc >= T.row0 && cc < r);   // a pair inside the tile was counted with its earlier row
+              }
+              ++r;
+            }
+            T.row1 = r;
+            total += blocks;
+            tiles.push_back(T);
+          }
+          const int K = (int)tiles.size();
+          if (target <= 512 || (K <= tile_div && K >= tile_div - tile_div / 32)) break;
+          target = std::max<long long>(512, total / tile_div + (K > tile_div ? total / tile_div / 64 + 1 : 1));
+        }
+      } else {
+        // the block-balanced cut did not fit the LDS (its largest tiles hold the most rows + staged entries): cut by
+        // slot count instead -- rows, halo and staging then vary less -- and halve the tiles until they fit
         tiles.clear();
-        long long total = 0;
         int r = 0;
         while (r < n) {
           TileDesc T{};
           T.row0 = r;
-          long long blocks = 0;
-          while (r < n && (r == T.row0 || (blocks < target && r - T.row0 < 4096))) {
-            for (int k = rowptr[r]; k < rowptr[r + 1]; ++k) {
-              const int cc = col[k];
-              blocks += cc >= 0 && !(cc >= T.row0 && cc < r);   // a pair inside the tile was counted with its earlier row
-            }
+          long long slots = 0;
+          while (r < n && (r == T.row0 || (slots < 2 * starget && r - T.row0 < 4096))) {
+            slots += rowptr[r + 1] - rowptr[r];
             ++r;
           }
           T.row1 = r;
-          total += blocks;
           tiles.push_back(T);
         }
-        const int K = (int)tiles.size();
-        if (attempt > 0 || target <= 512 || (K <= tile_div && K >= tile_div - tile_div / 32)) break;
-        target = std::max<long long>(512, total / tile_div + (K > tile_div ? total / tile_div / 64 + 1 : 1));
       }
       for (size_t t = 0; t < tiles.size(); ++t)
         for (int q = tiles[t].row0; q < tiles[t].row1; ++q) tile_of_row[q] = (int)t;
@@ -528,12 +547,14 @@ int plan_rows(int V, const double* poses, const uint8_t* fixed, int E, const int
       std::fill(mark.begin(), mark.end(), -1);
       P.tile_lds = (int)lds;
       if (fits) break;
-      if (target <= 64) {
-        P.tiles_ok = false;   // e.g. a hub vertex whose row alone overflows the LDS: no tile view
-        break;
+      if (attempt >= 1) {
+        if (starget <= 64) {
+          P.tiles_ok = false;   // e.g. a hub vertex whose row alone overflows the LDS: no tile view
+          break;
+        }
+        starget = std::max<long long>(64, starget / 2);
       }
-      target = std::max<long long>(64, target / 2);
-      if (attempt == 5) P.tiles_ok = false;
+      if (attempt == 6) P.tiles_ok = false;
     }
   }
   lap("tiles");

@@ -25,6 +25,7 @@
 // Sequential depth per Gauss-Newton iteration = 2 (levels + separators) steps of ~0.3-2 us instead of
 // ~150 launches.
 #include <algorithm>
+#include <atomic>
 #include <cstring>
 #include <numeric>
 #include <vector>
@@ -1050,12 +1051,18 @@ Direct* direct_create(hipStream_t s, DevArena* arena, int V, int n, const int* f
   if (xb_global && !D.xbg && e == hipSuccess) e = hipErrorOutOfMemory;
   d->xb_global = xb_global;
   if (e == hipSuccess && (!D.Wd || !D.Wo || !D.escr || !D.zsc)) e = hipErrorOutOfMemory;
-  static bool attr_set = false;   // per process and device function: idempotent, so a race only repeats the call
+  static std::atomic<unsigned long long> attr_devices{0};   // devices on which the LDS limit of the two kernels is raised
+  int dev_id = 0;
+  hipGetDevice(&dev_id);
+  const unsigned long long dev_bit = 1ull << (dev_id & 63);
+  const bool attr_set_already = (attr_devices.load() & dev_bit) != 0;
+  bool attr_set = attr_set_already;
   if (e == hipSuccess && !attr_set) {
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_direct<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget);
     if (e == hipSuccess)
       e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_direct<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget);
     attr_set = e == hipSuccess;
+    if (attr_set) attr_devices.fetch_or(dev_bit);
   }
   if (e != hipSuccess) {
     *err = std::string("direct_create: ") + hipGetErrorString(e);
