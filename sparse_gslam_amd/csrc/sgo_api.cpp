@@ -112,6 +112,10 @@ struct sgo_ctx {
 
   Amg* amg = nullptr;             // non-null when the AMG preconditioner is active
   bool amg_pending = false;       // the hierarchy is built on first use (graphs that optimize() through `direct`)
+  bool rows_pending = false;      // ... and so are the row plan / level-0 structures of the PCG path (build_structure)
+  std::vector<uint8_t> lz_fixed;  // what that deferred build needs of the caller's arrays
+  std::vector<int32_t> lz_ei, lz_ej;
+  int cu_count = 0;               // compute units of the device (tiles per launch)
   Direct* direct = nullptr;       // small-graph path: optimize() is one launch (sgo_direct.h)
   std::string direct_why;         // why the last graph did not qualify for it
   DirectResult* d_dres = nullptr;
@@ -210,6 +214,7 @@ void free_graph(sgo_ctx* c) {
     c->direct = nullptr;
   }
   c->amg_pending = false;
+  c->rows_pending = false;
   c->amg_arena.rewind();
   c->graph_arena.rewind();   // the caller has synchronised the stream: nothing in flight reads these arrays
   c->pcg_pred = 0;
@@ -567,16 +572,61 @@ int plan_rows(int V, const double* poses, const uint8_t* fixed, int E, const int
   return SGO_OK;
 }
 
+// The edge arrays, poses and chi2 buffers of a graph: all that chi2 / per-edge chi2 / the single-launch direct path
+// need.  Validates the edge list and fixes the hessian order (free active vertices in ascending id).
+int build_edges(sgo_ctx* c, int V, const double* poses, const uint8_t* fixed, int E, const int32_t* ei, const int32_t* ej,
+                const double* meas, const double* info, const double* phi) {
+  std::vector<int> deg(V, 0);
+  for (int e = 0; e < E; ++e) {
+    const int a = ei[e], b = ej[e];
+    if (a < 0 || a >= V || b < 0 || b >= V) {
+      c->err = "edge " + std::to_string(e) + " references a vertex outside [0, V)";
+      return SGO_EINVAL;
+    }
+    if (a == b) {
+      c->err = "edge " + std::to_string(e) + " is a self edge";
+      return SGO_EINVAL;
+    }
+    deg[a]++;
+    deg[b]++;
+  }
+  c->free_id.clear();
+  for (int v = 0; v < V; ++v)
+    if (!fixed[v] && deg[v] > 0) c->free_id.push_back(v);
+  c->V = V;
+  c->E = E;
+  c->n = (int)c->free_id.size();
+  int rc;
+  c->el.E = E;
+  double *d_meas = nullptr, *d_info = nullptr;
+  if ((rc = dalloc(c, &c->el.vi, (size_t)E)) || (rc = dalloc(c, &c->el.vj, (size_t)E)) || (rc = dalloc(c, &c->el.phi, (size_t)E)) ||
+      (rc = dalloc(c, &c->el.zinv, 3 * (size_t)E)) || (rc = dalloc(c, &c->el.info, 6 * (size_t)E)) ||
+      (rc = dalloc(c, &d_meas, 3 * (size_t)E)) || (rc = dalloc(c, &d_info, 6 * (size_t)E)))
+    return rc;
+  if (E > 0) {
+    HIP_TRY(c, hipMemcpyAsync(c->el.vi, ei, sizeof(int32_t) * (size_t)E, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->el.vj, ej, sizeof(int32_t) * (size_t)E, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->el.phi, phi, sizeof(double) * (size_t)E, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(d_meas, meas, sizeof(double) * 3 * (size_t)E, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(d_info, info, sizeof(double) * 6 * (size_t)E, hipMemcpyHostToDevice, c->stream));
+    launch_edge_prepare(c->stream, E, d_meas, d_info, c->el.zinv, c->el.info);
+  }
+  if ((rc = dalloc(c, &c->d_poses, 3 * (size_t)V))) return rc;
+  HIP_TRY(c, hipMemcpyAsync(c->d_poses, poses, sizeof(double) * 3 * (size_t)V, hipMemcpyHostToDevice, c->stream));
+  if ((rc = dalloc(c, &c->d_e2, (size_t)E))) return rc;
+  if ((rc = dalloc(c, &c->d_partials, 3 * (size_t)kMaxPartials))) return rc;
+  if ((rc = dalloc(c, &c->d_hist, 2 * (size_t)(SGO_MAX_ITERS + 2)))) return rc;
+  HIP_TRY(c, hipMemsetAsync(c->d_partials, 0, sizeof(double) * 3 * kMaxPartials, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));   // the caller's arrays may go away after sgo_set_graph_se2
+  return SGO_OK;
+}
+
+// Row plan, level-0 structures and vectors of the PCG path, after build_edges.
 int build_structure(sgo_ctx* c, int V, const double* poses, const uint8_t* fixed, int E, const int32_t* ei,
-                    const int32_t* ej, const double* meas, const double* info, const double* phi) {
+                    const int32_t* ej) {
   const double tb0 = wall_s();
   RowPlan P;
-  int tile_div = 256;   // one tile per CU: the larger the tiles, the fewer pairs straddle two of them
-  {
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0)
-      tile_div = prop.multiProcessorCount;
-  }
+  const int tile_div = c->cu_count > 0 ? c->cu_count : 256;   // one tile per CU: the larger the tiles, the fewer pairs straddle two of them
   {
     const int prc = plan_rows(V, poses, fixed, E, ei, ej, tile_div, &c->err, P);
     if (prc != SGO_OK) return prc;
@@ -588,12 +638,8 @@ int build_structure(sgo_ctx* c, int V, const double* poses, const uint8_t* fixed
     if (verbose) std::fprintf(stderr, "[sgo]   build %-17s %.1f ms\n", what, 1e3 * (t - tl));
     tl = t;
   };
-  c->free_id = P.free_id;
   c->row_of_asc = P.row_of_asc;
   const int n = P.n, ns = P.ns;
-  c->V = V;
-  c->E = E;
-  c->n = n;
   const std::vector<int>&row_vertex = P.row_vertex, &rowptr = P.rowptr, &pos_i = P.pos_i, &pos_j = P.pos_j;
   std::vector<int>& col = P.col;
   std::vector<TileDesc>& tiles = P.tiles;
@@ -909,30 +955,14 @@ int build_structure(sgo_ctx* c, int V, const double* poses, const uint8_t* fixed
   // edge arrays in caller order: indices / kernel parameter straight from the caller's buffers; the inverse
   // measurements and the SoA information are made on the device from the raw rows, and the per-slot operand
   // arrays of k_linearize are expanded there too
-  c->el.E = E;
   int* d_eidx = nullptr;
-  double *d_meas = nullptr, *d_info = nullptr;
   if ((rc = upload(c, &d_eidx, eidx))) return rc;
   if ((rc = upload(c, &c->es.flags, flags))) return rc;
   if ((rc = dalloc(c, &c->es.vi, (size_t)ns)) || (rc = dalloc(c, &c->es.vj, (size_t)ns)) || (rc = dalloc(c, &c->es.zinv, 3 * (size_t)ns)) ||
       (rc = dalloc(c, &c->es.info, 6 * (size_t)ns)) || (rc = dalloc(c, &c->es.phi, (size_t)ns)))
     return rc;
-  if ((rc = dalloc(c, &c->el.vi, (size_t)E)) || (rc = dalloc(c, &c->el.vj, (size_t)E)) || (rc = dalloc(c, &c->el.phi, (size_t)E)) ||
-      (rc = dalloc(c, &c->el.zinv, 3 * (size_t)E)) || (rc = dalloc(c, &c->el.info, 6 * (size_t)E)) ||
-      (rc = dalloc(c, &d_meas, 3 * (size_t)E)) || (rc = dalloc(c, &d_info, 6 * (size_t)E)))
-    return rc;
-  if (E > 0) {
-    HIP_TRY(c, hipMemcpyAsync(c->el.vi, ei, sizeof(int32_t) * (size_t)E, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(c->el.vj, ej, sizeof(int32_t) * (size_t)E, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(c->el.phi, phi, sizeof(double) * (size_t)E, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(d_meas, meas, sizeof(double) * 3 * (size_t)E, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(d_info, info, sizeof(double) * 6 * (size_t)E, hipMemcpyHostToDevice, c->stream));
-    launch_edge_prepare(c->stream, E, d_meas, d_info, c->el.zinv, c->el.info);
-    if (ns > 0) launch_slot_expand(c->stream, ns, d_eidx, c->el, c->es);
-  }
+  if (E > 0 && ns > 0) launch_slot_expand(c->stream, ns, d_eidx, c->el, c->es);
   if ((rc = upload(c, &c->d_free_id, row_vertex))) return rc;
-  if ((rc = dalloc(c, &c->d_poses, 3 * (size_t)V))) return rc;
-  HIP_TRY(c, hipMemcpyAsync(c->d_poses, poses, sizeof(double) * 3 * (size_t)V, hipMemcpyHostToDevice, c->stream));
   const size_t n3 = 3 * (size_t)n;
   if ((rc = dalloc(c, &c->d_dgb, 9 * (size_t)n))) return rc;
   if ((rc = dalloc(c, &c->d_b, n3))) return rc;
@@ -943,12 +973,8 @@ int build_structure(sgo_ctx* c, int V, const double* poses, const uint8_t* fixed
   if ((rc = dalloc(c, &c->d_q, n3))) return rc;
   if ((rc = dalloc(c, &c->d_s1, n3))) return rc;
   if ((rc = dalloc(c, &c->d_s2, n3))) return rc;
-  if ((rc = dalloc(c, &c->d_e2, (size_t)E))) return rc;
-  if ((rc = dalloc(c, &c->d_partials, 3 * (size_t)kMaxPartials))) return rc;
   if ((rc = dalloc(c, &c->d_zparts, 2 * (size_t)kMaxPartials))) return rc;
-  if ((rc = dalloc(c, &c->d_hist, 2 * (size_t)(SGO_MAX_ITERS + 2)))) return rc;
   if ((rc = dalloc(c, &c->d_S, 1))) return rc;
-  HIP_TRY(c, hipMemsetAsync(c->d_partials, 0, sizeof(double) * 3 * kMaxPartials, c->stream));
   HIP_TRY(c, hipMemsetAsync(c->d_S, 0, sizeof(PcgScalars), c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));  // host staging vectors die at return
   if (c->opts.verbose)
@@ -1202,12 +1228,45 @@ int build_amg(sgo_ctx* c) {
 
 // Vectors over the free vertices cross the API in g2o's hessian order and live on the device in the
 // internal (Hilbert) row order: permute on the way (test / single-step entry points only).
+// build_structure + what follows from it (multi-GPU tile range, tolerance rule)
+int build_rows(sgo_ctx* c, const double* poses, const uint8_t* fixed, const int32_t* ei, const int32_t* ej) {
+  int rc = build_structure(c, c->V, poses, fixed, c->E, ei, ej);
+  if (rc != SGO_OK) return rc;
+  c->shard_units = c->T0.ntile > 0 ? c->T0.ntile : c->S0.ngrp;
+  sgo_shard_range(c->shard_units, c->comm.nranks, c->comm.rank, &c->shard_u0, &c->shard_u1);
+  c->shard_row0 = c->unit_row0.empty() ? 0 : c->unit_row0[c->shard_u0];
+  c->shard_row1 = c->unit_row0.empty() ? c->n : c->unit_row0[c->shard_u1];
+  // Chain-like graphs (fewer than ~1.5 edges per free pose: under 4 Hessian blocks per row) are the
+  // ill-conditioned ones -- kappa(H) grows with the square of the chain length -- and a relative
+  // residual of 1e-8 then leaves errors that show in chi2 (3000 poses / 3150 edges: iterates 3e-6 and
+  // poses 7e-5 m from the direct-solver oracle at 1e-8, 1.4e-8 at 1e-9).  Their PCG iterations are the
+  // cheap ones, so they get a 10x tighter tolerance than opts.pcg_tol.
+  c->tol_scale = (c->n > 0 && (long long)c->A.nslot < 4LL * c->n) ? 0.1 : 1.0;   // logical slots: 2 per edge + 1 per row
+  return SGO_OK;
+}
+
+// Graphs that optimize() through the single-launch direct path have their PCG-path structures built by the first
+// entry point that needs them (sgo_linearize, sgo_hessian_apply, ...): the row order then follows the CURRENT poses.
+int ensure_rows(sgo_ctx* c) {
+  if (!c->rows_pending) return SGO_OK;
+  c->rows_pending = false;
+  std::vector<double> poses(3 * (size_t)c->V);
+  HIP_TRY(c, hipMemcpyAsync(poses.data(), c->d_poses, sizeof(double) * poses.size(), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  const int rc = build_rows(c, poses.data(), c->lz_fixed.data(), c->lz_ei.data(), c->lz_ej.data());
+  c->lz_fixed = std::vector<uint8_t>();
+  c->lz_ei = std::vector<int32_t>();
+  c->lz_ej = std::vector<int32_t>();
+  return rc;
+}
+
 // Graphs that optimize() through the single-launch direct path build their multigrid hierarchy only when a
 // single-step entry point (sgo_solve, sgo_precondition) or the PCG fallback asks for it.
 int ensure_amg(sgo_ctx* c) {
+  int rc = ensure_rows(c);
+  if (rc != SGO_OK) return rc;
   if (!c->amg_pending) return SGO_OK;
   c->amg_pending = false;
-  int rc;
   if ((rc = do_linearize(c)) != SGO_OK || (rc = build_amg(c)) != SGO_OK) return rc;
   c->linearized = false;
   return SGO_OK;
@@ -1317,6 +1376,10 @@ sgo_ctx* sgo_create(int device, const sgo_opts* opts) {
     return nullptr;
   }
   c->device = device;
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->cu_count = prop.multiProcessorCount;
+  }
   sgo_default_opts(&c->opts);
   if (opts) {
     size_t sz = std::min<size_t>(sizeof(sgo_opts), opts->struct_size > 0 ? (size_t)opts->struct_size : sizeof(sgo_opts));
@@ -1393,22 +1456,12 @@ int sgo_set_graph_se2(sgo_ctx* c, int32_t V, const double* poses, const uint8_t*
     hipStreamSynchronize(c->stream);
     free_graph(c);
     if (c->opts.verbose) std::fprintf(stderr, "[sgo] set_graph: release of the previous graph %.1f ms\n", 1e3 * (wall_s() - t0));
-    int rc = build_structure(c, V, poses, fixed, E, ei, ej, meas, info, phi);
+    int rc = build_edges(c, V, poses, fixed, E, ei, ej, meas, info, phi);
     if (rc != SGO_OK) {
       free_graph(c);
       return rc;
     }
     c->has_graph = true;
-    c->shard_units = c->T0.ntile > 0 ? c->T0.ntile : c->S0.ngrp;
-    sgo_shard_range(c->shard_units, c->comm.nranks, c->comm.rank, &c->shard_u0, &c->shard_u1);
-    c->shard_row0 = c->unit_row0.empty() ? 0 : c->unit_row0[c->shard_u0];
-    c->shard_row1 = c->unit_row0.empty() ? c->n : c->unit_row0[c->shard_u1];
-    // Chain-like graphs (fewer than ~1.5 edges per free pose: under 4 Hessian blocks per row) are the
-    // ill-conditioned ones -- kappa(H) grows with the square of the chain length -- and a relative
-    // residual of 1e-8 then leaves errors that show in chi2 (3000 poses / 3150 edges: iterates 3e-6 and
-    // poses 7e-5 m from the direct-solver oracle at 1e-8, 1.4e-8 at 1e-9).  Their PCG iterations are the
-    // cheap ones, so they get a 10x tighter tolerance than opts.pcg_tol.
-    c->tol_scale = (c->n > 0 && (long long)c->A.nslot < 4LL * c->n) ? 0.1 : 1.0;   // logical slots: 2 per edge + 1 per row
     c->solver_desc = "pcg_block_jacobi";
     c->direct_why.clear();
     if (c->opts.solver == SGO_SOLVER_PCG_AMG && c->n > 0 && c->opts.direct_rows > 0 && c->comm.nranks <= 1 && !c->comm.handle) {
@@ -1431,9 +1484,18 @@ int sgo_set_graph_se2(sgo_ctx* c, int32_t V, const double* poses, const uint8_t*
                          " levels + " + std::to_string(di.n_sep) + " separators (dense), " + std::to_string(di.slots) +
                          " stored blocks, " + std::to_string(di.contributions) + " block products per factorisation; pcg_amg on demand";
         c->amg_pending = true;
+        // the row plan and the level-0 structures of the PCG path wait for the first entry point that needs them
+        c->rows_pending = true;
+        c->lz_fixed.assign(fixed, fixed + V);
+        c->lz_ei.assign(ei, ei + E);
+        c->lz_ej.assign(ej, ej + E);
       } else if (c->opts.verbose) {
         std::fprintf(stderr, "[sgo] direct path not used: %s\n", c->direct_why.c_str());
       }
+    }
+    if (!c->rows_pending && (rc = build_rows(c, poses, fixed, ei, ej)) != SGO_OK) {
+      free_graph(c);
+      return rc;
     }
     if (c->opts.solver == SGO_SOLVER_PCG_AMG && c->n > 0 && !c->direct) {
       // the hierarchy is built from the Hessian at the initial poses (strength of connection)
@@ -1855,7 +1917,7 @@ int sgo_optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
 // k_spmv0<mode> (operand = the PCG direction buffer, whatever it holds), HIP events around them on the
 // context's stream; returns the mean microseconds per launch (< 0 on error).  variant 16: the wave-group kernel even when the graph has a tile view; variant 32: per-phase s_memtime stamps of the tile kernel on stderr (diagnostic).
 double sgo_debug_spmv0_us(sgo_ctx* c, int mode, int variant, int reps) {
-  if (check_graph(c) != SGO_OK || reps < 1 || c->n == 0) return -1.0;
+  if (check_graph(c) != SGO_OK || reps < 1 || c->n == 0 || ensure_rows(c) != SGO_OK) return -1.0;
   hipEvent_t a, b;
   if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return -1.0;
   Spmv0Args args{};
