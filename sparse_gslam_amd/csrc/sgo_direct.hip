@@ -374,6 +374,23 @@ __global__ __launch_bounds__(kDT) void k_direct(DirectDev D, EdgeListDev el, dou
     }
   };
   prefetch(0);
+  // dense phase: the block-update threads (waves 0-2 and 4-6) and the indices of each one's first three work items
+  constexpr int kBlockWorkers = 6 * 64;
+  const int npairs = ns * (ns + 1) / 2;
+  const int wid = (wave < 3 ? wave : wave - 1) * 64 + lane;   // meaningful on waves 0-2, 4-6
+  int sbi0 = 0, sbj0 = 0, sra0 = 0, srb0 = 0, sbi1 = 0, sbj1 = 0, sra1 = 0, srb1 = 0, sbi2 = 0, sbj2 = 0, sra2 = 0, srb2 = 0;
+  {
+    auto decode = [&](int g, int& bi, int& bj, int& ra, int& rb) {
+      const int pr = D.dpair[g < npairs ? g : 0];
+      bi = pr >> 8;
+      bj = pr & 255;
+      ra = tri_at(3 * bi, 0);
+      rb = tri_at(3 * bj, 0);
+    };
+    decode(wid, sbi0, sbj0, sra0, srb0);
+    decode(wid + kBlockWorkers, sbi1, sbj1, sra1, srb1);
+    decode(wid + 2 * kBlockWorkers, sbi2, sbj2, sra2, srb2);
+  }
   const unsigned long long clk0 = __builtin_amdgcn_s_memtime();
   int done = 0, fail = 0;
   for (int it = 0; it <= iters; ++it) {
@@ -507,13 +524,12 @@ __global__ __launch_bounds__(kDT) void k_direct(DirectDev D, EdgeListDev el, dou
       double iv[6];
 #pragma unroll
       for (int c = 0; c < 6; ++c) iv[c] = pinv[6 * p + c];
-      // Work items: one ROW of a trailing block (three lanes per block) or of a right-hand-side entry, on all waves
-      // but the last; the last wave's first lane forms the NEXT pivot block whole and inverts it for everybody.
-      // With a handful of busy waves a step costs the instruction stream of its longest wave (~5 cycles per
-      // instruction), so the two jobs run side by side instead of one after the other in the same wave.
-      constexpr int kWorkers = kDT - 64;
-      if (tid >= kWorkers) {
-        if (tid == kWorkers) {
+      // A step is bound by VALU issue (a wave64 instruction holds its SIMD for four cycles and only a few waves are
+      // busy), so the jobs are laid out by SIMD (wave w runs on SIMD w % 4): waves 0-2 and 4-6 update the trailing
+      // blocks, one thread per block with its indices in registers; wave 3 updates the right-hand side; wave 7's
+      // first lane forms the NEXT pivot block and factors it for everybody, sharing its SIMD only with wave 3.
+      if (wave == 7) {
+        if (lane == 0) {
           const int rb0 = tri_at(3 * (p + 1), 0), rb1 = rb0 + 3 * (p + 1) + 1, rb2 = rb1 + 3 * (p + 1) + 2;
           double W[9], Tm[9];
 #pragma unroll
@@ -522,14 +538,15 @@ __global__ __launch_bounds__(kDT) void k_direct(DirectDev D, EdgeListDev el, dou
             W[3 + q] = Sd[rb1 + P + q];
             W[6 + q] = Sd[rb2 + P + q];
           }
-          mul_sym(W, iv, Tm);
           const int d0 = rb0 + 3 * (p + 1), d1 = rb1 + 3 * (p + 1), d2 = rb2 + 3 * (p + 1);
-          const double e00 = Sd[d0] - (Tm[0] * W[0] + Tm[1] * W[1] + Tm[2] * W[2]);
-          const double e10 = Sd[d1] - (Tm[3] * W[0] + Tm[4] * W[1] + Tm[5] * W[2]);
-          const double e11 = Sd[d1 + 1] - (Tm[3] * W[3] + Tm[4] * W[4] + Tm[5] * W[5]);
-          const double e20 = Sd[d2] - (Tm[6] * W[0] + Tm[7] * W[1] + Tm[8] * W[2]);
-          const double e21 = Sd[d2 + 1] - (Tm[6] * W[3] + Tm[7] * W[4] + Tm[8] * W[5]);
-          const double e22 = Sd[d2 + 2] - (Tm[6] * W[6] + Tm[7] * W[7] + Tm[8] * W[8]);
+          const double o00 = Sd[d0], o10 = Sd[d1], o11 = Sd[d1 + 1], o20 = Sd[d2], o21 = Sd[d2 + 1], o22 = Sd[d2 + 2];
+          mul_sym(W, iv, Tm);
+          const double e00 = o00 - (Tm[0] * W[0] + Tm[1] * W[1] + Tm[2] * W[2]);
+          const double e10 = o10 - (Tm[3] * W[0] + Tm[4] * W[1] + Tm[5] * W[2]);
+          const double e11 = o11 - (Tm[3] * W[3] + Tm[4] * W[4] + Tm[5] * W[5]);
+          const double e20 = o20 - (Tm[6] * W[0] + Tm[7] * W[1] + Tm[8] * W[2]);
+          const double e21 = o21 - (Tm[6] * W[3] + Tm[7] * W[4] + Tm[8] * W[5]);
+          const double e22 = o22 - (Tm[6] * W[6] + Tm[7] * W[7] + Tm[8] * W[8]);
           double nv[6];
           const bool ok = inv_sym3(e00, e10, e20, e11, e21, e22, nv);
 #pragma unroll
@@ -542,28 +559,60 @@ __global__ __launch_bounds__(kDT) void k_direct(DirectDev D, EdgeListDev el, dou
           Sd[d2 + 2] = e22;
           if (!ok) atomicOr(&fail_flag, 1);
         }
-      } else {
+      } else if (wave == 3) {
         const double p0 = bs[P], p1 = bs[P + 1], p2 = bs[P + 2];
-        for (int u = tq; u < 3 * (cnt + m); u += kWorkers) {
-          const bool blk = u < 3 * cnt;
-          const int v = blk ? u : u - 3 * cnt;
-          const int g = v / 3, r = v - 3 * g;
-          const int pr = blk ? (int)dpl[g] : ((p + 1 + g) << 8), bi = pr >> 8, bj = pr & 255;
-          const int ra = tri_at(3 * bi + r, 0);
-          const double a0 = Sd[ra + P], a1 = Sd[ra + P + 1], a2 = Sd[ra + P + 2];
-          double t0, t1, t2;
-          solve3(iv, a0, a1, a2, t0, t1, t2);
-          if (!blk) {
-            bs[3 * bi + r] -= t0 * p0 + t1 * p1 + t2 * p2;
-            continue;
+        for (int bi = p + 1 + lane; bi < ns; bi += 64) {   // right-hand side of block row bi
+          const int ra0 = tri_at(3 * bi, 0), ra1 = ra0 + 3 * bi + 1, ra2 = ra1 + 3 * bi + 2;
+          double W[9], Tm[9];
+#pragma unroll
+          for (int q = 0; q < 3; ++q) {
+            W[q] = Sd[ra0 + P + q];
+            W[3 + q] = Sd[ra1 + P + q];
+            W[6 + q] = Sd[ra2 + P + q];
+          }
+          const double o0 = bs[3 * bi], o1 = bs[3 * bi + 1], o2 = bs[3 * bi + 2];
+          mul_sym(W, iv, Tm);
+          bs[3 * bi] = o0 - (Tm[0] * p0 + Tm[1] * p1 + Tm[2] * p2);
+          bs[3 * bi + 1] = o1 - (Tm[3] * p0 + Tm[4] * p1 + Tm[5] * p2);
+          bs[3 * bi + 2] = o2 - (Tm[6] * p0 + Tm[7] * p1 + Tm[8] * p2);
+        }
+      } else {
+        for (int g = wid, trip = 0; g < cnt; g += kBlockWorkers, ++trip) {
+          // which pair a work item is does not depend on the step (the trailing pairs of a step are a prefix of the
+          // table): a thread's first three are decoded once, in registers
+          int bi, bj, ra0, rb0;
+          if (trip == 0) { bi = sbi0; bj = sbj0; ra0 = sra0; rb0 = srb0; }
+          else if (trip == 1) { bi = sbi1; bj = sbj1; ra0 = sra1; rb0 = srb1; }
+          else if (trip == 2) { bi = sbi2; bj = sbj2; ra0 = sra2; rb0 = srb2; }
+          else {
+            const int pr = dpl[g];
+            bi = pr >> 8; bj = pr & 255; ra0 = tri_at(3 * bi, 0); rb0 = tri_at(3 * bj, 0);
+          }
+          if (bi == bj && bi == p + 1) continue;   // the next pivot block: wave 7's job
+          const int ra1 = ra0 + 3 * bi + 1, ra2 = ra1 + 3 * bi + 2, rb1 = rb0 + 3 * bj + 1, rb2 = rb1 + 3 * bj + 2;
+          double Wa[9], Wb[9], Tm[9], o[9];
+          // every load before any store: Sd is one array, so a store would fence the loads behind it
+#pragma unroll
+          for (int q = 0; q < 3; ++q) {
+            Wa[q] = Sd[ra0 + P + q]; Wa[3 + q] = Sd[ra1 + P + q]; Wa[6 + q] = Sd[ra2 + P + q];
+            Wb[q] = Sd[rb0 + P + q]; Wb[3 + q] = Sd[rb1 + P + q]; Wb[6 + q] = Sd[rb2 + P + q];
           }
           const bool dg = bi == bj;
-          if (dg && bi == p + 1) continue;   // the next pivot block: the last wave's job
-          const int rb0 = tri_at(3 * bj, 0), rb1 = rb0 + 3 * bj + 1, rb2 = rb1 + 3 * bj + 2;
-          double* out = Sd + ra + 3 * bj;
-          out[0] -= t0 * Sd[rb0 + P] + t1 * Sd[rb0 + P + 1] + t2 * Sd[rb0 + P + 2];
-          if (!dg || r >= 1) out[1] -= t0 * Sd[rb1 + P] + t1 * Sd[rb1 + P + 1] + t2 * Sd[rb1 + P + 2];
-          if (!dg || r >= 2) out[2] -= t0 * Sd[rb2 + P] + t1 * Sd[rb2 + P + 1] + t2 * Sd[rb2 + P + 2];
+          double* o0p = Sd + ra0 + 3 * bj;
+          double* o1p = Sd + ra1 + 3 * bj;
+          double* o2p = Sd + ra2 + 3 * bj;
+          o[0] = o0p[0]; o[3] = o1p[0]; o[4] = o1p[1]; o[6] = o2p[0]; o[7] = o2p[1]; o[8] = o2p[2];
+          o[1] = dg ? 0.0 : o0p[1]; o[2] = dg ? 0.0 : o0p[2]; o[5] = dg ? 0.0 : o1p[2];
+          mul_sym(Wa, iv, Tm);
+#pragma unroll
+          for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+              o[3 * r + q] -= Tm[3 * r] * Wb[3 * q] + Tm[3 * r + 1] * Wb[3 * q + 1] + Tm[3 * r + 2] * Wb[3 * q + 2];
+          o0p[0] = o[0]; o1p[0] = o[3]; o1p[1] = o[4]; o2p[0] = o[6]; o2p[1] = o[7]; o2p[2] = o[8];
+          if (!dg) {
+            o0p[1] = o[1]; o0p[2] = o[2]; o1p[2] = o[5];
+          }
         }
       }
       __syncthreads();
