@@ -38,7 +38,8 @@ namespace sgo {
 
 namespace {
 
-constexpr int kDT = 512;                // threads of the workgroup
+constexpr int kDT = 512;                // threads of the workgroup (eight waves: the separator phase assigns jobs by wave)
+static_assert(kDT == 512, "k_direct's separator phase lays its jobs out over exactly eight waves");
 constexpr int kMaxSep = 60;             // separators: 180 x 180 packed triangle = 130 KB of LDS
 constexpr int kMaxLevels = 24;
 constexpr int kMaxEdges = 1 << 18;
