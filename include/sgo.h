@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define SGO_VERSION 100          /* 0.1.0 */
+#define SGO_VERSION 101          /* 0.1.1: sgo_opts.direct_rows (took a reserved slot), sgo_solver_description */
 #define SGO_MAX_ITERS 256        /* capacity of the per-iteration arrays in sgo_stats */
 
 /* error codes (negative).  -1 mirrors g2o's optimize() "nothing to optimise". */

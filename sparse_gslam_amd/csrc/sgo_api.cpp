@@ -1428,9 +1428,13 @@ void sgo_destroy(sgo_ctx* c) {
 
 const char* sgo_solver_description(sgo_ctx* c) {
   if (!c || !c->has_graph) return "";
-  c->solver_text = c->solver_desc;
-  if (!c->direct && !c->direct_why.empty()) c->solver_text += "; direct path not used: " + c->direct_why;
-  return c->solver_text.c_str();
+  try {
+    c->solver_text = c->solver_desc;
+    if (!c->direct && !c->direct_why.empty()) c->solver_text += "; direct path not used: " + c->direct_why;
+    return c->solver_text.c_str();
+  } catch (...) {   // no C++ exception crosses the C boundary
+    return "";
+  }
 }
 
 const char* sgo_last_error(sgo_ctx* c) { return c ? c->err.c_str() : g_err.c_str(); }
