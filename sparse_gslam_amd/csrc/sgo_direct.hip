@@ -519,12 +519,18 @@ __global__ __launch_bounds__(kDT) void k_direct(DirectDev D, EdgeListDev el, dou
     }
     for (int k = tq; k < 3 * ns; k += kDT) bs[k] = xb[3 * (size_t)nI + k];
     __syncthreads();
+    double nextF[6] = {0, 0, 0, 0, 0, 0};   // wave 7, lane 0: the factor it made in the previous step (no LDS round trip for itself)
     for (int p = 0; p + 1 < ns; ++p) {
       const int m = ns - 1 - p, cnt = m * (m + 1) / 2;
       const int P = 3 * p;
       double iv[6];
+      if (wave == 7 && p > 0) {
 #pragma unroll
-      for (int c = 0; c < 6; ++c) iv[c] = pinv[6 * p + c];
+        for (int c = 0; c < 6; ++c) iv[c] = nextF[c];
+      } else {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) iv[c] = pinv[6 * p + c];
+      }
       // A step is bound by VALU issue (a wave64 instruction holds its SIMD for four cycles and only a few waves are
       // busy), so the jobs are laid out by SIMD (wave w runs on SIMD w % 4): waves 0-2 and 4-6 update the trailing
       // blocks, one thread per block with its indices in registers; wave 3 updates the right-hand side; wave 7's
@@ -548,16 +554,10 @@ __global__ __launch_bounds__(kDT) void k_direct(DirectDev D, EdgeListDev el, dou
           const double e20 = o20 - (Tm[6] * W[0] + Tm[7] * W[1] + Tm[8] * W[2]);
           const double e21 = o21 - (Tm[6] * W[3] + Tm[7] * W[4] + Tm[8] * W[5]);
           const double e22 = o22 - (Tm[6] * W[6] + Tm[7] * W[7] + Tm[8] * W[8]);
-          double nv[6];
-          const bool ok = inv_sym3(e00, e10, e20, e11, e21, e22, nv);
+          // (the block itself is not stored back: from here on only its factor is used)
+          const bool ok = inv_sym3(e00, e10, e20, e11, e21, e22, nextF);
 #pragma unroll
-          for (int c = 0; c < 6; ++c) pinv[6 * (p + 1) + c] = nv[c];
-          Sd[d0] = e00;
-          Sd[d1] = e10;
-          Sd[d1 + 1] = e11;
-          Sd[d2] = e20;
-          Sd[d2 + 1] = e21;
-          Sd[d2 + 2] = e22;
+          for (int c = 0; c < 6; ++c) pinv[6 * (p + 1) + c] = nextF[c];
           if (!ok) atomicOr(&fail_flag, 1);
         }
       } else if (wave == 3) {
