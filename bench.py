@@ -268,7 +268,11 @@ def main():
                                          "init_odom_probe below",
                        "V": g.V, "E": g.E, "gn_iters_per_step": args.iters,
                        "solver": {0: "pcg_block_jacobi", 1: "pcg_amg"}[opts.get("solver", o.solver)],
-                       "pcg_tol": opts.get("pcg_tol", o.pcg_tol), "parallelism": sharding},
+                       "pcg_tol": opts.get("pcg_tol", o.pcg_tol),
+                       "pcg_tol_cap": opts.get("pcg_tol_cap", o.pcg_tol_cap),
+                       "pcg_stop_rule": "||r|| <= pcg_tol * max(||b||, min(||b_first||, pcg_tol_cap / pcg_tol * ||b||)): "
+                                        "the absolute accuracy of the call's first solve, capped at pcg_tol_cap relative",
+                       "parallelism": sharding},
             "final_chi2": st["chi2"][-1], "final_robust_chi2": st["robust_chi2"][-1],
             "final_chi2_rel_err_vs_oracle": golden_rel_err(args.config, args.iters, st),
             "pcg_iters_per_gn_iter": float(np.mean(st["pcg_iters"])), "pcg_iters": st["pcg_iters"],

@@ -62,7 +62,10 @@ typedef struct sgo_opts {
   int32_t solver;          /* SGO_SOLVER_*; env SGO_SOLVER={pcg,amg} overrides the default */
   double pcg_tol;          /* stop when ||r|| <= pcg_tol * ||b||   (env SGO_PCG_TOL); chain-like graphs
                               (< 4 Hessian blocks per free pose, i.e. ill-conditioned and cheap to
-                              iterate on) use pcg_tol / 10 */
+                              iterate on) use pcg_tol / 10.  Inside one sgo_optimize_gn call the later
+                              Gauss-Newton iterations keep the ABSOLUTE accuracy of the first solve,
+                              ||r|| <= pcg_tol * ||b_first||, once their own right-hand side has shrunk
+                              below ||b_first|| -- see pcg_tol_cap */
   int32_t pcg_maxit;       /* cap on PCG iterations per GN iteration (env SGO_PCG_MAXIT) */
   int32_t pcg_chunk;       /* graph mode: pcg_chunk / 16 replays of the 2-iteration hipGraph are kept in
                               flight speculatively between checks of the device-side stop flag;
@@ -80,13 +83,18 @@ typedef struct sgo_opts {
                               (env SGO_DIRECT_ROWS); the single-step entry points keep using the PCG path.
                               The path itself works (and wins) up to ~100k chain-like poses; the default stops
                               where two backward-stable solvers stop agreeing to 1e-6 in chi2 (kappa ~ n^2) */
-  int32_t reserved[7];
+  double pcg_tol_cap;      /* loosest RELATIVE tolerance that absolute criterion may reach (default 1e-6; 0: every
+                              solve uses pcg_tol relative to its own ||b||; env SGO_PCG_TOL_CAP).  As Gauss-Newton
+                              converges ||b|| falls by orders of magnitude; solving each step to 1e-8 of ITSELF
+                              buys no accuracy of the iterates (chi2 is second order in the step's error) and
+                              costs a quarter of the PCG iterations */
+  int32_t reserved[5];
 } sgo_opts;
 
 /* Defaults (also applied when opts == NULL):
  * solver = PCG_AMG (graphs with <= 400 free poses are preconditioned by an explicit dense inverse,
  * i.e. solved directly; falls back to PCG_BJ only when a larger graph cannot be coarsened),
- * pcg_tol = 1e-8, pcg_maxit = 20000, pcg_chunk = 16, use_graph = 1, direct_rows = 8192. */
+ * pcg_tol = 1e-8, pcg_maxit = 20000, pcg_chunk = 16, use_graph = 1, direct_rows = 8192, pcg_tol_cap = 1e-6. */
 void sgo_default_opts(sgo_opts* o);
 
 typedef struct sgo_stats {

@@ -128,6 +128,8 @@ struct sgo_ctx {
   int pcg_exec_chunk = 0;
   int pcg_pred = 0;               // PCG iterations of the previous solve (prediction for the next)
   double tol_scale = 1.0;         // < 1 on chain-like graphs (see sgo_set_graph_se2)
+  double bb_ref = 0.0;            // |b|^2 of the first solve of the running sgo_optimize_gn (0: relative tolerance only)
+  double tol_cap = 0.0;           // loosest relative tolerance the absolute criterion may reach (0: off; opts.pcg_tol_cap)
   int pcg_softcap = 0;            // > 0: iteration cap of the next solve (sgo_optimize_gn: stale-hierarchy bail-out)
   int amg_best = 0;               // fewest PCG iterations seen with the current hierarchy (0: none yet);
                                   // kept across optimize() calls so that a hierarchy adapted to other poses is noticed
@@ -1010,11 +1012,11 @@ int start_pcg(sgo_ctx* c, int grid) {
     HIP_TRY(c, hipMemcpyAsync(c->d_p, c->d_z, sizeof(double) * 3 * (size_t)c->n, hipMemcpyDeviceToDevice, c->stream));
     Scope sc(c, K_INIT_SCALARS, 8.0 * (gz + grid));
     launch_init_scalars(c->stream, c->d_S, c->d_zparts, gz, c->d_partials + kMaxPartials, grid, c->opts.pcg_tol * c->tol_scale,
-                        c->pcg_softcap > 0 ? std::min(c->pcg_softcap, c->opts.pcg_maxit) : c->opts.pcg_maxit);
+                        c->pcg_softcap > 0 ? std::min(c->pcg_softcap, c->opts.pcg_maxit) : c->opts.pcg_maxit, c->bb_ref, c->tol_cap);
   } else {
     Scope sc(c, K_INIT_SCALARS, 16.0 * grid);
     launch_init_scalars(c->stream, c->d_S, c->d_partials, grid, c->d_partials + kMaxPartials, grid, c->opts.pcg_tol * c->tol_scale,
-                        c->pcg_softcap > 0 ? std::min(c->pcg_softcap, c->opts.pcg_maxit) : c->opts.pcg_maxit);
+                        c->pcg_softcap > 0 ? std::min(c->pcg_softcap, c->opts.pcg_maxit) : c->opts.pcg_maxit, c->bb_ref, c->tol_cap);
   }
   return SGO_OK;
 }
@@ -1338,6 +1340,8 @@ void sgo_default_opts(sgo_opts* o) {
   o->profile = 0;
   o->verbose = 0;
   o->direct_rows = 8192;
+  o->pcg_tol_cap = 1e-6;
+  if (const char* s = std::getenv("SGO_PCG_TOL_CAP")) o->pcg_tol_cap = std::atof(s);
   if (const char* s = std::getenv("SGO_DIRECT_ROWS")) o->direct_rows = std::atoi(s);
   if (const char* s = std::getenv("SGO_SOLVER")) {
     if (!std::strcmp(s, "pcg") || !std::strcmp(s, "bj")) o->solver = SGO_SOLVER_PCG_BJ;
@@ -1800,10 +1804,15 @@ int sgo_optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
       c->iter_events.push_back(e);
     }
     std::vector<hipEvent_t>& ev = c->iter_events;
-    struct SoftcapGuard {   // the bail-out cap applies to solves inside this call only
+    struct SoftcapGuard {   // the bail-out cap and the absolute accuracy target apply to solves inside this call only
       sgo_ctx* c;
-      ~SoftcapGuard() { c->pcg_softcap = 0; }
+      ~SoftcapGuard() {
+        c->pcg_softcap = 0;
+        c->bb_ref = 0.0;
+      }
     } softcap_guard{c};
+    c->bb_ref = 0.0;
+    c->tol_cap = c->opts.pcg_tol_cap > 0.0 ? std::max(c->opts.pcg_tol_cap, c->opts.pcg_tol * c->tol_scale) : 0.0;
     int done = 0;
     bool failed = false;
     int rebuilds = 0;
@@ -1842,16 +1851,23 @@ int sgo_optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
           std::fprintf(stderr, "[sgo] iteration %d: solve abandoned after %d PCG iterations, hierarchy rebuilt\n", it, wasted);
       }
       const PcgScalars S = *c->h_S;
+      if (it == 0 && c->tol_cap > 0.0 && S.stop == 1) c->bb_ref = S.bb;
       if (c->amg && S.stop != 3) {
-        if (best_pcg == 0 || S.iter < best_pcg) best_pcg = S.iter;
+        // Iteration counts are compared at EQUAL tolerance: a solve that stopped at the absolute criterion (a looser
+        // relative tolerance, see pcg_tol_cap) is scaled to what pcg_tol would have cost -- PCG converges linearly,
+        // iterations ~ log(1 / tolerance) -- or the staleness rules below would take every tight solve that follows
+        // a loose one for a stale hierarchy.
+        const double tol0 = c->opts.pcg_tol * c->tol_scale, tolk = std::sqrt(S.tol2);
+        const int eq_iter = (tolk > tol0 && tolk < 1.0 && tol0 > 0.0) ? (int)std::lround(S.iter * std::log(tol0) / std::log(tolk)) : S.iter;
+        if (best_pcg == 0 || eq_iter < best_pcg) best_pcg = eq_iter;
         // Redo the aggregation from the current values when that pays: always when the count has more
         // than doubled, and when it is > 25 % above the best while the PCG iterations it would save
         // over the remaining GN iterations exceed the set-up's cost (~150 PCG iterations' worth: host
         // aggregation + one more linearisation).  Counts only -- no clocks -- so that every rank of a
         // multi-GPU run takes the same decision.
         const int left = iters - it - 1;
-        const bool doubled = S.iter > 2 * best_pcg + 10;
-        const bool pays = 4 * S.iter > 5 * best_pcg && (long long)(S.iter - best_pcg) * left > 150;
+        const bool doubled = eq_iter > 2 * best_pcg + 10;
+        const bool pays = 4 * eq_iter > 5 * best_pcg && (long long)(eq_iter - best_pcg) * left > 150;
         if (rebuilds < 3 && (doubled || pays)) rebuild_next = true;
       }
       if (out) {

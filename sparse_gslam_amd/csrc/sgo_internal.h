@@ -510,7 +510,7 @@ void launch_linearize(hipStream_t s, const Sym0Dev& A, int g0, int g1, const Edg
 void launch_finalize(hipStream_t s, const Sym0Dev& A, const double* dgb, double* b, double* x, double* r, double* z,
                      double* p, double* xs, double omega, double* partials, int* grid_out);
 void launch_init_scalars(hipStream_t s, PcgScalars* S, const double* rz_parts, int n_rz, const double* bb_parts,
-                         int n_bb, double tol, int maxit);
+                         int n_bb, double tol, int maxit, double bb_ref, double tol_cap);
 int launch_spmv0(hipStream_t s, const Sym0Dev& A, int mode, const Spmv0Args& a);   // returns grid
 int launch_spmv0t(hipStream_t s, const Sym0Dev& A, const Tile0Dev& T, int mode, const Spmv0Args& a);   // returns grid
 // tile kernel when the graph has a tile view, the wave-group kernel otherwise

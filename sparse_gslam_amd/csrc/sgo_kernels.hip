@@ -265,7 +265,7 @@ __global__ __launch_bounds__(kBlock) void k_finalize(Sym0Dev A, const double* __
 
 __global__ __launch_bounds__(kBlock) void k_init_scalars(PcgScalars* S, const double* __restrict__ rz_parts, int n_rz,
                                                          const double* __restrict__ bb_parts, int n_bb, double tol,
-                                                         int maxit) {
+                                                         int maxit, double bb_ref, double tol_cap) {
   const double* const parts[2] = {rz_parts, bb_parts};
   const int cnt[2] = {n_rz, n_bb};
   double v[2];
@@ -278,7 +278,11 @@ __global__ __launch_bounds__(kBlock) void k_init_scalars(PcgScalars* S, const do
     S->pq = 0.0;
     S->alpha = 0.0;
     S->beta = 0.0;
-    S->tol2 = tol * tol;
+    // bb_ref > 0: ABSOLUTE accuracy of the call's first solve, ||r|| <= tol ||b_first||, for the later Gauss-Newton
+    // iterations whose right-hand side has shrunk (capped at the relative tolerance tol_cap)
+    double t2 = tol * tol;
+    if (bb_ref > 0.0 && bb > 0.0 && bb < bb_ref) t2 = fmin(tol_cap * tol_cap, t2 * (bb_ref / bb));
+    S->tol2 = t2;
     S->rz_prev = rz;
     S->iter = 0;
     S->iter_prev = 0;
@@ -872,8 +876,8 @@ void launch_finalize(hipStream_t s, const Sym0Dev& A, const double* dgb, double*
   *grid_out = grid;
 }
 void launch_init_scalars(hipStream_t s, PcgScalars* S, const double* rz_parts, int n_rz, const double* bb_parts,
-                         int n_bb, double tol, int maxit) {
-  SGO_LAUNCH(k_init_scalars, dim3(1), dim3(kBlock), 0, s, S, rz_parts, n_rz, bb_parts, n_bb, tol, maxit);
+                         int n_bb, double tol, int maxit, double bb_ref, double tol_cap) {
+  SGO_LAUNCH(k_init_scalars, dim3(1), dim3(kBlock), 0, s, S, rz_parts, n_rz, bb_parts, n_bb, tol, maxit, bb_ref, tol_cap);
 }
 void launch_edge_prepare(hipStream_t s, int E, const double* meas, const double* info, double* zinv, double* info_soa) {
   SGO_LAUNCH(k_edge_prepare, dim3(grid_for(E, kBlock)), dim3(kBlock), 0, s, E, meas, info, zinv, info_soa);
