@@ -511,6 +511,7 @@ void launch_finalize(hipStream_t s, const Sym0Dev& A, const double* dgb, double*
                      double* p, double* xs, double omega, double* partials, int* grid_out);
 void launch_init_scalars(hipStream_t s, PcgScalars* S, const double* rz_parts, int n_rz, const double* bb_parts,
                          int n_bb, double tol, int maxit, double bb_ref, double tol_cap);
+void launch_restart_scalars(hipStream_t s, PcgScalars* S, const double* rz_parts, int n_rz, int maxit);
 int launch_spmv0(hipStream_t s, const Sym0Dev& A, int mode, const Spmv0Args& a);   // returns grid
 int launch_spmv0t(hipStream_t s, const Sym0Dev& A, const Tile0Dev& T, int mode, const Spmv0Args& a);   // returns grid
 // tile kernel when the graph has a tile view, the wave-group kernel otherwise

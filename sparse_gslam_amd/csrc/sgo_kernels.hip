@@ -263,6 +263,22 @@ __global__ __launch_bounds__(kBlock) void k_finalize(Sym0Dev A, const double* __
   block_sum_store<2>(acc, partials, kMaxPartials);
 }
 
+// PCG continues an interrupted solve with another preconditioner: the caller has set z = M^-1 r, p = z for the
+// CURRENT residual; r.z is re-reduced, the recurrence scalars restart, x / r / iteration count / ||b|| / tolerance stay.
+__global__ __launch_bounds__(kBlock) void k_restart_scalars(PcgScalars* S, const double* __restrict__ rz_parts, int n_rz, int maxit) {
+  const double rz = block_reduce_parts(rz_parts, n_rz);
+  if (threadIdx.x == 0) {
+    S->rz = rz;
+    S->rz_prev = rz;
+    S->pq = 0.0;
+    S->alpha = 0.0;
+    S->beta = 0.0;
+    S->iter_prev = S->iter;
+    S->maxit = maxit;
+    S->stop = (isfinite(rz) && rz > 0.0) ? 0 : 3;
+  }
+}
+
 __global__ __launch_bounds__(kBlock) void k_init_scalars(PcgScalars* S, const double* __restrict__ rz_parts, int n_rz,
                                                          const double* __restrict__ bb_parts, int n_bb, double tol,
                                                          int maxit, double bb_ref, double tol_cap) {
@@ -874,6 +890,9 @@ void launch_finalize(hipStream_t s, const Sym0Dev& A, const double* dgb, double*
   const int grid = grid_for(A.n, kBlock);
   SGO_LAUNCH(k_finalize, dim3(grid), dim3(kBlock), 0, s, A, dgb, b, x, r, z, p, xs, omega, partials);
   *grid_out = grid;
+}
+void launch_restart_scalars(hipStream_t s, PcgScalars* S, const double* rz_parts, int n_rz, int maxit) {
+  SGO_LAUNCH(k_restart_scalars, dim3(1), dim3(kBlock), 0, s, S, rz_parts, n_rz, maxit);
 }
 void launch_init_scalars(hipStream_t s, PcgScalars* S, const double* rz_parts, int n_rz, const double* bb_parts,
                          int n_bb, double tol, int maxit, double bb_ref, double tol_cap) {
