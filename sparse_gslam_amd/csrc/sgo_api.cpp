@@ -488,7 +488,11 @@ int plan_rows(int V, const double* poses, const uint8_t* fixed, int E, const int
     std::vector<int> mark(std::max(n, 1), -1);
     for (int attempt = 0; attempt < 7; ++attempt) {
       long long lds = 0;
+      bool too_many = false;
       if (attempt == 0) {
+        // equal stored blocks per tile, a tile closed early when its LDS need (tracked exactly while rows are added:
+        // rows, distinct outside columns, intra-tile pairs) would pass the budget
+        int stamp = 1 << 20;
         for (int pass = 0; pass < 4; ++pass) {
           tiles.clear();
           long long total = 0;
@@ -496,12 +500,29 @@ int plan_rows(int V, const double* poses, const uint8_t* fixed, int E, const int
           while (r < n) {
             TileDesc T{};
             T.row0 = r;
-            long long blocks = 0;
+            ++stamp;
+            long long blocks = 0, halo = 0, staged = 0;
             while (r < n && (r == T.row0 || (blocks < target && r - T.row0 < 4096))) {
+              long long db = 0, dh = 0, ds = 0;
               for (int k = rowptr[r]; k < rowptr[r + 1]; ++k) {
                 const int cc = col[k];
-                blocks += cc >= 0 && !(cc >= T.row0 && cc < r);   // a pair inside the tile was counted with its earlier row
+                if (cc < 0) continue;
+                if (cc >= T.row0 && cc < r) {
+                  ++ds;            // the pair is inside the tile: counted as a block with its earlier row, staged here
+                } else {
+                  ++db;
+                  if (mark[cc] != stamp) {
+                    mark[cc] = stamp;
+                    ++dh;
+                  }
+                }
               }
+              const long long back = mark[r] == stamp ? 1 : 0;   // r was an outside column of the tile's earlier rows
+              const long long need = 24 * (2 * (long long)(r + 1 - T.row0) + (halo + dh - back) + (staged + ds));
+              if (r > T.row0 && need > lds_budget) break;   // (the marks this row left carry a stamp no later tile uses)
+              blocks += db;
+              halo += dh - back;
+              staged += ds;
               ++r;
             }
             T.row1 = r;
@@ -509,9 +530,11 @@ int plan_rows(int V, const double* poses, const uint8_t* fixed, int E, const int
             tiles.push_back(T);
           }
           const int K = (int)tiles.size();
+          too_many = K > tile_div && target > 512;
           if (target <= 512 || (K <= tile_div && K >= tile_div - tile_div / 32)) break;
           target = std::max<long long>(512, total / tile_div + (K > tile_div ? total / tile_div / 64 + 1 : 1));
         }
+        std::fill(mark.begin(), mark.end(), -1);
       } else {
         // the block-balanced cut did not fit the LDS (its largest tiles hold the most rows + staged entries): cut by
         // slot count instead -- rows, halo and staging then vary less -- and halve the tiles until they fit
@@ -532,7 +555,7 @@ int plan_rows(int V, const double* poses, const uint8_t* fixed, int E, const int
       for (size_t t = 0; t < tiles.size(); ++t)
         for (int q = tiles[t].row0; q < tiles[t].row1; ++q) tile_of_row[q] = (int)t;
       // exact LDS need per tile: rows + halo columns + rows + staged entries, 24 B each
-      bool fits = true;
+      bool fits = !too_many;   // more tiles than CUs because the LDS closed tiles early: the slot-balanced cut is better
       for (size_t t = 0; t < tiles.size() && fits; ++t) {
         const TileDesc& T = tiles[t];
         long long halo = 0, staged = 0;
