@@ -346,6 +346,15 @@ __device__ __forceinline__ void ratios2(const SpmvRatio& r1, const SpmvRatio& r2
 template <int MODE>
 __global__ __launch_bounds__(kBlock, ((MODE == SPMV_JACOBI || MODE == SPMV_PRE_RESID) ? 8 : 1))
 void k_spmv(BsrDev A, SpmvArgs a) {
+  // the first group's bounds are requested BEFORE the stop flag is waited for: on the coarse levels a launch is a
+  // chain of four or five dependent memory round trips, and this folds two of them into one
+  int g, gend, gstride;
+  group_walk(A.ngrp, &g, &gend, &gstride);
+  int gb0 = 0, ge0 = 0;
+  if (g < gend) {
+    gb0 = A.grp[g];
+    ge0 = A.grp[g + 1];
+  }
   if (a.S && a.S->stop) return;
   const int lane = threadIdx.x & 63;
   const size_t ns = (size_t)A.nslot;
@@ -381,10 +390,8 @@ void k_spmv(BsrDev A, SpmvArgs a) {
     }
   };
   double dotacc[2] = {0.0, 0.0};
-  int g, gend, gstride;
-  group_walk(A.ngrp, &g, &gend, &gstride);
-  for (; g < gend; g += gstride) {
-    const int gb = A.grp[g], ge = A.grp[g + 1];
+  for (bool first = true; g < gend; g += gstride, first = false) {
+    const int gb = first ? gb0 : A.grp[g], ge = first ? ge0 : A.grp[g + 1];
     double acc[3] = {0.0, 0.0, 0.0};
     int row = -1 - lane;
     for (int k = gb + lane; k < ge; k += 64) {
