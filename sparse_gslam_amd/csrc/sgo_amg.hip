@@ -1097,7 +1097,6 @@ struct Amg {
   const double* d_poses = nullptr;
   const int* d_free_id = nullptr;
   int kdepth = 1 << 20;  // levels <= kdepth use the K-cycle (two FCG steps), deeper ones a V-cycle
-  int nu_l2 = 0;          // > 0: smoothing sweeps on levels >= 2 (experiment, SGO_AMG_NU_L2)
   int fcg2_depth = 1 << 20;  // levels <= this take two FCG steps, deeper K-cycle levels one
   // coarsest dense inverse (row-major, leading dimension Np = N rounded up to 32)
   int N = 0, Np = 0;
@@ -1250,8 +1249,7 @@ int cycle(Amg* m, hipStream_t s, int l, const double* rhs, const double* rhs_sub
   }
   // further pre-smoothing sweeps (levels walked by the V-cycle only): sweep s applied to the residual
   // of sweep s-1 gives the next correction (accumulated into xs) and the next residual (rs <-> tR)
-  int nu = (l > 0 && L.tR && L.smoothed) ? std::max(1, m->cfg.nu_coarse) : 1;
-  if (l >= 2 && m->nu_l2 > 0) nu = m->nu_l2;   // experiment: SGO_AMG_NU_L2
+  const int nu = (l > 0 && L.tR && L.smoothed) ? std::max(1, m->cfg.nu_coarse) : 1;
   double* res = L.rs;
   for (int sw = 1; sw < nu; ++sw) {
     double* nxt = (res == L.rs) ? L.tR : L.rs;
@@ -1494,7 +1492,6 @@ Amg* amg_create(hipStream_t s, const BsrDev& A0, const Sym0Dev& S0, const Tile0D
   // per cent on graphs whose level 0 is itself launch-bound (10k / 40k: 2.67 instead of 2.51 ms).
   m->cfg.nu_coarse = A0.nslot >= 1000000 ? 2 : 1;
   if (const char* e = std::getenv("SGO_AMG_NU_COARSE")) m->cfg.nu_coarse = std::atoi(e);
-  if (const char* e = std::getenv("SGO_AMG_NU_L2")) m->nu_l2 = std::atoi(e);
   if (const char* e = std::getenv("SGO_AMG_SMOOTH")) m->cfg.smooth = std::atoi(e) != 0;
   if (const char* e = std::getenv("SGO_AMG_OMEGA_P")) m->cfg.omega_p = std::atof(e);
   // With the smoothed prolongator a V-cycle needs ~1.4x the PCG iterations of the K-cycle (C4: 39 vs

@@ -165,6 +165,33 @@ def test_amg_gauss_newton_matches_direct_oracle(opt_amg, name):
     assert np.abs(P - oP).max() <= 1e-5
 
 
+def test_tolerance_rules_at_their_boundaries():
+    """The two rules that set a solve's tolerance, checked where they switch.  (1) Chain-like graphs -- fewer than 4
+    Hessian blocks per free pose -- solve to pcg_tol / 10.  (2) Inside one optimize() call later solves keep the first
+    solve's ABSOLUTE accuracy, never looser than pcg_tol_cap relative; pcg_tol_cap = 0 and optimize(1) keep pcg_tol."""
+    def relres(g, iters=6, **kw):
+        with capi.Optimizer(0, direct_rows=0, **kw) as o:
+            o.set_graph(*g.arrays())
+            done, st = o.optimize(iters)
+            assert done == iters and all(st["pcg_converged"])
+            return np.array(st["pcg_relres"])
+    V = 2000
+    chain = synth.manhattan(V, int(1.45 * V), seed=31, info_mode="full")     # 2E + n < 4n
+    dense = synth.manhattan(V, int(1.55 * V), seed=31, info_mode="full")     # 2E + n > 4n
+    assert 2 * chain.E + (V - 1) < 4 * (V - 1) < 2 * dense.E + (V - 1)
+    assert relres(chain, pcg_tol_cap=0.0).max() <= 1e-9 and relres(dense, pcg_tol_cap=0.0).max() <= 1e-8
+    assert relres(dense, pcg_tol_cap=0.0).max() > 1e-9            # the denser graph is NOT solved tighter than asked
+    r = relres(dense, iters=12)                                    # default cap 1e-6
+    assert r[0] <= 1e-8 and r.max() <= 1e-6 and r[-1] > 1e-8       # first solve as asked, later ones absolute, capped
+    r = relres(dense, iters=12, pcg_tol_cap=1e-7)
+    assert r.max() <= 1e-7
+    with capi.Optimizer(0, direct_rows=0) as o:                    # one iteration per call: always the relative rule
+        o.set_graph(*dense.arrays())
+        for _ in range(6):
+            done, st = o.optimize(1)
+            assert done == 1 and st["pcg_relres"][0] <= 1e-8
+
+
 # ------------------------------------------------------------------ multi-GPU logic on one GPU
 def test_rank_partial_products_sum_to_the_single_rank_product_bitwise():
     """Multi-GPU scheme on one GPU: each emulated rank evaluates the level-0 product for the rows of its tile
