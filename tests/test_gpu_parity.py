@@ -192,6 +192,24 @@ def test_tolerance_rules_at_their_boundaries():
             assert done == 1 and st["pcg_relres"][0] <= 1e-8
 
 
+def test_stale_aggregation_is_rebuilt_and_the_result_still_matches(capfd):
+    """From a dead-reckoned start robust-kernel re-weighting moves the strong connections within a few iterations: the
+    count-based rule redoes the aggregation inside optimize() (verbose line), and the iterates still match the direct
+    oracle."""
+    g = synth.manhattan(V=3000, E=4500, seed=1, p_random=0.3, info_mode="diag", phi=1.0, init="odom")
+    with capi.Optimizer(0, direct_rows=0, verbose=1) as o:
+        o.set_graph(*g.arrays())
+        done, st = o.optimize(20)
+        P = o.get_poses()
+    err = capfd.readouterr().err
+    assert "multigrid hierarchy rebuilt before iteration" in err or "hierarchy rebuilt" in err, err[-2000:]
+    oP, ost = _oracle().gauss_newton(*g.arrays(), iters=20)
+    assert done == 20 == ost["iters_done"] and all(st["pcg_converged"])
+    rel = np.abs(np.array(st["chi2"]) - np.array(ost["chi2"])) / np.array(ost["chi2"])
+    assert rel.max() <= 1e-6, rel.max()
+    assert max(st["pcg_iters"]) < 400        # no solve ground on with a stale hierarchy
+
+
 # ------------------------------------------------------------------ multi-GPU logic on one GPU
 def test_rank_partial_products_sum_to_the_single_rank_product_bitwise():
     """Multi-GPU scheme on one GPU: each emulated rank evaluates the level-0 product for the rows of its tile
