@@ -128,6 +128,8 @@ struct sgo_ctx {
   int pcg_exec_chunk = 0;
   int pcg_pred = 0;               // PCG iterations of the previous solve (prediction for the next)
   double tol_scale = 1.0;         // < 1 on chain-like graphs (see sgo_set_graph_se2)
+  double* d_xprev = nullptr;      // the previous Gauss-Newton step of the running sgo_optimize_gn (PCG warm start)
+  bool warm_valid = false;
   bool amg_skip_update = false;   // this solve reuses the hierarchy's values of the previous one (sgo_optimize_gn's late iterations)
   double bb_ref = 0.0;            // |b|^2 of the first solve of the running sgo_optimize_gn (0: relative tolerance only)
   double tol_cap = 0.0;           // loosest relative tolerance the absolute criterion may reach (0: off; opts.pcg_tol_cap)
@@ -226,6 +228,8 @@ void free_graph(sgo_ctx* c) {
   c->T0 = Tile0Dev();
   c->es = EdgeSlotsDev();
   c->el = EdgeListDev();
+  c->d_xprev = nullptr;
+  c->warm_valid = false;
   c->has_graph = false;
   c->linearized = false;
 }
@@ -999,6 +1003,7 @@ int build_structure(sgo_ctx* c, int V, const double* poses, const uint8_t* fixed
   if ((rc = dalloc(c, &c->d_q, n3))) return rc;
   if ((rc = dalloc(c, &c->d_s1, n3))) return rc;
   if ((rc = dalloc(c, &c->d_s2, n3))) return rc;
+  if ((rc = dalloc(c, &c->d_xprev, n3))) return rc;
   if ((rc = dalloc(c, &c->d_zparts, 2 * (size_t)kMaxPartials))) return rc;
   if ((rc = dalloc(c, &c->d_S, 1))) return rc;
   HIP_TRY(c, hipMemsetAsync(c->d_S, 0, sizeof(PcgScalars), c->stream));
@@ -1028,8 +1033,39 @@ int do_chi2(sgo_ctx* c, double* d_out2, double* d_e2) {
 
 // PCG start state after k_finalize (x = 0, r = b, z = Dinv b, p = z; partials rz / bb with `grid`
 // entries).  With the AMG preconditioner: refresh the coarse operators, z = M^-1 b, p = z.
+int do_spmv(sgo_ctx* c, const double* x, double* y, bool dot, const PcgScalars* S, int* grid_out);
+
 int start_pcg(sgo_ctx* c, int grid) {
-  if (c->amg) {
+  if (c->amg && c->warm_valid && c->d_xprev) {
+    // Start from the previous Gauss-Newton step scaled by the energy-optimal factor: consecutive steps of a linearly
+    // converging iteration are nearly parallel, ||b - gamma H x_prev|| is 0.2-0.45 ||b|| on C4 / C2 (scripts/
+    // warm_probe.py), i.e. two PCG iterations for the price of one Hessian product.  Same stopping test, same
+    // solution; only the path to it is shorter.
+    const int maxit = c->pcg_softcap > 0 ? std::min(c->pcg_softcap, c->opts.pcg_maxit) : c->opts.pcg_maxit;
+    int rc;
+    if (!c->amg_skip_update && (rc = amg_update(c->amg, c->stream, &c->err))) return rc;
+    {
+      Scope sc(c, K_INIT_SCALARS, 16.0 * grid);   // ||b||^2, tolerance, iteration count (r.z is replaced below)
+      launch_init_scalars(c->stream, c->d_S, c->d_partials, grid, c->d_partials + kMaxPartials, grid, c->opts.pcg_tol * c->tol_scale,
+                          maxit, c->bb_ref, c->tol_cap);
+    }
+    int gq = 0, gd = 0;
+    if ((rc = do_spmv(c, c->d_xprev, c->d_q, true, nullptr, &gq))) return rc;
+    {
+      Scope sc(c, K_DOT, 48.0 * c->n);
+      launch_dot(c->stream, 3 * c->n, c->d_b, c->d_xprev, c->d_partials + 2 * kMaxPartials, nullptr, &gd);
+    }
+    {
+      Scope sc(c, K_UPDATE_XR, 120.0 * c->n);
+      launch_warm_start(c->stream, 3 * c->n, c->d_xprev, c->d_q, c->d_b, c->d_x, c->d_r, c->d_partials, gq,
+                        c->d_partials + 2 * kMaxPartials, gd);
+    }
+    const int gz = amg_apply(c->amg, c->stream, c->d_r, c->d_z, c->d_r, c->d_zparts, nullptr, nullptr, false);
+    if (amg_comm_failed(c->amg)) return SGO_ECOMM;
+    HIP_TRY(c, hipMemcpyAsync(c->d_p, c->d_z, sizeof(double) * 3 * (size_t)c->n, hipMemcpyDeviceToDevice, c->stream));
+    Scope sc(c, K_INIT_SCALARS, 8.0 * gz);
+    launch_restart_scalars(c->stream, c->d_S, c->d_zparts, gz, maxit, 1);
+  } else if (c->amg) {
     if (!c->amg_skip_update) {
       int rc = amg_update(c->amg, c->stream, &c->err);
       if (rc) return rc;
@@ -1223,7 +1259,7 @@ int continue_pcg_with_fresh_values(sgo_ctx* c, int maxit) {
   HIP_TRY(c, hipMemcpyAsync(c->d_p, c->d_z, sizeof(double) * 3 * (size_t)c->n, hipMemcpyDeviceToDevice, c->stream));
   {
     Scope sc(c, K_INIT_SCALARS, 8.0 * gz);
-    launch_restart_scalars(c->stream, c->d_S, c->d_zparts, gz, maxit);
+    launch_restart_scalars(c->stream, c->d_S, c->d_zparts, gz, maxit, 0);
   }
   return run_pcg(c);
 }
@@ -1850,8 +1886,11 @@ int sgo_optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
       ~SoftcapGuard() {
         c->pcg_softcap = 0;
         c->bb_ref = 0.0;
+        c->warm_valid = false;
       }
     } softcap_guard{c};
+    c->warm_valid = false;
+    static const bool warm_env = !(std::getenv("SGO_PCG_WARM") && std::atoi(std::getenv("SGO_PCG_WARM")) == 0);
     c->bb_ref = 0.0;
     c->tol_cap = c->opts.pcg_tol_cap > 0.0 ? std::max(c->opts.pcg_tol_cap, c->opts.pcg_tol * c->tol_scale) : 0.0;
     int done = 0;
@@ -1978,6 +2017,10 @@ int sgo_optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
       {
         Scope sc(c, K_POSE_UPDATE, 72.0 * c->n);
         launch_pose_update(c->stream, c->n, c->d_free_id, c->d_x, c->d_poses);
+      }
+      if (warm_env && c->amg && c->d_xprev) {   // (multi-GPU: the same replicated arithmetic on every rank)
+        HIP_TRY(c, hipMemcpyAsync(c->d_xprev, c->d_x, sizeof(double) * 3 * (size_t)c->n, hipMemcpyDeviceToDevice, c->stream));
+        c->warm_valid = !rebuild_next;   // a rebuilt hierarchy starts cold (its first solve sets the reference counts)
       }
       hipEventRecord(ev[3 * it + 2], c->stream);
       c->linearized = false;

@@ -511,7 +511,9 @@ void launch_finalize(hipStream_t s, const Sym0Dev& A, const double* dgb, double*
                      double* p, double* xs, double omega, double* partials, int* grid_out);
 void launch_init_scalars(hipStream_t s, PcgScalars* S, const double* rz_parts, int n_rz, const double* bb_parts,
                          int n_bb, double tol, int maxit, double bb_ref, double tol_cap);
-void launch_restart_scalars(hipStream_t s, PcgScalars* S, const double* rz_parts, int n_rz, int maxit);
+void launch_restart_scalars(hipStream_t s, PcgScalars* S, const double* rz_parts, int n_rz, int maxit, int keep_stop);
+void launch_warm_start(hipStream_t s, int n3, const double* xp, const double* q, const double* b, double* x, double* r,
+                       const double* xq_parts, int n_xq, const double* bx_parts, int n_bx);
 int launch_spmv0(hipStream_t s, const Sym0Dev& A, int mode, const Spmv0Args& a);   // returns grid
 int launch_spmv0t(hipStream_t s, const Sym0Dev& A, const Tile0Dev& T, int mode, const Spmv0Args& a);   // returns grid
 // tile kernel when the graph has a tile view, the wave-group kernel otherwise

@@ -265,7 +265,10 @@ __global__ __launch_bounds__(kBlock) void k_finalize(Sym0Dev A, const double* __
 
 // PCG continues an interrupted solve with another preconditioner: the caller has set z = M^-1 r, p = z for the
 // CURRENT residual; r.z is re-reduced, the recurrence scalars restart, x / r / iteration count / ||b|| / tolerance stay.
-__global__ __launch_bounds__(kBlock) void k_restart_scalars(PcgScalars* S, const double* __restrict__ rz_parts, int n_rz, int maxit) {
+// keep_stop: a stop flag that is already set stays (a solve that init found trivially converged); otherwise the flag
+// is cleared (a solve interrupted by its iteration cap carries on).
+__global__ __launch_bounds__(kBlock) void k_restart_scalars(PcgScalars* S, const double* __restrict__ rz_parts, int n_rz, int maxit,
+                                                            int keep_stop) {
   const double rz = block_reduce_parts(rz_parts, n_rz);
   if (threadIdx.x == 0) {
     S->rz = rz;
@@ -275,7 +278,24 @@ __global__ __launch_bounds__(kBlock) void k_restart_scalars(PcgScalars* S, const
     S->beta = 0.0;
     S->iter_prev = S->iter;
     S->maxit = maxit;
-    S->stop = (isfinite(rz) && rz > 0.0) ? 0 : 3;
+    if (!(keep_stop && S->stop)) S->stop = (isfinite(rz) && rz >= 0.0) ? (rz == 0.0 ? 1 : 0) : 3;
+  }
+}
+
+// PCG start from the previous Gauss-Newton step: x = gamma x_prev, r = b - gamma H x_prev with the energy-optimal
+// gamma = (b . x_prev) / (x_prev . H x_prev) (every workgroup re-reduces the two partial sums in the same order);
+// a useless gamma (non-finite, <= 0, > 4) gives the cold start x = 0, r = b.
+__global__ __launch_bounds__(kBlock) void k_warm_start(int n3, const double* __restrict__ xp, const double* __restrict__ q,
+                                                       const double* __restrict__ b, double* __restrict__ x, double* __restrict__ r,
+                                                       const double* __restrict__ xq_parts, int n_xq,
+                                                       const double* __restrict__ bx_parts, int n_bx) {
+  const double xq = block_reduce_parts(xq_parts, n_xq);
+  const double bx = block_reduce_parts(bx_parts, n_bx);
+  double gamma = bx / xq;
+  if (!(xq > 0.0) || !isfinite(gamma) || !(gamma > 0.0) || gamma > 4.0) gamma = 0.0;
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n3; i += gridDim.x * kBlock) {
+    x[i] = gamma * xp[i];
+    r[i] = b[i] - gamma * q[i];
   }
 }
 
@@ -898,8 +918,12 @@ void launch_finalize(hipStream_t s, const Sym0Dev& A, const double* dgb, double*
   SGO_LAUNCH(k_finalize, dim3(grid), dim3(kBlock), 0, s, A, dgb, b, x, r, z, p, xs, omega, partials);
   *grid_out = grid;
 }
-void launch_restart_scalars(hipStream_t s, PcgScalars* S, const double* rz_parts, int n_rz, int maxit) {
-  SGO_LAUNCH(k_restart_scalars, dim3(1), dim3(kBlock), 0, s, S, rz_parts, n_rz, maxit);
+void launch_restart_scalars(hipStream_t s, PcgScalars* S, const double* rz_parts, int n_rz, int maxit, int keep_stop) {
+  SGO_LAUNCH(k_restart_scalars, dim3(1), dim3(kBlock), 0, s, S, rz_parts, n_rz, maxit, keep_stop);
+}
+void launch_warm_start(hipStream_t s, int n3, const double* xp, const double* q, const double* b, double* x, double* r,
+                       const double* xq_parts, int n_xq, const double* bx_parts, int n_bx) {
+  SGO_LAUNCH(k_warm_start, dim3(grid_for(n3, kBlock)), dim3(kBlock), 0, s, n3, xp, q, b, x, r, xq_parts, n_xq, bx_parts, n_bx);
 }
 void launch_init_scalars(hipStream_t s, PcgScalars* S, const double* rz_parts, int n_rz, const double* bb_parts,
                          int n_bb, double tol, int maxit, double bb_ref, double tol_cap) {
