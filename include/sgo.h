@@ -88,13 +88,16 @@ typedef struct sgo_opts {
                               converges ||b|| falls by orders of magnitude; solving each step to 1e-8 of ITSELF
                               buys no accuracy of the iterates (chi2 is second order in the step's error) and
                               costs a quarter of the PCG iterations */
-  int32_t reserved[5];
+  int32_t pcg_warm_start;  /* 1 (default): from the second Gauss-Newton iteration of a call PCG starts from the previous
+                              step scaled by the energy-optimal factor (b.x_prev)/(x_prev.H x_prev) instead of from zero:
+                              same stopping test, about two iterations fewer per solve (env SGO_PCG_WARM) */
+  int32_t reserved[4];
 } sgo_opts;
 
 /* Defaults (also applied when opts == NULL):
  * solver = PCG_AMG (graphs with <= 400 free poses are preconditioned by an explicit dense inverse,
  * i.e. solved directly; falls back to PCG_BJ only when a larger graph cannot be coarsened),
- * pcg_tol = 1e-8, pcg_maxit = 20000, pcg_chunk = 16, use_graph = 1, direct_rows = 8192, pcg_tol_cap = 1e-6. */
+ * pcg_tol = 1e-8, pcg_maxit = 20000, pcg_chunk = 16, use_graph = 1, direct_rows = 8192, pcg_tol_cap = 1e-6, pcg_warm_start = 1. */
 void sgo_default_opts(sgo_opts* o);
 
 typedef struct sgo_stats {

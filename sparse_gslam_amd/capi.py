@@ -40,7 +40,7 @@ class Opts(C.Structure):
     _fields_ = [("struct_size", C.c_int32), ("solver", C.c_int32), ("pcg_tol", C.c_double),
                 ("pcg_maxit", C.c_int32), ("pcg_chunk", C.c_int32), ("use_graph", C.c_int32),
                 ("profile", C.c_int32), ("verbose", C.c_int32), ("direct_rows", C.c_int32),
-                ("pcg_tol_cap", C.c_double), ("reserved", C.c_int32 * 5)]
+                ("pcg_tol_cap", C.c_double), ("pcg_warm_start", C.c_int32), ("reserved", C.c_int32 * 4)]
 
 
 class Stats(C.Structure):

@@ -1418,6 +1418,8 @@ void sgo_default_opts(sgo_opts* o) {
   o->verbose = 0;
   o->direct_rows = 8192;
   o->pcg_tol_cap = 1e-6;
+  o->pcg_warm_start = 1;
+  if (const char* s = std::getenv("SGO_PCG_WARM")) o->pcg_warm_start = std::atoi(s);
   if (const char* s = std::getenv("SGO_PCG_TOL_CAP")) o->pcg_tol_cap = std::atof(s);
   if (const char* s = std::getenv("SGO_DIRECT_ROWS")) o->direct_rows = std::atoi(s);
   if (const char* s = std::getenv("SGO_SOLVER")) {
@@ -1890,7 +1892,7 @@ int sgo_optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
       }
     } softcap_guard{c};
     c->warm_valid = false;
-    static const bool warm_env = !(std::getenv("SGO_PCG_WARM") && std::atoi(std::getenv("SGO_PCG_WARM")) == 0);
+    const bool warm_env = c->opts.pcg_warm_start != 0;
     c->bb_ref = 0.0;
     c->tol_cap = c->opts.pcg_tol_cap > 0.0 ? std::max(c->opts.pcg_tol_cap, c->opts.pcg_tol * c->tol_scale) : 0.0;
     int done = 0;
