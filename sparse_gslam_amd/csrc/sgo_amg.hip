@@ -174,7 +174,8 @@ struct PDev {
   int nap = 0;               // blocks of AP
   double* apblk = nullptr;   // [nap][9]
   ProdMap ap;                // a = fine slot (i, j), b = P entry (j, c), tgt = AP entry (i, c)
-  ProdMap rap;               // a = P entry (i, a), b = AP entry (i, c), tgt = coarse slot (a, c)
+  ProdMap rap;               // a = P entry (i, a), b = AP entry (i, c), tgt = coarse slot (a, c), c >= a only
+  int* rap_mirror = nullptr; // [coarse slots] slot (c, a) of an upper slot (a, c): gets the transposed block (-1: none)
 };
 
 // block e of a pair-SoA array (blk_at) that is read once per cycle: four 16-byte and one 8-byte non-temporal
@@ -247,7 +248,7 @@ __global__ __launch_bounds__(kBlock) void k_p_values(BsrDev F, PDev P, const int
 template <bool X_BSR, bool TRANSPOSE_X, bool OUT_BSR>
 __global__ __launch_bounds__(kBlock) void k_block_products(ProdMap mp, BsrDev XA, const double* __restrict__ X,
                                                            const double* __restrict__ Y,
-                                                           double* __restrict__ out, size_t nout) {
+                                                           double* __restrict__ out, size_t nout, const int* __restrict__ mirror) {
   const int lane = threadIdx.x & 63;
   int gi, gend, gstride;
   group_walk(mp.ngrp, &gi, &gend, &gstride);
@@ -277,6 +278,15 @@ __global__ __launch_bounds__(kBlock) void k_block_products(ProdMap mp, BsrDev XA
       for (int c = 0; c < 9; ++c) {
         if (OUT_BSR) out[blk_at(c, (size_t)key, nout)] = acc[c];
         else out[9 * (size_t)key + c] = acc[c];
+      }
+      if (OUT_BSR && mirror) {   // symmetric target matrix: the block's transpose goes to the mirrored slot
+        const int mk = mirror[key];
+        if (mk >= 0) {
+#pragma unroll
+          for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) out[blk_at(3 * c + r, (size_t)mk, nout)] = acc[3 * r + c];
+        }
       }
     }
   }
@@ -785,7 +795,7 @@ struct SaHost {
   std::vector<int> ap_grp;
   HostLevel Hc;
   UVec rap_a, rap_b, rap_tgt;
-  std::vector<int> rap_grp;
+  std::vector<int> rap_grp, rap_mirror;
 };
 
 // Per-row counting sort of products by the local index q of their target: count(q) for every
@@ -982,9 +992,9 @@ bool sa_symbolic(const HostLevel& H, const std::vector<int>& agg, int nc, long l
       long long prod = 0;
       for (int t = t_ptr[a]; t < t_ptr[a + 1]; ++t) {
         const int i = o.t_row[t];
-        prod += ap_rowptr[i + 1] - ap_rowptr[i];
         for (int f = ap_rowptr[i]; f < ap_rowptr[i + 1]; ++f) {
           const int c = ap_col[f];
+          prod += c >= a;   // A_c is symmetric: only its upper triangle is computed, the lower is mirrored (rap_mirror)
           if (mark[c] != a) {
             mark[c] = a;
             ++cnt;
@@ -1037,13 +1047,15 @@ bool sa_symbolic(const HostLevel& H, const std::vector<int>& agg, int nc, long l
       rs.begin((int)uniq.size() + 1);
       for (int t = t_ptr[a]; t < t_ptr[a + 1]; ++t) {
         const int i = o.t_row[t];
-        for (int f = ap_rowptr[i]; f < ap_rowptr[i + 1]; ++f) rs.count(pos[ap_col[f]]);
+        for (int f = ap_rowptr[i]; f < ap_rowptr[i + 1]; ++f)
+          if (ap_col[f] >= a) rs.count(pos[ap_col[f]]);
       }
       rs.start((int)rpp[a], s0, rap_ptr.data());
       int *pa = o.rap_a.data(), *pb = o.rap_b.data(), *pt = o.rap_tgt.data();
       for (int t = t_ptr[a]; t < t_ptr[a + 1]; ++t) {
         const int e = t_idx[t], i = o.t_row[t];
         for (int f = ap_rowptr[i]; f < ap_rowptr[i + 1]; ++f) {
+          if (ap_col[f] < a) continue;
           const int q = pos[ap_col[f]], dst = rs.place(q);
           pa[dst] = e;
           pb[dst] = f;
@@ -1054,6 +1066,28 @@ bool sa_symbolic(const HostLevel& H, const std::vector<int>& agg, int nc, long l
   });
   rap_ptr[C.nslot] = nprod_rap;
   o.rap_grp = make_groups(rap_ptr);
+  // slot (a, c), c > a  ->  slot (c, a): where the numeric kernel stores the transposed block
+  o.rap_mirror.assign((size_t)C.nslot, -1);
+  host_parallel_for(nc, 256, [&](int lo, int hi, int) {
+    for (int a = lo; a < hi; ++a)
+      for (int k = C.rowptr[a] + 1; k < C.rowptr[a + 1]; ++k) {
+        const int c = C.col[k];
+        if (c < a) continue;
+        const int* b = C.col.data() + C.rowptr[c] + 1;
+        const int* e = C.col.data() + C.rowptr[c + 1];
+        const int* it = std::lower_bound(b, e, a);
+        o.rap_mirror[k] = (it != e && *it == a) ? (int)(it - C.col.data()) : -1;
+      }
+  });
+  {   // every lower slot must be some upper slot's mirror (the pattern of P^T A P is symmetric when A's is)
+    long long lower = 0, mirrored = 0;
+    for (int a = 0; a < nc; ++a)
+      for (int k = C.rowptr[a] + 1; k < C.rowptr[a + 1]; ++k) {
+        lower += C.col[k] < a;
+        mirrored += o.rap_mirror[k] >= 0;
+      }
+    if (lower != mirrored) return false;
+  }
   lap("RAP fill");
   return true;
 }
@@ -1139,12 +1173,12 @@ void launch_coarse_operator(Amg* m, hipStream_t s, AmgLevel& L, AmgLevel& C) {
   {
     Scope sc(m->prof, K_SA_AP, 156.0 * P.ap.n + 72.0 * P.nap);
     SGO_LAUNCH((k_block_products<true, false, false>), dim3(grid_for(P.ap.ngrp, kWavesPerBlock)), dim3(kBlock), 0, s,
-               P.ap, L.A, (const double*)nullptr, (const double*)P.blk, P.apblk, (size_t)P.nap);
+               P.ap, L.A, (const double*)nullptr, (const double*)P.blk, P.apblk, (size_t)P.nap, (const int*)nullptr);
   }
   {
     Scope sc(m->prof, K_SA_RAP, 156.0 * P.rap.n + 72.0 * C.A.nslot);
     SGO_LAUNCH((k_block_products<false, true, true>), dim3(grid_for(P.rap.ngrp, kWavesPerBlock)), dim3(kBlock), 0, s,
-               P.rap, BsrDev(), (const double*)P.blk, (const double*)P.apblk, C.A.blk, (size_t)C.A.nslot);
+               P.rap, BsrDev(), (const double*)P.blk, (const double*)P.apblk, C.A.blk, (size_t)C.A.nslot, (const int*)P.rap_mirror);
   }
 }
 
@@ -1711,6 +1745,7 @@ Amg* amg_create(hipStream_t s, const BsrDev& A0, const Sym0Dev& S0, const Tile0D
       P.rap.tgt = dev_upload(m->pool, sa.rap_tgt, s);
       P.rap.grp = dev_upload(m->pool, sa.rap_grp, s);
       P.rap.ngrp = (int)sa.rap_grp.size() - 1;
+      P.rap_mirror = dev_upload(m->pool, sa.rap_mirror, s);
       if (!P.rowptr || !P.row || !P.col || !P.blk || !P.val.a || !P.val.tgt || !P.val.grp || !P.r_grp || !P.t_pos || !P.t_row || !P.t_col || !P.t_blk || !P.r_blk || !P.t_grp ||
           !P.apblk || !P.ap.a || !P.ap.b || !P.ap.tgt || !P.ap.grp || !P.rap.a || !P.rap.b || !P.rap.tgt || !P.rap.grp)
         return fail("amg_create: out of device memory");
