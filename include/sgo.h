@@ -31,13 +31,14 @@
 #ifndef SGO_H_
 #define SGO_H_
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
 extern "C" {
 #endif
 
-#define SGO_VERSION 101          /* 0.1.1: sgo_opts.direct_rows (took a reserved slot), sgo_solver_description */
+#define SGO_VERSION 102          /* 0.1.2: sgo_comm_init_host; 0.1.1: sgo_opts.direct_rows (took a reserved slot), sgo_solver_description */
 #define SGO_MAX_ITERS 256        /* capacity of the per-iteration arrays in sgo_stats */
 
 /* error codes (negative).  -1 mirrors g2o's optimize() "nothing to optimise". */
@@ -232,6 +233,13 @@ double sgo_profile_overhead_ms(sgo_ctx* ctx);
 int sgo_comm_unique_id(void* id_out);
 int sgo_comm_init(sgo_ctx* ctx, int nranks, int rank, const void* unique_id);
 int sgo_comm_size(sgo_ctx* ctx);
+/* The same multi-GPU mode over a transport the CALLER brings (MPI, gloo, a socket layer) instead of RCCL: every
+ * collective copies its vector to pinned host memory, calls `fn` -- which must replace buf[0..count) by its sum
+ * over all ranks, bit-identical on every rank, and return 0 -- and copies the result back.  For nodes without
+ * xGMI / RCCL and for multi-process tests on one GPU; slower than sgo_comm_init.  `fn` is called on the thread
+ * that called into the library.  Must precede sgo_set_graph_se2. */
+typedef int (*sgo_host_allreduce_fn)(double* buf, size_t count, void* user);
+int sgo_comm_init_host(sgo_ctx* ctx, int nranks, int rank, sgo_host_allreduce_fn fn, void* user);
 /* The contiguous range [begin, end) of `count` work units (tiles, edges) that rank `rank` of
  * `nranks` evaluates.  Pure function (no GPU needed); exposed so the host layer and the CPU tests
  * can reproduce the partition. */

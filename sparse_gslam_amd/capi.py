@@ -28,7 +28,7 @@ SYMBOLS = [
     "sgo_precondition", "sgo_kernel_profile", "sgo_profile_reset", "sgo_profile_overhead_ms", "sgo_comm_unique_id",
     "sgo_comm_init", "sgo_comm_size", "sgo_shard_range", "sgo_debug_set_shard", "sgo_last_error",
     "sgo_closure_information", "sgo_plan_rows", "sgo_debug_coarse_rhs", "sgo_debug_spmv0_us",
-    "sgo_solver_description",
+    "sgo_solver_description", "sgo_comm_init_host",
 ]
 
 
@@ -67,6 +67,9 @@ class KernelStat(C.Structure):
     _fields_ = [("name", C.c_char_p), ("launches", C.c_int64), ("ms", C.c_double),
                 ("bytes", C.c_double)]
 
+
+# sgo_host_allreduce_fn: int fn(double* buf, size_t count, void* user)
+HOST_ALLREDUCE = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.c_size_t, C.c_void_p)
 
 _LIB = None
 
@@ -120,6 +123,7 @@ def lib():
     L.sgo_comm_unique_id.argtypes = [vp]
     L.sgo_comm_init.argtypes = [vp, C.c_int, C.c_int, vp]
     L.sgo_comm_size.argtypes = [vp]
+    L.sgo_comm_init_host.argtypes = [vp, C.c_int, C.c_int, HOST_ALLREDUCE, vp]
     L.sgo_shard_range.restype = None
     L.sgo_shard_range.argtypes = [C.c_int32, C.c_int32, C.c_int32, i32, i32]
     L.sgo_debug_set_shard.argtypes = [vp, C.c_int, C.c_int]
@@ -226,6 +230,20 @@ class Optimizer:
     def comm_init(self, nranks: int, rank: int, unique_id: bytes):
         buf = C.create_string_buffer(unique_id, UNIQUE_ID_BYTES)
         self._check(lib().sgo_comm_init(self._h, nranks, rank, C.cast(buf, C.c_void_p)), "sgo_comm_init")
+
+    def comm_init_host(self, nranks: int, rank: int, allreduce):
+        """Multi-GPU mode over the caller's transport (sgo_comm_init_host): `allreduce(a)` must replace the
+        float64 numpy array `a` in place by its sum over all ranks (e.g. a gloo all_reduce)."""
+        def _cb(buf, count, _user):
+            try:
+                allreduce(np.ctypeslib.as_array(buf, shape=(count,)))
+                return 0
+            except Exception:   # an exception must not unwind through the C frames
+                import traceback
+                traceback.print_exc()
+                return 1
+        self._host_cb = HOST_ALLREDUCE(_cb)   # keep the trampoline alive as long as the context
+        self._check(lib().sgo_comm_init_host(self._h, nranks, rank, self._host_cb, None), "sgo_comm_init_host")
 
     def debug_set_shard(self, nranks: int, rank: int):
         self._check(lib().sgo_debug_set_shard(self._h, nranks, rank), "sgo_debug_set_shard")

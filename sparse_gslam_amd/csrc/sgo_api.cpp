@@ -1109,7 +1109,7 @@ int do_spmv(sgo_ctx* c, const double* x, double* y, bool dot, const PcgScalars* 
   a.x = x;
   a.y = y;
   a.S = S;
-  if (c->comm.nranks > 1 || c->comm.handle) {
+  if (c->comm.nranks > 1 || c->comm.active()) {
     // multi-GPU: this rank's range of tiles only, zeros elsewhere, all-reduce of the product vector (every row
     // has exactly one non-zero contributor: the sum is exact), then the dot product on the full vectors --
     // the same arithmetic on every rank, so the replicated PCG recurrences stay bit-identical across ranks
@@ -1206,7 +1206,7 @@ int ensure_pcg_graph(sgo_ctx* c, int chunk) {
 // most two replays of early-exit launches are wasted.
 int run_pcg(sgo_ctx* c) {
   // collectives inside the loop: plain stream launches (RCCL calls are not captured into the hipGraph)
-  const bool graph = c->opts.use_graph && !c->opts.profile && !(c->comm.nranks > 1 || c->comm.handle);
+  const bool graph = c->opts.use_graph && !c->opts.profile && !(c->comm.nranks > 1 || c->comm.active());
   if (!graph) {
     const int chunk = std::max(1, c->opts.pcg_chunk);
     for (;;) {
@@ -1295,7 +1295,7 @@ int build_amg(sgo_ctx* c) {
   c->amg = amg_create(c->stream, c->A, c->S0, c->T0, c->H0, c->d_poses, c->d_free_id, cfg, prof, &aerr, &c->amg_scratch,
                       &c->amg_arena);
   if (c->amg) {
-    if (c->comm.nranks > 1 || c->comm.handle) amg_set_shard(c->amg, &c->comm, c->shard_u0, c->shard_u1, c->shard_row0, c->shard_row1);
+    if (c->comm.nranks > 1 || c->comm.active()) amg_set_shard(c->amg, &c->comm, c->shard_u0, c->shard_u1, c->shard_row0, c->shard_row1);
     amg_describe(c->amg, &c->solver_desc);
     c->solver_desc = "pcg_amg: " + c->solver_desc;
   } else {
@@ -1551,7 +1551,7 @@ int sgo_set_graph_se2(sgo_ctx* c, int32_t V, const double* poses, const uint8_t*
     c->has_graph = true;
     c->solver_desc = "pcg_block_jacobi";
     c->direct_why.clear();
-    if (c->opts.solver == SGO_SOLVER_PCG_AMG && c->n > 0 && c->opts.direct_rows > 0 && c->comm.nranks <= 1 && !c->comm.handle) {
+    if (c->opts.solver == SGO_SOLVER_PCG_AMG && c->n > 0 && c->opts.direct_rows > 0 && c->comm.nranks <= 1 && !c->comm.active()) {
       // Small graphs (the reference's own sizes): optimize() as ONE launch of a sparse direct solver when the
       // elimination analysis fits (sgo_direct.h); the multigrid hierarchy is then built only if a single-step
       // entry point asks for it.
@@ -2194,6 +2194,18 @@ int sgo_comm_init(sgo_ctx* c, int nranks, int rank, const void* unique_id) {
       return SGO_EINVAL;
     }
     return c->comm.init(nranks, rank, unique_id, &c->err) ? SGO_OK : SGO_ECOMM;
+  } SGO_CATCH(c)
+}
+
+int sgo_comm_init_host(sgo_ctx* c, int nranks, int rank, sgo_host_allreduce_fn fn, void* user) {
+  try {
+    if (!c || nranks < 1 || rank < 0 || rank >= nranks || !fn) return SGO_EINVAL;
+    hipSetDevice(c->device);
+    if (c->has_graph) {
+      c->err = "sgo_comm_init_host must precede sgo_set_graph_se2";
+      return SGO_EINVAL;
+    }
+    return c->comm.init_host(nranks, rank, fn, user) ? SGO_OK : SGO_ECOMM;
   } SGO_CATCH(c)
 }
 

@@ -5,7 +5,8 @@
 // product of the solve -- each rank evaluates the rows of its range of tiles and writes zeros
 // elsewhere, so the sum reproduces the full vector exactly -- and on the two chi2 partial sums
 // (BASELINE.json north_star).  A communicator of ONE
-// rank still calls ncclAllReduce (the single-GPU test of this path).
+// rank still calls ncclAllReduce (the single-GPU test of this path).  A caller may bring its own transport
+// instead (sgo_comm_init_host: MPI, gloo, ...): the same collectives, staged through pinned host memory.
 #include <dlfcn.h>
 
 #include <cstdlib>
@@ -105,14 +106,57 @@ bool Comm::init(int nranks_, int rank_, const void* id128, std::string* err) {
   return true;
 }
 
+bool Comm::init_host(int nranks_, int rank_, HostAllreduce fn, void* user) {
+  destroy();
+  host_fn = fn;
+  host_user = user;
+  nranks = nranks_;
+  rank = rank_;
+  return true;
+}
+
 void Comm::destroy() {
   if (handle) api().CommDestroy((ncclComm_t)handle);
   handle = nullptr;
+  if (stage) hipHostFree(stage);
+  stage = nullptr;
+  stage_cap = 0;
+  host_fn = nullptr;
+  host_user = nullptr;
   nranks = 1;
   rank = 0;
 }
 
 bool Comm::allreduce_f64(double* buf, size_t count, hipStream_t s, std::string* err) {
+  if (host_fn) {   // caller's transport: device -> pinned host -> callback (sum over ranks) -> device
+    if (count > stage_cap) {
+      if (stage) hipHostFree(stage);
+      stage = nullptr;
+      stage_cap = 0;
+      const size_t cap = count + count / 2 + 64;
+      if (hipHostMalloc((void**)&stage, cap * sizeof(double), hipHostMallocDefault) != hipSuccess) {
+        *err = "host transport: cannot allocate the pinned staging buffer";
+        return false;
+      }
+      stage_cap = cap;
+    }
+    if (hipMemcpyAsync(stage, buf, count * sizeof(double), hipMemcpyDeviceToHost, s) != hipSuccess ||
+        hipStreamSynchronize(s) != hipSuccess) {
+      *err = "host transport: device -> host copy failed";
+      return false;
+    }
+    const int rc = host_fn(stage, count, host_user);
+    if (rc != 0) {
+      *err = "host transport: the all-reduce callback returned " + std::to_string(rc);
+      return false;
+    }
+    // the next collective's device -> host copy is ordered behind this one on the stream: the buffer is free by then
+    if (hipMemcpyAsync(buf, stage, count * sizeof(double), hipMemcpyHostToDevice, s) != hipSuccess) {
+      *err = "host transport: host -> device copy failed";
+      return false;
+    }
+    return true;
+  }
   if (!handle) return true;   // no communicator (single GPU, or the rank-emulation test hook)
   int rc = api().AllReduce(buf, buf, count, kNcclFloat64, kNcclSum, (ncclComm_t)handle, s);
   if (rc != 0) {
@@ -123,6 +167,10 @@ bool Comm::allreduce_f64(double* buf, size_t count, hipStream_t s, std::string* 
 }
 
 bool Comm::allreduce_i32(int* buf, size_t count, hipStream_t s, std::string* err) {
+  if (host_fn) {
+    *err = "host transport: integer all-reduce is not provided";
+    return false;
+  }
   if (!handle) return true;
   int rc = api().AllReduce(buf, buf, count, kNcclInt32, kNcclSum, (ncclComm_t)handle, s);
   if (rc != 0) {

@@ -9,11 +9,20 @@ namespace sgo {
 
 bool comm_unique_id(void* out128, std::string* err);
 
+// in-place sum over ranks of `count` doubles in HOST memory; returns 0 on success (sgo_host_allreduce_fn, sgo.h)
+using HostAllreduce = int (*)(double* buf, size_t count, void* user);
+
 struct Comm {
-  void* handle = nullptr;
+  void* handle = nullptr;          // RCCL communicator
+  HostAllreduce host_fn = nullptr; // caller-supplied transport (sgo_comm_init_host): collectives staged through pinned memory
+  void* host_user = nullptr;
+  double* stage = nullptr;
+  size_t stage_cap = 0;
   int nranks = 1;
   int rank = 0;
+  bool active() const { return handle != nullptr || host_fn != nullptr; }
   bool init(int nranks, int rank, const void* id128, std::string* err);
+  bool init_host(int nranks, int rank, HostAllreduce fn, void* user);
   void destroy();
   // in-place sum over ranks on stream s (no-op when nranks == 1)
   bool allreduce_f64(double* buf, size_t count, hipStream_t s, std::string* err);
