@@ -1,11 +1,26 @@
 #!/usr/bin/env python3
-"""Per-kernel table of a bench.py JSON line (stdin): launches, total ms, average us, GB/s."""
-import json
+"""Per-kernel time table (profile mode: every launch bracketed by its own dispatch events) of optimize(iters) on a named
+config: `python scripts/kernel_table.py C4r [iters]`."""
+import os
 import sys
 
-d = json.loads(sys.stdin.readline())
-k = d["roofline"]["kernels"]
-print(f"gn_ms {d['gn_iter_ms_median']:.2f}  pcg/GN {d['pcg_iters_per_gn_iter']:.1f}  value {d['value']/1e6:.2f} M/s")
-for n, v in sorted(k.items(), key=lambda kv: -kv[1]["ms"]):
-    print(f"{n:<44s} launches {v['launches']:6d}  ms {v['ms']:8.3f}  avg_us {v['avg_us']:7.2f}  GB/s {v['GB/s']:7.1f}")
-print("total kernel ms", round(sum(v["ms"] for v in k.values()), 2))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from sparse_gslam_amd import capi, synth  # noqa: E402
+
+name = sys.argv[1] if len(sys.argv) > 1 else "C4"
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+g = synth.config(name)
+with capi.Optimizer(0, profile=1) as o:
+    o.set_graph(*g.arrays())
+    print(o.solver_description(), flush=True)
+    o.optimize(1)
+    o.profile_reset()
+    done, st = o.optimize(iters)
+    prof = o.kernel_profile()
+tot = sum(v["ms"] for v in prof.values())
+its = sum(st["pcg_iters"])
+print(f"{name}: {done} GN iterations, pcg {st['pcg_iters']}, kernel time {tot:.2f} ms = {tot / max(done, 1):.2f} ms per GN iteration, "
+      f"{1e3 * tot / max(its, 1):.0f} us per PCG iteration (all kernels)")
+for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"]):
+    print(f"  {k:44s} {v['launches']:7d} launches  {v['ms']:9.3f} ms  {1e3 * v['ms'] / v['launches']:8.2f} us avg  "
+          f"{v['launches'] / max(its, 1):6.2f} per PCG it  {100 * v['ms'] / tot:5.1f} %")

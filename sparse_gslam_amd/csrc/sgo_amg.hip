@@ -64,23 +64,31 @@ __global__ __launch_bounds__(kBlock) void k_positions0(int n, const int* __restr
   }
 }
 
-// Aggregate centres and lever arms: one thread per aggregate (members are few).
+// Aggregate centres and lever arms: one wave per aggregate (lanes stride over the members, wave-wide sums in a fixed
+// order).  An aggregate may hold hundreds of members -- the last level of a stalled hierarchy collapses into one --
+// which one thread per aggregate walked serially (57 us per launch on C4 with random closures, 24 us on C4).
 __global__ __launch_bounds__(kBlock) void k_centres(int nc, const int* __restrict__ mem_ptr, const int* __restrict__ mem,
                                                     const double* __restrict__ pos, double* __restrict__ cpos,
                                                     double* __restrict__ d) {
-  for (int a = blockIdx.x * kBlock + threadIdx.x; a < nc; a += gridDim.x * kBlock) {
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6), nwaves = gridDim.x * kWavesPerBlock;
+  for (int a = wave; a < nc; a += nwaves) {
     const int lo = mem_ptr[a], hi = mem_ptr[a + 1];
     double sx = 0.0, sy = 0.0;
-    for (int t = lo; t < hi; ++t) {
+    for (int t = lo + lane; t < hi; t += 64) {
       const int i = mem[t];
       sx += pos[2 * (size_t)i];
       sy += pos[2 * (size_t)i + 1];
     }
+    sx = __shfl(wave_sum(sx), 0);   // wave_sum leaves the total in lane 0
+    sy = __shfl(wave_sum(sy), 0);
     const double inv = 1.0 / (double)(hi - lo);
     const double cx = sx * inv, cy = sy * inv;
-    cpos[2 * (size_t)a] = cx;
-    cpos[2 * (size_t)a + 1] = cy;
-    for (int t = lo; t < hi; ++t) {
+    if (lane == 0) {
+      cpos[2 * (size_t)a] = cx;
+      cpos[2 * (size_t)a + 1] = cy;
+    }
+    for (int t = lo + lane; t < hi; t += 64) {
       const int i = mem[t];
       d[2 * (size_t)i] = pos[2 * (size_t)i] - cx;
       d[2 * (size_t)i + 1] = pos[2 * (size_t)i + 1] - cy;
@@ -1131,7 +1139,13 @@ struct Amg {
   const double* d_poses = nullptr;
   const int* d_free_id = nullptr;
   int kdepth = 1 << 20;  // levels <= kdepth use the K-cycle (two FCG steps), deeper ones a V-cycle
-  int fcg2_depth = 1 << 20;  // levels <= this take two FCG steps, deeper K-cycle levels one
+  // Levels <= this take two FCG steps, deeper K-cycle levels one.  Two steps everywhere visit level l 2^l times:
+  // on hierarchies of six levels (C4 with 5 % random closures: 100k -> 11k -> 2.5k -> 897 -> 627 -> 1) that is ~150
+  // coarse launches per PCG iteration.  Two steps on level 1 only keep the PCG counts within 3-9 % (C4r 580 -> 597
+  // over optimize(20)) at a third of the launches: C4r 22.5 -> 10.8 ms per GN iteration, 30k-pose graphs 1.2-1.3 x
+  // (scripts/kcycle_sweep.py, profiles/r02_kcycle_sweep.txt); one step everywhere is faster still on average but
+  // needs 40-50 % more iterations and doubles the worst solve.
+  int fcg2_depth = 1;
   // coarsest dense inverse (row-major, leading dimension Np = N rounded up to 32)
   int N = 0, Np = 0;
   double* inv = nullptr;
@@ -1423,7 +1437,7 @@ int amg_update(Amg* m, hipStream_t s, std::string* err) {
     AmgLevel& C = m->lv[l + 1];
     {
       Scope sc(m->prof, K_CENTRES, 36.0 * L.A.n);
-      SGO_LAUNCH(k_centres, dim3(grid_for(L.nc, kBlock)), dim3(kBlock), 0, s, L.nc, L.mem_ptr, L.mem, L.pos, C.pos, L.d);
+      SGO_LAUNCH(k_centres, dim3(grid_for(L.nc, kWavesPerBlock)), dim3(kBlock), 0, s, L.nc, L.mem_ptr, L.mem, L.pos, C.pos, L.d);
     }
     launch_coarse_operator(m, s, L, C);
     {
@@ -1783,7 +1797,7 @@ Amg* amg_create(hipStream_t s, const BsrDev& A0, const Sym0Dev& S0, const Tile0D
       if (!Cr.pos) return fail("amg_create: out of device memory");
       if (l == 0)
         SGO_LAUNCH(k_positions0, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, s, n, d_free_id, d_poses, Lr.pos);
-      SGO_LAUNCH(k_centres, dim3(grid_for(nc, kBlock)), dim3(kBlock), 0, s, nc, Lr.mem_ptr, Lr.mem, Lr.pos, Cr.pos, Lr.d);
+      SGO_LAUNCH(k_centres, dim3(grid_for(nc, kWavesPerBlock)), dim3(kBlock), 0, s, nc, Lr.mem_ptr, Lr.mem, Lr.pos, Cr.pos, Lr.d);
       launch_coarse_operator(m, s, Lr, Cr);
       if (l + 1 < m->cfg.max_levels) SGO_LAUNCH(k_level_dinv, dim3(grid_for(Cr.A.n, kBlock)), dim3(kBlock), 0, s, Cr.A);
       if (hipStreamSynchronize(s) != hipSuccess) return fail("amg_create: Galerkin kernel failed");

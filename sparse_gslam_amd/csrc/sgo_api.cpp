@@ -961,6 +961,17 @@ int build_structure(sgo_ctx* c, int V, const double* poses, const uint8_t* fixed
     if ((rc = upload(c, &TL.grow1, grow1))) return rc;
     if ((rc = upload(c, &TL.trowptr, trowptr))) return rc;
     if ((rc = upload(c, &TL.hcol, hcol))) return rc;
+    {
+      int hs = 0;
+      for (const TileDesc& T : tiles) hs = std::max(hs, std::min(T.h1 - T.h0, TL.threads));
+      hs = std::max(64, (hs + 63) / 64 * 64);
+      std::vector<int> hfirst((size_t)hs * tiles.size(), -1);
+      for (size_t t = 0; t < tiles.size(); ++t)
+        std::copy(hcol.begin() + tiles[t].h0, hcol.begin() + tiles[t].h0 + std::min(tiles[t].h1 - tiles[t].h0, hs),
+                  hfirst.begin() + (size_t)hs * t);
+      TL.hstride = hs;
+      if ((rc = upload(c, &TL.hfirst, hfirst))) return rc;
+    }
     if (c->opts.verbose)
       std::fprintf(stderr, "[sgo] level-0 tiles: %d tiles, %d B LDS, %d stored blocks for %d pairs (%.1f %% stored with both rows), %zu halo columns\n",
                    TL.ntile, TL.lds_bytes, nu, (nu + ntr) / 2, (nu + ntr) > 0 ? 100.0 * (nu - ntr) / (nu + ntr) : 0.0, hcol.size());

@@ -141,6 +141,8 @@ struct Tile0Dev {
   int* grow1 = nullptr;             // [ng1]
   int* trowptr = nullptr;           // [n + 1] staged entries of row r: [trowptr[r], trowptr[r+1])  (global numbering)
   int* hcol = nullptr;              // halo columns (global rows) of all tiles
+  int* hfirst = nullptr;            // [ntile][hstride] the first hstride halo columns of every tile at a fixed stride (-1 beyond the
+  int hstride = 0;                  // tile's own): their address does not depend on the tile descriptor, one round trip less
 };
 
 // Edge operands aligned with the level-0 compact slots (SoA over slots).  For a slot of row r that

@@ -612,7 +612,9 @@ __device__ __forceinline__ void tile_slot(const double* __restrict__ xs, double*
 
 template <int MODE, int kTileThreads>
 __global__ __launch_bounds__(kTileThreads) void k_spmv0t(Sym0Dev A, Tile0Dev TL, Spmv0Args a) {
-  if (a.S && a.S->stop) return;
+  // the stop flag, the tile descriptor and the tile's first halo column numbers are requested together (none of their
+  // addresses depends on another's value): phase 0 is a chain of two memory round trips instead of four
+  const int stop_flag = a.S ? a.S->stop : 0;
   extern __shared__ double lds[];
   __shared__ int next_group_cell;
   int* next_group = &next_group_cell;
@@ -625,7 +627,9 @@ __global__ __launch_bounds__(kTileThreads) void k_spmv0t(Sym0Dev A, Tile0Dev TL,
   const int ulo = a.u1 > 0 ? a.u0 : 0, nun = (a.u1 > 0 ? a.u1 : TL.ntile) - ulo;
   const int tlo = ulo + (int)(((long long)nun * xcd) >> 3), thi = ulo + (int)(((long long)nun * (xcd + 1)) >> 3);
   for (int t = tlo + slot; t < thi; t += per_xcd) {
+    const int hc_first = tid < TL.hstride ? TL.hfirst[(size_t)t * TL.hstride + tid] : -1;
     const TileDesc T = TL.tile[t];
+    if (stop_flag) return;
     const int nr = T.row1 - T.row0, nh = T.h1 - T.h0;
     long long* stamp = a.dbg_stamps ? a.dbg_stamps + 8 * (size_t)t : nullptr;
     if (stamp && tid == 0) stamp[0] = __builtin_amdgcn_s_memtime();
@@ -641,7 +645,7 @@ __global__ __launch_bounds__(kTileThreads) void k_spmv0t(Sym0Dev A, Tile0Dev TL,
       const int i = tid + q * kTileThreads;
       if (i < 3 * nr) xsl[q] = a.x[3 * (size_t)T.row0 + i];
     }
-    const int hc0 = tid < nh ? TL.hcol[T.h0 + tid] : -1;
+    const int hc0 = tid < TL.hstride ? hc_first : (tid < nh ? TL.hcol[T.h0 + tid] : -1);
     if (tid == 0) *next_group = T.g0 + NW;   // groups are handed out through an LDS counter (the first NW statically)
     int g = T.g0 + wave;
     bool has = g < T.g1;
