@@ -20,7 +20,7 @@ cases = [
 ]
 if len(sys.argv) > 1 and sys.argv[1] == "C5":
     cases = [("C5", lambda: synth.config("C5"))]
-settings = ["", "SGO_AMG_FCG2_DEPTH=2", "SGO_AMG_FCG2_DEPTH=1", "SGO_AMG_FCG2_DEPTH=0"]
+settings = os.environ.get("SGO_SWEEP", "|SGO_AMG_FCG2_DEPTH=2|SGO_AMG_FCG2_DEPTH=1|SGO_AMG_FCG2_DEPTH=0").split("|")
 for name, make in cases:
     g = make()
     for setting in settings:
