@@ -51,7 +51,17 @@ struct HostLevel {
 // lists; it is rewound here and may be rewound again by the caller once amg_create has returned.
 Amg* amg_create(hipStream_t s, const BsrDev& A0, const Sym0Dev& S0, const Tile0Dev& T0, const HostLevel& H0, const double* d_poses,
                 const int* d_free_id, const AmgConfig& cfg, const AmgProf& prof, std::string* err,
-                ChunkArena* scratch, DevArena* arena);
+                ChunkArena* scratch, DevArena* arena, struct AmgHostL0* pre0 = nullptr);
+// Level 0's host analysis (aggregation, patterns and product lists of the transfer, structure of level 1) made ahead
+// of amg_create from the level's logical structure and the strength weights w (Frobenius norms of the slots' blocks
+// at the initial poses, logical slot order): amg_host_l0_run may execute on a helper thread while the caller still
+// builds the level-0 storage; amg_create(..., pre0) then starts from its result.  `scratch` belongs to the run until
+// amg_create has returned.
+struct AmgHostL0;
+AmgHostL0* amg_host_l0_new();
+void amg_host_l0_run(AmgHostL0* p, const HostLevel& H0, const std::vector<double>& w, const AmgConfig& cfg, ChunkArena* scratch);
+void amg_host_l0_free(AmgHostL0* p);
+AmgConfig amg_effective_config(const AmgConfig& cfg_in, int n, int nslot);
 void amg_destroy(Amg* m);
 // Recompute the coarse operators for the current level-0 values and poses (once per GN iteration).
 int amg_update(Amg* m, hipStream_t s, std::string* err);

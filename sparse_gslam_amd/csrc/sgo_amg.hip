@@ -1100,6 +1100,137 @@ bool sa_symbolic(const HostLevel& H, const std::vector<int>& agg, int nc, long l
   return true;
 }
 
+
+// Everything the host decides about one coarsening step: aggregates, patterns and product lists of the smoothed
+// transfer (or the tentative one's Galerkin map), structure of the next level.  Depends on the level's structure and
+// on the strength weights only -- for level 0 it can therefore run on a helper thread while the caller still builds
+// the level-0 storage (amg_host_l0_start, sgo_api.cpp).
+struct HostCoarse {
+  std::vector<int> agg, visit_c, mem_ptr, mem;
+  int nc = 0;
+  bool stop = false;     // the level cannot be coarsened further
+  bool smooth = false;
+  SaHost sa;
+  HostLevel Hc;
+  std::vector<int> order, tgt, cptr, grp_g, grp_c;
+  double t_agg = 0, t_sort = 0, t_all = 0;
+  std::string err;
+};
+
+void host_coarsen(const HostLevel& H, const std::vector<double>& w, const AmgConfig& cfg, int l, ChunkArena* scratch, HostCoarse& o) {
+  const int n = H.n;
+  std::vector<int>& agg = o.agg;
+  const double theta_l = l == 0 ? cfg.theta : cfg.theta_coarse;
+  const auto tA = std::chrono::steady_clock::now();
+  auto ms_since = [](std::chrono::steady_clock::time_point t) {
+    return 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count();
+  };
+  int nc = aggregate(H, w, theta_l, agg);
+  if (nc > 0.9 * n) nc = aggregate(H, w, 0.0, agg);  // stalled: treat every connection as strong
+  if (nc > 0.9 * n || nc < 1) {                        // cannot coarsen further
+    o.stop = true;
+    return;
+  }
+  if (!H.visit.empty()) renumber_aggregates(agg, nc, o.visit_c);
+  o.nc = nc;
+  o.t_agg = ms_since(tA);
+
+  // members by aggregate
+  std::vector<int>&mem_ptr = o.mem_ptr, &mem = o.mem;
+  mem_ptr.assign((size_t)nc + 1, 0);
+  mem.resize(n);
+  for (int i = 0; i < n; ++i) mem_ptr[agg[i] + 1]++;
+  for (int a = 0; a < nc; ++a) mem_ptr[a + 1] += mem_ptr[a];
+  {
+    std::vector<int> fill(mem_ptr.begin(), mem_ptr.end() - 1);
+    for (int i = 0; i < n; ++i) mem[fill[agg[i]]++] = i;
+  }
+  HostLevel& Hc = o.Hc;
+  std::vector<int>&order = o.order, &tgt = o.tgt, &cptr = o.cptr;
+  SaHost& sa = o.sa;
+  if (scratch) {   // everything of the previous level has been uploaded (stream synchronised by the caller)
+    scratch->rewind();
+    sa.ap_a.arena = sa.ap_b.arena = sa.ap_tgt.arena = scratch;
+    sa.rap_a.arena = sa.rap_b.arena = sa.rap_tgt.arena = scratch;
+  }
+  bool smooth = cfg.smooth;
+  if (smooth) {
+    // product lists of at most 16 per fine slot (C4 needs 9-11, chain-like graphs 4-6) and a coarse
+    // operator with no more blocks than the fine one (C4 0.06x, chains 0.5x); beyond that the smoothed coarse operator is
+    // nearly dense (5 % random long-range closures on C4: 33 products per slot, 4.4x the blocks,
+    // 2x slower than the tentative hierarchy): this level keeps the tentative prolongator
+    const long long budget = std::min<long long>(1500000000LL, std::max<long long>(16LL * H.nslot, 2000000LL));
+    try {
+      smooth = sa_symbolic(H, agg, nc, budget, sa);
+    } catch (const std::bad_alloc&) {
+      smooth = false;
+    }
+    if (smooth) Hc = std::move(sa.Hc);
+    else sa = SaHost();
+    o.t_sort = ms_since(tA) - o.t_agg;
+  }
+  if (!smooth) {
+    // coarse slots: unique (agg[row], agg[col]); diagonal first in each row
+    const int ns = H.nslot;
+    std::vector<uint64_t> key(ns);
+    for (int k = 0; k < ns; ++k) {
+      const uint64_t cr = (uint64_t)agg[H.row[k]], cc = (uint64_t)agg[H.col[k]];
+      const uint64_t ccs = (cc == cr) ? 0 : cc + 1;  // diagonal sorts first
+      key[k] = (cr << 32) | ccs;
+    }
+    // stable order by key = two stable counting sorts (low word = column code, then high word = row):
+    // O(ns), a few ms for 2M slots where std::stable_sort with an indirect key took > 100 ms
+    order.resize(ns);
+    {
+      std::vector<int> tmp(ns), cnt((size_t)nc + 2, 0);
+      for (int k = 0; k < ns; ++k) cnt[(size_t)(key[k] & 0xffffffffull) + 1]++;
+      for (size_t b = 1; b < cnt.size(); ++b) cnt[b] += cnt[b - 1];
+      for (int k = 0; k < ns; ++k) tmp[cnt[(size_t)(key[k] & 0xffffffffull)]++] = k;
+      std::fill(cnt.begin(), cnt.end(), 0);
+      for (int k = 0; k < ns; ++k) cnt[(size_t)(key[k] >> 32) + 1]++;
+      for (size_t b = 1; b < cnt.size(); ++b) cnt[b] += cnt[b - 1];
+      for (int t = 0; t < ns; ++t) {
+        const int k = tmp[t];
+        order[cnt[(size_t)(key[k] >> 32)]++] = k;
+      }
+    }
+    o.t_sort = ms_since(tA) - o.t_agg;
+    Hc.n = nc;
+    tgt.resize(ns);   // contribution -> coarse slot; cptr: coarse slot -> contribution range
+    {
+      uint64_t prev = ~0ull;
+      int cs = -1;
+      for (int t = 0; t < ns; ++t) {
+        const uint64_t kk = key[order[t]];
+        if (kk != prev) {
+          ++cs;
+          prev = kk;
+          cptr.push_back(t);
+          const int cr = (int)(kk >> 32);
+          const uint64_t ccs = kk & 0xffffffffull;
+          Hc.row.push_back(cr);
+          Hc.col.push_back(ccs == 0 ? cr : (int)(ccs - 1));
+        }
+        tgt[t] = cs;
+      }
+      cptr.push_back(ns);
+    }
+    Hc.nslot = (int)Hc.row.size();
+    Hc.rowptr.assign(nc + 1, 0);
+    for (int k = 0; k < Hc.nslot; ++k) Hc.rowptr[Hc.row[k] + 1]++;
+    for (int a = 0; a < nc; ++a) Hc.rowptr[a + 1] += Hc.rowptr[a];
+    for (int a = 0; a < nc; ++a)
+      if (Hc.col[Hc.rowptr[a]] != a) {
+        o.err = "amg_create: internal error (coarse diagonal slot missing)";
+        return;
+      }
+    o.grp_g = make_groups(cptr);
+  }
+  o.smooth = smooth;
+  o.grp_c = make_groups(Hc.rowptr);
+  o.t_all = ms_since(tA);
+}
+
 }  // namespace
 
 // one level of the hierarchy on the device
@@ -1524,33 +1655,62 @@ int amg_apply(Amg* m, hipStream_t s, const double* r, double* z, const double* d
   return cycle(m, s, 0, r, nullptr, none, nullptr, z, dotvec, partials, S, dotvec2, xs0_ready);
 }
 
+// The configuration amg_create works with for a level-0 operator of n rows / nslot logical slots: the caller's
+// values, the environment overrides and the size-dependent choices.
+AmgConfig amg_effective_config(const AmgConfig& cfg_in, int n, int nslot) {
+  AmgConfig cfg = cfg_in;
+  if (const char* e = std::getenv("SGO_AMG_THETA")) cfg.theta = std::atof(e);
+  if (const char* e = std::getenv("SGO_AMG_OMEGA")) cfg.omega = std::atof(e);
+  if (const char* e = std::getenv("SGO_AMG_THETA_COARSE")) cfg.theta_coarse = std::atof(e);
+  // A sweep on a coarse level is a 5-10 us launch whatever the graph; it pays when a PCG iteration is
+  // dominated by level 0 (C4: 31 instead of 39 iterations, 9.7 instead of 10.6 ms) and costs a few
+  // per cent on graphs whose level 0 is itself launch-bound (10k / 40k: 2.67 instead of 2.51 ms).
+  cfg.nu_coarse = nslot >= 1000000 ? 2 : 1;
+  if (const char* e = std::getenv("SGO_AMG_NU_COARSE")) cfg.nu_coarse = std::atoi(e);
+  if (const char* e = std::getenv("SGO_AMG_SMOOTH")) cfg.smooth = std::atoi(e) != 0;
+  if (const char* e = std::getenv("SGO_AMG_OMEGA_P")) cfg.omega_p = std::atof(e);
+  // larger graphs afford a larger dense coarsest level (its inverse costs O(N^3) once per GN
+  // iteration, one K-cycle level less halves the coarse-level launches of every PCG iteration)
+  cfg.coarsest_nodes = std::min(1000, std::max(cfg.coarsest_nodes, n / 1500));
+  if (const char* e = std::getenv("SGO_AMG_COARSEST")) cfg.coarsest_nodes = std::atoi(e);
+  return cfg;
+}
+
+// Level 0's host analysis made AHEAD of amg_create: amg_host_l0_run is what a helper thread executes once the
+// strength weights `w` of the level-0 slots (logical order of H0) are on the host; amg_create(..., pre0) then skips its
+// own strength kernel, aggregation and symbolic phase for level 0.  `scratch` is used by the run (and must not be
+// touched by anybody else meanwhile).
+struct AmgHostL0 {
+  HostCoarse hc;
+  bool ready = false;
+};
+AmgHostL0* amg_host_l0_new() { return new AmgHostL0(); }
+void amg_host_l0_free(AmgHostL0* p) { delete p; }
+void amg_host_l0_run(AmgHostL0* p, const HostLevel& H0, const std::vector<double>& w, const AmgConfig& cfg_in, ChunkArena* scratch) {
+  try {
+    const AmgConfig cfg = amg_effective_config(cfg_in, H0.n, H0.nslot);
+    if (H0.n <= cfg.coarsest_nodes || 1 >= cfg.max_levels) return;   // amg_create will not coarsen level 0 at all
+    host_coarsen(H0, w, cfg, 0, scratch, p->hc);
+    p->ready = p->hc.err.empty();
+  } catch (...) {
+    p->ready = false;   // amg_create does the work itself (and reports what fails there)
+  }
+}
+
 Amg* amg_create(hipStream_t s, const BsrDev& A0, const Sym0Dev& S0, const Tile0Dev& T0, const HostLevel& H0, const double* d_poses,
                 const int* d_free_id, const AmgConfig& cfg_in, const AmgProf& prof, std::string* err,
-                ChunkArena* scratch, DevArena* arena) {
+                ChunkArena* scratch, DevArena* arena, AmgHostL0* pre0) {
   Amg* m = new Amg();
   m->pool = arena;
   m->cfg = cfg_in;
   m->S0 = S0;
   m->T0 = T0;
-  if (const char* e = std::getenv("SGO_AMG_THETA")) m->cfg.theta = std::atof(e);
-  if (const char* e = std::getenv("SGO_AMG_OMEGA")) m->cfg.omega = std::atof(e);
-  if (const char* e = std::getenv("SGO_AMG_THETA_COARSE")) m->cfg.theta_coarse = std::atof(e);
-  // A sweep on a coarse level is a 5-10 us launch whatever the graph; it pays when a PCG iteration is
-  // dominated by level 0 (C4: 31 instead of 39 iterations, 9.7 instead of 10.6 ms) and costs a few
-  // per cent on graphs whose level 0 is itself launch-bound (10k / 40k: 2.67 instead of 2.51 ms).
-  m->cfg.nu_coarse = A0.nslot >= 1000000 ? 2 : 1;
-  if (const char* e = std::getenv("SGO_AMG_NU_COARSE")) m->cfg.nu_coarse = std::atoi(e);
-  if (const char* e = std::getenv("SGO_AMG_SMOOTH")) m->cfg.smooth = std::atoi(e) != 0;
-  if (const char* e = std::getenv("SGO_AMG_OMEGA_P")) m->cfg.omega_p = std::atof(e);
+  m->cfg = amg_effective_config(cfg_in, A0.n, A0.nslot);
   // With the smoothed prolongator a V-cycle needs ~1.4x the PCG iterations of the K-cycle (C4: 39 vs
   // 27) at less than half the launches per iteration: V is the default there, K for the tentative one.
   if (m->cfg.smooth) m->kdepth = 0;
   if (const char* e = std::getenv("SGO_AMG_KDEPTH")) m->kdepth = std::atoi(e);
   if (const char* e = std::getenv("SGO_AMG_FCG2_DEPTH")) m->fcg2_depth = std::atoi(e);
-  // larger graphs afford a larger dense coarsest level (its inverse costs O(N^3) once per GN
-  // iteration, one K-cycle level less halves the coarse-level launches of every PCG iteration)
-  m->cfg.coarsest_nodes = std::min(1000, std::max(m->cfg.coarsest_nodes, A0.n / 1500));
-  if (const char* e = std::getenv("SGO_AMG_COARSEST")) m->cfg.coarsest_nodes = std::atoi(e);
   m->prof = prof;
   m->d_poses = d_poses;
   m->d_free_id = d_free_id;
@@ -1599,8 +1759,9 @@ Amg* amg_create(hipStream_t s, const BsrDev& A0, const Sym0Dev& S0, const Tile0D
     if (n <= m->cfg.coarsest_nodes || l + 1 >= m->cfg.max_levels) break;
 
     // strength of connection from the current values of this level
-    std::vector<double> w(H.nslot);
-    {
+    std::vector<double> w;
+    if (!(l == 0 && pre0 && pre0->ready)) {
+      w.resize(H.nslot);
       double* d_w = dev_alloc<double>(m->pool, (size_t)std::max(H.nslot, 1));   // (stays in the arena until its rewind)
       if (!d_w) return fail("amg_create: out of device memory");
       SGO_LAUNCH(k_block_norms, dim3(grid_for(H.nslot, kBlock)), dim3(kBlock), 0, s, L.A, d_w);
@@ -1608,110 +1769,28 @@ Amg* amg_create(hipStream_t s, const BsrDev& A0, const Sym0Dev& S0, const Tile0D
       const hipError_t e = hipStreamSynchronize(s);
       if (e != hipSuccess) return fail("amg_create: strength kernel failed");
     }
-    std::vector<int> agg;
-    const double theta_l = l == 0 ? m->cfg.theta : m->cfg.theta_coarse;
-    const auto tA = std::chrono::steady_clock::now();
+    HostCoarse hc_own;
+    HostCoarse* hcp = &hc_own;
+    if (l == 0 && pre0 && pre0->ready) {
+      hcp = &pre0->hc;   // made ahead on the helper thread, from the same structure and the strengths at the same poses
+    } else {
+      host_coarsen(H, w, m->cfg, l, scratch, hc_own);
+    }
+    HostCoarse& hc = *hcp;
+    if (!hc.err.empty()) return fail(hc.err);
+    if (hc.stop) break;
+    const int nc = hc.nc;
+    const bool smooth = hc.smooth;
+    std::vector<int>&agg = hc.agg, &mem_ptr = hc.mem_ptr, &mem = hc.mem, &order = hc.order, &tgt = hc.tgt, &grp_g = hc.grp_g,
+                    &grp_c = hc.grp_c, &visit_c = hc.visit_c;
+    SaHost& sa = hc.sa;
+    HostLevel& Hc = hc.Hc;
     auto ms_since = [](std::chrono::steady_clock::time_point t) {
       return 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count();
     };
-    double t_agg = 0, t_sort = 0;
-    int nc = aggregate(H, w, theta_l, agg);
-    if (nc > 0.9 * n) nc = aggregate(H, w, 0.0, agg);  // stalled: treat every connection as strong
-    if (nc > 0.9 * n || nc < 1) break;                   // cannot coarsen further
-    std::vector<int> visit_c;
-    if (!H.visit.empty()) renumber_aggregates(agg, nc, visit_c);
-    t_agg = ms_since(tA);
-
-    // members by aggregate
-    std::vector<int> mem_ptr(nc + 1, 0), mem(n);
-    for (int i = 0; i < n; ++i) mem_ptr[agg[i] + 1]++;
-    for (int a = 0; a < nc; ++a) mem_ptr[a + 1] += mem_ptr[a];
-    {
-      std::vector<int> fill(mem_ptr.begin(), mem_ptr.end() - 1);
-      for (int i = 0; i < n; ++i) mem[fill[agg[i]]++] = i;
-    }
-    HostLevel Hc;
-    std::vector<int> order, tgt, cptr, grp_g;
-    SaHost sa;
-    if (scratch) {   // everything of the previous level has been uploaded (stream synchronised below)
-      scratch->rewind();
-      sa.ap_a.arena = sa.ap_b.arena = sa.ap_tgt.arena = scratch;
-      sa.rap_a.arena = sa.rap_b.arena = sa.rap_tgt.arena = scratch;
-    }
-    bool smooth = m->cfg.smooth;
-    if (smooth) {
-      // product lists of at most 16 per fine slot (C4 needs 9-11, chain-like graphs 4-6) and a coarse
-      // operator with no more blocks than the fine one (C4 0.06x, chains 0.5x); beyond that the smoothed coarse operator is
-      // nearly dense (5 % random long-range closures on C4: 33 products per slot, 4.4x the blocks,
-      // 2x slower than the tentative hierarchy): this level keeps the tentative prolongator
-      const long long budget = std::min<long long>(1500000000LL, std::max<long long>(16LL * H.nslot, 2000000LL));
-      try {
-        smooth = sa_symbolic(H, agg, nc, budget, sa);
-      } catch (const std::bad_alloc&) {
-        smooth = false;
-      }
-      if (smooth) Hc = std::move(sa.Hc);
-      else sa = SaHost();
-      t_sort = ms_since(tA) - t_agg;
-    }
-    if (!smooth) {
-    // coarse slots: unique (agg[row], agg[col]); diagonal first in each row
-    const int ns = H.nslot;
-    std::vector<uint64_t> key(ns);
-    for (int k = 0; k < ns; ++k) {
-      const uint64_t cr = (uint64_t)agg[H.row[k]], cc = (uint64_t)agg[H.col[k]];
-      const uint64_t ccs = (cc == cr) ? 0 : cc + 1;  // diagonal sorts first
-      key[k] = (cr << 32) | ccs;
-    }
-    // stable order by key = two stable counting sorts (low word = column code, then high word = row):
-    // O(ns), a few ms for 2M slots where std::stable_sort with an indirect key took > 100 ms
-    order.resize(ns);
-    {
-      std::vector<int> tmp(ns), cnt((size_t)nc + 2, 0);
-      for (int k = 0; k < ns; ++k) cnt[(size_t)(key[k] & 0xffffffffull) + 1]++;
-      for (size_t b = 1; b < cnt.size(); ++b) cnt[b] += cnt[b - 1];
-      for (int k = 0; k < ns; ++k) tmp[cnt[(size_t)(key[k] & 0xffffffffull)]++] = k;
-      std::fill(cnt.begin(), cnt.end(), 0);
-      for (int k = 0; k < ns; ++k) cnt[(size_t)(key[k] >> 32) + 1]++;
-      for (size_t b = 1; b < cnt.size(); ++b) cnt[b] += cnt[b - 1];
-      for (int t = 0; t < ns; ++t) {
-        const int k = tmp[t];
-        order[cnt[(size_t)(key[k] >> 32)]++] = k;
-      }
-    }
-    t_sort = ms_since(tA) - t_agg;
-    Hc.n = nc;
-    tgt.resize(ns);   // contribution -> coarse slot; cptr: coarse slot -> contribution range
-    {
-      uint64_t prev = ~0ull;
-      int cs = -1;
-      for (int t = 0; t < ns; ++t) {
-        const uint64_t kk = key[order[t]];
-        if (kk != prev) {
-          ++cs;
-          prev = kk;
-          cptr.push_back(t);
-          const int cr = (int)(kk >> 32);
-          const uint64_t ccs = kk & 0xffffffffull;
-          Hc.row.push_back(cr);
-          Hc.col.push_back(ccs == 0 ? cr : (int)(ccs - 1));
-        }
-        tgt[t] = cs;
-      }
-      cptr.push_back(ns);
-    }
-    Hc.nslot = (int)Hc.row.size();
-    Hc.rowptr.assign(nc + 1, 0);
-    for (int k = 0; k < Hc.nslot; ++k) Hc.rowptr[Hc.row[k] + 1]++;
-    for (int a = 0; a < nc; ++a) Hc.rowptr[a + 1] += Hc.rowptr[a];
-    for (int a = 0; a < nc; ++a)
-      if (Hc.col[Hc.rowptr[a]] != a) return fail("amg_create: internal error (coarse diagonal slot missing)");
-    grp_g = make_groups(cptr);
-    }
-    std::vector<int> grp_c = make_groups(Hc.rowptr);
     if (std::getenv("SGO_VERBOSE"))
-      std::fprintf(stderr, "[sgo] amg level %d: host aggregation + coarse structure %.1f ms (aggregate %.1f, sort %.1f; n=%d -> %d)\n",
-                   l, ms_since(tA), t_agg, t_sort, n, nc);
+      std::fprintf(stderr, "[sgo] amg level %d: host aggregation + coarse structure %.1f ms (aggregate %.1f, sort %.1f; n=%d -> %d)%s\n",
+                   l, hc.t_all, hc.t_agg, hc.t_sort, n, nc, hcp == &hc_own ? "" : " [made ahead on the helper thread]");
 
     // upload transfer data of level l and the structure of level l+1
     const auto tU = std::chrono::steady_clock::now();

@@ -134,6 +134,10 @@ struct sgo_ctx {
   double bb_ref = 0.0;            // |b|^2 of the first solve of the running sgo_optimize_gn (0: relative tolerance only)
   double tol_cap = 0.0;           // loosest relative tolerance the absolute criterion may reach (0: off; opts.pcg_tol_cap)
   int pcg_softcap = 0;            // > 0: iteration cap of the next solve (sgo_optimize_gn: stale-hierarchy bail-out)
+  // level 0's multigrid host analysis running ahead on a helper thread (build_structure starts it, build_amg joins it)
+  AmgHostL0* l0_pre = nullptr;
+  std::thread l0_thread;
+  std::vector<double> l0_w;
   int amg_best = 0;               // fewest PCG iterations seen with the current hierarchy (0: none yet);
                                   // kept across optimize() calls so that a hierarchy adapted to other poses is noticed
   PcgScalars* h_S2 = nullptr;     // pinned [2]: pipelined read-back of the stop flag
@@ -205,7 +209,19 @@ int upload(sgo_ctx* c, T** p, const HostBuf<T>& v) {
   return SGO_OK;
 }
 
+// Joins the helper thread of the level-0 analysis; `keep`: leave its result for build_amg, otherwise drop it.
+void l0_join(sgo_ctx* c, bool keep) {
+  if (c->l0_thread.joinable()) c->l0_thread.join();
+  if (!keep && c->l0_pre) {
+    amg_host_l0_free(c->l0_pre);
+    c->l0_pre = nullptr;
+  }
+  if (!keep) c->l0_w = std::vector<double>();
+}
+void l0_discard(sgo_ctx* c) { l0_join(c, false); }
+
 void free_graph(sgo_ctx* c) {
+  l0_discard(c);
   if (c->pcg_exec) {
     hipGraphExecDestroy(c->pcg_exec);
     c->pcg_exec = nullptr;
@@ -374,8 +390,9 @@ struct RowPlan {
   bool tiles_ok = true;
 };
 
-int plan_rows(int V, const double* poses, const uint8_t* fixed, int E, const int32_t* ei, const int32_t* ej, int tile_div,
-              std::string* err, RowPlan& P) {
+// Row plan, first half: hessian order, internal (Hilbert) row order, compact slots per row.
+int plan_rows_order(int V, const double* poses, const uint8_t* fixed, int E, const int32_t* ei, const int32_t* ej,
+                    std::string* err, RowPlan& P) {
   const bool verbose = std::getenv("SGO_VERBOSE") != nullptr && (E > 200000 || std::atoi(std::getenv("SGO_VERBOSE")) > 1);
   double tl = wall_s();
   auto lap = [&](const char* what) {
@@ -466,8 +483,21 @@ int plan_rows(int V, const double* poses, const uint8_t* fixed, int E, const int
       }
     }
   }
-  const std::vector<int>& col = P.col;
   lap("slot positions");
+  return SGO_OK;
+}
+
+// Row plan, second half: the tiles of the level-0 product kernel.
+void plan_rows_tiles(int tile_div, RowPlan& P) {
+  const bool verbose = std::getenv("SGO_VERBOSE") != nullptr && (P.ns > 400000 || std::atoi(std::getenv("SGO_VERBOSE")) > 1);
+  double tl = wall_s();
+  auto lap = [&](const char* what) {
+    const double t = wall_s();
+    if (verbose) std::fprintf(stderr, "[sgo]   plan %-18s %.1f ms\n", what, 1e3 * (t - tl));
+    tl = t;
+  };
+  const int n = P.n, ns = P.ns;
+  const std::vector<int>&rowptr = P.rowptr, &col = P.col;
   // ---- tiles (Tile0Dev): consecutive rows, cut so that the blocks are spread evenly over ~2 tiles per CU
   // and a tile's LDS -- operand slice + halo, owned sums, one staging slot per intra-tile transposed slot --
   // fits kTileLdsMax.  A pair inside a tile stores its block with the lower row only (the other row's slot
@@ -599,6 +629,13 @@ int plan_rows(int V, const double* poses, const uint8_t* fixed, int E, const int
     tiles.clear();
     for (int r = 0; r < n; ++r) tile_of_row[r] = 0;
   }
+}
+
+int plan_rows(int V, const double* poses, const uint8_t* fixed, int E, const int32_t* ei, const int32_t* ej, int tile_div,
+              std::string* err, RowPlan& P) {
+  const int rc = plan_rows_order(V, poses, fixed, E, ei, ej, err, P);
+  if (rc != SGO_OK) return rc;
+  plan_rows_tiles(tile_div, P);
   return SGO_OK;
 }
 
@@ -655,10 +692,11 @@ int build_edges(sgo_ctx* c, int V, const double* poses, const uint8_t* fixed, in
 int build_structure(sgo_ctx* c, int V, const double* poses, const uint8_t* fixed, int E, const int32_t* ei,
                     const int32_t* ej) {
   const double tb0 = wall_s();
+  l0_discard(c);   // a helper thread of an earlier set-up that was never consumed
   RowPlan P;
   const int tile_div = c->cu_count > 0 ? c->cu_count : 256;   // one tile per CU: the larger the tiles, the fewer pairs straddle two of them
   {
-    const int prc = plan_rows(V, poses, fixed, E, ei, ej, tile_div, &c->err, P);
+    const int prc = plan_rows_order(V, poses, fixed, E, ei, ej, &c->err, P);
     if (prc != SGO_OK) return prc;
   }
   const bool verbose = c->opts.verbose && (E > 200000 || c->opts.verbose > 1);
@@ -675,8 +713,6 @@ int build_structure(sgo_ctx* c, int V, const double* poses, const uint8_t* fixed
   std::vector<TileDesc>& tiles = P.tiles;
   std::vector<int>& tile_of_row = P.tile_of_row;
   std::vector<int> hcol;
-  const int tile_lds = P.tile_lds;
-  bool tiles_ok = P.tiles_ok;
   HostArena& ar = c->stage;
   try {
     ar.reserve((size_t)ns * (3 * sizeof(int) + 4 + sizeof(unsigned int)) + 64 * 64);
@@ -707,6 +743,75 @@ int build_structure(sgo_ctx* c, int V, const double* poses, const uint8_t* fixed
     }
   });
   lap("edge operands");
+  // logical structure for the multigrid set-up (diagonal slot first, then the row's block slots): the pattern depends
+  // on the row plan only, not on the tiles
+  HostLevel& H = c->H0;
+  H.n = n;
+  H.visit = c->row_of_asc;   // the multigrid aggregation walks level 0 along the trajectory (ascending vertex id)
+  H.rowptr.assign((size_t)n + 1, 0);
+  for (int r = 0; r < n; ++r) {
+    int nb = 1;
+    for (int k = rowptr[r]; k < rowptr[r + 1]; ++k) nb += col[k] >= 0;
+    H.rowptr[r + 1] = H.rowptr[r] + nb;
+  }
+  H.nslot = H.rowptr[n];
+  H.row.resize(H.nslot);
+  H.col.resize(H.nslot);
+  parallel_for(n, [&](int r0, int r1) {
+    for (int r = r0; r < r1; ++r) {
+      int q = H.rowptr[r];
+      H.row[q] = r;
+      H.col[q] = r;
+      ++q;
+      for (int k = rowptr[r]; k < rowptr[r + 1]; ++k) {
+        if (col[k] < 0) {
+          flags[k] |= (unsigned char)kSlotFixedCol;
+          continue;
+        }
+        H.row[q] = r;
+        H.col[q] = col[k];
+        ++q;
+      }
+    }
+  });
+  lap("logical pattern");
+  int rc;
+  // per-slot edge index / side flags and the operand arrays of k_linearize (expanded on the device further down)
+  int* d_eidx = nullptr;
+  if ((rc = upload(c, &d_eidx, eidx))) return rc;
+  if ((rc = upload(c, &c->es.flags, flags))) return rc;
+  if ((rc = dalloc(c, &c->es.vi, (size_t)ns)) || (rc = dalloc(c, &c->es.vj, (size_t)ns)) || (rc = dalloc(c, &c->es.zinv, 3 * (size_t)ns)) ||
+      (rc = dalloc(c, &c->es.info, 6 * (size_t)ns)) || (rc = dalloc(c, &c->es.phi, (size_t)ns)))
+    return rc;
+  // Large graphs: the multigrid's host analysis of level 0 (greedy aggregation + patterns / product lists of the
+  // smoothed transfer: C4 11 + 17 ms, the longest sequential piece of the set-up) needs the strength weights and the
+  // logical pattern only.  The weights are made right here from the edge list (k_edge_strength / k_row_strength; the
+  // not yet expanded operand arrays serve as scratch), and a helper thread does the analysis while this one cuts the
+  // tiles, types the slots and uploads the level-0 storage; build_amg joins it.
+  {
+    bool pipeline = c->opts.solver == SGO_SOLVER_PCG_AMG && n >= 20000 && E > 0;
+    if (const char* e = std::getenv("SGO_SETUP_PIPELINE")) pipeline = pipeline && std::atoi(e) != 0;
+    if (pipeline) {
+      int *d_rowptr = nullptr, *d_hrowptr = nullptr;
+      if ((rc = upload(c, &d_rowptr, rowptr)) || (rc = upload(c, &d_hrowptr, H.rowptr))) return rc;
+      double *d_dcon = c->es.info, *d_wblk = c->es.phi, *d_w = c->es.zinv;   // 12 E = 6 ns, E <= ns, nslot <= n + ns <= 3 ns
+      launch_early_strength(c->stream, c->el, c->d_poses, n, d_rowptr, d_eidx, c->es.flags, d_hrowptr, d_wblk, d_dcon, d_w);
+      c->l0_w.resize((size_t)H.nslot);
+      HIP_TRY(c, hipMemcpyAsync(c->l0_w.data(), d_w, sizeof(double) * (size_t)H.nslot, hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(c, hipStreamSynchronize(c->stream));
+      c->l0_pre = amg_host_l0_new();
+      AmgHostL0* pre = c->l0_pre;
+      const HostLevel* Hp = &c->H0;
+      const std::vector<double>* wp = &c->l0_w;
+      ChunkArena* scr = &c->amg_scratch;
+      c->l0_thread = std::thread([pre, Hp, wp, scr] { amg_host_l0_run(pre, *Hp, *wp, AmgConfig(), scr); });
+      lap("early strengths");
+    }
+  }
+  plan_rows_tiles(tile_div, P);
+  const int tile_lds = P.tile_lds;
+  bool tiles_ok = P.tiles_ok;
+  tl = wall_s();
   // slot types
   parallel_for(n, [&](int r0, int r1) {
     for (int r = r0; r < r1; ++r)
@@ -785,31 +890,15 @@ int build_structure(sgo_ctx* c, int V, const double* poses, const uint8_t* fixed
     }
   });
   lap("groups tref meta");
-  // logical structure for the multigrid set-up (diagonal slot first, then the row's block slots)
-  HostLevel& H = c->H0;
-  H.n = n;
-  H.visit = c->row_of_asc;   // the multigrid aggregation walks level 0 along the trajectory (ascending vertex id)
-  H.rowptr.assign((size_t)n + 1, 0);
-  for (int r = 0; r < n; ++r) {
-    int nb = 1;
-    for (int k = rowptr[r]; k < rowptr[r + 1]; ++k) nb += type[k] != kSlotNoBlock;
-    H.rowptr[r + 1] = H.rowptr[r] + nb;
-  }
-  H.nslot = H.rowptr[n];
-  H.row.resize(H.nslot);
-  H.col.resize(H.nslot);
+  // where the logical slots' blocks live in the symmetric storage (diagonal / stored block / stored block transposed)
   std::vector<int> lref(H.nslot);
   parallel_for(n, [&](int r0, int r1) {
     for (int r = r0; r < r1; ++r) {
       int q = H.rowptr[r];
-      H.row[q] = r;
-      H.col[q] = r;
       lref[q] = ~r;
       ++q;
       for (int k = rowptr[r]; k < rowptr[r + 1]; ++k) {
         if (type[k] == kSlotNoBlock) continue;
-        H.row[q] = r;
-        H.col[q] = col[k];
         lref[q] = type[k] == kSlotOwned ? (own[k] << 1) : ((tref[tslot[k]] << 1) | 1);
         ++q;
       }
@@ -923,7 +1012,6 @@ int build_structure(sgo_ctx* c, int V, const double* poses, const uint8_t* fixed
 
   lap("tile arrays");
   const double tb1 = wall_s();
-  int rc;
   Sym0Dev& S = c->S0;
   S.n = n;
   S.nu = nu;
@@ -996,12 +1084,6 @@ int build_structure(sgo_ctx* c, int V, const double* poses, const uint8_t* fixed
   // edge arrays in caller order: indices / kernel parameter straight from the caller's buffers; the inverse
   // measurements and the SoA information are made on the device from the raw rows, and the per-slot operand
   // arrays of k_linearize are expanded there too
-  int* d_eidx = nullptr;
-  if ((rc = upload(c, &d_eidx, eidx))) return rc;
-  if ((rc = upload(c, &c->es.flags, flags))) return rc;
-  if ((rc = dalloc(c, &c->es.vi, (size_t)ns)) || (rc = dalloc(c, &c->es.vj, (size_t)ns)) || (rc = dalloc(c, &c->es.zinv, 3 * (size_t)ns)) ||
-      (rc = dalloc(c, &c->es.info, 6 * (size_t)ns)) || (rc = dalloc(c, &c->es.phi, (size_t)ns)))
-    return rc;
   if (E > 0 && ns > 0) launch_slot_expand(c->stream, ns, d_eidx, c->el, c->es);
   if ((rc = upload(c, &c->d_free_id, row_vertex))) return rc;
   const size_t n3 = 3 * (size_t)n;
@@ -1303,8 +1385,10 @@ int build_amg(sgo_ctx* c) {
     cc->amg_scope = nullptr;
   };
   std::string aerr;
+  l0_join(c, true);   // the helper thread's analysis of level 0, when set_graph started one (first build only)
   c->amg = amg_create(c->stream, c->A, c->S0, c->T0, c->H0, c->d_poses, c->d_free_id, cfg, prof, &aerr, &c->amg_scratch,
-                      &c->amg_arena);
+                      &c->amg_arena, c->l0_pre);
+  l0_discard(c);
   if (c->amg) {
     if (c->comm.nranks > 1 || c->comm.active()) amg_set_shard(c->amg, &c->comm, c->shard_u0, c->shard_u1, c->shard_row0, c->shard_row1);
     amg_describe(c->amg, &c->solver_desc);

@@ -148,7 +148,7 @@ struct Tile0Dev {
 // Edge operands aligned with the level-0 compact slots (SoA over slots).  For a slot of row r that
 // came from edge e = (i, j):  dir = 0 when r is the i side (row Jacobian A), 1 when r is the j side
 // (row Jacobian B).
-enum : int { kSlotDir = 1, kSlotNoEdge = 2 };
+enum : int { kSlotDir = 1, kSlotNoEdge = 2, kSlotFixedCol = 4 };   // FixedCol: the edge's other endpoint is fixed (no block)
 struct EdgeSlotsDev {
   int* vi = nullptr;      // vertex id of EdgeSE2::vertices()[0]
   int* vj = nullptr;      // vertex id of EdgeSE2::vertices()[1]
@@ -507,6 +507,9 @@ void launch_chi2(hipStream_t s, const EdgeListDev& el, int e0, int e1, const dou
 void launch_reduce2(hipStream_t s, const double* partials, int nparts, double* out2);
 void launch_edge_prepare(hipStream_t s, int E, const double* meas, const double* info, double* zinv, double* info_soa);
 void launch_slot_expand(hipStream_t s, int ncs, const int* eidx, const EdgeListDev& el, const EdgeSlotsDev& es);
+// strength weights of the logical slots (hrowptr: logical row pointers) straight from the edge list (sgo_kernels.hip)
+void launch_early_strength(hipStream_t s, const EdgeListDev& el, const double* poses, int n, const int* rowptr, const int* eidx,
+                           const unsigned char* flags, const int* hrowptr, double* wblk, double* dcon, double* w);
 void launch_linearize(hipStream_t s, const Sym0Dev& A, int g0, int g1, const EdgeSlotsDev& es, const double* poses,
                       double* dgb /*[n][9]*/);
 void launch_finalize(hipStream_t s, const Sym0Dev& A, const double* dgb, double* b, double* x, double* r, double* z,
