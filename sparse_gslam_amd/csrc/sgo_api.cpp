@@ -785,8 +785,8 @@ int build_structure(sgo_ctx* c, int V, const double* poses, const uint8_t* fixed
     return rc;
   // Large graphs: the multigrid's host analysis of level 0 (greedy aggregation + patterns / product lists of the
   // smoothed transfer: C4 11 + 17 ms, the longest sequential piece of the set-up) needs the strength weights and the
-  // logical pattern only.  The weights are made right here from the edge list (k_edge_strength / k_row_strength; the
-  // not yet expanded operand arrays serve as scratch), and a helper thread does the analysis while this one cuts the
+  // logical pattern only.  The weights are made right here from the edge list (k_row_strength; a not yet expanded
+  // operand array serves as scratch), and a helper thread does the analysis while this one cuts the
   // tiles, types the slots and uploads the level-0 storage; build_amg joins it.
   {
     bool pipeline = c->opts.solver == SGO_SOLVER_PCG_AMG && n >= 20000 && E > 0;
@@ -794,8 +794,8 @@ int build_structure(sgo_ctx* c, int V, const double* poses, const uint8_t* fixed
     if (pipeline) {
       int *d_rowptr = nullptr, *d_hrowptr = nullptr;
       if ((rc = upload(c, &d_rowptr, rowptr)) || (rc = upload(c, &d_hrowptr, H.rowptr))) return rc;
-      double *d_dcon = c->es.info, *d_wblk = c->es.phi, *d_w = c->es.zinv;   // 12 E = 6 ns, E <= ns, nslot <= n + ns <= 3 ns
-      launch_early_strength(c->stream, c->el, c->d_poses, n, d_rowptr, d_eidx, c->es.flags, d_hrowptr, d_wblk, d_dcon, d_w);
+      double* d_w = c->es.info;   // scratch: nslot <= n + ns <= 2 ns doubles of the 6 ns the not yet expanded operand array holds
+      launch_early_strength(c->stream, c->el, c->d_poses, n, d_rowptr, d_eidx, c->es.flags, d_hrowptr, d_w);
       c->l0_w.resize((size_t)H.nslot);
       HIP_TRY(c, hipMemcpyAsync(c->l0_w.data(), d_w, sizeof(double) * (size_t)H.nslot, hipMemcpyDeviceToHost, c->stream));
       HIP_TRY(c, hipStreamSynchronize(c->stream));

@@ -509,7 +509,7 @@ void launch_edge_prepare(hipStream_t s, int E, const double* meas, const double*
 void launch_slot_expand(hipStream_t s, int ncs, const int* eidx, const EdgeListDev& el, const EdgeSlotsDev& es);
 // strength weights of the logical slots (hrowptr: logical row pointers) straight from the edge list (sgo_kernels.hip)
 void launch_early_strength(hipStream_t s, const EdgeListDev& el, const double* poses, int n, const int* rowptr, const int* eidx,
-                           const unsigned char* flags, const int* hrowptr, double* wblk, double* dcon, double* w);
+                           const unsigned char* flags, const int* hrowptr, double* w);
 void launch_linearize(hipStream_t s, const Sym0Dev& A, int g0, int g1, const EdgeSlotsDev& es, const double* poses,
                       double* dgb /*[n][9]*/);
 void launch_finalize(hipStream_t s, const Sym0Dev& A, const double* dgb, double* b, double* x, double* r, double* z,

@@ -118,85 +118,74 @@ __global__ __launch_bounds__(kBlock) void k_slot_expand(int ncs, const int* __re
 
 // ---------------------------------------------------------------------------- early strength weights
 // The multigrid aggregation needs the Frobenius norms of the Hessian blocks at the initial poses and nothing else of
-// the matrix.  These two kernels produce them straight from the edge list and the per-row slot lists -- before the
-// level-0 storage (tiles, slot types) exists -- so that the host's aggregation and symbolic phase can run on a helper
-// thread while the storage is still being laid out (sgo_api.cpp, build_structure).
-// k_edge_strength: per edge, norm of the off-diagonal block A^T Ow B and the two diagonal contributions A^T Ow A,
-// B^T Ow B (6 unique entries each), same arithmetic as k_linearize.
-__global__ __launch_bounds__(kBlock) void k_edge_strength(EdgeListDev el, const double* __restrict__ poses,
-                                                          double* __restrict__ wblk, double* __restrict__ dcon) {
-  const size_t E = (size_t)el.E;
-  for (int e = blockIdx.x * kBlock + threadIdx.x; e < el.E; e += gridDim.x * kBlock) {
-    const int vi = el.vi[e], vj = el.vj[e];
-    const double xi = poses[3 * (size_t)vi], yi = poses[3 * (size_t)vi + 1], ti = poses[3 * (size_t)vi + 2];
-    const double xj = poses[3 * (size_t)vj], yj = poses[3 * (size_t)vj + 1], tj = poses[3 * (size_t)vj + 2];
-    const double zx = el.zinv[e], zy = el.zinv[E + e], zt = el.zinv[2 * E + e];
-    double sz, cz;
-    sincos(zt, &sz, &cz);
-    double er[3];
-    edge_error(xi, yi, ti, xj, yj, tj, zx, zy, zt, sz, cz, er);
-    double O[3][3];
-    O[0][0] = el.info[e]; O[0][1] = O[1][0] = el.info[E + e]; O[0][2] = O[2][0] = el.info[2 * E + e];
-    O[1][1] = el.info[3 * E + e]; O[1][2] = O[2][1] = el.info[4 * E + e]; O[2][2] = el.info[5 * E + e];
-    double e2 = 0.0;
-#pragma unroll
-    for (int a = 0; a < 3; ++a)
-#pragma unroll
-      for (int b = 0; b < 3; ++b) e2 += er[a] * O[a][b] * er[b];
-    double r0_, w;
-    dcs(e2, el.phi[e], &r0_, &w);
-    double si, ci;
-    sincos(ti, &si, &ci);
-    const double ddx = xj - xi, ddy = yj - yi;
-    const double a02 = -si * ddx + ci * ddy, a12 = -ci * ddx - si * ddy;
-    double A[3][3], B[3][3];
-    A[0][0] = cz * (-ci) - sz * si; A[0][1] = cz * (-si) - sz * (-ci); A[0][2] = cz * a02 - sz * a12;
-    A[1][0] = sz * (-ci) + cz * si; A[1][1] = sz * (-si) + cz * (-ci); A[1][2] = sz * a02 + cz * a12;
-    A[2][0] = 0.0; A[2][1] = 0.0; A[2][2] = -1.0;
-    B[0][0] = cz * ci - sz * (-si); B[0][1] = cz * si - sz * ci; B[0][2] = 0.0;
-    B[1][0] = sz * ci + cz * (-si); B[1][1] = sz * si + cz * ci; B[1][2] = 0.0;
-    B[2][0] = 0.0; B[2][1] = 0.0; B[2][2] = 1.0;
-    double TA[3][3], TB[3][3];   // Ow A, Ow B
-#pragma unroll
-    for (int a = 0; a < 3; ++a)
-#pragma unroll
-      for (int b = 0; b < 3; ++b) {
-        TA[a][b] = w * (O[a][0] * A[0][b] + O[a][1] * A[1][b] + O[a][2] * A[2][b]);
-        TB[a][b] = w * (O[a][0] * B[0][b] + O[a][1] * B[1][b] + O[a][2] * B[2][b]);
-      }
-    double off = 0.0;
-    double* d = dcon + 12 * (size_t)e;
-    int q = 0;
-#pragma unroll
-    for (int a = 0; a < 3; ++a)
-#pragma unroll
-      for (int b = 0; b < 3; ++b) {
-        const double ab = A[0][a] * TB[0][b] + A[1][a] * TB[1][b] + A[2][a] * TB[2][b];
-        off += ab * ab;
-        if (b >= a) {
-          d[q] = A[0][a] * TA[0][b] + A[1][a] * TA[1][b] + A[2][a] * TA[2][b];
-          d[6 + q] = B[0][a] * TB[0][b] + B[1][a] * TB[1][b] + B[2][a] * TB[2][b];
-          ++q;
-        }
-      }
-    wblk[e] = sqrt(off);
-  }
-}
-// k_row_strength: one thread per row walks the row's compact slots (edge, side): w of the logical slots of the row --
-// the diagonal slot first (norm of the summed diagonal contributions), then one per slot whose column is free.
+// the matrix.  This kernel produces them straight from the edge list and the per-row slot lists -- before the level-0
+// storage (tiles, slot types) exists -- so that the host's aggregation and symbolic phase can run on a helper thread
+// while the storage is still being laid out (sgo_api.cpp, build_structure).  One thread per row walks the row's
+// compact slots (edge, side) and evaluates each edge as k_linearize does: w of the row's logical slots -- the diagonal
+// slot first (norm of the summed R^T Ow R), then ||R^T Ow C||_F for every slot whose column is free.
 __global__ __launch_bounds__(kBlock) void k_row_strength(int n, const int* __restrict__ rowptr, const int* __restrict__ eidx,
                                                          const unsigned char* __restrict__ flags, const int* __restrict__ hrowptr,
-                                                         const double* __restrict__ wblk, const double* __restrict__ dcon,
-                                                         double* __restrict__ w) {
+                                                         EdgeListDev el, const double* __restrict__ poses, double* __restrict__ w) {
+  const size_t E = (size_t)el.E;
   for (int r = blockIdx.x * kBlock + threadIdx.x; r < n; r += gridDim.x * kBlock) {
     double d[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     int q = hrowptr[r] + 1;
     for (int k = rowptr[r]; k < rowptr[r + 1]; ++k) {
       const int e = eidx[k], fl = flags[k];
-      const double* c = dcon + 12 * (size_t)e + ((fl & kSlotDir) ? 6 : 0);
+      const int vi = el.vi[e], vj = el.vj[e];
+      const double xi = poses[3 * (size_t)vi], yi = poses[3 * (size_t)vi + 1], ti = poses[3 * (size_t)vi + 2];
+      const double xj = poses[3 * (size_t)vj], yj = poses[3 * (size_t)vj + 1], tj = poses[3 * (size_t)vj + 2];
+      const double zx = el.zinv[e], zy = el.zinv[E + e], zt = el.zinv[2 * E + e];
+      double sz, cz;
+      sincos(zt, &sz, &cz);
+      double er[3];
+      edge_error(xi, yi, ti, xj, yj, tj, zx, zy, zt, sz, cz, er);
+      double O[3][3];
+      O[0][0] = el.info[e]; O[0][1] = O[1][0] = el.info[E + e]; O[0][2] = O[2][0] = el.info[2 * E + e];
+      O[1][1] = el.info[3 * E + e]; O[1][2] = O[2][1] = el.info[4 * E + e]; O[2][2] = el.info[5 * E + e];
+      double e2 = 0.0;
 #pragma unroll
-      for (int t = 0; t < 6; ++t) d[t] += c[t];
-      if (!(fl & kSlotFixedCol)) w[q++] = wblk[e];
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) e2 += er[a] * O[a][b] * er[b];
+      double r0_, wt;
+      dcs(e2, el.phi[e], &r0_, &wt);
+      double si, ci;
+      sincos(ti, &si, &ci);
+      const double ddx = xj - xi, ddy = yj - yi;
+      const double a02 = -si * ddx + ci * ddy, a12 = -ci * ddx - si * ddy;
+      double A[3][3], B[3][3];
+      A[0][0] = cz * (-ci) - sz * si; A[0][1] = cz * (-si) - sz * (-ci); A[0][2] = cz * a02 - sz * a12;
+      A[1][0] = sz * (-ci) + cz * si; A[1][1] = sz * (-si) + cz * (-ci); A[1][2] = sz * a02 + cz * a12;
+      A[2][0] = 0.0; A[2][1] = 0.0; A[2][2] = -1.0;
+      B[0][0] = cz * ci - sz * (-si); B[0][1] = cz * si - sz * ci; B[0][2] = 0.0;
+      B[1][0] = sz * ci + cz * (-si); B[1][1] = sz * si + cz * ci; B[1][2] = 0.0;
+      B[2][0] = 0.0; B[2][1] = 0.0; B[2][2] = 1.0;
+      const bool dir = fl & kSlotDir;   // the row's Jacobian is B
+      double T[3][3];                   // Ow R
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+          const double r0b = dir ? B[0][b] : A[0][b], r1b = dir ? B[1][b] : A[1][b], r2b = dir ? B[2][b] : A[2][b];
+          T[a][b] = wt * (O[a][0] * r0b + O[a][1] * r1b + O[a][2] * r2b);
+        }
+      double off = 0.0;
+      int t = 0;
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+          // (R^T Ow C)[b][a] = sum_m T[m][b] C[m][a]  (T^T C: Ow is symmetric)
+          const double c0 = dir ? A[0][a] : B[0][a], c1 = dir ? A[1][a] : B[1][a], c2 = dir ? A[2][a] : B[2][a];
+          const double oc = T[0][b] * c0 + T[1][b] * c1 + T[2][b] * c2;
+          off += oc * oc;
+          if (b >= a) {
+            const double ra0 = dir ? B[0][a] : A[0][a], ra1 = dir ? B[1][a] : A[1][a], ra2 = dir ? B[2][a] : A[2][a];
+            d[t++] += ra0 * T[0][b] + ra1 * T[1][b] + ra2 * T[2][b];
+          }
+        }
+      if (!(fl & kSlotFixedCol)) w[q++] = sqrt(off);
     }
     w[hrowptr[r]] = sqrt(d[0] * d[0] + d[3] * d[3] + d[5] * d[5] + 2.0 * (d[1] * d[1] + d[2] * d[2] + d[4] * d[4]));
   }
@@ -1023,9 +1012,8 @@ void launch_edge_prepare(hipStream_t s, int E, const double* meas, const double*
   SGO_LAUNCH(k_edge_prepare, dim3(grid_for(E, kBlock)), dim3(kBlock), 0, s, E, meas, info, zinv, info_soa);
 }
 void launch_early_strength(hipStream_t s, const EdgeListDev& el, const double* poses, int n, const int* rowptr, const int* eidx,
-                           const unsigned char* flags, const int* hrowptr, double* wblk, double* dcon, double* w) {
-  if (el.E > 0) SGO_LAUNCH(k_edge_strength, dim3(grid_for(el.E, kBlock)), dim3(kBlock), 0, s, el, poses, wblk, dcon);
-  if (n > 0) SGO_LAUNCH(k_row_strength, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, s, n, rowptr, eidx, flags, hrowptr, (const double*)wblk, (const double*)dcon, w);
+                           const unsigned char* flags, const int* hrowptr, double* w) {
+  if (n > 0) SGO_LAUNCH(k_row_strength, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, s, n, rowptr, eidx, flags, hrowptr, el, poses, w);
 }
 void launch_slot_expand(hipStream_t s, int ncs, const int* eidx, const EdgeListDev& el, const EdgeSlotsDev& es) {
   SGO_LAUNCH(k_slot_expand, dim3(grid_for(ncs, kBlock)), dim3(kBlock), 0, s, ncs, eidx, el, es);
