@@ -714,9 +714,21 @@ int aggregate(const HostLevel& L, const std::vector<double>& w, double theta, st
     }
   });
   auto strong = [&](int, int k) { return sflag[k] != 0; };
+  // the visiting order (along the trajectory) jumps through the rows (numbered along the Hilbert curve): the next rows'
+  // slot lists are requested a few visits ahead
+  auto ahead = [&](int t) {
+    if (t + 8 < n) __builtin_prefetch(&L.rowptr[visit ? visit[t + 8] : t + 8]);
+    if (t + 4 < n) {
+      const int kp = L.rowptr[visit ? visit[t + 4] : t + 4];
+      __builtin_prefetch(&L.col[kp]);
+      __builtin_prefetch(&L.col[kp] + 16);
+      __builtin_prefetch(&sflag[kp]);
+    }
+  };
   int nc = 0;
   // pass 1: a node all of whose strong neighbours are free roots a new aggregate
   for (int t = 0; t < n; ++t) {
+    ahead(t);
     const int i = visit ? visit[t] : t;
     if (agg[i] >= 0) continue;
     bool any = false, ok = true;
@@ -734,6 +746,7 @@ int aggregate(const HostLevel& L, const std::vector<double>& w, double theta, st
   // pass 2: leftovers join the aggregate of their strongest aggregated strong neighbour
   std::vector<int> agg1(agg);
   for (int t = 0; t < n; ++t) {
+    ahead(t);
     const int i = visit ? visit[t] : t;
     if (agg1[i] >= 0) continue;
     double best = -1.0;

@@ -588,28 +588,39 @@ void plan_rows_tiles(int tile_div, RowPlan& P) {
       }
       for (size_t t = 0; t < tiles.size(); ++t)
         for (int q = tiles[t].row0; q < tiles[t].row1; ++q) tile_of_row[q] = (int)t;
-      // exact LDS need per tile: rows + halo columns + rows + staged entries, 24 B each
+      // exact LDS need per tile: rows + halo columns + rows + staged entries, 24 B each (tiles in parallel on the host
+      // pool, every worker with its own column marks)
       bool fits = !too_many;   // more tiles than CUs because the LDS closed tiles early: the slot-balanced cut is better
-      for (size_t t = 0; t < tiles.size() && fits; ++t) {
-        const TileDesc& T = tiles[t];
-        long long halo = 0, staged = 0;
-        for (int k = rowptr[T.row0]; k < rowptr[T.row1]; ++k) {
-          const int cc = col[k];
-          if (cc < 0) continue;
-          if (cc >= T.row0 && cc < T.row1) {
-            staged += 1;   // each intra-tile pair has two slots, one of them staged: count halves below
-          } else if (mark[cc] != (int)t) {
-            mark[cc] = (int)t;
-            ++halo;
+      if (fits) {
+        const int ntl = (int)tiles.size();
+        std::vector<long long> need_t((size_t)ntl, 0);
+        std::vector<unsigned char> bad_t((size_t)ntl, 0);
+        host_parallel_for(ntl, 8, [&](int t0, int t1, int) {
+          std::vector<int> mk(std::max(n, 1), -1);
+          for (int t = t0; t < t1; ++t) {
+            const TileDesc& T = tiles[t];
+            long long halo = 0, staged = 0;
+            for (int k = rowptr[T.row0]; k < rowptr[T.row1]; ++k) {
+              const int cc = col[k];
+              if (cc < 0) continue;
+              if (cc >= T.row0 && cc < T.row1) {
+                staged += 1;   // each intra-tile pair has two slots, one of them staged: count halves below
+              } else if (mk[cc] != t) {
+                mk[cc] = t;
+                ++halo;
+              }
+            }
+            staged /= 2;
+            const long long rows = T.row1 - T.row0;
+            need_t[t] = 24 * (2 * rows + halo + staged);
+            bad_t[t] = need_t[t] > lds_budget || rows + halo > 65000 || staged > 65000;
           }
+        });
+        for (int t = 0; t < ntl; ++t) {
+          if (bad_t[t]) fits = false;
+          lds = std::max(lds, need_t[t]);
         }
-        staged /= 2;
-        const long long rows = T.row1 - T.row0;
-        const long long need = 24 * (2 * rows + halo + staged);
-        if (need > lds_budget || rows + halo > 65000 || staged > 65000) fits = false;
-        lds = std::max(lds, need);
       }
-      std::fill(mark.begin(), mark.end(), -1);
       P.tile_lds = (int)lds;
       if (fits) break;
       if (attempt >= 1) {
@@ -829,11 +840,39 @@ int build_structure(sgo_ctx* c, int V, const double* poses, const uint8_t* fixed
   // tslot[k]: rank among the transposed slots
   std::vector<int> tslot((size_t)ns + 1);
   int nu = 0, ntr = 0;
-  for (int k = 0; k < ns; ++k) {
-    own[k] = nu;
-    tslot[k] = ntr;
-    nu += type[k] == kSlotOwned;
-    ntr += type[k] == kSlotTransposed;
+  {
+    // exclusive prefix counts in two passes over fixed chunks (counts per chunk, then the ranks inside each chunk)
+    const int nchunk = std::max(1, std::min(256, ns / 8192));
+    std::vector<int> cu((size_t)nchunk + 1, 0), ct((size_t)nchunk + 1, 0);
+    auto chunk_lo = [&](int q) { return (int)((long long)ns * q / nchunk); };
+    host_parallel_for(nchunk, 1, [&](int q0, int q1, int) {
+      for (int q = q0; q < q1; ++q) {
+        int a = 0, b = 0;
+        for (int k = chunk_lo(q); k < chunk_lo(q + 1); ++k) {
+          a += type[k] == kSlotOwned;
+          b += type[k] == kSlotTransposed;
+        }
+        cu[q + 1] = a;
+        ct[q + 1] = b;
+      }
+    });
+    for (int q = 0; q < nchunk; ++q) {
+      cu[q + 1] += cu[q];
+      ct[q + 1] += ct[q];
+    }
+    host_parallel_for(nchunk, 1, [&](int q0, int q1, int) {
+      for (int q = q0; q < q1; ++q) {
+        int a = cu[q], b = ct[q];
+        for (int k = chunk_lo(q); k < chunk_lo(q + 1); ++k) {
+          own[k] = a;
+          tslot[k] = b;
+          a += type[k] == kSlotOwned;
+          b += type[k] == kSlotTransposed;
+        }
+      }
+    });
+    nu = cu[nchunk];
+    ntr = ct[nchunk];
   }
   own[ns] = nu;
   tslot[ns] = ntr;
