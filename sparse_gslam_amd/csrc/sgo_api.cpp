@@ -815,7 +815,10 @@ int build_structure(sgo_ctx* c, int V, const double* poses, const uint8_t* fixed
       const HostLevel* Hp = &c->H0;
       const std::vector<double>* wp = &c->l0_w;
       ChunkArena* scr = &c->amg_scratch;
-      c->l0_thread = std::thread([pre, Hp, wp, scr] { amg_host_l0_run(pre, *Hp, *wp, AmgConfig(), scr); });
+      c->l0_thread = std::thread([pre, Hp, wp, scr] {
+        HostPool::lane() = 1;   // its own worker pool: runs beside this thread's regions instead of queueing with them
+        amg_host_l0_run(pre, *Hp, *wp, AmgConfig(), scr);
+      });
       lap("early strengths");
     }
   }

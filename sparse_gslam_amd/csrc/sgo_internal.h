@@ -385,9 +385,16 @@ struct DevArena {
 // 100-ms set-up.  One region at a time (contexts on different threads queue on the pool's mutex).
 class HostPool {
  public:
+  // Two pools: lane 0 serves the calling threads, lane 1 the helper thread of the set-up pipeline (sgo_api.cpp,
+  // build_structure), whose long regions -- the multigrid's symbolic phase -- would otherwise queue behind (and hold
+  // up) the many short regions of the structure build.  host_pool_lane() selects per thread.
+  static int& lane() {
+    static thread_local int l = 0;
+    return l;
+  }
   static HostPool& get() {
-    static HostPool p;
-    return p;
+    static HostPool p0, p1;
+    return lane() ? p1 : p0;
   }
   int size() const { return nthreads_; }
   // fn(t) for t in [0, ntasks), distributed over the workers and the caller
