@@ -839,7 +839,8 @@ struct RowSorter {
 // Returns false (nothing usable in `o`) when the product lists would exceed `budget` products: graphs
 // with many long-range edges make the smoothed coarse operators nearly dense, and the caller then
 // keeps the tentative prolongator for this level.
-bool sa_symbolic(const HostLevel& H, const std::vector<int>& agg, int nc, long long budget, SaHost& o) {
+bool sa_symbolic(const HostLevel& H, const std::vector<int>& agg, int nc, const std::vector<int>& mem_ptr,
+                 const std::vector<int>& mem, long long budget, SaHost& o) {
   const int n = H.n;
   const bool verbose = std::getenv("SGO_VERBOSE") != nullptr;
   auto t0 = std::chrono::steady_clock::now();
@@ -903,27 +904,45 @@ bool sa_symbolic(const HostLevel& H, const std::vector<int>& agg, int nc, long l
   val_ptr[np] = H.nslot;
   o.val_grp = make_groups(val_ptr);
   lap("P");
-  // ---- entries by coarse column (restriction walks P^T)
-  std::vector<int> t_ptr((size_t)nc + 1, 0);
-  for (int e = 0; e < np; ++e) t_ptr[(size_t)o.p_col[e] + 1]++;
-  for (int a = 0; a < nc; ++a) t_ptr[a + 1] += t_ptr[a];
-  std::vector<int> t_idx(np);
-  o.t_pos.resize(np);
-  o.t_row.resize(np);
-  o.t_col.resize(np);
-  {
-    std::vector<int> fill(t_ptr.begin(), t_ptr.end() - 1);
-    for (int e = 0; e < np; ++e) {
-      const int t = fill[o.p_col[e]]++;
-      t_idx[t] = e;
-      o.t_pos[e] = t;
-      o.t_row[t] = o.p_row[e];
-      o.t_col[t] = o.p_col[e];
-    }
+  // ---- early verdict on the coarse operator's size from every 32nd coarse row (the exact count comes after the AP
+  // pattern and product lists, which cost several times this whole function's share so far; graphs with long-range
+  // closures fail it -- C5: 0.37 s of lists made for nothing).  Row a of P^T A P holds the columns of the AP rows of the
+  // rows with a P entry in column a, i.e. of the members of a and their neighbours.
+  if (nc >= 256 && (long long)H.nslot <= 32LL * n) {   // (denser levels: the product count below says no at once)
+    const int step = 32, nsample = (nc + step - 1) / step;
+    std::vector<long long> cnt((size_t)nsample, 0);
+    host_parallel_for(nsample, 4, [&](int s0, int s1, int) {
+      std::vector<int> mark_c((size_t)nc, -1), mark_r((size_t)n, -1);
+      for (int sidx = s0; sidx < s1; ++sidx) {
+        const int a = sidx * step;
+        long long c_a = 0;
+        auto visit_row = [&](int i) {
+          if (mark_r[i] == a) return;
+          mark_r[i] = a;
+          for (int k = H.rowptr[i]; k < H.rowptr[i + 1]; ++k) {
+            const int j = H.col[k];
+            for (int e = o.p_rowptr[j]; e < o.p_rowptr[j + 1]; ++e) {
+              const int c = o.p_col[e];
+              if (mark_c[c] != a) {
+                mark_c[c] = a;
+                ++c_a;
+              }
+            }
+          }
+        };
+        for (int t = mem_ptr[a]; t < mem_ptr[a + 1]; ++t) {
+          const int m = mem[t];
+          for (int k = H.rowptr[m]; k < H.rowptr[m + 1]; ++k) visit_row(H.col[k]);   // (the diagonal slot is m itself)
+        }
+        cnt[sidx] = c_a;
+      }
+    });
+    long long sum = 0;
+    for (long long v : cnt) sum += v;
+    const double estimate = (double)sum * nc / nsample;
+    lap("coarse size estimate");
+    if (estimate > 1.5 * std::max(H.nslot, 4096)) return false;
   }
-  o.t_grp = make_groups(t_ptr);
-  o.r_grp = make_groups(o.p_rowptr);
-  lap("P^T lists");
   // ---- AP: row i holds the union of the P rows of the columns of row i
   std::vector<int> ap_rowptr((size_t)n + 1, 0);
   std::vector<long long> app((size_t)n + 1, 0);
@@ -953,6 +972,27 @@ bool sa_symbolic(const HostLevel& H, const std::vector<int>& agg, int nc, long l
   }
   lap("AP count");
   if (app[n] > budget || ap_rowptr[n] < 0) return false;
+  // ---- entries by coarse column (restriction walks P^T)
+  std::vector<int> t_ptr((size_t)nc + 1, 0);
+  for (int e = 0; e < np; ++e) t_ptr[(size_t)o.p_col[e] + 1]++;
+  for (int a = 0; a < nc; ++a) t_ptr[a + 1] += t_ptr[a];
+  std::vector<int> t_idx(np);
+  o.t_pos.resize(np);
+  o.t_row.resize(np);
+  o.t_col.resize(np);
+  {
+    std::vector<int> fill(t_ptr.begin(), t_ptr.end() - 1);
+    for (int e = 0; e < np; ++e) {
+      const int t = fill[o.p_col[e]]++;
+      t_idx[t] = e;
+      o.t_pos[e] = t;
+      o.t_row[t] = o.p_row[e];
+      o.t_col[t] = o.p_col[e];
+    }
+  }
+  o.t_grp = make_groups(t_ptr);
+  o.r_grp = make_groups(o.p_rowptr);
+  lap("P^T lists");
   o.nap = ap_rowptr[n];
   const int nprod_ap = (int)app[n];
   std::vector<int> ap_col((size_t)o.nap), ap_ptr((size_t)o.nap + 1);
@@ -1174,7 +1214,7 @@ void host_coarsen(const HostLevel& H, const std::vector<double>& w, const AmgCon
     // 2x slower than the tentative hierarchy): this level keeps the tentative prolongator
     const long long budget = std::min<long long>(1500000000LL, std::max<long long>(16LL * H.nslot, 2000000LL));
     try {
-      smooth = sa_symbolic(H, agg, nc, budget, sa);
+      smooth = sa_symbolic(H, agg, nc, mem_ptr, mem, budget, sa);
     } catch (const std::bad_alloc&) {
       smooth = false;
     }
@@ -1183,60 +1223,76 @@ void host_coarsen(const HostLevel& H, const std::vector<double>& w, const AmgCon
     o.t_sort = ms_since(tA) - o.t_agg;
   }
   if (!smooth) {
-    // coarse slots: unique (agg[row], agg[col]); diagonal first in each row
+    // coarse slots: unique (agg[row], agg[col]); diagonal first in each row, then ascending columns; the fine slots
+    // behind each coarse slot in ascending order.  Coarse row a collects the slots of its member rows (members and
+    // slots ascending), stably sorted by the coarse column code: rows in parallel on the host pool (the two global
+    // counting sorts this replaces were 0.25 s of sequential work on C5).
     const int ns = H.nslot;
-    std::vector<uint64_t> key(ns);
-    for (int k = 0; k < ns; ++k) {
-      const uint64_t cr = (uint64_t)agg[H.row[k]], cc = (uint64_t)agg[H.col[k]];
-      const uint64_t ccs = (cc == cr) ? 0 : cc + 1;  // diagonal sorts first
-      key[k] = (cr << 32) | ccs;
+    std::vector<int> cbase((size_t)nc + 1, 0), cs_cnt((size_t)nc + 1, 0);
+    for (int a = 0; a < nc; ++a) {
+      int len = 0;
+      for (int t = mem_ptr[a]; t < mem_ptr[a + 1]; ++t) len += H.rowptr[mem[t] + 1] - H.rowptr[mem[t]];
+      cbase[a + 1] = cbase[a] + len;
     }
-    // stable order by key = two stable counting sorts (low word = column code, then high word = row):
-    // O(ns), a few ms for 2M slots where std::stable_sort with an indirect key took > 100 ms
     order.resize(ns);
-    {
-      std::vector<int> tmp(ns), cnt((size_t)nc + 2, 0);
-      for (int k = 0; k < ns; ++k) cnt[(size_t)(key[k] & 0xffffffffull) + 1]++;
-      for (size_t b = 1; b < cnt.size(); ++b) cnt[b] += cnt[b - 1];
-      for (int k = 0; k < ns; ++k) tmp[cnt[(size_t)(key[k] & 0xffffffffull)]++] = k;
-      std::fill(cnt.begin(), cnt.end(), 0);
-      for (int k = 0; k < ns; ++k) cnt[(size_t)(key[k] >> 32) + 1]++;
-      for (size_t b = 1; b < cnt.size(); ++b) cnt[b] += cnt[b - 1];
-      for (int t = 0; t < ns; ++t) {
-        const int k = tmp[t];
-        order[cnt[(size_t)(key[k] >> 32)]++] = k;
-      }
-    }
-    o.t_sort = ms_since(tA) - o.t_agg;
-    Hc.n = nc;
     tgt.resize(ns);   // contribution -> coarse slot; cptr: coarse slot -> contribution range
-    {
-      uint64_t prev = ~0ull;
-      int cs = -1;
-      for (int t = 0; t < ns; ++t) {
-        const uint64_t kk = key[order[t]];
-        if (kk != prev) {
-          ++cs;
-          prev = kk;
-          cptr.push_back(t);
-          const int cr = (int)(kk >> 32);
-          const uint64_t ccs = kk & 0xffffffffull;
-          Hc.row.push_back(cr);
-          Hc.col.push_back(ccs == 0 ? cr : (int)(ccs - 1));
+    std::vector<uint32_t> code_sorted((size_t)ns);
+    host_parallel_for(nc, 64, [&](int a0, int a1, int) {
+      std::vector<std::pair<uint32_t, int>> items;
+      for (int a = a0; a < a1; ++a) {
+        items.clear();
+        for (int t = mem_ptr[a]; t < mem_ptr[a + 1]; ++t) {
+          const int i = mem[t];
+          for (int k = H.rowptr[i]; k < H.rowptr[i + 1]; ++k) {
+            const int cc = agg[H.col[k]];
+            items.emplace_back(cc == a ? 0u : (uint32_t)cc + 1u, k);   // diagonal sorts first
+          }
         }
-        tgt[t] = cs;
+        std::stable_sort(items.begin(), items.end(), [](const std::pair<uint32_t, int>& x, const std::pair<uint32_t, int>& y) { return x.first < y.first; });
+        int distinct = 0;
+        uint32_t prev = 0xFFFFFFFFu;
+        for (size_t q = 0; q < items.size(); ++q) {
+          order[(size_t)cbase[a] + q] = items[q].second;
+          code_sorted[(size_t)cbase[a] + q] = items[q].first;
+          tgt[(size_t)cbase[a] + q] = distinct - (items[q].first == prev ? 1 : 0);   // local slot number, made global below
+          if (items[q].first != prev) {
+            prev = items[q].first;
+            ++distinct;
+          }
+        }
+        cs_cnt[a + 1] = distinct;
       }
-      cptr.push_back(ns);
+    });
+    o.t_sort = ms_since(tA) - o.t_agg;
+    for (int a = 0; a < nc; ++a) cs_cnt[a + 1] += cs_cnt[a];
+    Hc.n = nc;
+    Hc.nslot = cs_cnt[nc];
+    Hc.row.resize(Hc.nslot);
+    Hc.col.resize(Hc.nslot);
+    Hc.rowptr.assign(cs_cnt.begin(), cs_cnt.end());
+    cptr.assign((size_t)Hc.nslot + 1, 0);
+    std::atomic<bool> diag_ok{true};
+    host_parallel_for(nc, 64, [&](int a0, int a1, int) {
+      for (int a = a0; a < a1; ++a) {
+        const int s0 = cs_cnt[a];
+        for (int t = cbase[a]; t < cbase[a + 1]; ++t) {
+          const bool first = t == cbase[a] || code_sorted[t] != code_sorted[t - 1];
+          tgt[t] += s0;
+          if (first) {
+            const int cs = tgt[t];
+            cptr[cs] = t;
+            Hc.row[cs] = a;
+            Hc.col[cs] = code_sorted[t] == 0 ? a : (int)(code_sorted[t] - 1);
+          }
+        }
+        if (cbase[a + 1] == cbase[a] || code_sorted[cbase[a]] != 0) diag_ok = false;
+      }
+    });
+    cptr[Hc.nslot] = ns;
+    if (!diag_ok) {
+      o.err = "amg_create: internal error (coarse diagonal slot missing)";
+      return;
     }
-    Hc.nslot = (int)Hc.row.size();
-    Hc.rowptr.assign(nc + 1, 0);
-    for (int k = 0; k < Hc.nslot; ++k) Hc.rowptr[Hc.row[k] + 1]++;
-    for (int a = 0; a < nc; ++a) Hc.rowptr[a + 1] += Hc.rowptr[a];
-    for (int a = 0; a < nc; ++a)
-      if (Hc.col[Hc.rowptr[a]] != a) {
-        o.err = "amg_create: internal error (coarse diagonal slot missing)";
-        return;
-      }
     o.grp_g = make_groups(cptr);
   }
   o.smooth = smooth;

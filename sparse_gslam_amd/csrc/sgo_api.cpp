@@ -520,6 +520,7 @@ void plan_rows_tiles(int tile_div, RowPlan& P) {
     long long target = std::max<long long>(512, (nblk / 2 * 5 / 4 + tile_div - 1) / tile_div);   // stored blocks per tile
     long long starget = std::max<long long>(512, (nblk / 2 + tile_div - 1) / tile_div);          // pairs per tile (fallback)
     std::vector<int> mark(std::max(n, 1), -1);
+    bool lds_limited = false;
     for (int attempt = 0; attempt < 7; ++attempt) {
       long long lds = 0;
       bool too_many = false;
@@ -530,7 +531,7 @@ void plan_rows_tiles(int tile_div, RowPlan& P) {
         for (int pass = 0; pass < 4; ++pass) {
           tiles.clear();
           long long total = 0;
-          int r = 0;
+          int r = 0, by_target = 0;
           while (r < n) {
             TileDesc T{};
             T.row0 = r;
@@ -561,9 +562,18 @@ void plan_rows_tiles(int tile_div, RowPlan& P) {
             }
             T.row1 = r;
             total += blocks;
+            by_target += blocks >= target;
             tiles.push_back(T);
           }
           const int K = (int)tiles.size();
+          // Graphs whose halo fills the LDS long before a CU's share of the blocks is reached (long-range closures;
+          // C5: ~4000 tiles of ~245 rows): every tile is as large as the LDS allows -- the fewest pairs stored twice --
+          // and with many tiles per CU the uneven block counts average out over a workgroup's tiles.  No larger block
+          // target changes this cut, and the slot-balanced fallback would only find smaller tiles by repeated halving.
+          if (K >= 4 * tile_div && 8 * by_target < K) {
+            lds_limited = true;
+            break;
+          }
           too_many = K > tile_div && target > 512;
           if (target <= 512 || (K <= tile_div && K >= tile_div - tile_div / 32)) break;
           target = std::max<long long>(512, total / tile_div + (K > tile_div ? total / tile_div / 64 + 1 : 1));
