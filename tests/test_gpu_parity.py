@@ -299,6 +299,24 @@ def test_single_rank_rccl_communicator_runs_the_collective_path():
     assert max(abs(x - y) for x, y in zip(sa["pcg_iters"], sb["pcg_iters"])) <= 2
 
 
+def test_rccl_collectives_captured_into_the_hipgraph_give_the_same_iterates(monkeypatch):
+    """SGO_COMM_GRAPH=1: ncclAllReduce captured into the replayed PCG graph (1-rank communicator) -- the same kernels
+    and collectives in the same order as the plain-launch collective path: identical results."""
+    g = synth.config("C2", info_mode="full")
+    res = []
+    for flag in (None, "1"):
+        if flag:
+            monkeypatch.setenv("SGO_COMM_GRAPH", flag)
+        with capi.Optimizer(0) as o:
+            o.comm_init(1, 0, capi.comm_unique_id())
+            o.set_graph(*g.arrays())
+            d, st = o.optimize(5)
+            res.append((d, st["chi2"], st["pcg_iters"], o.get_poses()))
+    assert res[0][0] == res[1][0] == 5
+    assert res[0][1] == res[1][1] and res[0][2] == res[1][2]
+    assert np.array_equal(res[0][3], res[1][3])
+
+
 # ------------------------------------------------------------------ execution modes agree
 def test_graph_replay_plain_launches_and_profile_mode_agree_bitwise():
     """hipGraph replay, plain stream launches and the event-bracketed profile mode run the same
