@@ -162,6 +162,8 @@ struct ProdMap {
 };
 struct PDev {
   int np = 0;                // blocks of P
+  int stream_nt = 1;         // the transfer kernels read r_blk / t_blk with non-temporal loads (large levels: the stream must
+                             // not displace the level-0 matrix from the Infinity Cache); small levels (0) stay in L2 between cycles
   int* rowptr = nullptr;     // [n + 1] entries of fine row i: [rowptr[i], rowptr[i+1]), coarse cols ascending
   int* row = nullptr;        // [np]
   int* col = nullptr;        // [np]
@@ -179,6 +181,8 @@ struct PDev {
   double* t_blk = nullptr;   // pair-SoA [np]: column order, streamed by the restriction (non-temporal loads)
   int* t_grp = nullptr;      // wave groups over the positions aligned to columns
   int t_ngrp = 0;
+  int* t_long = nullptr;     // [t_nlong][2] position ranges of the columns longer than kLongColumn entries (the last level of a
+  int t_nlong = 0;           // stalled hierarchy: thousands of fine rows in two aggregates): one WORKGROUP each (k_restrict_p_long)
   int nap = 0;               // blocks of AP
   double* apblk = nullptr;   // [nap][9]
   ProdMap ap;                // a = fine slot (i, j), b = P entry (j, c), tgt = AP entry (i, c)
@@ -189,12 +193,23 @@ struct PDev {
 // block e of a pair-SoA array (blk_at) that is read once per cycle: four 16-byte and one 8-byte non-temporal
 // loads per lane (the stream must not push the level-0 matrix out of the Infinity Cache)
 typedef double sgo_d2 __attribute__((ext_vector_type(2)));
+constexpr int kLongColumn = 512;   // entries of a P column from which a workgroup instead of a wave restricts it
 __device__ __forceinline__ void load9_stream(const double* __restrict__ base, size_t e, size_t n, double (&v)[9]) {
   const sgo_d2* __restrict__ bp = reinterpret_cast<const sgo_d2*>(base);
   const sgo_d2 p0 = __builtin_nontemporal_load(bp + e), p1 = __builtin_nontemporal_load(bp + n + e);
   const sgo_d2 p2 = __builtin_nontemporal_load(bp + 2 * n + e), p3 = __builtin_nontemporal_load(bp + 3 * n + e);
   v[0] = p0.x; v[1] = p0.y; v[2] = p1.x; v[3] = p1.y; v[4] = p2.x; v[5] = p2.y; v[6] = p3.x; v[7] = p3.y;
   v[8] = __builtin_nontemporal_load(base + 8 * n + e);
+}
+__device__ __forceinline__ void load9_pairs(const double* __restrict__ base, size_t e, size_t n, double (&v)[9], bool nt) {
+  if (nt) {
+    load9_stream(base, e, n, v);
+    return;
+  }
+  const sgo_d2* __restrict__ bp = reinterpret_cast<const sgo_d2*>(base);
+  const sgo_d2 p0 = bp[e], p1 = bp[n + e], p2 = bp[2 * n + e], p3 = bp[3 * n + e];
+  v[0] = p0.x; v[1] = p0.y; v[2] = p1.x; v[3] = p1.y; v[4] = p2.x; v[5] = p2.y; v[6] = p3.x; v[7] = p3.y;
+  v[8] = base[8 * n + e];
 }
 __device__ __forceinline__ void load9(const double* __restrict__ base, size_t e, double (&v)[9]) {
 #pragma unroll
@@ -312,6 +327,7 @@ __global__ __launch_bounds__(kBlock) void k_restrict_p(PDev P, const double* __r
   group_walk(P.t_ngrp, &g, &gend, &gstride);
   for (; g < gend; g += gstride) {
     const int gb = P.t_grp[g], ge = P.t_grp[g + 1];
+    if (P.t_nlong > 0 && ge - gb > kLongColumn) continue;   // k_restrict_p_long's
     double acc[3] = {0.0, 0.0, 0.0};
     int key = -1 - lane;
     for (int t = gb + lane; t < ge; t += 64) {
@@ -320,7 +336,7 @@ __global__ __launch_bounds__(kBlock) void k_restrict_p(PDev P, const double* __r
       if (row1 > 0 && ((int)i < row0 || (int)i >= row1)) continue;
       const double r0 = r[3 * i], r1 = r[3 * i + 1], r2 = r[3 * i + 2];
       double b[9];
-      load9_stream(P.t_blk, (size_t)t, np, b);
+      load9_pairs(P.t_blk, (size_t)t, np, b, P.stream_nt != 0);
       acc[0] += b[0] * r0 + b[3] * r1 + b[6] * r2;
       acc[1] += b[1] * r0 + b[4] * r1 + b[7] * r2;
       acc[2] += b[2] * r0 + b[5] * r1 + b[8] * r2;
@@ -333,6 +349,45 @@ __global__ __launch_bounds__(kBlock) void k_restrict_p(PDev P, const double* __r
       rc[3 * (size_t)key + 2] = acc[2];
     }
   }
+}
+
+// The columns k_restrict_p leaves out: one workgroup of 1024 threads per column, every thread a few entries (all of
+// them requested at once), wave sums and then the 16 wave totals added in a fixed order.  A single wave walking such a
+// column stride by stride is a chain of ~70 dependent round trips (C5's last level: 4 350 entries per column, 109 us).
+constexpr int kLongThreads = 1024;
+__global__ __launch_bounds__(kLongThreads) void k_restrict_p_long(PDev P, const double* __restrict__ r, double* __restrict__ rc,
+                                                                   const PcgScalars* S, int row0, int row1) {
+  if (S && S->stop) return;
+  __shared__ double sm[kLongThreads / 64][3];
+  const int gb = P.t_long[2 * blockIdx.x], ge = P.t_long[2 * blockIdx.x + 1];
+  const size_t np = (size_t)P.np;
+  double acc[3] = {0.0, 0.0, 0.0};
+  for (int t = gb + (int)threadIdx.x; t < ge; t += kLongThreads) {
+    const size_t i = (size_t)P.t_row[t];
+    if (row1 > 0 && ((int)i < row0 || (int)i >= row1)) continue;
+    const double r0 = r[3 * i], r1 = r[3 * i + 1], r2 = r[3 * i + 2];
+    double b[9];
+    load9_pairs(P.t_blk, (size_t)t, np, b, P.stream_nt != 0);
+    acc[0] += b[0] * r0 + b[3] * r1 + b[6] * r2;
+    acc[1] += b[1] * r0 + b[4] * r1 + b[7] * r2;
+    acc[2] += b[2] * r0 + b[5] * r1 + b[8] * r2;
+  }
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    const double v = wave_sum(acc[q]);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6][q] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    double v = sm[0][threadIdx.x];
+    for (int w = 1; w < kLongThreads / 64; ++w) v += sm[w][threadIdx.x];
+    rc[3 * (size_t)P.t_col[gb] + threadIdx.x] = v;
+  }
+}
+// r_c = P^T r on the stream (both kernels)
+void launch_restrict_p(hipStream_t s, const PDev& P, const double* r, double* rc, const PcgScalars* S, int row0, int row1) {
+  SGO_LAUNCH(k_restrict_p, dim3(grid_for(P.t_ngrp, kWavesPerBlock)), dim3(kBlock), 0, s, P, r, rc, S, row0, row1);
+  if (P.t_nlong > 0) SGO_LAUNCH(k_restrict_p_long, dim3(P.t_nlong), dim3(kLongThreads), 0, s, P, r, rc, S, row0, row1);
 }
 
 // x_i += sum over the entries e of row i of P_e (c1 u1 + c2 u2)[col(e)]  (+ xadd_i)
@@ -368,7 +423,7 @@ __global__ __launch_bounds__(kBlock) void k_prolong_p(int n, PDev P, const doubl
         w0 += c2 * u2[a]; w1 += c2 * u2[a + 1]; w2 += c2 * u2[a + 2];
       }
       double b[9];
-      load9_stream(P.r_blk, (size_t)e, np, b);
+      load9_pairs(P.r_blk, (size_t)e, np, b, P.stream_nt != 0);
       acc[0] += b[0] * w0 + b[1] * w1 + b[2] * w2;
       acc[1] += b[3] * w0 + b[4] * w1 + b[5] * w2;
       acc[2] += b[6] * w0 + b[7] * w1 + b[8] * w2;
@@ -1509,8 +1564,7 @@ int cycle(Amg* m, hipStream_t s, int l, const double* rhs, const double* rhs_sub
   }
   if (L.smoothed) {
     Scope sc(m->prof, K_RESTRICT_P, 84.0 * L.P.np + 24.0 * L.A.n + 24.0 * L.nc);
-    SGO_LAUNCH(k_restrict_p, dim3(grid_for(L.P.t_ngrp, kWavesPerBlock)), dim3(kBlock), 0, s, L.P,
-               (const double*)res, C.bk, S, sharded0 ? m->row0 : 0, sharded0 ? m->row1 : 0);
+    launch_restrict_p(s, L.P, res, C.bk, S, sharded0 ? m->row0 : 0, sharded0 ? m->row1 : 0);
   } else {
     Scope sc(m->prof, K_RESTRICT, 40.0 * L.A.n + 24.0 * L.nc);
     SGO_LAUNCH(k_restrict, dim3(grid_for(L.mem_ngrp, kWavesPerBlock)), dim3(kBlock), 0, s, L.mem_ngrp, L.mem_grp,
@@ -1696,8 +1750,7 @@ int amg_debug_coarse_rhs(Amg* m, hipStream_t s, const double* r, double* out_dev
   }
   if (!sharded || a.u1 > a.u0) launch_spmv0_any(s, m->S0, m->T0, S0_RESID, a);
   if (L.smoothed)
-    SGO_LAUNCH(k_restrict_p, dim3(grid_for(L.P.t_ngrp, kWavesPerBlock)), dim3(kBlock), 0, s, L.P, (const double*)L.rs, C.bk,
-               (const PcgScalars*)nullptr, sharded ? m->row0 : 0, sharded ? m->row1 : 0);
+    launch_restrict_p(s, L.P, L.rs, C.bk, nullptr, sharded ? m->row0 : 0, sharded ? m->row1 : 0);
   else
     SGO_LAUNCH(k_restrict, dim3(grid_for(L.mem_ngrp, kWavesPerBlock)), dim3(kBlock), 0, s, L.mem_ngrp, L.mem_grp, L.mem, L.agg,
                L.d, (const double*)L.rs, C.bk, (const PcgScalars*)nullptr, sharded ? m->row0 : 0, sharded ? m->row1 : 0);
@@ -1875,6 +1928,7 @@ Amg* amg_create(hipStream_t s, const BsrDev& A0, const Sym0Dev& S0, const Tile0D
       PDev& P = L.P;
       L.smoothed = true;
       P.np = (int)sa.p_row.size();
+      P.stream_nt = P.np >= 200000 ? 1 : 0;   // 2 x 72 B per block streamed per cycle: below ~30 MB it may stay cached
       P.rowptr = dev_upload(m->pool, sa.p_rowptr, s);
       P.row = dev_upload(m->pool, sa.p_row, s);
       P.col = dev_upload(m->pool, sa.p_col, s);
@@ -1893,6 +1947,16 @@ Amg* amg_create(hipStream_t s, const BsrDev& A0, const Sym0Dev& S0, const Tile0D
       P.r_blk = dev_alloc<double>(m->pool, 9 * (size_t)P.np);
       P.t_grp = dev_upload(m->pool, sa.t_grp, s);
       P.t_ngrp = (int)sa.t_grp.size() - 1;
+      std::vector<int> t_long;   // (lives until the stream is synchronised below)
+      for (size_t g = 0; g + 1 < sa.t_grp.size(); ++g)
+        if (sa.t_grp[g + 1] - sa.t_grp[g] > kLongColumn) {
+          t_long.push_back(sa.t_grp[g]);
+          t_long.push_back(sa.t_grp[g + 1]);
+        }
+      P.t_nlong = (int)t_long.size() / 2;
+      P.t_long = P.t_nlong ? dev_upload(m->pool, t_long, s) : nullptr;
+      if (P.t_nlong && !P.t_long) return fail("amg_create: out of device memory");
+      if (P.t_nlong && hipStreamSynchronize(s) != hipSuccess) return fail("amg_create: upload failed");
       P.nap = sa.nap;
       P.apblk = dev_alloc<double>(m->pool, 9 * (size_t)P.nap);
       P.ap.n = (int)sa.ap_a.size();
