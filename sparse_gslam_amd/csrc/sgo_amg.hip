@@ -320,13 +320,20 @@ __global__ __launch_bounds__(kBlock) void k_block_products(ProdMap mp, BsrDev XA
 // the ranks are then summed by an all-reduce of 3 n_c doubles instead of all-reducing the fine residual.
 __global__ __launch_bounds__(kBlock) void k_restrict_p(PDev P, const double* __restrict__ r, double* __restrict__ rc,
                                                        const PcgScalars* S, int row0, int row1) {
-  if (S && S->stop) return;
+  // (as in k_spmv: the first group's bounds are requested before the stop flag is waited for -- one dependent
+  // round trip less in a launch that is a chain of four)
   const int lane = threadIdx.x & 63;
   const size_t np = (size_t)P.np;
   int g, gend, gstride;
   group_walk(P.t_ngrp, &g, &gend, &gstride);
-  for (; g < gend; g += gstride) {
-    const int gb = P.t_grp[g], ge = P.t_grp[g + 1];
+  int gb0 = 0, ge0 = 0;
+  if (g < gend) {
+    gb0 = P.t_grp[g];
+    ge0 = P.t_grp[g + 1];
+  }
+  if (S && S->stop) return;
+  for (bool first = true; g < gend; g += gstride, first = false) {
+    const int gb = first ? gb0 : P.t_grp[g], ge = first ? ge0 : P.t_grp[g + 1];
     if (P.t_nlong > 0 && ge - gb > kLongColumn) continue;   // k_restrict_p_long's
     double acc[3] = {0.0, 0.0, 0.0};
     int key = -1 - lane;
@@ -395,9 +402,16 @@ __global__ __launch_bounds__(kBlock) void k_prolong_p(int n, PDev P, const doubl
                                                       const double* __restrict__ u2, SpmvRatio r2,
                                                       double* __restrict__ x, const PcgScalars* S,
                                                       const double* __restrict__ xadd) {
+  int g, gend, gstride;
+  group_walk(P.r_ngrp, &g, &gend, &gstride);
+  int gb0 = 0, ge0 = 0;   // requested before the stop flag is waited for (see k_restrict_p)
+  if (g < gend) {
+    gb0 = P.r_grp[g];
+    ge0 = P.r_grp[g + 1];
+  }
   if (S && S->stop) return;
   double c1 = 1.0, c2 = 0.0;
-  {
+  if (r1.num || u2) {   // (the plain V-cycle prolongates an unscaled correction: no partial sums to reduce)
     const double* const parts[4] = {r1.num ? r1.den : nullptr, r1.num, (u2 && r2.num) ? r2.den : nullptr,
                                     u2 ? r2.num : nullptr};
     const int cnt[4] = {r1.n_den, r1.n_num, r2.n_den, r2.n_num};
@@ -409,10 +423,8 @@ __global__ __launch_bounds__(kBlock) void k_prolong_p(int n, PDev P, const doubl
   // one lane per entry (entries are sorted by fine row), wavefront segmented sum per row
   const int lane = threadIdx.x & 63;
   const size_t np = (size_t)P.np;
-  int g, gend, gstride;
-  group_walk(P.r_ngrp, &g, &gend, &gstride);
-  for (; g < gend; g += gstride) {
-    const int gb = P.r_grp[g], ge = P.r_grp[g + 1];
+  for (bool first = true; g < gend; g += gstride, first = false) {
+    const int gb = first ? gb0 : P.r_grp[g], ge = first ? ge0 : P.r_grp[g + 1];
     double acc[3] = {0.0, 0.0, 0.0};
     int key = -1 - lane;
     for (int e = gb + lane; e < ge; e += 64) {
@@ -464,12 +476,17 @@ __global__ __launch_bounds__(kBlock) void k_restrict(int ngrp, const int* __rest
                                                      const int* __restrict__ agg, const double* __restrict__ d,
                                                      const double* __restrict__ r, double* __restrict__ rc,
                                                      const PcgScalars* S, int row0, int row1) {
-  if (S && S->stop) return;
   const int lane = threadIdx.x & 63;
   int g, gend, gstride;
   group_walk(ngrp, &g, &gend, &gstride);
-  for (; g < gend; g += gstride) {
-    const int gb = grp[g], ge = grp[g + 1];
+  int gb0 = 0, ge0 = 0;   // requested before the stop flag is waited for (see k_restrict_p)
+  if (g < gend) {
+    gb0 = grp[g];
+    ge0 = grp[g + 1];
+  }
+  if (S && S->stop) return;
+  for (bool first = true; g < gend; g += gstride, first = false) {
+    const int gb = first ? gb0 : grp[g], ge = first ? ge0 : grp[g + 1];
     double acc[3] = {0.0, 0.0, 0.0};
     int key = -1 - lane;
     for (int t = gb + lane; t < ge; t += 64) {
@@ -691,12 +708,19 @@ __global__ __launch_bounds__(kBlock) void k_gj_step(const double* __restrict__ M
 __global__ __launch_bounds__(kBlock) void k_dense_apply(int N, int Np, const double* __restrict__ inv,
                                                        const double* __restrict__ b, double* __restrict__ x,
                                                        const PcgScalars* S) {
-  if (S && S->stop) return;
   const int lane = threadIdx.x & 63;
-  for (int i = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6); i < N; i += gridDim.x * kWavesPerBlock) {
+  int i = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  // the first row's first stride is requested before the stop flag is waited for
+  double a0 = 0.0, b0 = 0.0;
+  if (i < N && lane < N) {
+    a0 = inv[(size_t)i * Np + lane];
+    b0 = b[lane];
+  }
+  if (S && S->stop) return;
+  for (bool first = true; i < N; i += gridDim.x * kWavesPerBlock, first = false) {
     const double* row = inv + (size_t)i * Np;
-    double s = 0.0;
-    for (int j = lane; j < N; j += 64) s += row[j] * b[j];
+    double s = first ? a0 * b0 : 0.0;
+    for (int j = lane + (first ? 64 : 0); j < N; j += 64) s += row[j] * b[j];
     s = wave_sum(s);
     if (lane == 0) x[i] = s;
   }
