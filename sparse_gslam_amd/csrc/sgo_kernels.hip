@@ -869,7 +869,25 @@ __global__ __launch_bounds__(kBlock) void k_update_xr(int n, PcgScalars* S, cons
                                                       double* __restrict__ r, double* __restrict__ z,
                                                       double* __restrict__ xs, double omega,
                                                       double* __restrict__ partials) {
-  // the scalars of the previous launches in one go, before the reduction's barriers
+  // the scalars of the previous launches in one go, before the reduction's barriers -- and this thread's first row
+  // of operands too (the grid gives every thread at most one row on all but the largest graphs): the partial sums'
+  // round trip and the operands' overlap instead of following each other
+  const int i0 = blockIdx.x * kBlock + threadIdx.x;
+  double pr[3] = {0, 0, 0}, pq_[3] = {0, 0, 0}, pp[3] = {0, 0, 0}, px[3] = {0, 0, 0}, pd[6] = {0, 0, 0, 0, 0, 0};
+  if (i0 < n) {
+    const size_t o = 3 * (size_t)i0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      pr[c] = r[o + c];
+      pq_[c] = q[o + c];
+      pp[c] = p[o + c];
+      px[c] = x[o + c];
+    }
+    if (dinv) {
+#pragma unroll
+      for (int c = 0; c < 6; ++c) pd[c] = dinv[6 * (size_t)i0 + c];
+    }
+  }
   const int stop0 = S->stop, iter0 = S->iter;
   const double rz = S->rz;
   if (stop0) return;
@@ -885,16 +903,28 @@ __global__ __launch_bounds__(kBlock) void k_update_xr(int n, PcgScalars* S, cons
   }
   if (bad) return;
   double acc[2] = {0.0, 0.0};
-  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+  for (int i = i0; i < n; i += gridDim.x * kBlock) {
     const size_t o = 3 * (size_t)i;
-    const double r0 = r[o] - alpha * q[o], r1 = r[o + 1] - alpha * q[o + 1], r2 = r[o + 2] - alpha * q[o + 2];
-    x[o] += alpha * p[o]; x[o + 1] += alpha * p[o + 1]; x[o + 2] += alpha * p[o + 2];
+    if (i != i0) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        pr[c] = r[o + c];
+        pq_[c] = q[o + c];
+        pp[c] = p[o + c];
+        px[c] = x[o + c];
+      }
+      if (dinv) {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) pd[c] = dinv[6 * (size_t)i + c];
+      }
+    }
+    const double r0 = pr[0] - alpha * pq_[0], r1 = pr[1] - alpha * pq_[1], r2 = pr[2] - alpha * pq_[2];
+    x[o] = px[0] + alpha * pp[0]; x[o + 1] = px[1] + alpha * pp[1]; x[o + 2] = px[2] + alpha * pp[2];
     r[o] = r0; r[o + 1] = r1; r[o + 2] = r2;
     if (dinv) {
-      const double* di = dinv + 6 * (size_t)i;
-      const double z0 = di[0] * r0 + di[1] * r1 + di[2] * r2;
-      const double z1 = di[1] * r0 + di[3] * r1 + di[4] * r2;
-      const double z2 = di[2] * r0 + di[4] * r1 + di[5] * r2;
+      const double z0 = pd[0] * r0 + pd[1] * r1 + pd[2] * r2;
+      const double z1 = pd[1] * r0 + pd[3] * r1 + pd[4] * r2;
+      const double z2 = pd[2] * r0 + pd[4] * r1 + pd[5] * r2;
       if (xs) {
         xs[o] = omega * z0; xs[o + 1] = omega * z1; xs[o + 2] = omega * z2;
       } else {
@@ -915,7 +945,14 @@ __global__ __launch_bounds__(kBlock) void k_update_p(int n3, PcgScalars* S, cons
                                                      const double* __restrict__ rr_parts, int n_rr,
                                                      const double* __restrict__ zq_parts, const double* __restrict__ z,
                                                      double* __restrict__ p) {
-  // the scalars of the previous launches in one go, before the reduction's barriers
+  // the scalars of the previous launches in one go, before the reduction's barriers, and this thread's first pair of
+  // operands (see k_update_xr)
+  const int i0 = blockIdx.x * kBlock + threadIdx.x;
+  double z0 = 0.0, p0 = 0.0;
+  if (i0 < n3) {
+    z0 = z[i0];
+    p0 = p[i0];
+  }
   const int stop0 = S->stop, iter_prev = S->iter_prev, maxit = S->maxit;
   const double alpha = S->alpha, rz_prev = S->rz_prev, tol2 = S->tol2, bb = S->bb;
   if (stop0) return;
@@ -938,7 +975,8 @@ __global__ __launch_bounds__(kBlock) void k_update_p(int n3, PcgScalars* S, cons
     if (stop) S->stop = stop;
   }
   if (stop) return;
-  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n3; i += gridDim.x * kBlock) p[i] = z[i] + beta * p[i];
+  if (i0 < n3) p[i0] = z0 + beta * p0;
+  for (int i = i0 + gridDim.x * kBlock; i < n3; i += gridDim.x * kBlock) p[i] = z[i] + beta * p[i];
 }
 
 // partials[blk] = sum a[i] * b[i]   (flat; used when the product had to be all-reduced first)
