@@ -580,6 +580,15 @@ __global__ __launch_bounds__(kBlock) void k_dense_fill(BsrDev A, int Np, double*
   for (int i = N + blockIdx.x * kBlock + threadIdx.x; i < Np; i += gridDim.x * kBlock) M[(size_t)i * Np + i] = 1.0;
 }
 
+// 1 / x by the hardware reciprocal and two Newton steps (the IEEE division is a chain of ~12 dependent instructions on
+// the critical path of every elimination step of the pivot-block inverse)
+__device__ __forceinline__ double gj_rcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);
+  r = fma(fma(-x, r, 1.0), r, r);
+  return r;
+}
+
 // P = inv(A_KK) by scalar Gauss-Jordan (one workgroup, one thread per matrix element: the element
 // lives in a register, only the pivot row / column travel through LDS; 2 barriers per step)
 __global__ __launch_bounds__(kGjB * kGjB) void k_gj_pivot(double* __restrict__ M, int Np, int kb, double* __restrict__ P,
@@ -593,7 +602,7 @@ __global__ __launch_bounds__(kGjB * kGjB) void k_gj_pivot(double* __restrict__ M
     double (*a)[kGjB + 1] = a2[k & 1];
     const double akk = a[k][k], akj = a[k][j], aik = a[i][k];
     if (threadIdx.x == 0 && (!(akk > 0.0) || !isfinite(akk))) *fail = 1;
-    const double p = (akk != 0.0) ? 1.0 / akk : 0.0;
+    const double p = (akk != 0.0) ? gj_rcp(akk) : 0.0;
     if (i == k) v = (j == k) ? p : akj * p;
     else if (j == k) v = -aik * p;
     else v = v - aik * (akj * p);
@@ -641,16 +650,34 @@ __global__ __launch_bounds__(kBlock) void k_gj_step(const double* __restrict__ M
     for (int q = 0; q < 4; ++q) dst[q] = Pin[r * kGjB + c0 + q];
     return;
   }
-  // first product: P A_Kj (row panel and general tiles) or A_iK P (column panel)
-  for (int e = t; e < kGjB * kGjB; e += kBlock) {
-    const int i = e / kGjB, j = e % kGjB;
+  // Everything this tile reads from global memory is requested up front -- the operands of the first product, the
+  // column-panel tile of the second and the tile itself -- so that a block step is ONE memory round trip deep instead
+  // of three (the step's launch is a dependent chain on the critical path of the whole inversion).
+  const bool general = bi != kb && bj != kb;
+  double x1[4], y1[4], x2[4] = {0, 0, 0, 0}, sv[4] = {0, 0, 0, 0};
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const int e = t + m * kBlock, i = e / kGjB, j = e % kGjB;
     if (bj == kb) {
-      X[i][j] = Min[(size_t)(bi * kGjB + i) * Np + K0 + j];
-      Y[i][j] = Pin[e];
+      x1[m] = Min[(size_t)(bi * kGjB + i) * Np + K0 + j];
+      y1[m] = Pin[e];
     } else {
-      X[i][j] = Pin[e];
-      Y[i][j] = Min[(size_t)(K0 + i) * Np + bj * kGjB + j];
+      x1[m] = Pin[e];
+      y1[m] = Min[(size_t)(K0 + i) * Np + bj * kGjB + j];
     }
+    if (general) x2[m] = Min[(size_t)(bi * kGjB + i) * Np + K0 + j];
+  }
+  if (general) {
+    const double* src = Min + (size_t)(bi * kGjB + r) * Np + bj * kGjB + c0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) sv[q] = src[q];
+  }
+  // first product: P A_Kj (row panel and general tiles) or A_iK P (column panel)
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const int e = t + m * kBlock;
+    X[e / kGjB][e % kGjB] = x1[m];
+    Y[e / kGjB][e % kGjB] = y1[m];
   }
   __syncthreads();
   double o[4];
@@ -669,12 +696,15 @@ __global__ __launch_bounds__(kBlock) void k_gj_step(const double* __restrict__ M
   __syncthreads();   // everyone is done reading X / Y
 #pragma unroll
   for (int q = 0; q < 4; ++q) Y[r][c0 + q] = o[q];
-  for (int e = t; e < kGjB * kGjB; e += kBlock) X[e / kGjB][e % kGjB] = Min[(size_t)(bi * kGjB + e / kGjB) * Np + K0 + e % kGjB];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const int e = t + m * kBlock;
+    X[e / kGjB][e % kGjB] = x2[m];
+  }
   __syncthreads();
   tile_mm(X, Y, o);
-  const double* src = Min + (size_t)(bi * kGjB + r) * Np + bj * kGjB + c0;
 #pragma unroll
-  for (int q = 0; q < 4; ++q) dst[q] = v[q] = src[q] - o[q];
+  for (int q = 0; q < 4; ++q) dst[q] = v[q] = sv[q] - o[q];
   if (bi != kb + 1 || bj != kb + 1) return;
   // next pivot block: Pout = inv(A_K'K') by scalar Gauss-Jordan
   __syncthreads();
@@ -689,7 +719,7 @@ __global__ __launch_bounds__(kBlock) void k_gj_step(const double* __restrict__ M
 #pragma unroll
     for (int q = 0; q < 4; ++q) akj[q] = rd[k][c0 + q];
     if (t == 0 && (!(akk > 0.0) || !isfinite(akk))) *fail = 1;
-    const double p = (akk != 0.0) ? 1.0 / akk : 0.0;
+    const double p = (akk != 0.0) ? gj_rcp(akk) : 0.0;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int c = c0 + q;
