@@ -19,6 +19,8 @@ struct AmgConfig {
                                // graphs with >= 10^6 level-0 blocks, where a coarse sweep is cheap next to level 0
   bool smooth = true;          // smoothed aggregation: P = (I - omega_p D^-1 A) T (env SGO_AMG_SMOOTH=0: tentative P)
   double omega_p = 0.66;       // damping of the prolongator smoothing step (env SGO_AMG_OMEGA_P)
+  bool lists_on_device = true;  // the product lists of A P and P^T A P are made on the device from the host's patterns
+                                // (env SGO_AMG_LISTS=host: on the host, the reference the device lists are tested against)
   int coarsest_nodes = 400;  // stop coarsening at or below this many nodes; that level is inverted densely
                              // (blocked Gauss-Jordan over 3x that many unknowns) once per GN iteration
 };

@@ -769,6 +769,180 @@ __global__ __launch_bounds__(kBlock) void k_dots2(int n, const double* __restric
   block_sum_store<2>(acc, partials, kMaxPartials);
 }
 
+// --------------------------------------------------------------------------------- product lists on the device
+// The patterns of P, A P and P^T A P come from the host (a per-row sort of a few distinct columns each); the lists of
+// block products behind every entry -- 13 M + 3 M triples on C4 level 0, the bulk of the symbolic phase's time and of
+// the set-up's upload -- are made here from the patterns: one thread per TARGET entry walks its candidates in the order
+// the host lists them (A P: the slots k of row i in ascending order, each contributing the entry of P row col(k) in
+// column c if it has one; P^T A P: the entries t of column a of P in ascending order, each contributing the entry of
+// A P row row(t) in column c) -- first counting, then, after a prefix sum over the targets, writing.
+struct ApPattern {
+  int nap = 0;
+  const int* ap_row = nullptr;     // [nap] fine row of target f
+  const int* ap_col = nullptr;     // [nap] coarse column of target f (ascending within a row)
+  const int* ap_rowptr = nullptr;  // [n + 1]
+};
+__device__ __forceinline__ int find_sorted(const int* __restrict__ v, int lo, int hi, int key) {   // position of key in v[lo, hi) or -1
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    const int x = v[mid];
+    if (x == key) return mid;
+    if (x < key) lo = mid + 1;
+    else hi = mid;
+  }
+  return -1;
+}
+template <bool FILL>
+__global__ __launch_bounds__(kBlock) void k_ap_list(ApPattern ap, const int* __restrict__ a_rowptr, const int* __restrict__ a_col,
+                                                    const int* __restrict__ p_rowptr, const int* __restrict__ p_col,
+                                                    int* __restrict__ cnt_or_ptr, int* __restrict__ la, int* __restrict__ lb,
+                                                    int* __restrict__ lt) {
+  for (int f = blockIdx.x * kBlock + threadIdx.x; f < ap.nap; f += gridDim.x * kBlock) {
+    const int i = ap.ap_row[f], c = ap.ap_col[f];
+    int out = FILL ? cnt_or_ptr[f] : 0;
+    for (int k = a_rowptr[i]; k < a_rowptr[i + 1]; ++k) {
+      const int j = a_col[k];
+      const int e = find_sorted(p_col, p_rowptr[j], p_rowptr[j + 1], c);
+      if (e < 0) continue;
+      if (FILL) {
+        la[out] = k;
+        lb[out] = e;
+        lt[out] = f;
+      }
+      ++out;
+    }
+    if (!FILL) cnt_or_ptr[f] = out;
+  }
+}
+template <bool FILL>
+__global__ __launch_bounds__(kBlock) void k_rap_list(int nslot_c, const int* __restrict__ c_row, const int* __restrict__ c_col,
+                                                     const int* __restrict__ t_ptr, const int* __restrict__ t_row,
+                                                     const int* __restrict__ t_idx, ApPattern ap, int* __restrict__ cnt_or_ptr,
+                                                     int* __restrict__ la, int* __restrict__ lb, int* __restrict__ lt) {
+  for (int sl = blockIdx.x * kBlock + threadIdx.x; sl < nslot_c; sl += gridDim.x * kBlock) {
+    const int a = c_row[sl], c = c_col[sl];
+    int out = FILL ? cnt_or_ptr[sl] : 0;
+    if (c >= a) {   // upper triangle only: the lower one is mirrored by the numeric kernel
+      for (int t = t_ptr[a]; t < t_ptr[a + 1]; ++t) {
+        const int i = t_row[t];
+        const int f = find_sorted(ap.ap_col, ap.ap_rowptr[i], ap.ap_rowptr[i + 1], c);
+        if (f < 0) continue;
+        if (FILL) {
+          la[out] = t_idx[t];
+          lb[out] = f;
+          lt[out] = sl;
+        }
+        ++out;
+      }
+    }
+    if (!FILL) cnt_or_ptr[sl] = out;
+  }
+}
+// Exclusive prefix sum of n ints in place (v[n] receives the total): blocks of kScanChunk elements summed, the block
+// sums scanned by one workgroup, the blocks rescanned with their offsets.
+constexpr int kScanChunk = 4096;
+__global__ __launch_bounds__(kBlock) void k_scan_sums(const int* __restrict__ v, int n, int* __restrict__ sums) {
+  __shared__ int sm[kBlock];
+  const int base = blockIdx.x * kScanChunk;
+  int acc = 0;
+  for (int q = threadIdx.x; q < kScanChunk && base + q < n; q += kBlock) acc += v[base + q];
+  sm[threadIdx.x] = acc;
+  __syncthreads();
+  for (int off = kBlock / 2; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) sm[threadIdx.x] += sm[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) sums[blockIdx.x] = sm[0];
+}
+__global__ __launch_bounds__(kBlock) void k_scan_top(int* __restrict__ sums, int nb) {   // one workgroup; sums[nb] = total
+  __shared__ int sm[kBlock];
+  __shared__ int carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < nb; base += kBlock) {
+    const int q = base + threadIdx.x;
+    const int x = q < nb ? sums[q] : 0;
+    sm[threadIdx.x] = x;
+    __syncthreads();
+    for (int off = 1; off < kBlock; off <<= 1) {   // Hillis-Steele inclusive scan
+      const int y = (int)threadIdx.x >= off ? sm[threadIdx.x - off] : 0;
+      __syncthreads();
+      sm[threadIdx.x] += y;
+      __syncthreads();
+    }
+    if (q < nb) sums[q] = carry + sm[threadIdx.x] - x;
+    __syncthreads();
+    if (threadIdx.x == 0) carry += sm[kBlock - 1];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) sums[nb] = carry;
+}
+__global__ __launch_bounds__(kBlock) void k_scan_apply(int* __restrict__ v, int n, const int* __restrict__ sums, int nb) {
+  // kScanChunk = 16 per thread: every thread scans its 16 consecutive elements, the threads' totals are scanned in LDS
+  __shared__ int sm[kBlock];
+  const int base = blockIdx.x * kScanChunk + threadIdx.x * (kScanChunk / kBlock);
+  int x[kScanChunk / kBlock], tot = 0;
+#pragma unroll
+  for (int q = 0; q < kScanChunk / kBlock; ++q) {
+    x[q] = base + q < n ? v[base + q] : 0;
+    tot += x[q];
+  }
+  sm[threadIdx.x] = tot;
+  __syncthreads();
+  for (int off = 1; off < kBlock; off <<= 1) {
+    const int y = (int)threadIdx.x >= off ? sm[threadIdx.x - off] : 0;
+    __syncthreads();
+    sm[threadIdx.x] += y;
+    __syncthreads();
+  }
+  int run = sums[blockIdx.x] + sm[threadIdx.x] - tot;
+#pragma unroll
+  for (int q = 0; q < kScanChunk / kBlock; ++q) {
+    if (base + q < n) v[base + q] = run;
+    run += x[q];
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) v[n] = sums[nb];
+}
+// Wave groups over the segments [ptr[f], ptr[f+1]): whole segments packed up to 64 items, a longer segment its own
+// group -- make_groups' rule, applied independently to chunks of kGroupChunk segments (a chunk starts a new group; the
+// grouping does not change a single sum).  Pass 1 counts a chunk's groups, pass 2 (after a prefix sum) writes them.
+constexpr int kGroupChunk = 2048;
+template <bool FILL>
+__global__ __launch_bounds__(kBlock) void k_group_chunks(const int* __restrict__ ptr, int nseg, int* __restrict__ cnt_or_off,
+                                                         int* __restrict__ grp) {
+  const int ch = blockIdx.x * kBlock + threadIdx.x, s0 = ch * kGroupChunk;
+  if (s0 >= nseg) return;
+  const int s1 = min(nseg, s0 + kGroupChunk);
+  int out = FILL ? cnt_or_off[ch] : 0, cur = 0, start = ptr[s0];
+  // a group is recorded by its START position; the list is closed with the total by the caller
+  bool open = false;
+  for (int f = s0; f < s1; ++f) {
+    const int b = ptr[f], e = ptr[f + 1], len = e - b;
+    if (open && cur + len > 64) {
+      if (FILL) grp[out] = start;
+      ++out;
+      open = false;
+      cur = 0;
+    }
+    if (!open) {
+      start = b;
+      open = true;
+    }
+    cur += len;
+    if (cur >= 64) {
+      if (FILL) grp[out] = start;
+      ++out;
+      open = false;
+      cur = 0;
+    }
+  }
+  if (open) {
+    if (FILL) grp[out] = start;
+    ++out;
+  }
+  if (!FILL) cnt_or_off[ch] = out;
+}
+
 // --------------------------------------------------------------------------------- host
 template <class T>
 T* dev_alloc(DevArena* pool, size_t count) {
@@ -926,6 +1100,10 @@ struct SaHost {
   HostLevel Hc;
   UVec rap_a, rap_b, rap_tgt;
   std::vector<int> rap_grp, rap_mirror;
+  // lists_on_device: the product lists (ap_*, rap_*) are NOT made here; the patterns they follow from are kept instead
+  bool lists_on_device = false;
+  std::vector<int> ap_rowptr, ap_col, ap_row, t_ptr, t_idx;
+  long long n_ap_prod = 0, n_rap_prod = 0;
 };
 
 // Per-row counting sort of products by the local index q of their target: count(q) for every
@@ -949,8 +1127,9 @@ struct RowSorter {
 // with many long-range edges make the smoothed coarse operators nearly dense, and the caller then
 // keeps the tentative prolongator for this level.
 bool sa_symbolic(const HostLevel& H, const std::vector<int>& agg, int nc, const std::vector<int>& mem_ptr,
-                 const std::vector<int>& mem, long long budget, SaHost& o) {
+                 const std::vector<int>& mem, long long budget, bool lists_on_device, SaHost& o) {
   const int n = H.n;
+  o.lists_on_device = lists_on_device;
   const bool verbose = std::getenv("SGO_VERBOSE") != nullptr;
   auto t0 = std::chrono::steady_clock::now();
   auto lap = [&](const char* what) {
@@ -1104,7 +1283,35 @@ bool sa_symbolic(const HostLevel& H, const std::vector<int>& agg, int nc, const 
   lap("P^T lists");
   o.nap = ap_rowptr[n];
   const int nprod_ap = (int)app[n];
-  std::vector<int> ap_col((size_t)o.nap), ap_ptr((size_t)o.nap + 1);
+  o.n_ap_prod = app[n];
+  std::vector<int> ap_col((size_t)o.nap), ap_ptr((size_t)(lists_on_device ? 0 : o.nap) + 1);
+  if (lists_on_device) {
+    // pattern only: the sorted distinct columns of every row (and the row of every entry, for the device's walk)
+    o.ap_row.resize((size_t)o.nap);
+    host_parallel_for(n, 256, [&](int lo, int hi, int) {
+      std::vector<int> mark((size_t)nc, -1), uniq;
+      for (int i = lo; i < hi; ++i) {
+        uniq.clear();
+        for (int k = H.rowptr[i]; k < H.rowptr[i + 1]; ++k) {
+          const int j = H.col[k];
+          for (int e = o.p_rowptr[j]; e < o.p_rowptr[j + 1]; ++e) {
+            const int c = o.p_col[e];
+            if (mark[c] != i) {
+              mark[c] = i;
+              uniq.push_back(c);
+            }
+          }
+        }
+        std::sort(uniq.begin(), uniq.end());
+        const int f0 = ap_rowptr[i];
+        for (size_t q = 0; q < uniq.size(); ++q) {
+          ap_col[f0 + q] = uniq[q];
+          o.ap_row[f0 + q] = i;
+        }
+      }
+    });
+    lap("AP pattern");
+  } else {
   o.ap_a.resize(nprod_ap);
   o.ap_b.resize(nprod_ap);
   o.ap_tgt.resize(nprod_ap);
@@ -1150,6 +1357,7 @@ bool sa_symbolic(const HostLevel& H, const std::vector<int>& agg, int nc, const 
   ap_ptr[o.nap] = nprod_ap;
   o.ap_grp = make_groups(ap_ptr);
   lap("AP fill");
+  }
   // ---- A_c = P^T AP: coarse row a collects, over the entries (i, a) of column a of P, row i of AP
   HostLevel& C = o.Hc;
   C.n = nc;
@@ -1183,9 +1391,36 @@ bool sa_symbolic(const HostLevel& H, const std::vector<int>& agg, int nc, const 
   if (app[n] + rpp[nc] > budget || C.rowptr[nc] > std::max(H.nslot, 4096)) return false;
   C.nslot = C.rowptr[nc];
   const int nprod_rap = (int)rpp[nc];
+  o.n_rap_prod = rpp[nc];
   C.row.resize(C.nslot);
   C.col.resize(C.nslot);
-  std::vector<int> rap_ptr((size_t)C.nslot + 1);
+  std::vector<int> rap_ptr((size_t)(lists_on_device ? 0 : C.nslot) + 1);
+  if (lists_on_device) {
+    host_parallel_for(nc, 64, [&](int lo, int hi, int) {
+      std::vector<int> mark((size_t)nc, -1), uniq;
+      for (int a = lo; a < hi; ++a) {
+        uniq.clear();
+        for (int t = t_ptr[a]; t < t_ptr[a + 1]; ++t) {
+          const int i = o.t_row[t];
+          for (int f = ap_rowptr[i]; f < ap_rowptr[i + 1]; ++f) {
+            const int c = ap_col[f];
+            if (mark[c] != a) {
+              mark[c] = a;
+              if (c != a) uniq.push_back(c);
+            }
+          }
+        }
+        std::sort(uniq.begin(), uniq.end());
+        const int s0 = C.rowptr[a];   // diagonal slot first (BsrDev convention), then ascending columns
+        C.row[s0] = a;
+        C.col[s0] = a;
+        for (size_t q = 0; q < uniq.size(); ++q) {
+          C.row[s0 + 1 + q] = a;
+          C.col[s0 + 1 + q] = uniq[q];
+        }
+      }
+    });
+  } else {
   o.rap_a.resize(nprod_rap);
   o.rap_b.resize(nprod_rap);
   o.rap_tgt.resize(nprod_rap);
@@ -1236,6 +1471,7 @@ bool sa_symbolic(const HostLevel& H, const std::vector<int>& agg, int nc, const 
   });
   rap_ptr[C.nslot] = nprod_rap;
   o.rap_grp = make_groups(rap_ptr);
+  }
   // slot (a, c), c > a  ->  slot (c, a): where the numeric kernel stores the transposed block
   o.rap_mirror.assign((size_t)C.nslot, -1);
   host_parallel_for(nc, 256, [&](int lo, int hi, int) {
@@ -1259,6 +1495,12 @@ bool sa_symbolic(const HostLevel& H, const std::vector<int>& agg, int nc, const 
     if (lower != mirrored) return false;
   }
   lap("RAP fill");
+  if (lists_on_device) {
+    o.ap_rowptr = std::move(ap_rowptr);
+    o.ap_col = std::move(ap_col);
+    o.t_ptr = std::move(t_ptr);
+    o.t_idx = std::move(t_idx);
+  }
   return true;
 }
 
@@ -1323,7 +1565,7 @@ void host_coarsen(const HostLevel& H, const std::vector<double>& w, const AmgCon
     // 2x slower than the tentative hierarchy): this level keeps the tentative prolongator
     const long long budget = std::min<long long>(1500000000LL, std::max<long long>(16LL * H.nslot, 2000000LL));
     try {
-      smooth = sa_symbolic(H, agg, nc, mem_ptr, mem, budget, sa);
+      smooth = sa_symbolic(H, agg, nc, mem_ptr, mem, budget, cfg.lists_on_device, sa);
     } catch (const std::bad_alloc&) {
       smooth = false;
     }
@@ -1831,6 +2073,35 @@ int amg_apply(Amg* m, hipStream_t s, const double* r, double* z, const double* d
   return cycle(m, s, 0, r, nullptr, none, nullptr, z, dotvec, partials, S, dotvec2, xs0_ready);
 }
 
+// v[0..n) counts -> exclusive prefix sums in place, v[n] = total (device, on the stream); `sums` holds n / kScanChunk + 2 ints
+void dev_scan_exclusive(hipStream_t s, int* v, int n, int* sums) {
+  const int nb = (n + kScanChunk - 1) / kScanChunk;
+  SGO_LAUNCH(k_scan_sums, dim3(std::max(nb, 1)), dim3(kBlock), 0, s, (const int*)v, n, sums);
+  SGO_LAUNCH(k_scan_top, dim3(1), dim3(kBlock), 0, s, sums, nb);
+  SGO_LAUNCH(k_scan_apply, dim3(std::max(nb, 1)), dim3(kBlock), 0, s, v, n, (const int*)sums, nb);
+}
+// Wave groups over the segments of ptr[0..nseg] on the device: returns the group list (ngrp + 1 starts, closed by the
+// total) and ngrp; synchronises the stream once (the group count sizes the list).  nullptr on failure.
+int* dev_make_groups(hipStream_t s, DevArena* pool, const int* ptr, int nseg, int total, int* ngrp_out) {
+  const int nch = std::max(1, (nseg + kGroupChunk - 1) / kGroupChunk);
+  int* cnt = dev_alloc<int>(pool, (size_t)nch + 1);
+  int* sums = dev_alloc<int>(pool, (size_t)nch / kScanChunk + 3);
+  if (!cnt || !sums) return nullptr;
+  hipMemsetAsync(cnt, 0, sizeof(int) * ((size_t)nch + 1), s);
+  SGO_LAUNCH((k_group_chunks<false>), dim3((nch + kBlock - 1) / kBlock), dim3(kBlock), 0, s, ptr, nseg, cnt, (int*)nullptr);
+  dev_scan_exclusive(s, cnt, nch, sums);
+  int ngrp = 0;
+  if (hipMemcpyAsync(&ngrp, cnt + nch, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+    return nullptr;
+  int* grp = dev_alloc<int>(pool, (size_t)ngrp + 1);
+  if (!grp) return nullptr;
+  SGO_LAUNCH((k_group_chunks<true>), dim3((nch + kBlock - 1) / kBlock), dim3(kBlock), 0, s, ptr, nseg, cnt, grp);
+  hipMemcpyAsync(grp + ngrp, &total, sizeof(int), hipMemcpyHostToDevice, s);
+  hipStreamSynchronize(s);   // `total` is a stack variable
+  *ngrp_out = ngrp;
+  return grp;
+}
+
 // The configuration amg_create works with for a level-0 operator of n rows / nslot logical slots: the caller's
 // values, the environment overrides and the size-dependent choices.
 AmgConfig amg_effective_config(const AmgConfig& cfg_in, int n, int nslot) {
@@ -1845,6 +2116,7 @@ AmgConfig amg_effective_config(const AmgConfig& cfg_in, int n, int nslot) {
   if (const char* e = std::getenv("SGO_AMG_NU_COARSE")) cfg.nu_coarse = std::atoi(e);
   if (const char* e = std::getenv("SGO_AMG_SMOOTH")) cfg.smooth = std::atoi(e) != 0;
   if (const char* e = std::getenv("SGO_AMG_OMEGA_P")) cfg.omega_p = std::atof(e);
+  if (const char* e = std::getenv("SGO_AMG_LISTS")) cfg.lists_on_device = std::string(e) != "host";
   // larger graphs afford a larger dense coarsest level (its inverse costs O(N^3) once per GN
   // iteration, one K-cycle level less halves the coarse-level launches of every PCG iteration)
   cfg.coarsest_nodes = std::min(1000, std::max(cfg.coarsest_nodes, n / 1500));
@@ -1978,6 +2250,7 @@ Amg* amg_create(hipStream_t s, const BsrDev& A0, const Sym0Dev& S0, const Tile0D
     L.mem_grp = dev_upload(m->pool, grp_m, s);
     L.mem_ngrp = (int)grp_m.size() - 1;
     L.d = dev_alloc<double>(m->pool, 2 * (size_t)n);
+    struct { int *ap_rowptr, *ap_col, *ap_row, *t_ptr, *t_idx; } l0_dev = {nullptr, nullptr, nullptr, nullptr, nullptr};
     if (smooth) {
       PDev& P = L.P;
       L.smoothed = true;
@@ -2013,6 +2286,19 @@ Amg* amg_create(hipStream_t s, const BsrDev& A0, const Sym0Dev& S0, const Tile0D
       if (P.t_nlong && hipStreamSynchronize(s) != hipSuccess) return fail("amg_create: upload failed");
       P.nap = sa.nap;
       P.apblk = dev_alloc<double>(m->pool, 9 * (size_t)P.nap);
+      int *d_ap_rowptr = nullptr, *d_ap_col = nullptr, *d_ap_row = nullptr, *d_t_ptr = nullptr, *d_t_idx = nullptr;
+      if (sa.lists_on_device) {
+        // the patterns go up (12 B per A P entry instead of 12 B per product); the lists are made below, once the
+        // coarse structure is on the device too
+        d_ap_rowptr = dev_upload(m->pool, sa.ap_rowptr, s);
+        d_ap_col = dev_upload(m->pool, sa.ap_col, s);
+        d_ap_row = dev_upload(m->pool, sa.ap_row, s);
+        d_t_ptr = dev_upload(m->pool, sa.t_ptr, s);
+        d_t_idx = dev_upload(m->pool, sa.t_idx, s);
+        if (!d_ap_rowptr || !d_ap_col || !d_ap_row || !d_t_ptr || !d_t_idx) return fail("amg_create: out of device memory");
+        P.ap.n = (int)sa.n_ap_prod;
+        P.rap.n = (int)sa.n_rap_prod;
+      } else {
       P.ap.n = (int)sa.ap_a.size();
       P.ap.a = dev_upload(m->pool, sa.ap_a, s);
       P.ap.b = dev_upload(m->pool, sa.ap_b, s);
@@ -2025,10 +2311,12 @@ Amg* amg_create(hipStream_t s, const BsrDev& A0, const Sym0Dev& S0, const Tile0D
       P.rap.tgt = dev_upload(m->pool, sa.rap_tgt, s);
       P.rap.grp = dev_upload(m->pool, sa.rap_grp, s);
       P.rap.ngrp = (int)sa.rap_grp.size() - 1;
+      }
       P.rap_mirror = dev_upload(m->pool, sa.rap_mirror, s);
       if (!P.rowptr || !P.row || !P.col || !P.blk || !P.val.a || !P.val.tgt || !P.val.grp || !P.r_grp || !P.t_pos || !P.t_row || !P.t_col || !P.t_blk || !P.r_blk || !P.t_grp ||
-          !P.apblk || !P.ap.a || !P.ap.b || !P.ap.tgt || !P.ap.grp || !P.rap.a || !P.rap.b || !P.rap.tgt || !P.rap.grp)
+          !P.apblk || (!sa.lists_on_device && (!P.ap.a || !P.ap.b || !P.ap.tgt || !P.ap.grp || !P.rap.a || !P.rap.b || !P.rap.tgt || !P.rap.grp)))
         return fail("amg_create: out of device memory");
+      l0_dev = {d_ap_rowptr, d_ap_col, d_ap_row, d_t_ptr, d_t_idx};
       std::snprintf(line, sizeof line, "(P %d, AP %d blocks; %d + %d products) ", P.np, P.nap, P.ap.n, P.rap.n);
       m->desc += line;
     } else {
@@ -2052,6 +2340,54 @@ Amg* amg_create(hipStream_t s, const BsrDev& A0, const Sym0Dev& S0, const Tile0D
     if (!L.agg || !L.mem_ptr || !L.mem || !L.mem_grp || !L.d || !C.A.row || !C.A.col ||
         !C.A.grp || !C.A.rowptr || !C.A.blk || !C.A.dinv)
       return fail("amg_create: out of device memory");
+    if (smooth && sa.lists_on_device) {
+      // product lists from the patterns: count per target, prefix sum, fill, wave groups (A P, then P^T A P)
+      PDev& P = L.P;
+      ApPattern ap;
+      ap.nap = P.nap;
+      ap.ap_row = l0_dev.ap_row;
+      ap.ap_col = l0_dev.ap_col;
+      ap.ap_rowptr = l0_dev.ap_rowptr;
+      const int nseg[2] = {P.nap, Hc.nslot};
+      const int nprod[2] = {P.ap.n, P.rap.n};
+      ProdMap* maps[2] = {&P.ap, &P.rap};
+      for (int w = 0; w < 2; ++w) {
+        int* ptr = dev_alloc<int>(m->pool, (size_t)nseg[w] + 1);
+        int* sums = dev_alloc<int>(m->pool, (size_t)nseg[w] / kScanChunk + 3);
+        int* la = dev_alloc<int>(m->pool, (size_t)std::max(nprod[w], 1));
+        int* lb = dev_alloc<int>(m->pool, (size_t)std::max(nprod[w], 1));
+        int* lt = dev_alloc<int>(m->pool, (size_t)std::max(nprod[w], 1));
+        if (!ptr || !sums || !la || !lb || !lt) return fail("amg_create: out of device memory");
+        const dim3 grid(grid_for(nseg[w], kBlock)), block(kBlock);
+        if (w == 0)
+          SGO_LAUNCH((k_ap_list<false>), grid, block, 0, s, ap, (const int*)L.A.rowptr, (const int*)L.A.col, (const int*)P.rowptr,
+                     (const int*)P.col, ptr, la, lb, lt);
+        else
+          SGO_LAUNCH((k_rap_list<false>), grid, block, 0, s, Hc.nslot, (const int*)C.A.row, (const int*)C.A.col,
+                     (const int*)l0_dev.t_ptr, (const int*)P.t_row, (const int*)l0_dev.t_idx, ap, ptr, la, lb, lt);
+        dev_scan_exclusive(s, ptr, nseg[w], sums);
+        if (w == 0)
+          SGO_LAUNCH((k_ap_list<true>), grid, block, 0, s, ap, (const int*)L.A.rowptr, (const int*)L.A.col, (const int*)P.rowptr,
+                     (const int*)P.col, ptr, la, lb, lt);
+        else
+          SGO_LAUNCH((k_rap_list<true>), grid, block, 0, s, Hc.nslot, (const int*)C.A.row, (const int*)C.A.col,
+                     (const int*)l0_dev.t_ptr, (const int*)P.t_row, (const int*)l0_dev.t_idx, ap, ptr, la, lb, lt);
+        int ngrp = 0, total = -1;
+        if (hipMemcpyAsync(&total, ptr + nseg[w], sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess ||
+            hipStreamSynchronize(s) != hipSuccess)
+          return fail("amg_create: product-list kernels failed");
+        if (total != nprod[w])
+          return fail("amg_create: internal error (device product lists: " + std::to_string(total) + " products, the host counted " +
+                      std::to_string(nprod[w]) + ")");
+        int* grp = dev_make_groups(s, m->pool, ptr, nseg[w], total, &ngrp);
+        if (!grp) return fail("amg_create: out of device memory");
+        maps[w]->a = la;
+        maps[w]->b = lb;
+        maps[w]->tgt = lt;
+        maps[w]->grp = grp;
+        maps[w]->ngrp = ngrp;
+      }
+    }
     if (hipStreamSynchronize(s) != hipSuccess) return fail("amg_create: upload failed");  // host vectors die below
     const double t_up = ms_since(tU);
     m->lv.push_back(C);  // invalidates L

@@ -58,3 +58,27 @@ def test_unused_helper_results_are_dropped_cleanly(monkeypatch):
         o2.set_graph(*arrs)
         done, st = o2.optimize(2)
         assert done == 2 and st["chi2"][-1] < st["chi2"][0]
+
+
+@pytest.mark.parametrize("name", ["C2", "big"])
+def test_device_made_product_lists_equal_the_host_lists(monkeypatch, name):
+    """The lists of block products behind every entry of A P and P^T A P are made on the device from the host's
+    patterns (k_ap_list / k_rap_list, prefix sums, wave groups); SGO_AMG_LISTS=host makes them on the host as before.
+    Same products in the same order per target; the wave-group boundaries differ (the device packs chunks of 2048
+    targets independently), and with them the association order of the wavefront segmented sums: identical
+    hierarchies and product counts, iterates equal to rounding."""
+    arrs = synth.config("C2", info_mode="full").arrays() if name == "C2" else _graph(0.0)
+    res = []
+    for mode in ("device", "host"):
+        monkeypatch.setenv("SGO_AMG_LISTS", mode)
+        with capi.Optimizer(0) as o:
+            o.set_graph(*arrs)
+            desc = o.solver_description()
+            done, st = o.optimize(5)
+            res.append((desc, done, st["chi2"], st["pcg_iters"], o.get_poses()))
+    assert res[0][0] == res[1][0], (res[0][0], res[1][0])
+    assert res[0][1] == res[1][1] == 5
+    assert res[0][3] == res[1][3]
+    for x, y in zip(res[0][2], res[1][2]):
+        assert abs(x - y) <= 1e-9 * y
+    assert np.abs(res[0][4] - res[1][4]).max() <= 1e-8
