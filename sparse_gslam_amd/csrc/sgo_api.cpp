@@ -457,32 +457,62 @@ int plan_rows_order(int V, const double* poses, const uint8_t* fixed, int E, con
   const std::vector<int>& hpos = P.hpos;
   lap("hilbert order");
   // compact slots: per row one slot per incident edge (edge order within the row)
+  // A stable counting sort of the edge endpoints by row (a row's slots in edge order), in parallel over contiguous
+  // chunks of the edge list: per-chunk counts per row, offsets by a prefix over (row, chunk), then every chunk places
+  // its own slots -- the same layout as one sequential pass (which took 6 ms of the critical path on C4, 94 ms on C5).
   std::vector<int>& rowptr = P.rowptr;
   rowptr.assign((size_t)n + 1, 0);
-  for (int e = 0; e < E; ++e) {
-    const int hi = hpos[ei[e]], hj = hpos[ej[e]];
-    if (hi >= 0) rowptr[hi + 1]++;
-    if (hj >= 0) rowptr[hj + 1]++;
-  }
+  const int nchunk = (E >= 200000 && n > 0) ? std::max(1, std::min(HostPool::get().size(), 16)) : 1;
+  auto chunk_lo = [&](int t) { return (int)((long long)E * t / nchunk); };
+  std::vector<int> ccnt((size_t)nchunk * std::max(n, 1), 0);   // [chunk][row], turned into the chunk's first position per row
+  host_parallel_for(nchunk, 1, [&](int t0, int t1, int) {
+    for (int t = t0; t < t1; ++t) {
+      int* c = ccnt.data() + (size_t)t * std::max(n, 1);
+      for (int e = chunk_lo(t); e < chunk_lo(t + 1); ++e) {
+        const int hi = hpos[ei[e]], hj = hpos[ej[e]];
+        if (hi >= 0) c[hi]++;
+        if (hj >= 0) c[hj]++;
+      }
+    }
+  });
+  parallel_for(n, [&](int r0, int r1) {
+    for (int r = r0; r < r1; ++r) {
+      int tot = 0;
+      for (int t = 0; t < nchunk; ++t) tot += ccnt[(size_t)t * n + r];
+      rowptr[r + 1] = tot;
+    }
+  });
   for (int r = 0; r < n; ++r) rowptr[r + 1] += rowptr[r];
   const int ns = P.ns = rowptr[n];
+  parallel_for(n, [&](int r0, int r1) {
+    for (int r = r0; r < r1; ++r) {
+      int at = rowptr[r];
+      for (int t = 0; t < nchunk; ++t) {
+        const int c = ccnt[(size_t)t * n + r];
+        ccnt[(size_t)t * n + r] = at;
+        at += c;
+      }
+    }
+  });
   P.pos_i.assign(E, -1);
   P.pos_j.assign(E, -1);
   P.col.resize((size_t)std::max(ns, 1));
-  {
-    std::vector<int> fill(rowptr.begin(), rowptr.end() - 1);
-    for (int e = 0; e < E; ++e) {
-      const int hi = hpos[ei[e]], hj = hpos[ej[e]];
-      if (hi >= 0) {
-        P.col[fill[hi]] = hj;
-        P.pos_i[e] = fill[hi]++;
-      }
-      if (hj >= 0) {
-        P.col[fill[hj]] = hi;
-        P.pos_j[e] = fill[hj]++;
+  host_parallel_for(nchunk, 1, [&](int t0, int t1, int) {
+    for (int t = t0; t < t1; ++t) {
+      int* fill = ccnt.data() + (size_t)t * std::max(n, 1);
+      for (int e = chunk_lo(t); e < chunk_lo(t + 1); ++e) {
+        const int hi = hpos[ei[e]], hj = hpos[ej[e]];
+        if (hi >= 0) {
+          P.col[fill[hi]] = hj;
+          P.pos_i[e] = fill[hi]++;
+        }
+        if (hj >= 0) {
+          P.col[fill[hj]] = hi;
+          P.pos_j[e] = fill[hj]++;
+        }
       }
     }
-  }
+  });
   lap("slot positions");
   return SGO_OK;
 }
