@@ -120,3 +120,23 @@ def test_plan_rows_is_a_partition_for_every_world_size():
         rb = plan["rank_row_begin"]
         assert rb[0] == 0 and rb[-1] == plan["n"] and np.all(np.diff(rb) >= 0)
         assert np.array_equal(np.sort(plan["row_vertex"]), np.flatnonzero(~g.fixed))
+
+
+def test_plan_rows_on_a_large_graph_with_long_range_edges(monkeypatch):
+    """E >= 200 000: the slot placement runs as a parallel stable counting sort over chunks of the edge list; 20 %
+    random closures and a small LDS budget (the experiment knob SGO_TILE_LDS stands in for the graphs of C5's kind,
+    which a CPU test cannot afford): the tile cut is limited by the LDS, many more tiles than CUs, and is taken as it
+    is.  The plan must still be a partition of the free vertices into consecutive tiles, with rank boundaries on
+    tile boundaries, and must not depend on the call (two calls agree)."""
+    monkeypatch.setenv("SGO_TILE_LDS", "6000")
+    g = synth.manhattan(30000, 250000, seed=8, p_random=0.2)
+    a = capi.plan_rows(g.poses, g.fixed, g.ei, g.ej, 8)
+    b = capi.plan_rows(g.poses, g.fixed, g.ei, g.ej, 8)
+    assert a["n"] == int((~g.fixed).sum())
+    assert np.array_equal(np.sort(a["row_vertex"]), np.flatnonzero(~g.fixed))
+    tb, rb = a["tile_row_begin"], a["rank_row_begin"]
+    assert tb[0] == 0 and tb[-1] == a["n"] and np.all(np.diff(tb) > 0)
+    assert tb.size - 1 >= 4 * 256       # closed by the LDS budget, not by a CU's share of the blocks
+    assert rb[0] == 0 and rb[-1] == a["n"] and set(rb.tolist()) <= set(tb.tolist())
+    for k in ("row_vertex", "tile_row_begin", "rank_row_begin"):
+        assert np.array_equal(a[k], b[k])
