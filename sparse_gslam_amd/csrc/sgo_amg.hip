@@ -984,60 +984,68 @@ int aggregate(const HostLevel& L, const std::vector<double>& w, double theta, st
   const int n = L.n;
   agg.assign(n, -1);
   const int* visit = L.visit.size() == (size_t)n ? L.visit.data() : nullptr;
-  std::vector<uint8_t> sflag(L.nslot, 0);   // strength of every slot, evaluated once (rows in parallel)
+  // The strong neighbours of every node (and their weights), compacted IN VISITING ORDER by the host pool: the three
+  // sequential passes below then stream through two flat arrays instead of hopping through the rows -- the visiting
+  // order (along the trajectory) is not the row order (along the Hilbert curve), and the hops were most of their time.
+  std::vector<int> sptr((size_t)n + 1, 0);
   host_parallel_for(n, 2048, [&](int lo, int hi, int) {
-    for (int i = lo; i < hi; ++i) {
+    for (int t = lo; t < hi; ++t) {
+      const int i = visit ? visit[t] : t;
       const double di = w[L.rowptr[i]];
+      int cnt = 0;
       for (int k = L.rowptr[i] + 1; k < L.rowptr[i + 1]; ++k) {
         const int j = L.col[k];
         if (j == i) continue;
-        const double t = theta * theta * di * w[L.rowptr[j]];   // w_ij >= theta sqrt(d_i d_j), squared
-        sflag[k] = (w[k] > 0.0 && w[k] * w[k] >= t) ? 1 : 0;
+        const double th = theta * theta * di * w[L.rowptr[j]];   // w_ij >= theta sqrt(d_i d_j), squared
+        cnt += (w[k] > 0.0 && w[k] * w[k] >= th) ? 1 : 0;
+      }
+      sptr[t + 1] = cnt;
+    }
+  });
+  for (int t = 0; t < n; ++t) sptr[t + 1] += sptr[t];
+  std::vector<int> scol((size_t)std::max(sptr[n], 1));
+  std::vector<double> sw((size_t)std::max(sptr[n], 1));
+  host_parallel_for(n, 2048, [&](int lo, int hi, int) {
+    for (int t = lo; t < hi; ++t) {
+      const int i = visit ? visit[t] : t;
+      const double di = w[L.rowptr[i]];
+      int q = sptr[t];
+      for (int k = L.rowptr[i] + 1; k < L.rowptr[i + 1]; ++k) {
+        const int j = L.col[k];
+        if (j == i) continue;
+        const double th = theta * theta * di * w[L.rowptr[j]];
+        if (w[k] > 0.0 && w[k] * w[k] >= th) {
+          scol[q] = j;
+          sw[q] = w[k];
+          ++q;
+        }
       }
     }
   });
-  auto strong = [&](int, int k) { return sflag[k] != 0; };
-  // the visiting order (along the trajectory) jumps through the rows (numbered along the Hilbert curve): the next rows'
-  // slot lists are requested a few visits ahead
-  auto ahead = [&](int t) {
-    if (t + 8 < n) __builtin_prefetch(&L.rowptr[visit ? visit[t + 8] : t + 8]);
-    if (t + 4 < n) {
-      const int kp = L.rowptr[visit ? visit[t + 4] : t + 4];
-      __builtin_prefetch(&L.col[kp]);
-      __builtin_prefetch(&L.col[kp] + 16);
-      __builtin_prefetch(&sflag[kp]);
-    }
-  };
   int nc = 0;
   // pass 1: a node all of whose strong neighbours are free roots a new aggregate
   for (int t = 0; t < n; ++t) {
-    ahead(t);
     const int i = visit ? visit[t] : t;
-    if (agg[i] >= 0) continue;
-    bool any = false, ok = true;
-    for (int k = L.rowptr[i] + 1; k < L.rowptr[i + 1] && ok; ++k)
-      if (strong(i, k)) {
-        any = true;
-        if (agg[L.col[k]] >= 0) ok = false;
-      }
-    if (!any || !ok) continue;
+    if (agg[i] >= 0 || sptr[t] == sptr[t + 1]) continue;
+    bool ok = true;
+    for (int q = sptr[t]; q < sptr[t + 1] && ok; ++q)
+      if (agg[scol[q]] >= 0) ok = false;
+    if (!ok) continue;
     agg[i] = nc;
-    for (int k = L.rowptr[i] + 1; k < L.rowptr[i + 1]; ++k)
-      if (strong(i, k)) agg[L.col[k]] = nc;
+    for (int q = sptr[t]; q < sptr[t + 1]; ++q) agg[scol[q]] = nc;
     ++nc;
   }
   // pass 2: leftovers join the aggregate of their strongest aggregated strong neighbour
   std::vector<int> agg1(agg);
   for (int t = 0; t < n; ++t) {
-    ahead(t);
     const int i = visit ? visit[t] : t;
     if (agg1[i] >= 0) continue;
     double best = -1.0;
     int ba = -1;
-    for (int k = L.rowptr[i] + 1; k < L.rowptr[i + 1]; ++k)
-      if (strong(i, k) && agg1[L.col[k]] >= 0 && w[k] > best) {
-        best = w[k];
-        ba = agg1[L.col[k]];
+    for (int q = sptr[t]; q < sptr[t + 1]; ++q)
+      if (agg1[scol[q]] >= 0 && sw[q] > best) {
+        best = sw[q];
+        ba = agg1[scol[q]];
       }
     if (ba >= 0) agg[i] = ba;
   }
@@ -1046,8 +1054,8 @@ int aggregate(const HostLevel& L, const std::vector<double>& w, double theta, st
     const int i = visit ? visit[t] : t;
     if (agg[i] >= 0) continue;
     agg[i] = nc;
-    for (int k = L.rowptr[i] + 1; k < L.rowptr[i + 1]; ++k)
-      if (strong(i, k) && agg[L.col[k]] < 0) agg[L.col[k]] = nc;
+    for (int q = sptr[t]; q < sptr[t + 1]; ++q)
+      if (agg[scol[q]] < 0) agg[scol[q]] = nc;
     ++nc;
   }
   return nc;
