@@ -792,26 +792,41 @@ __device__ __forceinline__ int find_sorted(const int* __restrict__ v, int lo, in
   }
   return -1;
 }
+// Eight lanes per target: lane q of a target's group takes the candidates q, q + 8, ... of the walk, the matches of one
+// round are ranked by a ballot (candidate order = lane order within a round), so the list keeps the host's order while
+// the walk -- a chain of dependent index loads and a binary search per candidate -- is eight times shorter.
 template <bool FILL>
 __global__ __launch_bounds__(kBlock) void k_ap_list(ApPattern ap, const int* __restrict__ a_rowptr, const int* __restrict__ a_col,
                                                     const int* __restrict__ p_rowptr, const int* __restrict__ p_col,
                                                     int* __restrict__ cnt_or_ptr, int* __restrict__ la, int* __restrict__ lb,
                                                     int* __restrict__ lt) {
-  for (int f = blockIdx.x * kBlock + threadIdx.x; f < ap.nap; f += gridDim.x * kBlock) {
-    const int i = ap.ap_row[f], c = ap.ap_col[f];
-    int out = FILL ? cnt_or_ptr[f] : 0;
-    for (int k = a_rowptr[i]; k < a_rowptr[i + 1]; ++k) {
-      const int j = a_col[k];
-      const int e = find_sorted(p_col, p_rowptr[j], p_rowptr[j + 1], c);
-      if (e < 0) continue;
-      if (FILL) {
-        la[out] = k;
-        lb[out] = e;
-        lt[out] = f;
+  const int lane = threadIdx.x & 63, sub = lane & 7, g8 = lane >> 3;
+  const int wave = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6), nwaves = gridDim.x * kWavesPerBlock;
+  for (int f0 = wave * 8; f0 < ap.nap; f0 += nwaves * 8) {
+    const int f = f0 + g8;
+    const bool valid = f < ap.nap;
+    const int i = valid ? ap.ap_row[f] : 0, c = valid ? ap.ap_col[f] : 0;
+    int k = valid ? a_rowptr[i] + sub : 0;
+    const int kend = valid ? a_rowptr[i + 1] : 0;
+    int out = (FILL && valid) ? cnt_or_ptr[f] : 0;
+    while (__any(k < kend)) {
+      int e = -1;
+      if (k < kend) {
+        const int j = a_col[k];
+        e = find_sorted(p_col, p_rowptr[j], p_rowptr[j + 1], c);
       }
-      ++out;
+      const unsigned long long m = __ballot(e >= 0);
+      const unsigned sm = (unsigned)(m >> (8 * g8)) & 0xFFu;
+      if (FILL && e >= 0) {
+        const int pos = out + __popc(sm & ((1u << sub) - 1u));
+        la[pos] = k;
+        lb[pos] = e;
+        lt[pos] = f;
+      }
+      out += __popc(sm);
+      k += 8;
     }
-    if (!FILL) cnt_or_ptr[f] = out;
+    if (!FILL && valid && sub == 0) cnt_or_ptr[f] = out;
   }
 }
 template <bool FILL>
@@ -819,23 +834,34 @@ __global__ __launch_bounds__(kBlock) void k_rap_list(int nslot_c, const int* __r
                                                      const int* __restrict__ t_ptr, const int* __restrict__ t_row,
                                                      const int* __restrict__ t_idx, ApPattern ap, int* __restrict__ cnt_or_ptr,
                                                      int* __restrict__ la, int* __restrict__ lb, int* __restrict__ lt) {
-  for (int sl = blockIdx.x * kBlock + threadIdx.x; sl < nslot_c; sl += gridDim.x * kBlock) {
-    const int a = c_row[sl], c = c_col[sl];
-    int out = FILL ? cnt_or_ptr[sl] : 0;
-    if (c >= a) {   // upper triangle only: the lower one is mirrored by the numeric kernel
-      for (int t = t_ptr[a]; t < t_ptr[a + 1]; ++t) {
+  const int lane = threadIdx.x & 63, sub = lane & 7, g8 = lane >> 3;
+  const int wave = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6), nwaves = gridDim.x * kWavesPerBlock;
+  for (int s0 = wave * 8; s0 < nslot_c; s0 += nwaves * 8) {
+    const int sl = s0 + g8;
+    const bool valid = sl < nslot_c;
+    const int a = valid ? c_row[sl] : 0, c = valid ? c_col[sl] : 0;
+    const bool upper = valid && c >= a;   // upper triangle only: the lower one is mirrored by the numeric kernel
+    int t = upper ? t_ptr[a] + sub : 0;
+    const int tend = upper ? t_ptr[a + 1] : 0;
+    int out = (FILL && valid) ? cnt_or_ptr[sl] : 0;
+    while (__any(t < tend)) {
+      int f = -1;
+      if (t < tend) {
         const int i = t_row[t];
-        const int f = find_sorted(ap.ap_col, ap.ap_rowptr[i], ap.ap_rowptr[i + 1], c);
-        if (f < 0) continue;
-        if (FILL) {
-          la[out] = t_idx[t];
-          lb[out] = f;
-          lt[out] = sl;
-        }
-        ++out;
+        f = find_sorted(ap.ap_col, ap.ap_rowptr[i], ap.ap_rowptr[i + 1], c);
       }
+      const unsigned long long m = __ballot(f >= 0);
+      const unsigned sm = (unsigned)(m >> (8 * g8)) & 0xFFu;
+      if (FILL && f >= 0) {
+        const int pos = out + __popc(sm & ((1u << sub) - 1u));
+        la[pos] = t_idx[t];
+        lb[pos] = f;
+        lt[pos] = sl;
+      }
+      out += __popc(sm);
+      t += 8;
     }
-    if (!FILL) cnt_or_ptr[sl] = out;
+    if (!FILL && valid && sub == 0) cnt_or_ptr[sl] = out;
   }
 }
 // Exclusive prefix sum of n ints in place (v[n] receives the total): blocks of kScanChunk elements summed, the block
@@ -904,9 +930,9 @@ __global__ __launch_bounds__(kBlock) void k_scan_apply(int* __restrict__ v, int 
   if (blockIdx.x == 0 && threadIdx.x == 0) v[n] = sums[nb];
 }
 // Wave groups over the segments [ptr[f], ptr[f+1]): whole segments packed up to 64 items, a longer segment its own
-// group -- make_groups' rule, applied independently to chunks of kGroupChunk segments (a chunk starts a new group; the
+// group -- make_groups' rule, applied independently to chunks of kGroupChunk segments (one thread each: short chunks keep the serial walk short; a chunk starts a new group; the
 // grouping does not change a single sum).  Pass 1 counts a chunk's groups, pass 2 (after a prefix sum) writes them.
-constexpr int kGroupChunk = 2048;
+constexpr int kGroupChunk = 256;
 template <bool FILL>
 __global__ __launch_bounds__(kBlock) void k_group_chunks(const int* __restrict__ ptr, int nseg, int* __restrict__ cnt_or_off,
                                                          int* __restrict__ grp) {
@@ -2348,6 +2374,7 @@ Amg* amg_create(hipStream_t s, const BsrDev& A0, const Sym0Dev& S0, const Tile0D
     if (!L.agg || !L.mem_ptr || !L.mem || !L.mem_grp || !L.d || !C.A.row || !C.A.col ||
         !C.A.grp || !C.A.rowptr || !C.A.blk || !C.A.dinv)
       return fail("amg_create: out of device memory");
+    const double t_up0 = ms_since(tU);
     if (smooth && sa.lists_on_device) {
       // product lists from the patterns: count per target, prefix sum, fill, wave groups (A P, then P^T A P)
       PDev& P = L.P;
@@ -2366,7 +2393,7 @@ Amg* amg_create(hipStream_t s, const BsrDev& A0, const Sym0Dev& S0, const Tile0D
         int* lb = dev_alloc<int>(m->pool, (size_t)std::max(nprod[w], 1));
         int* lt = dev_alloc<int>(m->pool, (size_t)std::max(nprod[w], 1));
         if (!ptr || !sums || !la || !lb || !lt) return fail("amg_create: out of device memory");
-        const dim3 grid(grid_for(nseg[w], kBlock)), block(kBlock);
+        const dim3 grid(grid_for(8LL * nseg[w], kBlock)), block(kBlock);   // eight lanes per target
         if (w == 0)
           SGO_LAUNCH((k_ap_list<false>), grid, block, 0, s, ap, (const int*)L.A.rowptr, (const int*)L.A.col, (const int*)P.rowptr,
                      (const int*)P.col, ptr, la, lb, lt);
@@ -2412,7 +2439,8 @@ Amg* amg_create(hipStream_t s, const BsrDev& A0, const Sym0Dev& S0, const Tile0D
       if (l + 1 < m->cfg.max_levels) SGO_LAUNCH(k_level_dinv, dim3(grid_for(Cr.A.n, kBlock)), dim3(kBlock), 0, s, Cr.A);
       if (hipStreamSynchronize(s) != hipSuccess) return fail("amg_create: Galerkin kernel failed");
       if (std::getenv("SGO_VERBOSE") && n > 20000)
-        std::fprintf(stderr, "[sgo] amg level %d: alloc + upload %.1f ms, first values %.1f ms\n", l, t_up, ms_since(tU) - t_up);
+        std::fprintf(stderr, "[sgo] amg level %d: alloc + upload %.1f ms (of which product lists on the device %.1f), first values %.1f ms\n", l, t_up,
+                     t_up - t_up0, ms_since(tU) - t_up);
     }
     Hown = std::move(Hc);
     Hown.visit = std::move(visit_c);
