@@ -446,7 +446,31 @@ int plan_rows_order(int V, const double* poses, const uint8_t* fixed, int E, con
         key[h] = ((uint64_t)d << 32) | (uint32_t)h;
       }
     });
-    std::sort(key.begin(), key.end());
+    // sorted in parallel: eight chunks by std::sort, then three rounds of pairwise merges (keys are distinct: the
+    // low word is the vertex's hessian index, so the order does not depend on how the work is split)
+    if (n >= 65536 && HostPool::get().size() >= 4) {
+      constexpr int kParts = 8;
+      int cut[kParts + 1];
+      for (int q = 0; q <= kParts; ++q) cut[q] = (int)((long long)n * q / kParts);
+      host_parallel_for(kParts, 1, [&](int q0, int q1, int) {
+        for (int q = q0; q < q1; ++q) std::sort(key.begin() + cut[q], key.begin() + cut[q + 1]);
+      });
+      std::vector<uint64_t> tmp(n);
+      std::vector<uint64_t>*src = &key, *dst = &tmp;
+      for (int width = 1; width < kParts; width *= 2) {
+        const int npairs = kParts / (2 * width);
+        host_parallel_for(npairs, 1, [&](int q0, int q1, int) {
+          for (int q = q0; q < q1; ++q) {
+            const int a = cut[2 * width * q], m = cut[2 * width * q + width], b = cut[2 * width * (q + 1)];
+            std::merge(src->begin() + a, src->begin() + m, src->begin() + m, src->begin() + b, dst->begin() + a);
+          }
+        });
+        std::swap(src, dst);
+      }
+      if (src != &key) key.swap(tmp);
+    } else {
+      std::sort(key.begin(), key.end());
+    }
     for (int r = 0; r < n; ++r) {
       const int h = (int)(key[r] & 0xffffffffu);
       P.row_of_asc[h] = r;
@@ -800,11 +824,14 @@ int build_structure(sgo_ctx* c, int V, const double* poses, const uint8_t* fixed
   H.n = n;
   H.visit = c->row_of_asc;   // the multigrid aggregation walks level 0 along the trajectory (ascending vertex id)
   H.rowptr.assign((size_t)n + 1, 0);
-  for (int r = 0; r < n; ++r) {
-    int nb = 1;
-    for (int k = rowptr[r]; k < rowptr[r + 1]; ++k) nb += col[k] >= 0;
-    H.rowptr[r + 1] = H.rowptr[r] + nb;
-  }
+  parallel_for(n, [&](int r0, int r1) {
+    for (int r = r0; r < r1; ++r) {
+      int nb = 1;
+      for (int k = rowptr[r]; k < rowptr[r + 1]; ++k) nb += col[k] >= 0;
+      H.rowptr[r + 1] = nb;
+    }
+  });
+  for (int r = 0; r < n; ++r) H.rowptr[r + 1] += H.rowptr[r];
   H.nslot = H.rowptr[n];
   H.row.resize(H.nslot);
   H.col.resize(H.nslot);
