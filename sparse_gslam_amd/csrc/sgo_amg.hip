@@ -1268,6 +1268,36 @@ bool sa_symbolic(const HostLevel& H, const std::vector<int>& agg, int nc, const 
   // ---- AP: row i holds the union of the P rows of the columns of row i
   std::vector<int> ap_rowptr((size_t)n + 1, 0);
   std::vector<long long> app((size_t)n + 1, 0);
+  // (device-lists mode: the sorted distinct columns are collected in the same traversal, per task, and copied to
+  // their place once the row pointers are known -- one walk over the 13 M (slot, P entry) pairs of C4 instead of two)
+  const int ap_tasks = std::max(1, std::min(HostPool::get().size(), n / 512));
+  std::vector<std::vector<int>> ap_local((size_t)(lists_on_device ? ap_tasks : 0));
+  if (lists_on_device) {
+    host_parallel_for(n, 512, [&](int lo, int hi, int task) {
+      std::vector<int> mark((size_t)nc, -1), uniq;
+      std::vector<int>& loc = ap_local[task];
+      loc.clear();
+      for (int i = lo; i < hi; ++i) {
+        uniq.clear();
+        long long prod = 0;
+        for (int k = H.rowptr[i]; k < H.rowptr[i + 1]; ++k) {
+          const int j = H.col[k];
+          prod += o.p_rowptr[j + 1] - o.p_rowptr[j];
+          for (int e = o.p_rowptr[j]; e < o.p_rowptr[j + 1]; ++e) {
+            const int c = o.p_col[e];
+            if (mark[c] != i) {
+              mark[c] = i;
+              uniq.push_back(c);
+            }
+          }
+        }
+        std::sort(uniq.begin(), uniq.end());
+        loc.insert(loc.end(), uniq.begin(), uniq.end());
+        ap_rowptr[i + 1] = (int)uniq.size();
+        app[i + 1] = prod;
+      }
+    });
+  } else
   host_parallel_for(n, 512, [&](int lo, int hi, int) {
     std::vector<int> mark((size_t)nc, -1);
     for (int i = lo; i < hi; ++i) {
@@ -1320,30 +1350,15 @@ bool sa_symbolic(const HostLevel& H, const std::vector<int>& agg, int nc, const 
   o.n_ap_prod = app[n];
   std::vector<int> ap_col((size_t)o.nap), ap_ptr((size_t)(lists_on_device ? 0 : o.nap) + 1);
   if (lists_on_device) {
-    // pattern only: the sorted distinct columns of every row (and the row of every entry, for the device's walk)
+    // pattern only: the tasks' column lists to their place (and the row of every entry, for the device's walk)
     o.ap_row.resize((size_t)o.nap);
-    host_parallel_for(n, 256, [&](int lo, int hi, int) {
-      std::vector<int> mark((size_t)nc, -1), uniq;
-      for (int i = lo; i < hi; ++i) {
-        uniq.clear();
-        for (int k = H.rowptr[i]; k < H.rowptr[i + 1]; ++k) {
-          const int j = H.col[k];
-          for (int e = o.p_rowptr[j]; e < o.p_rowptr[j + 1]; ++e) {
-            const int c = o.p_col[e];
-            if (mark[c] != i) {
-              mark[c] = i;
-              uniq.push_back(c);
-            }
-          }
-        }
-        std::sort(uniq.begin(), uniq.end());
-        const int f0 = ap_rowptr[i];
-        for (size_t q = 0; q < uniq.size(); ++q) {
-          ap_col[f0 + q] = uniq[q];
-          o.ap_row[f0 + q] = i;
-        }
-      }
+    host_parallel_for(n, 512, [&](int lo, int hi, int task) {
+      const std::vector<int>& loc = ap_local[task];
+      std::copy(loc.begin(), loc.end(), ap_col.begin() + ap_rowptr[lo]);
+      for (int i = lo; i < hi; ++i)
+        for (int f = ap_rowptr[i]; f < ap_rowptr[i + 1]; ++f) o.ap_row[f] = i;
     });
+    ap_local.clear();
     lap("AP pattern");
   } else {
   o.ap_a.resize(nprod_ap);
@@ -1397,6 +1412,38 @@ bool sa_symbolic(const HostLevel& H, const std::vector<int>& agg, int nc, const 
   C.n = nc;
   C.rowptr.assign((size_t)nc + 1, 0);
   std::vector<long long> rpp((size_t)nc + 1, 0);
+  const int rap_tasks = std::max(1, std::min(HostPool::get().size(), nc / 64));
+  std::vector<std::vector<int>> rap_local((size_t)(lists_on_device ? rap_tasks : 0));
+  if (lists_on_device) {   // counts and sorted distinct columns in one traversal (see A P above)
+    host_parallel_for(nc, 64, [&](int lo, int hi, int task) {
+      std::vector<int> mark((size_t)nc, -1), uniq;
+      std::vector<int>& loc = rap_local[task];
+      loc.clear();
+      for (int a = lo; a < hi; ++a) {
+        uniq.clear();
+        long long prod = 0;
+        bool diag = false;
+        for (int t = t_ptr[a]; t < t_ptr[a + 1]; ++t) {
+          const int i = o.t_row[t];
+          for (int f = ap_rowptr[i]; f < ap_rowptr[i + 1]; ++f) {
+            const int c = ap_col[f];
+            prod += c >= a;
+            if (mark[c] != a) {
+              mark[c] = a;
+              if (c != a) uniq.push_back(c);
+              else diag = true;
+            }
+          }
+        }
+        std::sort(uniq.begin(), uniq.end());
+        loc.push_back(a);   // diagonal slot first (BsrDev convention; every aggregate reaches itself: its own members' rows)
+        loc.insert(loc.end(), uniq.begin(), uniq.end());
+        C.rowptr[a + 1] = (int)uniq.size() + 1;
+        rpp[a + 1] = prod;
+        (void)diag;
+      }
+    });
+  } else
   host_parallel_for(nc, 64, [&](int lo, int hi, int) {
     std::vector<int> mark((size_t)nc, -1);
     for (int a = lo; a < hi; ++a) {
@@ -1430,30 +1477,13 @@ bool sa_symbolic(const HostLevel& H, const std::vector<int>& agg, int nc, const 
   C.col.resize(C.nslot);
   std::vector<int> rap_ptr((size_t)(lists_on_device ? 0 : C.nslot) + 1);
   if (lists_on_device) {
-    host_parallel_for(nc, 64, [&](int lo, int hi, int) {
-      std::vector<int> mark((size_t)nc, -1), uniq;
-      for (int a = lo; a < hi; ++a) {
-        uniq.clear();
-        for (int t = t_ptr[a]; t < t_ptr[a + 1]; ++t) {
-          const int i = o.t_row[t];
-          for (int f = ap_rowptr[i]; f < ap_rowptr[i + 1]; ++f) {
-            const int c = ap_col[f];
-            if (mark[c] != a) {
-              mark[c] = a;
-              if (c != a) uniq.push_back(c);
-            }
-          }
-        }
-        std::sort(uniq.begin(), uniq.end());
-        const int s0 = C.rowptr[a];   // diagonal slot first (BsrDev convention), then ascending columns
-        C.row[s0] = a;
-        C.col[s0] = a;
-        for (size_t q = 0; q < uniq.size(); ++q) {
-          C.row[s0 + 1 + q] = a;
-          C.col[s0 + 1 + q] = uniq[q];
-        }
-      }
+    host_parallel_for(nc, 64, [&](int lo, int hi, int task) {
+      const std::vector<int>& loc = rap_local[task];
+      std::copy(loc.begin(), loc.end(), C.col.begin() + C.rowptr[lo]);
+      for (int a = lo; a < hi; ++a)
+        for (int k = C.rowptr[a]; k < C.rowptr[a + 1]; ++k) C.row[k] = a;
     });
+    rap_local.clear();
   } else {
   o.rap_a.resize(nprod_rap);
   o.rap_b.resize(nprod_rap);

@@ -391,8 +391,10 @@ struct RowPlan {
 };
 
 // Row plan, first half: hessian order, internal (Hilbert) row order, compact slots per row.
+// `known_free`: the hessian order when the caller has already validated the edge list and listed the free active
+// vertices (build_edges does both for the chi2 path): the pass over the edges is then not repeated.
 int plan_rows_order(int V, const double* poses, const uint8_t* fixed, int E, const int32_t* ei, const int32_t* ej,
-                    std::string* err, RowPlan& P) {
+                    std::string* err, RowPlan& P, const std::vector<int>* known_free = nullptr) {
   const bool verbose = std::getenv("SGO_VERBOSE") != nullptr && (E > 200000 || std::atoi(std::getenv("SGO_VERBOSE")) > 1);
   double tl = wall_s();
   auto lap = [&](const char* what) {
@@ -400,24 +402,28 @@ int plan_rows_order(int V, const double* poses, const uint8_t* fixed, int E, con
     if (verbose) std::fprintf(stderr, "[sgo]   plan %-18s %.1f ms\n", what, 1e3 * (t - tl));
     tl = t;
   };
-  std::vector<int> deg(V, 0);
-  for (int e = 0; e < E; ++e) {
-    int a = ei[e], b = ej[e];
-    if (a < 0 || a >= V || b < 0 || b >= V) {
-      *err = "edge " + std::to_string(e) + " references a vertex outside [0, V)";
-      return SGO_EINVAL;
+  if (known_free) {
+    P.free_id = *known_free;
+  } else {
+    std::vector<int> deg(V, 0);
+    for (int e = 0; e < E; ++e) {
+      int a = ei[e], b = ej[e];
+      if (a < 0 || a >= V || b < 0 || b >= V) {
+        *err = "edge " + std::to_string(e) + " references a vertex outside [0, V)";
+        return SGO_EINVAL;
+      }
+      if (a == b) {
+        *err = "edge " + std::to_string(e) + " is a self edge";
+        return SGO_EINVAL;
+      }
+      deg[a]++;
+      deg[b]++;
     }
-    if (a == b) {
-      *err = "edge " + std::to_string(e) + " is a self edge";
-      return SGO_EINVAL;
-    }
-    deg[a]++;
-    deg[b]++;
+    // active free vertices in ascending id = g2o's hessian order (initializeOptimization)
+    P.free_id.clear();
+    for (int v = 0; v < V; ++v)
+      if (!fixed[v] && deg[v] > 0) P.free_id.push_back(v);
   }
-  // active free vertices in ascending id = g2o's hessian order (initializeOptimization)
-  P.free_id.clear();
-  for (int v = 0; v < V; ++v)
-    if (!fixed[v] && deg[v] > 0) P.free_id.push_back(v);
   const int n = P.n = (int)P.free_id.size();
   lap("degrees");
   // internal row order: Hilbert index of the initial position (ties and non-finite poses: by id)
@@ -581,43 +587,75 @@ void plan_rows_tiles(int tile_div, RowPlan& P) {
       if (attempt == 0) {
         // equal stored blocks per tile, a tile closed early when its LDS need (tracked exactly while rows are added:
         // rows, distinct outside columns, intra-tile pairs) would pass the budget
-        int stamp = 1 << 20;
+        // The greedy cut runs over kSeg row segments of equal slot counts in parallel (a segment starts a tile): one
+        // sequential pass over the 2 M slots of C4 took 5-6 ms of the set-up's critical path.
+        constexpr int kSeg = 8;
+        const int nseg = (n >= 32768 && HostPool::get().size() >= 4) ? kSeg : 1;
+        int seg_row[kSeg + 1];
+        for (int q = 0; q <= nseg; ++q) {
+          const long long want = (long long)ns * q / nseg;
+          seg_row[q] = q == nseg ? n : (int)(std::lower_bound(rowptr.begin(), rowptr.begin() + n, (int)want) - rowptr.begin());
+        }
+        std::vector<std::vector<int>> seg_mark((size_t)nseg);
+        std::vector<std::vector<TileDesc>> seg_tiles((size_t)nseg);
+        long long seg_total[kSeg];
+        int seg_by_target[kSeg], seg_stamp[kSeg];
+        for (int q = 0; q < nseg; ++q) seg_stamp[q] = 1 << 20;
         for (int pass = 0; pass < 4; ++pass) {
+          host_parallel_for(nseg, 1, [&](int q0, int q1, int) {
+            for (int q = q0; q < q1; ++q) {
+              std::vector<int>& mk = seg_mark[q];
+              if (mk.empty()) mk.assign(std::max(n, 1), -1);
+              std::vector<TileDesc>& out = seg_tiles[q];
+              out.clear();
+              int& stamp = seg_stamp[q];
+              long long total = 0;
+              int r = seg_row[q], by_target = 0;
+              const int rend = seg_row[q + 1];
+              while (r < rend) {
+                TileDesc T{};
+                T.row0 = r;
+                ++stamp;
+                long long blocks = 0, halo = 0, staged = 0;
+                while (r < rend && (r == T.row0 || (blocks < target && r - T.row0 < 4096))) {
+                  long long db = 0, dh = 0, ds = 0;
+                  for (int k = rowptr[r]; k < rowptr[r + 1]; ++k) {
+                    const int cc = col[k];
+                    if (cc < 0) continue;
+                    if (cc >= T.row0 && cc < r) {
+                      ++ds;            // the pair is inside the tile: counted as a block with its earlier row, staged here
+                    } else {
+                      ++db;
+                      if (mk[cc] != stamp) {
+                        mk[cc] = stamp;
+                        ++dh;
+                      }
+                    }
+                  }
+                  const long long back = mk[r] == stamp ? 1 : 0;   // r was an outside column of the tile's earlier rows
+                  const long long need = 24 * (2 * (long long)(r + 1 - T.row0) + (halo + dh - back) + (staged + ds));
+                  if (r > T.row0 && need > lds_budget) break;   // (the marks this row left carry a stamp no later tile uses)
+                  blocks += db;
+                  halo += dh - back;
+                  staged += ds;
+                  ++r;
+                }
+                T.row1 = r;
+                total += blocks;
+                by_target += blocks >= target;
+                out.push_back(T);
+              }
+              seg_total[q] = total;
+              seg_by_target[q] = by_target;
+            }
+          });
           tiles.clear();
           long long total = 0;
-          int r = 0, by_target = 0;
-          while (r < n) {
-            TileDesc T{};
-            T.row0 = r;
-            ++stamp;
-            long long blocks = 0, halo = 0, staged = 0;
-            while (r < n && (r == T.row0 || (blocks < target && r - T.row0 < 4096))) {
-              long long db = 0, dh = 0, ds = 0;
-              for (int k = rowptr[r]; k < rowptr[r + 1]; ++k) {
-                const int cc = col[k];
-                if (cc < 0) continue;
-                if (cc >= T.row0 && cc < r) {
-                  ++ds;            // the pair is inside the tile: counted as a block with its earlier row, staged here
-                } else {
-                  ++db;
-                  if (mark[cc] != stamp) {
-                    mark[cc] = stamp;
-                    ++dh;
-                  }
-                }
-              }
-              const long long back = mark[r] == stamp ? 1 : 0;   // r was an outside column of the tile's earlier rows
-              const long long need = 24 * (2 * (long long)(r + 1 - T.row0) + (halo + dh - back) + (staged + ds));
-              if (r > T.row0 && need > lds_budget) break;   // (the marks this row left carry a stamp no later tile uses)
-              blocks += db;
-              halo += dh - back;
-              staged += ds;
-              ++r;
-            }
-            T.row1 = r;
-            total += blocks;
-            by_target += blocks >= target;
-            tiles.push_back(T);
+          int by_target = 0;
+          for (int q = 0; q < nseg; ++q) {
+            tiles.insert(tiles.end(), seg_tiles[q].begin(), seg_tiles[q].end());
+            total += seg_total[q];
+            by_target += seg_by_target[q];
           }
           const int K = (int)tiles.size();
           // Graphs whose halo fills the LDS long before a CU's share of the blocks is reached (long-range closures;
@@ -771,7 +809,9 @@ int build_structure(sgo_ctx* c, int V, const double* poses, const uint8_t* fixed
   RowPlan P;
   const int tile_div = c->cu_count > 0 ? c->cu_count : 256;   // one tile per CU: the larger the tiles, the fewer pairs straddle two of them
   {
-    const int prc = plan_rows_order(V, poses, fixed, E, ei, ej, &c->err, P);
+    // (build_edges has validated the edges and listed the free active vertices of this very graph; the lazy path of
+    // graphs that took the direct solver keeps the lists too)
+    const int prc = plan_rows_order(V, poses, fixed, E, ei, ej, &c->err, P, (int)c->free_id.size() == c->n && c->V == V && c->E == E ? &c->free_id : nullptr);
     if (prc != SGO_OK) return prc;
   }
   const bool verbose = c->opts.verbose && (E > 200000 || c->opts.verbose > 1);
