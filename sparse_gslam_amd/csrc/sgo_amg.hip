@@ -1006,7 +1006,7 @@ std::vector<int> make_groups(const std::vector<int>& ptr) {
 
 // Greedy root-node aggregation (Vanek et al.) on the strength graph
 //   strong(i,j)  <=>  w_ij >= theta * sqrt(w_ii w_jj)
-int aggregate(const HostLevel& L, const std::vector<double>& w, double theta, std::vector<int>& agg) {
+int aggregate(const HostLevel& L, const std::vector<double>& w, double theta, std::vector<int>& agg, ChunkArena* scratch = nullptr) {
   const int n = L.n;
   agg.assign(n, -1);
   const int* visit = L.visit.size() == (size_t)n ? L.visit.data() : nullptr;
@@ -1029,8 +1029,20 @@ int aggregate(const HostLevel& L, const std::vector<double>& w, double theta, st
     }
   });
   for (int t = 0; t < n; ++t) sptr[t + 1] += sptr[t];
-  std::vector<int> scol((size_t)std::max(sptr[n], 1));
-  std::vector<double> sw((size_t)std::max(sptr[n], 1));
+  // (from the set-up's scratch arena when there is one: its pages are warm, a fresh 24 MB would be faulted in here)
+  std::vector<int> scol_own;
+  std::vector<double> sw_own;
+  int* scol;
+  double* sw;
+  if (scratch) {
+    scol = (int*)scratch->take(sizeof(int) * (size_t)std::max(sptr[n], 1));
+    sw = (double*)scratch->take(sizeof(double) * (size_t)std::max(sptr[n], 1));
+  } else {
+    scol_own.resize((size_t)std::max(sptr[n], 1));
+    sw_own.resize((size_t)std::max(sptr[n], 1));
+    scol = scol_own.data();
+    sw = sw_own.data();
+  }
   host_parallel_for(n, 2048, [&](int lo, int hi, int) {
     for (int t = lo; t < hi; ++t) {
       const int i = visit ? visit[t] : t;
@@ -1118,6 +1130,9 @@ struct UVec {
     n = count;
   }
   int* data() { return p; }
+  int* begin() { return p; }
+  int& operator[](size_t i) { return p[i]; }
+  const int& operator[](size_t i) const { return p[i]; }
   size_t size() const { return n; }
 };
 int* dev_upload(DevArena* pool, const UVec& v, hipStream_t s) {
@@ -1126,7 +1141,8 @@ int* dev_upload(DevArena* pool, const UVec& v, hipStream_t s) {
   return d;
 }
 struct SaHost {
-  std::vector<int> p_rowptr, p_row, p_col, val_src, val_tgt, val_grp;
+  std::vector<int> p_rowptr, p_row, p_col, val_grp;
+  UVec val_src, val_tgt;   // (the large lists live in the set-up's scratch arena: storage kept between set-ups, no fresh pages)
   std::vector<int> r_grp, t_pos, t_row, t_col, t_grp;
   int nap = 0;
   UVec ap_a, ap_b, ap_tgt;
@@ -1136,7 +1152,8 @@ struct SaHost {
   std::vector<int> rap_grp, rap_mirror;
   // lists_on_device: the product lists (ap_*, rap_*) are NOT made here; the patterns they follow from are kept instead
   bool lists_on_device = false;
-  std::vector<int> ap_rowptr, ap_col, ap_row, t_ptr, t_idx;
+  std::vector<int> ap_rowptr, t_ptr, t_idx;
+  UVec ap_col, ap_row;
   long long n_ap_prod = 0, n_rap_prod = 0;
 };
 
@@ -1348,7 +1365,9 @@ bool sa_symbolic(const HostLevel& H, const std::vector<int>& agg, int nc, const 
   o.nap = ap_rowptr[n];
   const int nprod_ap = (int)app[n];
   o.n_ap_prod = app[n];
-  std::vector<int> ap_col((size_t)o.nap), ap_ptr((size_t)(lists_on_device ? 0 : o.nap) + 1);
+  UVec& ap_col = o.ap_col;
+  ap_col.resize((size_t)o.nap);
+  std::vector<int> ap_ptr((size_t)(lists_on_device ? 0 : o.nap) + 1);
   if (lists_on_device) {
     // pattern only: the tasks' column lists to their place (and the row of every entry, for the device's walk)
     o.ap_row.resize((size_t)o.nap);
@@ -1561,7 +1580,6 @@ bool sa_symbolic(const HostLevel& H, const std::vector<int>& agg, int nc, const 
   lap("RAP fill");
   if (lists_on_device) {
     o.ap_rowptr = std::move(ap_rowptr);
-    o.ap_col = std::move(ap_col);
     o.t_ptr = std::move(t_ptr);
     o.t_idx = std::move(t_idx);
   }
@@ -1593,8 +1611,9 @@ void host_coarsen(const HostLevel& H, const std::vector<double>& w, const AmgCon
   auto ms_since = [](std::chrono::steady_clock::time_point t) {
     return 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count();
   };
-  int nc = aggregate(H, w, theta_l, agg);
-  if (nc > 0.9 * n) nc = aggregate(H, w, 0.0, agg);  // stalled: treat every connection as strong
+  if (scratch) scratch->rewind();   // (the previous level's lists have been uploaded: amg_create synchronises per level)
+  int nc = aggregate(H, w, theta_l, agg, scratch);
+  if (nc > 0.9 * n) nc = aggregate(H, w, 0.0, agg, scratch);  // stalled: treat every connection as strong
   if (nc > 0.9 * n || nc < 1) {                        // cannot coarsen further
     o.stop = true;
     return;
@@ -1619,6 +1638,7 @@ void host_coarsen(const HostLevel& H, const std::vector<double>& w, const AmgCon
   if (scratch) {   // everything of the previous level has been uploaded (stream synchronised by the caller)
     scratch->rewind();
     sa.ap_a.arena = sa.ap_b.arena = sa.ap_tgt.arena = scratch;
+    sa.val_src.arena = sa.val_tgt.arena = sa.ap_col.arena = sa.ap_row.arena = scratch;
     sa.rap_a.arena = sa.rap_b.arena = sa.rap_tgt.arena = scratch;
   }
   bool smooth = cfg.smooth;

@@ -216,7 +216,7 @@ void l0_join(sgo_ctx* c, bool keep) {
     amg_host_l0_free(c->l0_pre);
     c->l0_pre = nullptr;
   }
-  if (!keep) c->l0_w = std::vector<double>();
+  // (c->l0_w keeps its storage: a fresh 17-MB vector per call is 4000 page faults on the set-up's critical path)
 }
 void l0_discard(sgo_ctx* c) { l0_join(c, false); }
 
@@ -386,6 +386,7 @@ struct RowPlan {
   std::vector<int> col;          // [ns] column (internal row) of the slot, -1: fixed column
   std::vector<TileDesc> tiles;   // row0 / row1 filled in
   std::vector<int> tile_of_row;
+  std::vector<int> chunk_cnt;    // scratch of the slot placement ([chunk][row])
   int tile_lds = 0;
   bool tiles_ok = true;
 };
@@ -494,7 +495,8 @@ int plan_rows_order(int V, const double* poses, const uint8_t* fixed, int E, con
   rowptr.assign((size_t)n + 1, 0);
   const int nchunk = (E >= 200000 && n > 0) ? std::max(1, std::min(HostPool::get().size(), 16)) : 1;
   auto chunk_lo = [&](int t) { return (int)((long long)E * t / nchunk); };
-  std::vector<int> ccnt((size_t)nchunk * std::max(n, 1), 0);   // [chunk][row], turned into the chunk's first position per row
+  std::vector<int>& ccnt = P.chunk_cnt;   // [chunk][row], turned into the chunk's first position per row
+  ccnt.assign((size_t)nchunk * std::max(n, 1), 0);
   host_parallel_for(nchunk, 1, [&](int t0, int t1, int) {
     for (int t = t0; t < t1; ++t) {
       int* c = ccnt.data() + (size_t)t * std::max(n, 1);
@@ -806,7 +808,14 @@ int build_structure(sgo_ctx* c, int V, const double* poses, const uint8_t* fixed
                     const int32_t* ej) {
   const double tb0 = wall_s();
   l0_discard(c);   // a helper thread of an earlier set-up that was never consumed
-  RowPlan P;
+  // The plan's vectors (slot positions, columns, per-chunk counters: ~30 MB on C4) keep their storage between calls of
+  // this thread: the reference re-initialises its graph before every optimize(20), and fresh pages cost 2-3 ms of page
+  // faults per set-up on the critical path.
+  static thread_local RowPlan plan_storage;
+  RowPlan& P = plan_storage;
+  P.tiles.clear();
+  P.tile_lds = 0;
+  P.tiles_ok = true;
   const int tile_div = c->cu_count > 0 ? c->cu_count : 256;   // one tile per CU: the larger the tiles, the fewer pairs straddle two of them
   {
     // (build_edges has validated the edges and listed the free active vertices of this very graph; the lazy path of
