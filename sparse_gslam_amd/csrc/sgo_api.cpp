@@ -582,7 +582,6 @@ void plan_rows_tiles(int tile_div, RowPlan& P) {
     long long target = std::max<long long>(512, (nblk / 2 * 5 / 4 + tile_div - 1) / tile_div);   // stored blocks per tile
     long long starget = std::max<long long>(512, (nblk / 2 + tile_div - 1) / tile_div);          // pairs per tile (fallback)
     std::vector<int> mark(std::max(n, 1), -1);
-    bool lds_limited = false;
     for (int attempt = 0; attempt < 7; ++attempt) {
       long long lds = 0;
       bool too_many = false;
@@ -665,7 +664,7 @@ void plan_rows_tiles(int tile_div, RowPlan& P) {
           // and with many tiles per CU the uneven block counts average out over a workgroup's tiles.  No larger block
           // target changes this cut, and the slot-balanced fallback would only find smaller tiles by repeated halving.
           if (K >= 4 * tile_div && 8 * by_target < K) {
-            lds_limited = true;
+            too_many = false;   // (an earlier pass with a smaller target may have set it): the cut is verified and taken
             break;
           }
           too_many = K > tile_div && target > 512;
