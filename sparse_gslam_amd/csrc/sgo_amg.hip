@@ -1287,6 +1287,18 @@ bool sa_symbolic(const HostLevel& H, const std::vector<int>& agg, int nc, const 
   std::vector<long long> app((size_t)n + 1, 0);
   // (device-lists mode: the sorted distinct columns are collected in the same traversal, per task, and copied to
   // their place once the row pointers are known -- one walk over the 13 M (slot, P entry) pairs of C4 instead of two)
+  {   // the number of products is a sum of P row lengths over the slots: checked before any pattern is collected
+      // (dense coarse levels of graphs with long-range closures fail it: C5 level 2, 59 ms of pattern work for nothing)
+    std::vector<long long> part((size_t)std::max(1, std::min(HostPool::get().size(), n / 2048)) + 1, 0);
+    host_parallel_for(n, 2048, [&](int lo, int hi, int task) {
+      long long sum = 0;
+      for (int k = H.rowptr[lo]; k < H.rowptr[hi]; ++k) sum += o.p_rowptr[H.col[k] + 1] - o.p_rowptr[H.col[k]];
+      part[task] = sum;
+    });
+    long long total = 0;
+    for (long long v : part) total += v;
+    if (total > budget) return false;
+  }
   const int ap_tasks = std::max(1, std::min(HostPool::get().size(), n / 512));
   std::vector<std::vector<int>> ap_local((size_t)(lists_on_device ? ap_tasks : 0));
   if (lists_on_device) {
