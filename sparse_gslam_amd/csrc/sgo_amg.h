@@ -11,14 +11,14 @@
 namespace sgo {
 
 struct AmgConfig {
-  double theta = 0.02;     // strength-of-connection threshold on level 0 (env SGO_AMG_THETA)
-  double theta_coarse = 0.02;  // ... on the coarser levels (env SGO_AMG_THETA_COARSE)
-  double omega = 0.8;      // block-Jacobi damping (env SGO_AMG_OMEGA)
+  double theta = 0.02;     // strength-of-connection threshold on level 0
+  double theta_coarse = 0.02;  // ... on the coarser levels
+  double omega = 0.8;      // block-Jacobi damping
   int max_levels = 10;
-  int nu_coarse = 1;           // ... on the coarser V-cycle levels (env SGO_AMG_NU_COARSE); amg_create picks 2 for
+  int nu_coarse = 1;           // smoothing sweeps on the coarser V-cycle levels; amg_create picks 2 for
                                // graphs with >= 10^6 level-0 blocks, where a coarse sweep is cheap next to level 0
   bool smooth = true;          // smoothed aggregation: P = (I - omega_p D^-1 A) T (env SGO_AMG_SMOOTH=0: tentative P)
-  double omega_p = 0.66;       // damping of the prolongator smoothing step (env SGO_AMG_OMEGA_P)
+  double omega_p = 0.66;       // damping of the prolongator smoothing step
   bool lists_on_device = true;  // the product lists of A P and P^T A P are made on the device from the host's patterns
                                 // (env SGO_AMG_LISTS=host: on the host, the reference the device lists are tested against)
   int coarsest_nodes = 400;  // stop coarsening at or below this many nodes; that level is inverted densely

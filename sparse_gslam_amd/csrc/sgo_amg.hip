@@ -982,7 +982,7 @@ T* dev_upload(DevArena* pool, const std::vector<T>& v, hipStream_t s) {
 }
 
 // wave groups over segments [ptr[i], ptr[i+1]): whole segments packed up to 64 items; a longer
-// segment is its own group (same rule as the level-0 row groups in sgo_api.cpp)
+// segment is its own group (same rule as the level-0 row groups in sgo_structure.cpp)
 std::vector<int> make_groups(const std::vector<int>& ptr) {
   std::vector<int> grp;
   grp.push_back(0);
@@ -1602,7 +1602,7 @@ bool sa_symbolic(const HostLevel& H, const std::vector<int>& agg, int nc, const 
 // Everything the host decides about one coarsening step: aggregates, patterns and product lists of the smoothed
 // transfer (or the tentative one's Galerkin map), structure of the next level.  Depends on the level's structure and
 // on the strength weights only -- for level 0 it can therefore run on a helper thread while the caller still builds
-// the level-0 storage (amg_host_l0_start, sgo_api.cpp).
+// the level-0 storage (build_structure, sgo_structure.cpp).
 struct HostCoarse {
   std::vector<int> agg, visit_c, mem_ptr, mem;
   int nc = 0;
@@ -2202,21 +2202,15 @@ int* dev_make_groups(hipStream_t s, DevArena* pool, const int* ptr, int nseg, in
 // values, the environment overrides and the size-dependent choices.
 AmgConfig amg_effective_config(const AmgConfig& cfg_in, int n, int nslot) {
   AmgConfig cfg = cfg_in;
-  if (const char* e = std::getenv("SGO_AMG_THETA")) cfg.theta = std::atof(e);
-  if (const char* e = std::getenv("SGO_AMG_OMEGA")) cfg.omega = std::atof(e);
-  if (const char* e = std::getenv("SGO_AMG_THETA_COARSE")) cfg.theta_coarse = std::atof(e);
   // A sweep on a coarse level is a 5-10 us launch whatever the graph; it pays when a PCG iteration is
   // dominated by level 0 (C4: 31 instead of 39 iterations, 9.7 instead of 10.6 ms) and costs a few
   // per cent on graphs whose level 0 is itself launch-bound (10k / 40k: 2.67 instead of 2.51 ms).
   cfg.nu_coarse = nslot >= 1000000 ? 2 : 1;
-  if (const char* e = std::getenv("SGO_AMG_NU_COARSE")) cfg.nu_coarse = std::atoi(e);
   if (const char* e = std::getenv("SGO_AMG_SMOOTH")) cfg.smooth = std::atoi(e) != 0;
-  if (const char* e = std::getenv("SGO_AMG_OMEGA_P")) cfg.omega_p = std::atof(e);
   if (const char* e = std::getenv("SGO_AMG_LISTS")) cfg.lists_on_device = std::string(e) != "host";
   // larger graphs afford a larger dense coarsest level (its inverse costs O(N^3) once per GN
   // iteration, one K-cycle level less halves the coarse-level launches of every PCG iteration)
   cfg.coarsest_nodes = std::min(1000, std::max(cfg.coarsest_nodes, n / 1500));
-  if (const char* e = std::getenv("SGO_AMG_COARSEST")) cfg.coarsest_nodes = std::atoi(e);
   return cfg;
 }
 

@@ -1,0 +1,306 @@
+// sgo_ctx.h -- the context behind include/sgo.h's sgo_ctx and the declarations shared by the host sources of libsgo:
+//   sgo_plan.cpp       host-only row plan (hessian order, Hilbert row order, compact slots, tiles)
+//   sgo_structure.cpp  device-resident graph: edge arrays, level-0 storage, tile view, logical view
+//   sgo_solve.cpp      Gauss-Newton driver: chi2, linearise, PCG loop (hipGraph replay), multigrid set-up calls
+//   sgo_api.cpp        the C-ABI entry points
+// Not part of the public ABI.
+#pragma once
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "sgo_amg.h"
+#include "sgo_comm.h"
+#include "sgo_direct.h"
+#include "sgo_internal.h"
+
+using namespace sgo;   // (internal header: the global sgo_ctx of the C-ABI is made of sgo:: types)
+
+// Bump allocator over one host block that only ever grows (uninitialised memory, 64-byte aligned).
+struct HostArena {
+  std::unique_ptr<char[]> mem;
+  size_t cap = 0, used = 0;
+  void reserve(size_t bytes) {   // invalidates earlier take()s
+    used = 0;
+    if (bytes <= cap) return;
+    mem.reset();
+    cap = bytes + bytes / 4;
+    mem.reset(new char[cap + 64]);
+  }
+  void* take(size_t bytes) {
+    char* base = (char*)(((uintptr_t)mem.get() + 63) & ~(uintptr_t)63);
+    void* q = base + used;
+    used += (bytes + 63) & ~(size_t)63;
+    return used <= cap ? q : nullptr;
+  }
+};
+
+struct sgo_ctx {
+  int device = 0;
+  HostArena stage;
+  ChunkArena amg_scratch;   // host lists of the multigrid set-up, reused across set-ups
+  hipStream_t stream = nullptr;
+  sgo_opts opts{};
+  std::string err;
+  Comm comm;
+  int shard_u0 = 0, shard_u1 = 0, shard_units = 0;   // multi-GPU: this rank's range of level-0 work units (tiles)
+  int shard_row0 = 0, shard_row1 = 0;                //            = these rows
+  std::vector<int> unit_row0;                        // first row of every work unit (+ n at the end)
+
+  // graph (host)
+  bool has_graph = false;
+  int V = 0, E = 0, n = 0;
+  std::vector<int> free_id;      // hessian index (g2o order: free active vertices in ascending id) -> vertex id
+  std::vector<int> row_of_asc;   // hessian index -> internal row (Hilbert order, build_structure)
+  HostLevel H0;                  // logical level-0 structure on the host (multigrid set-up input)
+  double setup_seconds = 0.0;
+
+  // device
+  DevArena graph_arena;           // device arrays of the resident graph (rewound by the next set_graph)
+  DevArena amg_arena;             // ... of the multigrid hierarchy (rewound when the hierarchy is rebuilt)
+  double* d_poses = nullptr;
+  int* d_free_id = nullptr;
+  EdgeListDev el;
+  Sym0Dev S0;                    // level-0 Hessian, symmetric storage (the solve's products run on this)
+  Tile0Dev T0;                   // ... its tile view (ntile == 0: no tile view, products use the wave-group kernel)
+  BsrDev A;                      // its logical view (multigrid set-up kernels)
+  EdgeSlotsDev es;
+  double *d_dgb = nullptr, *d_b = nullptr, *d_x = nullptr, *d_r = nullptr, *d_z = nullptr, *d_p = nullptr,
+         *d_q = nullptr, *d_s1 = nullptr, *d_s2 = nullptr, *d_e2 = nullptr;
+  double* d_partials = nullptr;   // [3][kMaxPartials]
+  double* d_hist = nullptr;       // [SGO_MAX_ITERS + 2][2] chi2 history
+  PcgScalars* d_S = nullptr;
+  PcgScalars* h_S = nullptr;      // pinned
+  double* h_hist = nullptr;       // pinned
+  bool linearized = false;
+
+  Amg* amg = nullptr;             // non-null when the AMG preconditioner is active
+  bool amg_pending = false;       // the hierarchy is built on first use (graphs that optimize() through `direct`)
+  bool rows_pending = false;      // ... and so are the row plan / level-0 structures of the PCG path (build_structure)
+  std::vector<uint8_t> lz_fixed;  // what that deferred build needs of the caller's arrays
+  std::vector<int32_t> lz_ei, lz_ej;
+  Direct* direct = nullptr;       // small-graph path: optimize() is one launch (sgo_direct.h)
+  std::string direct_why;         // why the last graph did not qualify for it
+  DirectResult* d_dres = nullptr;
+  DirectResult* h_dres = nullptr; // pinned
+  double* d_zparts = nullptr;     // [2][kMaxPartials] partials of r.z from the cycle's last kernel
+  std::string solver_desc;
+  std::string solver_text;        // what sgo_solver_description hands out
+
+  hipGraphExec_t pcg_exec = nullptr;
+  int pcg_exec_chunk = 0;
+  int pcg_pred = 0;               // PCG iterations of the previous solve (prediction for the next)
+  double tol_scale = 1.0;         // < 1 on chain-like graphs (see sgo_set_graph_se2)
+  double* d_xprev = nullptr;      // the previous Gauss-Newton step of the running sgo_optimize_gn (PCG warm start)
+  bool warm_valid = false;
+  double bb_ref = 0.0;            // |b|^2 of the first solve of the running sgo_optimize_gn (0: relative tolerance only)
+  double tol_cap = 0.0;           // loosest relative tolerance the absolute criterion may reach (0: off; opts.pcg_tol_cap)
+  int pcg_softcap = 0;            // > 0: iteration cap of the next solve (sgo_optimize_gn: stale-hierarchy bail-out)
+  // level 0's multigrid host analysis running ahead on a helper thread (build_structure starts it, build_amg joins it)
+  AmgHostL0* l0_pre = nullptr;
+  std::thread l0_thread;
+  std::vector<double> l0_w;
+  int amg_best = 0;               // fewest PCG iterations seen with the current hierarchy (0: none yet);
+                                  // kept across optimize() calls so that a hierarchy adapted to other poses is noticed
+  PcgScalars* h_S2 = nullptr;     // pinned [2]: pipelined read-back of the stop flag
+  hipEvent_t ev_S[2] = {nullptr, nullptr};
+
+  // profiling
+  struct Rec { int kid; hipEvent_t a, b; };
+  std::vector<hipEvent_t> ev_pool;
+  std::vector<hipEvent_t> iter_events;   // time stamps of sgo_optimize_gn, reused across calls
+  std::vector<Rec> pending;
+  double prof_ms[K_COUNT] = {0};
+  int64_t prof_launches[K_COUNT] = {0};
+  double prof_bytes[K_COUNT] = {0};
+  void* amg_scope = nullptr;  // Scope* of the AMG launch being bracketed
+  double prof_null_ms = -1.0; // time of an empty event bracket on this stream (calibration)
+};
+
+namespace sgo {
+
+extern thread_local std::string g_err;   // error text of context-free calls (sgo_last_error(NULL))
+
+inline double wall_s() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// Static-partition parallel loop over [0, n) on the host pool (structure build only).
+template <class F>
+void parallel_for(int n, F&& fn) {
+  host_parallel_for(n, 8192, [&fn](int lo, int hi, int) { fn(lo, hi); });
+}
+
+#define HIP_TRY(ctx, expr)                                                                     \
+  do {                                                                                         \
+    hipError_t e_ = (expr);                                                                    \
+    if (e_ != hipSuccess) {                                                                    \
+      (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                          \
+      return SGO_EHIP;                                                                         \
+    }                                                                                          \
+  } while (0)
+
+template <class T>
+int dalloc(sgo_ctx* c, T** p, size_t count) {
+  const size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+  void* q = c->graph_arena.take(bytes);
+  if (!q) {
+    c->err = "out of device memory (" + std::to_string(bytes) + " bytes)";
+    return SGO_ENOMEM;
+  }
+  *p = (T*)q;
+  return SGO_OK;
+}
+
+template <class T>
+int upload(sgo_ctx* c, T** p, const std::vector<T>& v) {
+  int rc = dalloc(c, p, v.size());
+  if (rc) return rc;
+  if (!v.empty()) HIP_TRY(c, hipMemcpyAsync(*p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, c->stream));
+  return SGO_OK;
+}
+
+// Host staging buffer WITHOUT value-initialisation: the structure build writes every element it
+// later reads, and zero-filling ~300 MB of std::vector storage was a third of its time on C4.
+// The memory comes from the context's staging arena, which is kept between sgo_set_graph_se2 calls
+// (the reference re-initialises a slowly growing graph before every optimize(20)): no mmap / page
+// faults / munmap of ~300 MB per call.
+template <class T>
+struct HostBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  HostBuf(HostArena& a, size_t count) : p((T*)a.take(count * sizeof(T))), n(count) {}
+  T& operator[](size_t i) { return p[i]; }
+  const T& operator[](size_t i) const { return p[i]; }
+  T* data() { return p; }
+  size_t size() const { return n; }
+};
+template <class T>
+int upload(sgo_ctx* c, T** p, const HostBuf<T>& v) {
+  int rc = dalloc(c, p, v.n);
+  if (rc) return rc;
+  if (v.n) HIP_TRY(c, hipMemcpyAsync(*p, v.p, v.n * sizeof(T), hipMemcpyHostToDevice, c->stream));
+  return SGO_OK;
+}
+
+// ---- profiling: HIP events around each launch on the ctx stream (sgo_solve.cpp) ------------
+hipEvent_t get_event(sgo_ctx* c);
+void prof_calibrate(sgo_ctx* c);
+void prof_flush(sgo_ctx* c);
+// Brackets ONE kernel launch (default): the launch itself carries the events (SGO_LAUNCH ->
+// hipExtLaunchKernelGGL), so the measured time is the kernel's dispatch-to-completion time, as in
+// rocprofv3's kernel trace.  multi = true brackets a whole launch sequence with two event records.
+struct Scope {
+  sgo_ctx* c;
+  int kid;
+  bool multi;
+  hipEvent_t a = nullptr, b = nullptr;
+  Scope(sgo_ctx* c_, int kid_, double bytes, bool multi_ = false) : c(c_), kid(kid_), multi(multi_) {
+    if (!c->opts.profile) return;
+    if (c->prof_null_ms < 0.0) prof_calibrate(c);
+    c->prof_launches[kid]++;
+    c->prof_bytes[kid] += bytes;
+    a = get_event(c);
+    if (multi) {
+      hipEventRecord(a, c->stream);
+    } else {
+      b = get_event(c);
+      tl_launch_ev.start = a;
+      tl_launch_ev.stop = b;
+    }
+  }
+  ~Scope() {
+    if (!a) return;
+    if (multi) {
+      b = get_event(c);
+      hipEventRecord(b, c->stream);
+    } else if (tl_launch_ev.start == a) {  // no launch consumed the events: drop the sample
+      tl_launch_ev = LaunchEvents();
+      c->prof_launches[kid]--;
+      c->ev_pool.push_back(a);
+      c->ev_pool.push_back(b);
+      return;
+    }
+    c->pending.push_back({kid, a, b});
+    if (c->pending.size() >= 2048) prof_flush(c);
+  }
+};
+
+// ---- host-only row plan (sgo_plan.cpp) ------------------------------------------------------
+// The hessian index map of g2o -- free active vertices in ascending id -- is what the API speaks
+// (c->free_id, sgo_free_ids, sgo_linearize, ...).  Internally the rows are numbered along a Hilbert
+// curve through the initial poses (c->row_of_asc maps one to the other), which makes the symmetric
+// storage of Sym0Dev work: the endpoints of almost every edge end up a few hundred rows apart.
+// Host-only plan of the level-0 rows (no GPU involved; also behind sgo_plan_rows for the multi-process tests):
+// g2o's hessian order, the internal Hilbert row order, the compact slot positions of every edge and the tiles.
+struct RowPlan {
+  int n = 0, ns = 0;
+  std::vector<int> free_id;      // hessian index (free active vertices in ascending id) -> vertex id
+  std::vector<int> row_of_asc;   // hessian index -> internal row
+  std::vector<int> row_vertex;   // internal row -> vertex id
+  std::vector<int> hpos;         // vertex id -> internal row (-1: fixed or inactive)
+  std::vector<int> rowptr;       // [n + 1] compact slots of row r
+  std::vector<int> pos_i, pos_j; // [E] slot of edge e in the row of its first / second endpoint (-1: none)
+  std::vector<int> col;          // [ns] column (internal row) of the slot, -1: fixed column
+  std::vector<TileDesc> tiles;   // row0 / row1 filled in
+  std::vector<int> tile_of_row;
+  std::vector<int> chunk_cnt;    // scratch of the slot placement ([chunk][row])
+  int tile_lds = 0;
+  bool tiles_ok = true;
+};
+
+int plan_rows_order(int V, const double* poses, const uint8_t* fixed, int E, const int32_t* ei, const int32_t* ej,
+                    std::string* err, RowPlan& P, const std::vector<int>* known_free = nullptr);
+void plan_rows_tiles(int tile_div, RowPlan& P);
+int plan_rows(int V, const double* poses, const uint8_t* fixed, int E, const int32_t* ei, const int32_t* ej, int tile_div,
+              std::string* err, RowPlan& P);
+// One tile per CU of an MI355X.  A constant, not the device's CU count: every rank of a multi-GPU run -- and the
+// host-only sgo_plan_rows -- must cut the same tiles whatever device it sits on.
+constexpr int kTileDiv = 256;
+
+// ---- device-resident graph (sgo_structure.cpp) ----------------------------------------------
+void l0_join(sgo_ctx* c, bool keep);
+inline void l0_discard(sgo_ctx* c) { l0_join(c, false); }
+void free_graph(sgo_ctx* c);
+int build_edges(sgo_ctx* c, int V, const double* poses, const uint8_t* fixed, int E, const int32_t* ei, const int32_t* ej,
+                const double* meas, const double* info, const double* phi);
+int build_structure(sgo_ctx* c, int V, const double* poses, const uint8_t* fixed, int E, const int32_t* ei,
+                    const int32_t* ej);
+
+// ---- Gauss-Newton building blocks (sgo_solve.cpp) -------------------------------------------
+int do_chi2(sgo_ctx* c, double* d_out2, double* d_e2);
+int start_pcg(sgo_ctx* c, int grid);
+int do_linearize(sgo_ctx* c);
+int do_spmv(sgo_ctx* c, const double* x, double* y, bool dot, const PcgScalars* S, int* grid_out);
+int run_pcg(sgo_ctx* c);
+int build_amg(sgo_ctx* c);
+int build_rows(sgo_ctx* c, const double* poses, const uint8_t* fixed, const int32_t* ei, const int32_t* ej);
+int ensure_rows(sgo_ctx* c);
+int ensure_amg(sgo_ctx* c);
+int vec_to_device(sgo_ctx* c, const double* host_asc, double* dev);
+int vec_from_device(sgo_ctx* c, const double* dev, double* host_asc);
+int check_graph(sgo_ctx* c);
+int optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out);   // sgo_optimize_gn behind its argument checks
+double debug_spmv0_us(sgo_ctx* c, int mode, int variant, int reps);
+
+}  // namespace sgo
+
+// include/sgo.h promises that no exception crosses the C boundary: host allocations (std::vector, std::string, new)
+// inside an entry point are caught here and reported as SGO_ENOMEM / SGO_EINVAL
+#define SGO_CATCH(ctx)                                                              \
+  catch (const std::bad_alloc&) {                                                   \
+    if (ctx) (ctx)->err = "out of host memory";                                     \
+    return SGO_ENOMEM;                                                              \
+  }                                                                                 \
+  catch (const std::exception& e_) {                                                \
+    if (ctx) (ctx)->err = std::string("internal error: ") + e_.what();              \
+    return SGO_EINVAL;                                                              \
+  }                                                                                 \
+  catch (...) {                                                                     \
+    if (ctx) (ctx)->err = "internal error (unknown exception)";                     \
+    return SGO_EINVAL;                                                              \
+  }

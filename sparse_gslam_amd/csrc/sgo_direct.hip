@@ -25,6 +25,7 @@
 // Sequential depth per Gauss-Newton iteration = 2 (levels + separators) steps of ~0.3-2 us instead of
 // ~150 launches.
 #include <algorithm>
+#include <memory>
 #include <atomic>
 #include <cstring>
 #include <numeric>
@@ -877,7 +878,8 @@ Direct* direct_create(hipStream_t s, DevArena* arena, int V, int n, const int* f
   const size_t lds_bytes = lds_fixed + (xb_global ? 0 : sizeof(double) * 3 * (size_t)n);
   if (lds_bytes > kLdsBudget) return no("separator block exceeds the LDS");
 
-  Direct* d = new Direct();
+  std::unique_ptr<Direct> owner(new Direct());   // released to the caller at the end: a throwing std::vector below frees it
+  Direct* d = owner.get();
   std::vector<std::vector<int>> lcols((size_t)NL);
   for (int k = 0; k < nI; ++k) lcols[level[k]].push_back(k);
   // ---- slots: per level, per column (ascending), a column's blocks inside one wave
@@ -1026,7 +1028,6 @@ Direct* direct_create(hipStream_t s, DevArena* arena, int V, int n, const int* f
     }
     total_contrib += (long long)cl.size();
     if (total_contrib > kMaxContrib) {
-      delete d;
       return no("too much fill");
     }
     std::stable_sort(cl.begin(), cl.end(), [](const Contrib& x, const Contrib& y) { return x.target < y.target; });
@@ -1116,7 +1117,6 @@ Direct* direct_create(hipStream_t s, DevArena* arena, int V, int n, const int* f
   }
   if (e != hipSuccess) {
     *err = std::string("direct_create: ") + hipGetErrorString(e);
-    delete d;
     return nullptr;
   }
   d->info.n = n;
@@ -1126,7 +1126,7 @@ Direct* direct_create(hipStream_t s, DevArena* arena, int V, int n, const int* f
   d->info.slots = NB;
   d->info.contributions = (int)total_contrib;
   d->info.lds_bytes = lds_bytes;
-  return d;
+  return owner.release();
 }
 
 hipError_t direct_optimize(Direct* d, hipStream_t s, const EdgeListDev& el, double* d_poses, int iters, double* d_hist,

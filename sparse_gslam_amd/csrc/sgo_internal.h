@@ -4,20 +4,15 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
-#include <sched.h>
-
 #include <algorithm>
 #include <atomic>
-#include <condition_variable>
 #include <cstdint>
 #include <cstdlib>
-#include <functional>
-#include <mutex>
 #include <string>
-#include <thread>
 #include <vector>
 
 #include "sgo.h"
+#include "sgo_hostpool.h"
 
 namespace sgo {
 
@@ -67,7 +62,7 @@ __host__ __device__ inline size_t blk_at(int c, size_t k, size_t ns) {
 // ----------------------------------------------------------------------------------------
 // Level-0 Hessian in SYMMETRIC storage: H is symmetric, so every off-diagonal block is stored once
 // (72 B + indices per edge) and serves both y_i += B x_j and y_j += B^T x_i.
-//   * rows are numbered in Hilbert-curve order of the poses (sgo_api.cpp), which puts the two
+//   * rows are numbered in Hilbert-curve order of the poses (sgo_plan.cpp), which puts the two
 //     endpoints of almost every edge -- odometry steps and closures between nearby poses alike --
 //     a few hundred rows apart;
 //   * the compact slot list has, per row, one slot per incident off-diagonal block: the slot is
@@ -132,7 +127,6 @@ struct TileDesc {
 struct Tile0Dev {
   int ntile = 0;
   int lds_bytes = 0;          // dynamic LDS per workgroup (largest tile)
-  int threads = 1024;         // workgroup size (512 or 1024)
   TileDesc* tile = nullptr;
   unsigned int* cv = nullptr;       // [nu] owned slot u: LDS operand index (local row, or rows + halo number) in
                                     // bits 0..15, tile-relative staging slot of its twin in bits 16..31 (0xFFFF: none)
@@ -378,117 +372,6 @@ struct DevArena {
     chunks.clear();
   }
 };
-
-// Host worker pool for the structure builds (row plan, slot lists, multigrid pattern / product lists): up to
-// 32 threads (env SGO_HOST_THREADS; the cores this process may run on), created once per process and parked on a
-// condition variable between parallel regions -- spawning threads per region cost more than the regions of a
-// 100-ms set-up.  One region at a time (contexts on different threads queue on the pool's mutex).
-class HostPool {
- public:
-  // Two pools: lane 0 serves the calling threads, lane 1 the helper thread of the set-up pipeline (sgo_api.cpp,
-  // build_structure), whose long regions -- the multigrid's symbolic phase -- would otherwise queue behind (and hold
-  // up) the many short regions of the structure build.  host_pool_lane() selects per thread.
-  static int& lane() {
-    static thread_local int l = 0;
-    return l;
-  }
-  static HostPool& get() {
-    static HostPool p0, p1;
-    return lane() ? p1 : p0;
-  }
-  int size() const { return nthreads_; }
-  // fn(t) for t in [0, ntasks), distributed over the workers and the caller
-  template <class F>
-  void run(int ntasks, F&& fn) {
-    if (ntasks <= 0) return;
-    if (ntasks == 1 || nthreads_ <= 1) {
-      for (int t = 0; t < ntasks; ++t) fn(t);
-      return;
-    }
-    std::lock_guard<std::mutex> region(region_mu_);
-    std::function<void(int)> task = [&fn](int t) { fn(t); };
-    {
-      std::lock_guard<std::mutex> lk(mu_);
-      task_ = &task;
-      ntasks_ = ntasks;
-      next_.store(0);
-      pending_.store(ntasks);
-      ++generation_;
-    }
-    cv_.notify_all();
-    work();
-    std::unique_lock<std::mutex> lk(mu_);
-    done_cv_.wait(lk, [this] { return pending_.load() == 0; });
-    task_ = nullptr;
-  }
-
- private:
-  HostPool() {
-    int n = (int)std::thread::hardware_concurrency();
-#if defined(__linux__)
-    cpu_set_t set;
-    if (sched_getaffinity(0, sizeof(set), &set) == 0) n = CPU_COUNT(&set);
-#endif
-    n = std::max(1, std::min(n, 32));
-    if (const char* e = std::getenv("SGO_HOST_THREADS")) n = std::max(1, std::atoi(e));
-    nthreads_ = n;
-    for (int i = 1; i < n; ++i) workers_.emplace_back([this] { loop(); });
-  }
-  ~HostPool() {
-    {
-      std::lock_guard<std::mutex> lk(mu_);
-      quit_ = true;
-    }
-    cv_.notify_all();
-    for (auto& w : workers_) w.join();
-  }
-  void work() {
-    for (;;) {
-      const int t = next_.fetch_add(1);
-      if (t >= ntasks_) return;
-      (*task_)(t);
-      if (pending_.fetch_sub(1) == 1) {
-        std::lock_guard<std::mutex> lk(mu_);
-        done_cv_.notify_all();
-      }
-    }
-  }
-  void loop() {
-    long long seen = 0;
-    for (;;) {
-      {
-        std::unique_lock<std::mutex> lk(mu_);
-        cv_.wait(lk, [&] { return quit_ || generation_ != seen; });
-        if (quit_) return;
-        seen = generation_;
-      }
-      work();
-    }
-  }
-  int nthreads_ = 1;
-  std::vector<std::thread> workers_;
-  std::mutex region_mu_, mu_;
-  std::condition_variable cv_, done_cv_;
-  const std::function<void(int)>* task_ = nullptr;
-  int ntasks_ = 0;
-  std::atomic<int> next_{0}, pending_{0};
-  long long generation_ = 0;
-  bool quit_ = false;
-};
-
-// Static-partition parallel loop over [0, n) on the host pool (structure builds only).
-template <class F>
-inline void host_parallel_for(int n, int grain, F&& fn) {
-  const int T = std::max(1, std::min(HostPool::get().size(), n / std::max(1, grain)));
-  if (T == 1) {
-    fn(0, n, 0);
-    return;
-  }
-  HostPool::get().run(T, [&](int t) {
-    const int lo = (int)((long long)n * t / T), hi = (int)((long long)n * (t + 1) / T);
-    fn(lo, hi, t);
-  });
-}
 
 // ---- launch macro -------------------------------------------------------------------------
 // In profile mode (sgo_opts.profile) the bracket of the NEXT single launch is the kernel's own

@@ -120,7 +120,7 @@ __global__ __launch_bounds__(kBlock) void k_slot_expand(int ncs, const int* __re
 // The multigrid aggregation needs the Frobenius norms of the Hessian blocks at the initial poses and nothing else of
 // the matrix.  This kernel produces them straight from the edge list and the per-row slot lists -- before the level-0
 // storage (tiles, slot types) exists -- so that the host's aggregation and symbolic phase can run on a helper thread
-// while the storage is still being laid out (sgo_api.cpp, build_structure).  One thread per row walks the row's
+// while the storage is still being laid out (sgo_structure.cpp, build_structure).  One thread per row walks the row's
 // compact slots (edge, side) and evaluates each edge as k_linearize does: w of the row's logical slots -- the diagonal
 // slot first (norm of the summed R^T Ow R), then ||R^T Ow C||_F for every slot whose column is free.
 __global__ __launch_bounds__(kBlock) void k_row_strength(int n, const int* __restrict__ rowptr, const int* __restrict__ eidx,
@@ -1096,22 +1096,14 @@ void launch_spmv0t_inst(hipStream_t s, const Sym0Dev& A, const Tile0Dev& T, cons
 }
 int launch_spmv0t(hipStream_t s, const Sym0Dev& A, const Tile0Dev& T, int mode, const Spmv0Args& a) {
   // as many tile workgroups as fit the CUs' LDS are resident; more tiles are walked in a loop
-  const int per_cu = std::max(1, std::min(T.threads == 1024 ? 2 : 4, (160 * 1024) / std::max(T.lds_bytes + 512, 1)));
+  const int per_cu = std::max(1, std::min(2, (160 * 1024) / std::max(T.lds_bytes + 512, 1)));
   long long g = std::min<long long>(T.ntile, 256LL * per_cu);
   if (g < 8) g = 8;
   const int grid = (int)((g + 7) / 8 * 8);
-  if (T.threads == 1024) {
-    switch (mode) {
-      case S0_AX: launch_spmv0t_inst<S0_AX, 1024>(s, A, T, a, grid); break;
-      case S0_RESID: launch_spmv0t_inst<S0_RESID, 1024>(s, A, T, a, grid); break;
-      default: launch_spmv0t_inst<S0_JACOBI, 1024>(s, A, T, a, grid); break;
-    }
-  } else {
-    switch (mode) {
-      case S0_AX: launch_spmv0t_inst<S0_AX, 512>(s, A, T, a, grid); break;
-      case S0_RESID: launch_spmv0t_inst<S0_RESID, 512>(s, A, T, a, grid); break;
-      default: launch_spmv0t_inst<S0_JACOBI, 512>(s, A, T, a, grid); break;
-    }
+  switch (mode) {
+    case S0_AX: launch_spmv0t_inst<S0_AX, 1024>(s, A, T, a, grid); break;
+    case S0_RESID: launch_spmv0t_inst<S0_RESID, 1024>(s, A, T, a, grid); break;
+    default: launch_spmv0t_inst<S0_JACOBI, 1024>(s, A, T, a, grid); break;
   }
   return grid;
 }

@@ -1,0 +1,694 @@
+// sgo_solve.cpp -- host side of the Gauss-Newton iteration.
+//
+// Mirrors the control flow of g2o's SparseOptimizer::optimize() with OptimizationAlgorithmGaussNewton as sparse-gslam
+// configures it (src/sparse_gslam/src/graphs.cpp:17-23; called at submap_loop_closer.cpp:286-288 and
+// log_runner.cpp:203-204):
+//     for k in 0..iters:  computeActiveErrors; buildSystem; solve; update
+// with the linear solve done by preconditioned CG on the device instead of LinearSolverEigen.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "sgo_ctx.h"
+
+namespace sgo {
+
+// ---- profiling: HIP events around each launch on the ctx stream ---------------------------
+hipEvent_t get_event(sgo_ctx* c) {
+  if (!c->ev_pool.empty()) {
+    hipEvent_t e = c->ev_pool.back();
+    c->ev_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e;
+  hipEventCreate(&e);
+  return e;
+}
+// An event pair with nothing between them still measures a few us on the queue; it is measured
+// once (median of 33 empty brackets) and REPORTED (sgo_profile_overhead_ms) as the bias bound of
+// the per-kernel averages relative to rocprofv3's kernel durations -- it is not subtracted.
+void prof_calibrate(sgo_ctx* c) {
+  if (c->prof_null_ms >= 0.0) return;
+  std::vector<float> v;
+  for (int k = 0; k < 33; ++k) {
+    hipEvent_t a = get_event(c), b = get_event(c);
+    hipEventRecord(a, c->stream);
+    hipEventRecord(b, c->stream);
+    hipStreamSynchronize(c->stream);
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, a, b) == hipSuccess) v.push_back(ms);
+    c->ev_pool.push_back(a);
+    c->ev_pool.push_back(b);
+  }
+  std::sort(v.begin(), v.end());
+  c->prof_null_ms = v.empty() ? 0.0 : v[v.size() / 2];
+}
+void prof_flush(sgo_ctx* c) {
+  if (c->pending.empty()) return;
+  hipStreamSynchronize(c->stream);
+  for (auto& r : c->pending) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) c->prof_ms[r.kid] += ms;
+    c->ev_pool.push_back(r.a);
+    c->ev_pool.push_back(r.b);
+  }
+  c->pending.clear();
+}
+
+// ---- algorithmic bytes per launch ------------
+// Level-0 product: every stored off-diagonal block once with one index (76 B per edge), the diagonal
+// block (48 B), the operand and the result (24 B each) per row; + the right-hand side (RESID, JACOBI)
+// and the block-diagonal inverse (JACOBI).
+double bytes_spmv0(const Sym0Dev& A, int mode) {
+  return 76.0 * A.npairs + (96.0 + (mode != S0_AX ? 24.0 : 0.0) + (mode == S0_JACOBI ? 48.0 : 0.0)) * A.n;
+}
+// linearise + assemble: the row-parallel design reads each edge's operands once per endpoint row
+// (2 x 128 B: indices, inverse measurement, information, two poses), writes the off-diagonal block once
+// (72 B) and 72 B of (diagonal block, b) per row
+double bytes_linearize(const sgo_ctx* c) { return 128.0 * c->S0.ncs + 72.0 * c->S0.nu + 72.0 * c->n; }
+double bytes_chi2(const sgo_ctx* c) { return 96.0 * c->E + 24.0 * c->V; }
+
+// ---- one GN building block each ------------------------------------------------------------
+int do_chi2(sgo_ctx* c, double* d_out2, double* d_e2) {
+  int grid = 0;
+  {
+    Scope sc(c, K_CHI2, bytes_chi2(c));
+    int e0 = 0, e1 = c->E;
+    if (c->comm.nranks > 1 && !d_e2) sgo_shard_range(c->E, c->comm.nranks, c->comm.rank, &e0, &e1);
+    launch_chi2(c->stream, c->el, e0, e1, c->d_poses, d_e2, c->d_partials, &grid);
+  }
+  {
+    Scope sc(c, K_REDUCE2, 16.0 * grid);
+    launch_reduce2(c->stream, c->d_partials, grid, d_out2);
+  }
+  if (c->comm.nranks > 1 && !d_e2 && !c->comm.allreduce_f64(d_out2, 2, c->stream, &c->err)) return SGO_ECOMM;
+  return SGO_OK;
+}
+
+// PCG start state after k_finalize (x = 0, r = b, z = Dinv b, p = z; partials rz / bb with `grid`
+// entries).  With the AMG preconditioner: refresh the coarse operators, z = M^-1 b, p = z.
+int do_spmv(sgo_ctx* c, const double* x, double* y, bool dot, const PcgScalars* S, int* grid_out);
+
+int start_pcg(sgo_ctx* c, int grid) {
+  if (c->amg && c->warm_valid && c->d_xprev) {
+    // Start from the previous Gauss-Newton step scaled by the energy-optimal factor: consecutive steps of a linearly
+    // converging iteration are nearly parallel, ||b - gamma H x_prev|| is 0.2-0.45 ||b|| on C4 / C2 (scripts/
+    // warm_probe.py), i.e. two PCG iterations for the price of one Hessian product.  Same stopping test, same
+    // solution; only the path to it is shorter.
+    const int maxit = c->pcg_softcap > 0 ? std::min(c->pcg_softcap, c->opts.pcg_maxit) : c->opts.pcg_maxit;
+    int rc;
+    if ((rc = amg_update(c->amg, c->stream, &c->err))) return rc;
+    {
+      Scope sc(c, K_INIT_SCALARS, 16.0 * grid);   // ||b||^2, tolerance, iteration count (r.z is replaced below)
+      launch_init_scalars(c->stream, c->d_S, c->d_partials, grid, c->d_partials + kMaxPartials, grid, c->opts.pcg_tol * c->tol_scale,
+                          maxit, c->bb_ref, c->tol_cap);
+    }
+    int gq = 0, gd = 0;
+    if ((rc = do_spmv(c, c->d_xprev, c->d_q, true, nullptr, &gq))) return rc;
+    {
+      Scope sc(c, K_DOT, 48.0 * c->n);
+      launch_dot(c->stream, 3 * c->n, c->d_b, c->d_xprev, c->d_partials + 2 * kMaxPartials, nullptr, &gd);
+    }
+    {
+      Scope sc(c, K_UPDATE_XR, 120.0 * c->n);
+      launch_warm_start(c->stream, 3 * c->n, c->d_xprev, c->d_q, c->d_b, c->d_x, c->d_r, c->d_partials, gq,
+                        c->d_partials + 2 * kMaxPartials, gd);
+    }
+    const int gz = amg_apply(c->amg, c->stream, c->d_r, c->d_z, c->d_r, c->d_zparts, nullptr, nullptr, false);
+    if (amg_comm_failed(c->amg)) return SGO_ECOMM;
+    HIP_TRY(c, hipMemcpyAsync(c->d_p, c->d_z, sizeof(double) * 3 * (size_t)c->n, hipMemcpyDeviceToDevice, c->stream));
+    Scope sc(c, K_INIT_SCALARS, 8.0 * gz);
+    launch_restart_scalars(c->stream, c->d_S, c->d_zparts, gz, maxit, 1);
+  } else if (c->amg) {
+    int rc = amg_update(c->amg, c->stream, &c->err);
+    if (rc) return rc;
+    const int gz = amg_apply(c->amg, c->stream, c->d_r, c->d_z, c->d_r, c->d_zparts, nullptr, nullptr, true);
+    HIP_TRY(c, hipMemcpyAsync(c->d_p, c->d_z, sizeof(double) * 3 * (size_t)c->n, hipMemcpyDeviceToDevice, c->stream));
+    Scope sc(c, K_INIT_SCALARS, 8.0 * (gz + grid));
+    launch_init_scalars(c->stream, c->d_S, c->d_zparts, gz, c->d_partials + kMaxPartials, grid, c->opts.pcg_tol * c->tol_scale,
+                        c->pcg_softcap > 0 ? std::min(c->pcg_softcap, c->opts.pcg_maxit) : c->opts.pcg_maxit, c->bb_ref, c->tol_cap);
+  } else {
+    Scope sc(c, K_INIT_SCALARS, 16.0 * grid);
+    launch_init_scalars(c->stream, c->d_S, c->d_partials, grid, c->d_partials + kMaxPartials, grid, c->opts.pcg_tol * c->tol_scale,
+                        c->pcg_softcap > 0 ? std::min(c->pcg_softcap, c->opts.pcg_maxit) : c->opts.pcg_maxit, c->bb_ref, c->tol_cap);
+  }
+  return SGO_OK;
+}
+
+// buildSystem + preconditioner + PCG start state.  Multi-GPU: every rank linearises the whole graph (1.5 % of
+// a GN iteration; sharding it would mean all-reducing the blocks, 72 B per edge, to save it).
+int do_linearize(sgo_ctx* c) {
+  {
+    Scope sc(c, K_LINEARIZE, bytes_linearize(c));
+    launch_linearize(c->stream, c->S0, 0, c->S0.ngrp, c->es, c->d_poses, c->d_dgb);
+  }
+  int grid = 0;
+  {
+    Scope sc(c, K_FINALIZE, (72.0 + 48.0 + 48.0 + 6 * 24.0) * c->n);
+    launch_finalize(c->stream, c->S0, c->d_dgb, c->d_b, c->d_x, c->d_r, c->d_z, c->d_p,
+                    c->amg ? amg_xs0(c->amg) : nullptr, c->amg ? amg_omega(c->amg) : 0.0, c->d_partials, &grid);
+  }
+  int rc = start_pcg(c, grid);
+  if (rc) return rc;
+  c->linearized = true;
+  return SGO_OK;
+}
+
+// y = H x  (+ optional x.y partials).  The solve is replicated on every rank (identical H after
+// the all-reduce in do_linearize), so no collective is needed here.
+int do_spmv(sgo_ctx* c, const double* x, double* y, bool dot, const PcgScalars* S, int* grid_out) {
+  Spmv0Args a{};
+  a.x = x;
+  a.y = y;
+  a.S = S;
+  if (c->comm.nranks > 1 || c->comm.active()) {
+    // multi-GPU: this rank's range of tiles only, zeros elsewhere, all-reduce of the product vector (every row
+    // has exactly one non-zero contributor: the sum is exact), then the dot product on the full vectors --
+    // the same arithmetic on every rank, so the replicated PCG recurrences stay bit-identical across ranks
+    a.u0 = c->shard_u0;
+    a.u1 = c->shard_u1;
+    HIP_TRY(c, hipMemsetAsync(y, 0, sizeof(double) * 3 * (size_t)c->n, c->stream));
+    if (a.u1 > a.u0) {
+      Scope sc(c, c->T0.ntile > 0 ? K_SPMV0T_AX : K_SPMV0_AX, bytes_spmv0(c->S0, S0_AX) * (a.u1 - a.u0) / std::max(1, c->shard_units));
+      launch_spmv0_any(c->stream, c->S0, c->T0, S0_AX, a);
+    }
+    if (!c->comm.allreduce_f64(y, 3 * (size_t)c->n, c->stream, &c->err)) return SGO_ECOMM;
+    if (dot) {
+      int grid = 0;
+      Scope sc(c, K_DOT, 48.0 * c->n);
+      launch_dot(c->stream, 3 * c->n, x, y, c->d_partials, S, &grid);
+      if (grid_out) *grid_out = grid;
+    }
+    return SGO_OK;
+  }
+  Scope sc(c, c->T0.ntile > 0 ? K_SPMV0T_AX : K_SPMV0_AX, bytes_spmv0(c->S0, S0_AX));
+  if (dot) {
+    a.dotA = x;
+    a.partials = c->d_partials;
+  }
+  const int grid = launch_spmv0_any(c->stream, c->S0, c->T0, S0_AX, a);
+  if (grid_out) *grid_out = grid;
+  return SGO_OK;
+}
+
+int pcg_iteration(sgo_ctx* c) {
+  int g1 = 0, g2 = 0, rc;
+  if ((rc = do_spmv(c, c->d_p, c->d_q, true, c->d_S, &g1))) return rc;
+  double* parts2 = c->d_partials + kMaxPartials;  // [0] = r.z (block-Jacobi only), [1] = r.r
+  {
+    // block-Jacobi: z = Dinv r; multigrid: xs = omega Dinv r, the cycle's first level-0 sweep from zero
+    Scope sc(c, K_UPDATE_XR, (7 * 24.0 + 48.0) * c->n);
+    launch_update_xr(c->stream, c->n, c->d_S, c->d_partials, g1, c->S0.dinv, c->d_p, c->d_q, c->d_x, c->d_r, c->d_z,
+                     c->amg ? amg_xs0(c->amg) : nullptr, c->amg ? amg_omega(c->amg) : 0.0, parts2, &g2);
+  }
+  if (c->amg) {
+    // the K-cycle is a (mildly) variable preconditioner: flexible beta from z.q
+    const int gz = amg_apply(c->amg, c->stream, c->d_r, c->d_z, c->d_r, c->d_zparts, c->d_S, c->d_q, true);
+    if (amg_comm_failed(c->amg)) {
+      c->err = "collective failed inside the multigrid cycle";
+      return SGO_ECOMM;
+    }
+    Scope sc(c, K_UPDATE_P, 3 * 24.0 * c->n);
+    launch_update_p(c->stream, c->n, c->d_S, c->d_zparts, gz, parts2 + kMaxPartials, g2, c->d_zparts + kMaxPartials,
+                    c->d_z, c->d_p);
+  } else {
+    Scope sc(c, K_UPDATE_P, 3 * 24.0 * c->n);
+    launch_update_p(c->stream, c->n, c->d_S, parts2, g2, parts2 + kMaxPartials, g2, nullptr, c->d_z, c->d_p);
+  }
+  return SGO_OK;
+}
+
+int ensure_pcg_graph(sgo_ctx* c, int chunk) {
+  if (c->pcg_exec && c->pcg_exec_chunk == chunk) return SGO_OK;
+  if (c->pcg_exec) {
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    hipGraphExecDestroy(c->pcg_exec);
+    c->pcg_exec = nullptr;
+  }
+  hipGraph_t graph = nullptr;
+  HIP_TRY(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+  int rc = SGO_OK;
+  for (int k = 0; k < chunk && rc == SGO_OK; ++k) rc = pcg_iteration(c);
+  hipError_t e = hipStreamEndCapture(c->stream, &graph);
+  if (rc != SGO_OK) {
+    if (graph) hipGraphDestroy(graph);
+    return rc;
+  }
+  if (e != hipSuccess) {
+    c->err = std::string("hipStreamEndCapture: ") + hipGetErrorString(e);
+    return SGO_EHIP;
+  }
+  e = hipGraphInstantiate(&c->pcg_exec, graph, nullptr, nullptr, 0);
+  hipGraphDestroy(graph);
+  if (e != hipSuccess) {
+    c->pcg_exec = nullptr;
+    c->err = std::string("hipGraphInstantiate: ") + hipGetErrorString(e);
+    return SGO_EHIP;
+  }
+  c->pcg_exec_chunk = chunk;
+  return SGO_OK;
+}
+
+// Runs PCG from the state k_finalize left (x = 0, r = b, ...) until S.stop != 0.
+// Runs PCG from the state k_finalize / start_pcg left (x = 0, r = b, ...) until S.stop != 0.
+// Graph mode: a 2-iteration hipGraph is replayed; the first 0.8 * predicted - 4 iterations -- predicted
+// = the count of the previous solve -- go out without any host check, after that one replay is always
+// in flight while the host waits for the stop flag copied out after the previous one (kernels of
+// iterations past convergence exit on the flag), so the GPU never idles on a host round trip and at
+// most two replays of early-exit launches are wasted.
+int run_pcg(sgo_ctx* c) {
+  // collectives inside the loop: plain stream launches (RCCL calls are not captured into the hipGraph)
+  // Opt-in (env SGO_COMM_GRAPH=1): the RCCL collectives are captured into the hipGraph with the kernels around them
+  // (every rank replays the same graph the same number of times: the replay count follows the device-resident stop
+  // flag, which is bit-identical on all ranks).  Measured with a 1-rank communicator: 154 -> 167 M edge-Jacobians/s on
+  // C4; off by default because it has never run on more than one GPU.  Not possible with the host transport.
+  const bool comm_graph = c->comm.handle != nullptr && !c->comm.host_fn && std::getenv("SGO_COMM_GRAPH") != nullptr;
+  const bool graph = c->opts.use_graph && !c->opts.profile && (!(c->comm.nranks > 1 || c->comm.active()) || comm_graph);
+  if (!graph) {
+    const int chunk = std::max(1, c->opts.pcg_chunk);
+    for (;;) {
+      HIP_TRY(c, hipMemcpyAsync(c->h_S, c->d_S, sizeof(PcgScalars), hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(c, hipStreamSynchronize(c->stream));
+      if (c->h_S->stop) break;
+      for (int k = 0; k < chunk; ++k) {
+        int rc = pcg_iteration(c);
+        if (rc) return rc;
+      }
+    }
+    c->pcg_pred = c->h_S->iter;
+    return SGO_OK;
+  }
+  constexpr int kUnit = 2;   // iterations per graph replay
+  int rc = ensure_pcg_graph(c, kUnit);
+  if (rc) return rc;
+  // One replay (2 iterations, >= 100 us even on 1k-pose graphs) in flight hides the host's read of the
+  // stop flag; more only adds early-exit launches past convergence (measured: 8 iterations in flight
+  // cost 3.5 % on C4 and 10 % on C1).  pcg_chunk = 16 -> 1 replay; larger values scale it up.
+  const int chunk_launches = std::max(1, c->opts.pcg_chunk / 16);
+  // unchecked prefix: 80 % of the previous count minus a margin (a solve that converges earlier
+  // than that only wastes ~1 us per early-exit launch; tighter margins measured no different)
+  const int unchecked = std::max(0, (int)(0.8 * c->pcg_pred) - 4) / kUnit;
+  for (int k = 0; k < unchecked; ++k) HIP_TRY(c, hipGraphLaunch(c->pcg_exec, c->stream));
+  int slot = 0;
+  HIP_TRY(c, hipMemcpyAsync(&c->h_S2[slot], c->d_S, sizeof(PcgScalars), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipEventRecord(c->ev_S[slot], c->stream));
+  for (;;) {
+    for (int k = 0; k < chunk_launches; ++k) HIP_TRY(c, hipGraphLaunch(c->pcg_exec, c->stream));  // speculative
+    HIP_TRY(c, hipMemcpyAsync(&c->h_S2[slot ^ 1], c->d_S, sizeof(PcgScalars), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipEventRecord(c->ev_S[slot ^ 1], c->stream));
+    HIP_TRY(c, hipEventSynchronize(c->ev_S[slot]));
+    if (c->h_S2[slot].stop) break;
+    slot ^= 1;
+  }
+  *c->h_S = c->h_S2[slot];
+  c->pcg_pred = c->h_S->iter;
+  return SGO_OK;
+}
+
+// (Re)build the multigrid hierarchy from the CURRENT level-0 values (requires do_linearize).
+int build_amg(sgo_ctx* c) {
+  // speculative replays of the captured PCG iteration (and the launches queued behind them) may still be
+  // in flight: drain the stream before the exec and the old hierarchy's buffers go away
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (c->pcg_exec) {  // the captured PCG iteration references the old hierarchy's buffers
+    hipGraphExecDestroy(c->pcg_exec);
+    c->pcg_exec = nullptr;
+  }
+  c->pcg_pred = 0;  // the iteration count of the old hierarchy predicts nothing about the new one
+  c->amg_best = 0;
+  if (c->amg) {
+    amg_destroy(c->amg);
+    c->amg = nullptr;
+  }
+  c->amg_arena.rewind();
+  AmgConfig cfg;
+  AmgProf prof;
+  prof.user = c;
+  prof.begin = [](void* u, int kid, double bytes) {
+    sgo_ctx* cc = (sgo_ctx*)u;
+    cc->amg_scope = new Scope(cc, kid, bytes, kid == K_DENSE_INVERT);
+  };
+  prof.end = [](void* u) {
+    sgo_ctx* cc = (sgo_ctx*)u;
+    delete (Scope*)cc->amg_scope;
+    cc->amg_scope = nullptr;
+  };
+  std::string aerr;
+  l0_join(c, true);   // the helper thread's analysis of level 0, when set_graph started one (first build only)
+  c->amg = amg_create(c->stream, c->A, c->S0, c->T0, c->H0, c->d_poses, c->d_free_id, cfg, prof, &aerr, &c->amg_scratch,
+                      &c->amg_arena, c->l0_pre);
+  l0_discard(c);
+  if (c->amg) {
+    if (c->comm.nranks > 1 || c->comm.active()) amg_set_shard(c->amg, &c->comm, c->shard_u0, c->shard_u1, c->shard_row0, c->shard_row1);
+    amg_describe(c->amg, &c->solver_desc);
+    c->solver_desc = "pcg_amg: " + c->solver_desc;
+  } else {
+    c->solver_desc = "pcg_block_jacobi (AMG unavailable: " + aerr + ")";
+    if (c->opts.verbose) std::fprintf(stderr, "[sgo] %s\n", c->solver_desc.c_str());
+  }
+  return SGO_OK;
+}
+
+// Vectors over the free vertices cross the API in g2o's hessian order and live on the device in the
+// internal (Hilbert) row order: permute on the way (test / single-step entry points only).
+// build_structure + what follows from it (multi-GPU tile range, tolerance rule)
+int build_rows(sgo_ctx* c, const double* poses, const uint8_t* fixed, const int32_t* ei, const int32_t* ej) {
+  int rc = build_structure(c, c->V, poses, fixed, c->E, ei, ej);
+  if (rc != SGO_OK) return rc;
+  c->shard_units = c->T0.ntile > 0 ? c->T0.ntile : c->S0.ngrp;
+  sgo_shard_range(c->shard_units, c->comm.nranks, c->comm.rank, &c->shard_u0, &c->shard_u1);
+  c->shard_row0 = c->unit_row0.empty() ? 0 : c->unit_row0[c->shard_u0];
+  c->shard_row1 = c->unit_row0.empty() ? c->n : c->unit_row0[c->shard_u1];
+  // Chain-like graphs (fewer than ~1.5 edges per free pose: under 4 Hessian blocks per row) are the
+  // ill-conditioned ones -- kappa(H) grows with the square of the chain length -- and a relative
+  // residual of 1e-8 then leaves errors that show in chi2 (3000 poses / 3150 edges: iterates 3e-6 and
+  // poses 7e-5 m from the direct-solver oracle at 1e-8, 1.4e-8 at 1e-9).  Their PCG iterations are the
+  // cheap ones, so they get a 10x tighter tolerance than opts.pcg_tol.
+  c->tol_scale = (c->n > 0 && (long long)c->A.nslot < 4LL * c->n) ? 0.1 : 1.0;   // logical slots: 2 per edge + 1 per row
+  return SGO_OK;
+}
+
+// Graphs that optimize() through the single-launch direct path have their PCG-path structures built by the first
+// entry point that needs them (sgo_linearize, sgo_hessian_apply, ...): the row order then follows the CURRENT poses.
+int ensure_rows(sgo_ctx* c) {
+  if (!c->rows_pending) return SGO_OK;
+  std::vector<double> poses(3 * (size_t)c->V);
+  HIP_TRY(c, hipMemcpyAsync(poses.data(), c->d_poses, sizeof(double) * poses.size(), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  const int rc = build_rows(c, poses.data(), c->lz_fixed.data(), c->lz_ei.data(), c->lz_ej.data());
+  if (rc != SGO_OK) return rc;   // (still pending: a later call tries again instead of running on half-built structures)
+  c->rows_pending = false;
+  c->lz_fixed = std::vector<uint8_t>();
+  c->lz_ei = std::vector<int32_t>();
+  c->lz_ej = std::vector<int32_t>();
+  return rc;
+}
+
+// Graphs that optimize() through the single-launch direct path build their multigrid hierarchy only when a
+// single-step entry point (sgo_solve, sgo_precondition) or the PCG fallback asks for it.
+int ensure_amg(sgo_ctx* c) {
+  int rc = ensure_rows(c);
+  if (rc != SGO_OK) return rc;
+  if (!c->amg_pending) return SGO_OK;
+  if ((rc = do_linearize(c)) != SGO_OK || (rc = build_amg(c)) != SGO_OK) return rc;
+  c->amg_pending = false;
+  c->linearized = false;
+  return SGO_OK;
+}
+
+int vec_to_device(sgo_ctx* c, const double* host_asc, double* dev) {
+  std::vector<double> tmp(3 * (size_t)c->n);
+  for (int i = 0; i < c->n; ++i)
+    for (int q = 0; q < 3; ++q) tmp[3 * (size_t)c->row_of_asc[i] + q] = host_asc[3 * (size_t)i + q];
+  HIP_TRY(c, hipMemcpyAsync(dev, tmp.data(), sizeof(double) * tmp.size(), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return SGO_OK;
+}
+int vec_from_device(sgo_ctx* c, const double* dev, double* host_asc) {
+  std::vector<double> tmp(3 * (size_t)c->n);
+  HIP_TRY(c, hipMemcpyAsync(tmp.data(), dev, sizeof(double) * tmp.size(), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  for (int i = 0; i < c->n; ++i)
+    for (int q = 0; q < 3; ++q) host_asc[3 * (size_t)i + q] = tmp[3 * (size_t)c->row_of_asc[i] + q];
+  return SGO_OK;
+}
+
+int check_graph(sgo_ctx* c) {
+  if (!c) return SGO_EINVAL;
+  if (!c->has_graph) {
+    c->err = "no graph: call sgo_set_graph_se2 first";
+    return SGO_ENOGRAPH;
+  }
+  hipError_t e = hipSetDevice(c->device);
+  if (e != hipSuccess) {
+    c->err = std::string("hipSetDevice: ") + hipGetErrorString(e);
+    return SGO_EHIP;
+  }
+  return SGO_OK;
+}
+
+int optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
+    int rc = check_graph(c);
+    if (rc) return rc;
+    if (iters < 0 || iters > SGO_MAX_ITERS) {
+      c->err = "sgo_optimize_gn: iters must be in [0, SGO_MAX_ITERS]";
+      return SGO_EINVAL;
+    }
+    if (out) {
+      std::memset(out, 0, sizeof(*out));
+      out->iters_requested = iters;
+      out->seconds_setup = c->setup_seconds;
+    }
+    if (c->n == 0) return SGO_ENOTHING;
+    const double t0 = wall_s();
+    if (c->direct) {
+      // ---- small-graph path: the whole call is one launch (sgo_direct.h)
+      {
+        Scope sc(c, K_DIRECT, direct_bytes(c->direct, c->E, iters));
+        hipError_t he = direct_optimize(c->direct, c->stream, c->el, c->d_poses, iters, c->d_hist, c->d_dres);
+        if (he != hipSuccess) {
+          c->err = std::string("k_direct launch: ") + hipGetErrorString(he);
+          return SGO_EHIP;
+        }
+      }
+      HIP_TRY(c, hipMemcpyAsync(c->h_hist, c->d_hist, sizeof(double) * 2 * (size_t)(iters + 1), hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(c, hipMemcpyAsync(c->h_dres, c->d_dres, sizeof(DirectResult), hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(c, hipStreamSynchronize(c->stream));
+      prof_flush(c);
+      c->linearized = false;
+      const DirectResult& R = *c->h_dres;
+      const int done = R.done;
+      if (R.fail) {
+        c->err = std::string("direct factorisation failed in GN iteration ") + std::to_string(done) +
+                 (R.fail == 1 ? " (a pivot block is not positive definite: Hessian not positive definite)"
+                              : " (non-finite update)") + "; the step was not applied";
+      }
+      if (out) {
+        out->iters_done = done;
+        for (int k = 0; k <= done; ++k) {
+          out->chi2[k] = c->h_hist[2 * k];
+          out->robust_chi2[k] = c->h_hist[2 * k + 1];
+        }
+        const int timed = std::min(iters, done + (R.fail ? 1 : 0));
+        for (int k = 0; k < timed; ++k) {
+          out->pcg_iters[k] = 0;
+          out->pcg_converged[k] = (k < done) ? 1 : 0;
+          out->seconds_linearize[k] = 1e-8 * (double)(R.stamp[2 * k + 1] - R.stamp[2 * k]);
+          out->seconds[k] = 1e-8 * (double)(R.stamp[2 * k + 2] - R.stamp[2 * k]);
+          out->seconds_solve[k] = out->seconds[k] - out->seconds_linearize[k];
+        }
+        out->seconds_total = wall_s() - t0;
+      }
+      if (c->opts.verbose && done > 0)
+        std::fprintf(stderr, "[sgo] direct: %.0f MHz shader clock during the call\n",
+                     (double)R.cycles / (1e-2 * (double)(R.stamp[R.fail ? 2 * done + 2 : 2 * iters + 1] - R.stamp[0])));
+      if (c->opts.verbose && done > 0)
+        std::fprintf(stderr, "[sgo] direct, last iteration [us]: edges %.1f, assembly %.1f, sparse forward %.1f, separators %.1f + %.1f, "
+                     "sparse backward %.1f, update %.1f\n", 1e-2 * (double)(R.phase[1] - R.phase[0]), 1e-2 * (double)(R.phase[2] - R.phase[1]),
+                     1e-2 * (double)(R.phase[3] - R.phase[2]), 1e-2 * (double)(R.phase[4] - R.phase[3]), 1e-2 * (double)(R.phase[5] - R.phase[4]),
+                     1e-2 * (double)(R.phase[6] - R.phase[5]), 1e-2 * (double)(R.phase[7] - R.phase[6]));
+      if (c->opts.verbose > 1)
+        for (int k = 0; k <= done; ++k)
+          std::fprintf(stderr, "[sgo] iteration= %d\t chi2= %.9e\t robust= %.9e\t (direct)\n", k, c->h_hist[2 * k], c->h_hist[2 * k + 1]);
+      return R.fail ? 0 : done;
+    }
+    if ((rc = ensure_amg(c))) return rc;
+    // per-iteration time stamps: events are kept in the context and reused by later calls
+    while (c->iter_events.size() < 3 * (size_t)iters + 1) {
+      hipEvent_t e = nullptr;
+      HIP_TRY(c, hipEventCreate(&e));
+      c->iter_events.push_back(e);
+    }
+    std::vector<hipEvent_t>& ev = c->iter_events;
+    struct SoftcapGuard {   // the bail-out cap and the absolute accuracy target apply to solves inside this call only
+      sgo_ctx* c;
+      ~SoftcapGuard() {
+        c->pcg_softcap = 0;
+        c->bb_ref = 0.0;
+        c->warm_valid = false;
+      }
+    } softcap_guard{c};
+    c->warm_valid = false;
+    const bool warm_env = c->opts.pcg_warm_start != 0;
+    c->bb_ref = 0.0;
+    c->tol_cap = c->opts.pcg_tol_cap > 0.0 ? std::max(c->opts.pcg_tol_cap, c->opts.pcg_tol * c->tol_scale) : 0.0;
+    int done = 0;
+    bool failed = false;
+    int rebuilds = 0;
+    int& best_pcg = c->amg_best;
+    bool rebuild_next = false;
+    for (int it = 0; it < iters; ++it) {
+      hipEventRecord(ev[3 * it], c->stream);
+      c->pcg_softcap = (c->amg && c->amg_best > 0 && rebuilds < 3 && !rebuild_next) ? 4 * c->amg_best + 40 : 0;
+      if ((rc = do_chi2(c, c->d_hist + 2 * it, nullptr)) || (rc = do_linearize(c))) return rc;
+      if (rebuild_next && c->amg) {
+        // The aggregation was made from the Hessian of an earlier linearisation and robust-kernel
+        // re-weighting has changed the strength of connection since (see the rule below): redo the
+        // set-up from the current values (same cost as in sgo_set_graph_se2).
+        if ((rc = build_amg(c)) || (rc = do_linearize(c))) return rc;
+        rebuild_next = false;
+        ++rebuilds;
+        if (c->opts.verbose) std::fprintf(stderr, "[sgo] multigrid hierarchy rebuilt before iteration %d\n", it);
+      }
+      hipEventRecord(ev[3 * it + 1], c->stream);
+      int wasted = 0;
+      if ((rc = run_pcg(c))) {
+        return rc;
+      }
+      if (c->pcg_softcap > 0 && c->h_S->stop == 2 && c->h_S->iter < c->opts.pcg_maxit && c->amg) {
+        // The solve ran into the bail-out cap (4x the best count of this hierarchy): the aggregation no
+        // longer fits the re-weighted Hessian.  Redo the set-up from the current values and solve again
+        // from x = 0 instead of grinding on (seen: 735 iterations where the rebuilt hierarchy needs 16).
+        wasted = c->h_S->iter;
+        c->pcg_softcap = 0;
+        if ((rc = build_amg(c)) || (rc = do_linearize(c)) || (rc = run_pcg(c))) return rc;
+        ++rebuilds;
+        rebuild_next = false;
+        if (c->opts.verbose)
+          std::fprintf(stderr, "[sgo] iteration %d: solve abandoned after %d PCG iterations, hierarchy rebuilt\n", it, wasted);
+      }
+      const PcgScalars S = *c->h_S;
+      if (it == 0 && c->tol_cap > 0.0 && S.stop == 1) c->bb_ref = S.bb;
+      if (c->amg && S.stop != 3) {
+        // Iteration counts are compared at EQUAL tolerance: a solve that stopped at the absolute criterion (a looser
+        // relative tolerance, see pcg_tol_cap) is scaled to what pcg_tol would have cost -- PCG converges linearly,
+        // iterations ~ log(1 / tolerance) -- or the staleness rules below would take every tight solve that follows
+        // a loose one for a stale hierarchy.
+        const double tol0 = c->opts.pcg_tol * c->tol_scale, tolk = std::sqrt(S.tol2);
+        const int eq_iter = (tolk > tol0 && tolk < 1.0 && tol0 > 0.0) ? (int)std::lround(S.iter * std::log(tol0) / std::log(tolk)) : S.iter;
+        if (best_pcg == 0 || eq_iter < best_pcg) best_pcg = eq_iter;
+        // Redo the aggregation from the current values when that pays: always when the count has more
+        // than doubled, and when it is > 25 % above the best while the PCG iterations it would save
+        // over the remaining GN iterations exceed the set-up's cost (~150 PCG iterations' worth: host
+        // aggregation + one more linearisation).  Counts only -- no clocks -- so that every rank of a
+        // multi-GPU run takes the same decision.
+        const int left = iters - it - 1;
+        const bool doubled = eq_iter > 2 * best_pcg + 10;
+        const bool pays = 4 * eq_iter > 5 * best_pcg && (long long)(eq_iter - best_pcg) * left > 150;
+        if (rebuilds < 3 && (doubled || pays)) rebuild_next = true;
+      }
+      if (out) {
+        out->pcg_iters[it] = S.iter + wasted;   // an abandoned solve's iterations count too
+        out->pcg_converged[it] = S.stop == 1;
+        out->pcg_relres[it] = S.bb > 0 ? std::sqrt(S.rr / S.bb) : 0.0;
+      }
+      if (S.stop != 1) {
+        // Solver failure, as LinearSolverEigen::solve returning false (OptimizationAlgorithm::Fail): the
+        // step is NOT applied, estimates stay at the last successful update and the call returns 0 like
+        // g2o::SparseOptimizer::optimize.  stop == 3: p.Hp <= 0 or non-finite (H not positive definite);
+        // stop == 2: pcg_maxit iterations without reaching pcg_tol (an inexact step is never applied).
+        if (S.stop == 3) {
+          c->err = "PCG breakdown in GN iteration " + std::to_string(it) + " (Hessian not positive definite";
+          if (c->amg && amg_coarsest_not_spd(c->amg, c->stream)) c->err += "; its coarsest Galerkin operator has a non-positive pivot";
+          c->err += ")";
+        } else {
+          c->err = "PCG did not reach pcg_tol within pcg_maxit = " + std::to_string(c->opts.pcg_maxit) +
+                   " iterations in GN iteration " + std::to_string(it) + " (relative residual " +
+                   std::to_string(S.bb > 0 ? std::sqrt(S.rr / S.bb) : 0.0) + "); the step was not applied";
+        }
+        failed = true;
+        hipEventRecord(ev[3 * it + 2], c->stream);
+        break;
+      }
+      {
+        Scope sc(c, K_POSE_UPDATE, 72.0 * c->n);
+        launch_pose_update(c->stream, c->n, c->d_free_id, c->d_x, c->d_poses);
+      }
+      if (warm_env && c->amg && c->d_xprev) {   // (multi-GPU: the same replicated arithmetic on every rank)
+        HIP_TRY(c, hipMemcpyAsync(c->d_xprev, c->d_x, sizeof(double) * 3 * (size_t)c->n, hipMemcpyDeviceToDevice, c->stream));
+        c->warm_valid = !rebuild_next;   // a rebuilt hierarchy starts cold (its first solve sets the reference counts)
+      }
+      hipEventRecord(ev[3 * it + 2], c->stream);
+      c->linearized = false;
+      ++done;
+      if (c->opts.verbose)
+        std::fprintf(stderr, "[sgo] iteration= %d\t pcg= %d\t relres= %.3e\t |b|= %.3e\n", it, S.iter,
+                     S.bb > 0 ? std::sqrt(S.rr / S.bb) : 0.0, std::sqrt(S.bb));
+    }
+    c->pcg_softcap = 0;
+    if ((rc = do_chi2(c, c->d_hist + 2 * done, nullptr))) {
+      return rc;
+    }
+    HIP_TRY(c, hipMemcpyAsync(c->h_hist, c->d_hist, sizeof(double) * 2 * (size_t)(done + 1), hipMemcpyDeviceToHost,
+                              c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    prof_flush(c);
+    if (out) {
+      out->iters_done = done;
+      for (int k = 0; k <= done; ++k) {
+        out->chi2[k] = c->h_hist[2 * k];
+        out->robust_chi2[k] = c->h_hist[2 * k + 1];
+      }
+      const int timed = std::min(iters, done + 1);
+      for (int k = 0; k < timed; ++k) {
+        float a = 0.f, b = 0.f;
+        hipEventElapsedTime(&a, ev[3 * k], ev[3 * k + 1]);
+        hipEventElapsedTime(&b, ev[3 * k + 1], ev[3 * k + 2]);
+        out->seconds_linearize[k] = a * 1e-3;
+        out->seconds_solve[k] = b * 1e-3;
+        out->seconds[k] = (a + b) * 1e-3;
+      }
+      out->seconds_total = wall_s() - t0;
+    }
+    return failed ? 0 : done;   // g2o: optimize() returns 0 when the algorithm reported Fail
+}
+
+// Micro-benchmark of the level-0 product on the resident graph: `reps` back-to-back launches of
+// k_spmv0<mode> (operand = the PCG direction buffer, whatever it holds), HIP events around them on the
+// context's stream; returns the mean microseconds per launch (< 0 on error).  variant 16: the wave-group kernel even when the graph has a tile view; variant 32: per-phase s_memtime stamps of the tile kernel on stderr (diagnostic).
+double debug_spmv0_us(sgo_ctx* c, int mode, int variant, int reps) {
+  if (check_graph(c) != SGO_OK || reps < 1 || c->n == 0 || ensure_rows(c) != SGO_OK) return -1.0;
+  hipEvent_t a, b;
+  if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return -1.0;
+  Spmv0Args args{};
+  args.x = c->d_p;
+  args.y = c->d_s2;
+  args.b = c->d_b;
+  args.omega = 0.8;
+  const bool tiled = c->T0.ntile > 0 && !(variant & 16);   // variant 16: the wave-group kernel
+  long long* d_st = nullptr;
+  if ((variant & 32) && tiled) {
+    hipMalloc((void**)&d_st, sizeof(long long) * 8 * (size_t)c->T0.ntile);
+    hipMemset(d_st, 0, sizeof(long long) * 8 * (size_t)c->T0.ntile);
+    args.dbg_stamps = d_st;
+  }
+  if (tiled) launch_spmv0t(c->stream, c->S0, c->T0, mode, args);
+  else launch_spmv0(c->stream, c->S0, mode, args);
+  hipEventRecord(a, c->stream);
+  for (int k = 0; k < reps; ++k) {
+    if (tiled) launch_spmv0t(c->stream, c->S0, c->T0, mode, args);
+    else launch_spmv0(c->stream, c->S0, mode, args);
+  }
+  hipEventRecord(b, c->stream);
+  hipStreamSynchronize(c->stream);
+  float ms = 0.f;
+  hipEventElapsedTime(&ms, a, b);
+  hipEventDestroy(a);
+  hipEventDestroy(b);
+  if (d_st) {
+    std::vector<long long> st(8 * (size_t)c->T0.ntile);
+    hipMemcpy(st.data(), d_st, sizeof(long long) * st.size(), hipMemcpyDeviceToHost);
+    hipFree(d_st);
+    double ph[6] = {0, 0, 0, 0, 0, 0};
+    for (int t = 0; t < c->T0.ntile; ++t)
+      for (int q = 0; q < 6; ++q) ph[q] += (double)(st[8 * t + q + 1] - st[8 * t + q]);
+    std::fprintf(stderr, "[sgo] tile kernel phases, shader cycles of wave 0 (s_memtime), mean over %d tiles: phase 0 %.0f, barrier %.0f, "
+                 "phase 1 %.0f, barrier %.0f, phase 2 %.0f, barrier %.0f\n", c->T0.ntile,
+                 ph[0] / c->T0.ntile, ph[1] / c->T0.ntile, ph[2] / c->T0.ntile, ph[3] / c->T0.ntile, ph[4] / c->T0.ntile,
+                 ph[5] / c->T0.ntile);
+    long long s0 = st[0], s1 = st[0], e0 = st[6], e1 = st[6], dmin = st[6] - st[0], dmax = dmin;
+    double dsum = 0.0;
+    for (int t = 0; t < c->T0.ntile; ++t) {
+      const long long a0 = st[8 * t], a6 = st[8 * t + 6], dd = a6 - a0;
+      s0 = std::min(s0, a0); s1 = std::max(s1, a0); e0 = std::min(e0, a6); e1 = std::max(e1, a6);
+      dmin = std::min(dmin, dd); dmax = std::max(dmax, dd); dsum += (double)dd;
+    }
+    std::fprintf(stderr, "[sgo] tile kernel, per tile (wave 0): cycles min %lld mean %.0f max %lld; first stamps spread over %lld cycles, "
+                 "last stamps over %lld; first start to last end %lld cycles\n", dmin, dsum / c->T0.ntile, dmax, s1 - s0, e1 - e0, e1 - s0);
+  }
+  return 1e3 * ms / reps;
+}
+
+}  // namespace sgo

@@ -3,6 +3,8 @@ import ctypes
 import os
 import re
 
+import pytest
+
 from sparse_gslam_amd import capi
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -49,3 +51,18 @@ def test_header_compiles_as_plain_c(tmp_path):
                            os.path.join(ROOT, "examples", "c_api_demo.c"), "-L" + capi.CSRC, "-lsgo", "-L/opt/rocm/lib",
                            "-Wl,-rpath," + capi.CSRC, "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)])
     assert exe.exists()
+
+
+def test_hostpool_regions_under_tsan(tmp_path):
+    """The host worker pool of the set-up (sgo_hostpool.h) under ThreadSanitizer: regions of 2 and 256 tasks alternate;
+    every task runs exactly once and run() returns only when all have finished (a late worker could claim a
+    task of the NEXT region)."""
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    exe = tmp_path / "hostpool_tsan"
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=thread", "-I", os.path.join(ROOT, "sparse_gslam_amd", "csrc"),
+                           os.path.join(ROOT, "tests", "cpp", "hostpool_tsan.cpp"), "-o", str(exe), "-lpthread"])
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ThreadSanitizer" not in r.stderr, r.stdout + r.stderr
