@@ -32,6 +32,17 @@ struct AmgProf {
   void (*end)(void* user) = nullptr;
 };
 
+// Multi-GPU, row-owner mode: the partition (device and host image) and a way to have the exchange buffers grown
+struct AmgHalo {
+  HaloDev* dev = nullptr;            // amg_create fills in pemax / pent (entries of P in the boundary rows)
+  int G = 1, bmax = 0;
+  const int* bnd_host = nullptr;     // [G][bmax] boundary rows of every rank, -1 padded
+  bool (*reserve)(void* user, size_t packet_doubles) = nullptr;
+  void* user = nullptr;
+  const std::vector<double>* w0 = nullptr;   // strength weights of level 0's logical slots (the caller made them from the edge
+                                             // list: a rank holds current blocks for its own rows only)
+};
+
 struct ChunkArena;
 struct DevArena;   // device memory of the hierarchy: owned by the caller, rewound by it after amg_destroy
 struct Amg;  // opaque
@@ -53,7 +64,7 @@ struct HostLevel {
 // lists; it is rewound here and may be rewound again by the caller once amg_create has returned.
 Amg* amg_create(hipStream_t s, const BsrDev& A0, const Sym0Dev& S0, const Tile0Dev& T0, const HostLevel& H0, const double* d_poses,
                 const int* d_free_id, const AmgConfig& cfg, const AmgProf& prof, std::string* err,
-                ChunkArena* scratch, DevArena* arena, struct AmgHostL0* pre0 = nullptr);
+                ChunkArena* scratch, DevArena* arena, struct AmgHostL0* pre0 = nullptr, const AmgHalo* halo = nullptr);
 // Level 0's host analysis (aggregation, patterns and product lists of the transfer, structure of level 1) made ahead
 // of amg_create from the level's logical structure and the strength weights w (Frobenius norms of the slots' blocks
 // at the initial poses, logical slot order): amg_host_l0_run may execute on a helper thread while the caller still
@@ -63,6 +74,7 @@ struct AmgHostL0;
 AmgHostL0* amg_host_l0_new();
 void amg_host_l0_run(AmgHostL0* p, const HostLevel& H0, const std::vector<double>& w, const AmgConfig& cfg, ChunkArena* scratch);
 void amg_host_l0_free(AmgHostL0* p);
+bool amg_host_l0_ready(const AmgHostL0* p);
 AmgConfig amg_effective_config(const AmgConfig& cfg_in, int n, int nslot);
 void amg_destroy(Amg* m);
 // Recompute the coarse operators for the current level-0 values and poses (once per GN iteration).

@@ -105,7 +105,9 @@ struct GalerkinMap {
   const int* tgt = nullptr;  // coarse slot of contribution t
   const int* grp = nullptr;  // wave groups aligned to coarse-slot boundaries
 };
-__global__ __launch_bounds__(kBlock) void k_galerkin(BsrDev F, BsrDev C, GalerkinMap g, const double* __restrict__ d) {
+// Multi-GPU (row-owner mode): only the fine slots of the rows [row0, row1) contribute (row1 == 0: all); the ranks'
+// partial coarse operators are summed by an all-reduce.
+__global__ __launch_bounds__(kBlock) void k_galerkin(BsrDev F, BsrDev C, GalerkinMap g, const double* __restrict__ d, int row0, int row1) {
   const int lane = threadIdx.x & 63;
   const size_t ncs = (size_t)C.nslot;
   int gi, gend, gstride;
@@ -118,6 +120,7 @@ __global__ __launch_bounds__(kBlock) void k_galerkin(BsrDev F, BsrDev C, Galerki
       key = g.tgt[t];
       const int k = g.src[t];
       const int i = F.row[k], j = F.col[k];
+      if (row1 > 0 && (i < row0 || i >= row1)) continue;
       const double dxi = d[2 * (size_t)i], dyi = d[2 * (size_t)i + 1];
       const double dxj = d[2 * (size_t)j], dyj = d[2 * (size_t)j + 1];
       double b[9];
@@ -217,8 +220,9 @@ __device__ __forceinline__ void load9(const double* __restrict__ base, size_t e,
 }
 
 // P_e = [e is the own-aggregate entry] T_i - w D_i^-1 sum_{k in e} A_k T_col(k)
+// (multi-GPU, row-owner mode: the entries of the rows [row0, row1) only; row1 == 0: all)
 __global__ __launch_bounds__(kBlock) void k_p_values(BsrDev F, PDev P, const int* __restrict__ agg,
-                                                     const double* __restrict__ d, double omega_p) {
+                                                     const double* __restrict__ d, double omega_p, int row0, int row1) {
   const int lane = threadIdx.x & 63;
   int gi, gend, gstride;
   group_walk(P.val.ngrp, &gi, &gend, &gstride);
@@ -229,6 +233,13 @@ __global__ __launch_bounds__(kBlock) void k_p_values(BsrDev F, PDev P, const int
     for (int t = gb + lane; t < ge; t += 64) {
       key = P.val.tgt[t];
       const int k = P.val.a[t];
+      if (row1 > 0) {
+        const int i = F.row[k];
+        if (i < row0 || i >= row1) {
+          key = -1 - lane;
+          continue;
+        }
+      }
       const int j = F.col[k];
       const double dxj = d[2 * (size_t)j], dyj = d[2 * (size_t)j + 1];
       double b[9];
@@ -271,7 +282,8 @@ __global__ __launch_bounds__(kBlock) void k_p_values(BsrDev F, PDev P, const int
 template <bool X_BSR, bool TRANSPOSE_X, bool OUT_BSR>
 __global__ __launch_bounds__(kBlock) void k_block_products(ProdMap mp, BsrDev XA, const double* __restrict__ X,
                                                            const double* __restrict__ Y,
-                                                           double* __restrict__ out, size_t nout, const int* __restrict__ mirror) {
+                                                           double* __restrict__ out, size_t nout, const int* __restrict__ mirror,
+                                                           const int* __restrict__ rowof, int row0, int row1, int keep_key) {
   const int lane = threadIdx.x & 63;
   int gi, gend, gstride;
   group_walk(mp.ngrp, &gi, &gend, &gstride);
@@ -282,6 +294,16 @@ __global__ __launch_bounds__(kBlock) void k_block_products(ProdMap mp, BsrDev XA
     for (int t = gb + lane; t < ge; t += 64) {
       key = mp.tgt[t];
       const size_t ia = (size_t)mp.a[t], ib = (size_t)mp.b[t];
+      // multi-GPU, row-owner mode: only the products whose left operand lives in one of this rank's fine rows (rowof[a]).
+      // keep_key (P^T A P, summed over ranks afterwards): a target without any owned product still stores the zero it
+      // owes the all-reduce; otherwise (A P: a target's products all sit in one row) it is another rank's and is skipped
+      if (row1 > 0) {
+        const int i = rowof[ia];
+        if (i < row0 || i >= row1) {
+          if (!keep_key) key = -1 - lane;
+          continue;
+        }
+      }
       double x[9], y[9];
       if (X_BSR) load_block(XA, ia, x);
       else load9(X, ia, x);
@@ -401,7 +423,7 @@ void launch_restrict_p(hipStream_t s, const PDev& P, const double* r, double* rc
 __global__ __launch_bounds__(kBlock) void k_prolong_p(int n, PDev P, const double* __restrict__ u1, SpmvRatio r1,
                                                       const double* __restrict__ u2, SpmvRatio r2,
                                                       double* __restrict__ x, const PcgScalars* S,
-                                                      const double* __restrict__ xadd) {
+                                                      const double* __restrict__ xadd, int row0, int row1) {
   int g, gend, gstride;
   group_walk(P.r_ngrp, &g, &gend, &gstride);
   int gb0 = 0, ge0 = 0;   // requested before the stop flag is waited for (see k_restrict_p)
@@ -429,6 +451,10 @@ __global__ __launch_bounds__(kBlock) void k_prolong_p(int n, PDev P, const doubl
     int key = -1 - lane;
     for (int e = gb + lane; e < ge; e += 64) {
       key = P.row[e];
+      if (row1 > 0 && (key < row0 || key >= row1)) {   // multi-GPU: another rank's row
+        key = -1 - lane;
+        continue;
+      }
       const size_t a = 3 * (size_t)P.col[e];
       double w0 = c1 * u1[a], w1 = c1 * u1[a + 1], w2 = c1 * u1[a + 2];
       if (u2) {
@@ -513,7 +539,7 @@ __global__ __launch_bounds__(kBlock) void k_prolong_add(int n, const int* __rest
                                                         const double* __restrict__ u1, SpmvRatio r1,
                                                         const double* __restrict__ u2, SpmvRatio r2,
                                                         double* __restrict__ x, const PcgScalars* S,
-                                                        const double* __restrict__ xadd) {
+                                                        const double* __restrict__ xadd, int row0, int row1) {
   if (S && S->stop) return;
   double c1 = 1.0, c2 = 0.0;
   {
@@ -525,7 +551,8 @@ __global__ __launch_bounds__(kBlock) void k_prolong_add(int n, const int* __rest
     if (r1.num) c1 = (v[0] > 0.0 && isfinite(v[0]) && isfinite(v[1])) ? v[1] / v[0] : 0.0;
     if (u2) c2 = (v[2] > 0.0 && isfinite(v[2]) && isfinite(v[3])) ? v[3] / v[2] : 0.0;
   }
-  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+  const int ilo = row1 > 0 ? row0 : 0, ihi = row1 > 0 ? row1 : n;
+  for (int i = ilo + blockIdx.x * kBlock + threadIdx.x; i < ihi; i += gridDim.x * kBlock) {
     const size_t a = 3 * (size_t)agg[i], o = 3 * (size_t)i;
     double w0 = c1 * u1[a], w1 = c1 * u1[a + 1], w = c1 * u1[a + 2];
     if (u2) {
@@ -1778,7 +1805,8 @@ struct Amg {
   AmgProf prof;
   Sym0Dev S0;               // level-0 operator in symmetric storage (lv[0].A is its logical view)
   Tile0Dev T0;              // ... and its tile view
-  Comm* comm = nullptr;     // multi-GPU: level-0 products over the units [u0, u1) (= rows [row0, row1)) + all-reduce
+  Comm* comm = nullptr;     // multi-GPU, all-reduce mode: level-0 products over the units [u0, u1) (= rows [row0, row1)) + all-reduce
+  const HaloDev* halo = nullptr;   // multi-GPU, row-owner mode (sgo_internal.h): level-0 work on the owned rows, boundary exchanges
   int u0 = 0, u1 = 0, row0 = 0, row1 = 0;
   bool comm_failed = false;
   DevArena* pool = nullptr;   // the caller's arena (not owned)
@@ -1819,27 +1847,48 @@ double bytes_spmv(const BsrDev& A) { return 80.0 * A.nslot + 48.0 * A.n; }
 
 // Values of the operator of level l+1 from those of level l (lever arms L.d must be current):
 // tentative prolongator: one Galerkin pass; smoothed: P values, AP = A P, A_c = P^T AP.
-void launch_coarse_operator(Amg* m, hipStream_t s, AmgLevel& L, AmgLevel& C) {
+// Multi-GPU, row-owner mode (level 0 only; the coarser levels are replicated): every rank makes the entries of P and of
+// A P of its own fine rows -- A P needs the P rows of the neighbours' boundary rows: one exchange of 72-byte records --
+// and its rows' share of P^T A P; the ranks' partial coarse operators are summed by an all-reduce of the level-1 blocks.
+void launch_coarse_operator(Amg* m, hipStream_t s, AmgLevel& L, AmgLevel& C, bool level0) {
+  const HaloDev* H = level0 ? m->halo : nullptr;
+  const int row0 = H ? H->row0 : 0, row1 = H ? H->row1 : 0;
   if (!L.smoothed) {
-    Scope sc(m->prof, K_GALERKIN, (72.0 + 16.0 + 32.0) * L.A.nslot + 72.0 * C.A.nslot);
-    SGO_LAUNCH(k_galerkin, dim3(grid_for(L.gal.ngrp, kWavesPerBlock)), dim3(kBlock), 0, s, L.A, C.A, L.gal, L.d);
+    {
+      Scope sc(m->prof, K_GALERKIN, (72.0 + 16.0 + 32.0) * L.A.nslot + 72.0 * C.A.nslot);
+      SGO_LAUNCH(k_galerkin, dim3(grid_for(L.gal.ngrp, kWavesPerBlock)), dim3(kBlock), 0, s, L.A, C.A, L.gal, L.d, row0, row1);
+    }
+    if (H && H->comm) {
+      std::string e;
+      if (!H->comm->allreduce_f64(C.A.blk, 9 * (size_t)C.A.nslot, s, &e)) m->comm_failed = true;
+    }
     return;
   }
   PDev& P = L.P;
   {
     Scope sc(m->prof, K_SA_P, (72.0 + 12.0 + 16.0) * L.A.nslot + 80.0 * P.np);
     SGO_LAUNCH(k_p_values, dim3(grid_for(P.val.ngrp, kWavesPerBlock)), dim3(kBlock), 0, s, L.A, P, (const int*)L.agg,
-               (const double*)L.d, m->cfg.omega_p);
+               (const double*)L.d, m->cfg.omega_p, row0, row1);
+  }
+  if (H && H->comm) {
+    std::string e;
+    if (!halo_exchange(*H, s, P.blk, 9, H->pent, H->pemax, HaloScalars(), &e)) m->comm_failed = true;
   }
   {
     Scope sc(m->prof, K_SA_AP, 156.0 * P.ap.n + 72.0 * P.nap);
     SGO_LAUNCH((k_block_products<true, false, false>), dim3(grid_for(P.ap.ngrp, kWavesPerBlock)), dim3(kBlock), 0, s,
-               P.ap, L.A, (const double*)nullptr, (const double*)P.blk, P.apblk, (size_t)P.nap, (const int*)nullptr);
+               P.ap, L.A, (const double*)nullptr, (const double*)P.blk, P.apblk, (size_t)P.nap, (const int*)nullptr,
+               (const int*)L.A.row, row0, row1, 0);
   }
   {
     Scope sc(m->prof, K_SA_RAP, 156.0 * P.rap.n + 72.0 * C.A.nslot);
     SGO_LAUNCH((k_block_products<false, true, true>), dim3(grid_for(P.rap.ngrp, kWavesPerBlock)), dim3(kBlock), 0, s,
-               P.rap, BsrDev(), (const double*)P.blk, (const double*)P.apblk, C.A.blk, (size_t)C.A.nslot, (const int*)P.rap_mirror);
+               P.rap, BsrDev(), (const double*)P.blk, (const double*)P.apblk, C.A.blk, (size_t)C.A.nslot, (const int*)P.rap_mirror,
+               (const int*)P.row, row0, row1, 1);
+  }
+  if (H && H->comm) {
+    std::string e;
+    if (!H->comm->allreduce_f64(C.A.blk, 9 * (size_t)C.A.nslot, s, &e)) m->comm_failed = true;
   }
 }
 
@@ -1909,21 +1958,28 @@ int cycle(Amg* m, hipStream_t s, int l, const double* rhs, const double* rhs_sub
   AmgLevel& C = m->lv[l + 1];
   const int last = (int)m->lv.size() - 1;
   const double* rhs_eff = rhs;
-  const bool sharded0 = l == 0 && m->comm != nullptr;
+  const HaloDev* H = l == 0 ? m->halo : nullptr;           // multi-GPU, row-owner mode
+  const bool sharded0 = l == 0 && m->comm != nullptr && !H;   // multi-GPU, all-reduce mode
+  const int frow0 = H ? H->row0 : (sharded0 ? m->row0 : 0), frow1 = H ? H->row1 : (sharded0 ? m->row1 : 0);
   if (l == 0) {
     // finest level, symmetric storage: xs = omega Dinv rhs (first sweep from zero; normally left by the
     // producer of rhs), then the residual rs = rhs - H xs in one pass over the stored blocks
     if (!xs0_ready) {
       Scope sc(m->prof, K_DOT, 96.0 * L.A.n);
-      launch_precond_bj(s, L.A.n, m->S0.dinv, rhs, L.xs, m->cfg.omega);
+      if (H) launch_precond_bj(s, H->row1 - H->row0, m->S0.dinv + 6 * (size_t)H->row0, rhs + 3 * (size_t)H->row0, L.xs + 3 * (size_t)H->row0, m->cfg.omega);
+      else launch_precond_bj(s, L.A.n, m->S0.dinv, rhs, L.xs, m->cfg.omega);
     }
     Spmv0Args a{};
     a.x = L.xs; a.b = rhs; a.y = L.rs; a.S = S;
-    if (m->comm) {
+    if (H) {   // the neighbours' boundary rows of xs, then this rank's tiles
+      std::string e;
+      if (!halo_exchange(*H, s, L.xs, 3, H->bnd, H->bmax, HaloScalars(), &e)) m->comm_failed = true;
+      a.u0 = H->u0; a.u1 = H->u1;
+    } else if (m->comm) {
       a.u0 = m->u0; a.u1 = m->u1;
       hipMemsetAsync(L.rs, 0, sizeof(double) * 3 * (size_t)L.A.n, s);
     }
-    if (!m->comm || a.u1 > a.u0) {
+    if (!(H || m->comm) || a.u1 > a.u0) {
       Scope sc(m->prof, m->T0.ntile > 0 ? K_SPMV0T_RESID : K_SPMV0_RESID, 76.0 * m->S0.npairs + 120.0 * m->S0.n);
       launch_spmv0_any(s, m->S0, m->T0, S0_RESID, a);
     }
@@ -1956,15 +2012,15 @@ int cycle(Amg* m, hipStream_t s, int l, const double* rhs, const double* rhs_sub
   }
   if (L.smoothed) {
     Scope sc(m->prof, K_RESTRICT_P, 84.0 * L.P.np + 24.0 * L.A.n + 24.0 * L.nc);
-    launch_restrict_p(s, L.P, res, C.bk, S, sharded0 ? m->row0 : 0, sharded0 ? m->row1 : 0);
+    launch_restrict_p(s, L.P, res, C.bk, S, frow0, frow1);
   } else {
     Scope sc(m->prof, K_RESTRICT, 40.0 * L.A.n + 24.0 * L.nc);
     SGO_LAUNCH(k_restrict, dim3(grid_for(L.mem_ngrp, kWavesPerBlock)), dim3(kBlock), 0, s, L.mem_ngrp, L.mem_grp,
-                       L.mem, L.agg, L.d, res, C.bk, S, sharded0 ? m->row0 : 0, sharded0 ? m->row1 : 0);
+                       L.mem, L.agg, L.d, res, C.bk, S, frow0, frow1);
   }
-  if (sharded0) {   // the ranks' partial coarse right-hand sides (each from its own fine rows) -> their sum
+  if (sharded0 || H) {   // the ranks' partial coarse right-hand sides (each from its own fine rows) -> their sum
     std::string e;
-    if (!m->comm->allreduce_f64(C.bk, 3 * (size_t)C.A.n, s, &e)) m->comm_failed = true;
+    if (!(H ? H->comm : m->comm)->allreduce_f64(C.bk, 3 * (size_t)C.A.n, s, &e)) m->comm_failed = true;
   }
   CoarseSol cs;
   if (l + 1 == last) {
@@ -1991,11 +2047,11 @@ int cycle(Amg* m, hipStream_t s, int l, const double* rhs, const double* rhs_sub
     if (L.smoothed) {
       Scope sc(m->prof, K_PROLONG_P, 80.0 * L.P.np + 52.0 * L.A.n);
       SGO_LAUNCH(k_prolong_p, dim3(grid_for(L.P.r_ngrp, kWavesPerBlock)), dim3(kBlock), 0, s, L.A.n, L.P, cs.u1, cs.c1, cs.u2, cs.c2,
-                 L.xs, S, (const double*)nullptr);
+                 L.xs, S, (const double*)nullptr, H ? H->row0 : 0, H ? H->row1 : 0);
     } else {
       Scope sc(m->prof, K_PROLONG, 68.0 * L.A.n);
-      SGO_LAUNCH(k_prolong_add, dim3(grid_for(L.A.n, kBlock)), dim3(kBlock), 0, s, L.A.n, L.agg, L.d, cs.u1, cs.c1,
-                         cs.u2, cs.c2, L.xs, S, (const double*)nullptr);
+      SGO_LAUNCH(k_prolong_add, dim3(grid_for(H ? H->row1 - H->row0 : L.A.n, kBlock)), dim3(kBlock), 0, s, L.A.n, L.agg, L.d, cs.u1, cs.c1,
+                         cs.u2, cs.c2, L.xs, S, (const double*)nullptr, H ? H->row0 : 0, H ? H->row1 : 0);
     }
     Spmv0Args b{};
     b.x = L.xs; b.b = rhs; b.y = out; b.omega = m->cfg.omega; b.S = S;
@@ -2003,6 +2059,15 @@ int cycle(Amg* m, hipStream_t s, int l, const double* rhs, const double* rhs_sub
       b.dotA = dotvec;
       b.dotA2 = dotvec2;
       b.partials = dotparts;
+    }
+    if (H) {
+      // row-owner mode: the corrected xs of the neighbours' boundary rows, then the sweep over this rank's tiles; the dot
+      // products ride on the kernel as per-workgroup partials of the OWNED rows (the caller exchanges their sums)
+      std::string e;
+      if (!halo_exchange(*H, s, L.xs, 3, H->bnd, H->bmax, HaloScalars(), &e)) m->comm_failed = true;
+      b.u0 = H->u0; b.u1 = H->u1;
+      Scope sc(m->prof, m->T0.ntile > 0 ? K_SPMV0T_JACOBI : K_SPMV0_JACOBI, (76.0 * m->S0.npairs + 168.0 * m->S0.n) / H->G);
+      return launch_spmv0_any(s, m->S0, m->T0, S0_JACOBI, b);
     }
     if (m->comm) {
       // this rank's rows, zeros elsewhere, all-reduce, then the dot products on the full vector (replicated)
@@ -2025,14 +2090,10 @@ int cycle(Amg* m, hipStream_t s, int l, const double* rhs, const double* rhs_sub
     return launch_spmv0_any(s, m->S0, m->T0, S0_JACOBI, b);
   }
   if (L.smoothed) {
-    if (L.smoothed) {
+    {
       Scope sc(m->prof, K_PROLONG_P, 80.0 * L.P.np + 52.0 * L.A.n);
       SGO_LAUNCH(k_prolong_p, dim3(grid_for(L.P.r_ngrp, kWavesPerBlock)), dim3(kBlock), 0, s, L.A.n, L.P, cs.u1, cs.c1, cs.u2, cs.c2,
-                 L.xs, S, (const double*)nullptr);
-    } else {
-      Scope sc(m->prof, K_PROLONG, 68.0 * L.A.n);
-      SGO_LAUNCH(k_prolong_add, dim3(grid_for(L.A.n, kBlock)), dim3(kBlock), 0, s, L.A.n, L.agg, L.d, cs.u1, cs.c1,
-                         cs.u2, cs.c2, L.xs, S, (const double*)nullptr);
+                 L.xs, S, (const double*)nullptr, 0, 0);
     }
     // post-smoothing: nu sweeps, the first nu - 1 through the two residual buffers (free by now)
     for (int sw = 1; sw < nu; ++sw) {
@@ -2085,7 +2146,7 @@ int amg_update(Amg* m, hipStream_t s, std::string* err) {
       Scope sc(m->prof, K_CENTRES, 36.0 * L.A.n);
       SGO_LAUNCH(k_centres, dim3(grid_for(L.nc, kWavesPerBlock)), dim3(kBlock), 0, s, L.nc, L.mem_ptr, L.mem, L.pos, C.pos, L.d);
     }
-    launch_coarse_operator(m, s, L, C);
+    launch_coarse_operator(m, s, L, C, l == 0);
     {
       Scope sc(m->prof, K_LEVEL_DINV, 120.0 * C.A.n);
       SGO_LAUNCH(k_level_dinv, dim3(grid_for(C.A.n, kBlock)), dim3(kBlock), 0, s, C.A);
@@ -2224,6 +2285,7 @@ struct AmgHostL0 {
 };
 AmgHostL0* amg_host_l0_new() { return new AmgHostL0(); }
 void amg_host_l0_free(AmgHostL0* p) { delete p; }
+bool amg_host_l0_ready(const AmgHostL0* p) { return p && p->ready; }
 void amg_host_l0_run(AmgHostL0* p, const HostLevel& H0, const std::vector<double>& w, const AmgConfig& cfg_in, ChunkArena* scratch) {
   try {
     const AmgConfig cfg = amg_effective_config(cfg_in, H0.n, H0.nslot);
@@ -2237,8 +2299,9 @@ void amg_host_l0_run(AmgHostL0* p, const HostLevel& H0, const std::vector<double
 
 Amg* amg_create(hipStream_t s, const BsrDev& A0, const Sym0Dev& S0, const Tile0Dev& T0, const HostLevel& H0, const double* d_poses,
                 const int* d_free_id, const AmgConfig& cfg_in, const AmgProf& prof, std::string* err,
-                ChunkArena* scratch, DevArena* arena, AmgHostL0* pre0) {
+                ChunkArena* scratch, DevArena* arena, AmgHostL0* pre0, const AmgHalo* halo) {
   Amg* m = new Amg();
+  if (halo) m->halo = halo->dev;
   m->pool = arena;
   m->cfg = cfg_in;
   m->S0 = S0;
@@ -2298,7 +2361,10 @@ Amg* amg_create(hipStream_t s, const BsrDev& A0, const Sym0Dev& S0, const Tile0D
 
     // strength of connection from the current values of this level
     std::vector<double> w;
-    if (!(l == 0 && pre0 && pre0->ready)) {
+    if (l == 0 && halo && !(pre0 && pre0->ready)) {
+      if (!halo->w0 || (int)halo->w0->size() != H.nslot) return fail("amg_create: row-owner mode needs the level-0 strength weights");
+      w = *halo->w0;
+    } else if (!(l == 0 && pre0 && pre0->ready)) {
       w.resize(H.nslot);
       double* d_w = dev_alloc<double>(m->pool, (size_t)std::max(H.nslot, 1));   // (stays in the arena until its rewind)
       if (!d_w) return fail("amg_create: out of device memory");
@@ -2407,6 +2473,26 @@ Amg* amg_create(hipStream_t s, const BsrDev& A0, const Sym0Dev& S0, const Tile0D
           !P.apblk || (!sa.lists_on_device && (!P.ap.a || !P.ap.b || !P.ap.tgt || !P.ap.grp || !P.rap.a || !P.rap.b || !P.rap.tgt || !P.rap.grp)))
         return fail("amg_create: out of device memory");
       l0_dev = {d_ap_rowptr, d_ap_col, d_ap_row, d_t_ptr, d_t_idx};
+      if (l == 0 && halo) {
+        // the entries of P in every rank's boundary rows: what A P of a neighbour's rows gathers from this rank's P
+        std::vector<std::vector<int>> pe((size_t)halo->G);
+        int pemax = 1;
+        for (int q = 0; q < halo->G; ++q) {
+          for (int t = 0; t < halo->bmax; ++t) {
+            const int r = halo->bnd_host[(size_t)q * halo->bmax + t];
+            if (r < 0) break;
+            for (int e = sa.p_rowptr[r]; e < sa.p_rowptr[r + 1]; ++e) pe[q].push_back(e);
+          }
+          pemax = std::max(pemax, (int)pe[q].size());
+        }
+        std::vector<int> flat((size_t)halo->G * pemax, -1);
+        for (int q = 0; q < halo->G; ++q) std::copy(pe[q].begin(), pe[q].end(), flat.begin() + (size_t)q * pemax);
+        int* d_pe = dev_upload(m->pool, flat, s);
+        if (!d_pe || hipStreamSynchronize(s) != hipSuccess) return fail("amg_create: out of device memory");
+        halo->dev->pemax = pemax;
+        halo->dev->pent = d_pe;
+        if (halo->reserve && !halo->reserve(halo->user, (size_t)kHaloScalars + 9 * (size_t)pemax)) return fail("amg_create: out of device memory (exchange buffers)");
+      }
       std::snprintf(line, sizeof line, "(P %d, AP %d blocks; %d + %d products) ", P.np, P.nap, P.ap.n, P.rap.n);
       m->desc += line;
     } else {
@@ -2491,7 +2577,7 @@ Amg* amg_create(hipStream_t s, const BsrDev& A0, const Sym0Dev& S0, const Tile0D
       if (l == 0)
         SGO_LAUNCH(k_positions0, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, s, n, d_free_id, d_poses, Lr.pos);
       SGO_LAUNCH(k_centres, dim3(grid_for(nc, kWavesPerBlock)), dim3(kBlock), 0, s, nc, Lr.mem_ptr, Lr.mem, Lr.pos, Cr.pos, Lr.d);
-      launch_coarse_operator(m, s, Lr, Cr);
+      launch_coarse_operator(m, s, Lr, Cr, l == 0);
       if (l + 1 < m->cfg.max_levels) SGO_LAUNCH(k_level_dinv, dim3(grid_for(Cr.A.n, kBlock)), dim3(kBlock), 0, s, Cr.A);
       if (hipStreamSynchronize(s) != hipSuccess) return fail("amg_create: Galerkin kernel failed");
       if (std::getenv("SGO_VERBOSE") && n > 20000)

@@ -114,6 +114,8 @@ void sgo_destroy(sgo_ctx* c) {
   for (hipEvent_t ev : c->ev_S)
     if (ev) hipEventDestroy(ev);
   if (c->h_hist) hipHostFree(c->h_hist);
+  if (c->halo_send) hipFree(c->halo_send);
+  if (c->halo_recv) hipFree(c->halo_recv);
   if (c->h_dres) hipHostFree(c->h_dres);
   if (c->d_dres) hipFree(c->d_dres);
   if (c->stream) hipStreamDestroy(c->stream);
@@ -341,6 +343,7 @@ int sgo_linearize(sgo_ctx* c, double* b, double* diag, double* plain, double* ro
     if ((rc = ensure_amg(c))) return rc;
     if ((rc = do_chi2(c, c->d_hist, nullptr))) return rc;
     if ((rc = do_linearize(c))) return rc;
+    if (c->owner && !halo_gather_slices(c->halo, c->stream, c->d_dgb, 9, &c->err)) return SGO_ECOMM;   // every rank reports all rows
     std::vector<double> dgb(9 * (size_t)c->n);
     HIP_TRY(c, hipMemcpyAsync(dgb.data(), c->d_dgb, sizeof(double) * dgb.size(), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipMemcpyAsync(c->h_hist, c->d_hist, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -376,6 +379,7 @@ int sgo_hessian_apply(sgo_ctx* c, const double* x, double* y) {
     }
     if ((rc = vec_to_device(c, x, c->d_s1))) return rc;
     if ((rc = do_spmv(c, c->d_s1, c->d_s2, false, nullptr, nullptr))) return rc;
+    if (c->owner && !halo_gather_slices(c->halo, c->stream, c->d_s2, 3, &c->err)) return SGO_ECOMM;
     return vec_from_device(c, c->d_s2, y);
   } SGO_CATCH(c)
 }
@@ -391,7 +395,10 @@ int sgo_precondition(sgo_ctx* c, const double* r, double* z) {
     }
     if ((rc = vec_to_device(c, r, c->d_s1))) return rc;
     if (c->amg) amg_apply(c->amg, c->stream, c->d_s1, c->d_s2, nullptr, nullptr, nullptr);
+    else if (c->owner) launch_precond_bj(c->stream, c->halo.row1 - c->halo.row0, c->S0.dinv + 6 * (size_t)c->halo.row0, c->d_s1 + 3 * (size_t)c->halo.row0, c->d_s2 + 3 * (size_t)c->halo.row0, 1.0);
     else launch_precond_bj(c->stream, c->n, c->S0.dinv, c->d_s1, c->d_s2, 1.0);
+    if (c->amg && amg_comm_failed(c->amg)) return SGO_ECOMM;
+    if (c->owner && !halo_gather_slices(c->halo, c->stream, c->d_s2, 3, &c->err)) return SGO_ECOMM;
     return vec_from_device(c, c->d_s2, z);
   } SGO_CATCH(c)
 }
@@ -406,10 +413,11 @@ int sgo_solve(sgo_ctx* c, double* x, double* relres) {
     }
     // restart from the state of the last linearisation (idempotent re-finalize)
     int grid = 0;
-    launch_finalize(c->stream, c->S0, c->d_dgb, c->d_b, c->d_x, c->d_r, c->d_z, c->d_p,
-                    c->amg ? amg_xs0(c->amg) : nullptr, c->amg ? amg_omega(c->amg) : 0.0, c->d_partials, &grid);
+    launch_finalize(c->stream, c->S0, c->owner ? c->halo.row0 : 0, c->owner ? c->halo.row1 : c->n, c->d_dgb, c->d_b, c->d_x, c->d_r,
+                    c->d_z, c->d_p, c->amg ? amg_xs0(c->amg) : nullptr, c->amg ? amg_omega(c->amg) : 0.0, c->d_partials, &grid);
     if ((rc = start_pcg(c, grid))) return rc;
     if ((rc = run_pcg(c))) return rc;
+    if (c->owner && !halo_gather_slices(c->halo, c->stream, c->d_x, 3, &c->err)) return SGO_ECOMM;
     if (x && (rc = vec_from_device(c, c->d_x, x))) return rc;
     if (relres) *relres = c->h_S->bb > 0 ? std::sqrt(c->h_S->rr / c->h_S->bb) : 0.0;
     if (c->h_S->stop == 3) {

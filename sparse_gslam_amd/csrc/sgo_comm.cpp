@@ -31,6 +31,7 @@ struct Api {
   int (*CommInitRank)(ncclComm_t*, int, NcclUniqueId, int) = nullptr;
   int (*CommDestroy)(ncclComm_t) = nullptr;
   int (*AllReduce)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+  int (*AllGather)(const void*, void*, size_t, int, ncclComm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
   std::string err;
 };
@@ -60,8 +61,9 @@ bool load(std::string* err) {
   a.CommInitRank = (decltype(a.CommInitRank))dlsym(a.handle, "ncclCommInitRank");
   a.CommDestroy = (decltype(a.CommDestroy))dlsym(a.handle, "ncclCommDestroy");
   a.AllReduce = (decltype(a.AllReduce))dlsym(a.handle, "ncclAllReduce");
+  a.AllGather = (decltype(a.AllGather))dlsym(a.handle, "ncclAllGather");
   a.GetErrorString = (decltype(a.GetErrorString))dlsym(a.handle, "ncclGetErrorString");
-  if (!a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.AllReduce) {
+  if (!a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.AllReduce || !a.AllGather) {
     *err = "librccl lacks a required symbol";
     dlclose(a.handle);
     a.handle = nullptr;
@@ -106,9 +108,10 @@ bool Comm::init(int nranks_, int rank_, const void* id128, std::string* err) {
   return true;
 }
 
-bool Comm::init_host(int nranks_, int rank_, HostAllreduce fn, void* user) {
+bool Comm::init_host(int nranks_, int rank_, HostAllreduce fn, void* user, HostAllgather gather) {
   destroy();
   host_fn = fn;
+  host_gather_fn = gather;
   host_user = user;
   nranks = nranks_;
   rank = rank_;
@@ -122,24 +125,74 @@ void Comm::destroy() {
   stage = nullptr;
   stage_cap = 0;
   host_fn = nullptr;
+  host_gather_fn = nullptr;
   host_user = nullptr;
   nranks = 1;
   rank = 0;
 }
 
+bool Comm::stage_reserve(size_t count, std::string* err) {
+  if (count <= stage_cap) return true;
+  if (stage) hipHostFree(stage);
+  stage = nullptr;
+  stage_cap = 0;
+  const size_t cap = count + count / 2 + 64;
+  if (hipHostMalloc((void**)&stage, cap * sizeof(double), hipHostMallocDefault) != hipSuccess) {
+    *err = "host transport: cannot allocate the pinned staging buffer";
+    return false;
+  }
+  stage_cap = cap;
+  return true;
+}
+
+bool Comm::allgather_f64(const double* send, double* recv, size_t count, hipStream_t s, std::string* err) {
+  if (count == 0) return true;
+  if (host_fn) {   // caller's transport, staged through pinned host memory
+    const size_t total = count * (size_t)nranks;
+    if (!stage_reserve(total + count, err)) return false;
+    double* own = stage + total;   // this rank's contribution (behind the gathered image)
+    if (hipMemcpyAsync(own, send, count * sizeof(double), hipMemcpyDeviceToHost, s) != hipSuccess ||
+        hipStreamSynchronize(s) != hipSuccess) {
+      *err = "host transport: device -> host copy failed";
+      return false;
+    }
+    int rc;
+    if (host_gather_fn) {
+      rc = host_gather_fn(own, count, stage, host_user);
+    } else {
+      // an all-reduce of zero-padded slots IS an all-gather: every element has one non-zero contributor, the sum is exact
+      std::memset(stage, 0, total * sizeof(double));
+      std::memcpy(stage + (size_t)rank * count, own, count * sizeof(double));
+      rc = host_fn(stage, total, host_user);
+    }
+    if (rc != 0) {
+      *err = "host transport: the all-gather callback returned " + std::to_string(rc);
+      return false;
+    }
+    if (hipMemcpyAsync(recv, stage, total * sizeof(double), hipMemcpyHostToDevice, s) != hipSuccess) {
+      *err = "host transport: host -> device copy failed";
+      return false;
+    }
+    return true;
+  }
+  if (!handle) {   // no communicator: the rank-emulation test hook, or one rank
+    if (nranks == 1 && hipMemcpyAsync(recv, send, count * sizeof(double), hipMemcpyDeviceToDevice, s) != hipSuccess) {
+      *err = "all-gather: device copy failed";
+      return false;
+    }
+    return true;
+  }
+  int rc = api().AllGather(send, recv, count, kNcclFloat64, (ncclComm_t)handle, s);
+  if (rc != 0) {
+    *err = "ncclAllGather(f64): " + nccl_err(rc);
+    return false;
+  }
+  return true;
+}
+
 bool Comm::allreduce_f64(double* buf, size_t count, hipStream_t s, std::string* err) {
   if (host_fn) {   // caller's transport: device -> pinned host -> callback (sum over ranks) -> device
-    if (count > stage_cap) {
-      if (stage) hipHostFree(stage);
-      stage = nullptr;
-      stage_cap = 0;
-      const size_t cap = count + count / 2 + 64;
-      if (hipHostMalloc((void**)&stage, cap * sizeof(double), hipHostMallocDefault) != hipSuccess) {
-        *err = "host transport: cannot allocate the pinned staging buffer";
-        return false;
-      }
-      stage_cap = cap;
-    }
+    if (!stage_reserve(count, err)) return false;
     if (hipMemcpyAsync(stage, buf, count * sizeof(double), hipMemcpyDeviceToHost, s) != hipSuccess ||
         hipStreamSynchronize(s) != hipSuccess) {
       *err = "host transport: device -> host copy failed";

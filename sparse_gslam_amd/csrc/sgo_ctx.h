@@ -39,6 +39,14 @@ struct HostArena {
   }
 };
 
+// Host image of the row-owner partition (multi-GPU): what the multigrid set-up needs to list the entries of P in the
+// boundary rows.
+struct HaloHost {
+  int G = 1, me = 0, bmax = 0;
+  std::vector<int> rank_row;   // [G + 1]
+  std::vector<int> bnd;        // [G][bmax], -1 padded
+};
+
 struct sgo_ctx {
   int device = 0;
   HostArena stage;
@@ -50,6 +58,12 @@ struct sgo_ctx {
   int shard_u0 = 0, shard_u1 = 0, shard_units = 0;   // multi-GPU: this rank's range of level-0 work units (tiles)
   int shard_row0 = 0, shard_row1 = 0;                //            = these rows
   std::vector<int> unit_row0;                        // first row of every work unit (+ n at the end)
+  bool owner = false;            // multi-GPU row-owner mode (HaloDev, sgo_internal.h); false with a communicator: all-reduce mode
+  HaloDev halo;
+  HaloHost halo_host;
+  bool halo_failed = false;
+  double *halo_send = nullptr, *halo_recv = nullptr;   // exchange buffers (hipMalloc, grown on demand, kept across graphs)
+  size_t halo_cap = 0;
 
   // graph (host)
   bool has_graph = false;
@@ -69,6 +83,8 @@ struct sgo_ctx {
   Tile0Dev T0;                   // ... its tile view (ntile == 0: no tile view, products use the wave-group kernel)
   BsrDev A;                      // its logical view (multigrid set-up kernels)
   EdgeSlotsDev es;
+  int *d_rowptr = nullptr, *d_eidx = nullptr, *d_hrowptr = nullptr;   // compact-slot row pointers, slot -> edge, logical row pointers
+                                                                       // (k_row_strength: set-up pipeline and row-owner mode)
   double *d_dgb = nullptr, *d_b = nullptr, *d_x = nullptr, *d_r = nullptr, *d_z = nullptr, *d_p = nullptr,
          *d_q = nullptr, *d_s1 = nullptr, *d_s2 = nullptr, *d_e2 = nullptr;
   double* d_partials = nullptr;   // [3][kMaxPartials]
@@ -266,6 +282,7 @@ constexpr int kTileDiv = 256;
 void l0_join(sgo_ctx* c, bool keep);
 inline void l0_discard(sgo_ctx* c) { l0_join(c, false); }
 void free_graph(sgo_ctx* c);
+int halo_reserve(sgo_ctx* c, size_t packet_doubles);   // exchange buffers for packets of this many doubles per rank
 int build_edges(sgo_ctx* c, int V, const double* poses, const uint8_t* fixed, int E, const int32_t* ei, const int32_t* ej,
                 const double* meas, const double* info, const double* phi);
 int build_structure(sgo_ctx* c, int V, const double* poses, const uint8_t* fixed, int E, const int32_t* ei,

@@ -231,6 +231,43 @@ struct Spmv0Args {
                                  // are evaluated, i.e. only their rows of y are written (u1 == 0: all)
 };
 
+// ----------------------------------------------------------------------------------------
+// Multi-GPU, row-owner mode.  Rank r owns a contiguous range of tiles = the rows
+// [row0, row1): it linearises, multiplies, smooths, restricts, prolongates and updates these rows only.  What another
+// rank needs of a vector computed here are its BOUNDARY rows -- the rows with an edge into another rank's range; with
+// Hilbert-ordered rows a few per cent of the range -- and the partial sums of the dot products.  One exchange =
+// pack (this rank's scalars + boundary rows) -> all-gather of one fixed-size packet per rank -> unpack (every other
+// rank's boundary rows into the full-length vector at their global row numbers, the ranks' scalars side by side for
+// the consumers' fixed-order reduction: bit-identical on all ranks).  The same packets carry 72-byte records
+// (boundary rows of the smoothed prolongator, once per GN iteration); whole owned slices travel the same way once
+// per GN iteration (the step, for the replicated pose update).
+// ----------------------------------------------------------------------------------------
+struct Comm;
+constexpr int kHaloScalars = 4;      // scalar slots at the head of every packet
+struct HaloDev {
+  Comm* comm = nullptr;
+  int G = 1, me = 0;
+  int row0 = 0, row1 = 0;            // owned rows
+  int u0 = 0, u1 = 0;                // owned tiles
+  int g0 = 0, g1 = 0;                // owned wave groups of the compact slot list (k_linearize)
+  int bmax = 0;                      // boundary rows per rank (padded to the largest)
+  const int* bnd = nullptr;          // [G][bmax] boundary rows of every rank (global row numbers), -1 beyond a rank's own
+  int maxrows = 0;                   // owned rows per rank (largest)
+  const int* rank_row = nullptr;     // device [G + 1] first row of every rank
+  int pemax = 0;                     // entries of P in the boundary rows, per rank (padded): set by the multigrid set-up
+  const int* pent = nullptr;         // [G][pemax] their entry numbers, -1 beyond a rank's own
+  double* send = nullptr;            // one packet
+  double* recv = nullptr;            // [G] packets
+  size_t cap = 0;                    // doubles per packet the buffers hold
+  double* gparts = nullptr;          // [kHaloScalars][G] the ranks' scalars of the last exchange (slot-major)
+  bool* failed = nullptr;            // host flag: a collective failed
+};
+// scalars of an exchange: up to kHaloScalars arrays of per-workgroup partial sums, reduced in a fixed order by the pack kernel
+struct HaloScalars {
+  const double* parts[kHaloScalars] = {nullptr, nullptr, nullptr, nullptr};
+  int n[kHaloScalars] = {0, 0, 0, 0};
+};
+
 // One profiling slot per __global__ symbol (template instantiations separately), named as
 // rocprofv3 --kernel-trace prints them, so bench.py's event timings can be checked 1:1 against
 // the committed rocprof summaries.
@@ -402,7 +439,7 @@ void launch_early_strength(hipStream_t s, const EdgeListDev& el, const double* p
                            const unsigned char* flags, const int* hrowptr, double* w);
 void launch_linearize(hipStream_t s, const Sym0Dev& A, int g0, int g1, const EdgeSlotsDev& es, const double* poses,
                       double* dgb /*[n][9]*/);
-void launch_finalize(hipStream_t s, const Sym0Dev& A, const double* dgb, double* b, double* x, double* r, double* z,
+void launch_finalize(hipStream_t s, const Sym0Dev& A, int row0, int row1, const double* dgb, double* b, double* x, double* r, double* z,
                      double* p, double* xs, double omega, double* partials, int* grid_out);
 void launch_init_scalars(hipStream_t s, PcgScalars* S, const double* rz_parts, int n_rz, const double* bb_parts,
                          int n_bb, double tol, int maxit, double bb_ref, double tol_cap);
@@ -428,5 +465,11 @@ void launch_closure_cov(hipStream_t s, int n, const sgo_match_window* win, const
 void launch_dot(hipStream_t s, int n3, const double* a, const double* b, double* partials, const PcgScalars* S,
                 int* grid_out);
 void launch_precond_bj(hipStream_t s, int n, const double* dinv, const double* r, double* z, double scale);
+// row-owner mode: one exchange of `width`-double records (3: rows of a vector through H.bnd; 9: entries of P through H.pent;
+// idx == nullptr, width 0: scalars only) + the scalars; returns false when the collective failed
+bool halo_exchange(const HaloDev& H, hipStream_t s, double* data, int width, const int* idx, int idx_max, const HaloScalars& sc,
+                   std::string* err);
+// every rank's owned slice of a [n][width] array to every rank (the full-length array is valid everywhere afterwards)
+bool halo_gather_slices(const HaloDev& H, hipStream_t s, double* vec, int width, std::string* err);
 
 }  // namespace sgo

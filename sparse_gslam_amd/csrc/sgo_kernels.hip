@@ -20,6 +20,7 @@
 #include <algorithm>
 #include <cstdlib>
 
+#include "sgo_comm.h"
 #include "sgo_device.h"
 #include "sgo_internal.h"
 
@@ -298,13 +299,13 @@ __global__ __launch_bounds__(kBlock) void k_linearize(Sym0Dev A, int g0, int g1,
 // Per row: diagonal block (symmetric packing), block-diagonal inverse, and the PCG start state
 //   x = 0, r = b, z = Dinv b, p = z ; partials[0][blk] = r.z, partials[1][blk] = b.b
 // and, for the multigrid cycle's first smoothing sweep from zero, xs = omega Dinv b.
-__global__ __launch_bounds__(kBlock) void k_finalize(Sym0Dev A, const double* __restrict__ dgb,
+__global__ __launch_bounds__(kBlock) void k_finalize(Sym0Dev A, int row0, int row1, const double* __restrict__ dgb,
                                                      double* __restrict__ b, double* __restrict__ x,
                                                      double* __restrict__ r, double* __restrict__ z,
                                                      double* __restrict__ p, double* __restrict__ xs, double omega,
                                                      double* __restrict__ partials) {
   double acc[2] = {0.0, 0.0};
-  for (int i = blockIdx.x * kBlock + threadIdx.x; i < A.n; i += gridDim.x * kBlock) {
+  for (int i = row0 + blockIdx.x * kBlock + threadIdx.x; i < row1; i += gridDim.x * kBlock) {   // (multi-GPU: this rank's rows)
     const double* d = dgb + 9 * (size_t)i;
     const double d00 = d[0], d01 = d[1], d02 = d[2], d11 = d[3], d12 = d[4], d22 = d[5];
     const double b0 = d[6], b1 = d[7], b2 = d[8];
@@ -1012,9 +1013,104 @@ __global__ __launch_bounds__(kBlock) void k_pose_update(int n, const int* __rest
   }
 }
 
+// ---------------------------------------------------------------------------- row-owner exchanges
+// pack: workgroup 0 reduces the scalar partial arrays (fixed order) into the packet's head; all workgroups copy the
+// records idx[0 .. cnt) of `width` doubles each (padding entries, idx < 0, travel as zeros)
+__global__ __launch_bounds__(kBlock) void k_halo_pack(const double* __restrict__ data, int width, const int* __restrict__ idx,
+                                                      int cnt, double* __restrict__ send, HaloScalars sc) {
+  if (blockIdx.x == 0) {
+    const double* const parts[kHaloScalars] = {sc.parts[0], sc.parts[1], sc.parts[2], sc.parts[3]};
+    const int n[kHaloScalars] = {sc.n[0], sc.n[1], sc.n[2], sc.n[3]};
+    double v[kHaloScalars];
+    block_reduce_parts_n<kHaloScalars>(parts, n, v);
+    if (threadIdx.x == 0) {
+#pragma unroll
+      for (int k = 0; k < kHaloScalars; ++k) send[k] = v[k];
+    }
+  }
+  const long long total = (long long)cnt * width;
+  for (long long e = (long long)blockIdx.x * kBlock + threadIdx.x; e < total; e += (long long)gridDim.x * kBlock) {
+    const int i = (int)(e / width), c = (int)(e % width);
+    const int g = idx[i];
+    send[kHaloScalars + e] = g >= 0 ? data[(size_t)g * width + c] : 0.0;
+  }
+}
+// unpack: the other ranks' records to their global places, every rank's scalars side by side (slot-major)
+__global__ __launch_bounds__(kBlock) void k_halo_unpack(double* __restrict__ data, int width, const int* __restrict__ idx_all,
+                                                        int cnt, int G, int me, const double* __restrict__ recv, size_t stride,
+                                                        double* __restrict__ gparts) {
+  if (blockIdx.x == 0)
+    for (int t = threadIdx.x; t < kHaloScalars * G; t += kBlock) gparts[t] = recv[(size_t)(t % G) * stride + (size_t)(t / G)];
+  const long long per = (long long)cnt * width, total = per * G;
+  for (long long e = (long long)blockIdx.x * kBlock + threadIdx.x; e < total; e += (long long)gridDim.x * kBlock) {
+    const int s = (int)(e / per);
+    if (s == me) continue;
+    const long long rem = e - (long long)s * per;
+    const int i = (int)(rem / width), c = (int)(rem % width);
+    const int g = idx_all[(size_t)s * cnt + i];
+    if (g >= 0) data[(size_t)g * width + c] = recv[(size_t)s * stride + kHaloScalars + rem];
+  }
+}
+// the other ranks' owned slices of a flat vector to their places
+__global__ __launch_bounds__(kBlock) void k_slices_unpack(double* __restrict__ vec, int width, const int* __restrict__ rank_row, int G, int me,
+                                                          const double* __restrict__ recv, size_t stride) {
+  for (int s = 0; s < G; ++s) {
+    if (s == me) continue;
+    const size_t base = (size_t)width * (size_t)rank_row[s], cnt = (size_t)width * (size_t)(rank_row[s + 1] - rank_row[s]);
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < cnt; i += (size_t)gridDim.x * kBlock)
+      vec[base + i] = recv[(size_t)s * stride + i];
+  }
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------- launchers
+bool halo_exchange(const HaloDev& H, hipStream_t s, double* data, int width, const int* idx, int idx_max, const HaloScalars& sc,
+                   std::string* err) {
+  if (!H.comm) return true;
+  const int cnt = (data && idx) ? idx_max : 0;
+  const size_t stride = (size_t)kHaloScalars + (size_t)cnt * width;
+  if (stride > H.cap) {
+    if (err) *err = "row-owner exchange: packet larger than the exchange buffers";
+    if (H.failed) *H.failed = true;
+    return false;
+  }
+  SGO_LAUNCH(k_halo_pack, dim3(grid_for((long long)cnt * width, kBlock)), dim3(kBlock), 0, s, (const double*)data, width,
+             idx ? idx + (size_t)H.me * idx_max : (const int*)nullptr, cnt, H.send, sc);
+  std::string e;
+  if (!H.comm->allgather_f64(H.send, H.recv, stride, s, &e)) {
+    if (err) *err = e;
+    if (H.failed) *H.failed = true;
+    return false;
+  }
+  SGO_LAUNCH(k_halo_unpack, dim3(grid_for((long long)cnt * width * H.G, kBlock)), dim3(kBlock), 0, s, data, width, idx, cnt, H.G, H.me,
+             (const double*)H.recv, stride, H.gparts);
+  return true;
+}
+bool halo_gather_slices(const HaloDev& H, hipStream_t s, double* vec, int width, std::string* err) {
+  if (!H.comm || H.G <= 1) return true;
+  const size_t stride = (size_t)width * (size_t)H.maxrows;
+  if (stride > H.cap) {
+    if (err) *err = "row-owner exchange: slice larger than the exchange buffers";
+    if (H.failed) *H.failed = true;
+    return false;
+  }
+  if (hipMemcpyAsync(H.send, vec + (size_t)width * (size_t)H.row0, sizeof(double) * (size_t)width * (size_t)(H.row1 - H.row0), hipMemcpyDeviceToDevice, s) != hipSuccess) {
+    if (err) *err = "row-owner exchange: device copy failed";
+    if (H.failed) *H.failed = true;
+    return false;
+  }
+  std::string e;
+  if (!H.comm->allgather_f64(H.send, H.recv, stride, s, &e)) {
+    if (err) *err = e;
+    if (H.failed) *H.failed = true;
+    return false;
+  }
+  SGO_LAUNCH(k_slices_unpack, dim3(grid_for((long long)width * H.maxrows, kBlock)), dim3(kBlock), 0, s, vec, width, H.rank_row, H.G, H.me,
+             (const double*)H.recv, stride);
+  return true;
+}
+
 void launch_chi2(hipStream_t s, const EdgeListDev& el, int e0, int e1, const double* poses, double* e2_out,
                  double* partials, int* grid_out) {
   const int grid = grid_for(e1 - e0, kBlock);
@@ -1029,10 +1125,10 @@ void launch_linearize(hipStream_t s, const Sym0Dev& A, int g0, int g1, const Edg
   const int grid = grid_for(g1 - g0, kWavesPerBlock);
   SGO_LAUNCH(k_linearize, dim3(grid), dim3(kBlock), 0, s, A, g0, g1, es, poses, dgb);
 }
-void launch_finalize(hipStream_t s, const Sym0Dev& A, const double* dgb, double* b, double* x, double* r, double* z,
+void launch_finalize(hipStream_t s, const Sym0Dev& A, int row0, int row1, const double* dgb, double* b, double* x, double* r, double* z,
                      double* p, double* xs, double omega, double* partials, int* grid_out) {
-  const int grid = grid_for(A.n, kBlock);
-  SGO_LAUNCH(k_finalize, dim3(grid), dim3(kBlock), 0, s, A, dgb, b, x, r, z, p, xs, omega, partials);
+  const int grid = grid_for(row1 - row0, kBlock);
+  SGO_LAUNCH(k_finalize, dim3(grid), dim3(kBlock), 0, s, A, row0, row1, dgb, b, x, r, z, p, xs, omega, partials);
   *grid_out = grid;
 }
 void launch_restart_scalars(hipStream_t s, PcgScalars* S, const double* rz_parts, int n_rz, int maxit, int keep_stop) {

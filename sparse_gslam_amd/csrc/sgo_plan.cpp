@@ -421,7 +421,7 @@ int sgo_plan_rows(int32_t V, const double* poses, const uint8_t* fixed, int32_t 
   try {
     RowPlan P;
     std::string err;
-    const int rc = plan_rows(V, poses, fixed, E, ei, ej, kTileDiv, &err, P);
+    const int rc = plan_rows(V, poses, fixed, E, ei, ej, kTileDiv * std::max(1, (int)nranks), &err, P);   // as sgo_set_graph_se2 cuts them for this world size
     if (rc != SGO_OK) {
       g_err = err;
       return rc;

@@ -91,7 +91,76 @@ int do_chi2(sgo_ctx* c, double* d_out2, double* d_e2) {
 // entries).  With the AMG preconditioner: refresh the coarse operators, z = M^-1 b, p = z.
 int do_spmv(sgo_ctx* c, const double* x, double* y, bool dot, const PcgScalars* S, int* grid_out);
 
+// Row-owner mode (multi-GPU): every vector lives on this rank's rows [row0, row1); a product needs the neighbours'
+// boundary rows of its operand (one exchange), a dot product the other ranks' partial sums (they ride on an exchange and
+// are reduced in rank order by the consumer: bit-identical scalars, hence identical decisions, on every rank).
+static bool xch(sgo_ctx* c, double* vec, const HaloScalars& sc) {
+  return halo_exchange(c->halo, c->stream, vec, 3, c->halo.bnd, c->halo.bmax, sc, &c->err);
+}
+static HaloScalars scal(const double* p0, int n0, const double* p1 = nullptr, int n1 = 0, const double* p2 = nullptr, int n2 = 0) {
+  HaloScalars sc;
+  sc.parts[0] = p0; sc.n[0] = n0;
+  sc.parts[1] = p1; sc.n[1] = n1;
+  sc.parts[2] = p2; sc.n[2] = n2;
+  return sc;
+}
+
+static int start_pcg_owner(sgo_ctx* c, int grid) {
+  const HaloDev& H = c->halo;
+  const int G = H.G, nr = H.row1 - H.row0;
+  const size_t o3 = 3 * (size_t)H.row0;
+  const int maxit = c->pcg_softcap > 0 ? std::min(c->pcg_softcap, c->opts.pcg_maxit) : c->opts.pcg_maxit;
+  const double tol = c->opts.pcg_tol * c->tol_scale;
+  double* bb_parts = c->d_partials + kMaxPartials;   // k_finalize: [0] r.z (block-Jacobi), [1] b.b over the owned rows
+  int rc;
+  if (c->amg && (rc = amg_update(c->amg, c->stream, &c->err))) return rc;
+  if (c->amg && amg_comm_failed(c->amg)) return SGO_ECOMM;
+  if (!c->amg) {   // block-Jacobi: k_finalize left z = Dinv b, p = z and the partials of r.z
+    if (!xch(c, c->d_p, scal(c->d_partials, grid, bb_parts, grid))) return SGO_ECOMM;
+    Scope sc(c, K_INIT_SCALARS, 16.0 * G);
+    launch_init_scalars(c->stream, c->d_S, H.gparts, G, H.gparts + G, G, tol, maxit, c->bb_ref, c->tol_cap);
+    return SGO_OK;
+  }
+  if (c->warm_valid && c->d_xprev) {
+    // warm start (see start_pcg): x_prev is the previous step, gathered to every rank before the pose update
+    int gq = 0, gd = 0;
+    // (the product's kernel stores both of its dot-product rows: k_finalize's b.b partials move out of its way first)
+    double* bb_keep = c->d_zparts + kMaxPartials;
+    HIP_TRY(c, hipMemcpyAsync(bb_keep, bb_parts, sizeof(double) * (size_t)grid, hipMemcpyDeviceToDevice, c->stream));
+    if ((rc = do_spmv(c, c->d_xprev, c->d_q, true, nullptr, &gq))) return rc;
+    {
+      Scope sc(c, K_DOT, 48.0 * nr);
+      launch_dot(c->stream, 3 * nr, c->d_b + o3, c->d_xprev + o3, c->d_partials + 2 * kMaxPartials, nullptr, &gd);
+    }
+    if (!xch(c, nullptr, scal(bb_keep, grid, c->d_partials, gq, c->d_partials + 2 * kMaxPartials, gd))) return SGO_ECOMM;
+    {
+      Scope sc(c, K_INIT_SCALARS, 16.0 * G);   // ||b||^2, tolerance, iteration count (r.z is replaced below)
+      launch_init_scalars(c->stream, c->d_S, H.gparts, G, H.gparts, G, tol, maxit, c->bb_ref, c->tol_cap);
+    }
+    {
+      Scope sc(c, K_UPDATE_XR, 120.0 * nr);
+      launch_warm_start(c->stream, 3 * nr, c->d_xprev + o3, c->d_q + o3, c->d_b + o3, c->d_x + o3, c->d_r + o3, H.gparts + G, G,
+                        H.gparts + 2 * G, G);
+    }
+    const int gz = amg_apply(c->amg, c->stream, c->d_r, c->d_z, c->d_r, c->d_zparts, nullptr, nullptr, false);
+    if (amg_comm_failed(c->amg)) return SGO_ECOMM;
+    HIP_TRY(c, hipMemcpyAsync(c->d_p + o3, c->d_z + o3, sizeof(double) * 3 * (size_t)nr, hipMemcpyDeviceToDevice, c->stream));
+    if (!xch(c, c->d_p, scal(c->d_zparts, gz))) return SGO_ECOMM;
+    Scope sc(c, K_INIT_SCALARS, 8.0 * G);
+    launch_restart_scalars(c->stream, c->d_S, H.gparts, G, maxit, 1);
+    return SGO_OK;
+  }
+  const int gz = amg_apply(c->amg, c->stream, c->d_r, c->d_z, c->d_r, c->d_zparts, nullptr, nullptr, true);
+  if (amg_comm_failed(c->amg)) return SGO_ECOMM;
+  HIP_TRY(c, hipMemcpyAsync(c->d_p + o3, c->d_z + o3, sizeof(double) * 3 * (size_t)nr, hipMemcpyDeviceToDevice, c->stream));
+  if (!xch(c, c->d_p, scal(c->d_zparts, gz, bb_parts, grid))) return SGO_ECOMM;
+  Scope sc(c, K_INIT_SCALARS, 16.0 * G);
+  launch_init_scalars(c->stream, c->d_S, H.gparts, G, H.gparts + G, G, tol, maxit, c->bb_ref, c->tol_cap);
+  return SGO_OK;
+}
+
 int start_pcg(sgo_ctx* c, int grid) {
+  if (c->owner) return start_pcg_owner(c, grid);
   if (c->amg && c->warm_valid && c->d_xprev) {
     // Start from the previous Gauss-Newton step scaled by the energy-optimal factor: consecutive steps of a linearly
     // converging iteration are nearly parallel, ||b - gamma H x_prev|| is 0.2-0.45 ||b|| on C4 / C2 (scripts/
@@ -140,14 +209,16 @@ int start_pcg(sgo_ctx* c, int grid) {
 // buildSystem + preconditioner + PCG start state.  Multi-GPU: every rank linearises the whole graph (1.5 % of
 // a GN iteration; sharding it would mean all-reducing the blocks, 72 B per edge, to save it).
 int do_linearize(sgo_ctx* c) {
+  const int g0 = c->owner ? c->halo.g0 : 0, g1 = c->owner ? c->halo.g1 : c->S0.ngrp;   // row-owner mode: this rank's rows
+  const int row0 = c->owner ? c->halo.row0 : 0, row1 = c->owner ? c->halo.row1 : c->n;
   {
-    Scope sc(c, K_LINEARIZE, bytes_linearize(c));
-    launch_linearize(c->stream, c->S0, 0, c->S0.ngrp, c->es, c->d_poses, c->d_dgb);
+    Scope sc(c, K_LINEARIZE, bytes_linearize(c) * (g1 - g0) / std::max(1, c->S0.ngrp));
+    launch_linearize(c->stream, c->S0, g0, g1, c->es, c->d_poses, c->d_dgb);
   }
   int grid = 0;
   {
-    Scope sc(c, K_FINALIZE, (72.0 + 48.0 + 48.0 + 6 * 24.0) * c->n);
-    launch_finalize(c->stream, c->S0, c->d_dgb, c->d_b, c->d_x, c->d_r, c->d_z, c->d_p,
+    Scope sc(c, K_FINALIZE, (72.0 + 48.0 + 48.0 + 6 * 24.0) * (row1 - row0));
+    launch_finalize(c->stream, c->S0, row0, row1, c->d_dgb, c->d_b, c->d_x, c->d_r, c->d_z, c->d_p,
                     c->amg ? amg_xs0(c->amg) : nullptr, c->amg ? amg_omega(c->amg) : 0.0, c->d_partials, &grid);
   }
   int rc = start_pcg(c, grid);
@@ -163,6 +234,20 @@ int do_spmv(sgo_ctx* c, const double* x, double* y, bool dot, const PcgScalars* 
   a.x = x;
   a.y = y;
   a.S = S;
+  if (c->owner) {
+    // row-owner mode: this rank's tiles; x must hold the neighbours' boundary rows (the callers exchange them); the
+    // dot product rides on the kernel as partials over the owned rows
+    a.u0 = c->halo.u0;
+    a.u1 = c->halo.u1;
+    Scope sc(c, K_SPMV0T_AX, bytes_spmv0(c->S0, S0_AX) / c->halo.G);
+    if (dot) {
+      a.dotA = x;
+      a.partials = c->d_partials;
+    }
+    const int grid = launch_spmv0_any(c->stream, c->S0, c->T0, S0_AX, a);
+    if (grid_out) *grid_out = grid;
+    return SGO_OK;
+  }
   if (c->comm.nranks > 1 || c->comm.active()) {
     // multi-GPU: this rank's range of tiles only, zeros elsewhere, all-reduce of the product vector (every row
     // has exactly one non-zero contributor: the sum is exact), then the dot product on the full vectors --
@@ -193,7 +278,41 @@ int do_spmv(sgo_ctx* c, const double* x, double* y, bool dot, const PcgScalars* 
   return SGO_OK;
 }
 
+// One PCG iteration in row-owner mode: five small exchanges (p.q | xs + r.r | xs after the coarse correction | r.z, z.q |
+// p) and the all-reduce of the coarse right-hand side; all vector work on the owned rows.
+static int pcg_iteration_owner(sgo_ctx* c) {
+  const HaloDev& H = c->halo;
+  const int G = H.G, nr = H.row1 - H.row0;
+  const size_t o3 = 3 * (size_t)H.row0;
+  int g1 = 0, g2 = 0, rc;
+  if ((rc = do_spmv(c, c->d_p, c->d_q, true, c->d_S, &g1))) return rc;
+  if (!xch(c, nullptr, scal(c->d_partials, g1))) return SGO_ECOMM;
+  double* parts2 = c->d_partials + kMaxPartials;  // [0] = r.z (block-Jacobi only), [1] = r.r
+  {
+    Scope sc(c, K_UPDATE_XR, (7 * 24.0 + 48.0) * nr);
+    launch_update_xr(c->stream, nr, c->d_S, H.gparts, G, c->S0.dinv + 6 * (size_t)H.row0, c->d_p + o3, c->d_q + o3, c->d_x + o3,
+                     c->d_r + o3, c->d_z + o3, c->amg ? amg_xs0(c->amg) + o3 : nullptr, c->amg ? amg_omega(c->amg) : 0.0, parts2, &g2);
+  }
+  if (c->amg) {
+    const int gz = amg_apply(c->amg, c->stream, c->d_r, c->d_z, c->d_r, c->d_zparts, c->d_S, c->d_q, true);
+    if (amg_comm_failed(c->amg)) {
+      c->err = "collective failed inside the multigrid cycle";
+      return SGO_ECOMM;
+    }
+    if (!xch(c, nullptr, scal(c->d_zparts, gz, parts2 + kMaxPartials, g2, c->d_zparts + kMaxPartials, gz))) return SGO_ECOMM;
+    Scope sc(c, K_UPDATE_P, 3 * 24.0 * nr);
+    launch_update_p(c->stream, nr, c->d_S, H.gparts, G, H.gparts + G, G, H.gparts + 2 * G, c->d_z + o3, c->d_p + o3);
+  } else {
+    if (!xch(c, nullptr, scal(parts2, g2, parts2 + kMaxPartials, g2))) return SGO_ECOMM;
+    Scope sc(c, K_UPDATE_P, 3 * 24.0 * nr);
+    launch_update_p(c->stream, nr, c->d_S, H.gparts, G, H.gparts + G, G, nullptr, c->d_z + o3, c->d_p + o3);
+  }
+  if (!xch(c, c->d_p, HaloScalars())) return SGO_ECOMM;
+  return SGO_OK;
+}
+
 int pcg_iteration(sgo_ctx* c) {
+  if (c->owner) return pcg_iteration_owner(c);
   int g1 = 0, g2 = 0, rc;
   if ((rc = do_spmv(c, c->d_p, c->d_q, true, c->d_S, &g1))) return rc;
   double* parts2 = c->d_partials + kMaxPartials;  // [0] = r.z (block-Jacobi only), [1] = r.r
@@ -337,13 +456,46 @@ int build_amg(sgo_ctx* c) {
   };
   std::string aerr;
   l0_join(c, true);   // the helper thread's analysis of level 0, when set_graph started one (first build only)
+  AmgHalo ah;
+  std::vector<double> w0;
+  if (c->owner) {
+    // row-owner mode: a rank holds current blocks for its own rows only; the strength weights of ALL level-0 slots come
+    // from the (replicated) edge list at the current poses, as in the set-up pipeline
+    if (!(c->l0_pre && amg_host_l0_ready(c->l0_pre))) {
+      double* d_w = (double*)c->amg_arena.take(sizeof(double) * (size_t)std::max(c->H0.nslot, 1));
+      if (!d_w) {
+        c->err = "out of device memory";
+        return SGO_ENOMEM;
+      }
+      launch_early_strength(c->stream, c->el, c->d_poses, c->n, c->d_rowptr, c->d_eidx, c->es.flags, c->d_hrowptr, d_w);
+      w0.resize((size_t)c->H0.nslot);
+      HIP_TRY(c, hipMemcpyAsync(w0.data(), d_w, sizeof(double) * w0.size(), hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    ah.dev = &c->halo;
+    ah.G = c->halo_host.G;
+    ah.bmax = c->halo_host.bmax;
+    ah.bnd_host = c->halo_host.bnd.data();
+    ah.user = c;
+    ah.reserve = [](void* u, size_t doubles) { return halo_reserve((sgo_ctx*)u, doubles) == SGO_OK; };
+    ah.w0 = &w0;
+  }
   c->amg = amg_create(c->stream, c->A, c->S0, c->T0, c->H0, c->d_poses, c->d_free_id, cfg, prof, &aerr, &c->amg_scratch,
-                      &c->amg_arena, c->l0_pre);
+                      &c->amg_arena, c->l0_pre, c->owner ? &ah : nullptr);
   l0_discard(c);
+  if (c->amg && amg_comm_failed(c->amg)) {
+    c->err = "collective failed during the multigrid set-up";
+    return SGO_ECOMM;
+  }
   if (c->amg) {
-    if (c->comm.nranks > 1 || c->comm.active()) amg_set_shard(c->amg, &c->comm, c->shard_u0, c->shard_u1, c->shard_row0, c->shard_row1);
+    if (!c->owner && (c->comm.nranks > 1 || c->comm.active())) amg_set_shard(c->amg, &c->comm, c->shard_u0, c->shard_u1, c->shard_row0, c->shard_row1);
     amg_describe(c->amg, &c->solver_desc);
     c->solver_desc = "pcg_amg: " + c->solver_desc;
+    if (c->owner)
+      c->solver_desc += "; multi-GPU row-owner mode: rank " + std::to_string(c->halo.me) + " of " + std::to_string(c->halo.G) + " owns rows [" +
+                        std::to_string(c->halo.row0) + ", " + std::to_string(c->halo.row1) + "), largest boundary " + std::to_string(c->halo.bmax) + " rows";
+    else if (c->comm.nranks > 1 || c->comm.active())
+      c->solver_desc += "; multi-GPU all-reduce mode (" + std::to_string(c->comm.nranks) + " ranks)";
   } else {
     c->solver_desc = "pcg_block_jacobi (AMG unavailable: " + aerr + ")";
     if (c->opts.verbose) std::fprintf(stderr, "[sgo] %s\n", c->solver_desc.c_str());
@@ -592,6 +744,8 @@ int optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
         hipEventRecord(ev[3 * it + 2], c->stream);
         break;
       }
+      // (row-owner mode: every rank holds all poses; the ranks' slices of the step are gathered first)
+      if (c->owner && !halo_gather_slices(c->halo, c->stream, c->d_x, 3, &c->err)) return SGO_ECOMM;
       {
         Scope sc(c, K_POSE_UPDATE, 72.0 * c->n);
         launch_pose_update(c->stream, c->n, c->d_free_id, c->d_x, c->d_poses);

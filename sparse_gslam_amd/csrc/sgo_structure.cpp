@@ -22,6 +22,27 @@ void l0_join(sgo_ctx* c, bool keep) {
   // (c->l0_w keeps its storage: a fresh 17-MB vector per call is 4000 page faults on the set-up's critical path)
 }
 
+int halo_reserve(sgo_ctx* c, size_t packet_doubles) {
+  if (packet_doubles > c->halo_cap) {
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->halo_send) hipFree(c->halo_send);
+    if (c->halo_recv) hipFree(c->halo_recv);
+    c->halo_send = c->halo_recv = nullptr;
+    c->halo_cap = 0;
+    const size_t cap = packet_doubles + packet_doubles / 4 + 64;
+    if (hipMalloc((void**)&c->halo_send, sizeof(double) * cap) != hipSuccess ||
+        hipMalloc((void**)&c->halo_recv, sizeof(double) * cap * (size_t)std::max(1, c->comm.nranks)) != hipSuccess) {
+      c->err = "out of device memory (multi-GPU exchange buffers)";
+      return SGO_ENOMEM;
+    }
+    c->halo_cap = cap;
+  }
+  c->halo.send = c->halo_send;
+  c->halo.recv = c->halo_recv;
+  c->halo.cap = c->halo_cap;
+  return SGO_OK;
+}
+
 void free_graph(sgo_ctx* c) {
   l0_discard(c);
   if (c->pcg_exec) {
@@ -50,6 +71,9 @@ void free_graph(sgo_ctx* c) {
   c->warm_valid = false;
   c->has_graph = false;
   c->linearized = false;
+  c->owner = false;
+  c->halo = HaloDev();
+  c->halo_failed = false;
 }
 
 // The edge arrays, poses and chi2 buffers of a graph: all that chi2 / per-edge chi2 / the single-launch direct path
@@ -114,7 +138,9 @@ int build_structure(sgo_ctx* c, int V, const double* poses, const uint8_t* fixed
   P.tiles.clear();
   P.tile_lds = 0;
   P.tiles_ok = true;
-  const int tile_div = kTileDiv;   // one tile per CU: the larger the tiles, the fewer pairs straddle two of them
+  // one tile per CU -- the larger the tiles, the fewer pairs straddle two of them -- of every rank (multi-GPU: a rank owns
+  // 1 / nranks of the tiles and wants its own 256 CUs busy)
+  const int tile_div = kTileDiv * std::max(1, c->comm.nranks);
   {
     // (build_edges has validated the edges and listed the free active vertices of this very graph; the lazy path of
     // graphs that took the direct solver keeps the lists too)
@@ -204,6 +230,8 @@ int build_structure(sgo_ctx* c, int V, const double* poses, const uint8_t* fixed
   // per-slot edge index / side flags and the operand arrays of k_linearize (expanded on the device further down)
   int* d_eidx = nullptr;
   if ((rc = upload(c, &d_eidx, eidx))) return rc;
+  c->d_eidx = d_eidx;
+  c->d_rowptr = c->d_hrowptr = nullptr;
   if ((rc = upload(c, &c->es.flags, flags))) return rc;
   if ((rc = dalloc(c, &c->es.vi, (size_t)ns)) || (rc = dalloc(c, &c->es.vj, (size_t)ns)) || (rc = dalloc(c, &c->es.zinv, 3 * (size_t)ns)) ||
       (rc = dalloc(c, &c->es.info, 6 * (size_t)ns)) || (rc = dalloc(c, &c->es.phi, (size_t)ns)))
@@ -216,9 +244,11 @@ int build_structure(sgo_ctx* c, int V, const double* poses, const uint8_t* fixed
   {
     bool pipeline = c->opts.solver == SGO_SOLVER_PCG_AMG && n >= 20000 && E > 0;
     if (const char* e = std::getenv("SGO_SETUP_PIPELINE")) pipeline = pipeline && std::atoi(e) != 0;
+    if (pipeline || c->comm.active()) {   // (row-owner mode makes every later hierarchy's strength weights this way too)
+      if ((rc = upload(c, &c->d_rowptr, rowptr)) || (rc = upload(c, &c->d_hrowptr, H.rowptr))) return rc;
+    }
     if (pipeline) {
-      int *d_rowptr = nullptr, *d_hrowptr = nullptr;
-      if ((rc = upload(c, &d_rowptr, rowptr)) || (rc = upload(c, &d_hrowptr, H.rowptr))) return rc;
+      int *d_rowptr = c->d_rowptr, *d_hrowptr = c->d_hrowptr;
       double* d_w = c->es.info;   // scratch: nslot <= n + ns <= 2 ns doubles of the 6 ns the not yet expanded operand array holds
       launch_early_strength(c->stream, c->el, c->d_poses, n, d_rowptr, d_eidx, c->es.flags, d_hrowptr, d_w);
       c->l0_w.resize((size_t)H.nslot);
@@ -294,18 +324,26 @@ int build_structure(sgo_ctx* c, int V, const double* poses, const uint8_t* fixed
   own[ns] = nu;
   tslot[ns] = ntr;
   lap("types + ranks");
-  // wave groups over the compact slots: whole rows packed up to 64 slots; a longer row is its own group
+  // wave groups over the compact slots: whole rows packed up to 64 slots; a longer row is its own group; a tile starts
+  // a group, so that a range of tiles (one rank's rows, multi-GPU) is a range of groups
   std::vector<int> grp, grow;
+  std::vector<int> tile_g0;   // first group of every tile (+ the group count at the end)
   grp.push_back(0);
   {
     int cur = 0, first = 0;
+    size_t nt = 0;
     for (int r = 0; r < n; ++r) {
       const int len = rowptr[r + 1] - rowptr[r];
-      if (cur > 0 && cur + len > 64) {
+      const bool tile_start = tiles_ok && nt < tiles.size() && tiles[nt].row0 == r;
+      if (cur > 0 && (cur + len > 64 || tile_start)) {
         grp.push_back(rowptr[r]);
         grow.push_back(first);
         first = r;
         cur = 0;
+      }
+      if (tile_start) {
+        tile_g0.push_back((int)grow.size());
+        ++nt;
       }
       cur += len;
       if (cur >= 64) {  // full (or a long row): close the group here
@@ -319,6 +357,7 @@ int build_structure(sgo_ctx* c, int V, const double* poses, const uint8_t* fixed
       grp.push_back(ns);
       grow.push_back(first);
     }
+    tile_g0.push_back((int)grow.size());
   }
   const int ngrp = (int)grp.size() - 1;
   std::vector<int> gown(ngrp), gtr(ngrp), tref((size_t)std::max(ntr, 1));
@@ -491,6 +530,83 @@ int build_structure(sgo_ctx* c, int V, const double* poses, const uint8_t* fixed
     for (int g = 0; g < ngrp; ++g) c->unit_row0.push_back(grow[g]);
   }
   c->unit_row0.push_back(n);
+  // ---- multi-GPU, row-owner mode: the boundary rows of every rank (the rows with an edge into another rank's range)
+  c->owner = false;
+  c->halo = HaloDev();
+  c->halo_host = HaloHost();
+  if (c->comm.active() && tiles_ok && !tiles.empty() && n >= 2048) {   // (the rank-emulation hook without a communicator keeps the all-reduce mode's sharded passes)
+    const int G = c->comm.nranks, nt = (int)tiles.size();
+    HaloHost& HH = c->halo_host;
+    HH.G = G;
+    HH.me = c->comm.rank;
+    HH.rank_row.assign((size_t)G + 1, n);
+    std::vector<int> rank_u((size_t)G + 1, nt);
+    for (int q = 0; q < G; ++q) {
+      int b = 0, e = 0;
+      sgo_shard_range(nt, G, q, &b, &e);
+      rank_u[q] = b;
+      HH.rank_row[q] = b < nt ? tiles[b].row0 : n;
+    }
+    std::vector<unsigned char> isb((size_t)std::max(n, 1), 0);
+    parallel_for(n, [&](int r0, int r1) {
+      int q = 0;
+      for (int r = r0; r < r1; ++r) {
+        while (r >= HH.rank_row[q + 1]) ++q;
+        const int lo = HH.rank_row[q], hi = HH.rank_row[q + 1];
+        for (int k = rowptr[r]; k < rowptr[r + 1]; ++k)
+          if (type[k] != kSlotNoBlock && (col[k] < lo || col[k] >= hi)) {
+            isb[r] = 1;
+            break;
+          }
+      }
+    });
+    std::vector<std::vector<int>> lists((size_t)G);
+    long long total = 0;
+    int bmax = 0, maxrows = 0;
+    for (int q = 0; q < G; ++q) {
+      for (int r = HH.rank_row[q]; r < HH.rank_row[q + 1]; ++r)
+        if (isb[r]) lists[q].push_back(r);
+      total += (long long)lists[q].size();
+      bmax = std::max(bmax, (int)lists[q].size());
+      maxrows = std::max(maxrows, HH.rank_row[q + 1] - HH.rank_row[q]);
+    }
+    // Row ownership pays when the boundaries are thin (spatially local closures in Hilbert order: a few per cent of the
+    // rows); graphs with random long-range closures have every row on a boundary and keep the all-reduce of the
+    // product vectors ("keep both modes").  SGO_COMM_MODE=owner|allreduce forces one.
+    bool owner = 4 * total <= (long long)n;
+    if (const char* e = std::getenv("SGO_COMM_MODE")) owner = !std::strcmp(e, "owner") ? true : (!std::strcmp(e, "allreduce") ? false : owner);
+    if (owner) {
+      HH.bmax = std::max(bmax, 1);
+      HH.bnd.assign((size_t)G * HH.bmax, -1);
+      for (int q = 0; q < G; ++q) std::copy(lists[q].begin(), lists[q].end(), HH.bnd.begin() + (size_t)q * HH.bmax);
+      HaloDev& H = c->halo;
+      H.comm = &c->comm;
+      H.G = G;
+      H.me = HH.me;
+      H.row0 = HH.rank_row[HH.me];
+      H.row1 = HH.rank_row[HH.me + 1];
+      H.u0 = rank_u[HH.me];
+      H.u1 = rank_u[HH.me + 1];
+      H.g0 = tile_g0[H.u0];
+      H.g1 = tile_g0[H.u1];
+      H.bmax = HH.bmax;
+      H.maxrows = maxrows;
+      H.failed = &c->halo_failed;
+      int *d_bnd = nullptr, *d_rr = nullptr;
+      if ((rc = upload(c, &d_bnd, HH.bnd)) || (rc = upload(c, &d_rr, HH.rank_row))) return rc;
+      H.bnd = d_bnd;
+      H.rank_row = d_rr;
+      if ((rc = dalloc(c, &H.gparts, (size_t)kHaloScalars * G))) return rc;
+      HIP_TRY(c, hipMemsetAsync(H.gparts, 0, sizeof(double) * kHaloScalars * G, c->stream));
+      if ((rc = halo_reserve(c, std::max<size_t>((size_t)kHaloScalars + 3 * (size_t)HH.bmax, 9 * (size_t)maxrows)))) return rc;
+      c->owner = true;
+      if (c->opts.verbose)
+        std::fprintf(stderr, "[sgo] row-owner mode: rank %d of %d owns tiles [%d, %d) = rows [%d, %d); boundary rows %lld of %d (largest rank %d)\n",
+                     H.me, G, H.u0, H.u1, H.row0, H.row1, total, n, bmax);
+    } else if (c->opts.verbose) {
+      std::fprintf(stderr, "[sgo] multi-GPU: %lld of %d rows are boundary rows: all-reduce mode\n", total, n);
+    }
+  }
   Tile0Dev& TL = c->T0;
   TL = Tile0Dev();
   if (tiles_ok && !tiles.empty()) {

@@ -1,14 +1,17 @@
-"""The multi-GPU mode of libsgo run for real with world_size > 1 on ONE GPU.
+"""The multi-GPU modes of libsgo run for real with world_size > 1 on ONE GPU.
 
 RCCL refuses two ranks on one device, and the GPU box has one: the ranks here are separate processes that
 share the card and exchange through libsgo's caller-supplied transport (sgo_comm_init_host) with gloo
 underneath.  Everything else is the product's multi-rank path as bench.py --gpus N drives it: every rank
-marshals the same graph, evaluates its own range of tiles in every level-0 pass, all-reduces the product
-vectors, the coarse right-hand sides and chi2, and runs the replicated recurrences -- set-up, multigrid
-hierarchy, optimize(), stopping and rebuild decisions included.  Checked: no rank hangs or diverges (all
-ranks bit-identical, same number of collectives), and the result equals the 1-rank path through the same
-transport and the single-GPU path to rounding (the product vectors have one contributor per row and are exact;
-the coarse right-hand side is a sum of per-rank partials, whose order depends on the world size)."""
+marshals the same graph and
+  * row-owner mode (graphs whose closures are spatially local: thin boundaries in Hilbert order): linearises, multiplies,
+    smooths, restricts, prolongates and updates its own rows only, exchanges boundary rows and partial dot products,
+    all-reduces the coarse right-hand sides, the level-1 Galerkin blocks and chi2;
+  * all-reduce mode (random long-range closures: every row is a boundary row): evaluates its own range of tiles in every
+    level-0 pass and all-reduces the product vectors;
+set-up, multigrid hierarchy, optimize(), stopping and rebuild decisions included.  Checked: no rank hangs or diverges
+(all ranks bit-identical, same number of collectives), and the result equals the 1-rank path through the same
+transport and the single-GPU path to rounding."""
 import os
 import socket
 
@@ -59,9 +62,10 @@ def _worker(rank, world, port, name, iters, q):
             done, st = o.optimize(iters)
             P = o.get_poses()
             c, rc = o.chi2()
-        q.put((rank, done, st["chi2"], st["pcg_iters"], P.tobytes(), c, rc, calls[0]))
+            desc = o.solver_description()
+        q.put((rank, done, st["chi2"], st["pcg_iters"], P.tobytes(), c, rc, calls[0], desc))
     except Exception as e:   # report instead of leaving the parent waiting on the queue
-        q.put((rank, -1, repr(e), [], b"", 0.0, 0.0, 0))
+        q.put((rank, -1, repr(e), [], b"", 0.0, 0.0, 0, ""))
         raise
     finally:
         dist.destroy_process_group()
@@ -82,13 +86,19 @@ def _run(world, name, iters):
     return res
 
 
-@pytest.mark.parametrize("world,name", [(2, "C2"), (3, "C2"), (2, "random"), (2, "pipelined")])
-def test_ranks_agree_bitwise_and_match_one_rank(world, name):
+@pytest.mark.parametrize("world,name,mode", [(2, "C2", "owner"), (3, "C2", "owner"), (2, "random", "owner"), (2, "random", "allreduce"),
+                                             (3, "C2", "allreduce"), (2, "pipelined", "owner")])
+def test_ranks_agree_bitwise_and_match_one_rank(world, name, mode, monkeypatch):
     from sparse_gslam_amd import capi
     iters = 5
+    # the library picks the mode by the share of boundary rows (C2, pipelined: 2-5 %; random: 20 %: still row-owner; beyond
+    # a quarter of the rows: all-reduce); the all-reduce cases force it so that both modes run on the same graphs
+    if mode == "allreduce":
+        monkeypatch.setenv("SGO_COMM_MODE", "allreduce")     # (inherited by the spawned rank processes)
     res = _run(world, name, iters)
     assert all(r[1] == iters for r in res), [r[:3] for r in res]
-    _, _, chi2_0, its_0, P0, c0, rc0, calls0 = res[0]
+    _, _, chi2_0, its_0, P0, c0, rc0, calls0, desc0 = res[0]
+    assert ("all-reduce mode" if mode == "allreduce" else "row-owner mode") in desc0, desc0
     for r in res[1:]:        # every rank holds the same iterates, bit for bit, and took the same decisions
         assert r[2] == chi2_0 and r[3] == its_0 and r[4] == P0 and r[7] == calls0
     assert calls0 >= 3 * sum(its_0)     # two product vectors + one coarse right-hand side per PCG iteration

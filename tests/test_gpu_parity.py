@@ -211,10 +211,12 @@ def test_stale_aggregation_is_rebuilt_and_the_result_still_matches(capfd):
 
 
 # ------------------------------------------------------------------ multi-GPU logic on one GPU
-def test_rank_partial_products_sum_to_the_single_rank_product_bitwise():
+def test_rank_partial_products_sum_to_the_single_rank_product():
     """Multi-GPU scheme on one GPU: each emulated rank evaluates the level-0 product for the rows of its tile
-    range only (zeros elsewhere); the sum over ranks -- what ncclAllReduce computes -- must equal the
-    single-rank product bit for bit, and every row must have exactly one contributing rank."""
+    range only (zeros elsewhere); every row has exactly one contributing rank, so the sum over ranks -- what
+    ncclAllReduce computes in the all-reduce mode -- is the full product.  A world of G ranks cuts 256 G tiles (every
+    rank keeps its own 256 CUs busy), so a row's blocks are summed in another order than in the one-rank cut:
+    agreement with the single-rank product to rounding, not bitwise."""
     g = synth.config("C2", info_mode="full")
     x = np.random.default_rng(3).standard_normal((int((~g.fixed).sum()), 3))
     with capi.Optimizer(0, solver=capi.SOLVER_PCG_BJ) as full:
@@ -239,7 +241,7 @@ def test_rank_partial_products_sum_to_the_single_rank_product_bitwise():
             assert not np.any(nz & ~mine)
             owners += nz
             sy += y
-        assert np.array_equal(sy, fy), world
+        assert np.abs(sy - fy).max() <= 1e-13 * np.abs(fy).max(), world
         assert owners.max() == 1
 
 
