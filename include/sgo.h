@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define SGO_VERSION 102          /* 0.1.2: sgo_comm_init_host; 0.1.1: sgo_opts.direct_rows (took a reserved slot), sgo_solver_description */
+#define SGO_VERSION 103          /* 0.1.3: row-owner multi-GPU mode (sgo_comm_host_allgather, sgo_debug_level0_bytes); 0.1.2: sgo_comm_init_host; 0.1.1: sgo_opts.direct_rows (took a reserved slot), sgo_solver_description */
 #define SGO_MAX_ITERS 256        /* capacity of the per-iteration arrays in sgo_stats */
 
 /* error codes (negative).  -1 mirrors g2o's optimize() "nothing to optimise". */
@@ -218,15 +218,21 @@ int sgo_profile_reset(sgo_ctx* ctx);
 double sgo_profile_overhead_ms(sgo_ctx* ctx);
 
 /* ---- multi-GPU: one process per GPU, RCCL over xGMI ------------------------------------------
- * Every rank is given the SAME full graph (sgo_set_graph_se2 with identical arguments).  The rows of the
- * level-0 Hessian are cut into tiles of consecutive rows (Hilbert order of the poses); rank r owns the
- * contiguous range of tiles sgo_shard_range(ntiles, nranks, r).  Every level-0 Hessian product of the solve
- * -- H p of the CG recurrence and the two smoothing passes of the multigrid cycle, i.e. every pass over
- * the edges' blocks -- is evaluated by each rank for the rows of its tiles only, zeros elsewhere, and the
- * product vector is summed over ranks with ncclAllReduce (one non-zero contributor per row: the sum is
- * exact), the per-PCG-step exchange BASELINE.json's north_star names.  chi2 is summed over edge ranges the
- * same way.  Linearisation (1.5 % of an iteration), the coarse multigrid levels and the vector recurrences
- * run replicated, on bit-identical data, so every rank takes the same decisions. */
+ * Every rank is given the SAME full graph (sgo_set_graph_se2 with identical arguments) and makes the same row plan: the
+ * rows of the level-0 Hessian in Hilbert order of the poses, cut into 256 tiles per rank; rank r owns the contiguous range
+ * of tiles sgo_shard_range(ntiles, nranks, r).  Two modes, chosen per graph (sgo_solver_description says which):
+ *   row-owner mode  (at most a quarter of the rows have an edge into another rank's range -- spatially local closures): a rank
+ *     holds the Hessian blocks and edge operands of ITS rows only and linearises, multiplies, smooths, restricts, prolongates and
+ *     updates these rows; per PCG iteration it exchanges the boundary rows of three vectors and the partial sums of the dot
+ *     products (fixed-size all-gather packets, reduced in rank order: bit-identical scalars on all ranks) and all-reduces the
+ *     coarse right-hand side; per Gauss-Newton iteration the boundary rows of the smoothed prolongator and the step (for the
+ *     replicated pose update) travel, and the level-1 Galerkin blocks are all-reduced.  The coarse multigrid levels run replicated.
+ *   all-reduce mode (random long-range closures: most rows are boundary rows): every rank holds the whole graph, evaluates every
+ *     level-0 Hessian product of the solve for the rows of its tiles only, zeros elsewhere, and the product vector is summed over
+ *     ranks with ncclAllReduce (one non-zero contributor per row: the sum is exact) -- the per-PCG-step exchange BASELINE.json's
+ *     north_star names.  Linearisation, coarse levels and vector recurrences run replicated on bit-identical data.
+ * chi2 is summed over edge ranges in both.  Every rank takes the same decisions (stopping, hierarchy rebuilds) from
+ * bit-identical scalars. */
 /* 128-byte unique id for rendezvous (wraps ncclGetUniqueId); rank 0 creates it, the host layer
  * broadcasts it (torch.distributed / MPI / a file), every rank passes it to sgo_comm_init. */
 #define SGO_UNIQUE_ID_BYTES 128
@@ -240,6 +246,11 @@ int sgo_comm_size(sgo_ctx* ctx);
  * that called into the library.  Must precede sgo_set_graph_se2. */
 typedef int (*sgo_host_allreduce_fn)(double* buf, size_t count, void* user);
 int sgo_comm_init_host(sgo_ctx* ctx, int nranks, int rank, sgo_host_allreduce_fn fn, void* user);
+/* Optional companion of sgo_comm_init_host for the row-owner mode's packets: recv[r * count .. (r + 1) * count) = rank r's
+ * send[0 .. count) (host memory), return 0.  Without it libsgo performs an all-gather as an all-reduce of zero-padded slots
+ * through `fn` (exact, nranks times the bytes).  Call after sgo_comm_init_host, before sgo_set_graph_se2. */
+typedef int (*sgo_host_allgather_fn)(const double* send, size_t count, double* recv, void* user);
+int sgo_comm_host_allgather(sgo_ctx* ctx, sgo_host_allgather_fn fn);
 /* The contiguous range [begin, end) of `count` work units (tiles, edges) that rank `rank` of
  * `nranks` evaluates.  Pure function (no GPU needed); exposed so the host layer and the CPU tests
  * can reproduce the partition. */
@@ -268,6 +279,9 @@ int sgo_debug_set_shard(sgo_ctx* ctx, int nranks, int rank);
  *   resident graph (mode 0 = H x, 1 = residual, 2 = Jacobi sweep); variant 16 selects the wave-group kernel,
  *   variant 32 prints per-phase cycle stamps of the tile kernel. */
 int sgo_debug_coarse_rhs(sgo_ctx* ctx, const double* r, double* out, int cap);
+/* Device bytes of the level-0 structure THIS rank holds for the resident graph (Hessian blocks, per-slot edge operands,
+ * per-slot / per-block index arrays, level-0 transfer blocks and product lists): proportional to 1 / nranks in row-owner mode. */
+int64_t sgo_debug_level0_bytes(sgo_ctx* ctx);
 double sgo_debug_spmv0_us(sgo_ctx* ctx, int mode, int variant, int reps);
 
 /* One line naming the solver the resident graph's sgo_optimize_gn runs ("direct_ldlt: ...", "pcg_amg: L0 n=... ",

@@ -28,7 +28,7 @@ SYMBOLS = [
     "sgo_precondition", "sgo_kernel_profile", "sgo_profile_reset", "sgo_profile_overhead_ms", "sgo_comm_unique_id",
     "sgo_comm_init", "sgo_comm_size", "sgo_shard_range", "sgo_debug_set_shard", "sgo_last_error",
     "sgo_closure_information", "sgo_plan_rows", "sgo_debug_coarse_rhs", "sgo_debug_spmv0_us",
-    "sgo_solver_description", "sgo_comm_init_host",
+    "sgo_solver_description", "sgo_comm_init_host", "sgo_comm_host_allgather", "sgo_debug_level0_bytes",
 ]
 
 
@@ -70,6 +70,7 @@ class KernelStat(C.Structure):
 
 # sgo_host_allreduce_fn: int fn(double* buf, size_t count, void* user)
 HOST_ALLREDUCE = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.c_size_t, C.c_void_p)
+HOST_ALLGATHER = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.c_size_t, C.POINTER(C.c_double), C.c_void_p)
 
 _LIB = None
 
@@ -124,6 +125,9 @@ def lib():
     L.sgo_comm_init.argtypes = [vp, C.c_int, C.c_int, vp]
     L.sgo_comm_size.argtypes = [vp]
     L.sgo_comm_init_host.argtypes = [vp, C.c_int, C.c_int, HOST_ALLREDUCE, vp]
+    L.sgo_comm_host_allgather.argtypes = [vp, HOST_ALLGATHER]
+    L.sgo_debug_level0_bytes.restype = C.c_int64
+    L.sgo_debug_level0_bytes.argtypes = [vp]
     L.sgo_shard_range.restype = None
     L.sgo_shard_range.argtypes = [C.c_int32, C.c_int32, C.c_int32, i32, i32]
     L.sgo_debug_set_shard.argtypes = [vp, C.c_int, C.c_int]
@@ -231,9 +235,10 @@ class Optimizer:
         buf = C.create_string_buffer(unique_id, UNIQUE_ID_BYTES)
         self._check(lib().sgo_comm_init(self._h, nranks, rank, C.cast(buf, C.c_void_p)), "sgo_comm_init")
 
-    def comm_init_host(self, nranks: int, rank: int, allreduce):
+    def comm_init_host(self, nranks: int, rank: int, allreduce, allgather=None):
         """Multi-GPU mode over the caller's transport (sgo_comm_init_host): `allreduce(a)` must replace the
-        float64 numpy array `a` in place by its sum over all ranks (e.g. a gloo all_reduce)."""
+        float64 numpy array `a` in place by its sum over all ranks (e.g. a gloo all_reduce); the optional
+        `allgather(send, recv)` fills recv (nranks * len(send)) with every rank's send (sgo_comm_host_allgather)."""
         def _cb(buf, count, _user):
             try:
                 allreduce(np.ctypeslib.as_array(buf, shape=(count,)))
@@ -244,6 +249,21 @@ class Optimizer:
                 return 1
         self._host_cb = HOST_ALLREDUCE(_cb)   # keep the trampoline alive as long as the context
         self._check(lib().sgo_comm_init_host(self._h, nranks, rank, self._host_cb, None), "sgo_comm_init_host")
+        if allgather is not None:
+            def _gcb(send, count, recv, _user):
+                try:
+                    allgather(np.ctypeslib.as_array(send, shape=(count,)), np.ctypeslib.as_array(recv, shape=(count * nranks,)))
+                    return 0
+                except Exception:
+                    import traceback
+                    traceback.print_exc()
+                    return 1
+            self._host_gcb = HOST_ALLGATHER(_gcb)
+            self._check(lib().sgo_comm_host_allgather(self._h, self._host_gcb), "sgo_comm_host_allgather")
+
+    def level0_bytes(self) -> int:
+        """Device bytes of the level-0 structure this rank holds (sgo_debug_level0_bytes)."""
+        return int(lib().sgo_debug_level0_bytes(self._h))
 
     def debug_set_shard(self, nranks: int, rank: int):
         self._check(lib().sgo_debug_set_shard(self._h, nranks, rank), "sgo_debug_set_shard")

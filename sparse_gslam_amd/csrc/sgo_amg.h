@@ -99,6 +99,7 @@ double amg_omega(const Amg* m);
 // true when the last amg_update met a non-positive pivot in the coarsest operator (synchronises `s`)
 bool amg_coarsest_not_spd(Amg* m, hipStream_t s);
 int amg_num_levels(const Amg* m);
+long long amg_level0_bytes(const Amg* m);   // device bytes of the level-0 transfer (P, A P, product lists) this rank holds
 void amg_describe(const Amg* m, std::string* out);
 
 }  // namespace sgo

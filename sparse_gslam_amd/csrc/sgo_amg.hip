@@ -171,8 +171,13 @@ struct PDev {
   int* row = nullptr;        // [np]
   int* col = nullptr;        // [np]
   double* blk = nullptr;     // [np][9]: the copy the block products GATHER from (one 72-byte record each)
-  double* r_blk = nullptr;   // pair-SoA [np] (blk_at): the copy the prolongation STREAMS (row order,
+  // The two streamed copies are indexed by GLOBAL entry / position numbers; in multi-GPU row-owner mode (level 0) they hold
+  // this rank's rows' entries only: allocated for the rank's range, base pointers shifted, pair strides r_n / t_n and
+  // component-8 base pointers of their own (as Sym0Dev::ublk).
+  int r_n = 0;               // pair stride of r_blk (= np; the rank's entries in row-owner mode)
+  double* r_blk = nullptr;   // pair-SoA (blk_at): the copy the prolongation STREAMS (row order,
                              // non-temporal loads: read once per cycle, must not push the level-0 matrix out of the MALL)
+  double* r_blk8 = nullptr;
   int* r_grp = nullptr;      // wave groups over the entries aligned to fine rows (prolongation)
   int r_ngrp = 0;
   ProdMap val;               // a = fine slot k = (i, j), tgt = entry (i, agg(j))
@@ -181,7 +186,9 @@ struct PDev {
   int* t_pos = nullptr;      // [np] position of entry e in column order
   int* t_row = nullptr;      // [np] fine row at position t
   int* t_col = nullptr;      // [np] coarse column at position t
-  double* t_blk = nullptr;   // pair-SoA [np]: column order, streamed by the restriction (non-temporal loads)
+  int t_n = 0;               // entries in the column-ordered copy = its pair stride (= np; the rank's rows' entries in row-owner mode)
+  double* t_blk = nullptr;   // pair-SoA: column order, streamed by the restriction (non-temporal loads)
+  double* t_blk8 = nullptr;
   int* t_grp = nullptr;      // wave groups over the positions aligned to columns
   int t_ngrp = 0;
   int* t_long = nullptr;     // [t_nlong][2] position ranges of the columns longer than kLongColumn entries (the last level of a
@@ -191,28 +198,30 @@ struct PDev {
   ProdMap ap;                // a = fine slot (i, j), b = P entry (j, c), tgt = AP entry (i, c)
   ProdMap rap;               // a = P entry (i, a), b = AP entry (i, c), tgt = coarse slot (a, c), c >= a only
   int* rap_mirror = nullptr; // [coarse slots] slot (c, a) of an upper slot (a, c): gets the transposed block (-1: none)
+  bool local_lists = false;  // row-owner mode: val / ap / rap list THIS rank's rows' products only (targets of P^T A P without
+                             // any are not visited: the caller zeroes the coarse blocks first)
 };
 
 // block e of a pair-SoA array (blk_at) that is read once per cycle: four 16-byte and one 8-byte non-temporal
 // loads per lane (the stream must not push the level-0 matrix out of the Infinity Cache)
 typedef double sgo_d2 __attribute__((ext_vector_type(2)));
 constexpr int kLongColumn = 512;   // entries of a P column from which a workgroup instead of a wave restricts it
-__device__ __forceinline__ void load9_stream(const double* __restrict__ base, size_t e, size_t n, double (&v)[9]) {
+__device__ __forceinline__ void load9_stream(const double* __restrict__ base, const double* __restrict__ base8, size_t e, size_t n, double (&v)[9]) {
   const sgo_d2* __restrict__ bp = reinterpret_cast<const sgo_d2*>(base);
   const sgo_d2 p0 = __builtin_nontemporal_load(bp + e), p1 = __builtin_nontemporal_load(bp + n + e);
   const sgo_d2 p2 = __builtin_nontemporal_load(bp + 2 * n + e), p3 = __builtin_nontemporal_load(bp + 3 * n + e);
   v[0] = p0.x; v[1] = p0.y; v[2] = p1.x; v[3] = p1.y; v[4] = p2.x; v[5] = p2.y; v[6] = p3.x; v[7] = p3.y;
-  v[8] = __builtin_nontemporal_load(base + 8 * n + e);
+  v[8] = __builtin_nontemporal_load(base8 + e);
 }
-__device__ __forceinline__ void load9_pairs(const double* __restrict__ base, size_t e, size_t n, double (&v)[9], bool nt) {
+__device__ __forceinline__ void load9_pairs(const double* __restrict__ base, const double* __restrict__ base8, size_t e, size_t n, double (&v)[9], bool nt) {
   if (nt) {
-    load9_stream(base, e, n, v);
+    load9_stream(base, base8, e, n, v);
     return;
   }
   const sgo_d2* __restrict__ bp = reinterpret_cast<const sgo_d2*>(base);
   const sgo_d2 p0 = bp[e], p1 = bp[n + e], p2 = bp[2 * n + e], p3 = bp[3 * n + e];
   v[0] = p0.x; v[1] = p0.y; v[2] = p1.x; v[3] = p1.y; v[4] = p2.x; v[5] = p2.y; v[6] = p3.x; v[7] = p3.y;
-  v[8] = base[8 * n + e];
+  v[8] = base8[e];
 }
 __device__ __forceinline__ void load9(const double* __restrict__ base, size_t e, double (&v)[9]) {
 #pragma unroll
@@ -265,13 +274,16 @@ __global__ __launch_bounds__(kBlock) void k_p_values(BsrDev F, PDev P, const int
         o[2] += -d[2 * i + 1];
         o[5] += d[2 * i];
       }
-      const size_t tp = (size_t)P.t_pos[key], np = (size_t)P.np;
+      const size_t tp = (size_t)P.t_pos[key];
 #pragma unroll
-      for (int c = 0; c < 9; ++c) {
-        P.blk[9 * (size_t)key + c] = o[c];
-        P.r_blk[blk_at(c, key, np)] = o[c];
-        P.t_blk[blk_at(c, tp, np)] = o[c];
+      for (int c = 0; c < 9; ++c) P.blk[9 * (size_t)key + c] = o[c];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        P.r_blk[blk_at(c, key, (size_t)P.r_n)] = o[c];
+        P.t_blk[blk_at(c, tp, (size_t)P.t_n)] = o[c];
       }
+      P.r_blk8[key] = o[8];
+      P.t_blk8[tp] = o[8];
     }
   }
 }
@@ -345,7 +357,7 @@ __global__ __launch_bounds__(kBlock) void k_restrict_p(PDev P, const double* __r
   // (as in k_spmv: the first group's bounds are requested before the stop flag is waited for -- one dependent
   // round trip less in a launch that is a chain of four)
   const int lane = threadIdx.x & 63;
-  const size_t np = (size_t)P.np;
+  const size_t np = (size_t)P.t_n;
   int g, gend, gstride;
   group_walk(P.t_ngrp, &g, &gend, &gstride);
   int gb0 = 0, ge0 = 0;
@@ -365,7 +377,7 @@ __global__ __launch_bounds__(kBlock) void k_restrict_p(PDev P, const double* __r
       if (row1 > 0 && ((int)i < row0 || (int)i >= row1)) continue;
       const double r0 = r[3 * i], r1 = r[3 * i + 1], r2 = r[3 * i + 2];
       double b[9];
-      load9_pairs(P.t_blk, (size_t)t, np, b, P.stream_nt != 0);
+      load9_pairs(P.t_blk, P.t_blk8, (size_t)t, np, b, P.stream_nt != 0);
       acc[0] += b[0] * r0 + b[3] * r1 + b[6] * r2;
       acc[1] += b[1] * r0 + b[4] * r1 + b[7] * r2;
       acc[2] += b[2] * r0 + b[5] * r1 + b[8] * r2;
@@ -389,14 +401,14 @@ __global__ __launch_bounds__(kLongThreads) void k_restrict_p_long(PDev P, const 
   if (S && S->stop) return;
   __shared__ double sm[kLongThreads / 64][3];
   const int gb = P.t_long[2 * blockIdx.x], ge = P.t_long[2 * blockIdx.x + 1];
-  const size_t np = (size_t)P.np;
+  const size_t np = (size_t)P.t_n;
   double acc[3] = {0.0, 0.0, 0.0};
   for (int t = gb + (int)threadIdx.x; t < ge; t += kLongThreads) {
     const size_t i = (size_t)P.t_row[t];
     if (row1 > 0 && ((int)i < row0 || (int)i >= row1)) continue;
     const double r0 = r[3 * i], r1 = r[3 * i + 1], r2 = r[3 * i + 2];
     double b[9];
-    load9_pairs(P.t_blk, (size_t)t, np, b, P.stream_nt != 0);
+    load9_pairs(P.t_blk, P.t_blk8, (size_t)t, np, b, P.stream_nt != 0);
     acc[0] += b[0] * r0 + b[3] * r1 + b[6] * r2;
     acc[1] += b[1] * r0 + b[4] * r1 + b[7] * r2;
     acc[2] += b[2] * r0 + b[5] * r1 + b[8] * r2;
@@ -444,7 +456,7 @@ __global__ __launch_bounds__(kBlock) void k_prolong_p(int n, PDev P, const doubl
   }
   // one lane per entry (entries are sorted by fine row), wavefront segmented sum per row
   const int lane = threadIdx.x & 63;
-  const size_t np = (size_t)P.np;
+  const size_t np = (size_t)P.r_n;
   for (bool first = true; g < gend; g += gstride, first = false) {
     const int gb = first ? gb0 : P.r_grp[g], ge = first ? ge0 : P.r_grp[g + 1];
     double acc[3] = {0.0, 0.0, 0.0};
@@ -461,7 +473,7 @@ __global__ __launch_bounds__(kBlock) void k_prolong_p(int n, PDev P, const doubl
         w0 += c2 * u2[a]; w1 += c2 * u2[a + 1]; w2 += c2 * u2[a + 2];
       }
       double b[9];
-      load9_pairs(P.r_blk, (size_t)e, np, b, P.stream_nt != 0);
+      load9_pairs(P.r_blk, P.r_blk8, (size_t)e, np, b, P.stream_nt != 0);
       acc[0] += b[0] * w0 + b[1] * w1 + b[2] * w2;
       acc[1] += b[3] * w0 + b[4] * w1 + b[5] * w2;
       acc[2] += b[6] * w0 + b[7] * w1 + b[8] * w2;
@@ -804,6 +816,8 @@ __global__ __launch_bounds__(kBlock) void k_dots2(int n, const double* __restric
 // column c if it has one; P^T A P: the entries t of column a of P in ascending order, each contributing the entry of
 // A P row row(t) in column c) -- first counting, then, after a prefix sum over the targets, writing.
 struct ApPattern {
+  int f_lo = 0;                    // targets [f_lo, nap) are listed (row-owner mode: this rank's rows' entries; the arrays
+                                   // indexed by a target are then allocated for that range and shifted)
   int nap = 0;
   const int* ap_row = nullptr;     // [nap] fine row of target f
   const int* ap_col = nullptr;     // [nap] coarse column of target f (ascending within a row)
@@ -829,7 +843,7 @@ __global__ __launch_bounds__(kBlock) void k_ap_list(ApPattern ap, const int* __r
                                                     int* __restrict__ lt) {
   const int lane = threadIdx.x & 63, sub = lane & 7, g8 = lane >> 3;
   const int wave = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6), nwaves = gridDim.x * kWavesPerBlock;
-  for (int f0 = wave * 8; f0 < ap.nap; f0 += nwaves * 8) {
+  for (int f0 = ap.f_lo + wave * 8; f0 < ap.nap; f0 += nwaves * 8) {
     const int f = f0 + g8;
     const bool valid = f < ap.nap;
     const int i = valid ? ap.ap_row[f] : 0, c = valid ? ap.ap_col[f] : 0;
@@ -1012,7 +1026,7 @@ T* dev_upload(DevArena* pool, const std::vector<T>& v, hipStream_t s) {
 // segment is its own group (same rule as the level-0 row groups in sgo_structure.cpp)
 std::vector<int> make_groups(const std::vector<int>& ptr) {
   std::vector<int> grp;
-  grp.push_back(0);
+  grp.push_back(ptr.empty() ? 0 : ptr[0]);   // (a rank's sub-range of a global list starts at its own first item)
   const int nseg = (int)ptr.size() - 1;
   int cur = 0;
   for (int r = 0; r < nseg; ++r) {
@@ -1809,6 +1823,7 @@ struct Amg {
   const HaloDev* halo = nullptr;   // multi-GPU, row-owner mode (sgo_internal.h): level-0 work on the owned rows, boundary exchanges
   int u0 = 0, u1 = 0, row0 = 0, row1 = 0;
   bool comm_failed = false;
+  long long level0_bytes = 0;   // device bytes of the level-0 transfer data (P blocks, A P blocks, product lists)
   DevArena* pool = nullptr;   // the caller's arena (not owned)
   std::vector<AmgLevel> lv;
   const double* d_poses = nullptr;
@@ -1878,13 +1893,14 @@ void launch_coarse_operator(Amg* m, hipStream_t s, AmgLevel& L, AmgLevel& C, boo
     Scope sc(m->prof, K_SA_AP, 156.0 * P.ap.n + 72.0 * P.nap);
     SGO_LAUNCH((k_block_products<true, false, false>), dim3(grid_for(P.ap.ngrp, kWavesPerBlock)), dim3(kBlock), 0, s,
                P.ap, L.A, (const double*)nullptr, (const double*)P.blk, P.apblk, (size_t)P.nap, (const int*)nullptr,
-               (const int*)L.A.row, row0, row1, 0);
+               (const int*)L.A.row, row0, P.local_lists ? 0 : row1, 0);   // (local lists hold this rank's products only: no filter)
   }
+  if (P.local_lists) hipMemsetAsync(C.A.blk, 0, sizeof(double) * 9 * (size_t)C.A.nslot, s);   // targets this rank has no product for
   {
     Scope sc(m->prof, K_SA_RAP, 156.0 * P.rap.n + 72.0 * C.A.nslot);
     SGO_LAUNCH((k_block_products<false, true, true>), dim3(grid_for(P.rap.ngrp, kWavesPerBlock)), dim3(kBlock), 0, s,
                P.rap, BsrDev(), (const double*)P.blk, (const double*)P.apblk, C.A.blk, (size_t)C.A.nslot, (const int*)P.rap_mirror,
-               (const int*)P.row, row0, row1, 1);
+               (const int*)P.row, row0, P.local_lists ? 0 : row1, 1);
   }
   if (H && H->comm) {
     std::string e;
@@ -2010,6 +2026,7 @@ int cycle(Amg* m, hipStream_t s, int l, const double* rhs, const double* rhs_sub
     launch_spmv_ex(s, L.A, SPMV_PRE_RESID_ACC, a);
     res = nxt;
   }
+  if (H && L.smoothed && L.P.local_lists) hipMemsetAsync(C.bk, 0, sizeof(double) * 3 * (size_t)C.A.n, s);   // coarse rows none of this rank's rows reaches
   if (L.smoothed) {
     Scope sc(m->prof, K_RESTRICT_P, 84.0 * L.P.np + 24.0 * L.A.n + 24.0 * L.nc);
     launch_restrict_p(s, L.P, res, C.bk, S, frow0, frow1);
@@ -2117,6 +2134,7 @@ int cycle(Amg* m, hipStream_t s, int l, const double* rhs, const double* rhs_sub
 }  // namespace
 
 int amg_num_levels(const Amg* m) { return m ? (int)m->lv.size() : 0; }
+long long amg_level0_bytes(const Amg* m) { return m ? m->level0_bytes : 0; }
 bool amg_coarsest_not_spd(Amg* m, hipStream_t s) {
   int f = 0;
   if (!m || !m->d_fail) return false;
@@ -2407,50 +2425,113 @@ Amg* amg_create(hipStream_t s, const BsrDev& A0, const Sym0Dev& S0, const Tile0D
     L.mem_ngrp = (int)grp_m.size() - 1;
     L.d = dev_alloc<double>(m->pool, 2 * (size_t)n);
     struct { int *ap_rowptr, *ap_col, *ap_row, *t_ptr, *t_idx; } l0_dev = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    struct { bool own; int F0, F1; } l0_own = {false, 0, 0};
     if (smooth) {
       PDev& P = L.P;
       L.smoothed = true;
+      // Row-owner mode (level 0): the value lists, the streamed copies of P, the blocks of A P and the product lists are made
+      // for this rank's rows only -- allocated for the rank's range of entries, base pointers shifted so that global entry
+      // numbers address them; the patterns (a few integers per entry) and the gathered copy P.blk stay whole.
+      const bool own = l == 0 && halo != nullptr;
+      if (own && !sa.lists_on_device) return fail("amg_create: the row-owner mode needs the device-made product lists (SGO_AMG_LISTS=host is single-GPU only)");
+      const int orow0 = own ? halo->dev->row0 : 0, orow1 = own ? halo->dev->row1 : n;
+      const size_t E0 = (size_t)sa.p_rowptr[orow0], E1 = (size_t)sa.p_rowptr[orow1], npl = E1 - E0;   // entries of P held
+      const size_t V0 = (size_t)H.rowptr[orow0], V1 = (size_t)H.rowptr[orow1];                        // their value products
+      auto up_range = [&](const int* host, size_t lo, size_t hi) -> int* {   // device copy of host[lo, hi), addressed by global numbers
+        int* d = dev_alloc<int>(m->pool, hi - lo);
+        if (d && hi > lo) hipMemcpyAsync(d, host + lo, (hi - lo) * sizeof(int), hipMemcpyHostToDevice, s);
+        return d ? d - lo : nullptr;
+      };
+      P.local_lists = own;
       P.np = (int)sa.p_row.size();
-      P.stream_nt = P.np >= 200000 ? 1 : 0;   // 2 x 72 B per block streamed per cycle: below ~30 MB it may stay cached
+      P.stream_nt = npl >= 200000 ? 1 : 0;   // 2 x 72 B per block streamed per cycle: below ~30 MB it may stay cached
       P.rowptr = dev_upload(m->pool, sa.p_rowptr, s);
       P.row = dev_upload(m->pool, sa.p_row, s);
       P.col = dev_upload(m->pool, sa.p_col, s);
       P.blk = dev_alloc<double>(m->pool, 9 * (size_t)P.np);
-      P.val.n = H.nslot;
-      P.val.a = dev_upload(m->pool, sa.val_src, s);
-      P.val.tgt = dev_upload(m->pool, sa.val_tgt, s);
-      P.val.grp = dev_upload(m->pool, sa.val_grp, s);
-      P.val.ngrp = (int)sa.val_grp.size() - 1;
-      P.r_grp = dev_upload(m->pool, sa.r_grp, s);
-      P.r_ngrp = (int)sa.r_grp.size() - 1;
-      P.t_pos = dev_upload(m->pool, sa.t_pos, s);
-      P.t_row = dev_upload(m->pool, sa.t_row, s);
-      P.t_col = dev_upload(m->pool, sa.t_col, s);
-      P.t_blk = dev_alloc<double>(m->pool, 9 * (size_t)P.np);
-      P.r_blk = dev_alloc<double>(m->pool, 9 * (size_t)P.np);
-      P.t_grp = dev_upload(m->pool, sa.t_grp, s);
-      P.t_ngrp = (int)sa.t_grp.size() - 1;
+      P.val.n = (int)(V1 - V0);
+      P.val.a = up_range(sa.val_src.data(), V0, V1);
+      P.val.tgt = up_range(sa.val_tgt.data(), V0, V1);
+      std::vector<int> val_grp_l, r_grp_l, t_pos_l, t_row_l, t_col_l, t_idx_l, t_ptr_l, t_grp_l;   // (live until the stream is synchronised below)
+      if (own) {
+        std::vector<int> vptr;
+        for (size_t q = V0; q < V1; ++q)
+          if (q == V0 || sa.val_tgt[q] != sa.val_tgt[q - 1]) vptr.push_back((int)q);
+        vptr.push_back((int)V1);
+        val_grp_l = make_groups(vptr);
+        r_grp_l = make_groups(std::vector<int>(sa.p_rowptr.begin() + orow0, sa.p_rowptr.begin() + orow1 + 1));
+        // this rank's rows' entries in column order (what the restriction streams and what P^T A P is listed from)
+        t_pos_l.assign(npl, 0);
+        t_ptr_l.assign((size_t)nc + 1, 0);
+        t_row_l.reserve(npl);
+        t_col_l.reserve(npl);
+        t_idx_l.reserve(npl);
+        for (int a = 0; a < nc; ++a) {
+          for (int t = sa.t_ptr[a]; t < sa.t_ptr[a + 1]; ++t) {
+            const int i = sa.t_row[t];
+            if (i < orow0 || i >= orow1) continue;
+            const int e = sa.t_idx[t];
+            t_pos_l[(size_t)e - E0] = (int)t_row_l.size();
+            t_row_l.push_back(i);
+            t_col_l.push_back(a);
+            t_idx_l.push_back(e);
+          }
+          t_ptr_l[(size_t)a + 1] = (int)t_row_l.size();
+        }
+        t_grp_l = make_groups(t_ptr_l);
+      }
+      const std::vector<int>& val_grp = own ? val_grp_l : sa.val_grp;
+      const std::vector<int>& r_grp = own ? r_grp_l : sa.r_grp;
+      const std::vector<int>& t_grp = own ? t_grp_l : sa.t_grp;
+      P.val.grp = dev_upload(m->pool, val_grp, s);
+      P.val.ngrp = (int)val_grp.size() - 1;
+      P.r_grp = dev_upload(m->pool, r_grp, s);
+      P.r_ngrp = (int)r_grp.size() - 1;
+      P.t_pos = own ? up_range(t_pos_l.data() - E0, E0, E1) : dev_upload(m->pool, sa.t_pos, s);
+      P.t_row = dev_upload(m->pool, own ? t_row_l : sa.t_row, s);
+      P.t_col = dev_upload(m->pool, own ? t_col_l : sa.t_col, s);
+      P.r_n = P.t_n = (int)npl;
+      {
+        double* rb = dev_alloc<double>(m->pool, 9 * npl);
+        double* tb = dev_alloc<double>(m->pool, 9 * npl);
+        if (!rb || !tb) return fail("amg_create: out of device memory");
+        P.r_blk = rb - 2 * E0;            // row order, addressed by global entry numbers
+        P.r_blk8 = rb + 8 * npl - E0;
+        P.t_blk = tb;                     // column order, addressed by the rank's own positions
+        P.t_blk8 = tb + 8 * npl;
+      }
+      P.t_grp = dev_upload(m->pool, t_grp, s);
+      P.t_ngrp = (int)t_grp.size() - 1;
       std::vector<int> t_long;   // (lives until the stream is synchronised below)
-      for (size_t g = 0; g + 1 < sa.t_grp.size(); ++g)
-        if (sa.t_grp[g + 1] - sa.t_grp[g] > kLongColumn) {
-          t_long.push_back(sa.t_grp[g]);
-          t_long.push_back(sa.t_grp[g + 1]);
+      for (size_t g = 0; g + 1 < t_grp.size(); ++g)
+        if (t_grp[g + 1] - t_grp[g] > kLongColumn) {
+          t_long.push_back(t_grp[g]);
+          t_long.push_back(t_grp[g + 1]);
         }
       P.t_nlong = (int)t_long.size() / 2;
       P.t_long = P.t_nlong ? dev_upload(m->pool, t_long, s) : nullptr;
       if (P.t_nlong && !P.t_long) return fail("amg_create: out of device memory");
       if (P.t_nlong && hipStreamSynchronize(s) != hipSuccess) return fail("amg_create: upload failed");
       P.nap = sa.nap;
-      P.apblk = dev_alloc<double>(m->pool, 9 * (size_t)P.nap);
+      size_t F0 = 0, F1 = (size_t)sa.nap;
+      if (own) {
+        F0 = (size_t)sa.ap_rowptr[orow0];
+        F1 = (size_t)sa.ap_rowptr[orow1];
+      }
+      {
+        double* ab = dev_alloc<double>(m->pool, 9 * (F1 - F0));
+        if (!ab) return fail("amg_create: out of device memory");
+        P.apblk = ab - 9 * F0;
+      }
       int *d_ap_rowptr = nullptr, *d_ap_col = nullptr, *d_ap_row = nullptr, *d_t_ptr = nullptr, *d_t_idx = nullptr;
       if (sa.lists_on_device) {
         // the patterns go up (12 B per A P entry instead of 12 B per product); the lists are made below, once the
         // coarse structure is on the device too
         d_ap_rowptr = dev_upload(m->pool, sa.ap_rowptr, s);
-        d_ap_col = dev_upload(m->pool, sa.ap_col, s);
-        d_ap_row = dev_upload(m->pool, sa.ap_row, s);
-        d_t_ptr = dev_upload(m->pool, sa.t_ptr, s);
-        d_t_idx = dev_upload(m->pool, sa.t_idx, s);
+        d_ap_col = up_range(sa.ap_col.data(), F0, F1);
+        d_ap_row = up_range(sa.ap_row.data(), F0, F1);
+        d_t_ptr = dev_upload(m->pool, own ? t_ptr_l : sa.t_ptr, s);
+        d_t_idx = dev_upload(m->pool, own ? t_idx_l : sa.t_idx, s);
         if (!d_ap_rowptr || !d_ap_col || !d_ap_row || !d_t_ptr || !d_t_idx) return fail("amg_create: out of device memory");
         P.ap.n = (int)sa.n_ap_prod;
         P.rap.n = (int)sa.n_rap_prod;
@@ -2469,9 +2550,12 @@ Amg* amg_create(hipStream_t s, const BsrDev& A0, const Sym0Dev& S0, const Tile0D
       P.rap.ngrp = (int)sa.rap_grp.size() - 1;
       }
       P.rap_mirror = dev_upload(m->pool, sa.rap_mirror, s);
-      if (!P.rowptr || !P.row || !P.col || !P.blk || !P.val.a || !P.val.tgt || !P.val.grp || !P.r_grp || !P.t_pos || !P.t_row || !P.t_col || !P.t_blk || !P.r_blk || !P.t_grp ||
-          !P.apblk || (!sa.lists_on_device && (!P.ap.a || !P.ap.b || !P.ap.tgt || !P.ap.grp || !P.rap.a || !P.rap.b || !P.rap.tgt || !P.rap.grp)))
+      if (!P.rowptr || !P.row || !P.col || !P.blk || !P.val.a || !P.val.tgt || !P.val.grp || !P.r_grp || !P.t_pos || !P.t_row || !P.t_col || !P.t_grp ||
+          (!sa.lists_on_device && (!P.ap.a || !P.ap.b || !P.ap.tgt || !P.ap.grp || !P.rap.a || !P.rap.b || !P.rap.tgt || !P.rap.grp)))
         return fail("amg_create: out of device memory");
+      if (own && hipStreamSynchronize(s) != hipSuccess) return fail("amg_create: upload failed");   // (the rank-local host lists die with this scope)
+      if (l == 0) m->level0_bytes += (long long)(72 * (size_t)P.np + 144 * npl + 72 * (F1 - F0) + 8 * (V1 - V0) + 12 * npl + 8 * (F1 - F0));
+      l0_own = {own, (int)F0, (int)F1};
       l0_dev = {d_ap_rowptr, d_ap_col, d_ap_row, d_t_ptr, d_t_idx};
       if (l == 0 && halo) {
         // the entries of P in every rank's boundary rows: what A P of a neighbour's rows gathers from this rank's P
@@ -2525,16 +2609,18 @@ Amg* amg_create(hipStream_t s, const BsrDev& A0, const Sym0Dev& S0, const Tile0D
       ap.ap_row = l0_dev.ap_row;
       ap.ap_col = l0_dev.ap_col;
       ap.ap_rowptr = l0_dev.ap_rowptr;
-      const int nseg[2] = {P.nap, Hc.nslot};
+      ap.f_lo = l0_own.own ? l0_own.F0 : 0;
+      ap.nap = l0_own.own ? l0_own.F1 : P.nap;
+      const int seg_lo[2] = {ap.f_lo, 0};
+      const int nseg[2] = {ap.nap - ap.f_lo, Hc.nslot};
       const int nprod[2] = {P.ap.n, P.rap.n};
       ProdMap* maps[2] = {&P.ap, &P.rap};
       for (int w = 0; w < 2; ++w) {
-        int* ptr = dev_alloc<int>(m->pool, (size_t)nseg[w] + 1);
+        int* ptr0 = dev_alloc<int>(m->pool, (size_t)nseg[w] + 1);
         int* sums = dev_alloc<int>(m->pool, (size_t)nseg[w] / kScanChunk + 3);
-        int* la = dev_alloc<int>(m->pool, (size_t)std::max(nprod[w], 1));
-        int* lb = dev_alloc<int>(m->pool, (size_t)std::max(nprod[w], 1));
-        int* lt = dev_alloc<int>(m->pool, (size_t)std::max(nprod[w], 1));
-        if (!ptr || !sums || !la || !lb || !lt) return fail("amg_create: out of device memory");
+        if (!ptr0 || !sums) return fail("amg_create: out of device memory");
+        int* ptr = ptr0 - seg_lo[w];   // addressed by global target numbers
+        int *la = nullptr, *lb = nullptr, *lt = nullptr;
         const dim3 grid(grid_for(8LL * nseg[w], kBlock)), block(kBlock);   // eight lanes per target
         if (w == 0)
           SGO_LAUNCH((k_ap_list<false>), grid, block, 0, s, ap, (const int*)L.A.rowptr, (const int*)L.A.col, (const int*)P.rowptr,
@@ -2542,27 +2628,34 @@ Amg* amg_create(hipStream_t s, const BsrDev& A0, const Sym0Dev& S0, const Tile0D
         else
           SGO_LAUNCH((k_rap_list<false>), grid, block, 0, s, Hc.nslot, (const int*)C.A.row, (const int*)C.A.col,
                      (const int*)l0_dev.t_ptr, (const int*)P.t_row, (const int*)l0_dev.t_idx, ap, ptr, la, lb, lt);
-        dev_scan_exclusive(s, ptr, nseg[w], sums);
+        dev_scan_exclusive(s, ptr0, nseg[w], sums);
+        int ngrp = 0, total = -1;
+        if (hipMemcpyAsync(&total, ptr0 + nseg[w], sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess ||
+            hipStreamSynchronize(s) != hipSuccess)
+          return fail("amg_create: product-list kernels failed");
+        if (!l0_own.own && total != nprod[w])
+          return fail("amg_create: internal error (device product lists: " + std::to_string(total) + " products, the host counted " +
+                      std::to_string(nprod[w]) + ")");
+        if (total < 0 || total > nprod[w]) return fail("amg_create: internal error (device product lists)");
+        la = dev_alloc<int>(m->pool, (size_t)std::max(total, 1));
+        lb = dev_alloc<int>(m->pool, (size_t)std::max(total, 1));
+        lt = dev_alloc<int>(m->pool, (size_t)std::max(total, 1));
+        if (!la || !lb || !lt) return fail("amg_create: out of device memory");
         if (w == 0)
           SGO_LAUNCH((k_ap_list<true>), grid, block, 0, s, ap, (const int*)L.A.rowptr, (const int*)L.A.col, (const int*)P.rowptr,
                      (const int*)P.col, ptr, la, lb, lt);
         else
           SGO_LAUNCH((k_rap_list<true>), grid, block, 0, s, Hc.nslot, (const int*)C.A.row, (const int*)C.A.col,
                      (const int*)l0_dev.t_ptr, (const int*)P.t_row, (const int*)l0_dev.t_idx, ap, ptr, la, lb, lt);
-        int ngrp = 0, total = -1;
-        if (hipMemcpyAsync(&total, ptr + nseg[w], sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess ||
-            hipStreamSynchronize(s) != hipSuccess)
-          return fail("amg_create: product-list kernels failed");
-        if (total != nprod[w])
-          return fail("amg_create: internal error (device product lists: " + std::to_string(total) + " products, the host counted " +
-                      std::to_string(nprod[w]) + ")");
-        int* grp = dev_make_groups(s, m->pool, ptr, nseg[w], total, &ngrp);
+        int* grp = dev_make_groups(s, m->pool, ptr0, nseg[w], total, &ngrp);
         if (!grp) return fail("amg_create: out of device memory");
+        maps[w]->n = total;
         maps[w]->a = la;
         maps[w]->b = lb;
         maps[w]->tgt = lt;
         maps[w]->grp = grp;
         maps[w]->ngrp = ngrp;
+        if (l == 0) m->level0_bytes += 12LL * total;
       }
     }
     if (hipStreamSynchronize(s) != hipSuccess) return fail("amg_create: upload failed");  // host vectors die below

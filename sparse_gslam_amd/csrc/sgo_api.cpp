@@ -517,6 +517,21 @@ int sgo_comm_init_host(sgo_ctx* c, int nranks, int rank, sgo_host_allreduce_fn f
   } SGO_CATCH(c)
 }
 
+int sgo_comm_host_allgather(sgo_ctx* c, sgo_host_allgather_fn fn) {
+  if (!c || !c->comm.host_fn) return SGO_EINVAL;
+  if (c->has_graph) {
+    c->err = "sgo_comm_host_allgather must precede sgo_set_graph_se2";
+    return SGO_EINVAL;
+  }
+  c->comm.host_gather_fn = fn;
+  return SGO_OK;
+}
+
+int64_t sgo_debug_level0_bytes(sgo_ctx* c) {
+  if (check_graph(c) != SGO_OK) return -1;
+  return (int64_t)c->level0_bytes + (c->amg ? (int64_t)amg_level0_bytes(c->amg) : 0);
+}
+
 int sgo_comm_size(sgo_ctx* c) { return c ? c->comm.nranks : SGO_EINVAL; }
 
 int sgo_debug_set_shard(sgo_ctx* c, int nranks, int rank) {

@@ -189,7 +189,8 @@ __device__ __forceinline__ void load_block(const BsrDev& A, size_t k, double (&b
   const size_t u = (size_t)(r >> 1);
   double t[9];
 #pragma unroll
-  for (int c = 0; c < 9; ++c) t[c] = A.ublk[blk_at(c, u, A.nu)];
+  for (int c = 0; c < 8; ++c) t[c] = A.ublk[blk_at(c, u, A.nus)];
+  t[8] = A.ublk8[u];
   const bool tr = r & 1;
   b[0] = t[0]; b[4] = t[4]; b[8] = t[8];
   b[1] = tr ? t[3] : t[1]; b[3] = tr ? t[1] : t[3];

@@ -46,8 +46,10 @@ struct BsrDev {
   double* dinv = nullptr; // [n][6] inverse of the diagonal block, symmetric packing
   // level 0 only: references into the symmetric storage
   const int* ref = nullptr;     // [nslot]
-  const double* ublk = nullptr; // pair-SoA over nu stored off-diagonal blocks
-  size_t nu = 0;
+  const double* ublk = nullptr; // pair-SoA over the stored off-diagonal blocks (components 0..7; see Sym0Dev)
+  const double* ublk8 = nullptr;// component 8
+  size_t nu = 0;                // blocks the symmetric storage holds in all
+  size_t nus = 0;               // pair stride of ublk (= nu on one GPU; the blocks THIS rank holds in row-owner mode)
   const double* dblk = nullptr; // [n][6]
 };
 
@@ -94,7 +96,13 @@ struct Sym0Dev {
   int* grow = nullptr;           // [ngrp] first row of group g
   int* gown = nullptr;           // [ngrp] storage index of the group's first owned slot
   int* gtr = nullptr;            // [ngrp] position in tref of the group's first transposed slot
-  double* ublk = nullptr;        // pair-SoA [nu]
+  // The block arrays are indexed by GLOBAL storage numbers.  In multi-GPU row-owner mode a rank holds the blocks (and the
+  // per-slot / per-block index arrays) of its own rows only: the arrays are allocated for the rank's range and the base
+  // pointers are shifted so that global numbers address them -- which is why component 8 has a base pointer of its own
+  // (pair p of block u sits at ublk + 2 (p nus + u), component 8 at ublk8 + u) and the pair stride is a field (nus).
+  int nus = 0;                   // pair stride of ublk: stored blocks held by this rank (= nu on one GPU)
+  double* ublk = nullptr;        // pair-SoA, components 0..7
+  double* ublk8 = nullptr;       // component 8
   double* dblk = nullptr;        // [n][6]
   double* dinv = nullptr;        // [n][6]
 };
@@ -144,11 +152,13 @@ struct Tile0Dev {
 // (row Jacobian B).
 enum : int { kSlotDir = 1, kSlotNoEdge = 2, kSlotFixedCol = 4 };   // FixedCol: the edge's other endpoint is fixed (no block)
 struct EdgeSlotsDev {
+  int stride = 0;         // component stride of zinv / info: the slots held (= ncs on one GPU; this rank's slots in row-owner mode,
+                          // with base pointers shifted so that global slot numbers address them)
   int* vi = nullptr;      // vertex id of EdgeSE2::vertices()[0]
   int* vj = nullptr;      // vertex id of EdgeSE2::vertices()[1]
   unsigned char* flags = nullptr;
-  double* zinv = nullptr; // [3][ncs] cached inverse measurement (EdgeSE2::setMeasurement)
-  double* info = nullptr; // [6][ncs]
+  double* zinv = nullptr; // [3][stride] cached inverse measurement (EdgeSE2::setMeasurement)
+  double* info = nullptr; // [6][stride]
   double* phi = nullptr;  // [ncs]
 };
 
@@ -433,7 +443,7 @@ void launch_chi2(hipStream_t s, const EdgeListDev& el, int e0, int e1, const dou
                  double* partials /*[2][kMaxPartials]*/, int* grid_out);
 void launch_reduce2(hipStream_t s, const double* partials, int nparts, double* out2);
 void launch_edge_prepare(hipStream_t s, int E, const double* meas, const double* info, double* zinv, double* info_soa);
-void launch_slot_expand(hipStream_t s, int ncs, const int* eidx, const EdgeListDev& el, const EdgeSlotsDev& es);
+void launch_slot_expand(hipStream_t s, int k0, int k1, const int* eidx, const EdgeListDev& el, const EdgeSlotsDev& es);   // slots [k0, k1)
 // strength weights of the logical slots (hrowptr: logical row pointers) straight from the edge list (sgo_kernels.hip)
 void launch_early_strength(hipStream_t s, const EdgeListDev& el, const double* poses, int n, const int* rowptr, const int* eidx,
                            const unsigned char* flags, const int* hrowptr, double* w);

@@ -103,9 +103,9 @@ __global__ __launch_bounds__(kBlock) void k_edge_prepare(int E, const double* __
 }
 // The per-slot operand arrays of k_linearize (coalesced per slot) from the per-edge arrays: slot k came from
 // edge eidx[k]; the host only lists that index and the side (4 + 1 B per slot instead of 96 B).
-__global__ __launch_bounds__(kBlock) void k_slot_expand(int ncs, const int* __restrict__ eidx, EdgeListDev el, EdgeSlotsDev es) {
-  const size_t ns = (size_t)ncs, E = (size_t)el.E;
-  for (int k = blockIdx.x * kBlock + threadIdx.x; k < ncs; k += gridDim.x * kBlock) {
+__global__ __launch_bounds__(kBlock) void k_slot_expand(int k0, int k1, const int* __restrict__ eidx, EdgeListDev el, EdgeSlotsDev es) {
+  const size_t ns = (size_t)es.stride, E = (size_t)el.E;
+  for (int k = k0 + blockIdx.x * kBlock + threadIdx.x; k < k1; k += gridDim.x * kBlock) {
     const size_t e = (size_t)eidx[k];
     es.vi[k] = el.vi[e];
     es.vj[k] = el.vj[e];
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(kBlock) void k_row_strength(int n, const int* __res
 __global__ __launch_bounds__(kBlock) void k_linearize(Sym0Dev A, int g0, int g1, EdgeSlotsDev es,
                                                       const double* __restrict__ poses, double* __restrict__ dgb) {
   const int lane = threadIdx.x & 63;
-  const size_t ns = (size_t)A.ncs, nu = (size_t)A.nu;
+  const size_t ns = (size_t)es.stride, nu = (size_t)A.nus;
   int g, gend, gstride;
   group_walk(g1 - g0, &g, &gend, &gstride);   // this rank's band of row groups [g0, g1)
   g += g0;
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(kBlock) void k_linearize(Sym0Dev A, int g0, int g1,
         bp[nu + idx] = make_double2(T00 * C02 + T10 * C12 + T20 * C22, T01 * C00 + T11 * C10);
         bp[2 * nu + idx] = make_double2(T01 * C01 + T11 * C11, T01 * C02 + T11 * C12 + T21 * C22);
         bp[3 * nu + idx] = make_double2(T02 * C00 + T12 * C10, T02 * C01 + T12 * C11);
-        A.ublk[8 * nu + idx] = T02 * C02 + T12 * C12 + T22 * C22;
+        A.ublk8[idx] = T02 * C02 + T12 * C12 + T22 * C22;
       }
     }
     seg_scan<9>(row, acc, lane);
@@ -569,7 +569,7 @@ template <int MODE>
 __global__ __launch_bounds__(kBlock, 8) void k_spmv0(Sym0Dev A, Spmv0Args a) {
   if (a.S && a.S->stop) return;
   const int lane = threadIdx.x & 63;
-  const size_t nu = (size_t)A.nu;
+  const size_t nu = (size_t)A.nus;
   const double2* __restrict__ bp = reinterpret_cast<const double2*>(A.ublk);
   double dotacc[2] = {0.0, 0.0};
   const int ulo = a.u1 > 0 ? a.u0 : 0, uhi = a.u1 > 0 ? a.u1 : A.ngrp;
@@ -600,7 +600,7 @@ __global__ __launch_bounds__(kBlock, 8) void k_spmv0(Sym0Dev A, Spmv0Args a) {
         const size_t c = 3 * (size_t)A.col[k];
         const double x0 = a.x[c], x1 = a.x[c + 1], x2 = a.x[c + 2];
         const double2 p0 = bp[idx], p1 = bp[nu + idx], p2 = bp[2 * nu + idx], p3 = bp[3 * nu + idx];
-        const double b8 = A.ublk[8 * nu + idx];
+        const double b8 = A.ublk8[idx];
         // row-major b0..b8 = p0.x p0.y p1.x | p1.y p2.x p2.y | p3.x p3.y b8 ; transposed: swap (1,3) (2,6) (5,7)
         const double m01 = tr ? p1.y : p0.y, m02 = tr ? p3.x : p1.x;
         const double m10 = tr ? p0.y : p1.y, m12 = tr ? p3.y : p2.y;
@@ -663,7 +663,7 @@ __device__ __forceinline__ void tile_group_load(const Sym0Dev& A, const Tile0Dev
     L.cw = TL.cv[k];
     L.off = TL.off1[k];
     L.p0 = bp[k]; L.p1 = bp[nu + k]; L.p2 = bp[2 * nu + k]; L.p3 = bp[3 * nu + k];
-    L.b8 = A.ublk[8 * nu + k];
+    L.b8 = A.ublk8[k];
   }
 }
 // u = B x_col into acc, v = B^T x_row to the twin's staging slot
@@ -696,7 +696,7 @@ __global__ __launch_bounds__(kTileThreads) void k_spmv0t(Sym0Dev A, Tile0Dev TL,
   int* next_group = &next_group_cell;
   constexpr int NW = kTileThreads / 64;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const size_t nu = (size_t)A.nu;
+  const size_t nu = (size_t)A.nus;
   const double2* __restrict__ bp = reinterpret_cast<const double2*>(A.ublk);
   double dotacc[2] = {0.0, 0.0};
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
@@ -785,7 +785,7 @@ __global__ __launch_bounds__(kTileThreads) void k_spmv0t(Sym0Dev A, Tile0Dev TL,
         const unsigned cw = TL.cv[k];
         row = cur.r0 + TL.off1[k];
         const double2 p0 = bp[k], p1 = bp[nu + k], p2 = bp[2 * nu + k], p3 = bp[3 * nu + k];
-        const double b8 = A.ublk[8 * nu + k];
+        const double b8 = A.ublk8[k];
         tile_slot(xs, vst, row - T.row0, cw, p0, p1, p2, p3, b8, acc);
       }
       seg_scan<3>(row, acc, lane);
@@ -1149,8 +1149,8 @@ void launch_early_strength(hipStream_t s, const EdgeListDev& el, const double* p
                            const unsigned char* flags, const int* hrowptr, double* w) {
   if (n > 0) SGO_LAUNCH(k_row_strength, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, s, n, rowptr, eidx, flags, hrowptr, el, poses, w);
 }
-void launch_slot_expand(hipStream_t s, int ncs, const int* eidx, const EdgeListDev& el, const EdgeSlotsDev& es) {
-  SGO_LAUNCH(k_slot_expand, dim3(grid_for(ncs, kBlock)), dim3(kBlock), 0, s, ncs, eidx, el, es);
+void launch_slot_expand(hipStream_t s, int k0, int k1, const int* eidx, const EdgeListDev& el, const EdgeSlotsDev& es) {
+  SGO_LAUNCH(k_slot_expand, dim3(grid_for(k1 - k0, kBlock)), dim3(kBlock), 0, s, k0, k1, eidx, el, es);
 }
 int launch_spmv_ex(hipStream_t s, const BsrDev& A, int mode, const SpmvArgs& a) {
   const int grid = grid_for(A.ngrp, kWavesPerBlock);

@@ -793,7 +793,7 @@ int optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
 // k_spmv0<mode> (operand = the PCG direction buffer, whatever it holds), HIP events around them on the
 // context's stream; returns the mean microseconds per launch (< 0 on error).  variant 16: the wave-group kernel even when the graph has a tile view; variant 32: per-phase s_memtime stamps of the tile kernel on stderr (diagnostic).
 double debug_spmv0_us(sgo_ctx* c, int mode, int variant, int reps) {
-  if (check_graph(c) != SGO_OK || reps < 1 || c->n == 0 || ensure_rows(c) != SGO_OK) return -1.0;
+  if (check_graph(c) != SGO_OK || reps < 1 || c->n == 0 || ensure_rows(c) != SGO_OK || c->owner) return -1.0;
   hipEvent_t a, b;
   if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return -1.0;
   Spmv0Args args{};

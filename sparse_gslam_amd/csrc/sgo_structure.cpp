@@ -233,8 +233,11 @@ int build_structure(sgo_ctx* c, int V, const double* poses, const uint8_t* fixed
   c->d_eidx = d_eidx;
   c->d_rowptr = c->d_hrowptr = nullptr;
   if ((rc = upload(c, &c->es.flags, flags))) return rc;
-  if ((rc = dalloc(c, &c->es.vi, (size_t)ns)) || (rc = dalloc(c, &c->es.vj, (size_t)ns)) || (rc = dalloc(c, &c->es.zinv, 3 * (size_t)ns)) ||
-      (rc = dalloc(c, &c->es.info, 6 * (size_t)ns)) || (rc = dalloc(c, &c->es.phi, (size_t)ns)))
+  // (with a communicator the operand arrays are allocated further down, for this rank's slots only in row-owner mode)
+  const bool es_early = !c->comm.active();
+  c->es.stride = ns;
+  if (es_early && ((rc = dalloc(c, &c->es.vi, (size_t)ns)) || (rc = dalloc(c, &c->es.vj, (size_t)ns)) || (rc = dalloc(c, &c->es.zinv, 3 * (size_t)ns)) ||
+                   (rc = dalloc(c, &c->es.info, 6 * (size_t)ns)) || (rc = dalloc(c, &c->es.phi, (size_t)ns))))
     return rc;
   // Large graphs: the multigrid's host analysis of level 0 (greedy aggregation + patterns / product lists of the
   // smoothed transfer: C4 11 + 17 ms, the longest sequential piece of the set-up) needs the strength weights and the
@@ -250,6 +253,7 @@ int build_structure(sgo_ctx* c, int V, const double* poses, const uint8_t* fixed
     if (pipeline) {
       int *d_rowptr = c->d_rowptr, *d_hrowptr = c->d_hrowptr;
       double* d_w = c->es.info;   // scratch: nslot <= n + ns <= 2 ns doubles of the 6 ns the not yet expanded operand array holds
+      if (!es_early && (rc = dalloc(c, &d_w, (size_t)H.nslot))) return rc;
       launch_early_strength(c->stream, c->el, c->d_poses, n, d_rowptr, d_eidx, c->es.flags, d_hrowptr, d_w);
       c->l0_w.resize((size_t)H.nslot);
       HIP_TRY(c, hipMemcpyAsync(c->l0_w.data(), d_w, sizeof(double) * (size_t)H.nslot, hipMemcpyDeviceToHost, c->stream));
@@ -507,29 +511,6 @@ int build_structure(sgo_ctx* c, int V, const double* poses, const uint8_t* fixed
 
   lap("tile arrays");
   const double tb1 = wall_s();
-  Sym0Dev& S = c->S0;
-  S.n = n;
-  S.nu = nu;
-  S.npairs = (nu + ntr) / 2;   // owned = intra pairs + 2 x inter pairs, transposed = intra pairs
-  S.ncs = ns;
-  S.ngrp = ngrp;
-  if ((rc = upload(c, &S.col, col))) return rc;
-  if ((rc = upload(c, &S.meta, meta))) return rc;
-  if ((rc = upload(c, &S.tref, tref))) return rc;
-  if ((rc = upload(c, &S.grp, grp))) return rc;
-  if ((rc = upload(c, &S.grow, grow))) return rc;
-  if ((rc = upload(c, &S.gown, gown))) return rc;
-  if ((rc = upload(c, &S.gtr, gtr))) return rc;
-  if ((rc = dalloc(c, &S.ublk, 9 * (size_t)nu))) return rc;
-  if ((rc = dalloc(c, &S.dblk, 6 * (size_t)n))) return rc;
-  if ((rc = dalloc(c, &S.dinv, 6 * (size_t)n))) return rc;
-  c->unit_row0.clear();   // first row of every level-0 work unit (tiles, or wave groups without a tile view)
-  if (tiles_ok && !tiles.empty()) {
-    for (const TileDesc& T : tiles) c->unit_row0.push_back(T.row0);
-  } else {
-    for (int g = 0; g < ngrp; ++g) c->unit_row0.push_back(grow[g]);
-  }
-  c->unit_row0.push_back(n);
   // ---- multi-GPU, row-owner mode: the boundary rows of every rank (the rows with an edge into another rank's range)
   c->owner = false;
   c->halo = HaloDev();
@@ -607,6 +588,71 @@ int build_structure(sgo_ctx* c, int V, const double* poses, const uint8_t* fixed
       std::fprintf(stderr, "[sgo] multi-GPU: %lld of %d rows are boundary rows: all-reduce mode\n", total, n);
     }
   }
+  // Row-owner mode: the per-slot and per-block arrays are allocated and uploaded for this rank's rows only; the base
+  // pointers are shifted so that the kernels keep addressing them by global slot / storage numbers.
+  const bool own_only = c->owner;
+  const int orow0 = own_only ? c->halo.row0 : 0, orow1 = own_only ? c->halo.row1 : n;
+  const size_t K0 = (size_t)rowptr[orow0], K1 = (size_t)rowptr[orow1];            // compact slots
+  const size_t U0 = (size_t)own[K0], U1 = (size_t)own[K1];                        // stored blocks
+  const size_t R0 = (size_t)tslot[K0], R1 = (size_t)tslot[K1];                    // transposed slots
+  c->level0_bytes = 0;
+  auto up_range = [&](auto** p, const auto* host, size_t lo, size_t hi) -> int {
+    using T = std::remove_const_t<std::remove_pointer_t<decltype(host)>>;
+    T* q = nullptr;
+    int r = dalloc(c, &q, hi - lo);
+    if (r) return r;
+    if (hi > lo) HIP_TRY(c, hipMemcpyAsync(q, host + lo, (hi - lo) * sizeof(T), hipMemcpyHostToDevice, c->stream));
+    *p = q - lo;   // (global numbers address the rank's range)
+    c->level0_bytes += (long long)((hi - lo) * sizeof(T));
+    return SGO_OK;
+  };
+  Sym0Dev& S = c->S0;
+  S.n = n;
+  S.nu = nu;
+  S.npairs = (nu + ntr) / 2;   // owned = intra pairs + 2 x inter pairs, transposed = intra pairs
+  S.ncs = ns;
+  S.ngrp = ngrp;
+  S.nus = (int)(U1 - U0);
+  if ((rc = up_range(&S.col, col.data(), K0, K1))) return rc;
+  if ((rc = up_range(&S.meta, meta.data(), K0, K1))) return rc;
+  if ((rc = up_range(&S.tref, tref.data(), R0, R1))) return rc;
+  if ((rc = upload(c, &S.grp, grp))) return rc;
+  if ((rc = upload(c, &S.grow, grow))) return rc;
+  if ((rc = upload(c, &S.gown, gown))) return rc;
+  if ((rc = upload(c, &S.gtr, gtr))) return rc;
+  {
+    double* ub = nullptr;
+    if ((rc = dalloc(c, &ub, 9 * (U1 - U0)))) return rc;
+    S.ublk = ub - 2 * U0;                       // pair p of block u: ublk + 2 (p nus + u)
+    S.ublk8 = ub + 8 * (U1 - U0) - U0;          // component 8 of block u: ublk8 + u
+    c->level0_bytes += (long long)(72 * (U1 - U0));
+  }
+  if ((rc = dalloc(c, &S.dblk, 6 * (size_t)n))) return rc;
+  if ((rc = dalloc(c, &S.dinv, 6 * (size_t)n))) return rc;
+  if (!es_early) {   // the operand arrays of k_linearize: this rank's slots
+    const size_t nsl = K1 - K0;
+    int *vi = nullptr, *vj = nullptr;
+    double *zi = nullptr, *in = nullptr, *ph = nullptr;
+    if ((rc = dalloc(c, &vi, nsl)) || (rc = dalloc(c, &vj, nsl)) || (rc = dalloc(c, &zi, 3 * nsl)) || (rc = dalloc(c, &in, 6 * nsl)) ||
+        (rc = dalloc(c, &ph, nsl)))
+      return rc;
+    c->es.stride = (int)nsl;
+    c->es.vi = vi - K0;
+    c->es.vj = vj - K0;
+    c->es.zinv = zi - K0;
+    c->es.info = in - K0;
+    c->es.phi = ph - K0;
+    c->level0_bytes += (long long)(88 * nsl);
+  } else {
+    c->level0_bytes += (long long)(88 * (size_t)ns);
+  }
+  c->unit_row0.clear();   // first row of every level-0 work unit (tiles, or wave groups without a tile view)
+  if (tiles_ok && !tiles.empty()) {
+    for (const TileDesc& T : tiles) c->unit_row0.push_back(T.row0);
+  } else {
+    for (int g = 0; g < ngrp; ++g) c->unit_row0.push_back(grow[g]);
+  }
+  c->unit_row0.push_back(n);
   Tile0Dev& TL = c->T0;
   TL = Tile0Dev();
   if (tiles_ok && !tiles.empty()) {
@@ -614,8 +660,8 @@ int build_structure(sgo_ctx* c, int V, const double* poses, const uint8_t* fixed
     TL.lds_bytes = tile_lds;
     if (hcol.empty()) hcol.push_back(0);
     if ((rc = upload(c, &TL.tile, tiles))) return rc;
-    if ((rc = upload(c, &TL.cv, cv))) return rc;
-    if ((rc = upload(c, &TL.off1, off1))) return rc;
+    if ((rc = up_range(&TL.cv, cv.data(), U0, U1))) return rc;
+    if ((rc = up_range(&TL.off1, off1.data(), U0, U1))) return rc;
     if ((rc = upload(c, &TL.grp1, grp1))) return rc;
     if ((rc = upload(c, &TL.grow1, grow1))) return rc;
     if ((rc = upload(c, &TL.trowptr, trowptr))) return rc;
@@ -640,6 +686,7 @@ int build_structure(sgo_ctx* c, int V, const double* poses, const uint8_t* fixed
   A.n = n;
   A.nslot = H.nslot;
   A.ngrp = 0;
+  // (the logical view stays whole on every rank: the product-list kernels of the multigrid set-up walk other ranks' rows' patterns)
   if ((rc = upload(c, &A.row, H.row))) return rc;
   if ((rc = upload(c, &A.col, H.col))) return rc;
   if ((rc = upload(c, &A.rowptr, H.rowptr))) return rc;
@@ -649,13 +696,15 @@ int build_structure(sgo_ctx* c, int V, const double* poses, const uint8_t* fixed
     A.ref = d_ref;
   }
   A.ublk = S.ublk;
+  A.ublk8 = S.ublk8;
+  A.nus = (size_t)S.nus;
   A.nu = (size_t)nu;
   A.dblk = S.dblk;
   A.dinv = S.dinv;
   // edge arrays in caller order: indices / kernel parameter straight from the caller's buffers; the inverse
   // measurements and the SoA information are made on the device from the raw rows, and the per-slot operand
   // arrays of k_linearize are expanded there too
-  if (E > 0 && ns > 0) launch_slot_expand(c->stream, ns, d_eidx, c->el, c->es);
+  if (E > 0 && K1 > K0) launch_slot_expand(c->stream, (int)K0, (int)K1, d_eidx, c->el, c->es);
   if ((rc = upload(c, &c->d_free_id, row_vertex))) return rc;
   const size_t n3 = 3 * (size_t)n;
   if ((rc = dalloc(c, &c->d_dgb, 9 * (size_t)n))) return rc;

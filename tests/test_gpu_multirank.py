@@ -62,7 +62,7 @@ def _worker(rank, world, port, name, iters, q):
             done, st = o.optimize(iters)
             P = o.get_poses()
             c, rc = o.chi2()
-            desc = o.solver_description()
+            desc = o.solver_description() + f" level0_bytes={o.level0_bytes()}"
         q.put((rank, done, st["chi2"], st["pcg_iters"], P.tobytes(), c, rc, calls[0], desc))
     except Exception as e:   # report instead of leaving the parent waiting on the queue
         q.put((rank, -1, repr(e), [], b"", 0.0, 0.0, 0, ""))
@@ -79,7 +79,7 @@ def _run(world, name, iters):
     procs = [ctx.Process(target=_worker, args=(r, world, port, name, iters, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted(q.get(timeout=600) for _ in procs)
+    res = sorted(q.get(timeout=240) for _ in procs)
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
@@ -103,12 +103,21 @@ def test_ranks_agree_bitwise_and_match_one_rank(world, name, mode, monkeypatch):
         assert r[2] == chi2_0 and r[3] == its_0 and r[4] == P0 and r[7] == calls0
     assert calls0 >= 3 * sum(its_0)     # two product vectors + one coarse right-hand side per PCG iteration
     g = _graph(name)
+    rank_bytes = [int(r[8].rsplit("level0_bytes=", 1)[1]) for r in res]
     # one rank through the same transport
     with capi.Optimizer(0) as o:
         o.comm_init_host(1, 0, lambda a: None)
         o.set_graph(*g.arrays())
         d1, s1 = o.optimize(iters)
         P1 = o.get_poses()
+        bytes1 = o.level0_bytes()
+    if mode == "owner":
+        # a rank holds the level-0 blocks, edge operands, transfer blocks and product lists of ITS rows: 1 / world of the
+        # one-rank bytes each, up to the pairs the 256-per-rank tile cut stores twice and the entries kept for the boundary
+        assert max(rank_bytes) <= 1.25 * bytes1 / world + (4 << 20), (rank_bytes, bytes1)
+        assert sum(rank_bytes) <= 1.25 * bytes1 + world * (4 << 20), (rank_bytes, bytes1)
+    else:
+        assert min(rank_bytes) >= 0.9 * bytes1      # all-reduce mode: every rank holds the whole graph
     assert d1 == iters and max(abs(a - b) for a, b in zip(s1["pcg_iters"], its_0)) <= 1
     # (two PCG solves to 1e-8 with differently rounded coarse right-hand sides: poses agree to the solves' accuracy)
     assert np.abs(np.frombuffer(P0, dtype=np.float64).reshape(-1, 3) - P1).max() <= 1e-6
