@@ -10,10 +10,12 @@ steps x iters x E / time = edge-Jacobian evaluations per second per GN iteration
 (structure + edge arrays) already resident in HBM when the timed region starts; the only upload in
 the timed region is the 24*V-byte pose reset at the start of each step.
 
-N > 1: launched by ``python -m torch.distributed.run``; one rank per GPU.  Every rank holds the full
-graph; every level-0 Hessian product of the solve (each pass over the edges' blocks: three per PCG
-iteration) is evaluated by rank r for the rows of its range of tiles and the product vector is
-all-reduced with RCCL inside libsgo.  Total work is fixed => "scaling": "strong".
+N > 1: launched by ``python -m torch.distributed.run``; one rank per GPU, libsgo's own RCCL communicator.  Every rank
+marshals the same graph; in row-owner mode (graphs with spatially local closures, C4) a rank holds the Hessian blocks
+and edge operands of its own contiguous range of rows only, does all level-0 work for these rows and exchanges boundary
+rows + partial dot products in small all-gather packets; graphs whose rows are mostly boundary
+rows (random closures) keep every rank's copy whole and all-reduce the product vectors.  Total work is fixed =>
+"scaling": "strong".
 """
 from __future__ import annotations
 
@@ -197,9 +199,7 @@ def main():
     if args.tol:
         opts["pcg_tol"] = args.tol
     opt = capi.Optimizer(local_rank, **opts)
-    sharding = "single GPU" if world == 1 else (
-        f"level-0 Hessian products sharded over {world} tile ranges + ncclAllReduce of the product vector per PCG "
-        f"step; linearisation, coarse multigrid levels and vector recurrences replicated")
+    sharding = "single GPU"   # (N > 1: replaced by the library's own description of the mode it chose for this graph)
     if world > 1 or os.environ.get("SGO_BENCH_FORCE_COMM"):
         # rendezvous for libsgo's own RCCL communicator: rank 0 makes the id, torch broadcasts it.  No
         # communicator, no multi-GPU number: a failure on any rank ends the run with a non-zero exit code
@@ -223,6 +223,8 @@ def main():
         elif comm_error:
             raise SystemExit(comm_error)
     opt.set_graph(*g.arrays())
+    if world > 1:
+        sharding = opt.solver_description().split("; multi-GPU ", 1)[-1]
     sg_ms = []                     # steady state of repeated calls (the reference re-initialises before every optimize(20)):
     for _ in range(11):            # median of 11 -- host threads decide single samples
         t_sg = time.perf_counter()
@@ -351,6 +353,13 @@ def main():
                                 "frac": fk["bytes"] / (fk["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS},
             "gn_iteration": {"bytes": b_gn, "seconds": t_gn, "pcg_iters": K, "achieved": b_gn / t_gn / 1e9,
                              "frac": b_gn / t_gn / 1e9 / HBM_PEAK_GBS},
+            # share of the profiled kernel time spent in kernels that a rank of a multi-GPU run (row-owner mode)
+            # evaluates for ITS rows only: level-0 products, linearisation, vector updates, level-0 transfers and the
+            # level-0 part of the hierarchy refresh ("@level0" slots); the rest (coarse levels, dense inverse) is replicated
+            "row_owner_sharded_frac": (lambda sh, tot: sh / tot if tot > 0 else None)(
+                sum(v["ms"] for n, v in prof.items() if n.startswith(("k_spmv0", "k_linearize", "k_finalize", "k_update_", "k_dot", "k_chi2",
+                                                                        "k_pose_update")) or n.endswith("@level0")),
+                sum(v["ms"] for v in prof.values())),
             "note": "achieved = algorithmic bytes (SURVEY.md section 8(d): every stored block once with one index, "
                     "76 B per edge, + the per-row vectors; DESIGN.md section 4) of all launches of this kernel / their "
                     "summed HIP-event time; the events are the dispatch's own start/stop stamps "

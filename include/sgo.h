@@ -88,7 +88,7 @@ typedef struct sgo_opts {
                               solve uses pcg_tol relative to its own ||b||; env SGO_PCG_TOL_CAP).  As Gauss-Newton
                               converges ||b|| falls by orders of magnitude; solving each step to 1e-8 of ITSELF
                               buys no accuracy of the iterates (chi2 is second order in the step's error) and
-                              costs a quarter of the PCG iterations (DESIGN.md section 7) */
+                              costs a quarter of the PCG iterations (DESIGN.md section 3) */
   int32_t pcg_warm_start;  /* 1 (default): from the second Gauss-Newton iteration of a call PCG starts from the previous
                               step scaled by the energy-optimal factor (b.x_prev)/(x_prev.H x_prev) instead of from zero:
                               same stopping test, about two iterations fewer per solve (env SGO_PCG_WARM) */

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Parity margin vs PCG tolerance: max relative chi2 error per GN iterate against the committed goldens /
-the CPU oracle, for several pcg_tol values (decides the default tolerance)."""
+the CPU oracle, for several pcg_tol values (decides the default tolerance; DESIGN.md section 3, NOTES.md section 7)."""
 import os
 import sys
 

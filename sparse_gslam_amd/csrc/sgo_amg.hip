@@ -1870,7 +1870,7 @@ void launch_coarse_operator(Amg* m, hipStream_t s, AmgLevel& L, AmgLevel& C, boo
   const int row0 = H ? H->row0 : 0, row1 = H ? H->row1 : 0;
   if (!L.smoothed) {
     {
-      Scope sc(m->prof, K_GALERKIN, (72.0 + 16.0 + 32.0) * L.A.nslot + 72.0 * C.A.nslot);
+      Scope sc(m->prof, level0 ? K_GALERKIN0 : K_GALERKIN, (72.0 + 16.0 + 32.0) * L.A.nslot + 72.0 * C.A.nslot);
       SGO_LAUNCH(k_galerkin, dim3(grid_for(L.gal.ngrp, kWavesPerBlock)), dim3(kBlock), 0, s, L.A, C.A, L.gal, L.d, row0, row1);
     }
     if (H && H->comm) {
@@ -1881,7 +1881,7 @@ void launch_coarse_operator(Amg* m, hipStream_t s, AmgLevel& L, AmgLevel& C, boo
   }
   PDev& P = L.P;
   {
-    Scope sc(m->prof, K_SA_P, (72.0 + 12.0 + 16.0) * L.A.nslot + 80.0 * P.np);
+    Scope sc(m->prof, level0 ? K_SA_P0 : K_SA_P, (72.0 + 12.0 + 16.0) * P.val.n + 80.0 * P.r_n);
     SGO_LAUNCH(k_p_values, dim3(grid_for(P.val.ngrp, kWavesPerBlock)), dim3(kBlock), 0, s, L.A, P, (const int*)L.agg,
                (const double*)L.d, m->cfg.omega_p, row0, row1);
   }
@@ -1890,14 +1890,14 @@ void launch_coarse_operator(Amg* m, hipStream_t s, AmgLevel& L, AmgLevel& C, boo
     if (!halo_exchange(*H, s, P.blk, 9, H->pent, H->pemax, HaloScalars(), &e)) m->comm_failed = true;
   }
   {
-    Scope sc(m->prof, K_SA_AP, 156.0 * P.ap.n + 72.0 * P.nap);
+    Scope sc(m->prof, level0 ? K_SA_AP0 : K_SA_AP, 156.0 * P.ap.n + 72.0 * P.nap);
     SGO_LAUNCH((k_block_products<true, false, false>), dim3(grid_for(P.ap.ngrp, kWavesPerBlock)), dim3(kBlock), 0, s,
                P.ap, L.A, (const double*)nullptr, (const double*)P.blk, P.apblk, (size_t)P.nap, (const int*)nullptr,
                (const int*)L.A.row, row0, P.local_lists ? 0 : row1, 0);   // (local lists hold this rank's products only: no filter)
   }
   if (P.local_lists) hipMemsetAsync(C.A.blk, 0, sizeof(double) * 9 * (size_t)C.A.nslot, s);   // targets this rank has no product for
   {
-    Scope sc(m->prof, K_SA_RAP, 156.0 * P.rap.n + 72.0 * C.A.nslot);
+    Scope sc(m->prof, level0 ? K_SA_RAP0 : K_SA_RAP, 156.0 * P.rap.n + 72.0 * C.A.nslot);
     SGO_LAUNCH((k_block_products<false, true, true>), dim3(grid_for(P.rap.ngrp, kWavesPerBlock)), dim3(kBlock), 0, s,
                P.rap, BsrDev(), (const double*)P.blk, (const double*)P.apblk, C.A.blk, (size_t)C.A.nslot, (const int*)P.rap_mirror,
                (const int*)P.row, row0, P.local_lists ? 0 : row1, 1);
@@ -2028,10 +2028,10 @@ int cycle(Amg* m, hipStream_t s, int l, const double* rhs, const double* rhs_sub
   }
   if (H && L.smoothed && L.P.local_lists) hipMemsetAsync(C.bk, 0, sizeof(double) * 3 * (size_t)C.A.n, s);   // coarse rows none of this rank's rows reaches
   if (L.smoothed) {
-    Scope sc(m->prof, K_RESTRICT_P, 84.0 * L.P.np + 24.0 * L.A.n + 24.0 * L.nc);
+    Scope sc(m->prof, l == 0 ? K_RESTRICT_P0 : K_RESTRICT_P, 84.0 * L.P.t_n + 24.0 * L.A.n + 24.0 * L.nc);
     launch_restrict_p(s, L.P, res, C.bk, S, frow0, frow1);
   } else {
-    Scope sc(m->prof, K_RESTRICT, 40.0 * L.A.n + 24.0 * L.nc);
+    Scope sc(m->prof, l == 0 ? K_RESTRICT0 : K_RESTRICT, 40.0 * L.A.n + 24.0 * L.nc);
     SGO_LAUNCH(k_restrict, dim3(grid_for(L.mem_ngrp, kWavesPerBlock)), dim3(kBlock), 0, s, L.mem_ngrp, L.mem_grp,
                        L.mem, L.agg, L.d, res, C.bk, S, frow0, frow1);
   }
@@ -2062,11 +2062,11 @@ int cycle(Amg* m, hipStream_t s, int l, const double* rhs, const double* rhs_sub
   }
   if (l == 0) {   // prolongation, then the post-smoothing sweep on the symmetric storage
     if (L.smoothed) {
-      Scope sc(m->prof, K_PROLONG_P, 80.0 * L.P.np + 52.0 * L.A.n);
+      Scope sc(m->prof, K_PROLONG_P0, 80.0 * L.P.r_n + 52.0 * L.A.n);
       SGO_LAUNCH(k_prolong_p, dim3(grid_for(L.P.r_ngrp, kWavesPerBlock)), dim3(kBlock), 0, s, L.A.n, L.P, cs.u1, cs.c1, cs.u2, cs.c2,
                  L.xs, S, (const double*)nullptr, H ? H->row0 : 0, H ? H->row1 : 0);
     } else {
-      Scope sc(m->prof, K_PROLONG, 68.0 * L.A.n);
+      Scope sc(m->prof, K_PROLONG0, 68.0 * L.A.n);
       SGO_LAUNCH(k_prolong_add, dim3(grid_for(H ? H->row1 - H->row0 : L.A.n, kBlock)), dim3(kBlock), 0, s, L.A.n, L.agg, L.d, cs.u1, cs.c1,
                          cs.u2, cs.c2, L.xs, S, (const double*)nullptr, H ? H->row0 : 0, H ? H->row1 : 0);
     }

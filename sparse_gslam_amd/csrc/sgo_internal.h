@@ -321,6 +321,17 @@ enum KernelId : int {
   K_SPMV0T_RESID,
   K_SPMV0T_JACOBI,
   K_DIRECT,
+  // the transfer / set-up kernels' launches on the FINEST level in slots of their own ("<kernel> @level0"): these are the
+  // ones a rank of a multi-GPU run evaluates for its own rows only; the same kernels' coarse-level launches stay in the
+  // plain slots
+  K_RESTRICT_P0,
+  K_PROLONG_P0,
+  K_SA_P0,
+  K_SA_AP0,
+  K_SA_RAP0,
+  K_GALERKIN0,
+  K_RESTRICT0,
+  K_PROLONG0,
   K_COUNT
 };
 extern const char* const kKernelNames[K_COUNT];

@@ -35,7 +35,8 @@ const char* const kKernelNames[K_COUNT] = {
     "k_gj_step (dense inverse, all block steps)", "k_dense_apply", "k_p_values", "k_block_products<1, 0, 0>",
     "k_block_products<0, 1, 1>", "k_restrict_p", "k_prolong_p", "k_spmv<7>",
     "k_spmv0<0>", "k_spmv0<1>", "k_spmv0<2>", "k_spmv0t<0, 1024>", "k_spmv0t<1, 1024>", "k_spmv0t<2, 1024>",
-    "k_direct"};
+    "k_direct", "k_restrict_p @level0", "k_prolong_p @level0", "k_p_values @level0", "k_block_products<1, 0, 0> @level0",
+    "k_block_products<0, 1, 1> @level0", "k_galerkin @level0", "k_restrict @level0", "k_prolong_add @level0"};
 
 namespace {
 
@@ -411,7 +412,7 @@ __global__ __launch_bounds__(kBlock) void k_init_scalars(PcgScalars* S, const do
 //   SPMV_PRE_RESID    y2 = omega Dinv b ; y = b - A y2            (first sweep from x = 0 fused with
 //                     the residual: the gathered operand is omega Dinv[col] b[col])
 // Fused variants used on the coarse multigrid levels, where a launch costs more than its data
-// (DESIGN.md section 7); scalars c1, c2 are ratios of per-block partial sums that every block
+// (NOTES.md section 7); scalars c1, c2 are ratios of per-block partial sums that every block
 // reduces itself in a fixed order:
 //   SPMV_JACOBI_P     as JACOBI with x' = x + P (c1 u1 + c2 u2)   (prolongation of the coarse
 //                     correction, itself the FCG combination of the child level, fused in)

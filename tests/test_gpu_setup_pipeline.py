@@ -1,6 +1,6 @@
 """sgo_set_graph_se2 on large graphs: the multigrid's host analysis of level 0 runs on a helper thread, fed by
 strength weights computed straight from the edge list (k_row_strength), while the calling
-thread lays out the level-0 storage.  The weights are the Frobenius norms of the same
+thread lays out the level-0 storage (NOTES.md section 7).  The weights are the Frobenius norms of the same
 Hessian blocks the serial set-up reads back from the assembled matrix, so both set-ups must build the same
 hierarchy: same level sizes, same PCG iteration counts, same iterates to rounding.  Also covers fixed vertices
 in the middle of the graph (slots without a block), duplicate edges, graph replacement while a helper result is
