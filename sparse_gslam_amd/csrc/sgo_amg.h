@@ -82,10 +82,11 @@ int amg_update(Amg* m, hipStream_t s, std::string* err);
 // z = M^-1 r (one cycle).  If dotvec != nullptr, partials[0..nparts) receive the per-block
 // partial sums of dotvec . z; returns nparts (the grid of the last kernel).
 // dotvec2 (optional) adds partials[kMaxPartials + ..] = dotvec2 . z.
-// xs0_ready: the producer of r has already left omega Dinv r in amg_xs0() (k_finalize, k_update_xr) --
-// the cycle's first level-0 smoothing sweep from zero -- otherwise the cycle computes it first.
+// xs0_ready: 1 = the producer of r has already left omega Dinv r in amg_xs0() (k_finalize, k_update_xr) --
+// the cycle's first level-0 smoothing sweep from zero --, 0 = the cycle computes it first; 2 (multi-GPU row-owner
+// mode) = as 1, and the copies of the neighbours' boundary rows are current too (no exchange at the cycle's entry).
 int amg_apply(Amg* m, hipStream_t s, const double* r, double* z, const double* dotvec, double* partials,
-              const PcgScalars* S, const double* dotvec2 = nullptr, bool xs0_ready = false);
+              const PcgScalars* S, const double* dotvec2 = nullptr, int xs0_ready = 0);
 // Multi-GPU: the cycle's two level-0 products evaluate the work units [u0, u1) only (this rank's tiles = the rows
 // [row0, row1)); the residual pass stays a per-rank partial that the restriction folds into a partial coarse
 // right-hand side, which is all-reduced over `comm` (3 n_c doubles); the post-smoothing pass's result is all-reduced

@@ -1919,7 +1919,7 @@ struct CoarseSol {
 
 int cycle(Amg* m, hipStream_t s, int l, const double* rhs, const double* rhs_sub, const SpmvRatio& rhs_c,
           double* rhs_out, double* out, const double* dotvec, double* dotparts, const PcgScalars* S,
-          const double* dotvec2 = nullptr, bool xs0_ready = false);
+          const double* dotvec2 = nullptr, int xs0_ready = 0);
 
 // Two flexible-CG steps on level l for A x = bk (Notay's K-cycle), with the vector updates
 // fused into the neighbouring SpMV-type launches:
@@ -1969,7 +1969,7 @@ CoarseSol fcg(Amg* m, hipStream_t s, int l, const PcgScalars* S) {
 // dotvec . out (and dotvec2 . out).  Returns the grid of the last kernel.
 int cycle(Amg* m, hipStream_t s, int l, const double* rhs, const double* rhs_sub, const SpmvRatio& rhs_c,
           double* rhs_out, double* out, const double* dotvec, double* dotparts, const PcgScalars* S,
-          const double* dotvec2, bool xs0_ready) {
+          const double* dotvec2, int xs0_ready) {
   AmgLevel& L = m->lv[l];
   AmgLevel& C = m->lv[l + 1];
   const int last = (int)m->lv.size() - 1;
@@ -1987,9 +1987,9 @@ int cycle(Amg* m, hipStream_t s, int l, const double* rhs, const double* rhs_sub
     }
     Spmv0Args a{};
     a.x = L.xs; a.b = rhs; a.y = L.rs; a.S = S;
-    if (H) {   // the neighbours' boundary rows of xs, then this rank's tiles
+    if (H) {   // the neighbours' boundary rows of xs (unless the caller keeps them current itself), then this rank's tiles
       std::string e;
-      if (!halo_exchange(*H, s, L.xs, 3, H->bnd, H->bmax, HaloScalars(), &e)) m->comm_failed = true;
+      if (xs0_ready < 2 && !halo_exchange(*H, s, L.xs, 3, H->bnd, H->bmax, HaloScalars(), &e)) m->comm_failed = true;
       a.u0 = H->u0; a.u1 = H->u1;
     } else if (m->comm) {
       a.u0 = m->u0; a.u1 = m->u1;
@@ -2232,7 +2232,7 @@ double* amg_xs0(Amg* m) { return (m && m->lv.size() > 1) ? m->lv[0].xs : nullptr
 double amg_omega(const Amg* m) { return m ? m->cfg.omega : 0.0; }
 
 int amg_apply(Amg* m, hipStream_t s, const double* r, double* z, const double* dotvec, double* partials,
-              const PcgScalars* S, const double* dotvec2, bool xs0_ready) {
+              const PcgScalars* S, const double* dotvec2, int xs0_ready) {
   if (m->lv.size() == 1) {  // single (dense) level: z = H^-1 r
     {
       Scope sc(m->prof, K_DENSE_APPLY, 8.0 * m->N * m->N);

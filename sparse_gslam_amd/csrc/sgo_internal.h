@@ -264,6 +264,8 @@ struct HaloDev {
   const int* bnd = nullptr;          // [G][bmax] boundary rows of every rank (global row numbers), -1 beyond a rank's own
   int maxrows = 0;                   // owned rows per rank (largest)
   const int* rank_row = nullptr;     // device [G + 1] first row of every rank
+  int nhalo = 0;                     // boundary rows of all OTHER ranks ...
+  const int* halo_rows = nullptr;    // ... listed: the rows whose copies this rank keeps current (a superset of what its tiles gather)
   int pemax = 0;                     // entries of P in the boundary rows, per rank (padded): set by the multigrid set-up
   const int* pent = nullptr;         // [G][pemax] their entry numbers, -1 beyond a rank's own
   double* send = nullptr;            // one packet
@@ -486,6 +488,12 @@ void launch_closure_cov(hipStream_t s, int n, const sgo_match_window* win, const
 void launch_dot(hipStream_t s, int n3, const double* a, const double* b, double* partials, const PcgScalars* S,
                 int* grid_out);
 void launch_precond_bj(hipStream_t s, int n, const double* dinv, const double* r, double* z, double scale);
+// row-owner mode: the recurrences of k_update_xr / k_update_p repeated on a LIST of rows (the copies of the neighbours'
+// boundary rows this rank keeps: same inputs, same arithmetic, hence bit-identical to the owner's values) with the
+// alpha / beta the preceding k_update_xr / k_update_p left in S
+void launch_update_xr_rows(hipStream_t s, int nrows, const int* rows, const PcgScalars* S, const double* dinv, const double* p,
+                           const double* q, double* r, double* xs, double omega);
+void launch_update_p_rows(hipStream_t s, int nrows, const int* rows, const PcgScalars* S, const double* z, double* p);
 // row-owner mode: one exchange of `width`-double records (3: rows of a vector through H.bnd; 9: entries of P through H.pent;
 // idx == nullptr, width 0: scalars only) + the scalars; returns false when the collective failed
 bool halo_exchange(const HaloDev& H, hipStream_t s, double* data, int width, const int* idx, int idx_max, const HaloScalars& sc,

@@ -1014,6 +1014,36 @@ __global__ __launch_bounds__(kBlock) void k_pose_update(int n, const int* __rest
   }
 }
 
+// ---------------------------------------------------------------------------- row-owner mode: halo-row recurrences
+__global__ __launch_bounds__(kBlock) void k_update_xr_rows(int nrows, const int* __restrict__ rows, const PcgScalars* S,
+                                                           const double* __restrict__ dinv, const double* __restrict__ p,
+                                                           const double* __restrict__ q, double* __restrict__ r,
+                                                           double* __restrict__ xs, double omega) {
+  if (S->stop) return;   // (stopped before, or this iteration's k_update_xr met a breakdown: nothing moved there either)
+  const double alpha = S->alpha;
+  for (int t = blockIdx.x * kBlock + threadIdx.x; t < nrows; t += gridDim.x * kBlock) {
+    const size_t i = (size_t)rows[t], o = 3 * i;
+    const double r0 = r[o] - alpha * q[o], r1 = r[o + 1] - alpha * q[o + 1], r2 = r[o + 2] - alpha * q[o + 2];
+    r[o] = r0; r[o + 1] = r1; r[o + 2] = r2;
+    if (xs) {
+      const double* pd = dinv + 6 * i;
+      const double z0 = pd[0] * r0 + pd[1] * r1 + pd[2] * r2;
+      const double z1 = pd[1] * r0 + pd[3] * r1 + pd[4] * r2;
+      const double z2 = pd[2] * r0 + pd[4] * r1 + pd[5] * r2;
+      xs[o] = omega * z0; xs[o + 1] = omega * z1; xs[o + 2] = omega * z2;
+    }
+  }
+}
+__global__ __launch_bounds__(kBlock) void k_update_p_rows(int nrows, const int* __restrict__ rows, const PcgScalars* S,
+                                                          const double* __restrict__ z, double* __restrict__ p) {
+  if (S->stop) return;   // (this iteration's k_update_p did not move p either)
+  const double beta = S->beta;
+  for (int t = blockIdx.x * kBlock + threadIdx.x; t < nrows; t += gridDim.x * kBlock) {
+    const size_t o = 3 * (size_t)rows[t];
+    p[o] = z[o] + beta * p[o]; p[o + 1] = z[o + 1] + beta * p[o + 1]; p[o + 2] = z[o + 2] + beta * p[o + 2];
+  }
+}
+
 // ---------------------------------------------------------------------------- row-owner exchanges
 // pack: workgroup 0 reduces the scalar partial arrays (fixed order) into the packet's head; all workgroups copy the
 // records idx[0 .. cnt) of `width` doubles each (padding entries, idx < 0, travel as zeros)
@@ -1066,6 +1096,13 @@ __global__ __launch_bounds__(kBlock) void k_slices_unpack(double* __restrict__ v
 }  // namespace
 
 // ---------------------------------------------------------------------------- launchers
+void launch_update_xr_rows(hipStream_t s, int nrows, const int* rows, const PcgScalars* S, const double* dinv, const double* p,
+                           const double* q, double* r, double* xs, double omega) {
+  if (nrows > 0) SGO_LAUNCH(k_update_xr_rows, dim3(grid_for(nrows, kBlock)), dim3(kBlock), 0, s, nrows, rows, S, dinv, p, q, r, xs, omega);
+}
+void launch_update_p_rows(hipStream_t s, int nrows, const int* rows, const PcgScalars* S, const double* z, double* p) {
+  if (nrows > 0) SGO_LAUNCH(k_update_p_rows, dim3(grid_for(nrows, kBlock)), dim3(kBlock), 0, s, nrows, rows, S, z, p);
+}
 bool halo_exchange(const HaloDev& H, hipStream_t s, double* data, int width, const int* idx, int idx_max, const HaloScalars& sc,
                    std::string* err) {
   if (!H.comm) return true;

@@ -115,6 +115,8 @@ static int start_pcg_owner(sgo_ctx* c, int grid) {
   int rc;
   if (c->amg && (rc = amg_update(c->amg, c->stream, &c->err))) return rc;
   if (c->amg && amg_comm_failed(c->amg)) return SGO_ECOMM;
+  // the block-diagonal inverse of the neighbours' boundary rows (the halo-row recurrences of the iterations apply it)
+  if (c->amg && !halo_exchange(H, c->stream, c->S0.dinv, 6, H.bnd, H.bmax, HaloScalars(), &c->err)) return SGO_ECOMM;
   if (!c->amg) {   // block-Jacobi: k_finalize left z = Dinv b, p = z and the partials of r.z
     if (!xch(c, c->d_p, scal(c->d_partials, grid, bb_parts, grid))) return SGO_ECOMM;
     Scope sc(c, K_INIT_SCALARS, 16.0 * G);
@@ -142,20 +144,26 @@ static int start_pcg_owner(sgo_ctx* c, int grid) {
       launch_warm_start(c->stream, 3 * nr, c->d_xprev + o3, c->d_q + o3, c->d_b + o3, c->d_x + o3, c->d_r + o3, H.gparts + G, G,
                         H.gparts + 2 * G, G);
     }
-    const int gz = amg_apply(c->amg, c->stream, c->d_r, c->d_z, c->d_r, c->d_zparts, nullptr, nullptr, false);
+    const int gz = amg_apply(c->amg, c->stream, c->d_r, c->d_z, c->d_r, c->d_zparts, nullptr, nullptr, 0);
     if (amg_comm_failed(c->amg)) return SGO_ECOMM;
     HIP_TRY(c, hipMemcpyAsync(c->d_p + o3, c->d_z + o3, sizeof(double) * 3 * (size_t)nr, hipMemcpyDeviceToDevice, c->stream));
     if (!xch(c, c->d_p, scal(c->d_zparts, gz))) return SGO_ECOMM;
-    Scope sc(c, K_INIT_SCALARS, 8.0 * G);
-    launch_restart_scalars(c->stream, c->d_S, H.gparts, G, maxit, 1);
+    {
+      Scope sc(c, K_INIT_SCALARS, 8.0 * G);
+      launch_restart_scalars(c->stream, c->d_S, H.gparts, G, maxit, 1);
+    }
+    if (!xch(c, c->d_r, HaloScalars())) return SGO_ECOMM;   // the halo rows' copies of r start here
     return SGO_OK;
   }
-  const int gz = amg_apply(c->amg, c->stream, c->d_r, c->d_z, c->d_r, c->d_zparts, nullptr, nullptr, true);
+  const int gz = amg_apply(c->amg, c->stream, c->d_r, c->d_z, c->d_r, c->d_zparts, nullptr, nullptr, 1);
   if (amg_comm_failed(c->amg)) return SGO_ECOMM;
   HIP_TRY(c, hipMemcpyAsync(c->d_p + o3, c->d_z + o3, sizeof(double) * 3 * (size_t)nr, hipMemcpyDeviceToDevice, c->stream));
   if (!xch(c, c->d_p, scal(c->d_zparts, gz, bb_parts, grid))) return SGO_ECOMM;
-  Scope sc(c, K_INIT_SCALARS, 16.0 * G);
-  launch_init_scalars(c->stream, c->d_S, H.gparts, G, H.gparts + G, G, tol, maxit, c->bb_ref, c->tol_cap);
+  {
+    Scope sc(c, K_INIT_SCALARS, 16.0 * G);
+    launch_init_scalars(c->stream, c->d_S, H.gparts, G, H.gparts + G, G, tol, maxit, c->bb_ref, c->tol_cap);
+  }
+  if (!xch(c, c->d_r, HaloScalars())) return SGO_ECOMM;   // the halo rows' copies of r start here
   return SGO_OK;
 }
 
@@ -278,32 +286,48 @@ int do_spmv(sgo_ctx* c, const double* x, double* y, bool dot, const PcgScalars* 
   return SGO_OK;
 }
 
-// One PCG iteration in row-owner mode: five small exchanges (p.q | xs + r.r | xs after the coarse correction | r.z, z.q |
-// p) and the all-reduce of the coarse right-hand side; all vector work on the owned rows.
+// One PCG iteration in row-owner mode: three exchanges -- q's boundary with the partial sums of p.q | xs's boundary after
+// the coarse correction | z's boundary with the partial sums of r.z, r.r, z.q -- and the all-reduce of the coarse
+// right-hand side; all vector work on the owned rows.  The copies of the neighbours' boundary rows ("halo rows") of r, xs
+// and p are kept current by repeating the recurrences on them (k_update_*_rows: same inputs, same arithmetic as the
+// owner's: bit-identical), which is what saves the exchanges of xs and p.
 static int pcg_iteration_owner(sgo_ctx* c) {
   const HaloDev& H = c->halo;
   const int G = H.G, nr = H.row1 - H.row0;
   const size_t o3 = 3 * (size_t)H.row0;
   int g1 = 0, g2 = 0, rc;
   if ((rc = do_spmv(c, c->d_p, c->d_q, true, c->d_S, &g1))) return rc;
-  if (!xch(c, nullptr, scal(c->d_partials, g1))) return SGO_ECOMM;
   double* parts2 = c->d_partials + kMaxPartials;  // [0] = r.z (block-Jacobi only), [1] = r.r
-  {
-    Scope sc(c, K_UPDATE_XR, (7 * 24.0 + 48.0) * nr);
-    launch_update_xr(c->stream, nr, c->d_S, H.gparts, G, c->S0.dinv + 6 * (size_t)H.row0, c->d_p + o3, c->d_q + o3, c->d_x + o3,
-                     c->d_r + o3, c->d_z + o3, c->amg ? amg_xs0(c->amg) + o3 : nullptr, c->amg ? amg_omega(c->amg) : 0.0, parts2, &g2);
-  }
   if (c->amg) {
-    const int gz = amg_apply(c->amg, c->stream, c->d_r, c->d_z, c->d_r, c->d_zparts, c->d_S, c->d_q, true);
+    if (!xch(c, c->d_q, scal(c->d_partials, g1))) return SGO_ECOMM;
+    {
+      Scope sc(c, K_UPDATE_XR, (7 * 24.0 + 48.0) * nr);
+      launch_update_xr(c->stream, nr, c->d_S, H.gparts, G, c->S0.dinv + 6 * (size_t)H.row0, c->d_p + o3, c->d_q + o3, c->d_x + o3,
+                       c->d_r + o3, c->d_z + o3, amg_xs0(c->amg) + o3, amg_omega(c->amg), parts2, &g2);
+    }
+    launch_update_xr_rows(c->stream, H.nhalo, H.halo_rows, c->d_S, c->S0.dinv, c->d_p, c->d_q, c->d_r, amg_xs0(c->amg), amg_omega(c->amg));
+    const int gz = amg_apply(c->amg, c->stream, c->d_r, c->d_z, c->d_r, c->d_zparts, c->d_S, c->d_q, 2);
     if (amg_comm_failed(c->amg)) {
       c->err = "collective failed inside the multigrid cycle";
       return SGO_ECOMM;
     }
-    if (!xch(c, nullptr, scal(c->d_zparts, gz, parts2 + kMaxPartials, g2, c->d_zparts + kMaxPartials, gz))) return SGO_ECOMM;
-    Scope sc(c, K_UPDATE_P, 3 * 24.0 * nr);
-    launch_update_p(c->stream, nr, c->d_S, H.gparts, G, H.gparts + G, G, H.gparts + 2 * G, c->d_z + o3, c->d_p + o3);
-  } else {
-    if (!xch(c, nullptr, scal(parts2, g2, parts2 + kMaxPartials, g2))) return SGO_ECOMM;
+    if (!xch(c, c->d_z, scal(c->d_zparts, gz, parts2 + kMaxPartials, g2, c->d_zparts + kMaxPartials, gz))) return SGO_ECOMM;
+    {
+      Scope sc(c, K_UPDATE_P, 3 * 24.0 * nr);
+      launch_update_p(c->stream, nr, c->d_S, H.gparts, G, H.gparts + G, G, H.gparts + 2 * G, c->d_z + o3, c->d_p + o3);
+    }
+    launch_update_p_rows(c->stream, H.nhalo, H.halo_rows, c->d_S, c->d_z, c->d_p);
+    return SGO_OK;
+  }
+  // block-Jacobi: p.q | r.z, r.r | p
+  if (!xch(c, nullptr, scal(c->d_partials, g1))) return SGO_ECOMM;
+  {
+    Scope sc(c, K_UPDATE_XR, (7 * 24.0 + 48.0) * nr);
+    launch_update_xr(c->stream, nr, c->d_S, H.gparts, G, c->S0.dinv + 6 * (size_t)H.row0, c->d_p + o3, c->d_q + o3, c->d_x + o3,
+                     c->d_r + o3, c->d_z + o3, nullptr, 0.0, parts2, &g2);
+  }
+  if (!xch(c, nullptr, scal(parts2, g2, parts2 + kMaxPartials, g2))) return SGO_ECOMM;
+  {
     Scope sc(c, K_UPDATE_P, 3 * 24.0 * nr);
     launch_update_p(c->stream, nr, c->d_S, H.gparts, G, H.gparts + G, G, nullptr, c->d_z + o3, c->d_p + o3);
   }

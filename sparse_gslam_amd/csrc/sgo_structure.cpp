@@ -573,10 +573,17 @@ int build_structure(sgo_ctx* c, int V, const double* poses, const uint8_t* fixed
       H.bmax = HH.bmax;
       H.maxrows = maxrows;
       H.failed = &c->halo_failed;
-      int *d_bnd = nullptr, *d_rr = nullptr;
-      if ((rc = upload(c, &d_bnd, HH.bnd)) || (rc = upload(c, &d_rr, HH.rank_row))) return rc;
+      int *d_bnd = nullptr, *d_rr = nullptr, *d_hr = nullptr;
+      std::vector<int> others;
+      for (int q = 0; q < G; ++q)
+        if (q != HH.me) others.insert(others.end(), lists[q].begin(), lists[q].end());
+      H.nhalo = (int)others.size();
+      if (others.empty()) others.push_back(0);
+      if ((rc = upload(c, &d_bnd, HH.bnd)) || (rc = upload(c, &d_rr, HH.rank_row)) || (rc = upload(c, &d_hr, others))) return rc;
+      HIP_TRY(c, hipStreamSynchronize(c->stream));   // `others` is a local
       H.bnd = d_bnd;
       H.rank_row = d_rr;
+      H.halo_rows = d_hr;
       if ((rc = dalloc(c, &H.gparts, (size_t)kHaloScalars * G))) return rc;
       HIP_TRY(c, hipMemsetAsync(H.gparts, 0, sizeof(double) * kHaloScalars * G, c->stream));
       if ((rc = halo_reserve(c, std::max<size_t>((size_t)kHaloScalars + 3 * (size_t)HH.bmax, 9 * (size_t)maxrows)))) return rc;
