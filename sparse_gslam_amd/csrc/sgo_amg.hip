@@ -174,10 +174,12 @@ struct PDev {
   // The two streamed copies are indexed by GLOBAL entry / position numbers; in multi-GPU row-owner mode (level 0) they hold
   // this rank's rows' entries only: allocated for the rank's range, base pointers shifted, pair strides r_n / t_n and
   // component-8 base pointers of their own (as Sym0Dev::ublk).
-  int r_n = 0;               // pair stride of r_blk (= np; the rank's entries in row-owner mode)
-  double* r_blk = nullptr;   // pair-SoA (blk_at): the copy the prolongation STREAMS (row order,
+  // They are fp32 (the transfers are inside the preconditioner; the Galerkin products gather the fp64 records of blk):
+  // quads (0..3), (4..7) as two float4 per entry + component 8, i.e. two 16-byte loads and one 4-byte load per lane.
+  int r_n = 0;               // quad stride of r_blk (= np; the rank's entries in row-owner mode)
+  float* r_blk = nullptr;    // quad-SoA: the copy the prolongation STREAMS (row order,
                              // non-temporal loads: read once per cycle, must not push the level-0 matrix out of the MALL)
-  double* r_blk8 = nullptr;
+  float* r_blk8 = nullptr;
   int* r_grp = nullptr;      // wave groups over the entries aligned to fine rows (prolongation)
   int r_ngrp = 0;
   ProdMap val;               // a = fine slot k = (i, j), tgt = entry (i, agg(j))
@@ -186,9 +188,9 @@ struct PDev {
   int* t_pos = nullptr;      // [np] position of entry e in column order
   int* t_row = nullptr;      // [np] fine row at position t
   int* t_col = nullptr;      // [np] coarse column at position t
-  int t_n = 0;               // entries in the column-ordered copy = its pair stride (= np; the rank's rows' entries in row-owner mode)
-  double* t_blk = nullptr;   // pair-SoA: column order, streamed by the restriction (non-temporal loads)
-  double* t_blk8 = nullptr;
+  int t_n = 0;               // entries in the column-ordered copy = its quad stride (= np; the rank's rows' entries in row-owner mode)
+  float* t_blk = nullptr;    // quad-SoA: column order, streamed by the restriction (non-temporal loads)
+  float* t_blk8 = nullptr;
   int* t_grp = nullptr;      // wave groups over the positions aligned to columns
   int t_ngrp = 0;
   int* t_long = nullptr;     // [t_nlong][2] position ranges of the columns longer than kLongColumn entries (the last level of a
@@ -202,26 +204,26 @@ struct PDev {
                              // any are not visited: the caller zeroes the coarse blocks first)
 };
 
-// block e of a pair-SoA array (blk_at) that is read once per cycle: four 16-byte and one 8-byte non-temporal
-// loads per lane (the stream must not push the level-0 matrix out of the Infinity Cache)
+// entry e of a streamed fp32 copy of P (quad-SoA): two 16-byte loads and one 4-byte load per lane; non-temporal on the
+// large levels (read once per cycle: the stream must not push the level-0 matrix out of the Infinity Cache)
 typedef double sgo_d2 __attribute__((ext_vector_type(2)));
+typedef float sgo_f4 __attribute__((ext_vector_type(4)));
 constexpr int kLongColumn = 512;   // entries of a P column from which a workgroup instead of a wave restricts it
-__device__ __forceinline__ void load9_stream(const double* __restrict__ base, const double* __restrict__ base8, size_t e, size_t n, double (&v)[9]) {
-  const sgo_d2* __restrict__ bp = reinterpret_cast<const sgo_d2*>(base);
-  const sgo_d2 p0 = __builtin_nontemporal_load(bp + e), p1 = __builtin_nontemporal_load(bp + n + e);
-  const sgo_d2 p2 = __builtin_nontemporal_load(bp + 2 * n + e), p3 = __builtin_nontemporal_load(bp + 3 * n + e);
-  v[0] = p0.x; v[1] = p0.y; v[2] = p1.x; v[3] = p1.y; v[4] = p2.x; v[5] = p2.y; v[6] = p3.x; v[7] = p3.y;
-  v[8] = __builtin_nontemporal_load(base8 + e);
-}
-__device__ __forceinline__ void load9_pairs(const double* __restrict__ base, const double* __restrict__ base8, size_t e, size_t n, double (&v)[9], bool nt) {
+__device__ __forceinline__ void load9_pairs(const float* __restrict__ base, const float* __restrict__ base8, size_t e, size_t n,
+                                            double (&v)[9], bool nt) {
+  const sgo_f4* __restrict__ bp = reinterpret_cast<const sgo_f4*>(base);
+  sgo_f4 q0, q1;
+  float f8;
   if (nt) {
-    load9_stream(base, base8, e, n, v);
-    return;
+    q0 = __builtin_nontemporal_load(bp + e);
+    q1 = __builtin_nontemporal_load(bp + n + e);
+    f8 = __builtin_nontemporal_load(base8 + e);
+  } else {
+    q0 = bp[e];
+    q1 = bp[n + e];
+    f8 = base8[e];
   }
-  const sgo_d2* __restrict__ bp = reinterpret_cast<const sgo_d2*>(base);
-  const sgo_d2 p0 = bp[e], p1 = bp[n + e], p2 = bp[2 * n + e], p3 = bp[3 * n + e];
-  v[0] = p0.x; v[1] = p0.y; v[2] = p1.x; v[3] = p1.y; v[4] = p2.x; v[5] = p2.y; v[6] = p3.x; v[7] = p3.y;
-  v[8] = base8[e];
+  v[0] = q0.x; v[1] = q0.y; v[2] = q0.z; v[3] = q0.w; v[4] = q1.x; v[5] = q1.y; v[6] = q1.z; v[7] = q1.w; v[8] = f8;
 }
 __device__ __forceinline__ void load9(const double* __restrict__ base, size_t e, double (&v)[9]) {
 #pragma unroll
@@ -277,13 +279,17 @@ __global__ __launch_bounds__(kBlock) void k_p_values(BsrDev F, PDev P, const int
       const size_t tp = (size_t)P.t_pos[key];
 #pragma unroll
       for (int c = 0; c < 9; ++c) P.blk[9 * (size_t)key + c] = o[c];
-#pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        P.r_blk[blk_at(c, key, (size_t)P.r_n)] = o[c];
-        P.t_blk[blk_at(c, tp, (size_t)P.t_n)] = o[c];
+      {
+        const sgo_f4 q0 = {(float)o[0], (float)o[1], (float)o[2], (float)o[3]}, q1 = {(float)o[4], (float)o[5], (float)o[6], (float)o[7]};
+        sgo_f4* rq = reinterpret_cast<sgo_f4*>(P.r_blk);
+        sgo_f4* tq = reinterpret_cast<sgo_f4*>(P.t_blk);
+        rq[key] = q0;
+        rq[(size_t)P.r_n + key] = q1;
+        tq[tp] = q0;
+        tq[(size_t)P.t_n + tp] = q1;
+        P.r_blk8[key] = (float)o[8];
+        P.t_blk8[tp] = (float)o[8];
       }
-      P.r_blk8[key] = o[8];
-      P.t_blk8[tp] = o[8];
     }
   }
 }
@@ -1996,7 +2002,9 @@ int cycle(Amg* m, hipStream_t s, int l, const double* rhs, const double* rhs_sub
       hipMemsetAsync(L.rs, 0, sizeof(double) * 3 * (size_t)L.A.n, s);
     }
     if (!(H || m->comm) || a.u1 > a.u0) {
-      Scope sc(m->prof, m->T0.ntile > 0 ? K_SPMV0T_RESID : K_SPMV0_RESID, 76.0 * m->S0.npairs + 120.0 * m->S0.n);
+      const bool f32 = m->T0.ntile > 0 && m->S0.fblk != nullptr;   // (fp32 copy of the blocks: 36 + 4 B per pair)
+      Scope sc(m->prof, m->T0.ntile > 0 ? (f32 ? K_SPMV0T_RESID_F32 : K_SPMV0T_RESID) : K_SPMV0_RESID,
+               ((f32 ? 40.0 : 76.0) * m->S0.npairs + 120.0 * m->S0.n) / (H ? H->G : 1));
       launch_spmv0_any(s, m->S0, m->T0, S0_RESID, a);
     }
     // multi-GPU: the residual stays a per-rank partial (this rank's rows); the restriction below takes only those
@@ -2028,7 +2036,7 @@ int cycle(Amg* m, hipStream_t s, int l, const double* rhs, const double* rhs_sub
   }
   if (H && L.smoothed && L.P.local_lists) hipMemsetAsync(C.bk, 0, sizeof(double) * 3 * (size_t)C.A.n, s);   // coarse rows none of this rank's rows reaches
   if (L.smoothed) {
-    Scope sc(m->prof, l == 0 ? K_RESTRICT_P0 : K_RESTRICT_P, 84.0 * L.P.t_n + 24.0 * L.A.n + 24.0 * L.nc);
+    Scope sc(m->prof, l == 0 ? K_RESTRICT_P0 : K_RESTRICT_P, 44.0 * L.P.t_n + 24.0 * L.A.n + 24.0 * L.nc);
     launch_restrict_p(s, L.P, res, C.bk, S, frow0, frow1);
   } else {
     Scope sc(m->prof, l == 0 ? K_RESTRICT0 : K_RESTRICT, 40.0 * L.A.n + 24.0 * L.nc);
@@ -2062,7 +2070,7 @@ int cycle(Amg* m, hipStream_t s, int l, const double* rhs, const double* rhs_sub
   }
   if (l == 0) {   // prolongation, then the post-smoothing sweep on the symmetric storage
     if (L.smoothed) {
-      Scope sc(m->prof, K_PROLONG_P0, 80.0 * L.P.r_n + 52.0 * L.A.n);
+      Scope sc(m->prof, K_PROLONG_P0, 44.0 * L.P.r_n + 52.0 * L.A.n);
       SGO_LAUNCH(k_prolong_p, dim3(grid_for(L.P.r_ngrp, kWavesPerBlock)), dim3(kBlock), 0, s, L.A.n, L.P, cs.u1, cs.c1, cs.u2, cs.c2,
                  L.xs, S, (const double*)nullptr, H ? H->row0 : 0, H ? H->row1 : 0);
     } else {
@@ -2083,7 +2091,7 @@ int cycle(Amg* m, hipStream_t s, int l, const double* rhs, const double* rhs_sub
       std::string e;
       if (!halo_exchange(*H, s, L.xs, 3, H->bnd, H->bmax, HaloScalars(), &e)) m->comm_failed = true;
       b.u0 = H->u0; b.u1 = H->u1;
-      Scope sc(m->prof, m->T0.ntile > 0 ? K_SPMV0T_JACOBI : K_SPMV0_JACOBI, (76.0 * m->S0.npairs + 168.0 * m->S0.n) / H->G);
+      Scope sc(m->prof, m->S0.fblk ? K_SPMV0T_JACOBI_F32 : K_SPMV0T_JACOBI, ((m->S0.fblk ? 40.0 : 76.0) * m->S0.npairs + 168.0 * m->S0.n) / H->G);
       return launch_spmv0_any(s, m->S0, m->T0, S0_JACOBI, b);
     }
     if (m->comm) {
@@ -2103,7 +2111,8 @@ int cycle(Amg* m, hipStream_t s, int l, const double* rhs, const double* rhs_sub
       SGO_LAUNCH(k_dots2, dim3(grid), dim3(kBlock), 0, s, 3 * L.A.n, (const double*)out, dotvec, dotvec2, dotparts, S);
       return grid;
     }
-    Scope sc(m->prof, m->T0.ntile > 0 ? K_SPMV0T_JACOBI : K_SPMV0_JACOBI, 76.0 * m->S0.npairs + 168.0 * m->S0.n);
+    const bool f32 = m->T0.ntile > 0 && m->S0.fblk != nullptr;
+    Scope sc(m->prof, m->T0.ntile > 0 ? (f32 ? K_SPMV0T_JACOBI_F32 : K_SPMV0T_JACOBI) : K_SPMV0_JACOBI, (f32 ? 40.0 : 76.0) * m->S0.npairs + 168.0 * m->S0.n);
     return launch_spmv0_any(s, m->S0, m->T0, S0_JACOBI, b);
   }
   if (L.smoothed) {
@@ -2492,10 +2501,10 @@ Amg* amg_create(hipStream_t s, const BsrDev& A0, const Sym0Dev& S0, const Tile0D
       P.t_col = dev_upload(m->pool, own ? t_col_l : sa.t_col, s);
       P.r_n = P.t_n = (int)npl;
       {
-        double* rb = dev_alloc<double>(m->pool, 9 * npl);
-        double* tb = dev_alloc<double>(m->pool, 9 * npl);
+        float* rb = dev_alloc<float>(m->pool, 9 * npl + 4);
+        float* tb = dev_alloc<float>(m->pool, 9 * npl + 4);
         if (!rb || !tb) return fail("amg_create: out of device memory");
-        P.r_blk = rb - 2 * E0;            // row order, addressed by global entry numbers
+        P.r_blk = rb - 4 * E0;            // row order, addressed by global entry numbers
         P.r_blk8 = rb + 8 * npl - E0;
         P.t_blk = tb;                     // column order, addressed by the rank's own positions
         P.t_blk8 = tb + 8 * npl;
@@ -2554,7 +2563,7 @@ Amg* amg_create(hipStream_t s, const BsrDev& A0, const Sym0Dev& S0, const Tile0D
           (!sa.lists_on_device && (!P.ap.a || !P.ap.b || !P.ap.tgt || !P.ap.grp || !P.rap.a || !P.rap.b || !P.rap.tgt || !P.rap.grp)))
         return fail("amg_create: out of device memory");
       if (own && hipStreamSynchronize(s) != hipSuccess) return fail("amg_create: upload failed");   // (the rank-local host lists die with this scope)
-      if (l == 0) m->level0_bytes += (long long)(72 * (size_t)P.np + 144 * npl + 72 * (F1 - F0) + 8 * (V1 - V0) + 12 * npl + 8 * (F1 - F0));
+      if (l == 0) m->level0_bytes += (long long)(72 * (size_t)P.np + 72 * npl + 72 * (F1 - F0) + 8 * (V1 - V0) + 12 * npl + 8 * (F1 - F0));
       l0_own = {own, (int)F0, (int)F1};
       l0_dev = {d_ap_rowptr, d_ap_col, d_ap_row, d_t_ptr, d_t_idx};
       if (l == 0 && halo) {

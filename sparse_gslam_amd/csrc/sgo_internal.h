@@ -103,6 +103,12 @@ struct Sym0Dev {
   int nus = 0;                   // pair stride of ublk: stored blocks held by this rank (= nu on one GPU)
   double* ublk = nullptr;        // pair-SoA, components 0..7
   double* ublk8 = nullptr;       // component 8
+  // fp32 copy of the stored blocks for the PRECONDITIONER's two level-0 passes (residual pass and post-smoothing sweep of
+  // the multigrid cycle; H p of the CG recurrence, residuals and results stay fp64: SURVEY.md section 7 names this
+  // mitigation): components (0..3), (4..7) as two float4 per block -- 16-byte loads per lane as the fp64 pairs -- and
+  // component 8; same numbering, stride and shifting as ublk.  nullptr: the passes read ublk (env SGO_PRECOND_F32=0).
+  float* fblk = nullptr;         // quad-SoA: quad q of block u at fblk + 4 (q nus + u)
+  float* fblk8 = nullptr;
   double* dblk = nullptr;        // [n][6]
   double* dinv = nullptr;        // [n][6]
 };
@@ -237,6 +243,7 @@ struct Spmv0Args {
   double* partials = nullptr;    // [2][kMaxPartials]
   const PcgScalars* S = nullptr; // optional early-out flag
   long long* dbg_stamps = nullptr;   // diagnostic builds: [ntile][8] s_memtime stamps of the tile kernel's phases
+  bool force_f64 = false;        // RESID / JACOBI on the fp64 blocks although an fp32 copy exists (measurements)
   int u0 = 0, u1 = 0;            // multi-GPU: only the work units [u0, u1) -- tiles (k_spmv0t) or wave groups (k_spmv0) --
                                  // are evaluated, i.e. only their rows of y are written (u1 == 0: all)
 };
@@ -326,6 +333,8 @@ enum KernelId : int {
   // the transfer / set-up kernels' launches on the FINEST level in slots of their own ("<kernel> @level0"): these are the
   // ones a rank of a multi-GPU run evaluates for its own rows only; the same kernels' coarse-level launches stay in the
   // plain slots
+  K_SPMV0T_RESID_F32,   // the preconditioner's two level-0 passes on the fp32 copy of the blocks
+  K_SPMV0T_JACOBI_F32,
   K_RESTRICT_P0,
   K_PROLONG_P0,
   K_SA_P0,

@@ -34,8 +34,8 @@ const char* const kKernelNames[K_COUNT] = {
     "k_pose_update", "k_positions0", "k_centres",   "k_galerkin",   "k_level_dinv",   "k_restrict", "k_prolong_add",
     "k_gj_step (dense inverse, all block steps)", "k_dense_apply", "k_p_values", "k_block_products<1, 0, 0>",
     "k_block_products<0, 1, 1>", "k_restrict_p", "k_prolong_p", "k_spmv<7>",
-    "k_spmv0<0>", "k_spmv0<1>", "k_spmv0<2>", "k_spmv0t<0, 1024>", "k_spmv0t<1, 1024>", "k_spmv0t<2, 1024>",
-    "k_direct", "k_restrict_p @level0", "k_prolong_p @level0", "k_p_values @level0", "k_block_products<1, 0, 0> @level0",
+    "k_spmv0<0>", "k_spmv0<1>", "k_spmv0<2>", "k_spmv0t<0, 1024, 0>", "k_spmv0t<1, 1024, 0>", "k_spmv0t<2, 1024, 0>",
+    "k_direct", "k_spmv0t<1, 1024, 1>", "k_spmv0t<2, 1024, 1>", "k_restrict_p @level0", "k_prolong_p @level0", "k_p_values @level0", "k_block_products<1, 0, 0> @level0",
     "k_block_products<0, 1, 1> @level0", "k_galerkin @level0", "k_restrict @level0", "k_prolong_add @level0"};
 
 namespace {
@@ -283,7 +283,16 @@ __global__ __launch_bounds__(kBlock) void k_linearize(Sym0Dev A, int g0, int g1,
         bp[nu + idx] = make_double2(T00 * C02 + T10 * C12 + T20 * C22, T01 * C00 + T11 * C10);
         bp[2 * nu + idx] = make_double2(T01 * C01 + T11 * C11, T01 * C02 + T11 * C12 + T21 * C22);
         bp[3 * nu + idx] = make_double2(T02 * C00 + T12 * C10, T02 * C01 + T12 * C11);
-        A.ublk8[idx] = T02 * C02 + T12 * C12 + T22 * C22;
+        const double b8 = T02 * C02 + T12 * C12 + T22 * C22;
+        A.ublk8[idx] = b8;
+        if (A.fblk) {   // fp32 copy for the preconditioner's passes
+          float4* __restrict__ fp = reinterpret_cast<float4*>(A.fblk);
+          fp[idx] = make_float4((float)(T00 * C00 + T10 * C10), (float)(T00 * C01 + T10 * C11),
+                                (float)(T00 * C02 + T10 * C12 + T20 * C22), (float)(T01 * C00 + T11 * C10));
+          fp[nu + idx] = make_float4((float)(T01 * C01 + T11 * C11), (float)(T01 * C02 + T11 * C12 + T21 * C22),
+                                     (float)(T02 * C00 + T12 * C10), (float)(T02 * C01 + T12 * C11));
+          A.fblk8[idx] = (float)b8;
+        }
       }
     }
     seg_scan<9>(row, acc, lane);
@@ -645,16 +654,43 @@ __global__ __launch_bounds__(kBlock, 8) void k_spmv0(Sym0Dev A, Spmv0Args a) {
 // contributions of intra-tile pairs travel through LDS staging.  Modes and epilogues as k_spmv0.  One
 // workgroup works on one tile at a time; workgroups of XCD x walk the x-th contiguous eighth of the tiles.
 // one wave's loads for the first 64 slots of a phase-1 group, issued a whole group ahead of their use
+// a stored block as it comes from memory: fp64 pair-SoA (four 16-byte loads + one 8-byte load) or the fp32 copy of the
+// preconditioner's passes (two 16-byte loads + one 4-byte load)
+template <bool F32> struct TileBlk;
+template <> struct TileBlk<false> {
+  double2 p0, p1, p2, p3;
+  double b8;
+  __device__ __forceinline__ void load(const Sym0Dev& A, size_t nu, int k) {
+    const double2* __restrict__ bp = reinterpret_cast<const double2*>(A.ublk);
+    p0 = bp[k]; p1 = bp[nu + k]; p2 = bp[2 * nu + k]; p3 = bp[3 * nu + k];
+    b8 = A.ublk8[k];
+  }
+  __device__ __forceinline__ void get(double (&b)[9]) const {
+    b[0] = p0.x; b[1] = p0.y; b[2] = p1.x; b[3] = p1.y; b[4] = p2.x; b[5] = p2.y; b[6] = p3.x; b[7] = p3.y; b[8] = b8;
+  }
+};
+template <> struct TileBlk<true> {
+  float4 q0, q1;
+  float b8;
+  __device__ __forceinline__ void load(const Sym0Dev& A, size_t nu, int k) {
+    const float4* __restrict__ fp = reinterpret_cast<const float4*>(A.fblk);
+    q0 = fp[k]; q1 = fp[nu + k];
+    b8 = A.fblk8[k];
+  }
+  __device__ __forceinline__ void get(double (&b)[9]) const {
+    b[0] = q0.x; b[1] = q0.y; b[2] = q0.z; b[3] = q0.w; b[4] = q1.x; b[5] = q1.y; b[6] = q1.z; b[7] = q1.w; b[8] = b8;
+  }
+};
+template <bool F32>
 struct TileGroupLoad {
   int gb, ge, r0;
   bool valid;
   unsigned cw;
   int off;
-  double2 p0, p1, p2, p3;
-  double b8;
+  TileBlk<F32> blk;
 };
-__device__ __forceinline__ void tile_group_load(const Sym0Dev& A, const Tile0Dev& TL, const double2* __restrict__ bp, size_t nu,
-                                                int g, int lane, TileGroupLoad& L) {
+template <bool F32>
+__device__ __forceinline__ void tile_group_load(const Sym0Dev& A, const Tile0Dev& TL, size_t nu, int g, int lane, TileGroupLoad<F32>& L) {
   L.gb = TL.grp1[g];
   L.ge = TL.grp1[g + 1];
   L.r0 = TL.grow1[g];
@@ -663,31 +699,29 @@ __device__ __forceinline__ void tile_group_load(const Sym0Dev& A, const Tile0Dev
   if (L.valid) {
     L.cw = TL.cv[k];
     L.off = TL.off1[k];
-    L.p0 = bp[k]; L.p1 = bp[nu + k]; L.p2 = bp[2 * nu + k]; L.p3 = bp[3 * nu + k];
-    L.b8 = A.ublk8[k];
+    L.blk.load(A, nu, k);
   }
 }
 // u = B x_col into acc, v = B^T x_row to the twin's staging slot
 __device__ __forceinline__ void tile_slot(const double* __restrict__ xs, double* __restrict__ vst, int rowl, unsigned cw,
-                                          const double2& p0, const double2& p1, const double2& p2, const double2& p3, double b8,
-                                          double (&acc)[3]) {
+                                          const double (&b)[9], double (&acc)[3]) {
   const double* xc = xs + 3 * (cw & 0xFFFFu);
   const double x0 = xc[0], x1 = xc[1], x2 = xc[2];
-  acc[0] += p0.x * x0 + p0.y * x1 + p1.x * x2;
-  acc[1] += p1.y * x0 + p2.x * x1 + p2.y * x2;
-  acc[2] += p3.x * x0 + p3.y * x1 + b8 * x2;
+  acc[0] += b[0] * x0 + b[1] * x1 + b[2] * x2;
+  acc[1] += b[3] * x0 + b[4] * x1 + b[5] * x2;
+  acc[2] += b[6] * x0 + b[7] * x1 + b[8] * x2;
   const unsigned vp = cw >> 16;
   if (vp != 0xFFFFu) {   // the twin row is in this tile: hand it B^T x_row through LDS
     const double* xr = xs + 3 * rowl;
     const double s0 = xr[0], s1 = xr[1], s2 = xr[2];
     double* v = vst + 3 * vp;
-    v[0] = p0.x * s0 + p1.y * s1 + p3.x * s2;
-    v[1] = p0.y * s0 + p2.x * s1 + p3.y * s2;
-    v[2] = p1.x * s0 + p2.y * s1 + b8 * s2;
+    v[0] = b[0] * s0 + b[3] * s1 + b[6] * s2;
+    v[1] = b[1] * s0 + b[4] * s1 + b[7] * s2;
+    v[2] = b[2] * s0 + b[5] * s1 + b[8] * s2;
   }
 }
 
-template <int MODE, int kTileThreads>
+template <int MODE, int kTileThreads, bool F32 = false>
 __global__ __launch_bounds__(kTileThreads) void k_spmv0t(Sym0Dev A, Tile0Dev TL, Spmv0Args a) {
   // the stop flag, the tile descriptor and the tile's first halo column numbers are requested together (none of their
   // addresses depends on another's value): phase 0 is a chain of two memory round trips instead of four
@@ -698,7 +732,6 @@ __global__ __launch_bounds__(kTileThreads) void k_spmv0t(Sym0Dev A, Tile0Dev TL,
   constexpr int NW = kTileThreads / 64;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const size_t nu = (size_t)A.nus;
-  const double2* __restrict__ bp = reinterpret_cast<const double2*>(A.ublk);
   double dotacc[2] = {0.0, 0.0};
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
   const int ulo = a.u1 > 0 ? a.u0 : 0, nun = (a.u1 > 0 ? a.u1 : TL.ntile) - ulo;
@@ -726,9 +759,9 @@ __global__ __launch_bounds__(kTileThreads) void k_spmv0t(Sym0Dev A, Tile0Dev TL,
     if (tid == 0) *next_group = T.g0 + NW;   // groups are handed out through an LDS counter (the first NW statically)
     int g = T.g0 + wave;
     bool has = g < T.g1;
-    TileGroupLoad cur;
+    TileGroupLoad<F32> cur;
     cur.valid = false;
-    if (has) tile_group_load(A, TL, bp, nu, g, lane, cur);
+    if (has) tile_group_load<F32>(A, TL, nu, g, lane, cur);
     int e0 = 0, e1 = 0;
     double dd0 = 0, dd1 = 0, dd2 = 0, dd3 = 0, dd4 = 0, dd5 = 0;
     if (tid < nr) {
@@ -773,21 +806,25 @@ __global__ __launch_bounds__(kTileThreads) void k_spmv0t(Sym0Dev A, Tile0Dev TL,
       if (lane == 0) gn = atomicAdd(next_group, 1);
       gn = __builtin_amdgcn_readfirstlane(gn);
       const bool hasn = gn < T.g1;
-      TileGroupLoad nxt;
+      TileGroupLoad<F32> nxt;
       nxt.valid = false;
-      if (hasn) tile_group_load(A, TL, bp, nu, gn, lane, nxt);
+      if (hasn) tile_group_load<F32>(A, TL, nu, gn, lane, nxt);
       double acc[3] = {0.0, 0.0, 0.0};
       int row = -1 - lane;
       if (cur.valid) {
         row = cur.r0 + cur.off;
-        tile_slot(xs, vst, row - T.row0, cur.cw, cur.p0, cur.p1, cur.p2, cur.p3, cur.b8, acc);
+        double b[9];
+        cur.blk.get(b);
+        tile_slot(xs, vst, row - T.row0, cur.cw, b, acc);
       }
       for (int k = cur.gb + 64 + lane; k < cur.ge; k += 64) {   // a row longer than one wave
         const unsigned cw = TL.cv[k];
         row = cur.r0 + TL.off1[k];
-        const double2 p0 = bp[k], p1 = bp[nu + k], p2 = bp[2 * nu + k], p3 = bp[3 * nu + k];
-        const double b8 = A.ublk8[k];
-        tile_slot(xs, vst, row - T.row0, cw, p0, p1, p2, p3, b8, acc);
+        TileBlk<F32> bl;
+        bl.load(A, nu, k);
+        double b[9];
+        bl.get(b);
+        tile_slot(xs, vst, row - T.row0, cw, b, acc);
       }
       seg_scan<3>(row, acc, lane);
       const int rn = __shfl_down(row, 1);
@@ -1217,16 +1254,16 @@ int launch_spmv0(hipStream_t s, const Sym0Dev& A, int mode, const Spmv0Args& a) 
   }
   return grid;
 }
-template <int MODE, int NT>
+template <int MODE, int NT, bool F32>
 void launch_spmv0t_inst(hipStream_t s, const Sym0Dev& A, const Tile0Dev& T, const Spmv0Args& a, int grid) {
   static int lds_allowed = 0;   // dynamic LDS beyond 64 KB needs the attribute once per kernel
   if (T.lds_bytes > 65536 && T.lds_bytes > lds_allowed) {
     constexpr int kDynMax = 160 * 1024 - 2048;   // the kernel's static LDS (scalars, dot partials) comes on top
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spmv0t<MODE, NT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spmv0t<MODE, NT, F32>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             kDynMax) == hipSuccess)
       lds_allowed = kDynMax;
   }
-  SGO_LAUNCH((k_spmv0t<MODE, NT>), dim3(grid), dim3(NT), (size_t)T.lds_bytes, s, A, T, a);
+  SGO_LAUNCH((k_spmv0t<MODE, NT, F32>), dim3(grid), dim3(NT), (size_t)T.lds_bytes, s, A, T, a);
 }
 int launch_spmv0t(hipStream_t s, const Sym0Dev& A, const Tile0Dev& T, int mode, const Spmv0Args& a) {
   // as many tile workgroups as fit the CUs' LDS are resident; more tiles are walked in a loop
@@ -1234,10 +1271,18 @@ int launch_spmv0t(hipStream_t s, const Sym0Dev& A, const Tile0Dev& T, int mode, 
   long long g = std::min<long long>(T.ntile, 256LL * per_cu);
   if (g < 8) g = 8;
   const int grid = (int)((g + 7) / 8 * 8);
+  // the preconditioner's two passes read the fp32 copy of the blocks when there is one; H p always the fp64 blocks
+  const bool f32 = A.fblk != nullptr && !a.force_f64;
   switch (mode) {
-    case S0_AX: launch_spmv0t_inst<S0_AX, 1024>(s, A, T, a, grid); break;
-    case S0_RESID: launch_spmv0t_inst<S0_RESID, 1024>(s, A, T, a, grid); break;
-    default: launch_spmv0t_inst<S0_JACOBI, 1024>(s, A, T, a, grid); break;
+    case S0_AX: launch_spmv0t_inst<S0_AX, 1024, false>(s, A, T, a, grid); break;
+    case S0_RESID:
+      if (f32) launch_spmv0t_inst<S0_RESID, 1024, true>(s, A, T, a, grid);
+      else launch_spmv0t_inst<S0_RESID, 1024, false>(s, A, T, a, grid);
+      break;
+    default:
+      if (f32) launch_spmv0t_inst<S0_JACOBI, 1024, true>(s, A, T, a, grid);
+      else launch_spmv0t_inst<S0_JACOBI, 1024, false>(s, A, T, a, grid);
+      break;
   }
   return grid;
 }

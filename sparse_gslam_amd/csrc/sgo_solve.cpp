@@ -825,6 +825,7 @@ double debug_spmv0_us(sgo_ctx* c, int mode, int variant, int reps) {
   args.y = c->d_s2;
   args.b = c->d_b;
   args.omega = 0.8;
+  args.force_f64 = (variant & 64) != 0;   // variant 64: RESID / JACOBI on the fp64 blocks although an fp32 copy exists
   const bool tiled = c->T0.ntile > 0 && !(variant & 16);   // variant 16: the wave-group kernel
   long long* d_st = nullptr;
   if ((variant & 32) && tiled) {

@@ -633,6 +633,18 @@ int build_structure(sgo_ctx* c, int V, const double* poses, const uint8_t* fixed
     S.ublk = ub - 2 * U0;                       // pair p of block u: ublk + 2 (p nus + u)
     S.ublk8 = ub + 8 * (U1 - U0) - U0;          // component 8 of block u: ublk8 + u
     c->level0_bytes += (long long)(72 * (U1 - U0));
+    // fp32 copy for the preconditioner's level-0 passes (tile view only; SGO_PRECOND_F32=0: the passes read the fp64 blocks)
+    S.fblk = nullptr;
+    S.fblk8 = nullptr;
+    bool f32 = tiles_ok && !tiles.empty() && c->opts.solver == SGO_SOLVER_PCG_AMG;
+    if (const char* e = std::getenv("SGO_PRECOND_F32")) f32 = f32 && std::atoi(e) != 0;
+    if (f32) {
+      float* fb = nullptr;
+      if ((rc = dalloc(c, &fb, 9 * (U1 - U0) + 4))) return rc;
+      S.fblk = fb - 4 * U0;                     // quad q of block u: fblk + 4 (q nus + u)
+      S.fblk8 = fb + 8 * (U1 - U0) - U0;
+      c->level0_bytes += (long long)(36 * (U1 - U0));
+    }
   }
   if ((rc = dalloc(c, &S.dblk, 6 * (size_t)n))) return rc;
   if ((rc = dalloc(c, &S.dinv, 6 * (size_t)n))) return rc;
