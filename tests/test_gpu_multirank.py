@@ -35,6 +35,8 @@ def _graph(name):
         return synth.config("C2", info_mode="full")
     if name == "random":     # long-range closures: the tentative-prolongator fallback levels
         return synth.manhattan(8000, 32000, seed=11, info_mode="full", p_random=0.05)
+    if name == "C4":         # configs[3] at full size (100k poses / 1M edges): the bench workload of bench.py --gpus N
+        return synth.config("C4")
     if name == "pipelined":  # >= 20 000 free poses: the set-up's helper thread is active on every rank (bench.py's C4 at N > 1)
         return synth.manhattan(24000, 150000, seed=77, info_mode="full")
     raise KeyError(name)
@@ -132,3 +134,20 @@ def test_ranks_agree_bitwise_and_match_one_rank(world, name, mode, monkeypatch):
     assert np.abs(Ps - P1).max() <= 1e-6
     for a, b in zip(chi2_0, ss["chi2"]):
         assert abs(a - b) <= 1e-7 * b   # (the solves' tolerance: a tenth of BASELINE.json's bound)
+
+
+def test_c4_full_size_two_ranks_row_owner_mode_matches_the_direct_solver_golden():
+    """configs[3] (100k poses / 1M edges) with two rank processes in row-owner mode: every iterate's chi2 within BASELINE.json's
+    1e-6 of the sparse-direct-solver oracle's fixture (tests/golden/C4_direct.npz), ranks bit-identical, and each rank holds
+    about half of the level-0 structure."""
+    import os as _os
+    f = np.load(_os.path.join(_os.path.dirname(__file__), "golden", "C4_direct.npz"))
+    iters = 4
+    res = _run(2, "C4", iters)
+    assert all(r[1] == iters for r in res), [r[:3] for r in res]
+    assert "row-owner mode" in res[0][8], res[0][8]
+    assert res[0][2] == res[1][2] and res[0][3] == res[1][3] and res[0][4] == res[1][4]
+    for k in range(iters + 1):
+        assert abs(res[0][2][k] - f["chi2"][k]) <= 1e-6 * f["chi2"][k], k
+    b = [int(r[8].rsplit("level0_bytes=", 1)[1]) for r in res]
+    assert 0.8 <= b[0] / b[1] <= 1.25, b        # (tiles hold equal numbers of blocks: the ranks' shares are even)
