@@ -3,7 +3,7 @@
 # repo root: `gpurun -- bash scripts/profile_round.sh r01`); outputs land in gpurun_out/.
 # rocprofv3 wants cwd and TMPDIR under /tmp; --pmc passes are separate from the --stats pass.
 set -u
-tag=${1:-r02}
+tag=${1:-r03}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp; export TMPDIR=/tmp
 # Plain stream launches (no hipGraph) for the profiled passes, as in bench.py's own roofline leg: graph
@@ -24,6 +24,16 @@ unset SGO_USE_GRAPH
 cp $O/${tag}_pmc_traffic_amg_c4.json $R/profiles/${tag}_pmc_traffic_amg_c4.json
 cd $R
 python3 bench.py 2>/dev/null | tail -1 > $O/${tag}_bench_c4.json
+python3 bench.py --steps 20 --warmup 5 2>/dev/null | tail -1 > $O/${tag}_bench_c4_steps20.json
 python3 bench.py --config C2 2>/dev/null | tail -1 > $O/${tag}_bench_c2.json
-python3 scripts/short.py < $O/${tag}_bench_c4.json; python3 scripts/short.py < $O/${tag}_bench_c2.json
+python3 bench.py --config C3s 2>/dev/null | tail -1 > $O/${tag}_bench_c3s.json
+for c in c4 c4_steps20 c2 c3s; do python3 - $O/${tag}_bench_$c.json <<'PY'
+import json, sys
+d = json.load(open(sys.argv[1]))
+r = d.get("roofline", {})
+print(sys.argv[1].split("/")[-1], round(d["value"] / 1e6, 1), "M/s;", round(d["gn_iter_ms_median"], 3), "ms per GN iteration;", d["pcg_iters_per_gn_iter"],
+      "PCG its; set_graph", round(d["set_graph_ms"], 1), "ms;", r.get("kernel"), "frac", r.get("frac"), "traffic", r.get("traffic"),
+      "sharded", r.get("row_owner_sharded_frac"), "odom", d.get("value_init_odom"))
+PY
+done
 python3 scripts/robustness.py > $O/${tag}_robustness_raw.txt 2>/dev/null; cat $O/${tag}_robustness_raw.txt

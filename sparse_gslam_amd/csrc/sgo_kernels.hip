@@ -34,8 +34,8 @@ const char* const kKernelNames[K_COUNT] = {
     "k_pose_update", "k_positions0", "k_centres",   "k_galerkin",   "k_level_dinv",   "k_restrict", "k_prolong_add",
     "k_gj_step (dense inverse, all block steps)", "k_dense_apply", "k_p_values", "k_block_products<1, 0, 0>",
     "k_block_products<0, 1, 1>", "k_restrict_p", "k_prolong_p", "k_spmv<7>",
-    "k_spmv0<0>", "k_spmv0<1>", "k_spmv0<2>", "k_spmv0t<0, 1024, 0>", "k_spmv0t<1, 1024, 0>", "k_spmv0t<2, 1024, 0>",
-    "k_direct", "k_spmv0t<1, 1024, 1>", "k_spmv0t<2, 1024, 1>", "k_restrict_p @level0", "k_prolong_p @level0", "k_p_values @level0", "k_block_products<1, 0, 0> @level0",
+    "k_spmv0<0>", "k_spmv0<1>", "k_spmv0<2>", "k_spmv0t<0, 1024, false>", "k_spmv0t<1, 1024, false>", "k_spmv0t<2, 1024, false>",
+    "k_direct", "k_spmv0t<1, 1024, true>", "k_spmv0t<2, 1024, true>", "k_restrict_p @level0", "k_prolong_p @level0", "k_p_values @level0", "k_block_products<1, 0, 0> @level0",
     "k_block_products<0, 1, 1> @level0", "k_galerkin @level0", "k_restrict @level0", "k_prolong_add @level0"};
 
 namespace {

@@ -334,7 +334,7 @@ def test_graph_replay_plain_launches_and_profile_mode_agree_bitwise():
                 prof = o.kernel_profile()
                 # 6 GN iterations + the linearisation of the multigrid set-up
                 # (the level-0 launches of the block-stream kernels are kept in slots of their own)
-                assert prof["k_linearize"]["launches"] in (6, 7) and prof["k_spmv0t<0, 1024, 0>"]["ms"] > 0
+                assert prof["k_linearize"]["launches"] in (6, 7) and prof["k_spmv0t<0, 1024, false>"]["ms"] > 0
                 assert 0 <= o.profile_overhead_ms() < 0.1
     for r in res[1:]:
         assert r[0] == res[0][0] == 6 and r[1] == res[0][1] and r[2] == res[0][2]
