@@ -2297,7 +2297,10 @@ AmgConfig amg_effective_config(const AmgConfig& cfg_in, int n, int nslot) {
   if (const char* e = std::getenv("SGO_AMG_SMOOTH")) cfg.smooth = std::atoi(e) != 0;
   if (const char* e = std::getenv("SGO_AMG_LISTS")) cfg.lists_on_device = std::string(e) != "host";
   // larger graphs afford a larger dense coarsest level (its inverse costs O(N^3) once per GN
-  // iteration, one K-cycle level less halves the coarse-level launches of every PCG iteration)
+  // iteration, one K-cycle level less halves the coarse-level launches of every PCG iteration).  A SMALLER dense level
+  // (one more sparse level) was measured in round 3: the dense inverse gets cheaper but the cycle weaker -- stopping at
+  // <= 128 instead of <= 400 nodes: C2 19.6 -> 25.4 PCG iterations (1.76 -> 1.98 ms per GN iteration), C4 22.1 -> 26.5
+  // (4.81 -> 5.82 ms); <= 48: C4 30.7 iterations (6.24 ms)
   cfg.coarsest_nodes = std::min(1000, std::max(cfg.coarsest_nodes, n / 1500));
   return cfg;
 }
