@@ -1,0 +1,123 @@
+#!/usr/bin/env python3
+"""Soak of the multi-GPU modes with rank processes on ONE GPU (host transport over gloo): random graph shapes (closures
+local / partly random, extra fixed vertices, duplicate edges, full information), both modes, smoothed and tentative
+hierarchies, the block-Jacobi solver; every case: ranks bit-identical, and chi2 history / poses within the solves'
+accuracy of the single-GPU run.  Usage: python scripts/owner_stress.py [cases] [seed]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def make_case(k, seed):
+    from sparse_gslam_amd import synth
+    rng = np.random.default_rng(seed * 1000 + k)
+    V = int(rng.integers(2500, 30000))
+    epv = float(rng.uniform(1.3, 8.0))
+    E = max(V + 10, int(V * epv))
+    p_random = float(rng.choice([0.0, 0.0, 0.0, 0.01, 0.05]))
+    g = synth.manhattan(V, E, seed=int(rng.integers(1, 1 << 30)), p_random=p_random, info_mode=str(rng.choice(["diag", "full"])),
+                        phi=float(rng.choice([1.0, 10.0])))
+    if rng.random() < 0.4:      # a few extra fixed vertices
+        g.fixed[rng.integers(1, V, size=3)] = True
+    if rng.random() < 0.4:      # duplicate edges
+        dup = rng.integers(V - 1, g.E, size=20)
+        for name in ("ei", "ej", "meas", "info", "phi"):
+            setattr(g, name, np.concatenate([getattr(g, name), getattr(g, name)[dup]]))
+    world = int(rng.choice([2, 3, 4]))
+    env = {}
+    r = rng.random()
+    if r < 0.25:
+        env["SGO_COMM_MODE"] = "allreduce"
+    elif r < 0.4:
+        env["SGO_AMG_SMOOTH"] = "0"
+    solver = "pcg" if (V < 6000 and rng.random() < 0.15) else "amg"
+    return g, world, env, solver, f"V={V} E={g.E} p_random={p_random} world={world} env={env} solver={solver}"
+
+
+def worker(rank, world, port, k, seed, iters, q):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from sparse_gslam_amd import capi
+        g, _, env, solver, _ = make_case(k, seed)
+        os.environ.update(env)
+
+        def allreduce(a):
+            dist.all_reduce(torch.from_numpy(a))
+
+        opts = dict(solver=capi.SOLVER_PCG_BJ, pcg_maxit=60000) if solver == "pcg" else {}
+        with capi.Optimizer(0, **opts) as o:
+            o.comm_init_host(world, rank, allreduce)
+            o.set_graph(*g.arrays())
+            done, st = o.optimize(iters)
+            P = o.get_poses()
+            desc = o.solver_description()
+        q.put((rank, done, st["chi2"], st["pcg_iters"], P.tobytes(), desc.split("multi-GPU")[-1]))
+    except Exception as e:
+        q.put((rank, -1, repr(e), [], b"", ""))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+def main():
+    import socket
+    import torch.multiprocessing as mp
+    from sparse_gslam_amd import capi
+    ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    iters = 4
+    bad = 0
+    for k in range(ncases):
+        g, world, env, solver, label = make_case(k, seed)
+        t0 = time.time()
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        procs = [ctx.Process(target=worker, args=(r, world, port, k, seed, iters, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        try:
+            res = sorted(q.get(timeout=150) for _ in procs)
+        except Exception as e:
+            print(f"case {k}: {label}: NO ANSWER ({e!r})", flush=True)
+            for p in procs:
+                p.kill()
+            bad += 1
+            continue
+        for p in procs:
+            p.join(timeout=60)
+        old = {kk: os.environ.get(kk) for kk in env}
+        os.environ.update(env)
+        opts = dict(solver=capi.SOLVER_PCG_BJ, pcg_maxit=60000) if solver == "pcg" else {}
+        with capi.Optimizer(0, **opts) as o:
+            o.set_graph(*g.arrays())
+            d1, s1 = o.optimize(iters)
+            P1 = o.get_poses()
+        for kk, vv in old.items():
+            if vv is None:
+                os.environ.pop(kk, None)
+            else:
+                os.environ[kk] = vv
+        ok = all(r[1] == d1 for r in res)
+        same = ok and all(r[2] == res[0][2] and r[3] == res[0][3] and r[4] == res[0][4] for r in res[1:])
+        rel = max((abs(a - b) / max(b, 1e-30) for a, b in zip(res[0][2], s1["chi2"])), default=0.0) if ok and d1 > 0 else float("nan")
+        dp = np.abs(np.frombuffer(res[0][4], dtype=np.float64).reshape(-1, 3) - P1).max() if ok else float("nan")
+        verdict = "ok" if (ok and same and rel <= 1e-6 and dp <= 1e-4) else "MISMATCH"
+        bad += verdict != "ok"
+        print(f"case {k}: {label}: {verdict}; done {[r[1] for r in res]} vs {d1}; ranks identical {same}; chi2 rel {rel:.1e}; poses {dp:.1e}; "
+              f"pcg {res[0][3]} vs {s1['pcg_iters']};{res[0][5]} ({time.time() - t0:.1f} s)", flush=True)
+    print(f"{ncases} cases, {bad} bad", flush=True)
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
