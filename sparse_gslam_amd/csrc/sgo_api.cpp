@@ -197,6 +197,7 @@ int sgo_set_graph_se2(sgo_ctx* c, int32_t V, const double* poses, const uint8_t*
       free_graph(c);
       return rc;
     }
+    if (c->opts.solver != SGO_SOLVER_PCG_AMG) c->solver_desc += multi_gpu_description(c);
     if (c->opts.solver == SGO_SOLVER_PCG_AMG && c->n > 0 && !c->direct) {
       // the hierarchy is built from the Hessian at the initial poses (strength of connection)
       const double ta0 = wall_s();

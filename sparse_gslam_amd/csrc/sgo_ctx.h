@@ -296,6 +296,7 @@ int do_linearize(sgo_ctx* c);
 int do_spmv(sgo_ctx* c, const double* x, double* y, bool dot, const PcgScalars* S, int* grid_out);
 int run_pcg(sgo_ctx* c);
 int build_amg(sgo_ctx* c);
+std::string multi_gpu_description(const sgo_ctx* c);
 int build_rows(sgo_ctx* c, const double* poses, const uint8_t* fixed, const int32_t* ei, const int32_t* ej);
 int ensure_rows(sgo_ctx* c);
 int ensure_amg(sgo_ctx* c);

@@ -451,6 +451,14 @@ int run_pcg(sgo_ctx* c) {
 }
 
 // (Re)build the multigrid hierarchy from the CURRENT level-0 values (requires do_linearize).
+std::string multi_gpu_description(const sgo_ctx* c) {
+  if (c->owner)
+    return "; multi-GPU row-owner mode: rank " + std::to_string(c->halo.me) + " of " + std::to_string(c->halo.G) + " owns rows [" +
+           std::to_string(c->halo.row0) + ", " + std::to_string(c->halo.row1) + "), largest boundary " + std::to_string(c->halo.bmax) + " rows";
+  if (c->comm.nranks > 1 || c->comm.active()) return "; multi-GPU all-reduce mode (" + std::to_string(c->comm.nranks) + " ranks)";
+  return "";
+}
+
 int build_amg(sgo_ctx* c) {
   // speculative replays of the captured PCG iteration (and the launches queued behind them) may still be
   // in flight: drain the stream before the exec and the old hierarchy's buffers go away
@@ -515,11 +523,7 @@ int build_amg(sgo_ctx* c) {
     if (!c->owner && (c->comm.nranks > 1 || c->comm.active())) amg_set_shard(c->amg, &c->comm, c->shard_u0, c->shard_u1, c->shard_row0, c->shard_row1);
     amg_describe(c->amg, &c->solver_desc);
     c->solver_desc = "pcg_amg: " + c->solver_desc;
-    if (c->owner)
-      c->solver_desc += "; multi-GPU row-owner mode: rank " + std::to_string(c->halo.me) + " of " + std::to_string(c->halo.G) + " owns rows [" +
-                        std::to_string(c->halo.row0) + ", " + std::to_string(c->halo.row1) + "), largest boundary " + std::to_string(c->halo.bmax) + " rows";
-    else if (c->comm.nranks > 1 || c->comm.active())
-      c->solver_desc += "; multi-GPU all-reduce mode (" + std::to_string(c->comm.nranks) + " ranks)";
+    c->solver_desc += multi_gpu_description(c);
   } else {
     c->solver_desc = "pcg_block_jacobi (AMG unavailable: " + aerr + ")";
     if (c->opts.verbose) std::fprintf(stderr, "[sgo] %s\n", c->solver_desc.c_str());

@@ -35,11 +35,18 @@ def _graph(name):
         return synth.config("C2", info_mode="full")
     if name == "random":     # long-range closures: the tentative-prolongator fallback levels
         return synth.manhattan(8000, 32000, seed=11, info_mode="full", p_random=0.05)
+    if name == "bj":         # the block-Jacobi solver BASELINE.json names (thousands of PCG iterations: a small graph, one GN iteration)
+        return synth.manhattan(3000, 12000, seed=5, info_mode="full")
     if name == "C4":         # configs[3] at full size (100k poses / 1M edges): the bench workload of bench.py --gpus N
         return synth.config("C4")
     if name == "pipelined":  # >= 20 000 free poses: the set-up's helper thread is active on every rank (bench.py's C4 at N > 1)
         return synth.manhattan(24000, 150000, seed=77, info_mode="full")
     raise KeyError(name)
+
+
+def _opts(name):
+    from sparse_gslam_amd import capi
+    return dict(solver=capi.SOLVER_PCG_BJ, pcg_maxit=100000) if name == "bj" else {}
 
 
 def _worker(rank, world, port, name, iters, q):
@@ -58,7 +65,7 @@ def _worker(rank, world, port, name, iters, q):
             dist.all_reduce(t)
             calls[0] += 1
 
-        with capi.Optimizer(0) as o:
+        with capi.Optimizer(0, **_opts(name)) as o:
             o.comm_init_host(world, rank, allreduce)
             o.set_graph(*g.arrays())
             done, st = o.optimize(iters)
@@ -89,10 +96,10 @@ def _run(world, name, iters):
 
 
 @pytest.mark.parametrize("world,name,mode", [(2, "C2", "owner"), (3, "C2", "owner"), (2, "random", "owner"), (2, "random", "allreduce"),
-                                             (3, "C2", "allreduce"), (2, "pipelined", "owner")])
+                                             (3, "C2", "allreduce"), (2, "pipelined", "owner"), (2, "bj", "owner")])
 def test_ranks_agree_bitwise_and_match_one_rank(world, name, mode, monkeypatch):
     from sparse_gslam_amd import capi
-    iters = 5
+    iters = 1 if name == "bj" else 5
     # the library picks the mode by the share of boundary rows (C2, pipelined: 2-5 %; random: 20 %: still row-owner; beyond
     # a quarter of the rows: all-reduce); the all-reduce cases force it so that both modes run on the same graphs
     if mode == "allreduce":
@@ -107,7 +114,7 @@ def test_ranks_agree_bitwise_and_match_one_rank(world, name, mode, monkeypatch):
     g = _graph(name)
     rank_bytes = [int(r[8].rsplit("level0_bytes=", 1)[1]) for r in res]
     # one rank through the same transport
-    with capi.Optimizer(0) as o:
+    with capi.Optimizer(0, **_opts(name)) as o:
         o.comm_init_host(1, 0, lambda a: None)
         o.set_graph(*g.arrays())
         d1, s1 = o.optimize(iters)
@@ -120,13 +127,13 @@ def test_ranks_agree_bitwise_and_match_one_rank(world, name, mode, monkeypatch):
         assert sum(rank_bytes) <= 1.25 * bytes1 + world * (4 << 20), (rank_bytes, bytes1)
     else:
         assert min(rank_bytes) >= 0.9 * bytes1      # all-reduce mode: every rank holds the whole graph
-    assert d1 == iters and max(abs(a - b) for a, b in zip(s1["pcg_iters"], its_0)) <= 1
+    assert d1 == iters and max(abs(a - b) for a, b in zip(s1["pcg_iters"], its_0)) <= (1 if name != "bj" else 0.02 * max(its_0))
     # (two PCG solves to 1e-8 with differently rounded coarse right-hand sides: poses agree to the solves' accuracy)
     assert np.abs(np.frombuffer(P0, dtype=np.float64).reshape(-1, 3) - P1).max() <= 1e-6
     for a, b in zip(chi2_0, s1["chi2"]):
         assert abs(a - b) <= 1e-7 * b   # (the solves' tolerance: a tenth of BASELINE.json's bound)
     # and the single-GPU path (fused dot products, hipGraph replay): agreement to rounding
-    with capi.Optimizer(0) as o:
+    with capi.Optimizer(0, **_opts(name)) as o:
         o.set_graph(*g.arrays())
         ds, ss = o.optimize(iters)
         Ps = o.get_poses()
