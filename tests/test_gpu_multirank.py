@@ -65,8 +65,16 @@ def _worker(rank, world, port, name, iters, q):
             dist.all_reduce(t)
             calls[0] += 1
 
+        def allgather(send, recv):     # the optional companion transport of the row-owner mode's packets
+            out = [torch.empty(send.size, dtype=torch.float64) for _ in range(world)]
+            dist.all_gather(out, torch.from_numpy(send.copy()))
+            for r, t in enumerate(out):
+                recv[r * send.size:(r + 1) * send.size] = t.numpy()
+            calls[0] += 1
+
         with capi.Optimizer(0, **_opts(name)) as o:
-            o.comm_init_host(world, rank, allreduce)
+            # (one case brings a real all-gather; the others let libsgo perform it as an all-reduce of zero-padded slots)
+            o.comm_init_host(world, rank, allreduce, allgather if name == "pipelined" else None)
             o.set_graph(*g.arrays())
             done, st = o.optimize(iters)
             P = o.get_poses()
