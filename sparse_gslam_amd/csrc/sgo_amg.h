@@ -92,7 +92,7 @@ int amg_apply(Amg* m, hipStream_t s, const double* r, double* z, const double* d
 // right-hand side, which is all-reduced over `comm` (3 n_c doubles); the post-smoothing pass's result is all-reduced
 // as a whole (3 n doubles).  Everything else of the cycle runs replicated.
 struct Comm;
-void amg_set_shard(Amg* m, Comm* comm, int u0, int u1, int row0, int row1);
+void amg_set_shard(Amg* m, Comm* comm, int u0, int u1, int row0, int row1, const HaloDev* slices = nullptr);   // slices: all-gather the product vectors by rank slices
 bool amg_comm_failed(const Amg* m);
 int amg_debug_coarse_rhs(Amg* m, hipStream_t s, const double* r, double* out_dev, int cap3);   // test hook, see sgo_amg.hip
 double* amg_xs0(Amg* m);     // [n][3] on the device; nullptr for a single-level (dense) hierarchy

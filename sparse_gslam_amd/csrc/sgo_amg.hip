@@ -1827,6 +1827,7 @@ struct Amg {
   Tile0Dev T0;              // ... and its tile view
   Comm* comm = nullptr;     // multi-GPU, all-reduce mode: level-0 products over the units [u0, u1) (= rows [row0, row1)) + all-reduce
   const HaloDev* halo = nullptr;   // multi-GPU, row-owner mode (sgo_internal.h): level-0 work on the owned rows, boundary exchanges
+  const HaloDev* slices = nullptr; // multi-GPU, all-reduce mode with a communicator: product vectors all-gathered by rank slices
   int u0 = 0, u1 = 0, row0 = 0, row1 = 0;
   bool comm_failed = false;
   long long level0_bytes = 0;   // device bytes of the level-0 transfer data (P blocks, A P blocks, product lists)
@@ -1999,7 +2000,7 @@ int cycle(Amg* m, hipStream_t s, int l, const double* rhs, const double* rhs_sub
       a.u0 = H->u0; a.u1 = H->u1;
     } else if (m->comm) {
       a.u0 = m->u0; a.u1 = m->u1;
-      hipMemsetAsync(L.rs, 0, sizeof(double) * 3 * (size_t)L.A.n, s);
+      if (!m->slices) hipMemsetAsync(L.rs, 0, sizeof(double) * 3 * (size_t)L.A.n, s);   // (the restriction reads this rank's rows only)
     }
     if (!(H || m->comm) || a.u1 > a.u0) {
       const bool f32 = m->T0.ntile > 0 && m->S0.fblk != nullptr;   // (fp32 copy of the blocks: 36 + 4 B per pair)
@@ -2098,13 +2099,17 @@ int cycle(Amg* m, hipStream_t s, int l, const double* rhs, const double* rhs_sub
       // this rank's rows, zeros elsewhere, all-reduce, then the dot products on the full vector (replicated)
       b.u0 = m->u0; b.u1 = m->u1;
       b.dotA = nullptr; b.dotA2 = nullptr; b.partials = nullptr;
-      hipMemsetAsync(out, 0, sizeof(double) * 3 * (size_t)L.A.n, s);
+      if (!m->slices) hipMemsetAsync(out, 0, sizeof(double) * 3 * (size_t)L.A.n, s);
       if (b.u1 > b.u0) {
         Scope sc(m->prof, m->T0.ntile > 0 ? K_SPMV0T_JACOBI : K_SPMV0_JACOBI, 76.0 * m->S0.npairs + 168.0 * m->S0.n);
         launch_spmv0_any(s, m->S0, m->T0, S0_JACOBI, b);
       }
       std::string e;
-      if (!m->comm->allreduce_f64(out, 3 * (size_t)L.A.n, s, &e)) m->comm_failed = true;
+      if (m->slices) {
+        if (!halo_gather_slices(*m->slices, s, out, 3, &e)) m->comm_failed = true;
+      } else if (!m->comm->allreduce_f64(out, 3 * (size_t)L.A.n, s, &e)) {
+        m->comm_failed = true;
+      }
       if (!dotvec) return 0;
       const int grid = grid_for(3LL * L.A.n, kBlock);
       Scope sc(m->prof, K_DOT, 72.0 * L.A.n);
@@ -2204,7 +2209,8 @@ int amg_update(Amg* m, hipStream_t s, std::string* err) {
   return SGO_OK;
 }
 
-void amg_set_shard(Amg* m, Comm* comm, int u0, int u1, int row0, int row1) {
+void amg_set_shard(Amg* m, Comm* comm, int u0, int u1, int row0, int row1, const HaloDev* slices) {
+  m->slices = slices;
   m->comm = comm;
   m->u0 = u0;
   m->u1 = u1;

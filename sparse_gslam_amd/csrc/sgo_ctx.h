@@ -59,6 +59,7 @@ struct sgo_ctx {
   int shard_row0 = 0, shard_row1 = 0;                //            = these rows
   std::vector<int> unit_row0;                        // first row of every work unit (+ n at the end)
   bool owner = false;            // multi-GPU row-owner mode (HaloDev, sgo_internal.h); false with a communicator: all-reduce mode
+  bool gather_slices = false;    // all-reduce mode with a communicator: product vectors travel as an all-gather of the ranks' slices
   HaloDev halo;
   HaloHost halo_host;
   bool halo_failed = false;

@@ -262,12 +262,18 @@ int do_spmv(sgo_ctx* c, const double* x, double* y, bool dot, const PcgScalars* 
     // the same arithmetic on every rank, so the replicated PCG recurrences stay bit-identical across ranks
     a.u0 = c->shard_u0;
     a.u1 = c->shard_u1;
-    HIP_TRY(c, hipMemsetAsync(y, 0, sizeof(double) * 3 * (size_t)c->n, c->stream));
+    // (with a communicator the ranks' slices are all-gathered -- one contributor per row: nothing to sum, no zero fill;
+    // the rank-emulation hook has no communicator: zeros elsewhere, so that a test can add the ranks' partial results)
+    if (!c->gather_slices) HIP_TRY(c, hipMemsetAsync(y, 0, sizeof(double) * 3 * (size_t)c->n, c->stream));
     if (a.u1 > a.u0) {
       Scope sc(c, c->T0.ntile > 0 ? K_SPMV0T_AX : K_SPMV0_AX, bytes_spmv0(c->S0, S0_AX) * (a.u1 - a.u0) / std::max(1, c->shard_units));
       launch_spmv0_any(c->stream, c->S0, c->T0, S0_AX, a);
     }
-    if (!c->comm.allreduce_f64(y, 3 * (size_t)c->n, c->stream, &c->err)) return SGO_ECOMM;
+    if (c->gather_slices) {
+      if (!halo_gather_slices(c->halo, c->stream, y, 3, &c->err)) return SGO_ECOMM;
+    } else if (!c->comm.allreduce_f64(y, 3 * (size_t)c->n, c->stream, &c->err)) {
+      return SGO_ECOMM;
+    }
     if (dot) {
       int grid = 0;
       Scope sc(c, K_DOT, 48.0 * c->n);
@@ -520,7 +526,8 @@ int build_amg(sgo_ctx* c) {
     return SGO_ECOMM;
   }
   if (c->amg) {
-    if (!c->owner && (c->comm.nranks > 1 || c->comm.active())) amg_set_shard(c->amg, &c->comm, c->shard_u0, c->shard_u1, c->shard_row0, c->shard_row1);
+    if (!c->owner && (c->comm.nranks > 1 || c->comm.active()))
+      amg_set_shard(c->amg, &c->comm, c->shard_u0, c->shard_u1, c->shard_row0, c->shard_row1, c->gather_slices ? &c->halo : nullptr);
     amg_describe(c->amg, &c->solver_desc);
     c->solver_desc = "pcg_amg: " + c->solver_desc;
     c->solver_desc += multi_gpu_description(c);

@@ -72,6 +72,7 @@ void free_graph(sgo_ctx* c) {
   c->has_graph = false;
   c->linearized = false;
   c->owner = false;
+  c->gather_slices = false;
   c->halo = HaloDev();
   c->halo_failed = false;
 }
@@ -513,6 +514,7 @@ int build_structure(sgo_ctx* c, int V, const double* poses, const uint8_t* fixed
   const double tb1 = wall_s();
   // ---- multi-GPU, row-owner mode: the boundary rows of every rank (the rows with an edge into another rank's range)
   c->owner = false;
+  c->gather_slices = false;
   c->halo = HaloDev();
   c->halo_host = HaloHost();
   if (c->comm.active() && tiles_ok && !tiles.empty() && n >= 2048) {   // (the rank-emulation hook without a communicator keeps the all-reduce mode's sharded passes)
@@ -591,8 +593,26 @@ int build_structure(sgo_ctx* c, int V, const double* poses, const uint8_t* fixed
       if (c->opts.verbose)
         std::fprintf(stderr, "[sgo] row-owner mode: rank %d of %d owns tiles [%d, %d) = rows [%d, %d); boundary rows %lld of %d (largest rank %d)\n",
                      H.me, G, H.u0, H.u1, H.row0, H.row1, total, n, bmax);
-    } else if (c->opts.verbose) {
-      std::fprintf(stderr, "[sgo] multi-GPU: %lld of %d rows are boundary rows: all-reduce mode\n", total, n);
+    } else {
+      // all-reduce mode: every rank holds the whole graph and evaluates the level-0 products for the rows of its tiles;
+      // the product vectors travel as an all-gather of the ranks' (contiguous) slices -- half the bytes of an all-reduce
+      // with zero fill, one contributor per row either way
+      HaloDev& H = c->halo;
+      H.comm = &c->comm;
+      H.G = G;
+      H.me = HH.me;
+      H.row0 = HH.rank_row[HH.me];
+      H.row1 = HH.rank_row[HH.me + 1];
+      H.u0 = rank_u[HH.me];
+      H.u1 = rank_u[HH.me + 1];
+      H.maxrows = maxrows;
+      H.failed = &c->halo_failed;
+      int* d_rr = nullptr;
+      if ((rc = upload(c, &d_rr, HH.rank_row))) return rc;
+      H.rank_row = d_rr;
+      if ((rc = halo_reserve(c, 3 * (size_t)maxrows))) return rc;
+      c->gather_slices = true;
+      if (c->opts.verbose) std::fprintf(stderr, "[sgo] multi-GPU: %lld of %d rows are boundary rows: all-reduce mode\n", total, n);
     }
   }
   // Row-owner mode: the per-slot and per-block arrays are allocated and uploaded for this rank's rows only; the base
