@@ -35,6 +35,8 @@ def _graph(name):
         return synth.config("C2", info_mode="full")
     if name == "random":     # long-range closures: the tentative-prolongator fallback levels
         return synth.manhattan(8000, 32000, seed=11, info_mode="full", p_random=0.05)
+    if name == "rebuild":    # robust-kernel re-weighting from a dead-reckoned start: the hierarchy is rebuilt inside optimize()
+        return synth.manhattan(V=3000, E=4500, seed=1, p_random=0.3, info_mode="diag", phi=1.0, init="odom")
     if name == "bj":         # the block-Jacobi solver BASELINE.json names (thousands of PCG iterations: a small graph, one GN iteration)
         return synth.manhattan(3000, 12000, seed=5, info_mode="full")
     if name == "C4":         # configs[3] at full size (100k poses / 1M edges): the bench workload of bench.py --gpus N
@@ -166,3 +168,90 @@ def test_c4_full_size_two_ranks_row_owner_mode_matches_the_direct_solver_golden(
         assert abs(res[0][2][k] - f["chi2"][k]) <= 1e-6 * f["chi2"][k], k
     b = [int(r[8].rsplit("level0_bytes=", 1)[1]) for r in res]
     assert 0.8 <= b[0] / b[1] <= 1.25, b        # (tiles hold equal numbers of blocks: the ranks' shares are even)
+
+
+def _api_worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from sparse_gslam_amd import capi
+        g = _graph("C2")
+        with capi.Optimizer(0, pcg_tol=1e-10) as o:
+            o.comm_init_host(world, rank, lambda a: dist.all_reduce(torch.from_numpy(a)))
+            o.set_graph(*g.arrays())
+            b, diag, c2, rc2 = o.linearize()
+            x = np.random.default_rng(3).standard_normal(b.shape)
+            y = o.hessian_apply(x)
+            z = o.precondition(x)
+            sol, its, relres = o.solve()
+            e2 = o.edge_chi2()
+            desc = o.solver_description()
+        q.put((rank, b.tobytes(), diag.tobytes(), c2, rc2, y.tobytes(), z.tobytes(), sol.tobytes(), its, e2.tobytes(), desc))
+    except Exception as e:
+        q.put((rank, repr(e)))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+def test_single_step_entry_points_in_row_owner_mode():
+    """sgo_linearize / sgo_hessian_apply / sgo_precondition / sgo_solve / sgo_edge_chi2 with two rank processes in row-owner
+    mode: every rank reports the FULL vectors (the ranks' slices are gathered at the boundary), identical on both ranks, and
+    equal to the single-GPU results to rounding (1e-9 for the solve: two PCG runs to 1e-10)."""
+    import torch.multiprocessing as mp
+    from sparse_gslam_amd import capi
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_api_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert all(len(r) == 11 for r in res), res
+    assert "row-owner mode" in res[0][10]
+    for k in (1, 2, 5, 6, 7, 9):
+        assert res[0][k] == res[1][k], k          # bit-identical on the two ranks
+    g = _graph("C2")
+    with capi.Optimizer(0, pcg_tol=1e-10) as o:
+        o.set_graph(*g.arrays())
+        b, diag, c2, rc2 = o.linearize()
+        x = np.random.default_rng(3).standard_normal(b.shape)
+        y = o.hessian_apply(x)
+        z = o.precondition(x)
+        sol, its, relres = o.solve()
+        e2 = o.edge_chi2()
+    f = lambda k, shape: np.frombuffer(res[0][k], dtype=np.float64).reshape(shape)   # noqa: E731
+    assert np.abs(f(1, b.shape) - b).max() <= 1e-12 * np.abs(b).max()
+    assert np.abs(f(2, diag.shape) - diag).max() <= 1e-12 * np.abs(diag).max()
+    assert abs(res[0][3] - c2) <= 1e-12 * c2 and abs(res[0][4] - rc2) <= 1e-12 * rc2
+    assert np.abs(f(5, y.shape) - y).max() <= 1e-12 * np.abs(y).max()     # (another tile cut: rounding)
+    assert np.abs(f(6, z.shape) - z).max() <= 1e-6 * np.abs(z).max()      # (fp32 blocks inside the preconditioner, other tiles)
+    assert np.abs(f(7, sol.shape) - sol).max() <= 1e-8 * np.abs(sol).max()
+    assert np.array_equal(f(9, e2.shape), e2)
+
+
+def test_hierarchy_rebuild_inside_optimize_in_row_owner_mode(monkeypatch):
+    """The stale-aggregation rule (counts only: every rank decides alike) redoes the multigrid set-up inside optimize() with
+    two rank processes in row-owner mode (forced: the graph's random closures would pick the all-reduce mode): ranks
+    bit-identical, iterates within the parity bound of the single-GPU run, which rebuilds at the same iterations."""
+    from sparse_gslam_amd import capi
+    monkeypatch.setenv("SGO_COMM_MODE", "owner")
+    res = _run(2, "rebuild", 20)
+    assert all(r[1] == 20 for r in res), [r[:3] for r in res]
+    assert "row-owner mode" in res[0][8]
+    assert res[0][2] == res[1][2] and res[0][3] == res[1][3] and res[0][4] == res[1][4]
+    monkeypatch.delenv("SGO_COMM_MODE")
+    g = _graph("rebuild")
+    with capi.Optimizer(0, direct_rows=0) as o:
+        o.set_graph(*g.arrays())
+        d, st = o.optimize(20)
+    assert d == 20
+    for a, b in zip(res[0][2], st["chi2"]):
+        assert abs(a - b) <= 1e-6 * b
+    assert max(res[0][3]) < 400        # no solve ground on with a stale hierarchy
