@@ -279,6 +279,7 @@ int plan_rows(int V, const double* poses, const uint8_t* fixed, int E, const int
 // One tile per CU of an MI355X.  A constant, not the device's CU count: every rank of a multi-GPU run -- and the
 // host-only sgo_plan_rows -- must cut the same tiles whatever device it sits on.
 constexpr int kTileDiv = 256;
+constexpr long long kSmallGraphPairs = 150000;   // below: the wave-group kernel instead of the tile kernel (sgo_plan.cpp)
 
 // ---- device-resident graph (sgo_structure.cpp) ----------------------------------------------
 void l0_join(sgo_ctx* c, bool keep);

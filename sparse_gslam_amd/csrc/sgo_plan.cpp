@@ -231,6 +231,21 @@ void plan_rows_tiles(int tile_div, RowPlan& P) {
     if (const char* e = std::getenv("SGO_TILE_LDS")) lds_budget = std::atoi(e);   // test hook: small tiles on small graphs
     long long nblk = 0;
     for (int k = 0; k < ns; ++k) nblk += col[k] >= 0;
+    // Small graphs take the wave-group kernel (k_spmv0: one lane per slot, no LDS tiles): below ~150 k connected pairs a
+    // level-0 pass is a chain of dependent round trips, not a stream, and the tile kernel's three phases + two barriers
+    // are the longer chain (measured per pass, tile / wave-group: 40 k pairs 5.4 / 4.4 us, 100 k 8.6 / 5.1, 200 k 7.0 / 7.7,
+    // 400 k 10 / 15, 1 M 18-21 / 33-37).  Multi-GPU runs keep the tiles (the unit of the partition); SGO_SPMV0=tile forces them.
+    {
+      const char* e = std::getenv("SGO_SPMV0");
+      const bool force_tile = e && !std::strcmp(e, "tile");
+      if (!force_tile && tile_div <= kTileDiv && nblk / 2 < kSmallGraphPairs) {
+        P.tiles_ok = false;
+        tiles.clear();
+        for (int r = 0; r < n; ++r) tile_of_row[r] = 0;
+        lap("tiles (small graph: wave-group kernel)");
+        return;
+      }
+    }
     // A tile costs what it STORES (measured, C4: 4.8 cycles per stored block + 90 per wave group, against 20-47 k
     // cycles per tile when tiles were cut by slot count): its slots with a free column minus its intra-tile pairs,
     // which are stored once.  Tiles are cut greedily to a block target; the target is re-derived from the total

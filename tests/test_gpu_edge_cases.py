@@ -23,13 +23,23 @@ def _check_against_oracle(opt, args, iters=10, tol=1e-6):
     return P
 
 
-@pytest.fixture(scope="module", params=["auto", "pcg"])
+@pytest.fixture(scope="module", params=["auto", "pcg", "pcg-tiles"])
 def opt(request):
-    """Both ways a small graph can run: the single-launch direct path where it qualifies (default), and the
-    multigrid PCG path alone (direct_rows = 0)."""
-    o = capi.Optimizer(0, pcg_tol=1e-10, pcg_maxit=100000, **({"direct_rows": 0} if request.param == "pcg" else {}))
+    """The ways a small graph can run: the single-launch direct path where it qualifies (default), the multigrid PCG path
+    alone (direct_rows = 0) with the level-0 product kernel small graphs get (wave groups), and the same with the tile
+    kernel of the large graphs forced (SGO_SPMV0=tile; read at every sgo_set_graph_se2)."""
+    import os
+    old = os.environ.get("SGO_SPMV0")
+    if request.param == "pcg-tiles":
+        os.environ["SGO_SPMV0"] = "tile"
+    o = capi.Optimizer(0, pcg_tol=1e-10, pcg_maxit=100000, **({"direct_rows": 0} if request.param != "auto" else {}))
     yield o
     o.close()
+    if request.param == "pcg-tiles":
+        if old is None:
+            os.environ.pop("SGO_SPMV0", None)
+        else:
+            os.environ["SGO_SPMV0"] = old
 
 
 def test_duplicate_edges_and_edges_to_fixed_vertices(opt):

@@ -56,6 +56,31 @@ def test_spmv_matches_oracle(opt):
     assert np.abs(y - oy).max() <= 1e-12 * np.abs(oy).max()
 
 
+@pytest.mark.parametrize("kernel", ["tile", "group"])
+def test_both_level0_kernels_match_the_oracle(kernel, monkeypatch):
+    """Small graphs (< 150 k connected pairs) take the wave-group product kernel k_spmv0, large ones the tile kernel k_spmv0t:
+    both forced on C2 (SGO_SPMV0), product, solve and five GN iterations against the oracle."""
+    monkeypatch.setenv("SGO_SPMV0", kernel)
+    g = synth.config("C2", info_mode="full")
+    with capi.Optimizer(0, pcg_tol=1e-10, direct_rows=0, profile=1) as o:
+        o.set_graph(*g.arrays())
+        b, _, _, _ = o.linearize()
+        x = np.random.default_rng(0).standard_normal((o.n_free, 3))
+        y = o.hessian_apply(x)
+        oy = _oracle().hessian_apply(*g.arrays(), x).reshape(-1, 3)
+        assert np.abs(y - oy).max() <= 1e-12 * np.abs(oy).max()
+        sol, it, relres = o.solve()
+        assert np.linalg.norm(b - o.hessian_apply(sol)) <= 1e-8 * np.linalg.norm(b)
+        done, st = o.optimize(5)
+        prof = o.kernel_profile()
+    used = {n for n, v in prof.items() if v["launches"] > 0}
+    assert ("k_spmv0t<0, 1024, false>" in used) == (kernel == "tile") and ("k_spmv0<0>" in used) == (kernel == "group"), used
+    oP, ost = _oracle().gauss_newton(*g.arrays(), iters=5)
+    assert done == 5
+    for a, c in zip(st["chi2"], ost["chi2"]):
+        assert abs(a - c) <= 1e-6 * c
+
+
 def test_pcg_solves_the_normal_equations(opt):
     g = synth.config("C1", info_mode="full")
     opt.set_graph(*g.arrays())
@@ -245,10 +270,13 @@ def test_rank_partial_products_sum_to_the_single_rank_product():
         assert owners.max() == 1
 
 
-def test_rank_partial_coarse_right_hand_sides_sum_to_the_single_rank_one():
+def test_rank_partial_coarse_right_hand_sides_sum_to_the_single_rank_one(monkeypatch):
     """The other exchange of the multi-GPU cycle: each rank restricts the residual of ITS rows only and the
     partial coarse right-hand sides are all-reduced (3 n_c doubles).  Emulated ranks on one GPU: the partials sum
-    to the single-rank vector (to rounding: the per-column sums are split differently)."""
+    to the single-rank vector (to rounding: the per-column sums are split differently).  The single-rank context is given
+    the tile kernel too (a graph of C2's size would take the wave-group kernel, whose residual pass reads the fp64 blocks
+    where the tile kernel's reads their fp32 copy: the comparison is between partitions, not between kernels)."""
+    monkeypatch.setenv("SGO_SPMV0", "tile")
     import ctypes as C
     L = capi.lib()
     L.sgo_debug_coarse_rhs.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int]
@@ -334,7 +362,7 @@ def test_graph_replay_plain_launches_and_profile_mode_agree_bitwise():
                 prof = o.kernel_profile()
                 # 6 GN iterations + the linearisation of the multigrid set-up
                 # (the level-0 launches of the block-stream kernels are kept in slots of their own)
-                assert prof["k_linearize"]["launches"] in (6, 7) and prof["k_spmv0t<0, 1024, false>"]["ms"] > 0
+                assert prof["k_linearize"]["launches"] in (6, 7) and prof["k_spmv0<0>"]["ms"] > 0
                 assert 0 <= o.profile_overhead_ms() < 0.1
     for r in res[1:]:
         assert r[0] == res[0][0] == 6 and r[1] == res[0][1] and r[2] == res[0][2]
