@@ -592,6 +592,9 @@ __global__ __launch_bounds__(kBlock) void k_prolong_add(int n, const int* __rest
 //   A_iK <- -A_iK P (i != K);  A_KK <- P.
 // The matrix is stored row-major with leading dimension Np = N rounded up to 32 and an identity
 // on the padding, so every tile is full.  One launch per pivot block (k_gj_step).
+// (64 x 64 blocks with 1024 threads -- half the sequential block steps -- were measured in round 3: much slower, C2 1.71 ->
+// 2.77 ms and C4 4.84 -> 5.86 ms per GN iteration: the 64 elimination steps of a pivot block with sixteen waves at every
+// barrier cost more than the launches they save.)
 constexpr int kGjB = 32;
 
 // The coarse levels' slots are unique per (row, col) (the host lists them so): one thread per slot stores its
