@@ -122,6 +122,40 @@ def test_plan_rows_is_a_partition_for_every_world_size():
         assert np.array_equal(np.sort(plan["row_vertex"]), np.flatnonzero(~g.fixed))
 
 
+def test_every_rank_gets_its_own_256_tiles_and_thin_boundaries():
+    """A world of G ranks cuts 256 G tiles (each rank keeps its own CUs busy; a one-GPU graph of this size would take the
+    wave-group kernel and no tiles at all), rank boundaries sit on tile boundaries, the ranks' shares of the stored blocks
+    are even, and -- the premise of the row-owner mode -- only a few per cent of the rows have an edge into another rank's
+    range when the closures are spatially local (Hilbert row order)."""
+    g = synth.manhattan(40000, 300000, seed=12)
+    ntiles = {}
+    for world in (1, 2, 4, 8):
+        plan = capi.plan_rows(g.poses, g.fixed, g.ei, g.ej, world)
+        tb, rb, n = plan["tile_row_begin"], plan["rank_row_begin"], plan["n"]
+        ntiles[world] = tb.size - 1
+        assert set(rb.tolist()) <= set(tb.tolist())
+        if world == 1:
+            continue
+        row_of = np.full(g.V, -1, dtype=np.int64)
+        row_of[plan["row_vertex"]] = np.arange(n)
+        ri, rj = row_of[g.ei], row_of[g.ej]
+        ok = (ri >= 0) & (rj >= 0)
+        qi = np.searchsorted(rb, ri[ok], side="right") - 1
+        qj = np.searchsorted(rb, rj[ok], side="right") - 1
+        cross = qi != qj
+        isb = np.zeros(n, dtype=bool)
+        isb[ri[ok][cross]] = True
+        isb[rj[ok][cross]] = True
+        assert isb.sum() <= 0.25 * n, (world, int(isb.sum()))          # the library's row-owner criterion
+        assert isb.sum() <= 0.12 * n, (world, int(isb.sum()))          # in fact a few per cent
+        # even shares: the tiles are cut to equal stored blocks, a rank owns ntiles / world of them
+        deg = np.bincount(np.concatenate([ri[ok], rj[ok]]), minlength=n)
+        share = np.array([deg[rb[q]:rb[q + 1]].sum() for q in range(world)], dtype=float)
+        assert share.max() <= 1.25 * share.mean(), (world, share)
+    # 256 per rank until a tile would fall below 512 stored blocks (a 300 k-edge graph: ~800 tiles at most)
+    assert 240 <= ntiles[1] <= 256 + 8 and ntiles[2] > 1.8 * ntiles[1] and ntiles[8] >= ntiles[4] > 1.5 * ntiles[2]
+
+
 def test_plan_rows_on_a_large_graph_with_long_range_edges(monkeypatch):
     """E >= 200 000: the slot placement runs as a parallel stable counting sort over chunks of the edge list; 20 %
     random closures and a small LDS budget (the experiment knob SGO_TILE_LDS stands in for the graphs of C5's kind,
