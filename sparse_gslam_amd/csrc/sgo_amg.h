@@ -19,6 +19,10 @@ struct AmgConfig {
                                // graphs with >= 10^6 level-0 blocks, where a coarse sweep is cheap next to level 0
   bool smooth = true;          // smoothed aggregation: P = (I - omega_p D^-1 A) T (env SGO_AMG_SMOOTH=0: tentative P)
   double omega_p = 0.66;       // damping of the prolongator smoothing step
+  bool fold = true;             // folded V-cycle (sgo_amg.hip): the post- and pre-smoothing sweeps of the smoothed levels folded into
+                                // the transfer operator P~ = (I - omega D^-1 A) P; one sweep per level (env SGO_AMG_FOLD=0: the
+                                // sweeps as launches of their own, nu_coarse as below)
+  int fold0_rows = 30000;       // ... level 0 too on graphs of at most this many rows (single GPU)
   bool lists_on_device = true;  // the product lists of A P and P^T A P are made on the device from the host's patterns
                                 // (env SGO_AMG_LISTS=host: on the host, the reference the device lists are tested against)
   int coarsest_nodes = 400;  // stop coarsening at or below this many nodes; that level is inverted densely

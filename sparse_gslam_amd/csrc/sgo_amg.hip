@@ -34,6 +34,7 @@
 #include <vector>
 
 #include "sgo_amg.h"
+#include "sgo_sort.h"
 #include "sgo_comm.h"
 #include "sgo_device.h"
 
@@ -358,14 +359,47 @@ __global__ __launch_bounds__(kBlock) void k_block_products(ProdMap mp, BsrDev XA
 // rc[a] = sum over the entries e of column a of P_e^T r[row(e)]   (column-ordered copy of P)
 // Multi-GPU: only the fine rows [row0, row1) contribute (row1 == 0: all) -- the partial coarse right-hand sides of
 // the ranks are then summed by an all-reduce of 3 n_c doubles instead of all-reducing the fine residual.
+// The first nb_main workgroups walk the wave groups; columns longer than kLongColumn entries are left to the workgroups
+// behind them, ONE WORKGROUP each in the same launch (every thread a few entries, all of them requested at once; wave sums,
+// then the wave totals added in a fixed order): a single wave walking such a column stride by stride is a chain of ~70
+// dependent round trips (C5's last level: 4 350 entries per column, 109 us), a launch of its own costs 4 us per cycle.
 __global__ __launch_bounds__(kBlock) void k_restrict_p(PDev P, const double* __restrict__ r, double* __restrict__ rc,
-                                                       const PcgScalars* S, int row0, int row1) {
-  // (as in k_spmv: the first group's bounds are requested before the stop flag is waited for -- one dependent
-  // round trip less in a launch that is a chain of four)
+                                                       const PcgScalars* S, int row0, int row1, int nb_main) {
   const int lane = threadIdx.x & 63;
   const size_t np = (size_t)P.t_n;
+  if ((int)blockIdx.x >= nb_main) {   // a long column
+    if (S && S->stop) return;
+    __shared__ double sm[kWavesPerBlock][3];
+    const int lc = (int)blockIdx.x - nb_main;
+    const int gb = P.t_long[2 * lc], ge = P.t_long[2 * lc + 1];
+    double acc[3] = {0.0, 0.0, 0.0};
+    for (int t = gb + (int)threadIdx.x; t < ge; t += kBlock) {
+      const size_t i = (size_t)P.t_row[t];
+      if (row1 > 0 && ((int)i < row0 || (int)i >= row1)) continue;
+      const double r0 = r[3 * i], r1 = r[3 * i + 1], r2 = r[3 * i + 2];
+      double b[9];
+      load9_pairs(P.t_blk, P.t_blk8, (size_t)t, np, b, P.stream_nt != 0);
+      acc[0] += b[0] * r0 + b[3] * r1 + b[6] * r2;
+      acc[1] += b[1] * r0 + b[4] * r1 + b[7] * r2;
+      acc[2] += b[2] * r0 + b[5] * r1 + b[8] * r2;
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const double v = wave_sum(acc[q]);
+      if (lane == 0) sm[threadIdx.x >> 6][q] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+      double v = sm[0][threadIdx.x];
+      for (int w = 1; w < kWavesPerBlock; ++w) v += sm[w][threadIdx.x];
+      rc[3 * (size_t)P.t_col[gb] + threadIdx.x] = v;
+    }
+    return;
+  }
+  // (as in k_spmv: the first group's bounds are requested before the stop flag is waited for -- one dependent
+  // round trip less in a launch that is a chain of four)
   int g, gend, gstride;
-  group_walk(P.t_ngrp, &g, &gend, &gstride);
+  group_walk_n(P.t_ngrp, nb_main, &g, &gend, &gstride);
   int gb0 = 0, ge0 = 0;
   if (g < gend) {
     gb0 = P.t_grp[g];
@@ -374,7 +408,7 @@ __global__ __launch_bounds__(kBlock) void k_restrict_p(PDev P, const double* __r
   if (S && S->stop) return;
   for (bool first = true; g < gend; g += gstride, first = false) {
     const int gb = first ? gb0 : P.t_grp[g], ge = first ? ge0 : P.t_grp[g + 1];
-    if (P.t_nlong > 0 && ge - gb > kLongColumn) continue;   // k_restrict_p_long's
+    if (P.t_nlong > 0 && ge - gb > kLongColumn) continue;   // a long column: the workgroups at the end of the grid
     double acc[3] = {0.0, 0.0, 0.0};
     int key = -1 - lane;
     for (int t = gb + lane; t < ge; t += 64) {
@@ -397,44 +431,10 @@ __global__ __launch_bounds__(kBlock) void k_restrict_p(PDev P, const double* __r
     }
   }
 }
-
-// The columns k_restrict_p leaves out: one workgroup of 1024 threads per column, every thread a few entries (all of
-// them requested at once), wave sums and then the 16 wave totals added in a fixed order.  A single wave walking such a
-// column stride by stride is a chain of ~70 dependent round trips (C5's last level: 4 350 entries per column, 109 us).
-constexpr int kLongThreads = 1024;
-__global__ __launch_bounds__(kLongThreads) void k_restrict_p_long(PDev P, const double* __restrict__ r, double* __restrict__ rc,
-                                                                   const PcgScalars* S, int row0, int row1) {
-  if (S && S->stop) return;
-  __shared__ double sm[kLongThreads / 64][3];
-  const int gb = P.t_long[2 * blockIdx.x], ge = P.t_long[2 * blockIdx.x + 1];
-  const size_t np = (size_t)P.t_n;
-  double acc[3] = {0.0, 0.0, 0.0};
-  for (int t = gb + (int)threadIdx.x; t < ge; t += kLongThreads) {
-    const size_t i = (size_t)P.t_row[t];
-    if (row1 > 0 && ((int)i < row0 || (int)i >= row1)) continue;
-    const double r0 = r[3 * i], r1 = r[3 * i + 1], r2 = r[3 * i + 2];
-    double b[9];
-    load9_pairs(P.t_blk, P.t_blk8, (size_t)t, np, b, P.stream_nt != 0);
-    acc[0] += b[0] * r0 + b[3] * r1 + b[6] * r2;
-    acc[1] += b[1] * r0 + b[4] * r1 + b[7] * r2;
-    acc[2] += b[2] * r0 + b[5] * r1 + b[8] * r2;
-  }
-#pragma unroll
-  for (int q = 0; q < 3; ++q) {
-    const double v = wave_sum(acc[q]);
-    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6][q] = v;
-  }
-  __syncthreads();
-  if (threadIdx.x < 3) {
-    double v = sm[0][threadIdx.x];
-    for (int w = 1; w < kLongThreads / 64; ++w) v += sm[w][threadIdx.x];
-    rc[3 * (size_t)P.t_col[gb] + threadIdx.x] = v;
-  }
-}
-// r_c = P^T r on the stream (both kernels)
+// r_c = P^T r on the stream
 void launch_restrict_p(hipStream_t s, const PDev& P, const double* r, double* rc, const PcgScalars* S, int row0, int row1) {
-  SGO_LAUNCH(k_restrict_p, dim3(grid_for(P.t_ngrp, kWavesPerBlock)), dim3(kBlock), 0, s, P, r, rc, S, row0, row1);
-  if (P.t_nlong > 0) SGO_LAUNCH(k_restrict_p_long, dim3(P.t_nlong), dim3(kLongThreads), 0, s, P, r, rc, S, row0, row1);
+  const int nb = grid_for(P.t_ngrp, kWavesPerBlock);
+  SGO_LAUNCH(k_restrict_p, dim3(nb + P.t_nlong), dim3(kBlock), 0, s, P, r, rc, S, row0, row1, nb);
 }
 
 // x_i += sum over the entries e of row i of P_e (c1 u1 + c2 u2)[col(e)]  (+ xadd_i)
@@ -492,6 +492,361 @@ __global__ __launch_bounds__(kBlock) void k_prolong_p(int n, PDev P, const doubl
         acc[0] += xadd[o]; acc[1] += xadd[o + 1]; acc[2] += xadd[o + 2];
       }
       x[o] += acc[0]; x[o + 1] += acc[1]; x[o + 2] += acc[2];
+    }
+  }
+}
+
+__device__ __forceinline__ int find_sorted(const int* __restrict__ v, int lo, int hi, int key) {   // position of key in v[lo, hi) or -1
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    const int x = v[mid];
+    if (x == key) return mid;
+    if (x < key) lo = mid + 1;
+    else hi = mid;
+  }
+  return -1;
+}
+
+// ------------------------------------------------------------------ folded V-cycle
+// One damped block-Jacobi sweep before and after the coarse correction, S = I - w D^-1 A, first sweep from zero:
+//   x1 = w D^-1 r;  r1 = r - A x1 = S^T r;  e = P B_c P^T r1;  z = S (x1 + e) + w D^-1 r
+//      = [x1 + w D^-1 r1]  +  (S P) B_c (S P)^T r
+// i.e. the multiplicative cycle IS an additive one with the transfer operator P~ = S P = P - w D^-1 (A P) -- whose
+// blocks follow from A P, which the Galerkin product makes anyway -- and the two-sweep term M2 r = x1 + w D^-1 (r - A x1),
+// which does not depend on the coarse correction.  A level then costs two launches on the critical path of the cycle
+// (restriction with P~^T, prolongation with P~) instead of four (sweep + residual, restriction, prolongation, sweep):
+// on level 0 (small graphs only, see amg_create) the M2 term is the level-0 Jacobi pass -- one pass instead of residual pass +
+// sweep --; on the coarser levels it is folded into the prolongation launch (k_up_fold: the row's slots of A and its entries of P~ in one list).
+// Same preconditioner in exact arithmetic (B_c: the coarser levels' cycle, recursively the same), symmetric as before
+// (restriction and prolongation read the same rounded fp32 values of P~).
+struct FoldDev {   // pattern of P~ (= that of A P); arrays addressed by GLOBAL A P entry numbers f (row-owner mode: shifted)
+  int f_lo = 0, f_hi = 0;      // entries held (this rank's rows' in row-owner mode)
+  const int* row = nullptr;    // fine row of entry f
+  const int* col = nullptr;    // coarse column of entry f
+  int* ap2p = nullptr;         // entry of P at the same (row, column), -1: none
+  int* st_pos = nullptr;       // position of f in column order, 0-based within the entries held
+};
+struct UpDev {     // levels >= 1: per row its slots of A, then its entries of P~, as ONE row-major list
+  int n = 0, ngrp = 0;
+  const int* row = nullptr;
+  const int* idx = nullptr;    // slot k >= 0, or ~f for entry f of P~
+  const int* col = nullptr;    // column of the slot / coarse column of the entry
+  const int* grp = nullptr;    // wave groups aligned to rows
+};
+
+__global__ __launch_bounds__(kBlock) void k_fold_match(FoldDev F, const int* __restrict__ p_rowptr, const int* __restrict__ p_col,
+                                                       unsigned long long* __restrict__ keys) {
+  for (int f = F.f_lo + blockIdx.x * kBlock + threadIdx.x; f < F.f_hi; f += gridDim.x * kBlock) {
+    const int i = F.row[f], c = F.col[f];
+    F.ap2p[f] = find_sorted(p_col, p_rowptr[i], p_rowptr[i + 1], c);
+    keys[f - F.f_lo] = ((unsigned long long)(unsigned)c << 32) | (unsigned)(f - F.f_lo);   // (column, row-major rank): sorted = column order
+  }
+}
+__global__ __launch_bounds__(kBlock) void k_fold_unpack(FoldDev F, const unsigned long long* __restrict__ sorted, int* __restrict__ t_row,
+                                                        int* __restrict__ t_col) {
+  const int nf = F.f_hi - F.f_lo;
+  for (int t = blockIdx.x * kBlock + threadIdx.x; t < nf; t += gridDim.x * kBlock) {
+    const unsigned long long k = sorted[t];
+    const int f = F.f_lo + (int)(unsigned)(k & 0xffffffffull);
+    F.st_pos[f] = t;
+    t_col[t] = (int)(k >> 32);
+    t_row[t] = F.row[f];
+  }
+}
+// ptr[c] = first position of column c in the sorted keys (c = 0 .. nc; ptr[nc] = nf)
+__global__ __launch_bounds__(kBlock) void k_fold_colptr(const unsigned long long* __restrict__ sorted, int nf, int nc, int* __restrict__ ptr) {
+  for (int c = blockIdx.x * kBlock + threadIdx.x; c <= nc; c += gridDim.x * kBlock) {
+    const unsigned long long key = (unsigned long long)(unsigned)c << 32;
+    int lo = 0, hi = nf;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (sorted[mid] < key) lo = mid + 1;
+      else hi = mid;
+    }
+    ptr[c] = lo;
+  }
+}
+// the wave groups longer than kLongColumn (single long columns): their ranges, in any order (one workgroup each later on)
+__global__ __launch_bounds__(kBlock) void k_fold_long(const int* __restrict__ grp, int ngrp, int* __restrict__ count, int* __restrict__ ranges,
+                                                      int cap) {
+  for (int g = blockIdx.x * kBlock + threadIdx.x; g < ngrp; g += gridDim.x * kBlock) {
+    const int b = grp[g], e = grp[g + 1];
+    if (e - b > kLongColumn) {
+      const int q = atomicAdd(count, 1);
+      if (q < cap) {
+        ranges[2 * q] = b;
+        ranges[2 * q + 1] = e;
+      }
+    }
+  }
+}
+
+// P~_f = P_(row, col) - w D_row^-1 (A P)_f : the row-ordered and the column-ordered fp32 copies the folded cycle streams
+__global__ __launch_bounds__(kBlock) void k_ptilde_values(FoldDev F, const double* __restrict__ apblk, const double* __restrict__ pblk,
+                                                          const double* __restrict__ dinv, double omega, PDev PS) {
+  for (int f = F.f_lo + blockIdx.x * kBlock + threadIdx.x; f < F.f_hi; f += gridDim.x * kBlock) {
+    const size_t i = (size_t)F.row[f];
+    const int e = F.ap2p[f];
+    const size_t tp = (size_t)F.st_pos[f];
+    const double* di = dinv + 6 * i;
+    double a[9], o[9];
+    load9(apblk, (size_t)f, a);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      o[c] = -omega * (di[0] * a[c] + di[1] * a[3 + c] + di[2] * a[6 + c]);
+      o[3 + c] = -omega * (di[1] * a[c] + di[3] * a[3 + c] + di[4] * a[6 + c]);
+      o[6 + c] = -omega * (di[2] * a[c] + di[4] * a[3 + c] + di[5] * a[6 + c]);
+    }
+    if (e >= 0) {
+#pragma unroll
+      for (int c = 0; c < 9; ++c) o[c] += pblk[9 * (size_t)e + c];
+    }
+    const sgo_f4 q0 = {(float)o[0], (float)o[1], (float)o[2], (float)o[3]}, q1 = {(float)o[4], (float)o[5], (float)o[6], (float)o[7]};
+    sgo_f4* rq = reinterpret_cast<sgo_f4*>(PS.r_blk);
+    sgo_f4* tq = reinterpret_cast<sgo_f4*>(PS.t_blk);
+    rq[f] = q0;
+    rq[(size_t)PS.r_n + f] = q1;
+    tq[tp] = q0;
+    tq[(size_t)PS.t_n + tp] = q1;
+    PS.r_blk8[f] = (float)o[8];
+    PS.t_blk8[tp] = (float)o[8];
+  }
+}
+
+// Level 0: z_i = y_i + sum over the entries f of row i of P~_f (c1 u1 + c2 u2)[col(f)]; optional partials of dotA . z, dotA2 . z
+// (P: the view of P~ -- row / col / r_grp / r_blk of the folded operator; rows outside [row0, row1) are another rank's).
+// Workgroups of 1024 threads: the consumer of the dot products re-reduces one partial sum per WORKGROUP in every one of its
+// own workgroups, so there should be a few hundred of them -- while a wave should not walk more than two or three groups,
+// each a chain of three dependent round trips (512 workgroups of 256 threads: 28 us on C4 instead of 12).
+constexpr int kFoldThreads = 1024;
+__global__ __launch_bounds__(kFoldThreads, 2) void k_prolong_fold(PDev P, const double* __restrict__ u1, SpmvRatio r1,
+                                                               const double* __restrict__ u2, SpmvRatio r2, const double* __restrict__ y,
+                                                               double* __restrict__ out, const PcgScalars* S, const double* __restrict__ dotA,
+                                                               const double* __restrict__ dotA2, double* __restrict__ partials, int row0,
+                                                               int row1) {
+  constexpr int NW = kFoldThreads / 64;
+  __shared__ double sm[4][NW];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // XCD-aware walk (group_walk's rule) for NW waves per workgroup
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
+  const int glo = (int)(((long long)P.r_ngrp * xcd) >> 3), gend = (int)(((long long)P.r_ngrp * (xcd + 1)) >> 3);
+  const int gstride = per_xcd * NW;
+  int g = glo + slot * NW + wave;
+  int gb0 = 0, ge0 = 0;   // requested before the stop flag is waited for (see k_restrict_p)
+  if (g < gend) {
+    gb0 = P.r_grp[g];
+    ge0 = P.r_grp[g + 1];
+  }
+  if (S && S->stop) return;
+  double c1 = 1.0, c2 = 0.0;
+  if (r1.num || u2) {   // ratios of partial sums (K-cycle below): every workgroup reduces them in the same fixed order
+    const double* const parts[4] = {r1.num ? r1.den : nullptr, r1.num, (u2 && r2.num) ? r2.den : nullptr, u2 ? r2.num : nullptr};
+    const int cnt[4] = {r1.n_den, r1.n_num, r2.n_den, r2.n_num};
+    double v[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      double t = 0.0;
+      if (parts[c])
+        for (int i = threadIdx.x; i < cnt[c]; i += kFoldThreads) t += parts[c][i];
+      t = wave_sum(t);
+      if (lane == 0) sm[c][wave] = t;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      double t = sm[c][0];
+#pragma unroll
+      for (int k = 1; k < NW; ++k) t += sm[c][k];
+      v[c] = t;
+    }
+    __syncthreads();
+    if (r1.num) c1 = (v[0] > 0.0 && isfinite(v[0]) && isfinite(v[1])) ? v[1] / v[0] : 0.0;
+    if (u2) c2 = (v[2] > 0.0 && isfinite(v[2]) && isfinite(v[3])) ? v[3] / v[2] : 0.0;
+  }
+  const size_t np = (size_t)P.r_n;
+  double dotacc[2] = {0.0, 0.0};
+  // A wave walks its groups with the NEXT group's bounds and first 64 entries already requested while the current group
+  // is worked on (two groups per wave on C4: four dependent round trips instead of six).
+  const sgo_f4* __restrict__ bq = reinterpret_cast<const sgo_f4*>(P.r_blk);
+  int gb = gb0, ge = ge0;
+  int n_key = -1 - lane, n_col = 0;
+  sgo_f4 n_q0 = {0.f, 0.f, 0.f, 0.f}, n_q1 = {0.f, 0.f, 0.f, 0.f};
+  float n_f8 = 0.f;
+  auto request = [&](int b0, int e0) {   // lane's entry of the group [b0, e0), first stride
+    n_key = -1 - lane;
+    const int e = b0 + lane;
+    if (e < e0) {
+      n_key = P.row[e];
+      n_col = P.col[e];
+      if (P.stream_nt) {
+        n_q0 = __builtin_nontemporal_load(bq + e);
+        n_q1 = __builtin_nontemporal_load(bq + np + e);
+        n_f8 = __builtin_nontemporal_load(P.r_blk8 + e);
+      } else {
+        n_q0 = bq[e];
+        n_q1 = bq[np + e];
+        n_f8 = P.r_blk8[e];
+      }
+    }
+  };
+  if (g < gend) request(gb, ge);
+  while (g < gend) {
+    // current group's first stride: what was requested; then the next group's requests go out
+    int key = n_key;
+    const int col = n_col;
+    const sgo_f4 q0 = n_q0, q1 = n_q1;
+    const float f8 = n_f8;
+    const int cgb = gb, cge = ge;
+    const int gn = g + gstride;
+    if (gn < gend) {
+      gb = P.r_grp[gn];
+      ge = P.r_grp[gn + 1];
+    }
+    if (row1 > 0 && key >= 0 && (key < row0 || key >= row1)) key = -1 - lane;   // multi-GPU: another rank's row
+    double acc[3] = {0.0, 0.0, 0.0};
+    double y0 = 0.0, y1 = 0.0, y2 = 0.0;
+    if (key >= 0) {
+      const size_t a = 3 * (size_t)col, o = 3 * (size_t)key;
+      double w0 = c1 * u1[a], w1 = c1 * u1[a + 1], w2 = c1 * u1[a + 2];
+      if (u2) {
+        w0 += c2 * u2[a]; w1 += c2 * u2[a + 1]; w2 += c2 * u2[a + 2];
+      }
+      y0 = y[o]; y1 = y[o + 1]; y2 = y[o + 2];   // the row's own term, requested before the scan
+      acc[0] = (double)q0.x * w0 + (double)q0.y * w1 + (double)q0.z * w2;
+      acc[1] = (double)q0.w * w0 + (double)q1.x * w1 + (double)q1.y * w2;
+      acc[2] = (double)q1.z * w0 + (double)q1.w * w1 + (double)f8 * w2;
+    }
+    if (gn < gend) request(gb, ge);
+    for (int e = cgb + 64 + lane; e < cge; e += 64) {   // a row with more than 64 entries (its own group): the further strides
+      const int k2 = P.row[e];
+      if (row1 > 0 && (k2 < row0 || k2 >= row1)) continue;
+      key = k2;
+      const size_t a = 3 * (size_t)P.col[e];
+      double w0 = c1 * u1[a], w1 = c1 * u1[a + 1], w2 = c1 * u1[a + 2];
+      if (u2) {
+        w0 += c2 * u2[a]; w1 += c2 * u2[a + 1]; w2 += c2 * u2[a + 2];
+      }
+      double b[9];
+      load9_pairs(P.r_blk, P.r_blk8, (size_t)e, np, b, P.stream_nt != 0);
+      acc[0] += b[0] * w0 + b[1] * w1 + b[2] * w2;
+      acc[1] += b[3] * w0 + b[4] * w1 + b[5] * w2;
+      acc[2] += b[6] * w0 + b[7] * w1 + b[8] * w2;
+      const size_t o = 3 * (size_t)key;
+      y0 = y[o]; y1 = y[o + 1]; y2 = y[o + 2];
+    }
+    seg_scan<3>(key, acc, lane);
+    const int kn = __shfl_down(key, 1);
+    if (key >= 0 && (lane == 63 || kn != key)) {
+      const size_t o = 3 * (size_t)key;
+      const double o0 = y0 + acc[0], o1 = y1 + acc[1], o2 = y2 + acc[2];
+      out[o] = o0; out[o + 1] = o1; out[o + 2] = o2;
+      if (dotA) dotacc[0] += dotA[o] * o0 + dotA[o + 1] * o1 + dotA[o + 2] * o2;
+      if (dotA2) dotacc[1] += dotA2[o] * o0 + dotA2[o + 1] * o1 + dotA2[o + 2] * o2;
+    }
+    g = gn;
+  }
+  if (partials) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const double t = wave_sum(dotacc[i]);
+      if (lane == 0) sm[i][wave] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        double t = sm[i][0];
+#pragma unroll
+        for (int k = 1; k < NW; ++k) t += sm[i][k];
+        partials[(size_t)i * kMaxPartials + blockIdx.x] = t;
+      }
+    }
+  }
+}
+
+// Levels >= 1: out_i = M2 b |_i + sum_f P~_f (c1 u1 + c2 u2)[col(f)],  M2 b = x1 + w D^-1 (b - A x1), x1 = w D^-1 b
+// (the operand of a slot (i, j) is made on the fly from b_j and D_j^-1: nothing but b and the coarse solution is read)
+__global__ __launch_bounds__(kBlock) void k_up_fold(BsrDev A, UpDev U, PDev PS, const double* __restrict__ b, double omega,
+                                                    const double* __restrict__ u1, SpmvRatio r1, const double* __restrict__ u2,
+                                                    SpmvRatio r2, double* __restrict__ out, const PcgScalars* S,
+                                                    const double* __restrict__ xadd) {
+  int g, gend, gstride;
+  group_walk(U.ngrp, &g, &gend, &gstride);
+  int gb0 = 0, ge0 = 0;
+  if (g < gend) {
+    gb0 = U.grp[g];
+    ge0 = U.grp[g + 1];
+  }
+  if (S && S->stop) return;
+  double c1 = 1.0, c2 = 0.0;
+  if (r1.num || u2) {
+    const double* const parts[4] = {r1.num ? r1.den : nullptr, r1.num, (u2 && r2.num) ? r2.den : nullptr,
+                                    u2 ? r2.num : nullptr};
+    const int cnt[4] = {r1.n_den, r1.n_num, r2.n_den, r2.n_num};
+    double v[4];
+    block_reduce_parts_n<4>(parts, cnt, v);
+    if (r1.num) c1 = (v[0] > 0.0 && isfinite(v[0]) && isfinite(v[1])) ? v[1] / v[0] : 0.0;
+    if (u2) c2 = (v[2] > 0.0 && isfinite(v[2]) && isfinite(v[3])) ? v[3] / v[2] : 0.0;
+  }
+  const int lane = threadIdx.x & 63;
+  const size_t ns = (size_t)A.nslot, np = (size_t)PS.r_n;
+  for (bool first = true; g < gend; g += gstride, first = false) {
+    const int gb = first ? gb0 : U.grp[g], ge = first ? ge0 : U.grp[g + 1];
+    double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};   // [0..2] A x1, [3..5] P~ e
+    int key = -1 - lane;
+    for (int t = gb + lane; t < ge; t += 64) {
+      key = U.row[t];
+      const int idx = U.idx[t];
+      const size_t j = (size_t)U.col[t];
+      if (idx >= 0) {
+        const size_t k = (size_t)idx;
+        const double* dj = A.dinv + 6 * j;
+        const double b0 = b[3 * j], b1 = b[3 * j + 1], b2 = b[3 * j + 2];
+        const double x0 = omega * (dj[0] * b0 + dj[1] * b1 + dj[2] * b2);
+        const double x1 = omega * (dj[1] * b0 + dj[3] * b1 + dj[4] * b2);
+        const double x2 = omega * (dj[2] * b0 + dj[4] * b1 + dj[5] * b2);
+        const double2* __restrict__ bp = reinterpret_cast<const double2*>(A.blk);
+        const double2 p0 = bp[k], p1 = bp[ns + k], p2 = bp[2 * ns + k], p3 = bp[3 * ns + k];
+        const double b8 = A.blk[8 * ns + k];
+        acc[0] += p0.x * x0 + p0.y * x1 + p1.x * x2;
+        acc[1] += p1.y * x0 + p2.x * x1 + p2.y * x2;
+        acc[2] += p3.x * x0 + p3.y * x1 + b8 * x2;
+      } else {
+        const size_t f = (size_t)(~idx);
+        double w0 = c1 * u1[3 * j], w1 = c1 * u1[3 * j + 1], w2 = c1 * u1[3 * j + 2];
+        if (u2) {
+          w0 += c2 * u2[3 * j]; w1 += c2 * u2[3 * j + 1]; w2 += c2 * u2[3 * j + 2];
+        }
+        double q[9];
+        load9_pairs(PS.r_blk, PS.r_blk8, f, np, q, false);
+        acc[3] += q[0] * w0 + q[1] * w1 + q[2] * w2;
+        acc[4] += q[3] * w0 + q[4] * w1 + q[5] * w2;
+        acc[5] += q[6] * w0 + q[7] * w1 + q[8] * w2;
+      }
+    }
+    // the row's own right-hand side and block-diagonal inverse, requested before the scan
+    double bi0 = 0.0, bi1 = 0.0, bi2 = 0.0, d0 = 0.0, d1 = 0.0, d2 = 0.0, d3 = 0.0, d4 = 0.0, d5 = 0.0;
+    if (key >= 0) {
+      const size_t i = (size_t)key;
+      bi0 = b[3 * i]; bi1 = b[3 * i + 1]; bi2 = b[3 * i + 2];
+      const double* di = A.dinv + 6 * i;
+      d0 = di[0]; d1 = di[1]; d2 = di[2]; d3 = di[3]; d4 = di[4]; d5 = di[5];
+    }
+    seg_scan<6>(key, acc, lane);
+    const int kn = __shfl_down(key, 1);
+    if (key >= 0 && (lane == 63 || kn != key)) {
+      const size_t o = 3 * (size_t)key;
+      // x1 + w D^-1 (b - A x1) = w D^-1 (2 b - A x1) evaluated as the cycle does: x1 first, then the residual's sweep
+      const double x0 = omega * (d0 * bi0 + d1 * bi1 + d2 * bi2), x1 = omega * (d1 * bi0 + d3 * bi1 + d4 * bi2),
+                   x2 = omega * (d2 * bi0 + d4 * bi1 + d5 * bi2);
+      const double r0 = bi0 - acc[0], rr1 = bi1 - acc[1], rr2 = bi2 - acc[2];
+      double o0 = x0 + omega * (d0 * r0 + d1 * rr1 + d2 * rr2) + acc[3];
+      double o1 = x1 + omega * (d1 * r0 + d3 * rr1 + d4 * rr2) + acc[4];
+      double o2 = x2 + omega * (d2 * r0 + d4 * rr1 + d5 * rr2) + acc[5];
+      if (xadd) {   // (an outer sweep's iterate the folded cycle corrects)
+        o0 += xadd[o]; o1 += xadd[o + 1]; o2 += xadd[o + 2];
+      }
+      out[o] = o0; out[o + 1] = o1; out[o + 2] = o2;
     }
   }
 }
@@ -832,16 +1187,6 @@ struct ApPattern {
   const int* ap_col = nullptr;     // [nap] coarse column of target f (ascending within a row)
   const int* ap_rowptr = nullptr;  // [n + 1]
 };
-__device__ __forceinline__ int find_sorted(const int* __restrict__ v, int lo, int hi, int key) {   // position of key in v[lo, hi) or -1
-  while (lo < hi) {
-    const int mid = (lo + hi) >> 1;
-    const int x = v[mid];
-    if (x == key) return mid;
-    if (x < key) lo = mid + 1;
-    else hi = mid;
-  }
-  return -1;
-}
 // Eight lanes per target: lane q of a target's group takes the candidates q, q + 8, ... of the walk, the matches of one
 // round are ranked by a ballot (candidate order = lane order within a round), so the list keeps the host's order while
 // the walk -- a chain of dependent index loads and a binary search per candidate -- is eight times shorter.
@@ -1815,6 +2160,12 @@ struct AmgLevel {
   GalerkinMap gal;
   bool smoothed = false;    // transfer by the smoothed prolongator P (below) instead of the tentative one
   PDev P;
+  // folded cycle (see "folded V-cycle" above): the transfer operator P~ = (I - w D^-1 A) P as a PDev VIEW (row / col /
+  // r_* / t_* of P~'s pattern, the one of A P), its pattern bookkeeping, and on levels >= 1 the merged list of k_up_fold
+  bool fold = false;
+  PDev PS;
+  FoldDev F;
+  UpDev U;
   // work vectors [n][3]
   double *xs = nullptr, *rs = nullptr;                     // smoother state of cycle()
   double* tR = nullptr;                                    // second residual buffer of multi-sweep smoothing
@@ -1905,6 +2256,11 @@ void launch_coarse_operator(Amg* m, hipStream_t s, AmgLevel& L, AmgLevel& C, boo
                P.ap, L.A, (const double*)nullptr, (const double*)P.blk, P.apblk, (size_t)P.nap, (const int*)nullptr,
                (const int*)L.A.row, row0, P.local_lists ? 0 : row1, 0);   // (local lists hold this rank's products only: no filter)
   }
+  if (L.fold) {
+    Scope sc(m->prof, level0 ? K_PTILDE0 : K_PTILDE, (72.0 + 36.0 + 72.0 + 12.0 + 72.0) * (L.F.f_hi - L.F.f_lo));
+    SGO_LAUNCH(k_ptilde_values, dim3(grid_for((long long)(L.F.f_hi - L.F.f_lo), kBlock)), dim3(kBlock), 0, s, L.F, (const double*)P.apblk,
+               (const double*)P.blk, (const double*)L.A.dinv, m->cfg.omega, L.PS);
+  }
   if (P.local_lists) hipMemsetAsync(C.A.blk, 0, sizeof(double) * 9 * (size_t)C.A.nslot, s);   // targets this rank has no product for
   {
     Scope sc(m->prof, level0 ? K_SA_RAP0 : K_SA_RAP, 156.0 * P.rap.n + 72.0 * C.A.nslot);
@@ -1977,12 +2333,91 @@ CoarseSol fcg(Amg* m, hipStream_t s, int l, const PcgScalars* S) {
 // steps), prolongation fused into the post-smoothing launch on levels >= 1 (separate launch on
 // level 0, where the extra gathers would cost more than the launch).  Optional partials of
 // dotvec . out (and dotvec2 . out).  Returns the grid of the last kernel.
+// The coarse solve for the right-hand side C.bk of level l + 1, as the parent level sees it.
+CoarseSol coarse_solve(Amg* m, hipStream_t s, int l, const PcgScalars* S) {
+  AmgLevel& C = m->lv[l + 1];
+  const int last = (int)m->lv.size() - 1;
+  CoarseSol cs;
+  if (l + 1 == last) {
+    Scope sc(m->prof, K_DENSE_APPLY, 8.0 * m->N * m->N);
+    SGO_LAUNCH(k_dense_apply, dim3(grid_for(m->N, kWavesPerBlock)), dim3(kBlock), 0, s, m->N, m->Np, m->inv, C.bk,
+                       C.xk, S);
+    cs.u1 = C.xk;
+  } else if (l + 1 > m->kdepth && m->lv[l + 1].smoothed) {  // V-cycle below the K-cycle depth; a level whose own
+                                                             // transfer is the tentative one always gets the K-cycle
+    SpmvRatio none;
+    cycle(m, s, l + 1, C.bk, nullptr, none, nullptr, C.xk, nullptr, nullptr, S);
+    cs.u1 = C.xk;
+  } else {
+    cs = fcg(m, s, l + 1, S);
+  }
+  return cs;
+}
+
+// out = cycle(l, rhs) in the folded form (see "folded V-cycle"): restriction with P~^T of the right-hand side itself,
+// coarse solve, prolongation with P~ onto the two-sweep term M2 rhs -- on level 0 the level-0 Jacobi pass; on the coarser
+// levels part of the prolongation launch.
+int cycle_fold(Amg* m, hipStream_t s, int l, const double* rhs, double* out, const double* dotvec, double* dotparts,
+               const PcgScalars* S, const double* dotvec2, int xs0_ready, const double* xadd = nullptr) {
+  AmgLevel& L = m->lv[l];
+  AmgLevel& C = m->lv[l + 1];
+  if (l == 0) {   // (single GPU: multi-GPU runs keep level 0 unfolded)
+    if (!xs0_ready) {   // xs = omega Dinv rhs (normally left by the producer of rhs)
+      Scope sc(m->prof, K_DOT, 96.0 * L.A.n);
+      launch_precond_bj(s, L.A.n, m->S0.dinv, rhs, L.xs, m->cfg.omega);
+    }
+    // M2 rhs = xs + omega Dinv (rhs - H xs): the level-0 Jacobi pass, into rs.  (It does not depend on the coarse levels;
+    // running it BESIDE them on a second stream -- a parallel branch of the captured hipGraph -- was measured: the fork and
+    // join cost 25 us per PCG iteration on this runtime, C2 1.45 -> 1.95 ms per GN iteration.)
+    Spmv0Args b{};
+    b.x = L.xs; b.b = rhs; b.y = L.rs; b.omega = m->cfg.omega; b.S = S;
+    const bool f32 = m->T0.ntile > 0 && m->S0.fblk != nullptr;
+    Scope sc(m->prof, m->T0.ntile > 0 ? (f32 ? K_SPMV0T_JACOBI_F32 : K_SPMV0T_JACOBI) : K_SPMV0_JACOBI,
+             (f32 ? 40.0 : 76.0) * m->S0.npairs + 168.0 * m->S0.n);
+    launch_spmv0_any(s, m->S0, m->T0, S0_JACOBI, b);
+  }
+  {
+    Scope sc(m->prof, l == 0 ? K_RESTRICT_P0 : K_RESTRICT_P, 44.0 * L.PS.t_n + 24.0 * L.A.n + 24.0 * L.nc);
+    launch_restrict_p(s, L.PS, rhs, C.bk, S, 0, 0);
+  }
+  const CoarseSol cs = coarse_solve(m, s, l, S);
+  if (l > 0) {
+    Scope sc(m->prof, K_UP_FOLD, 80.0 * L.A.nslot + 44.0 * L.PS.r_n + 100.0 * L.A.n);
+    const int grid = grid_for(L.U.ngrp, kWavesPerBlock);
+    SGO_LAUNCH(k_up_fold, dim3(grid), dim3(kBlock), 0, s, L.A, L.U, L.PS, rhs, m->cfg.omega, cs.u1, cs.c1, cs.u2, cs.c2, out, S, xadd);
+    return grid;
+  }
+  // (the dot products' partial sums are re-reduced by every workgroup of the consumer: a few hundred of them, not thousands)
+  const int grid = std::min(grid_for(L.PS.r_ngrp, kFoldThreads / 64), 512);
+  Scope sc(m->prof, K_PROLONG_FOLD0, 44.0 * L.PS.r_n + 72.0 * L.A.n);
+  SGO_LAUNCH(k_prolong_fold, dim3(grid), dim3(kFoldThreads), 0, s, L.PS, cs.u1, cs.c1, cs.u2, cs.c2, (const double*)L.rs, out, S, dotvec,
+             dotvec2, dotvec ? dotparts : nullptr, 0, 0);
+  return grid;
+}
+
 int cycle(Amg* m, hipStream_t s, int l, const double* rhs, const double* rhs_sub, const SpmvRatio& rhs_c,
           double* rhs_out, double* out, const double* dotvec, double* dotparts, const PcgScalars* S,
           const double* dotvec2, int xs0_ready) {
   AmgLevel& L = m->lv[l];
   AmgLevel& C = m->lv[l + 1];
-  const int last = (int)m->lv.size() - 1;
+  {
+    const int nu_l = (l > 0 && L.tR && L.smoothed) ? std::max(1, m->cfg.nu_coarse) : 1;
+    if (L.fold && nu_l == 1 && !rhs_sub && (l == 0 ? !(m->halo || m->comm) : !dotvec)) return cycle_fold(m, s, l, rhs, out, dotvec, dotparts, S, dotvec2, xs0_ready);
+    if (L.fold && nu_l == 2 && !rhs_sub && l > 0 && !dotvec) {
+      // two sweeps per side = one explicit sweep around the folded cycle: S E S with E the folded cycle's error propagator
+      {   // xs = omega Dinv rhs, rs = rhs - A xs
+        SpmvArgs a{};
+        a.b = rhs; a.y = L.rs; a.y2 = L.xs; a.omega = m->cfg.omega; a.S = S;
+        Scope sc(m->prof, K_SPMV_PRE_RESID, 80.0 * L.A.nslot + 120.0 * L.A.n);
+        launch_spmv_ex(s, L.A, SPMV_PRE_RESID, a);
+      }
+      cycle_fold(m, s, l, L.rs, L.tR, nullptr, nullptr, S, nullptr, 0, L.xs);   // tR = xs + cycle(rs)
+      SpmvArgs a{};
+      a.x = L.tR; a.b = rhs; a.y = out; a.omega = m->cfg.omega; a.S = S;
+      Scope sc(m->prof, K_SPMV_JACOBI, 80.0 * L.A.nslot + 120.0 * L.A.n);
+      return launch_spmv_ex(s, L.A, SPMV_JACOBI, a);
+    }
+  }
   const double* rhs_eff = rhs;
   const HaloDev* H = l == 0 ? m->halo : nullptr;           // multi-GPU, row-owner mode
   const bool sharded0 = l == 0 && m->comm != nullptr && !H;   // multi-GPU, all-reduce mode
@@ -2051,20 +2486,7 @@ int cycle(Amg* m, hipStream_t s, int l, const double* rhs, const double* rhs_sub
     std::string e;
     if (!(H ? H->comm : m->comm)->allreduce_f64(C.bk, 3 * (size_t)C.A.n, s, &e)) m->comm_failed = true;
   }
-  CoarseSol cs;
-  if (l + 1 == last) {
-    Scope sc(m->prof, K_DENSE_APPLY, 8.0 * m->N * m->N);
-    SGO_LAUNCH(k_dense_apply, dim3(grid_for(m->N, kWavesPerBlock)), dim3(kBlock), 0, s, m->N, m->Np, m->inv, C.bk,
-                       C.xk, S);
-    cs.u1 = C.xk;
-  } else if (l + 1 > m->kdepth && m->lv[l + 1].smoothed) {  // V-cycle below the K-cycle depth; a level whose own
-                                                             // transfer is the tentative one always gets the K-cycle
-    SpmvRatio none;
-    cycle(m, s, l + 1, C.bk, nullptr, none, nullptr, C.xk, nullptr, nullptr, S);
-    cs.u1 = C.xk;
-  } else {
-    cs = fcg(m, s, l + 1, S);
-  }
+  const CoarseSol cs = coarse_solve(m, s, l, S);
   SpmvArgs a{};
   a.x = L.xs; a.b = rhs_eff; a.y = out; a.omega = m->cfg.omega; a.S = S;
   if (dotvec) {
@@ -2166,6 +2588,7 @@ void amg_destroy(Amg* m) {
   delete m;   // the device memory belongs to the caller's arena
 }
 
+
 int amg_update(Amg* m, hipStream_t s, std::string* err) {
   const int last = (int)m->lv.size() - 1;
   {
@@ -2229,10 +2652,15 @@ int amg_debug_coarse_rhs(Amg* m, hipStream_t s, const double* r, double* out_dev
   AmgLevel& C = m->lv[1];
   const int n3c = 3 * C.A.n;
   if (cap3 < n3c) return -1;
+  const bool sharded = m->comm != nullptr;
+  if (L.fold) {   // folded cycle: the restriction with P~^T of r itself (the same vector in exact arithmetic)
+    launch_restrict_p(s, L.PS, r, C.bk, nullptr, sharded ? m->row0 : 0, sharded ? m->row1 : 0);
+    hipMemcpyAsync(out_dev, C.bk, sizeof(double) * n3c, hipMemcpyDeviceToDevice, s);
+    return n3c;
+  }
   launch_precond_bj(s, L.A.n, m->S0.dinv, r, L.xs, m->cfg.omega);
   Spmv0Args a{};
   a.x = L.xs; a.b = r; a.y = L.rs;
-  const bool sharded = m->comm != nullptr;
   if (sharded) {
     a.u0 = m->u0; a.u1 = m->u1;
     hipMemsetAsync(L.rs, 0, sizeof(double) * 3 * (size_t)L.A.n, s);
@@ -2305,6 +2733,12 @@ AmgConfig amg_effective_config(const AmgConfig& cfg_in, int n, int nslot) {
   cfg.nu_coarse = nslot >= 1000000 ? 2 : 1;
   if (const char* e = std::getenv("SGO_AMG_SMOOTH")) cfg.smooth = std::atoi(e) != 0;
   if (const char* e = std::getenv("SGO_AMG_LISTS")) cfg.lists_on_device = std::string(e) != "host";
+  if (const char* e = std::getenv("SGO_AMG_FOLD")) cfg.fold = std::atoi(e) != 0;
+  cfg.fold = cfg.fold && cfg.smooth && cfg.lists_on_device;
+  // the folded cycle has ONE sweep per level folded into the transfers (two would need the pattern of A A P); what it saves
+  // per PCG iteration outweighs the iterations a second coarse sweep saves (C4: 22 -> 28 iterations at 150 -> ... us each)
+  if (cfg.fold && std::getenv("SGO_AMG_FOLD_NU1")) cfg.nu_coarse = 1;
+  if (const char* e = std::getenv("SGO_AMG_NU")) cfg.nu_coarse = std::max(1, std::atoi(e));
   // larger graphs afford a larger dense coarsest level (its inverse costs O(N^3) once per GN
   // iteration, one K-cycle level less halves the coarse-level launches of every PCG iteration).  A SMALLER dense level
   // (one more sparse level) was measured in round 3: the dense inverse gets cheaper but the cycle weaker -- stopping at
@@ -2578,6 +3012,106 @@ Amg* amg_create(hipStream_t s, const BsrDev& A0, const Sym0Dev& S0, const Tile0D
       if (l == 0) m->level0_bytes += (long long)(72 * (size_t)P.np + 72 * npl + 72 * (F1 - F0) + 8 * (V1 - V0) + 12 * npl + 8 * (F1 - F0));
       l0_own = {own, (int)F0, (int)F1};
       l0_dev = {d_ap_rowptr, d_ap_col, d_ap_row, d_t_ptr, d_t_idx};
+      // (Level 0 is folded only where it is itself launch-bound: P~ has the pattern of A P, twice the entries of P, and on
+      // large graphs streaming it twice per cycle costs what the saved launch and pass bring -- C4: restriction + prolongation
+      // 14 + 20 us with P~ against 11 + 9 us with P.  Multi-GPU runs keep level 0 unfolded as well.)
+      if (m->cfg.fold && sa.lists_on_device && F1 > F0 && (l > 0 || (!halo && n <= m->cfg.fold0_rows))) {
+        // ---- folded cycle: pattern bookkeeping of P~ (the pattern of A P) -- which entry of P sits at the same place, the
+        // column order (a device radix sort of (column, row-major rank) keys instead of a host counting sort), its wave
+        // groups and long columns -- and the two streamed fp32 copies
+        const size_t nf = F1 - F0;
+        FoldDev& Fd = L.F;
+        Fd.f_lo = (int)F0;
+        Fd.f_hi = (int)F1;
+        Fd.row = d_ap_row;
+        Fd.col = d_ap_col;
+        int* a2p = dev_alloc<int>(m->pool, nf);
+        int* stp = dev_alloc<int>(m->pool, nf);
+        unsigned long long* keys = dev_alloc<unsigned long long>(m->pool, nf);
+        unsigned long long* sorted = dev_alloc<unsigned long long>(m->pool, nf);
+        int bits = 33;
+        while (bits < 64 && (1ull << (bits - 32)) <= (unsigned long long)nc) ++bits;
+        const size_t tmp_bytes = sort_u64_temp_bytes(nf, bits);
+        void* tmp = tmp_bytes ? m->pool->take(tmp_bytes) : nullptr;
+        int* st_row = dev_alloc<int>(m->pool, nf);
+        int* st_col = dev_alloc<int>(m->pool, nf);
+        int* st_ptr = dev_alloc<int>(m->pool, (size_t)nc + 1);
+        constexpr int kLongCap = 4096;
+        int* d_cnt = dev_alloc<int>(m->pool, 1);
+        int* ranges = dev_alloc<int>(m->pool, 2 * (size_t)kLongCap);
+        float* sb = dev_alloc<float>(m->pool, 9 * nf + 4);
+        float* tb = dev_alloc<float>(m->pool, 9 * nf + 4);
+        if (!a2p || !stp || !keys || !sorted || !tmp || !st_row || !st_col || !st_ptr || !d_cnt || !ranges || !sb || !tb)
+          return fail("amg_create: out of device memory");
+        Fd.ap2p = a2p - F0;
+        Fd.st_pos = stp - F0;
+        SGO_LAUNCH(k_fold_match, dim3(grid_for((long long)nf, kBlock)), dim3(kBlock), 0, s, Fd, (const int*)P.rowptr, (const int*)P.col, keys);
+        if (!sort_u64(tmp, tmp_bytes, (const uint64_t*)keys, (uint64_t*)sorted, nf, bits, s)) return fail("amg_create: device sort failed");
+        SGO_LAUNCH(k_fold_unpack, dim3(grid_for((long long)nf, kBlock)), dim3(kBlock), 0, s, Fd, (const unsigned long long*)sorted, st_row, st_col);
+        SGO_LAUNCH(k_fold_colptr, dim3(grid_for((long long)nc + 1, kBlock)), dim3(kBlock), 0, s, (const unsigned long long*)sorted, (int)nf, nc, st_ptr);
+        int st_ngrp = 0;
+        int* st_grp = dev_make_groups(s, m->pool, st_ptr, nc, (int)nf, &st_ngrp);
+        if (!st_grp) return fail("amg_create: out of device memory");
+        hipMemsetAsync(d_cnt, 0, sizeof(int), s);
+        SGO_LAUNCH(k_fold_long, dim3(grid_for((long long)st_ngrp, kBlock)), dim3(kBlock), 0, s, (const int*)st_grp, st_ngrp, d_cnt, ranges, kLongCap);
+        int nlong = 0;
+        if (hipMemcpyAsync(&nlong, d_cnt, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+          return fail("amg_create: folded-transfer kernels failed");
+        std::vector<int> s_grp = make_groups(std::vector<int>(sa.ap_rowptr.begin() + orow0, sa.ap_rowptr.begin() + orow1 + 1));
+        PDev& PS = L.PS;
+        PS = PDev();
+        PS.np = (int)nf;
+        PS.stream_nt = nf >= 200000 ? 1 : 0;
+        PS.row = d_ap_row;
+        PS.col = d_ap_col;
+        PS.r_n = PS.t_n = (int)nf;
+        PS.r_blk = sb - 4 * F0;
+        PS.r_blk8 = sb + 8 * nf - F0;
+        PS.t_blk = tb;
+        PS.t_blk8 = tb + 8 * nf;
+        PS.r_grp = dev_upload(m->pool, s_grp, s);
+        PS.r_ngrp = (int)s_grp.size() - 1;
+        PS.t_row = st_row;
+        PS.t_col = st_col;
+        PS.t_grp = st_grp;
+        PS.t_ngrp = st_ngrp;
+        PS.t_long = ranges;
+        PS.t_nlong = nlong;
+        if (!PS.r_grp) return fail("amg_create: out of device memory");
+        if (l > 0) {
+          // levels >= 1: the slots of A and the entries of P~ of every row as one list (k_up_fold)
+          std::vector<int> u_ptr((size_t)n + 1, 0), u_row, u_idx, u_col;
+          for (int i = 0; i < n; ++i) u_ptr[(size_t)i + 1] = u_ptr[i] + (H.rowptr[i + 1] - H.rowptr[i]) + (sa.ap_rowptr[i + 1] - sa.ap_rowptr[i]);
+          u_row.resize((size_t)u_ptr[n]);
+          u_idx.resize((size_t)u_ptr[n]);
+          u_col.resize((size_t)u_ptr[n]);
+          for (int i = 0; i < n; ++i) {
+            int q = u_ptr[i];
+            for (int k = H.rowptr[i]; k < H.rowptr[i + 1]; ++k, ++q) {
+              u_row[q] = i;
+              u_idx[q] = k;
+              u_col[q] = H.col[k];
+            }
+            for (int f = sa.ap_rowptr[i]; f < sa.ap_rowptr[i + 1]; ++f, ++q) {
+              u_row[q] = i;
+              u_idx[q] = ~f;
+              u_col[q] = sa.ap_col[f];
+            }
+          }
+          std::vector<int> u_grp = make_groups(u_ptr);
+          UpDev& U = L.U;
+          U.n = u_ptr[n];
+          U.row = dev_upload(m->pool, u_row, s);
+          U.idx = dev_upload(m->pool, u_idx, s);
+          U.col = dev_upload(m->pool, u_col, s);
+          U.grp = dev_upload(m->pool, u_grp, s);
+          U.ngrp = (int)u_grp.size() - 1;
+          if (!U.row || !U.idx || !U.col || !U.grp) return fail("amg_create: out of device memory");
+        }
+        if (hipStreamSynchronize(s) != hipSuccess) return fail("amg_create: upload failed");   // (host lists of this scope)
+        L.fold = nlong <= kLongCap;
+        if (l == 0) m->level0_bytes += (long long)(72 * nf + 28 * nf);
+      }
       if (l == 0 && halo) {
         // the entries of P in every rank's boundary rows: what A P of a neighbour's rows gathers from this rank's P
         std::vector<std::vector<int>> pe((size_t)halo->G);

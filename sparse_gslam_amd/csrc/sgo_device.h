@@ -201,6 +201,14 @@ __device__ __forceinline__ void load_block(const BsrDev& A, size_t k, double (&b
 // Map (block, wave) -> first group and stride so that XCD x (blocks with blockIdx % 8 == x under
 // the observed round-robin dispatch; speed only, never correctness) walks the contiguous band
 // [x * ngrp / 8, (x + 1) * ngrp / 8) of groups.
+// (nblocks: the workgroups that walk -- a multiple of 8; a launch may carry more behind them with another job)
+__device__ __forceinline__ void group_walk_n(int ngrp, int nblocks, int* first, int* last, int* stride) {
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd = nblocks >> 3;
+  const int lo = (int)(((long long)ngrp * xcd) >> 3), hi = (int)(((long long)ngrp * (xcd + 1)) >> 3);
+  *first = lo + slot * kWavesPerBlock + (threadIdx.x >> 6);
+  *last = hi;
+  *stride = per_xcd * kWavesPerBlock;
+}
 __device__ __forceinline__ void group_walk(int ngrp, int* first, int* last, int* stride) {
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
   const int lo = (int)(((long long)ngrp * xcd) >> 3), hi = (int)(((long long)ngrp * (xcd + 1)) >> 3);

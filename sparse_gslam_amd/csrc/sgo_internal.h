@@ -343,6 +343,11 @@ enum KernelId : int {
   K_GALERKIN0,
   K_RESTRICT0,
   K_PROLONG0,
+  // folded cycle (sgo_amg.hip): values of the folded transfer operator, its prolongation launches
+  K_PTILDE,
+  K_PTILDE0,
+  K_UP_FOLD,
+  K_PROLONG_FOLD0,
   K_COUNT
 };
 extern const char* const kKernelNames[K_COUNT];
