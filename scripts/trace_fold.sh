@@ -2,7 +2,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp; export TMPDIR=/tmp
 O=$R/gpurun_out
 rm -rf $O/trace_fold
-rocprofv3 --kernel-trace --output-format csv -d $O/trace_fold -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline > $O/trace_fold.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $O/trace_fold -- python3 $R/bench.py --config ${CFG:-C4} --steps 1 --warmup 1 --no-cpu-baseline --no-roofline > $O/trace_fold.log 2>&1
 f=$(find $O/trace_fold -name "*kernel_trace.csv" | head -1)
 python3 - $f <<'PY'
 import csv, sys
