@@ -363,14 +363,15 @@ __global__ __launch_bounds__(kBlock) void k_block_products(ProdMap mp, BsrDev XA
 // behind them, ONE WORKGROUP each in the same launch (every thread a few entries, all of them requested at once; wave sums,
 // then the wave totals added in a fixed order): a single wave walking such a column stride by stride is a chain of ~70
 // dependent round trips (C5's last level: 4 350 entries per column, 109 us), a launch of its own costs 4 us per cycle.
-__global__ __launch_bounds__(kBlock) void k_restrict_p(PDev P, const double* __restrict__ r, double* __restrict__ rc,
-                                                       const PcgScalars* S, int row0, int row1, int nb_main) {
+// (block: this workgroup's index within the restriction's part of the launch)
+__device__ __forceinline__ void restrict_groups(const PDev& P, const double* __restrict__ r, double* __restrict__ rc,
+                                                const PcgScalars* S, int row0, int row1, int nb_main, int block) {
   const int lane = threadIdx.x & 63;
   const size_t np = (size_t)P.t_n;
-  if ((int)blockIdx.x >= nb_main) {   // a long column
+  if (block >= nb_main) {   // a long column
     if (S && S->stop) return;
     __shared__ double sm[kWavesPerBlock][3];
-    const int lc = (int)blockIdx.x - nb_main;
+    const int lc = block - nb_main;
     const int gb = P.t_long[2 * lc], ge = P.t_long[2 * lc + 1];
     double acc[3] = {0.0, 0.0, 0.0};
     for (int t = gb + (int)threadIdx.x; t < ge; t += kBlock) {
@@ -399,7 +400,7 @@ __global__ __launch_bounds__(kBlock) void k_restrict_p(PDev P, const double* __r
   // (as in k_spmv: the first group's bounds are requested before the stop flag is waited for -- one dependent
   // round trip less in a launch that is a chain of four)
   int g, gend, gstride;
-  group_walk_n(P.t_ngrp, nb_main, &g, &gend, &gstride);
+  group_walk_b(P.t_ngrp, nb_main, block, &g, &gend, &gstride);
   int gb0 = 0, ge0 = 0;
   if (g < gend) {
     gb0 = P.t_grp[g];
@@ -430,6 +431,18 @@ __global__ __launch_bounds__(kBlock) void k_restrict_p(PDev P, const double* __r
       rc[3 * (size_t)key + 2] = acc[2];
     }
   }
+}
+__global__ __launch_bounds__(kBlock) void k_restrict_p(PDev P, const double* __restrict__ r, double* __restrict__ rc,
+                                                       const PcgScalars* S, int row0, int row1, int nb_main) {
+  restrict_groups(P, r, rc, S, row0, row1, nb_main, (int)blockIdx.x);
+}
+// The folded cycle's two level-0 launches that read the same right-hand side and do not depend on each other -- the
+// Jacobi pass of the wave-group kernel (M2 r, workgroups [0, nb_spmv)) and the restriction with P~^T (the workgroups
+// behind them) -- as ONE launch: on the graphs that fold level 0 a launch costs more than what it moves.
+__global__ __launch_bounds__(kBlock, 8) void k_jacobi0_restrict(Sym0Dev A, Spmv0Args a, int nb_spmv, PDev P, double* __restrict__ rc,
+                                                                 int nb_main) {
+  if ((int)blockIdx.x < nb_spmv) spmv0_groups<S0_JACOBI>(A, a, nb_spmv);
+  else restrict_groups(P, a.b, rc, a.S, 0, 0, nb_main, (int)blockIdx.x - nb_spmv);
 }
 // r_c = P^T r on the stream
 void launch_restrict_p(hipStream_t s, const PDev& P, const double* r, double* rc, const PcgScalars* S, int row0, int row1) {
@@ -2361,6 +2374,7 @@ int cycle_fold(Amg* m, hipStream_t s, int l, const double* rhs, double* out, con
                const PcgScalars* S, const double* dotvec2, int xs0_ready, const double* xadd = nullptr) {
   AmgLevel& L = m->lv[l];
   AmgLevel& C = m->lv[l + 1];
+  bool fused0 = false;
   if (l == 0) {   // (single GPU: multi-GPU runs keep level 0 unfolded)
     if (!xs0_ready) {   // xs = omega Dinv rhs (normally left by the producer of rhs)
       Scope sc(m->prof, K_DOT, 96.0 * L.A.n);
@@ -2371,12 +2385,18 @@ int cycle_fold(Amg* m, hipStream_t s, int l, const double* rhs, double* out, con
     // join cost 25 us per PCG iteration on this runtime, C2 1.45 -> 1.95 ms per GN iteration.)
     Spmv0Args b{};
     b.x = L.xs; b.b = rhs; b.y = L.rs; b.omega = m->cfg.omega; b.S = S;
-    const bool f32 = m->T0.ntile > 0 && m->S0.fblk != nullptr;
-    Scope sc(m->prof, m->T0.ntile > 0 ? (f32 ? K_SPMV0T_JACOBI_F32 : K_SPMV0T_JACOBI) : K_SPMV0_JACOBI,
-             (f32 ? 40.0 : 76.0) * m->S0.npairs + 168.0 * m->S0.n);
-    launch_spmv0_any(s, m->S0, m->T0, S0_JACOBI, b);
+    if (m->T0.ntile == 0) {   // wave-group kernel: the pass and the restriction in one launch
+      const int nb_spmv = grid_for(m->S0.ngrp, kWavesPerBlock), nb_main = grid_for(L.PS.t_ngrp, kWavesPerBlock);
+      Scope sc(m->prof, K_JACOBI0_RESTRICT, 76.0 * m->S0.npairs + 168.0 * m->S0.n + 44.0 * L.PS.t_n + 24.0 * L.A.n + 24.0 * L.nc);
+      SGO_LAUNCH(k_jacobi0_restrict, dim3(nb_spmv + nb_main + L.PS.t_nlong), dim3(kBlock), 0, s, m->S0, b, nb_spmv, L.PS, C.bk, nb_main);
+      fused0 = true;
+    } else {
+      const bool f32 = m->S0.fblk != nullptr;
+      Scope sc(m->prof, f32 ? K_SPMV0T_JACOBI_F32 : K_SPMV0T_JACOBI, (f32 ? 40.0 : 76.0) * m->S0.npairs + 168.0 * m->S0.n);
+      launch_spmv0_any(s, m->S0, m->T0, S0_JACOBI, b);
+    }
   }
-  {
+  if (!fused0) {
     Scope sc(m->prof, l == 0 ? K_RESTRICT_P0 : K_RESTRICT_P, 44.0 * L.PS.t_n + 24.0 * L.A.n + 24.0 * L.nc);
     launch_restrict_p(s, L.PS, rhs, C.bk, S, 0, 0);
   }

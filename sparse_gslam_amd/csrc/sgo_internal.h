@@ -348,6 +348,7 @@ enum KernelId : int {
   K_PTILDE0,
   K_UP_FOLD,
   K_PROLONG_FOLD0,
+  K_JACOBI0_RESTRICT,
   K_COUNT
 };
 extern const char* const kKernelNames[K_COUNT];

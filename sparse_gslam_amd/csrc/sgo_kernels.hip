@@ -37,7 +37,7 @@ const char* const kKernelNames[K_COUNT] = {
     "k_spmv0<0>", "k_spmv0<1>", "k_spmv0<2>", "k_spmv0t<0, 1024, false>", "k_spmv0t<1, 1024, false>", "k_spmv0t<2, 1024, false>",
     "k_direct", "k_spmv0t<1, 1024, true>", "k_spmv0t<2, 1024, true>", "k_restrict_p @level0", "k_prolong_p @level0", "k_p_values @level0", "k_block_products<1, 0, 0> @level0",
     "k_block_products<0, 1, 1> @level0", "k_galerkin @level0", "k_restrict @level0", "k_prolong_add @level0",
-    "k_ptilde_values", "k_ptilde_values @level0", "k_up_fold", "k_prolong_fold @level0"};
+    "k_ptilde_values", "k_ptilde_values @level0", "k_up_fold", "k_prolong_fold @level0", "k_jacobi0_restrict @level0"};
 
 namespace {
 
@@ -578,75 +578,7 @@ void k_spmv(BsrDev A, SpmvArgs a) {
 // Bounded to 8 workgroups per CU (<= 64 VGPRs) so that the whole 2048-block grid is resident.
 template <int MODE>
 __global__ __launch_bounds__(kBlock, 8) void k_spmv0(Sym0Dev A, Spmv0Args a) {
-  if (a.S && a.S->stop) return;
-  const int lane = threadIdx.x & 63;
-  const size_t nu = (size_t)A.nus;
-  const double2* __restrict__ bp = reinterpret_cast<const double2*>(A.ublk);
-  double dotacc[2] = {0.0, 0.0};
-  const int ulo = a.u1 > 0 ? a.u0 : 0, uhi = a.u1 > 0 ? a.u1 : A.ngrp;
-  int g, gend, gstride;
-  group_walk(uhi - ulo, &g, &gend, &gstride);
-  g += ulo;
-  gend += ulo;
-  for (; g < gend; g += gstride) {
-    const int gb = A.grp[g], ge = A.grp[g + 1], r0 = A.grow[g];
-    int ob = A.gown[g], tb = A.gtr[g];
-    double acc[3] = {0.0, 0.0, 0.0};
-    int row = -1 - lane;
-    for (int kb = gb; kb < ge; kb += 64) {
-      const int k = kb + lane;
-      const bool active = k < ge;
-      const int m = active ? (int)A.meta[k] : (kSlotNoBlock << 6);
-      const int type = m >> 6;
-      const unsigned long long omask = __ballot(type == kSlotOwned), tmask = __ballot(type == kSlotTransposed);
-      const int orank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(omask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)omask, 0u));
-      const int trank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(tmask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)tmask, 0u));
-      int idx = ob + orank;
-      const bool tr = type == kSlotTransposed;
-      if (tr) idx = A.tref[tb + trank];
-      ob += __popcll(omask);
-      tb += __popcll(tmask);
-      if (active) row = r0 + (m & 63);
-      if (type != kSlotNoBlock) {
-        const size_t c = 3 * (size_t)A.col[k];
-        const double x0 = a.x[c], x1 = a.x[c + 1], x2 = a.x[c + 2];
-        const double2 p0 = bp[idx], p1 = bp[nu + idx], p2 = bp[2 * nu + idx], p3 = bp[3 * nu + idx];
-        const double b8 = A.ublk8[idx];
-        // row-major b0..b8 = p0.x p0.y p1.x | p1.y p2.x p2.y | p3.x p3.y b8 ; transposed: swap (1,3) (2,6) (5,7)
-        const double m01 = tr ? p1.y : p0.y, m02 = tr ? p3.x : p1.x;
-        const double m10 = tr ? p0.y : p1.y, m12 = tr ? p3.y : p2.y;
-        const double m20 = tr ? p1.x : p3.x, m21 = tr ? p2.y : p3.y;
-        acc[0] += p0.x * x0 + m01 * x1 + m02 * x2;
-        acc[1] += m10 * x0 + p2.x * x1 + m12 * x2;
-        acc[2] += m20 * x0 + m21 * x1 + b8 * x2;
-      }
-    }
-    seg_scan<3>(row, acc, lane);
-    const int rn = __shfl_down(row, 1);
-    if (row >= 0 && (lane == 63 || rn != row)) {
-      const size_t o = 3 * (size_t)row;
-      const double* dd = A.dblk + 6 * (size_t)row;
-      const double s0 = a.x[o], s1 = a.x[o + 1], s2 = a.x[o + 2];
-      double o0 = acc[0] + dd[0] * s0 + dd[1] * s1 + dd[2] * s2;
-      double o1 = acc[1] + dd[1] * s0 + dd[3] * s1 + dd[4] * s2;
-      double o2 = acc[2] + dd[2] * s0 + dd[4] * s1 + dd[5] * s2;
-      if (MODE != S0_AX) {
-        const double t0 = a.b[o] - o0, t1 = a.b[o + 1] - o1, t2 = a.b[o + 2] - o2;
-        if (MODE == S0_JACOBI) {
-          const double* di = A.dinv + 6 * (size_t)row;
-          o0 = s0 + a.omega * (di[0] * t0 + di[1] * t1 + di[2] * t2);
-          o1 = s1 + a.omega * (di[1] * t0 + di[3] * t1 + di[4] * t2);
-          o2 = s2 + a.omega * (di[2] * t0 + di[4] * t1 + di[5] * t2);
-        } else {
-          o0 = t0; o1 = t1; o2 = t2;
-        }
-      }
-      a.y[o] = o0; a.y[o + 1] = o1; a.y[o + 2] = o2;
-      if (a.dotA) dotacc[0] += a.dotA[o] * o0 + a.dotA[o + 1] * o1 + a.dotA[o + 2] * o2;
-      if (a.dotA2) dotacc[1] += a.dotA2[o] * o0 + a.dotA2[o + 1] * o1 + a.dotA2[o + 2] * o2;
-    }
-  }
-  if (a.partials) block_sum_store<2>(dotacc, a.partials, kMaxPartials);
+  spmv0_groups<MODE>(A, a, (int)gridDim.x);
 }
 
 // ---------------------------------------------------------------------------- k_spmv0t
