@@ -1028,16 +1028,20 @@ __global__ __launch_bounds__(kGjB * kGjB) void k_gj_pivot(double* __restrict__ M
   P[threadIdx.x] = v;
 }
 
-// C = alpha * X * Y for 32x32 tiles held in LDS; each of the 256 threads produces 4 entries
-__device__ __forceinline__ void tile_mm(const double (*X)[kGjB + 1], const double (*Y)[kGjB + 1], double (&out)[4]) {
-  const int r = threadIdx.x >> 3, c0 = (threadIdx.x & 7) * 4;
+// Z = X * Y for 32x32 fp64 tiles held in LDS, on the matrix cores: wave w of the workgroup's four makes the 16x16 quadrant
+// (w >> 1, w & 1) in eight v_mfma_f64_16x16x4_f64 steps -- two LDS reads per lane and step, where the scalar loop (one row
+// x four columns per thread) read five per k: the tile products of a block step were LDS-bandwidth-bound, ~5 us of its
+// 17 with two or three workgroups per CU.  Operand lane maps: A[row = lane & 15][k = lane >> 4], B[k = lane >> 4][col =
+// lane & 15]; result register q of a lane is row (lane >> 4) + 4 q, column lane & 15.
+typedef double sgo_d4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void tile_mm(const double (*X)[kGjB + 1], const double (*Y)[kGjB + 1], double (*Z)[kGjB + 1]) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int i0 = 16 * (w >> 1), j0 = 16 * (w & 1), lr = lane & 15, lk = lane >> 4;
+  sgo_d4 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-  for (int q = 0; q < 4; ++q) out[q] = 0.0;
-  for (int k = 0; k < kGjB; ++k) {
-    const double x = X[r][k];
+  for (int s = 0; s < kGjB / 4; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(X[i0 + lr][4 * s + lk], Y[4 * s + lk][j0 + lr], acc, 0, 0, 0);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) out[q] += x * Y[k][c0 + q];
-  }
+  for (int q = 0; q < 4; ++q) Z[i0 + lk + 4 * q][j0 + lr] = acc[q];
 }
 
 // One Gauss-Jordan block step K = kb is ONE launch over all 32x32 tiles, reading the matrix of the previous
@@ -1055,7 +1059,7 @@ __device__ __forceinline__ void tile_mm(const double (*X)[kGjB + 1], const doubl
 __global__ __launch_bounds__(kBlock) void k_gj_step(const double* __restrict__ Min, double* __restrict__ Mout, int Np, int kb,
                                                     const double* __restrict__ Pin, double* __restrict__ Pout,
                                                     int* __restrict__ fail) {
-  __shared__ double X[kGjB][kGjB + 1], Y[kGjB][kGjB + 1];
+  __shared__ double X[kGjB][kGjB + 1], Y[kGjB][kGjB + 1], Z[kGjB][kGjB + 1];
   const int t = threadIdx.x, K0 = kb * kGjB;
   const int bj = blockIdx.x, bi = blockIdx.y;
   const int r = t >> 3, c0 = (t & 7) * 4;
@@ -1088,7 +1092,7 @@ __global__ __launch_bounds__(kBlock) void k_gj_step(const double* __restrict__ M
 #pragma unroll
     for (int q = 0; q < 4; ++q) sv[q] = src[q];
   }
-  // first product: P A_Kj (row panel and general tiles) or A_iK P (column panel)
+  // first product: Z = P A_Kj (row panel and general tiles) or A_iK P (column panel)
 #pragma unroll
   for (int m = 0; m < 4; ++m) {
     const int e = t + m * kBlock;
@@ -1096,31 +1100,29 @@ __global__ __launch_bounds__(kBlock) void k_gj_step(const double* __restrict__ M
     Y[e / kGjB][e % kGjB] = y1[m];
   }
   __syncthreads();
-  double o[4];
-  tile_mm(X, Y, o);
+  tile_mm(X, Y, Z);
+  __syncthreads();
   if (bi == kb) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) dst[q] = o[q];
+    for (int q = 0; q < 4; ++q) dst[q] = Z[r][c0 + q];
     return;
   }
   if (bj == kb) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) dst[q] = -o[q];
+    for (int q = 0; q < 4; ++q) dst[q] = -Z[r][c0 + q];
     return;
   }
-  // general tile: A_ij - A_iK (P A_Kj)
-  __syncthreads();   // everyone is done reading X / Y
-#pragma unroll
-  for (int q = 0; q < 4; ++q) Y[r][c0 + q] = o[q];
+  // general tile: A_ij - A_iK (P A_Kj): the second product's right operand is Z as it lies; X takes A_iK, Y the product
 #pragma unroll
   for (int m = 0; m < 4; ++m) {
     const int e = t + m * kBlock;
     X[e / kGjB][e % kGjB] = x2[m];
   }
   __syncthreads();
-  tile_mm(X, Y, o);
+  tile_mm(X, Z, Y);
+  __syncthreads();
 #pragma unroll
-  for (int q = 0; q < 4; ++q) dst[q] = v[q] = sv[q] - o[q];
+  for (int q = 0; q < 4; ++q) dst[q] = v[q] = sv[q] - Y[r][c0 + q];
   if (bi != kb + 1 || bj != kb + 1) return;
   // next pivot block: Pout = inv(A_K'K') by scalar Gauss-Jordan
   __syncthreads();
