@@ -298,6 +298,11 @@ __global__ __launch_bounds__(kBlock) void k_p_values(BsrDev F, PDev P, const int
 // out_t = sum over the products of target t of  X(a) * Y(b)   (TRANSPOSE_X: X(a)^T * Y(b))
 // X blocks: the logical slots of a level's operator XA (X_BSR; load_block) or plain records X[nx][9];
 // Y plain [ny][9]; out plain or pair-SoA (a BsrDev's blk).
+// (C4 level 0: 13 M products of A P in 445 us, 3 M of P^T A P in 170 us.  Measured in round 3 and dropped: a second copy of
+// the level-0 blocks as 72-byte records for the gathers of A -- 434 us, and the linearisation pays 19 us for writing it:
+// lanes of a target share their A blocks, the pair-SoA image is not what costs; records of P / A P padded to 80 bytes so
+// that a record is five 16-byte-aligned loads instead of nine 8-byte ones -- A P 474 us, P^T A P 165 us: bytes, not load
+// instructions, are what the gathers pay for.)
 template <bool X_BSR, bool TRANSPOSE_X, bool OUT_BSR>
 __global__ __launch_bounds__(kBlock) void k_block_products(ProdMap mp, BsrDev XA, const double* __restrict__ X,
                                                            const double* __restrict__ Y,
