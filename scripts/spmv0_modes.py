@@ -21,4 +21,5 @@ with capi.Optimizer(0) as o:
     for mode, label in ((0, "H p"), (1, "residual pass"), (2, "Jacobi sweep")):
         a = L.sgo_debug_spmv0_us(o._h, mode, 0, reps)
         b = L.sgo_debug_spmv0_us(o._h, mode, 64, reps)
-        print(f"{name} {label:14s}: {a:7.2f} us (default blocks)  {b:7.2f} us (fp64 blocks)", flush=True)
+        ga = L.sgo_debug_spmv0_us(o._h, mode, 128, reps)   # as nodes of a replayed hipGraph
+        print(f"{name} {label:14s}: {a:7.2f} us (default blocks)  {b:7.2f} us (fp64 blocks)  {ga:7.2f} us as hipGraph nodes", flush=True)

@@ -12,9 +12,9 @@ rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 names = [r["Kernel_Name"] for r in rows]
 # find the last k_pose_update, take the 60 kernels before it
 idx = max(i for i, n in enumerate(names) if "k_pose_update" in n)
-t0 = int(rows[idx - 70]["Start_Timestamp"])
+W = int(__import__("os").environ.get("WIN", "70")); t0 = int(rows[idx - W]["Start_Timestamp"])
 prev_end = None
-for r in rows[idx - 70: idx + 1]:
+for r in rows[idx - W: idx - W + 71]:
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
     n = r["Kernel_Name"].replace("sgo::(anonymous namespace)::", "").replace("void ", "")[:44]
     gap = (s - prev_end) / 1e3 if prev_end else 0.0

@@ -444,7 +444,7 @@ __global__ __launch_bounds__(kBlock) void k_restrict_p(PDev P, const double* __r
 // The folded cycle's two level-0 launches that read the same right-hand side and do not depend on each other -- the
 // Jacobi pass of the wave-group kernel (M2 r, workgroups [0, nb_spmv)) and the restriction with P~^T (the workgroups
 // behind them) -- as ONE launch: on the graphs that fold level 0 a launch costs more than what it moves.
-__global__ __launch_bounds__(kBlock, 8) void k_jacobi0_restrict(Sym0Dev A, Spmv0Args a, int nb_spmv, PDev P, double* __restrict__ rc,
+__global__ __launch_bounds__(kBlock, 4) void k_jacobi0_restrict(Sym0Dev A, Spmv0Args a, int nb_spmv, PDev P, double* __restrict__ rc,
                                                                  int nb_main) {
   if ((int)blockIdx.x < nb_spmv) spmv0_groups<S0_JACOBI>(A, a, nb_spmv);
   else restrict_groups(P, a.b, rc, a.S, 0, 0, nb_main, (int)blockIdx.x - nb_spmv);

@@ -575,9 +575,10 @@ void k_spmv(BsrDev A, SpmvArgs a) {
 //                                                     first smoothing sweep from zero + residual)
 //   S0_JACOBI  y = x + omega Dinv (b - H x)          (damped block-Jacobi sweep)
 // Optional dot partials: partials[0] += dotA[row].y[row], partials[1] += dotA2[row].y[row].
-// Bounded to 8 workgroups per CU (<= 64 VGPRs) so that the whole 2048-block grid is resident.
+// (Graphs below kSmallGraphPairs take it: a few hundred to a thousand workgroups; the row data held across the scan costs
+// registers, 4 workgroups per CU are plenty.)
 template <int MODE>
-__global__ __launch_bounds__(kBlock, 8) void k_spmv0(Sym0Dev A, Spmv0Args a) {
+__global__ __launch_bounds__(kBlock, 4) void k_spmv0(Sym0Dev A, Spmv0Args a) {
   spmv0_groups<MODE>(A, a, (int)gridDim.x);
 }
 

@@ -429,7 +429,8 @@ int run_pcg(sgo_ctx* c) {
     c->pcg_pred = c->h_S->iter;
     return SGO_OK;
   }
-  constexpr int kUnit = 2;   // iterations per graph replay
+  constexpr int kUnit = 2;   // iterations per graph replay (1: 44.6, 2: 41.2, 4: 42, 8: 47 us per PCG iteration on C2 -- a replay costs
+                             // ~7 us, an iteration past convergence eight early-exit nodes)
   int rc = ensure_pcg_graph(c, kUnit);
   if (rc) return rc;
   // One replay (2 iterations, >= 100 us even on 1k-pose graphs) in flight hides the host's read of the
@@ -846,12 +847,32 @@ double debug_spmv0_us(sgo_ctx* c, int mode, int variant, int reps) {
   }
   if (tiled) launch_spmv0t(c->stream, c->S0, c->T0, mode, args);
   else launch_spmv0(c->stream, c->S0, mode, args);
+  if (variant & 128) {   // variant 128: as nodes of a replayed hipGraph (16 launches per graph), the way the solve runs them
+    hipGraph_t g = nullptr;
+    hipGraphExec_t ex = nullptr;
+    hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal);
+    for (int k = 0; k < 16; ++k) {
+      if (tiled) launch_spmv0t(c->stream, c->S0, c->T0, mode, args);
+      else launch_spmv0(c->stream, c->S0, mode, args);
+    }
+    hipStreamEndCapture(c->stream, &g);
+    if (!g || hipGraphInstantiate(&ex, g, nullptr, nullptr, 0) != hipSuccess) return -1.0;
+    hipGraphLaunch(ex, c->stream);
+    hipEventRecord(a, c->stream);
+    for (int k = 0; k < (reps + 15) / 16; ++k) hipGraphLaunch(ex, c->stream);
+    hipEventRecord(b, c->stream);
+    hipStreamSynchronize(c->stream);
+    hipGraphExecDestroy(ex);
+    hipGraphDestroy(g);
+    reps = (reps + 15) / 16 * 16;
+  } else {
   hipEventRecord(a, c->stream);
   for (int k = 0; k < reps; ++k) {
     if (tiled) launch_spmv0t(c->stream, c->S0, c->T0, mode, args);
     else launch_spmv0(c->stream, c->S0, mode, args);
   }
   hipEventRecord(b, c->stream);
+  }
   hipStreamSynchronize(c->stream);
   float ms = 0.f;
   hipEventElapsedTime(&ms, a, b);
