@@ -106,6 +106,33 @@ double run_any(hipStream_t s, int K, int reps, F launch) {
   return 1e3 * ms / (reps * K);
 }
 
+// a grid barrier inside one launch (all workgroups resident): arrive on a counter, spin until the generation's count is
+// reached; agent-scope release / acquire around it, as a producer -> consumer phase change needs.  NB barriers per launch,
+// between them one dependent read of what another workgroup wrote in the previous phase.
+__global__ __launch_bounds__(256) void k_barriers(unsigned* __restrict__ counter, int* __restrict__ buf, int nb, int* __restrict__ fail) {
+  const unsigned G = gridDim.x;
+  int v = threadIdx.x;
+  for (int b = 0; b < nb; ++b) {
+    buf[blockIdx.x * 256 + threadIdx.x] = v + b;
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const unsigned target = (unsigned)(b + 1) * G;
+      __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      int spins = 0;
+      while (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        if (++spins > 2000000) {
+          *fail = 1;
+          break;
+        }
+      }
+    }
+    __syncthreads();
+    v = __hip_atomic_load(&buf[((blockIdx.x + 1) % G) * 256 + threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (v == -12345) fail[1] = v;
+}
+
 template <int D>
 double run(hipStream_t s, const int* next, int* out, int n, int grid, int K, int reps) {
   hipGraph_t g;
@@ -165,6 +192,36 @@ int main() {
     for (int np : {64, 352, 2048})
       std::printf("reduction of %4d partial sums + update of 30000 values, grid 118: %.2f us per node\n", np,
                   run_any(s, K, reps, [&](int) { hipLaunchKernelGGL(k_reduce_update, dim3(118), dim3(256), 0, s, (const double*)parts, np, (const double*)z, p, 30000); }));
+  }
+  {
+    unsigned* counter;
+    int *bbuf, *fail;
+    hipMalloc(&counter, 4);
+    hipMalloc(&bbuf, 256 * 256 * sizeof(int));
+    hipMalloc(&fail, 8);
+    hipMemset(fail, 0, 8);
+    for (int G : {8, 32, 64, 128, 256}) {
+      for (int nb : {1, 5, 9}) {
+        hipEvent_t e0, e1;
+        hipEventCreate(&e0);
+        hipEventCreate(&e1);
+        float best = 1e9f;
+        for (int rep = 0; rep < 20; ++rep) {
+          hipMemsetAsync(counter, 0, 4, s);
+          hipEventRecord(e0, s);
+          hipLaunchKernelGGL(k_barriers, dim3(G), dim3(256), 0, s, counter, bbuf, nb, fail);
+          hipEventRecord(e1, s);
+          hipEventSynchronize(e1);
+          float ms = 0;
+          hipEventElapsedTime(&ms, e0, e1);
+          best = ms < best ? ms : best;
+        }
+        std::printf("one launch of %3d workgroups with %d grid barriers: %.2f us%s", G, nb, 1e3 * best, nb == 9 ? "\n" : ";  ");
+      }
+    }
+    int hf[2] = {0, 0};
+    hipMemcpy(hf, fail, 8, hipMemcpyDeviceToHost);
+    if (hf[0]) std::printf("  (a barrier gave up spinning)\n");
   }
   int *fa, *fb;
   hipMalloc(&fa, 2048 * 256 * sizeof(int));
