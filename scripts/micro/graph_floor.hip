@@ -186,6 +186,20 @@ int main() {
     hipMemset(p, 0, 30000 * sizeof(double));
     std::printf("256-byte argument block, two dependent loads, grid 256: %.2f us per node\n",
                 run_any(s, K, reps, [&](int) { hipLaunchKernelGGL(k_bigargs, dim3(256), dim3(256), 0, s, ba, out); }));
+    {   // the same kernel as plain stream launches, back to back
+      hipEvent_t e0, e1;
+      hipEventCreate(&e0);
+      hipEventCreate(&e1);
+      for (int r = 0; r < 64; ++r) hipLaunchKernelGGL(k_reduce_update, dim3(118), dim3(256), 0, s, (const double*)parts, 352, (const double*)z, p, 30000);
+      hipStreamSynchronize(s);
+      hipEventRecord(e0, s);
+      for (int r = 0; r < 2048; ++r) hipLaunchKernelGGL(k_reduce_update, dim3(118), dim3(256), 0, s, (const double*)parts, 352, (const double*)z, p, 30000);
+      hipEventRecord(e1, s);
+      hipEventSynchronize(e1);
+      float ms = 0;
+      hipEventElapsedTime(&ms, e0, e1);
+      std::printf("the same kernel as 2048 plain stream launches: %.2f us per launch\n", 1e3 * ms / 2048);
+    }
     for (int kk : {4, 8, 16, 32, 64, 128})
       std::printf("graph of %3d such nodes (352 partial sums), replayed back to back: %.2f us per node\n", kk,
                   run_any(s, kk, reps * 64 / kk, [&](int) { hipLaunchKernelGGL(k_reduce_update, dim3(118), dim3(256), 0, s, (const double*)parts, 352, (const double*)z, p, 30000); }));

@@ -1019,15 +1019,23 @@ __global__ __launch_bounds__(kGjB * kGjB) void k_gj_pivot(double* __restrict__ M
   double v = M[(size_t)(base + i) * Np + base + j];
   a2[0][i][j] = v;
   __syncthreads();
-  for (int k = 0; k < kGjB; ++k) {
-    double (*a)[kGjB + 1] = a2[k & 1];
-    const double akk = a[k][k], akj = a[k][j], aik = a[i][k];
-    if (threadIdx.x == 0 && (!(akk > 0.0) || !isfinite(akk))) *fail = 1;
-    const double p = (akk != 0.0) ? gj_rcp(akk) : 0.0;
-    if (i == k) v = (j == k) ? p : akj * p;
-    else if (j == k) v = -aik * p;
-    else v = v - aik * (akj * p);
-    a2[(k + 1) & 1][i][j] = v;
+  // TWO pivots per elimination step (the 2 x 2 pivot block of an SPD matrix is inverted in closed form): 16 barrier-separated
+  // steps instead of 32 -- the steps, not their arithmetic, are what the inverse costs
+  for (int k = 0; k < kGjB; k += 2) {
+    double (*a)[kGjB + 1] = a2[(k >> 1) & 1];
+    const double pa = a[k][k], pb = a[k][k + 1], pd = a[k + 1][k + 1];
+    const double det = pa * pd - pb * pb;
+    if (threadIdx.x == 0 && (!(pa > 0.0) || !(det > 0.0) || !isfinite(det))) *fail = 1;
+    const double id = (det != 0.0) ? gj_rcp(det) : 0.0;
+    const double p00 = pd * id, p01 = -pb * id, p11 = pa * id;
+    const double a0j = a[k][j], a1j = a[k + 1][j], ai0 = a[i][k], ai1 = a[i][k + 1];
+    const double t0 = ai0 * p00 + ai1 * p01, t1 = ai0 * p01 + ai1 * p11;
+    if (i == k) v = (j == k) ? p00 : ((j == k + 1) ? p01 : p00 * a0j + p01 * a1j);
+    else if (i == k + 1) v = (j == k) ? p01 : ((j == k + 1) ? p11 : p01 * a0j + p11 * a1j);
+    else if (j == k) v = -t0;
+    else if (j == k + 1) v = -t1;
+    else v = v - (t0 * a0j + t1 * a1j);
+    a2[((k >> 1) + 1) & 1][i][j] = v;
     __syncthreads();
   }
   P[threadIdx.x] = v;
@@ -1134,21 +1142,30 @@ __global__ __launch_bounds__(kBlock) void k_gj_step(const double* __restrict__ M
 #pragma unroll
   for (int q = 0; q < 4; ++q) X[r][c0 + q] = v[q];
   __syncthreads();
-  for (int k = 0; k < kGjB; ++k) {
-    double (*rd)[kGjB + 1] = (k & 1) ? Y : X;
-    double (*wr)[kGjB + 1] = (k & 1) ? X : Y;
-    const double akk = rd[k][k], aik = rd[r][k];
-    double akj[4];
+  for (int k = 0; k < kGjB; k += 2) {   // two pivots per step (see k_gj_pivot)
+    double (*rd)[kGjB + 1] = ((k >> 1) & 1) ? Y : X;
+    double (*wr)[kGjB + 1] = ((k >> 1) & 1) ? X : Y;
+    const double pa = rd[k][k], pb = rd[k][k + 1], pd = rd[k + 1][k + 1];
+    const double ar0 = rd[r][k], ar1 = rd[r][k + 1];
+    double a0c[4], a1c[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) akj[q] = rd[k][c0 + q];
-    if (t == 0 && (!(akk > 0.0) || !isfinite(akk))) *fail = 1;
-    const double p = (akk != 0.0) ? gj_rcp(akk) : 0.0;
+    for (int q = 0; q < 4; ++q) {
+      a0c[q] = rd[k][c0 + q];
+      a1c[q] = rd[k + 1][c0 + q];
+    }
+    const double det = pa * pd - pb * pb;
+    if (t == 0 && (!(pa > 0.0) || !(det > 0.0) || !isfinite(det))) *fail = 1;
+    const double id = (det != 0.0) ? gj_rcp(det) : 0.0;
+    const double p00 = pd * id, p01 = -pb * id, p11 = pa * id;
+    const double t0 = ar0 * p00 + ar1 * p01, t1 = ar0 * p01 + ar1 * p11;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int c = c0 + q;
-      if (r == k) v[q] = (c == k) ? p : akj[q] * p;
-      else if (c == k) v[q] = -aik * p;
-      else v[q] = v[q] - aik * (akj[q] * p);
+      if (r == k) v[q] = (c == k) ? p00 : ((c == k + 1) ? p01 : p00 * a0c[q] + p01 * a1c[q]);
+      else if (r == k + 1) v[q] = (c == k) ? p01 : ((c == k + 1) ? p11 : p01 * a0c[q] + p11 * a1c[q]);
+      else if (c == k) v[q] = -t0;
+      else if (c == k + 1) v[q] = -t1;
+      else v[q] = v[q] - (t0 * a0c[q] + t1 * a1c[q]);
       wr[r][c0 + q] = v[q];
     }
     __syncthreads();
