@@ -22,7 +22,8 @@ struct AmgConfig {
   bool fold = true;             // folded V-cycle (sgo_amg.hip): the post- and pre-smoothing sweeps of the smoothed levels folded into
                                 // the transfer operator P~ = (I - omega D^-1 A) P; one sweep per level (env SGO_AMG_FOLD=0: the
                                 // sweeps as launches of their own, nu_coarse as below)
-  int fold0_rows = 30000;       // ... level 0 too on graphs of at most this many rows (single GPU)
+  int fold0_rows = 60000;       // ... level 0 too on graphs of at most this many rows (single GPU; measured, scripts/fold0_sweep.py:
+                                // 50k rows / 500k edges 2.84 against 2.94 ms per GN iteration, C4's 100k rows 4.62 against 4.54)
   bool lists_on_device = true;  // the product lists of A P and P^T A P are made on the device from the host's patterns
                                 // (env SGO_AMG_LISTS=host: on the host, the reference the device lists are tested against)
   int coarsest_nodes = 400;  // stop coarsening at or below this many nodes; that level is inverted densely

@@ -2778,6 +2778,7 @@ AmgConfig amg_effective_config(const AmgConfig& cfg_in, int n, int nslot) {
   if (const char* e = std::getenv("SGO_AMG_SMOOTH")) cfg.smooth = std::atoi(e) != 0;
   if (const char* e = std::getenv("SGO_AMG_LISTS")) cfg.lists_on_device = std::string(e) != "host";
   if (const char* e = std::getenv("SGO_AMG_FOLD")) cfg.fold = std::atoi(e) != 0;
+  if (const char* e = std::getenv("SGO_AMG_FOLD0_ROWS")) cfg.fold0_rows = std::atoi(e);
   cfg.fold = cfg.fold && cfg.smooth && cfg.lists_on_device;
   // the folded cycle has ONE sweep per level folded into the transfers (two would need the pattern of A A P); what it saves
   // per PCG iteration outweighs the iterations a second coarse sweep saves (C4: 22 -> 28 iterations at 150 -> ... us each)
