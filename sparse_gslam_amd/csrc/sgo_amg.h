@@ -16,7 +16,7 @@ struct AmgConfig {
   double omega = 0.8;      // block-Jacobi damping
   int max_levels = 10;
   int nu_coarse = 1;           // smoothing sweeps on the coarser V-cycle levels; amg_create picks 2 for
-                               // graphs with >= 10^6 level-0 blocks, where a coarse sweep is cheap next to level 0
+                               // graphs with >= 6 * 10^5 level-0 blocks, where a coarse sweep is cheap next to level 0
   bool smooth = true;          // smoothed aggregation: P = (I - omega_p D^-1 A) T (env SGO_AMG_SMOOTH=0: tentative P)
   double omega_p = 0.66;       // damping of the prolongator smoothing step
   bool fold = true;             // folded V-cycle (sgo_amg.hip): the post- and pre-smoothing sweeps of the smoothed levels folded into

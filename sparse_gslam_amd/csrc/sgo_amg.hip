@@ -2774,7 +2774,8 @@ AmgConfig amg_effective_config(const AmgConfig& cfg_in, int n, int nslot) {
   // A sweep on a coarse level is a 5-10 us launch whatever the graph; it pays when a PCG iteration is
   // dominated by level 0 (C4: 31 instead of 39 iterations, 9.7 instead of 10.6 ms) and costs a few
   // per cent on graphs whose level 0 is itself launch-bound (10k / 40k: 2.67 instead of 2.51 ms).
-  cfg.nu_coarse = nslot >= 1000000 ? 2 : 1;
+  cfg.nu_coarse = nslot >= 600000 ? 2 : 1;   // (with the folded cycle, scripts/nu_sweep.py: 30k / 300k 2.38 -> 2.31, 50k / 500k 3.00 -> 2.84 ms per GN
+                                             // iteration with two sweeps; 20k / 200k 1.81 -> 1.91, C2 1.24 -> 1.36)
   if (const char* e = std::getenv("SGO_AMG_SMOOTH")) cfg.smooth = std::atoi(e) != 0;
   if (const char* e = std::getenv("SGO_AMG_LISTS")) cfg.lists_on_device = std::string(e) != "host";
   if (const char* e = std::getenv("SGO_AMG_FOLD")) cfg.fold = std::atoi(e) != 0;
