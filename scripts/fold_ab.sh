@@ -1,3 +1,4 @@
+# A/B of the folded multigrid cycle against SGO_AMG_FOLD=0 on the bench configs (gpurun -- 'CONFIGS="C4 C2" bash scripts/fold_ab.sh').
 set -e
 cd $GRAFT_REPO_ROOT
 pr() { python3 -c "

@@ -1,3 +1,5 @@
+# rocprofv3 kernel timeline of the replayed PCG hipGraph near the end of a solve (CFG=C2 WIN=330 for a window further back):
+# start, duration and gap of every kernel -- what a node of the graph costs back to back.
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp; export TMPDIR=/tmp
 O=$R/gpurun_out

@@ -632,7 +632,7 @@ __global__ __launch_bounds__(kBlock) void k_ptilde_values(FoldDev F, const doubl
 }
 
 // Level 0: z_i = y_i + sum over the entries f of row i of P~_f (c1 u1 + c2 u2)[col(f)]; optional partials of dotA . z, dotA2 . z
-// (P: the view of P~ -- row / col / r_grp / r_blk of the folded operator; rows outside [row0, row1) are another rank's).
+// (P: the view of P~ -- row / col / r_grp / r_blk of the folded operator; single GPU: multi-GPU runs keep level 0 unfolded).
 // Workgroups of 1024 threads: the consumer of the dot products re-reduces one partial sum per WORKGROUP in every one of its
 // own workgroups, so there should be a few hundred of them -- while a wave should not walk more than two or three groups,
 // each a chain of three dependent round trips (512 workgroups of 256 threads: 28 us on C4 instead of 12).
@@ -640,8 +640,7 @@ constexpr int kFoldThreads = 1024;
 __global__ __launch_bounds__(kFoldThreads, 2) void k_prolong_fold(PDev P, const double* __restrict__ u1, SpmvRatio r1,
                                                                const double* __restrict__ u2, SpmvRatio r2, const double* __restrict__ y,
                                                                double* __restrict__ out, const PcgScalars* S, const double* __restrict__ dotA,
-                                                               const double* __restrict__ dotA2, double* __restrict__ partials, int row0,
-                                                               int row1) {
+                                                               const double* __restrict__ dotA2, double* __restrict__ partials) {
   constexpr int NW = kFoldThreads / 64;
   __shared__ double sm[4][NW];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -720,7 +719,6 @@ __global__ __launch_bounds__(kFoldThreads, 2) void k_prolong_fold(PDev P, const 
       gb = P.r_grp[gn];
       ge = P.r_grp[gn + 1];
     }
-    if (row1 > 0 && key >= 0 && (key < row0 || key >= row1)) key = -1 - lane;   // multi-GPU: another rank's row
     double acc[3] = {0.0, 0.0, 0.0};
     double y0 = 0.0, y1 = 0.0, y2 = 0.0;
     if (key >= 0) {
@@ -736,9 +734,7 @@ __global__ __launch_bounds__(kFoldThreads, 2) void k_prolong_fold(PDev P, const 
     }
     if (gn < gend) request(gb, ge);
     for (int e = cgb + 64 + lane; e < cge; e += 64) {   // a row with more than 64 entries (its own group): the further strides
-      const int k2 = P.row[e];
-      if (row1 > 0 && (k2 < row0 || k2 >= row1)) continue;
-      key = k2;
+      key = P.row[e];
       const size_t a = 3 * (size_t)P.col[e];
       double w0 = c1 * u1[a], w1 = c1 * u1[a + 1], w2 = c1 * u1[a + 2];
       if (u2) {
@@ -2435,7 +2431,7 @@ int cycle_fold(Amg* m, hipStream_t s, int l, const double* rhs, double* out, con
   const int grid = std::min(grid_for(L.PS.r_ngrp, kFoldThreads / 64), 512);
   Scope sc(m->prof, K_PROLONG_FOLD0, 44.0 * L.PS.r_n + 72.0 * L.A.n);
   SGO_LAUNCH(k_prolong_fold, dim3(grid), dim3(kFoldThreads), 0, s, L.PS, cs.u1, cs.c1, cs.u2, cs.c2, (const double*)L.rs, out, S, dotvec,
-             dotvec2, dotvec ? dotparts : nullptr, 0, 0);
+             dotvec2, dotvec ? dotparts : nullptr);
   return grid;
 }
 
