@@ -151,11 +151,12 @@ __device__ __forceinline__ double dpp_double(double v) {
 template <int N, int CTRL, int ROW_MASK>
 __device__ __forceinline__ void seg_scan_step(int row, double (&v)[N]) {
   constexpr int kNoKey = (int)0x80000000;   // lanes without a source lane see a key no lane has
-  const bool take = dpp_int<CTRL, ROW_MASK>(kNoKey, row) == row;
+  // (v += f u with f = 1.0 / 0.0 instead of a select and an add: one fused multiply-add, bit-identical for finite u)
+  const double f = dpp_int<CTRL, ROW_MASK>(kNoKey, row) == row ? 1.0 : 0.0;
 #pragma unroll
   for (int i = 0; i < N; ++i) {
     const double u = dpp_double<CTRL, ROW_MASK>(v[i]);
-    if (take) v[i] += u;
+    v[i] = fma(f, u, v[i]);
   }
 }
 template <int N>
