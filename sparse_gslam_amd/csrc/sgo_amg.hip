@@ -142,7 +142,7 @@ __global__ __launch_bounds__(kBlock) void k_galerkin(BsrDev F, BsrDev C, Galerki
       acc[8] += -dyi * m02 + dxi * m12 + m22;
     }
     seg_scan<9>(key, acc, lane);
-    const int kn = __shfl_down(key, 1);
+    const int kn = next_lane_key(key);
     if (key >= 0 && (lane == 63 || kn != key)) {
 #pragma unroll
       for (int c = 0; c < 9; ++c) C.blk[blk_at(c, key, ncs)] = acc[c];
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(kBlock) void k_p_values(BsrDev F, PDev P, const int
       acc[6] += b[6]; acc[7] += b[7]; acc[8] += -dyj * b[6] + dxj * b[7] + b[8];
     }
     seg_scan<9>(key, acc, lane);
-    const int kn = __shfl_down(key, 1);
+    const int kn = next_lane_key(key);
     if (key >= 0 && (lane == 63 || kn != key)) {
       const size_t i = (size_t)P.row[key];
       const double* di = F.dinv + 6 * i;
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(kBlock) void k_block_products(ProdMap mp, BsrDev XA
         }
     }
     seg_scan<9>(key, acc, lane);
-    const int kn = __shfl_down(key, 1);
+    const int kn = next_lane_key(key);
     if (key >= 0 && (lane == 63 || kn != key)) {
 #pragma unroll
       for (int c = 0; c < 9; ++c) {
@@ -429,7 +429,7 @@ __device__ __forceinline__ void restrict_groups(const PDev& P, const double* __r
       acc[2] += b[2] * r0 + b[5] * r1 + b[8] * r2;
     }
     seg_scan<3>(key, acc, lane);
-    const int kn = __shfl_down(key, 1);
+    const int kn = next_lane_key(key);
     if (key >= 0 && (lane == 63 || kn != key)) {
       rc[3 * (size_t)key] = acc[0];
       rc[3 * (size_t)key + 1] = acc[1];
@@ -503,7 +503,7 @@ __global__ __launch_bounds__(kBlock) void k_prolong_p(int n, PDev P, const doubl
       acc[2] += b[6] * w0 + b[7] * w1 + b[8] * w2;
     }
     seg_scan<3>(key, acc, lane);
-    const int kn = __shfl_down(key, 1);
+    const int kn = next_lane_key(key);
     if (key >= 0 && (lane == 63 || kn != key)) {
       const size_t o = 3 * (size_t)key;
       if (xadd) {
@@ -749,7 +749,7 @@ __global__ __launch_bounds__(kFoldThreads, 2) void k_prolong_fold(PDev P, const 
       y0 = y[o]; y1 = y[o + 1]; y2 = y[o + 2];
     }
     seg_scan<3>(key, acc, lane);
-    const int kn = __shfl_down(key, 1);
+    const int kn = next_lane_key(key);
     if (key >= 0 && (lane == 63 || kn != key)) {
       const size_t o = 3 * (size_t)key;
       const double o0 = y0 + acc[0], o1 = y1 + acc[1], o2 = y2 + acc[2];
@@ -847,7 +847,7 @@ __global__ __launch_bounds__(kBlock) void k_up_fold(BsrDev A, UpDev U, PDev PS, 
       d0 = di[0]; d1 = di[1]; d2 = di[2]; d3 = di[3]; d4 = di[4]; d5 = di[5];
     }
     seg_scan<6>(key, acc, lane);
-    const int kn = __shfl_down(key, 1);
+    const int kn = next_lane_key(key);
     if (key >= 0 && (lane == 63 || kn != key)) {
       const size_t o = 3 * (size_t)key;
       // x1 + w D^-1 (b - A x1) = w D^-1 (2 b - A x1) evaluated as the cycle does: x1 first, then the residual's sweep
@@ -912,7 +912,7 @@ __global__ __launch_bounds__(kBlock) void k_restrict(int ngrp, const int* __rest
       acc[2] += -d[2 * (size_t)i + 1] * r0 + d[2 * (size_t)i] * r1 + r2;
     }
     seg_scan<3>(key, acc, lane);
-    const int kn = __shfl_down(key, 1);
+    const int kn = next_lane_key(key);
     if (key >= 0 && (lane == 63 || kn != key)) {
       rc[3 * (size_t)key] = acc[0];
       rc[3 * (size_t)key + 1] = acc[1];

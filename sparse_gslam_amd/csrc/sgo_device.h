@@ -139,10 +139,16 @@ __device__ __forceinline__ void block_reduce_parts_n(const double* const (&parts
 // the keys of the ACTIVE lanes are non-decreasing along the wave (slots sorted by target), so a lane whose
 // key equals that of the last lane of the previous row(s) belongs to a segment that spans everything in
 // between.  Inactive lanes carry unique negative keys and never match.
+// (Full row mask: bound_ctrl makes the lanes without a source lane read 0, so no lane keeps `old` and the compiler has no
+// destination to initialise -- two moves per double and step less.  A key of 0 can then match row 0 at the start of a row
+// of 16 lanes, where the value that comes with it is 0 as well: nothing is added.)
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ int dpp_int(int old, int v) {
+  if (ROW_MASK == 0xF) return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
   return __builtin_amdgcn_update_dpp(old, v, CTRL, ROW_MASK, 0xF, false);
 }
+// key of the next lane (lane 63: 0), by a wavefront shift on the vector ALU instead of a permute through the LDS crossbar
+__device__ __forceinline__ int next_lane_key(int key) { return __builtin_amdgcn_update_dpp(0, key, 0x130, 0xF, 0xF, true); }
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ double dpp_double(double v) {
   const int lo = dpp_int<CTRL, ROW_MASK>(0, __double2loint(v)), hi = dpp_int<CTRL, ROW_MASK>(0, __double2hiint(v));
@@ -300,7 +306,7 @@ __device__ __forceinline__ void spmv0_groups(const Sym0Dev& A, const Spmv0Args& 
       }
     }
     seg_scan<3>(row, acc, lane);
-    const int rn = __shfl_down(row, 1);
+    const int rn = next_lane_key(row);
     if (row >= 0 && (lane == 63 || rn != row)) {
       const size_t o = 3 * (size_t)row;
       double o0 = acc[0] + dd0 * s0 + dd1 * s1 + dd2 * s2;

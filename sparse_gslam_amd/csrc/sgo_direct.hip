@@ -683,7 +683,7 @@ __global__ __launch_bounds__(kDT) void k_direct(DirectDev D, EdgeListDev el, dou
         }
         const int key = col >= 0 ? col : -1 - lane;
         seg_scan<3>(key, v, lane);
-        const int nk = __shfl_down(key, 1);
+        const int nk = next_lane_key(key);
         if (col >= 0 && (lane == 63 || nk != key)) {
           double iv[6];
           const bool ok = inv_sym3(d00, d01, d02, d11, d12, d22, iv);

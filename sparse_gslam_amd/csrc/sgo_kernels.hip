@@ -297,7 +297,7 @@ __global__ __launch_bounds__(kBlock) void k_linearize(Sym0Dev A, int g0, int g1,
       }
     }
     seg_scan<9>(row, acc, lane);
-    const int rn = __shfl_down(row, 1);
+    const int rn = next_lane_key(row);
     if (row >= 0 && (lane == 63 || rn != row)) {
       double* d = dgb + 9 * (size_t)row;
 #pragma unroll
@@ -515,7 +515,7 @@ void k_spmv(BsrDev A, SpmvArgs a) {
       acc[2] += b6 * x0 + b7 * x1 + b8 * x2;
     }
     seg_scan<3>(row, acc, lane);
-    const int rn = __shfl_down(row, 1);
+    const int rn = next_lane_key(row);
     if (row >= 0 && (lane == 63 || rn != row)) {
       const size_t o = 3 * (size_t)row;
       double o0 = acc[0], o1 = acc[1], o2 = acc[2];
@@ -761,7 +761,7 @@ __global__ __launch_bounds__(kTileThreads) void k_spmv0t(Sym0Dev A, Tile0Dev TL,
         tile_slot(xs, vst, row - T.row0, cw, b, acc);
       }
       seg_scan<3>(row, acc, lane);
-      const int rn = __shfl_down(row, 1);
+      const int rn = next_lane_key(row);
       if (row >= 0 && (lane == 63 || rn != row)) {   // a row's owned slots sit in exactly one group: single writer
         double* d = ys + 3 * (row - T.row0);
         d[0] = acc[0]; d[1] = acc[1]; d[2] = acc[2];
