@@ -311,8 +311,17 @@ __global__ __launch_bounds__(kBlock) void k_block_products(ProdMap mp, BsrDev XA
   const int lane = threadIdx.x & 63;
   int gi, gend, gstride;
   group_walk(mp.ngrp, &gi, &gend, &gstride);
+  int ngb = 0, nge = 0;   // the next group's bounds are requested while the current group is worked on
+  if (gi < gend) {
+    ngb = mp.grp[gi];
+    nge = mp.grp[gi + 1];
+  }
   for (; gi < gend; gi += gstride) {
-    const int gb = mp.grp[gi], ge = mp.grp[gi + 1];
+    const int gb = ngb, ge = nge;
+    if (gi + gstride < gend) {
+      ngb = mp.grp[gi + gstride];
+      nge = mp.grp[gi + gstride + 1];
+    }
     double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     int key = -1 - lane;
     for (int t = gb + lane; t < ge; t += 64) {
@@ -328,10 +337,12 @@ __global__ __launch_bounds__(kBlock) void k_block_products(ProdMap mp, BsrDev XA
           continue;
         }
       }
+      // (the right operand first: its address is known from the index triple, while the left operand of A P hangs on a
+      // chain of its own -- slot -> reference -> block; requested behind that chain it was one dependent round trip more)
       double x[9], y[9];
+      load9(Y, ib, y);
       if (X_BSR) load_block(XA, ia, x);
       else load9(X, ia, x);
-      load9(Y, ib, y);
 #pragma unroll
       for (int r = 0; r < 3; ++r)
 #pragma unroll
