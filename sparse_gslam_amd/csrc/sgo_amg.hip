@@ -645,10 +645,9 @@ __global__ __launch_bounds__(kBlock) void k_ptilde_values(FoldDev F, const doubl
 // Level 0: z_i = y_i + sum over the entries f of row i of P~_f (c1 u1 + c2 u2)[col(f)]; optional partials of dotA . z, dotA2 . z
 // (P: the view of P~ -- row / col / r_grp / r_blk of the folded operator; single GPU: multi-GPU runs keep level 0 unfolded).
 // Workgroups of 1024 threads: the consumer of the dot products re-reduces one partial sum per WORKGROUP in every one of its
-// own workgroups, so there should be a few hundred of them -- while a wave should not walk more than two or three groups,
-// each a chain of three dependent round trips (512 workgroups of 256 threads: 28 us on C4 instead of 12).
+// own workgroups, so there should be a few hundred of them.
 constexpr int kFoldThreads = 1024;
-__global__ __launch_bounds__(kFoldThreads, 2) void k_prolong_fold(PDev P, const double* __restrict__ u1, SpmvRatio r1,
+__global__ __launch_bounds__(kFoldThreads) void k_prolong_fold(PDev P, const double* __restrict__ u1, SpmvRatio r1,
                                                                const double* __restrict__ u2, SpmvRatio r2, const double* __restrict__ y,
                                                                double* __restrict__ out, const PcgScalars* S, const double* __restrict__ dotA,
                                                                const double* __restrict__ dotA2, double* __restrict__ partials) {
@@ -683,8 +682,8 @@ __global__ __launch_bounds__(kFoldThreads, 2) void k_prolong_fold(PDev P, const 
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       double t = sm[c][0];
-#pragma unroll
-      for (int k = 1; k < NW; ++k) t += sm[c][k];
+#pragma unroll 1
+      for (int k = 1; k < NW; ++k) t += sm[c][k];   // (not unrolled: 64 LDS reads in flight would set the kernel's register count)
       v[c] = t;
     }
     __syncthreads();
@@ -693,58 +692,11 @@ __global__ __launch_bounds__(kFoldThreads, 2) void k_prolong_fold(PDev P, const 
   }
   const size_t np = (size_t)P.r_n;
   double dotacc[2] = {0.0, 0.0};
-  // A wave walks its groups with the NEXT group's bounds and first 64 entries already requested while the current group
-  // is worked on (two groups per wave on C4: four dependent round trips instead of six).
-  const sgo_f4* __restrict__ bq = reinterpret_cast<const sgo_f4*>(P.r_blk);
-  int gb = gb0, ge = ge0;
-  int n_key = -1 - lane, n_col = 0;
-  sgo_f4 n_q0 = {0.f, 0.f, 0.f, 0.f}, n_q1 = {0.f, 0.f, 0.f, 0.f};
-  float n_f8 = 0.f;
-  auto request = [&](int b0, int e0) {   // lane's entry of the group [b0, e0), first stride
-    n_key = -1 - lane;
-    const int e = b0 + lane;
-    if (e < e0) {
-      n_key = P.row[e];
-      n_col = P.col[e];
-      if (P.stream_nt) {
-        n_q0 = __builtin_nontemporal_load(bq + e);
-        n_q1 = __builtin_nontemporal_load(bq + np + e);
-        n_f8 = __builtin_nontemporal_load(P.r_blk8 + e);
-      } else {
-        n_q0 = bq[e];
-        n_q1 = bq[np + e];
-        n_f8 = P.r_blk8[e];
-      }
-    }
-  };
-  if (g < gend) request(gb, ge);
-  while (g < gend) {
-    // current group's first stride: what was requested; then the next group's requests go out
-    int key = n_key;
-    const int col = n_col;
-    const sgo_f4 q0 = n_q0, q1 = n_q1;
-    const float f8 = n_f8;
-    const int cgb = gb, cge = ge;
-    const int gn = g + gstride;
-    if (gn < gend) {
-      gb = P.r_grp[gn];
-      ge = P.r_grp[gn + 1];
-    }
+  for (bool first = true; g < gend; g += gstride, first = false) {
+    const int gb = first ? gb0 : P.r_grp[g], ge = first ? ge0 : P.r_grp[g + 1];
     double acc[3] = {0.0, 0.0, 0.0};
-    double y0 = 0.0, y1 = 0.0, y2 = 0.0;
-    if (key >= 0) {
-      const size_t a = 3 * (size_t)col, o = 3 * (size_t)key;
-      double w0 = c1 * u1[a], w1 = c1 * u1[a + 1], w2 = c1 * u1[a + 2];
-      if (u2) {
-        w0 += c2 * u2[a]; w1 += c2 * u2[a + 1]; w2 += c2 * u2[a + 2];
-      }
-      y0 = y[o]; y1 = y[o + 1]; y2 = y[o + 2];   // the row's own term, requested before the scan
-      acc[0] = (double)q0.x * w0 + (double)q0.y * w1 + (double)q0.z * w2;
-      acc[1] = (double)q0.w * w0 + (double)q1.x * w1 + (double)q1.y * w2;
-      acc[2] = (double)q1.z * w0 + (double)q1.w * w1 + (double)f8 * w2;
-    }
-    if (gn < gend) request(gb, ge);
-    for (int e = cgb + 64 + lane; e < cge; e += 64) {   // a row with more than 64 entries (its own group): the further strides
+    int key = -1 - lane;
+    for (int e = gb + lane; e < ge; e += 64) {
       key = P.row[e];
       const size_t a = 3 * (size_t)P.col[e];
       double w0 = c1 * u1[a], w1 = c1 * u1[a + 1], w2 = c1 * u1[a + 2];
@@ -756,6 +708,10 @@ __global__ __launch_bounds__(kFoldThreads, 2) void k_prolong_fold(PDev P, const 
       acc[0] += b[0] * w0 + b[1] * w1 + b[2] * w2;
       acc[1] += b[3] * w0 + b[4] * w1 + b[5] * w2;
       acc[2] += b[6] * w0 + b[7] * w1 + b[8] * w2;
+    }
+    // the row's own term is requested before the scan (one dependent round trip less)
+    double y0 = 0.0, y1 = 0.0, y2 = 0.0;
+    if (key >= 0) {
       const size_t o = 3 * (size_t)key;
       y0 = y[o]; y1 = y[o + 1]; y2 = y[o + 2];
     }
@@ -768,7 +724,6 @@ __global__ __launch_bounds__(kFoldThreads, 2) void k_prolong_fold(PDev P, const 
       if (dotA) dotacc[0] += dotA[o] * o0 + dotA[o + 1] * o1 + dotA[o + 2] * o2;
       if (dotA2) dotacc[1] += dotA2[o] * o0 + dotA2[o + 1] * o1 + dotA2[o + 2] * o2;
     }
-    g = gn;
   }
   if (partials) {
 #pragma unroll

@@ -179,30 +179,36 @@ __device__ __forceinline__ void seg_scan(int row, double (&v)[N], int /*lane*/) 
 // the coarse levels; on level 0 through ref[] from the symmetric storage (diagonal blocks in symmetric
 // packing, off-diagonal blocks stored once and transposed for the other endpoint's row).
 __device__ __forceinline__ void load_block(const BsrDev& A, size_t k, double (&b)[9]) {
+  // All three sources fill nine named scalars and ONE sequence of stores hands them to the caller's array.  (With a store
+  // sequence per branch the optimiser merges the branches' last stores into one store through a phi of POINTERS -- b[8] on
+  // two paths, b[7] on the third -- and the caller's array can then no longer live in registers: the Galerkin products,
+  // k_p_values and k_block_norms went through scratch memory for it.)
+  double v0, v1, v2, v3, v4, v5, v6, v7, v8;
   if (A.ref == nullptr) {
     const size_t ns = (size_t)A.nslot;
-#pragma unroll
-    for (int c = 0; c < 9; ++c) b[c] = A.blk[blk_at(c, k, ns)];
-    return;
+    v0 = A.blk[blk_at(0, k, ns)]; v1 = A.blk[blk_at(1, k, ns)]; v2 = A.blk[blk_at(2, k, ns)];
+    v3 = A.blk[blk_at(3, k, ns)]; v4 = A.blk[blk_at(4, k, ns)]; v5 = A.blk[blk_at(5, k, ns)];
+    v6 = A.blk[blk_at(6, k, ns)]; v7 = A.blk[blk_at(7, k, ns)]; v8 = A.blk[blk_at(8, k, ns)];
+  } else {
+    const int r = A.ref[k];
+    if (r < 0) {
+      const double* d = A.dblk + 6 * (size_t)(~r);
+      v0 = d[0]; v1 = d[1]; v2 = d[2];
+      v3 = v1; v4 = d[3]; v5 = d[4];
+      v6 = v2; v7 = v5; v8 = d[5];
+    } else {
+      const size_t u = (size_t)(r >> 1), nu = (size_t)A.nus;
+      const double2* __restrict__ bp = reinterpret_cast<const double2*>(A.ublk);
+      const double2 p0 = bp[u], p1 = bp[nu + u], p2 = bp[2 * nu + u], p3 = bp[3 * nu + u];
+      const bool tr = r & 1;
+      // stored row-major p0.x p0.y p1.x | p1.y p2.x p2.y | p3.x p3.y ublk8 ; transposed: swap (1,3) (2,6) (5,7)
+      v0 = p0.x; v4 = p2.x; v8 = A.ublk8[u];
+      v1 = tr ? p1.y : p0.y; v3 = tr ? p0.y : p1.y;
+      v2 = tr ? p3.x : p1.x; v6 = tr ? p1.x : p3.x;
+      v5 = tr ? p3.y : p2.y; v7 = tr ? p2.y : p3.y;
+    }
   }
-  const int r = A.ref[k];
-  if (r < 0) {
-    const double* d = A.dblk + 6 * (size_t)(~r);
-    b[0] = d[0]; b[1] = d[1]; b[2] = d[2];
-    b[3] = d[1]; b[4] = d[3]; b[5] = d[4];
-    b[6] = d[2]; b[7] = d[4]; b[8] = d[5];
-    return;
-  }
-  const size_t u = (size_t)(r >> 1);
-  double t[9];
-#pragma unroll
-  for (int c = 0; c < 8; ++c) t[c] = A.ublk[blk_at(c, u, A.nus)];
-  t[8] = A.ublk8[u];
-  const bool tr = r & 1;
-  b[0] = t[0]; b[4] = t[4]; b[8] = t[8];
-  b[1] = tr ? t[3] : t[1]; b[3] = tr ? t[1] : t[3];
-  b[2] = tr ? t[6] : t[2]; b[6] = tr ? t[2] : t[6];
-  b[5] = tr ? t[7] : t[5]; b[7] = tr ? t[5] : t[7];
+  b[0] = v0; b[1] = v1; b[2] = v2; b[3] = v3; b[4] = v4; b[5] = v5; b[6] = v6; b[7] = v7; b[8] = v8;
 }
 
 // Map (block, wave) -> first group and stride so that XCD x (blocks with blockIdx % 8 == x under
