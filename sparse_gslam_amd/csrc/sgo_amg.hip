@@ -81,8 +81,8 @@ __global__ __launch_bounds__(kBlock) void k_centres(int nc, const int* __restric
       sx += pos[2 * (size_t)i];
       sy += pos[2 * (size_t)i + 1];
     }
-    sx = __shfl(wave_sum(sx), 0);   // wave_sum leaves the total in lane 0
-    sy = __shfl(wave_sum(sy), 0);
+    sx = wave_sum(sx);   // (the total, in every lane)
+    sy = wave_sum(sy);
     const double inv = 1.0 / (double)(hi - lo);
     const double cx = sx * inv, cy = sy * inv;
     if (lane == 0) {

@@ -50,11 +50,7 @@ __device__ __forceinline__ void dcs(double e2, double phi, double* rho0, double*
   *rho1 = r1;
 }
 
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
-  return v;  // lane 0
-}
+__device__ __forceinline__ double wave_sum(double v);   // (below, with the DPP helpers)
 
 // Block-wide sums of N values; thread 0 stores them to out[i * stride + blockIdx.x].
 template <int N>
@@ -154,6 +150,20 @@ __device__ __forceinline__ double dpp_double(double v) {
   const int lo = dpp_int<CTRL, ROW_MASK>(0, __double2loint(v)), hi = dpp_int<CTRL, ROW_MASK>(0, __double2hiint(v));
   return __hiloint2double(hi, lo);
 }
+// Sum over the wave, the same in every lane: an inclusive scan by DPP moves on the vector ALU (the total ends up in lane
+// 63) and two v_readlane.  (The shuffle tree it replaces went through ds_bpermute: twelve LDS-crossbar round trips in a
+// dependent chain of six, in the prologue of every kernel that re-reduces partial sums and at the end of every kernel
+// that leaves some.)
+__device__ __forceinline__ double wave_sum(double v) {
+  v += dpp_double<0x111, 0xF>(v);   // row_shr:1
+  v += dpp_double<0x112, 0xF>(v);   // row_shr:2
+  v += dpp_double<0x114, 0xF>(v);   // row_shr:4
+  v += dpp_double<0x118, 0xF>(v);   // row_shr:8
+  v += dpp_double<0x142, 0xA>(v);   // row_bcast15 into rows 1 and 3
+  v += dpp_double<0x143, 0xC>(v);   // row_bcast31 into rows 2 and 3
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
+
 template <int N, int CTRL, int ROW_MASK>
 __device__ __forceinline__ void seg_scan_step(int row, double (&v)[N]) {
   constexpr int kNoKey = (int)0x80000000;   // lanes without a source lane see a key no lane has
