@@ -1152,7 +1152,25 @@ __global__ __launch_bounds__(kBlock) void k_dense_apply(int N, int Np, const dou
   for (bool first = true; i < N; i += gridDim.x * kWavesPerBlock, first = false) {
     const double* row = inv + (size_t)i * Np;
     double s = first ? a0 * b0 : 0.0;
-    for (int j = lane + (first ? 64 : 0); j < N; j += 64) s += row[j] * b[j];
+    // four strides per trip, all eight loads requested before the first product (as a plain loop the compiler waits for
+    // every stride's pair of loads before it requests the next: eleven dependent round trips for N = 750)
+    int j = lane + (first ? 64 : 0);
+    for (; j + 192 < N; j += 256) {
+      const double r0 = row[j], r1 = row[j + 64], r2 = row[j + 128], r3 = row[j + 192];
+      const double c0 = b[j], c1 = b[j + 64], c2 = b[j + 128], c3 = b[j + 192];
+      s += r0 * c0;
+      s += r1 * c1;
+      s += r2 * c2;
+      s += r3 * c3;
+    }
+    {
+      const bool h0 = j < N, h1 = j + 64 < N, h2 = j + 128 < N;
+      const double r0 = h0 ? row[j] : 0.0, r1 = h1 ? row[j + 64] : 0.0, r2 = h2 ? row[j + 128] : 0.0;
+      const double c0 = h0 ? b[j] : 0.0, c1 = h1 ? b[j + 64] : 0.0, c2 = h2 ? b[j + 128] : 0.0;
+      s += r0 * c0;
+      s += r1 * c1;
+      s += r2 * c2;
+    }
     s = wave_sum(s);
     if (lane == 0) x[i] = s;
   }
