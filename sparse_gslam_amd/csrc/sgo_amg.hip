@@ -2761,9 +2761,9 @@ AmgConfig amg_effective_config(const AmgConfig& cfg_in, int n, int nslot) {
   if (const char* e = std::getenv("SGO_AMG_FOLD")) cfg.fold = std::atoi(e) != 0;
   if (const char* e = std::getenv("SGO_AMG_FOLD0_ROWS")) cfg.fold0_rows = std::atoi(e);
   cfg.fold = cfg.fold && cfg.smooth && cfg.lists_on_device;
-  // the folded cycle has ONE sweep per level folded into the transfers (two would need the pattern of A A P); what it saves
-  // per PCG iteration outweighs the iterations a second coarse sweep saves (C4: 22 -> 28 iterations at 150 -> ... us each)
-  if (cfg.fold && std::getenv("SGO_AMG_FOLD_NU1")) cfg.nu_coarse = 1;
+  // (the folded cycle folds ONE sweep per side into the transfers -- two would need the pattern of A A P; a second sweep is
+  // one explicit sweep around it, see cycle().  One sweep everywhere was measured on C4: five coarse launches instead of
+  // nine, but 27.9 instead of 22.1 PCG iterations, 5.07 against 4.59 ms per GN iteration)
   if (const char* e = std::getenv("SGO_AMG_NU")) cfg.nu_coarse = std::max(1, std::atoi(e));
   // larger graphs afford a larger dense coarsest level (its inverse costs O(N^3) once per GN
   // iteration, one K-cycle level less halves the coarse-level launches of every PCG iteration).  A SMALLER dense level
