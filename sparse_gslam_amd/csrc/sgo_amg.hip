@@ -2495,7 +2495,7 @@ Amg* amg_create(hipStream_t s, const BsrDev& A0, const Sym0Dev& S0, const Tile0D
       launch_coarse_operator(m, s, Lr, Cr, l == 0);
       if (l + 1 < m->cfg.max_levels) SGO_LAUNCH(k_level_dinv, dim3(grid_for(Cr.A.n, kBlock)), dim3(kBlock), 0, s, Cr.A);
       if (hipStreamSynchronize(s) != hipSuccess) return fail("amg_create: Galerkin kernel failed");
-      if (std::getenv("SGO_VERBOSE") && n > 20000)
+      if (std::getenv("SGO_VERBOSE") && (n > 20000 || std::atoi(std::getenv("SGO_VERBOSE")) > 1))
         std::fprintf(stderr, "[sgo] amg level %d: alloc + upload %.1f ms (of which product lists on the device %.1f), first values %.1f ms\n", l, t_up,
                      t_up - t_up0, ms_since(tU) - t_up);
     }
