@@ -2014,6 +2014,15 @@ AmgConfig amg_effective_config(const AmgConfig& cfg_in, int n, int nslot) {
                                              // iteration with two sweeps; 20k / 200k 1.81 -> 1.91, C2 1.24 -> 1.36)
   if (const char* e = std::getenv("SGO_AMG_SMOOTH")) cfg.smooth = std::atoi(e) != 0;
   if (const char* e = std::getenv("SGO_AMG_LISTS")) cfg.lists_on_device = std::string(e) != "host";
+  // (experiment knobs of scripts/param_sweep.py.  Round 3, folded cycle, optimize(20) on C4 / C2 / C3s: omega 0.7 / 0.8 / 0.9 /
+  // 1.0 -> 473 / 442 / 422 / 1015 PCG iterations on C4 (0.9 is 3-5 % better on every shape of scripts/robustness.py, 1.0 is
+  // past the cliff: the default keeps its margin); omega_p 0.5 / 0.66 / 0.8 / 1.0 -> 486 / 442 / 557 / 809; theta 0.01 / 0.02 /
+  // 0.04 -> C2 387 / 391 / 285, C3s 598 / 549 / 499, but on C4 theta 0.04 makes the smoothed level-0 operator too dense, the
+  // hierarchy falls back to the tentative transfer with stagnating levels (100k -> 13k -> 4.6k -> 2.6k -> 2.0k) and the first
+  // solve does not converge: the threshold is not a free parameter)
+  if (const char* e = std::getenv("SGO_AMG_OMEGA")) cfg.omega = std::atof(e);
+  if (const char* e = std::getenv("SGO_AMG_OMEGA_P")) cfg.omega_p = std::atof(e);
+  if (const char* e = std::getenv("SGO_AMG_THETA")) cfg.theta = cfg.theta_coarse = std::atof(e);
   if (const char* e = std::getenv("SGO_AMG_FOLD")) cfg.fold = std::atoi(e) != 0;
   if (const char* e = std::getenv("SGO_AMG_FOLD0_ROWS")) cfg.fold0_rows = std::atoi(e);
   cfg.fold = cfg.fold && cfg.smooth && cfg.lists_on_device;
