@@ -13,6 +13,7 @@ namespace sgo {
 struct AmgConfig {
   double theta = 0.02;     // strength-of-connection threshold on level 0
   double theta_coarse = 0.02;  // ... on the coarser levels
+  double theta_scale = 1.0;    // both thresholds are multiplied by this (the caller halves it when a hierarchy's first solve stalls)
   double omega = 0.8;      // block-Jacobi damping
   int max_levels = 10;
   int nu_coarse = 1;           // smoothing sweeps on the coarser V-cycle levels; amg_create picks 2 for

@@ -2551,7 +2551,7 @@ Amg* amg_create(hipStream_t s, const BsrDev& A0, const Sym0Dev& S0, const Tile0D
   if (!m->inv0 || !m->inv1 || !m->d_fail || !m->gjP[0] || !m->gjP[1]) return fail("amg_create: out of device memory");
   hipMemsetAsync(m->d_fail, 0, sizeof(int), s);
   std::snprintf(line, sizeof line, "coarsest dense N=%d; theta=%.3g omega=%.2f", m->N,
-                m->cfg.theta, m->cfg.omega);
+                m->cfg.theta * m->cfg.theta_scale, m->cfg.omega);
   m->desc += line;
   return m;
 }

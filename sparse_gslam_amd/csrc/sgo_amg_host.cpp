@@ -591,7 +591,7 @@ bool sa_symbolic(const HostLevel& H, const std::vector<int>& agg, int nc, const 
 void host_coarsen(const HostLevel& H, const std::vector<double>& w, const AmgConfig& cfg, int l, ChunkArena* scratch, HostCoarse& o) {
   const int n = H.n;
   std::vector<int>& agg = o.agg;
-  const double theta_l = l == 0 ? cfg.theta : cfg.theta_coarse;
+  const double theta_l = (l == 0 ? cfg.theta : cfg.theta_coarse) * cfg.theta_scale;
   const auto tA = std::chrono::steady_clock::now();
   auto ms_since = [](std::chrono::steady_clock::time_point t) {
     return 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count();

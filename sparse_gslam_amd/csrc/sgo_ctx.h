@@ -118,6 +118,7 @@ struct sgo_ctx {
   double bb_ref = 0.0;            // |b|^2 of the first solve of the running sgo_optimize_gn (0: relative tolerance only)
   double tol_cap = 0.0;           // loosest relative tolerance the absolute criterion may reach (0: off; opts.pcg_tol_cap)
   int pcg_softcap = 0;            // > 0: iteration cap of the next solve (sgo_optimize_gn: stale-hierarchy bail-out)
+  double amg_theta_scale = 1.0;   // strength thresholds of the next hierarchy build, as a factor (halved when a hierarchy's first solve stalls)
   // level 0's multigrid host analysis running ahead on a helper thread (build_structure starts it, build_amg joins it)
   AmgHostL0* l0_pre = nullptr;
   std::thread l0_thread;

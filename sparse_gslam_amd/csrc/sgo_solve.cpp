@@ -482,6 +482,7 @@ int build_amg(sgo_ctx* c) {
   }
   c->amg_arena.rewind();
   AmgConfig cfg;
+  cfg.theta_scale = c->amg_theta_scale;
   AmgProf prof;
   prof.user = c;
   prof.begin = [](void* u, int kid, double bytes) {
@@ -710,6 +711,12 @@ int optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
     for (int it = 0; it < iters; ++it) {
       hipEventRecord(ev[3 * it], c->stream);
       c->pcg_softcap = (c->amg && c->amg_best > 0 && rebuilds < 3 && !rebuild_next) ? 4 * c->amg_best + 40 : 0;
+      // A hierarchy that has never solved anything gets kFirstSolveCap iterations: one whose first solve needs more has a
+      // coarse space that does not carry the slow modes (seen with a larger strength threshold on C4: the smoothed level-0
+      // operator too dense, tentative transfers, levels that stop shrinking -- no convergence in 20 000 iterations), and the
+      // set-up is redone with HALF the strength thresholds (larger aggregates, sparser coarse operators) instead.
+      constexpr int kFirstSolveCap = 600;
+      if (c->amg && c->amg_best == 0 && rebuilds < 3 && c->amg_theta_scale > 0.2) c->pcg_softcap = kFirstSolveCap;
       if ((rc = do_chi2(c, c->d_hist + 2 * it, nullptr)) || (rc = do_linearize(c))) return rc;
       if (rebuild_next && c->amg) {
         // The aggregation was made from the Hessian of an earlier linearisation and robust-kernel
@@ -731,6 +738,7 @@ int optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
         // from x = 0 instead of grinding on (seen: 735 iterations where the rebuilt hierarchy needs 16).
         wasted = c->h_S->iter;
         c->pcg_softcap = 0;
+        if (c->amg_best == 0) c->amg_theta_scale *= 0.5;   // this hierarchy never worked: coarsen more aggressively
         if ((rc = build_amg(c)) || (rc = do_linearize(c)) || (rc = run_pcg(c))) return rc;
         ++rebuilds;
         rebuild_next = false;
