@@ -832,19 +832,6 @@ __global__ __launch_bounds__(kBlock) void k_up_fold(BsrDev A, UpDev U, PDev PS, 
   }
 }
 
-// fp32 copy of a coarse level's blocks for the cycle's products on it (BsrDev::fblk)
-__global__ __launch_bounds__(kBlock) void k_blk_f32(BsrDev A) {
-  const size_t ns = (size_t)A.nslot;
-  const double2* __restrict__ bp = reinterpret_cast<const double2*>(A.blk);
-  float4* __restrict__ fp = reinterpret_cast<float4*>(A.fblk);
-  for (size_t k = (size_t)blockIdx.x * kBlock + threadIdx.x; k < ns; k += (size_t)gridDim.x * kBlock) {
-    const double2 p0 = bp[k], p1 = bp[ns + k], p2 = bp[2 * ns + k], p3 = bp[3 * ns + k];
-    fp[k] = make_float4((float)p0.x, (float)p0.y, (float)p1.x, (float)p1.y);
-    fp[ns + k] = make_float4((float)p2.x, (float)p2.y, (float)p3.x, (float)p3.y);
-    A.fblk8[k] = (float)A.blk[8 * ns + k];
-  }
-}
-
 // dinv of a coarse level from its diagonal slots (first slot of each row)
 __global__ __launch_bounds__(kBlock) void k_level_dinv(BsrDev A) {
   const size_t ns = (size_t)A.nslot;
@@ -1509,7 +1496,6 @@ void launch_coarse_operator(Amg* m, hipStream_t s, AmgLevel& L, AmgLevel& C, boo
       std::string e;
       if (!H->comm->allreduce_f64(C.A.blk, 9 * (size_t)C.A.nslot, s, &e)) m->comm_failed = true;
     }
-    if (C.A.fblk) SGO_LAUNCH(k_blk_f32, dim3(grid_for(C.A.nslot, kBlock)), dim3(kBlock), 0, s, C.A);
     return;
   }
   PDev& P = L.P;
@@ -1544,7 +1530,6 @@ void launch_coarse_operator(Amg* m, hipStream_t s, AmgLevel& L, AmgLevel& C, boo
     std::string e;
     if (!H->comm->allreduce_f64(C.A.blk, 9 * (size_t)C.A.nslot, s, &e)) m->comm_failed = true;
   }
-  if (C.A.fblk) SGO_LAUNCH(k_blk_f32, dim3(grid_for(C.A.nslot, kBlock)), dim3(kBlock), 0, s, C.A);
 }
 
 // The coarse solution of level l as seen by its parent: xk (dense level) or the flexible-CG
@@ -2018,8 +2003,8 @@ AmgConfig amg_effective_config(const AmgConfig& cfg_in, int n, int nslot) {
   // 1.0 -> 473 / 442 / 422 / 1015 PCG iterations on C4 (0.9 is 3-5 % better on every shape of scripts/robustness.py, 1.0 is
   // past the cliff: the default keeps its margin); omega_p 0.5 / 0.66 / 0.8 / 1.0 -> 486 / 442 / 557 / 809; theta 0.01 / 0.02 /
   // 0.04 -> C2 387 / 391 / 285, C3s 598 / 549 / 499, but on C4 theta 0.04 makes the smoothed level-0 operator too dense, the
-  // hierarchy falls back to the tentative transfer with stagnating levels (100k -> 13k -> 4.6k -> 2.6k -> 2.0k) and the first
-  // solve does not converge: the threshold is not a free parameter)
+  // hierarchy falls back to the tentative transfer with stagnating levels (100k -> 13k -> 4.6k -> 2.6k -> 2.0k) and needs
+  // 175 iterations for the first solve instead of 30: the threshold is not a free parameter)
   if (const char* e = std::getenv("SGO_AMG_OMEGA")) cfg.omega = std::atof(e);
   if (const char* e = std::getenv("SGO_AMG_OMEGA_P")) cfg.omega_p = std::atof(e);
   if (const char* e = std::getenv("SGO_AMG_THETA")) cfg.theta = cfg.theta_coarse = std::atof(e);
@@ -2442,14 +2427,6 @@ Amg* amg_create(hipStream_t s, const BsrDev& A0, const Sym0Dev& S0, const Tile0D
     C.A.grp = dev_upload(m->pool, grp_c, s);
     C.A.rowptr = dev_upload(m->pool, Hc.rowptr, s);
     C.A.blk = dev_alloc<double>(m->pool, 9 * (size_t)Hc.nslot);
-    // (levels of >= 100k slots: a sweep on them moves 8+ MB, bandwidth-bound -- C5's levels 1-3 hold 2.0 / 1.2 / 0.9 M slots
-    // and their K-cycle products were half of a PCG iteration; below that a sweep is a launch-bound kernel either way)
-    if (Hc.nslot >= 100000 && !(std::getenv("SGO_PRECOND_F32") && std::atoi(std::getenv("SGO_PRECOND_F32")) == 0)) {
-      float* fb = dev_alloc<float>(m->pool, 9 * (size_t)Hc.nslot + 4);
-      if (!fb) return fail("amg_create: out of device memory");
-      C.A.fblk = fb;
-      C.A.fblk8 = fb + 8 * (size_t)Hc.nslot;
-    }
     C.A.dinv = dev_alloc<double>(m->pool, 6 * (size_t)nc);
     if (!L.agg || !L.mem_ptr || !L.mem || !L.mem_grp || !L.d || !C.A.row || !C.A.col ||
         !C.A.grp || !C.A.rowptr || !C.A.blk || !C.A.dinv)

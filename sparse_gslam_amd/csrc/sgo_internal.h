@@ -44,11 +44,6 @@ struct BsrDev {
   int* rowptr = nullptr;  // [n + 1]
   double* blk = nullptr;  // 9 * nslot doubles, layout blk_at()   (nullptr on level 0)
   double* dinv = nullptr; // [n][6] inverse of the diagonal block, symmetric packing
-  // coarse levels with enough slots for their sweeps to be bandwidth-bound: an fp32 copy of blk (two float4 + one float per slot,
-  // quad q of slot k at fblk + 4 (q nslot + k), component 8 at fblk8 + k) that the multigrid cycle's products on the level read --
-  // preconditioner only, as the level-0 passes' copy (Sym0Dev::fblk); the Galerkin products and inverses read blk
-  float* fblk = nullptr;
-  float* fblk8 = nullptr;
   // level 0 only: references into the symmetric storage
   const int* ref = nullptr;     // [nslot]
   const double* ublk = nullptr; // pair-SoA over the stored off-diagonal blocks (components 0..7; see Sym0Dev)

@@ -505,18 +505,11 @@ void k_spmv(BsrDev A, SpmvArgs a) {
       row = A.row[k];
       double x0, x1, x2;
       operand((size_t)A.col[k], x0, x1, x2);
-      double b0, b1, b2, b3, b4, b5, b6, b7, b8;
-      if (A.fblk) {   // the level's fp32 copy: two 16-byte loads + one 4-byte load
-        const float4* __restrict__ fp = reinterpret_cast<const float4*>(A.fblk);
-        const float4 q0 = fp[k], q1 = fp[ns + k];
-        const float f8 = A.fblk8[k];
-        b0 = q0.x; b1 = q0.y; b2 = q0.z; b3 = q0.w; b4 = q1.x; b5 = q1.y; b6 = q1.z; b7 = q1.w; b8 = f8;
-      } else {        // four 16-byte loads (component pairs) + one 8-byte load
-        const double2* __restrict__ bp = reinterpret_cast<const double2*>(A.blk);
-        const double2 p0 = bp[k], p1 = bp[ns + k], p2 = bp[2 * ns + k], p3 = bp[3 * ns + k];
-        b0 = p0.x; b1 = p0.y; b2 = p1.x; b3 = p1.y; b4 = p2.x; b5 = p2.y; b6 = p3.x; b7 = p3.y;
-        b8 = A.blk[8 * ns + k];
-      }
+      // four 16-byte loads (component pairs) + one 8-byte load
+      const double2* __restrict__ bp = reinterpret_cast<const double2*>(A.blk);
+      const double2 p0 = bp[k], p1 = bp[ns + k], p2 = bp[2 * ns + k], p3 = bp[3 * ns + k];
+      const double b0 = p0.x, b1 = p0.y, b2 = p1.x, b3 = p1.y, b4 = p2.x, b5 = p2.y, b6 = p3.x, b7 = p3.y;
+      const double b8 = A.blk[8 * ns + k];
       acc[0] += b0 * x0 + b1 * x1 + b2 * x2;
       acc[1] += b3 * x0 + b4 * x1 + b5 * x2;
       acc[2] += b6 * x0 + b7 * x1 + b8 * x2;

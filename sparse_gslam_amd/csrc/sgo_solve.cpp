@@ -711,12 +711,12 @@ int optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
     for (int it = 0; it < iters; ++it) {
       hipEventRecord(ev[3 * it], c->stream);
       c->pcg_softcap = (c->amg && c->amg_best > 0 && rebuilds < 3 && !rebuild_next) ? 4 * c->amg_best + 40 : 0;
-      // A hierarchy that has never solved anything gets kFirstSolveCap iterations: one whose first solve needs more has a
-      // coarse space that does not carry the slow modes (seen with a larger strength threshold on C4: the smoothed level-0
-      // operator too dense, tentative transfers, levels that stop shrinking -- no convergence in 20 000 iterations), and the
-      // set-up is redone with HALF the strength thresholds (larger aggregates, sparser coarse operators) instead.
-      constexpr int kFirstSolveCap = 600;
-      if (c->amg && c->amg_best == 0 && rebuilds < 3 && c->amg_theta_scale > 0.2) c->pcg_softcap = kFirstSolveCap;
+      // A hierarchy that has never solved anything gets 600 iterations (the hardest first solves seen take 200-350: C4 from a
+      // dead-reckoned start): one that needs more has a coarse space that does not carry the slow modes, and the set-up is
+      // redone with HALF the strength thresholds (larger aggregates, sparser coarse operators) instead of grinding on to
+      // pcg_maxit.  (SGO_FIRST_SOLVE_CAP: test hook.)
+      const int first_solve_cap = std::getenv("SGO_FIRST_SOLVE_CAP") ? std::max(1, std::atoi(std::getenv("SGO_FIRST_SOLVE_CAP"))) : 600;
+      if (c->amg && c->amg_best == 0 && rebuilds < 3 && c->amg_theta_scale > 0.2) c->pcg_softcap = first_solve_cap;
       if ((rc = do_chi2(c, c->d_hist + 2 * it, nullptr)) || (rc = do_linearize(c))) return rc;
       if (rebuild_next && c->amg) {
         // The aggregation was made from the Hessian of an earlier linearisation and robust-kernel
