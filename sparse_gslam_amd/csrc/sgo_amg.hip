@@ -2004,7 +2004,9 @@ AmgConfig amg_effective_config(const AmgConfig& cfg_in, int n, int nslot) {
   // past the cliff: the default keeps its margin); omega_p 0.5 / 0.66 / 0.8 / 1.0 -> 486 / 442 / 557 / 809; theta 0.01 / 0.02 /
   // 0.04 -> C2 387 / 391 / 285, C3s 598 / 549 / 499, but on C4 theta 0.04 makes the smoothed level-0 operator too dense, the
   // hierarchy falls back to the tentative transfer with stagnating levels (100k -> 13k -> 4.6k -> 2.6k -> 2.0k) and needs
-  // 175 iterations for the first solve instead of 30: the threshold is not a free parameter)
+  // 175 iterations for the first solve instead of 30; 0.025 / 0.03 keep the smoothed transfer on C4 but its denser coarse
+  // operators double the time (85 -> 159 / 167 ms), and 10k poses / 100k edges goes 354 -> 552 / 748 iterations: the
+  // threshold is not a free parameter)
   if (const char* e = std::getenv("SGO_AMG_OMEGA")) cfg.omega = std::atof(e);
   if (const char* e = std::getenv("SGO_AMG_OMEGA_P")) cfg.omega_p = std::atof(e);
   if (const char* e = std::getenv("SGO_AMG_THETA")) cfg.theta = cfg.theta_coarse = std::atof(e);
