@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""The reference's flow on a config: sgo_set_graph_se2 + optimize(20), four cycles on one context -- ms of each part and the
+first Gauss-Newton iterations' times (`python scripts/cycle_time.py C4 C2`)."""
 import sys, os, time
 sys.path.insert(0, os.getcwd())
 from sparse_gslam_amd import capi, synth

@@ -1,5 +1,5 @@
 #!/bin/bash
-# PMC passes over scripts/spmv0_probe.py (a few counters per pass); prints per-kernel means.
+# PMC passes over scripts/spmv0_modes.py (a few counters per pass); prints per-kernel means.
 # usage: gpurun -- bash scripts/pmc_probe.sh "CNT1 CNT2" "CNT3 ..." ...
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -10,7 +10,7 @@ for set in "$@"; do
   i=$((i+1))
   O=$R/gpurun_out/pmcp_$i
   rm -rf $O
-  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $O -- python3 $R/scripts/spmv0_probe.py C4 > $O.log 2>&1
+  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $O -- python3 $R/scripts/spmv0_modes.py C4 > $O.log 2>&1
   python3 - "$O" <<'PY'
 import sys, glob, csv, collections, re
 acc = collections.defaultdict(lambda: collections.defaultdict(list))

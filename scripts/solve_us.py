@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""Microseconds per PCG iteration (the solve phase of every Gauss-Newton iteration divided by its PCG count) and ms of the
+linearisation + hierarchy refresh, unprofiled, as optimize(20) runs them (`python scripts/solve_us.py C2 C4`)."""
 import sys, os
 sys.path.insert(0, os.getcwd())
 from sparse_gslam_amd import capi, synth
