@@ -13,6 +13,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+def BJ_OPTS(capi):
+    """The block-Jacobi solver BASELINE.json names: thousands of iterations per solve on a system of condition ~1e8.  At the
+    default pcg_tol = 1e-8 two runs whose reductions are ordered differently (another partition) agree to what that
+    tolerance leaves of the solution -- 8.7e-6 in chi2 was seen with 4 ranks, above BASELINE.json's 1e-6 -- so this solver's
+    cases run at 1e-10 (and without the absolute-accuracy cap), where the partitions agree within the bound."""
+    return dict(solver=capi.SOLVER_PCG_BJ, pcg_maxit=200000, pcg_tol=1e-10, pcg_tol_cap=0.0)
+
+
 def make_case(k, seed):
     from sparse_gslam_amd import synth
     rng = np.random.default_rng(seed * 1000 + k)
@@ -53,7 +61,7 @@ def worker(rank, world, port, k, seed, iters, q):
         def allreduce(a):
             dist.all_reduce(torch.from_numpy(a))
 
-        opts = dict(solver=capi.SOLVER_PCG_BJ, pcg_maxit=60000) if solver == "pcg" else {}
+        opts = BJ_OPTS(capi) if solver == "pcg" else {}
         with capi.Optimizer(0, **opts) as o:
             o.comm_init_host(world, rank, allreduce)
             o.set_graph(*g.arrays())
@@ -97,7 +105,7 @@ def main():
             p.join(timeout=60)
         old = {kk: os.environ.get(kk) for kk in env}
         os.environ.update(env)
-        opts = dict(solver=capi.SOLVER_PCG_BJ, pcg_maxit=60000) if solver == "pcg" else {}
+        opts = BJ_OPTS(capi) if solver == "pcg" else {}
         with capi.Optimizer(0, **opts) as o:
             o.set_graph(*g.arrays())
             d1, s1 = o.optimize(iters)
@@ -111,10 +119,7 @@ def main():
         same = ok and all(r[2] == res[0][2] and r[3] == res[0][3] and r[4] == res[0][4] for r in res[1:])
         rel = max((abs(a - b) / max(b, 1e-30) for a, b in zip(res[0][2], s1["chi2"])), default=0.0) if ok and d1 > 0 else float("nan")
         dp = np.abs(np.frombuffer(res[0][4], dtype=np.float64).reshape(-1, 3) - P1).max() if ok else float("nan")
-        # (block-Jacobi PCG: thousands of iterations per solve on a system of condition ~1e8 -- two runs whose reductions are
-        # ordered differently agree to what pcg_tol leaves of the solution, not to 1e-6; seen: 8.7e-6 after solves of 5 000
-        # iterations, ranks bit-identical)
-        rel_tol = 1e-4 if solver == "pcg" else 1e-6
+        rel_tol = 1e-6      # BASELINE.json's bound, for every solver (the block-Jacobi cases run at pcg_tol 1e-10: BJ_OPTS)
         verdict = "ok" if (ok and same and rel <= rel_tol and dp <= 1e-4) else "MISMATCH"
         bad += verdict != "ok"
         print(f"case {k}: {label}: {verdict}; done {[r[1] for r in res]} vs {d1}; ranks identical {same}; chi2 rel {rel:.1e}; poses {dp:.1e}; "

@@ -445,6 +445,10 @@ int sgo_debug_coarse_rhs(sgo_ctx* c, const double* r, double* out, int cap) {
   int rc = check_graph(c);
   if (rc) return rc;
   if (!r || !out || !c->linearized) return SGO_EINVAL;
+  if (c->owner) {   // this rank holds its own rows' blocks and transfer entries only: the hook walks whole-graph arrays
+    c->err = "sgo_debug_coarse_rhs: not available in multi-GPU row-owner mode";
+    return SGO_EINVAL;
+  }
   if (ensure_amg(c)) return 0;
   if (!c->amg) return 0;
   if ((rc = vec_to_device(c, r, c->d_s1))) return rc;

@@ -1,12 +1,14 @@
-// sgo_comm.cpp -- RCCL binding for the edge-sharded multi-GPU mode (one process per GPU).
+// sgo_comm.cpp -- RCCL binding of the multi-GPU modes (one process per GPU).
 //
-// librccl is dlopen'ed on first use so that the single-GPU product path carries no RCCL
-// dependency.  Only ncclAllReduce(sum) is used: on the product vector of every level-0 Hessian
-// product of the solve -- each rank evaluates the rows of its range of tiles and writes zeros
-// elsewhere, so the sum reproduces the full vector exactly -- and on the two chi2 partial sums
-// (BASELINE.json north_star).  A communicator of ONE
-// rank still calls ncclAllReduce (the single-GPU test of this path).  A caller may bring its own transport
-// instead (sgo_comm_init_host: MPI, gloo, ...): the same collectives, staged through pinned host memory.
+// librccl is dlopen'ed on first use so that the single-GPU product path carries no RCCL dependency.  Two collectives:
+//   ncclAllGather  row-owner mode's exchanges (one fixed-size packet per rank: partial dot products + boundary rows of a
+//                  vector, or 72-byte records of the smoothed prolongator) and the ranks' owned slices of a vector
+//                  (the Gauss-Newton step; the all-reduce mode's product vectors: one contributor per row, nothing to sum);
+//   ncclAllReduce  (sum) the coarse right-hand side of every multigrid cycle, the level-1 Galerkin blocks once per GN
+//                  iteration, the two chi2 sums, and -- rank-emulation hook only -- zero-filled product vectors.
+// A communicator of ONE rank still calls both (the single-GPU test of this path).  A caller may bring its own transport
+// instead (sgo_comm_init_host + optional sgo_comm_host_allgather: MPI, gloo, ...): the same collectives, staged through
+// pinned host memory.
 #include <dlfcn.h>
 
 #include <cstdlib>

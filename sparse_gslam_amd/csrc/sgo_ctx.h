@@ -60,12 +60,15 @@ struct sgo_ctx {
   std::vector<int> unit_row0;                        // first row of every work unit (+ n at the end)
   bool owner = false;            // multi-GPU row-owner mode (HaloDev, sgo_internal.h); false with a communicator: all-reduce mode
   bool gather_slices = false;    // all-reduce mode with a communicator: product vectors travel as an all-gather of the ranks' slices
+  bool replicated = false;       // multi-rank context, but this graph has fewer level-0 work units than ranks: every rank runs the
+                                 // whole single-GPU computation (bit-identical on all ranks, no collective), see build_rows
   HaloDev halo;
   HaloHost halo_host;
   bool halo_failed = false;
   long long level0_bytes = 0;    // device bytes of the level-0 structure this rank holds (blocks, operands, per-slot / per-block indices)
   double *halo_send = nullptr, *halo_recv = nullptr;   // exchange buffers (hipMalloc, grown on demand, kept across graphs)
   size_t halo_cap = 0;
+  int halo_ranks = 0;            // world size the receive buffer was sized for
 
   // graph (host)
   bool has_graph = false;
@@ -141,6 +144,9 @@ struct sgo_ctx {
 };
 
 namespace sgo {
+
+// does this graph's solve run sharded over the ranks of the context's communicator (or of the rank-emulation hook)?
+inline bool multi_rank(const sgo_ctx* c) { return (c->comm.nranks > 1 || c->comm.active()) && !c->replicated; }
 
 extern thread_local std::string g_err;   // error text of context-free calls (sgo_last_error(NULL))
 

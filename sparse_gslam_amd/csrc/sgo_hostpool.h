@@ -34,10 +34,7 @@ class HostPool {
     static thread_local int l = 0;
     return l;
   }
-  static HostPool& get() {
-    static HostPool p0, p1;
-    return lane() ? p1 : p0;
-  }
+  static HostPool& get() { return lane() ? pool1() : pool0(); }
   int size() const { return nthreads_; }
   // fn(t) for t in [0, ntasks), distributed over the workers and the caller
   template <class F>
@@ -78,12 +75,25 @@ class HostPool {
   HostPool& operator=(const HostPool&) = delete;
 
  private:
+  // each lane is created by its first user (a process that never runs the set-up pipeline parks no second pool)
+  static HostPool& pool0() {
+    static HostPool p;
+    return p;
+  }
+  static HostPool& pool1() {
+    static HostPool p;
+    return p;
+  }
+  // Default size: the cores this process may run on, at most 32 -- shared among the rank processes of one node
+  // (LOCAL_WORLD_SIZE, as torch.distributed.run exports it: 8 ranks on a node would otherwise park 8 x 2 x 31 threads and
+  // oversubscribe the host during the parallel structure build).  SGO_HOST_THREADS overrides.
   HostPool() {
     int n = (int)std::thread::hardware_concurrency();
 #if defined(__linux__)
     cpu_set_t set;
     if (sched_getaffinity(0, sizeof(set), &set) == 0) n = CPU_COUNT(&set);
 #endif
+    if (const char* e = std::getenv("LOCAL_WORLD_SIZE")) n /= std::max(1, std::atoi(e));
     n = std::max(1, std::min(n, 32));
     if (const char* e = std::getenv("SGO_HOST_THREADS")) n = std::max(1, std::atoi(e));
     start(n);

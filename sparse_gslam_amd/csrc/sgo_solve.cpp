@@ -76,14 +76,14 @@ int do_chi2(sgo_ctx* c, double* d_out2, double* d_e2) {
   {
     Scope sc(c, K_CHI2, bytes_chi2(c));
     int e0 = 0, e1 = c->E;
-    if (c->comm.nranks > 1 && !d_e2) sgo_shard_range(c->E, c->comm.nranks, c->comm.rank, &e0, &e1);
+    if (c->comm.nranks > 1 && !c->replicated && !d_e2) sgo_shard_range(c->E, c->comm.nranks, c->comm.rank, &e0, &e1);
     launch_chi2(c->stream, c->el, e0, e1, c->d_poses, d_e2, c->d_partials, &grid);
   }
   {
     Scope sc(c, K_REDUCE2, 16.0 * grid);
     launch_reduce2(c->stream, c->d_partials, grid, d_out2);
   }
-  if (c->comm.nranks > 1 && !d_e2 && !c->comm.allreduce_f64(d_out2, 2, c->stream, &c->err)) return SGO_ECOMM;
+  if (c->comm.nranks > 1 && !c->replicated && !d_e2 && !c->comm.allreduce_f64(d_out2, 2, c->stream, &c->err)) return SGO_ECOMM;
   return SGO_OK;
 }
 
@@ -256,7 +256,7 @@ int do_spmv(sgo_ctx* c, const double* x, double* y, bool dot, const PcgScalars* 
     if (grid_out) *grid_out = grid;
     return SGO_OK;
   }
-  if (c->comm.nranks > 1 || c->comm.active()) {
+  if (multi_rank(c)) {
     // multi-GPU: this rank's range of tiles only, zeros elsewhere, all-reduce of the product vector (every row
     // has exactly one non-zero contributor: the sum is exact), then the dot product on the full vectors --
     // the same arithmetic on every rank, so the replicated PCG recurrences stay bit-identical across ranks
@@ -414,7 +414,7 @@ int run_pcg(sgo_ctx* c) {
   // flag, which is bit-identical on all ranks).  Measured with a 1-rank communicator: 154 -> 167 M edge-Jacobians/s on
   // C4; off by default because it has never run on more than one GPU.  Not possible with the host transport.
   const bool comm_graph = c->comm.handle != nullptr && !c->comm.host_fn && std::getenv("SGO_COMM_GRAPH") != nullptr;
-  const bool graph = c->opts.use_graph && !c->opts.profile && (!(c->comm.nranks > 1 || c->comm.active()) || comm_graph);
+  const bool graph = c->opts.use_graph && !c->opts.profile && (!multi_rank(c) || comm_graph);
   if (!graph) {
     const int chunk = std::max(1, c->opts.pcg_chunk);
     for (;;) {
@@ -462,7 +462,8 @@ std::string multi_gpu_description(const sgo_ctx* c) {
   if (c->owner)
     return "; multi-GPU row-owner mode: rank " + std::to_string(c->halo.me) + " of " + std::to_string(c->halo.G) + " owns rows [" +
            std::to_string(c->halo.row0) + ", " + std::to_string(c->halo.row1) + "), largest boundary " + std::to_string(c->halo.bmax) + " rows";
-  if (c->comm.nranks > 1 || c->comm.active()) return "; multi-GPU all-reduce mode (" + std::to_string(c->comm.nranks) + " ranks)";
+  if (multi_rank(c)) return "; multi-GPU all-reduce mode (" + std::to_string(c->comm.nranks) + " ranks)";
+  if (c->replicated) return "; multi-GPU: replicated on all " + std::to_string(c->comm.nranks) + " ranks (fewer level-0 work units than ranks)";
   return "";
 }
 
@@ -528,7 +529,7 @@ int build_amg(sgo_ctx* c) {
     return SGO_ECOMM;
   }
   if (c->amg) {
-    if (!c->owner && (c->comm.nranks > 1 || c->comm.active()))
+    if (!c->owner && multi_rank(c))
       amg_set_shard(c->amg, &c->comm, c->shard_u0, c->shard_u1, c->shard_row0, c->shard_row1, c->gather_slices ? &c->halo : nullptr);
     amg_describe(c->amg, &c->solver_desc);
     c->solver_desc = "pcg_amg: " + c->solver_desc;
@@ -547,9 +548,19 @@ int build_rows(sgo_ctx* c, const double* poses, const uint8_t* fixed, const int3
   int rc = build_structure(c, c->V, poses, fixed, c->E, ei, ej);
   if (rc != SGO_OK) return rc;
   c->shard_units = c->T0.ntile > 0 ? c->T0.ntile : c->S0.ngrp;
-  sgo_shard_range(c->shard_units, c->comm.nranks, c->comm.rank, &c->shard_u0, &c->shard_u1);
-  c->shard_row0 = c->unit_row0.empty() ? 0 : c->unit_row0[c->shard_u0];
-  c->shard_row1 = c->unit_row0.empty() ? c->n : c->unit_row0[c->shard_u1];
+  // A graph with fewer work units than ranks (a few hundred poses on 8 GPUs) would leave some rank an EMPTY range, which the
+  // level-0 kernels and the transfers read as "all" (u1 == 0 / row1 == 0): such a graph is not sharded at all -- every rank
+  // runs the single-GPU computation on its own copy (same arithmetic: bit-identical ranks, no collective).
+  c->replicated = (c->comm.nranks > 1 || c->comm.active()) && !c->owner && !c->gather_slices && c->shard_units < c->comm.nranks;
+  if (c->replicated) {
+    c->shard_u0 = c->shard_u1 = 0;
+    c->shard_row0 = 0;
+    c->shard_row1 = c->n;
+  } else {
+    sgo_shard_range(c->shard_units, c->comm.nranks, c->comm.rank, &c->shard_u0, &c->shard_u1);
+    c->shard_row0 = c->unit_row0.empty() ? 0 : c->unit_row0[c->shard_u0];
+    c->shard_row1 = c->unit_row0.empty() ? c->n : c->unit_row0[c->shard_u1];
+  }
   // Chain-like graphs (fewer than ~1.5 edges per free pose: under 4 Hessian blocks per row) are the
   // ill-conditioned ones -- kappa(H) grows with the square of the chain length -- and a relative
   // residual of 1e-8 then leaves errors that show in chi2 (3000 poses / 3150 edges: iterates 3e-6 and

@@ -23,19 +23,24 @@ void l0_join(sgo_ctx* c, bool keep) {
 }
 
 int halo_reserve(sgo_ctx* c, size_t packet_doubles) {
-  if (packet_doubles > c->halo_cap) {
+  // the receive buffer holds one packet per rank: it is remade when the packets grow AND when the communicator has
+  // more ranks than the buffers were made for (a context may be given another communicator between graphs)
+  const int ranks = std::max(1, c->comm.nranks);
+  if (packet_doubles > c->halo_cap || ranks > c->halo_ranks) {
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (c->halo_send) hipFree(c->halo_send);
     if (c->halo_recv) hipFree(c->halo_recv);
     c->halo_send = c->halo_recv = nullptr;
+    const size_t cap = std::max(c->halo_cap, packet_doubles + packet_doubles / 4 + 64);
     c->halo_cap = 0;
-    const size_t cap = packet_doubles + packet_doubles / 4 + 64;
+    c->halo_ranks = 0;
     if (hipMalloc((void**)&c->halo_send, sizeof(double) * cap) != hipSuccess ||
-        hipMalloc((void**)&c->halo_recv, sizeof(double) * cap * (size_t)std::max(1, c->comm.nranks)) != hipSuccess) {
+        hipMalloc((void**)&c->halo_recv, sizeof(double) * cap * (size_t)ranks) != hipSuccess) {
       c->err = "out of device memory (multi-GPU exchange buffers)";
       return SGO_ENOMEM;
     }
     c->halo_cap = cap;
+    c->halo_ranks = ranks;
   }
   c->halo.send = c->halo_send;
   c->halo.recv = c->halo_recv;
@@ -74,6 +79,7 @@ void free_graph(sgo_ctx* c) {
   c->linearized = false;
   c->owner = false;
   c->gather_slices = false;
+  c->replicated = false;
   c->halo = HaloDev();
   c->halo_failed = false;
 }
@@ -516,9 +522,13 @@ int build_structure(sgo_ctx* c, int V, const double* poses, const uint8_t* fixed
   // ---- multi-GPU, row-owner mode: the boundary rows of every rank (the rows with an edge into another rank's range)
   c->owner = false;
   c->gather_slices = false;
+  c->replicated = false;
   c->halo = HaloDev();
   c->halo_host = HaloHost();
-  if (c->comm.active() && tiles_ok && !tiles.empty() && n >= 2048) {   // (the rank-emulation hook without a communicator keeps the all-reduce mode's sharded passes)
+  // (the rank-emulation hook without a communicator keeps the all-reduce mode's sharded passes; fewer tiles than ranks:
+  // some rank's range would be empty -- build_rows then runs the graph replicated.  SGO_OWNER_MIN_ROWS: test hook)
+  const int owner_min_rows = std::getenv("SGO_OWNER_MIN_ROWS") ? std::atoi(std::getenv("SGO_OWNER_MIN_ROWS")) : 2048;
+  if (c->comm.active() && tiles_ok && (int)tiles.size() >= c->comm.nranks && n >= owner_min_rows) {
     const int G = c->comm.nranks, nt = (int)tiles.size();
     HaloHost& HH = c->halo_host;
     HH.G = G;
@@ -559,6 +569,8 @@ int build_structure(sgo_ctx* c, int V, const double* poses, const uint8_t* fixed
     // product vectors ("keep both modes").  SGO_COMM_MODE=owner|allreduce forces one.
     bool owner = 4 * total <= (long long)n;
     if (const char* e = std::getenv("SGO_COMM_MODE")) owner = !std::strcmp(e, "owner") ? true : (!std::strcmp(e, "allreduce") ? false : owner);
+    // (every rank owns at least one tile -- nt >= G above -- and so at least one row: the level-0 kernels read an empty
+    // range, u1 == 0, as "all tiles")
     if (owner) {
       HH.bmax = std::max(bmax, 1);
       HH.bnd.assign((size_t)G * HH.bmax, -1);

@@ -41,6 +41,8 @@ def _graph(name):
         return synth.manhattan(3000, 12000, seed=5, info_mode="full")
     if name == "C4":         # configs[3] at full size (100k poses / 1M edges): the bench workload of bench.py --gpus N
         return synth.config("C4")
+    if name == "tiny":       # fewer level-0 tiles than ranks (a rank's range would be empty): runs replicated on every rank
+        return synth.manhattan(700, 760, seed=9, info_mode="full")
     if name == "pipelined":  # >= 20 000 free poses: the set-up's helper thread is active on every rank (bench.py's C4 at N > 1)
         return synth.manhattan(24000, 150000, seed=77, info_mode="full")
     raise KeyError(name)
@@ -255,3 +257,28 @@ def test_hierarchy_rebuild_inside_optimize_in_row_owner_mode(monkeypatch):
     for a, b in zip(res[0][2], st["chi2"]):
         assert abs(a - b) <= 1e-6 * b
     assert max(res[0][3]) < 400        # no solve ground on with a stale hierarchy
+
+
+def test_fewer_tiles_than_ranks_runs_replicated():
+    """A graph whose level-0 plan has fewer tiles than ranks would leave a rank an empty range, which the level-0 kernels and
+    the transfers read as "everything" (u1 == 0 / row1 == 0): out-of-bounds reads in row-owner mode, double-counted coarse
+    right-hand sides in all-reduce mode.  Such graphs run replicated -- every rank the whole single-GPU computation, no
+    collective inside the solve: ranks bit-identical, and equal to the single-GPU path to rounding (that one multiplies through
+    the wave-group kernel, the ranks through the tile kernel)."""
+    from sparse_gslam_amd import capi
+    g = _graph("tiny")
+    plan = capi.plan_rows(g.poses, g.fixed, g.ei, g.ej, nranks=3)
+    assert len(plan["tile_row_begin"]) - 1 < 3          # the premise: fewer tiles than ranks
+    res = _run(3, "tiny", 5)
+    assert all(r[1] == 5 for r in res), [r[:3] for r in res]
+    assert "replicated" in res[0][8], res[0][8]
+    for r in res[1:]:
+        assert r[2] == res[0][2] and r[3] == res[0][3] and r[4] == res[0][4]
+    with capi.Optimizer(0, direct_rows=0) as o:        # the multigrid-PCG path the ranks ran (a communicator rules the direct path out)
+        o.set_graph(*g.arrays())
+        d, st = o.optimize(5)
+        P = o.get_poses()
+    assert d == 5
+    assert np.abs(np.frombuffer(res[0][4], dtype=np.float64).reshape(-1, 3) - P).max() <= 1e-9
+    for a, b in zip(res[0][2], st["chi2"]):
+        assert abs(a - b) <= 1e-9 * b
