@@ -30,7 +30,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 measured copy)
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec ...
+HBM_COPY_GBS = 6290.0  # ... and the copy rate measured there (frac_of_measured_copy)
 
 
 def cpu_baseline(g, iters: int):
@@ -315,7 +316,7 @@ def main():
             p.set_graph(*g.arrays())
             p.profile_reset()
             p.optimize(min(args.iters, 4))
-            raw = p.kernel_profile()
+            raw = p.kernel_profile(quantiles=True)
             overhead_us = 1e3 * p.profile_overhead_ms()
         prof = raw
         # dominant kernel: the kernel FUNCTION with the largest summed time (the three epilogue forms of the
@@ -327,7 +328,11 @@ def main():
             f["ms"] += v["ms"]; f["launches"] += v["launches"]; f["bytes"] += v["bytes"]; f["members"].append(n)
         fname, fk = max(fam.items(), key=lambda kv: kv[1]["ms"])
         name, k = max(((n, prof[n]) for n in fk["members"]), key=lambda kv: kv[1]["ms"])
-        achieved = k["bytes"] / (k["ms"] * 1e-3) / 1e9
+        # per launch: algorithmic bytes / MEDIAN single-launch duration (profile mode reads the stop flag after every PCG
+        # iteration: no early-exit launch past convergence among the samples; the mean is reported beside it)
+        bytes_per_launch = k["bytes"] / k["launches"]
+        med_us = k.get("median_us", 1e3 * k["ms"] / k["launches"])
+        achieved = bytes_per_launch / (med_us * 1e-6) / 1e9
         # HBM traffic of the same kernel from the separate rocprofv3 --pmc passes (FETCH_SIZE x2,
         # WRITE_SIZE; scripts/pmc_summary.py), committed per round under profiles/
         traffic, traffic_src = None, None
@@ -336,6 +341,19 @@ def main():
             kk = json.load(open(cand))["kernels"].get(name)
             if kk:
                 traffic, traffic_src = kk["hbm_bytes_per_launch"], os.path.relpath(cand, ROOT)
+        # the same kernel INSIDE the replayed hipGraph of a solve (back to back with its neighbours): median of the working
+        # dispatches of a rocprofv3 --kernel-trace pass over this bench in graph mode (scripts/profile_round.sh ->
+        # scripts/trace_summary.py), committed per round under profiles/
+        in_solve = None
+        for cand in sorted(__import__("glob").glob(os.path.join(ROOT, "profiles", f"r*_trace_summary_{args.config.lower()}_graph.json"))):
+            kk = json.load(open(cand))["kernels"].get(name)
+            if kk:
+                in_solve = {"median_us": kk["median_us"], "p10_us": kk["p10_us"], "p90_us": kk["p90_us"],
+                            "working_dispatches": kk["working"], "dispatches": kk["dispatches"],
+                            "achieved": bytes_per_launch / (kk["median_us"] * 1e-6) / 1e9,
+                            "frac": bytes_per_launch / (kk["median_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                            "frac_of_measured_copy": bytes_per_launch / (kk["median_us"] * 1e-6) / 1e9 / HBM_COPY_GBS,
+                            "source": os.path.relpath(cand, ROOT)}
         # whole-iteration figure of SURVEY.md section 8(d): B_GN = B_lin + K B_pcg + 48 V over the median
         # GN iteration time, B_lin = 200 E + 72 V, B_pcg = 76 E + 430 V, K = PCG iterations per GN iteration
         K = float(np.mean(st["pcg_iters"]))
@@ -343,16 +361,19 @@ def main():
         t_gn = float(np.median(st["seconds"]))
         out["roofline"] = {
             "bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+            "frac": achieved / HBM_PEAK_GBS, "frac_of_measured_copy": achieved / HBM_COPY_GBS, "measured_copy_GBs": HBM_COPY_GBS,
+            "traffic": traffic, "traffic_source": traffic_src,
+            "median_launch_us": med_us, "p10_launch_us": k.get("p10_us"), "p90_launch_us": k.get("p90_us"),
             "avg_launch_us": 1e3 * k["ms"] / k["launches"], "launches": k["launches"],
             "event_bracket_overhead_us": overhead_us,
-            "algorithmic_bytes_per_launch": k["bytes"] / k["launches"],
+            "algorithmic_bytes_per_launch": bytes_per_launch,
+            "in_solve": in_solve,
             "kernel_function": {"name": fname, "instantiations": sorted(fk["members"]), "launches": fk["launches"],
                                 "ms": round(fk["ms"], 3), "avg_launch_us": 1e3 * fk["ms"] / fk["launches"],
                                 "achieved": fk["bytes"] / (fk["ms"] * 1e-3) / 1e9,
                                 "frac": fk["bytes"] / (fk["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS},
             "gn_iteration": {"bytes": b_gn, "seconds": t_gn, "pcg_iters": K, "achieved": b_gn / t_gn / 1e9,
-                             "frac": b_gn / t_gn / 1e9 / HBM_PEAK_GBS},
+                             "frac": b_gn / t_gn / 1e9 / HBM_PEAK_GBS, "frac_of_measured_copy": b_gn / t_gn / 1e9 / HBM_COPY_GBS},
             # share of the profiled kernel time spent in kernels that a rank of a multi-GPU run (row-owner mode)
             # evaluates for ITS rows only: level-0 products, linearisation, vector updates, level-0 transfers and the
             # level-0 part of the hierarchy refresh ("@level0" slots); the rest (coarse levels, dense inverse) is replicated
@@ -360,14 +381,16 @@ def main():
                 sum(v["ms"] for n, v in prof.items() if n.startswith(("k_spmv0", "k_linearize", "k_finalize", "k_update_", "k_dot", "k_chi2",
                                                                         "k_pose_update")) or n.endswith("@level0")),
                 sum(v["ms"] for v in prof.values())),
-            "note": "achieved = algorithmic bytes (SURVEY.md section 8(d): every stored block once with one index, "
-                    "76 B per edge, + the per-row vectors; DESIGN.md section 4) of all launches of this kernel / their "
-                    "summed HIP-event time; the events are the dispatch's own start/stop stamps "
+            "note": "achieved = algorithmic bytes per launch (SURVEY.md section 8(d): every stored block once with one index, "
+                    "76 B per edge, + the per-row vectors; DESIGN.md section 4) / the MEDIAN HIP-event duration of this "
+                    "kernel's launches (no launch past convergence among them); the events are the dispatch's own start/stop stamps "
                     "(hipExtLaunchKernelGGL), comparable with rocprofv3 kernel durations; traffic = mean HBM "
                     "bytes per launch from rocprofv3 --pmc passes; gn_iteration = B_GN / t_GN of section 8(d); "
                     "per-kernel table uses rocprofv3's kernel names",
             "kernels": {n: {"launches": v["launches"], "ms": round(v["ms"], 3),
                             "avg_us": round(1e3 * v["ms"] / v["launches"], 2),
+                            "median_us": round(v.get("median_us", 0.0), 2), "p10_us": round(v.get("p10_us", 0.0), 2),
+                            "p90_us": round(v.get("p90_us", 0.0), 2),
                             "GB/s": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)}
                         for n, v in prof.items() if v["ms"] > 0}}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

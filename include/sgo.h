@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define SGO_VERSION 103          /* 0.1.3: row-owner multi-GPU mode (sgo_comm_host_allgather, sgo_debug_level0_bytes); 0.1.2: sgo_comm_init_host; 0.1.1: sgo_opts.direct_rows (took a reserved slot), sgo_solver_description */
+#define SGO_VERSION 104          /* 0.1.4: sgo_kernel_profile_samples, sgo_update_graph_se2 (incremental set-up); 0.1.3: row-owner multi-GPU mode (sgo_comm_host_allgather, sgo_debug_level0_bytes); 0.1.2: sgo_comm_init_host; 0.1.1: sgo_opts.direct_rows (took a reserved slot), sgo_solver_description */
 #define SGO_MAX_ITERS 256        /* capacity of the per-iteration arrays in sgo_stats */
 
 /* error codes (negative).  -1 mirrors g2o's optimize() "nothing to optimise". */
@@ -212,6 +212,11 @@ typedef struct sgo_kernel_stat {
   double bytes;
 } sgo_kernel_stat;
 int sgo_kernel_profile(sgo_ctx* ctx, sgo_kernel_stat* out, int cap);
+/* The single launches behind slot `slot` of sgo_kernel_profile (same order of slots): their durations in milliseconds, in
+ * launch order, up to the first 16384 per slot since the last sgo_profile_reset -- for medians and percentiles (a mean hides
+ * what a few outliers or early-exit launches do to it).  In profile mode the PCG loop checks the stop flag after every
+ * iteration, so no launch past convergence is among them.  Returns the number of samples written (<= cap), < 0 on error. */
+int sgo_kernel_profile_samples(sgo_ctx* ctx, int slot, float* out_ms, int cap);
 int sgo_profile_reset(sgo_ctx* ctx);
 /* Milliseconds an EMPTY event bracket measures on this context's stream: the upper bound of the
  * per-launch bias of sgo_kernel_profile's times relative to rocprofv3 kernel durations. */

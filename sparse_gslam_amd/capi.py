@@ -29,6 +29,7 @@ SYMBOLS = [
     "sgo_comm_init", "sgo_comm_size", "sgo_shard_range", "sgo_debug_set_shard", "sgo_last_error",
     "sgo_closure_information", "sgo_plan_rows", "sgo_debug_coarse_rhs", "sgo_debug_spmv0_us",
     "sgo_solver_description", "sgo_comm_init_host", "sgo_comm_host_allgather", "sgo_debug_level0_bytes",
+    "sgo_kernel_profile_samples",
 ]
 
 
@@ -116,6 +117,7 @@ def lib():
     L.sgo_solve.argtypes = [vp, d, d]
     L.sgo_precondition.argtypes = [vp, d, d]
     L.sgo_kernel_profile.argtypes = [vp, C.POINTER(KernelStat), C.c_int]
+    L.sgo_kernel_profile_samples.argtypes = [vp, C.c_int, C.POINTER(C.c_float), C.c_int]
     L.sgo_solver_description.restype = C.c_char_p
     L.sgo_solver_description.argtypes = [vp]
     L.sgo_profile_reset.argtypes = [vp]
@@ -387,14 +389,22 @@ class Optimizer:
         return lib().sgo_solver_description(self._h).decode()
 
     # -- profiling
-    def kernel_profile(self):
-        arr = (KernelStat * 64)()
-        n = self._check(lib().sgo_kernel_profile(self._h, arr, 64), "sgo_kernel_profile")
+    def kernel_profile(self, quantiles: bool = False):
+        """Per-kernel launches / summed ms / algorithmic bytes (sgo_kernel_profile); quantiles=True adds the median, 10th and
+        90th percentile of the single-launch durations in microseconds (sgo_kernel_profile_samples)."""
+        arr = (KernelStat * 128)()
+        n = self._check(lib().sgo_kernel_profile(self._h, arr, 128), "sgo_kernel_profile")
         out = {}
-        for k in range(min(n, 64)):
+        buf = np.empty(16384, dtype=np.float32) if quantiles else None
+        for k in range(min(n, 128)):
             if arr[k].launches:
-                out[arr[k].name.decode()] = dict(launches=int(arr[k].launches), ms=arr[k].ms,
-                                                 bytes=arr[k].bytes)
+                d = dict(launches=int(arr[k].launches), ms=arr[k].ms, bytes=arr[k].bytes)
+                if quantiles:
+                    m = lib().sgo_kernel_profile_samples(self._h, k, buf.ctypes.data_as(C.POINTER(C.c_float)), buf.size)
+                    if m > 0:
+                        q = np.percentile(1e3 * buf[:m].astype(np.float64), [10, 50, 90])
+                        d.update(samples=int(m), p10_us=float(q[0]), median_us=float(q[1]), p90_us=float(q[2]))
+                out[arr[k].name.decode()] = d
         return out
 
     def profile_overhead_ms(self):

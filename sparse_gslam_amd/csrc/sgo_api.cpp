@@ -474,6 +474,17 @@ int sgo_kernel_profile(sgo_ctx* c, sgo_kernel_stat* out, int cap) {
   } SGO_CATCH(c)
 }
 
+int sgo_kernel_profile_samples(sgo_ctx* c, int slot, float* out_ms, int cap) {
+  try {
+    if (!c || slot < 0 || slot >= K_COUNT || cap < 0 || (cap > 0 && !out_ms)) return SGO_EINVAL;
+    prof_flush(c);
+    const std::vector<float>& v = c->prof_samples[slot];
+    const int n = (int)std::min<size_t>(v.size(), (size_t)cap);
+    std::copy(v.begin(), v.begin() + n, out_ms);
+    return n;
+  } SGO_CATCH(c)
+}
+
 double sgo_profile_overhead_ms(sgo_ctx* c) {
   if (!c) return -1.0;
   if (c->prof_null_ms < 0.0) prof_calibrate(c);
@@ -488,6 +499,7 @@ int sgo_profile_reset(sgo_ctx* c) {
       c->prof_ms[k] = 0;
       c->prof_launches[k] = 0;
       c->prof_bytes[k] = 0;
+      c->prof_samples[k].clear();
     }
     return SGO_OK;
   } SGO_CATCH(c)

@@ -139,6 +139,8 @@ struct sgo_ctx {
   double prof_ms[K_COUNT] = {0};
   int64_t prof_launches[K_COUNT] = {0};
   double prof_bytes[K_COUNT] = {0};
+  std::vector<float> prof_samples[K_COUNT];   // single-launch durations (ms), the first kProfSamples per slot
+  static constexpr size_t kProfSamples = 16384;
   void* amg_scope = nullptr;  // Scope* of the AMG launch being bracketed
   double prof_null_ms = -1.0; // time of an empty event bracket on this stream (calibration)
 };

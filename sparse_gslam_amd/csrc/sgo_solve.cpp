@@ -50,7 +50,10 @@ void prof_flush(sgo_ctx* c) {
   hipStreamSynchronize(c->stream);
   for (auto& r : c->pending) {
     float ms = 0.f;
-    if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) c->prof_ms[r.kid] += ms;
+    if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+      c->prof_ms[r.kid] += ms;
+      if (c->prof_samples[r.kid].size() < sgo_ctx::kProfSamples) c->prof_samples[r.kid].push_back(ms);
+    }
     c->ev_pool.push_back(r.a);
     c->ev_pool.push_back(r.b);
   }
@@ -416,7 +419,9 @@ int run_pcg(sgo_ctx* c) {
   const bool comm_graph = c->comm.handle != nullptr && !c->comm.host_fn && std::getenv("SGO_COMM_GRAPH") != nullptr;
   const bool graph = c->opts.use_graph && !c->opts.profile && (!multi_rank(c) || comm_graph);
   if (!graph) {
-    const int chunk = std::max(1, c->opts.pcg_chunk);
+    // (profile mode: the stop flag is read after EVERY iteration, so that no early-exit launch past convergence is among
+    // the timed launches -- their 1.5-us dispatches would pull the per-kernel figures down)
+    const int chunk = c->opts.profile ? 1 : std::max(1, c->opts.pcg_chunk);
     for (;;) {
       HIP_TRY(c, hipMemcpyAsync(c->h_S, c->d_S, sizeof(PcgScalars), hipMemcpyDeviceToHost, c->stream));
       HIP_TRY(c, hipStreamSynchronize(c->stream));
