@@ -809,6 +809,8 @@ class SparseOptimizer : public OptimizableGraph {
   }
 
   const sgo_stats* lastStats() const { return _lastStats.get(); }
+  // which solver / set-up the backend used for the graph it holds (extension for the tests: sgo_solver_description)
+  std::string backendDescription() const { return _ctx ? std::string(sgo_solver_description(_ctx)) : std::string(); }
   // Levenberg-Marquardt bookkeeping of the last optimize() on the host solver (extension for the tests; g2o
   // exposes the same numbers through OptimizationAlgorithmLevenberg::currentLambda() / levenbergIterations()
   // and its verbose output): damping after the iteration, robust chi2 after it, trials it took.
@@ -995,19 +997,13 @@ class SparseOptimizer : public OptimizableGraph {
   // marshal the pointer graph into the flat arrays of sgo_set_graph_se2 (compact vertex numbering
   // in ascending id) and upload.  g2o rebuilds the system from the edge objects on every optimize(),
   // so measurement / information / fixed / kernel-delta changes made between two optimize() calls
-  // without an initializeOptimization() must be seen: the arrays are marshalled every time and only
-  // when they hash equal to what the device holds is the upload reduced to the poses.
-  static uint64_t hashBytes(uint64_t h, const void* p, size_t n) {   // FNV-1a over 8-byte words + tail
-    const unsigned char* c = static_cast<const unsigned char*>(p);
-    size_t i = 0;
-    for (; i + 8 <= n; i += 8) {
-      uint64_t w;
-      std::memcpy(&w, c + i, 8);
-      h = (h ^ w) * 1099511628211ull;
-    }
-    for (; i < n; ++i) h = (h ^ c[i]) * 1099511628211ull;
-    return h;
-  }
+  // without an initializeOptimization() must be seen: the arrays are marshalled every time and compared
+  // with what the device holds.  Three outcomes:
+  //   * identical graph: only the poses are uploaded (sgo_set_poses);
+  //   * the device's graph is a PREFIX of the new one -- what the reference's loop closer produces: the graph it
+  //     optimised before + a chain of new poses + one closure (slc.cpp:205-226, :272-287) -- : sgo_update_graph_se2,
+  //     which keeps the resident structures when the appended part allows it (include/sgo.h);
+  //   * anything else: sgo_set_graph_se2.
   bool uploadGraph() {
     if (!_ctx) {
       _ctx = sgo_create(-1, nullptr);
@@ -1026,7 +1022,11 @@ class SparseOptimizer : public OptimizableGraph {
       v->setTempIndex(k);   // compact numbering in ascending id (the array index sgo uses)
     }
     std::vector<uint8_t> fixed(V);
-    for (int k = 0; k < V; ++k) fixed[k] = _activeVertices[k]->fixed() ? 1 : 0;
+    std::vector<int32_t> vid(V);
+    for (int k = 0; k < V; ++k) {
+      fixed[k] = _activeVertices[k]->fixed() ? 1 : 0;
+      vid[k] = _activeVertices[k]->id();
+    }
     std::vector<int32_t> ei(E), ej(E);
     std::vector<double> meas(3 * (size_t)E), info(6 * (size_t)E), phi(E);
     for (int k = 0; k < E; ++k) {
@@ -1039,29 +1039,36 @@ class SparseOptimizer : public OptimizableGraph {
       o[0] = O(0, 0); o[1] = O(0, 1); o[2] = O(0, 2); o[3] = O(1, 1); o[4] = O(1, 2); o[5] = O(2, 2);
       phi[k] = e->robustKernel() ? e->robustKernel()->delta() : -1.0;
     }
-    uint64_t h = 1469598103934665603ull;
-    h = hashBytes(h, fixed.data(), fixed.size());
-    h = hashBytes(h, ei.data(), sizeof(int32_t) * ei.size());
-    h = hashBytes(h, ej.data(), sizeof(int32_t) * ej.size());
-    h = hashBytes(h, meas.data(), sizeof(double) * meas.size());
-    h = hashBytes(h, info.data(), sizeof(double) * info.size());
-    h = hashBytes(h, phi.data(), sizeof(double) * phi.size());
-    if (_graphOnDevice && h == _deviceGraphHash && V == _deviceV && E == _deviceE) {
+    // is the device's graph (the previous marshal) a prefix of this one?  Same vertex ids and fixed flags for its
+    // vertices (compact numbers then agree), bit-identical edge records for its edges
+    auto same = [](const void* a, const void* b, size_t n) { return n == 0 || std::memcmp(a, b, n) == 0; };
+    const int dV = (int)_m.vid.size(), dE = (int)_m.ei.size();
+    const bool prefix = _graphOnDevice && V >= dV && E >= dE && same(vid.data(), _m.vid.data(), sizeof(int32_t) * (size_t)dV) &&
+                        same(fixed.data(), _m.fixed.data(), (size_t)dV) && same(ei.data(), _m.ei.data(), sizeof(int32_t) * (size_t)dE) &&
+                        same(ej.data(), _m.ej.data(), sizeof(int32_t) * (size_t)dE) && same(meas.data(), _m.meas.data(), sizeof(double) * 3 * (size_t)dE) &&
+                        same(info.data(), _m.info.data(), sizeof(double) * 6 * (size_t)dE) && same(phi.data(), _m.phi.data(), sizeof(double) * (size_t)dE);
+    if (prefix && V == dV && E == dE) {
       if (sgo_set_poses(_ctx, poses.data()) == SGO_OK) return true;
       std::cerr << "SparseOptimizer: " << sgo_last_error(_ctx) << std::endl;
       return false;
     }
     _graphOnDevice = false;
-    int rc = sgo_set_graph_se2(_ctx, V, poses.data(), fixed.data(), E, ei.data(), ej.data(), meas.data(), info.data(),
-                               phi.data());
+    const int rc = prefix ? sgo_update_graph_se2(_ctx, V, poses.data(), fixed.data(), E, ei.data(), ej.data(), meas.data(), info.data(),
+                                                 phi.data(), dE)
+                          : sgo_set_graph_se2(_ctx, V, poses.data(), fixed.data(), E, ei.data(), ej.data(), meas.data(), info.data(),
+                                              phi.data());
     if (rc != SGO_OK) {
       std::cerr << "SparseOptimizer: " << sgo_last_error(_ctx) << std::endl;
       return false;
     }
     _graphOnDevice = true;
-    _deviceGraphHash = h;
-    _deviceV = V;
-    _deviceE = E;
+    _m.vid.swap(vid);
+    _m.fixed.swap(fixed);
+    _m.ei.swap(ei);
+    _m.ej.swap(ej);
+    _m.meas.swap(meas);
+    _m.info.swap(info);
+    _m.phi.swap(phi);
     return true;
   }
   void downloadEstimates() {
@@ -1086,8 +1093,11 @@ class SparseOptimizer : public OptimizableGraph {
   std::vector<OptimizableGraph::Edge*> _activeEdges;
   sgo_ctx* _ctx = nullptr;
   bool _graphOnDevice = false;
-  uint64_t _deviceGraphHash = 0;
-  int _deviceV = 0, _deviceE = 0;
+  struct Marshalled {   // what the device holds, as it was marshalled
+    std::vector<int32_t> vid, ei, ej;
+    std::vector<uint8_t> fixed;
+    std::vector<double> meas, info, phi;
+  } _m;
   std::unique_ptr<sgo_stats> _lastStats;
   std::deque<VertexSE2> _loadedVertices;   // objects created by load(): the optimiser's own
   std::deque<EdgeSE2> _loadedEdges;

@@ -137,6 +137,25 @@ int sgo_set_graph_se2(sgo_ctx* ctx, int32_t V, const double* poses, const uint8_
                       const int32_t* ei, const int32_t* ej, const double* meas, const double* info,
                       const double* phi);
 
+/* Incremental form of the same call for the reference's flow: after every accepted loop closure it appends a chain of
+ * new poses with their odometry edges (slc.cpp:205-226) and one closure edge (slc.cpp:272-285) to the graph it optimised
+ * before, then calls initializeOptimization(); optimize(20) again (slc.cpp:286-287).  Arguments as sgo_set_graph_se2 -- the
+ * WHOLE new graph -- plus n_resident_edges: the caller's statement that edges [0, n_resident_edges) and the vertices they
+ * use are the graph this context already holds, unchanged (ids, measurement, information, kernel, fixed flags; estimates
+ * may differ: `poses` is uploaded in full).  When that is the resident graph and the appended part has the shape above --
+ * new free poses whose mutual edges form a chain in id order, any edges between new and resident poses or among resident
+ * poses, within the capacities of sgo_overlay.h -- the appended part becomes an overlay beside the resident level-0
+ * structure and multigrid hierarchy, which are kept (the Gauss-Newton systems are still solved exactly: the chain is
+ * eliminated by a block-tridiagonal factorisation, the resident rows by PCG on the Schur complement).  Otherwise --
+ * including n_resident_edges == 0, a multi-GPU context, a graph on the single-launch direct path, an overlay whose PCG
+ * iteration counts have drifted -- the call IS sgo_set_graph_se2.  sgo_solver_description says which happened.  While an
+ * overlay is resident the single-step entry points (sgo_linearize, sgo_hessian_apply, sgo_precondition, sgo_solve) return
+ * SGO_EINVAL; sgo_optimize_gn, sgo_chi2, sgo_edge_chi2, sgo_get_poses, sgo_set_poses, sgo_num_free, sgo_free_ids cover the
+ * whole graph. */
+int sgo_update_graph_se2(sgo_ctx* ctx, int32_t V, const double* poses, const uint8_t* fixed, int32_t E,
+                         const int32_t* ei, const int32_t* ej, const double* meas, const double* info,
+                         const double* phi, int32_t n_resident_edges);
+
 /* Replaces: VertexSE2::setEstimate on every vertex (slc.cpp:219) without a structure rebuild. */
 int sgo_set_poses(sgo_ctx* ctx, const double* poses);
 /* Replaces: reading VertexSE2::estimate() after optimize() (slc.cpp:144-148, log_runner.cpp:258-267). */

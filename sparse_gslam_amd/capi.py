@@ -29,7 +29,7 @@ SYMBOLS = [
     "sgo_comm_init", "sgo_comm_size", "sgo_shard_range", "sgo_debug_set_shard", "sgo_last_error",
     "sgo_closure_information", "sgo_plan_rows", "sgo_debug_coarse_rhs", "sgo_debug_spmv0_us",
     "sgo_solver_description", "sgo_comm_init_host", "sgo_comm_host_allgather", "sgo_debug_level0_bytes",
-    "sgo_kernel_profile_samples",
+    "sgo_kernel_profile_samples", "sgo_update_graph_se2",
 ]
 
 
@@ -105,6 +105,7 @@ def lib():
     L.sgo_create.argtypes = [C.c_int, C.POINTER(Opts)]
     L.sgo_destroy.argtypes = [vp]
     L.sgo_set_graph_se2.argtypes = [vp, C.c_int32, d, u8, C.c_int32, i32, i32, d, d, d]
+    L.sgo_update_graph_se2.argtypes = [vp, C.c_int32, d, u8, C.c_int32, i32, i32, d, d, d, C.c_int32]
     L.sgo_set_poses.argtypes = [vp, d]
     L.sgo_get_poses.argtypes = [vp, d]
     L.sgo_optimize_gn.argtypes = [vp, C.c_int32, C.POINTER(Stats)]
@@ -284,6 +285,22 @@ class Optimizer:
         self._check(lib().sgo_set_graph_se2(self._h, p.shape[0], _dp(p), f.ctypes.data_as(C.POINTER(C.c_uint8)),
                                             a.size, _ip(a), _ip(b), _dp(m), _dp(o), _dp(ph)),
                     "sgo_set_graph_se2")
+        self.V, self.E = p.shape[0], a.size
+
+    def update_graph(self, poses, fixed, ei, ej, meas, info, phi, n_resident_edges: int):
+        """sgo_update_graph_se2: the whole new graph + how many leading edges are the resident graph's (incremental set-up)."""
+        p = np.ascontiguousarray(poses, dtype=np.float64).reshape(-1, 3)
+        f = np.ascontiguousarray(fixed, dtype=np.uint8)
+        a = np.ascontiguousarray(ei, dtype=np.int32)
+        b = np.ascontiguousarray(ej, dtype=np.int32)
+        m = np.ascontiguousarray(meas, dtype=np.float64).reshape(-1, 3)
+        o = np.ascontiguousarray(info, dtype=np.float64).reshape(-1, 6)
+        ph = np.ascontiguousarray(phi, dtype=np.float64)
+        if not (f.shape[0] == p.shape[0] and a.size == b.size == m.shape[0] == o.shape[0] == ph.size):
+            raise ValueError("inconsistent array sizes")
+        self._check(lib().sgo_update_graph_se2(self._h, p.shape[0], _dp(p), f.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                               a.size, _ip(a), _ip(b), _dp(m), _dp(o), _dp(ph), int(n_resident_edges)),
+                    "sgo_update_graph_se2")
         self.V, self.E = p.shape[0], a.size
 
     def set_poses(self, poses):

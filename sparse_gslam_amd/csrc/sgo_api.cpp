@@ -107,6 +107,7 @@ void sgo_destroy(sgo_ctx* c) {
   c->graph_arena.release();
   c->amg_arena.release();
   c->comm.destroy();
+  overlay_release(c->ov);
   for (hipEvent_t e : c->ev_pool) hipEventDestroy(e);
   for (hipEvent_t e : c->iter_events) hipEventDestroy(e);
   if (c->h_S) hipHostFree(c->h_S);
@@ -127,6 +128,10 @@ const char* sgo_solver_description(sgo_ctx* c) {
   try {
     c->solver_text = c->solver_desc;
     if (!c->direct && !c->direct_why.empty()) c->solver_text += "; direct path not used: " + c->direct_why;
+    if (c->ov.active)
+      c->solver_text += "; incremental overlay: " + std::to_string(c->ov.dev.k) + " appended rows, " + std::to_string(c->ov.dev.nt) +
+                        " touched rows, " + std::to_string(c->ov.dev.el.cnt) + " appended edges (" + std::to_string(c->ov.updates) + " updates)";
+    if (!c->update_note.empty()) c->solver_text += "; last update: " + c->update_note;
     return c->solver_text.c_str();
   } catch (...) {   // no C++ exception crosses the C boundary
     return "";
@@ -208,10 +213,108 @@ int sgo_set_graph_se2(sgo_ctx* c, int32_t V, const double* poses, const uint8_t*
       if (c->opts.verbose) std::fprintf(stderr, "[sgo] set_graph: multigrid set-up %.1f ms\n", 1e3 * (wall_s() - ta0));
       c->linearized = false;
     }
+    // what an incremental update (sgo_update_graph_se2) appends to
+    c->ov.base_V = V;
+    c->ov.base_E = E;
+    c->ov.base_n = c->n;
+    c->ov.fixed.assign(fixed, fixed + V);
     c->setup_seconds = wall_s() - t0;
     if (c->opts.verbose)
       std::fprintf(stderr, "[sgo] solver: %s\n[sgo] set_graph: total %.1f ms\n", c->solver_desc.c_str(), 1e3 * c->setup_seconds);
     return SGO_OK;
+  } SGO_CATCH(c)
+}
+
+// Incremental re-initialisation: see include/sgo.h and sgo_overlay.h.
+int sgo_update_graph_se2(sgo_ctx* c, int32_t V, const double* poses, const uint8_t* fixed, int32_t E, const int32_t* ei,
+                         const int32_t* ej, const double* meas, const double* info, const double* phi, int32_t n_resident_edges) {
+  try {
+    if (!c) return SGO_EINVAL;
+    if (V <= 0 || E < 0 || !poses || !fixed || (E > 0 && (!ei || !ej || !meas || !info || !phi)) || n_resident_edges < 0 || n_resident_edges > E) {
+      c->err = "sgo_update_graph_se2: bad argument";
+      return SGO_EINVAL;
+    }
+    const double t0 = wall_s();
+    Overlay& ov = c->ov;
+    std::string why;
+    const int res_E = c->has_graph ? ov.base_E + (int)ov.ei.size() : 0;
+    bool env_on = true;
+    if (const char* e = std::getenv("SGO_INCREMENTAL")) env_on = std::atoi(e) != 0;
+    if (!c->has_graph) why = "no resident graph";
+    else if (!env_on) why = "disabled (SGO_INCREMENTAL=0)";
+    else if (n_resident_edges == 0) why = "the caller reports no common prefix";
+    else if (c->direct || c->rows_pending || c->amg_pending) why = "the resident graph takes the single-launch direct path (its set-up is cheap)";
+    else if (!c->amg || c->opts.solver != SGO_SOLVER_PCG_AMG) why = "no multigrid hierarchy resident";
+    else if (c->comm.nranks > 1 || c->comm.active()) why = "multi-GPU contexts re-partition";
+    else if (n_resident_edges != res_E || V < c->V) why = "the resident graph is not a prefix of the new one";
+    else if (V - ov.base_V > kOvMaxVerts || E - ov.base_E > kOvMaxEdges) why = "the appended part has outgrown the overlay";
+    else if (std::memcmp(fixed, ov.fixed.data(), (size_t)c->V) != 0) why = "fixed flags of resident vertices changed";
+    else if (ov.hpos.size() != (size_t)ov.base_V) why = "no row map of the resident structure";
+    // an overlay that costs too many PCG iterations (counts only) is dropped for a fresh hierarchy that knows the closures
+    else if (ov.active && c->its_base > 0.0 && c->its_last > 1.25 * c->its_base + 3.0) why = "the overlay costs too many PCG iterations";
+    if (why.empty()) {
+      for (int e = n_resident_edges; e < E; ++e) {
+        const int a = ei[e], b = ej[e];
+        if (a < 0 || a >= V || b < 0 || b >= V) {
+          c->err = "edge " + std::to_string(e) + " references a vertex outside [0, V)";
+          return SGO_EINVAL;
+        }
+        if (a == b) {
+          c->err = "edge " + std::to_string(e) + " is a self edge";
+          return SGO_EINVAL;
+        }
+      }
+      hipError_t he = hipSetDevice(c->device);
+      if (he != hipSuccess) {
+        c->err = std::string("hipSetDevice: ") + hipGetErrorString(he);
+        return SGO_EHIP;
+      }
+      // the update is tried on copies of the host state: a shape the overlay cannot take leaves the resident graph as it was
+      const size_t old_ne = ov.ei.size();
+      const int dE = E - n_resident_edges;
+      ov.ei.insert(ov.ei.end(), ei + n_resident_edges, ei + E);
+      ov.ej.insert(ov.ej.end(), ej + n_resident_edges, ej + E);
+      const std::vector<unsigned char> old_fixed = ov.fixed;
+      ov.fixed.assign(fixed, fixed + V);
+      const OverlayDev old_dev = ov.dev;
+      const std::vector<int> old_new = ov.new_vertex;
+      hipStreamSynchronize(c->stream);   // (nothing of an earlier optimize() may still read the overlay's structure arrays)
+      bool ok = overlay_upload_edges(ov, c->stream, (int)old_ne, dE, ei + n_resident_edges, ej + n_resident_edges,
+                                     meas + 3 * (size_t)n_resident_edges, info + 6 * (size_t)n_resident_edges, phi + n_resident_edges, &c->err);
+      if (ok) ok = overlay_build(ov, V, c->stream, &why, &c->err);
+      if (ok && hipMemcpyAsync(c->d_poses, poses, sizeof(double) * 3 * (size_t)V, hipMemcpyHostToDevice, c->stream) != hipSuccess) {
+        ok = false;
+        why = "pose upload failed";
+      }
+      if (ok && hipStreamSynchronize(c->stream) != hipSuccess) {   // the caller's arrays may go away after the call
+        ok = false;
+        why = "device error";
+      }
+      if (ok) {
+        ov.active = ov.dev.k + ov.dev.nt > 0;
+        ov.updates++;
+        c->V = V;
+        c->E = E;
+        c->linearized = false;
+        c->warm_valid = false;
+        c->setup_seconds = wall_s() - t0;
+        c->update_note = "incremental (" + std::to_string(dE) + " edges appended in " + std::to_string(1e3 * c->setup_seconds).substr(0, 5) + " ms)";
+        if (c->opts.verbose)
+          std::fprintf(stderr, "[sgo] update_graph: %d edges / %d vertices appended as overlay (%d rows, %d touched) in %.2f ms\n", dE,
+                       V - (int)old_fixed.size(), ov.dev.k, ov.dev.nt, 1e3 * c->setup_seconds);
+        return SGO_OK;
+      }
+      ov.ei.resize(old_ne);
+      ov.ej.resize(old_ne);
+      ov.fixed = old_fixed;
+      ov.dev = old_dev;
+      ov.new_vertex = old_new;
+      if (why.empty()) why = "overlay set-up failed";
+    }
+    if (c->opts.verbose) std::fprintf(stderr, "[sgo] update_graph: full set-up (%s)\n", why.c_str());
+    const int rc = sgo_set_graph_se2(c, V, poses, fixed, E, ei, ej, meas, info, phi);
+    if (rc == SGO_OK) c->update_note = "full set-up (" + why + ")";
+    return rc;
   } SGO_CATCH(c)
 }
 
@@ -240,7 +343,7 @@ int sgo_get_poses(sgo_ctx* c, double* poses) {
 
 int sgo_num_free(sgo_ctx* c) {
   int rc = check_graph(c);
-  return rc ? rc : c->n;
+  return rc ? rc : c->n + (c->ov.active ? c->ov.dev.k : 0);
 }
 
 int sgo_free_ids(sgo_ctx* c, int32_t* out) {
@@ -248,6 +351,10 @@ int sgo_free_ids(sgo_ctx* c, int32_t* out) {
     int rc = check_graph(c);
     if (rc) return rc;
     if (!out) return SGO_EINVAL;
+    if (c->ov.active && c->ov.dev.k > 0) {   // g2o's hessian order over the resident and the appended free poses
+      std::merge(c->free_id.begin(), c->free_id.end(), c->ov.new_vertex.begin(), c->ov.new_vertex.end(), out);
+      return c->n + c->ov.dev.k;
+    }
     std::copy(c->free_id.begin(), c->free_id.end(), out);
     return c->n;
   } SGO_CATCH(c)
@@ -340,6 +447,10 @@ int sgo_linearize(sgo_ctx* c, double* b, double* diag, double* plain, double* ro
   try {
     int rc = check_graph(c);
     if (rc) return rc;
+    if (c->ov.active) {
+      c->err = "single-step entry points need a full set-up: the resident graph carries an incremental overlay (call sgo_set_graph_se2)";
+      return SGO_EINVAL;
+    }
     if (c->n == 0) return SGO_ENOTHING;
     if ((rc = ensure_amg(c))) return rc;
     if ((rc = do_chi2(c, c->d_hist, nullptr))) return rc;
@@ -373,6 +484,10 @@ int sgo_hessian_apply(sgo_ctx* c, const double* x, double* y) {
   try {
     int rc = check_graph(c);
     if (rc) return rc;
+    if (c->ov.active) {
+      c->err = "single-step entry points need a full set-up: the resident graph carries an incremental overlay (call sgo_set_graph_se2)";
+      return SGO_EINVAL;
+    }
     if (!x || !y) return SGO_EINVAL;
     if (!c->linearized) {
       c->err = "sgo_hessian_apply: call sgo_linearize first";
@@ -389,6 +504,10 @@ int sgo_precondition(sgo_ctx* c, const double* r, double* z) {
   try {
     int rc = check_graph(c);
     if (rc) return rc;
+    if (c->ov.active) {
+      c->err = "single-step entry points need a full set-up: the resident graph carries an incremental overlay (call sgo_set_graph_se2)";
+      return SGO_EINVAL;
+    }
     if (!r || !z) return SGO_EINVAL;
     if (!c->linearized) {
       c->err = "sgo_precondition: call sgo_linearize first";
@@ -408,6 +527,10 @@ int sgo_solve(sgo_ctx* c, double* x, double* relres) {
   try {
     int rc = check_graph(c);
     if (rc) return rc;
+    if (c->ov.active) {
+      c->err = "single-step entry points need a full set-up: the resident graph carries an incremental overlay (call sgo_set_graph_se2)";
+      return SGO_EINVAL;
+    }
     if (!c->linearized) {
       c->err = "sgo_solve: call sgo_linearize first";
       return SGO_EINVAL;
@@ -444,7 +567,7 @@ double sgo_debug_spmv0_us(sgo_ctx* c, int mode, int variant, int reps) { return 
 int sgo_debug_coarse_rhs(sgo_ctx* c, const double* r, double* out, int cap) {
   int rc = check_graph(c);
   if (rc) return rc;
-  if (!r || !out || !c->linearized) return SGO_EINVAL;
+  if (!r || !out || !c->linearized || c->ov.active) return SGO_EINVAL;
   if (c->owner) {   // this rank holds its own rows' blocks and transfer entries only: the hook walks whole-graph arrays
     c->err = "sgo_debug_coarse_rhs: not available in multi-GPU row-owner mode";
     return SGO_EINVAL;

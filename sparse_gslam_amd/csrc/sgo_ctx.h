@@ -17,6 +17,7 @@
 #include "sgo_comm.h"
 #include "sgo_direct.h"
 #include "sgo_internal.h"
+#include "sgo_overlay.h"
 
 using namespace sgo;   // (internal header: the global sgo_ctx of the C-ABI is made of sgo:: types)
 
@@ -130,6 +131,14 @@ struct sgo_ctx {
                                   // kept across optimize() calls so that a hierarchy adapted to other poses is noticed
   PcgScalars* h_S2 = nullptr;     // pinned [2]: pipelined read-back of the stop flag
   hipEvent_t ev_S[2] = {nullptr, nullptr};
+
+  // incremental re-initialisation (sgo_update_graph_se2, sgo_overlay.h): V / E above count the appended part too, n stays
+  // the resident structure's rows
+  Overlay ov;
+  bool pcg_exec_ov = false;       // the captured PCG iteration contains the overlay's operator term
+  double its_base = 0.0;          // mean PCG iterations per solve of the first optimize() on the resident structure alone,
+  double its_last = 0.0;          // ... of the latest optimize(): an overlay that costs too many iterations is dropped for a full set-up
+  std::string update_note;        // what the last sgo_update_graph_se2 did (sgo_solver_description)
 
   // profiling
   struct Rec { int kid; hipEvent_t a, b; };

@@ -170,7 +170,8 @@ struct EdgeSlotsDev {
 
 // Original edge list (edge order of sgo_set_graph_se2), SoA, for chi2 / per-edge chi2.
 struct EdgeListDev {
-  int E = 0;
+  int E = 0;              // edges = component stride of zinv / info (the overlay's list: its capacity, see cnt)
+  int cnt = 0;            // valid edges when the list is kept at a fixed capacity (OverlayDev::el); otherwise unused
   int* vi = nullptr;
   int* vj = nullptr;
   double* zinv = nullptr; // [3][E]
@@ -467,10 +468,13 @@ extern thread_local LaunchEvents tl_launch_ev;
 
 // ---- kernel launchers (sgo_kernels.hip) --------------------------------------------------
 // All take the stream; none allocates or synchronises (hipGraph-capturable).
+// el2 (optional): a second list whose first el2->cnt edges are summed by the same launch (the incremental set-up's
+// appended edges, sgo_overlay.h); their per-edge values follow the first list's in e2_out
 void launch_chi2(hipStream_t s, const EdgeListDev& el, int e0, int e1, const double* poses, double* e2_out,
-                 double* partials /*[2][kMaxPartials]*/, int* grid_out);
+                 double* partials /*[2][kMaxPartials]*/, int* grid_out, const EdgeListDev* el2 = nullptr);
 void launch_reduce2(hipStream_t s, const double* partials, int nparts, double* out2);
-void launch_edge_prepare(hipStream_t s, int E, const double* meas, const double* info, double* zinv, double* info_soa);
+// meas / info: E raw rows; outputs at SoA positions [at, at + E) of arrays with component stride `stride`
+void launch_edge_prepare(hipStream_t s, int E, const double* meas, const double* info, double* zinv, double* info_soa, size_t stride, size_t at);
 void launch_slot_expand(hipStream_t s, int k0, int k1, const int* eidx, const EdgeListDev& el, const EdgeSlotsDev& es);   // slots [k0, k1)
 // strength weights of the logical slots (hrowptr: logical row pointers) straight from the edge list (sgo_kernels.hip)
 void launch_early_strength(hipStream_t s, const EdgeListDev& el, const double* poses, int n, const int* rowptr, const int* eidx,

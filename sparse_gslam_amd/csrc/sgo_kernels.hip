@@ -47,9 +47,8 @@ struct EdgeLin {
 };
 
 // ---------------------------------------------------------------------------- k_chi2
-__global__ __launch_bounds__(kBlock) void k_chi2(EdgeListDev el, int e0, int e1, const double* __restrict__ poses,
-                                                 double* __restrict__ e2_out, double* __restrict__ partials) {
-  double acc[2] = {0.0, 0.0};
+__device__ __forceinline__ void chi2_range(const EdgeListDev& el, int e0, int e1, const double* __restrict__ poses,
+                                           double* __restrict__ e2_out, double (&acc)[2]) {
   const int E = el.E;
   for (int k = e0 + blockIdx.x * kBlock + threadIdx.x; k < e1; k += gridDim.x * kBlock) {
     const int vi = el.vi[k], vj = el.vj[k];
@@ -72,6 +71,13 @@ __global__ __launch_bounds__(kBlock) void k_chi2(EdgeListDev el, int e0, int e1,
     acc[0] += e2;
     acc[1] += r0;
   }
+}
+// edges [e0, e1) of el, then the first el2.cnt edges of el2 (an empty list when there is no overlay)
+__global__ __launch_bounds__(kBlock) void k_chi2(EdgeListDev el, int e0, int e1, EdgeListDev el2, const double* __restrict__ poses,
+                                                 double* __restrict__ e2_out, double* __restrict__ partials) {
+  double acc[2] = {0.0, 0.0};
+  chi2_range(el, e0, e1, poses, e2_out, acc);
+  if (el2.cnt > 0) chi2_range(el2, 0, el2.cnt, poses, e2_out ? e2_out + el.E : nullptr, acc);
   block_sum_store<2>(acc, partials, kMaxPartials);
 }
 
@@ -90,17 +96,18 @@ __global__ __launch_bounds__(kBlock) void k_reduce2(const double* __restrict__ p
 // EdgeSE2::setMeasurement caches the inverse measurement (computed once per set_graph): zinv = Z^-1 in SoA,
 // and the information's upper triangle from the caller's AoS rows to SoA.
 __global__ __launch_bounds__(kBlock) void k_edge_prepare(int E, const double* __restrict__ meas, const double* __restrict__ info,
-                                                         double* __restrict__ zinv, double* __restrict__ info_soa) {
+                                                         double* __restrict__ zinv, double* __restrict__ info_soa, size_t stride, size_t at) {
   for (int e = blockIdx.x * kBlock + threadIdx.x; e < E; e += gridDim.x * kBlock) {
     const double zx = meas[3 * (size_t)e], zy = meas[3 * (size_t)e + 1], zt = meas[3 * (size_t)e + 2];
     const double th = norm_theta(-zt);
     double sn, cs;
     sincos(th, &sn, &cs);
-    zinv[e] = cs * (-zx) - sn * (-zy);
-    zinv[(size_t)E + e] = sn * (-zx) + cs * (-zy);
-    zinv[2 * (size_t)E + e] = th;
+    const size_t o = at + (size_t)e;
+    zinv[o] = cs * (-zx) - sn * (-zy);
+    zinv[stride + o] = sn * (-zx) + cs * (-zy);
+    zinv[2 * stride + o] = th;
 #pragma unroll
-    for (int q = 0; q < 6; ++q) info_soa[q * (size_t)E + e] = info[6 * (size_t)e + q];
+    for (int q = 0; q < 6; ++q) info_soa[q * stride + o] = info[6 * (size_t)e + q];
   }
 }
 // The per-slot operand arrays of k_linearize (coalesced per slot) from the per-edge arrays: slot k came from
@@ -1121,9 +1128,9 @@ bool halo_gather_slices(const HaloDev& H, hipStream_t s, double* vec, int width,
 }
 
 void launch_chi2(hipStream_t s, const EdgeListDev& el, int e0, int e1, const double* poses, double* e2_out,
-                 double* partials, int* grid_out) {
+                 double* partials, int* grid_out, const EdgeListDev* el2) {
   const int grid = grid_for(e1 - e0, kBlock);
-  SGO_LAUNCH(k_chi2, dim3(grid), dim3(kBlock), 0, s, el, e0, e1, poses, e2_out, partials);
+  SGO_LAUNCH(k_chi2, dim3(grid), dim3(kBlock), 0, s, el, e0, e1, el2 ? *el2 : EdgeListDev(), poses, e2_out, partials);
   *grid_out = grid;
 }
 void launch_reduce2(hipStream_t s, const double* partials, int nparts, double* out2) {
@@ -1151,8 +1158,8 @@ void launch_init_scalars(hipStream_t s, PcgScalars* S, const double* rz_parts, i
                          int n_bb, double tol, int maxit, double bb_ref, double tol_cap) {
   SGO_LAUNCH(k_init_scalars, dim3(1), dim3(kBlock), 0, s, S, rz_parts, n_rz, bb_parts, n_bb, tol, maxit, bb_ref, tol_cap);
 }
-void launch_edge_prepare(hipStream_t s, int E, const double* meas, const double* info, double* zinv, double* info_soa) {
-  SGO_LAUNCH(k_edge_prepare, dim3(grid_for(E, kBlock)), dim3(kBlock), 0, s, E, meas, info, zinv, info_soa);
+void launch_edge_prepare(hipStream_t s, int E, const double* meas, const double* info, double* zinv, double* info_soa, size_t stride, size_t at) {
+  SGO_LAUNCH(k_edge_prepare, dim3(grid_for(E, kBlock)), dim3(kBlock), 0, s, E, meas, info, zinv, info_soa, stride, at);
 }
 void launch_early_strength(hipStream_t s, const EdgeListDev& el, const double* poses, int n, const int* rowptr, const int* eidx,
                            const unsigned char* flags, const int* hrowptr, double* w) {

@@ -1,0 +1,531 @@
+// sgo_overlay.hip -- kernels and host side of the incremental re-initialisation (sgo_overlay.h): the appended edges'
+// linearisation, the block-tridiagonal elimination of the appended chain, the operator's rank-3|T| term and the chain's
+// back-substitution.  gfx950, wave64.  All sums in a fixed order (one thread per target, recompute instead of scatter).
+#include <algorithm>
+#include <cstring>
+
+#include "sgo_device.h"
+#include "sgo_overlay.h"
+
+namespace sgo {
+namespace {
+
+constexpr int kOvTile = 32;          // chain rows per LDS tile of the elimination
+constexpr int kOvThreads = 256;
+constexpr int kOvCols = 3 * kOvMaxTouched + 1;
+
+// What edge e contributes to the row on its `side` (0: vertices()[0], Jacobian A; 1: vertices()[1], Jacobian B):
+// D += R^T Ow R (symmetric packing), b -= R^T Ow e, blk = R^T Ow C (block towards the other endpoint).  The arithmetic of
+// k_linearize (EdgeSE2::computeError, linearizeOplus, RobustKernelDCS::robustify, constructQuadraticForm).
+__device__ __forceinline__ void ov_edge_terms(const EdgeListDev& el, int e, int side, const double* __restrict__ poses,
+                                              double (&D)[6], double (&b)[3], double (&blk)[9]) {
+  const size_t ns = (size_t)el.E;
+  const int vi = el.vi[e], vj = el.vj[e];
+  const double xi = poses[3 * (size_t)vi], yi = poses[3 * (size_t)vi + 1], ti = poses[3 * (size_t)vi + 2];
+  const double xj = poses[3 * (size_t)vj], yj = poses[3 * (size_t)vj + 1], tj = poses[3 * (size_t)vj + 2];
+  const double zx = el.zinv[e], zy = el.zinv[ns + e], zt = el.zinv[2 * ns + e];
+  double sz, cz;
+  sincos(zt, &sz, &cz);
+  double er[3];
+  edge_error(xi, yi, ti, xj, yj, tj, zx, zy, zt, sz, cz, er);
+  const double o00 = el.info[e], o01 = el.info[ns + e], o02 = el.info[2 * ns + e];
+  const double o11 = el.info[3 * ns + e], o12 = el.info[4 * ns + e], o22 = el.info[5 * ns + e];
+  double oe0 = o00 * er[0] + o01 * er[1] + o02 * er[2];
+  double oe1 = o01 * er[0] + o11 * er[1] + o12 * er[2];
+  double oe2 = o02 * er[0] + o12 * er[1] + o22 * er[2];
+  const double e2 = er[0] * oe0 + er[1] * oe1 + er[2] * oe2;
+  double r0_, w;
+  dcs(e2, el.phi[e], &r0_, &w);
+  const double w00 = w * o00, w01 = w * o01, w02 = w * o02, w11 = w * o11, w12 = w * o12, w22 = w * o22;
+  oe0 *= w; oe1 *= w; oe2 *= w;
+  double si, ci;
+  sincos(ti, &si, &ci);
+  const double ddx = xj - xi, ddy = yj - yi;
+  const double a02 = -si * ddx + ci * ddy, a12 = -ci * ddx - si * ddy;
+  const double A00 = cz * (-ci) - sz * si, A01 = cz * (-si) - sz * (-ci), A02 = cz * a02 - sz * a12;
+  const double A10 = sz * (-ci) + cz * si, A11 = sz * (-si) + cz * (-ci), A12 = sz * a02 + cz * a12;
+  const double B00 = cz * ci - sz * (-si), B01 = cz * si - sz * ci;
+  const double B10 = sz * ci + cz * (-si), B11 = sz * si + cz * ci;
+  const bool dir = side != 0;
+  const double R00 = dir ? B00 : A00, R01 = dir ? B01 : A01, R02 = dir ? 0.0 : A02;
+  const double R10 = dir ? B10 : A10, R11 = dir ? B11 : A11, R12 = dir ? 0.0 : A12;
+  const double R22 = dir ? 1.0 : -1.0;
+  const double T00 = w00 * R00 + w01 * R10, T01 = w00 * R01 + w01 * R11, T02 = w00 * R02 + w01 * R12 + w02 * R22;
+  const double T10 = w01 * R00 + w11 * R10, T11 = w01 * R01 + w11 * R11, T12 = w01 * R02 + w11 * R12 + w12 * R22;
+  const double T20 = w02 * R00 + w12 * R10, T21 = w02 * R01 + w12 * R11, T22 = w02 * R02 + w12 * R12 + w22 * R22;
+  D[0] += R00 * T00 + R10 * T10;
+  D[1] += R00 * T01 + R10 * T11;
+  D[2] += R00 * T02 + R10 * T12;
+  D[3] += R01 * T01 + R11 * T11;
+  D[4] += R01 * T02 + R11 * T12;
+  D[5] += R02 * T02 + R12 * T12 + R22 * T22;
+  b[0] -= R00 * oe0 + R10 * oe1;
+  b[1] -= R01 * oe0 + R11 * oe1;
+  b[2] -= R02 * oe0 + R12 * oe1 + R22 * oe2;
+  const double C00 = dir ? A00 : B00, C01 = dir ? A01 : B01, C02 = dir ? A02 : 0.0;
+  const double C10 = dir ? A10 : B10, C11 = dir ? A11 : B11, C12 = dir ? A12 : 0.0;
+  const double C22 = dir ? -1.0 : 1.0;
+  blk[0] = T00 * C00 + T10 * C10; blk[1] = T00 * C01 + T10 * C11; blk[2] = T00 * C02 + T10 * C12 + T20 * C22;
+  blk[3] = T01 * C00 + T11 * C10; blk[4] = T01 * C01 + T11 * C11; blk[5] = T01 * C02 + T11 * C12 + T21 * C22;
+  blk[6] = T02 * C00 + T12 * C10; blk[7] = T02 * C01 + T12 * C11; blk[8] = T02 * C02 + T12 * C12 + T22 * C22;
+}
+
+// ---------------------------------------------------------------------------- k_ov_lin
+// One thread per overlay row (new rows, then touched rows): the row's appended edges in entry order.
+//   new row i:     Dn[i], b_N (last column of H0), Un[i] = H_{i,i+1}, H0 blocks towards touched rows
+//   touched row t: M0 rows 3t..3t+2 (its own diagonal contribution and blocks towards other touched rows), bt
+__global__ __launch_bounds__(kOvThreads) void k_ov_lin(OverlayDev O, const double* __restrict__ poses) {
+  const int r = blockIdx.x * kOvThreads + threadIdx.x;
+  const int k = O.k, nt = O.nt, nc = O.ncol, nt3 = 3 * nt;
+  if (r >= k + nt) return;
+  double D[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
+  if (r < k) {
+    double* h = O.H0 + (size_t)3 * r * nc;
+    for (int q = 0; q < 3 * nc; ++q) h[q] = 0.0;
+    double U[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int t = O.rp[r]; t < O.rp[r + 1]; ++t) {
+      double blk[9];
+      ov_edge_terms(O.el, O.ent_edge[t], O.ent_side[t], poses, D, b, blk);
+      const int oth = O.ent_other[t];
+      if (oth == kOvOtherFixed) continue;
+      if (oth >= 0) {
+        if (oth == r + 1) {
+#pragma unroll
+          for (int q = 0; q < 9; ++q) U[q] += blk[q];
+        }
+      } else {
+        const int tc = 3 * (-1 - oth);
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+          for (int c2 = 0; c2 < 3; ++c2) h[a * nc + tc + c2] += blk[3 * a + c2];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 6; ++q) O.Dn[6 * (size_t)r + q] = D[q];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) O.Un[9 * (size_t)r + q] = U[q];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) h[a * nc + nt3] = b[a];
+  } else {
+    const int t0 = r - k;
+    double* m = O.M0 + (size_t)3 * t0 * nt3;
+    for (int q = 0; q < 3 * nt3; ++q) m[q] = 0.0;
+    for (int t = O.rp[r]; t < O.rp[r + 1]; ++t) {
+      double blk[9];
+      ov_edge_terms(O.el, O.ent_edge[t], O.ent_side[t], poses, D, b, blk);
+      const int oth = O.ent_other[t];
+      if (oth == kOvOtherFixed || oth >= 0) continue;   // (blocks towards new rows come from the new rows' side)
+      const int tc = 3 * (-1 - oth);
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int c2 = 0; c2 < 3; ++c2) m[a * nt3 + tc + c2] += blk[3 * a + c2];
+    }
+    const int dc = 3 * t0;
+    m[0 * nt3 + dc] += D[0]; m[0 * nt3 + dc + 1] += D[1]; m[0 * nt3 + dc + 2] += D[2];
+    m[1 * nt3 + dc] += D[1]; m[1 * nt3 + dc + 1] += D[3]; m[1 * nt3 + dc + 2] += D[4];
+    m[2 * nt3 + dc] += D[2]; m[2 * nt3 + dc + 1] += D[4]; m[2 * nt3 + dc + 2] += D[5];
+    O.bt[dc] = b[0]; O.bt[dc + 1] = b[1]; O.bt[dc + 2] = b[2];
+  }
+}
+
+// symmetric 3x3 inverse (packing 00 01 02 11 12 22); false when the block is not positive definite
+__device__ __forceinline__ bool sym3_inverse(const double (&d)[6], double (&v)[6]) {
+  const double c00 = d[3] * d[5] - d[4] * d[4], c01 = d[2] * d[4] - d[1] * d[5], c02 = d[1] * d[4] - d[2] * d[3];
+  const double c11 = d[0] * d[5] - d[2] * d[2], c12 = d[1] * d[2] - d[0] * d[4], c22 = d[0] * d[3] - d[1] * d[1];
+  const double det = d[0] * c00 + d[1] * c01 + d[2] * c02;
+  const bool ok = d[0] > 0.0 && c22 > 0.0 && det > 0.0 && isfinite(det);
+  const double id = ok ? 1.0 / det : 0.0;
+  v[0] = c00 * id; v[1] = c01 * id; v[2] = c02 * id; v[3] = c11 * id; v[4] = c12 * id; v[5] = c22 * id;
+  return ok;
+}
+
+// ---------------------------------------------------------------------------- k_ov_solve
+// One workgroup.  Block-tridiagonal LDL^T of H_NN along the chain with the ncol right-hand sides [H_NT | b_N] on the lanes
+// of wave 0 (every lane repeats the 3x3 pivot arithmetic: uniform), the chain walked in LDS tiles of kOvTile rows that all
+// threads load and store; then M = M0 - H_TN Y (symmetrised) and g = bt - H_TN y_b, which is added to the touched rows'
+// right-hand sides in dgb.  A pivot block that is not positive definite (an appended chain that hangs in the air) makes
+// g non-finite: the PCG start then reports a breakdown, as for any Hessian that is not positive definite.
+__global__ __launch_bounds__(kOvThreads) void k_ov_solve(OverlayDev O, double* __restrict__ dgb) {
+  __shared__ double Yt[3 * kOvTile * kOvCols];
+  __shared__ double Dt[kOvTile * 6], Ut[kOvTile * 9], Sv[kOvTile * 6];
+  __shared__ int fail;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int k = O.k, nc = O.ncol, nt3 = 3 * O.nt;
+  if (tid == 0) fail = 0;
+  __syncthreads();
+  // ---- forward elimination
+  double sp[6] = {0, 0, 0, 0, 0, 0}, up[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, rpv[3] = {0, 0, 0};
+  for (int t0 = 0; t0 < k; t0 += kOvTile) {
+    const int rows = min(kOvTile, k - t0);
+    for (int i = tid; i < 3 * rows * nc; i += kOvThreads) Yt[i] = O.H0[(size_t)3 * t0 * nc + i];
+    for (int i = tid; i < 6 * rows; i += kOvThreads) Dt[i] = O.Dn[6 * (size_t)t0 + i];
+    for (int i = tid; i < 9 * rows; i += kOvThreads) Ut[i] = O.Un[9 * (size_t)t0 + i];
+    __syncthreads();
+    if (wave == 0) {
+      for (int i = 0; i < rows; ++i) {
+        double S[6];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) S[q] = Dt[6 * i + q];
+        double r[3] = {0, 0, 0};
+        if (lane < nc) {
+          r[0] = Yt[(3 * i) * nc + lane]; r[1] = Yt[(3 * i + 1) * nc + lane]; r[2] = Yt[(3 * i + 2) * nc + lane];
+        }
+        if (t0 + i > 0) {
+          // L = U_prev^T Sinv_prev ; S -= L U_prev ; r -= L r_prev
+          const double P[9] = {sp[0], sp[1], sp[2], sp[1], sp[3], sp[4], sp[2], sp[4], sp[5]};
+          double L[9];
+#pragma unroll
+          for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int c2 = 0; c2 < 3; ++c2) L[3 * a + c2] = up[a] * P[c2] + up[3 + a] * P[3 + c2] + up[6 + a] * P[6 + c2];
+          S[0] -= L[0] * up[0] + L[1] * up[3] + L[2] * up[6];
+          S[1] -= L[0] * up[1] + L[1] * up[4] + L[2] * up[7];
+          S[2] -= L[0] * up[2] + L[1] * up[5] + L[2] * up[8];
+          S[3] -= L[3] * up[1] + L[4] * up[4] + L[5] * up[7];
+          S[4] -= L[3] * up[2] + L[4] * up[5] + L[5] * up[8];
+          S[5] -= L[6] * up[2] + L[7] * up[5] + L[8] * up[8];
+#pragma unroll
+          for (int a = 0; a < 3; ++a) r[a] -= L[3 * a] * rpv[0] + L[3 * a + 1] * rpv[1] + L[3 * a + 2] * rpv[2];
+        }
+        double si[6];
+        if (!sym3_inverse(S, si) && lane == 0) fail = 1;
+        if (lane < 6) Sv[6 * i + lane] = si[lane];
+        if (lane < nc) {
+          Yt[(3 * i) * nc + lane] = r[0]; Yt[(3 * i + 1) * nc + lane] = r[1]; Yt[(3 * i + 2) * nc + lane] = r[2];
+        }
+#pragma unroll
+        for (int q = 0; q < 6; ++q) sp[q] = si[q];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) up[q] = Ut[9 * i + q];
+        rpv[0] = r[0]; rpv[1] = r[1]; rpv[2] = r[2];
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < 3 * rows * nc; i += kOvThreads) O.Y[(size_t)3 * t0 * nc + i] = Yt[i];
+    for (int i = tid; i < 6 * rows; i += kOvThreads) O.Sinv[6 * (size_t)t0 + i] = Sv[i];
+    __syncthreads();
+  }
+  // ---- back substitution: y_i = Sinv_i (r_i - U_i y_{i+1})
+  double yn[3] = {0, 0, 0};
+  const int ntile = (k + kOvTile - 1) / kOvTile;
+  for (int tt = ntile - 1; tt >= 0; --tt) {
+    const int t0 = tt * kOvTile, rows = min(kOvTile, k - t0);
+    for (int i = tid; i < 3 * rows * nc; i += kOvThreads) Yt[i] = O.Y[(size_t)3 * t0 * nc + i];
+    for (int i = tid; i < 6 * rows; i += kOvThreads) Sv[i] = O.Sinv[6 * (size_t)t0 + i];
+    for (int i = tid; i < 9 * rows; i += kOvThreads) Ut[i] = O.Un[9 * (size_t)t0 + i];
+    __syncthreads();
+    if (wave == 0 && lane < nc) {
+      for (int i = rows - 1; i >= 0; --i) {
+        double r[3] = {Yt[(3 * i) * nc + lane], Yt[(3 * i + 1) * nc + lane], Yt[(3 * i + 2) * nc + lane]};
+        if (t0 + i < k - 1) {
+          const double* U = Ut + 9 * i;
+#pragma unroll
+          for (int a = 0; a < 3; ++a) r[a] -= U[3 * a] * yn[0] + U[3 * a + 1] * yn[1] + U[3 * a + 2] * yn[2];
+        }
+        const double* v = Sv + 6 * i;
+        yn[0] = v[0] * r[0] + v[1] * r[1] + v[2] * r[2];
+        yn[1] = v[1] * r[0] + v[3] * r[1] + v[4] * r[2];
+        yn[2] = v[2] * r[0] + v[4] * r[1] + v[5] * r[2];
+        Yt[(3 * i) * nc + lane] = yn[0]; Yt[(3 * i + 1) * nc + lane] = yn[1]; Yt[(3 * i + 2) * nc + lane] = yn[2];
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < 3 * rows * nc; i += kOvThreads) O.Y[(size_t)3 * t0 * nc + i] = Yt[i];
+    __syncthreads();
+  }
+  // ---- M = sym(M0 - H_TN Y), g = bt - H_TN y_b  (H_TN = H_NT^T: only the rows listed in nz carry blocks)
+  const bool bad = fail != 0;
+  for (int idx = tid; idx < nt3 * (nt3 + 1); idx += kOvThreads) {
+    const int a = idx / (nt3 + 1), bcol = idx % (nt3 + 1);
+    double s1 = 0.0, s2 = 0.0;
+    for (int z = 0; z < O.nnz; ++z) {
+      const size_t base = (size_t)3 * O.nz[z] * nc;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const double* h = O.H0 + base + (size_t)q * nc;
+        const double* y = O.Y + base + (size_t)q * nc;
+        s1 += h[a] * y[bcol];
+        if (bcol < nt3) s2 += h[bcol] * y[a];
+      }
+    }
+    if (bcol < nt3) {
+      const double mab = O.M0[a * nt3 + bcol] - s1, mba = O.M0[bcol * nt3 + a] - s2;
+      O.M[a * nt3 + bcol] = 0.5 * (mab + mba);
+    } else {
+      const double g = bad ? __builtin_nan("") : O.bt[a] - s1;
+      dgb[9 * (size_t)O.trow[a / 3] + 6 + a % 3] += g;
+    }
+  }
+  if (bad && tid == 0) dgb[6] = __builtin_nan("");   // (also when no resident row is touched: the solve must report the failure)
+}
+
+// ---------------------------------------------------------------------------- k_ov_ax
+// q_T += M p_T after the base product H_base p; the dot product p . q of the PCG recurrence gets its share added to the
+// product's first partial sum (single writer, after the product kernel: fixed order).  One wave.  The sizes come from the
+// device-resident header so that a captured hipGraph stays valid across updates.
+__global__ __launch_bounds__(64) void k_ov_ax(const int* __restrict__ hdr, const int* __restrict__ trow, const double* __restrict__ M,
+                                              const double* __restrict__ p, double* __restrict__ q, double* __restrict__ partials0,
+                                              const PcgScalars* S) {
+  __shared__ double pt[3 * kOvMaxTouched];
+  if (S && S->stop) return;
+  const int nt3 = 3 * hdr[1], r = threadIdx.x;
+  if (nt3 == 0) return;
+  size_t at = 0;
+  if (r < nt3) {
+    at = 3 * (size_t)trow[r / 3] + r % 3;
+    pt[r] = p[at];
+  }
+  __syncthreads();
+  double d = 0.0;
+  if (r < nt3) {
+    for (int c2 = 0; c2 < nt3; ++c2) d += M[r * nt3 + c2] * pt[c2];
+    q[at] += d;
+    d *= pt[r];
+  }
+  if (partials0) {
+    const double s = wave_sum(d);
+    if (r == 0) partials0[0] += s;
+  }
+}
+
+// ---------------------------------------------------------------------------- k_ov_finish
+// x_N = y_b - Y_T x_T, then VertexSE2::oplusImpl on the new poses.
+__global__ __launch_bounds__(kOvThreads) void k_ov_finish(OverlayDev O, const double* __restrict__ x, double* __restrict__ poses) {
+  __shared__ double xt[3 * kOvMaxTouched];
+  const int nt3 = 3 * O.nt, nc = O.ncol;
+  if ((int)threadIdx.x < nt3) xt[threadIdx.x] = x[3 * (size_t)O.trow[threadIdx.x / 3] + threadIdx.x % 3];
+  __syncthreads();
+  for (int i = blockIdx.x * kOvThreads + threadIdx.x; i < O.k; i += gridDim.x * kOvThreads) {
+    double xn[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const double* y = O.Y + (size_t)(3 * i + a) * nc;
+      double v = y[nt3];
+      for (int c2 = 0; c2 < nt3; ++c2) v -= y[c2] * xt[c2];
+      xn[a] = v;
+    }
+    const size_t v3 = 3 * (size_t)O.vtx[i];
+    poses[v3] += xn[0];
+    poses[v3 + 1] += xn[1];
+    poses[v3 + 2] = norm_theta(poses[v3 + 2] + xn[2]);
+  }
+}
+
+}  // namespace
+
+void launch_ov_lin(hipStream_t s, const OverlayDev& O, const double* poses) {
+  const int rows = O.k + O.nt;
+  if (rows > 0) SGO_LAUNCH(k_ov_lin, dim3((rows + kOvThreads - 1) / kOvThreads), dim3(kOvThreads), 0, s, O, poses);
+}
+void launch_ov_solve(hipStream_t s, const OverlayDev& O, double* dgb) {
+  if (O.k + O.nt > 0) SGO_LAUNCH(k_ov_solve, dim3(1), dim3(kOvThreads), 0, s, O, dgb);
+}
+void launch_ov_ax(hipStream_t s, const OverlayDev& O, const double* p, double* q, double* partials0, const PcgScalars* S) {
+  SGO_LAUNCH(k_ov_ax, dim3(1), dim3(64), 0, s, O.hdr, O.trow, (const double*)O.M, p, q, partials0, S);
+}
+void launch_ov_finish(hipStream_t s, const OverlayDev& O, const double* x, double* poses) {
+  if (O.k > 0) SGO_LAUNCH(k_ov_finish, dim3((O.k + kOvThreads - 1) / kOvThreads), dim3(kOvThreads), 0, s, O, x, poses);
+}
+
+// ---------------------------------------------------------------------------- host side
+// Device buffers of an overlay, carved out of one allocation made at first use (capacities of sgo_overlay.h):
+//   ints:    header[4] = {k, nt, ncol, nnz} | rp | ent_edge | ent_other | vtx | trow | nz | el.vi | el.vj
+//   bytes:   ent_side
+//   doubles: el.phi, el.zinv[3], el.info[6], raw meas / info staging, Dn, Un, H0, Y, Sinv, M0, bt, M
+namespace {
+struct Layout {
+  size_t i_hdr, i_rp, i_edge, i_other, i_vtx, i_trow, i_nz, i_vi, i_vj, n_int;
+  size_t d_phi, d_zinv, d_info, d_raw, d_Dn, d_Un, d_H0, d_Y, d_Sinv, d_M0, d_bt, d_M, n_dbl;
+  Layout() {
+    size_t o = 0;
+    i_hdr = o; o += 4;
+    i_rp = o; o += kOvMaxRows + kOvMaxTouched + 1;
+    i_edge = o; o += 2 * kOvMaxEdges;
+    i_other = o; o += 2 * kOvMaxEdges;
+    i_vtx = o; o += kOvMaxRows + kOvMaxTouched;
+    i_trow = o; o += kOvMaxTouched;
+    i_nz = o; o += kOvMaxRows;
+    n_int = o;                       // the structure part (uploaded per update) ends here
+    i_vi = o; o += kOvMaxEdges;
+    i_vj = o; o += kOvMaxEdges;
+    const size_t ints = o;
+    (void)ints;
+    o = 0;
+    d_phi = o; o += kOvMaxEdges;
+    d_zinv = o; o += 3 * (size_t)kOvMaxEdges;
+    d_info = o; o += 6 * (size_t)kOvMaxEdges;
+    d_raw = o; o += 9 * (size_t)kOvMaxEdges;
+    d_Dn = o; o += 6 * (size_t)kOvMaxRows;
+    d_Un = o; o += 9 * (size_t)kOvMaxRows;
+    d_H0 = o; o += 3 * (size_t)kOvMaxRows * kOvCols;
+    d_Y = o; o += 3 * (size_t)kOvMaxRows * kOvCols;
+    d_Sinv = o; o += 6 * (size_t)kOvMaxRows;
+    d_M0 = o; o += (size_t)(kOvCols - 1) * (kOvCols - 1);
+    d_bt = o; o += kOvCols;
+    d_M = o; o += (size_t)(kOvCols - 1) * (kOvCols - 1);
+    n_dbl = o;
+  }
+  size_t int_total() const { return i_vj + kOvMaxEdges; }
+};
+const Layout& layout() {
+  static const Layout L;
+  return L;
+}
+}  // namespace
+
+static bool overlay_alloc(Overlay& ov, std::string* err) {
+  if (ov.buf) return true;
+  const Layout& L = layout();
+  const size_t bytes = sizeof(double) * L.n_dbl + sizeof(int) * L.int_total() + 2 * (size_t)kOvMaxEdges + 256;
+  if (hipMalloc(&ov.buf, bytes) != hipSuccess) {
+    ov.buf = nullptr;
+    if (err) *err = "out of device memory (incremental set-up buffers)";
+    return false;
+  }
+  double* d = (double*)ov.buf;
+  ov.d_int = (int*)(d + L.n_dbl);
+  ov.d_side = (unsigned char*)(ov.d_int + L.int_total());
+  OverlayDev& O = ov.dev;
+  O.el.E = kOvMaxEdges;
+  O.el.cnt = 0;
+  O.el.vi = ov.d_int + L.i_vi;
+  O.el.vj = ov.d_int + L.i_vj;
+  O.el.phi = d + L.d_phi;
+  O.el.zinv = d + L.d_zinv;
+  O.el.info = d + L.d_info;
+  O.hdr = ov.d_int + L.i_hdr;
+  O.rp = ov.d_int + L.i_rp;
+  O.ent_edge = ov.d_int + L.i_edge;
+  O.ent_other = ov.d_int + L.i_other;
+  O.ent_side = ov.d_side;
+  O.vtx = ov.d_int + L.i_vtx;
+  O.trow = ov.d_int + L.i_trow;
+  O.nz = ov.d_int + L.i_nz;
+  O.Dn = d + L.d_Dn;
+  O.Un = d + L.d_Un;
+  O.H0 = d + L.d_H0;
+  O.Y = d + L.d_Y;
+  O.Sinv = d + L.d_Sinv;
+  O.M0 = d + L.d_M0;
+  O.bt = d + L.d_bt;
+  O.M = d + L.d_M;
+  return true;
+}
+
+void overlay_release(Overlay& ov) {
+  if (ov.buf) hipFree(ov.buf);
+  ov = Overlay();
+}
+
+bool overlay_upload_edges(Overlay& ov, hipStream_t s, int at, int cnt, const int32_t* ei, const int32_t* ej, const double* meas,
+                          const double* info, const double* phi, std::string* err) {
+  if (!overlay_alloc(ov, err)) return false;
+  if (cnt <= 0) return true;
+  const Layout& L = layout();
+  double* d = (double*)ov.buf;
+  double* raw = d + L.d_raw;
+  hipError_t e = hipMemcpyAsync(ov.dev.el.vi + at, ei, sizeof(int32_t) * (size_t)cnt, hipMemcpyHostToDevice, s);
+  if (e == hipSuccess) e = hipMemcpyAsync(ov.dev.el.vj + at, ej, sizeof(int32_t) * (size_t)cnt, hipMemcpyHostToDevice, s);
+  if (e == hipSuccess) e = hipMemcpyAsync(ov.dev.el.phi + at, phi, sizeof(double) * (size_t)cnt, hipMemcpyHostToDevice, s);
+  if (e == hipSuccess) e = hipMemcpyAsync(raw, meas, sizeof(double) * 3 * (size_t)cnt, hipMemcpyHostToDevice, s);
+  if (e == hipSuccess) e = hipMemcpyAsync(raw + 3 * (size_t)kOvMaxEdges, info, sizeof(double) * 6 * (size_t)cnt, hipMemcpyHostToDevice, s);
+  if (e != hipSuccess) {
+    if (err) *err = std::string("incremental set-up: edge upload: ") + hipGetErrorString(e);
+    return false;
+  }
+  launch_edge_prepare(s, cnt, raw, raw + 3 * (size_t)kOvMaxEdges, ov.dev.el.zinv, ov.dev.el.info, (size_t)kOvMaxEdges, (size_t)at);
+  return true;
+}
+
+bool overlay_build(Overlay& ov, int V, hipStream_t s, std::string* why, std::string* err) {
+  const int ne = (int)ov.ei.size();
+  if (ne > kOvMaxEdges) { *why = "more appended edges than the overlay holds"; return false; }
+  if (!overlay_alloc(ov, err)) { *why = "no device memory"; return false; }
+  // classes of the endpoints: base row (touched), fixed, or a new row
+  auto base_row = [&](int v) { return v < ov.base_V ? ov.hpos[v] : -1; };
+  std::vector<int> nv, tr;
+  for (int e = 0; e < ne; ++e)
+    for (int v : {ov.ei[e], ov.ej[e]}) {
+      if (ov.fixed[v]) continue;
+      const int br = base_row(v);
+      if (br >= 0) tr.push_back(br);
+      else nv.push_back(v);
+    }
+  std::sort(nv.begin(), nv.end());
+  nv.erase(std::unique(nv.begin(), nv.end()), nv.end());
+  std::sort(tr.begin(), tr.end());
+  tr.erase(std::unique(tr.begin(), tr.end()), tr.end());
+  const int k = (int)nv.size(), nt = (int)tr.size();
+  if (k > kOvMaxRows) { *why = "more appended poses than the overlay holds"; return false; }
+  if (nt > kOvMaxTouched) { *why = "the appended edges end in more resident rows than the overlay holds"; return false; }
+  auto code = [&](int v) -> int {   // >= 0 new row, -1 - t touched row, kOvOtherFixed
+    if (ov.fixed[v]) return kOvOtherFixed;
+    const int br = base_row(v);
+    if (br >= 0) return -1 - (int)(std::lower_bound(tr.begin(), tr.end(), br) - tr.begin());
+    return (int)(std::lower_bound(nv.begin(), nv.end(), v) - nv.begin());
+  };
+  const Layout& L = layout();
+  std::vector<int> hi(L.n_int, 0);
+  std::vector<unsigned char> hs(2 * (size_t)std::max(ne, 1), 0);
+  int* rp = hi.data() + L.i_rp;
+  std::vector<int> ca(ne), cb(ne);
+  std::vector<int> cntr((size_t)k + nt + 1, 0);
+  auto rowof = [&](int c) { return c >= 0 ? c : k + (-1 - c); };
+  for (int e = 0; e < ne; ++e) {
+    ca[e] = code(ov.ei[e]);
+    cb[e] = code(ov.ej[e]);
+    if (ca[e] >= 0 && cb[e] >= 0 && std::abs(ca[e] - cb[e]) != 1) {
+      *why = "appended edges among the new poses do not form a chain";
+      return false;
+    }
+    if (ca[e] == kOvOtherFixed && cb[e] == kOvOtherFixed) continue;   // (never active: the marshal layer drops such edges)
+    if (ca[e] != kOvOtherFixed) cntr[rowof(ca[e]) + 1]++;
+    if (cb[e] != kOvOtherFixed) cntr[rowof(cb[e]) + 1]++;
+  }
+  for (int r = 0; r < k + nt; ++r) cntr[r + 1] += cntr[r];
+  std::copy(cntr.begin(), cntr.end(), rp);
+  std::vector<int> fill(cntr.begin(), cntr.end() - 1);
+  int* ent_edge = hi.data() + L.i_edge;
+  int* ent_other = hi.data() + L.i_other;
+  for (int e = 0; e < ne; ++e) {   // entries in edge order: every row's sums are taken in that order
+    if (ca[e] != kOvOtherFixed) {
+      const int t = fill[rowof(ca[e])]++;
+      ent_edge[t] = e; ent_other[t] = cb[e]; hs[t] = 0;
+    }
+    if (cb[e] != kOvOtherFixed) {
+      const int t = fill[rowof(cb[e])]++;
+      ent_edge[t] = e; ent_other[t] = ca[e]; hs[t] = 1;
+    }
+  }
+  int* vtx = hi.data() + L.i_vtx;
+  for (int i = 0; i < k; ++i) vtx[i] = nv[i];
+  // (vertex ids of the touched rows are not needed: their poses are read through the edges' endpoints)
+  int* trow = hi.data() + L.i_trow;
+  for (int t = 0; t < nt; ++t) trow[t] = tr[t];
+  int nnz = 0;
+  int* nz = hi.data() + L.i_nz;
+  for (int i = 0; i < k; ++i) {
+    bool any = false;
+    for (int t = rp[i]; t < rp[i + 1]; ++t) any = any || (ent_other[t] < 0 && ent_other[t] != kOvOtherFixed);
+    if (any) nz[nnz++] = i;
+  }
+  hi[L.i_hdr] = k; hi[L.i_hdr + 1] = nt; hi[L.i_hdr + 2] = 3 * nt + 1; hi[L.i_hdr + 3] = nnz;
+  hipError_t e1 = hipMemcpyAsync(ov.d_int, hi.data(), sizeof(int) * L.n_int, hipMemcpyHostToDevice, s);
+  if (e1 == hipSuccess) e1 = hipMemcpyAsync(ov.d_side, hs.data(), hs.size(), hipMemcpyHostToDevice, s);
+  if (e1 == hipSuccess) e1 = hipStreamSynchronize(s);   // (the staging vectors die here)
+  if (e1 != hipSuccess) {
+    if (err) *err = std::string("incremental set-up: structure upload: ") + hipGetErrorString(e1);
+    *why = "upload failed";
+    return false;
+  }
+  OverlayDev& O = ov.dev;
+  O.k = k; O.nt = nt; O.ncol = 3 * nt + 1; O.nnz = nnz;
+  O.el.cnt = ne;
+  ov.new_vertex = nv;
+  (void)V;
+  return true;
+}
+
+}  // namespace sgo

@@ -80,7 +80,7 @@ int do_chi2(sgo_ctx* c, double* d_out2, double* d_e2) {
     Scope sc(c, K_CHI2, bytes_chi2(c));
     int e0 = 0, e1 = c->E;
     if (c->comm.nranks > 1 && !c->replicated && !d_e2) sgo_shard_range(c->E, c->comm.nranks, c->comm.rank, &e0, &e1);
-    launch_chi2(c->stream, c->el, e0, e1, c->d_poses, d_e2, c->d_partials, &grid);
+    launch_chi2(c->stream, c->el, e0, e1, c->d_poses, d_e2, c->d_partials, &grid, c->ov.active ? &c->ov.dev.el : nullptr);
   }
   {
     Scope sc(c, K_REDUCE2, 16.0 * grid);
@@ -226,6 +226,12 @@ int do_linearize(sgo_ctx* c) {
     Scope sc(c, K_LINEARIZE, bytes_linearize(c) * (g1 - g0) / std::max(1, c->S0.ngrp));
     launch_linearize(c->stream, c->S0, g0, g1, c->es, c->d_poses, c->d_dgb);
   }
+  if (c->ov.active) {
+    // incremental set-up (sgo_overlay.h): the appended edges' linearisation, the elimination of the appended chain; the
+    // touched rows' right-hand sides in dgb receive g = b_T - H_TN H_NN^-1 b_N before k_finalize reads them
+    launch_ov_lin(c->stream, c->ov.dev, c->d_poses);
+    launch_ov_solve(c->stream, c->ov.dev, c->d_dgb);
+  }
   int grid = 0;
   {
     Scope sc(c, K_FINALIZE, (72.0 + 48.0 + 48.0 + 6 * 24.0) * (row1 - row0));
@@ -291,6 +297,7 @@ int do_spmv(sgo_ctx* c, const double* x, double* y, bool dot, const PcgScalars* 
     a.partials = c->d_partials;
   }
   const int grid = launch_spmv0_any(c->stream, c->S0, c->T0, S0_AX, a);
+  if (c->ov.active) launch_ov_ax(c->stream, c->ov.dev, x, y, dot ? c->d_partials : nullptr, S);   // + U M U^T x (sgo_overlay.h)
   if (grid_out) *grid_out = grid;
   return SGO_OK;
 }
@@ -373,7 +380,7 @@ int pcg_iteration(sgo_ctx* c) {
 }
 
 int ensure_pcg_graph(sgo_ctx* c, int chunk) {
-  if (c->pcg_exec && c->pcg_exec_chunk == chunk) return SGO_OK;
+  if (c->pcg_exec && c->pcg_exec_chunk == chunk && c->pcg_exec_ov == c->ov.active) return SGO_OK;
   if (c->pcg_exec) {
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     hipGraphExecDestroy(c->pcg_exec);
@@ -400,6 +407,7 @@ int ensure_pcg_graph(sgo_ctx* c, int chunk) {
     return SGO_EHIP;
   }
   c->pcg_exec_chunk = chunk;
+  c->pcg_exec_ov = c->ov.active;
   return SGO_OK;
 }
 
@@ -724,6 +732,7 @@ int optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
     int rebuilds = 0;
     int& best_pcg = c->amg_best;
     bool rebuild_next = false;
+    double its_sum = 0.0;
     for (int it = 0; it < iters; ++it) {
       hipEventRecord(ev[3 * it], c->stream);
       c->pcg_softcap = (c->amg && c->amg_best > 0 && rebuilds < 3 && !rebuild_next) ? 4 * c->amg_best + 40 : 0;
@@ -781,6 +790,7 @@ int optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
         const bool pays = 4 * eq_iter > 5 * best_pcg && (long long)(eq_iter - best_pcg) * left > 150;
         if (rebuilds < 3 && (doubled || pays)) rebuild_next = true;
       }
+      its_sum += S.iter + wasted;
       if (out) {
         out->pcg_iters[it] = S.iter + wasted;   // an abandoned solve's iterations count too
         out->pcg_converged[it] = S.stop == 1;
@@ -806,6 +816,7 @@ int optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
       }
       // (row-owner mode: every rank holds all poses; the ranks' slices of the step are gathered first)
       if (c->owner && !halo_gather_slices(c->halo, c->stream, c->d_x, 3, &c->err)) return SGO_ECOMM;
+      if (c->ov.active) launch_ov_finish(c->stream, c->ov.dev, c->d_x, c->d_poses);   // x_N and the appended poses' update
       {
         Scope sc(c, K_POSE_UPDATE, 72.0 * c->n);
         launch_pose_update(c->stream, c->n, c->d_free_id, c->d_x, c->d_poses);
@@ -822,6 +833,10 @@ int optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
                      S.bb > 0 ? std::sqrt(S.rr / S.bb) : 0.0, std::sqrt(S.bb));
     }
     c->pcg_softcap = 0;
+    if (done > 0) {   // mean PCG iterations per solve: the incremental set-up's staleness rule compares them (counts only)
+      c->its_last = its_sum / done;
+      if (!c->ov.active && c->its_base == 0.0) c->its_base = c->its_last;
+    }
     if ((rc = do_chi2(c, c->d_hist + 2 * done, nullptr))) {
       return rc;
     }
@@ -853,7 +868,7 @@ int optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
 // k_spmv0<mode> (operand = the PCG direction buffer, whatever it holds), HIP events around them on the
 // context's stream; returns the mean microseconds per launch (< 0 on error).  variant 16: the wave-group kernel even when the graph has a tile view; variant 32: per-phase s_memtime stamps of the tile kernel on stderr (diagnostic).
 double debug_spmv0_us(sgo_ctx* c, int mode, int variant, int reps) {
-  if (check_graph(c) != SGO_OK || reps < 1 || c->n == 0 || ensure_rows(c) != SGO_OK || c->owner) return -1.0;
+  if (check_graph(c) != SGO_OK || reps < 1 || c->n == 0 || ensure_rows(c) != SGO_OK || c->owner || c->ov.active) return -1.0;
   hipEvent_t a, b;
   if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return -1.0;
   Spmv0Args args{};

@@ -82,6 +82,18 @@ void free_graph(sgo_ctx* c) {
   c->replicated = false;
   c->halo = HaloDev();
   c->halo_failed = false;
+  c->ov.active = false;
+  c->ov.ei.clear();
+  c->ov.ej.clear();
+  c->ov.new_vertex.clear();
+  c->ov.hpos.clear();
+  c->ov.updates = 0;
+  c->ov.dev.k = c->ov.dev.nt = c->ov.dev.nnz = 0;
+  c->ov.dev.ncol = 1;
+  c->ov.dev.el.cnt = 0;
+  c->pcg_exec_ov = false;
+  c->its_base = c->its_last = 0.0;
+  c->update_note.clear();
 }
 
 // The edge arrays, poses and chi2 buffers of a graph: all that chi2 / per-edge chi2 / the single-launch direct path
@@ -121,11 +133,12 @@ int build_edges(sgo_ctx* c, int V, const double* poses, const uint8_t* fixed, in
     HIP_TRY(c, hipMemcpyAsync(c->el.phi, phi, sizeof(double) * (size_t)E, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(d_meas, meas, sizeof(double) * 3 * (size_t)E, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(d_info, info, sizeof(double) * 6 * (size_t)E, hipMemcpyHostToDevice, c->stream));
-    launch_edge_prepare(c->stream, E, d_meas, d_info, c->el.zinv, c->el.info);
+    launch_edge_prepare(c->stream, E, d_meas, d_info, c->el.zinv, c->el.info, (size_t)E, 0);
   }
-  if ((rc = dalloc(c, &c->d_poses, 3 * (size_t)V))) return rc;
+  // (capacity for the vertices / edges an incremental update may append, sgo_overlay.h)
+  if ((rc = dalloc(c, &c->d_poses, 3 * ((size_t)V + kOvMaxVerts)))) return rc;
   HIP_TRY(c, hipMemcpyAsync(c->d_poses, poses, sizeof(double) * 3 * (size_t)V, hipMemcpyHostToDevice, c->stream));
-  if ((rc = dalloc(c, &c->d_e2, (size_t)E))) return rc;
+  if ((rc = dalloc(c, &c->d_e2, (size_t)E + kOvMaxEdges))) return rc;
   if ((rc = dalloc(c, &c->d_partials, 3 * (size_t)kMaxPartials))) return rc;
   if ((rc = dalloc(c, &c->d_hist, 2 * (size_t)(SGO_MAX_ITERS + 2)))) return rc;
   HIP_TRY(c, hipMemsetAsync(c->d_partials, 0, sizeof(double) * 3 * kMaxPartials, c->stream));
@@ -163,6 +176,7 @@ int build_structure(sgo_ctx* c, int V, const double* poses, const uint8_t* fixed
     tl = t;
   };
   c->row_of_asc = P.row_of_asc;
+  c->ov.hpos = P.hpos;   // vertex -> row of the resident structure: what an incremental update classifies appended edges by
   const int n = P.n, ns = P.ns;
   const std::vector<int>&row_vertex = P.row_vertex, &rowptr = P.rowptr, &pos_i = P.pos_i, &pos_j = P.pos_j;
   std::vector<int>& col = P.col;

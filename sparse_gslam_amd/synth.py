@@ -262,6 +262,50 @@ def _build(truth, E, rng, seed, p_random, info_mode, phi, init, tail, sigma_xy, 
                            closure_radius=float(r_used), init=init, tail=int(tail)))
 
 
+def chain_init(poses: np.ndarray, meas_odom: np.ndarray, first: int, last: int) -> None:
+    """Initial guess of the appended poses first..last (inclusive), in place: each chained from its predecessor's CURRENT
+    estimate through the odometry measurement (slc.cpp:219: pose->setEstimate(prev->estimate() * edge->measurement())).
+    meas_odom[k] is the measurement of edge (k, k + 1)."""
+    x, y, t = poses[first - 1]
+    for k in range(first - 1, last):
+        c, s = math.cos(t), math.sin(t)
+        m = meas_odom[k]
+        x, y = x + c * m[0] - s * m[1], y + s * m[0] + c * m[1]
+        t = float(_wrap(t + m[2]))
+        poses[k + 1] = (x, y, t)
+
+
+def append_session(V0: int, E0: int, steps: int, chain: int, seed: int, *, info_mode: str = "diag", phi: float = 1.0,
+                   closures_per_step: int = 1):
+    """The reference's usage pattern on a graph of ANY size (slc.cpp:205-226, :272-287): a resident graph of about V0 poses /
+    E0 edges, then `steps` accepted loop closures, each appending the `chain` poses driven since the last one (with their
+    odometry edges) and `closures_per_step` closure edges between one of the new poses and an old pose nearby.
+
+    One manhattan world of V0 + steps * chain poses is generated; the base is its sub-graph on the first V0 poses (edges in
+    the generator's order), the steps take the following chunks.  Returns (base Graph -- poses near the optimum, as after
+    the previous optimize(20) --, list of steps, full Graph): a step is a dict with V (poses after it) and the appended
+    ei / ej / meas / info / phi; the appended poses' initial guess is chain_init() from the estimates at that time."""
+    Vt = V0 + steps * chain
+    g = manhattan(Vt, int(round(E0 * (Vt / V0))), seed, 0.0, info_mode=info_mode, phi=phi, init="incremental", tail=0)
+    keep = (g.ei < V0) & (g.ej < V0)
+    base = Graph(g.poses[:V0].copy(), g.fixed[:V0].copy(), g.ei[keep], g.ej[keep], g.meas[keep], g.info[keep], g.phi[keep],
+                 g.truth[:V0], dict(g.meta, V=V0, E=int(keep.sum()), init="incremental", tail=0))
+    out = []
+    lo, hi = np.minimum(g.ei, g.ej), np.maximum(g.ei, g.ej)
+    is_odom = np.arange(g.E) < Vt - 1
+    for st in range(steps):
+        a, b = V0 + st * chain, V0 + (st + 1) * chain          # the appended poses [a, b)
+        odo = np.arange(a - 1, b - 1)                           # edges (a-1, a) ... (b-2, b-1)
+        cand = np.flatnonzero(~is_odom & (hi >= a) & (hi < b) & (lo < a))
+        # the closure hangs on a pose in the middle of the chunk when one exists (slc.cpp:279: poses[mid]), else the nearest
+        mid = (a + b) // 2
+        cand = cand[np.argsort(np.abs(hi[cand] - mid), kind="stable")][:closures_per_step]
+        idx = np.concatenate([odo, np.sort(cand)])
+        out.append(dict(V=b, ei=g.ei[idx], ej=g.ej[idx], meas=g.meas[idx], info=g.info[idx], phi=g.phi[idx],
+                        closures=int(cand.size)))
+    return base, out, g
+
+
 def _euler(a, b, c):
     ca, sa, cb, sb, cc, sc = np.cos(a), np.sin(a), np.cos(b), np.sin(b), np.cos(c), np.sin(c)
     Q = np.empty(a.shape + (3, 3))

@@ -126,3 +126,50 @@ def test_reference_custom_type_headers_compile_against_the_shim(tmp_path):
     assert out.returncode == 0, out.stdout + out.stderr
     its, chi2 = out.stdout.split()[:2]
     assert int(its) >= 1 and float(chi2) < 1e-12
+
+
+@pytest.mark.gpu
+def test_loop_closer_growth_pattern_takes_the_incremental_update(tmp_path, monkeypatch):
+    """slc.cpp:205-226 + :272-287 through the shim on a graph of the multigrid path's size: every optimize() after the first
+    sees the previous graph as a prefix and goes through sgo_update_graph_se2 (the resident structures are kept); chi2 after
+    each step and the final poses agree with the CPU oracle following the same steps."""
+    from oracle import c_oracle as co
+    monkeypatch.setenv("SGO_DIRECT_ROWS", "0")      # (graphs of this size would otherwise take the single-launch direct path)
+    subprocess.check_call(["make", "-s", "-C", CPP, "replay_incremental"])
+    iters, phi = 6, 1.0
+    base, steps, g = synth.append_session(1500, 4500, 3, 12, seed=21, info_mode="full", phi=phi)
+
+    def rows(ei, ej, ph, meas, info):
+        return "".join(" ".join(map(str, [int(ei[k]), int(ej[k]), int(ph[k] >= 0)] + [repr(float(v)) for v in meas[k]] +
+                                     [repr(float(v)) for v in info[k]])) + "\n" for k in range(len(ei)))
+    sf, of = tmp_path / "s.txt", tmp_path / "o.txt"
+    with open(sf, "w") as f:
+        f.write(f"{base.V} {base.E} {len(steps)} {phi!r}\n")
+        np.savetxt(f, base.poses, fmt="%.17g")
+        f.write(rows(base.ei, base.ej, base.phi, base.meas, base.info))
+        for st in steps:
+            f.write(f"{st['V']} {len(st['ei'])}\n")
+            f.write(rows(st["ei"], st["ej"], st["phi"], st["meas"], st["info"]))
+    subprocess.check_call([os.path.join(CPP, "replay_incremental"), str(sf), str(of), str(iters)])
+    lines = open(of).read().split("\n")
+    # the CPU oracle through the same steps
+    P, so = co.gauss_newton(*base.arrays(), iters=iters)
+    arrs = [base.ei, base.ej, base.meas, base.info, base.phi]
+    done, c, r = lines[0].split(" | ")[0].split()
+    assert int(done) == iters and abs(float(c) - so["chi2"][-1]) <= 1e-6 * so["chi2"][-1]
+    for k, st in enumerate(steps):
+        arrs = [np.concatenate([a, st[n]]) for a, n in zip(arrs, ("ei", "ej", "meas", "info", "phi"))]
+        P0 = np.empty((st["V"], 3))
+        P0[: P.shape[0]] = P
+        synth.chain_init(P0, g.meas[: g.V - 1], P.shape[0], st["V"] - 1)
+        fixed = np.zeros(st["V"], dtype=bool)
+        fixed[0] = True
+        P, so = co.gauss_newton(P0, fixed, *arrs, iters=iters)
+        head, desc = lines[k + 1].split(" | ")
+        done, c, r = head.split()
+        assert int(done) == iters
+        assert abs(float(c) - so["chi2"][-1]) <= 1e-6 * so["chi2"][-1], (k, c, so["chi2"][-1])
+        assert abs(float(r) - so["robust_chi2"][-1]) <= 1e-6 * so["robust_chi2"][-1]
+        assert "incremental overlay" in desc, desc
+    Pg = np.loadtxt(lines[len(steps) + 1: len(steps) + 1 + P.shape[0]])
+    assert np.abs(Pg - P).max() <= 1e-6
