@@ -155,6 +155,61 @@ def reference_usage_session(device: int, V: int = 1000, closures: int = 30):
             "final_chi2_rel_err_vs_oracle_max": worst}
 
 
+def incremental_session(device: int, V: int, E: int, seed: int, steps: int = 12, chain: int = 25, iters: int = 20):
+    """The reference's usage pattern at the BENCH workload's size (slc.cpp:205-226, :272-287): a resident graph of V poses /
+    E edges, then `steps` accepted loop closures, each appending `chain` new poses with their odometry edges and one
+    closure, re-initialising and running optimize(iters).  Through sgo_update_graph_se2 (the resident level-0 structure and
+    multigrid hierarchy are kept, the appended part is an overlay: sparse_gslam_amd/csrc/sgo_overlay.h) against a fresh
+    sgo_set_graph_se2 of the same arrays from the same initial poses on a second context: set-up and optimize() times, PCG
+    iterations, and the worst relative chi2 difference over all iterates of all steps (bound 1e-6)."""
+    from sparse_gslam_amd import capi, synth
+    base, app, g = synth.append_session(V, E, steps, chain, seed)
+    odom_meas = g.meas[: g.V - 1]
+    arrs = [base.ei, base.ej, base.meas, base.info, base.phi]
+    t_up, t_opt, t_set, t_fopt, its, fits, worst, descs = [], [], [], [], [], [], 0.0, []
+    with capi.Optimizer(device) as inc, capi.Optimizer(device) as fresh:
+        inc.set_graph(*base.arrays())
+        d, st = inc.optimize(iters)
+        P = inc.get_poses()
+        E_res = base.E
+        for k, a in enumerate(app):
+            arrs = [np.concatenate([x, a[n]]) for x, n in zip(arrs, ("ei", "ej", "meas", "info", "phi"))]
+            P0 = np.empty((a["V"], 3))
+            P0[: P.shape[0]] = P
+            synth.chain_init(P0, odom_meas, P.shape[0], a["V"] - 1)
+            fixed = np.zeros(a["V"], dtype=bool)
+            fixed[0] = True
+            t = time.perf_counter()
+            inc.update_graph(P0, fixed, *arrs, E_res)
+            t1 = time.perf_counter()
+            d, st = inc.optimize(iters)
+            t2 = time.perf_counter()
+            P = inc.get_poses()
+            descs.append(inc.solver_description().split("; last update: ")[-1])
+            t_up.append(1e3 * (t1 - t)); t_opt.append(1e3 * (t2 - t1)); its.append(float(np.mean(st["pcg_iters"])))
+            t = time.perf_counter()
+            fresh.set_graph(P0, fixed, *arrs)
+            t1 = time.perf_counter()
+            df, sf = fresh.optimize(iters)
+            t2 = time.perf_counter()
+            t_set.append(1e3 * (t1 - t)); t_fopt.append(1e3 * (t2 - t1)); fits.append(float(np.mean(sf["pcg_iters"])))
+            if d == iters == df:
+                worst = max(worst, max(abs(x - y) / y for x, y in zip(st["chi2"], sf["chi2"])),
+                            max(abs(x - y) / y for x, y in zip(st["robust_chi2"], sf["robust_chi2"])))
+            else:
+                worst = float("nan")
+            E_res = arrs[0].size
+    med = lambda v: float(np.median(v))   # noqa: E731
+    return {"workload": f"append_session(V={V}, E={E}, seed={seed}): {steps} closures, each {chain} new poses + odometry + 1 closure, "
+                        f"optimize({iters}) after each",
+            "update_ms_median": med(t_up), "update_ms_min_max": [float(min(t_up)), float(max(t_up))],
+            "optimize_ms_median": med(t_opt), "setup_plus_optimize_ms": med(np.add(t_up, t_opt)),
+            "pcg_iters_per_gn_iter": its,
+            "fresh_set_graph_ms_median": med(t_set), "fresh_optimize_ms_median": med(t_fopt),
+            "fresh_setup_plus_optimize_ms": med(np.add(t_set, t_fopt)), "fresh_pcg_iters_per_gn_iter": fits,
+            "max_rel_chi2_diff_vs_fresh_setup": worst, "bound": 1e-6, "updates": descs}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -192,7 +247,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def note(msg):   # progress on stderr (a run that stays silent for minutes is taken to be hung by the GPU runner)
+        if rank == 0:
+            print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+    note(f"generating {args.config}")
     g = synth.config(args.config)   # every rank builds the same graph (deterministic generator)
+    note(f"graph ready: V={g.V} E={g.E}")
 
     opts = {}
     if args.solver:
@@ -240,6 +301,7 @@ def main():
             raise SystemExit(f"optimize stopped after {done} iterations: {st}")
         return st
 
+    note(f"set_graph steady state {set_graph_steady_ms:.1f} ms; warm-up")
     for _ in range(args.warmup):
         step()
     barrier()
@@ -293,7 +355,8 @@ def main():
         }
     opt.close()
 
-    if rank == 0 and world == 1 and not args.no_roofline and args.config in synth.CONFIGS:
+    note(f"timed region done: {1e3 * dt / args.steps:.1f} ms per step")
+    if rank == 0 and world == 1 and not args.no_roofline and args.config in synth.CONFIGS and g.V <= 200_000:
         # BASELINE.md's dead-reckoned start on the same graph: PCG iterations per GN iteration and where the robust
         # chi2 goes over optimize(20) -- the evidence behind init=incremental as the bench workload
         go = synth.config(args.config, init="odom")
@@ -308,6 +371,7 @@ def main():
                                   "robust_chi2_min": min(ps["robust_chi2"]),
                                   "gn_iter_ms_median": 1e3 * float(np.median(ps["seconds"][:max(pd, 1)]))}
     if rank == 0 and world == 1 and not args.no_roofline:
+        note("roofline leg")
         # roofline leg: the same workload again with every launch bracketed by HIP events on the
         # context's stream (profile=1 disables the hipGraph so that single launches can be timed)
         popts = dict(opts)
@@ -394,8 +458,12 @@ def main():
                             "GB/s": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)}
                         for n, v in prof.items() if v["ms"] > 0}}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        note("cpu baseline")
         out["cpu_baseline"] = cpu_baseline(g, args.iters)
         out["reference_usage_session"] = reference_usage_session(local_rank)
+    if rank == 0 and world == 1 and not args.no_roofline and args.config in ("C2", "C4"):
+        note("incremental session")
+        out["incremental_session"] = incremental_session(local_rank, g.V, g.E, g.meta["seed"], iters=args.iters)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

@@ -307,6 +307,10 @@ int sgo_debug_coarse_rhs(sgo_ctx* ctx, const double* r, double* out, int cap);
  * per-slot / per-block index arrays, level-0 transfer blocks and product lists): proportional to 1 / nranks in row-owner mode. */
 int64_t sgo_debug_level0_bytes(sgo_ctx* ctx);
 double sgo_debug_spmv0_us(sgo_ctx* ctx, int mode, int variant, int reps);
+/* Diagnostic (env SGO_LANCZOS=1 when the graph is set): alpha, beta of every PCG iteration of the last solve as pairs in
+ * iteration order -- the Lanczos matrix of the preconditioned operator follows from them (scripts/ritz_probe.py).  Returns
+ * the iterations written (<= cap pairs), < 0 on error. */
+int sgo_debug_lanczos(sgo_ctx* ctx, double* out, int cap);
 
 /* One line naming the solver the resident graph's sgo_optimize_gn runs ("direct_ldlt: ...", "pcg_amg: L0 n=... ",
  * "pcg_block_jacobi ..."): which path a graph took, and for the direct path's refusals the reason

@@ -42,7 +42,7 @@ if [ "$cfg" = "C4" ]; then
   python3 bench.py --config C3s 2>/dev/null | tail -1 > $O/${tag}_bench_c3s.json
   list="c4 c4_steps20 c2 c3s"
 else
-  python3 bench.py --config $cfg --no-cpu-baseline 2>/dev/null | tail -1 > $O/${tag}_bench_$lc.json
+  python3 bench.py --config $cfg --no-cpu-baseline 2> $O/${tag}_bench_$lc.err | tail -1 > $O/${tag}_bench_$lc.json
   list="$lc"
 fi
 for c in $list; do python3 - $O/${tag}_bench_$c.json <<'PY'

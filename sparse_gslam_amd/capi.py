@@ -29,7 +29,7 @@ SYMBOLS = [
     "sgo_comm_init", "sgo_comm_size", "sgo_shard_range", "sgo_debug_set_shard", "sgo_last_error",
     "sgo_closure_information", "sgo_plan_rows", "sgo_debug_coarse_rhs", "sgo_debug_spmv0_us",
     "sgo_solver_description", "sgo_comm_init_host", "sgo_comm_host_allgather", "sgo_debug_level0_bytes",
-    "sgo_kernel_profile_samples", "sgo_update_graph_se2",
+    "sgo_kernel_profile_samples", "sgo_update_graph_se2", "sgo_debug_lanczos",
 ]
 
 
@@ -106,6 +106,7 @@ def lib():
     L.sgo_destroy.argtypes = [vp]
     L.sgo_set_graph_se2.argtypes = [vp, C.c_int32, d, u8, C.c_int32, i32, i32, d, d, d]
     L.sgo_update_graph_se2.argtypes = [vp, C.c_int32, d, u8, C.c_int32, i32, i32, d, d, d, C.c_int32]
+    L.sgo_debug_lanczos.argtypes = [vp, d, C.c_int]
     L.sgo_set_poses.argtypes = [vp, d]
     L.sgo_get_poses.argtypes = [vp, d]
     L.sgo_optimize_gn.argtypes = [vp, C.c_int32, C.POINTER(Stats)]
@@ -396,6 +397,12 @@ class Optimizer:
         rr = C.c_double()
         it = self._check(lib().sgo_solve(self._h, _dp(x), C.byref(rr)), "sgo_solve")
         return x, it, rr.value
+
+    def lanczos(self):
+        """(alpha, beta) of every PCG iteration of the last solve (needs env SGO_LANCZOS=1 at set_graph)."""
+        buf = np.empty((2048, 2))
+        n = self._check(lib().sgo_debug_lanczos(self._h, _dp(buf), 2048), "sgo_debug_lanczos")
+        return buf[:n, 0].copy(), buf[:n, 1].copy()
 
     def last_error(self) -> str:
         """Text of the last error on this context (sgo_last_error)."""

@@ -583,6 +583,21 @@ int sgo_debug_coarse_rhs(sgo_ctx* c, const double* r, double* out, int cap) {
   return n3;
 }
 
+// Diagnostic (env SGO_LANCZOS=1 at sgo_set_graph_se2): alpha / beta of every PCG iteration of the last solve, pairs in
+// iteration order; returns the number of iterations written (the Lanczos matrix of the preconditioned operator follows
+// from them: scripts/ritz_probe.py), < 0 on error.
+int sgo_debug_lanczos(sgo_ctx* c, double* out, int cap) {
+  int rc = check_graph(c);
+  if (rc) return rc;
+  if (!c->d_lanczos || !out || !c->h_S) return SGO_EINVAL;
+  const int n = std::min(std::min(c->h_S->iter, (int)kLanczosMax), cap);
+  if (n > 0) {
+    HIP_TRY(c, hipMemcpyAsync(out, c->d_lanczos, sizeof(double) * 2 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+  }
+  return n;
+}
+
 int sgo_kernel_profile(sgo_ctx* c, sgo_kernel_stat* out, int cap) {
   try {
     if (!c || (cap > 0 && !out)) return SGO_EINVAL;

@@ -96,6 +96,7 @@ struct sgo_ctx {
   double* d_partials = nullptr;   // [3][kMaxPartials]
   double* d_hist = nullptr;       // [SGO_MAX_ITERS + 2][2] chi2 history
   PcgScalars* d_S = nullptr;
+  double* d_lanczos = nullptr;    // [2 kLanczosMax] alpha / beta per PCG iteration of the last solve (diagnostic, env SGO_LANCZOS=1)
   PcgScalars* h_S = nullptr;      // pinned
   double* h_hist = nullptr;       // pinned
   bool linearized = false;

@@ -499,8 +499,9 @@ int launch_spmv_ex(hipStream_t s, const BsrDev& A, int mode, const SpmvArgs& a);
 void launch_update_xr(hipStream_t s, int n, PcgScalars* S, const double* pq_parts, int n_pq, const double* dinv,
                       const double* p, const double* q, double* x, double* r, double* z, double* xs, double omega,
                       double* partials, int* grid_out);
+constexpr int kLanczosMax = 2048;    // PCG iterations whose alpha / beta the diagnostic record keeps (env SGO_LANCZOS=1)
 void launch_update_p(hipStream_t s, int n, PcgScalars* S, const double* rz_parts, int n_rz, const double* rr_parts,
-                     int n_rr, const double* zq_parts, const double* z, double* p);
+                     int n_rr, const double* zq_parts, const double* z, double* p, double* lanczos = nullptr);
 void launch_pose_update(hipStream_t s, int n, const int* free_id, const double* x, double* poses);
 void launch_closure_cov(hipStream_t s, int n, const sgo_match_window* win, const float* scores, double* cov,
                         double* info);

@@ -924,7 +924,7 @@ __global__ __launch_bounds__(kBlock) void k_update_xr(int n, PcgScalars* S, cons
 __global__ __launch_bounds__(kBlock) void k_update_p(int n3, PcgScalars* S, const double* __restrict__ rz_parts, int n_rz,
                                                      const double* __restrict__ rr_parts, int n_rr,
                                                      const double* __restrict__ zq_parts, const double* __restrict__ z,
-                                                     double* __restrict__ p) {
+                                                     double* __restrict__ p, double* __restrict__ lanczos) {
   // the scalars of the previous launches in one go, before the reduction's barriers, and this thread's first pair of
   // operands (see k_update_xr)
   const int i0 = blockIdx.x * kBlock + threadIdx.x;
@@ -953,6 +953,10 @@ __global__ __launch_bounds__(kBlock) void k_update_p(int n3, PcgScalars* S, cons
     S->rr = rr;
     S->iter = iter_prev + 1;
     if (stop) S->stop = stop;
+    if (lanczos && iter_prev < kLanczosMax) {   // diagnostic: the recurrence's alpha / beta of this iteration (Lanczos matrix of M^-1 H)
+      lanczos[2 * iter_prev] = alpha;
+      lanczos[2 * iter_prev + 1] = beta;
+    }
   }
   if (stop) return;
   if (i0 < n3) p[i0] = z0 + beta * p0;
@@ -1235,9 +1239,9 @@ void launch_update_xr(hipStream_t s, int n, PcgScalars* S, const double* pq_part
   if (grid_out) *grid_out = grid;
 }
 void launch_update_p(hipStream_t s, int n, PcgScalars* S, const double* rz_parts, int n_rz, const double* rr_parts,
-                     int n_rr, const double* zq_parts, const double* z, double* p) {
+                     int n_rr, const double* zq_parts, const double* z, double* p, double* lanczos) {
   const int grid = grid_for(3LL * n, kBlock);
-  SGO_LAUNCH(k_update_p, dim3(grid), dim3(kBlock), 0, s, 3 * n, S, rz_parts, n_rz, rr_parts, n_rr, zq_parts, z, p);
+  SGO_LAUNCH(k_update_p, dim3(grid), dim3(kBlock), 0, s, 3 * n, S, rz_parts, n_rz, rr_parts, n_rr, zq_parts, z, p, lanczos);
 }
 // Score-weighted sample covariance of a scan-match window and its inverse: one wave per match,
 // lanes stride over the window's samples (k fastest, as the reference's loops), ten fp64 sums

@@ -371,7 +371,7 @@ int pcg_iteration(sgo_ctx* c) {
     }
     Scope sc(c, K_UPDATE_P, 3 * 24.0 * c->n);
     launch_update_p(c->stream, c->n, c->d_S, c->d_zparts, gz, parts2 + kMaxPartials, g2, c->d_zparts + kMaxPartials,
-                    c->d_z, c->d_p);
+                    c->d_z, c->d_p, c->d_lanczos);
   } else {
     Scope sc(c, K_UPDATE_P, 3 * 24.0 * c->n);
     launch_update_p(c->stream, c->n, c->d_S, parts2, g2, parts2 + kMaxPartials, g2, nullptr, c->d_z, c->d_p);

@@ -785,6 +785,8 @@ int build_structure(sgo_ctx* c, int V, const double* poses, const uint8_t* fixed
   if ((rc = dalloc(c, &c->d_xprev, n3))) return rc;
   if ((rc = dalloc(c, &c->d_zparts, 2 * (size_t)kMaxPartials))) return rc;
   if ((rc = dalloc(c, &c->d_S, 1))) return rc;
+  c->d_lanczos = nullptr;
+  if (std::getenv("SGO_LANCZOS") && (rc = dalloc(c, &c->d_lanczos, 2 * (size_t)kLanczosMax))) return rc;
   HIP_TRY(c, hipMemsetAsync(c->d_S, 0, sizeof(PcgScalars), c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));  // host staging vectors die at return
   if (c->opts.verbose)
