@@ -78,8 +78,8 @@ int do_chi2(sgo_ctx* c, double* d_out2, double* d_e2) {
   int grid = 0;
   {
     Scope sc(c, K_CHI2, bytes_chi2(c));
-    int e0 = 0, e1 = c->E;
-    if (c->comm.nranks > 1 && !c->replicated && !d_e2) sgo_shard_range(c->E, c->comm.nranks, c->comm.rank, &e0, &e1);
+    int e0 = 0, e1 = c->el.E;   // (the resident edge list; c->E also counts the edges an incremental update appended: el2 below)
+    if (c->comm.nranks > 1 && !c->replicated && !d_e2) sgo_shard_range(c->el.E, c->comm.nranks, c->comm.rank, &e0, &e1);
     launch_chi2(c->stream, c->el, e0, e1, c->d_poses, d_e2, c->d_partials, &grid, c->ov.active ? &c->ov.dev.el : nullptr);
   }
   {
