@@ -276,13 +276,22 @@ int sgo_update_graph_se2(sgo_ctx* c, int32_t V, const double* poses, const uint8
       ov.ej.insert(ov.ej.end(), ej + n_resident_edges, ej + E);
       const std::vector<unsigned char> old_fixed = ov.fixed;
       ov.fixed.assign(fixed, fixed + V);
+      double tl = wall_s();
+      auto lap = [&](const char* what) {
+        const double t = wall_s();
+        if (c->opts.verbose > 1) std::fprintf(stderr, "[sgo]   update %-16s %.3f ms\n", what, 1e3 * (t - tl));
+        tl = t;
+      };
       hipStreamSynchronize(c->stream);   // (nothing of an earlier optimize() may still read the overlay's structure arrays)
+      lap("stream drain");
       bool ok = overlay_upload_edges(ov, c->stream, (int)old_ne, 0, nullptr, nullptr, nullptr, nullptr, nullptr, &c->err);   // (allocates on first use)
       const OverlayDev old_dev = ov.dev;   // (with the device pointers in place: restored when the new shape is refused)
       const std::vector<int> old_new = ov.new_vertex;
       if (ok) ok = overlay_upload_edges(ov, c->stream, (int)old_ne, dE, ei + n_resident_edges, ej + n_resident_edges,
                                      meas + 3 * (size_t)n_resident_edges, info + 6 * (size_t)n_resident_edges, phi + n_resident_edges, &c->err);
+      lap("edge upload");
       if (ok) ok = overlay_build(ov, V, c->stream, &why, &c->err);
+      lap("overlay build");
       if (ok && hipMemcpyAsync(c->d_poses, poses, sizeof(double) * 3 * (size_t)V, hipMemcpyHostToDevice, c->stream) != hipSuccess) {
         ok = false;
         why = "pose upload failed";
@@ -291,6 +300,7 @@ int sgo_update_graph_se2(sgo_ctx* c, int32_t V, const double* poses, const uint8
         ok = false;
         why = "device error";
       }
+      lap("poses + sync");
       if (ok) {
         ov.active = ov.dev.k + ov.dev.nt > 0;
         ov.updates++;

@@ -71,6 +71,8 @@ struct Overlay {
   void* buf = nullptr;
   int* d_int = nullptr;                       // structure arrays
   unsigned char* d_side = nullptr;
+  int* h_int = nullptr;                       // their pinned host images (a pageable source of this size makes the runtime pin and
+  unsigned char* h_side = nullptr;            // unpin it per copy: 10-20 ms per update, measured)
   int updates = 0;                            // updates absorbed since the base was built
 };
 

@@ -384,6 +384,14 @@ static bool overlay_alloc(Overlay& ov, std::string* err) {
     if (err) *err = "out of device memory (incremental set-up buffers)";
     return false;
   }
+  if (hipHostMalloc((void**)&ov.h_int, sizeof(int) * L.n_int + 2 * (size_t)kOvMaxEdges) != hipSuccess) {
+    hipFree(ov.buf);
+    ov.buf = nullptr;
+    ov.h_int = nullptr;
+    if (err) *err = "out of pinned host memory (incremental set-up buffers)";
+    return false;
+  }
+  ov.h_side = (unsigned char*)(ov.h_int + L.n_int);
   double* d = (double*)ov.buf;
   ov.d_int = (int*)(d + L.n_dbl);
   ov.d_side = (unsigned char*)(ov.d_int + L.int_total());
@@ -416,6 +424,7 @@ static bool overlay_alloc(Overlay& ov, std::string* err) {
 
 void overlay_release(Overlay& ov) {
   if (ov.buf) hipFree(ov.buf);
+  if (ov.h_int) hipHostFree(ov.h_int);
   ov = Overlay();
 }
 
@@ -467,9 +476,9 @@ bool overlay_build(Overlay& ov, int V, hipStream_t s, std::string* why, std::str
     return (int)(std::lower_bound(nv.begin(), nv.end(), v) - nv.begin());
   };
   const Layout& L = layout();
-  std::vector<int> hi(L.n_int, 0);
-  std::vector<unsigned char> hs(2 * (size_t)std::max(ne, 1), 0);
-  int* rp = hi.data() + L.i_rp;
+  int* hi = ov.h_int;              // (the stream was drained by the caller: the previous update's copy has long finished)
+  unsigned char* hs = ov.h_side;
+  int* rp = hi + L.i_rp;
   std::vector<int> ca(ne), cb(ne);
   std::vector<int> cntr((size_t)k + nt + 1, 0);
   auto rowof = [&](int c) { return c >= 0 ? c : k + (-1 - c); };
@@ -487,8 +496,8 @@ bool overlay_build(Overlay& ov, int V, hipStream_t s, std::string* why, std::str
   for (int r = 0; r < k + nt; ++r) cntr[r + 1] += cntr[r];
   std::copy(cntr.begin(), cntr.end(), rp);
   std::vector<int> fill(cntr.begin(), cntr.end() - 1);
-  int* ent_edge = hi.data() + L.i_edge;
-  int* ent_other = hi.data() + L.i_other;
+  int* ent_edge = hi + L.i_edge;
+  int* ent_other = hi + L.i_other;
   for (int e = 0; e < ne; ++e) {   // entries in edge order: every row's sums are taken in that order
     if (ca[e] != kOvOtherFixed) {
       const int t = fill[rowof(ca[e])]++;
@@ -499,22 +508,31 @@ bool overlay_build(Overlay& ov, int V, hipStream_t s, std::string* why, std::str
       ent_edge[t] = e; ent_other[t] = ca[e]; hs[t] = 1;
     }
   }
-  int* vtx = hi.data() + L.i_vtx;
+  int* vtx = hi + L.i_vtx;
   for (int i = 0; i < k; ++i) vtx[i] = nv[i];
   // (vertex ids of the touched rows are not needed: their poses are read through the edges' endpoints)
-  int* trow = hi.data() + L.i_trow;
+  int* trow = hi + L.i_trow;
   for (int t = 0; t < nt; ++t) trow[t] = tr[t];
   int nnz = 0;
-  int* nz = hi.data() + L.i_nz;
+  int* nz = hi + L.i_nz;
   for (int i = 0; i < k; ++i) {
     bool any = false;
     for (int t = rp[i]; t < rp[i + 1]; ++t) any = any || (ent_other[t] < 0 && ent_other[t] != kOvOtherFixed);
     if (any) nz[nnz++] = i;
   }
   hi[L.i_hdr] = k; hi[L.i_hdr + 1] = nt; hi[L.i_hdr + 2] = 3 * nt + 1; hi[L.i_hdr + 3] = nnz;
-  hipError_t e1 = hipMemcpyAsync(ov.d_int, hi.data(), sizeof(int) * L.n_int, hipMemcpyHostToDevice, s);
-  if (e1 == hipSuccess) e1 = hipMemcpyAsync(ov.d_side, hs.data(), hs.size(), hipMemcpyHostToDevice, s);
-  if (e1 == hipSuccess) e1 = hipStreamSynchronize(s);   // (the staging vectors die here)
+  // only what is used travels: header + row pointers, the entries, vertex / row lists
+  const size_t nent = (size_t)cntr[(size_t)k + nt];
+  hipError_t e1 = hipMemcpyAsync(ov.d_int, hi, sizeof(int) * (L.i_rp + (size_t)k + nt + 1), hipMemcpyHostToDevice, s);
+  auto up = [&](size_t at, size_t cnt) {
+    if (e1 == hipSuccess && cnt > 0) e1 = hipMemcpyAsync(ov.d_int + at, hi + at, sizeof(int) * cnt, hipMemcpyHostToDevice, s);
+  };
+  up(L.i_edge, nent);
+  up(L.i_other, nent);
+  up(L.i_vtx, (size_t)k);
+  up(L.i_trow, (size_t)nt);
+  up(L.i_nz, (size_t)nnz);
+  if (e1 == hipSuccess && nent > 0) e1 = hipMemcpyAsync(ov.d_side, hs, nent, hipMemcpyHostToDevice, s);
   if (e1 != hipSuccess) {
     if (err) *err = std::string("incremental set-up: structure upload: ") + hipGetErrorString(e1);
     *why = "upload failed";

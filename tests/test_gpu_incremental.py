@@ -65,8 +65,13 @@ def _session(V0, E0, nsteps, chain, seed, iters=8, oracle=False, **kw):
 
 def test_append_chain_and_closure_matches_fresh_setup_and_oracle():
     worst, descs, its = _session(3000, 12000, 5, 20, seed=3, oracle=True)
-    assert all("incremental overlay" in d for d in descs), descs
-    assert "100 appended rows" in descs[-1], descs[-1]
+    # the overlay accumulates over the first three closures; the fourth closure ends in a pose of an EARLIER update -- an edge
+    # among appended poses that is not a chain edge -- and the update falls back to the full set-up (saying so); the fifth
+    # starts a new overlay on the rebuilt structure
+    assert all("incremental overlay" in d for d in descs[:3]), descs
+    assert "60 appended rows, 3 touched rows" in descs[2], descs[2]
+    assert "full set-up (appended edges among the new poses do not form a chain)" in descs[3], descs[3]
+    assert "incremental overlay: 20 appended rows" in descs[4], descs[4]
     # the resident hierarchy preconditions the updated system about as well as a fresh one: a handful of iterations more
     assert all(a <= b + 8 for a, b in its), its
 
@@ -74,6 +79,7 @@ def test_append_chain_and_closure_matches_fresh_setup_and_oracle():
 def test_full_information_phi10_long_chains_and_two_closures_per_step():
     worst, descs, its = _session(6000, 30000, 4, 60, seed=11, info_mode="full", phi=10.0, closures_per_step=2)
     assert all("incremental overlay" in d for d in descs), descs
+    assert "240 appended rows, 9 touched rows" in descs[-1], descs[-1]
 
 
 def _one_update(mutate, expect_overlay, V0=2500, seed=5, iters=6):
