@@ -654,7 +654,8 @@ class SparseOptimizer : public OptimizableGraph {
               [](OptimizableGraph::Vertex* a, OptimizableGraph::Vertex* b) { return a->id() < b->id(); });
     int h = 0;
     for (auto* v : _activeVertices) v->setHessianIndex(v->fixed() ? -1 : h++);
-    _graphOnDevice = false;
+    // (what the device holds stays known: optimize() marshals the active sets again and compares -- an unchanged graph
+    // uploads poses only, a graph that grew by a chain and a closure becomes an incremental update)
     return true;
   }
   // upstream appends the new vertices / edges to the active sets (new vertices get the next hessian indices)
@@ -692,7 +693,6 @@ class SparseOptimizer : public OptimizableGraph {
       _activeVertices.push_back(v);
     }
     for (auto* e : ne) _activeEdges.push_back(e);
-    _graphOnDevice = false;
     return true;
   }
 

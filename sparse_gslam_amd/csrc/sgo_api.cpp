@@ -603,8 +603,13 @@ int sgo_debug_lanczos(sgo_ctx* c, double* out, int cap) {
   if (!c->d_lanczos || !out || !c->h_S) return SGO_EINVAL;
   const int n = std::min(std::min(c->h_S->iter, (int)kLanczosMax), cap);
   if (n > 0) {
-    HIP_TRY(c, hipMemcpyAsync(out, c->d_lanczos, sizeof(double) * 2 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    std::vector<double> t(3 * (size_t)n);
+    HIP_TRY(c, hipMemcpyAsync(t.data(), c->d_lanczos, sizeof(double) * 3 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (int j = 0; j < n; ++j) {
+      out[2 * j] = t[3 * (size_t)j];
+      out[2 * j + 1] = t[3 * (size_t)j + 1];
+    }
   }
   return n;
 }

@@ -96,7 +96,19 @@ struct sgo_ctx {
   double* d_partials = nullptr;   // [3][kMaxPartials]
   double* d_hist = nullptr;       // [SGO_MAX_ITERS + 2][2] chi2 history
   PcgScalars* d_S = nullptr;
-  double* d_lanczos = nullptr;    // [2 kLanczosMax] alpha / beta per PCG iteration of the last solve (diagnostic, env SGO_LANCZOS=1)
+  double* d_lanczos = nullptr;    // [kLanczosMax][3] alpha, beta, r.z per PCG iteration of the last recorded solve
+  // Deflated PCG: Ritz vectors of M^-1 H taken from the Lanczos matrix of one undeflated solve are recycled as deflation space
+  // by the solves that follow (the Gauss-Newton systems of one optimize() -- and of the next calls on the same structure --
+  // differ little); see start_pcg / build_ritz in sgo_solve.cpp
+  int defl_k = 0;                 // vectors (0: off; env SGO_DEFLATE, default 8)
+  int defl_zmax = 0;              // Lanczos vectors the record holds
+  bool defl_ready = false;        // W is valid for the current hierarchy
+  bool defl_on = false;           // the running solve is deflated
+  bool defl_rec = false;          // the running solve records its Lanczos data
+  int defl_best = 0;              // fewest iterations of a deflated solve with the current W (staleness rule, counts only)
+  double *d_W = nullptr, *d_HW = nullptr, *d_Ginv = nullptr, *d_dparts = nullptr, *d_gram = nullptr, *d_Zbuf = nullptr, *d_ritzC = nullptr;
+  bool pred_defl = false;         // pcg_pred came from a deflated solve
+  int pcg_exec_key = 0;           // what the captured PCG iteration contains (overlay term, deflation, recording)
   PcgScalars* h_S = nullptr;      // pinned
   double* h_hist = nullptr;       // pinned
   bool linearized = false;
@@ -136,7 +148,6 @@ struct sgo_ctx {
   // incremental re-initialisation (sgo_update_graph_se2, sgo_overlay.h): V / E above count the appended part too, n stays
   // the resident structure's rows
   Overlay ov;
-  bool pcg_exec_ov = false;       // the captured PCG iteration contains the overlay's operator term
   double its_base = 0.0;          // mean PCG iterations per solve of the first optimize() on the resident structure alone,
   double its_last = 0.0;          // ... of the latest optimize(): an overlay that costs too many iterations is dropped for a full set-up
   std::string update_note;        // what the last sgo_update_graph_se2 did (sgo_solver_description)
