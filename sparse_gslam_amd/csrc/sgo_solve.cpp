@@ -173,7 +173,8 @@ static int start_pcg_owner(sgo_ctx* c, int grid) {
 // ---- deflated PCG: recycled Ritz vectors ----------------------------------------------------------------------------
 // The preconditioned operator M^-1 H of these graphs has a dense low end (C4: 0.053 0.059 0.084 0.10 0.13 0.16 0.20 0.23 ...
 // up to 1.0, the same to three digits in every Gauss-Newton iteration: scripts/ritz_probe.py): the iteration counts are set by
-// that end.  One solve runs plain PCG and records its Lanczos data -- (alpha_j, beta_j, r_j.z_j) and the vectors z_j --, the
+// that end.  (OPT-IN, env SGO_DEFLATE=k: it did not pay -- see the note at the allocation in sgo_structure.cpp.)  One solve
+// runs plain PCG and records its Lanczos data -- (alpha_j, beta_j, r_j.z_j) and the vectors z_j --, the
 // k smallest Ritz pairs of the Lanczos matrix give W = Z Y (build_ritz), and the solves that follow keep their directions
 // H-orthogonal to W (k_update_p): 30 -> 17 iterations with k = 8 on a prototype of that spectrum, for k extra Hessian
 // products per Gauss-Newton iteration (H W) and one extra launch + 2 k vector reads per PCG iteration.

@@ -793,7 +793,11 @@ int build_structure(sgo_ctx* c, int V, const double* poses, const uint8_t* fixed
   c->defl_ready = c->defl_on = c->defl_rec = false;
   c->defl_best = 0;
   {
-    int k = 8;
+    // OFF by default -- measured in round 4 (NOTES.md section 9): the low end of the spectrum of M^-1 H is a continuum, not a few
+    // outliers: with 8 recycled Ritz vectors deflated the smallest Ritz value of C4 moves from 0.056 to 0.074 (not to the 9th,
+    // 0.276), 30 -> 25 iterations, and H W + the extra launch cost more than that saves (4.0 -> 4.9 ms per GN iteration).
+    // SGO_DEFLATE=k (<= 8) turns it on.
+    int k = 0;
     if (const char* e = std::getenv("SGO_DEFLATE")) k = std::max(0, std::min(kDeflMax, std::atoi(e)));
     if (c->opts.solver != SGO_SOLVER_PCG_AMG || c->comm.active() || c->comm.nranks > 1 || n < 2000) k = 0;   // (small graphs: a dense or two-level solve)
     if (k > 0 || std::getenv("SGO_LANCZOS")) {
