@@ -392,32 +392,46 @@ def main():
             f["ms"] += v["ms"]; f["launches"] += v["launches"]; f["bytes"] += v["bytes"]; f["members"].append(n)
         fname, fk = max(fam.items(), key=lambda kv: kv[1]["ms"])
         name, k = max(((n, prof[n]) for n in fk["members"]), key=lambda kv: kv[1]["ms"])
-        # per launch: algorithmic bytes / MEDIAN single-launch duration (profile mode reads the stop flag after every PCG
-        # iteration: no early-exit launch past convergence among the samples; the mean is reported beside it)
-        bytes_per_launch = k["bytes"] / k["launches"]
-        med_us = k.get("median_us", 1e3 * k["ms"] / k["launches"])
-        achieved = bytes_per_launch / (med_us * 1e-6) / 1e9
-        # HBM traffic of the same kernel from the separate rocprofv3 --pmc passes (FETCH_SIZE x2,
-        # WRITE_SIZE; scripts/pmc_summary.py), committed per round under profiles/
-        traffic, traffic_src = None, None
+        import glob as _glob
+
+        def kernel_roofline(kname):
+            """per launch: algorithmic bytes / MEDIAN single-launch duration (profile mode reads the stop flag after every PCG
+            iteration: no early-exit launch past convergence among the samples; the mean is reported beside it), the HBM
+            traffic of the same kernel from the separate rocprofv3 --pmc passes (FETCH_SIZE x2, WRITE_SIZE;
+            scripts/pmc_summary.py) and its median INSIDE the replayed hipGraph of a solve (working dispatches of a
+            rocprofv3 --kernel-trace pass in graph mode: scripts/profile_round.sh -> scripts/trace_summary.py), both committed
+            per round under profiles/"""
+            kk = prof[kname]
+            bpl = kk["bytes"] / kk["launches"]
+            med = kk.get("median_us", 1e3 * kk["ms"] / kk["launches"])
+            ach = bpl / (med * 1e-6) / 1e9
+            tr, tr_src, ins = None, None, None
+            for cand in sorted(_glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_traffic_{solver_name}_{args.config.lower()}.json"))):
+                e = json.load(open(cand))["kernels"].get(kname)
+                if e:
+                    tr, tr_src = e["hbm_bytes_per_launch"], os.path.relpath(cand, ROOT)
+            for cand in sorted(_glob.glob(os.path.join(ROOT, "profiles", f"r*_trace_summary_{args.config.lower()}_graph.json"))):
+                e = json.load(open(cand))["kernels"].get(kname)
+                if e:
+                    ins = {"median_us": e["median_us"], "p10_us": e["p10_us"], "p90_us": e["p90_us"],
+                           "working_dispatches": e["working"], "dispatches": e["dispatches"],
+                           "achieved": bpl / (e["median_us"] * 1e-6) / 1e9,
+                           "frac": bpl / (e["median_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                           "frac_of_measured_copy": bpl / (e["median_us"] * 1e-6) / 1e9 / HBM_COPY_GBS,
+                           "source": os.path.relpath(cand, ROOT)}
+            return {"kernel": kname, "achieved": ach, "frac": ach / HBM_PEAK_GBS, "frac_of_measured_copy": ach / HBM_COPY_GBS,
+                    "traffic": tr, "traffic_source": tr_src, "traffic_over_algorithmic": (tr / bpl) if tr else None,
+                    "median_launch_us": med, "p10_launch_us": kk.get("p10_us"), "p90_launch_us": kk.get("p90_us"),
+                    "avg_launch_us": 1e3 * kk["ms"] / kk["launches"], "launches": kk["launches"],
+                    "algorithmic_bytes_per_launch": bpl, "in_solve": ins}
+
         solver_name = {0: "bj", 1: "amg"}[opts.get("solver", capi.default_opts().solver)]
-        for cand in sorted(__import__("glob").glob(os.path.join(ROOT, "profiles", f"r*_pmc_traffic_{solver_name}_{args.config.lower()}.json"))):
-            kk = json.load(open(cand))["kernels"].get(name)
-            if kk:
-                traffic, traffic_src = kk["hbm_bytes_per_launch"], os.path.relpath(cand, ROOT)
-        # the same kernel INSIDE the replayed hipGraph of a solve (back to back with its neighbours): median of the working
-        # dispatches of a rocprofv3 --kernel-trace pass over this bench in graph mode (scripts/profile_round.sh ->
-        # scripts/trace_summary.py), committed per round under profiles/
-        in_solve = None
-        for cand in sorted(__import__("glob").glob(os.path.join(ROOT, "profiles", f"r*_trace_summary_{args.config.lower()}_graph.json"))):
-            kk = json.load(open(cand))["kernels"].get(name)
-            if kk:
-                in_solve = {"median_us": kk["median_us"], "p10_us": kk["p10_us"], "p90_us": kk["p90_us"],
-                            "working_dispatches": kk["working"], "dispatches": kk["dispatches"],
-                            "achieved": bytes_per_launch / (kk["median_us"] * 1e-6) / 1e9,
-                            "frac": bytes_per_launch / (kk["median_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                            "frac_of_measured_copy": bytes_per_launch / (kk["median_us"] * 1e-6) / 1e9 / HBM_COPY_GBS,
-                            "source": os.path.relpath(cand, ROOT)}
+        dom = kernel_roofline(name)
+        achieved, traffic, traffic_src, med_us, bytes_per_launch, in_solve = (dom["achieved"], dom["traffic"], dom["traffic_source"],
+                                                                               dom["median_launch_us"], dom["algorithmic_bytes_per_launch"],
+                                                                               dom["in_solve"])
+        # the Hessian product of the solve (level 0, fp64 blocks) whatever the dominant kernel is: at C5's size HBM is its bound
+        hp_name = next((n for n in ("k_spmv0t<0, 1024, false>", "k_spmv0<0>") if n in prof), None)
         # whole-iteration figure of SURVEY.md section 8(d): B_GN = B_lin + K B_pcg + 48 V over the median
         # GN iteration time, B_lin = 200 E + 72 V, B_pcg = 76 E + 430 V, K = PCG iterations per GN iteration
         K = float(np.mean(st["pcg_iters"]))
@@ -432,6 +446,7 @@ def main():
             "event_bracket_overhead_us": overhead_us,
             "algorithmic_bytes_per_launch": bytes_per_launch,
             "in_solve": in_solve,
+            "level0_product": kernel_roofline(hp_name) if hp_name else None,
             "kernel_function": {"name": fname, "instantiations": sorted(fk["members"]), "launches": fk["launches"],
                                 "ms": round(fk["ms"], 3), "avg_launch_us": 1e3 * fk["ms"] / fk["launches"],
                                 "achieved": fk["bytes"] / (fk["ms"] * 1e-3) / 1e9,
