@@ -1020,76 +1020,6 @@ __device__ __forceinline__ void tile_mm(const double (*X)[kGjB + 1], const doubl
   for (int q = 0; q < 4; ++q) Z[i0 + lk + 4 * q][j0 + lr] = acc[q];
 }
 
-// Dense product on the matrix cores for the Newton-Schulz refresh of the coarsest inverse (amg_update): one workgroup per
-// 32x32 tile of C, the K loop over 32x32 tiles of A and B through double-buffered LDS (the next pair of tiles is requested
-// from memory before the current one is multiplied: one barrier per step), every wave a 16x16 quadrant accumulated in
-// registers across the whole K loop (v_mfma_f64_16x16x4_f64).
-//   MODE 0: C = I - A B, and the tile's share of ||C||_F^2 to parts[tile]   (the residual of an approximate inverse)
-//   MODE 1: C = D + A B                                                      (X + X R)
-template <int MODE>
-__global__ __launch_bounds__(kBlock) void k_dense_gemm(int Np, const double* __restrict__ A, const double* __restrict__ B,
-                                                       const double* __restrict__ D, double* __restrict__ C, double* __restrict__ parts) {
-  __shared__ double X[2][kGjB][kGjB + 1], Y[2][kGjB][kGjB + 1];
-  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-  const int bj = blockIdx.x, bi = blockIdx.y, nb = Np / kGjB;
-  const int i0 = 16 * (w >> 1), j0 = 16 * (w & 1), lr = lane & 15, lk = lane >> 4;
-  double xa[4], yb[4];
-  auto fetch = [&](int kb) {
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      const int e = t + m * kBlock, i = e / kGjB, j = e % kGjB;
-      xa[m] = A[(size_t)(bi * kGjB + i) * Np + kb * kGjB + j];
-      yb[m] = B[(size_t)(kb * kGjB + i) * Np + bj * kGjB + j];
-    }
-  };
-  auto stash = [&](int buf) {
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      const int e = t + m * kBlock;
-      X[buf][e / kGjB][e % kGjB] = xa[m];
-      Y[buf][e / kGjB][e % kGjB] = yb[m];
-    }
-  };
-  fetch(0);
-  stash(0);
-  __syncthreads();
-  sgo_d4 acc = {0.0, 0.0, 0.0, 0.0};
-  for (int kb = 0; kb < nb; ++kb) {
-    const int cur = kb & 1;
-    if (kb + 1 < nb) fetch(kb + 1);
-#pragma unroll
-    for (int st = 0; st < kGjB / 4; ++st)
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(X[cur][i0 + lr][4 * st + lk], Y[cur][4 * st + lk][j0 + lr], acc, 0, 0, 0);
-    if (kb + 1 < nb) stash(cur ^ 1);   // (the other buffer: its readers finished before the previous barrier)
-    __syncthreads();
-  }
-  double fro = 0.0;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int row = bi * kGjB + i0 + lk + 4 * q, col = bj * kGjB + j0 + lr;
-    double v;
-    if (MODE == 0) {
-      v = (row == col ? 1.0 : 0.0) - acc[q];
-      fro += v * v;
-    } else {
-      v = D[(size_t)row * Np + col] + acc[q];
-    }
-    C[(size_t)row * Np + col] = v;
-  }
-  if (MODE == 0) {
-    __shared__ double fs[kWavesPerBlock];
-    const double sum = wave_sum(fro);
-    if (lane == 0) fs[w] = sum;
-    __syncthreads();
-    if (t == 0) parts[bi * nb + bj] = (fs[0] + fs[1]) + (fs[2] + fs[3]);
-  }
-}
-// out[0] = sum(parts[0 .. n)) in a fixed order (one workgroup)
-__global__ __launch_bounds__(kBlock) void k_sum_parts(const double* __restrict__ parts, int n, double* __restrict__ out) {
-  const double v = block_reduce_parts(parts, n);
-  if (threadIdx.x == 0) out[0] = v;
-}
-
 // One Gauss-Jordan block step K = kb is ONE launch over all 32x32 tiles, reading the matrix of the previous
 // step (Min) and writing the next one (Mout) -- ping-pong, so that no tile is read after another workgroup
 // has overwritten it and no panel kernel has to run first:
@@ -1532,12 +1462,6 @@ struct Amg {
   double* inv1 = nullptr;
   double* gjP[2] = {nullptr, nullptr};   // [32][32] inverse of the current / next pivot block
   int* d_fail = nullptr;
-  // Newton-Schulz refresh of the inverse (amg_update): the current operator, the residual I - A X, a scratch iterate, the
-  // residual's norm (device partial sums + total, pinned host copy)
-  double *nsA = nullptr, *nsR = nullptr, *nsT = nullptr, *nsParts = nullptr;
-  double* nsHost = nullptr;
-  bool inv_valid = false;        // m->inv holds the inverse of an earlier refresh
-  int ns_refreshes = 0, gj_refreshes = 0;
   std::string desc;
 };
 
@@ -1926,7 +1850,6 @@ void amg_describe(const Amg* m, std::string* out) { *out = m ? m->desc : ""; }
 
 void amg_destroy(Amg* m) {
   if (!m) return;
-  if (m->nsHost) hipHostFree(m->nsHost);
   delete m;   // the device memory belongs to the caller's arena
 }
 
@@ -1955,56 +1878,18 @@ int amg_update(Amg* m, hipStream_t s, std::string* err) {
   {
     Scope sc(m->prof, K_DENSE_INVERT, 8.0 * m->Np * m->Np);
     const int nb = m->Np / kGjB;
-    const size_t nn = (size_t)m->Np * m->Np;
-    auto fill = [&](double* M) {
-      hipMemsetAsync(M, 0, sizeof(double) * nn, s);
-      if (last > 0)
-        SGO_LAUNCH(k_dense_fill_unique, dim3(grid_for(m->lv[last].A.nslot, kBlock)), dim3(kBlock), 0, s, m->lv[last].A, m->Np, M);
-      else   // level 0 can hold several slots per (row, col): duplicate edges
-        SGO_LAUNCH(k_dense_fill, dim3(grid_for(m->lv[last].A.n, kBlock)), dim3(kBlock), 0, s, m->lv[last].A, m->Np, M);
-    };
-    // Newton-Schulz refresh: consecutive Gauss-Newton systems differ little, so the inverse X of the previous refresh is an
-    // approximate inverse of the current operator A.  With R = I - A X the iteration X <- X + X R squares the residual
-    // (R <- R^2 exactly, whatever the conditioning), stays symmetric, and is two dense products per step on the fp64 matrix
-    // cores instead of the Np / 32 dependent block steps of the Gauss-Jordan inversion.  ||R||_F (one host read-back) decides:
-    // <= 1e-9 keep X; <= 1e-5 one step; <= 3e-3 two; <= 0.05 three (residual <= 1e-10 afterwards in every case); larger --
-    // robust-kernel re-weighting moved the operator too far -- the Gauss-Jordan inversion from scratch.
-    bool done = false;
-    if (m->inv_valid && m->nsA) {
-      fill(m->nsA);
-      SGO_LAUNCH((k_dense_gemm<0>), dim3(nb, nb), dim3(kBlock), 0, s, m->Np, (const double*)m->nsA, (const double*)m->inv, (const double*)nullptr, m->nsR, m->nsParts);
-      SGO_LAUNCH(k_sum_parts, dim3(1), dim3(kBlock), 0, s, (const double*)m->nsParts, nb * nb, m->nsParts + (size_t)nb * nb);
-      hipMemcpyAsync(m->nsHost, m->nsParts + (size_t)nb * nb, sizeof(double), hipMemcpyDeviceToHost, s);
-      hipStreamSynchronize(s);
-      const double nrm = std::sqrt(m->nsHost[0]);
-      int steps = -1;
-      if (std::isfinite(nrm)) steps = nrm <= 1e-9 ? 0 : (nrm <= 1e-5 ? 1 : (nrm <= 3e-3 ? 2 : (nrm <= 0.05 ? 3 : -1)));
-      if (steps >= 0) {
-        const double* X = m->inv;
-        for (int st = 1; st <= steps; ++st) {
-          double* dst = (st & 1) ? m->nsT : m->inv;
-          SGO_LAUNCH((k_dense_gemm<1>), dim3(nb, nb), dim3(kBlock), 0, s, m->Np, X, (const double*)m->nsR, X, dst, (double*)nullptr);
-          X = dst;
-          if (st < steps)
-            SGO_LAUNCH((k_dense_gemm<0>), dim3(nb, nb), dim3(kBlock), 0, s, m->Np, (const double*)m->nsA, X, (const double*)nullptr, m->nsR, m->nsParts);
-        }
-        if (X != m->inv) hipMemcpyAsync(m->inv, X, sizeof(double) * nn, hipMemcpyDeviceToDevice, s);
-        done = true;
-        m->ns_refreshes++;
-      }
-    }
-    if (!done) {
-      m->gj_refreshes++;
-      fill(m->inv0);
-      hipMemsetAsync(m->d_fail, 0, sizeof(int), s);
-      SGO_LAUNCH(k_gj_pivot, dim3(1), dim3(kGjB * kGjB), 0, s, m->inv0, m->Np, 0, m->gjP[0], m->d_fail);
-      for (int kb = 0; kb < nb; ++kb) {   // the result of step kb lands in buffer (kb + 1) & 1: m->inv after the last one
-        const double* src = (kb & 1) ? m->inv1 : m->inv0;
-        double* dst = (kb & 1) ? m->inv0 : m->inv1;
-        SGO_LAUNCH(k_gj_step, dim3(nb, nb), dim3(kBlock), 0, s, src, dst, m->Np, kb, (const double*)m->gjP[kb & 1],
-                   m->gjP[(kb + 1) & 1], m->d_fail);
-      }
-      m->inv_valid = true;
+    hipMemsetAsync(m->inv0, 0, sizeof(double) * (size_t)m->Np * m->Np, s);
+    hipMemsetAsync(m->d_fail, 0, sizeof(int), s);
+    if (last > 0)
+      SGO_LAUNCH(k_dense_fill_unique, dim3(grid_for(m->lv[last].A.nslot, kBlock)), dim3(kBlock), 0, s, m->lv[last].A, m->Np, m->inv0);
+    else   // level 0 can hold several slots per (row, col): duplicate edges
+      SGO_LAUNCH(k_dense_fill, dim3(grid_for(m->lv[last].A.n, kBlock)), dim3(kBlock), 0, s, m->lv[last].A, m->Np, m->inv0);
+    SGO_LAUNCH(k_gj_pivot, dim3(1), dim3(kGjB * kGjB), 0, s, m->inv0, m->Np, 0, m->gjP[0], m->d_fail);
+    for (int kb = 0; kb < nb; ++kb) {   // the result of step kb lands in buffer (kb + 1) & 1: m->inv after the last one
+      const double* src = (kb & 1) ? m->inv1 : m->inv0;
+      double* dst = (kb & 1) ? m->inv0 : m->inv1;
+      SGO_LAUNCH(k_gj_step, dim3(nb, nb), dim3(kBlock), 0, s, src, dst, m->Np, kb, (const double*)m->gjP[kb & 1],
+                 m->gjP[(kb + 1) & 1], m->d_fail);
     }
   }
   const hipError_t le = hipGetLastError();
@@ -2643,21 +2528,6 @@ Amg* amg_create(hipStream_t s, const BsrDev& A0, const Sym0Dev& S0, const Tile0D
   m->inv = ((m->Np / kGjB) & 1) ? m->inv1 : m->inv0;
   m->d_fail = dev_alloc<int>(m->pool, 1);
   if (!m->inv0 || !m->inv1 || !m->d_fail || !m->gjP[0] || !m->gjP[1]) return fail("amg_create: out of device memory");
-  {
-    bool ns = true;   // Newton-Schulz refresh of the dense inverse (env SGO_DENSE_NS=0: Gauss-Jordan from scratch every time)
-    if (const char* e = std::getenv("SGO_DENSE_NS")) ns = std::atoi(e) != 0;
-    if (ns) {
-      const size_t nn = (size_t)m->Np * m->Np, nb2 = (size_t)(m->Np / kGjB) * (m->Np / kGjB);
-      m->nsA = dev_alloc<double>(m->pool, nn);
-      m->nsR = dev_alloc<double>(m->pool, nn);
-      m->nsT = dev_alloc<double>(m->pool, nn);
-      m->nsParts = dev_alloc<double>(m->pool, nb2 + 1);
-      if (!m->nsA || !m->nsR || !m->nsT || !m->nsParts || hipHostMalloc((void**)&m->nsHost, sizeof(double)) != hipSuccess) {
-        m->nsA = nullptr;   // (not fatal: the refresh falls back to the full inversion)
-        m->nsHost = nullptr;
-      }
-    }
-  }
   hipMemsetAsync(m->d_fail, 0, sizeof(int), s);
   std::snprintf(line, sizeof line, "coarsest dense N=%d; theta=%.3g omega=%.2f", m->N,
                 m->cfg.theta * m->cfg.theta_scale, m->cfg.omega);
