@@ -86,6 +86,8 @@ sgo_ctx* sgo_create(int device, const sgo_opts* opts) {
   if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
       (e = hipHostMalloc((void**)&c->h_S, sizeof(PcgScalars))) != hipSuccess ||
       (e = hipHostMalloc((void**)&c->h_S2, 2 * sizeof(PcgScalars))) != hipSuccess ||
+      (e = hipHostMalloc((void**)&c->h_Sz, sizeof(PcgScalars))) != hipSuccess ||
+      (e = hipHostGetDevicePointer((void**)&c->d_Sz, c->h_Sz, 0)) != hipSuccess ||
       (e = hipEventCreateWithFlags(&c->ev_S[0], hipEventDisableTiming)) != hipSuccess ||
       (e = hipEventCreateWithFlags(&c->ev_S[1], hipEventDisableTiming)) != hipSuccess ||
       (e = hipHostMalloc((void**)&c->h_hist, sizeof(double) * 2 * (SGO_MAX_ITERS + 2))) != hipSuccess ||
@@ -112,6 +114,7 @@ void sgo_destroy(sgo_ctx* c) {
   for (hipEvent_t e : c->iter_events) hipEventDestroy(e);
   if (c->h_S) hipHostFree(c->h_S);
   if (c->h_S2) hipHostFree(c->h_S2);
+  if (c->h_Sz) hipHostFree(c->h_Sz);
   for (hipEvent_t ev : c->ev_S)
     if (ev) hipEventDestroy(ev);
   if (c->h_hist) hipHostFree(c->h_hist);

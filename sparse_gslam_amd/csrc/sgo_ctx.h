@@ -142,7 +142,9 @@ struct sgo_ctx {
   std::vector<double> l0_w;
   int amg_best = 0;               // fewest PCG iterations seen with the current hierarchy (0: none yet);
                                   // kept across optimize() calls so that a hierarchy adapted to other poses is noticed
-  PcgScalars* h_S2 = nullptr;     // pinned [2]: pipelined read-back of the stop flag
+  PcgScalars* h_S2 = nullptr;     // pinned [2]: pipelined read-back of the stop flag (plain launches)
+  PcgScalars* h_Sz = nullptr;     // pinned: the scalars as the last k_update_p left them (RecDev::mirror; hipGraph replay)
+  PcgScalars* d_Sz = nullptr;     // ... its device address
   hipEvent_t ev_S[2] = {nullptr, nullptr};
 
   // incremental re-initialisation (sgo_update_graph_se2, sgo_overlay.h): V / E above count the appended part too, n stays

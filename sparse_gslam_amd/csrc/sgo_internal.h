@@ -515,6 +515,9 @@ struct DeflDev {
   double* dparts = nullptr;           // [kDeflMax][kDeflGrid] partial sums of (HW)^T z (or W^T r)
 };
 struct RecDev {                       // recording of a solve's Lanczos data (the next solves' deflation space is made from it)
+  PcgScalars* mirror = nullptr;       // pinned host copy of the scalars, rewritten by every iteration's k_update_p (also by the
+                                      // early-exit ones): the host reads the stop flag there behind an event instead of
+                                      // queueing a device-to-host copy kernel after every graph replay
   double* lanczos = nullptr;          // [kLanczosMax][3] alpha_j, beta_j, r_j . z_j
   double* Z = nullptr;                // [zmax][stride] z_j
   int zmax = 0;

@@ -955,7 +955,10 @@ __global__ __launch_bounds__(kBlock) void k_update_p(int n3, PcgScalars* S, cons
   }
   const int stop0 = S->stop, iter_prev = S->iter_prev, maxit = S->maxit;
   const double alpha = S->alpha, rz_prev = S->rz_prev, tol2 = S->tol2, bb = S->bb;
-  if (stop0) return;
+  if (stop0) {
+    if (rec.mirror && blockIdx.x == 0 && threadIdx.x == 0) *rec.mirror = *S;   // (a solve stopped by another kernel, or iterations past convergence)
+    return;
+  }
   // flexible CG (variable preconditioner, e.g. the K-cycle): z_new.(r_new - r_old) = -alpha z_new.q
   const double* const parts[3] = {rz_parts, rr_parts, zq_parts};
   const int cnt[3] = {n_rz, n_rr, n_rz};
@@ -977,6 +980,12 @@ __global__ __launch_bounds__(kBlock) void k_update_p(int n3, PcgScalars* S, cons
       rec.lanczos[3 * iter_prev] = alpha;
       rec.lanczos[3 * iter_prev + 1] = beta;
       rec.lanczos[3 * iter_prev + 2] = rz_prev;
+    }
+    if (rec.mirror) {
+      PcgScalars m = *S;   // (pq, alpha, rz_prev, iter_prev as this iteration's k_update_xr left them)
+      m.beta = beta; m.rz = rz; m.rr = rr; m.iter = iter_prev + 1;
+      if (stop) m.stop = stop;
+      *rec.mirror = m;
     }
   }
   // the Lanczos vector of the next iteration (z_0 was recorded by the start)
