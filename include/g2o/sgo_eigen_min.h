@@ -22,6 +22,10 @@ namespace Eigen {
 
 template <class T>
 using aligned_allocator = std::allocator<T>;
+// Eigen::Ref<T> as the reference's ls_extractor/utils.h uses it -- a parameter type that binds a matrix (or, for Ref<const T>,
+// a temporary) without a copy: with fixed-size value types a plain reference does the same
+template <class T>
+using Ref = T&;
 
 template <class S, int R, int C>
 class Matrix {

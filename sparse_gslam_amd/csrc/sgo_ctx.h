@@ -66,6 +66,7 @@ struct sgo_ctx {
   HaloDev halo;
   HaloHost halo_host;
   bool halo_failed = false;
+  bool comm_graph_failed = false;   // capturing the RCCL collectives into the PCG hipGraph failed once: plain launches since
   long long level0_bytes = 0;    // device bytes of the level-0 structure this rank holds (blocks, operands, per-slot / per-block indices)
   double *halo_send = nullptr, *halo_recv = nullptr;   // exchange buffers (hipMalloc, grown on demand, kept across graphs)
   size_t halo_cap = 0;

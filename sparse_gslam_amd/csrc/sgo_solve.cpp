@@ -554,13 +554,27 @@ int ensure_pcg_graph(sgo_ctx* c, int chunk) {
 // iterations past convergence exit on the flag), so the GPU never idles on a host round trip and at
 // most two replays of early-exit launches are wasted.
 int run_pcg(sgo_ctx* c) {
-  // collectives inside the loop: plain stream launches (RCCL calls are not captured into the hipGraph)
-  // Opt-in (env SGO_COMM_GRAPH=1): the RCCL collectives are captured into the hipGraph with the kernels around them
-  // (every rank replays the same graph the same number of times: the replay count follows the device-resident stop
-  // flag, which is bit-identical on all ranks).  Measured with a 1-rank communicator: 154 -> 167 M edge-Jacobians/s on
-  // C4; off by default because it has never run on more than one GPU.  Not possible with the host transport.
-  const bool comm_graph = c->comm.handle != nullptr && !c->comm.host_fn && std::getenv("SGO_COMM_GRAPH") != nullptr;
-  const bool graph = c->opts.use_graph && !c->opts.profile && (!multi_rank(c) || comm_graph);
+  // Multi-GPU with an RCCL communicator: the collectives are captured into the hipGraph with the kernels around them (every
+  // rank replays the same graph the same number of times: the replay count follows snapshots of the device-resident stop flag
+  // taken at fixed points of the stream, bit-identical on all ranks; the exchanges of the set-up and of the solve's start have
+  // run eagerly before, so the communicator's channels exist when the capture begins).  Measured with a 1-rank communicator
+  // on C4: 191 -> 203 M edge-Jacobians/s.  SGO_COMM_GRAPH=0 keeps plain stream launches; a capture that fails falls back to
+  // them for the rest of the context's life.  Not possible with the host transport (a host callback inside the loop).
+  bool comm_graph = c->comm.handle != nullptr && !c->comm.host_fn && !c->comm_graph_failed;
+  if (const char* e = std::getenv("SGO_COMM_GRAPH")) comm_graph = comm_graph && std::atoi(e) != 0;
+  bool graph = c->opts.use_graph && !c->opts.profile && (!multi_rank(c) || comm_graph);
+  constexpr int kUnit = 2;   // iterations per graph replay (1: 44.6, 2: 41.2, 4: 42, 8: 47 us per PCG iteration on C2 -- a replay costs
+                             // ~7 us, an iteration past convergence eight early-exit nodes)
+  if (graph) {
+    const int grc = ensure_pcg_graph(c, kUnit);
+    if (grc != SGO_OK && multi_rank(c)) {
+      c->comm_graph_failed = true;
+      graph = false;
+      if (c->opts.verbose) std::fprintf(stderr, "[sgo] capturing the collectives failed (%s): plain stream launches from here on\n", c->err.c_str());
+    } else if (grc != SGO_OK) {
+      return grc;
+    }
+  }
   if (!graph) {
     // (profile mode: the stop flag is read after EVERY iteration, so that no early-exit launch past convergence is among
     // the timed launches -- their 1.5-us dispatches would pull the per-kernel figures down)
@@ -577,10 +591,6 @@ int run_pcg(sgo_ctx* c) {
     c->pcg_pred = c->h_S->iter;
     return SGO_OK;
   }
-  constexpr int kUnit = 2;   // iterations per graph replay (1: 44.6, 2: 41.2, 4: 42, 8: 47 us per PCG iteration on C2 -- a replay costs
-                             // ~7 us, an iteration past convergence eight early-exit nodes)
-  int rc = ensure_pcg_graph(c, kUnit);
-  if (rc) return rc;
   // One replay (2 iterations, >= 100 us even on 1k-pose graphs) in flight hides the host's read of the
   // stop flag; more only adds early-exit launches past convergence (measured: 8 iterations in flight
   // cost 3.5 % on C4 and 10 % on C1).  pcg_chunk = 16 -> 1 replay; larger values scale it up.
@@ -596,7 +606,8 @@ int run_pcg(sgo_ctx* c) {
   // The stop flag is read from the pinned mirror every k_update_p rewrites (RecDev::mirror) behind an event: no copy kernel
   // between replays (4.3 us each on the stream, measured).  The mirror may already show the state of the replay in flight --
   // a later iteration of the same solve, equally valid; once a stop flag is set nothing moves any more.
-  const bool mirror = !multi_rank(c) && !c->owner;   // (the multi-rank iterations do not pass the mirror: they keep the copy)
+  static const bool mirror_env = !(std::getenv("SGO_MIRROR") && std::atoi(std::getenv("SGO_MIRROR")) == 0);
+  const bool mirror = mirror_env && !multi_rank(c) && !c->owner;   // (the multi-rank iterations do not pass the mirror: they keep the copy)
   int slot = 0;
   auto snapshot = [&](int sl) -> hipError_t {
     if (!mirror) {

@@ -11,6 +11,11 @@
 // Call sequence as src/sparse_gslam/src/drone.cpp:146-156: initializeOptimization / push / optimize(15, false),
 // then new vertices + edges / updateInitialization / push / optimize(15, true).
 //
+// With -DSGO_REF_SOURCES the restated classes are left out and the program uses the REFERENCE's own g2o::VertexRhoTheta /
+// g2o::EdgeSE2RhoTheta: declarations from include/g2o_bindings/*.h, definitions from src/g2o_bindings/{vertex_rhotheta,
+// edge_se2_rhotheta}.cpp compiled verbatim from the read-only checkout and linked in (tests/test_landmark_lm.py, CPU box
+// only) -- the same schedule then runs through the reference's computeError / oplusImpl and ls_extractor/utils.h.
+//
 // usage: landmark_rhotheta <graph.txt>; prints, per stage, "STAGE iterations chi2" and one
 // "IT lambda chi2 trials" line per iteration, then "V id est...".
 #include <cmath>
@@ -31,6 +36,14 @@
 #include "g2o/types/slam2d/edge_se2.h"
 #include "g2o/types/slam2d/vertex_se2.h"
 
+#ifdef SGO_REF_SOURCES
+#include "g2o_bindings/edge_se2_rhotheta.h"
+#include "g2o_bindings/vertex_rhotheta.h"
+namespace g2o {
+using VertexLineRT = VertexRhoTheta;
+using EdgePoseLineRT = EdgeSE2RhoTheta;
+}  // namespace g2o
+#else
 namespace g2o {
 
 inline Eigen::Vector2d move_line(const Eigen::Vector2d& rt, const Eigen::Vector2d& trans, double angle) {
@@ -73,6 +86,7 @@ class EdgePoseLineRT : public BaseBinaryEdge<2, Eigen::Vector2d, VertexSE2, Vert
 };
 
 }  // namespace g2o
+#endif
 
 int main(int argc, char** argv) {
   using namespace g2o;

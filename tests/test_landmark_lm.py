@@ -85,3 +85,60 @@ def test_shim_lm_matches_the_oracle_goldens():
         assert 1 <= s["iterations"] <= 15
     for vid, est in gold["final"].items():
         assert np.abs(np.array(verts[vid]) - np.array(est)).max() <= 1e-6, vid
+
+
+REF = "/root/reference/src"
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference checkout not present (GPU box)")
+def test_reference_binding_sources_compile_verbatim_and_reproduce_the_goldens(tmp_path):
+    """The reference's own src/g2o_bindings/{edge_se2_rhotheta,vertex_rhotheta}.cpp -- and through them
+    ls_extractor/utils.h -- compiled verbatim from the read-only checkout against the compat headers (the only stand-in is
+    tests/ref_stub/boost/array.hpp = std::array, for two covariance helpers the path never calls), linked with the landmark
+    program, which then runs the golden schedule through THEIR computeError / oplusImpl.  (src/graphs.cpp is not built:
+    graphs.h pulls in pose_with_observation.h -> Cartographer + ROS message headers, libraries the image lacks; its two
+    set-up functions are what tests/cpp/replay_posegraph.cpp and landmark_graph.cpp spell out.)
+    Two checks: (1) their computeError against this repo's restatement on 2000 pose / line pairs: equal to rounding (1e-13);
+    (2) the golden LM schedule: lambda_0 to 1e-6, every significant iterate's chi2 to 1e-5 -- the numeric Jacobians (central
+    differences, delta = 1e-9) amplify the last-bit differences between two compilations of the same formula by 1e9, which is
+    the 4e-7 seen in chi2 after the first iteration; the restated classes, compiled in one unit with the solver, hold 1e-8."""
+    inc = ["-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "tests", "eigen_stub"),
+           "-I" + os.path.join(ROOT, "tests", "ref_stub"), "-I" + os.path.join(REF, "sparse_gslam", "include"),
+           "-I" + os.path.join(REF, "ls_extractor", "include")]
+    objs = []
+    for name in ("edge_se2_rhotheta", "vertex_rhotheta"):
+        o = str(tmp_path / (name + ".o"))
+        subprocess.check_call(["g++", "-std=c++14", "-O2", "-c", os.path.join(REF, "sparse_gslam", "src", "g2o_bindings", name + ".cpp"),
+                               "-o", o] + inc)
+        objs.append(o)
+    chk = str(tmp_path / "ref_sources_check")
+    link = ["-L" + os.path.join(ROOT, "sparse_gslam_amd", "csrc"), "-lsgo", "-L/opt/rocm/lib",
+            "-Wl,-rpath," + os.path.join(ROOT, "sparse_gslam_amd", "csrc"), "-Wl,-rpath,/opt/rocm/lib"]
+    subprocess.check_call(["g++", "-std=c++14", "-O2", os.path.join(CPP, "ref_sources_check.cpp")] + objs + inc + link + ["-o", chk])
+    r = subprocess.run([chk], capture_output=True, text=True)
+    assert r.returncode == 0 and float(r.stdout.split()[0]) <= 1e-13, r.stdout + r.stderr
+    exe = str(tmp_path / "landmark_ref")
+    subprocess.check_call(["g++", "-std=c++14", "-O2", "-DSGO_REF_SOURCES", os.path.join(CPP, "landmark_rhotheta.cpp")] + objs + inc +
+                          ["-L" + os.path.join(ROOT, "sparse_gslam_amd", "csrc"), "-lsgo", "-L/opt/rocm/lib",
+                           "-Wl,-rpath," + os.path.join(ROOT, "sparse_gslam_amd", "csrc"), "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    out = subprocess.run([exe, os.path.join(GOLD, "lm_landmark_graph.txt")], capture_output=True, text=True, check=True).stdout.splitlines()
+    gold = json.load(open(os.path.join(GOLD, "lm_landmark.json")))
+    stages = []
+    for line in out:
+        tok = line.split()
+        if tok[0] == "STAGE":
+            stages.append(dict(iterations=int(tok[1]), chi2=float(tok[2]), trace=[]))
+        elif tok[0] == "IT":
+            stages[-1]["trace"].append(dict(lam=float(tok[1]), chi2=float(tok[2]), trials=int(tok[3])))
+    assert len(stages) == 2
+    for s, gs in zip(stages, gold["stages"]):
+        sig = _significant(gs["trace"])
+        for k, gt in enumerate(sig):
+            st = s["trace"][k]
+            assert abs(st["chi2"] - gt["chi2"]) <= 1e-5 * gt["chi2"], (k, st, gt)
+            if k == 0:
+                assert abs(st["lam"] - gt["lam"]) <= 1e-6 * gt["lam"] and st["trials"] == gt["trials"], (st, gt)
+        assert abs(s["chi2"] - gs["chi2"]) <= 1e-5 * gs["chi2"]
