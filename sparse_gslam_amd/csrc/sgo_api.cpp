@@ -132,8 +132,9 @@ const char* sgo_solver_description(sgo_ctx* c) {
     c->solver_text = c->solver_desc;
     if (!c->direct && !c->direct_why.empty()) c->solver_text += "; direct path not used: " + c->direct_why;
     if (c->ov.active)
-      c->solver_text += "; incremental overlay: " + std::to_string(c->ov.dev.k) + " appended rows, " + std::to_string(c->ov.dev.nt) +
-                        " touched rows, " + std::to_string(c->ov.dev.el.cnt) + " appended edges (" + std::to_string(c->ov.updates) + " updates)";
+      c->solver_text += "; incremental overlay: " + std::to_string(c->ov.new_vertex.size()) + " appended rows (" + std::to_string(c->ov.dev.nx) +
+                        " hubs), " + std::to_string(c->ov.dev.nt) + " touched rows, " + std::to_string(c->ov.dev.el.cnt) + " appended edges (" +
+                        std::to_string(c->ov.updates) + " updates)";
     if (!c->update_note.empty()) c->solver_text += "; last update: " + c->update_note;
     return c->solver_text.c_str();
   } catch (...) {   // no C++ exception crosses the C boundary
@@ -305,7 +306,7 @@ int sgo_update_graph_se2(sgo_ctx* c, int32_t V, const double* poses, const uint8
       }
       lap("poses + sync");
       if (ok) {
-        ov.active = ov.dev.k + ov.dev.nt > 0;
+        ov.active = ov.dev.k + ov.dev.nt + ov.dev.nx > 0;
         ov.updates++;
         c->V = V;
         c->E = E;
@@ -314,8 +315,8 @@ int sgo_update_graph_se2(sgo_ctx* c, int32_t V, const double* poses, const uint8
         c->setup_seconds = wall_s() - t0;
         c->update_note = "incremental (" + std::to_string(dE) + " edges appended in " + std::to_string(1e3 * c->setup_seconds).substr(0, 5) + " ms)";
         if (c->opts.verbose)
-          std::fprintf(stderr, "[sgo] update_graph: %d edges / %d vertices appended as overlay (%d rows, %d touched) in %.2f ms\n", dE,
-                       V - (int)old_fixed.size(), ov.dev.k, ov.dev.nt, 1e3 * c->setup_seconds);
+          std::fprintf(stderr, "[sgo] update_graph: %d edges / %d vertices appended as overlay (%d chain rows, %d hubs, %d touched) in %.2f ms\n", dE,
+                       V - (int)old_fixed.size(), ov.dev.k, ov.dev.nx, ov.dev.nt, 1e3 * c->setup_seconds);
         return SGO_OK;
       }
       ov.ei.resize(old_ne);
@@ -357,7 +358,7 @@ int sgo_get_poses(sgo_ctx* c, double* poses) {
 
 int sgo_num_free(sgo_ctx* c) {
   int rc = check_graph(c);
-  return rc ? rc : c->n + (c->ov.active ? c->ov.dev.k : 0);
+  return rc ? rc : c->n + (c->ov.active ? (int)c->ov.new_vertex.size() : 0);
 }
 
 int sgo_free_ids(sgo_ctx* c, int32_t* out) {
@@ -365,9 +366,9 @@ int sgo_free_ids(sgo_ctx* c, int32_t* out) {
     int rc = check_graph(c);
     if (rc) return rc;
     if (!out) return SGO_EINVAL;
-    if (c->ov.active && c->ov.dev.k > 0) {   // g2o's hessian order over the resident and the appended free poses
+    if (c->ov.active && !c->ov.new_vertex.empty()) {   // g2o's hessian order over the resident and the appended free poses
       std::merge(c->free_id.begin(), c->free_id.end(), c->ov.new_vertex.begin(), c->ov.new_vertex.end(), out);
-      return c->n + c->ov.dev.k;
+      return c->n + (int)c->ov.new_vertex.size();
     }
     std::copy(c->free_id.begin(), c->free_id.end(), out);
     return c->n;

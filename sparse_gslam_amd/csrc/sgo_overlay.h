@@ -4,8 +4,11 @@
 // The reference calls initializeOptimization(); optimize(20) after every accepted loop closure on the previous graph +
 // a chain of new poses with their odometry edges + one closure (src/sparse_gslam/src/submap_loop_closer.cpp:205-226,
 // :272-287).  The appended part is kept beside the resident ("base") structures as an overlay:
-//   * new rows N  -- the appended free poses; the edges among them must form a chain in pose order (block-tridiagonal
+//   * new rows N  -- the appended free poses; the edges among consecutive ones form a chain in pose order (block-tridiagonal
 //     H_NN), which is what slc.cpp:205-226 appends;
+//   * hub rows X  -- appended poses with an edge to a NON-neighbouring appended pose (a closure that ends in a pose of an
+//     earlier update, slc.cpp:279): one endpoint of every such edge is taken out of the chain, which leaves N a set of chain
+//     segments; the hubs are eliminated after them from the small dense Schur complement;
 //   * touched rows T -- the base rows an appended edge ends in (the chain's anchor, the closure's old endpoint).
 // With x = [x_O; x_N] the Gauss-Newton system is solved EXACTLY as
 //     S x_O = g,   S = H_OO - H_ON H_NN^-1 H_NO,   g = b_O - H_ON H_NN^-1 b_N,   x_N = H_NN^-1 (b_N - H_NO x_O)
@@ -29,14 +32,15 @@
 namespace sgo {
 
 constexpr int kOvMaxRows = 512;      // new rows (poses of the appended chain)
-constexpr int kOvMaxTouched = 16;    // touched base rows
+constexpr int kOvMaxTouched = 16;    // touched base rows + hub rows
 constexpr int kOvMaxEdges = 4096;    // appended edges
 constexpr int kOvMaxVerts = 4096;    // appended vertices (active or not)
 constexpr int kOvOtherFixed = -(1 << 30);   // entry code: the edge's other endpoint is fixed (no block)
 
 struct OverlayDev {
-  int k = 0, nt = 0, ncol = 1;       // new rows, touched rows, right-hand-side columns 3 nt + 1
-  int nnz = 0;                       // new rows with a block into a touched row
+  int k = 0, nt = 0, ncol = 1;       // chain rows, touched base rows, right-hand-side columns 3 (nt + nx) + 1
+  int nnz = 0;                       // chain rows with a block into a touched or hub row
+  int nx = 0;                        // hub rows (numbered nt .. nt + nx - 1 among the "kept" rows K = T u X)
   EdgeListDev el;                    // appended edges (capacity kOvMaxEdges, el.cnt valid)
   // structure (host-made per update)
   const int* hdr = nullptr;          // [4] = {k, nt, ncol, nnz} on the device (k_ov_ax reads its sizes here: a captured hipGraph stays valid)
@@ -44,7 +48,7 @@ struct OverlayDev {
   const int* ent_edge = nullptr;     // entry: index into el
   const int* ent_other = nullptr;    // entry: other endpoint: >= 0 new row, -1 - t touched row t, kOvOtherFixed
   const unsigned char* ent_side = nullptr;   // entry: 0 = this row is vertices()[0] (Jacobian A), 1 = vertices()[1] (B)
-  const int* vtx = nullptr;          // [k + nt] vertex id of the overlay row
+  const int* vtx = nullptr;          // [k + nx] vertex id of the chain rows, then of the hub rows
   const int* trow = nullptr;         // [nt] base row of touched row t
   const int* nz = nullptr;           // [nnz] the new rows with a block into a touched row
   // values (per Gauss-Newton iteration)
@@ -53,9 +57,12 @@ struct OverlayDev {
   double* H0 = nullptr;              // [3 k][ncol] row-major: [H_NT | b_N]
   double* Y = nullptr;               // [3 k][ncol] H_NN^-1 [H_NT | b_N]
   double* Sinv = nullptr;            // [k][6]  inverses of the pivot blocks
-  double* M0 = nullptr;              // [3 nt][3 nt] appended edges' direct contributions to the touched rows
-  double* bt = nullptr;              // [3 nt]       ... to their right-hand side
-  double* M = nullptr;               // [3 nt][3 nt] M0 - H_TN H_NN^-1 H_NT, symmetrised
+  double* M0 = nullptr;              // [3 nk][3 nk] appended edges' direct contributions to the kept rows (nk = nt + nx)
+  double* bt = nullptr;              // [3 nk]       ... to their right-hand side
+  double* S = nullptr;               // [3 nk][3 nk] M0 - H_KN H_NN^-1 H_NK, symmetrised; gk [3 nk] the matching right-hand side
+  double* gk = nullptr;
+  double* Wx = nullptr;              // [3 nx][3 nt + 1] S_XX^-1 [S_XT | g_X]: the hubs' back-substitution
+  double* M = nullptr;               // [3 nt][3 nt] S_TT - S_TX S_XX^-1 S_XT, symmetrised: the operator's term on the touched rows
 };
 
 // Host state of the overlay (lives in the context)

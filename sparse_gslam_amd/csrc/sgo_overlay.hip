@@ -76,7 +76,7 @@ __device__ __forceinline__ void ov_edge_terms(const EdgeListDev& el, int e, int 
 //   touched row t: M0 rows 3t..3t+2 (its own diagonal contribution and blocks towards other touched rows), bt
 __global__ __launch_bounds__(kOvThreads) void k_ov_lin(OverlayDev O, const double* __restrict__ poses) {
   const int r = blockIdx.x * kOvThreads + threadIdx.x;
-  const int k = O.k, nt = O.nt, nc = O.ncol, nt3 = 3 * nt;
+  const int k = O.k, nt = O.nt + O.nx, nc = O.ncol, nt3 = 3 * nt;   // (nt: the kept rows -- touched base rows, then hubs)
   if (r >= k + nt) return;
   double D[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
   if (r < k) {
@@ -150,10 +150,10 @@ __device__ __forceinline__ bool sym3_inverse(const double (&d)[6], double (&v)[6
 __global__ __launch_bounds__(kOvThreads) void k_ov_solve(OverlayDev O, double* __restrict__ dgb) {
   __shared__ double Yt[3 * kOvTile * kOvCols];
   __shared__ double Dt[kOvTile * 6], Ut[kOvTile * 9], Sv[kOvTile * 6];
-  __shared__ int fail;
+  __shared__ int fail, bad_x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int k = O.k, nc = O.ncol, nt3 = 3 * O.nt;
-  if (tid == 0) fail = 0;
+  const int k = O.k, nc = O.ncol, nk3 = 3 * (O.nt + O.nx);
+  if (tid == 0) fail = bad_x = 0;
   __syncthreads();
   // ---- forward elimination
   double sp[6] = {0, 0, 0, 0, 0, 0}, up[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, rpv[3] = {0, 0, 0};
@@ -235,10 +235,10 @@ __global__ __launch_bounds__(kOvThreads) void k_ov_solve(OverlayDev O, double* _
     for (int i = tid; i < 3 * rows * nc; i += kOvThreads) O.Y[(size_t)3 * t0 * nc + i] = Yt[i];
     __syncthreads();
   }
-  // ---- M = sym(M0 - H_TN Y), g = bt - H_TN y_b  (H_TN = H_NT^T: only the rows listed in nz carry blocks)
+  // ---- S = sym(M0 - H_KN Y), gk = bt - H_KN y_b over the kept rows K (H_KN = H_NK^T: only the rows listed in nz carry blocks)
   const bool bad = fail != 0;
-  for (int idx = tid; idx < nt3 * (nt3 + 1); idx += kOvThreads) {
-    const int a = idx / (nt3 + 1), bcol = idx % (nt3 + 1);
+  for (int idx = tid; idx < nk3 * (nk3 + 1); idx += kOvThreads) {
+    const int a = idx / (nk3 + 1), bcol = idx % (nk3 + 1);
     double s1 = 0.0, s2 = 0.0;
     for (int z = 0; z < O.nnz; ++z) {
       const size_t base = (size_t)3 * O.nz[z] * nc;
@@ -247,18 +247,63 @@ __global__ __launch_bounds__(kOvThreads) void k_ov_solve(OverlayDev O, double* _
         const double* h = O.H0 + base + (size_t)q * nc;
         const double* y = O.Y + base + (size_t)q * nc;
         s1 += h[a] * y[bcol];
-        if (bcol < nt3) s2 += h[bcol] * y[a];
+        if (bcol < nk3) s2 += h[bcol] * y[a];
       }
     }
-    if (bcol < nt3) {
-      const double mab = O.M0[a * nt3 + bcol] - s1, mba = O.M0[bcol * nt3 + a] - s2;
-      O.M[a * nt3 + bcol] = 0.5 * (mab + mba);
+    if (bcol < nk3) {
+      const double mab = O.M0[a * nk3 + bcol] - s1, mba = O.M0[bcol * nk3 + a] - s2;
+      O.S[a * nk3 + bcol] = 0.5 * (mab + mba);
     } else {
-      const double g = bad ? __builtin_nan("") : O.bt[a] - s1;
+      O.gk[a] = O.bt[a] - s1;
+    }
+  }
+  __syncthreads();
+  // ---- the hubs: G = [S_XX | S_XT | g_X] -> S_XX^-1 [...] by Gauss-Jordan (SPD, no pivoting) in LDS, one lane per column
+  const int nt3 = 3 * O.nt, nx3 = 3 * O.nx, gw = nx3 + nt3 + 1;
+  double* G = Yt;   // (the chain's tiles are done with it)
+  if (nx3 > 0) {
+    for (int e = tid; e < nx3 * gw; e += kOvThreads) {
+      const int r2 = e / gw, c2 = e % gw;
+      G[e] = c2 < nx3 ? O.S[(nt3 + r2) * nk3 + nt3 + c2] : (c2 < nx3 + nt3 ? O.S[(nt3 + r2) * nk3 + (c2 - nx3)] : O.gk[nt3 + r2]);
+    }
+    __syncthreads();
+    if (wave == 0) {
+      // reduced row echelon form of [S_XX | S_XT | g_X]: lane c owns column c.  Within a step every lane reads what it needs
+      // of the pivot row / the pivot column's factor before the instruction that overwrites it (one instruction stream).
+      for (int pv = 0; pv < nx3; ++pv) {
+        const double piv = G[pv * gw + pv];
+        if (lane == 0 && (!(piv > 0.0) || !isfinite(piv))) bad_x = 1;
+        const double ip = piv != 0.0 ? 1.0 / piv : 0.0;
+        const double prow = lane < gw ? G[pv * gw + lane] * ip : 0.0;
+        for (int r2 = 0; r2 < nx3; ++r2) {
+          if (r2 == pv) continue;
+          const double f = G[r2 * gw + pv];
+          if (lane < gw) G[r2 * gw + lane] -= f * prow;
+        }
+        if (lane < gw) G[pv * gw + lane] = prow;
+      }
+      // W = S_XX^-1 [S_XT | g_X] sits in the columns nx3 .. gw-1
+      for (int e = lane; e < nx3 * (nt3 + 1); e += 64) O.Wx[e] = G[(e / (nt3 + 1)) * gw + nx3 + e % (nt3 + 1)];
+    }
+    __syncthreads();
+  }
+  const bool failed = bad || bad_x != 0;
+  // ---- M = sym(S_TT - S_TX W_T) on the touched rows, g_T = gk_T - S_TX W_g into the right-hand sides of dgb
+  for (int idx = tid; idx < nt3 * (nt3 + 1); idx += kOvThreads) {
+    const int a = idx / (nt3 + 1), bcol = idx % (nt3 + 1);
+    double s1 = 0.0, s2 = 0.0;
+    for (int r2 = 0; r2 < nx3; ++r2) {
+      s1 += O.S[a * nk3 + nt3 + r2] * G[r2 * gw + nx3 + bcol];
+      if (bcol < nt3) s2 += O.S[bcol * nk3 + nt3 + r2] * G[r2 * gw + nx3 + a];
+    }
+    if (bcol < nt3) {
+      O.M[a * nt3 + bcol] = 0.5 * ((O.S[a * nk3 + bcol] - s1) + (O.S[bcol * nk3 + a] - s2));
+    } else {
+      const double g = failed ? __builtin_nan("") : O.gk[a] - s1;
       dgb[9 * (size_t)O.trow[a / 3] + 6 + a % 3] += g;
     }
   }
-  if (bad && tid == 0) dgb[6] = __builtin_nan("");   // (also when no resident row is touched: the solve must report the failure)
+  if (failed && tid == 0) dgb[6] = __builtin_nan("");   // (also when no resident row is touched: the solve must report the failure)
 }
 
 // ---------------------------------------------------------------------------- k_ov_ax
@@ -291,19 +336,32 @@ __global__ __launch_bounds__(64) void k_ov_ax(const int* __restrict__ hdr, const
 }
 
 // ---------------------------------------------------------------------------- k_ov_finish
-// x_N = y_b - Y_T x_T, then VertexSE2::oplusImpl on the new poses.
+// x_X = W_g - W_T x_T (hubs), x_N = y_b - Y_K [x_T; x_X] (chain rows), then VertexSE2::oplusImpl on the appended poses.
 __global__ __launch_bounds__(kOvThreads) void k_ov_finish(OverlayDev O, const double* __restrict__ x, double* __restrict__ poses) {
-  __shared__ double xt[3 * kOvMaxTouched];
-  const int nt3 = 3 * O.nt, nc = O.ncol;
-  if ((int)threadIdx.x < nt3) xt[threadIdx.x] = x[3 * (size_t)O.trow[threadIdx.x / 3] + threadIdx.x % 3];
+  __shared__ double xk[3 * kOvMaxTouched];
+  const int nt3 = 3 * O.nt, nx3 = 3 * O.nx, nk3 = nt3 + nx3, nc = O.ncol, t = threadIdx.x;
+  if (t < nt3) xk[t] = x[3 * (size_t)O.trow[t / 3] + t % 3];
   __syncthreads();
-  for (int i = blockIdx.x * kOvThreads + threadIdx.x; i < O.k; i += gridDim.x * kOvThreads) {
+  if (t < nx3) {
+    const double* w = O.Wx + (size_t)t * (nt3 + 1);
+    double v = w[nt3];
+    for (int c2 = 0; c2 < nt3; ++c2) v -= w[c2] * xk[c2];
+    xk[nt3 + t] = v;
+  }
+  __syncthreads();
+  if (blockIdx.x == 0 && t < O.nx) {   // the hubs' poses
+    const size_t v3 = 3 * (size_t)O.vtx[O.k + t];
+    poses[v3] += xk[nt3 + 3 * t];
+    poses[v3 + 1] += xk[nt3 + 3 * t + 1];
+    poses[v3 + 2] = norm_theta(poses[v3 + 2] + xk[nt3 + 3 * t + 2]);
+  }
+  for (int i = blockIdx.x * kOvThreads + t; i < O.k; i += gridDim.x * kOvThreads) {
     double xn[3];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
       const double* y = O.Y + (size_t)(3 * i + a) * nc;
-      double v = y[nt3];
-      for (int c2 = 0; c2 < nt3; ++c2) v -= y[c2] * xt[c2];
+      double v = y[nk3];
+      for (int c2 = 0; c2 < nk3; ++c2) v -= y[c2] * xk[c2];
       xn[a] = v;
     }
     const size_t v3 = 3 * (size_t)O.vtx[i];
@@ -316,17 +374,17 @@ __global__ __launch_bounds__(kOvThreads) void k_ov_finish(OverlayDev O, const do
 }  // namespace
 
 void launch_ov_lin(hipStream_t s, const OverlayDev& O, const double* poses) {
-  const int rows = O.k + O.nt;
+  const int rows = O.k + O.nt + O.nx;
   if (rows > 0) SGO_LAUNCH(k_ov_lin, dim3((rows + kOvThreads - 1) / kOvThreads), dim3(kOvThreads), 0, s, O, poses);
 }
 void launch_ov_solve(hipStream_t s, const OverlayDev& O, double* dgb) {
-  if (O.k + O.nt > 0) SGO_LAUNCH(k_ov_solve, dim3(1), dim3(kOvThreads), 0, s, O, dgb);
+  if (O.k + O.nt + O.nx > 0) SGO_LAUNCH(k_ov_solve, dim3(1), dim3(kOvThreads), 0, s, O, dgb);
 }
 void launch_ov_ax(hipStream_t s, const OverlayDev& O, const double* p, double* q, double* partials0, const PcgScalars* S) {
   SGO_LAUNCH(k_ov_ax, dim3(1), dim3(64), 0, s, O.hdr, O.trow, (const double*)O.M, p, q, partials0, S);
 }
 void launch_ov_finish(hipStream_t s, const OverlayDev& O, const double* x, double* poses) {
-  if (O.k > 0) SGO_LAUNCH(k_ov_finish, dim3((O.k + kOvThreads - 1) / kOvThreads), dim3(kOvThreads), 0, s, O, x, poses);
+  if (O.k + O.nx > 0) SGO_LAUNCH(k_ov_finish, dim3(std::max(1, (O.k + kOvThreads - 1) / kOvThreads)), dim3(kOvThreads), 0, s, O, x, poses);
 }
 
 // ---------------------------------------------------------------------------- host side
@@ -337,10 +395,10 @@ void launch_ov_finish(hipStream_t s, const OverlayDev& O, const double* x, doubl
 namespace {
 struct Layout {
   size_t i_hdr, i_rp, i_edge, i_other, i_vtx, i_trow, i_nz, i_vi, i_vj, n_int;
-  size_t d_phi, d_zinv, d_info, d_raw, d_Dn, d_Un, d_H0, d_Y, d_Sinv, d_M0, d_bt, d_M, n_dbl;
+  size_t d_phi, d_zinv, d_info, d_raw, d_Dn, d_Un, d_H0, d_Y, d_Sinv, d_M0, d_bt, d_M, d_S, d_gk, d_Wx, n_dbl;
   Layout() {
     size_t o = 0;
-    i_hdr = o; o += 4;
+    i_hdr = o; o += 8;
     i_rp = o; o += kOvMaxRows + kOvMaxTouched + 1;
     i_edge = o; o += 2 * kOvMaxEdges;
     i_other = o; o += 2 * kOvMaxEdges;
@@ -365,6 +423,9 @@ struct Layout {
     d_M0 = o; o += (size_t)(kOvCols - 1) * (kOvCols - 1);
     d_bt = o; o += kOvCols;
     d_M = o; o += (size_t)(kOvCols - 1) * (kOvCols - 1);
+    d_S = o; o += (size_t)(kOvCols - 1) * (kOvCols - 1);
+    d_gk = o; o += kOvCols;
+    d_Wx = o; o += (size_t)(kOvCols - 1) * kOvCols;
     n_dbl = o;
   }
   size_t int_total() const { return i_vj + kOvMaxEdges; }
@@ -419,6 +480,9 @@ static bool overlay_alloc(Overlay& ov, std::string* err) {
   O.M0 = d + L.d_M0;
   O.bt = d + L.d_bt;
   O.M = d + L.d_M;
+  O.S = d + L.d_S;
+  O.gk = d + L.d_gk;
+  O.Wx = d + L.d_Wx;
   return true;
 }
 
@@ -466,34 +530,55 @@ bool overlay_build(Overlay& ov, int V, hipStream_t s, std::string* why, std::str
   nv.erase(std::unique(nv.begin(), nv.end()), nv.end());
   std::sort(tr.begin(), tr.end());
   tr.erase(std::unique(tr.begin(), tr.end()), tr.end());
-  const int k = (int)nv.size(), nt = (int)tr.size();
-  if (k > kOvMaxRows) { *why = "more appended poses than the overlay holds"; return false; }
-  if (nt > kOvMaxTouched) { *why = "the appended edges end in more resident rows than the overlay holds"; return false; }
-  auto code = [&](int v) -> int {   // >= 0 new row, -1 - t touched row, kOvOtherFixed
+  const int nnew = (int)nv.size(), nt = (int)tr.size();
+  auto new_idx = [&](int v) { return (int)(std::lower_bound(nv.begin(), nv.end(), v) - nv.begin()); };
+  // hubs: an edge between two appended poses that are not neighbours in the chain takes its later endpoint out of the chain
+  std::vector<char> is_hub((size_t)nnew, 0);
+  for (int e = 0; e < ne; ++e) {
+    const int a2 = ov.ei[e], b2 = ov.ej[e];
+    if (ov.fixed[a2] || ov.fixed[b2] || base_row(a2) >= 0 || base_row(b2) >= 0) continue;
+    const int ia = new_idx(a2), ib = new_idx(b2);
+    if (std::abs(ia - ib) != 1 && !is_hub[ia] && !is_hub[ib]) is_hub[std::max(ia, ib)] = 1;
+  }
+  std::vector<int> chain_pos((size_t)nnew, -1), hub_pos((size_t)nnew, -1), chain_v, hub_v;
+  for (int i = 0; i < nnew; ++i) {
+    if (is_hub[i]) {
+      hub_pos[i] = (int)hub_v.size();
+      hub_v.push_back(nv[i]);
+    } else {
+      chain_pos[i] = (int)chain_v.size();
+      chain_v.push_back(nv[i]);
+    }
+  }
+  const int k = (int)chain_v.size(), nx = (int)hub_v.size(), nk = nt + nx;
+  if (nnew > kOvMaxRows) { *why = "more appended poses than the overlay holds"; return false; }
+  if (nk > kOvMaxTouched) { *why = "the appended edges end in more resident rows (and hub poses) than the overlay holds"; return false; }
+  auto code = [&](int v) -> int {   // >= 0 chain row, -1 - t kept row t (touched base rows, then hubs), kOvOtherFixed
     if (ov.fixed[v]) return kOvOtherFixed;
     const int br = base_row(v);
     if (br >= 0) return -1 - (int)(std::lower_bound(tr.begin(), tr.end(), br) - tr.begin());
-    return (int)(std::lower_bound(nv.begin(), nv.end(), v) - nv.begin());
+    const int i = new_idx(v);
+    return is_hub[i] ? -1 - (nt + hub_pos[i]) : chain_pos[i];
   };
   const Layout& L = layout();
   int* hi = ov.h_int;              // (the stream was drained by the caller: the previous update's copy has long finished)
   unsigned char* hs = ov.h_side;
   int* rp = hi + L.i_rp;
   std::vector<int> ca(ne), cb(ne);
-  std::vector<int> cntr((size_t)k + nt + 1, 0);
+  std::vector<int> cntr((size_t)k + nk + 1, 0);
   auto rowof = [&](int c) { return c >= 0 ? c : k + (-1 - c); };
   for (int e = 0; e < ne; ++e) {
     ca[e] = code(ov.ei[e]);
     cb[e] = code(ov.ej[e]);
     if (ca[e] >= 0 && cb[e] >= 0 && std::abs(ca[e] - cb[e]) != 1) {
-      *why = "appended edges among the new poses do not form a chain";
+      *why = "appended edges among the new poses do not form chain segments";   // (cannot happen: such an edge has a hub endpoint)
       return false;
     }
     if (ca[e] == kOvOtherFixed && cb[e] == kOvOtherFixed) continue;   // (never active: the marshal layer drops such edges)
     if (ca[e] != kOvOtherFixed) cntr[rowof(ca[e]) + 1]++;
     if (cb[e] != kOvOtherFixed) cntr[rowof(cb[e]) + 1]++;
   }
-  for (int r = 0; r < k + nt; ++r) cntr[r + 1] += cntr[r];
+  for (int r = 0; r < k + nk; ++r) cntr[r + 1] += cntr[r];
   std::copy(cntr.begin(), cntr.end(), rp);
   std::vector<int> fill(cntr.begin(), cntr.end() - 1);
   int* ent_edge = hi + L.i_edge;
@@ -509,8 +594,9 @@ bool overlay_build(Overlay& ov, int V, hipStream_t s, std::string* why, std::str
     }
   }
   int* vtx = hi + L.i_vtx;
-  for (int i = 0; i < k; ++i) vtx[i] = nv[i];
-  // (vertex ids of the touched rows are not needed: their poses are read through the edges' endpoints)
+  for (int i = 0; i < k; ++i) vtx[i] = chain_v[i];
+  for (int j = 0; j < nx; ++j) vtx[k + j] = hub_v[j];
+  // (vertex ids of the touched base rows are not needed: their poses are read through the edges' endpoints)
   int* trow = hi + L.i_trow;
   for (int t = 0; t < nt; ++t) trow[t] = tr[t];
   int nnz = 0;
@@ -520,16 +606,16 @@ bool overlay_build(Overlay& ov, int V, hipStream_t s, std::string* why, std::str
     for (int t = rp[i]; t < rp[i + 1]; ++t) any = any || (ent_other[t] < 0 && ent_other[t] != kOvOtherFixed);
     if (any) nz[nnz++] = i;
   }
-  hi[L.i_hdr] = k; hi[L.i_hdr + 1] = nt; hi[L.i_hdr + 2] = 3 * nt + 1; hi[L.i_hdr + 3] = nnz;
+  hi[L.i_hdr] = k; hi[L.i_hdr + 1] = nt; hi[L.i_hdr + 2] = 3 * nk + 1; hi[L.i_hdr + 3] = nnz; hi[L.i_hdr + 4] = nx;
   // only what is used travels: header + row pointers, the entries, vertex / row lists
-  const size_t nent = (size_t)cntr[(size_t)k + nt];
-  hipError_t e1 = hipMemcpyAsync(ov.d_int, hi, sizeof(int) * (L.i_rp + (size_t)k + nt + 1), hipMemcpyHostToDevice, s);
+  const size_t nent = (size_t)cntr[(size_t)k + nk];
+  hipError_t e1 = hipMemcpyAsync(ov.d_int, hi, sizeof(int) * (L.i_rp + (size_t)k + nk + 1), hipMemcpyHostToDevice, s);
   auto up = [&](size_t at, size_t cnt) {
     if (e1 == hipSuccess && cnt > 0) e1 = hipMemcpyAsync(ov.d_int + at, hi + at, sizeof(int) * cnt, hipMemcpyHostToDevice, s);
   };
   up(L.i_edge, nent);
   up(L.i_other, nent);
-  up(L.i_vtx, (size_t)k);
+  up(L.i_vtx, (size_t)k + nx);
   up(L.i_trow, (size_t)nt);
   up(L.i_nz, (size_t)nnz);
   if (e1 == hipSuccess && nent > 0) e1 = hipMemcpyAsync(ov.d_side, hs, nent, hipMemcpyHostToDevice, s);
@@ -539,7 +625,7 @@ bool overlay_build(Overlay& ov, int V, hipStream_t s, std::string* why, std::str
     return false;
   }
   OverlayDev& O = ov.dev;
-  O.k = k; O.nt = nt; O.ncol = 3 * nt + 1; O.nnz = nnz;
+  O.k = k; O.nt = nt; O.nx = nx; O.ncol = 3 * nk + 1; O.nnz = nnz;
   O.el.cnt = ne;
   ov.new_vertex = nv;
   (void)V;

@@ -88,7 +88,7 @@ void free_graph(sgo_ctx* c) {
   c->ov.new_vertex.clear();
   c->ov.hpos.clear();
   c->ov.updates = 0;
-  c->ov.dev.k = c->ov.dev.nt = c->ov.dev.nnz = 0;
+  c->ov.dev.k = c->ov.dev.nt = c->ov.dev.nnz = c->ov.dev.nx = 0;
   c->ov.dev.ncol = 1;
   c->ov.dev.el.cnt = 0;
   c->pcg_exec_key = 0;

@@ -65,13 +65,12 @@ def _session(V0, E0, nsteps, chain, seed, iters=8, oracle=False, **kw):
 
 def test_append_chain_and_closure_matches_fresh_setup_and_oracle():
     worst, descs, its = _session(3000, 12000, 5, 20, seed=3, oracle=True)
-    # the overlay accumulates over the first three closures; the fourth closure ends in a pose of an EARLIER update -- an edge
-    # among appended poses that is not a chain edge -- and the update falls back to the full set-up (saying so); the fifth
-    # starts a new overlay on the rebuilt structure
-    assert all("incremental overlay" in d for d in descs[:3]), descs
-    assert "60 appended rows, 3 touched rows" in descs[2], descs[2]
-    assert "full set-up (appended edges among the new poses do not form a chain)" in descs[3], descs[3]
-    assert "incremental overlay: 20 appended rows" in descs[4], descs[4]
+    # the overlay accumulates over all five closures; the fourth closure ends in a pose of an EARLIER update -- an edge among
+    # appended poses that is not a chain edge: its later endpoint becomes a hub, eliminated after the chain segments
+    assert all("incremental overlay" in d for d in descs), descs
+    assert "60 appended rows (0 hubs), 3 touched rows" in descs[2], descs[2]
+    assert "80 appended rows (1 hubs)" in descs[3], descs[3]
+    assert "100 appended rows (1 hubs)" in descs[4], descs[4]
     # the resident hierarchy preconditions the updated system about as well as a fresh one: a handful of iterations more
     assert all(a <= b + 8 for a, b in its), its
 
@@ -138,11 +137,16 @@ def test_edges_to_fixed_vertices_and_a_fixed_appended_pose():
     _one_update(mutate, True)
 
 
-def test_non_chain_edges_among_appended_poses_fall_back_to_the_full_setup():
+def test_non_chain_edges_among_appended_poses_become_hubs():
     def mutate(st, base):
-        _add_edge(st, base.V + 2, base.V + 9, phi=1.0)
-    desc, d = _one_update(mutate, False)
-    assert "do not form a chain" in desc
+        _add_edge(st, base.V + 2, base.V + 9, phi=1.0)       # a closure inside the appended chain: pose V+9 becomes a hub
+        _add_edge(st, base.V + 4, base.V + 12, phi=1.0)      # a second one, disjoint
+        _add_edge(st, base.V + 9, base.V + 12, phi=1.0)      # hub - hub
+        _add_edge(st, 0, base.V + 12, phi=1.0)               # hub - fixed vertex
+        _add_edge(st, 321, base.V + 9, phi=1.0)              # resident pose - hub
+        _add_edge(st, base.V + 12, base.V + 2, phi=1.0)      # hub - chain pose, reversed orientation
+    desc, d = _one_update(mutate, True)
+    assert "(2 hubs)" in desc, desc
 
 
 def test_changed_prefix_and_too_many_touched_rows_fall_back():
@@ -151,6 +155,14 @@ def test_changed_prefix_and_too_many_touched_rows_fall_back():
             _add_edge(st, base.V + 8, 50 + 37 * q, phi=1.0)
     desc, d = _one_update(mutate, False)
     assert "more resident rows" in desc
+
+    def mutate2(st, base):                         # nine disjoint closures inside the chain + the touched rows: over the 16 kept rows
+        for q in range(7):
+            _add_edge(st, base.V + q, base.V + q + 8, phi=1.0)
+        for q in range(10):
+            _add_edge(st, base.V + 3, 60 + 41 * q, phi=1.0)
+    desc, d = _one_update(mutate2, False)
+    assert "more resident rows (and hub poses)" in desc
     base, steps, g = synth.append_session(2500, 10000, 1, 16, 5)
     V, fixed, ei, ej, meas, info, phi = _cat(base, steps, 1)
     with capi.Optimizer(0, direct_rows=0) as o:
