@@ -70,7 +70,7 @@ def test_append_chain_and_closure_matches_fresh_setup_and_oracle():
     assert all("incremental overlay" in d for d in descs), descs
     assert "60 appended rows (0 hubs), 3 touched rows" in descs[2], descs[2]
     assert "80 appended rows (1 hubs)" in descs[3], descs[3]
-    assert "100 appended rows (1 hubs)" in descs[4], descs[4]
+    assert "100 appended rows (2 hubs)" in descs[4], descs[4]
     # the resident hierarchy preconditions the updated system about as well as a fresh one: a handful of iterations more
     assert all(a <= b + 8 for a, b in its), its
 
@@ -78,7 +78,7 @@ def test_append_chain_and_closure_matches_fresh_setup_and_oracle():
 def test_full_information_phi10_long_chains_and_two_closures_per_step():
     worst, descs, its = _session(6000, 30000, 4, 60, seed=11, info_mode="full", phi=10.0, closures_per_step=2)
     assert all("incremental overlay" in d for d in descs), descs
-    assert "240 appended rows, 9 touched rows" in descs[-1], descs[-1]
+    assert "240 appended rows (0 hubs), 9 touched rows" in descs[-1], descs[-1]
 
 
 def _one_update(mutate, expect_overlay, V0=2500, seed=5, iters=6):
