@@ -155,7 +155,7 @@ def reference_usage_session(device: int, V: int = 1000, closures: int = 30):
             "final_chi2_rel_err_vs_oracle_max": worst}
 
 
-def incremental_session(device: int, V: int, E: int, seed: int, steps: int = 12, chain: int = 25, iters: int = 20):
+def incremental_session(device: int, V: int, E: int, seed: int, steps: int = 12, chain: int = 25, iters: int = 20, compare: bool = True):
     """The reference's usage pattern at the BENCH workload's size (slc.cpp:205-226, :272-287): a resident graph of V poses /
     E edges, then `steps` accepted loop closures, each appending `chain` new poses with their odometry edges and one
     closure, re-initialising and running optimize(iters).  Through sgo_update_graph_se2 (the resident level-0 structure and
@@ -187,6 +187,9 @@ def incremental_session(device: int, V: int, E: int, seed: int, steps: int = 12,
             P = inc.get_poses()
             descs.append(inc.solver_description().split("; last update: ")[-1])
             t_up.append(1e3 * (t1 - t)); t_opt.append(1e3 * (t2 - t1)); its.append(float(np.mean(st["pcg_iters"])))
+            if not compare:
+                E_res = arrs[0].size
+                continue
             t = time.perf_counter()
             fresh.set_graph(P0, fixed, *arrs)
             t1 = time.perf_counter()
@@ -199,7 +202,9 @@ def incremental_session(device: int, V: int, E: int, seed: int, steps: int = 12,
             else:
                 worst = float("nan")
             E_res = arrs[0].size
-    med = lambda v: float(np.median(v))   # noqa: E731
+    med = lambda v: float(np.median(v)) if len(v) else None   # noqa: E731
+    if not compare:
+        return {"update_ms": [round(x, 3) for x in t_up], "optimize_ms_median": med(t_opt), "pcg_iters_per_gn_iter": its, "updates": descs}
     return {"workload": f"append_session(V={V}, E={E}, seed={seed}): {steps} closures, each {chain} new poses + odometry + 1 closure, "
                         f"optimize({iters}) after each",
             "update_ms_median": med(t_up), "update_ms_min_max": [float(min(t_up)), float(max(t_up))],

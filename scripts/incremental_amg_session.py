@@ -11,4 +11,5 @@ import bench  # noqa: E402
 if __name__ == "__main__":
     a = [int(x) for x in sys.argv[1:]]
     V, E, steps, chain, seed = (a + [100000, 1000000, 12, 25, 4][len(a):])[:5]
-    print(json.dumps(bench.incremental_session(0, V, E, seed, steps, chain), indent=1))
+    compare = os.environ.get("SGO_SESSION_COMPARE", "1") != "0"   # 0: without the fresh set-up beside every update
+    print(json.dumps(bench.incremental_session(0, V, E, seed, steps, chain, compare=compare), indent=1))

@@ -115,6 +115,7 @@ void sgo_destroy(sgo_ctx* c) {
   if (c->h_S) hipHostFree(c->h_S);
   if (c->h_S2) hipHostFree(c->h_S2);
   if (c->h_Sz) hipHostFree(c->h_Sz);
+  if (c->h_pose_stage) hipHostFree(c->h_pose_stage);
   for (hipEvent_t ev : c->ev_S)
     if (ev) hipEventDestroy(ev);
   if (c->h_hist) hipHostFree(c->h_hist);
@@ -282,6 +283,7 @@ int sgo_update_graph_se2(sgo_ctx* c, int32_t V, const double* poses, const uint8
       ov.fixed.assign(fixed, fixed + V);
       double tl = wall_s();
       auto lap = [&](const char* what) {
+        if (c->opts.verbose > 2) hipStreamSynchronize(c->stream);   // (diagnostic: charge the device time to the phase that queued it)
         const double t = wall_s();
         if (c->opts.verbose > 1) std::fprintf(stderr, "[sgo]   update %-16s %.3f ms\n", what, 1e3 * (t - tl));
         tl = t;
@@ -296,7 +298,7 @@ int sgo_update_graph_se2(sgo_ctx* c, int32_t V, const double* poses, const uint8
       lap("edge upload");
       if (ok) ok = overlay_build(ov, V, c->stream, &why, &c->err);
       lap("overlay build");
-      if (ok && hipMemcpyAsync(c->d_poses, poses, sizeof(double) * 3 * (size_t)V, hipMemcpyHostToDevice, c->stream) != hipSuccess) {
+      if (ok && upload_poses(c, poses, V) != SGO_OK) {
         ok = false;
         why = "pose upload failed";
       }
@@ -338,7 +340,7 @@ int sgo_set_poses(sgo_ctx* c, const double* poses) {
     int rc = check_graph(c);
     if (rc) return rc;
     if (!poses) return SGO_EINVAL;
-    HIP_TRY(c, hipMemcpyAsync(c->d_poses, poses, sizeof(double) * 3 * (size_t)c->V, hipMemcpyHostToDevice, c->stream));
+    if ((rc = upload_poses(c, poses, c->V))) return rc;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->linearized = false;
     return SGO_OK;

@@ -144,6 +144,8 @@ struct sgo_ctx {
   int amg_best = 0;               // fewest PCG iterations seen with the current hierarchy (0: none yet);
                                   // kept across optimize() calls so that a hierarchy adapted to other poses is noticed
   PcgScalars* h_S2 = nullptr;     // pinned [2]: pipelined read-back of the stop flag (plain launches)
+  double* h_pose_stage = nullptr; // pinned staging of the pose uploads (sgo_set_poses / sgo_update_graph_se2): a pageable source makes
+  size_t pose_stage_cap = 0;      // the runtime pin and unpin the caller's buffer per call -- 10-20 ms every few calls on fresh buffers
   PcgScalars* h_Sz = nullptr;     // pinned: the scalars as the last k_update_p left them (RecDev::mirror; hipGraph replay)
   PcgScalars* d_Sz = nullptr;     // ... its device address
   hipEvent_t ev_S[2] = {nullptr, nullptr};
@@ -315,6 +317,7 @@ constexpr int kTileDiv = 256;
 constexpr long long kSmallGraphPairs = 150000;   // below: the wave-group kernel instead of the tile kernel (sgo_plan.cpp)
 
 // ---- device-resident graph (sgo_structure.cpp) ----------------------------------------------
+int upload_poses(sgo_ctx* c, const double* poses, int V);   // through the pinned staging buffer; returns after the copy was queued AND the caller's array is no longer needed
 void l0_join(sgo_ctx* c, bool keep);
 inline void l0_discard(sgo_ctx* c) { l0_join(c, false); }
 void free_graph(sgo_ctx* c);

@@ -80,6 +80,7 @@ struct Overlay {
   unsigned char* d_side = nullptr;
   int* h_int = nullptr;                       // their pinned host images (a pageable source of this size makes the runtime pin and
   unsigned char* h_side = nullptr;            // unpin it per copy: 10-20 ms per update, measured)
+  double* h_edge = nullptr;                   // pinned staging of an update's appended edges: [10][kOvMaxEdges] doubles + 2 x ints
   int updates = 0;                            // updates absorbed since the base was built
 };
 

@@ -445,7 +445,9 @@ static bool overlay_alloc(Overlay& ov, std::string* err) {
     if (err) *err = "out of device memory (incremental set-up buffers)";
     return false;
   }
-  if (hipHostMalloc((void**)&ov.h_int, sizeof(int) * L.n_int + 2 * (size_t)kOvMaxEdges) != hipSuccess) {
+  if (hipHostMalloc((void**)&ov.h_int, sizeof(int) * L.n_int + 2 * (size_t)kOvMaxEdges) != hipSuccess ||
+      hipHostMalloc((void**)&ov.h_edge, (sizeof(double) * 10 + sizeof(int) * 2) * (size_t)kOvMaxEdges) != hipSuccess) {
+    if (ov.h_int) hipHostFree(ov.h_int);
     hipFree(ov.buf);
     ov.buf = nullptr;
     ov.h_int = nullptr;
@@ -489,6 +491,7 @@ static bool overlay_alloc(Overlay& ov, std::string* err) {
 void overlay_release(Overlay& ov) {
   if (ov.buf) hipFree(ov.buf);
   if (ov.h_int) hipHostFree(ov.h_int);
+  if (ov.h_edge) hipHostFree(ov.h_edge);
   ov = Overlay();
 }
 
@@ -499,11 +502,21 @@ bool overlay_upload_edges(Overlay& ov, hipStream_t s, int at, int cnt, const int
   const Layout& L = layout();
   double* d = (double*)ov.buf;
   double* raw = d + L.d_raw;
-  hipError_t e = hipMemcpyAsync(ov.dev.el.vi + at, ei, sizeof(int32_t) * (size_t)cnt, hipMemcpyHostToDevice, s);
-  if (e == hipSuccess) e = hipMemcpyAsync(ov.dev.el.vj + at, ej, sizeof(int32_t) * (size_t)cnt, hipMemcpyHostToDevice, s);
-  if (e == hipSuccess) e = hipMemcpyAsync(ov.dev.el.phi + at, phi, sizeof(double) * (size_t)cnt, hipMemcpyHostToDevice, s);
-  if (e == hipSuccess) e = hipMemcpyAsync(raw, meas, sizeof(double) * 3 * (size_t)cnt, hipMemcpyHostToDevice, s);
-  if (e == hipSuccess) e = hipMemcpyAsync(raw + 3 * (size_t)kOvMaxEdges, info, sizeof(double) * 6 * (size_t)cnt, hipMemcpyHostToDevice, s);
+  // through pinned staging (the caller has drained the stream: the previous update's copies have left it)
+  double* hm = ov.h_edge;                              // meas [3 cnt] | info [6 cnt] | phi [cnt] | ei, ej
+  double* hi6 = hm + 3 * (size_t)kOvMaxEdges;
+  double* hp = hi6 + 6 * (size_t)kOvMaxEdges;
+  int* hv = (int*)(hp + kOvMaxEdges);
+  std::memcpy(hm, meas, sizeof(double) * 3 * (size_t)cnt);
+  std::memcpy(hi6, info, sizeof(double) * 6 * (size_t)cnt);
+  std::memcpy(hp, phi, sizeof(double) * (size_t)cnt);
+  std::memcpy(hv, ei, sizeof(int32_t) * (size_t)cnt);
+  std::memcpy(hv + kOvMaxEdges, ej, sizeof(int32_t) * (size_t)cnt);
+  hipError_t e = hipMemcpyAsync(ov.dev.el.vi + at, hv, sizeof(int32_t) * (size_t)cnt, hipMemcpyHostToDevice, s);
+  if (e == hipSuccess) e = hipMemcpyAsync(ov.dev.el.vj + at, hv + kOvMaxEdges, sizeof(int32_t) * (size_t)cnt, hipMemcpyHostToDevice, s);
+  if (e == hipSuccess) e = hipMemcpyAsync(ov.dev.el.phi + at, hp, sizeof(double) * (size_t)cnt, hipMemcpyHostToDevice, s);
+  if (e == hipSuccess) e = hipMemcpyAsync(raw, hm, sizeof(double) * 3 * (size_t)cnt, hipMemcpyHostToDevice, s);
+  if (e == hipSuccess) e = hipMemcpyAsync(raw + 3 * (size_t)kOvMaxEdges, hi6, sizeof(double) * 6 * (size_t)cnt, hipMemcpyHostToDevice, s);
   if (e != hipSuccess) {
     if (err) *err = std::string("incremental set-up: edge upload: ") + hipGetErrorString(e);
     return false;

@@ -22,6 +22,32 @@ void l0_join(sgo_ctx* c, bool keep) {
   // (c->l0_w keeps its storage: a fresh 17-MB vector per call is 4000 page faults on the set-up's critical path)
 }
 
+int upload_poses(sgo_ctx* c, const double* poses, int V) {
+  const size_t cnt = 3 * (size_t)V;
+  if (cnt > c->pose_stage_cap) {
+    HIP_TRY(c, hipStreamSynchronize(c->stream));   // (an earlier copy may still read the old buffer)
+    if (c->h_pose_stage) hipHostFree(c->h_pose_stage);
+    c->h_pose_stage = nullptr;
+    c->pose_stage_cap = 0;
+    const size_t cap = cnt + cnt / 4 + 3 * (size_t)kOvMaxVerts;
+    if (hipHostMalloc((void**)&c->h_pose_stage, sizeof(double) * cap) != hipSuccess) {
+      c->h_pose_stage = nullptr;
+      c->err = "out of pinned host memory (pose staging)";
+      return SGO_ENOMEM;
+    }
+    c->pose_stage_cap = cap;
+  } else {
+    HIP_TRY(c, hipStreamSynchronize(c->stream));   // the previous upload has left the staging buffer
+  }
+  const double t0 = wall_s();
+  std::memcpy(c->h_pose_stage, poses, sizeof(double) * cnt);
+  const double t1 = wall_s();
+  HIP_TRY(c, hipMemcpyAsync(c->d_poses, c->h_pose_stage, sizeof(double) * cnt, hipMemcpyHostToDevice, c->stream));
+  if (c->opts.verbose > 1)
+    std::fprintf(stderr, "[sgo]   pose staging: host copy %.3f ms, queueing the upload %.3f ms\n", 1e3 * (t1 - t0), 1e3 * (wall_s() - t1));
+  return SGO_OK;
+}
+
 int halo_reserve(sgo_ctx* c, size_t packet_doubles) {
   // the receive buffer holds one packet per rank: it is remade when the packets grow AND when the communicator has
   // more ranks than the buffers were made for (a context may be given another communicator between graphs)
