@@ -84,8 +84,11 @@ def main():
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     iters = 4
     bad = 0
+    only = os.environ.get("OWNER_STRESS_ONLY")     # "pcg": only the block-Jacobi cases of the sequence
     for k in range(ncases):
         g, world, env, solver, label = make_case(k, seed)
+        if only and solver != only:
+            continue
         t0 = time.time()
         s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
         ctx = mp.get_context("spawn")
