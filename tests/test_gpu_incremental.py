@@ -210,3 +210,32 @@ def test_single_step_entry_points_refuse_an_overlay_and_set_poses_covers_all():
         c2 = o.chi2()
         assert abs(c1[0] - c2[0]) <= 1e-12 * c2[0] and abs(c1[1] - c2[1]) <= 1e-12 * c2[1]
         o.linearize()
+
+
+def test_update_that_only_adds_closures_between_resident_poses():
+    """no new pose at all (the loop closer matched two old submaps): the overlay is just the dense term on the touched rows"""
+    base, steps, g = synth.append_session(2500, 10000, 1, 16, 5)
+    rng = np.random.default_rng(2)
+    pairs = [(300, 1700), (42, 2400), (300, 1700)]
+    sig = np.array([synth.SIGMA_XY, synth.SIGMA_XY, synth.SIGMA_TH])
+    ei = np.concatenate([base.ei, np.array([p[0] for p in pairs], np.int32)])
+    ej = np.concatenate([base.ej, np.array([p[1] for p in pairs], np.int32)])
+    z = np.array([synth._rel(g.truth[[a]], g.truth[[b]])[0] + rng.standard_normal(3) * sig for a, b in pairs])
+    meas = np.concatenate([base.meas, z])
+    info = np.concatenate([base.info, np.tile(base.info[-1], (len(pairs), 1))])
+    phi = np.concatenate([base.phi, np.full(len(pairs), 1.0)])
+    with capi.Optimizer(0, direct_rows=0) as inc, capi.Optimizer(0, direct_rows=0) as fresh:
+        inc.set_graph(*base.arrays())
+        inc.optimize(4)
+        P0 = inc.get_poses()
+        inc.update_graph(P0, base.fixed, ei, ej, meas, info, phi, base.E)
+        desc = inc.solver_description()
+        d1, s1 = inc.optimize(6)
+        P1 = inc.get_poses()
+        fresh.set_graph(P0, base.fixed, ei, ej, meas, info, phi)
+        d2, s2 = fresh.optimize(6)
+        P2 = fresh.get_poses()
+    assert "incremental overlay: 0 appended rows (0 hubs), 4 touched rows, 3 appended edges" in desc, desc
+    assert d1 == d2 == 6
+    assert max(abs(a - b) / b for a, b in zip(s1["chi2"], s2["chi2"])) <= 1e-6
+    assert np.abs(P1 - P2).max() <= 1e-5
