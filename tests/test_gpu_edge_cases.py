@@ -163,7 +163,7 @@ def test_c99_example_runs(tmp_path):
                            "-Wl,-rpath," + capi.CSRC, "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)])
     out = subprocess.run([str(exe)], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert "iterations 10" in out.stdout
+    assert "iterations 10" in out.stdout and "after the update: iterations 10" in out.stdout
 
 
 def test_repeated_set_graph_and_optimize_do_not_leak_device_memory():
