@@ -16,6 +16,11 @@ and edge operands of its own contiguous range of rows only, does all level-0 wor
 rows + partial dot products in small all-gather packets; graphs whose rows are mostly boundary
 rows (random closures) keep every rank's copy whole and all-reduce the product vectors.  Total work is fixed =>
 "scaling": "strong".
+
+Beside `value` the line carries `roofline` (median-based, recomputable from profiles/: DESIGN.md section 4), `cpu_baseline`,
+`value_init_odom` (BASELINE.md's literal dead-reckoned start), `reference_usage_session` (the reference's flow at its own
+graph size: the single-launch direct path) and `incremental_session` (the reference's flow at the bench workload's size:
+sgo_update_graph_se2 per closure against a fresh sgo_set_graph_se2).
 """
 from __future__ import annotations
 
