@@ -247,7 +247,7 @@ double sgo_profile_overhead_ms(sgo_ctx* ctx);
  * of tiles sgo_shard_range(ntiles, nranks, r).  Two modes, chosen per graph (sgo_solver_description says which):
  *   row-owner mode  (at most a quarter of the rows have an edge into another rank's range -- spatially local closures): a rank
  *     holds the Hessian blocks and edge operands of ITS rows only and linearises, multiplies, smooths, restricts, prolongates and
- *     updates these rows; per PCG iteration it exchanges the boundary rows of three vectors and the partial sums of the dot
+ *     updates these rows; per PCG iteration it exchanges the boundary rows of two vectors and the partial sums of the dot
  *     products (fixed-size all-gather packets, reduced in rank order: bit-identical scalars on all ranks) and all-reduces the
  *     coarse right-hand side; per Gauss-Newton iteration the boundary rows of the smoothed prolongator and the step (for the
  *     replicated pose update) travel, and the level-1 Galerkin blocks are all-reduced.  The coarse multigrid levels run replicated.

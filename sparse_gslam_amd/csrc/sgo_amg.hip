@@ -922,6 +922,58 @@ __global__ __launch_bounds__(kBlock) void k_prolong_add(int n, const int* __rest
   }
 }
 
+// Row-owner mode: the prolongated coarse correction on a LIST of rows -- the copies of the neighbours' boundary rows this rank
+// keeps -- so that the post-smoothing sweep finds x1 + P e there without an exchange: the coarse solution is replicated, the
+// boundary rows' entries of P travel once per Gauss-Newton iteration (the gathered records P.blk), and x1 = omega Dinv r on these
+// rows is kept current by the repeated recurrences (k_update_xr_rows).  The records are rounded to the fp32 values the owner's
+// k_prolong_p streams, so only the order of a row's few additions differs from the owner's result.  P.np == 0: tentative
+// transfer (aggregate + lever arm, as k_prolong_add).
+__global__ __launch_bounds__(kBlock) void k_prolong_rows(int nrows, const int* __restrict__ rows, PDev P, const int* __restrict__ agg,
+                                                         const double* __restrict__ d, const double* __restrict__ u1, SpmvRatio r1,
+                                                         const double* __restrict__ u2, SpmvRatio r2, double* __restrict__ x,
+                                                         const PcgScalars* S) {
+  if (S && S->stop) return;
+  double c1 = 1.0, c2 = 0.0;
+  if (r1.num || u2) {
+    const double* const parts[4] = {r1.num ? r1.den : nullptr, r1.num, (u2 && r2.num) ? r2.den : nullptr, u2 ? r2.num : nullptr};
+    const int cnt[4] = {r1.n_den, r1.n_num, r2.n_den, r2.n_num};
+    double v[4];
+    block_reduce_parts_n<4>(parts, cnt, v);
+    if (r1.num) c1 = (v[0] > 0.0 && isfinite(v[0]) && isfinite(v[1])) ? v[1] / v[0] : 0.0;
+    if (u2) c2 = (v[2] > 0.0 && isfinite(v[2]) && isfinite(v[3])) ? v[3] / v[2] : 0.0;
+  }
+  for (int t = blockIdx.x * kBlock + threadIdx.x; t < nrows; t += gridDim.x * kBlock) {
+    const size_t i = (size_t)rows[t], o = 3 * i;
+    if (P.np > 0) {
+      double acc[3] = {0.0, 0.0, 0.0};
+      for (int e = P.rowptr[i]; e < P.rowptr[i + 1]; ++e) {
+        const size_t a = 3 * (size_t)P.col[e];
+        double w0 = c1 * u1[a], w1 = c1 * u1[a + 1], w2 = c1 * u1[a + 2];
+        if (u2) {
+          w0 += c2 * u2[a]; w1 += c2 * u2[a + 1]; w2 += c2 * u2[a + 2];
+        }
+        const double* bl = P.blk + 9 * (size_t)e;
+        double b[9];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) b[q] = (double)(float)bl[q];
+        acc[0] += b[0] * w0 + b[1] * w1 + b[2] * w2;
+        acc[1] += b[3] * w0 + b[4] * w1 + b[5] * w2;
+        acc[2] += b[6] * w0 + b[7] * w1 + b[8] * w2;
+      }
+      x[o] += acc[0]; x[o + 1] += acc[1]; x[o + 2] += acc[2];
+    } else {
+      const size_t a = 3 * (size_t)agg[i];
+      double w0 = c1 * u1[a], w1 = c1 * u1[a + 1], w = c1 * u1[a + 2];
+      if (u2) {
+        w0 += c2 * u2[a]; w1 += c2 * u2[a + 1]; w += c2 * u2[a + 2];
+      }
+      x[o] += w0 - d[2 * i + 1] * w;
+      x[o + 1] += w1 + d[2 * i] * w;
+      x[o + 2] += w;
+    }
+  }
+}
+
 // Coarsest level: explicit dense inverse, recomputed every GN iteration by a blocked in-place
 // Gauss-Jordan (SPD, no pivoting) spread over many workgroups: for pivot block K (32 x 32)
 //   P = inv(A_KK);  A_Kj <- P A_Kj (j != K);  A_ij <- A_ij - A_iK A_Kj (i, j != K);
@@ -1779,8 +1831,17 @@ int cycle(Amg* m, hipStream_t s, int l, const double* rhs, const double* rhs_sub
     if (H) {
       // row-owner mode: the corrected xs of the neighbours' boundary rows, then the sweep over this rank's tiles; the dot
       // products ride on the kernel as per-workgroup partials of the OWNED rows (the caller exchanges their sums)
-      std::string e;
-      if (!halo_exchange(*H, s, L.xs, 3, H->bnd, H->bmax, HaloScalars(), &e)) m->comm_failed = true;
+      // (no exchange for that: this rank prolongates the replicated coarse solution on its copies of the neighbours' boundary
+      // rows itself, k_prolong_rows; SGO_OWNER_XS_EXCHANGE=1 keeps the exchange of round 3)
+      static const bool xs_exchange = std::getenv("SGO_OWNER_XS_EXCHANGE") && std::atoi(std::getenv("SGO_OWNER_XS_EXCHANGE")) != 0;
+      if (xs_exchange) {
+        std::string e;
+        if (!halo_exchange(*H, s, L.xs, 3, H->bnd, H->bmax, HaloScalars(), &e)) m->comm_failed = true;
+      } else if (H->nhalo > 0) {
+        PDev Ph = L.smoothed ? L.P : PDev();
+        SGO_LAUNCH(k_prolong_rows, dim3(grid_for(H->nhalo, kBlock)), dim3(kBlock), 0, s, H->nhalo, H->halo_rows, Ph, (const int*)L.agg,
+                   (const double*)L.d, cs.u1, cs.c1, cs.u2, cs.c2, L.xs, S);
+      }
       b.u0 = H->u0; b.u1 = H->u1;
       Scope sc(m->prof, m->S0.fblk ? K_SPMV0T_JACOBI_F32 : K_SPMV0T_JACOBI, ((m->S0.fblk ? 40.0 : 76.0) * m->S0.npairs + 168.0 * m->S0.n) / H->G);
       return launch_spmv0_any(s, m->S0, m->T0, S0_JACOBI, b);

@@ -433,11 +433,11 @@ int do_spmv(sgo_ctx* c, const double* x, double* y, bool dot, const PcgScalars* 
   return SGO_OK;
 }
 
-// One PCG iteration in row-owner mode: three exchanges -- q's boundary with the partial sums of p.q | xs's boundary after
-// the coarse correction | z's boundary with the partial sums of r.z, r.r, z.q -- and the all-reduce of the coarse
-// right-hand side; all vector work on the owned rows.  The copies of the neighbours' boundary rows ("halo rows") of r, xs
-// and p are kept current by repeating the recurrences on them (k_update_*_rows: same inputs, same arithmetic as the
-// owner's: bit-identical), which is what saves the exchanges of xs and p.
+// One PCG iteration in row-owner mode: two exchanges -- q's boundary with the partial sums of p.q | z's boundary with the
+// partial sums of r.z, r.r, z.q -- and the all-reduce of the coarse right-hand side; all vector work on the owned rows.  The
+// copies of the neighbours' boundary rows ("halo rows") of r, xs and p are kept current by repeating the recurrences on them
+// (k_update_*_rows: same inputs, same arithmetic as the owner's: bit-identical), and the cycle prolongates the replicated
+// coarse solution on them itself (k_prolong_rows, sgo_amg.hip): no exchange of xs, p or the corrected xs.
 static int pcg_iteration_owner(sgo_ctx* c) {
   const HaloDev& H = c->halo;
   const int G = H.G, nr = H.row1 - H.row0;
