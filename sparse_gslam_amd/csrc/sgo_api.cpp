@@ -255,8 +255,9 @@ int sgo_update_graph_se2(sgo_ctx* c, int32_t V, const double* poses, const uint8
     else if (V - ov.base_V > kOvMaxVerts || E - ov.base_E > kOvMaxEdges) why = "the appended part has outgrown the overlay";
     else if (std::memcmp(fixed, ov.fixed.data(), (size_t)c->V) != 0) why = "fixed flags of resident vertices changed";
     else if (ov.hpos.size() != (size_t)ov.base_V) why = "no row map of the resident structure";
-    // an overlay that costs too many PCG iterations (counts only) is dropped for a fresh hierarchy that knows the closures
-    else if (ov.active && c->its_base > 0.0 && c->its_last > 1.25 * c->its_base + 3.0) why = "the overlay costs too many PCG iterations";
+    // an overlay that costs too many PCG iterations (counts only: the first solves of the optimize() calls, which run at the same
+    // relative tolerance) is dropped for a fresh hierarchy that knows the closures
+    else if (ov.active && c->its_base > 0 && 4 * c->its_last > 5 * c->its_base + 12) why = "the overlay costs too many PCG iterations";
     if (why.empty()) {
       for (int e = n_resident_edges; e < E; ++e) {
         const int a = ei[e], b = ej[e];
@@ -314,6 +315,9 @@ int sgo_update_graph_se2(sgo_ctx* c, int32_t V, const double* poses, const uint8
         c->E = E;
         c->linearized = false;
         c->warm_valid = false;
+        // the hierarchy's own staleness rule compares a solve with the best count seen so far (sgo_solve.cpp): the solves after
+        // an update have another right-hand side (the appended poses' residual) -- their first one sets a new reference
+        c->amg_best = 0;
         c->setup_seconds = wall_s() - t0;
         c->update_note = "incremental (" + std::to_string(dE) + " edges appended in " + std::to_string(1e3 * c->setup_seconds).substr(0, 5) + " ms)";
         if (c->opts.verbose)

@@ -153,8 +153,12 @@ struct sgo_ctx {
   // incremental re-initialisation (sgo_update_graph_se2, sgo_overlay.h): V / E above count the appended part too, n stays
   // the resident structure's rows
   Overlay ov;
-  double its_base = 0.0;          // mean PCG iterations per solve of the first optimize() on the resident structure alone,
-  double its_last = 0.0;          // ... of the latest optimize(): an overlay that costs too many iterations is dropped for a full set-up
+  // PCG iterations of the FIRST solve of an optimize() call -- always run at pcg_tol relative to its own right-hand side, hence
+  // comparable from call to call (the later solves of a call stop at the absolute accuracy of the first and their counts follow
+  // how far the right-hand side has shrunk): of the first call on the resident structure alone, and of the latest call.  An
+  // overlay whose first solve costs too many more is dropped for a full set-up (counts only).
+  int its_base = 0;
+  int its_last = 0;
   std::string update_note;        // what the last sgo_update_graph_se2 did (sgo_solver_description)
 
   // profiling

@@ -965,6 +965,10 @@ int optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
         if (c->defl_on && !rebuild_next && eq_iter > best_pcg + best_pcg / 2 + 4) c->defl_ready = false;
       }
       its_sum += S.iter + wasted;
+      if (it == 0 && S.stop == 1) {   // the call's first solve: what the incremental set-up's staleness rule compares (sgo_ctx.h)
+        c->its_last = S.iter;
+        if (!c->ov.active && c->its_base == 0) c->its_base = S.iter;
+      }
       if (out) {
         out->pcg_iters[it] = S.iter + wasted;   // an abandoned solve's iterations count too
         out->pcg_converged[it] = S.stop == 1;
@@ -1007,10 +1011,7 @@ int optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
                      S.bb > 0 ? std::sqrt(S.rr / S.bb) : 0.0, std::sqrt(S.bb));
     }
     c->pcg_softcap = 0;
-    if (done > 0) {   // mean PCG iterations per solve: the incremental set-up's staleness rule compares them (counts only)
-      c->its_last = its_sum / done;
-      if (!c->ov.active && c->its_base == 0.0) c->its_base = c->its_last;
-    }
+    (void)its_sum;
     if ((rc = do_chi2(c, c->d_hist + 2 * done, nullptr))) {
       return rc;
     }

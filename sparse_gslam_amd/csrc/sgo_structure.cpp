@@ -120,7 +120,7 @@ void free_graph(sgo_ctx* c) {
   c->pcg_exec_key = 0;
   c->defl_ready = c->defl_on = c->defl_rec = false;
   c->defl_k = 0;
-  c->its_base = c->its_last = 0.0;
+  c->its_base = c->its_last = 0;
   c->update_note.clear();
 }
 
