@@ -287,6 +287,15 @@ void sgo_shard_range(int32_t count, int32_t nranks, int32_t rank, int32_t* begin
 int sgo_plan_rows(int32_t V, const double* poses, const uint8_t* fixed, int32_t E, const int32_t* ei, const int32_t* ej,
                   int32_t nranks, int32_t* n_free, int32_t* row_vertex, int32_t* ntiles, int32_t* tile_row_begin,
                   int32_t tile_cap, int32_t* rank_row_begin);
+/* The elimination plan of the multifrontal path (mid-size graphs: DESIGN.md section 5c), computed on the host alone (no GPU,
+ * no context).  stats[12] = { free poses, fronts, levels, largest front (scalar rows), its own poses, its boundary poses,
+ * flops per factorisation, flops on the critical path (largest front of every level), 16-column panels on the critical path,
+ * bytes of frontal matrices, row order (0 Hilbert, 1 id), assembly targets }; elim_vertex[n] (optional): vertex id at every
+ * elimination position; front_of_elim[n] (optional): its front (fronts are numbered children-first).  leaf <= 0 and
+ * max_crit_mflop <= 0 take the defaults of sgo_set_graph_se2.  SGO_ENOTHING: the graph does not qualify (sgo_last_error
+ * says why; stats[0] is still set). */
+int sgo_mfront_plan(int32_t V, const double* poses, const uint8_t* fixed, int32_t E, const int32_t* ei, const int32_t* ej,
+                    int32_t leaf, double max_crit_mflop, int64_t* stats, int32_t* elim_vertex, int32_t* front_of_elim);
 
 /* Test hook: make this context evaluate the tile range of rank `rank` of `nranks` WITHOUT a
  * communicator (collectives are skipped), so that the per-rank partial products can be inspected on

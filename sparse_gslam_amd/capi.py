@@ -27,7 +27,7 @@ SYMBOLS = [
     "sgo_num_free", "sgo_free_ids", "sgo_linearize", "sgo_hessian_apply", "sgo_solve",
     "sgo_precondition", "sgo_kernel_profile", "sgo_profile_reset", "sgo_profile_overhead_ms", "sgo_comm_unique_id",
     "sgo_comm_init", "sgo_comm_size", "sgo_shard_range", "sgo_debug_set_shard", "sgo_last_error",
-    "sgo_closure_information", "sgo_plan_rows", "sgo_debug_coarse_rhs", "sgo_debug_spmv0_us",
+    "sgo_closure_information", "sgo_plan_rows", "sgo_mfront_plan", "sgo_debug_coarse_rhs", "sgo_debug_spmv0_us",
     "sgo_solver_description", "sgo_comm_init_host", "sgo_comm_host_allgather", "sgo_debug_level0_bytes",
     "sgo_kernel_profile_samples", "sgo_update_graph_se2", "sgo_debug_lanczos",
 ]
@@ -184,6 +184,38 @@ def plan_rows(poses, fixed, ei, ej, nranks: int = 1):
         raise SgoError(f"sgo_plan_rows: rc={rc}: " + lib().sgo_last_error(None).decode())
     return dict(n=n.value, row_vertex=rv[: n.value].copy(), tile_row_begin=tb[: nt.value + 1].copy(),
                 rank_row_begin=rb.copy())
+
+
+MFRONT_STATS = ("n", "fronts", "levels", "max_dim", "max_own", "max_bnd", "flops", "crit_flops", "crit_panels",
+                "arena_bytes", "order_kind", "targets")
+
+
+def mfront_plan(poses, fixed, ei, ej, leaf: int = 0, max_crit_mflop: float = 0.0):
+    """Host-only elimination plan of the multifrontal path (sgo_mfront_plan; needs no GPU): dict of MFRONT_STATS plus
+    ``qualifies``, ``why``, ``elim_vertex`` (n,), ``front_of_elim`` (n,)."""
+    p = np.ascontiguousarray(poses, dtype=np.float64).reshape(-1, 3)
+    f = np.ascontiguousarray(fixed, dtype=np.uint8)
+    a = np.ascontiguousarray(ei, dtype=np.int32)
+    b = np.ascontiguousarray(ej, dtype=np.int32)
+    V = p.shape[0]
+    st = np.zeros(12, dtype=np.int64)
+    ev = np.full(V, -1, dtype=np.int32)
+    fe = np.full(V, -1, dtype=np.int32)
+    L = lib()
+    L.sgo_mfront_plan.argtypes = [C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_uint8), C.c_int32, C.POINTER(C.c_int32),
+                                  C.POINTER(C.c_int32), C.c_int32, C.c_double, C.POINTER(C.c_int64), C.POINTER(C.c_int32),
+                                  C.POINTER(C.c_int32)]
+    rc = L.sgo_mfront_plan(V, _dp(p), f.ctypes.data_as(C.POINTER(C.c_uint8)), a.size, _ip(a), _ip(b), leaf, max_crit_mflop,
+                           st.ctypes.data_as(C.POINTER(C.c_int64)), _ip(ev), _ip(fe))
+    if rc not in (0, -1):
+        raise SgoError(f"sgo_mfront_plan: rc={rc}: " + L.sgo_last_error(None).decode())
+    out = {k: int(v) for k, v in zip(MFRONT_STATS, st)}
+    out["qualifies"] = rc == 0
+    out["why"] = "" if rc == 0 else L.sgo_last_error(None).decode()
+    n = out["n"]
+    out["elim_vertex"] = ev[:n].copy()
+    out["front_of_elim"] = fe[:n].copy()
+    return out
 
 
 def comm_unique_id() -> bytes:

@@ -132,6 +132,7 @@ const char* sgo_solver_description(sgo_ctx* c) {
   try {
     c->solver_text = c->solver_desc;
     if (!c->direct && !c->direct_why.empty()) c->solver_text += "; direct path not used: " + c->direct_why;
+    if (!c->direct && !c->mf && !c->mf_why.empty()) c->solver_text += "; multifrontal path not used: " + c->mf_why;
     if (c->ov.active)
       c->solver_text += "; incremental overlay: " + std::to_string(c->ov.new_vertex.size()) + " appended rows (" + std::to_string(c->ov.dev.nx) +
                         " hubs), " + std::to_string(c->ov.dev.nt) + " touched rows, " + std::to_string(c->ov.dev.el.cnt) + " appended edges (" +
@@ -202,13 +203,48 @@ int sgo_set_graph_se2(sgo_ctx* c, int32_t V, const double* poses, const uint8_t*
       } else if (c->opts.verbose) {
         std::fprintf(stderr, "[sgo] direct path not used: %s\n", c->direct_why.c_str());
       }
+      // Mid-size graphs (the reference's largest: a few thousand poses, a closure every few poses): a multifrontal sparse
+      // Cholesky factorisation, one launch per level of the elimination tree (sgo_mfront.h), when the tree's critical path
+      // is short enough.  SGO_MFRONT=0 keeps the multigrid PCG; SGO_MFRONT_ROWS bounds the graph size.
+      bool mf_on = true;
+      int mf_rows = 32768;
+      if (const char* s = std::getenv("SGO_MFRONT")) mf_on = std::atoi(s) != 0;
+      if (const char* s = std::getenv("SGO_MFRONT_ROWS")) mf_rows = std::atoi(s);
+      c->mf_why.clear();
+      if (!c->direct && mf_on && mf_rows > 0) {
+        std::string merr;
+        const double tm0 = wall_s();
+        c->mf = mfront_create(c->stream, V, c->n, c->free_id.data(), poses, E, ei, ej, mf_rows, &c->mf_why, &merr);
+        if (!c->mf && !merr.empty()) {
+          c->err = merr;
+          free_graph(c);
+          return SGO_EHIP;
+        }
+        if (c->opts.verbose) std::fprintf(stderr, "[sgo] set_graph: multifrontal analysis %.2f ms\n", 1e3 * (wall_s() - tm0));
+        if (c->mf) {
+          const MfrontInfo& mi = mfront_info(c->mf);
+          char buf[320];
+          std::snprintf(buf, sizeof buf, "multifrontal_cholesky: %d fronts in %d levels (nested dissection in %s order), largest front %d rows "
+                        "(%d own + %d boundary poses), %.0f Mflop per factorisation, %.1f on the critical path in %d panels, %.1f MB of fronts; "
+                        "pcg_amg on demand", mi.fronts, mi.height + 1, mi.order_kind == 0 ? "Hilbert" : "id", mi.max_dim, mi.max_own, mi.max_bnd,
+                        1e-6 * mi.flops, 1e-6 * mi.crit_flops, mi.crit_panels, 1e-6 * (double)mi.arena_bytes);
+          c->solver_desc = buf;
+          c->amg_pending = true;
+          c->rows_pending = true;
+          c->lz_fixed.assign(fixed, fixed + V);
+          c->lz_ei.assign(ei, ei + E);
+          c->lz_ej.assign(ej, ej + E);
+        } else if (c->opts.verbose) {
+          std::fprintf(stderr, "[sgo] multifrontal path not used: %s\n", c->mf_why.c_str());
+        }
+      }
     }
     if (!c->rows_pending && (rc = build_rows(c, poses, fixed, ei, ej)) != SGO_OK) {
       free_graph(c);
       return rc;
     }
     if (c->opts.solver != SGO_SOLVER_PCG_AMG) c->solver_desc += multi_gpu_description(c);
-    if (c->opts.solver == SGO_SOLVER_PCG_AMG && c->n > 0 && !c->direct) {
+    if (c->opts.solver == SGO_SOLVER_PCG_AMG && c->n > 0 && !c->direct && !c->mf) {
       // the hierarchy is built from the Hessian at the initial poses (strength of connection)
       const double ta0 = wall_s();
       if ((rc = do_linearize(c)) != SGO_OK || (rc = build_amg(c)) != SGO_OK) {
@@ -248,7 +284,7 @@ int sgo_update_graph_se2(sgo_ctx* c, int32_t V, const double* poses, const uint8
     if (!c->has_graph) why = "no resident graph";
     else if (!env_on) why = "disabled (SGO_INCREMENTAL=0)";
     else if (n_resident_edges == 0) why = "the caller reports no common prefix";
-    else if (c->direct || c->rows_pending || c->amg_pending) why = "the resident graph takes the single-launch direct path (its set-up is cheap)";
+    else if (c->direct || c->rows_pending || c->amg_pending) why = c->mf ? "the resident graph takes the multifrontal path (its set-up is cheap)" : "the resident graph takes the single-launch direct path (its set-up is cheap)";
     else if (!c->amg || c->opts.solver != SGO_SOLVER_PCG_AMG) why = "no multigrid hierarchy resident";
     else if (c->comm.nranks > 1 || c->comm.active()) why = "multi-GPU contexts re-partition";
     else if (n_resident_edges != res_E || V < c->V) why = "the resident graph is not a prefix of the new one";

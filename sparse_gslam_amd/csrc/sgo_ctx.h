@@ -16,6 +16,7 @@
 #include "sgo_amg.h"
 #include "sgo_comm.h"
 #include "sgo_direct.h"
+#include "sgo_mfront.h"
 #include "sgo_internal.h"
 #include "sgo_overlay.h"
 
@@ -121,6 +122,8 @@ struct sgo_ctx {
   std::vector<int32_t> lz_ei, lz_ej;
   Direct* direct = nullptr;       // small-graph path: optimize() is one launch (sgo_direct.h)
   std::string direct_why;         // why the last graph did not qualify for it
+  Mfront* mf = nullptr;           // mid-size path: optimize() through the multifrontal factorisation (sgo_mfront.h)
+  std::string mf_why;             // why the last graph did not qualify for it
   DirectResult* d_dres = nullptr;
   DirectResult* h_dres = nullptr; // pinned
   double* d_zparts = nullptr;     // [2][kMaxPartials] partials of r.z from the cycle's last kernel

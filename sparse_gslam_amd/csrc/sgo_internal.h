@@ -350,6 +350,7 @@ enum KernelId : int {
   K_UP_FOLD,
   K_PROLONG_FOLD0,
   K_JACOBI0_RESTRICT,
+  K_MFRONT,             // the multifrontal path: all launches of one optimize() (sgo_mfront.h)
   K_COUNT
 };
 extern const char* const kKernelNames[K_COUNT];
@@ -404,6 +405,32 @@ struct ChunkArena {
     return nb.base;
   }
 };
+
+// Hilbert-curve index of the cell (x, y) of a 2^order x 2^order grid.
+inline uint32_t hilbert_index(uint32_t x, uint32_t y, int order) {
+  uint32_t d = 0;
+  for (uint32_t s = 1u << (order - 1); s > 0; s >>= 1) {
+    const uint32_t rx = (x & s) ? 1u : 0u, ry = (y & s) ? 1u : 0u;
+    d += s * s * ((3u * rx) ^ ry);
+    if (ry == 0) {   // rotate the quadrant
+      if (rx == 1) {
+        x = s - 1 - (x & (s - 1));
+        y = s - 1 - (y & (s - 1));
+      } else {
+        x &= s - 1;
+        y &= s - 1;
+      }
+      const uint32_t t = x;
+      x = y;
+      y = t;
+    } else {
+      x &= s - 1;
+      y &= s - 1;
+    }
+  }
+  return d;
+}
+
 
 // Device memory that survives between set-ups: a graph's ~60 arrays (and the multigrid hierarchy's ~100) are
 // carved out of a few large hipMalloc'ed chunks that are rewound, not freed, when the next graph arrives --

@@ -37,7 +37,8 @@ const char* const kKernelNames[K_COUNT] = {
     "k_spmv0<0>", "k_spmv0<1>", "k_spmv0<2>", "k_spmv0t<0, 1024, false>", "k_spmv0t<1, 1024, false>", "k_spmv0t<2, 1024, false>",
     "k_direct", "k_spmv0t<1, 1024, true>", "k_spmv0t<2, 1024, true>", "k_restrict_p @level0", "k_prolong_p @level0", "k_p_values @level0", "k_block_products<1, 0, 0> @level0",
     "k_block_products<0, 1, 1> @level0", "k_galerkin @level0", "k_restrict @level0", "k_prolong_add @level0",
-    "k_ptilde_values", "k_ptilde_values @level0", "k_up_fold", "k_prolong_fold @level0", "k_jacobi0_restrict @level0"};
+    "k_ptilde_values", "k_ptilde_values @level0", "k_up_fold", "k_prolong_fold @level0", "k_jacobi0_restrict @level0",
+    "k_mf_edges + k_mf_factor + k_mf_solve + k_mf_update (multifrontal optimize)"};
 
 namespace {
 

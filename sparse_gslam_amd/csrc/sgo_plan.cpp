@@ -11,35 +11,6 @@
 
 using namespace sgo;
 
-namespace {
-
-// Hilbert-curve index of the cell (x, y) of a 2^order x 2^order grid.
-uint32_t hilbert_index(uint32_t x, uint32_t y, int order) {
-  uint32_t d = 0;
-  for (uint32_t s = 1u << (order - 1); s > 0; s >>= 1) {
-    const uint32_t rx = (x & s) ? 1u : 0u, ry = (y & s) ? 1u : 0u;
-    d += s * s * ((3u * rx) ^ ry);
-    if (ry == 0) {   // rotate the quadrant
-      if (rx == 1) {
-        x = s - 1 - (x & (s - 1));
-        y = s - 1 - (y & (s - 1));
-      } else {
-        x &= s - 1;
-        y &= s - 1;
-      }
-      const uint32_t t = x;
-      x = y;
-      y = t;
-    } else {
-      x &= s - 1;
-      y &= s - 1;
-    }
-  }
-  return d;
-}
-
-}  // namespace
-
 namespace sgo {
 
 // ---- structure build: SparseOptimizer::initializeOptimization + BlockSolver::buildStructure -
@@ -468,6 +439,58 @@ int sgo_plan_rows(int32_t V, const double* poses, const uint8_t* fixed, int32_t 
     return SGO_OK;
   } catch (const std::bad_alloc&) {
     g_err = "sgo_plan_rows: out of host memory";
+    return SGO_ENOMEM;
+  }
+}
+
+int sgo_mfront_plan(int32_t V, const double* poses, const uint8_t* fixed, int32_t E, const int32_t* ei, const int32_t* ej,
+                    int32_t leaf, double max_crit_mflop, int64_t* stats, int32_t* elim_vertex, int32_t* front_of_elim) {
+  if (V <= 0 || E < 0 || !poses || !fixed || (E > 0 && (!ei || !ej)) || !stats) return SGO_EINVAL;
+  try {
+    std::vector<int> deg((size_t)V, 0), free_id;
+    for (int e = 0; e < E; ++e) {
+      if (ei[e] < 0 || ei[e] >= V || ej[e] < 0 || ej[e] >= V || ei[e] == ej[e]) {
+        g_err = "sgo_mfront_plan: bad edge " + std::to_string(e);
+        return SGO_EINVAL;
+      }
+      deg[ei[e]]++;
+      deg[ej[e]]++;
+    }
+    for (int v = 0; v < V; ++v)
+      if (!fixed[v] && deg[v] > 0) free_id.push_back(v);
+    MfLimits lim;
+    lim.max_rows = 1 << 30;
+    if (leaf > 0) lim.leaf = leaf;
+    if (max_crit_mflop > 0.0) {
+      lim.max_crit_flops = 1e6 * max_crit_mflop;
+      lim.max_degree = 1e9;   // (an explicit budget: analyse whatever the density)
+    }
+    MfPlan P;
+    std::string why;
+    std::memset(stats, 0, sizeof(int64_t) * 12);
+    stats[0] = (int64_t)free_id.size();
+    if (!mfront_analyze(V, (int)free_id.size(), free_id.data(), poses, E, ei, ej, lim, &P, &why)) {
+      g_err = why;
+      return SGO_ENOTHING;   // the graph does not qualify (sgo_last_error says why)
+    }
+    stats[1] = (int64_t)P.fronts.size();
+    stats[2] = P.height + 1;
+    stats[3] = P.max_dim;
+    stats[4] = P.max_own;
+    stats[5] = P.max_bnd;
+    stats[6] = (int64_t)P.flops;
+    stats[7] = (int64_t)P.crit_flops;
+    stats[8] = P.crit_panels;
+    stats[9] = P.arena_doubles * 8;
+    stats[10] = P.order_kind;
+    stats[11] = (int64_t)P.targets.size();
+    if (elim_vertex) std::copy(P.elim_vertex.begin(), P.elim_vertex.end(), elim_vertex);
+    if (front_of_elim)
+      for (size_t f = 0; f < P.fronts.size(); ++f)
+        for (int q = 0; q < P.fronts[f].own; ++q) front_of_elim[P.fronts[f].e0 + q] = (int32_t)f;
+    return SGO_OK;
+  } catch (const std::bad_alloc&) {
+    g_err = "sgo_mfront_plan: out of host memory";
     return SGO_ENOMEM;
   }
 }

@@ -826,13 +826,21 @@ int optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
     }
     if (c->n == 0) return SGO_ENOTHING;
     const double t0 = wall_s();
-    if (c->direct) {
-      // ---- small-graph path: the whole call is one launch (sgo_direct.h)
-      {
+    if (c->direct || c->mf) {
+      // ---- small-graph path: the whole call is one launch (sgo_direct.h); mid-size path: one launch per level of the
+      // elimination tree and Gauss-Newton iteration, no host round trip inside the call (sgo_mfront.h)
+      if (c->direct) {
         Scope sc(c, K_DIRECT, direct_bytes(c->direct, c->E, iters));
         hipError_t he = direct_optimize(c->direct, c->stream, c->el, c->d_poses, iters, c->d_hist, c->d_dres);
         if (he != hipSuccess) {
           c->err = std::string("k_direct launch: ") + hipGetErrorString(he);
+          return SGO_EHIP;
+        }
+      } else {
+        Scope sc(c, K_MFRONT, mfront_bytes(c->mf, c->E, iters), true);
+        hipError_t he = mfront_optimize(c->mf, c->stream, c->el, c->d_poses, iters, c->d_hist, c->d_dres);
+        if (he != hipSuccess) {
+          c->err = std::string("multifrontal launch: ") + hipGetErrorString(he);
           return SGO_EHIP;
         }
       }
@@ -844,7 +852,7 @@ int optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
       const DirectResult& R = *c->h_dres;
       const int done = R.done;
       if (R.fail) {
-        c->err = std::string("direct factorisation failed in GN iteration ") + std::to_string(done) +
+        c->err = std::string(c->direct ? "direct" : "multifrontal") + " factorisation failed in GN iteration " + std::to_string(done) +
                  (R.fail == 1 ? " (a pivot block is not positive definite: Hessian not positive definite)"
                               : " (non-finite update)") + "; the step was not applied";
       }
@@ -864,17 +872,17 @@ int optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
         }
         out->seconds_total = wall_s() - t0;
       }
-      if (c->opts.verbose && done > 0)
+      if (c->opts.verbose && done > 0 && c->direct)
         std::fprintf(stderr, "[sgo] direct: %.0f MHz shader clock during the call\n",
                      (double)R.cycles / (1e-2 * (double)(R.stamp[R.fail ? 2 * done + 2 : 2 * iters + 1] - R.stamp[0])));
-      if (c->opts.verbose && done > 0)
+      if (c->opts.verbose && done > 0 && c->direct)
         std::fprintf(stderr, "[sgo] direct, last iteration [us]: edges %.1f, assembly %.1f, sparse forward %.1f, separators %.1f + %.1f, "
                      "sparse backward %.1f, update %.1f\n", 1e-2 * (double)(R.phase[1] - R.phase[0]), 1e-2 * (double)(R.phase[2] - R.phase[1]),
                      1e-2 * (double)(R.phase[3] - R.phase[2]), 1e-2 * (double)(R.phase[4] - R.phase[3]), 1e-2 * (double)(R.phase[5] - R.phase[4]),
                      1e-2 * (double)(R.phase[6] - R.phase[5]), 1e-2 * (double)(R.phase[7] - R.phase[6]));
       if (c->opts.verbose > 1)
         for (int k = 0; k <= done; ++k)
-          std::fprintf(stderr, "[sgo] iteration= %d\t chi2= %.9e\t robust= %.9e\t (direct)\n", k, c->h_hist[2 * k], c->h_hist[2 * k + 1]);
+          std::fprintf(stderr, "[sgo] iteration= %d\t chi2= %.9e\t robust= %.9e\t (%s)\n", k, c->h_hist[2 * k], c->h_hist[2 * k + 1], c->direct ? "direct" : "multifrontal");
       return R.fail ? 0 : done;
     }
     if ((rc = ensure_amg(c))) return rc;

@@ -88,6 +88,10 @@ void free_graph(sgo_ctx* c) {
     direct_destroy(c->direct);
     c->direct = nullptr;
   }
+  if (c->mf) {
+    mfront_destroy(c->mf);
+    c->mf = nullptr;
+  }
   c->amg_pending = false;
   c->amg_theta_scale = 1.0;
   c->rows_pending = false;
