@@ -32,7 +32,7 @@ struct MfFrontDev {
   long long off;
   int nb, bnd_off;
   int kid[2];
-  int map_off[2];
+  int pinv_off[2];   // child k: pinv[pinv_off[k] + local pose] = its index among the child's boundary poses, -1: not there
   int tgt0, tgt1;
 };
 
@@ -41,13 +41,15 @@ struct MfDev {
   const MfFrontDev* fronts = nullptr;
   const int* level_front = nullptr;
   const int* bnd = nullptr;
-  const int* cmap = nullptr;
+  const int* pinv = nullptr;
+  const int2* mtile = nullptr;   // k_mf_merge's work list: (front, tile row | tile column << 16), level by level
   const MfTarget* targets = nullptr;
   const int* contrib = nullptr;
   const int* elim_vertex = nullptr;
   double* arena = nullptr;
   double* elem = nullptr;      // [E][kElemStride]
   double* x = nullptr;         // [3 n] by elimination position
+  double* invd = nullptr;      // [3 n] 1 / L[c][c] of every eliminated scalar row (k_mf_panels), for the substitution
   double* partials = nullptr;  // [2][kMaxPartials]
   long long* dbg = nullptr;    // diagnostic runs (SGO_MFRONT_DEBUG): [nfront][8] s_memtime cycles of the factor kernel's phases
   int* flags = nullptr;        // [0] fail (1 not positive definite, 2 non-finite update)  [1] iteration of the failure
@@ -68,6 +70,16 @@ __device__ __forceinline__ double mf_readlane(double v, int l) {   // l wave-uni
 // cycles per step before, the whole K loop of a panel update was latency).
 __device__ __forceinline__ void mf_tile_dot(const double* __restrict__ pa, const double* __restrict__ pb, size_t ld, int K, int lk, mf_d4& acc) {
   int kk = 0;
+  for (; kk + 64 <= K; kk += 64) {
+    double av[16], bv[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      av[u] = pa[(size_t)(kk + 4 * u) * ld];
+      bv[u] = pb[(size_t)(kk + 4 * u) * ld];
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
+  }
   for (; kk + 32 <= K; kk += 32) {
     double av[8], bv[8];
 #pragma unroll
@@ -189,11 +201,72 @@ __global__ __launch_bounds__(kBlock) void k_mf_edges(MfDev M, EdgeListDev el, co
   }
 }
 
-// ---------------------------------------------------------------------------- k_mf_factor
-__global__ __launch_bounds__(kMfThreads) void k_mf_factor(MfDev M, int lvl0, int it, int stamp_slot, DirectResult* __restrict__ res) {
-  extern __shared__ double Pn[];            // panel: column c at Pn + c * ldp, rows relative to k0
+// ---------------------------------------------------------------------------- k_mf_merge
+// A front's matrix from its children, GATHERED per 16 x 16 tile of the parent by many workgroups (the upper levels have few
+// fronts; one workgroup per front moved every element of a 200-row front through one CU's L2 port twice: 30-60 us per
+// level, measured): element (row, col) = sum over the children that hold both poses of
+//     F22_child[row', col'] - L21_child[row', :] . L21_child[col', :]
+// -- the child's Schur complement is formed HERE, on the matrix cores, tile by tile in the parent's index space (a lane's
+// operand row is the child row its parent row maps to), so no update matrix is ever written or read back, and elements no
+// child reaches are written as zeros (no clearing pass).  The edges' own contributions are added by k_mf_panels afterwards.
+// One wave per tile; fixed order of the two children: bitwise reproducible.
+__global__ __launch_bounds__(kBlock) void k_mf_merge(MfDev M, int t0, int t1) {
+  if (M.flags[0]) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lr = lane & 15, lk = lane >> 4;
+  for (int t = t0 + (int)blockIdx.x * kWavesPerBlock + wave; t < t1; t += (int)gridDim.x * kWavesPerBlock) {
+    const int2 te = M.mtile[t];
+    const MfFrontDev F = M.fronts[te.x];
+    const int R0 = 16 * (te.y & 0xffff), C0 = 16 * (te.y >> 16);
+    const int m = F.m, ld = F.ld;
+    double* __restrict__ A = M.arena + F.off;
+    double tot[4] = {0.0, 0.0, 0.0, 0.0};
+    const int prow = R0 + lr, pcol = C0 + lr;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      if (F.kid[k] < 0) continue;
+      const MfFrontDev C = M.fronts[F.kid[k]];
+      const int* __restrict__ pinv = M.pinv + F.pinv_off[k];
+      auto cmap = [&](int r) -> int {   // parent scalar row -> child scalar row, -1: the child does not hold that pose
+        if (r >= m) return r == m ? C.m : -1;
+        const int b = pinv[r / 3];
+        return b < 0 ? -1 : C.own3 + 3 * b + r % 3;
+      };
+      const int ca = cmap(prow);
+      const int cb = pcol < m ? cmap(pcol) : -1;
+      int orow[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) orow[q] = cmap(R0 + lk + 4 * q);
+      if (__ballot(ca >= 0) == 0 || __ballot(cb >= 0) == 0) continue;   // the child holds no row or no column of this tile
+      const double* __restrict__ Cm = M.arena + C.off;
+      double cur[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) cur[q] = (orow[q] >= 0 && cb >= 0) ? Cm[(size_t)cb * C.ld + orow[q]] : 0.0;
+      mf_d4 acc = {0.0, 0.0, 0.0, 0.0};
+      mf_tile_dot(Cm + (size_t)lk * C.ld + (ca >= 0 ? ca : C.m), Cm + (size_t)lk * C.ld + (cb >= 0 ? cb : C.m), (size_t)C.ld, C.own3, lk, acc);
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (orow[q] >= 0 && cb >= 0) tot[q] += cur[q] - acc[q];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int row = R0 + lk + 4 * q;
+      if (row <= m && pcol < m && row >= pcol) A[(size_t)pcol * ld + row] = tot[q];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------- k_mf_panels
+// One workgroup per front: the edges' contributions, then the own columns in panels of 16:
+//   D1  P = A[k0.., k0 .. k0+16) - L[k0.., 0 .. k0) L[k0 .. k0+16, 0 .. k0)^T to LDS (matrix cores, operands from L2);
+//   D2  the 16 x 16 Cholesky on wave 0 and the inverse of its factor on wave 1, one pivot behind (rows on the lanes, columns in
+//       registers, broadcasts by v_readlane; wave 0 hands every finished column and pivot to wave 1 through LDS);
+//   D3  L21 = P21 L11^-T on the matrix cores, straight to the front's matrix.
+__global__ __launch_bounds__(kMfThreads) void k_mf_panels(MfDev M, int lvl0, int it, int stamp_slot, DirectResult* __restrict__ res) {
+  extern __shared__ double Pn[];               // panel: column c at Pn + c * ldp, rows relative to k0 
   __shared__ double Yt[kMfPanel * kMfPanel];   // Yt[t * 16 + c] = (L11^-1)[c][t]
-  __shared__ int s_fail;
+  __shared__ double LX[kMfPanel][kMfPanel];    // LX[j][i] = L11[i][j]: column j as wave 0 finishes it
+  __shared__ double LI[kMfPanel];              // 1 / L11[j][j]
+  __shared__ int s_step, s_fail;
   if (stamp_slot >= 0 && blockIdx.x == 0 && threadIdx.x == 0) res->stamp[stamp_slot] = (unsigned long long)wall_clock64();
   if (M.flags[0]) return;
   const MfFrontDev F = M.fronts[M.level_front[lvl0 + blockIdx.x]];
@@ -202,7 +275,10 @@ __global__ __launch_bounds__(kMfThreads) void k_mf_factor(MfDev M, int lvl0, int
   const int m = F.m, s3 = F.own3, ld = F.ld;
   if (m == 0) return;
   double* __restrict__ A = M.arena + F.off;
-  if (tid == 0) s_fail = 0;
+  if (tid == 0) {
+    s_fail = 0;
+    s_step = 0;
+  }
   long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   long long tprev = M.dbg ? (long long)__builtin_amdgcn_s_memtime() : 0;
   auto lapse = [&](int k) {
@@ -212,46 +288,49 @@ __global__ __launch_bounds__(kMfThreads) void k_mf_factor(MfDev M, int lvl0, int
       tprev = now;
     }
   };
-  // ---- A. clear
-  {
+  // ---- A. a leaf has no k_mf_merge before it: clear
+  if (F.kid[0] < 0 && F.kid[1] < 0) {
     const long long tot = (long long)ld * m / 2;   // ld is even
     double2* A2 = reinterpret_cast<double2*>(A);
     for (long long i = tid; i < tot; i += kMfThreads) A2[i] = make_double2(0.0, 0.0);
+    __syncthreads();
   }
-  __syncthreads();
   lapse(0);
   // ---- B. the edges whose first-eliminated endpoint is a pose of this front: one thread per 3x3 target, contributions in edge order
   for (int t = F.tgt0 + tid; t < F.tgt1; t += kMfThreads) {
     const MfTarget T = M.targets[t];
+    int cv4[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) cv4[q] = M.contrib[min(T.c0 + q, T.c1 - 1)];
     if (T.li == T.lj) {
-      double D[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
-      int cv4[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) cv4[q] = M.contrib[min(T.c0 + q, T.c1 - 1)];
-      for (int c = T.c0; c < T.c1; ++c) {
-        const int v = (c - T.c0 < 4) ? cv4[c - T.c0] : M.contrib[c];
-        const double* el = M.elem + (size_t)kElemStride * (v >> 2);
-        const int side = v & 1;
-#pragma unroll
-        for (int q = 0; q < 6; ++q) D[q] += el[6 * side + q];
-#pragma unroll
-        for (int q = 0; q < 3; ++q) b[q] += el[21 + 3 * side + q];
-      }
       const size_t c0 = 3 * (size_t)T.li;
-      A[c0 * ld + c0] = D[0];
-      A[c0 * ld + c0 + 1] = D[1];
-      A[c0 * ld + c0 + 2] = D[2];
-      A[(c0 + 1) * ld + c0 + 1] = D[3];
-      A[(c0 + 1) * ld + c0 + 2] = D[4];
-      A[(c0 + 2) * ld + c0 + 2] = D[5];
+      double* d[9] = {A + c0 * ld + c0,           A + c0 * ld + c0 + 1,       A + c0 * ld + c0 + 2, A + (c0 + 1) * ld + c0 + 1, A + (c0 + 1) * ld + c0 + 2,
+                      A + (c0 + 2) * ld + c0 + 2, A + c0 * ld + m,            A + (c0 + 1) * ld + m, A + (c0 + 2) * ld + m};
+      double v[9];
 #pragma unroll
-      for (int q = 0; q < 3; ++q) A[(c0 + q) * ld + m] = b[q];
-    } else {
-      double H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+      for (int q = 0; q < 9; ++q) v[q] = *d[q];
       for (int c = T.c0; c < T.c1; ++c) {
-        const int v = M.contrib[c];
-        const double* el = M.elem + (size_t)kElemStride * (v >> 2) + 12;
-        if ((v & 3) == 2) {
+        const int w = (c - T.c0 < 4) ? cv4[c - T.c0] : M.contrib[c];
+        const double* el = M.elem + (size_t)kElemStride * (w >> 2);
+        const int side = w & 1;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) v[q] += el[6 * side + q];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) v[6 + q] += el[21 + 3 * side + q];
+      }
+#pragma unroll
+      for (int q = 0; q < 9; ++q) *d[q] = v[q];
+    } else {
+      const size_t r0 = 3 * (size_t)T.li, c0 = 3 * (size_t)T.lj;
+      double H[9];
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) H[3 * a + b] = A[(c0 + b) * ld + r0 + a];
+      for (int c = T.c0; c < T.c1; ++c) {
+        const int w = (c - T.c0 < 4) ? cv4[c - T.c0] : M.contrib[c];
+        const double* el = M.elem + (size_t)kElemStride * (w >> 2) + 12;
+        if ((w & 3) == 2) {
 #pragma unroll
           for (int q = 0; q < 9; ++q) H[q] += el[q];
         } else {
@@ -261,7 +340,6 @@ __global__ __launch_bounds__(kMfThreads) void k_mf_factor(MfDev M, int lvl0, int
             for (int b = 0; b < 3; ++b) H[3 * a + b] += el[3 * b + a];
         }
       }
-      const size_t r0 = 3 * (size_t)T.li, c0 = 3 * (size_t)T.lj;
 #pragma unroll
       for (int a = 0; a < 3; ++a)
 #pragma unroll
@@ -270,45 +348,71 @@ __global__ __launch_bounds__(kMfThreads) void k_mf_factor(MfDev M, int lvl0, int
   }
   __syncthreads();
   lapse(1);
-  // ---- C. extend-add: the children's update matrices (a child's boundary maps monotonically into this front: lower stays lower)
-  for (int k = 0; k < 2; ++k) {
-    if (F.kid[k] < 0) continue;
-    const MfFrontDev C = M.fronts[F.kid[k]];
-    const int nb3 = C.m - C.own3;
-    if (nb3 > 0) {
-      const double* __restrict__ U = M.arena + C.off + (size_t)C.own3 * C.ld + C.own3;
-      const int* __restrict__ map = M.cmap + F.map_off[k];
-      // rows in strips of 64 (one wave per strip and column), four columns of a strip in flight per wave: every element is a
-      // dependent read-modify-write through L2, so the loads of several are issued before the first store
-      const int nstrip = (nb3 + 1 + 63) >> 6;
-      for (int w = wave; w < nstrip * ((nb3 + 3) >> 2); w += kMfNW) {
-        const int strip = w % nstrip, j0 = 4 * (w / nstrip);
-        const int i = 64 * strip + lane;
-        if (i > nb3) continue;
-        const int row = (i == nb3) ? m : 3 * map[i / 3] + i % 3;
-        double u[4], a[4];
-        size_t at[4];
+  // D2: the 16 x 16 diagonal block of the panel at Pd (columns k0 .. k0 + wp): Cholesky on wave 0, the inverse of the factor on
+  // wave 1, one pivot behind; L11 goes to the front's matrix, the inverse to Yt, the pivots' reciprocals to M.invd
+  auto diag16 = [&](const double* Pd, int ldp, int k0, int wp) {
+  if (wave == 0) {
+    int i = lr;
+    asm volatile("" : "+v"(i));   // (opaque: or the unit-matrix selects of all 16 columns are hoisted out of the panel loop and held in registers)
+    double a[kMfPanel];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int j = min(j0 + q, nb3 - 1);
-          at[q] = (3 * (size_t)map[j / 3] + j % 3) * ld + row;
-          u[q] = U[(size_t)j * C.ld + i];
-          a[q] = A[at[q]];
-        }
+    for (int c = 0; c < kMfPanel; ++c) a[c] = (i < wp && c < wp) ? Pd[c * ldp + i] : (c == i ? 1.0 : 0.0);
+    bool ok = true;
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-          if (j0 + q < nb3 && i >= j0 + q) A[at[q]] = a[q] + u[q];
-      }
+    for (int j = 0; j < kMfPanel; ++j) {
+      const double d = mf_readlane(a[j], j);
+      ok = ok && d > 0.0 && isfinite(d);
+      const double inv = mf_rsqrt(d);
+      const double lij = a[j] * inv;   // lane j: sqrt(d)
+      a[j] = lij;
+      // (a wave's LDS operations execute in order, so the other wave sees the column before the counter: no waiting here --
+      // the fence only keeps the compiler from moving the stores)
+      if (lane < kMfPanel) LX[j][i] = lij;
+      if (lane == 0) LI[j] = inv;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __hip_atomic_store(&s_step, j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+      for (int c = j + 1; c < kMfPanel; ++c) a[c] -= lij * mf_readlane(lij, c);
+      __builtin_amdgcn_sched_barrier(0);   // (pivots are sequential anyway; without it the scheduler hoists the broadcasts of several steps and spills scalar registers)
     }
-    __syncthreads();
+    if (lane < wp) {
+#pragma unroll
+      for (int c = 0; c < kMfPanel; ++c)
+        if (c <= i) A[(size_t)(k0 + c) * ld + k0 + i] = a[c];
+    }
+    if (!ok && lane == 0) s_fail = 1;
+  } else if (wave == 1) {
+    int i = lr;
+    asm volatile("" : "+v"(i));   // (opaque: or the unit-matrix selects of all 16 columns are hoisted out of the panel loop and held in registers)
+    double y[kMfPanel];
+#pragma unroll
+    for (int c = 0; c < kMfPanel; ++c) y[c] = (c == i) ? 1.0 : 0.0;
+    double myinv = 1.0;
+#pragma unroll
+    for (int j = 0; j < kMfPanel; ++j) {
+      while (__hip_atomic_load(&s_step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= j) {
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const double inv = LI[j];
+      const double lm = (i > j) ? LX[j][i] * inv : 0.0;
+      if (i == j) myinv = inv;
+#pragma unroll
+      for (int c = 0; c <= j; ++c) y[c] -= lm * mf_readlane(y[c], j);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (lane < kMfPanel) {
+#pragma unroll
+      for (int c = 0; c < kMfPanel; ++c) Yt[c * kMfPanel + i] = (c <= i) ? y[c] * myinv : 0.0;
+      if (i < wp) M.invd[3 * (size_t)F.e0 + k0 + i] = myinv;
+    }
   }
-  lapse(2);
-  // ---- D. own columns in panels of 16: left-looking update, 16x16 Cholesky + inverse, panel solve
+  };
+  // ---- D. own columns in panels of 16
   const int ldp = (m + 2) | 1;
   for (int k0 = 0; k0 < s3; k0 += kMfPanel) {
     const int wp = min(kMfPanel, s3 - k0), R = m + 1 - k0;
     const bool cv = lr < wp;
-    // D1: P = A[k0.., k0 .. k0+wp) - L[k0.., 0 .. k0) L[k0 .. k0+wp, 0 .. k0)^T  ->  LDS
+    // D1
     for (int rt = wave; rt < ((R + 15) >> 4); rt += kMfNW) {
       const int r0 = k0 + 16 * rt;
       mf_d4 acc = {0.0, 0.0, 0.0, 0.0};
@@ -323,46 +427,10 @@ __global__ __launch_bounds__(kMfThreads) void k_mf_factor(MfDev M, int lvl0, int
       }
     }
     __syncthreads();
-    lapse(3);
-    // D2: wave 0: Cholesky of the wp x wp diagonal block and the inverse of its factor, rows on the lanes (lane & 15), columns in
-    // registers, pivot column / finished inverse row broadcast by v_readlane
-    if (wave == 0) {
-      const int i = lr;
-      double a[kMfPanel], y[kMfPanel];
-#pragma unroll
-      for (int c = 0; c < kMfPanel; ++c) {
-        a[c] = (i < wp && c < wp) ? Pn[c * ldp + i] : (c == i ? 1.0 : 0.0);
-        y[c] = (c == i) ? 1.0 : 0.0;
-      }
-      bool ok = true;
-#pragma unroll
-      for (int j = 0; j < kMfPanel; ++j) {
-        const double d = mf_readlane(a[j], j);
-        ok = ok && d > 0.0 && isfinite(d);
-        const double inv = mf_rsqrt(d);
-        const double lij = a[j] * inv;   // lane j: sqrt(d)
-        a[j] = lij;
-        const bool below = i > j;
-#pragma unroll
-        for (int c = j + 1; c < kMfPanel; ++c) a[c] -= lij * mf_readlane(lij, c);
-#pragma unroll
-        for (int c = 0; c <= j; ++c) {
-          if (i == j) y[c] *= inv;
-          const double yjc = mf_readlane(y[c], j);
-          if (below) y[c] -= lij * yjc;
-        }
-      }
-      if (lane < kMfPanel) {
-#pragma unroll
-        for (int c = 0; c < kMfPanel; ++c) {
-          if (i < wp && c <= i) Pn[c * ldp + i] = a[c];
-          Yt[c * kMfPanel + i] = (c <= i) ? y[c] : 0.0;
-        }
-      }
-      if (!ok && lane == 0) s_fail = 1;
-    }
+    lapse(2);
+    diag16(Pn, ldp, k0, wp);
     __syncthreads();
-    lapse(4);
+    lapse(3);
     if (s_fail) {
       if (tid == 0) {
         M.flags[1] = it;
@@ -370,7 +438,8 @@ __global__ __launch_bounds__(kMfThreads) void k_mf_factor(MfDev M, int lvl0, int
       }
       return;
     }
-    // D3: rows below the diagonal block: L21 = P21 L11^-T on the matrix cores (a row tile is private to its wave)
+    if (tid == 0) s_step = 0;   // (read again only after the barrier that ends the next D1)
+    // D3: rows below the diagonal block, straight to the front's matrix
     {
       const int R2 = R - wp;
       for (int rt = wave; rt < ((R2 + 15) >> 4); rt += kMfNW) {
@@ -385,49 +454,110 @@ __global__ __launch_bounds__(kMfThreads) void k_mf_factor(MfDev M, int lvl0, int
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int row = rr0 + lk + 4 * q;
-          if (row < R && cv) Pn[lr * ldp + row] = acc[q];
+          if (row < R && cv) A[(size_t)(k0 + lr) * ld + k0 + row] = acc[q];
         }
       }
     }
     __syncthreads();
-    lapse(5);
-    // D4: the finished columns back to the front's matrix
-    for (int c = wave; c < wp; c += kMfNW)
-      for (int r = c + lane; r < R; r += 64) A[(size_t)(k0 + c) * ld + k0 + r] = Pn[c * ldp + r];
-    __syncthreads();
-    lapse(6);
+    lapse(4);
   }
-  // ---- E. update matrix: U = A22 - L21 L21^T (lower triangle of the boundary rows + the right-hand side row), in place
-  const int nb3 = m - s3;
-  if (s3 > 0 && nb3 > 0) {
-    const int nct = (nb3 + 15) >> 4, nrt = (nb3 + 1 + 15) >> 4;
-    int cnt = 0;
-    for (int ct = 0; ct < nct; ++ct)
-      for (int rt = ct; rt < nrt; ++rt, ++cnt) {
-        if ((cnt & (kMfNW - 1)) != wave) continue;
-        const int r0 = s3 + 16 * rt, c0 = s3 + 16 * ct;
-        mf_d4 acc = {0.0, 0.0, 0.0, 0.0};
-        double cur[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) cur[q] = A[(size_t)min(c0 + lr, m - 1) * ld + min(r0 + lk + 4 * q, m)];
-        mf_tile_dot(A + (size_t)lk * ld + min(r0 + lr, m), A + (size_t)lk * ld + min(c0 + lr, m), (size_t)ld, s3, lk, acc);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int row = r0 + lk + 4 * q, col = c0 + lr;
-          if (row <= m && col < m && row >= col) A[(size_t)col * ld + row] = cur[q] - acc[q];
-        }
-      }
-  }
-  if (M.dbg) {
-    __syncthreads();
-    lapse(7);
-    if (tid == 0)
-      for (int k = 0; k < 8; ++k) M.dbg[8 * (size_t)M.level_front[lvl0 + blockIdx.x] + k] = ph[k];
-  }
+
+  if (M.dbg && tid == 0)
+    for (int k = 0; k < 8; ++k) M.dbg[8 * (size_t)M.level_front[lvl0 + blockIdx.x] + k] = ph[k];
 }
 
 // ---------------------------------------------------------------------------- k_mf_solve
+// Backward substitution of one level (top-down), one workgroup per front.  Everything the front reads of its factor is
+// requested up front -- the triangle L11 to LDS (packed by rows), the products of the boundary block L21^T x_bnd by one wave
+// per column (columns are contiguous) -- and the sequential part (16 x 16 triangular solves, then the finished block's
+// contribution to the columns before it) runs on ONE wave from LDS, without barriers.  Fronts whose triangle does not fit
+// the LDS take k_mf_solve_big.
+constexpr int kMfSolveOwn = 144;   // own scalar rows up to which L11 is held in LDS (packed: 83.5 KB)
+constexpr int kMfSolveBnd = 256;   // ... and boundary scalar rows up to which the whole block L21 is requested in one go
+constexpr int kMfSolveCols = (kMfSolveOwn + kMfNW - 1) / kMfNW;   // columns per wave
 __global__ __launch_bounds__(kMfThreads) void k_mf_solve(MfDev M, int lvl0) {
+  extern __shared__ double Ls[];               // row r of L11 at r (r + 1) / 2
+  __shared__ double xs[kMfSolveOwn + kMfSolveBnd];
+  __shared__ double tt[kMfSolveOwn], dinv[kMfSolveOwn];
+  if (M.flags[0]) return;
+  const MfFrontDev F = M.fronts[M.level_front[lvl0 + blockIdx.x]];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m = F.m, s3 = F.own3, ld = F.ld, nb3 = m - s3;
+  if (s3 == 0 || s3 > kMfSolveOwn || nb3 > kMfSolveBnd) return;
+  const double* __restrict__ A = M.arena + F.off;
+  // everything this front reads from memory is requested here, before the first use: the boundary poses' solution, the
+  // block L21 (this wave's columns c = wave, wave + 8, ...: up to 18 columns x 4 strips of 64 rows per lane), the triangle
+  double xb = 0.0;
+  if (tid < nb3) xb = M.x[3 * (size_t)M.bnd[F.bnd_off + tid / 3] + tid % 3];
+  double v[kMfSolveCols][kMfSolveBnd / 64], yc[kMfSolveCols];
+#pragma unroll
+  for (int q = 0; q < kMfSolveCols; ++q) {
+    const int c = wave + kMfNW * q;
+    const double* col = A + (size_t)min(c, s3 - 1) * ld;
+#pragma unroll
+    for (int ch = 0; ch < kMfSolveBnd / 64; ++ch) {
+      const int r = s3 + 64 * ch + lane;
+      v[q][ch] = (c < s3 && r < m) ? col[r] : 0.0;
+    }
+    yc[q] = (c < s3 && lane == 0) ? col[m] : 0.0;
+  }
+  if (tid < s3) dinv[tid] = M.invd[3 * (size_t)F.e0 + tid];
+  for (int c = wave; c < s3; c += kMfNW)
+    for (int r = c + lane; r < s3; r += 64) Ls[r * (r + 1) / 2 + c] = A[(size_t)c * ld + r];
+  if (tid < nb3) xs[s3 + tid] = xb;
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < kMfSolveCols; ++q) {
+    const int c = wave + kMfNW * q;
+    if (c < s3) {   // uniform per wave
+      double sum = 0.0;
+#pragma unroll
+      for (int ch = 0; ch < kMfSolveBnd / 64; ++ch) {
+        const int r = s3 + 64 * ch + lane;
+        if (r < m) sum += v[q][ch] * xs[r];
+      }
+      sum = wave_sum(sum);
+      if (lane == 0) tt[c] = yc[q] - sum;
+    }
+  }
+  __syncthreads();
+  if (wave != 0) return;
+  const int i = lane & 15;
+  for (int c0 = ((s3 - 1) / kMfPanel) * kMfPanel; c0 >= 0; c0 -= kMfPanel) {
+    const int wp = min(kMfPanel, s3 - c0);
+    double t = (i < wp) ? tt[c0 + i] : 0.0;
+    const double di = (i < wp) ? dinv[c0 + i] : 0.0;
+#pragma unroll
+    for (int r = kMfPanel - 1; r >= 0; --r) {
+      if (r < wp) {   // uniform
+        const int rr = c0 + r;
+        const double xr = mf_readlane(t * di, r);
+        if (i < r) t -= Ls[rr * (rr + 1) / 2 + c0 + i] * xr;
+        else if (i == r) t = xr;
+      }
+    }
+    if (lane < wp) {
+      xs[c0 + lane] = t;
+      M.x[3 * (size_t)F.e0 + c0 + lane] = t;
+      if (!isfinite(t)) M.flags[2] = 1;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    // the finished block's contribution to the columns before it
+    for (int c = lane; c < c0; c += 64) {
+      double s = tt[c];
+#pragma unroll 4
+      for (int r = 0; r < wp; ++r) {
+        const int rr = c0 + r;
+        s -= Ls[rr * (rr + 1) / 2 + c] * xs[rr];
+      }
+      tt[c] = s;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  }
+}
+
+// the same for a front of any size: blocks of 16 columns, one wave per column for the products with everything below the block
+__global__ __launch_bounds__(kMfThreads) void k_mf_solve_big(MfDev M, int lvl0) {
   __shared__ double xs[kMfMaxDim + 1];
   __shared__ double tt[kMfPanel];
   __shared__ double Ld[kMfPanel * (kMfPanel + 1)];
@@ -435,13 +565,12 @@ __global__ __launch_bounds__(kMfThreads) void k_mf_solve(MfDev M, int lvl0) {
   const MfFrontDev F = M.fronts[M.level_front[lvl0 + blockIdx.x]];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m = F.m, s3 = F.own3, ld = F.ld;
-  if (s3 == 0) return;
+  if (s3 == 0 || (s3 <= kMfSolveOwn && m - s3 <= kMfSolveBnd)) return;
   const double* __restrict__ A = M.arena + F.off;
   for (int i = tid; i < m - s3; i += kMfThreads) xs[s3 + i] = M.x[3 * (size_t)M.bnd[F.bnd_off + i / 3] + i % 3];
   __syncthreads();
   for (int c0 = ((s3 - 1) / kMfPanel) * kMfPanel; c0 >= 0; c0 -= kMfPanel) {
     const int wp = min(kMfPanel, s3 - c0);
-    // t_c = y_c - sum over the rows below the block of L[r][c] x_r: one wave per column (columns are contiguous)
     for (int cw = wave; cw < wp; cw += kMfNW) {
       const double* col = A + (size_t)(c0 + cw) * ld;
       double sum = 0.0;
@@ -460,7 +589,7 @@ __global__ __launch_bounds__(kMfThreads) void k_mf_solve(MfDev M, int lvl0) {
 #pragma unroll
       for (int r = kMfPanel - 1; r >= 0; --r) {
         if (r < wp) {   // uniform
-          const double xr = mf_readlane(t, r) / Ld[r * (kMfPanel + 1) + r];
+          const double xr = mf_readlane(t, r) * M.invd[3 * (size_t)F.e0 + c0 + r];
           if (i < r) t -= Ld[r * (kMfPanel + 1) + i] * xr;
           else if (i == r) t = xr;
         }
@@ -511,7 +640,10 @@ struct Mfront {
   MfrontInfo info;
   MfDev dev;
   void* buf = nullptr;
-  std::vector<int> level_lds;   // dynamic LDS of the factor launch of every level
+  std::vector<int> level_lds;        // dynamic LDS of the panel launch of every level
+  std::vector<int> level_solve_lds;  // ... of the substitution launch
+  std::vector<char> level_big;       // the level has a front whose triangle does not fit the LDS (k_mf_solve_big runs too)
+  std::vector<int> mtile_ptr;        // k_mf_merge's tiles of level h: [mtile_ptr[h], mtile_ptr[h + 1])
 };
 
 const MfrontInfo& mfront_info(const Mfront* m) { return m->info; }
@@ -556,12 +688,40 @@ Mfront* mfront_create(hipStream_t s, int V, int n, const int* free_id, const dou
     D.bnd_off = F.bnd_off;
     D.kid[0] = F.kid[0];
     D.kid[1] = F.kid[1];
-    D.map_off[0] = F.map_off[0];
-    D.map_off[1] = F.map_off[1];
+    D.pinv_off[0] = D.pinv_off[1] = 0;
     D.tgt0 = F.tgt0;
     D.tgt1 = F.tgt1;
   }
+  // inverse extend-add maps and the merge kernel's tiles
+  std::vector<int> pinv;
+  std::vector<int2> mtile;
+  M->mtile_ptr.assign((size_t)P.height + 2, 0);
+  for (int f = 0; f < nf; ++f) {
+    const MfFront& F = P.fronts[f];
+    for (int k = 0; k < 2; ++k) {
+      if (F.kid[k] < 0) continue;
+      fd[f].pinv_off[k] = (int)pinv.size();
+      pinv.resize(pinv.size() + (size_t)(F.own + F.nb), -1);
+      const MfFront& C = P.fronts[F.kid[k]];
+      for (int b = 0; b < C.nb; ++b) pinv[(size_t)fd[f].pinv_off[k] + P.cmap[(size_t)F.map_off[k] + b]] = b;
+    }
+  }
+  for (int h = 1; h <= P.height; ++h) {
+    M->mtile_ptr[h] = (int)mtile.size();
+    for (int q = P.level_ptr[h]; q < P.level_ptr[h + 1]; ++q) {
+      const int f = P.level_front[q];
+      const int mm = 3 * (P.fronts[f].own + P.fronts[f].nb);
+      const int nrt = (mm + 1 + 15) / 16, nct = (mm + 15) / 16;
+      for (int tc = 0; tc < nct; ++tc)
+        for (int tr = tc; tr < nrt; ++tr) mtile.push_back(make_int2(f, tr | (tc << 16)));
+    }
+  }
+  M->mtile_ptr[0] = 0;
+  M->mtile_ptr[(size_t)P.height + 1] = (int)mtile.size();
+  if (P.height >= 1) M->mtile_ptr[1] = 0;
   M->level_lds.assign((size_t)P.height + 1, 0);
+  M->level_solve_lds.assign((size_t)P.height + 1, 0);
+  M->level_big.assign((size_t)P.height + 1, 0);
   for (int h = 0; h <= P.height; ++h) {
     int mm = 0;
     for (int q = P.level_ptr[h]; q < P.level_ptr[h + 1]; ++q) {
@@ -569,6 +729,13 @@ Mfront* mfront_create(hipStream_t s, int V, int n, const int* free_id, const dou
       mm = std::max(mm, 3 * (F.own + F.nb));
     }
     M->level_lds[h] = (int)sizeof(double) * kMfPanel * ((mm + 2) | 1);
+    int so = 0;
+    for (int q = P.level_ptr[h]; q < P.level_ptr[h + 1]; ++q) {
+      const int s3 = 3 * P.fronts[P.level_front[q]].own;
+      if (s3 <= kMfSolveOwn && 3 * P.fronts[P.level_front[q]].nb <= kMfSolveBnd) so = std::max(so, s3);
+      else M->level_big[h] = 1;
+    }
+    M->level_solve_lds[h] = (int)sizeof(double) * std::max(1, so * (so + 1) / 2);
   }
   // one allocation, carved
   struct Part {
@@ -587,12 +754,14 @@ Mfront* mfront_create(hipStream_t s, int V, int n, const int* free_id, const dou
   const size_t i_fr = add(fd.data(), sizeof(MfFrontDev) * fd.size());
   const size_t i_lf = add(P.level_front.data(), sizeof(int) * P.level_front.size());
   const size_t i_bn = add(P.bnd.data(), sizeof(int) * std::max<size_t>(P.bnd.size(), 1));
-  const size_t i_cm = add(P.cmap.data(), sizeof(int) * std::max<size_t>(P.cmap.size(), 1));
+  const size_t i_cm = add(pinv.data(), sizeof(int) * std::max<size_t>(pinv.size(), 1));
+  const size_t i_mt = add(mtile.data(), sizeof(int2) * std::max<size_t>(mtile.size(), 1));
   const size_t i_tg = add(P.targets.data(), sizeof(MfTarget) * std::max<size_t>(P.targets.size(), 1));
   const size_t i_ct = add(P.contrib.data(), sizeof(int) * std::max<size_t>(P.contrib.size(), 1));
   const size_t i_ev = add(P.elim_vertex.data(), sizeof(int) * P.elim_vertex.size());
   const size_t i_el = add(nullptr, sizeof(double) * kElemStride * (size_t)std::max(E, 1));
   const size_t i_x = add(nullptr, sizeof(double) * 3 * (size_t)n);
+  const size_t i_id = add(nullptr, sizeof(double) * 3 * (size_t)n);
   const size_t i_pt = add(nullptr, sizeof(double) * 2 * kMaxPartials);
   const size_t i_fl = add(nullptr, sizeof(int) * 8);
   const bool debug = std::getenv("SGO_MFRONT_DEBUG") != nullptr;
@@ -608,7 +777,7 @@ Mfront* mfront_create(hipStream_t s, int V, int n, const int* free_id, const dou
   char* base = (char*)M->buf;
   for (const Part& p : parts) {
     if (!p.src || p.bytes == 0) continue;
-    const bool empty = (p.src == P.bnd.data() && P.bnd.empty()) || (p.src == P.cmap.data() && P.cmap.empty()) ||
+    const bool empty = (p.src == P.bnd.data() && P.bnd.empty()) || (p.src == pinv.data() && pinv.empty()) || (p.src == mtile.data() && mtile.empty()) ||
                        (p.src == P.targets.data() && P.targets.empty()) || (p.src == P.contrib.data() && P.contrib.empty());
     if (empty) continue;
     he = hipMemcpyAsync(base + p.at, p.src, p.bytes, hipMemcpyHostToDevice, s);
@@ -630,20 +799,24 @@ Mfront* mfront_create(hipStream_t s, int V, int n, const int* free_id, const dou
   D.fronts = (const MfFrontDev*)(base + parts[i_fr].at);
   D.level_front = (const int*)(base + parts[i_lf].at);
   D.bnd = (const int*)(base + parts[i_bn].at);
-  D.cmap = (const int*)(base + parts[i_cm].at);
+  D.pinv = (const int*)(base + parts[i_cm].at);
+  D.mtile = (const int2*)(base + parts[i_mt].at);
   D.targets = (const MfTarget*)(base + parts[i_tg].at);
   D.contrib = (const int*)(base + parts[i_ct].at);
   D.elim_vertex = (const int*)(base + parts[i_ev].at);
   D.elem = (double*)(base + parts[i_el].at);
   D.x = (double*)(base + parts[i_x].at);
+  D.invd = (double*)(base + parts[i_id].at);
   D.partials = (double*)(base + parts[i_pt].at);
   D.flags = (int*)(base + parts[i_fl].at);
   D.arena = (double*)(base + parts[i_ar].at);
   D.dbg = debug ? (long long*)(base + parts[i_db].at) : nullptr;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mf_factor), hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mf_panels), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)sizeof(double) * kMfPanel * ((kMfMaxDim + 2) | 1));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mf_solve), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)sizeof(double) * kMfSolveOwn * (kMfSolveOwn + 1) / 2);
     attr_set = true;
   }
   return M.release();
@@ -663,11 +836,17 @@ hipError_t mfront_optimize(Mfront* m, hipStream_t s, const EdgeListDev& el, doub
     if (last) break;
     for (int h = 0; h <= P.height; ++h) {
       const int cnt = P.level_ptr[h + 1] - P.level_ptr[h];
-      hipLaunchKernelGGL(k_mf_factor, dim3(cnt), dim3(kMfThreads), (size_t)m->level_lds[h], s, D, P.level_ptr[h], it, h == 0 ? 2 * it + 1 : -1, d_res);
+      if (h > 0) {
+        const int nt = m->mtile_ptr[h + 1] - m->mtile_ptr[h];
+        const int grid = std::max(1, std::min((nt + kWavesPerBlock - 1) / kWavesPerBlock, 8192));
+        hipLaunchKernelGGL(k_mf_merge, dim3(grid), dim3(kBlock), 0, s, D, m->mtile_ptr[h], m->mtile_ptr[h + 1]);
+      }
+      hipLaunchKernelGGL(k_mf_panels, dim3(cnt), dim3(kMfThreads), (size_t)m->level_lds[h], s, D, P.level_ptr[h], it, h == 0 ? 2 * it + 1 : -1, d_res);
     }
     for (int h = P.height; h >= 0; --h) {
       const int cnt = P.level_ptr[h + 1] - P.level_ptr[h];
-      hipLaunchKernelGGL(k_mf_solve, dim3(cnt), dim3(kMfThreads), 0, s, D, P.level_ptr[h]);
+      hipLaunchKernelGGL(k_mf_solve, dim3(cnt), dim3(kMfThreads), (size_t)m->level_solve_lds[h], s, D, P.level_ptr[h]);
+      if (m->level_big[h]) hipLaunchKernelGGL(k_mf_solve_big, dim3(cnt), dim3(kMfThreads), 0, s, D, P.level_ptr[h]);
     }
     hipLaunchKernelGGL(k_mf_update, dim3(ugrid), dim3(kBlock), 0, s, D, d_poses, it);
   }
@@ -675,7 +854,7 @@ hipError_t mfront_optimize(Mfront* m, hipStream_t s, const EdgeListDev& el, doub
   if (D.dbg && iters > 0) {   // diagnostic: phases of the LAST factorisation, per level the front with the longest total
     std::vector<long long> h(8 * P.fronts.size());
     if (hipStreamSynchronize(s) == hipSuccess && hipMemcpy(h.data(), D.dbg, sizeof(long long) * h.size(), hipMemcpyDeviceToHost) == hipSuccess) {
-      std::fprintf(stderr, "[sgo] multifrontal phases [cycles] per level (slowest front): clear, edges, extend-add, then per front summed over panels: update, chol16, trsm, store, schur\n");
+      std::fprintf(stderr, "[sgo] multifrontal phases [cycles] per level (slowest front): clear, edges, then summed over the panels: update, chol16 + inverse, trsm + store\n");
       for (int lv = 0; lv <= P.height; ++lv) {
         int bf = -1;
         long long bt = -1;
