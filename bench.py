@@ -345,7 +345,7 @@ def main():
                                          "from a dead-reckoned start (init=odom) undamped GN + DCS does not converge: "
                                          "init_odom_probe below",
                        "V": g.V, "E": g.E, "gn_iters_per_step": args.iters,
-                       "solver": {0: "pcg_block_jacobi", 1: "pcg_amg"}[opts.get("solver", o.solver)],
+                       "solver": opt.solver_description().split(":")[0],
                        "pcg_tol": opts.get("pcg_tol", o.pcg_tol),
                        "pcg_tol_cap": opts.get("pcg_tol_cap", o.pcg_tol_cap),
                        "pcg_stop_rule": "||r|| <= pcg_tol * max(||b||, min(||b_first||, pcg_tol_cap / pcg_tol * ||b||)): "

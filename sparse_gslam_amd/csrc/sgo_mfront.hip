@@ -34,6 +34,7 @@ struct MfFrontDev {
   int kid[2];
   int pinv_off[2];   // child k: pinv[pinv_off[k] + local pose] = its index among the child's boundary poses, -1: not there
   int tgt0, tgt1;
+  int parent;
 };
 
 struct MfDev {
@@ -46,6 +47,8 @@ struct MfDev {
   const MfTarget* targets = nullptr;
   const int* contrib = nullptr;
   const int* elim_vertex = nullptr;
+  const int* solve_order = nullptr;   // fronts root first (levels top-down): the single-launch substitution's workgroup order
+  int* done = nullptr;                // [nfront] generation of the last substitution that finished the front
   double* arena = nullptr;
   double* elem = nullptr;      // [E][kElemStride]
   double* x = nullptr;         // [3 n] by elimination position
@@ -467,107 +470,130 @@ __global__ __launch_bounds__(kMfThreads) void k_mf_panels(MfDev M, int lvl0, int
 }
 
 // ---------------------------------------------------------------------------- k_mf_solve
-// Backward substitution of one level (top-down), one workgroup per front.  Everything the front reads of its factor is
-// requested up front -- the triangle L11 to LDS (packed by rows), the products of the boundary block L21^T x_bnd by one wave
-// per column (columns are contiguous) -- and the sequential part (16 x 16 triangular solves, then the finished block's
-// contribution to the columns before it) runs on ONE wave from LDS, without barriers.  Fronts whose triangle does not fit
-// the LDS take k_mf_solve_big.
+// Backward substitution, one workgroup per front.  Everything the front reads of its factor is requested up front -- the
+// triangle L11 to LDS (packed by rows), the boundary block L21 into registers (one wave per column: columns are contiguous) --
+// and the sequential part (16 x 16 triangular solves, then the finished block's contribution to the columns before it) runs
+// on ONE wave from LDS, without barriers.  Fronts too large for that take the generic branch (blocks of 16 columns, the
+// products with everything below a block by one wave per column).
+// gen == 0 (default): one level per launch, top-down.  gen > 0 (SGO_MFRONT_FUSED_SOLVE=1): ONE launch for the whole tree --
+// workgroups ordered root first, a front waits for its parent's flag (device-scope acquire / release; a workgroup only ever
+// waits for one with a lower index, which the dispatcher has started before it).  Measured and not the default: the ten
+// launch boundaries go, but every device-scope release writes the XCD's L2 back -- full of the factor just made -- and the
+// chain of ten of them costs more than the launches did (C3s: 0.78 against 0.67 ms per Gauss-Newton iteration).
 constexpr int kMfSolveOwn = 144;   // own scalar rows up to which L11 is held in LDS (packed: 83.5 KB)
 constexpr int kMfSolveBnd = 256;   // ... and boundary scalar rows up to which the whole block L21 is requested in one go
 constexpr int kMfSolveCols = (kMfSolveOwn + kMfNW - 1) / kMfNW;   // columns per wave
-__global__ __launch_bounds__(kMfThreads) void k_mf_solve(MfDev M, int lvl0) {
+__global__ __launch_bounds__(kMfThreads) void k_mf_solve(MfDev M, int lvl0, int gen) {
   extern __shared__ double Ls[];               // row r of L11 at r (r + 1) / 2
-  __shared__ double xs[kMfSolveOwn + kMfSolveBnd];
+  __shared__ double xs[kMfMaxDim + 1];
   __shared__ double tt[kMfSolveOwn], dinv[kMfSolveOwn];
-  if (M.flags[0]) return;
-  const MfFrontDev F = M.fronts[M.level_front[lvl0 + blockIdx.x]];
+  __shared__ double Ld[kMfPanel * (kMfPanel + 1)];
+  const int f = gen > 0 ? M.solve_order[blockIdx.x] : M.level_front[lvl0 + blockIdx.x];
+  const MfFrontDev F = M.fronts[f];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m = F.m, s3 = F.own3, ld = F.ld, nb3 = m - s3;
-  if (s3 == 0 || s3 > kMfSolveOwn || nb3 > kMfSolveBnd) return;
-  const double* __restrict__ A = M.arena + F.off;
-  // everything this front reads from memory is requested here, before the first use: the boundary poses' solution, the
-  // block L21 (this wave's columns c = wave, wave + 8, ...: up to 18 columns x 4 strips of 64 rows per lane), the triangle
-  double xb = 0.0;
-  if (tid < nb3) xb = M.x[3 * (size_t)M.bnd[F.bnd_off + tid / 3] + tid % 3];
-  double v[kMfSolveCols][kMfSolveBnd / 64], yc[kMfSolveCols];
-#pragma unroll
-  for (int q = 0; q < kMfSolveCols; ++q) {
-    const int c = wave + kMfNW * q;
-    const double* col = A + (size_t)min(c, s3 - 1) * ld;
-#pragma unroll
-    for (int ch = 0; ch < kMfSolveBnd / 64; ++ch) {
-      const int r = s3 + 64 * ch + lane;
-      v[q][ch] = (c < s3 && r < m) ? col[r] : 0.0;
+  auto signal = [&]() {   // (called by wave 0 only, all its lanes: the fence covers the wave's stores of x)
+    if (gen > 0) {
+      __threadfence();
+      if (lane == 0) __hip_atomic_store(M.done + f, gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
-    yc[q] = (c < s3 && lane == 0) ? col[m] : 0.0;
+  };
+  auto wait_parent = [&]() {   // all threads; returns after the parent's x is visible to every wave of this workgroup
+    if (gen > 0) {
+      if (F.parent >= 0 && tid == 0) {
+        int polls = 0;
+        while (__hip_atomic_load(M.done + F.parent, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != gen) {
+          if (++polls > (1 << 22)) {   // never seen; a stuck launch would take the box down, a flagged failure does not
+            M.flags[2] = 1;
+            break;
+          }
+          __builtin_amdgcn_s_sleep(2);
+        }
+      }
+      __syncthreads();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+  };
+  if (M.flags[0] || s3 == 0) {   // nothing to solve here; a front without pivots still passes its ancestors' word on
+    if (!M.flags[0]) wait_parent();
+    if (wave == 0) signal();
+    return;
   }
-  if (tid < s3) dinv[tid] = M.invd[3 * (size_t)F.e0 + tid];
-  for (int c = wave; c < s3; c += kMfNW)
-    for (int r = c + lane; r < s3; r += 64) Ls[r * (r + 1) / 2 + c] = A[(size_t)c * ld + r];
-  if (tid < nb3) xs[s3 + tid] = xb;
-  __syncthreads();
+  const double* __restrict__ A = M.arena + F.off;
+  if (s3 <= kMfSolveOwn && nb3 <= kMfSolveBnd) {
+    // the block L21 (this wave's columns c = wave, wave + 8, ...: up to 18 columns x 4 strips of 64 rows per lane), the triangle
+    double v[kMfSolveCols][kMfSolveBnd / 64], yc[kMfSolveCols];
 #pragma unroll
-  for (int q = 0; q < kMfSolveCols; ++q) {
-    const int c = wave + kMfNW * q;
-    if (c < s3) {   // uniform per wave
-      double sum = 0.0;
+    for (int q = 0; q < kMfSolveCols; ++q) {
+      const int c = wave + kMfNW * q;
+      const double* col = A + (size_t)min(c, s3 - 1) * ld;
 #pragma unroll
       for (int ch = 0; ch < kMfSolveBnd / 64; ++ch) {
         const int r = s3 + 64 * ch + lane;
-        if (r < m) sum += v[q][ch] * xs[r];
+        v[q][ch] = (c < s3 && r < m) ? col[r] : 0.0;
       }
-      sum = wave_sum(sum);
-      if (lane == 0) tt[c] = yc[q] - sum;
+      yc[q] = (c < s3 && lane == 0) ? col[m] : 0.0;
     }
-  }
-  __syncthreads();
-  if (wave != 0) return;
-  const int i = lane & 15;
-  for (int c0 = ((s3 - 1) / kMfPanel) * kMfPanel; c0 >= 0; c0 -= kMfPanel) {
-    const int wp = min(kMfPanel, s3 - c0);
-    double t = (i < wp) ? tt[c0 + i] : 0.0;
-    const double di = (i < wp) ? dinv[c0 + i] : 0.0;
+    if (tid < s3) dinv[tid] = M.invd[3 * (size_t)F.e0 + tid];
+    for (int c = wave; c < s3; c += kMfNW)
+      for (int r = c + lane; r < s3; r += 64) Ls[r * (r + 1) / 2 + c] = A[(size_t)c * ld + r];
+    wait_parent();
+    if (tid < nb3) xs[s3 + tid] = M.x[3 * (size_t)M.bnd[F.bnd_off + tid / 3] + tid % 3];
+    __syncthreads();
 #pragma unroll
-    for (int r = kMfPanel - 1; r >= 0; --r) {
-      if (r < wp) {   // uniform
-        const int rr = c0 + r;
-        const double xr = mf_readlane(t * di, r);
-        if (i < r) t -= Ls[rr * (rr + 1) / 2 + c0 + i] * xr;
-        else if (i == r) t = xr;
+    for (int q = 0; q < kMfSolveCols; ++q) {
+      const int c = wave + kMfNW * q;
+      if (c < s3) {   // uniform per wave
+        double sum = 0.0;
+#pragma unroll
+        for (int ch = 0; ch < kMfSolveBnd / 64; ++ch) {
+          const int r = s3 + 64 * ch + lane;
+          if (r < m) sum += v[q][ch] * xs[r];
+        }
+        sum = wave_sum(sum);
+        if (lane == 0) tt[c] = yc[q] - sum;
       }
     }
-    if (lane < wp) {
-      xs[c0 + lane] = t;
-      M.x[3 * (size_t)F.e0 + c0 + lane] = t;
-      if (!isfinite(t)) M.flags[2] = 1;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    // the finished block's contribution to the columns before it
-    for (int c = lane; c < c0; c += 64) {
-      double s = tt[c];
+    __syncthreads();
+    if (wave != 0) return;
+    const int i = lane & 15;
+    for (int c0 = ((s3 - 1) / kMfPanel) * kMfPanel; c0 >= 0; c0 -= kMfPanel) {
+      const int wp = min(kMfPanel, s3 - c0);
+      double t = (i < wp) ? tt[c0 + i] : 0.0;
+      const double di = (i < wp) ? dinv[c0 + i] : 0.0;
+#pragma unroll
+      for (int r = kMfPanel - 1; r >= 0; --r) {
+        if (r < wp) {   // uniform
+          const int rr = c0 + r;
+          const double xr = mf_readlane(t * di, r);
+          if (i < r) t -= Ls[rr * (rr + 1) / 2 + c0 + i] * xr;
+          else if (i == r) t = xr;
+        }
+      }
+      if (lane < wp) {
+        xs[c0 + lane] = t;
+        M.x[3 * (size_t)F.e0 + c0 + lane] = t;
+        if (!isfinite(t)) M.flags[2] = 1;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      // the finished block's contribution to the columns before it
+      for (int c = lane; c < c0; c += 64) {
+        double s = tt[c];
 #pragma unroll 4
-      for (int r = 0; r < wp; ++r) {
-        const int rr = c0 + r;
-        s -= Ls[rr * (rr + 1) / 2 + c] * xs[rr];
+        for (int r = 0; r < wp; ++r) {
+          const int rr = c0 + r;
+          s -= Ls[rr * (rr + 1) / 2 + c] * xs[rr];
+        }
+        tt[c] = s;
       }
-      tt[c] = s;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    signal();
+    return;
   }
-}
-
-// the same for a front of any size: blocks of 16 columns, one wave per column for the products with everything below the block
-__global__ __launch_bounds__(kMfThreads) void k_mf_solve_big(MfDev M, int lvl0) {
-  __shared__ double xs[kMfMaxDim + 1];
-  __shared__ double tt[kMfPanel];
-  __shared__ double Ld[kMfPanel * (kMfPanel + 1)];
-  if (M.flags[0]) return;
-  const MfFrontDev F = M.fronts[M.level_front[lvl0 + blockIdx.x]];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int m = F.m, s3 = F.own3, ld = F.ld;
-  if (s3 == 0 || (s3 <= kMfSolveOwn && m - s3 <= kMfSolveBnd)) return;
-  const double* __restrict__ A = M.arena + F.off;
-  for (int i = tid; i < m - s3; i += kMfThreads) xs[s3 + i] = M.x[3 * (size_t)M.bnd[F.bnd_off + i / 3] + i % 3];
+  // ---- generic branch
+  wait_parent();
+  for (int i = tid; i < nb3; i += kMfThreads) xs[s3 + i] = M.x[3 * (size_t)M.bnd[F.bnd_off + i / 3] + i % 3];
   __syncthreads();
   for (int c0 = ((s3 - 1) / kMfPanel) * kMfPanel; c0 >= 0; c0 -= kMfPanel) {
     const int wp = min(kMfPanel, s3 - c0);
@@ -602,6 +628,7 @@ __global__ __launch_bounds__(kMfThreads) void k_mf_solve_big(MfDev M, int lvl0) 
     }
     __syncthreads();
   }
+  if (wave == 0) signal();
 }
 
 // ---------------------------------------------------------------------------- k_mf_update
@@ -642,7 +669,9 @@ struct Mfront {
   void* buf = nullptr;
   std::vector<int> level_lds;        // dynamic LDS of the panel launch of every level
   std::vector<int> level_solve_lds;  // ... of the substitution launch
-  std::vector<char> level_big;       // the level has a front whose triangle does not fit the LDS (k_mf_solve_big runs too)
+  int solve_lds_all = 0;             // ... of the single-launch substitution
+  int gen = 0;                       // substitutions run so far (the flags' generation)
+  bool fused_solve = false;
   std::vector<int> mtile_ptr;        // k_mf_merge's tiles of level h: [mtile_ptr[h], mtile_ptr[h + 1])
 };
 
@@ -691,6 +720,7 @@ Mfront* mfront_create(hipStream_t s, int V, int n, const int* free_id, const dou
     D.pinv_off[0] = D.pinv_off[1] = 0;
     D.tgt0 = F.tgt0;
     D.tgt1 = F.tgt1;
+    D.parent = F.parent;
   }
   // inverse extend-add maps and the merge kernel's tiles
   std::vector<int> pinv;
@@ -721,7 +751,10 @@ Mfront* mfront_create(hipStream_t s, int V, int n, const int* free_id, const dou
   if (P.height >= 1) M->mtile_ptr[1] = 0;
   M->level_lds.assign((size_t)P.height + 1, 0);
   M->level_solve_lds.assign((size_t)P.height + 1, 0);
-  M->level_big.assign((size_t)P.height + 1, 0);
+  std::vector<int> solve_order;
+  for (int h = P.height; h >= 0; --h)
+    for (int q = P.level_ptr[h]; q < P.level_ptr[h + 1]; ++q) solve_order.push_back(P.level_front[q]);
+  if (const char* e = std::getenv("SGO_MFRONT_FUSED_SOLVE")) M->fused_solve = std::atoi(e) != 0;
   for (int h = 0; h <= P.height; ++h) {
     int mm = 0;
     for (int q = P.level_ptr[h]; q < P.level_ptr[h + 1]; ++q) {
@@ -733,9 +766,9 @@ Mfront* mfront_create(hipStream_t s, int V, int n, const int* free_id, const dou
     for (int q = P.level_ptr[h]; q < P.level_ptr[h + 1]; ++q) {
       const int s3 = 3 * P.fronts[P.level_front[q]].own;
       if (s3 <= kMfSolveOwn && 3 * P.fronts[P.level_front[q]].nb <= kMfSolveBnd) so = std::max(so, s3);
-      else M->level_big[h] = 1;
     }
     M->level_solve_lds[h] = (int)sizeof(double) * std::max(1, so * (so + 1) / 2);
+    M->solve_lds_all = std::max(M->solve_lds_all, M->level_solve_lds[h]);
   }
   // one allocation, carved
   struct Part {
@@ -759,6 +792,8 @@ Mfront* mfront_create(hipStream_t s, int V, int n, const int* free_id, const dou
   const size_t i_tg = add(P.targets.data(), sizeof(MfTarget) * std::max<size_t>(P.targets.size(), 1));
   const size_t i_ct = add(P.contrib.data(), sizeof(int) * std::max<size_t>(P.contrib.size(), 1));
   const size_t i_ev = add(P.elim_vertex.data(), sizeof(int) * P.elim_vertex.size());
+  const size_t i_so = add(solve_order.data(), sizeof(int) * solve_order.size());
+  const size_t i_dn = add(nullptr, sizeof(int) * (size_t)nf);
   const size_t i_el = add(nullptr, sizeof(double) * kElemStride * (size_t)std::max(E, 1));
   const size_t i_x = add(nullptr, sizeof(double) * 3 * (size_t)n);
   const size_t i_id = add(nullptr, sizeof(double) * 3 * (size_t)n);
@@ -787,6 +822,7 @@ Mfront* mfront_create(hipStream_t s, int V, int n, const int* free_id, const dou
     }
   }
   he = hipMemsetAsync(base + parts[i_fl].at, 0, sizeof(int) * 8, s);
+  if (he == hipSuccess) he = hipMemsetAsync(base + parts[i_dn].at, 0, sizeof(int) * (size_t)nf, s);
   if (he == hipSuccess) he = hipStreamSynchronize(s);   // (the host vectors above go out of scope)
   if (he != hipSuccess) {
     if (err) *err = std::string("multifrontal plan upload: ") + hipGetErrorString(he);
@@ -804,6 +840,8 @@ Mfront* mfront_create(hipStream_t s, int V, int n, const int* free_id, const dou
   D.targets = (const MfTarget*)(base + parts[i_tg].at);
   D.contrib = (const int*)(base + parts[i_ct].at);
   D.elim_vertex = (const int*)(base + parts[i_ev].at);
+  D.solve_order = (const int*)(base + parts[i_so].at);
+  D.done = (int*)(base + parts[i_dn].at);
   D.elem = (double*)(base + parts[i_el].at);
   D.x = (double*)(base + parts[i_x].at);
   D.invd = (double*)(base + parts[i_id].at);
@@ -843,10 +881,13 @@ hipError_t mfront_optimize(Mfront* m, hipStream_t s, const EdgeListDev& el, doub
       }
       hipLaunchKernelGGL(k_mf_panels, dim3(cnt), dim3(kMfThreads), (size_t)m->level_lds[h], s, D, P.level_ptr[h], it, h == 0 ? 2 * it + 1 : -1, d_res);
     }
-    for (int h = P.height; h >= 0; --h) {
-      const int cnt = P.level_ptr[h + 1] - P.level_ptr[h];
-      hipLaunchKernelGGL(k_mf_solve, dim3(cnt), dim3(kMfThreads), (size_t)m->level_solve_lds[h], s, D, P.level_ptr[h]);
-      if (m->level_big[h]) hipLaunchKernelGGL(k_mf_solve_big, dim3(cnt), dim3(kMfThreads), 0, s, D, P.level_ptr[h]);
+    if (m->fused_solve) {
+      hipLaunchKernelGGL(k_mf_solve, dim3((unsigned)P.fronts.size()), dim3(kMfThreads), (size_t)m->solve_lds_all, s, D, 0, ++m->gen);
+    } else {
+      for (int h = P.height; h >= 0; --h) {
+        const int cnt = P.level_ptr[h + 1] - P.level_ptr[h];
+        hipLaunchKernelGGL(k_mf_solve, dim3(cnt), dim3(kMfThreads), (size_t)m->level_solve_lds[h], s, D, P.level_ptr[h], 0);
+      }
     }
     hipLaunchKernelGGL(k_mf_update, dim3(ugrid), dim3(kBlock), 0, s, D, d_poses, it);
   }
