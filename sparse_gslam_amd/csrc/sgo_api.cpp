@@ -207,7 +207,7 @@ int sgo_set_graph_se2(sgo_ctx* c, int32_t V, const double* poses, const uint8_t*
       // Cholesky factorisation, one launch per level of the elimination tree (sgo_mfront.h), when the tree's critical path
       // is short enough.  SGO_MFRONT=0 keeps the multigrid PCG; SGO_MFRONT_ROWS bounds the graph size.
       bool mf_on = true;
-      int mf_rows = 32768;
+      int mf_rows = 12288;
       if (const char* s = std::getenv("SGO_MFRONT")) mf_on = std::atoi(s) != 0;
       if (const char* s = std::getenv("SGO_MFRONT_ROWS")) mf_rows = std::atoi(s);
       c->mf_why.clear();

@@ -250,6 +250,29 @@ bool mfront_analyze(int V, int n, const int* free_id, const double* poses, int E
     Dissector D(adjp, adj, n, lim.leaf);
     std::vector<int> all(n);
     std::iota(all.begin(), all.end(), 0);
+    if (n > 4096) {
+      // Larger graphs: the three top separators first (three linear passes).  The fronts of the root's children hold their own
+      // separator plus, as boundary, most of the root's: when that estimate -- two of some ten levels -- already takes half the budget the full analysis
+      // -- tens of milliseconds of every set-up of a graph that then takes the multigrid path anyway -- is not run.
+      std::vector<int> s0, sa, sb, A, B;
+      D.split(all, (size_t)n / 2, &s0);
+      std::sort(s0.begin(), s0.end());
+      for (int r = 0; r < n; ++r) {
+        if (std::binary_search(s0.begin(), s0.end(), r)) continue;
+        (r < n / 2 ? A : B).push_back(r);
+      }
+      if (A.size() > 1) D.split(A, A.size() / 2, &sa);
+      if (B.size() > 1) D.split(B, B.size() / 2, &sb);
+      const double o = 3.0 * (double)std::max(sa.size(), sb.size()), mm = o + 3.0 * (double)s0.size(), r0 = 3.0 * (double)s0.size();
+      const double est = r0 * r0 * r0 / 3.0 + o * mm * mm - mm * o * o + o * o * o / 3.0;
+      if (est > 0.5 * lim.max_crit_flops) {
+        char buf[200];
+        std::snprintf(buf, sizeof buf, "about %.0f Mflop on the critical path of the elimination tree already in its two top levels "
+                      "(separators of %zu and %zu poses): more than half of the budget of %.0f", 1e-6 * est, s0.size(), std::max(sa.size(), sb.size()), 1e-6 * lim.max_crit_flops);
+        last_why = buf;
+        continue;
+      }
+    }
     const int root = D.dissect(all);
     (void)root;
     std::vector<Node>& nodes = D.nodes;
