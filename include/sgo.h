@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define SGO_VERSION 104          /* 0.1.4: sgo_kernel_profile_samples, sgo_update_graph_se2 (incremental set-up); 0.1.3: row-owner multi-GPU mode (sgo_comm_host_allgather, sgo_debug_level0_bytes); 0.1.2: sgo_comm_init_host; 0.1.1: sgo_opts.direct_rows (took a reserved slot), sgo_solver_description */
+#define SGO_VERSION 105          /* 0.1.5: the multifrontal path for mid-size graphs (sgo_mfront_plan; sgo_solver_description names it); 0.1.4: sgo_kernel_profile_samples, sgo_update_graph_se2 (incremental set-up); 0.1.3: row-owner multi-GPU mode (sgo_comm_host_allgather, sgo_debug_level0_bytes); 0.1.2: sgo_comm_init_host; 0.1.1: sgo_opts.direct_rows (took a reserved slot), sgo_solver_description */
 #define SGO_MAX_ITERS 256        /* capacity of the per-iteration arrays in sgo_stats */
 
 /* error codes (negative).  -1 mirrors g2o's optimize() "nothing to optimise". */
@@ -83,7 +83,13 @@ typedef struct sgo_opts {
                               LDL^T (nested dissection of the chain, separators dense in LDS); 0 = never
                               (env SGO_DIRECT_ROWS); the single-step entry points keep using the PCG path.
                               The path itself works (and wins) up to ~100k chain-like poses; the default stops
-                              where two backward-stable solvers stop agreeing to 1e-6 in chi2 (kappa ~ n^2) */
+                              where two backward-stable solvers stop agreeing to 1e-6 in chi2 (kappa ~ n^2).
+                              Graphs it refuses are offered to the MID-SIZE path next (same conditions: PCG_AMG, one
+                              GPU, direct_rows > 0): a multifrontal sparse Cholesky factorisation in nested-dissection
+                              order, one launch per level of the elimination tree -- up to 12 288 free poses (env
+                              SGO_MFRONT_ROWS), at most 2.5 edges per pose, no front of more than 1 023 rows and
+                              at most 80 Mflop on the tree's critical path (env SGO_MFRONT_CRIT_MFLOP); env
+                              SGO_MFRONT=0 switches it off.  What it refuses takes the multigrid PCG */
   double pcg_tol_cap;      /* loosest RELATIVE tolerance that absolute criterion may reach (default 1e-6; 0: every
                               solve uses pcg_tol relative to its own ||b||; env SGO_PCG_TOL_CAP).  As Gauss-Newton
                               converges ||b|| falls by orders of magnitude; solving each step to 1e-8 of ITSELF
@@ -321,9 +327,10 @@ double sgo_debug_spmv0_us(sgo_ctx* ctx, int mode, int variant, int reps);
  * the iterations written (<= cap pairs), < 0 on error. */
 int sgo_debug_lanczos(sgo_ctx* ctx, double* out, int cap);
 
-/* One line naming the solver the resident graph's sgo_optimize_gn runs ("direct_ldlt: ...", "pcg_amg: L0 n=... ",
- * "pcg_block_jacobi ..."): which path a graph took, and for the direct path's refusals the reason
- * ("pcg_amg: ...; direct path not used: more separators than the dense block holds").  Never NULL. */
+/* One line naming the solver the resident graph's sgo_optimize_gn runs ("direct_ldlt: ...", "multifrontal_cholesky: ...",
+ * "pcg_amg: L0 n=... ", "pcg_block_jacobi ..."): which path a graph took, and for the refusals of the direct and the
+ * multifrontal path the reason ("pcg_amg: ...; direct path not used: more separators than the dense block holds;
+ * multifrontal path not used: 4.00 edges per free pose > 2.50").  Never NULL. */
 const char* sgo_solver_description(sgo_ctx* ctx);
 
 /* Text of the last error on this context (or, with ctx == NULL, of the last failed sgo_create /
