@@ -269,7 +269,8 @@ __global__ __launch_bounds__(kMfThreads) void k_mf_panels(MfDev M, int lvl0, int
   __shared__ double Yt[kMfPanel * kMfPanel];   // Yt[t * 16 + c] = (L11^-1)[c][t]
   __shared__ double LX[kMfPanel][kMfPanel];    // LX[j][i] = L11[i][j]: column j as wave 0 finishes it
   __shared__ double LI[kMfPanel];              // 1 / L11[j][j]
-  __shared__ int s_step, s_fail;
+  __shared__ double HX[kMfPanel / 2][kMfPanel]; // columns 8 .. 15 after pivots 0 .. 7 (wave 2 -> wave 0)
+  __shared__ int s_half, s_fail;
   if (stamp_slot >= 0 && blockIdx.x == 0 && threadIdx.x == 0) res->stamp[stamp_slot] = (unsigned long long)wall_clock64();
   if (M.flags[0]) return;
   const MfFrontDev F = M.fronts[M.level_front[lvl0 + blockIdx.x]];
@@ -280,8 +281,9 @@ __global__ __launch_bounds__(kMfThreads) void k_mf_panels(MfDev M, int lvl0, int
   double* __restrict__ A = M.arena + F.off;
   if (tid == 0) {
     s_fail = 0;
-    s_step = 0;
+    s_half = 0;
   }
+  if (tid < kMfPanel) LI[tid] = 0.0;
   long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   long long tprev = M.dbg ? (long long)__builtin_amdgcn_s_memtime() : 0;
   auto lapse = [&](int k) {
@@ -354,61 +356,112 @@ __global__ __launch_bounds__(kMfThreads) void k_mf_panels(MfDev M, int lvl0, int
   // D2: the 16 x 16 diagonal block of the panel at Pd (columns k0 .. k0 + wp): Cholesky on wave 0, the inverse of the factor on
   // wave 1, one pivot behind; L11 goes to the front's matrix, the inverse to Yt, the pivots' reciprocals to M.invd
   auto diag16 = [&](const double* Pd, int ldp, int k0, int wp) {
-  if (wave == 0) {
-    int i = lr;
-    asm volatile("" : "+v"(i));   // (opaque: or the unit-matrix selects of all 16 columns are hoisted out of the panel loop and held in registers)
-    double a[kMfPanel];
+    // Four waves share the block's 16 pivots.  Wave 0 runs the pivot chain and keeps the columns it needs next (0 .. 7, then
+    // 8 .. 15); wave 2 applies pivots 0 .. 7 to columns 8 .. 15 and hands them over; waves 1 and 3 build the inverse of the
+    // factor (columns 0 .. 4 and 5 .. 15: equal shares of the 136 updates).  The followers run one pivot behind: wave 0
+    // publishes column j (LX[j]) and THEN the pivot's reciprocal (LI[j], zero until then) -- a wave's LDS operations execute in
+    // order, so a follower that reads LI[j] and LX[j] in that order and finds LI[j] non-zero has the column too: one LDS round
+    // trip per pivot and follower, no flag, no barrier.  A pivot step is issue-bound (two v_readlane + one fma per broadcast
+    // element at ~8 cycles each): the shares keep every wave at <= ~30 instructions per pivot.
+    constexpr int kHalf = kMfPanel / 2, kInvCut = 5;
+    auto follow = [&](int j, int i, double& lij, double& inv) {   // column j and 1 / L[j][j] as soon as wave 0 has them
+      do {
+        inv = __hip_atomic_load(&LI[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // (relaxed LDS atomics: plain ds_read / ds_write;
+        lij = __hip_atomic_load(&LX[j][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // `volatile` would become FLAT accesses with sc0 sc1 and a vmcnt wait)
+      } while (inv == 0.0);
+    };
+    if (wave == 0) {
+      int i = lr;
+      asm volatile("" : "+v"(i));   // (opaque: or the unit-matrix selects of all 16 columns are hoisted out of the panel loop and held in registers)
+      double a[kMfPanel];
 #pragma unroll
-    for (int c = 0; c < kMfPanel; ++c) a[c] = (i < wp && c < wp) ? Pd[c * ldp + i] : (c == i ? 1.0 : 0.0);
-    bool ok = true;
+      for (int c = 0; c < kHalf; ++c) a[c] = (i < wp && c < wp) ? Pd[c * ldp + i] : (c == i ? 1.0 : 0.0);
 #pragma unroll
-    for (int j = 0; j < kMfPanel; ++j) {
-      const double d = mf_readlane(a[j], j);
-      ok = ok && d > 0.0 && isfinite(d);
-      const double inv = mf_rsqrt(d);
-      const double lij = a[j] * inv;   // lane j: sqrt(d)
-      a[j] = lij;
-      // (a wave's LDS operations execute in order, so the other wave sees the column before the counter: no waiting here --
-      // the fence only keeps the compiler from moving the stores)
-      if (lane < kMfPanel) LX[j][i] = lij;
-      if (lane == 0) LI[j] = inv;
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __hip_atomic_store(&s_step, j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      for (int c = kHalf; c < kMfPanel; ++c) a[c] = 0.0;
+      bool ok = true;
 #pragma unroll
-      for (int c = j + 1; c < kMfPanel; ++c) a[c] -= lij * mf_readlane(lij, c);
-      __builtin_amdgcn_sched_barrier(0);   // (pivots are sequential anyway; without it the scheduler hoists the broadcasts of several steps and spills scalar registers)
-    }
-    if (lane < wp) {
+      for (int j = 0; j < kMfPanel; ++j) {
+        if (j == kHalf) {   // columns 8 .. 15 with pivots 0 .. 7 applied, from wave 2
+          while (__hip_atomic_load(&s_half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) {
+          }
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-      for (int c = 0; c < kMfPanel; ++c)
-        if (c <= i) A[(size_t)(k0 + c) * ld + k0 + i] = a[c];
-    }
-    if (!ok && lane == 0) s_fail = 1;
-  } else if (wave == 1) {
-    int i = lr;
-    asm volatile("" : "+v"(i));   // (opaque: or the unit-matrix selects of all 16 columns are hoisted out of the panel loop and held in registers)
-    double y[kMfPanel];
+          for (int c = kHalf; c < kMfPanel; ++c) a[c] = HX[c - kHalf][i];
+        }
+        const double d = mf_readlane(a[j], j);
+        ok = ok && d > 0.0 && isfinite(d);
+        double inv = mf_rsqrt(d);
+        if (!(inv > 0.0) || !isfinite(inv)) inv = 1.0;   // (a failed pivot: the followers wait for a NON-ZERO reciprocal; the call fails after the barrier)
+        const double lij = a[j] * inv;   // lane j: sqrt(d)
+        a[j] = lij;
+        if (lane < kMfPanel) LX[j][i] = lij;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // (compiler ordering only: the hardware keeps a wave's LDS stores in order)
+        if (lane == 0) __hip_atomic_store(&LI[j], inv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #pragma unroll
-    for (int c = 0; c < kMfPanel; ++c) y[c] = (c == i) ? 1.0 : 0.0;
-    double myinv = 1.0;
-#pragma unroll
-    for (int j = 0; j < kMfPanel; ++j) {
-      while (__hip_atomic_load(&s_step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= j) {
+        for (int c = j + 1; c < (j < kHalf ? kHalf : kMfPanel); ++c) a[c] -= lij * mf_readlane(lij, c);
+        __builtin_amdgcn_sched_barrier(0);   // (pivots are sequential anyway; without it the scheduler hoists the broadcasts of several steps and spills scalar registers)
       }
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      const double inv = LI[j];
-      const double lm = (i > j) ? LX[j][i] * inv : 0.0;
-      if (i == j) myinv = inv;
+      if (lane < wp) {
 #pragma unroll
-      for (int c = 0; c <= j; ++c) y[c] -= lm * mf_readlane(y[c], j);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    if (lane < kMfPanel) {
+        for (int c = 0; c < kMfPanel; ++c)
+          if (c <= i) A[(size_t)(k0 + c) * ld + k0 + i] = a[c];
+      }
+      if (!ok && lane == 0) s_fail = 1;
+    } else if (wave == 1 || wave == 3) {
+      // the inverse of the factor: z_i = e_i - sum_{t < i} L[i][t] / L[t][t] z_t (row t final after pivot t), Y[i] = z_i / L[i][i]
+      int i = lr;
+      asm volatile("" : "+v"(i));
+      const bool lowc = wave == 1;          // this wave's columns: [0, kInvCut) or [kInvCut, 16)
+      double y[kMfPanel];
 #pragma unroll
-      for (int c = 0; c < kMfPanel; ++c) Yt[c * kMfPanel + i] = (c <= i) ? y[c] * myinv : 0.0;
-      if (i < wp) M.invd[3 * (size_t)F.e0 + k0 + i] = myinv;
+      for (int c = 0; c < kMfPanel; ++c) y[c] = (c == i) ? 1.0 : 0.0;
+      double myinv = 1.0;
+#pragma unroll
+      for (int j = 0; j < kMfPanel; ++j) {
+        double lij, inv;
+        follow(j, i, lij, inv);
+        const double lm = (i > j) ? lij * inv : 0.0;
+        if (i == j) myinv = inv;
+        if (lowc) {
+#pragma unroll
+          for (int c = 0; c <= (j < kInvCut - 1 ? j : kInvCut - 1); ++c) y[c] -= lm * mf_readlane(y[c], j);
+        } else {
+#pragma unroll
+          for (int c = kInvCut; c <= j; ++c) y[c] -= lm * mf_readlane(y[c], j);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (lane < kMfPanel) {
+        if (lowc) {
+#pragma unroll
+          for (int c = 0; c < kInvCut; ++c) Yt[c * kMfPanel + i] = (c <= i) ? y[c] * myinv : 0.0;
+          if (i < wp) M.invd[3 * (size_t)F.e0 + k0 + i] = myinv;
+        } else {
+#pragma unroll
+          for (int c = kInvCut; c < kMfPanel; ++c) Yt[c * kMfPanel + i] = (c <= i) ? y[c] * myinv : 0.0;
+        }
+      }
+    } else if (wave == 2) {
+      int i = lr;
+      asm volatile("" : "+v"(i));
+      double bq[kHalf];
+#pragma unroll
+      for (int c = 0; c < kHalf; ++c) bq[c] = (i < wp && c + kHalf < wp) ? Pd[(c + kHalf) * ldp + i] : (c + kHalf == i ? 1.0 : 0.0);
+#pragma unroll
+      for (int j = 0; j < kHalf; ++j) {
+        double lij, inv;
+        follow(j, i, lij, inv);
+#pragma unroll
+        for (int c = 0; c < kHalf; ++c) bq[c] -= lij * mf_readlane(lij, c + kHalf);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (lane < kMfPanel) {
+#pragma unroll
+        for (int c = 0; c < kHalf; ++c) HX[c][i] = bq[c];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __hip_atomic_store(&s_half, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
-  }
   };
   // ---- D. own columns in panels of 16
   const int ldp = (m + 2) | 1;
@@ -441,7 +494,8 @@ __global__ __launch_bounds__(kMfThreads) void k_mf_panels(MfDev M, int lvl0, int
       }
       return;
     }
-    if (tid == 0) s_step = 0;   // (read again only after the barrier that ends the next D1)
+    if (tid == 0) s_half = 0;   // (both are read again only after the barrier that ends the next D1)
+    if (tid < kMfPanel) LI[tid] = 0.0;
     // D3: rows below the diagonal block, straight to the front's matrix
     {
       const int R2 = R - wp;
