@@ -903,13 +903,16 @@ Mfront* mfront_create(hipStream_t s, int V, int n, const int* free_id, const dou
   D.flags = (int*)(base + parts[i_fl].at);
   D.arena = (double*)(base + parts[i_ar].at);
   D.dbg = debug ? (long long*)(base + parts[i_db].at) : nullptr;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mf_panels), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)sizeof(double) * kMfPanel * ((kMfMaxDim + 2) | 1));
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mf_solve), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)sizeof(double) * kMfSolveOwn * (kMfSolveOwn + 1) / 2);
-    attr_set = true;
+  // (per call: the attribute belongs to the current device's copy of the kernel, and a process may hold contexts on several)
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mf_panels), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)sizeof(double) * kMfPanel * ((kMfMaxDim + 2) | 1)) != hipSuccess ||
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mf_solve), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)sizeof(double) * kMfSolveOwn * (kMfSolveOwn + 1) / 2) != hipSuccess) {
+    (void)hipGetLastError();
+    hipFree(M->buf);
+    M->buf = nullptr;
+    if (why) *why = "the device does not grant the kernels' dynamic LDS";
+    return nullptr;
   }
   return M.release();
 }
