@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <memory>
 #include <vector>
 
 #include "sgo_device.h"
@@ -743,7 +744,7 @@ Mfront* mfront_create(hipStream_t s, int V, int n, const int* free_id, const dou
   lim.max_rows = max_rows;
   if (const char* e = std::getenv("SGO_MFRONT_LEAF")) lim.leaf = std::max(4, std::atoi(e));
   if (const char* e = std::getenv("SGO_MFRONT_CRIT_MFLOP")) lim.max_crit_flops = 1e6 * std::atof(e);
-  std::unique_ptr<Mfront> M(new Mfront);
+  std::unique_ptr<Mfront, void (*)(Mfront*)> M(new Mfront, &mfront_destroy);   // (frees the device buffer on every early return)
   if (!mfront_analyze(V, n, free_id, poses, E, ei, ej, lim, &M->plan, why)) return nullptr;
   const MfPlan& P = M->plan;
   M->info.n = n;
@@ -909,8 +910,6 @@ Mfront* mfront_create(hipStream_t s, int V, int n, const int* free_id, const dou
       hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mf_solve), hipFuncAttributeMaxDynamicSharedMemorySize,
                           (int)sizeof(double) * kMfSolveOwn * (kMfSolveOwn + 1) / 2) != hipSuccess) {
     (void)hipGetLastError();
-    hipFree(M->buf);
-    M->buf = nullptr;
     if (why) *why = "the device does not grant the kernels' dynamic LDS";
     return nullptr;
   }
