@@ -160,6 +160,49 @@ def reference_usage_session(device: int, V: int = 1000, closures: int = 30):
             "final_chi2_rel_err_vs_oracle_max": worst}
 
 
+def midsize_usage_session(device: int, name: str = "C3s", last_n: int = 25):
+    """The same flow at the size of the reference's LARGEST graphs (mit-killian: 5 489 keyframe poses / 7 629 edges, C3s): the
+    last `last_n` accepted closures of the run -- the graph up to each closure's later endpoint is re-initialised and optimised
+    with optimize(20), as slc.cpp:286-287 does.  Such graphs take the multifrontal path: per closure the
+    symbolic analysis + upload (sgo_set_graph_se2), 20 numeric factorisations + solves, the read-back; the CPU oracle beside it
+    (its own analysis + 20 x sparse LDL^T, one thread)."""
+    from oracle import c_oracle
+    from sparse_gslam_amd import capi, synth
+    g = synth.config(name)
+    V = g.V
+    odo, clo = np.arange(V - 1), np.arange(V - 1, g.E)
+    clo = clo[np.argsort(np.maximum(g.ei[clo], g.ej[clo]), kind="stable")]
+    pg, pc = g.poses.copy(), g.poses.copy()
+    tg, tc, ts, worst, desc = [], [], [], 0.0, ""
+    with capi.Optimizer(device) as opt:
+        for k in range(len(clo) - last_n - 1, len(clo)):
+            c = clo[k]
+            last = int(max(g.ei[c], g.ej[c]))
+            edges = np.concatenate([odo[:last], clo[: k + 1]])
+            edges = edges[(g.ei[edges] <= last) & (g.ej[edges] <= last)]
+            sl = slice(0, last + 1)
+            a = lambda P: (P[sl], g.fixed[sl], g.ei[edges], g.ej[edges], g.meas[edges], g.info[edges], g.phi[edges])  # noqa: E731
+            t = time.perf_counter()
+            opt.set_graph(*a(pg))
+            t1 = time.perf_counter()
+            done, st = opt.optimize(20)
+            pg[sl] = opt.get_poses()
+            tg.append(time.perf_counter() - t)
+            ts.append(t1 - t)
+            desc = opt.solver_description().split(":")[0]
+            t = time.perf_counter()
+            P, ost = c_oracle.gauss_newton(*a(pc), iters=20)
+            pc[sl] = P
+            tc.append(time.perf_counter() - t)
+            worst = max(worst, abs(st["chi2"][-1] - ost["chi2"][-1]) / ost["chi2"][-1])
+    tg, tc, ts = 1e3 * np.array(tg[1:]), 1e3 * np.array(tc[1:]), 1e3 * np.array(ts[1:])   # the first call carries one-time initialisation
+    return {"workload": f"{name}: the last {last_n} closures of the run (graphs of {int(max(g.ei[clo[-last_n]], g.ej[clo[-last_n]])) + 1} "
+                        f"to {V} poses), sgo_set_graph_se2 + optimize(20) + read-back after each",
+            "solver": desc, "closures_timed": int(tg.size), "ms_per_closure_median": float(np.median(tg)),
+            "set_graph_ms_median": float(np.median(ts)), "cpu_oracle_ms_per_closure_median": float(np.median(tc)),
+            "cpu_oracle_threads": 1, "final_chi2_rel_err_vs_oracle_max": worst}
+
+
 def incremental_session(device: int, V: int, E: int, seed: int, steps: int = 12, chain: int = 25, iters: int = 20, compare: bool = True):
     """The reference's usage pattern at the BENCH workload's size (slc.cpp:205-226, :272-287): a resident graph of V poses /
     E edges, then `steps` accepted loop closures, each appending `chain` new poses with their odometry edges and one
@@ -486,6 +529,9 @@ def main():
         note("cpu baseline")
         out["cpu_baseline"] = cpu_baseline(g, args.iters)
         out["reference_usage_session"] = reference_usage_session(local_rank)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.config == "C3s":
+        note("mid-size usage session")
+        out["midsize_usage_session"] = midsize_usage_session(local_rank, args.config)
     if rank == 0 and world == 1 and not args.no_roofline and args.config in ("C2", "C4"):
         note("incremental session")
         out["incremental_session"] = incremental_session(local_rank, g.V, g.E, g.meta["seed"], iters=args.iters)

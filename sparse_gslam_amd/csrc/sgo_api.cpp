@@ -214,7 +214,7 @@ int sgo_set_graph_se2(sgo_ctx* c, int32_t V, const double* poses, const uint8_t*
       if (!c->direct && mf_on && mf_rows > 0) {
         std::string merr;
         const double tm0 = wall_s();
-        c->mf = mfront_create(c->stream, V, c->n, c->free_id.data(), poses, E, ei, ej, mf_rows, &c->mf_why, &merr);
+        c->mf = mfront_create(c->stream, &c->graph_arena, V, c->n, c->free_id.data(), poses, E, ei, ej, mf_rows, &c->mf_order_hint, &c->mf_why, &merr);
         if (!c->mf && !merr.empty()) {
           c->err = merr;
           free_graph(c);

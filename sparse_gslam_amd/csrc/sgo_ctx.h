@@ -124,6 +124,7 @@ struct sgo_ctx {
   std::string direct_why;         // why the last graph did not qualify for it
   Mfront* mf = nullptr;           // mid-size path: optimize() through the multifrontal factorisation (sgo_mfront.h)
   std::string mf_why;             // why the last graph did not qualify for it
+  int mf_order_hint = -1;         // row order | poses << 1 of the last graph that took it (the next set-up of a grown graph analyses that order alone)
   DirectResult* d_dres = nullptr;
   DirectResult* h_dres = nullptr; // pinned
   double* d_zparts = nullptr;     // [2][kMaxPartials] partials of r.z from the cycle's last kernel

@@ -77,6 +77,7 @@ struct MfLimits {
   long long max_arena_bytes = (long long)1 << 30;
   double max_degree = 2.5;           // edges between free poses per free pose: above it the graph is refused unanalysed
   int both_orders_rows = 8192;       // up to this size both row orders are analysed, above it only the Hilbert order
+  int only_kind = -1;                // >= 0: analyse this row order alone (the caller knows which one wins on this graph's kind)
 };
 
 // Host analysis.  false with *why set: the graph does not qualify.
@@ -92,8 +93,11 @@ struct MfrontInfo {
 };
 
 // nullptr with *why set: the graph does not qualify; nullptr with *err set: HIP failure.
-Mfront* mfront_create(hipStream_t s, int V, int n, const int* free_id, const double* poses, int E, const int* ei, const int* ej,
-                      int max_rows, std::string* why, std::string* err);
+// Device arrays come out of `arena` (the context's per-graph arena: rewound, not freed, by the next set-up -- the reference
+// re-initialises after every closure).  *order_hint (in / out, -1: none): the row order the previous graph of this context
+// chose; when the new graph has about as many poses that order is analysed alone.
+Mfront* mfront_create(hipStream_t s, DevArena* arena, int V, int n, const int* free_id, const double* poses, int E, const int* ei,
+                      const int* ej, int max_rows, int* order_hint, std::string* why, std::string* err);
 void mfront_destroy(Mfront* m);
 const MfrontInfo& mfront_info(const Mfront* m);
 // iters x { edges + chi2, factorise (levels up), substitute (levels down), update } + the closing chi2 on the stream; outputs

@@ -733,19 +733,27 @@ struct Mfront {
 const MfrontInfo& mfront_info(const Mfront* m) { return m->info; }
 
 void mfront_destroy(Mfront* m) {
-  if (!m) return;
-  if (m->buf) hipFree(m->buf);
-  delete m;
+  delete m;   // (the device arrays belong to the caller's arena)
 }
 
-Mfront* mfront_create(hipStream_t s, int V, int n, const int* free_id, const double* poses, int E, const int* ei, const int* ej,
-                      int max_rows, std::string* why, std::string* err) {
+Mfront* mfront_create(hipStream_t s, DevArena* arena, int V, int n, const int* free_id, const double* poses, int E, const int* ei,
+                      const int* ej, int max_rows, int* order_hint, std::string* why, std::string* err) {
   MfLimits lim;
   lim.max_rows = max_rows;
+  // order_hint: kind | poses << 1 of the context's previous graph
+  if (order_hint && *order_hint >= 0) {
+    const int prev_n = *order_hint >> 1;
+    if (std::abs(prev_n - n) * 10 <= prev_n) lim.only_kind = *order_hint & 1;
+  }
   if (const char* e = std::getenv("SGO_MFRONT_LEAF")) lim.leaf = std::max(4, std::atoi(e));
   if (const char* e = std::getenv("SGO_MFRONT_CRIT_MFLOP")) lim.max_crit_flops = 1e6 * std::atof(e);
   std::unique_ptr<Mfront, void (*)(Mfront*)> M(new Mfront, &mfront_destroy);   // (frees the device buffer on every early return)
-  if (!mfront_analyze(V, n, free_id, poses, E, ei, ej, lim, &M->plan, why)) return nullptr;
+  if (!mfront_analyze(V, n, free_id, poses, E, ei, ej, lim, &M->plan, why)) {
+    if (lim.only_kind < 0) return nullptr;
+    lim.only_kind = -1;   // the hinted order no longer qualifies: the full analysis has the last word
+    if (!mfront_analyze(V, n, free_id, poses, E, ei, ej, lim, &M->plan, why)) return nullptr;
+  }
+  if (order_hint) *order_hint = M->plan.order_kind | (n << 1);
   const MfPlan& P = M->plan;
   M->info.n = n;
   M->info.fronts = (int)P.fronts.size();
@@ -857,9 +865,9 @@ Mfront* mfront_create(hipStream_t s, int V, int n, const int* free_id, const dou
   const bool debug = std::getenv("SGO_MFRONT_DEBUG") != nullptr;
   const size_t i_db = add(nullptr, debug ? sizeof(long long) * 8 * (size_t)nf : 0);
   const size_t i_ar = add(nullptr, sizeof(double) * (size_t)P.arena_doubles);
-  hipError_t he = hipMalloc(&M->buf, total);
-  if (he != hipSuccess) {
-    M->buf = nullptr;
+  hipError_t he = hipSuccess;
+  M->buf = arena->take(total);
+  if (!M->buf) {
     if (why) *why = "frontal matrices do not fit the device (" + std::to_string(total >> 20) + " MiB)";
     (void)hipGetLastError();
     return nullptr;

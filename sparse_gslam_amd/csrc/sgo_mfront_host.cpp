@@ -198,6 +198,7 @@ bool mfront_analyze(int V, int n, const int* free_id, const double* poses, int E
   bool have = false;
   std::string last_why;
   for (int kind = 0; kind < ((n <= lim.both_orders_rows) ? 2 : 1); ++kind) {
+    if (lim.only_kind >= 0 && kind != lim.only_kind) continue;
     // ---- row order
     std::vector<int> row_vertex(n), row_of((size_t)V, -1);
     if (kind == 0) {
