@@ -10,15 +10,16 @@
 //     separator = a MINIMUM vertex cover of the cut (Koenig's theorem on the bipartite cut graph), leaves of <= 32 poses --,
 //     the fronts' row structures, the assembly lists (every edge goes to the front of its first-eliminated endpoint) and the
 //     extend-add maps, the fronts of equal height gathered into levels.
-//   * Device, per Gauss-Newton iteration: one launch per LEVEL of the tree for the factorisation (one workgroup per front:
-//     assembly from the per-edge terms, extend-add of the children's update matrices, left-looking partial Cholesky in
-//     16-column panels -- panel update and Schur complement on the fp64 matrix cores, v_mfma_f64_16x16x4_f64 -- with the
-//     right-hand side as the front's last ROW, so the forward substitution rides along), one launch per level for the
-//     backward substitution, one for the edges (error, Jacobians, 6x6 element and chi2), one for the update.  No atomics on
-//     floating-point data; every sum has a fixed order.
+//   * Device, per Gauss-Newton iteration: two launches per LEVEL of the tree for the factorisation -- a parent's matrix is
+//     gathered tile by tile from its children by many workgroups, the children's Schur complements formed on the fly on the
+//     fp64 matrix cores (v_mfma_f64_16x16x4_f64: no update matrix is stored); then one workgroup per front adds the edges'
+//     terms and factorises the own columns left-looking in 16-column panels, with the right-hand side as the front's last
+//     ROW, so the forward substitution rides along --, one launch per level for the backward substitution, one for the edges
+//     (error, Jacobians, 6x6 element and chi2), one for the update.  No atomics on floating-point data; every sum has a fixed
+//     order.
 // A graph qualifies when the critical path of its tree (the largest front of every level) is short enough and no front
 // outgrows a workgroup's LDS panel; otherwise the caller keeps the multigrid PCG (C2's Manhattan world with four edges per
-// pose has 1 100-row fronts and 0.9 Gflop on the critical path: not for one workgroup per front).
+// pose has 580-row fronts and 0.24 Gflop on the critical path: not for one workgroup per front).
 #pragma once
 #include <cstdint>
 #include <string>

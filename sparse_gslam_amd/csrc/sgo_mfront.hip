@@ -2,16 +2,19 @@
 //   k_mf_edges    EdgeSE2::computeError + linearizeOplus + robust weighting, the 6x6 element of every edge (D_ii, D_jj, H_ij,
 //                 b_i, b_j) and chi2 / robust chi2 (g2o: OptimizationAlgorithmGaussNewton::solve -> computeActiveErrors,
 //                 linearizeOplus, constructQuadraticForm; src/sparse_gslam/src/graphs.cpp:9-37 chooses the algorithm)
-//   k_mf_factor   one launch per level of the elimination tree, one workgroup per front: assembly, extend-add, partial
-//                 Cholesky (LinearSolverEigen / CHOLMOD's numeric factorisation, graphs.cpp:19)
+//   k_mf_merge    one launch per level >= 1, thousands of waves: a parent's matrix gathered per 16 x 16 tile from its children,
+//                 whose Schur complements are formed on the fly (fp64 matrix cores)                  } LinearSolverEigen /
+//   k_mf_panels   one launch per level, one workgroup per front: the edges' contributions, then the own  } CHOLMOD's numeric
+//                 columns factorised in panels of 16                                                  } factorisation, graphs.cpp:19
 //   k_mf_solve    one launch per level, top-down: backward substitution
 //   k_mf_update   SparseOptimizer::update -> VertexSE2::oplusImpl
 // A front's matrix is column-major with leading dimension ld, lower triangle, rows 0 .. m-1 = its poses' scalar rows (own
 // first, then boundary, both in elimination order) and row m = the right-hand side: the Cholesky factor of [[H, b], [b^T, .]]
 // carries L^-1 b in its last row, and the Schur complement's last row is the children's contribution to the parent's
-// right-hand side.  Bounds: assembly and extend-add are L2 traffic (a front is read and written once), the panel loop is a
-// chain of barrier-separated steps (16-column panels: update on the matrix cores -> 16x16 Cholesky + inverse in one wave's
-// registers -> panel solve on the matrix cores), the Schur complement is fp64 MFMA work on operands that sit in L2.
+// right-hand side.  Bounds: the merge is L2 operand traffic spread over the chip; the panel loop is a chain of
+// barrier-separated steps (update on the matrix cores, operands from L2 at ~15 B per cycle of the CU's address path -> 16 x 16
+// Cholesky + inverse on four waves' registers, bound by the pivot chain's latency -> panel solve on the matrix cores);
+// the substitution is launch floor + two memory round trips per level.  Measurements: DESIGN.md section 5c, NOTES.md section 10.
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
