@@ -111,6 +111,17 @@ def test_two_runs_are_bitwise_identical():
     assert a[2]["chi2"] == b[2]["chi2"] and np.array_equal(a[3], b[3])
 
 
+def test_single_launch_substitution_option_is_the_same_arithmetic(monkeypatch):
+    """SGO_MFRONT_FUSED_SOLVE=1: the backward substitution of the whole tree as ONE launch, fronts waiting for their parents'
+    flags (measured slower than one launch per level -- DESIGN.md section 5c -- and kept as an option): same sums in the same
+    order, bit for bit."""
+    g = chain_graph(2500, 700, seed=12)
+    a = run(g.arrays())
+    monkeypatch.setenv("SGO_MFRONT_FUSED_SOLVE", "1")
+    b = run(g.arrays())
+    assert a[1] == b[1] == 20 and a[2]["chi2"] == b[2]["chi2"] and np.array_equal(a[3], b[3])
+
+
 def test_duplicate_edges_fixed_poses_a_hub_and_edges_between_fixed_poses():
     """Several edges on one pair (summed in edge order), a pose with many incident closures, fixed poses in the middle
     of the chain (their edges contribute to the free endpoint's diagonal block and right-hand side only), edges between
