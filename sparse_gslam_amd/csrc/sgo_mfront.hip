@@ -57,6 +57,7 @@ struct MfDev {
   double* elem = nullptr;      // [E][kElemStride]
   double* x = nullptr;         // [3 n] by elimination position
   double* invd = nullptr;      // [3 n] 1 / L[c][c] of every eliminated scalar row (k_mf_panels), for the substitution
+  double* yinv = nullptr;      // [3 n][16] row i of the inverse of its 16 x 16 diagonal block's factor (zeros right of the diagonal)
   double* partials = nullptr;  // [2][kMaxPartials]
   long long* dbg = nullptr;    // diagnostic runs (SGO_MFRONT_DEBUG): [nfront][8] s_memtime cycles of the factor kernel's phases
   int* flags = nullptr;        // [0] fail (1 not positive definite, 2 non-finite update)  [1] iteration of the failure
@@ -438,11 +439,19 @@ __global__ __launch_bounds__(kMfThreads) void k_mf_panels(MfDev M, int lvl0, int
       if (lane < kMfPanel) {
         if (lowc) {
 #pragma unroll
-          for (int c = 0; c < kInvCut; ++c) Yt[c * kMfPanel + i] = (c <= i) ? y[c] * myinv : 0.0;
+          for (int c = 0; c < kInvCut; ++c) {
+            const double v = (c <= i) ? y[c] * myinv : 0.0;
+            Yt[c * kMfPanel + i] = v;
+            if (i < wp) M.yinv[(3 * (size_t)F.e0 + k0 + i) * kMfPanel + c] = v;
+          }
           if (i < wp) M.invd[3 * (size_t)F.e0 + k0 + i] = myinv;
         } else {
 #pragma unroll
-          for (int c = kInvCut; c < kMfPanel; ++c) Yt[c * kMfPanel + i] = (c <= i) ? y[c] * myinv : 0.0;
+          for (int c = kInvCut; c < kMfPanel; ++c) {
+            const double v = (c <= i) ? y[c] * myinv : 0.0;
+            Yt[c * kMfPanel + i] = v;
+            if (i < wp) M.yinv[(3 * (size_t)F.e0 + k0 + i) * kMfPanel + c] = v;
+          }
         }
       }
     } else if (wave == 2) {
@@ -544,7 +553,8 @@ constexpr int kMfSolveCols = (kMfSolveOwn + kMfNW - 1) / kMfNW;   // columns per
 __global__ __launch_bounds__(kMfThreads) void k_mf_solve(MfDev M, int lvl0, int gen) {
   extern __shared__ double Ls[];               // row r of L11 at r (r + 1) / 2
   __shared__ double xs[kMfMaxDim + 1];
-  __shared__ double tt[kMfSolveOwn], dinv[kMfSolveOwn];
+  __shared__ double tt[kMfSolveOwn];
+  __shared__ double Yl[kMfSolveOwn * kMfPanel];   // the inverses of the diagonal blocks' factors, row by row
   __shared__ double Ld[kMfPanel * (kMfPanel + 1)];
   const int f = gen > 0 ? M.solve_order[blockIdx.x] : M.level_front[lvl0 + blockIdx.x];
   const MfFrontDev F = M.fronts[f];
@@ -592,7 +602,7 @@ __global__ __launch_bounds__(kMfThreads) void k_mf_solve(MfDev M, int lvl0, int 
       }
       yc[q] = (c < s3 && lane == 0) ? col[m] : 0.0;
     }
-    if (tid < s3) dinv[tid] = M.invd[3 * (size_t)F.e0 + tid];
+    for (int e = tid; e < s3 * kMfPanel; e += kMfThreads) Yl[e] = M.yinv[3 * (size_t)F.e0 * kMfPanel + e];
     for (int c = wave; c < s3; c += kMfNW)
       for (int r = c + lane; r < s3; r += 64) Ls[r * (r + 1) / 2 + c] = A[(size_t)c * ld + r];
     wait_parent();
@@ -617,17 +627,13 @@ __global__ __launch_bounds__(kMfThreads) void k_mf_solve(MfDev M, int lvl0, int 
     const int i = lane & 15;
     for (int c0 = ((s3 - 1) / kMfPanel) * kMfPanel; c0 >= 0; c0 -= kMfPanel) {
       const int wp = min(kMfPanel, s3 - c0);
-      double t = (i < wp) ? tt[c0 + i] : 0.0;
-      const double di = (i < wp) ? dinv[c0 + i] : 0.0;
+      // x_blk = L_dd^-T t_blk with the block's inverse from the factorisation: 16 independent broadcast-fma pairs per lane
+      // instead of a chain of 16 dependent steps
+      const double tv = (i < wp) ? tt[c0 + i] : 0.0;
+      double t = 0.0;
 #pragma unroll
-      for (int r = kMfPanel - 1; r >= 0; --r) {
-        if (r < wp) {   // uniform
-          const int rr = c0 + r;
-          const double xr = mf_readlane(t * di, r);
-          if (i < r) t -= Ls[rr * (rr + 1) / 2 + c0 + i] * xr;
-          else if (i == r) t = xr;
-        }
-      }
+      for (int r = 0; r < kMfPanel; ++r)
+        if (r < wp) t += Yl[(c0 + r) * kMfPanel + i] * mf_readlane(tv, r);   // (L^-1)[r][i] is zero for i > r
       if (lane < wp) {
         xs[c0 + lane] = t;
         M.x[3 * (size_t)F.e0 + c0 + lane] = t;
@@ -863,6 +869,7 @@ Mfront* mfront_create(hipStream_t s, DevArena* arena, int V, int n, const int* f
   const size_t i_el = add(nullptr, sizeof(double) * kElemStride * (size_t)std::max(E, 1));
   const size_t i_x = add(nullptr, sizeof(double) * 3 * (size_t)n);
   const size_t i_id = add(nullptr, sizeof(double) * 3 * (size_t)n);
+  const size_t i_yi = add(nullptr, sizeof(double) * 3 * (size_t)n * kMfPanel);
   const size_t i_pt = add(nullptr, sizeof(double) * 2 * kMaxPartials);
   const size_t i_fl = add(nullptr, sizeof(int) * 8);
   const bool debug = std::getenv("SGO_MFRONT_DEBUG") != nullptr;
@@ -911,6 +918,7 @@ Mfront* mfront_create(hipStream_t s, DevArena* arena, int V, int n, const int* f
   D.elem = (double*)(base + parts[i_el].at);
   D.x = (double*)(base + parts[i_x].at);
   D.invd = (double*)(base + parts[i_id].at);
+  D.yinv = (double*)(base + parts[i_yi].at);
   D.partials = (double*)(base + parts[i_pt].at);
   D.flags = (int*)(base + parts[i_fl].at);
   D.arena = (double*)(base + parts[i_ar].at);
