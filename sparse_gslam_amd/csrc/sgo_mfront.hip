@@ -368,7 +368,7 @@ __global__ __launch_bounds__(kMfThreads) void k_mf_panels(MfDev M, int lvl0, int
     // order, so a follower that reads LI[j] and LX[j] in that order and finds LI[j] non-zero has the column too: one LDS round
     // trip per pivot and follower, no flag, no barrier.  A pivot step is issue-bound (two v_readlane + one fma per broadcast
     // element at ~8 cycles each): the shares keep every wave at <= ~30 instructions per pivot.
-    constexpr int kHalf = kMfPanel / 2, kInvCut = 5;
+    constexpr int kHalf = kMfPanel / 2, kInvCut = 5, kHand = 6;
     auto follow = [&](int j, int i, double& lij, double& inv) {   // column j and 1 / L[j][j] as soon as wave 0 has them
       do {
         inv = __hip_atomic_load(&LI[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // (relaxed LDS atomics: plain ds_read / ds_write;
@@ -386,12 +386,19 @@ __global__ __launch_bounds__(kMfThreads) void k_mf_panels(MfDev M, int lvl0, int
       bool ok = true;
 #pragma unroll
       for (int j = 0; j < kMfPanel; ++j) {
-        if (j == kHalf) {   // columns 8 .. 15 with pivots 0 .. 7 applied, from wave 2
+        if (j == kHalf) {
+          // columns 8 .. 15 with pivots 0 .. kHand-1 applied, from wave 2 -- which finished them two pivots ago (a hand-over
+          // after pivot 7 stalled this wave for 1.5 k cycles per panel: the follower is always a pivot behind) --, then the
+          // pivots kHand .. 7 this wave has made since (their columns are still in a[])
           while (__hip_atomic_load(&s_half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) {
           }
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
           for (int c = kHalf; c < kMfPanel; ++c) a[c] = HX[c - kHalf][i];
+#pragma unroll
+          for (int jj = kHand; jj < kHalf; ++jj)
+#pragma unroll
+            for (int c = kHalf; c < kMfPanel; ++c) a[c] -= a[jj] * mf_readlane(a[jj], c);
         }
         const double d = mf_readlane(a[j], j);
         ok = ok && d > 0.0 && isfinite(d);
@@ -406,12 +413,7 @@ __global__ __launch_bounds__(kMfThreads) void k_mf_panels(MfDev M, int lvl0, int
         for (int c = j + 1; c < (j < kHalf ? kHalf : kMfPanel); ++c) a[c] -= lij * mf_readlane(lij, c);
         __builtin_amdgcn_sched_barrier(0);   // (pivots are sequential anyway; without it the scheduler hoists the broadcasts of several steps and spills scalar registers)
       }
-      if (lane < wp) {
-#pragma unroll
-        for (int c = 0; c < kMfPanel; ++c)
-          if (c <= i) A[(size_t)(k0 + c) * ld + k0 + i] = a[c];
-      }
-      if (!ok && lane == 0) s_fail = 1;
+      if (!ok && lane == 0) s_fail = 1;   // (the factor block goes to memory from LX, by wave 2)
     } else if (wave == 1 || wave == 3) {
       // the inverse of the factor: z_i = e_i - sum_{t < i} L[i][t] / L[t][t] z_t (row t final after pivot t), Y[i] = z_i / L[i][i]
       int i = lr;
@@ -461,7 +463,7 @@ __global__ __launch_bounds__(kMfThreads) void k_mf_panels(MfDev M, int lvl0, int
 #pragma unroll
       for (int c = 0; c < kHalf; ++c) bq[c] = (i < wp && c + kHalf < wp) ? Pd[(c + kHalf) * ldp + i] : (c + kHalf == i ? 1.0 : 0.0);
 #pragma unroll
-      for (int j = 0; j < kHalf; ++j) {
+      for (int j = 0; j < kHand; ++j) {
         double lij, inv;
         follow(j, i, lij, inv);
 #pragma unroll
@@ -474,6 +476,13 @@ __global__ __launch_bounds__(kMfThreads) void k_mf_panels(MfDev M, int lvl0, int
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __hip_atomic_store(&s_half, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      // the finished factor block to the front's matrix, column by column as wave 0 publishes them (off wave 0's path)
+#pragma unroll
+      for (int c = 0; c < kMfPanel; ++c) {
+        double lic, inv;
+        follow(c, i, lic, inv);
+        if (lane < wp && c <= i) A[(size_t)(k0 + c) * ld + k0 + i] = lic;
+      }
     }
   };
   // ---- D. own columns in panels of 16
