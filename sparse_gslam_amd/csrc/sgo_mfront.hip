@@ -765,6 +765,7 @@ Mfront* mfront_create(hipStream_t s, DevArena* arena, int V, int n, const int* f
   }
   if (const char* e = std::getenv("SGO_MFRONT_LEAF")) lim.leaf = std::max(4, std::atoi(e));
   if (const char* e = std::getenv("SGO_MFRONT_CRIT_MFLOP")) lim.max_crit_flops = 1e6 * std::atof(e);
+  if (const char* e = std::getenv("SGO_MFRONT_DEGREE")) lim.max_degree = std::atof(e);
   std::unique_ptr<Mfront, void (*)(Mfront*)> M(new Mfront, &mfront_destroy);   // (frees the device buffer on every early return)
   if (!mfront_analyze(V, n, free_id, poses, E, ei, ej, lim, &M->plan, why)) {
     if (lim.only_kind < 0) return nullptr;
