@@ -40,11 +40,15 @@ def _write_graph(path, g, phi):
 
 
 @pytest.mark.gpu
-def test_call_site_replay_matches_oracle(tmp_path):
+@pytest.mark.parametrize("V,E", [(300, 700), (2500, 3400)])
+def test_call_site_replay_matches_oracle(tmp_path, V, E):
+    """The reference's call sequence through the g2o-compatible header (slc.cpp:205-288: build, initializeOptimization,
+    optimize(20), chi2 gate at 11.345 with removeEdge, re-initialise, optimize(20)) on a graph that takes the multigrid
+    path and on one of the size and closure density of the reference's largest (the multifrontal path)."""
     from oracle import c_oracle as co
     exe = _build()
     phi = 1.0
-    g = synth.manhattan(300, 700, seed=31, info_mode="full", phi=phi)
+    g = synth.manhattan(V, E, seed=31, info_mode="full", phi=phi)
     # corrupt a few closures so that the 11.345 gate has something to remove
     rng = np.random.default_rng(0)
     bad = g.meta["n_odom"] + rng.choice(g.E - g.meta["n_odom"], size=12, replace=False)
