@@ -372,7 +372,8 @@ __global__ __launch_bounds__(kMfThreads) void k_mf_panels(MfDev M, int lvl0, int
     auto follow = [&](int j, int i, double& lij, double& inv) {   // column j and 1 / L[j][j] as soon as wave 0 has them
       do {
         inv = __hip_atomic_load(&LI[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // (relaxed LDS atomics: plain ds_read / ds_write;
-        lij = __hip_atomic_load(&LX[j][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // `volatile` would become FLAT accesses with sc0 sc1 and a vmcnt wait)
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");                              // `volatile` would become FLAT accesses with sc0 sc1 and a
+        lij = __hip_atomic_load(&LX[j][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // vmcnt wait; the fence pins the order of the two reads for the compiler)
       } while (inv == 0.0);
     };
     if (wave == 0) {
