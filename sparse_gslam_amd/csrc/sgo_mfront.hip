@@ -61,7 +61,7 @@ struct MfDev {
   double* partials = nullptr;  // [2][kMaxPartials]
   long long* dbg = nullptr;    // diagnostic runs (SGO_MFRONT_DEBUG): [nfront][8] s_memtime cycles of the factor kernel's phases
   int* flags = nullptr;        // [0] fail (1 not positive definite, 2 non-finite update)  [1] iteration of the failure
-                               // [2] a back-substitution produced a non-finite value  [3] updates applied  [4] ticket of k_mf_edges
+                               // [2] a back-substitution produced a non-finite value  [3] updates applied
 };
 
 typedef double mf_d4 __attribute__((ext_vector_type(4)));
@@ -192,20 +192,23 @@ __global__ __launch_bounds__(kBlock) void k_mf_edges(MfDev M, EdgeListDev el, co
 #pragma unroll
     for (int a = 0; a < 3; ++a) out[q++] = -w * (B[0][a] * oe[0] + B[1][a] * oe[1] + B[2][a] * oe[2]);
   }
+  // per-workgroup partial sums; the next launch on the stream (the first level's panel kernel, or k_mf_finish after the closing
+  // pass) adds them in a fixed order: mf_chi2_sum
   block_sum_store<2>(acc, M.partials, kMaxPartials);
-  // the last workgroup to arrive sums the partials in a fixed order (an integer ticket: no floating-point atomics)
-  __shared__ int s_last;
-  __threadfence();
-  if (threadIdx.x == 0) s_last = atomicAdd(M.flags + 4, 1) == (int)gridDim.x - 1;
-  __syncthreads();
-  if (!s_last) return;
-  __threadfence();
-  const double c0 = block_reduce_parts(M.partials, (int)gridDim.x);
-  const double c1 = block_reduce_parts(M.partials + kMaxPartials, (int)gridDim.x);
-  if (threadIdx.x == 0) {
+}
+
+// one wave: hist[2 it], hist[2 it + 1] = the sums of k_mf_edges' nparts partial sums, always in the same order
+__device__ __forceinline__ void mf_chi2_sum(const double* __restrict__ partials, int nparts, double* __restrict__ hist, int it, int lane) {
+  double c0 = 0.0, c1 = 0.0;
+  for (int q = lane; q < nparts; q += 64) {
+    c0 += partials[q];
+    c1 += partials[kMaxPartials + q];
+  }
+  c0 = wave_sum(c0);
+  c1 = wave_sum(c1);
+  if (lane == 0) {
     hist[2 * it] = c0;
     hist[2 * it + 1] = c1;
-    M.flags[4] = 0;
   }
 }
 
@@ -269,7 +272,8 @@ __global__ __launch_bounds__(kBlock) void k_mf_merge(MfDev M, int t0, int t1) {
 //   D2  the 16 x 16 Cholesky on wave 0 and the inverse of its factor on wave 1, one pivot behind (rows on the lanes, columns in
 //       registers, broadcasts by v_readlane; wave 0 hands every finished column and pivot to wave 1 through LDS);
 //   D3  L21 = P21 L11^-T on the matrix cores, straight to the front's matrix.
-__global__ __launch_bounds__(kMfThreads) void k_mf_panels(MfDev M, int lvl0, int it, int stamp_slot, DirectResult* __restrict__ res) {
+__global__ __launch_bounds__(kMfThreads) void k_mf_panels(MfDev M, int lvl0, int it, int stamp_slot, int nparts, double* __restrict__ hist,
+                                                         DirectResult* __restrict__ res) {
   extern __shared__ double Pn[];               // panel: column c at Pn + c * ldp, rows relative to k0 
   __shared__ double Yt[kMfPanel * kMfPanel];   // Yt[t * 16 + c] = (L11^-1)[c][t]
   __shared__ double LX[kMfPanel][kMfPanel];    // LX[j][i] = L11[i][j]: column j as wave 0 finishes it
@@ -278,6 +282,8 @@ __global__ __launch_bounds__(kMfThreads) void k_mf_panels(MfDev M, int lvl0, int
   __shared__ int s_half, s_fail;
   if (stamp_slot >= 0 && blockIdx.x == 0 && threadIdx.x == 0) res->stamp[stamp_slot] = (unsigned long long)wall_clock64();
   if (M.flags[0]) return;
+  if (nparts > 0 && blockIdx.x == 0 && threadIdx.x >= kMfThreads - 64)   // (the first level's launch: chi2 of this iteration; the last wave, idle in most phases)
+    mf_chi2_sum(M.partials, nparts, hist, it, threadIdx.x & 63);
   const MfFrontDev F = M.fronts[M.level_front[lvl0 + blockIdx.x]];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, lk = lane >> 4;
@@ -724,7 +730,9 @@ __global__ __launch_bounds__(kBlock) void k_mf_update(MfDev M, double* __restric
   if (blockIdx.x == 0 && threadIdx.x == 0) M.flags[3] = it + 1;
 }
 
-__global__ void k_mf_finish(MfDev M, int iters, DirectResult* __restrict__ res) {
+__global__ __launch_bounds__(64) void k_mf_finish(MfDev M, int iters, int nparts, double* __restrict__ hist, DirectResult* __restrict__ res) {
+  if (!M.flags[0]) mf_chi2_sum(M.partials, nparts, hist, iters, threadIdx.x);   // the closing pass
+  if (threadIdx.x != 0) return;
   const unsigned long long now = (unsigned long long)wall_clock64();
   res->done = M.flags[3];
   res->fail = M.flags[0];
@@ -965,7 +973,8 @@ hipError_t mfront_optimize(Mfront* m, hipStream_t s, const EdgeListDev& el, doub
         const int grid = std::max(1, std::min((nt + kWavesPerBlock - 1) / kWavesPerBlock, 8192));
         hipLaunchKernelGGL(k_mf_merge, dim3(grid), dim3(kBlock), 0, s, D, m->mtile_ptr[h], m->mtile_ptr[h + 1]);
       }
-      hipLaunchKernelGGL(k_mf_panels, dim3(cnt), dim3(kMfThreads), (size_t)m->level_lds[h], s, D, P.level_ptr[h], it, h == 0 ? 2 * it + 1 : -1, d_res);
+      hipLaunchKernelGGL(k_mf_panels, dim3(cnt), dim3(kMfThreads), (size_t)m->level_lds[h], s, D, P.level_ptr[h], it, h == 0 ? 2 * it + 1 : -1,
+                         h == 0 ? egrid : 0, d_hist, d_res);
     }
     if (m->fused_solve) {
       hipLaunchKernelGGL(k_mf_solve, dim3((unsigned)P.fronts.size()), dim3(kMfThreads), (size_t)m->solve_lds_all, s, D, 0, ++m->gen);
@@ -977,7 +986,7 @@ hipError_t mfront_optimize(Mfront* m, hipStream_t s, const EdgeListDev& el, doub
     }
     hipLaunchKernelGGL(k_mf_update, dim3(ugrid), dim3(kBlock), 0, s, D, d_poses, it);
   }
-  hipLaunchKernelGGL(k_mf_finish, dim3(1), dim3(1), 0, s, D, iters, d_res);
+  hipLaunchKernelGGL(k_mf_finish, dim3(1), dim3(64), 0, s, D, iters, egrid, d_hist, d_res);
   if (D.dbg && iters > 0) {   // diagnostic: phases of the LAST factorisation, per level the front with the longest total
     std::vector<long long> h(8 * P.fronts.size());
     if (hipStreamSynchronize(s) == hipSuccess && hipMemcpy(h.data(), D.dbg, sizeof(long long) * h.size(), hipMemcpyDeviceToHost) == hipSuccess) {
