@@ -1593,6 +1593,28 @@ struct CoarseSol {
   SpmvRatio c1, c2;
 };
 
+// xs = omega Dinv rhs (first sweep from zero), rs = rhs - A xs on a coarse level.  One fused launch (the gathered operand is
+// omega Dinv[col] rhs[col]: 72 B per slot) where a launch costs more than the level's data; on a LARGE level (C5's first coarse
+// levels: millions of slots) the sweep from zero as a vector kernel of its own and a plain residual pass that gathers 24 B per slot.
+constexpr int kUnfuseSlots = 1000000;
+static void pre_resid(Amg* m, hipStream_t s, AmgLevel& L, const double* rhs, const PcgScalars* S) {
+  SpmvArgs a{};
+  a.b = rhs; a.y = L.rs; a.omega = m->cfg.omega; a.S = S;
+  if (L.A.nslot >= kUnfuseSlots) {
+    {
+      Scope sc(m->prof, K_DOT, 96.0 * L.A.n);
+      launch_precond_bj(s, L.A.n, L.A.dinv, rhs, L.xs, m->cfg.omega);
+    }
+    a.x = L.xs;
+    Scope sc(m->prof, K_SPMV_RESID, 80.0 * L.A.nslot + 72.0 * L.A.n);
+    launch_spmv_ex(s, L.A, SPMV_RESID, a);
+    return;
+  }
+  a.y2 = L.xs;
+  Scope sc(m->prof, K_SPMV_PRE_RESID, 80.0 * L.A.nslot + 120.0 * L.A.n);
+  launch_spmv_ex(s, L.A, SPMV_PRE_RESID, a);
+}
+
 int cycle(Amg* m, hipStream_t s, int l, const double* rhs, const double* rhs_sub, const SpmvRatio& rhs_c,
           double* rhs_out, double* out, const double* dotvec, double* dotparts, const PcgScalars* S,
           const double* dotvec2 = nullptr, int xs0_ready = 0);
@@ -1722,12 +1744,7 @@ int cycle(Amg* m, hipStream_t s, int l, const double* rhs, const double* rhs_sub
     if (L.fold && nu_l == 1 && !rhs_sub && (l == 0 ? !(m->halo || m->comm) : !dotvec)) return cycle_fold(m, s, l, rhs, out, dotvec, dotparts, S, dotvec2, xs0_ready);
     if (L.fold && nu_l == 2 && !rhs_sub && l > 0 && !dotvec) {
       // two sweeps per side = one explicit sweep around the folded cycle: S E S with E the folded cycle's error propagator
-      {   // xs = omega Dinv rhs, rs = rhs - A xs
-        SpmvArgs a{};
-        a.b = rhs; a.y = L.rs; a.y2 = L.xs; a.omega = m->cfg.omega; a.S = S;
-        Scope sc(m->prof, K_SPMV_PRE_RESID, 80.0 * L.A.nslot + 120.0 * L.A.n);
-        launch_spmv_ex(s, L.A, SPMV_PRE_RESID, a);
-      }
+      pre_resid(m, s, L, rhs, S);   // xs = omega Dinv rhs, rs = rhs - A xs
       cycle_fold(m, s, l, L.rs, L.tR, nullptr, nullptr, S, nullptr, 0, L.xs);   // tR = xs + cycle(rs)
       SpmvArgs a{};
       a.x = L.tR; a.b = rhs; a.y = out; a.omega = m->cfg.omega; a.S = S;
@@ -1774,8 +1791,7 @@ int cycle(Amg* m, hipStream_t s, int l, const double* rhs, const double* rhs_sub
       Scope sc(m->prof, K_SPMV_PRE_RESID_S, 80.0 * L.A.nslot + 168.0 * L.A.n);
       launch_spmv_ex(s, L.A, SPMV_PRE_RESID_S, a);
     } else {
-      Scope sc(m->prof, K_SPMV_PRE_RESID, 80.0 * L.A.nslot + 120.0 * L.A.n);
-      launch_spmv_ex(s, L.A, SPMV_PRE_RESID, a);
+      pre_resid(m, s, L, rhs, S);
     }
   }
   // further pre-smoothing sweeps (levels walked by the V-cycle only): sweep s applied to the residual
@@ -1887,6 +1903,17 @@ int cycle(Amg* m, hipStream_t s, int l, const double* rhs, const double* rhs_sub
         launch_spmv_ex(s, L.A, SPMV_JACOBI, b);
       }
       a.x = dst;
+    }
+    Scope sc(m->prof, K_SPMV_JACOBI, 80.0 * L.A.nslot + 120.0 * L.A.n);
+    return launch_spmv_ex(s, L.A, SPMV_JACOBI, a);
+  }
+  if (L.A.nslot >= kUnfuseSlots && a.x == L.xs) {
+    // a large level: the prolongation as a vector kernel of its own (same arithmetic, in place), then a plain sweep that gathers
+    // 24 B per slot instead of x, the aggregate number, the coarse vectors and the lever arm (68-92 B)
+    {
+      Scope sc(m->prof, K_PROLONG, 52.0 * L.A.n + 48.0 * L.nc);
+      SGO_LAUNCH(k_prolong_add, dim3(grid_for(L.A.n, kBlock)), dim3(kBlock), 0, s, L.A.n, L.agg, L.d, cs.u1, cs.c1, cs.u2, cs.c2, L.xs, S,
+                 (const double*)nullptr, 0, 0);
     }
     Scope sc(m->prof, K_SPMV_JACOBI, 80.0 * L.A.nslot + 120.0 * L.A.n);
     return launch_spmv_ex(s, L.A, SPMV_JACOBI, a);
