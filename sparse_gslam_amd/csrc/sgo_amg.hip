@@ -1596,7 +1596,7 @@ struct CoarseSol {
 // xs = omega Dinv rhs (first sweep from zero), rs = rhs - A xs on a coarse level.  One fused launch (the gathered operand is
 // omega Dinv[col] rhs[col]: 72 B per slot) where a launch costs more than the level's data; on a LARGE level (C5's first coarse
 // levels: millions of slots) the sweep from zero as a vector kernel of its own and a plain residual pass that gathers 24 B per slot.
-constexpr int kUnfuseSlots = 1000000;
+constexpr int kUnfuseSlots = 400000;   // (swept on C5 / C4r: 10^6 87.0 / 64.4 M edge-Jacobians/s, 4 10^5 89.4 / 65.3, 1.5 10^5 89.9 / 64.8, 5 10^4 90.3 / 63.4)
 static void pre_resid(Amg* m, hipStream_t s, AmgLevel& L, const double* rhs, const PcgScalars* S) {
   SpmvArgs a{};
   a.b = rhs; a.y = L.rs; a.omega = m->cfg.omega; a.S = S;
