@@ -2,7 +2,7 @@
 import sys
 import time
 
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from sparse_gslam_amd import capi, synth  # noqa: E402
 
 name = sys.argv[1] if len(sys.argv) > 1 else "C3s"

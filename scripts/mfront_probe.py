@@ -8,7 +8,7 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from sparse_gslam_amd import capi, synth  # noqa: E402
 
 
