@@ -39,13 +39,13 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s 
 HBM_COPY_GBS = 6290.0  # ... and the copy rate measured there (frac_of_measured_copy)
 
 
-def cpu_baseline(g, iters: int):
+def cpu_baseline(g, iters: int, config: str = ""):
     """CPU restatement of g2o's GN (not g2o itself: g2o / Eigen are not in the image) on the host cores, the three
     variants of SURVEY.md section 8(d), each on a BOUNDED sample of the workload:
     A  single thread, sparse direct LDL^T (the reference's solver class) on the sub-graph of the first 30 000
        poses -- the direct solver's cost is super-linear in the graph size (fill-in), so the rate on the sample
-       is an UPPER bound of the rate on the full graph (full C4: 39 s per GN iteration, measured once offline
-       while the golden fixture was generated, scripts/make_golden_large.py);
+       is an UPPER bound of the rate on the full graph (`full_graph`: the full-size figure, read from the committed
+       golden fixture's 'seconds' -- measured once while scripts/make_golden_large.py generated it);
     B  single thread, block-Jacobi PCG on the FULL graph: linearise + assemble, then a bounded number of PCG
        iterations; block-Jacobi PCG needs thousands of iterations per solve on these graphs (7 764 on C2, more
        than 20 000 on C4, profiles/r01_bj_c4_bench.json), so the figure is seconds per PCG iteration and the
@@ -60,9 +60,17 @@ def cpu_baseline(g, iters: int):
     Es = int(keep.sum())
     _, st = c_oracle.gauss_newton(*args, iters=3, solver="direct")
     med = float(np.median(st["seconds"][1:]))   # iteration 0 also pays the symbolic analysis (once per optimize())
-    note = ""
-    if g.V == 100_000 and g.E == 1_000_000:
-        note = "; full graph measured offline: 39 s per GN iteration = 25.6 k edge-Jacobians/s"
+    # the FULL graph through the same solver: not timed here (13 min of CPU), read from the committed fixture the golden run left
+    # (tests/golden/<config>_direct.npz 'seconds': per-iteration times of scripts/make_golden_large.py on the build container's cores)
+    full = None
+    gpath = os.path.join(ROOT, "tests", "golden", f"{config}_direct.npz")
+    if config and Vs < g.V and os.path.exists(gpath):
+        gf = np.load(gpath)
+        if "seconds" in gf.files and gf["seconds"].size > 2:
+            sec = float(np.median(gf["seconds"][1:]))
+            full = {"V": g.V, "E": g.E, "seconds_per_gn_iter_median": sec, "value": g.E / sec, "unit": "edge-Jacobians/s per GN iter",
+                    "source": os.path.relpath(gpath, ROOT) + "['seconds'] (measured when the fixture was generated, on the build "
+                              "container's host, not on this box)"}
     try:
         ncores = len(os.sched_getaffinity(0))
     except AttributeError:
@@ -98,11 +106,13 @@ def cpu_baseline(g, iters: int):
     r, per_it = timed(best, 200)
     variants["C_pcg_openmp"] = entry(best, r, per_it, dict(host_cores=ncores, seconds_per_pcg_iteration_by_threads=sweep))
     return dict(value=Es / med, unit="edge-Jacobians/s per GN iter", cores=1, kind="port", host_cores=ncores,
+                sample_V=Vs, sample_E=Es, workload_V=g.V, workload_E=g.E,
                 sample=f"variant A: CPU restatement of g2o GN (not g2o itself: g2o/Eigen are not in the image): "
                        f"single-thread C++ oracle, sparse direct LDL^T + min-degree ordering, on the "
-                       f"first {Vs} poses / {Es} edges of the workload, median of GN iterations 2-3 "
-                       f"(numeric factorisation + solve; symbolic analysis excluded){note}",
-                variants=variants)
+                       f"first {Vs} poses / {Es} edges of the workload (NOT the whole workload: sample_V / sample_E; the direct "
+                       f"solver's cost is super-linear in the size, so this rate is an upper bound of the full graph's), median "
+                       f"of GN iterations 2-3 (numeric factorisation + solve; symbolic analysis excluded)",
+                full_graph=full, variants=variants)
 
 
 def golden_rel_err(config, iters, st):
@@ -274,6 +284,12 @@ def main():
     ap.add_argument("--tol", type=float, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--transport", choices=("rccl", "host"), default="rccl",
+                    help="N > 1 only.  rccl: one rank per GPU, libsgo's own RCCL communicator (the measured configuration).  host: the "
+                         "same launcher, rendezvous, sharding, MAX-reduce and JSON with libsgo's caller-supplied transport "
+                         "(sgo_comm_init_host + gloo) -- rank processes may then SHARE a GPU (rank r uses device r mod the number of "
+                         "devices), which is how the --gpus N code path runs end to end on a box with one GPU; its value is a "
+                         "functional check, not a scaling measurement, and the line says so")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -291,9 +307,13 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    host_transport = world > 1 and args.transport == "host"
+    if host_transport:
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group("gloo" if host_transport else "nccl", rank=rank, world_size=world)
+    red_dev = "cpu" if host_transport else "cuda"   # where the host layer's own small reductions live
 
     def barrier():
         if world > 1:
@@ -315,7 +335,18 @@ def main():
         opts["pcg_tol"] = args.tol
     opt = capi.Optimizer(local_rank, **opts)
     sharding = "single GPU"   # (N > 1: replaced by the library's own description of the mode it chose for this graph)
-    if world > 1 or os.environ.get("SGO_BENCH_FORCE_COMM"):
+    if host_transport:
+        def _allreduce(a):
+            dist.all_reduce(torch.from_numpy(a))
+
+        def _allgather(send, recv):
+            parts = [torch.empty(send.size, dtype=torch.float64) for _ in range(world)]
+            dist.all_gather(parts, torch.from_numpy(send.copy()))
+            for r, t in enumerate(parts):
+                recv[r * send.size:(r + 1) * send.size] = t.numpy()
+
+        opt.comm_init_host(world, rank, _allreduce, _allgather)
+    elif world > 1 or os.environ.get("SGO_BENCH_FORCE_COMM"):
         # rendezvous for libsgo's own RCCL communicator: rank 0 makes the id, torch broadcasts it.  No
         # communicator, no multi-GPU number: a failure on any rank ends the run with a non-zero exit code
         # instead of silently benchmarking N replicas.
@@ -328,7 +359,7 @@ def main():
         except capi.SgoError as e:
             comm_error = str(e)
         if world > 1:
-            ok = torch.tensor([0 if comm_error else 1], dtype=torch.int32, device="cuda")
+            ok = torch.tensor([0 if comm_error else 1], dtype=torch.int32, device=red_dev)
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
             if int(ok.item()) == 0:
                 opt.close()
@@ -365,7 +396,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -393,7 +424,10 @@ def main():
                        "pcg_tol_cap": opts.get("pcg_tol_cap", o.pcg_tol_cap),
                        "pcg_stop_rule": "||r|| <= pcg_tol * max(||b||, min(||b_first||, pcg_tol_cap / pcg_tol * ||b||)): "
                                         "the absolute accuracy of the call's first solve, capped at pcg_tol_cap relative",
-                       "parallelism": sharding},
+                       "parallelism": sharding,
+                       "transport": ("host (sgo_comm_init_host + gloo; rank processes share GPUs: a functional run of the --gpus N "
+                                     "path, NOT a scaling measurement)" if host_transport else
+                                     ("rccl" if world > 1 else "none (single GPU)"))},
             "final_chi2": st["chi2"][-1], "final_robust_chi2": st["robust_chi2"][-1],
             "final_chi2_rel_err_vs_oracle": golden_rel_err(args.config, args.iters, st),
             "pcg_iters_per_gn_iter": float(np.mean(st["pcg_iters"])), "pcg_iters": st["pcg_iters"],
@@ -527,7 +561,7 @@ def main():
                         for n, v in prof.items() if v["ms"] > 0}}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         note("cpu baseline")
-        out["cpu_baseline"] = cpu_baseline(g, args.iters)
+        out["cpu_baseline"] = cpu_baseline(g, args.iters, args.config)
         out["reference_usage_session"] = reference_usage_session(local_rank)
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.config == "C3s":
         note("mid-size usage session")

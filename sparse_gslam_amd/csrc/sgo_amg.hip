@@ -1848,12 +1848,8 @@ int cycle(Amg* m, hipStream_t s, int l, const double* rhs, const double* rhs_sub
       // row-owner mode: the corrected xs of the neighbours' boundary rows, then the sweep over this rank's tiles; the dot
       // products ride on the kernel as per-workgroup partials of the OWNED rows (the caller exchanges their sums)
       // (no exchange for that: this rank prolongates the replicated coarse solution on its copies of the neighbours' boundary
-      // rows itself, k_prolong_rows; SGO_OWNER_XS_EXCHANGE=1 keeps the exchange of round 3)
-      static const bool xs_exchange = std::getenv("SGO_OWNER_XS_EXCHANGE") && std::atoi(std::getenv("SGO_OWNER_XS_EXCHANGE")) != 0;
-      if (xs_exchange) {
-        std::string e;
-        if (!halo_exchange(*H, s, L.xs, 3, H->bnd, H->bmax, HaloScalars(), &e)) m->comm_failed = true;
-      } else if (H->nhalo > 0) {
+      // rows itself, k_prolong_rows)
+      if (H->nhalo > 0) {
         PDev Ph = L.smoothed ? L.P : PDev();
         SGO_LAUNCH(k_prolong_rows, dim3(grid_for(H->nhalo, kBlock)), dim3(kBlock), 0, s, H->nhalo, H->halo_rows, Ph, (const int*)L.agg,
                    (const double*)L.d, cs.u1, cs.c1, cs.u2, cs.c2, L.xs, S);

@@ -123,6 +123,7 @@ void sgo_destroy(sgo_ctx* c) {
   if (c->halo_recv) hipFree(c->halo_recv);
   if (c->h_dres) hipHostFree(c->h_dres);
   if (c->d_dres) hipFree(c->d_dres);
+  if (c->d_comm_flag) hipFree(c->d_comm_flag);
   if (c->stream) hipStreamDestroy(c->stream);
   delete c;
 }
@@ -284,7 +285,12 @@ int sgo_update_graph_se2(sgo_ctx* c, int32_t V, const double* poses, const uint8
     if (!c->has_graph) why = "no resident graph";
     else if (!env_on) why = "disabled (SGO_INCREMENTAL=0)";
     else if (n_resident_edges == 0) why = "the caller reports no common prefix";
-    else if (c->direct || c->rows_pending || c->amg_pending) why = c->mf ? "the resident graph takes the multifrontal path (its set-up is cheap)" : "the resident graph takes the single-launch direct path (its set-up is cheap)";
+    // (c->direct / c->mf themselves, not only the pending flags: a single-step entry point -- sgo_linearize, sgo_solve -- builds the
+    // PCG structures of such a graph on demand and clears the flags, while sgo_optimize_gn keeps taking the factorisation path,
+    // which knows nothing of an overlay)
+    else if (c->mf) why = "the resident graph takes the multifrontal path (its set-up is cheap)";
+    else if (c->direct) why = "the resident graph takes the single-launch direct path (its set-up is cheap)";
+    else if (c->rows_pending || c->amg_pending) why = "the resident graph's PCG structures are not built";
     else if (!c->amg || c->opts.solver != SGO_SOLVER_PCG_AMG) why = "no multigrid hierarchy resident";
     else if (c->comm.nranks > 1 || c->comm.active()) why = "multi-GPU contexts re-partition";
     else if (n_resident_edges != res_E || V < c->V) why = "the resident graph is not a prefix of the new one";
@@ -644,20 +650,22 @@ int sgo_debug_coarse_rhs(sgo_ctx* c, const double* r, double* out, int cap) {
 // iteration order; returns the number of iterations written (the Lanczos matrix of the preconditioned operator follows
 // from them: scripts/ritz_probe.py), < 0 on error.
 int sgo_debug_lanczos(sgo_ctx* c, double* out, int cap) {
-  int rc = check_graph(c);
-  if (rc) return rc;
-  if (!c->d_lanczos || !out || !c->h_S) return SGO_EINVAL;
-  const int n = std::min(std::min(c->h_S->iter, (int)kLanczosMax), cap);
-  if (n > 0) {
-    std::vector<double> t(3 * (size_t)n);
-    HIP_TRY(c, hipMemcpyAsync(t.data(), c->d_lanczos, sizeof(double) * 3 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    for (int j = 0; j < n; ++j) {
-      out[2 * j] = t[3 * (size_t)j];
-      out[2 * j + 1] = t[3 * (size_t)j + 1];
+  try {
+    int rc = check_graph(c);
+    if (rc) return rc;
+    if (!c->d_lanczos || !out || !c->h_S) return SGO_EINVAL;
+    const int n = std::min(std::min(c->h_S->iter, (int)kLanczosMax), cap);
+    if (n > 0) {
+      std::vector<double> t(3 * (size_t)n);
+      HIP_TRY(c, hipMemcpyAsync(t.data(), c->d_lanczos, sizeof(double) * 3 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(c, hipStreamSynchronize(c->stream));
+      for (int j = 0; j < n; ++j) {
+        out[2 * j] = t[3 * (size_t)j];
+        out[2 * j + 1] = t[3 * (size_t)j + 1];
+      }
     }
-  }
-  return n;
+    return n;
+  } SGO_CATCH(c)
 }
 
 int sgo_kernel_profile(sgo_ctx* c, sgo_kernel_stat* out, int cap) {

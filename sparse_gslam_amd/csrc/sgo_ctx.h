@@ -67,6 +67,7 @@ struct sgo_ctx {
   HaloDev halo;
   HaloHost halo_host;
   bool halo_failed = false;
+  int* d_comm_flag = nullptr;       // one int for the collective decision about the captured PCG graph (run_pcg)
   bool comm_graph_failed = false;   // capturing the RCCL collectives into the PCG hipGraph failed once: plain launches since
   long long level0_bytes = 0;    // device bytes of the level-0 structure this rank holds (blocks, operands, per-slot / per-block indices)
   double *halo_send = nullptr, *halo_recv = nullptr;   // exchange buffers (hipMalloc, grown on demand, kept across graphs)
@@ -98,19 +99,8 @@ struct sgo_ctx {
   double* d_partials = nullptr;   // [3][kMaxPartials]
   double* d_hist = nullptr;       // [SGO_MAX_ITERS + 2][2] chi2 history
   PcgScalars* d_S = nullptr;
-  double* d_lanczos = nullptr;    // [kLanczosMax][3] alpha, beta, r.z per PCG iteration of the last recorded solve
-  // Deflated PCG: Ritz vectors of M^-1 H taken from the Lanczos matrix of one undeflated solve are recycled as deflation space
-  // by the solves that follow (the Gauss-Newton systems of one optimize() -- and of the next calls on the same structure --
-  // differ little); see start_pcg / build_ritz in sgo_solve.cpp
-  int defl_k = 0;                 // vectors (0: off; env SGO_DEFLATE, default 8)
-  int defl_zmax = 0;              // Lanczos vectors the record holds
-  bool defl_ready = false;        // W is valid for the current hierarchy
-  bool defl_on = false;           // the running solve is deflated
-  bool defl_rec = false;          // the running solve records its Lanczos data
-  int defl_best = 0;              // fewest iterations of a deflated solve with the current W (staleness rule, counts only)
-  double *d_W = nullptr, *d_HW = nullptr, *d_Ginv = nullptr, *d_dparts = nullptr, *d_gram = nullptr, *d_Zbuf = nullptr, *d_ritzC = nullptr;
-  bool pred_defl = false;         // pcg_pred came from a deflated solve
-  int pcg_exec_key = 0;           // what the captured PCG iteration contains (overlay term, deflation, recording)
+  double* d_lanczos = nullptr;    // [kLanczosMax][3] alpha, beta, r.z per PCG iteration of the last solve (env SGO_LANCZOS; lives in the graph arena)
+  int pcg_exec_key = 0;           // what the captured PCG iteration contains (overlay term)
   PcgScalars* h_S = nullptr;      // pinned
   double* h_hist = nullptr;       // pinned
   bool linearized = false;

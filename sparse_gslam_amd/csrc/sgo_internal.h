@@ -526,43 +526,15 @@ int launch_spmv_ex(hipStream_t s, const BsrDev& A, int mode, const SpmvArgs& a);
 void launch_update_xr(hipStream_t s, int n, PcgScalars* S, const double* pq_parts, int n_pq, const double* dinv,
                       const double* p, const double* q, double* x, double* r, double* z, double* xs, double omega,
                       double* partials, int* grid_out);
-// ---- deflated PCG (sgo_solve.cpp: recycled Ritz vectors across the Gauss-Newton iterations of one optimize()) ----------
-// W (k vectors over the 3 n unknowns) spans approximations of the eigenvectors of M^-1 H with the smallest eigenvalues, taken
-// from the Lanczos matrix of an earlier (undeflated) solve; with HW = H W and Ginv = (W^T H W)^-1 of the CURRENT H the
-// recurrence keeps every direction H-orthogonal to W:  p = z + beta p - W Ginv (HW)^T z   (Saad, Yeung, Erhel, Guyomarc'h 2000).
-constexpr int kDeflMax = 8;           // vectors
-constexpr int kDeflGrid = 256;        // workgroups of the dot-product kernel (= partial sums per vector)
-constexpr int kLanczosMax = 2048;     // PCG iterations whose (alpha, beta, r.z) the record keeps
-struct DeflDev {
-  int k = 0;                          // 0: off
-  size_t stride = 0;                  // 3 n
-  const double* W = nullptr;          // [k][stride]
-  const double* HW = nullptr;         // [k][stride]
-  const double* Ginv = nullptr;       // [kDeflMax][kDeflMax] row-major (zero when W^T H W was not positive definite: the solve is then plain PCG)
-  double* dparts = nullptr;           // [kDeflMax][kDeflGrid] partial sums of (HW)^T z (or W^T r)
-};
-struct RecDev {                       // recording of a solve's Lanczos data (the next solves' deflation space is made from it)
+constexpr int kLanczosMax = 2048;     // PCG iterations whose (alpha, beta, r.z) the diagnostic record keeps
+struct RecDev {                       // what k_update_p leaves for the host besides the recurrence
   PcgScalars* mirror = nullptr;       // pinned host copy of the scalars, rewritten by every iteration's k_update_p (also by the
                                       // early-exit ones): the host reads the stop flag there behind an event instead of
                                       // queueing a device-to-host copy kernel after every graph replay
   double* lanczos = nullptr;          // [kLanczosMax][3] alpha_j, beta_j, r_j . z_j
-  double* Z = nullptr;                // [zmax][stride] z_j
-  int zmax = 0;
-  size_t stride = 0;
 };
 void launch_update_p(hipStream_t s, int n, PcgScalars* S, const double* rz_parts, int n_rz, const double* rr_parts,
-                     int n_rr, const double* zq_parts, const double* z, double* p, const RecDev& rec = RecDev(),
-                     const DeflDev& df = DeflDev());
-// dparts[i][blk] = partial sums of V_i . v for the k vectors V = (transposed ? df.W : df.HW)
-void launch_defl_dots(hipStream_t s, const DeflDev& df, bool use_w, const double* v, const PcgScalars* S);
-// x += W c, r -= HW c with c = Ginv d (d from df.dparts): the start's projection, W^T r = 0 afterwards
-void launch_defl_project(hipStream_t s, const DeflDev& df, double* x, double* r);
-// p = z - W Ginv d: the first direction
-void launch_defl_p0(hipStream_t s, const DeflDev& df, const double* z, double* p);
-// G = W^T HW -> Ginv (zero when not positive definite); scratch: [kDeflMax * kDeflMax][kDeflGrid] partial sums
-void launch_defl_gram(hipStream_t s, const DeflDev& df, double* Ginv, double* scratch);
-// W_i = sum_j C[j][i] Z_j  (m recorded vectors, k Ritz vectors; C on the device, [m][kDeflMax])
-void launch_ritz_combine(hipStream_t s, size_t stride, int m, int k, const double* Z, const double* C, double* W);
+                     int n_rr, const double* zq_parts, const double* z, double* p, const RecDev& rec = RecDev());
 void launch_pose_update(hipStream_t s, int n, const int* free_id, const double* x, double* poses);
 void launch_closure_cov(hipStream_t s, int n, const sgo_match_window* win, const float* scores, double* cov,
                         double* info);

@@ -922,30 +922,10 @@ __global__ __launch_bounds__(kBlock) void k_update_xr(int n, PcgScalars* S, cons
 // workgroup as above, then p = z + beta p (flat over 3n).  Reads rz_prev / alpha, which the
 // k_update_xr of this iteration recorded, so workgroup 0 can overwrite S->rz while the others
 // are still running.
-// c = Ginv d with d_i = sum of df.dparts[i][0 .. kDeflGrid): every workgroup reduces the partial sums in the same fixed order
-__device__ __forceinline__ void defl_coeffs(const DeflDev& df, double (&c)[kDeflMax]) {
-  static_assert(kDeflMax == 8, "the pointer list below is written out for 8 vectors");
-  const double* const parts[kDeflMax] = {
-      df.k > 0 ? df.dparts : nullptr,                  df.k > 1 ? df.dparts + 1 * kDeflGrid : nullptr,
-      df.k > 2 ? df.dparts + 2 * kDeflGrid : nullptr,  df.k > 3 ? df.dparts + 3 * kDeflGrid : nullptr,
-      df.k > 4 ? df.dparts + 4 * kDeflGrid : nullptr,  df.k > 5 ? df.dparts + 5 * kDeflGrid : nullptr,
-      df.k > 6 ? df.dparts + 6 * kDeflGrid : nullptr,  df.k > 7 ? df.dparts + 7 * kDeflGrid : nullptr};
-  const int cnt[kDeflMax] = {kDeflGrid, kDeflGrid, kDeflGrid, kDeflGrid, kDeflGrid, kDeflGrid, kDeflGrid, kDeflGrid};
-  double d[kDeflMax];
-  block_reduce_parts_n<kDeflMax>(parts, cnt, d);
-#pragma unroll
-  for (int i = 0; i < kDeflMax; ++i) {
-    double v = 0.0;
-#pragma unroll
-    for (int j = 0; j < kDeflMax; ++j) v += df.Ginv[i * kDeflMax + j] * d[j];
-    c[i] = v;
-  }
-}
-
 __global__ __launch_bounds__(kBlock) void k_update_p(int n3, PcgScalars* S, const double* __restrict__ rz_parts, int n_rz,
                                                      const double* __restrict__ rr_parts, int n_rr,
                                                      const double* __restrict__ zq_parts, const double* __restrict__ z,
-                                                     double* __restrict__ p, RecDev rec, DeflDev df) {
+                                                     double* __restrict__ p, RecDev rec) {
   // the scalars of the previous launches in one go, before the reduction's barriers, and this thread's first pair of
   // operands (see k_update_xr)
   const int i0 = blockIdx.x * kBlock + threadIdx.x;
@@ -989,149 +969,12 @@ __global__ __launch_bounds__(kBlock) void k_update_p(int n3, PcgScalars* S, cons
       *rec.mirror = m;
     }
   }
-  // the Lanczos vector of the next iteration (z_0 was recorded by the start)
-  const bool record = rec.Z != nullptr && iter_prev + 1 < rec.zmax;
-  double* zrec = record ? rec.Z + (size_t)(iter_prev + 1) * rec.stride : nullptr;
   if (stop) return;
-  if (df.k > 0) {
-    // deflated recurrence: p = z + beta p - W (Ginv (HW)^T z)
-    double c[kDeflMax];
-    defl_coeffs(df, c);
-    for (int i = i0; i < n3; i += gridDim.x * kBlock) {
-      const double zi = (i == i0) ? z0 : z[i], pi = (i == i0) ? p0 : p[i];
-      double w = 0.0;
-#pragma unroll
-      for (int j = 0; j < kDeflMax; ++j)
-        if (j < df.k) w += c[j] * df.W[(size_t)j * df.stride + i];
-      p[i] = zi + beta * pi - w;
-    }
-    return;
-  }
   if (i0 < n3) {
     p[i0] = z0 + beta * p0;
-    if (zrec) zrec[i0] = z0;
   }
   for (int i = i0 + gridDim.x * kBlock; i < n3; i += gridDim.x * kBlock) {
-    const double zi = z[i];
-    p[i] = zi + beta * p[i];
-    if (zrec) zrec[i] = zi;
-  }
-}
-
-// dparts[j][blk] = partial sums of V_j . v over the block's elements (grid kDeflGrid)
-__global__ __launch_bounds__(kBlock) void k_defl_dots(DeflDev df, const double* __restrict__ V, const double* __restrict__ v,
-                                                      const PcgScalars* S) {
-  if (S && S->stop) return;
-  const size_t n3 = df.stride;
-  double acc[kDeflMax];
-#pragma unroll
-  for (int j = 0; j < kDeflMax; ++j) acc[j] = 0.0;
-  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n3; i += (size_t)gridDim.x * kBlock) {
-    const double vi = v[i];
-#pragma unroll
-    for (int j = 0; j < kDeflMax; ++j)
-      if (j < df.k) acc[j] += V[(size_t)j * n3 + i] * vi;
-  }
-  block_sum_store<kDeflMax>(acc, df.dparts, kDeflGrid);
-}
-
-__global__ __launch_bounds__(kBlock) void k_defl_project(DeflDev df, double* __restrict__ x, double* __restrict__ r) {
-  double c[kDeflMax];
-  defl_coeffs(df, c);
-  const size_t n3 = df.stride;
-  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n3; i += (size_t)gridDim.x * kBlock) {
-    double dx = 0.0, dr = 0.0;
-#pragma unroll
-    for (int j = 0; j < kDeflMax; ++j)
-      if (j < df.k) {
-        dx += c[j] * df.W[(size_t)j * n3 + i];
-        dr += c[j] * df.HW[(size_t)j * n3 + i];
-      }
-    x[i] += dx;
-    r[i] -= dr;
-  }
-}
-
-__global__ __launch_bounds__(kBlock) void k_defl_p0(DeflDev df, const double* __restrict__ z, double* __restrict__ p) {
-  double c[kDeflMax];
-  defl_coeffs(df, c);
-  const size_t n3 = df.stride;
-  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n3; i += (size_t)gridDim.x * kBlock) {
-    double w = 0.0;
-#pragma unroll
-    for (int j = 0; j < kDeflMax; ++j)
-      if (j < df.k) w += c[j] * df.W[(size_t)j * n3 + i];
-    p[i] = z[i] - w;
-  }
-}
-
-// Gram matrix W^T HW: one launch per row i (partial sums of W_i . HW_j for all j through k_defl_dots' body), then the
-// inverse by Gauss-Jordan on one thread (k <= 8); not positive definite or non-finite: Ginv = 0 (plain PCG)
-__global__ __launch_bounds__(kBlock) void k_defl_gram_row(DeflDev df, int row, double* __restrict__ scratch) {
-  const size_t n3 = df.stride;
-  double acc[kDeflMax];
-#pragma unroll
-  for (int j = 0; j < kDeflMax; ++j) acc[j] = 0.0;
-  const double* wi = df.W + (size_t)row * n3;
-  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n3; i += (size_t)gridDim.x * kBlock) {
-    const double vi = wi[i];
-#pragma unroll
-    for (int j = 0; j < kDeflMax; ++j)
-      if (j < df.k) acc[j] += df.HW[(size_t)j * n3 + i] * vi;
-  }
-  block_sum_store<kDeflMax>(acc, scratch + (size_t)row * kDeflMax * kDeflGrid, kDeflGrid);
-}
-__global__ __launch_bounds__(kBlock) void k_defl_gram_finish(int k, const double* __restrict__ scratch, double* __restrict__ Ginv) {
-  __shared__ double G[kDeflMax][kDeflMax];
-  for (int e = threadIdx.x >> 6; e < kDeflMax * kDeflMax; e += kWavesPerBlock) {   // one wave per entry, fixed order
-    const double* part = scratch + (size_t)e * kDeflGrid;
-    double sum = 0.0;
-    for (int i = threadIdx.x & 63; i < kDeflGrid; i += 64) sum += part[i];
-    sum = wave_sum(sum);
-    if ((threadIdx.x & 63) == 0) G[e / kDeflMax][e % kDeflMax] = sum;
-  }
-  __syncthreads();
-  if (threadIdx.x != 0) return;
-  double A[kDeflMax][kDeflMax], I[kDeflMax][kDeflMax];
-  bool ok = true;
-  for (int i = 0; i < kDeflMax; ++i)
-    for (int j = 0; j < kDeflMax; ++j) {
-      A[i][j] = (i < k && j < k) ? 0.5 * (G[i][j] + G[j][i]) : (i == j ? 1.0 : 0.0);
-      I[i][j] = i == j ? 1.0 : 0.0;
-    }
-  for (int c2 = 0; c2 < k && ok; ++c2) {   // Gauss-Jordan without pivoting (SPD): a non-positive pivot gives up
-    const double piv = A[c2][c2];
-    if (!(piv > 0.0) || !isfinite(piv)) { ok = false; break; }
-    const double ip = 1.0 / piv;
-    for (int j = 0; j < kDeflMax; ++j) { A[c2][j] *= ip; I[c2][j] *= ip; }
-    for (int i = 0; i < k; ++i) {
-      if (i == c2) continue;
-      const double f = A[i][c2];
-      for (int j = 0; j < kDeflMax; ++j) { A[i][j] -= f * A[c2][j]; I[i][j] -= f * I[c2][j]; }
-    }
-  }
-  for (int i = 0; i < kDeflMax; ++i)
-    for (int j = 0; j < kDeflMax; ++j) Ginv[i * kDeflMax + j] = (ok && i < k && j < k) ? I[i][j] : 0.0;
-}
-
-// W_i = sum_j C[j][i] Z_j
-__global__ __launch_bounds__(kBlock) void k_ritz_combine(size_t n3, int m, int k, const double* __restrict__ Z, const double* __restrict__ C,
-                                                         double* __restrict__ W) {
-  extern __shared__ double cs[];   // [m][kDeflMax]
-  for (int e = threadIdx.x; e < m * kDeflMax; e += kBlock) cs[e] = C[e];
-  __syncthreads();
-  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n3; i += (size_t)gridDim.x * kBlock) {
-    double w[kDeflMax];
-#pragma unroll
-    for (int q = 0; q < kDeflMax; ++q) w[q] = 0.0;
-    for (int j = 0; j < m; ++j) {
-      const double zj = Z[(size_t)j * n3 + i];
-#pragma unroll
-      for (int q = 0; q < kDeflMax; ++q) w[q] += cs[j * kDeflMax + q] * zj;
-    }
-#pragma unroll
-    for (int q = 0; q < kDeflMax; ++q)
-      if (q < k) W[(size_t)q * n3 + i] = w[q];
+    p[i] = z[i] + beta * p[i];
   }
 }
 
@@ -1411,25 +1254,9 @@ void launch_update_xr(hipStream_t s, int n, PcgScalars* S, const double* pq_part
   if (grid_out) *grid_out = grid;
 }
 void launch_update_p(hipStream_t s, int n, PcgScalars* S, const double* rz_parts, int n_rz, const double* rr_parts,
-                     int n_rr, const double* zq_parts, const double* z, double* p, const RecDev& rec, const DeflDev& df) {
+                     int n_rr, const double* zq_parts, const double* z, double* p, const RecDev& rec) {
   const int grid = grid_for(3LL * n, kBlock);
-  SGO_LAUNCH(k_update_p, dim3(grid), dim3(kBlock), 0, s, 3 * n, S, rz_parts, n_rz, rr_parts, n_rr, zq_parts, z, p, rec, df);
-}
-void launch_defl_dots(hipStream_t s, const DeflDev& df, bool use_w, const double* v, const PcgScalars* S) {
-  SGO_LAUNCH(k_defl_dots, dim3(kDeflGrid), dim3(kBlock), 0, s, df, use_w ? df.W : df.HW, v, S);
-}
-void launch_defl_project(hipStream_t s, const DeflDev& df, double* x, double* r) {
-  SGO_LAUNCH(k_defl_project, dim3(grid_for((long long)df.stride, kBlock)), dim3(kBlock), 0, s, df, x, r);
-}
-void launch_defl_p0(hipStream_t s, const DeflDev& df, const double* z, double* p) {
-  SGO_LAUNCH(k_defl_p0, dim3(grid_for((long long)df.stride, kBlock)), dim3(kBlock), 0, s, df, z, p);
-}
-void launch_defl_gram(hipStream_t s, const DeflDev& df, double* Ginv, double* scratch) {
-  for (int i = 0; i < df.k; ++i) SGO_LAUNCH(k_defl_gram_row, dim3(kDeflGrid), dim3(kBlock), 0, s, df, i, scratch);
-  SGO_LAUNCH(k_defl_gram_finish, dim3(1), dim3(kBlock), 0, s, df.k, (const double*)scratch, Ginv);
-}
-void launch_ritz_combine(hipStream_t s, size_t stride, int m, int k, const double* Z, const double* C, double* W) {
-  SGO_LAUNCH(k_ritz_combine, dim3(grid_for((long long)stride, kBlock)), dim3(kBlock), sizeof(double) * (size_t)m * kDeflMax, s, stride, m, k, Z, C, W);
+  SGO_LAUNCH(k_update_p, dim3(grid), dim3(kBlock), 0, s, 3 * n, S, rz_parts, n_rz, rr_parts, n_rr, zq_parts, z, p, rec);
 }
 // Score-weighted sample covariance of a scan-match window and its inverse: one wave per match,
 // lanes stride over the window's samples (k fastest, as the reference's loops), ten fp64 sums

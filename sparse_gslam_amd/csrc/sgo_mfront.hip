@@ -51,8 +51,6 @@ struct MfDev {
   const MfTarget* targets = nullptr;
   const int* contrib = nullptr;
   const int* elim_vertex = nullptr;
-  const int* solve_order = nullptr;   // fronts root first (levels top-down): the single-launch substitution's workgroup order
-  int* done = nullptr;                // [nfront] generation of the last substitution that finished the front
   double* arena = nullptr;
   double* elem = nullptr;      // [E][kElemStride]
   double* x = nullptr;         // [3 n] by elimination position
@@ -558,51 +556,24 @@ __global__ __launch_bounds__(kMfThreads) void k_mf_panels(MfDev M, int lvl0, int
 // and the sequential part (16 x 16 triangular solves, then the finished block's contribution to the columns before it) runs
 // on ONE wave from LDS, without barriers.  Fronts too large for that take the generic branch (blocks of 16 columns, the
 // products with everything below a block by one wave per column).
-// gen == 0 (default): one level per launch, top-down.  gen > 0 (SGO_MFRONT_FUSED_SOLVE=1): ONE launch for the whole tree --
-// workgroups ordered root first, a front waits for its parent's flag (device-scope acquire / release; a workgroup only ever
-// waits for one with a lower index, which the dispatcher has started before it).  Measured and not the default: the ten
-// launch boundaries go, but every device-scope release writes the XCD's L2 back -- full of the factor just made -- and the
-// chain of ten of them costs more than the launches did (C3s: 0.78 against 0.67 ms per Gauss-Newton iteration).
+// One level per launch, top-down.  (The whole tree in ONE launch, a front waiting for its parent's flag, was measured in
+// round 4 and removed in round 5: the ten launch boundaries go, but every device-scope release writes the XCD's L2 back -- full
+// of the factor just made -- and the chain of ten of them costs more than the launches did: C3s 0.78 against 0.67 ms per
+// Gauss-Newton iteration.)
 constexpr int kMfSolveOwn = 144;   // own scalar rows up to which L11 is held in LDS (packed: 83.5 KB)
 constexpr int kMfSolveBnd = 256;   // ... and boundary scalar rows up to which the whole block L21 is requested in one go
 constexpr int kMfSolveCols = (kMfSolveOwn + kMfNW - 1) / kMfNW;   // columns per wave
-__global__ __launch_bounds__(kMfThreads) void k_mf_solve(MfDev M, int lvl0, int gen) {
+__global__ __launch_bounds__(kMfThreads) void k_mf_solve(MfDev M, int lvl0) {
   extern __shared__ double Ls[];               // row r of L11 at r (r + 1) / 2
   __shared__ double xs[kMfMaxDim + 1];
   __shared__ double tt[kMfSolveOwn];
   __shared__ double Yl[kMfSolveOwn * kMfPanel];   // the inverses of the diagonal blocks' factors, row by row
   __shared__ double Ld[kMfPanel * (kMfPanel + 1)];
-  const int f = gen > 0 ? M.solve_order[blockIdx.x] : M.level_front[lvl0 + blockIdx.x];
+  const int f = M.level_front[lvl0 + blockIdx.x];
   const MfFrontDev F = M.fronts[f];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m = F.m, s3 = F.own3, ld = F.ld, nb3 = m - s3;
-  auto signal = [&]() {   // (called by wave 0 only, all its lanes: the fence covers the wave's stores of x)
-    if (gen > 0) {
-      __threadfence();
-      if (lane == 0) __hip_atomic_store(M.done + f, gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  };
-  auto wait_parent = [&]() {   // all threads; returns after the parent's x is visible to every wave of this workgroup
-    if (gen > 0) {
-      if (F.parent >= 0 && tid == 0) {
-        int polls = 0;
-        while (__hip_atomic_load(M.done + F.parent, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != gen) {
-          if (++polls > (1 << 22)) {   // never seen; a stuck launch would take the box down, a flagged failure does not
-            M.flags[2] = 1;
-            break;
-          }
-          __builtin_amdgcn_s_sleep(2);
-        }
-      }
-      __syncthreads();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    }
-  };
-  if (M.flags[0] || s3 == 0) {   // nothing to solve here; a front without pivots still passes its ancestors' word on
-    if (!M.flags[0]) wait_parent();
-    if (wave == 0) signal();
-    return;
-  }
+  if (M.flags[0] || s3 == 0) return;   // nothing to solve here
   const double* __restrict__ A = M.arena + F.off;
   if (s3 <= kMfSolveOwn && nb3 <= kMfSolveBnd) {
     // the block L21 (this wave's columns c = wave, wave + 8, ...: up to 18 columns x 4 strips of 64 rows per lane), the triangle
@@ -621,7 +592,6 @@ __global__ __launch_bounds__(kMfThreads) void k_mf_solve(MfDev M, int lvl0, int 
     for (int e = tid; e < s3 * kMfPanel; e += kMfThreads) Yl[e] = M.yinv[3 * (size_t)F.e0 * kMfPanel + e];
     for (int c = wave; c < s3; c += kMfNW)
       for (int r = c + lane; r < s3; r += 64) Ls[r * (r + 1) / 2 + c] = A[(size_t)c * ld + r];
-    wait_parent();
     if (tid < nb3) xs[s3 + tid] = M.x[3 * (size_t)M.bnd[F.bnd_off + tid / 3] + tid % 3];
     __syncthreads();
 #pragma unroll
@@ -668,11 +638,9 @@ __global__ __launch_bounds__(kMfThreads) void k_mf_solve(MfDev M, int lvl0, int 
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     }
-    signal();
     return;
   }
   // ---- generic branch
-  wait_parent();
   for (int i = tid; i < nb3; i += kMfThreads) xs[s3 + i] = M.x[3 * (size_t)M.bnd[F.bnd_off + i / 3] + i % 3];
   __syncthreads();
   for (int c0 = ((s3 - 1) / kMfPanel) * kMfPanel; c0 >= 0; c0 -= kMfPanel) {
@@ -708,7 +676,6 @@ __global__ __launch_bounds__(kMfThreads) void k_mf_solve(MfDev M, int lvl0, int 
     }
     __syncthreads();
   }
-  if (wave == 0) signal();
 }
 
 // ---------------------------------------------------------------------------- k_mf_update
@@ -751,9 +718,6 @@ struct Mfront {
   void* buf = nullptr;
   std::vector<int> level_lds;        // dynamic LDS of the panel launch of every level
   std::vector<int> level_solve_lds;  // ... of the substitution launch
-  int solve_lds_all = 0;             // ... of the single-launch substitution
-  int gen = 0;                       // substitutions run so far (the flags' generation)
-  bool fused_solve = false;
   std::vector<int> mtile_ptr;        // k_mf_merge's tiles of level h: [mtile_ptr[h], mtile_ptr[h + 1])
 };
 
@@ -842,10 +806,6 @@ Mfront* mfront_create(hipStream_t s, DevArena* arena, int V, int n, const int* f
   if (P.height >= 1) M->mtile_ptr[1] = 0;
   M->level_lds.assign((size_t)P.height + 1, 0);
   M->level_solve_lds.assign((size_t)P.height + 1, 0);
-  std::vector<int> solve_order;
-  for (int h = P.height; h >= 0; --h)
-    for (int q = P.level_ptr[h]; q < P.level_ptr[h + 1]; ++q) solve_order.push_back(P.level_front[q]);
-  if (const char* e = std::getenv("SGO_MFRONT_FUSED_SOLVE")) M->fused_solve = std::atoi(e) != 0;
   for (int h = 0; h <= P.height; ++h) {
     int mm = 0;
     for (int q = P.level_ptr[h]; q < P.level_ptr[h + 1]; ++q) {
@@ -859,7 +819,6 @@ Mfront* mfront_create(hipStream_t s, DevArena* arena, int V, int n, const int* f
       if (s3 <= kMfSolveOwn && 3 * P.fronts[P.level_front[q]].nb <= kMfSolveBnd) so = std::max(so, s3);
     }
     M->level_solve_lds[h] = (int)sizeof(double) * std::max(1, so * (so + 1) / 2);
-    M->solve_lds_all = std::max(M->solve_lds_all, M->level_solve_lds[h]);
   }
   // one allocation, carved
   struct Part {
@@ -883,8 +842,6 @@ Mfront* mfront_create(hipStream_t s, DevArena* arena, int V, int n, const int* f
   const size_t i_tg = add(P.targets.data(), sizeof(MfTarget) * std::max<size_t>(P.targets.size(), 1));
   const size_t i_ct = add(P.contrib.data(), sizeof(int) * std::max<size_t>(P.contrib.size(), 1));
   const size_t i_ev = add(P.elim_vertex.data(), sizeof(int) * P.elim_vertex.size());
-  const size_t i_so = add(solve_order.data(), sizeof(int) * solve_order.size());
-  const size_t i_dn = add(nullptr, sizeof(int) * (size_t)nf);
   const size_t i_el = add(nullptr, sizeof(double) * kElemStride * (size_t)std::max(E, 1));
   const size_t i_x = add(nullptr, sizeof(double) * 3 * (size_t)n);
   const size_t i_id = add(nullptr, sizeof(double) * 3 * (size_t)n);
@@ -914,7 +871,6 @@ Mfront* mfront_create(hipStream_t s, DevArena* arena, int V, int n, const int* f
     }
   }
   he = hipMemsetAsync(base + parts[i_fl].at, 0, sizeof(int) * 8, s);
-  if (he == hipSuccess) he = hipMemsetAsync(base + parts[i_dn].at, 0, sizeof(int) * (size_t)nf, s);
   if (he == hipSuccess) he = hipStreamSynchronize(s);   // (the host vectors above go out of scope)
   if (he != hipSuccess) {
     if (err) *err = std::string("multifrontal plan upload: ") + hipGetErrorString(he);
@@ -932,8 +888,6 @@ Mfront* mfront_create(hipStream_t s, DevArena* arena, int V, int n, const int* f
   D.targets = (const MfTarget*)(base + parts[i_tg].at);
   D.contrib = (const int*)(base + parts[i_ct].at);
   D.elim_vertex = (const int*)(base + parts[i_ev].at);
-  D.solve_order = (const int*)(base + parts[i_so].at);
-  D.done = (int*)(base + parts[i_dn].at);
   D.elem = (double*)(base + parts[i_el].at);
   D.x = (double*)(base + parts[i_x].at);
   D.invd = (double*)(base + parts[i_id].at);
@@ -976,13 +930,9 @@ hipError_t mfront_optimize(Mfront* m, hipStream_t s, const EdgeListDev& el, doub
       hipLaunchKernelGGL(k_mf_panels, dim3(cnt), dim3(kMfThreads), (size_t)m->level_lds[h], s, D, P.level_ptr[h], it, h == 0 ? 2 * it + 1 : -1,
                          h == 0 ? egrid : 0, d_hist, d_res);
     }
-    if (m->fused_solve) {
-      hipLaunchKernelGGL(k_mf_solve, dim3((unsigned)P.fronts.size()), dim3(kMfThreads), (size_t)m->solve_lds_all, s, D, 0, ++m->gen);
-    } else {
-      for (int h = P.height; h >= 0; --h) {
-        const int cnt = P.level_ptr[h + 1] - P.level_ptr[h];
-        hipLaunchKernelGGL(k_mf_solve, dim3(cnt), dim3(kMfThreads), (size_t)m->level_solve_lds[h], s, D, P.level_ptr[h], 0);
-      }
+    for (int h = P.height; h >= 0; --h) {
+      const int cnt = P.level_ptr[h + 1] - P.level_ptr[h];
+      hipLaunchKernelGGL(k_mf_solve, dim3(cnt), dim3(kMfThreads), (size_t)m->level_solve_lds[h], s, D, P.level_ptr[h]);
     }
     hipLaunchKernelGGL(k_mf_update, dim3(ugrid), dim3(kBlock), 0, s, D, d_poses, it);
   }

@@ -170,131 +170,22 @@ static int start_pcg_owner(sgo_ctx* c, int grid) {
   return SGO_OK;
 }
 
-// ---- deflated PCG: recycled Ritz vectors ----------------------------------------------------------------------------
-// The preconditioned operator M^-1 H of these graphs has a dense low end (C4: 0.053 0.059 0.084 0.10 0.13 0.16 0.20 0.23 ...
-// up to 1.0, the same to three digits in every Gauss-Newton iteration: scripts/ritz_probe.py): the iteration counts are set by
-// that end.  (OPT-IN, env SGO_DEFLATE=k: it did not pay -- see the note at the allocation in sgo_structure.cpp.)  One solve
-// runs plain PCG and records its Lanczos data -- (alpha_j, beta_j, r_j.z_j) and the vectors z_j --, the
-// k smallest Ritz pairs of the Lanczos matrix give W = Z Y (build_ritz), and the solves that follow keep their directions
-// H-orthogonal to W (k_update_p): 30 -> 17 iterations with k = 8 on a prototype of that spectrum, for k extra Hessian
-// products per Gauss-Newton iteration (H W) and one extra launch + 2 k vector reads per PCG iteration.
-static DeflDev defl_dev(const sgo_ctx* c) {
-  DeflDev d;
-  if (!c->defl_on) return d;
-  d.k = c->defl_k;
-  d.stride = 3 * (size_t)c->n;
-  d.W = c->d_W;
-  d.HW = c->d_HW;
-  d.Ginv = c->d_Ginv;
-  d.dparts = c->d_dparts;
-  return d;
-}
+// what k_update_p records besides the recurrence: the pinned mirror of the scalars and (diagnostic, env SGO_LANCZOS=1) the
+// recurrence's coefficients per iteration -- the Lanczos matrix of M^-1 H follows from them (scripts/ritz_probe.py)
 static RecDev rec_dev(const sgo_ctx* c) {
   RecDev r;
   r.mirror = c->d_Sz;
   r.lanczos = c->d_lanczos;
-  if (c->defl_rec) {
-    r.Z = c->d_Zbuf;
-    r.zmax = c->defl_zmax;
-    r.stride = 3 * (size_t)c->n;
-  }
   return r;
-}
-
-// eigenvalues (ascending) and eigenvectors (columns of V, row-major [m][m]) of a symmetric matrix by cyclic Jacobi rotations
-static void jacobi_eigh(int m, std::vector<double>& A, std::vector<double>& V, std::vector<double>& ev) {
-  V.assign((size_t)m * m, 0.0);
-  for (int i = 0; i < m; ++i) V[(size_t)i * m + i] = 1.0;
-  for (int sweep = 0; sweep < 60; ++sweep) {
-    double off = 0.0;
-    for (int i = 0; i < m; ++i)
-      for (int j = i + 1; j < m; ++j) off += A[(size_t)i * m + j] * A[(size_t)i * m + j];
-    if (off < 1e-30) break;
-    for (int p = 0; p < m; ++p)
-      for (int q = p + 1; q < m; ++q) {
-        const double apq = A[(size_t)p * m + q];
-        if (std::fabs(apq) < 1e-300) continue;
-        const double theta = (A[(size_t)q * m + q] - A[(size_t)p * m + p]) / (2.0 * apq);
-        const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
-        const double cs = 1.0 / std::sqrt(t * t + 1.0), sn = t * cs;
-        for (int k = 0; k < m; ++k) {
-          const double akp = A[(size_t)k * m + p], akq = A[(size_t)k * m + q];
-          A[(size_t)k * m + p] = cs * akp - sn * akq;
-          A[(size_t)k * m + q] = sn * akp + cs * akq;
-        }
-        for (int k = 0; k < m; ++k) {
-          const double apk = A[(size_t)p * m + k], aqk = A[(size_t)q * m + k];
-          A[(size_t)p * m + k] = cs * apk - sn * aqk;
-          A[(size_t)q * m + k] = sn * apk + cs * aqk;
-        }
-        for (int k = 0; k < m; ++k) {
-          const double vkp = V[(size_t)k * m + p], vkq = V[(size_t)k * m + q];
-          V[(size_t)k * m + p] = cs * vkp - sn * vkq;
-          V[(size_t)k * m + q] = sn * vkp + cs * vkq;
-        }
-      }
-  }
-  ev.resize(m);
-  for (int i = 0; i < m; ++i) ev[i] = A[(size_t)i * m + i];
-}
-
-// W from the record of the solve that just converged after `iters` iterations: Lanczos matrix T (diagonal 1 / alpha_j +
-// beta_{j-1} / alpha_{j-1}, off-diagonal -sqrt(beta_j) / alpha_j) over the first m = min(iters, zmax) steps, its k smallest
-// Ritz pairs (theta, y), W_i = sum_j y_ji z_j / sqrt(r_j . z_j).
-static int build_ritz(sgo_ctx* c, int iters) {
-  const int m = std::min(std::min(iters, c->defl_zmax), (int)kLanczosMax), k = c->defl_k;
-  if (m < k + 4 || m > 64) return SGO_OK;   // too short a solve to learn from (or a record longer than the combine kernel's table)
-  std::vector<double> lz(3 * (size_t)m);
-  HIP_TRY(c, hipMemcpyAsync(lz.data(), c->d_lanczos, sizeof(double) * lz.size(), hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
-  std::vector<double> T((size_t)m * m, 0.0), Y, ev;
-  for (int j = 0; j < m; ++j) {
-    const double a = lz[3 * (size_t)j], b = lz[3 * (size_t)j + 1], rz = lz[3 * (size_t)j + 2];
-    if (!(a > 0.0) || !(b >= 0.0) || !(rz > 0.0) || !std::isfinite(a) || !std::isfinite(b) || !std::isfinite(rz)) return SGO_OK;
-    T[(size_t)j * m + j] = 1.0 / a + (j > 0 ? lz[3 * (size_t)(j - 1) + 1] / lz[3 * (size_t)(j - 1)] : 0.0);
-    if (j + 1 < m) T[(size_t)j * m + j + 1] = T[(size_t)(j + 1) * m + j] = -std::sqrt(b) / a;
-  }
-  jacobi_eigh(m, T, Y, ev);
-  std::vector<int> order(m);
-  for (int i = 0; i < m; ++i) order[i] = i;
-  std::sort(order.begin(), order.end(), [&](int a, int b) { return ev[a] < ev[b]; });
-  std::vector<double> C((size_t)m * kDeflMax, 0.0);
-  for (int j = 0; j < m; ++j) {
-    const double sc = 1.0 / std::sqrt(lz[3 * (size_t)j + 2]);
-    for (int i = 0; i < k; ++i) C[(size_t)j * kDeflMax + i] = Y[(size_t)j * m + order[i]] * sc;
-  }
-  HIP_TRY(c, hipMemcpyAsync(c->d_ritzC, C.data(), sizeof(double) * C.size(), hipMemcpyHostToDevice, c->stream));
-  launch_ritz_combine(c->stream, 3 * (size_t)c->n, m, k, c->d_Zbuf, c->d_ritzC, c->d_W);
-  HIP_TRY(c, hipStreamSynchronize(c->stream));   // (C is a local)
-  c->defl_ready = true;
-  c->defl_best = 0;
-  if (c->opts.verbose) {
-    std::fprintf(stderr, "[sgo] deflation space from %d Lanczos steps; Ritz values", m);
-    for (int i = 0; i < std::min(m, k + 2); ++i) std::fprintf(stderr, " %.4f", ev[order[i]]);
-    std::fprintf(stderr, " ... %.4f\n", ev[order[m - 1]]);
-  }
-  return SGO_OK;
 }
 
 int start_pcg(sgo_ctx* c, int grid) {
   if (c->owner) return start_pcg_owner(c, grid);
-  c->defl_on = c->defl_rec = false;
   const int maxit = c->pcg_softcap > 0 ? std::min(c->pcg_softcap, c->opts.pcg_maxit) : c->opts.pcg_maxit;
   const double tol = c->opts.pcg_tol * c->tol_scale;
   if (c->amg) {
     int rc = amg_update(c->amg, c->stream, &c->err);
     if (rc) return rc;
-    const bool can_defl = c->defl_k > 0 && c->d_W && !multi_rank(c);
-    if (can_defl && c->defl_ready) {
-      // H W and (W^T H W)^-1 for the current Hessian
-      c->defl_on = true;
-      const size_t n3 = 3 * (size_t)c->n;
-      for (int i = 0; i < c->defl_k; ++i)
-        if ((rc = do_spmv(c, c->d_W + (size_t)i * n3, c->d_HW + (size_t)i * n3, false, nullptr, nullptr))) return rc;
-      launch_defl_gram(c->stream, defl_dev(c), c->d_Ginv, c->d_gram);
-    } else if (can_defl) {
-      c->defl_rec = true;
-    }
     const bool warm = c->warm_valid && c->d_xprev;
     if (warm) {
       // Start from the previous Gauss-Newton step scaled by the energy-optimal factor: consecutive steps of a linearly
@@ -318,22 +209,10 @@ int start_pcg(sgo_ctx* c, int grid) {
       }
     }
     // (cold: k_finalize left x = 0, r = b and xs = omega Dinv b, the cycle's first sweep from zero)
-    int xs_ready = warm ? 0 : 1;
-    if (c->defl_on) {   // x += W c, r -= H W c with c = (W^T H W)^-1 W^T r: W^T r = 0 from here on
-      launch_defl_dots(c->stream, defl_dev(c), true, c->d_r, nullptr);
-      launch_defl_project(c->stream, defl_dev(c), c->d_x, c->d_r);
-      xs_ready = 0;
-    }
+    const int xs_ready = warm ? 0 : 1;
     const int gz = amg_apply(c->amg, c->stream, c->d_r, c->d_z, c->d_r, c->d_zparts, nullptr, nullptr, xs_ready);
     if (amg_comm_failed(c->amg)) return SGO_ECOMM;
-    if (c->defl_on) {
-      launch_defl_dots(c->stream, defl_dev(c), false, c->d_z, nullptr);
-      launch_defl_p0(c->stream, defl_dev(c), c->d_z, c->d_p);
-    } else {
-      HIP_TRY(c, hipMemcpyAsync(c->d_p, c->d_z, sizeof(double) * 3 * (size_t)c->n, hipMemcpyDeviceToDevice, c->stream));
-    }
-    if (c->defl_rec)   // the first Lanczos vector
-      HIP_TRY(c, hipMemcpyAsync(c->d_Zbuf, c->d_z, sizeof(double) * 3 * (size_t)c->n, hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->d_p, c->d_z, sizeof(double) * 3 * (size_t)c->n, hipMemcpyDeviceToDevice, c->stream));
     if (warm) {
       Scope sc(c, K_INIT_SCALARS, 8.0 * gz);
       launch_restart_scalars(c->stream, c->d_S, c->d_zparts, gz, maxit, 1);
@@ -500,10 +379,9 @@ int pcg_iteration(sgo_ctx* c) {
       c->err = "collective failed inside the multigrid cycle";
       return SGO_ECOMM;
     }
-    if (c->defl_on) launch_defl_dots(c->stream, defl_dev(c), false, c->d_z, c->d_S);   // (H W)^T z
     Scope sc(c, K_UPDATE_P, 3 * 24.0 * c->n);
     launch_update_p(c->stream, c->n, c->d_S, c->d_zparts, gz, parts2 + kMaxPartials, g2, c->d_zparts + kMaxPartials,
-                    c->d_z, c->d_p, rec_dev(c), defl_dev(c));
+                    c->d_z, c->d_p, rec_dev(c));
   } else {
     Scope sc(c, K_UPDATE_P, 3 * 24.0 * c->n);
     RecDev rec;
@@ -513,9 +391,11 @@ int pcg_iteration(sgo_ctx* c) {
   return SGO_OK;
 }
 
-int ensure_pcg_graph(sgo_ctx* c, int chunk) {
-  const int key = (c->ov.active ? 1 : 0) | (c->defl_on ? 2 : 0) | (c->defl_rec ? 4 : 0);
+int ensure_pcg_graph(sgo_ctx* c, int chunk, bool* captured) {
+  const int key = c->ov.active ? 1 : 0;
+  if (captured) *captured = false;
   if (c->pcg_exec && c->pcg_exec_chunk == chunk && c->pcg_exec_key == key) return SGO_OK;
+  if (captured) *captured = true;   // (attempted: every rank of a multi-GPU run gets here at the same solve)
   if (c->pcg_exec) {
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     hipGraphExecDestroy(c->pcg_exec);
@@ -558,19 +438,45 @@ int run_pcg(sgo_ctx* c) {
   // rank replays the same graph the same number of times: the replay count follows snapshots of the device-resident stop flag
   // taken at fixed points of the stream, bit-identical on all ranks; the exchanges of the set-up and of the solve's start have
   // run eagerly before, so the communicator's channels exist when the capture begins).  Measured with a 1-rank communicator
-  // on C4: 191 -> 203 M edge-Jacobians/s.  SGO_COMM_GRAPH=0 keeps plain stream launches; a capture that fails falls back to
-  // them for the rest of the context's life.  Not possible with the host transport (a host callback inside the loop).
-  bool comm_graph = c->comm.handle != nullptr && !c->comm.host_fn && !c->comm_graph_failed;
-  if (const char* e = std::getenv("SGO_COMM_GRAPH")) comm_graph = comm_graph && std::atoi(e) != 0;
+  // on C4: 191 -> 203 M edge-Jacobians/s.  Not possible with the host transport (a host callback inside the loop).
+  // DEFAULT: on for a 1-rank communicator (the measured case: no peer to wait for), OFF for nranks > 1 -- RCCL with more than
+  // one rank has never executed on this code (no multi-GPU node: DESIGN.md section 6), and a hang there would cost the whole
+  // run; SGO_COMM_GRAPH=1 opts in, =0 opts out.  Whether the capture worked is decided COLLECTIVELY (an eager all-reduce of
+  // the ranks' failure flags right after the attempt): ranks that replay graphs and ranks that launch plainly would issue
+  // different numbers of collectives per solve and hang each other, so either all ranks replay or all fall back.
+  bool comm_graph = c->comm.handle != nullptr && !c->comm.host_fn && !c->comm_graph_failed && c->comm.nranks <= 1;
+  if (const char* e = std::getenv("SGO_COMM_GRAPH"))
+    comm_graph = c->comm.handle != nullptr && !c->comm.host_fn && !c->comm_graph_failed && std::atoi(e) != 0;
   bool graph = c->opts.use_graph && !c->opts.profile && (!multi_rank(c) || comm_graph);
   constexpr int kUnit = 2;   // iterations per graph replay (1: 44.6, 2: 41.2, 4: 42, 8: 47 us per PCG iteration on C2 -- a replay costs
                              // ~7 us, an iteration past convergence eight early-exit nodes)
   if (graph) {
-    const int grc = ensure_pcg_graph(c, kUnit);
-    if (grc != SGO_OK && multi_rank(c)) {
-      c->comm_graph_failed = true;
-      graph = false;
-      if (c->opts.verbose) std::fprintf(stderr, "[sgo] capturing the collectives failed (%s): plain stream launches from here on\n", c->err.c_str());
+    bool attempted = false;
+    const int grc = ensure_pcg_graph(c, kUnit, &attempted);
+    if (multi_rank(c)) {
+      int failed = grc != SGO_OK ? 1 : 0;
+      if (attempted && c->comm.nranks > 1) {   // the ranks agree on the outcome before anyone replays
+        if (!c->d_comm_flag) HIP_TRY(c, hipMalloc((void**)&c->d_comm_flag, sizeof(int)));
+        HIP_TRY(c, hipMemcpyAsync(c->d_comm_flag, &failed, sizeof(int), hipMemcpyHostToDevice, c->stream));
+        std::string cerr;
+        if (!c->comm.allreduce_i32(c->d_comm_flag, 1, c->stream, &cerr)) {
+          c->err = "all-reduce of the capture flags: " + cerr;
+          return SGO_ECOMM;
+        }
+        HIP_TRY(c, hipMemcpyAsync(&failed, c->d_comm_flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+      }
+      if (failed) {
+        if (c->pcg_exec) {   // (this rank's capture worked, another rank's did not)
+          hipGraphExecDestroy(c->pcg_exec);
+          c->pcg_exec = nullptr;
+        }
+        c->comm_graph_failed = true;
+        graph = false;
+        if (c->opts.verbose)
+          std::fprintf(stderr, "[sgo] capturing the collectives failed on %d rank(s)%s%s: plain stream launches on all ranks from here on\n", failed,
+                       grc != SGO_OK ? "; here: " : "", grc != SGO_OK ? c->err.c_str() : "");
+      }
     } else if (grc != SGO_OK) {
       return grc;
     }
@@ -597,10 +503,7 @@ int run_pcg(sgo_ctx* c) {
   const int chunk_launches = std::max(1, c->opts.pcg_chunk / 16);
   // unchecked prefix: 80 % of the previous count minus a margin (a solve that converges earlier
   // than that only wastes ~1 us per early-exit launch; tighter margins measured no different)
-  // (a prediction made by a solve of the other kind -- plain / deflated -- is scaled: deflation takes about 0.6 of the count)
-  int pred = c->pcg_pred;
-  if (c->defl_on != c->pred_defl) pred = c->defl_on ? pred * 6 / 10 : pred;
-  c->pred_defl = c->defl_on;
+  const int pred = c->pcg_pred;
   const int unchecked = std::max(0, (int)(0.8 * pred) - 4) / kUnit;
   for (int k = 0; k < unchecked; ++k) HIP_TRY(c, hipGraphLaunch(c->pcg_exec, c->stream));
   // The stop flag is read from the pinned mirror every k_update_p rewrites (RecDev::mirror) behind an event: no copy kernel
@@ -658,8 +561,6 @@ int build_amg(sgo_ctx* c) {
   }
   c->pcg_pred = 0;  // the iteration count of the old hierarchy predicts nothing about the new one
   c->amg_best = 0;
-  c->defl_ready = false;   // (Ritz vectors of the old preconditioned operator)
-  c->defl_best = 0;
   if (c->amg) {
     amg_destroy(c->amg);
     c->amg = nullptr;
@@ -714,11 +615,21 @@ int build_amg(sgo_ctx* c) {
   if (c->amg) {
     if (!c->owner && multi_rank(c))
       amg_set_shard(c->amg, &c->comm, c->shard_u0, c->shard_u1, c->shard_row0, c->shard_row1, c->gather_slices ? &c->halo : nullptr);
-    amg_describe(c->amg, &c->solver_desc);
-    c->solver_desc = "pcg_amg: " + c->solver_desc;
-    c->solver_desc += multi_gpu_description(c);
+    // (a graph on the single-launch direct or the multifrontal path gets here through a single-step entry point -- sgo_linearize,
+    // sgo_solve --: sgo_optimize_gn keeps running the factorisation, and the description keeps saying so)
+    std::string amg_desc;
+    amg_describe(c->amg, &amg_desc);
+    if (c->direct || c->mf) {
+      const size_t cut = c->solver_desc.find("; single-step entry points: ");
+      if (cut != std::string::npos) c->solver_desc.resize(cut);
+      c->solver_desc += "; single-step entry points: pcg_amg: " + amg_desc;
+    } else {
+      c->solver_desc = "pcg_amg: " + amg_desc;
+      c->solver_desc += multi_gpu_description(c);
+    }
   } else {
-    c->solver_desc = "pcg_block_jacobi (AMG unavailable: " + aerr + ")";
+    if (c->direct || c->mf) c->solver_desc += "; single-step entry points: pcg_block_jacobi (AMG unavailable: " + aerr + ")";
+    else c->solver_desc = "pcg_block_jacobi (AMG unavailable: " + aerr + ")";
     if (c->opts.verbose) std::fprintf(stderr, "[sgo] %s\n", c->solver_desc.c_str());
   }
   return SGO_OK;
@@ -948,9 +859,7 @@ int optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
           std::fprintf(stderr, "[sgo] iteration %d: solve abandoned after %d PCG iterations, hierarchy rebuilt\n", it, wasted);
       }
       const PcgScalars S = *c->h_S;
-      // iteration counts are compared among solves of the same kind (plain / deflated)
-      int& best_pcg = c->defl_on ? c->defl_best : c->amg_best;
-      if (c->defl_rec && S.stop == 1 && (rc = build_ritz(c, S.iter))) return rc;   // the next solves' deflation space
+      int& best_pcg = c->amg_best;
       if (it == 0 && c->tol_cap > 0.0 && S.stop == 1) c->bb_ref = S.bb;
       if (c->amg && S.stop != 3) {
         // Iteration counts are compared at EQUAL tolerance: a solve that stopped at the absolute criterion (a looser
@@ -969,8 +878,6 @@ int optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
         const bool doubled = eq_iter > 2 * best_pcg + 10;
         const bool pays = 4 * eq_iter > 5 * best_pcg && (long long)(eq_iter - best_pcg) * left > 150;
         if (rebuilds < 3 && (doubled || pays)) rebuild_next = true;
-        // a deflation space that has drifted away from the slow modes (counts only): the next solve runs plain and records again
-        if (c->defl_on && !rebuild_next && eq_iter > best_pcg + best_pcg / 2 + 4) c->defl_ready = false;
       }
       its_sum += S.iter + wasted;
       if (it == 0 && S.stop == 1) {   // the call's first solve: what the incremental set-up's staleness rule compares (sgo_ctx.h)

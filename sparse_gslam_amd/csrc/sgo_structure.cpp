@@ -122,8 +122,7 @@ void free_graph(sgo_ctx* c) {
   c->ov.dev.ncol = 1;
   c->ov.dev.el.cnt = 0;
   c->pcg_exec_key = 0;
-  c->defl_ready = c->defl_on = c->defl_rec = false;
-  c->defl_k = 0;
+  c->d_lanczos = nullptr;   // (lived in the graph arena)
   c->its_base = c->its_last = 0;
   c->update_note.clear();
 }
@@ -817,34 +816,9 @@ int build_structure(sgo_ctx* c, int V, const double* poses, const uint8_t* fixed
   if ((rc = dalloc(c, &c->d_xprev, n3))) return rc;
   if ((rc = dalloc(c, &c->d_zparts, 2 * (size_t)kMaxPartials))) return rc;
   if ((rc = dalloc(c, &c->d_S, 1))) return rc;
-  // deflated PCG (single GPU, multigrid preconditioner): W, H W, the record of one solve's Lanczos vectors
+  // diagnostic record of the PCG recurrence's coefficients (scripts/ritz_probe.py)
   c->d_lanczos = nullptr;
-  c->defl_k = 0;
-  c->defl_ready = c->defl_on = c->defl_rec = false;
-  c->defl_best = 0;
-  {
-    // OFF by default -- measured in round 4 (NOTES.md section 9): the low end of the spectrum of M^-1 H is a continuum, not a few
-    // outliers: with 8 recycled Ritz vectors deflated the smallest Ritz value of C4 moves from 0.056 to 0.074 (not to the 9th,
-    // 0.276), 30 -> 25 iterations, and H W + the extra launch cost more than that saves (4.0 -> 4.9 ms per GN iteration).
-    // SGO_DEFLATE=k (<= 8) turns it on.
-    int k = 0;
-    if (const char* e = std::getenv("SGO_DEFLATE")) k = std::max(0, std::min(kDeflMax, std::atoi(e)));
-    if (c->opts.solver != SGO_SOLVER_PCG_AMG || c->comm.active() || c->comm.nranks > 1 || n < 2000) k = 0;   // (small graphs: a dense or two-level solve)
-    if (k > 0 || std::getenv("SGO_LANCZOS")) {
-      if ((rc = dalloc(c, &c->d_lanczos, 3 * (size_t)kLanczosMax))) return rc;
-    }
-    if (k > 0) {
-      // as many Lanczos vectors as 1 GiB holds, at most 64 (the smallest Ritz values have settled long before)
-      c->defl_zmax = (int)std::max<size_t>(16, std::min<size_t>(64, ((size_t)1 << 30) / (sizeof(double) * n3 + 1)));
-      if ((rc = dalloc(c, &c->d_W, (size_t)k * n3)) || (rc = dalloc(c, &c->d_HW, (size_t)k * n3)) ||
-          (rc = dalloc(c, &c->d_Ginv, (size_t)kDeflMax * kDeflMax)) || (rc = dalloc(c, &c->d_dparts, (size_t)kDeflMax * kDeflGrid)) ||
-          (rc = dalloc(c, &c->d_gram, (size_t)kDeflMax * kDeflMax * kDeflGrid)) || (rc = dalloc(c, &c->d_Zbuf, (size_t)c->defl_zmax * n3)) ||
-          (rc = dalloc(c, &c->d_ritzC, (size_t)64 * kDeflMax)))
-        return rc;
-      HIP_TRY(c, hipMemsetAsync(c->d_dparts, 0, sizeof(double) * kDeflMax * kDeflGrid, c->stream));
-      c->defl_k = k;
-    }
-  }
+  if (std::getenv("SGO_LANCZOS") && (rc = dalloc(c, &c->d_lanczos, 3 * (size_t)kLanczosMax))) return rc;
   HIP_TRY(c, hipMemsetAsync(c->d_S, 0, sizeof(PcgScalars), c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));  // host staging vectors die at return
   if (c->opts.verbose)

@@ -111,17 +111,6 @@ def test_two_runs_are_bitwise_identical():
     assert a[2]["chi2"] == b[2]["chi2"] and np.array_equal(a[3], b[3])
 
 
-def test_single_launch_substitution_option_is_the_same_arithmetic(monkeypatch):
-    """SGO_MFRONT_FUSED_SOLVE=1: the backward substitution of the whole tree as ONE launch, fronts waiting for their parents'
-    flags (measured slower than one launch per level -- DESIGN.md section 5c -- and kept as an option): same sums in the same
-    order, bit for bit."""
-    g = chain_graph(2500, 700, seed=12)
-    a = run(g.arrays())
-    monkeypatch.setenv("SGO_MFRONT_FUSED_SOLVE", "1")
-    b = run(g.arrays())
-    assert a[1] == b[1] == 20 and a[2]["chi2"] == b[2]["chi2"] and np.array_equal(a[3], b[3])
-
-
 def test_duplicate_edges_fixed_poses_a_hub_and_edges_between_fixed_poses():
     """Several edges on one pair (summed in edge order), a pose with many incident closures, fixed poses in the middle
     of the chain (their edges contribute to the free endpoint's diagonal block and right-hand side only), edges between
@@ -300,6 +289,41 @@ def test_growth_through_the_update_entry_point_is_a_full_set_up_and_says_so():
         o.set_graph(P, fixed, cat("ei"), cat("ej"), cat("meas"), cat("info"), cat("phi"))
         done2, st2 = o.optimize(5)
         assert done == done2 == 5 and st["chi2"] == st2["chi2"] and np.array_equal(Pu, o.get_poses())
+
+
+def test_update_after_a_single_step_entry_point_is_still_a_full_set_up():
+    """sgo_linearize on a multifrontal graph builds the PCG structures on demand and clears the pending flags; a
+    following sgo_update_graph_se2 must NOT become an overlay (sgo_optimize_gn keeps taking the factorisation path, which would
+    leave the appended poses and edges out): it is a full set-up, the description keeps naming the factorisation, and the
+    iterates equal those of a fresh sgo_set_graph_se2 bit for bit."""
+    base, steps, g = synth.append_session(1500, 2200, 1, 10, 29, info_mode="full", phi=0.75)
+    V1 = steps[0]["V"]
+    fixed = np.zeros(V1, dtype=bool)
+    fixed[:base.V] = base.fixed
+    cat = lambda k: np.concatenate([getattr(base, k), steps[0][k]])   # noqa: E731
+    with capi.Optimizer(0, direct_rows=1) as o:
+        o.set_graph(*base.arrays())
+        assert o.solver_description().startswith("multifrontal_cholesky")
+        o.linearize()   # ensure_amg: hierarchy on demand
+        d = o.solver_description()
+        assert d.startswith("multifrontal_cholesky") and "single-step entry points: pcg_" in d, d
+        P = np.zeros((V1, 3))
+        P[:base.V] = o.get_poses()
+        synth.chain_init(P, g.meas[: g.V - 1], base.V, V1 - 1)
+        o.update_graph(P, fixed, cat("ei"), cat("ej"), cat("meas"), cat("info"), cat("phi"), base.E)
+        d = o.solver_description()
+        assert d.startswith("multifrontal_cholesky") and "incremental overlay" not in d and "full set-up" in d, d
+        assert o.n_free == V1 - int(fixed.sum())
+        done, st = o.optimize(5)
+        Pu = o.get_poses()
+        c_after, _ = o.chi2()
+    with capi.Optimizer(0, direct_rows=1) as o:
+        o.set_graph(P, fixed, cat("ei"), cat("ej"), cat("meas"), cat("info"), cat("phi"))
+        done2, st2 = o.optimize(5)
+        assert done == done2 == 5 and st["chi2"] == st2["chi2"] and np.array_equal(Pu, o.get_poses())
+        assert st["chi2"][-1] == pytest.approx(c_after, rel=1e-12)   # the history covers the appended edges too
+    # the appended poses moved (they were optimised)
+    assert np.abs(Pu[base.V:] - P[base.V:]).max() > 0.0
 
 
 def test_profile_names_the_path_and_stats_carry_device_times():

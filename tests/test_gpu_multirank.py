@@ -282,3 +282,31 @@ def test_fewer_tiles_than_ranks_runs_replicated():
     assert np.abs(np.frombuffer(res[0][4], dtype=np.float64).reshape(-1, 3) - P).max() <= 1e-9
     for a, b in zip(res[0][2], st["chi2"]):
         assert abs(a - b) <= 1e-9 * b
+
+
+def test_bench_gpus_2_runs_end_to_end_over_the_host_transport():
+    """`bench.py --gpus N` as the driver launches it (python -m torch.distributed.run, one process per rank, rendezvous on
+    127.0.0.1), with --transport host: the rank processes share this box's one GPU and libsgo's collectives go through
+    sgo_comm_init_host + gloo.  The whole launcher path runs -- rendezvous, every rank marshalling the graph, the library's
+    choice of the sharding mode, barrier + MAX-reduce of the time, ONE JSON line from rank 0 -- and the final chi2 is within
+    BASELINE.json's 1e-6 of the direct-solver golden.  (A functional run: the line's `transport` says it is no scaling figure.)"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+           "--config", "C2", "--transport", "host", "--no-cpu-baseline", "--no-roofline"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout          # rank 0 alone prints
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 1 and out["scaling"] == "strong"
+    assert out["metric"].startswith("edge-Jacobians/sec per GN iter")
+    assert "row-owner mode" in out["config"]["parallelism"] or "all-reduce mode" in out["config"]["parallelism"], out["config"]
+    assert out["config"]["transport"].startswith("host")
+    assert out["value"] > 0 and out["ms_per_step"] > 0
+    err = out["final_chi2_rel_err_vs_oracle"]
+    assert err is not None and err["value"] <= 1e-6, err
