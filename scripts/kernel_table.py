@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-kernel time table (profile mode: every launch bracketed by its own dispatch events) of optimize(iters) on a named
-config: `python scripts/kernel_table.py C4r [iters]`."""
+config: `python scripts/kernel_table.py C4r [iters] [key=value ...]` (generator overrides, e.g. init=odom)."""
 import os
 import sys
 
@@ -9,7 +9,8 @@ from sparse_gslam_amd import capi, synth  # noqa: E402
 
 name = sys.argv[1] if len(sys.argv) > 1 else "C4"
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 4
-g = synth.config(name)
+over = dict(a.split("=", 1) for a in sys.argv[3:])
+g = synth.config(name, **over)
 with capi.Optimizer(0, profile=1) as o:
     o.set_graph(*g.arrays())
     print(o.solver_description(), flush=True)
