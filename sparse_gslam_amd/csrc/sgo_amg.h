@@ -20,6 +20,12 @@ struct AmgConfig {
                                // graphs with >= 6 * 10^5 level-0 blocks, where a coarse sweep is cheap next to level 0
   bool smooth = true;          // smoothed aggregation: P = (I - omega_p D^-1 A) T (env SGO_AMG_SMOOTH=0: tentative P)
   double omega_p = 0.66;       // damping of the prolongator smoothing step
+  double theta_filter = 1e-3;       // ... "strong" for that filter: w_ij >= theta_filter sqrt(w_ii w_jj) -- far below the aggregation's
+                                    // threshold: only connections that are NEGLIGIBLE are dropped (closures DCS has switched off),
+                                    // not merely the ones the aggregation does not follow (env SGO_AMG_THETA_FILTER)
+  bool filtered_smoothing = true;   // a level whose transfer smoothed with the whole operator would be too dense tries the operator of
+                                    // the strong connections before it falls back to the tentative transfer (SaHost::filtered,
+                                    // sgo_amg_host.h; env SGO_AMG_FILTER=0: straight to the tentative one, as before round 5)
   bool fold = true;             // folded V-cycle (sgo_amg.hip): the post- and pre-smoothing sweeps of the smoothed levels folded into
                                 // the transfer operator P~ = (I - omega D^-1 A) P; one sweep per level (env SGO_AMG_FOLD=0: the
                                 // sweeps as launches of their own, nu_coarse as below)
@@ -106,6 +112,7 @@ double amg_omega(const Amg* m);
 // true when the last amg_update met a non-positive pivot in the coarsest operator (synchronises `s`)
 bool amg_coarsest_not_spd(Amg* m, hipStream_t s);
 int amg_num_levels(const Amg* m);
+bool amg_has_filtered(const Amg* m);   // some level's transfer is smoothed with the filtered operator (SaHost::filtered)
 long long amg_level0_bytes(const Amg* m);   // device bytes of the level-0 transfer (P, A P, product lists) this rank holds
 void amg_describe(const Amg* m, std::string* out);
 

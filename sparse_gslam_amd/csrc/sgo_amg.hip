@@ -204,6 +204,13 @@ struct PDev {
   int* rap_mirror = nullptr; // [coarse slots] slot (c, a) of an upper slot (a, c): gets the transposed block (-1: none)
   bool local_lists = false;  // row-owner mode: val / ap / rap list THIS rank's rows' products only (targets of P^T A P without
                              // any are not visited: the caller zeroes the coarse blocks first)
+  // FILTERED smoothing (SaHost::filtered): P = (I - w D_F^-1 A_F) T with the operator of the strong connections.  val lists
+  // the kept slots only; the diagonal block and its inverse come from here instead of from the level's operator
+  const unsigned char* strong = nullptr;   // [nslot]
+  double* dF = nullptr;                    // [n][9] D_F, row-major (k_filtered_diag; NOT symmetric on the coarse levels, see there)
+  double* dinvF = nullptr;                 // [n][9] its inverse
+  int* f_grp = nullptr;                    // wave groups over the level's slots aligned to rows (level 0's logical view has none)
+  int f_ngrp = 0;
 };
 
 // entry e of a streamed fp32 copy of P (quad-SoA): two 16-byte loads and one 4-byte load per lane; non-temporal on the
@@ -232,7 +239,83 @@ __device__ __forceinline__ void load9(const double* __restrict__ base, size_t e,
   for (int c = 0; c < 9; ++c) v[c] = base[9 * e + c];
 }
 
+// Diagonal blocks of the FILTERED operator A_F (smoothing the tentative transfer with the strong connections only, SaHost in
+// sgo_amg_host.h).  A weak block A_ij is dropped TOGETHER WITH its share of the diagonal block: every edge's contribution to row
+// i annihilates the rigid motions, A_ii^e T(p_i) + A_ij^e T(p_j) = 0 with T(p) = [[1,0,-p_y],[0,1,p_x],[0,0,1]], hence
+// A_ii^e = -A_ij^e G_ji with G_ji = T(p_j) T(p_i)^-1 = T(p_j - p_i) -- which holds for the assembled blocks and, because the
+// transfers reproduce the rigid motions exactly, for the Galerkin operators of the coarse levels too.  So
+//     D_F,i = D_i + sum over the weak slots k = (i, j) of A_k T(p_j - p_i)
+// is the diagonal block the strong connections alone would have assembled (anchored rows keep their anchor: an edge to a fixed
+// vertex has no off-diagonal block to be weak), and A_F T = 0 in the interior exactly as A T = 0: the smoothed columns keep
+// representing the rigid motions.  D_F is NOT symmetrised: on level 0 every term A_k T(p_j - p_i) = -A_ii^e is symmetric, but a
+// coarse level's operator is a sum of elements over up to four nodes each (a fine edge seen through the smoothed transfer), only
+// the SUM over an element's nodes is symmetric, and the symmetric part alone does not keep the row sums: A_F T = O(1e-5 |D|)
+// instead of 0, the next level's transfer then misses the rigid motions by as much -- five orders of magnitude above the weak
+// connections' own energy -- and the cycle stalls (measured on a numpy prototype of the whole hierarchy, 20k poses from a
+// dead-reckoned start: 141 PCG iterations with the symmetrised block, 36 without; the tentative transfer: 266).  D_F is only a
+// recipe for P; the coarse operator P^T A P is symmetric whatever it is.
+// One lane per slot, rows in wave groups, segmented scan per row; the row's last lane adds D_i and inverts (general 3x3).
+// Rows [row0, row1) only when row1 > 0.
+__global__ __launch_bounds__(kBlock) void k_filtered_diag(BsrDev F, const int* __restrict__ grp, int ngrp, const unsigned char* __restrict__ strong,
+                                                          const double* __restrict__ pos, double* __restrict__ dF, double* __restrict__ dinvF,
+                                                          int row0, int row1) {
+  const int lane = threadIdx.x & 63;
+  int gi, gend, gstride;
+  group_walk(ngrp, &gi, &gend, &gstride);
+  for (; gi < gend; gi += gstride) {
+    const int gb = grp[gi], ge = grp[gi + 1];
+    double acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // [9]: the row's kept off-diagonal slots (counted)
+    int key = -1 - lane;
+    for (int k = gb + lane; k < ge; k += 64) {
+      const int i = F.row[k];
+      if (row1 > 0 && (i < row0 || i >= row1)) {
+        key = -1 - lane;
+        continue;
+      }
+      key = i;
+      const int j = F.col[k];
+      if (j == i) continue;
+      if (strong[k]) {
+        acc[9] += 1.0;
+        continue;
+      }
+      const double dx = pos[2 * (size_t)j] - pos[2 * (size_t)i], dy = pos[2 * (size_t)j + 1] - pos[2 * (size_t)i + 1];
+      double b[9];
+      load_block(F, (size_t)k, b);
+      acc[0] += b[0]; acc[1] += b[1]; acc[2] += -dy * b[0] + dx * b[1] + b[2];
+      acc[3] += b[3]; acc[4] += b[4]; acc[5] += -dy * b[3] + dx * b[4] + b[5];
+      acc[6] += b[6]; acc[7] += b[7]; acc[8] += -dy * b[6] + dx * b[7] + b[8];
+    }
+    seg_scan<10>(key, acc, lane);
+    const int kn = next_lane_key(key);
+    if (key >= 0 && (lane == 63 || kn != key)) {
+      double d[9];
+      load_block(F, (size_t)F.rowptr[key], d);   // the diagonal slot comes first in its row
+      // (a row without any kept connection keeps its whole diagonal block: with everything lumped D_F would be the row sum of
+      // the rigid motions -- zero up to rounding in the interior -- and its "inverse" noise; nothing smooths such a row anyway)
+      const double keep = acc[9] > 0.0 ? 1.0 : 0.0;
+#pragma unroll
+      for (int c = 0; c < 9; ++c) d[c] += keep * acc[c];
+      // inverse by cofactors: inv[r][c] = cof[c][r] / det
+      const double c00 = d[4] * d[8] - d[5] * d[7], c01 = d[5] * d[6] - d[3] * d[8], c02 = d[3] * d[7] - d[4] * d[6];
+      const double c10 = d[2] * d[7] - d[1] * d[8], c11 = d[0] * d[8] - d[2] * d[6], c12 = d[1] * d[6] - d[0] * d[7];
+      const double c20 = d[1] * d[5] - d[2] * d[4], c21 = d[2] * d[3] - d[0] * d[5], c22 = d[0] * d[4] - d[1] * d[3];
+      const double det = d[0] * c00 + d[1] * c01 + d[2] * c02;
+      const double id = (det != 0.0 && isfinite(det)) ? 1.0 / det : 0.0;
+      double* o = dF + 9 * (size_t)key;
+#pragma unroll
+      for (int c = 0; c < 9; ++c) o[c] = d[c];
+      double* di = dinvF + 9 * (size_t)key;
+      di[0] = c00 * id; di[1] = c10 * id; di[2] = c20 * id;
+      di[3] = c01 * id; di[4] = c11 * id; di[5] = c21 * id;
+      di[6] = c02 * id; di[7] = c12 * id; di[8] = c22 * id;
+    }
+  }
+}
+
 // P_e = [e is the own-aggregate entry] T_i - w D_i^-1 sum_{k in e} A_k T_col(k)
+// (filtered smoothing, P.dF != nullptr: the listed slots are the kept ones, D_F in place of D_i -- also for the diagonal slot's
+// own term)
 // (multi-GPU, row-owner mode: the entries of the rows [row0, row1) only; row1 == 0: all)
 __global__ __launch_bounds__(kBlock) void k_p_values(BsrDev F, PDev P, const int* __restrict__ agg,
                                                      const double* __restrict__ d, double omega_p, int row0, int row1) {
@@ -257,6 +340,11 @@ __global__ __launch_bounds__(kBlock) void k_p_values(BsrDev F, PDev P, const int
       const double dxj = d[2 * (size_t)j], dyj = d[2 * (size_t)j + 1];
       double b[9];
       load_block(F, (size_t)k, b);
+      if (P.dF && k == F.rowptr[j]) {   // the diagonal slot of a filtered level (column j = its own row)
+        const double* f = P.dF + 9 * (size_t)j;
+#pragma unroll
+        for (int c = 0; c < 9; ++c) b[c] = f[c];
+      }
       acc[0] += b[0]; acc[1] += b[1]; acc[2] += -dyj * b[0] + dxj * b[1] + b[2];
       acc[3] += b[3]; acc[4] += b[4]; acc[5] += -dyj * b[3] + dxj * b[4] + b[5];
       acc[6] += b[6]; acc[7] += b[7]; acc[8] += -dyj * b[6] + dxj * b[7] + b[8];
@@ -265,13 +353,23 @@ __global__ __launch_bounds__(kBlock) void k_p_values(BsrDev F, PDev P, const int
     const int kn = next_lane_key(key);
     if (key >= 0 && (lane == 63 || kn != key)) {
       const size_t i = (size_t)P.row[key];
-      const double* di = F.dinv + 6 * i;
       double o[9];
+      if (P.dinvF) {   // filtered smoothing: the general 3x3 inverse of D_F
+        const double* di = P.dinvF + 9 * i;
 #pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        o[c] = -omega_p * (di[0] * acc[c] + di[1] * acc[3 + c] + di[2] * acc[6 + c]);
-        o[3 + c] = -omega_p * (di[1] * acc[c] + di[3] * acc[3 + c] + di[4] * acc[6 + c]);
-        o[6 + c] = -omega_p * (di[2] * acc[c] + di[4] * acc[3 + c] + di[5] * acc[6 + c]);
+        for (int c = 0; c < 3; ++c) {
+          o[c] = -omega_p * (di[0] * acc[c] + di[1] * acc[3 + c] + di[2] * acc[6 + c]);
+          o[3 + c] = -omega_p * (di[3] * acc[c] + di[4] * acc[3 + c] + di[5] * acc[6 + c]);
+          o[6 + c] = -omega_p * (di[6] * acc[c] + di[7] * acc[3 + c] + di[8] * acc[6 + c]);
+        }
+      } else {
+        const double* di = F.dinv + 6 * i;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          o[c] = -omega_p * (di[0] * acc[c] + di[1] * acc[3 + c] + di[2] * acc[6 + c]);
+          o[3 + c] = -omega_p * (di[1] * acc[c] + di[3] * acc[3 + c] + di[4] * acc[6 + c]);
+          o[6 + c] = -omega_p * (di[2] * acc[c] + di[4] * acc[3 + c] + di[5] * acc[6 + c]);
+        }
       }
       if (P.col[key] == agg[i]) {
         o[0] += 1.0; o[4] += 1.0; o[8] += 1.0;
@@ -1551,6 +1649,11 @@ void launch_coarse_operator(Amg* m, hipStream_t s, AmgLevel& L, AmgLevel& C, boo
     return;
   }
   PDev& P = L.P;
+  if (P.dF) {   // filtered smoothing: the diagonal blocks of the strong connections' operator first
+    Scope sc(m->prof, level0 ? K_SA_P0 : K_SA_P, (72.0 + 9.0 + 16.0) * L.A.nslot + 144.0 * L.A.n);
+    SGO_LAUNCH(k_filtered_diag, dim3(grid_for(P.f_ngrp, kWavesPerBlock)), dim3(kBlock), 0, s, L.A, (const int*)P.f_grp, P.f_ngrp, P.strong,
+               (const double*)L.pos, P.dF, P.dinvF, row0, row1);
+  }
   {
     Scope sc(m->prof, level0 ? K_SA_P0 : K_SA_P, (72.0 + 12.0 + 16.0) * P.val.n + 80.0 * P.r_n);
     SGO_LAUNCH(k_p_values, dim3(grid_for(P.val.ngrp, kWavesPerBlock)), dim3(kBlock), 0, s, L.A, P, (const int*)L.agg,
@@ -1922,6 +2025,12 @@ int cycle(Amg* m, hipStream_t s, int l, const double* rhs, const double* rhs_sub
 }  // namespace
 
 int amg_num_levels(const Amg* m) { return m ? (int)m->lv.size() : 0; }
+bool amg_has_filtered(const Amg* m) {
+  if (m)
+    for (const AmgLevel& L : m->lv)
+      if (L.smoothed && L.P.dF) return true;
+  return false;
+}
 long long amg_level0_bytes(const Amg* m) { return m ? m->level0_bytes : 0; }
 bool amg_coarsest_not_spd(Amg* m, hipStream_t s) {
   int f = 0;
@@ -2083,6 +2192,8 @@ AmgConfig amg_effective_config(const AmgConfig& cfg_in, int n, int nslot) {
                                              // iteration with two sweeps; 20k / 200k 1.81 -> 1.91, C2 1.24 -> 1.36)
   if (const char* e = std::getenv("SGO_AMG_SMOOTH")) cfg.smooth = std::atoi(e) != 0;
   if (const char* e = std::getenv("SGO_AMG_LISTS")) cfg.lists_on_device = std::string(e) != "host";
+  if (const char* e = std::getenv("SGO_AMG_THETA_FILTER")) cfg.theta_filter = std::atof(e);
+  if (const char* e = std::getenv("SGO_AMG_FILTER")) cfg.filtered_smoothing = cfg.filtered_smoothing && std::atoi(e) != 0;   // (can only switch it off)
   // (experiment knobs of scripts/param_sweep.py.  Round 3, folded cycle, optimize(20) on C4 / C2 / C3s: omega 0.7 / 0.8 / 0.9 /
   // 1.0 -> 473 / 442 / 422 / 1015 PCG iterations on C4 (0.9 is 3-5 % better on every shape of scripts/robustness.py, 1.0 is
   // past the cliff: the default keeps its margin); omega_p 0.5 / 0.66 / 0.8 / 1.0 -> 486 / 442 / 557 / 809; theta 0.01 / 0.02 /
@@ -2253,13 +2364,25 @@ Amg* amg_create(hipStream_t s, const BsrDev& A0, const Sym0Dev& S0, const Tile0D
       if (own && !sa.lists_on_device) return fail("amg_create: the row-owner mode needs the device-made product lists (SGO_AMG_LISTS=host is single-GPU only)");
       const int orow0 = own ? halo->dev->row0 : 0, orow1 = own ? halo->dev->row1 : n;
       const size_t E0 = (size_t)sa.p_rowptr[orow0], E1 = (size_t)sa.p_rowptr[orow1], npl = E1 - E0;   // entries of P held
-      const size_t V0 = (size_t)H.rowptr[orow0], V1 = (size_t)H.rowptr[orow1];                        // their value products
+      const size_t V0 = (size_t)sa.val_rowptr[orow0], V1 = (size_t)sa.val_rowptr[orow1];              // their value products (kept slots)
       auto up_range = [&](const int* host, size_t lo, size_t hi) -> int* {   // device copy of host[lo, hi), addressed by global numbers
         int* d = dev_alloc<int>(m->pool, hi - lo);
         if (d && hi > lo) hipMemcpyAsync(d, host + lo, (hi - lo) * sizeof(int), hipMemcpyHostToDevice, s);
         return d ? d - lo : nullptr;
       };
       P.local_lists = own;
+      if (sa.filtered) {
+        unsigned char* d_strong = (unsigned char*)m->pool->take(std::max<size_t>(sa.strong.size(), 1));
+        P.dF = dev_alloc<double>(m->pool, 9 * (size_t)n);
+        P.dinvF = dev_alloc<double>(m->pool, 9 * (size_t)n);
+        if (!d_strong || !P.dF || !P.dinvF) return fail("amg_create: out of device memory");
+        hipMemcpyAsync(d_strong, sa.strong.data(), sa.strong.size(), hipMemcpyHostToDevice, s);
+        P.strong = d_strong;
+        const std::vector<int> fg = make_groups(H.rowptr);
+        P.f_grp = dev_upload(m->pool, fg, s);
+        P.f_ngrp = (int)fg.size() - 1;
+        if (!P.f_grp || hipStreamSynchronize(s) != hipSuccess) return fail("amg_create: out of device memory");   // (fg is a local)
+      }
       P.np = (int)sa.p_row.size();
       P.stream_nt = npl >= 200000 ? 1 : 0;   // 2 x 72 B per block streamed per cycle: below ~30 MB it may stay cached
       P.rowptr = dev_upload(m->pool, sa.p_rowptr, s);
@@ -2494,7 +2617,7 @@ Amg* amg_create(hipStream_t s, const BsrDev& A0, const Sym0Dev& S0, const Tile0D
         halo->dev->pent = d_pe;
         if (halo->reserve && !halo->reserve(halo->user, (size_t)kHaloScalars + 9 * (size_t)pemax)) return fail("amg_create: out of device memory (exchange buffers)");
       }
-      std::snprintf(line, sizeof line, "(P %d, AP %d blocks; %d + %d products) ", P.np, P.nap, P.ap.n, P.rap.n);
+      std::snprintf(line, sizeof line, "(P %d%s, AP %d blocks; %d + %d products) ", P.np, sa.filtered ? " filtered" : "", P.nap, P.ap.n, P.rap.n);
       m->desc += line;
     } else {
       L.gal.n = H.nslot;

@@ -165,9 +165,11 @@ struct RowSorter {
 // with many long-range edges make the smoothed coarse operators nearly dense, and the caller then
 // keeps the tentative prolongator for this level.
 bool sa_symbolic(const HostLevel& H, const std::vector<int>& agg, int nc, const std::vector<int>& mem_ptr,
-                 const std::vector<int>& mem, long long budget, bool lists_on_device, SaHost& o) {
+                 const std::vector<int>& mem, long long budget, bool lists_on_device, SaHost& o, const unsigned char* strong = nullptr) {
   const int n = H.n;
   o.lists_on_device = lists_on_device;
+  // (filtered smoothing: a slot the filter drops contributes neither to P's pattern nor to its values)
+  auto kept = [&](int k) { return strong == nullptr || strong[k] != 0; };
   const bool verbose = std::getenv("SGO_VERBOSE") != nullptr;
   auto t0 = std::chrono::steady_clock::now();
   auto lap = [&](const char* what) {
@@ -177,11 +179,14 @@ bool sa_symbolic(const HostLevel& H, const std::vector<int>& agg, int nc, const 
   };
   // ---- P: row i holds the aggregates of the columns of row i (its own among them: diagonal slot)
   o.p_rowptr.assign((size_t)n + 1, 0);
+  o.val_rowptr.assign((size_t)n + 1, 0);
   host_parallel_for(n, 512, [&](int lo, int hi, int) {
     std::vector<int> mark((size_t)nc, -1);
     for (int i = lo; i < hi; ++i) {
-      int cnt = 0;
+      int cnt = 0, nk = 0;
       for (int k = H.rowptr[i]; k < H.rowptr[i + 1]; ++k) {
+        if (!kept(k)) continue;
+        ++nk;
         const int a = agg[H.col[k]];
         if (mark[a] != i) {
           mark[a] = i;
@@ -189,14 +194,18 @@ bool sa_symbolic(const HostLevel& H, const std::vector<int>& agg, int nc, const 
         }
       }
       o.p_rowptr[i + 1] = cnt;
+      o.val_rowptr[i + 1] = nk;
     }
   });
-  for (int i = 0; i < n; ++i) o.p_rowptr[i + 1] += o.p_rowptr[i];
-  const int np = o.p_rowptr[n];
+  for (int i = 0; i < n; ++i) {
+    o.p_rowptr[i + 1] += o.p_rowptr[i];
+    o.val_rowptr[i + 1] += o.val_rowptr[i];
+  }
+  const int np = o.p_rowptr[n], nval = o.val_rowptr[n];
   o.p_row.resize(np);
   o.p_col.resize(np);
-  o.val_src.resize(H.nslot);
-  o.val_tgt.resize(H.nslot);
+  o.val_src.resize(nval);
+  o.val_tgt.resize(nval);
   std::vector<int> val_ptr((size_t)np + 1);
   host_parallel_for(n, 512, [&](int lo, int hi, int) {
     std::vector<int> mark((size_t)nc, -1), pos((size_t)nc, 0), uniq;
@@ -204,6 +213,7 @@ bool sa_symbolic(const HostLevel& H, const std::vector<int>& agg, int nc, const 
     for (int i = lo; i < hi; ++i) {
       uniq.clear();
       for (int k = H.rowptr[i]; k < H.rowptr[i + 1]; ++k) {
+        if (!kept(k)) continue;
         const int a = agg[H.col[k]];
         if (mark[a] != i) {
           mark[a] = i;
@@ -218,16 +228,18 @@ bool sa_symbolic(const HostLevel& H, const std::vector<int>& agg, int nc, const 
         o.p_col[e0 + q] = uniq[q];
       }
       rs.begin((int)uniq.size());
-      for (int k = H.rowptr[i]; k < H.rowptr[i + 1]; ++k) rs.count(pos[agg[H.col[k]]]);
-      rs.start(H.rowptr[i], e0, val_ptr.data());
+      for (int k = H.rowptr[i]; k < H.rowptr[i + 1]; ++k)
+        if (kept(k)) rs.count(pos[agg[H.col[k]]]);
+      rs.start(o.val_rowptr[i], e0, val_ptr.data());
       for (int k = H.rowptr[i]; k < H.rowptr[i + 1]; ++k) {
+        if (!kept(k)) continue;
         const int q = pos[agg[H.col[k]]], dst = rs.place(q);
         o.val_src[dst] = k;
         o.val_tgt[dst] = e0 + q;
       }
     }
   });
-  val_ptr[np] = H.nslot;
+  val_ptr[np] = nval;
   o.val_grp = make_groups(val_ptr);
   lap("P");
   // ---- early verdict on the coarse operator's size from every 32nd coarse row (the exact count comes after the AP
@@ -597,8 +609,12 @@ void host_coarsen(const HostLevel& H, const std::vector<double>& w, const AmgCon
     return 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count();
   };
   if (scratch) scratch->rewind();   // (the previous level's lists have been uploaded: amg_create synchronises per level)
+  double theta_used = theta_l;
   int nc = aggregate(H, w, theta_l, agg, scratch);
-  if (nc > 0.9 * n) nc = aggregate(H, w, 0.0, agg, scratch);  // stalled: treat every connection as strong
+  if (nc > 0.9 * n) {   // stalled: treat every connection as strong
+    nc = aggregate(H, w, 0.0, agg, scratch);
+    theta_used = 0.0;
+  }
   if (nc > 0.9 * n || nc < 1) {                        // cannot coarsen further
     o.stop = true;
     return;
@@ -637,6 +653,53 @@ void host_coarsen(const HostLevel& H, const std::vector<double>& w, const AmgCon
       smooth = sa_symbolic(H, agg, nc, mem_ptr, mem, budget, cfg.lists_on_device, sa);
     } catch (const std::bad_alloc&) {
       smooth = false;
+    }
+    if (!smooth && theta_used > 0.0 && cfg.filtered_smoothing) {
+      // Second attempt: FILTERED smoothing.  The whole operator made P too dense -- many connections per row, e.g. the 10^6
+      // closures DCS has switched off at a dead-reckoned start (BASELINE.md's literal workload), each of them negligible next to
+      // the odometry chain --: smooth T with the operator of the strong connections only (the aggregation's own criterion), keep
+      // every connection in the Galerkin products.  Refused like the first when the coarse operator would still be too dense
+      // (random long-range closures at full weight are strong: C4r, C5 keep the tentative transfer).
+      sa = SaHost();
+      if (scratch) {
+        scratch->rewind();   // (the refused attempt's lists)
+        sa.ap_a.arena = sa.ap_b.arena = sa.ap_tgt.arena = scratch;
+        sa.val_src.arena = sa.val_tgt.arena = sa.ap_col.arena = sa.ap_row.arena = scratch;
+        sa.rap_a.arena = sa.rap_b.arena = sa.rap_tgt.arena = scratch;
+      }
+      std::vector<unsigned char> strong((size_t)H.nslot, 1);
+      long long nweak = 0;
+      {
+        std::vector<long long> part((size_t)std::max(1, std::min(HostPool::get().size(), n / 2048)) + 1, 0);
+        host_parallel_for(n, 2048, [&](int lo, int hi, int task) {
+          long long cnt = 0;
+          for (int i = lo; i < hi; ++i) {
+            const double di = w[H.rowptr[i]];
+            for (int k = H.rowptr[i] + 1; k < H.rowptr[i + 1]; ++k) {
+              const int j = H.col[k];
+              if (j == i) continue;   // (level 0: the block-less slot of an edge to a fixed vertex aliases the diagonal)
+              const double th = cfg.theta_filter * cfg.theta_filter * di * w[H.rowptr[j]];   // (aggregate()'s criterion, at the filter's threshold)
+              if (!(w[k] > 0.0 && w[k] * w[k] >= th)) {
+                strong[k] = 0;
+                ++cnt;
+              }
+            }
+          }
+          part[task] = cnt;
+        });
+        for (long long v : part) nweak += v;
+      }
+      if (nweak > 0) {
+        try {
+          smooth = sa_symbolic(H, agg, nc, mem_ptr, mem, budget, cfg.lists_on_device, sa, strong.data());
+        } catch (const std::bad_alloc&) {
+          smooth = false;
+        }
+      }
+      if (smooth) {
+        sa.filtered = true;
+        sa.strong = std::move(strong);
+      }
     }
     if (smooth) Hc = std::move(sa.Hc);
     else sa = SaHost();

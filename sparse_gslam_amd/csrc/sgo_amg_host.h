@@ -40,6 +40,13 @@ struct UVec {
   size_t size() const { return n; }
 };
 struct SaHost {
+  // FILTERED smoothing (the second attempt of host_coarsen, when the transfer smoothed with the whole operator is refused as too
+  // dense): P = (I - w D_F^-1 A_F) T with A_F the operator of the STRONG connections only (the aggregation's criterion) -- the
+  // weak blocks dropped together with their share of the diagonal, so that A_F still annihilates the rigid motions (k_filtered_diag,
+  // sgo_amg.hip).  P then has the pattern of the strong neighbours' aggregates; A P and P^T A P are made from the WHOLE operator.
+  bool filtered = false;
+  std::vector<unsigned char> strong;   // [nslot] 1 = kept by the filter (diagonal and alias slots included); empty when !filtered
+  std::vector<int> val_rowptr;         // [n + 1] range of row i's value products in val_src / val_tgt (the row's KEPT slots)
   std::vector<int> p_rowptr, p_row, p_col, val_grp;
   UVec val_src, val_tgt;   // (the large lists live in the set-up's scratch arena: storage kept between set-ups, no fresh pages)
   std::vector<int> r_grp, t_pos, t_row, t_col, t_grp;
@@ -64,7 +71,7 @@ struct HostCoarse {
   std::vector<int> agg, visit_c, mem_ptr, mem;
   int nc = 0;
   bool stop = false;     // the level cannot be coarsened further
-  bool smooth = false;
+  bool smooth = false;   // (sa.filtered says which smoothing)
   SaHost sa;
   HostLevel Hc;
   std::vector<int> order, tgt, cptr, grp_g, grp_c;

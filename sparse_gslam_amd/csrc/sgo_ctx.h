@@ -67,6 +67,8 @@ struct sgo_ctx {
   HaloDev halo;
   HaloHost halo_host;
   bool halo_failed = false;
+  bool amg_no_filter = false;       // this graph's hierarchy rebuilds keep the tentative transfer where the smoothed one is refused
+                                    // (a filtered hierarchy's solve was abandoned: optimize_gn); cleared by the next set-up
   int* d_comm_flag = nullptr;       // one int for the collective decision about the captured PCG graph (run_pcg)
   bool comm_graph_failed = false;   // capturing the RCCL collectives into the PCG hipGraph failed once: plain launches since
   long long level0_bytes = 0;    // device bytes of the level-0 structure this rank holds (blocks, operands, per-slot / per-block indices)

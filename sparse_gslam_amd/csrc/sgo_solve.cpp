@@ -568,6 +568,7 @@ int build_amg(sgo_ctx* c) {
   c->amg_arena.rewind();
   AmgConfig cfg;
   cfg.theta_scale = c->amg_theta_scale;
+  cfg.filtered_smoothing = !c->amg_no_filter;
   AmgProf prof;
   prof.user = c;
   prof.begin = [](void* u, int kid, double bytes) {
@@ -820,16 +821,20 @@ int optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
     bool failed = false;
     int rebuilds = 0;
     bool rebuild_next = false;
+    // (a cap on the set-ups redone inside one call, against thrashing: three for a short call, one per three Gauss-Newton
+    // iterations for a long one.  Round 5: with three flat, a call whose weights keep changing -- DCS from a dead-reckoned
+    // start -- used them up by iteration 6 and then had no safety net left: its 10th solve ground on to pcg_maxit.)
+    const int max_rebuilds = std::max(3, (iters + 2) / 3 + (std::getenv("SGO_MAX_REBUILDS") ? std::atoi(std::getenv("SGO_MAX_REBUILDS")) : 0));
     double its_sum = 0.0;
     for (int it = 0; it < iters; ++it) {
       hipEventRecord(ev[3 * it], c->stream);
-      c->pcg_softcap = (c->amg && c->amg_best > 0 && rebuilds < 3 && !rebuild_next) ? 4 * c->amg_best + 40 : 0;
+      c->pcg_softcap = (c->amg && c->amg_best > 0 && rebuilds < max_rebuilds && !rebuild_next) ? 4 * c->amg_best + 40 : 0;
       // A hierarchy that has never solved anything gets 600 iterations (the hardest first solves seen take 200-350: C4 from a
       // dead-reckoned start): one that needs more has a coarse space that does not carry the slow modes, and the set-up is
       // redone with HALF the strength thresholds (larger aggregates, sparser coarse operators) instead of grinding on to
       // pcg_maxit.  (SGO_FIRST_SOLVE_CAP: test hook.)
       const int first_solve_cap = std::getenv("SGO_FIRST_SOLVE_CAP") ? std::max(1, std::atoi(std::getenv("SGO_FIRST_SOLVE_CAP"))) : 600;
-      if (c->amg && c->amg_best == 0 && rebuilds < 3 && c->amg_theta_scale > 0.2) c->pcg_softcap = first_solve_cap;
+      if (c->amg && c->amg_best == 0 && rebuilds < max_rebuilds && c->amg_theta_scale > 0.2) c->pcg_softcap = first_solve_cap;
       if ((rc = do_chi2(c, c->d_hist + 2 * it, nullptr)) || (rc = do_linearize(c))) return rc;
       if (rebuild_next && c->amg) {
         // The aggregation was made from the Hessian of an earlier linearisation and robust-kernel
@@ -851,7 +856,11 @@ int optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
         // from x = 0 instead of grinding on (seen: 735 iterations where the rebuilt hierarchy needs 16).
         wasted = c->h_S->iter;
         c->pcg_softcap = 0;
-        if (c->amg_best == 0) c->amg_theta_scale *= 0.5;   // this hierarchy never worked: coarsen more aggressively
+        // (a hierarchy with FILTERED transfers -- sgo_amg_host.h -- whose solve is abandoned: the strengths it was filtered by no
+        // longer describe the matrix, and such a hierarchy does not degrade gracefully -- strong connections lumped into the
+        // diagonal -- : this graph keeps the tentative transfers on those levels from here on)
+        if (amg_has_filtered(c->amg)) c->amg_no_filter = true;
+        else if (c->amg_best == 0) c->amg_theta_scale *= 0.5;   // this hierarchy never worked: coarsen more aggressively
         if ((rc = build_amg(c)) || (rc = do_linearize(c)) || (rc = run_pcg(c))) return rc;
         ++rebuilds;
         rebuild_next = false;
@@ -874,10 +883,13 @@ int optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
         // over the remaining GN iterations exceed the set-up's cost (~150 PCG iterations' worth: host
         // aggregation + one more linearisation).  Counts only -- no clocks -- so that every rank of a
         // multi-GPU run takes the same decision.
+        // (crediting a rebuild only for as long as the previous one of this call stayed good -- weights that keep changing -- was
+        // measured in round 5 on C4 from a dead-reckoned start and is worse: the hierarchy left in place went from 74 to 400
+        // iterations two solves later; median 29.8 against 23.3 ms per Gauss-Newton iteration)
         const int left = iters - it - 1;
         const bool doubled = eq_iter > 2 * best_pcg + 10;
         const bool pays = 4 * eq_iter > 5 * best_pcg && (long long)(eq_iter - best_pcg) * left > 150;
-        if (rebuilds < 3 && (doubled || pays)) rebuild_next = true;
+        if (rebuilds < max_rebuilds && (doubled || pays)) rebuild_next = true;
       }
       its_sum += S.iter + wasted;
       if (it == 0 && S.stop == 1) {   // the call's first solve: what the incremental set-up's staleness rule compares (sgo_ctx.h)

@@ -94,6 +94,7 @@ void free_graph(sgo_ctx* c) {
   }
   c->amg_pending = false;
   c->amg_theta_scale = 1.0;
+  c->amg_no_filter = false;
   c->rows_pending = false;
   c->amg_arena.rewind();
   c->graph_arena.rewind();   // the caller has synchronised the stream: nothing in flight reads these arrays
