@@ -10,11 +10,13 @@ from sparse_gslam_amd import capi, synth  # noqa: E402
 name = sys.argv[1] if len(sys.argv) > 1 else "C4"
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 over = dict(a.split("=", 1) for a in sys.argv[3:])
+skip = int(over.pop("skip", 1))      # Gauss-Newton iterations run before the profiled ones (skip=15: a call's late iterations)
 g = synth.config(name, **over)
 with capi.Optimizer(0, profile=1) as o:
     o.set_graph(*g.arrays())
     print(o.solver_description(), flush=True)
-    o.optimize(1)
+    o.optimize(skip)
+    print(o.solver_description(), flush=True)
     o.profile_reset()
     done, st = o.optimize(iters)
     prof = o.kernel_profile()

@@ -2736,8 +2736,14 @@ Amg* amg_create(hipStream_t s, const BsrDev& A0, const Sym0Dev& S0, const Tile0D
   m->d_fail = dev_alloc<int>(m->pool, 1);
   if (!m->inv0 || !m->inv1 || !m->d_fail || !m->gjP[0] || !m->gjP[1]) return fail("amg_create: out of device memory");
   hipMemsetAsync(m->d_fail, 0, sizeof(int), s);
-  std::snprintf(line, sizeof line, "coarsest dense N=%d; theta=%.3g omega=%.2f", m->N,
-                m->cfg.theta * m->cfg.theta_scale, m->cfg.omega);
+  // Two sweeps per coarse level (amg_effective_config) pay while the coarse levels are small next to level 0.  A hierarchy
+  // whose level 1 holds more than a quarter of level 0's blocks -- filtered transfers along the trajectory: aggregates of three
+  // poses whose rows keep all their closures, C4 from a dead-reckoned start: 1.15 M of 2.1 M -- pays four bandwidth-bound
+  // passes per level for them: one sweep there (measured: 23.3 -> 20.9 ms per Gauss-Newton iteration at that start; C4's usual
+  // hierarchy, level 1 at 6 %, keeps two: 4.06 against 4.45 ms with one).
+  if (last >= 1 && !std::getenv("SGO_AMG_NU") && 4LL * m->lv[1].A.nslot > (long long)m->lv[0].A.nslot) m->cfg.nu_coarse = 1;
+  std::snprintf(line, sizeof line, "coarsest dense N=%d; theta=%.3g omega=%.2f nu=%d", m->N,
+                m->cfg.theta * m->cfg.theta_scale, m->cfg.omega, m->cfg.nu_coarse);
   m->desc += line;
   return m;
 }
