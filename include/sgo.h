@@ -101,6 +101,24 @@ typedef struct sgo_opts {
   int32_t reserved[4];
 } sgo_opts;
 
+/* Environment variables (the call sites are frozen, so knobs come from the environment).  Read when a
+ * context is created or a graph is set, never inside a solve.
+ *   mirrors of sgo_opts fields (the environment wins): SGO_SOLVER={pcg,amg}, SGO_PCG_TOL, SGO_PCG_TOL_CAP, SGO_PCG_MAXIT,
+ *     SGO_PCG_CHUNK, SGO_PCG_WARM, SGO_USE_GRAPH, SGO_PROFILE, SGO_VERBOSE, SGO_DIRECT_ROWS, SGO_DEVICE
+ *   path selection: SGO_MFRONT=0 (no multifrontal path), SGO_MFRONT_ROWS / _CRIT_MFLOP / _DEGREE / _LEAF (its admission limits
+ *     and leaf size), SGO_INCREMENTAL=0 (sgo_update_graph_se2 is always a full set-up), SGO_SPMV0={tile,group} (level-0 product
+ *     kernel), SGO_PRECOND_F32=0 (fp64 blocks in the preconditioner's level-0 passes)
+ *   multigrid set-up: SGO_AMG_THETA (strength threshold), SGO_AMG_THETA_FILTER / SGO_AMG_FILTER=0 (filtered smoothing),
+ *     SGO_AMG_SMOOTH=0 (tentative transfers only), SGO_AMG_OMEGA, SGO_AMG_OMEGA_P, SGO_AMG_NU, SGO_AMG_FOLD, SGO_AMG_FOLD0_ROWS,
+ *     SGO_AMG_KDEPTH, SGO_AMG_FCG2_DEPTH (cycle shape), SGO_HOST_THREADS (worker pool of the host set-up)
+ *   multi-GPU: SGO_COMM_MODE={owner,allreduce}, SGO_COMM_GRAPH (see sgo_comm_init), SGO_OWNER_MIN_ROWS, SGO_RCCL_LIB (library path)
+ *   test hooks and A/B switches of scripts/ (not for production): SGO_AMG_LISTS=host, SGO_SETUP_PIPELINE, SGO_TILE_LDS,
+ *     SGO_FIRST_SOLVE_CAP, SGO_MIRROR, SGO_LANCZOS (sgo_debug_lanczos), SGO_MFRONT_DEBUG
+ * Removed in round 5 (measured, not kept: NOTES.md sections 9-10): SGO_DEFLATE, SGO_OWNER_XS_EXCHANGE, SGO_MFRONT_FUSED_SOLVE.
+ * Of the interface SURVEY.md section 8(b) sketched, three items do not exist, on purpose: SGO_NGPU (one process per GPU: the
+ * launcher sets the world size, sgo_comm_init takes it), SGO_SOLVER=direct_cpu (the product has no CPU path; the CPU solver is
+ * the oracle, test infrastructure), sgo_stats.bytes_moved (algorithmic bytes are per kernel: sgo_kernel_profile). */
+
 /* Defaults (also applied when opts == NULL):
  * solver = PCG_AMG (graphs with <= 400 free poses are preconditioned by an explicit dense inverse,
  * i.e. solved directly; falls back to PCG_BJ only when a larger graph cannot be coarsened),

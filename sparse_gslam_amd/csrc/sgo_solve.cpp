@@ -824,7 +824,7 @@ int optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
     // (a cap on the set-ups redone inside one call, against thrashing: three for a short call, one per three Gauss-Newton
     // iterations for a long one.  Round 5: with three flat, a call whose weights keep changing -- DCS from a dead-reckoned
     // start -- used them up by iteration 6 and then had no safety net left: its 10th solve ground on to pcg_maxit.)
-    const int max_rebuilds = std::max(3, (iters + 2) / 3 + (std::getenv("SGO_MAX_REBUILDS") ? std::atoi(std::getenv("SGO_MAX_REBUILDS")) : 0));
+    const int max_rebuilds = std::max(3, (iters + 2) / 3);
     double its_sum = 0.0;
     for (int it = 0; it < iters; ++it) {
       hipEventRecord(ev[3 * it], c->stream);
