@@ -36,11 +36,12 @@ with capi.Optimizer(0) as opt:
             continue
         iters = 6
         opt.set_graph(*g.arrays())
-        path = opt.solver_description().split(":")[0]
+        desc = opt.solver_description()
+        path = desc.split(":")[0] + ("+filtered" if " filtered" in desc else "")   # (filtered smoothing on some level: round 5)
         paths[path] = paths.get(path, 0) + 1
         done, st = opt.optimize(iters)
         P = opt.get_poses()
-        line = f"{case:3d} {path:21s} V={V:6d} E={E:6d} {kw['info_mode']:4s} p_rand={kw['p_random']:.2f} init={kw['init']:11s} done={done} pcg={st['pcg_iters']}"
+        line = f"{case:3d} {path:22s} V={V:6d} E={E:6d} {kw['info_mode']:4s} p_rand={kw['p_random']:.2f} init={kw['init']:11s} done={done} pcg={st['pcg_iters']}"
         ok = np.isfinite(P).all() and done in (0, iters)
         if V <= 3000:
             oP, ost = c_oracle.gauss_newton(*g.arrays(), iters=iters)

@@ -811,7 +811,12 @@ __global__ __launch_bounds__(kTileThreads) void k_spmv0t(Sym0Dev A, Tile0Dev TL,
         }
       }
       a.y[o] = o0; a.y[o + 1] = o1; a.y[o + 2] = o2;
-      if (a.dotA) dotacc[0] += a.dotA[o] * o0 + a.dotA[o + 1] * o1 + a.dotA[o + 2] * o2;
+      if (MODE == S0_AX && a.dotA == a.x) {
+        // p . H p: the operand row is in LDS already (s0..s2, the same values): no global round trip at the tail of the launch
+        dotacc[0] += s0 * o0 + s1 * o1 + s2 * o2;
+      } else if (a.dotA) {
+        dotacc[0] += a.dotA[o] * o0 + a.dotA[o + 1] * o1 + a.dotA[o + 2] * o2;
+      }
       if (a.dotA2) dotacc[1] += a.dotA2[o] * o0 + a.dotA2[o + 1] * o1 + a.dotA2[o + 2] * o2;
     }
     if (stamp && tid == 0) stamp[5] = __builtin_amdgcn_s_memtime();
