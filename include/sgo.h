@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define SGO_VERSION 105          /* 0.1.5: the multifrontal path for mid-size graphs (sgo_mfront_plan; sgo_solver_description names it); 0.1.4: sgo_kernel_profile_samples, sgo_update_graph_se2 (incremental set-up); 0.1.3: row-owner multi-GPU mode (sgo_comm_host_allgather, sgo_debug_level0_bytes); 0.1.2: sgo_comm_init_host; 0.1.1: sgo_opts.direct_rows (took a reserved slot), sgo_solver_description */
+#define SGO_VERSION 106          /* 0.1.6: sgo_plan_rows takes the measurements (row order of graphs whose poses contradict their closures); 0.1.5: the multifrontal path for mid-size graphs (sgo_mfront_plan; sgo_solver_description names it); 0.1.4: sgo_kernel_profile_samples, sgo_update_graph_se2 (incremental set-up); 0.1.3: row-owner multi-GPU mode (sgo_comm_host_allgather, sgo_debug_level0_bytes); 0.1.2: sgo_comm_init_host; 0.1.1: sgo_opts.direct_rows (took a reserved slot), sgo_solver_description */
 #define SGO_MAX_ITERS 256        /* capacity of the per-iteration arrays in sgo_stats */
 
 /* error codes (negative).  -1 mirrors g2o's optimize() "nothing to optimise". */
@@ -307,10 +307,12 @@ void sgo_shard_range(int32_t count, int32_t nranks, int32_t rank, int32_t* begin
  * number of free active vertices n, the vertex id of every internal row (row_vertex[n], Hilbert order), the
  * tiles (tile_row_begin[ntiles + 1], capacity tile_cap) and the first row of every rank's tile range
  * (rank_row_begin[nranks + 1]).  Output pointers may be NULL.  Lets multi-process callers and the CPU tests
- * see which rows of a level-0 product each rank contributes. */
+ * see which rows of a level-0 product each rank contributes.  meas (as sgo_set_graph_se2's; may be NULL): with it the plan is
+ * also the one sgo_set_graph_se2 makes for a graph whose initial poses contradict its closures -- a dead-reckoned start --,
+ * whose rows are ordered by spanning-tree positions instead of the poses (0.1.6). */
 int sgo_plan_rows(int32_t V, const double* poses, const uint8_t* fixed, int32_t E, const int32_t* ei, const int32_t* ej,
                   int32_t nranks, int32_t* n_free, int32_t* row_vertex, int32_t* ntiles, int32_t* tile_row_begin,
-                  int32_t tile_cap, int32_t* rank_row_begin);
+                  int32_t tile_cap, int32_t* rank_row_begin, const double* meas);
 /* The elimination plan of the multifrontal path (mid-size graphs: DESIGN.md section 5c), computed on the host alone (no GPU,
  * no context).  stats[12] = { free poses, fronts, levels, largest front (scalar rows), its own poses, its boundary poses,
  * flops per factorisation, flops on the critical path (largest front of every level), 16-column panels on the critical path,

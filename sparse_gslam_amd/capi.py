@@ -136,7 +136,7 @@ def lib():
     L.sgo_shard_range.argtypes = [C.c_int32, C.c_int32, C.c_int32, i32, i32]
     L.sgo_debug_set_shard.argtypes = [vp, C.c_int, C.c_int]
     L.sgo_closure_information.argtypes = [vp, C.c_int32, C.POINTER(MatchWindow), C.POINTER(C.c_float), C.c_int64, d, d]
-    L.sgo_plan_rows.argtypes = [C.c_int32, d, u8, C.c_int32, i32, i32, C.c_int32, i32, i32, i32, i32, C.c_int32, i32]
+    L.sgo_plan_rows.argtypes = [C.c_int32, d, u8, C.c_int32, i32, i32, C.c_int32, i32, i32, i32, i32, C.c_int32, i32, d]
     L.sgo_last_error.restype = C.c_char_p
     L.sgo_last_error.argtypes = [vp]
     _LIB = L
@@ -165,9 +165,10 @@ def shard_range(count: int, nranks: int, rank: int):
     return a.value, b.value
 
 
-def plan_rows(poses, fixed, ei, ej, nranks: int = 1):
+def plan_rows(poses, fixed, ei, ej, nranks: int = 1, meas=None):
     """Host-only row plan of a graph (sgo_plan_rows; needs no GPU): dict with n, row_vertex (n,),
-    tile_row_begin (ntiles + 1,), rank_row_begin (nranks + 1,)."""
+    tile_row_begin (ntiles + 1,), rank_row_begin (nranks + 1,).  meas: the measurements (as set_graph's) -- with them the plan is
+    also right for a graph whose initial poses contradict its closures (rows ordered by spanning-tree positions)."""
     p = np.ascontiguousarray(poses, dtype=np.float64).reshape(-1, 3)
     f = np.ascontiguousarray(fixed, dtype=np.uint8)
     a = np.ascontiguousarray(ei, dtype=np.int32)
@@ -179,7 +180,8 @@ def plan_rows(poses, fixed, ei, ej, nranks: int = 1):
     tb = np.empty(V + 2, dtype=np.int32)
     rb = np.empty(nranks + 1, dtype=np.int32)
     rc = lib().sgo_plan_rows(V, _dp(p), f.ctypes.data_as(C.POINTER(C.c_uint8)), a.size, _ip(a), _ip(b), nranks,
-                             C.byref(n), _ip(rv), C.byref(nt), _ip(tb), tb.size, _ip(rb))
+                             C.byref(n), _ip(rv), C.byref(nt), _ip(tb), tb.size, _ip(rb),
+                             _dp(np.ascontiguousarray(meas, dtype=np.float64).reshape(-1, 3)) if meas is not None else None)
     if rc != 0:
         raise SgoError(f"sgo_plan_rows: rc={rc}: " + lib().sgo_last_error(None).decode())
     return dict(n=n.value, row_vertex=rv[: n.value].copy(), tile_row_begin=tb[: nt.value + 1].copy(),

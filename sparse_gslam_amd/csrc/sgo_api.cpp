@@ -240,6 +240,14 @@ int sgo_set_graph_se2(sgo_ctx* c, int32_t V, const double* poses, const uint8_t*
         }
       }
     }
+    if (!c->rows_pending) {
+      // a graph whose initial poses contradict its closures gets its ROW ORDER from spanning-tree positions (sgo_plan.cpp)
+      const double tp0 = wall_s();
+      if (!plan_order_positions(V, poses, fixed, E, ei, ej, meas, c->order_xy)) c->order_xy.clear();
+      else if (c->opts.verbose)
+        std::fprintf(stderr, "[sgo] set_graph: the initial poses contradict the closures: row order from spanning-tree positions (%.1f ms)\n",
+                     1e3 * (wall_s() - tp0));
+    }
     if (!c->rows_pending && (rc = build_rows(c, poses, fixed, ei, ej)) != SGO_OK) {
       free_graph(c);
       return rc;

@@ -67,6 +67,8 @@ struct sgo_ctx {
   HaloDev halo;
   HaloHost halo_host;
   bool halo_failed = false;
+  std::vector<double> order_xy;     // [V][2] positions the row order follows when they are not the initial poses (a graph whose
+                                    // poses contradict its closures: plan_order_positions, sgo_plan.cpp); empty otherwise
   bool amg_no_filter = false;       // this graph's hierarchy rebuilds keep the tentative transfer where the smoothed one is refused
                                     // (a filtered hierarchy's solve was abandoned: optimize_gn); cleared by the next set-up
   int* d_comm_flag = nullptr;       // one int for the collective decision about the captured PCG graph (run_pcg)
@@ -307,10 +309,12 @@ struct RowPlan {
 };
 
 int plan_rows_order(int V, const double* poses, const uint8_t* fixed, int E, const int32_t* ei, const int32_t* ej,
-                    std::string* err, RowPlan& P, const std::vector<int>* known_free = nullptr);
+                    std::string* err, RowPlan& P, const std::vector<int>* known_free = nullptr, const double* order_xy = nullptr);
+bool plan_order_positions(int V, const double* poses, const uint8_t* fixed, int E, const int32_t* ei, const int32_t* ej,
+                          const double* meas, std::vector<double>& xy);
 void plan_rows_tiles(int tile_div, RowPlan& P);
 int plan_rows(int V, const double* poses, const uint8_t* fixed, int E, const int32_t* ei, const int32_t* ej, int tile_div,
-              std::string* err, RowPlan& P);
+              std::string* err, RowPlan& P, const double* meas = nullptr);
 // One tile per CU of an MI355X.  A constant, not the device's CU count: every rank of a multi-GPU run -- and the
 // host-only sgo_plan_rows -- must cut the same tiles whatever device it sits on.
 constexpr int kTileDiv = 256;

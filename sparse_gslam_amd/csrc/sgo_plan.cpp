@@ -23,8 +23,105 @@ namespace sgo {
 // Row plan, first half: hessian order, internal (Hilbert) row order, compact slots per row.
 // `known_free`: the hessian order when the caller has already validated the edge list and listed the free active
 // vertices (build_edges does both for the chi2 path): the pass over the edges is then not repeated.
+// Positions for the ROW ORDER of a graph whose initial poses contradict its closures (a dead-reckoned start: BASELINE.md's
+// literal workload).  The Hilbert order exists to put the two endpoints of an edge a few hundred rows apart; it does so when
+// the poses are roughly where the edges say.  Poses chained through odometry alone drift by tens of metres over 10^5 steps, the
+// closures then connect rows that are far apart along the curve, and the level-0 tiles of C4 hold 61 % of their pairs twice and
+// 260 k halo columns instead of 23 % and 69 k -- every level-0 pass a third slower.  The order is a property of the GRAPH, not
+// of the estimate: when more than a quarter of a sample of the non-odometry edges are off by more than max(1, 2 |z|) in
+// translation, the positions that order the rows come from a breadth-first spanning tree over ALL edges from the fixed
+// vertices (vertex 0 without any): closures shortcut the drift, a pose is a handful of composed measurements away from its
+// root.  The estimates are not touched.  Returns false (xy untouched) for a consistent graph or without measurements.
+bool plan_order_positions(int V, const double* poses, const uint8_t* fixed, int E, const int32_t* ei, const int32_t* ej,
+                          const double* meas, std::vector<double>& xy) {
+  if (!meas || E < 64 || V < 64) return false;
+  // ---- the check: every (E / 4096)-th edge that is not a step along the trajectory
+  {
+    const int step = std::max(1, E / 4096);
+    int seen = 0, off = 0;
+    for (int e = 0; e < E; e += step) {
+      const int a = ei[e], b = ej[e];
+      if (a < 0 || a >= V || b < 0 || b >= V || a == b || a - b == 1 || b - a == 1) continue;
+      const double* pa = poses + 3 * (size_t)a;
+      const double* pb = poses + 3 * (size_t)b;
+      const double* z = meas + 3 * (size_t)e;
+      if (!std::isfinite(pa[0] + pa[1] + pa[2] + pb[0] + pb[1])) continue;
+      const double c = std::cos(pa[2]), s = std::sin(pa[2]);
+      const double dx = pa[0] + c * z[0] - s * z[1] - pb[0], dy = pa[1] + s * z[0] + c * z[1] - pb[1];
+      const double lim = std::max(1.0, 2.0 * std::sqrt(z[0] * z[0] + z[1] * z[1]));
+      ++seen;
+      if (dx * dx + dy * dy > lim * lim) ++off;
+    }
+    if (seen < 32 || 4 * off <= seen) return false;
+  }
+  // ---- adjacency (edge id and direction per entry), breadth-first composition of the measurements
+  std::vector<int> ptr((size_t)V + 1, 0);
+  for (int e = 0; e < E; ++e) {
+    const int a = ei[e], b = ej[e];
+    if (a < 0 || a >= V || b < 0 || b >= V || a == b) continue;   // (reported by the plan proper)
+    ptr[(size_t)a + 1]++;
+    ptr[(size_t)b + 1]++;
+  }
+  for (int v = 0; v < V; ++v) ptr[(size_t)v + 1] += ptr[v];
+  std::vector<int> adj((size_t)ptr[V]), fill(ptr.begin(), ptr.end() - 1);
+  for (int e = 0; e < E; ++e) {
+    const int a = ei[e], b = ej[e];
+    if (a < 0 || a >= V || b < 0 || b >= V || a == b) continue;
+    adj[(size_t)fill[a]++] = 2 * e;        // this vertex is the edge's first endpoint
+    adj[(size_t)fill[b]++] = 2 * e + 1;    // ... its second
+  }
+  std::vector<double> q(poses, poses + 3 * (size_t)V);
+  std::vector<unsigned char> done((size_t)V, 0);
+  std::vector<int> queue;
+  queue.reserve(V);
+  for (int v = 0; v < V; ++v)
+    if (fixed[v]) {
+      done[v] = 1;
+      queue.push_back(v);
+    }
+  size_t head = 0;
+  for (int seed = 0; seed <= V; ++seed) {   // components without a fixed vertex start from their lowest id, at its given pose
+    for (; head < queue.size(); ++head) {
+      const int v = queue[head];
+      const double* pv = &q[3 * (size_t)v];
+      for (int t = ptr[v]; t < ptr[(size_t)v + 1]; ++t) {
+        const int e = adj[t] >> 1;
+        const bool first = !(adj[t] & 1);
+        const int u = first ? ej[e] : ei[e];
+        if (done[u]) continue;
+        const double* z = meas + 3 * (size_t)e;
+        double* pu = &q[3 * (size_t)u];
+        if (first) {   // X_u = X_v * Z
+          const double c = std::cos(pv[2]), s = std::sin(pv[2]);
+          pu[0] = pv[0] + c * z[0] - s * z[1];
+          pu[1] = pv[1] + s * z[0] + c * z[1];
+          pu[2] = pv[2] + z[2];
+        } else {       // X_u = X_v * Z^-1
+          const double th = pv[2] - z[2], c = std::cos(th), s = std::sin(th);
+          pu[0] = pv[0] - (c * z[0] - s * z[1]);
+          pu[1] = pv[1] - (s * z[0] + c * z[1]);
+          pu[2] = th;
+        }
+        done[u] = 1;
+        queue.push_back(u);
+      }
+    }
+    if (seed == V) break;
+    if (!done[seed] && ptr[(size_t)seed + 1] > ptr[seed]) {
+      done[seed] = 1;
+      queue.push_back(seed);
+    }
+  }
+  xy.resize(2 * (size_t)V);
+  for (int v = 0; v < V; ++v) {
+    xy[2 * (size_t)v] = q[3 * (size_t)v];
+    xy[2 * (size_t)v + 1] = q[3 * (size_t)v + 1];
+  }
+  return true;
+}
+
 int plan_rows_order(int V, const double* poses, const uint8_t* fixed, int E, const int32_t* ei, const int32_t* ej,
-                    std::string* err, RowPlan& P, const std::vector<int>* known_free) {
+                    std::string* err, RowPlan& P, const std::vector<int>* known_free, const double* order_xy) {
   const bool verbose = std::getenv("SGO_VERBOSE") != nullptr && (E > 200000 || std::atoi(std::getenv("SGO_VERBOSE")) > 1);
   double tl = wall_s();
   auto lap = [&](const char* what) {
@@ -62,8 +159,11 @@ int plan_rows_order(int V, const double* poses, const uint8_t* fixed, int E, con
   P.row_of_asc.assign(n, 0);
   {
     double lo[2] = {1e300, 1e300}, hi[2] = {-1e300, -1e300};
+    // (order_xy: the positions the order follows when they are not the initial poses -- plan_order_positions)
+    const double* pos = order_xy ? order_xy : poses;
+    const size_t pstride = order_xy ? 2 : 3;
     for (int h = 0; h < n; ++h) {
-      const double* q = poses + 3 * (size_t)P.free_id[h];
+      const double* q = pos + pstride * (size_t)P.free_id[h];
       for (int d = 0; d < 2; ++d)
         if (std::isfinite(q[d])) {
           lo[d] = std::min(lo[d], q[d]);
@@ -75,7 +175,7 @@ int plan_rows_order(int V, const double* poses, const uint8_t* fixed, int E, con
     std::vector<uint64_t> key(n);
     parallel_for(n, [&](int h0, int h1) {
       for (int h = h0; h < h1; ++h) {
-        const double* q = poses + 3 * (size_t)P.free_id[h];
+        const double* q = pos + pstride * (size_t)P.free_id[h];
         uint32_t d = 0;
         if (std::isfinite(q[0]) && std::isfinite(q[1]) && scale > 0.0)
           d = hilbert_index((uint32_t)((q[0] - lo[0]) * scale), (uint32_t)((q[1] - lo[1]) * scale), 16);
@@ -389,8 +489,10 @@ void plan_rows_tiles(int tile_div, RowPlan& P) {
 }
 
 int plan_rows(int V, const double* poses, const uint8_t* fixed, int E, const int32_t* ei, const int32_t* ej, int tile_div,
-              std::string* err, RowPlan& P) {
-  const int rc = plan_rows_order(V, poses, fixed, E, ei, ej, err, P);
+              std::string* err, RowPlan& P, const double* meas) {
+  std::vector<double> xy;
+  const bool alt = plan_order_positions(V, poses, fixed, E, ei, ej, meas, xy);
+  const int rc = plan_rows_order(V, poses, fixed, E, ei, ej, err, P, nullptr, alt ? xy.data() : nullptr);
   if (rc != SGO_OK) return rc;
   plan_rows_tiles(tile_div, P);
   return SGO_OK;
@@ -402,12 +504,12 @@ extern "C" {
 
 int sgo_plan_rows(int32_t V, const double* poses, const uint8_t* fixed, int32_t E, const int32_t* ei, const int32_t* ej,
                   int32_t nranks, int32_t* n_free, int32_t* row_vertex, int32_t* ntiles, int32_t* tile_row_begin,
-                  int32_t tile_cap, int32_t* rank_row_begin) {
+                  int32_t tile_cap, int32_t* rank_row_begin, const double* meas) {
   if (V <= 0 || E < 0 || !poses || !fixed || (E > 0 && (!ei || !ej)) || nranks < 1 || !n_free) return SGO_EINVAL;
   try {
     RowPlan P;
     std::string err;
-    const int rc = plan_rows(V, poses, fixed, E, ei, ej, kTileDiv * std::max(1, (int)nranks), &err, P);   // as sgo_set_graph_se2 cuts them for this world size
+    const int rc = plan_rows(V, poses, fixed, E, ei, ej, kTileDiv * std::max(1, (int)nranks), &err, P, meas);   // as sgo_set_graph_se2 cuts them for this world size
     if (rc != SGO_OK) {
       g_err = err;
       return rc;

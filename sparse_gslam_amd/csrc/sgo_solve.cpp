@@ -856,10 +856,11 @@ int optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
         // from x = 0 instead of grinding on (seen: 735 iterations where the rebuilt hierarchy needs 16).
         wasted = c->h_S->iter;
         c->pcg_softcap = 0;
-        // (a hierarchy with FILTERED transfers -- sgo_amg_host.h -- whose solve is abandoned: the strengths it was filtered by no
-        // longer describe the matrix, and such a hierarchy does not degrade gracefully -- strong connections lumped into the
-        // diagonal -- : this graph keeps the tentative transfers on those levels from here on)
-        if (amg_has_filtered(c->amg)) c->amg_no_filter = true;
+        // (a hierarchy with FILTERED transfers -- sgo_amg_host.h -- that never solved anything: what the filter dropped is not
+        // negligible together on this graph, it keeps the tentative transfers on those levels from here on.  One that HAS solved
+        // and is abandoned now is stale -- connections it lumped into the diagonal have become strong, and such a hierarchy does
+        // not degrade gracefully --: the rebuild filters by the current values)
+        if (c->amg_best == 0 && amg_has_filtered(c->amg)) c->amg_no_filter = true;
         else if (c->amg_best == 0) c->amg_theta_scale *= 0.5;   // this hierarchy never worked: coarsen more aggressively
         if ((rc = build_amg(c)) || (rc = do_linearize(c)) || (rc = run_pcg(c))) return rc;
         ++rebuilds;

@@ -95,6 +95,7 @@ void free_graph(sgo_ctx* c) {
   c->amg_pending = false;
   c->amg_theta_scale = 1.0;
   c->amg_no_filter = false;
+  c->order_xy.clear();
   c->rows_pending = false;
   c->amg_arena.rewind();
   c->graph_arena.rewind();   // the caller has synchronised the stream: nothing in flight reads these arrays
@@ -197,7 +198,8 @@ int build_structure(sgo_ctx* c, int V, const double* poses, const uint8_t* fixed
   {
     // (build_edges has validated the edges and listed the free active vertices of this very graph; the lazy path of
     // graphs that took the direct solver keeps the lists too)
-    const int prc = plan_rows_order(V, poses, fixed, E, ei, ej, &c->err, P, (int)c->free_id.size() == c->n && c->V == V && c->E == E ? &c->free_id : nullptr);
+    const int prc = plan_rows_order(V, poses, fixed, E, ei, ej, &c->err, P, (int)c->free_id.size() == c->n && c->V == V && c->E == E ? &c->free_id : nullptr,
+                                    c->order_xy.size() == 2 * (size_t)V ? c->order_xy.data() : nullptr);
     if (prc != SGO_OK) return prc;
   }
   const bool verbose = c->opts.verbose && (E > 200000 || c->opts.verbose > 1);

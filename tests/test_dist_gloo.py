@@ -174,3 +174,26 @@ def test_plan_rows_on_a_large_graph_with_long_range_edges(monkeypatch):
     assert rb[0] == 0 and rb[-1] == a["n"] and set(rb.tolist()) <= set(tb.tolist())
     for k in ("row_vertex", "tile_row_begin", "rank_row_begin"):
         assert np.array_equal(a[k], b[k])
+
+
+def test_row_order_of_a_graph_whose_poses_contradict_its_closures():
+    """Host-only (sgo_plan_rows with the measurements, ABI 0.1.6): from a dead-reckoned start the Hilbert order of the POSES puts
+    the endpoints of the closures thousands of rows apart; the plan then orders the rows by spanning-tree positions (breadth-first
+    over all edges from the fixed vertex) -- a permutation of the same rows, with the closures' endpoints close again -- and
+    leaves a consistent graph's order alone."""
+    from sparse_gslam_amd import capi, synth
+    g = synth.manhattan(20000, 100000, seed=3, init="odom")
+    a = capi.plan_rows(g.poses, g.fixed, g.ei, g.ej)
+    b = capi.plan_rows(g.poses, g.fixed, g.ei, g.ej, meas=g.meas)
+    assert a["n"] == b["n"] and np.array_equal(np.sort(a["row_vertex"]), np.sort(b["row_vertex"]))
+
+    def spread(plan):
+        hp = np.full(g.V, -1)
+        hp[plan["row_vertex"]] = np.arange(plan["n"])
+        m = (hp[g.ei] >= 0) & (hp[g.ej] >= 0)
+        return float(np.median(np.abs(hp[g.ei][m] - hp[g.ej][m])))
+    assert spread(b) < 0.25 * spread(a), (spread(a), spread(b))
+    c = synth.manhattan(20000, 100000, seed=3)          # near the optimum: the poses agree with the closures
+    pa = capi.plan_rows(c.poses, c.fixed, c.ei, c.ej)
+    pb = capi.plan_rows(c.poses, c.fixed, c.ei, c.ej, meas=c.meas)
+    assert np.array_equal(pa["row_vertex"], pb["row_vertex"])
