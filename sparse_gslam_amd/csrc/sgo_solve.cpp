@@ -840,6 +840,7 @@ int optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
         // The aggregation was made from the Hessian of an earlier linearisation and robust-kernel
         // re-weighting has changed the strength of connection since (see the rule below): redo the
         // set-up from the current values (same cost as in sgo_set_graph_se2).
+        if (rebuilds + 1 >= max_rebuilds) c->amg_no_filter = true;   // (the call's last rebuild: see the abandoned solve below)
         if ((rc = build_amg(c)) || (rc = do_linearize(c))) return rc;
         rebuild_next = false;
         ++rebuilds;
@@ -862,6 +863,10 @@ int optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
         // not degrade gracefully --: the rebuild filters by the current values)
         if (c->amg_best == 0 && amg_has_filtered(c->amg)) c->amg_no_filter = true;
         else if (c->amg_best == 0) c->amg_theta_scale *= 0.5;   // this hierarchy never worked: coarsen more aggressively
+        // The hierarchy the call's LAST rebuild leaves has no safety net behind it (no bail-out cap without a rebuild to follow):
+        // it keeps the tentative transfers, which go stale gracefully -- 190 -> 240 iterations where a stale filtered one can
+        // grind on to pcg_maxit (seen with another aggregation threshold from the dead-reckoned start: 11 059, then 20 000)
+        if (rebuilds + 1 >= max_rebuilds) c->amg_no_filter = true;
         if ((rc = build_amg(c)) || (rc = do_linearize(c)) || (rc = run_pcg(c))) return rc;
         ++rebuilds;
         rebuild_next = false;
