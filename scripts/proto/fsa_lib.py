@@ -51,10 +51,13 @@ def build(H,pos0,reuse=None,dynamic_mask=True):
             # the stale mask by (row, col) key (patterns of coarse levels may differ slightly: default weak)
             key=rows.astype(np.int64)*n+indices
             old=reuse[l]['strong_keys']
+            fresh_strong=strong
             if dynamic_mask=="and": strong=(np.isin(key,old)&strong)|dm      # pattern-restricted dynamic mask
             else: strong=np.isin(key,old)|dm
+            nolump = fresh_strong & ~strong if dynamic_mask=="nolump" else None   # newly strong, not in the pattern: kept out of the lumping
         lev['strong_keys']=(rows.astype(np.int64)*n+indices)[strong]
         weak=~strong
+        if reuse is not None and dynamic_mask=="nolump": weak=weak & ~nolump
         G=Tm(pos[indices[weak]]-pos[rows[weak]])
         corr=np.zeros((n,3,3)); np.add.at(corr,rows[weak],data[weak]@G)
         DF=D+corr

@@ -26,5 +26,8 @@ for step in range(1,4):
     anded=build(H1,pos1,reuse=hier0,dynamic_mask="and")
     ita,_=solve(anded,b1)
     print(f"   stale aggregates + (stale AND fresh) mask {ita}")
+    nl=build(H1,pos1,reuse=hier0,dynamic_mask="nolump")
+    itn,_=solve(nl,b1)
+    print(f"   stale aggregates + stale mask, newly strong connections not lumped {itn}")
     print(f"GN{step}: robust chi2 {rc:.4g}: fresh {itf}; stale aggregates + stale mask {its}; stale aggregates + fresh mask {itd}",flush=True)
     hier0=fresh; x0=xf
