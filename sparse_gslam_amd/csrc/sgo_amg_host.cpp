@@ -654,7 +654,25 @@ void host_coarsen(const HostLevel& H, const std::vector<double>& w, const AmgCon
     } catch (const std::bad_alloc&) {
       smooth = false;
     }
-    if (!smooth && theta_used > 0.0 && cfg.filtered_smoothing) {
+    // (not on a nearly dense level -- more than 48 slots per row: a refused attempt there costs more than the whole level, C4r's
+    // 897-row level 11 ms -- and a sample of the rows says first whether the filter would drop most connections at all.  The
+    // SMALL levels of a chain-like hierarchy do matter: with the attempt limited to levels of >= 4 096 rows C4's first solve from
+    // the dead-reckoned start took 91 instead of 56 iterations.)
+    bool try_filtered = !smooth && theta_used > 0.0 && cfg.filtered_smoothing && n >= 512 && (long long)H.nslot <= 48LL * n;
+    if (try_filtered) {
+      long long seen = 0, weak = 0;
+      for (int i = 0; i < n; i += 16) {
+        const double di = w[H.rowptr[i]];
+        for (int k = H.rowptr[i] + 1; k < H.rowptr[i + 1]; ++k) {
+          const int j = H.col[k];
+          if (j == i) continue;
+          ++seen;
+          weak += !(w[k] > 0.0 && w[k] * w[k] >= cfg.theta_filter * cfg.theta_filter * di * w[H.rowptr[j]]);
+        }
+      }
+      try_filtered = 5 * weak >= 2 * seen;   // (the full count below decides at one half)
+    }
+    if (try_filtered) {
       // Second attempt: FILTERED smoothing.  The whole operator made P too dense -- many connections per row, e.g. the 10^6
       // closures DCS has switched off at a dead-reckoned start (BASELINE.md's literal workload), each of them negligible next to
       // the odometry chain --: smooth T with the operator of the strong connections only (the aggregation's own criterion), keep
@@ -689,7 +707,10 @@ void host_coarsen(const HostLevel& H, const std::vector<double>& w, const AmgCon
         });
         for (long long v : part) nweak += v;
       }
-      if (nweak > 0) {
+      // (worth the second pass over the patterns only when the filter drops most of the connections -- at the dead-reckoned
+      // start 89 % --: with few of them negligible P's pattern is nearly the refused one.  C5 / C4r, whose random closures are at
+      // full weight, paid 20 % of their set-up for an attempt that could not succeed.)
+      if (2 * nweak >= (long long)H.nslot - n) {
         try {
           smooth = sa_symbolic(H, agg, nc, mem_ptr, mem, budget, cfg.lists_on_device, sa, strong.data());
         } catch (const std::bad_alloc&) {
