@@ -792,8 +792,23 @@ __global__ __launch_bounds__(kTileThreads) void k_spmv0t(Sym0Dev A, Tile0Dev TL,
       }
       const double s0 = xs[3 * i], s1 = xs[3 * i + 1], s2 = xs[3 * i + 2];
       double o0 = ys[3 * i], o1 = ys[3 * i + 1], o2 = ys[3 * i + 2];
-      for (int e = e0; e < e1; ++e) {
-        o0 += vst[3 * e]; o1 += vst[3 * e + 1]; o2 += vst[3 * e + 2];
+      {
+        // the staged entries in their fixed order, four entries' LDS reads in flight at a time (the same additions in the same
+        // order: a loop that reads and adds one entry per trip is a chain of LDS latencies)
+        constexpr int kB = F32 ? 4 : 2;   // (the fp64 instantiations sit at 126 of 128 VGPRs: four entries in flight spilled)
+        int e = e0;
+        for (; e + kB <= e1; e += kB) {
+          double v[3 * kB];
+#pragma unroll
+          for (int q = 0; q < 3 * kB; ++q) v[q] = vst[3 * e + q];
+#pragma unroll
+          for (int q = 0; q < kB; ++q) {
+            o0 += v[3 * q]; o1 += v[3 * q + 1]; o2 += v[3 * q + 2];
+          }
+        }
+        for (; e < e1; ++e) {
+          o0 += vst[3 * e]; o1 += vst[3 * e + 1]; o2 += vst[3 * e + 2];
+        }
       }
       o0 += dd0 * s0 + dd1 * s1 + dd2 * s2;
       o1 += dd1 * s0 + dd3 * s1 + dd4 * s2;
@@ -820,7 +835,7 @@ __global__ __launch_bounds__(kTileThreads) void k_spmv0t(Sym0Dev A, Tile0Dev TL,
       if (a.dotA2) dotacc[1] += a.dotA2[o] * o0 + a.dotA2[o + 1] * o1 + a.dotA2[o + 2] * o2;
     }
     if (stamp && tid == 0) stamp[5] = __builtin_amdgcn_s_memtime();
-    __syncthreads();   // the next tile reuses the LDS
+    if (t + per_xcd < thi) __syncthreads();   // the next tile reuses the LDS (a workgroup's last -- usually only -- tile: nothing to wait for)
     if (stamp && tid == 0) stamp[6] = __builtin_amdgcn_s_memtime();
   }
   if (a.partials) {
