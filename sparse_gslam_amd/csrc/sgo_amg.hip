@@ -294,6 +294,17 @@ __global__ __launch_bounds__(kBlock) void k_filtered_diag(BsrDev F, const int* _
       // (a row without any kept connection keeps its whole diagonal block: with everything lumped D_F would be the row sum of
       // the rigid motions -- zero up to rounding in the interior -- and its "inverse" noise; nothing smooths such a row anyway)
       const double keep = acc[9] > 0.0 ? 1.0 : 0.0;
+      // How much of the row's stiffness the dropped connections carried: L = -acc is the sum of their (positive semi-definite)
+      // shares of the diagonal block, and trace(D^-1 L) bounds the largest eigenvalue of D^-1 L.  "Negligible" is judged by
+      // Frobenius norms; with full information matrices a block's norm can be dominated by one direction (the rotation's, with
+      // its lever arms) while the dropped connections carry most of another -- D_F is then nearly singular there and the
+      // smoothed row blows up (seen: 150 k poses / 900 k edges, full information, from a dead-reckoned start: PCG broke down
+      // in the sixth Gauss-Newton iteration).  Such a row is not smoothed at all: its inverse is written as zero, which
+      // k_p_values turns into the tentative row T_i -- the rigid motions stay reproduced exactly.
+      const double* dv = F.dinv + 6 * (size_t)key;
+      const double tr = -(dv[0] * acc[0] + dv[1] * (acc[1] + acc[3]) + dv[2] * (acc[2] + acc[6]) + dv[3] * acc[4] + dv[4] * (acc[5] + acc[7]) +
+                          dv[5] * acc[8]);
+      const bool unsafe = !(tr <= 0.5);   // (also when tr is not finite)
 #pragma unroll
       for (int c = 0; c < 9; ++c) d[c] += keep * acc[c];
       // inverse by cofactors: inv[r][c] = cof[c][r] / det
@@ -301,7 +312,7 @@ __global__ __launch_bounds__(kBlock) void k_filtered_diag(BsrDev F, const int* _
       const double c10 = d[2] * d[7] - d[1] * d[8], c11 = d[0] * d[8] - d[2] * d[6], c12 = d[1] * d[6] - d[0] * d[7];
       const double c20 = d[1] * d[5] - d[2] * d[4], c21 = d[2] * d[3] - d[0] * d[5], c22 = d[0] * d[4] - d[1] * d[3];
       const double det = d[0] * c00 + d[1] * c01 + d[2] * c02;
-      const double id = (det != 0.0 && isfinite(det)) ? 1.0 / det : 0.0;
+      const double id = (det != 0.0 && isfinite(det) && !(unsafe && keep != 0.0)) ? 1.0 / det : 0.0;
       double* o = dF + 9 * (size_t)key;
 #pragma unroll
       for (int c = 0; c < 9; ++c) o[c] = d[c];

@@ -873,6 +873,19 @@ int optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
         if (c->opts.verbose)
           std::fprintf(stderr, "[sgo] iteration %d: solve abandoned after %d PCG iterations, hierarchy rebuilt\n", it, wasted);
       }
+      if (c->h_S->stop == 3 && c->amg && amg_has_filtered(c->amg) && rebuilds < max_rebuilds) {
+        // A breakdown (p.Hp <= 0 or a non-finite scalar) behind a hierarchy with FILTERED transfers: the Gauss-Newton Hessian is
+        // positive semi-definite by construction, so the first suspect is the preconditioner -- the set-up is redone with the
+        // tentative transfers and the solve repeated once; a Hessian that really is indefinite fails again and is reported.
+        wasted += c->h_S->iter;
+        c->amg_no_filter = true;
+        c->pcg_softcap = 0;
+        if ((rc = build_amg(c)) || (rc = do_linearize(c)) || (rc = run_pcg(c))) return rc;
+        ++rebuilds;
+        rebuild_next = false;
+        if (c->opts.verbose)
+          std::fprintf(stderr, "[sgo] iteration %d: PCG breakdown behind a filtered hierarchy, rebuilt with tentative transfers and solved again\n", it);
+      }
       const PcgScalars S = *c->h_S;
       int& best_pcg = c->amg_best;
       if (it == 0 && c->tol_cap > 0.0 && S.stop == 1) c->bb_ref = S.bb;
