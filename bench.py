@@ -439,6 +439,11 @@ def main():
             "setup_plus_optimize_ms": set_graph_steady_ms + 1e3 * dt / args.steps,
             "edge_jacobians_per_s_incl_setup": args.iters * g.E / (1e-3 * set_graph_steady_ms + dt / args.steps),
             "linearize_ms_median": 1e3 * float(np.median(st["seconds_linearize"])),
+            # lagged refresh of the multigrid hierarchy's coarse operators (sgo_solve.cpp): how many solves of the last timed
+            # optimize() call kept the operators of the solve before (every solve runs to pcg_tol on the current Hessian either way;
+            # SGO_AMG_LAG=0 refreshes before every solve)
+            "coarse_operator_refresh": (opt.solver_description().split("; last sgo_optimize_gn: ")[1].split(";")[0]
+                                        if "; last sgo_optimize_gn: " in opt.solver_description() else "refreshed before every solve"),
         }
     opt.close()
 

@@ -102,7 +102,7 @@ typedef struct sgo_opts {
 } sgo_opts;
 
 /* Environment variables (the call sites are frozen, so knobs come from the environment).  Read when a
- * context is created or a graph is set, never inside a solve.
+ * context is created or a graph is set, or at the start of sgo_optimize_gn -- never inside a solve.
  *   mirrors of sgo_opts fields (the environment wins): SGO_SOLVER={pcg,amg}, SGO_PCG_TOL, SGO_PCG_TOL_CAP, SGO_PCG_MAXIT,
  *     SGO_PCG_CHUNK, SGO_PCG_WARM, SGO_USE_GRAPH, SGO_PROFILE, SGO_VERBOSE, SGO_DIRECT_ROWS, SGO_DEVICE
  *   path selection: SGO_MFRONT=0 (no multifrontal path), SGO_MFRONT_ROWS / _CRIT_MFLOP / _DEGREE / _LEAF (its admission limits
@@ -111,9 +111,13 @@ typedef struct sgo_opts {
  *   multigrid set-up: SGO_AMG_THETA (strength threshold), SGO_AMG_THETA_FILTER / SGO_AMG_FILTER=0 (filtered smoothing),
  *     SGO_AMG_SMOOTH=0 (tentative transfers only), SGO_AMG_OMEGA, SGO_AMG_OMEGA_P, SGO_AMG_NU, SGO_AMG_FOLD, SGO_AMG_FOLD0_ROWS,
  *     SGO_AMG_KDEPTH, SGO_AMG_FCG2_DEPTH (cycle shape), SGO_HOST_THREADS (worker pool of the host set-up)
+ *   inside sgo_optimize_gn: SGO_AMG_LAG=0 (the hierarchy's coarse operators are refreshed before EVERY solve; default: a solve keeps
+ *     those of the solve before while the level-0 diagonal blocks have barely moved), SGO_AMG_LAG_TAU (the
+ *     largest relative movement a solve may keep them over, 0.006)
  *   multi-GPU: SGO_COMM_MODE={owner,allreduce}, SGO_COMM_GRAPH (see sgo_comm_init), SGO_OWNER_MIN_ROWS, SGO_RCCL_LIB (library path)
  *   test hooks and A/B switches of scripts/ (not for production): SGO_AMG_LISTS=host, SGO_SETUP_PIPELINE, SGO_TILE_LDS,
- *     SGO_FIRST_SOLVE_CAP, SGO_MIRROR, SGO_LANCZOS (sgo_debug_lanczos), SGO_MFRONT_DEBUG
+ *     SGO_FIRST_SOLVE_CAP, SGO_MIRROR, SGO_LANCZOS (sgo_debug_lanczos), SGO_MFRONT_DEBUG, SGO_AMG_LAG_FORCE / SGO_AMG_LAG_SLOPE
+ *     (scripts/lag_calib.py, tests/test_gpu_lagged_refresh.py)
  * Removed in round 5 (measured, not kept: NOTES.md sections 9-10): SGO_DEFLATE, SGO_OWNER_XS_EXCHANGE, SGO_MFRONT_FUSED_SOLVE.
  * Of the interface SURVEY.md section 8(b) sketched, three items do not exist, on purpose: SGO_NGPU (one process per GPU: the
  * launcher sets the world size, sgo_comm_init takes it), SGO_SOLVER=direct_cpu (the product has no CPU path; the CPU solver is

@@ -88,6 +88,8 @@ sgo_ctx* sgo_create(int device, const sgo_opts* opts) {
       (e = hipHostMalloc((void**)&c->h_S2, 2 * sizeof(PcgScalars))) != hipSuccess ||
       (e = hipHostMalloc((void**)&c->h_Sz, sizeof(PcgScalars))) != hipSuccess ||
       (e = hipHostGetDevicePointer((void**)&c->d_Sz, c->h_Sz, 0)) != hipSuccess ||
+      (e = hipHostMalloc((void**)&c->h_dchg, 3 * sizeof(double) * kMaxPartials)) != hipSuccess ||
+      (e = hipHostGetDevicePointer((void**)&c->h_dchg_dev, c->h_dchg, 0)) != hipSuccess ||
       (e = hipEventCreateWithFlags(&c->ev_S[0], hipEventDisableTiming)) != hipSuccess ||
       (e = hipEventCreateWithFlags(&c->ev_S[1], hipEventDisableTiming)) != hipSuccess ||
       (e = hipHostMalloc((void**)&c->h_hist, sizeof(double) * 2 * (SGO_MAX_ITERS + 2))) != hipSuccess ||
@@ -115,6 +117,7 @@ void sgo_destroy(sgo_ctx* c) {
   if (c->h_S) hipHostFree(c->h_S);
   if (c->h_S2) hipHostFree(c->h_S2);
   if (c->h_Sz) hipHostFree(c->h_Sz);
+  if (c->h_dchg) hipHostFree(c->h_dchg);
   if (c->h_pose_stage) hipHostFree(c->h_pose_stage);
   for (hipEvent_t ev : c->ev_S)
     if (ev) hipEventDestroy(ev);
@@ -139,6 +142,7 @@ const char* sgo_solver_description(sgo_ctx* c) {
                         " hubs), " + std::to_string(c->ov.dev.nt) + " touched rows, " + std::to_string(c->ov.dev.el.cnt) + " appended edges (" +
                         std::to_string(c->ov.updates) + " updates)";
     if (!c->update_note.empty()) c->solver_text += "; last update: " + c->update_note;
+    if (!c->lag_note.empty()) c->solver_text += "; " + c->lag_note;
     return c->solver_text.c_str();
   } catch (...) {   // no C++ exception crosses the C boundary
     return "";

@@ -69,6 +69,33 @@ struct sgo_ctx {
   bool halo_failed = false;
   std::vector<double> order_xy;     // [V][2] positions the row order follows when they are not the initial poses (a graph whose
                                     // poses contradict its closures: plan_order_positions, sgo_plan.cpp); empty otherwise
+  // Lagged refresh of the hierarchy's coarse operators (optimize_gn): d_dref = the level-0 diagonal blocks the coarse operators were
+  // last made from, h_dchg = k_diag_change's three sums (host-mapped), amg_lag_tau = relative movement up to which a solve keeps them
+  bool amg_skip_update = false;     // this solve keeps the coarse operators of the previous one
+  bool amg_lag_on = false;          // inside sgo_optimize_gn, after the call's first refresh
+  bool amg_force_keep = false;      // calibration hook (SGO_AMG_LAG_FORCE, scripts/lag_calib.py)
+  bool amg_lag_expect = false;      // the previous iteration's movement says this one may keep: do_linearize waits for the sums
+  bool amg_dchg_pending = false;    // k_diag_change's sums of this iteration have not been read yet
+  bool amg_ref_valid = false;       // d_dref holds the blocks of the resident coarse operators
+  double amg_lag_tau = 0.0;
+  // what a unit of movement costs this graph's solves in PCG iterations, learned from the kept solves (C4: ~1000, a 50k / 250k
+  // graph: ~4000-8000); a solve keeps while slope x movement <= 4 iterations (a refresh is worth 5-10).  Carried over a set-up when
+  // the graph has about the size of the one before (the reference re-initialises a slowly growing graph before every optimize).
+  double amg_lag_slope = 4000.0;
+  bool amg_lag_slope_seen = false;
+  int amg_lag_n = 0;
+  int probe_dev_k = -1;             // what the device's PcgScalars hold (k_set_probe is launched only on a change)
+  double probe_dev_max = -1.0;
+  int amg_probe_k = 0;              // progress probe of the kept solves (PcgScalars::probe_k / probe_max), from the last fresh solve
+  double amg_probe_max = 0.0;
+  int amg_lag_cap = 0;              // iteration cap of a solve behind kept operators (then: refresh and solve again)
+  double amg_lag_rows = 1.0;        // ... and the share of rows that may have moved by more than a quarter
+  double* d_dref = nullptr;
+  double* h_dchg = nullptr;         // pinned [3][kMaxPartials]: k_diag_change's per-workgroup sums
+  int dchg_grid = 0;                // ... of the launch whose sums are pending
+  double* h_dchg_dev = nullptr;     // its device address
+  double last_dchg[3] = {0, 0, 0};
+  std::string lag_note;             // sgo_solver_description: how many solves of the last call kept their coarse operators
   bool amg_no_filter = false;       // this graph's hierarchy rebuilds keep the tentative transfer where the smoothed one is refused
                                     // (a filtered hierarchy's solve was abandoned: optimize_gn); cleared by the next set-up
   int* d_comm_flag = nullptr;       // one int for the collective decision about the captured PCG graph (run_pcg)

@@ -191,8 +191,15 @@ struct PcgScalars {
   double rz_prev; // r.z before this iteration's update (recorded by k_update_xr for k_update_p)
   int iter;
   int maxit;
-  int stop;       // 0 run, 1 converged, 2 maxit, 3 breakdown (pq <= 0 or non-finite)
+  int stop;       // 0 run, 1 converged, 2 maxit, 3 breakdown (pq <= 0 or non-finite), 4 progress probe (below)
   int iter_prev;  // iter as k_update_xr saw it
+  // Progress probe (lagged refresh of the multigrid hierarchy's coarse operators, sgo_solve.cpp): the k_update_p of iteration probe_k
+  // records r.r / b.b, and with probe_max > 0 stops the solve with stop = 4 when that ratio is above probe_max -- a solve behind
+  // kept coarse operators that converges visibly slower than the last one behind fresh ones
+  int probe_k;
+  int pad_;
+  double probe_rel;
+  double probe_max;
 };
 
 // k_spmv modes and arguments (see sgo_kernels.hip)
@@ -508,10 +515,13 @@ void launch_early_strength(hipStream_t s, const EdgeListDev& el, const double* p
                            const unsigned char* flags, const int* hrowptr, double* w);
 void launch_linearize(hipStream_t s, const Sym0Dev& A, int g0, int g1, const EdgeSlotsDev& es, const double* poses,
                       double* dgb /*[n][9]*/);
+// (partials: [3][kMaxPartials], host-mapped -- the host adds the workgroups' sums itself, in order; returns the number of workgroups)
+int launch_diag_change(hipStream_t s, int row0, int row1, const double* dblk, double* dref, bool store_ref, double* partials);
 void launch_finalize(hipStream_t s, const Sym0Dev& A, int row0, int row1, const double* dgb, double* b, double* x, double* r, double* z,
                      double* p, double* xs, double omega, double* partials, int* grid_out);
 void launch_init_scalars(hipStream_t s, PcgScalars* S, const double* rz_parts, int n_rz, const double* bb_parts,
                          int n_bb, double tol, int maxit, double bb_ref, double tol_cap);
+void launch_set_probe(hipStream_t s, PcgScalars* S, int probe_k, double probe_max);
 void launch_restart_scalars(hipStream_t s, PcgScalars* S, const double* rz_parts, int n_rz, int maxit, int keep_stop);
 void launch_warm_start(hipStream_t s, int n3, const double* xp, const double* q, const double* b, double* x, double* r,
                        const double* xq_parts, int n_xq, const double* bx_parts, int n_bx);

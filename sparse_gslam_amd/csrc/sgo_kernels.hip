@@ -358,6 +358,36 @@ __global__ __launch_bounds__(kBlock) void k_finalize(Sym0Dev A, int row0, int ro
   block_sum_store<2>(acc, partials, kMaxPartials);
 }
 
+// How far the level-0 diagonal blocks have moved since the multigrid hierarchy's coarse operators were last refreshed:
+// partials [0] sum_i ||D_i - Dref_i||_F, [1] sum_i ||D_i||_F, [2] rows whose block moved by more than a quarter of its norm.
+// (optimize_gn decides from these whether this Gauss-Newton iteration's solve keeps the coarse operators of the last one.)
+__global__ __launch_bounds__(kBlock) void k_diag_change(int row0, int row1, const double* __restrict__ dblk, double* __restrict__ dref,
+                                                        int store_ref, double* __restrict__ partials) {
+  double acc[3] = {0.0, 0.0, 0.0};
+  for (int i = row0 + blockIdx.x * kBlock + threadIdx.x; i < row1; i += gridDim.x * kBlock) {
+    const double* d = dblk + 6 * (size_t)i;
+    double* e = dref + 6 * (size_t)i;
+    double dn = 0.0, nn = 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const double w = (k == 0 || k == 3 || k == 5) ? 1.0 : 2.0, v = d[k], u = v - e[k];
+      dn += w * u * u;
+      nn += w * v * v;
+      if (store_ref) e[k] = v;   // (the caller already knows this solve refreshes: the blocks become the new reference)
+    }
+    dn = sqrt(dn);
+    nn = sqrt(nn);
+    acc[0] += dn;
+    acc[1] += nn;
+    acc[2] += (dn > 0.25 * nn) ? 1.0 : 0.0;
+  }
+  block_sum_store<3>(acc, partials, kMaxPartials);
+}
+__global__ void k_set_probe(PcgScalars* S, int probe_k, double probe_max) {
+  S->probe_k = probe_k;
+  S->probe_rel = 0.0;
+  S->probe_max = probe_max;
+}
 // PCG continues an interrupted solve with another preconditioner: the caller has set z = M^-1 r, p = z for the
 // CURRENT residual; r.z is re-reduced, the recurrence scalars restart, x / r / iteration count / ||b|| / tolerance stay.
 // keep_stop: a stop flag that is already set stays (a solve that init found trivially converged); otherwise the flag
@@ -971,7 +1001,10 @@ __global__ __launch_bounds__(kBlock) void k_update_p(int n3, PcgScalars* S, cons
   if (!isfinite(rz) || !isfinite(rr)) stop = 3;
   else if (rr <= tol2 * bb) stop = 1;
   else if (iter_prev + 1 >= maxit) stop = 2;
+  const bool probe = iter_prev + 1 == S->probe_k;
+  if (probe && !stop && S->probe_max > 0.0 && rr > S->probe_max * bb) stop = 4;
   if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (probe) S->probe_rel = rr / bb;
     S->beta = beta;
     S->rz = rz;
     S->rr = rr;
@@ -985,6 +1018,7 @@ __global__ __launch_bounds__(kBlock) void k_update_p(int n3, PcgScalars* S, cons
     if (rec.mirror) {
       PcgScalars m = *S;   // (pq, alpha, rz_prev, iter_prev as this iteration's k_update_xr left them)
       m.beta = beta; m.rz = rz; m.rr = rr; m.iter = iter_prev + 1;
+      if (probe) m.probe_rel = rr / bb;
       if (stop) m.stop = stop;
       *rec.mirror = m;
     }
@@ -1185,6 +1219,14 @@ void launch_finalize(hipStream_t s, const Sym0Dev& A, int row0, int row1, const 
   const int grid = grid_for(row1 - row0, kBlock);
   SGO_LAUNCH(k_finalize, dim3(grid), dim3(kBlock), 0, s, A, row0, row1, dgb, b, x, r, z, p, xs, omega, partials);
   *grid_out = grid;
+}
+int launch_diag_change(hipStream_t s, int row0, int row1, const double* dblk, double* dref, bool store_ref, double* partials) {
+  const int grid = grid_for(row1 - row0, kBlock);
+  SGO_LAUNCH(k_diag_change, dim3(grid), dim3(kBlock), 0, s, row0, row1, dblk, dref, store_ref ? 1 : 0, partials);
+  return grid;
+}
+void launch_set_probe(hipStream_t s, PcgScalars* S, int probe_k, double probe_max) {
+  SGO_LAUNCH(k_set_probe, dim3(1), dim3(1), 0, s, S, probe_k, probe_max);
 }
 void launch_restart_scalars(hipStream_t s, PcgScalars* S, const double* rz_parts, int n_rz, int maxit, int keep_stop) {
   SGO_LAUNCH(k_restart_scalars, dim3(1), dim3(kBlock), 0, s, S, rz_parts, n_rz, maxit, keep_stop);

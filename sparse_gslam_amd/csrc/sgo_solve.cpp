@@ -116,7 +116,7 @@ static int start_pcg_owner(sgo_ctx* c, int grid) {
   const double tol = c->opts.pcg_tol * c->tol_scale;
   double* bb_parts = c->d_partials + kMaxPartials;   // k_finalize: [0] r.z (block-Jacobi), [1] b.b over the owned rows
   int rc;
-  if (c->amg && (rc = amg_update(c->amg, c->stream, &c->err))) return rc;
+  if (c->amg && !c->amg_skip_update && (rc = amg_update(c->amg, c->stream, &c->err))) return rc;
   if (c->amg && amg_comm_failed(c->amg)) return SGO_ECOMM;
   // the block-diagonal inverse of the neighbours' boundary rows (the halo-row recurrences of the iterations apply it)
   if (c->amg && !halo_exchange(H, c->stream, c->S0.dinv, 6, H.bnd, H.bmax, HaloScalars(), &c->err)) return SGO_ECOMM;
@@ -179,12 +179,28 @@ static RecDev rec_dev(const sgo_ctx* c) {
   return r;
 }
 
+static void read_diag_change(sgo_ctx* c) {   // (after a synchronisation behind the launch)
+  const volatile double* h = c->h_dchg;
+  for (int k = 0; k < 3; ++k) {
+    double v = 0.0;
+    for (int i = 0; i < c->dchg_grid; ++i) v += h[(size_t)k * kMaxPartials + i];
+    c->last_dchg[k] = v;
+  }
+  c->amg_dchg_pending = false;
+}
+static void set_probe(sgo_ctx* c, int k, double max) {
+  if (k == c->probe_dev_k && max == c->probe_dev_max) return;
+  launch_set_probe(c->stream, c->d_S, k, max);
+  c->probe_dev_k = k;
+  c->probe_dev_max = max;
+}
+
 int start_pcg(sgo_ctx* c, int grid) {
   if (c->owner) return start_pcg_owner(c, grid);
   const int maxit = c->pcg_softcap > 0 ? std::min(c->pcg_softcap, c->opts.pcg_maxit) : c->opts.pcg_maxit;
   const double tol = c->opts.pcg_tol * c->tol_scale;
   if (c->amg) {
-    int rc = amg_update(c->amg, c->stream, &c->err);
+    int rc = c->amg_skip_update ? SGO_OK : amg_update(c->amg, c->stream, &c->err);
     if (rc) return rc;
     const bool warm = c->warm_valid && c->d_xprev;
     if (warm) {
@@ -220,10 +236,35 @@ int start_pcg(sgo_ctx* c, int grid) {
       Scope sc(c, K_INIT_SCALARS, 8.0 * (gz + grid));
       launch_init_scalars(c->stream, c->d_S, c->d_zparts, gz, c->d_partials + kMaxPartials, grid, tol, maxit, c->bb_ref, c->tol_cap);
     }
+    // progress probe of the lagged refresh (PcgScalars): a fresh solve records, a solve behind kept operators is held to the record
+    set_probe(c, c->amg_lag_on ? c->amg_probe_k : 0, c->amg_skip_update ? c->amg_probe_max : 0.0);
   } else {
     Scope sc(c, K_INIT_SCALARS, 16.0 * grid);
     launch_init_scalars(c->stream, c->d_S, c->d_partials, grid, c->d_partials + kMaxPartials, grid, tol, maxit, c->bb_ref, c->tol_cap);
   }
+  return SGO_OK;
+}
+
+// The movement of the level-0 diagonal blocks up to which a solve keeps its coarse operators: what costs this graph's solves four
+// PCG iterations by the slope learned from its kept solves (sgo_ctx.h), at most amg_lag_tau.
+static double lag_allowed(const sgo_ctx* c) { return std::min(c->amg_lag_tau, 4.0 / std::max(c->amg_lag_slope, 1.0)); }
+
+// A solve behind KEPT coarse operators was stopped (its progress probe, or its iteration cap): the operators are refreshed and the
+// solve carries on from its current x and r -- z = M^-1 r with the new cycle, p = z, the recurrence restarts (what the kept
+// iterations gained in the residual stays; the Krylov memory goes, about two iterations' worth).  Single GPU only.
+static int refresh_and_continue(sgo_ctx* c, int maxit) {
+  int rc = amg_update(c->amg, c->stream, &c->err);
+  if (rc) return rc;
+  HIP_TRY(c, hipMemcpyAsync(c->d_dref, c->S0.dblk, sizeof(double) * 6 * (size_t)c->n, hipMemcpyDeviceToDevice, c->stream));
+  c->amg_ref_valid = true;
+  c->amg_skip_update = false;
+  const int gz = amg_apply(c->amg, c->stream, c->d_r, c->d_z, c->d_r, c->d_zparts, nullptr, nullptr, 0);
+  HIP_TRY(c, hipMemcpyAsync(c->d_p, c->d_z, sizeof(double) * 3 * (size_t)c->n, hipMemcpyDeviceToDevice, c->stream));
+  {
+    Scope sc(c, K_INIT_SCALARS, 8.0 * gz);
+    launch_restart_scalars(c->stream, c->d_S, c->d_zparts, gz, maxit, 0);
+  }
+  set_probe(c, 0, 0.0);
   return SGO_OK;
 }
 
@@ -247,6 +288,37 @@ int do_linearize(sgo_ctx* c) {
     Scope sc(c, K_FINALIZE, (72.0 + 48.0 + 48.0 + 6 * 24.0) * (row1 - row0));
     launch_finalize(c->stream, c->S0, row0, row1, c->d_dgb, c->d_b, c->d_x, c->d_r, c->d_z, c->d_p,
                     c->amg ? amg_xs0(c->amg) : nullptr, c->amg ? amg_omega(c->amg) : 0.0, c->d_partials, &grid);
+  }
+  if (c->amg && c->amg_lag_on && !c->owner && !c->ov.active && c->d_dref) {
+    // Lagged refresh: a solve keeps the coarse operators of the previous one while the level-0 diagonal blocks have moved little
+    // (lag_allowed: relative, summed over the rows) since those operators were made.
+    c->amg_skip_update = false;
+    c->amg_dchg_pending = false;
+    // The host waits for the sums -- the one round trip of the scheme, with the launches of the refresh not yet queued behind it:
+    // 40-50 us -- only when the movement of the PREVIOUS iteration says this one may keep (a converging call's steps shrink);
+    // otherwise the solve refreshes, the sums are read behind the solve's own synchronisation, and the kernel that measures
+    // stores the new reference on its way.
+    const bool wait = c->amg_ref_valid && ((c->amg_lag_expect && c->amg_probe_max > 0.0) || c->amg_force_keep);
+    c->dchg_grid = launch_diag_change(c->stream, 0, c->n, c->S0.dblk, c->d_dref, !wait, c->h_dchg_dev);
+    c->amg_dchg_pending = c->amg_ref_valid;
+    if (wait) {
+      HIP_TRY(c, hipStreamSynchronize(c->stream));
+      read_diag_change(c);
+      const double rel = c->last_dchg[1] > 0.0 ? c->last_dchg[0] / c->last_dchg[1] : 1.0;
+      c->amg_skip_update = rel <= lag_allowed(c) && c->last_dchg[2] <= c->amg_lag_rows && c->amg_probe_max > 0.0;
+      if (c->amg_force_keep) {   // calibration (SGO_AMG_LAG_FORCE=N): every solve after iteration N keeps, whatever moved
+        c->amg_skip_update = true;
+        c->amg_lag_cap = 0;
+        c->amg_probe_max = 0.0;
+      }
+      if (!c->amg_skip_update)
+        HIP_TRY(c, hipMemcpyAsync(c->d_dref, c->S0.dblk, sizeof(double) * 6 * (size_t)c->n, hipMemcpyDeviceToDevice, c->stream));
+    }
+    if (c->amg_skip_update && c->amg_lag_cap > 0) c->pcg_softcap = c->pcg_softcap > 0 ? std::min(c->pcg_softcap, c->amg_lag_cap) : c->amg_lag_cap;
+    if (!c->amg_skip_update) c->amg_ref_valid = true;
+  } else {
+    c->amg_skip_update = false;
+    c->amg_ref_valid = false;
   }
   int rc = start_pcg(c, grid);
   if (rc) return rc;
@@ -555,6 +627,7 @@ int build_amg(sgo_ctx* c) {
   // speculative replays of the captured PCG iteration (and the launches queued behind them) may still be
   // in flight: drain the stream before the exec and the old hierarchy's buffers go away
   HIP_TRY(c, hipStreamSynchronize(c->stream));
+  c->amg_ref_valid = false;   // (the lagged refresh's reference blocks belong to the old hierarchy's coarse operators)
   if (c->pcg_exec) {  // the captured PCG iteration references the old hierarchy's buffers
     hipGraphExecDestroy(c->pcg_exec);
     c->pcg_exec = nullptr;
@@ -811,8 +884,32 @@ int optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
         c->pcg_softcap = 0;
         c->bb_ref = 0.0;
         c->warm_valid = false;
+        c->amg_lag_on = false;
+        c->amg_skip_update = false;
       }
     } softcap_guard{c};
+    // Lagged refresh of the coarse operators (do_linearize): on by default on one GPU (the sharded modes refresh before every solve:
+    // a decision the ranks must take alike, not exercised on hardware); SGO_AMG_LAG=0 refreshes before every solve.
+    // The call's first solve always refreshes (the incremental set-up's staleness rule compares first solves, sgo_ctx.h).
+    c->amg_lag_tau = std::getenv("SGO_AMG_LAG_TAU") ? std::atof(std::getenv("SGO_AMG_LAG_TAU")) : 0.006;
+    c->amg_lag_rows = 32.0;
+    if (c->amg_lag_n == 0 || std::abs(c->n - c->amg_lag_n) > c->amg_lag_n / 10) {   // another graph: its sensitivity is not known yet
+      c->amg_lag_slope = 4000.0;
+      c->amg_lag_slope_seen = false;
+    }
+    c->amg_lag_n = c->n;
+    if (const char* e = std::getenv("SGO_AMG_LAG_SLOPE")) {   // test hook: the sensitivity every call starts from (1: keep whatever SGO_AMG_LAG_TAU allows)
+      c->amg_lag_slope = std::atof(e);
+      c->amg_lag_slope_seen = false;
+    }
+    c->amg_lag_on = !(std::getenv("SGO_AMG_LAG") && std::atoi(std::getenv("SGO_AMG_LAG")) == 0) && !multi_rank(c);   // (replicated ranks: the whole single-GPU computation each)
+    c->amg_ref_valid = false;
+    c->amg_probe_max = 0.0;
+    c->amg_lag_expect = false;
+    if (c->amg_probe_k < 4) c->amg_probe_k = 6;
+    int fresh_pcg = 0;   // the count of the last solve behind freshly made coarse operators
+    int kept_solves = 0;
+    c->lag_note.clear();
     c->warm_valid = false;
     const bool warm_env = c->opts.pcg_warm_start != 0;
     c->bb_ref = 0.0;
@@ -835,6 +932,9 @@ int optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
       // pcg_maxit.  (SGO_FIRST_SOLVE_CAP: test hook.)
       const int first_solve_cap = std::getenv("SGO_FIRST_SOLVE_CAP") ? std::max(1, std::atoi(std::getenv("SGO_FIRST_SOLVE_CAP"))) : 600;
       if (c->amg && c->amg_best == 0 && rebuilds < max_rebuilds && c->amg_theta_scale > 0.2) c->pcg_softcap = first_solve_cap;
+      c->amg_lag_cap = fresh_pcg > 0 ? fresh_pcg + 3 : 0;
+      c->amg_force_keep = std::getenv("SGO_AMG_LAG_FORCE") && it > std::atoi(std::getenv("SGO_AMG_LAG_FORCE"));
+      if (rebuild_next) c->amg_ref_valid = false;
       if ((rc = do_chi2(c, c->d_hist + 2 * it, nullptr)) || (rc = do_linearize(c))) return rc;
       if (rebuild_next && c->amg) {
         // The aggregation was made from the Hessian of an earlier linearisation and robust-kernel
@@ -850,6 +950,23 @@ int optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
       int wasted = 0;
       if ((rc = run_pcg(c))) {
         return rc;
+      }
+      bool kept_interrupted = false;
+      if (c->amg_skip_update && c->amg && (c->h_S->stop == 4 || (c->h_S->stop == 2 && c->h_S->iter < c->opts.pcg_maxit && c->pcg_softcap > 0))) {
+        // A solve behind KEPT coarse operators (lagged refresh, do_linearize) that its progress probe stopped -- after a third of the
+        // last fresh count its residual was more than half a decade behind that solve's -- or that reached its cap, the
+        // fresh count + 3: the operators are refreshed and the solve carries on from where it is.
+        const int at = c->h_S->iter;
+        c->pcg_softcap = (c->amg_best > 0 && rebuilds < max_rebuilds) ? 4 * c->amg_best + 40 + at : 0;
+        const int maxit = c->pcg_softcap > 0 ? std::min(c->pcg_softcap, c->opts.pcg_maxit) : c->opts.pcg_maxit;
+        c->pcg_pred = std::max(2, fresh_pcg);
+        if ((rc = refresh_and_continue(c, maxit)) || (rc = run_pcg(c))) return rc;
+        kept_interrupted = true;
+        const double moved = c->last_dchg[1] > 0.0 ? c->last_dchg[0] / c->last_dchg[1] : 0.0;
+        c->amg_lag_slope = std::max(c->amg_lag_slope, 16.0 / std::max(moved, 1e-6));   // (counted as sixteen iterations over)
+        c->amg_lag_slope_seen = true;
+        if (c->opts.verbose)
+          std::fprintf(stderr, "[sgo] iteration %d: solve behind kept coarse operators interrupted after %d PCG iterations, operators refreshed\n", it, at);
       }
       if (c->pcg_softcap > 0 && c->h_S->stop == 2 && c->h_S->iter < c->opts.pcg_maxit && c->amg) {
         // The solve ran into the bail-out cap (4x the best count of this hierarchy): the aggregation no
@@ -886,6 +1003,13 @@ int optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
         if (c->opts.verbose)
           std::fprintf(stderr, "[sgo] iteration %d: PCG breakdown behind a filtered hierarchy, rebuilt with tentative transfers and solved again\n", it);
       }
+      if (c->amg_dchg_pending) read_diag_change(c);   // (written before the solve began; the solve's end was waited for)
+      if (c->amg_lag_on) {
+        // what the blocks moved by in this iteration, against the operators' reference: when they were refreshed now, the NEXT
+        // iteration's movement against them will be about this iteration's one-step movement or less
+        const double moved = c->last_dchg[1] > 0.0 ? c->last_dchg[0] / c->last_dchg[1] : 1.0;
+        c->amg_lag_expect = c->amg_ref_valid && moved <= 2.0 * lag_allowed(c) && c->last_dchg[2] <= 4.0 * c->amg_lag_rows;
+      }
       const PcgScalars S = *c->h_S;
       int& best_pcg = c->amg_best;
       if (it == 0 && c->tol_cap > 0.0 && S.stop == 1) c->bb_ref = S.bb;
@@ -896,6 +1020,29 @@ int optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
         // a loose one for a stale hierarchy.
         const double tol0 = c->opts.pcg_tol * c->tol_scale, tolk = std::sqrt(S.tol2);
         const int eq_iter = (tolk > tol0 && tolk < 1.0 && tol0 > 0.0) ? (int)std::lround(S.iter * std::log(tol0) / std::log(tolk)) : S.iter;
+        if (kept_interrupted) {
+          // (counts of a solve that changed its preconditioner half-way say nothing about either hierarchy state)
+        } else if (c->amg_skip_update) {
+          ++kept_solves;
+          // behind kept coarse operators: judged against the last fresh solve only -- when the lag has cost more than a refresh is
+          // worth (~ 8-10 PCG iterations on C2 / C4), the next solve refreshes whatever the blocks' movement says
+          if (eq_iter > fresh_pcg + 8 + fresh_pcg / 4) c->amg_ref_valid = false;
+          // ... and every kept solve teaches what movement costs on this graph (the first observation replaces the cautious start,
+          // later ones raise the slope at once and lower it slowly)
+          const double moved = c->last_dchg[1] > 0.0 ? c->last_dchg[0] / c->last_dchg[1] : 0.0;
+          const double obs = std::max(0.5, (double)(eq_iter - fresh_pcg)) / std::max(moved, 1e-6);
+          c->amg_lag_slope = c->amg_lag_slope_seen ? std::max(obs, 0.8 * c->amg_lag_slope) : obs;
+          c->amg_lag_slope_seen = true;
+        } else {
+        fresh_pcg = eq_iter;
+        // the progress probe of the solves that keep these operators: iteration fresh / 3 (at least 4), half a decade of slack
+        if (S.probe_k > 0 && S.iter >= S.probe_k && S.probe_rel > 0.0) c->amg_probe_max = 10.0 * S.probe_rel;
+        else if (S.probe_k > 0) c->amg_probe_max = 0.0;
+        const int k_new = std::max(4, S.iter / 3);
+        if (S.probe_k < 4 || std::abs(k_new - S.probe_k) > 1) {   // (the record was taken at another iteration: the next fresh solve records anew)
+          c->amg_probe_k = k_new;
+          c->amg_probe_max = 0.0;
+        }
         if (best_pcg == 0 || eq_iter < best_pcg) best_pcg = eq_iter;
         // Redo the aggregation from the current values when that pays: always when the count has more
         // than doubled, and when it is > 25 % above the best while the PCG iterations it would save
@@ -909,6 +1056,7 @@ int optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
         const bool doubled = eq_iter > 2 * best_pcg + 10;
         const bool pays = 4 * eq_iter > 5 * best_pcg && (long long)(eq_iter - best_pcg) * left > 150;
         if (rebuilds < max_rebuilds && (doubled || pays)) rebuild_next = true;
+        }
       }
       its_sum += S.iter + wasted;
       if (it == 0 && S.stop == 1) {   // the call's first solve: what the incremental set-up's staleness rule compares (sgo_ctx.h)
@@ -953,11 +1101,14 @@ int optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
       c->linearized = false;
       ++done;
       if (c->opts.verbose)
-        std::fprintf(stderr, "[sgo] iteration= %d\t pcg= %d\t relres= %.3e\t |b|= %.3e\n", it, S.iter,
-                     S.bb > 0 ? std::sqrt(S.rr / S.bb) : 0.0, std::sqrt(S.bb));
+        std::fprintf(stderr, "[sgo] iteration= %d\t pcg= %d\t relres= %.3e\t |b|= %.3e\t diag moved %.3e (%.0f rows > 1/4; kept up to %.1e)%s\n", it, S.iter,
+                     S.bb > 0 ? std::sqrt(S.rr / S.bb) : 0.0, std::sqrt(S.bb), c->last_dchg[1] > 0 ? c->last_dchg[0] / c->last_dchg[1] : 0.0,
+                     c->last_dchg[2], lag_allowed(c), c->amg_skip_update ? " coarse operators kept" : "");
     }
     c->pcg_softcap = 0;
     (void)its_sum;
+    if (kept_solves > 0)
+      c->lag_note = "last sgo_optimize_gn: " + std::to_string(kept_solves) + " of " + std::to_string(done) + " solves kept the coarse operators of the one before";
     if ((rc = do_chi2(c, c->d_hist + 2 * done, nullptr))) {
       return rc;
     }

@@ -106,6 +106,8 @@ void free_graph(sgo_ctx* c) {
   c->es = EdgeSlotsDev();
   c->el = EdgeListDev();
   c->d_xprev = nullptr;
+  c->d_dref = nullptr;
+  c->amg_ref_valid = false;
   c->warm_valid = false;
   c->has_graph = false;
   c->linearized = false;
@@ -127,6 +129,7 @@ void free_graph(sgo_ctx* c) {
   c->d_lanczos = nullptr;   // (lived in the graph arena)
   c->its_base = c->its_last = 0;
   c->update_note.clear();
+  c->lag_note.clear();
 }
 
 // The edge arrays, poses and chi2 buffers of a graph: all that chi2 / per-edge chi2 / the single-launch direct path
@@ -817,12 +820,15 @@ int build_structure(sgo_ctx* c, int V, const double* poses, const uint8_t* fixed
   if ((rc = dalloc(c, &c->d_s1, n3))) return rc;
   if ((rc = dalloc(c, &c->d_s2, n3))) return rc;
   if ((rc = dalloc(c, &c->d_xprev, n3))) return rc;
+  if ((rc = dalloc(c, &c->d_dref, 6 * (size_t)std::max(n, 1)))) return rc;
   if ((rc = dalloc(c, &c->d_zparts, 2 * (size_t)kMaxPartials))) return rc;
   if ((rc = dalloc(c, &c->d_S, 1))) return rc;
   // diagnostic record of the PCG recurrence's coefficients (scripts/ritz_probe.py)
   c->d_lanczos = nullptr;
   if (std::getenv("SGO_LANCZOS") && (rc = dalloc(c, &c->d_lanczos, 3 * (size_t)kLanczosMax))) return rc;
   HIP_TRY(c, hipMemsetAsync(c->d_S, 0, sizeof(PcgScalars), c->stream));
+  c->probe_dev_k = 0;   // (what set_probe, sgo_solve.cpp, believes the device holds)
+  c->probe_dev_max = 0.0;
   HIP_TRY(c, hipStreamSynchronize(c->stream));  // host staging vectors die at return
   if (c->opts.verbose)
     std::fprintf(stderr, "[sgo] set_graph: host structure %.1f ms, alloc+upload %.1f ms (%d rows, %d stored blocks, %d slots)\n",
