@@ -289,7 +289,7 @@ int do_linearize(sgo_ctx* c) {
     launch_finalize(c->stream, c->S0, row0, row1, c->d_dgb, c->d_b, c->d_x, c->d_r, c->d_z, c->d_p,
                     c->amg ? amg_xs0(c->amg) : nullptr, c->amg ? amg_omega(c->amg) : 0.0, c->d_partials, &grid);
   }
-  if (c->amg && c->amg_lag_on && !c->owner && !c->ov.active && c->d_dref) {
+  if (c->amg && c->amg_lag_on && !c->owner && c->d_dref) {   // (an incremental overlay changes nothing here: the hierarchy is the resident rows')
     // Lagged refresh: a solve keeps the coarse operators of the previous one while the level-0 diagonal blocks have moved little
     // (lag_allowed: relative, summed over the rows) since those operators were made.
     c->amg_skip_update = false;
