@@ -81,7 +81,7 @@ struct sgo_ctx {
   // what a unit of movement costs this graph's solves in PCG iterations, learned from the kept solves (C4: ~1000, a 50k / 250k
   // graph: ~4000-8000); a solve keeps while slope x movement <= 4 iterations (a refresh is worth 5-10).  Carried over a set-up when
   // the graph has about the size of the one before (the reference re-initialises a slowly growing graph before every optimize).
-  double amg_lag_slope = 4000.0;
+  double amg_lag_slope = 2700.0;
   bool amg_lag_slope_seen = false;
   int amg_lag_n = 0;
   int probe_dev_k = -1;             // what the device's PcgScalars hold (k_set_probe is launched only on a change)

@@ -894,7 +894,7 @@ int optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
     c->amg_lag_tau = std::getenv("SGO_AMG_LAG_TAU") ? std::atof(std::getenv("SGO_AMG_LAG_TAU")) : 0.006;
     c->amg_lag_rows = 32.0;
     if (c->amg_lag_n == 0 || std::abs(c->n - c->amg_lag_n) > c->amg_lag_n / 10) {   // another graph: its sensitivity is not known yet
-      c->amg_lag_slope = 4000.0;
+      c->amg_lag_slope = 2700.0;
       c->amg_lag_slope_seen = false;
     }
     c->amg_lag_n = c->n;

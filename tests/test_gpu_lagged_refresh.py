@@ -70,8 +70,9 @@ def test_the_first_solve_of_a_call_always_refreshes():
         assert kept <= 2
 
 
-def test_a_kept_solve_that_falls_behind_is_interrupted_refreshed_and_carried_on(monkeypatch, capfd):
-    """Test hooks make every solve keep whose blocks moved by up to 5 % (the product's own start: 0.1 %): some of them converge
+@pytest.mark.parametrize("use_graph", [1, 0])
+def test_a_kept_solve_that_falls_behind_is_interrupted_refreshed_and_carried_on(use_graph, monkeypatch, capfd):
+    """Test hooks make every solve keep whose blocks moved by up to 5 % (the product's own start: 0.15 %): some of them converge
     visibly slower than the last fresh solve, their progress probe (or their iteration cap) stops them, the operators are refreshed
     and the solve carries on from its current x and r.  The iterates stay where the golden has them."""
     monkeypatch.setenv("SGO_MFRONT", "0")
@@ -80,7 +81,9 @@ def test_a_kept_solve_that_falls_behind_is_interrupted_refreshed_and_carried_on(
     monkeypatch.setenv("SGO_VERBOSE", "1")
     g = synth.config("C2")
     f = np.load(os.path.join(GOLDEN, "C2_direct.npz"))
-    done, st, P, desc = run(g)
+    with capi.Optimizer(0, direct_rows=0, use_graph=use_graph) as opt:   # (replayed hipGraph, and plain launches with a flag read per chunk)
+        opt.set_graph(*g.arrays())
+        done, st = opt.optimize(20)
     err = capfd.readouterr().err
     assert done == 20 and all(st["pcg_converged"][:20])
     assert "solve behind kept coarse operators interrupted" in err, err[-3000:]
