@@ -116,7 +116,7 @@ typedef struct sgo_opts {
  *     largest relative movement a solve may keep them over, 0.006)
  *   multi-GPU: SGO_COMM_MODE={owner,allreduce}, SGO_COMM_GRAPH (see sgo_comm_init), SGO_OWNER_MIN_ROWS, SGO_RCCL_LIB (library path)
  *   test hooks and A/B switches of scripts/ (not for production): SGO_AMG_LISTS=host, SGO_SETUP_PIPELINE, SGO_TILE_LDS,
- *     SGO_FIRST_SOLVE_CAP, SGO_MIRROR, SGO_LANCZOS (sgo_debug_lanczos), SGO_MFRONT_DEBUG, SGO_AMG_LAG_FORCE / SGO_AMG_LAG_SLOPE
+ *     SGO_FIRST_SOLVE_CAP, SGO_PCG_STALL_WINDOW, SGO_MIRROR, SGO_LANCZOS (sgo_debug_lanczos), SGO_MFRONT_DEBUG, SGO_AMG_LAG_FORCE / SGO_AMG_LAG_SLOPE
  *     (scripts/lag_calib.py, tests/test_gpu_lagged_refresh.py)
  * Removed in round 5 (measured, not kept: NOTES.md sections 9-10): SGO_DEFLATE, SGO_OWNER_XS_EXCHANGE, SGO_MFRONT_FUSED_SOLVE.
  * Of the interface SURVEY.md section 8(b) sketched, three items do not exist, on purpose: SGO_NGPU (one process per GPU: the
@@ -192,7 +192,9 @@ int sgo_get_poses(sgo_ctx* ctx, double* poses);
 /* Replaces: SparseOptimizer::optimize(iters) with OptimizationAlgorithmGaussNewton (slc.cpp:287,
  * log_runner.cpp:204): iters x { computeActiveErrors; buildSystem; solve; update }, no damping, no
  * convergence test.  Returns iterations done; 0 when a linear solve failed -- PCG breakdown (H not
- * positive definite) or pcg_maxit reached without pcg_tol: that step is not applied, the estimates stay
+ * positive definite) or pcg_maxit reached without pcg_tol (on one GPU also: the residual has not reached a new minimum for
+ * max(3000, 30 x the previous solve's count) iterations -- a solve that stagnates is not ground on to pcg_maxit): that step
+ * is not applied, the estimates stay
  * at the last applied update (out->iters_done of them) and sgo_last_error has the reason, as
  * g2o::SparseOptimizer::optimize returns 0 on OptimizationAlgorithm::Fail; SGO_ENOTHING (-1) when
  * there is no free active vertex; or another negative code.

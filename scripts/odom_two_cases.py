@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sparse_gslam_amd import capi, synth
 V, E, seed = 200000, 2000000, 7
 g = synth.manhattan(V, E, seed=seed, init="odom", info_mode="full", phi=10.0)
-with capi.Optimizer(0, pcg_maxit=3000) as o:
+with capi.Optimizer(0) as o:
     o.set_graph(*g.arrays())
     print(o.solver_description()[:300])
     t = time.perf_counter(); d, st = o.optimize(20); to = time.perf_counter() - t

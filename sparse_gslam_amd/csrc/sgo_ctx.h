@@ -155,6 +155,8 @@ struct sgo_ctx {
   hipGraphExec_t pcg_exec = nullptr;
   int pcg_exec_chunk = 0;
   int pcg_pred = 0;               // PCG iterations of the previous solve (prediction for the next)
+  bool pcg_stalled = false;       // run_pcg ended the last solve because r.r had not reached a new minimum for pcg_stall_window iterations
+  int pcg_stall_window = 0;
   double tol_scale = 1.0;         // < 1 on chain-like graphs (see sgo_set_graph_se2)
   double* d_xprev = nullptr;      // the previous Gauss-Newton step of the running sgo_optimize_gn (PCG warm start)
   bool warm_valid = false;

@@ -522,6 +522,7 @@ void launch_finalize(hipStream_t s, const Sym0Dev& A, int row0, int row1, const 
 void launch_init_scalars(hipStream_t s, PcgScalars* S, const double* rz_parts, int n_rz, const double* bb_parts,
                          int n_bb, double tol, int maxit, double bb_ref, double tol_cap);
 void launch_set_probe(hipStream_t s, PcgScalars* S, int probe_k, double probe_max);
+void launch_force_stop(hipStream_t s, PcgScalars* S, PcgScalars* mirror);
 void launch_restart_scalars(hipStream_t s, PcgScalars* S, const double* rz_parts, int n_rz, int maxit, int keep_stop);
 void launch_warm_start(hipStream_t s, int n3, const double* xp, const double* q, const double* b, double* x, double* r,
                        const double* xq_parts, int n_xq, const double* bx_parts, int n_bx);

@@ -383,6 +383,11 @@ __global__ __launch_bounds__(kBlock) void k_diag_change(int row0, int row1, cons
   }
   block_sum_store<3>(acc, partials, kMaxPartials);
 }
+// The host has seen no new minimum of r.r for thousands of iterations (run_pcg): the solve ends as one that ran out of iterations.
+__global__ void k_force_stop(PcgScalars* S, PcgScalars* mirror) {
+  if (S->stop == 0) S->stop = 2;
+  if (mirror) *mirror = *S;
+}
 __global__ void k_set_probe(PcgScalars* S, int probe_k, double probe_max) {
   S->probe_k = probe_k;
   S->probe_rel = 0.0;
@@ -1225,6 +1230,7 @@ int launch_diag_change(hipStream_t s, int row0, int row1, const double* dblk, do
   SGO_LAUNCH(k_diag_change, dim3(grid), dim3(kBlock), 0, s, row0, row1, dblk, dref, store_ref ? 1 : 0, partials);
   return grid;
 }
+void launch_force_stop(hipStream_t s, PcgScalars* S, PcgScalars* mirror) { SGO_LAUNCH(k_force_stop, dim3(1), dim3(1), 0, s, S, mirror); }
 void launch_set_probe(hipStream_t s, PcgScalars* S, int probe_k, double probe_max) {
   SGO_LAUNCH(k_set_probe, dim3(1), dim3(1), 0, s, S, probe_k, probe_max);
 }

@@ -519,6 +519,25 @@ int run_pcg(sgo_ctx* c) {
   bool comm_graph = c->comm.handle != nullptr && !c->comm.host_fn && !c->comm_graph_failed && c->comm.nranks <= 1;
   if (const char* e = std::getenv("SGO_COMM_GRAPH"))
     comm_graph = c->comm.handle != nullptr && !c->comm.host_fn && !c->comm_graph_failed && std::atoi(e) != 0;
+  // Stagnation guard (single GPU: the decision reads a clock-free but rank-local snapshot): a solve whose r.r has not reached a new
+  // minimum for max(3000, 30 x the previous solve's count) iterations is ended as one that ran out of iterations -- the systems
+  // PCG cannot finish in double precision otherwise grind on to pcg_maxit, three times per call.
+  c->pcg_stalled = false;
+  c->pcg_stall_window = multi_rank(c) ? 0 : std::max(3000, 30 * std::max(1, c->pcg_pred));
+  if (const char* e = std::getenv("SGO_PCG_STALL_WINDOW")) c->pcg_stall_window = multi_rank(c) ? 0 : std::atoi(e);   // (test hook; 0: no guard)
+  double stall_rr = -1.0;
+  int stall_it = 0;
+  auto stalled = [&](const volatile PcgScalars* S) -> bool {
+    if (c->pcg_stall_window <= 0 || c->pcg_stalled) return false;
+    const double rr = S->rr;
+    const int it = S->iter;
+    if (stall_rr < 0.0 || rr < stall_rr) {
+      stall_rr = rr;
+      stall_it = it;
+      return false;
+    }
+    return it - stall_it > c->pcg_stall_window;
+  };
   bool graph = c->opts.use_graph && !c->opts.profile && (!multi_rank(c) || comm_graph);
   constexpr int kUnit = 2;   // iterations per graph replay (1: 44.6, 2: 41.2, 4: 42, 8: 47 us per PCG iteration on C2 -- a replay costs
                              // ~7 us, an iteration past convergence eight early-exit nodes)
@@ -561,6 +580,11 @@ int run_pcg(sgo_ctx* c) {
       HIP_TRY(c, hipMemcpyAsync(c->h_S, c->d_S, sizeof(PcgScalars), hipMemcpyDeviceToHost, c->stream));
       HIP_TRY(c, hipStreamSynchronize(c->stream));
       if (c->h_S->stop) break;
+      if (stalled(c->h_S)) {
+        c->pcg_stalled = true;
+        launch_force_stop(c->stream, c->d_S, nullptr);
+        continue;
+      }
       for (int k = 0; k < chunk; ++k) {
         int rc = pcg_iteration(c);
         if (rc) return rc;
@@ -600,6 +624,10 @@ int run_pcg(sgo_ctx* c) {
     HIP_TRY(c, snapshot(slot ^ 1));
     HIP_TRY(c, hipEventSynchronize(c->ev_S[slot]));
     if (mirror ? ((volatile PcgScalars*)c->h_Sz)->stop : c->h_S2[slot].stop) break;
+    if (stalled(mirror ? (volatile PcgScalars*)c->h_Sz : (volatile PcgScalars*)&c->h_S2[slot])) {
+      c->pcg_stalled = true;
+      launch_force_stop(c->stream, c->d_S, mirror ? c->d_Sz : nullptr);
+    }
     slot ^= 1;
   }
   if (mirror) {
@@ -1078,8 +1106,10 @@ int optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
           if (c->amg && amg_coarsest_not_spd(c->amg, c->stream)) c->err += "; its coarsest Galerkin operator has a non-positive pivot";
           c->err += ")";
         } else {
-          c->err = "PCG did not reach pcg_tol within pcg_maxit = " + std::to_string(c->opts.pcg_maxit) +
-                   " iterations in GN iteration " + std::to_string(it) + " (relative residual " +
+          c->err = (c->pcg_stalled ? "PCG stagnated (no new minimum of the residual in the last " + std::to_string(c->pcg_stall_window) + " of " +
+                                         std::to_string(S.iter) + " iterations; pcg_maxit = "
+                                   : "PCG did not reach pcg_tol within pcg_maxit = ") + std::to_string(c->opts.pcg_maxit) +
+                   (c->pcg_stalled ? ")" : " iterations") + " in GN iteration " + std::to_string(it) + " (relative residual " +
                    std::to_string(S.bb > 0 ? std::sqrt(S.rr / S.bb) : 0.0) + "); the step was not applied";
         }
         failed = true;

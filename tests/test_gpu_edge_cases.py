@@ -191,3 +191,26 @@ def test_repeated_set_graph_and_optimize_do_not_leak_device_memory():
             assert done == 3
         grown = used() - base
     assert grown < 64 << 20, f"device memory grew by {grown / 2**20:.1f} MiB over 40 set_graph/optimize cycles"
+
+
+def test_a_solve_that_stagnates_ends_before_pcg_maxit(monkeypatch):
+    """run_pcg's stagnation guard: a solve whose residual has not reached a new minimum for a window of iterations ends as one that
+    ran out of iterations (the step is not applied, the call returns 0, the estimates stay).  The product's window is
+    max(3000, 30 x the previous count); the test hook shrinks it to 2 iterations, which the non-monotone residual of block-Jacobi
+    PCG on a 2 000-pose graph exceeds long before it converges."""
+    from sparse_gslam_amd import synth
+    g = synth.manhattan(2000, 6000, seed=5)
+    monkeypatch.setenv("SGO_PCG_STALL_WINDOW", "2")
+    with capi.Optimizer(0, solver=capi.SOLVER_PCG_BJ, direct_rows=0) as o:
+        o.set_graph(*g.arrays())
+        P0 = o.get_poses()
+        done, st = o.optimize(3)
+        assert done == 0
+        assert "stagnated" in o.last_error(), o.last_error()
+        assert st["pcg_iters"][0] < 2000
+        assert np.array_equal(o.get_poses(), P0)
+    monkeypatch.delenv("SGO_PCG_STALL_WINDOW")
+    with capi.Optimizer(0, solver=capi.SOLVER_PCG_BJ, direct_rows=0) as o:   # (the product's window lets the same solve finish)
+        o.set_graph(*g.arrays())
+        done, st = o.optimize(3)
+        assert done == 3, o.last_error()
