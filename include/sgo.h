@@ -112,8 +112,9 @@ typedef struct sgo_opts {
  *     SGO_AMG_SMOOTH=0 (tentative transfers only), SGO_AMG_OMEGA, SGO_AMG_OMEGA_P, SGO_AMG_NU, SGO_AMG_FOLD, SGO_AMG_FOLD0_ROWS,
  *     SGO_AMG_KDEPTH, SGO_AMG_FCG2_DEPTH (cycle shape), SGO_HOST_THREADS (worker pool of the host set-up)
  *   inside sgo_optimize_gn: SGO_AMG_LAG=0 (the hierarchy's coarse operators are refreshed before EVERY solve; default: a solve keeps
- *     those of the solve before while the level-0 diagonal blocks have barely moved), SGO_AMG_LAG_TAU (the
- *     largest relative movement a solve may keep them over, 0.006)
+ *     those of the solve before while the level-0 diagonal blocks have barely moved, and a hierarchy whose aggregation the blocks
+ *     have moved far away from is re-made once inside the next call: DESIGN.md section 5), SGO_AMG_LAG_TAU (the largest relative
+ *     movement a solve may keep its coarse operators over, 0.006)
  *   multi-GPU: SGO_COMM_MODE={owner,allreduce}, SGO_COMM_GRAPH (see sgo_comm_init), SGO_OWNER_MIN_ROWS, SGO_RCCL_LIB (library path)
  *   test hooks and A/B switches of scripts/ (not for production): SGO_AMG_LISTS=host, SGO_SETUP_PIPELINE, SGO_TILE_LDS,
  *     SGO_FIRST_SOLVE_CAP, SGO_PCG_STALL_WINDOW, SGO_MIRROR, SGO_LANCZOS (sgo_debug_lanczos), SGO_MFRONT_DEBUG, SGO_AMG_LAG_FORCE / SGO_AMG_LAG_SLOPE

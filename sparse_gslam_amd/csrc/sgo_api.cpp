@@ -88,7 +88,7 @@ sgo_ctx* sgo_create(int device, const sgo_opts* opts) {
       (e = hipHostMalloc((void**)&c->h_S2, 2 * sizeof(PcgScalars))) != hipSuccess ||
       (e = hipHostMalloc((void**)&c->h_Sz, sizeof(PcgScalars))) != hipSuccess ||
       (e = hipHostGetDevicePointer((void**)&c->d_Sz, c->h_Sz, 0)) != hipSuccess ||
-      (e = hipHostMalloc((void**)&c->h_dchg, 3 * sizeof(double) * kMaxPartials)) != hipSuccess ||
+      (e = hipHostMalloc((void**)&c->h_dchg, 6 * sizeof(double) * kMaxPartials)) != hipSuccess ||
       (e = hipHostGetDevicePointer((void**)&c->h_dchg_dev, c->h_dchg, 0)) != hipSuccess ||
       (e = hipEventCreateWithFlags(&c->ev_S[0], hipEventDisableTiming)) != hipSuccess ||
       (e = hipEventCreateWithFlags(&c->ev_S[1], hipEventDisableTiming)) != hipSuccess ||

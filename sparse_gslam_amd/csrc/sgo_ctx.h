@@ -91,7 +91,13 @@ struct sgo_ctx {
   int amg_lag_cap = 0;              // iteration cap of a solve behind kept operators (then: refresh and solve again)
   double amg_lag_rows = 1.0;        // ... and the share of rows that may have moved by more than a quarter
   double* d_dref = nullptr;
-  double* h_dchg = nullptr;         // pinned [3][kMaxPartials]: k_diag_change's per-workgroup sums
+  // ... and the blocks the hierarchy's AGGREGATION was made from (build_amg): a call whose first solve finds them far from the
+  // current ones and needs visibly more iterations than the hierarchy's best redoes the set-up once (optimize_gn)
+  double* d_dref_agg = nullptr;
+  bool agg_ref_valid = false;
+  int agg_best = 0;                 // the fewest PCG iterations a fresh solve behind this aggregation has taken
+  int agg_grid = 0;                 // k_diag_change's workgroups of that measurement (sums in the second half of h_dchg), 0: none pending
+  double* h_dchg = nullptr;         // pinned [2][3][kMaxPartials]: k_diag_change's per-workgroup sums (against d_dref, against d_dref_agg)
   int dchg_grid = 0;                // ... of the launch whose sums are pending
   double* h_dchg_dev = nullptr;     // its device address
   double last_dchg[3] = {0, 0, 0};

@@ -107,6 +107,8 @@ void free_graph(sgo_ctx* c) {
   c->el = EdgeListDev();
   c->d_xprev = nullptr;
   c->d_dref = nullptr;
+  c->d_dref_agg = nullptr;
+  c->agg_ref_valid = false;
   c->amg_ref_valid = false;
   c->warm_valid = false;
   c->has_graph = false;
@@ -820,7 +822,7 @@ int build_structure(sgo_ctx* c, int V, const double* poses, const uint8_t* fixed
   if ((rc = dalloc(c, &c->d_s1, n3))) return rc;
   if ((rc = dalloc(c, &c->d_s2, n3))) return rc;
   if ((rc = dalloc(c, &c->d_xprev, n3))) return rc;
-  if ((rc = dalloc(c, &c->d_dref, 6 * (size_t)std::max(n, 1)))) return rc;
+  if ((rc = dalloc(c, &c->d_dref, 6 * (size_t)std::max(n, 1))) || (rc = dalloc(c, &c->d_dref_agg, 6 * (size_t)std::max(n, 1)))) return rc;
   if ((rc = dalloc(c, &c->d_zparts, 2 * (size_t)kMaxPartials))) return rc;
   if ((rc = dalloc(c, &c->d_S, 1))) return rc;
   // diagnostic record of the PCG recurrence's coefficients (scripts/ritz_probe.py)

@@ -89,3 +89,41 @@ def test_a_kept_solve_that_falls_behind_is_interrupted_refreshed_and_carried_on(
     assert "solve behind kept coarse operators interrupted" in err, err[-3000:]
     for k in range(21):
         assert abs(st["chi2"][k] - f["chi2"][k]) <= 1e-6 * f["chi2"][k], k
+
+
+def test_a_hierarchy_aggregated_at_poor_poses_is_redone_once_when_the_next_call_finds_the_blocks_far_away(monkeypatch):
+    """A graph set up at its initial poses and optimised, then grown through sgo_update_graph_se2 (the reference's flow,
+    slc.cpp:205-287): the first call after the optimisation finds the level-0 blocks 21 % away from those the hierarchy was
+    aggregated from and its first solve well above the aggregation's best count -- the set-up is redone once, inside that call; the
+    calls after it find nothing to redo.  Every iterate agrees with a fresh set-up of the same arrays."""
+    monkeypatch.setenv("SGO_MFRONT", "0")
+    base, app, g = synth.append_session(10000, 40000, 3, 25, 4)
+    odom_meas = g.meas[: g.V - 1]
+    arrs = [base.ei, base.ej, base.meas, base.info, base.phi]
+    notes, its = [], []
+    with capi.Optimizer(0, direct_rows=0) as inc, capi.Optimizer(0, direct_rows=0) as fresh:
+        inc.set_graph(*base.arrays())
+        done, st = inc.optimize(20)
+        assert done == 20 and "re-aggregated" not in inc.solver_description()
+        P, E_res = inc.get_poses(), base.E
+        for a in app:
+            arrs = [np.concatenate([x, a[n]]) for x, n in zip(arrs, ("ei", "ej", "meas", "info", "phi"))]
+            P0 = np.empty((a["V"], 3))
+            P0[: P.shape[0]] = P
+            synth.chain_init(P0, odom_meas, P.shape[0], a["V"] - 1)
+            fixed = np.zeros(a["V"], dtype=bool)
+            fixed[0] = True
+            inc.update_graph(P0, fixed, *arrs, E_res)
+            done, st = inc.optimize(20)
+            assert done == 20 and all(st["pcg_converged"][:20])
+            notes.append("re-aggregated" in inc.solver_description())
+            its.append(float(np.mean(st["pcg_iters"][:20])))
+            P, E_res = inc.get_poses(), arrs[0].size
+            fresh.set_graph(P0, fixed, *arrs)
+            df, sf = fresh.optimize(20)
+            assert df == 20
+            for k in range(21):
+                assert abs(st["chi2"][k] - sf["chi2"][k]) <= 1e-6 * sf["chi2"][k], k
+                assert abs(st["robust_chi2"][k] - sf["robust_chi2"][k]) <= 1e-6 * sf["robust_chi2"][k], k
+    assert notes == [True, False, False], notes
+    assert its[2] <= its[0] + 1.0, its   # (the calls behind the re-made hierarchy do not need more iterations than the one that re-made it)
