@@ -110,6 +110,7 @@ void sgo_destroy(sgo_ctx* c) {
   free_graph(c);
   c->graph_arena.release();
   c->amg_arena.release();
+  c->amg_arena_prev.release();
   c->comm.destroy();
   overlay_release(c->ov);
   for (hipEvent_t e : c->ev_pool) hipEventDestroy(e);

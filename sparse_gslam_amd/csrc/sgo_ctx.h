@@ -122,6 +122,12 @@ struct sgo_ctx {
   // device
   DevArena graph_arena;           // device arrays of the resident graph (rewound by the next set_graph)
   DevArena amg_arena;             // ... of the multigrid hierarchy (rewound when the hierarchy is rebuilt)
+  // The hierarchy a TRIAL rebuild replaced (optimize_gn's re-aggregation rule): kept with its arena until the trial is decided -- a
+  // re-made hierarchy that does not solve visibly faster is dropped for it (revert_amg) -- or until the next rebuild.
+  DevArena amg_arena_prev;
+  Amg* amg_prev = nullptr;
+  std::string amg_prev_desc;
+  bool agg_rule_off = false;      // a trial was lost on this graph: the rule does not fire again before the next set-up
   double* d_poses = nullptr;
   int* d_free_id = nullptr;
   EdgeListDev el;
@@ -372,7 +378,8 @@ int start_pcg(sgo_ctx* c, int grid);
 int do_linearize(sgo_ctx* c);
 int do_spmv(sgo_ctx* c, const double* x, double* y, bool dot, const PcgScalars* S, int* grid_out);
 int run_pcg(sgo_ctx* c);
-int build_amg(sgo_ctx* c);
+int build_amg(sgo_ctx* c, bool keep_old = false);
+int revert_amg(sgo_ctx* c);
 std::string multi_gpu_description(const sgo_ctx* c);
 int build_rows(sgo_ctx* c, const double* poses, const uint8_t* fixed, const int32_t* ei, const int32_t* ej);
 int ensure_rows(sgo_ctx* c);

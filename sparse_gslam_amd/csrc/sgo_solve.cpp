@@ -651,7 +651,7 @@ std::string multi_gpu_description(const sgo_ctx* c) {
   return "";
 }
 
-int build_amg(sgo_ctx* c) {
+int build_amg(sgo_ctx* c, bool keep_old) {
   // speculative replays of the captured PCG iteration (and the launches queued behind them) may still be
   // in flight: drain the stream before the exec and the old hierarchy's buffers go away
   HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -663,6 +663,17 @@ int build_amg(sgo_ctx* c) {
   c->pcg_pred = 0;  // the iteration count of the old hierarchy predicts nothing about the new one
   c->amg_best = 0;
   c->agg_best = 0;
+  if (c->amg_prev) {   // (whatever an earlier trial kept is gone now)
+    amg_destroy(c->amg_prev);
+    c->amg_prev = nullptr;
+  }
+  if (keep_old && c->amg) {   // trial rebuild: the old hierarchy stays intact in its arena, the new one goes into the other
+    c->amg_prev = c->amg;
+    c->amg = nullptr;
+    c->amg_prev_desc = c->solver_desc;
+    std::swap(c->amg_arena.chunks, c->amg_arena_prev.chunks);
+    std::swap(c->amg_arena.next_chunk, c->amg_arena_prev.next_chunk);
+  }
   if (c->amg) {
     amg_destroy(c->amg);
     c->amg = nullptr;
@@ -739,6 +750,31 @@ int build_amg(sgo_ctx* c) {
     HIP_TRY(c, hipMemcpyAsync(c->d_dref_agg, c->S0.dblk, sizeof(double) * 6 * (size_t)c->n, hipMemcpyDeviceToDevice, c->stream));
     c->agg_ref_valid = true;
   }
+  return SGO_OK;
+}
+
+// The hierarchy a trial rebuild made is dropped for the one it replaced (build_amg(c, true) kept it): the old one's values are
+// refreshed by the next solve's amg_update like any other iteration's.
+int revert_amg(sgo_ctx* c) {
+  if (!c->amg_prev) return SGO_OK;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (c->pcg_exec) {   // (the captured PCG iteration references the dropped hierarchy's buffers)
+    hipGraphExecDestroy(c->pcg_exec);
+    c->pcg_exec = nullptr;
+  }
+  if (c->amg) amg_destroy(c->amg);
+  c->amg = c->amg_prev;
+  c->amg_prev = nullptr;
+  std::swap(c->amg_arena.chunks, c->amg_arena_prev.chunks);
+  std::swap(c->amg_arena.next_chunk, c->amg_arena_prev.next_chunk);
+  c->amg_arena_prev.rewind();
+  c->solver_desc = c->amg_prev_desc;
+  c->pcg_pred = 0;
+  c->amg_best = 0;
+  c->agg_best = 0;
+  c->amg_ref_valid = false;   // its coarse operators are two iterations old: the next solve refreshes
+  c->amg_probe_max = 0.0;
+  c->agg_ref_valid = false;   // (and the blocks it was aggregated from are not known any more: the rule is off for this graph anyway)
   return SGO_OK;
 }
 
@@ -943,6 +979,7 @@ int optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
     int fresh_pcg = 0;   // the count of the last solve behind freshly made coarse operators
     int kept_solves = 0;
     std::string agg_note;
+    int trial = 0, trial_old = 0, trial_best = 0, trial_seen = 0;   // the re-aggregation rule's trial: 1 = rebuild pending, 2 = judging the new hierarchy's first solves
     c->lag_note.clear();
     c->warm_valid = false;
     const bool warm_env = c->opts.pcg_warm_start != 0;
@@ -968,6 +1005,7 @@ int optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
       if (c->amg && c->amg_best == 0 && rebuilds < max_rebuilds && c->amg_theta_scale > 0.2) c->pcg_softcap = first_solve_cap;
       c->amg_lag_cap = fresh_pcg > 0 ? fresh_pcg + 3 : 0;
       c->amg_force_keep = std::getenv("SGO_AMG_LAG_FORCE") && it > std::atoi(std::getenv("SGO_AMG_LAG_FORCE"));
+      if (trial == 2) c->amg_ref_valid = false;   // (the trial's solves are fresh ones)
       if (rebuild_next) c->amg_ref_valid = false;
       if ((rc = do_chi2(c, c->d_hist + 2 * it, nullptr)) || (rc = do_linearize(c))) return rc;
       c->agg_grid = 0;
@@ -978,7 +1016,8 @@ int optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
         // re-weighting has changed the strength of connection since (see the rule below): redo the
         // set-up from the current values (same cost as in sgo_set_graph_se2).
         if (rebuilds + 1 >= max_rebuilds) c->amg_no_filter = true;   // (the call's last rebuild: see the abandoned solve below)
-        if ((rc = build_amg(c)) || (rc = do_linearize(c))) return rc;
+        if ((rc = build_amg(c, trial == 1)) || (rc = do_linearize(c))) return rc;
+        if (trial == 1) trial = 2;
         rebuild_next = false;
         ++rebuilds;
         if (c->opts.verbose) std::fprintf(stderr, "[sgo] multigrid hierarchy rebuilt before iteration %d\n", it);
@@ -1000,7 +1039,9 @@ int optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
         if ((rc = refresh_and_continue(c, maxit)) || (rc = run_pcg(c))) return rc;
         kept_interrupted = true;
         const double moved = c->last_dchg[1] > 0.0 ? c->last_dchg[0] / c->last_dchg[1] : 0.0;
-        c->amg_lag_slope = std::max(c->amg_lag_slope, 16.0 / std::max(moved, 1e-6));   // (counted as sixteen iterations over)
+        // (counted as sixteen iterations over -- but never past what forbids keeping over 0.01 % of movement: an interruption at next
+        // to no movement was not the movement's doing, and a slope that only kept solves can lower must not lock them out)
+        c->amg_lag_slope = std::min(std::max(c->amg_lag_slope, 16.0 / std::max(moved, 1e-6)), 40000.0);
         c->amg_lag_slope_seen = true;
         if (c->opts.verbose)
           std::fprintf(stderr, "[sgo] iteration %d: solve behind kept coarse operators interrupted after %d PCG iterations, operators refreshed\n", it, at);
@@ -1067,11 +1108,29 @@ int optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
           // ... and every kept solve teaches what movement costs on this graph (the first observation replaces the cautious start,
           // later ones raise the slope at once and lower it slowly)
           const double moved = c->last_dchg[1] > 0.0 ? c->last_dchg[0] / c->last_dchg[1] : 0.0;
-          const double obs = std::max(0.5, (double)(eq_iter - fresh_pcg)) / std::max(moved, 1e-6);
+          const double obs = std::min(40000.0, std::max(0.5, (double)(eq_iter - fresh_pcg)) / std::max(moved, 1e-5));
           c->amg_lag_slope = c->amg_lag_slope_seen ? std::max(obs, 0.8 * c->amg_lag_slope) : obs;
           c->amg_lag_slope_seen = true;
         } else {
         fresh_pcg = eq_iter;
+        if (c->amg_lag_slope > 2700.0) c->amg_lag_slope = std::max(2700.0, 0.95 * c->amg_lag_slope);   // (a high slope is re-examined in time)
+        if (trial == 2) {
+          // The re-made hierarchy's first two (fresh, warm-started) solves against the old one's first solve of this call (cold): a
+          // hierarchy that is better shows it at once -- 22 / 24 against 33 on the C4-sized session --; one that is not -- the
+          // re-aggregation can lose a smoothed transfer it had, 42 / 38 against 27 on a 40 k / 60 k graph -- is dropped for the old.
+          trial_best = trial_seen == 0 ? eq_iter : std::min(trial_best, eq_iter);
+          if (++trial_seen == 2) {
+            trial = 0;
+            if (100 * trial_best > 85 * trial_old) {
+              if ((rc = revert_amg(c))) return rc;
+              c->agg_rule_off = true;
+              rebuild_next = false;
+              fresh_pcg = 0;
+              agg_note = "a re-aggregated hierarchy was tried in the last sgo_optimize_gn and dropped (" + std::to_string(trial_best) + " PCG iterations against the old one's " + std::to_string(trial_old) + ")";
+              if (c->opts.verbose) std::fprintf(stderr, "[sgo] iteration %d: the re-aggregated hierarchy is no better (%d against %d): the old one is back\n", it, trial_best, trial_old);
+            }
+          }
+        }
         if (c->agg_best == 0 || eq_iter < c->agg_best) c->agg_best = eq_iter;   // (an incremental update resets amg_best, not this)
         // the progress probe of the solves that keep these operators: iteration fresh / 3 (at least 4), half a decade of slack
         if (S.probe_k > 0 && S.iter >= S.probe_k && S.probe_rel > 0.0) c->amg_probe_max = 10.0 * S.probe_rel;
@@ -1107,8 +1166,10 @@ int optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
           c->agg_grid = 0;
           const bool moved_far = v[1] > 0.0 && (v[0] > 0.05 * v[1] || v[2] > 0.01 * (double)c->n);
           if (c->opts.verbose) std::fprintf(stderr, "[sgo] since the aggregation: blocks moved by %.2f %%, %.0f rows by a quarter; first solve %d, best of this aggregation %d\n", v[1] > 0 ? 100.0 * v[0] / v[1] : 0.0, v[2], eq_iter, c->agg_best);
-          if (moved_far && c->agg_best > 0 && 10 * eq_iter > 11 * c->agg_best && rebuilds < max_rebuilds && !rebuild_next) {
+          if (moved_far && !c->agg_rule_off && iters - it >= 5 && c->agg_best > 0 && 10 * eq_iter > 11 * c->agg_best && rebuilds < max_rebuilds && !rebuild_next) {
             rebuild_next = true;
+            trial = 1;
+            trial_old = eq_iter;
             char nb[160];
             std::snprintf(nb, sizeof nb, "hierarchy re-aggregated in the last sgo_optimize_gn (the blocks had moved by %.0f %% since it was made)", 100.0 * v[0] / v[1]);
             agg_note = nb;

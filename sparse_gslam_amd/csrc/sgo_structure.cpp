@@ -84,6 +84,11 @@ void free_graph(sgo_ctx* c) {
     amg_destroy(c->amg);
     c->amg = nullptr;
   }
+  if (c->amg_prev) {
+    amg_destroy(c->amg_prev);
+    c->amg_prev = nullptr;
+  }
+  c->agg_rule_off = false;
   if (c->direct) {
     direct_destroy(c->direct);
     c->direct = nullptr;
@@ -98,6 +103,7 @@ void free_graph(sgo_ctx* c) {
   c->order_xy.clear();
   c->rows_pending = false;
   c->amg_arena.rewind();
+  c->amg_arena_prev.rewind();
   c->graph_arena.rewind();   // the caller has synchronised the stream: nothing in flight reads these arrays
   c->pcg_pred = 0;
   c->A = BsrDev();
