@@ -1,5 +1,7 @@
+"""bench.py's incremental session (the reference's flow on the C4-sized graph) with the round-5 refresh rules off (SGO_AMG_LAG=0)
+and on.  python scripts/incremental_lag_probe.py"""
 import os, sys, json
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 for lag in ("0", "1"):
     os.environ["SGO_AMG_LAG"] = lag

@@ -1,4 +1,5 @@
 #!/bin/bash
+# PMC passes (FETCH_SIZE, WRITE_SIZE) of the C5 bench on their own, for when scripts/profile_round.sh lost one of them to a profiler crash.
 R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out; cd /tmp; export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf $O/pmc_${c}_c5

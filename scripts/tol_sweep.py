@@ -1,7 +1,10 @@
+"""C4 against its golden for a few PCG tolerances / tolerance caps: iteration counts, time, chi2 error per iterate (round 3).
+python scripts/tol_sweep.py"""
 import sys, numpy as np
-sys.path.insert(0,'/root/repo')
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sparse_gslam_amd import capi, synth
-f=np.load('/root/repo/tests/golden/C4_direct.npz')
+f=np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests', 'golden', 'C4_direct.npz'))
 g=synth.config("C4")
 for tol in (1e-8,1e-7,1e-6,1e-5):
     with capi.Optimizer(0,pcg_tol=tol) as o:
