@@ -1240,6 +1240,11 @@ int optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
     HIP_TRY(c, hipMemcpyAsync(c->h_hist, c->d_hist, sizeof(double) * 2 * (size_t)(done + 1), hipMemcpyDeviceToHost,
                               c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->amg_prev && trial == 0) {   // a trial that was accepted: the replaced hierarchy and its arena go (once per graph, a few ms)
+      amg_destroy(c->amg_prev);
+      c->amg_prev = nullptr;
+      c->amg_arena_prev.release();
+    }
     prof_flush(c);
     if (out) {
       out->iters_done = done;
