@@ -976,6 +976,7 @@ int optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
     c->amg_probe_max = 0.0;
     c->amg_lag_expect = false;
     if (c->amg_probe_k < 4) c->amg_probe_k = 6;
+    const int force_from = std::getenv("SGO_AMG_LAG_FORCE") ? std::atoi(std::getenv("SGO_AMG_LAG_FORCE")) : -1;   // (calibration hook, scripts/lag_calib.py)
     int fresh_pcg = 0;   // the count of the last solve behind freshly made coarse operators
     int kept_solves = 0;
     std::string agg_note;
@@ -1004,7 +1005,7 @@ int optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
       const int first_solve_cap = std::getenv("SGO_FIRST_SOLVE_CAP") ? std::max(1, std::atoi(std::getenv("SGO_FIRST_SOLVE_CAP"))) : 600;
       if (c->amg && c->amg_best == 0 && rebuilds < max_rebuilds && c->amg_theta_scale > 0.2) c->pcg_softcap = first_solve_cap;
       c->amg_lag_cap = fresh_pcg > 0 ? fresh_pcg + 3 : 0;
-      c->amg_force_keep = std::getenv("SGO_AMG_LAG_FORCE") && it > std::atoi(std::getenv("SGO_AMG_LAG_FORCE"));
+      c->amg_force_keep = force_from >= 0 && it > force_from;
       if (trial == 2) c->amg_ref_valid = false;   // (the trial's solves are fresh ones)
       if (rebuild_next) c->amg_ref_valid = false;
       if ((rc = do_chi2(c, c->d_hist + 2 * it, nullptr)) || (rc = do_linearize(c))) return rc;
