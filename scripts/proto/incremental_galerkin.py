@@ -1,0 +1,106 @@
+"""numpy prototype: what the coarse operators of a Gauss-Newton iteration may be made from, short of a full refresh.
+
+Along optimize(20) of a graph from the bench's incremental start (the CPU oracle's iterates), at every iteration k >= 1 the
+hierarchy's aggregates are those of iteration 0 and PCG (1e-8) on the CURRENT Hessian is preconditioned by a cycle whose level-0
+smoother uses the current Hessian and whose coarse operators are
+
+  fresh      P and P^T A P from the current Hessian                                  -- what a refresh costs 1.2 ms for on C4
+  kept       everything from iteration k-1                                            -- the lagged refresh's kept solve
+  frozen P   P from iteration k-1, P^T A P from the current Hessian
+  mixed tau  P from iteration k-1, P^T A_mix P with A_mix = the edges whose DCS weight moved by more than tau (relative) or whose
+             end poses turned by more than tau radians taken at the current poses, all other edges as they were at iteration k-1:
+             the incremental Galerkin update A_c += P^T dA P over the changed slots only
+
+  python scripts/proto/incremental_galerkin.py V E [iters]
+"""
+import os
+import sys
+
+import numpy as np
+import scipy.sparse as sp
+import scipy.sparse.linalg as spla
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from oracle import np_oracle  # noqa: E402
+from sparse_gslam_amd import synth  # noqa: E402
+import fsa_lib  # noqa: E402
+from fsa_lib import build, cyc  # noqa: E402
+
+fsa_lib.np, fsa_lib.sp, fsa_lib.spla = np, sp, spla
+V, E = int(sys.argv[1]), int(sys.argv[2])
+iters = int(sys.argv[3]) if len(sys.argv) > 3 else 12
+omega = fsa_lib.omega
+
+
+def dinv_of(A):
+    n = A.shape[0] // 3
+    B = A.tobsr(blocksize=(3, 3)); B.sort_indices()
+    rows = np.repeat(np.arange(n), np.diff(B.indptr)); dm = rows == B.indices
+    D = np.zeros((n, 3, 3)); D[rows[dm]] = B.data[dm]
+    return sp.bsr_matrix((np.linalg.inv(0.5 * (D + D.transpose(0, 2, 1))), np.arange(n), np.arange(n + 1)), shape=A.shape).tocsr()
+
+
+def with_P(old, H_true, H_coarse_from):
+    """levels with the transfers of `old`, level 0 = H_true (smoother, residual), coarse operators from H_coarse_from."""
+    out = []
+    A = H_coarse_from.tocsr()
+    for l, L in enumerate(old):
+        lev = dict(n=L["n"])
+        lev["A"] = H_true.tocsr() if l == 0 else A
+        lev["Dinv"] = dinv_of(lev["A"])
+        if "P" in L:
+            lev["P"] = L["P"]
+            A = (L["P"].T @ A @ L["P"]).tocsr()
+        else:
+            lev["lu"] = spla.splu(sp.csc_matrix(A))
+        out.append(lev)
+    return out
+
+
+def kept(old, H_true):
+    out = [dict(L) for L in old]
+    out[0] = dict(old[0]); out[0]["A"] = H_true.tocsr(); out[0]["Dinv"] = dinv_of(H_true)
+    return out
+
+
+def pcg(Hop, levels, b, maxit=1500):
+    x = np.zeros_like(b); r = b.copy(); z = cyc(levels, 0, r); p = z.copy(); rz = r @ z; bn = np.linalg.norm(b); it = 0
+    while it < maxit:
+        q = Hop @ p; a = rz / (p @ q); x += a * p; r -= a * q; it += 1
+        if np.linalg.norm(r) <= 1e-8 * bn:
+            break
+        z = cyc(levels, 0, r); rzn = r @ z; p = z + (rzn / rz) * p; rz = rzn
+    return it, x
+
+
+g = synth.manhattan(V, E, seed=4)
+fixed, ei, ej, meas, info, phi = g.fixed, g.ei, g.ej, g.meas, g.info, g.phi
+poses = g.poses.copy()
+free = np.flatnonzero(~fixed)
+H0, b0, _, _ = np_oracle.linearize(poses, fixed, ei, ej, meas, info, phi)
+agg_levels = build(H0.tocsr(), poses[free, :2])
+prev_levels, prev_poses, prev_w = None, None, None
+print(f"V={V} E={E}; levels {[L['n'] for L in agg_levels]}")
+for k in range(iters):
+    H, b, c2, rc2 = np_oracle.linearize(poses, fixed, ei, ej, meas, info, phi)
+    H = H.tocsr()
+    _, _, e2 = np_oracle.chi2(poses, ei, ej, meas, info, phi)
+    _, w = np_oracle.dcs_rho(e2, phi)
+    fresh = build(H, poses[free, :2], reuse=agg_levels)
+    it_f, dx = pcg(H, fresh, b)
+    line = f"it {k:2d}  fresh {it_f:3d}"
+    if prev_levels is not None:
+        it_k, _ = pcg(H, kept(prev_levels, H), b)
+        it_p, _ = pcg(H, with_P(prev_levels, H, H), b)
+        line += f"   kept {it_k:3d}   frozen P {it_p:3d}"
+        dth = np.abs(np_oracle.normalize_theta(poses[:, 2] - prev_poses[:, 2]))
+        for tau in (0.2, 0.05, 0.01):
+            ch = (np.abs(w - prev_w) > tau * np.maximum(w, prev_w)) | (dth[ei] > tau) | (dth[ej] > tau)
+            Hc, _, _, _ = np_oracle.linearize(poses, fixed, ei[ch], ej[ch], meas[ch], info[ch], phi[ch]) if ch.any() else (sp.csr_matrix(H.shape), 0, 0, 0)
+            Hu, _, _, _ = np_oracle.linearize(prev_poses, fixed, ei[~ch], ej[~ch], meas[~ch], info[~ch], phi[~ch])
+            it_m, _ = pcg(H, with_P(prev_levels, H, (Hc + Hu).tocsr()), b)
+            line += f"   mixed {tau}: {it_m:3d} ({int(ch.sum())} edges)"
+    print(line, flush=True)
+    prev_levels, prev_poses, prev_w = fresh, poses.copy(), w
+    poses = np_oracle.oplus(poses, fixed, dx)
