@@ -979,6 +979,7 @@ int optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
     const int force_from = std::getenv("SGO_AMG_LAG_FORCE") ? std::atoi(std::getenv("SGO_AMG_LAG_FORCE")) : -1;   // (calibration hook, scripts/lag_calib.py)
     int fresh_pcg = 0;   // the count of the last solve behind freshly made coarse operators
     int kept_solves = 0;
+    int call_best = 0;   // the fewest (equal-tolerance) iterations a fresh solve of this call has taken
     std::string agg_note;
     int trial = 0, trial_old = 0, trial_best = 0, trial_seen = 0;   // the re-aggregation rule's trial: 1 = rebuild pending, 2 = judging the new hierarchy's first solves
     c->lag_note.clear();
@@ -1021,6 +1022,7 @@ int optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
         if (trial == 1) trial = 2;
         rebuild_next = false;
         ++rebuilds;
+        call_best = 0;   // (another hierarchy: its first solve sets the reference)
         if (c->opts.verbose) std::fprintf(stderr, "[sgo] multigrid hierarchy rebuilt before iteration %d\n", it);
       }
       hipEventRecord(ev[3 * it + 1], c->stream);
@@ -1065,6 +1067,7 @@ int optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
         if (rebuilds + 1 >= max_rebuilds) c->amg_no_filter = true;
         if ((rc = build_amg(c)) || (rc = do_linearize(c)) || (rc = run_pcg(c))) return rc;
         ++rebuilds;
+        call_best = 0;   // (another hierarchy: its first solve sets the reference)
         rebuild_next = false;
         if (c->opts.verbose)
           std::fprintf(stderr, "[sgo] iteration %d: solve abandoned after %d PCG iterations, hierarchy rebuilt\n", it, wasted);
@@ -1078,6 +1081,7 @@ int optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
         c->pcg_softcap = 0;
         if ((rc = build_amg(c)) || (rc = do_linearize(c)) || (rc = run_pcg(c))) return rc;
         ++rebuilds;
+        call_best = 0;   // (another hierarchy: its first solve sets the reference)
         rebuild_next = false;
         if (c->opts.verbose)
           std::fprintf(stderr, "[sgo] iteration %d: PCG breakdown behind a filtered hierarchy, rebuilt with tentative transfers and solved again\n", it);
@@ -1124,6 +1128,7 @@ int optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
             trial = 0;
             if (100 * trial_best > 85 * trial_old) {
               if ((rc = revert_amg(c))) return rc;
+              call_best = 0;
               c->agg_rule_off = true;
               rebuild_next = false;
               fresh_pcg = 0;
@@ -1150,9 +1155,14 @@ int optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
         // (crediting a rebuild only for as long as the previous one of this call stayed good -- weights that keep changing -- was
         // measured in round 5 on C4 from a dead-reckoned start and is worse: the hierarchy left in place went from 74 to 400
         // iterations two solves later; median 29.8 against 23.3 ms per Gauss-Newton iteration)
+        // (against the best count of THIS call: the first solve of a call from a far start is harder than the last solves of the call
+        // before whatever the hierarchy -- C5 re-optimised from its initial poses: 88 iterations against the 31 the previous call ended
+        // with -- and with the best carried over, every such call redid the set-up after its first solve, at a state the NEXT call's
+        // start then found useless: 2.2 instead of 1.4 s per call.  Staleness across calls is the movement rule's business, below.)
+        if (call_best == 0 || eq_iter < call_best) call_best = eq_iter;
         const int left = iters - it - 1;
-        const bool doubled = eq_iter > 2 * best_pcg + 10;
-        const bool pays = 4 * eq_iter > 5 * best_pcg && (long long)(eq_iter - best_pcg) * left > 150;
+        const bool doubled = eq_iter > 2 * call_best + 10;
+        const bool pays = 4 * eq_iter > 5 * call_best && (long long)(eq_iter - call_best) * left > 150;
         if (rebuilds < max_rebuilds && (doubled || pays)) rebuild_next = true;
         // The aggregation's own staleness, across calls: the hierarchy was aggregated from blocks that have since moved a lot -- a
         // graph set up at poor poses and optimised since -- and this call's first solve needs visibly more iterations than the
