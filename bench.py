@@ -266,10 +266,13 @@ def incremental_session(device: int, V: int, E: int, seed: int, steps: int = 12,
     return {"workload": f"append_session(V={V}, E={E}, seed={seed}): {steps} closures, each {chain} new poses + odometry + 1 closure, "
                         f"optimize({iters}) after each",
             "update_ms_median": med(t_up), "update_ms_min_max": [float(min(t_up)), float(max(t_up))],
-            "optimize_ms_median": med(t_opt), "setup_plus_optimize_ms": med(np.add(t_up, t_opt)),
+            # (median + median, not the median of the sums: single updates carry the 15-30 ms a stream takes to come back after the
+            # loop's host-side idle -- DESIGN.md section 5b, update_ms_min_max shows them --, and with five or seven of twelve
+            # affected the median of the sums jumps by 10 ms between two runs of the same code)
+            "optimize_ms_median": med(t_opt), "setup_plus_optimize_ms": med(t_up) + med(t_opt),
             "pcg_iters_per_gn_iter": its,
             "fresh_set_graph_ms_median": med(t_set), "fresh_optimize_ms_median": med(t_fopt),
-            "fresh_setup_plus_optimize_ms": med(np.add(t_set, t_fopt)), "fresh_pcg_iters_per_gn_iter": fits,
+            "fresh_setup_plus_optimize_ms": med(t_set) + med(t_fopt), "fresh_pcg_iters_per_gn_iter": fits,
             "max_rel_chi2_diff_vs_fresh_setup": worst, "bound": 1e-6, "updates": descs}
 
 
