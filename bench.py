@@ -224,6 +224,17 @@ def incremental_session(device: int, V: int, E: int, seed: int, steps: int = 12,
     base, app, g = synth.append_session(V, E, steps, chain, seed)
     odom_meas = g.meas[: g.V - 1]
     arrs = [base.ei, base.ej, base.meas, base.info, base.phi]
+    # The grown graph's arrays are allocated ONCE at their final size and filled in place, as a C++ caller's containers grow: up to
+    # round 5 this loop made them anew per closure (np.concatenate: ~100 MB mapped and unmapped), and the driver's work behind the
+    # munmap of a process with device queues landed on the next submission -- single updates of 15-35 ms, half of them in some runs
+    # (scripts/update_outlier_probe.py).
+    names = ("ei", "ej", "meas", "info", "phi")
+    e_max = base.E + sum(len(a["ei"]) for a in app)
+    bufs = [np.empty((e_max,) + x.shape[1:], dtype=x.dtype) for x in arrs]
+    for b_, x in zip(bufs, arrs):
+        b_[: base.E] = x
+    pbuf, fbuf, ne = np.empty((app[-1]["V"], 3)), np.zeros(app[-1]["V"], dtype=bool), base.E
+    fbuf[0] = True
     t_up, t_opt, t_set, t_fopt, its, fits, worst, descs = [], [], [], [], [], [], 0.0, []
     with capi.Optimizer(device) as inc, capi.Optimizer(device) as fresh:
         inc.set_graph(*base.arrays())
@@ -231,12 +242,14 @@ def incremental_session(device: int, V: int, E: int, seed: int, steps: int = 12,
         P = inc.get_poses()
         E_res = base.E
         for k, a in enumerate(app):
-            arrs = [np.concatenate([x, a[n]]) for x, n in zip(arrs, ("ei", "ej", "meas", "info", "phi"))]
-            P0 = np.empty((a["V"], 3))
+            k_new = len(a["ei"])
+            for b_, n in zip(bufs, names):
+                b_[ne: ne + k_new] = a[n]
+            ne += k_new
+            arrs = [b_[:ne] for b_ in bufs]
+            P0, fixed = pbuf[: a["V"]], fbuf[: a["V"]]
             P0[: P.shape[0]] = P
             synth.chain_init(P0, odom_meas, P.shape[0], a["V"] - 1)
-            fixed = np.zeros(a["V"], dtype=bool)
-            fixed[0] = True
             t = time.perf_counter()
             inc.update_graph(P0, fixed, *arrs, E_res)
             t1 = time.perf_counter()
