@@ -1251,10 +1251,10 @@ int optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
     HIP_TRY(c, hipMemcpyAsync(c->h_hist, c->d_hist, sizeof(double) * 2 * (size_t)(done + 1), hipMemcpyDeviceToHost,
                               c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (c->amg_prev && trial == 0) {   // a trial that was accepted: the replaced hierarchy and its arena go (once per graph, a few ms)
-      amg_destroy(c->amg_prev);
+    if (c->amg_prev && trial == 0) {   // a trial that was accepted: the replaced hierarchy goes; its arena keeps its chunks for the next
+      amg_destroy(c->amg_prev);      // trial (released and re-grown every time, the chunk size doubled until each trial took a gigabyte)
       c->amg_prev = nullptr;
-      c->amg_arena_prev.release();
+      c->amg_arena_prev.rewind();
     }
     prof_flush(c);
     if (out) {

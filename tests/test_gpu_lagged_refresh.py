@@ -175,3 +175,29 @@ def test_re_optimising_from_the_same_start_does_not_redo_the_set_up():
     assert desc1 == desc0                                   # (the same hierarchy: nothing was rebuilt)
     assert s1["pcg_iters"][:20] == s0["pcg_iters"][:20]
     assert np.max(np.abs(np.array(s1["chi2"][:21]) / np.array(s0["chi2"][:21]) - 1.0)) <= 1e-9
+
+
+def test_set_ups_trials_and_reverts_do_not_grow_device_memory(monkeypatch):
+    """Two graphs alternate on one context, three optimize(20) calls each time -- one of them runs the re-aggregation trial and reverts
+    it (second arena), the other accepts its trial (the replaced hierarchy is dropped at the end of the call, its arena keeps its chunks for
+    the next trial).  Free device memory after the second round of both is what it is after four more."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+
+    def free():
+        f, t = ctypes.c_size_t(0), ctypes.c_size_t(0)
+        assert hip.hipMemGetInfo(ctypes.byref(f), ctypes.byref(t)) == 0
+        return f.value
+
+    monkeypatch.setenv("SGO_MFRONT", "0")
+    graphs = [synth.config("C2"), synth.manhattan(40000, 60000, seed=1795)]
+    with capi.Optimizer(0, direct_rows=0) as opt:
+        marks = []
+        for rnd in range(6):
+            for g in graphs:
+                opt.set_graph(*g.arrays())
+                for _ in range(3):
+                    done, _ = opt.optimize(20)
+                    assert done == 20
+            marks.append(free())
+    assert marks[-1] >= marks[1] - (64 << 20), [m >> 20 for m in marks]   # (both arenas have grown to their graphs by the end of round 1 and stay)
