@@ -14,7 +14,10 @@ smoother uses the current Hessian and whose coarse operators are
   tentative  P from iteration k-1, A_1 += T^T (H_k - H_{k-1}) T with the TENTATIVE prolongator T: one product per level-0 block
   chained    the same carried forward from the last full refresh (every FULL-th iteration), transfers frozen there
 
-  python scripts/proto/incremental_galerkin.py V E [iters] [FULL]
+  delta chained  transfers frozen at iteration 0; an edge re-enters the coarse operators at the current poses when its weight or an
+             end angle has moved by more than CT since it was last included -- the delta refresh as it would run on the device
+
+  python scripts/proto/incremental_galerkin.py V E [iters] [FULL] [CT]
 """
 import os
 import sys
@@ -112,6 +115,8 @@ agg_levels = build(H0.tocsr(), poses[free, :2])
 prev_levels, prev_poses, prev_w, prev_H = None, None, None, None
 FULL = int(sys.argv[4]) if len(sys.argv) > 4 else 100
 chain_levels = chain_A1 = chain_pos = None
+CT = float(sys.argv[5]) if len(sys.argv) > 5 else 0.1
+hist_poses = []
 print(f"V={V} E={E}; levels {[L['n'] for L in agg_levels]}")
 for k in range(iters):
     H, b, c2, rc2 = np_oracle.linearize(poses, fixed, ei, ej, meas, info, phi)
@@ -141,6 +146,23 @@ for k in range(iters):
             chain_A1 = (chain_A1 + Tc.T @ (H - prev_H) @ Tc).tocsr()
             it_c, _ = pcg(H, with_A1(chain_levels, H, chain_A1), b)
             line += f"   chained {it_c:3d}"
+        # the delta refresh as it would run: transfers frozen at iteration 0, H_mix carried forward -- an edge is re-included at the
+        # current poses when its DCS weight has moved by more than CT (relative) or an end pose has turned by more than CT since the
+        # edge was last included
+        if k >= 1:
+            w_inc = np.array([hist_w[last_inc[e]][e] for e in range(len(ei))]) if False else inc_w
+            dth_inc = np.maximum(np.abs(np_oracle.normalize_theta(poses[ei, 2] - inc_th_i)), np.abs(np_oracle.normalize_theta(poses[ej, 2] - inc_th_j)))
+            F = (np.abs(w - inc_w) > CT * np.maximum(w, inc_w)) | (dth_inc > CT)
+            for j in np.unique(last_inc[F]):
+                sel = F & (last_inc == j)
+                Hj, _, _, _ = np_oracle.linearize(hist_poses[j], fixed, ei[sel], ej[sel], meas[sel], info[sel], phi[sel])
+                H_mix = H_mix - Hj
+            if F.any():
+                Hn, _, _, _ = np_oracle.linearize(poses, fixed, ei[F], ej[F], meas[F], info[F], phi[F])
+                H_mix = (H_mix + Hn).tocsr()
+            last_inc[F] = k; inc_w[F] = w[F]; inc_th_i[F] = poses[ei[F], 2]; inc_th_j[F] = poses[ej[F], 2]
+            it_d, _ = pcg(H, with_P(agg_levels_fresh0, H, H_mix), b)
+            line += f"   delta chained ({CT}) {it_d:3d} ({int(F.sum())} edges)"
         dth = np.abs(np_oracle.normalize_theta(poses[:, 2] - prev_poses[:, 2]))
         for tau in (0.2, 0.05, 0.01):
             ch = (np.abs(w - prev_w) > tau * np.maximum(w, prev_w)) | (dth[ei] > tau) | (dth[ej] > tau)
@@ -149,6 +171,10 @@ for k in range(iters):
             it_m, _ = pcg(H, with_P(prev_levels, H, (Hc + Hu).tocsr()), b)
             line += f"   mixed {tau}: {it_m:3d} ({int(ch.sum())} edges)"
     print(line, flush=True)
+    hist_poses.append(poses.copy())
+    if k == 0:
+        agg_levels_fresh0, H_mix = fresh, H.copy()
+        last_inc = np.zeros(len(ei), dtype=int); inc_w = w.copy(); inc_th_i = poses[ei, 2].copy(); inc_th_j = poses[ej, 2].copy()
     if prev_levels is None or k % FULL == 0:
         chain_levels, chain_A1, chain_pos = fresh, fresh[1]["A"], poses[free, :2].copy()
     prev_levels, prev_poses, prev_w, prev_H = fresh, poses.copy(), w, H
