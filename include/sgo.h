@@ -102,7 +102,8 @@ typedef struct sgo_opts {
 } sgo_opts;
 
 /* Environment variables (the call sites are frozen, so knobs come from the environment).  Read when a
- * context is created or a graph is set, or at the start of sgo_optimize_gn -- never inside a solve.
+ * context is created or a graph is set, or at the start of sgo_optimize_gn / sgo_solve (sgo_ctx::CallKnobs, read_call_knobs) -- never
+ * inside a solve.
  *   mirrors of sgo_opts fields (the environment wins): SGO_SOLVER={pcg,amg}, SGO_PCG_TOL, SGO_PCG_TOL_CAP, SGO_PCG_MAXIT,
  *     SGO_PCG_CHUNK, SGO_PCG_WARM, SGO_USE_GRAPH, SGO_PROFILE, SGO_VERBOSE, SGO_DIRECT_ROWS, SGO_DEVICE
  *   path selection: SGO_MFRONT=0 (no multifrontal path), SGO_MFRONT_ROWS / _CRIT_MFLOP / _DEGREE / _LEAF (its admission limits
@@ -117,7 +118,7 @@ typedef struct sgo_opts {
  *     movement a solve may keep its coarse operators over, 0.006)
  *   multi-GPU: SGO_COMM_MODE={owner,allreduce}, SGO_COMM_GRAPH (see sgo_comm_init), SGO_OWNER_MIN_ROWS, SGO_RCCL_LIB (library path)
  *   test hooks and A/B switches of scripts/ (not for production): SGO_AMG_LISTS=host, SGO_SETUP_PIPELINE, SGO_TILE_LDS,
- *     SGO_FIRST_SOLVE_CAP, SGO_PCG_STALL_WINDOW, SGO_MIRROR, SGO_LANCZOS (sgo_debug_lanczos), SGO_MFRONT_DEBUG, SGO_AMG_LAG_FORCE / SGO_AMG_LAG_SLOPE
+ *     SGO_FIRST_SOLVE_CAP, SGO_PCG_STALL_WINDOW, SGO_TEST_FAIL_TRIAL_BUILD, SGO_MIRROR, SGO_LANCZOS (sgo_debug_lanczos), SGO_MFRONT_DEBUG, SGO_AMG_LAG_FORCE / SGO_AMG_LAG_SLOPE
  *     (scripts/lag_calib.py, tests/test_gpu_lagged_refresh.py)
  * Removed in round 5 (measured, not kept: NOTES.md sections 9-10): SGO_DEFLATE, SGO_OWNER_XS_EXCHANGE, SGO_MFRONT_FUSED_SOLVE.
  * Of the interface SURVEY.md section 8(b) sketched, three items do not exist, on purpose: SGO_NGPU (one process per GPU: the
@@ -316,7 +317,11 @@ void sgo_shard_range(int32_t count, int32_t nranks, int32_t rank, int32_t* begin
  * (rank_row_begin[nranks + 1]).  Output pointers may be NULL.  Lets multi-process callers and the CPU tests
  * see which rows of a level-0 product each rank contributes.  meas (as sgo_set_graph_se2's; may be NULL): with it the plan is
  * also the one sgo_set_graph_se2 makes for a graph whose initial poses contradict its closures -- a dead-reckoned start --,
- * whose rows are ordered by spanning-tree positions instead of the poses (0.1.6). */
+ * whose rows are ordered by spanning-tree positions instead of the poses (0.1.6).  Exception: a graph sgo_set_graph_se2 puts
+ * on a factorisation path (single-launch direct, multifrontal: <= 12 288 free poses) has no level-0 row plan at set-up; the first
+ * single-step entry point (sgo_linearize, ...) makes one from the poses CURRENT at that moment in plain Hilbert order, which this
+ * function reproduces when given those poses and meas = NULL.  (The trailing `meas` argument was ADDED in 0.1.6: a caller built
+ * against an older header must be rebuilt -- SGO_VERSION / sgo_version() is the check.) */
 int sgo_plan_rows(int32_t V, const double* poses, const uint8_t* fixed, int32_t E, const int32_t* ei, const int32_t* ej,
                   int32_t nranks, int32_t* n_free, int32_t* row_vertex, int32_t* ntiles, int32_t* tile_row_begin,
                   int32_t tile_cap, int32_t* rank_row_begin, const double* meas);

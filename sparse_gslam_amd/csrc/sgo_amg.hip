@@ -292,7 +292,10 @@ __global__ __launch_bounds__(kBlock) void k_filtered_diag(BsrDev F, const int* _
       double d[9];
       load_block(F, (size_t)F.rowptr[key], d);   // the diagonal slot comes first in its row
       // (a row without any kept connection keeps its whole diagonal block: with everything lumped D_F would be the row sum of
-      // the rigid motions -- zero up to rounding in the interior -- and its "inverse" noise; nothing smooths such a row anyway)
+      // the rigid motions -- zero up to rounding in the interior -- and its "inverse" noise.  Its inverse is written as ZERO, like
+      // an unsafe row's below: k_p_values still lists the row's diagonal slot, and with D_F = D that term alone would make
+      // P_i = (1 - omega_p) T_i -- a row that no longer reproduces the rigid motions (both neighbours heavy hubs, or every
+      // closure switched off by DCS: exactly the start the filter exists for).  With a zero inverse the row stays T_i.)
       const double keep = acc[9] > 0.0 ? 1.0 : 0.0;
       // How much of the row's stiffness the dropped connections carried: L = -acc is the sum of their (positive semi-definite)
       // shares of the diagonal block, and trace(D^-1 L) bounds the largest eigenvalue of D^-1 L.  "Negligible" is judged by
@@ -312,7 +315,7 @@ __global__ __launch_bounds__(kBlock) void k_filtered_diag(BsrDev F, const int* _
       const double c10 = d[2] * d[7] - d[1] * d[8], c11 = d[0] * d[8] - d[2] * d[6], c12 = d[1] * d[6] - d[0] * d[7];
       const double c20 = d[1] * d[5] - d[2] * d[4], c21 = d[2] * d[3] - d[0] * d[5], c22 = d[0] * d[4] - d[1] * d[3];
       const double det = d[0] * c00 + d[1] * c01 + d[2] * c02;
-      const double id = (det != 0.0 && isfinite(det) && !(unsafe && keep != 0.0)) ? 1.0 / det : 0.0;
+      const double id = (det != 0.0 && isfinite(det) && keep != 0.0 && !unsafe) ? 1.0 / det : 0.0;
       double* o = dF + 9 * (size_t)key;
 #pragma unroll
       for (int c = 0; c < 9; ++c) o[c] = d[c];

@@ -611,6 +611,7 @@ int sgo_solve(sgo_ctx* c, double* x, double* relres) {
       c->err = "sgo_solve: call sgo_linearize first";
       return SGO_EINVAL;
     }
+    read_call_knobs(c);
     // restart from the state of the last linearisation (idempotent re-finalize)
     int grid = 0;
     launch_finalize(c->stream, c->S0, c->owner ? c->halo.row0 : 0, c->owner ? c->halo.row1 : c->n, c->d_dgb, c->d_b, c->d_x, c->d_r,

@@ -128,6 +128,15 @@ struct sgo_ctx {
   Amg* amg_prev = nullptr;
   std::string amg_prev_desc;
   bool agg_rule_off = false;      // a trial was lost on this graph: the rule does not fire again before the next set-up
+  // The environment knobs a solve depends on, read ONCE per entry-point call (read_call_knobs: sgo_optimize_gn, sgo_solve) and
+  // never inside a solve (include/sgo.h's table says so).
+  struct CallKnobs {
+    int comm_graph = -1;          // SGO_COMM_GRAPH: -1 unset (the default rule decides), 0 / 1
+    int stall_window = -1;        // SGO_PCG_STALL_WINDOW: -1 unset
+    int first_solve_cap = 600;    // SGO_FIRST_SOLVE_CAP (test hook)
+    bool fail_trial_build = false;   // SGO_TEST_FAIL_TRIAL_BUILD (test hook: the re-aggregation trial's set-up "fails")
+  } knobs;
+  bool test_fail_trial_build = false;
   double* d_poses = nullptr;
   int* d_free_id = nullptr;
   EdgeListDev el;
@@ -378,6 +387,7 @@ int start_pcg(sgo_ctx* c, int grid);
 int do_linearize(sgo_ctx* c);
 int do_spmv(sgo_ctx* c, const double* x, double* y, bool dot, const PcgScalars* S, int* grid_out);
 int run_pcg(sgo_ctx* c);
+void read_call_knobs(sgo_ctx* c);   // the environment knobs of a solve, once per entry-point call
 int build_amg(sgo_ctx* c, bool keep_old = false);
 int revert_amg(sgo_ctx* c);
 std::string multi_gpu_description(const sgo_ctx* c);

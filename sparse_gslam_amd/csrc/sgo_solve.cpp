@@ -108,7 +108,9 @@ static HaloScalars scal(const double* p0, int n0, const double* p1 = nullptr, in
   return sc;
 }
 
+static void set_probe(sgo_ctx* c, int k, double max);
 static int start_pcg_owner(sgo_ctx* c, int grid) {
+  set_probe(c, 0, 0.0);   // (the progress probe belongs to the single-GPU lagged refresh: never armed here)
   const HaloDev& H = c->halo;
   const int G = H.G, nr = H.row1 - H.row0;
   const size_t o3 = 3 * (size_t)H.row0;
@@ -241,6 +243,7 @@ int start_pcg(sgo_ctx* c, int grid) {
   } else {
     Scope sc(c, K_INIT_SCALARS, 16.0 * grid);
     launch_init_scalars(c->stream, c->d_S, c->d_partials, grid, c->d_partials + kMaxPartials, grid, tol, maxit, c->bb_ref, c->tol_cap);
+    set_probe(c, 0, 0.0);   // (a probe left armed by an earlier solve behind a hierarchy this graph has since lost would raise stop = 4 here)
   }
   return SGO_OK;
 }
@@ -505,6 +508,16 @@ int ensure_pcg_graph(sgo_ctx* c, int chunk, bool* captured) {
 // in flight while the host waits for the stop flag copied out after the previous one (kernels of
 // iterations past convergence exit on the flag), so the GPU never idles on a host round trip and at
 // most two replays of early-exit launches are wasted.
+void read_call_knobs(sgo_ctx* c) {
+  sgo_ctx::CallKnobs k;
+  if (const char* e = std::getenv("SGO_COMM_GRAPH")) k.comm_graph = std::atoi(e) != 0 ? 1 : 0;
+  if (const char* e = std::getenv("SGO_PCG_STALL_WINDOW")) k.stall_window = std::max(0, std::atoi(e));
+  if (const char* e = std::getenv("SGO_FIRST_SOLVE_CAP")) k.first_solve_cap = std::max(1, std::atoi(e));
+  if (const char* e = std::getenv("SGO_TEST_FAIL_TRIAL_BUILD")) k.fail_trial_build = std::atoi(e) != 0;
+  c->knobs = k;
+  c->test_fail_trial_build = k.fail_trial_build;
+}
+
 int run_pcg(sgo_ctx* c) {
   // Multi-GPU with an RCCL communicator: the collectives are captured into the hipGraph with the kernels around them (every
   // rank replays the same graph the same number of times: the replay count follows snapshots of the device-resident stop flag
@@ -517,14 +530,14 @@ int run_pcg(sgo_ctx* c) {
   // the ranks' failure flags right after the attempt): ranks that replay graphs and ranks that launch plainly would issue
   // different numbers of collectives per solve and hang each other, so either all ranks replay or all fall back.
   bool comm_graph = c->comm.handle != nullptr && !c->comm.host_fn && !c->comm_graph_failed && c->comm.nranks <= 1;
-  if (const char* e = std::getenv("SGO_COMM_GRAPH"))
-    comm_graph = c->comm.handle != nullptr && !c->comm.host_fn && !c->comm_graph_failed && std::atoi(e) != 0;
+  if (c->knobs.comm_graph >= 0)
+    comm_graph = c->comm.handle != nullptr && !c->comm.host_fn && !c->comm_graph_failed && c->knobs.comm_graph != 0;
   // Stagnation guard (single GPU: the decision reads a clock-free but rank-local snapshot): a solve whose r.r has not reached a new
   // minimum for max(3000, 30 x the previous solve's count) iterations is ended as one that ran out of iterations -- the systems
   // PCG cannot finish in double precision otherwise grind on to pcg_maxit, three times per call.
   c->pcg_stalled = false;
   c->pcg_stall_window = multi_rank(c) ? 0 : std::max(3000, 30 * std::max(1, c->pcg_pred));
-  if (const char* e = std::getenv("SGO_PCG_STALL_WINDOW")) c->pcg_stall_window = multi_rank(c) ? 0 : std::atoi(e);   // (test hook; 0: no guard)
+  if (c->knobs.stall_window >= 0) c->pcg_stall_window = multi_rank(c) ? 0 : c->knobs.stall_window;   // (test hook; 0: no guard)
   double stall_rr = -1.0;
   int stall_it = 0;
   auto stalled = [&](const volatile PcgScalars* S) -> bool {
@@ -679,6 +692,10 @@ int build_amg(sgo_ctx* c, bool keep_old) {
     c->amg = nullptr;
   }
   c->amg_arena.rewind();
+  if (keep_old && c->amg_prev && c->test_fail_trial_build) {   // test hook (SGO_TEST_FAIL_TRIAL_BUILD, read once per sgo_optimize_gn): the trial's set-up "fails"
+    c->solver_desc = "pcg_block_jacobi (AMG unavailable: test hook)";
+    return SGO_OK;
+  }
   AmgConfig cfg;
   cfg.theta_scale = c->amg_theta_scale;
   cfg.filtered_smoothing = !c->amg_no_filter;
@@ -880,6 +897,7 @@ int optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
     }
     if (c->n == 0) return SGO_ENOTHING;
     const double t0 = wall_s();
+    read_call_knobs(c);
     if (c->direct || c->mf) {
       // ---- small-graph path: the whole call is one launch (sgo_direct.h); mid-size path: one launch per level of the
       // elimination tree and Gauss-Newton iteration, no host round trip inside the call (sgo_mfront.h)
@@ -1003,7 +1021,7 @@ int optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
       // dead-reckoned start): one that needs more has a coarse space that does not carry the slow modes, and the set-up is
       // redone with HALF the strength thresholds (larger aggregates, sparser coarse operators) instead of grinding on to
       // pcg_maxit.  (SGO_FIRST_SOLVE_CAP: test hook.)
-      const int first_solve_cap = std::getenv("SGO_FIRST_SOLVE_CAP") ? std::max(1, std::atoi(std::getenv("SGO_FIRST_SOLVE_CAP"))) : 600;
+      const int first_solve_cap = c->knobs.first_solve_cap;
       if (c->amg && c->amg_best == 0 && rebuilds < max_rebuilds && c->amg_theta_scale > 0.2) c->pcg_softcap = first_solve_cap;
       c->amg_lag_cap = fresh_pcg > 0 ? fresh_pcg + 3 : 0;
       c->amg_force_keep = force_from >= 0 && it > force_from;
@@ -1018,12 +1036,32 @@ int optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
         // re-weighting has changed the strength of connection since (see the rule below): redo the
         // set-up from the current values (same cost as in sgo_set_graph_se2).
         if (rebuilds + 1 >= max_rebuilds) c->amg_no_filter = true;   // (the call's last rebuild: see the abandoned solve below)
-        if ((rc = build_amg(c, trial == 1)) || (rc = do_linearize(c))) return rc;
+        const bool was_trial = trial == 1;
+        rc = build_amg(c, was_trial);
+        if (was_trial && c->amg_prev && (rc != SGO_OK || !c->amg) && rc != SGO_ECOMM) {
+          // A TRIAL whose set-up did not come about (out of device memory -- a trial holds two hierarchies --, or the graph at its
+          // current values cannot be coarsened): the hierarchy that was parked for the comparison is intact and comes back; the
+          // re-aggregation rule is off for this graph, and the call carries on as if it had never tried.  (Without this the solve
+          // ran behind block-Jacobi under the old hierarchy's bail-out cap and failed, with the working hierarchy unused in
+          // amg_prev for every later call: ADVICE round 5.)
+          const std::string why = c->err;
+          if ((rc = revert_amg(c))) return rc;
+          trial = 0;
+          c->agg_rule_off = true;
+          rebuild_next = false;
+          c->err.clear();
+          agg_note = "a re-aggregation was attempted in the last sgo_optimize_gn and its set-up failed" + (why.empty() ? std::string() : " (" + why + ")") +
+                     ": the previous hierarchy stays";
+          if (c->opts.verbose) std::fprintf(stderr, "[sgo] iteration %d: the trial set-up failed; the previous hierarchy is back\n", it);
+          if ((rc = do_linearize(c))) return rc;
+        } else {
+        if (rc || (rc = do_linearize(c))) return rc;
         if (trial == 1) trial = 2;
         rebuild_next = false;
         ++rebuilds;
         call_best = 0;   // (another hierarchy: its first solve sets the reference)
         if (c->opts.verbose) std::fprintf(stderr, "[sgo] multigrid hierarchy rebuilt before iteration %d\n", it);
+        }
       }
       hipEventRecord(ev[3 * it + 1], c->stream);
       int wasted = 0;

@@ -162,7 +162,7 @@ def trajectory_graph(truth: np.ndarray, E: int, seed: int, *, info_mode: str = "
                      init: str = "incremental", tail: int = 200, sigma_xy: float = SIGMA_XY,
                      sigma_th: float = SIGMA_TH, closure_radius: float = 1.0, min_sep: int = 40) -> Graph:
     """The same construction on a GIVEN trajectory (e.g. the intel-lab keyframe trajectory the
-    reference ships as a result file, tests/golden/ref_trajectories.npz): odometry chain plus
+    reference ships as a result file; fixture: reference_trajectory below): odometry chain plus
     ``E - (V-1)`` closures between poses that revisit the same place (within ``closure_radius``
     metres, at least ``min_sep`` keyframes apart), DCS delta ``phi`` on the closures
     (datasets/intel-lab/slam-11.yaml:38 uses 10)."""
@@ -321,14 +321,19 @@ def _euler(a, b, c):
     return Q
 
 
-def reference_trajectory(name: str) -> np.ndarray:
+TRAJECTORY_FILE = None   # set by the caller (tests/conftest.py, bench.py): the package itself ships no data and reads nothing of tests/
+
+
+def reference_trajectory(name: str, path: str | None = None) -> np.ndarray:
     """Keyframe trajectory (V,3) of one of the reference's shipped result files
-    (src/sparse_gslam/datasets/<name>/*30pts.txt, CARMEN FLASER lines sorted by time stamp),
-    from the committed fixture tests/golden/ref_trajectories.npz (scripts/make_traj_fixture.py)."""
+    (src/sparse_gslam/datasets/<name>/*30pts.txt, CARMEN FLASER lines sorted by time stamp), from a fixture made by
+    scripts/make_traj_fixture.py.  The file is the CALLER's: `path`, else synth.TRAJECTORY_FILE, else $SGO_REF_TRAJECTORIES."""
     import os
 
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden",
-                        "ref_trajectories.npz")
+    path = path or TRAJECTORY_FILE or os.environ.get("SGO_REF_TRAJECTORIES")
+    if not path:
+        raise FileNotFoundError("reference_trajectory: no trajectory fixture given (argument `path`, synth.TRAJECTORY_FILE or "
+                                "$SGO_REF_TRAJECTORIES; the repository keeps one at tests/golden/ref_trajectories.npz)")
     with np.load(path) as z:
         return z[name].copy()
 

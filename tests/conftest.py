@@ -10,6 +10,9 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the reference's shipped keyframe trajectories (C1i / C1a): a fixture of the TEST tree, handed to the generator by its caller
+    from sparse_gslam_amd import synth
+    synth.TRAJECTORY_FILE = os.path.join(ROOT, "tests", "golden", "ref_trajectories.npz")
 
 
 @pytest.fixture(scope="session")

@@ -41,6 +41,10 @@ def test_no_oracle_in_product():
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "import oracle" not in text and "from oracle" not in text, f
                 assert "sgo_oracle" not in text and "np_oracle" not in text, f
+                # ... and opens nothing of the test tree (round 5's review: synth.py read tests/golden/ref_trajectories.npz)
+                if f.endswith(".py"):
+                    assert '"tests"' not in text and "'tests'" not in text and "tests/golden/" not in text.replace(
+                        "the repository keeps one at tests/golden/ref_trajectories.npz", ""), f
 
 
 def test_header_compiles_as_plain_c(tmp_path):

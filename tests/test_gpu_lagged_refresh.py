@@ -157,6 +157,38 @@ def test_a_re_aggregated_hierarchy_that_is_no_better_is_dropped_for_the_old_one(
     assert i1[2] <= 1.15 * i0[2], (i1, i0)                   # (behind the old hierarchy again: the counts of the context that never tried)
 
 
+def test_a_trial_whose_set_up_fails_puts_the_old_hierarchy_back(monkeypatch):
+    """the re-aggregation trial parks the working hierarchy and builds a second one beside it -- when that set-up
+    does not come about (out of device memory, a graph that cannot be coarsened at its current values; here: a test hook) the
+    parked hierarchy must come back and the call carry on, instead of solving behind block-Jacobi under the old hierarchy's cap and
+    failing, with the working hierarchy unused for every later call.  Same graph and calls as the test above."""
+    monkeypatch.setenv("SGO_MFRONT", "0")
+    g = synth.manhattan(40000, 60000, seed=1795, info_mode="diag", p_random=0.0)
+    runs = {}
+    for lag in ("1", "0"):
+        monkeypatch.setenv("SGO_AMG_LAG", lag)
+        if lag == "1":
+            monkeypatch.setenv("SGO_TEST_FAIL_TRIAL_BUILD", "1")
+        else:
+            monkeypatch.delenv("SGO_TEST_FAIL_TRIAL_BUILD")
+        with capi.Optimizer(0, direct_rows=0) as opt:
+            opt.set_graph(*g.arrays())
+            chi, descs, its = [], [], []
+            for _ in range(3):
+                done, st = opt.optimize(20)
+                assert done == 20 and all(st["pcg_converged"][:20]), (done, opt.last_error())
+                chi += list(st["chi2"][:21])
+                its.append(float(np.mean(st["pcg_iters"][:20])))
+                descs.append(opt.solver_description())
+            runs[lag] = (np.array(chi), descs, its)
+    c1, d1, i1 = runs["1"]
+    c0, _, i0 = runs["0"]
+    assert "its set-up failed" in d1[1] and d1[1].startswith("pcg_amg"), d1[1]
+    assert "re-aggregat" not in d1[2] and d1[2].startswith("pcg_amg")   # (the rule is off for this graph from here on)
+    assert np.max(np.abs(c1 - c0) / c0) <= 1e-6
+    assert i1[2] <= 1.15 * i0[2], (i1, i0)
+
+
 def test_re_optimising_from_the_same_start_does_not_redo_the_set_up():
     """C4r (5 % random closures): the first solve of a call from the initial poses takes 67 PCG iterations, the last ones 22.  The count
     rules compare with the best count of the CURRENT call -- with the best carried over from the call before, 67 > 2 x 22 + 10 read
