@@ -35,6 +35,14 @@ struct AmgConfig {
                                 // (env SGO_AMG_LISTS=host: on the host, the reference the device lists are tested against)
   int coarsest_nodes = 400;  // stop coarsening at or below this many nodes; that level is inverted densely
                              // (blocked Gauss-Jordan over 3x that many unknowns) once per GN iteration
+  // A rebuild inside sgo_optimize_gn may KEEP the aggregates of the hierarchy it replaces (the partition of every level's nodes)
+  // and re-make everything that depends on the values -- the filter's mask, the patterns of P, A P and P^T A P, the lists --:
+  // level l's aggregate of node i (renumbered form) and the visiting order handed to level l + 1.  nullptr: aggregate anew.
+  const struct AmgKeptAgg* keep_agg = nullptr;
+};
+struct AmgKeptAgg {
+  std::vector<std::vector<int>> agg, visit_c;   // per coarsened level
+  std::vector<int> nc;
 };
 
 // profiling hook supplied by the context (brackets a launch with HIP events when enabled)
@@ -115,5 +123,6 @@ int amg_num_levels(const Amg* m);
 bool amg_has_filtered(const Amg* m);   // some level's transfer is smoothed with the filtered operator (SaHost::filtered)
 long long amg_level0_bytes(const Amg* m);   // device bytes of the level-0 transfer (P, A P, product lists) this rank holds
 void amg_describe(const Amg* m, std::string* out);
+void amg_kept_aggregates(const Amg* m, AmgKeptAgg* out);   // host copies of the hierarchy's aggregates (AmgConfig::keep_agg)
 
 }  // namespace sgo

@@ -1627,6 +1627,7 @@ struct Amg {
   double* gjP[2] = {nullptr, nullptr};   // [32][32] inverse of the current / next pivot block
   int* d_fail = nullptr;
   std::string desc;
+  AmgKeptAgg kept;   // host copies of every level's aggregates (a rebuild may keep them: AmgConfig::keep_agg)
 };
 
 namespace {
@@ -2054,6 +2055,9 @@ bool amg_coarsest_not_spd(Amg* m, hipStream_t s) {
   return f != 0;
 }
 void amg_describe(const Amg* m, std::string* out) { *out = m ? m->desc : ""; }
+void amg_kept_aggregates(const Amg* m, AmgKeptAgg* out) {
+  if (m && out) *out = m->kept;
+}
 
 void amg_destroy(Amg* m) {
   if (!m) return;
@@ -2335,6 +2339,12 @@ Amg* amg_create(hipStream_t s, const BsrDev& A0, const Sym0Dev& S0, const Tile0D
     }
     HostCoarse hc_own;
     HostCoarse* hcp = &hc_own;
+    if (m->cfg.keep_agg && l < (int)m->cfg.keep_agg->agg.size() && (int)m->cfg.keep_agg->agg[l].size() == n && !(l == 0 && pre0 && pre0->ready)) {
+      hc_own.agg = m->cfg.keep_agg->agg[l];
+      hc_own.visit_c = m->cfg.keep_agg->visit_c[l];
+      hc_own.nc = m->cfg.keep_agg->nc[l];
+      hc_own.reuse_agg = true;
+    }
     if (l == 0 && pre0 && pre0->ready) {
       hcp = &pre0->hc;   // made ahead on the helper thread, from the same structure and the strengths at the same poses
     } else {
@@ -2359,6 +2369,9 @@ Amg* amg_create(hipStream_t s, const BsrDev& A0, const Sym0Dev& S0, const Tile0D
     // upload transfer data of level l and the structure of level l+1
     const auto tU = std::chrono::steady_clock::now();
     L.nc = nc;
+    m->kept.agg.push_back(agg);
+    m->kept.visit_c.push_back(visit_c);
+    m->kept.nc.push_back(nc);
     L.agg = dev_upload(m->pool, agg, s);
     L.mem_ptr = dev_upload(m->pool, mem_ptr, s);
     L.mem = dev_upload(m->pool, mem, s);
@@ -2756,6 +2769,7 @@ Amg* amg_create(hipStream_t s, const BsrDev& A0, const Sym0Dev& S0, const Tile0D
   // passes per level for them: one sweep there (measured: 23.3 -> 20.9 ms per Gauss-Newton iteration at that start; C4's usual
   // hierarchy, level 1 at 6 %, keeps two: 4.06 against 4.45 ms with one).
   if (last >= 1 && !std::getenv("SGO_AMG_NU") && 4LL * m->lv[1].A.nslot > (long long)m->lv[0].A.nslot) m->cfg.nu_coarse = 1;
+  m->cfg.keep_agg = nullptr;   // (the caller's object: only read during this set-up)
   std::snprintf(line, sizeof line, "coarsest dense N=%d; theta=%.3g omega=%.2f nu=%d", m->N,
                 m->cfg.theta * m->cfg.theta_scale, m->cfg.omega, m->cfg.nu_coarse);
   m->desc += line;

@@ -610,7 +610,12 @@ void host_coarsen(const HostLevel& H, const std::vector<double>& w, const AmgCon
   };
   if (scratch) scratch->rewind();   // (the previous level's lists have been uploaded: amg_create synchronises per level)
   double theta_used = theta_l;
-  int nc = aggregate(H, w, theta_l, agg, scratch);
+  int nc;
+  if (o.reuse_agg && (int)agg.size() == n && o.nc > 0) {
+    nc = o.nc;   // (kept from the hierarchy this one replaces: already renumbered, visit_c given)
+  } else {
+  o.reuse_agg = false;
+  nc = aggregate(H, w, theta_l, agg, scratch);
   if (nc > 0.9 * n) {   // stalled: treat every connection as strong
     nc = aggregate(H, w, 0.0, agg, scratch);
     theta_used = 0.0;
@@ -620,6 +625,7 @@ void host_coarsen(const HostLevel& H, const std::vector<double>& w, const AmgCon
     return;
   }
   if (!H.visit.empty()) renumber_aggregates(agg, nc, o.visit_c);
+  }
   o.nc = nc;
   o.t_agg = ms_since(tA);
 

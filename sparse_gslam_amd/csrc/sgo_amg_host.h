@@ -70,6 +70,7 @@ struct SaHost {
 struct HostCoarse {
   std::vector<int> agg, visit_c, mem_ptr, mem;
   int nc = 0;
+  bool reuse_agg = false;   // agg / visit_c / nc are GIVEN (AmgConfig::keep_agg): host_coarsen skips the aggregation
   bool stop = false;     // the level cannot be coarsened further
   bool smooth = false;   // (sa.filtered says which smoothing)
   SaHost sa;

@@ -135,8 +135,10 @@ struct sgo_ctx {
     int stall_window = -1;        // SGO_PCG_STALL_WINDOW: -1 unset
     int first_solve_cap = 600;    // SGO_FIRST_SOLVE_CAP (test hook)
     bool fail_trial_build = false;   // SGO_TEST_FAIL_TRIAL_BUILD (test hook: the re-aggregation trial's set-up "fails")
+    bool keep_agg = false;           // SGO_AMG_KEEP_AGG: a rebuild inside the call keeps the replaced hierarchy's aggregates
   } knobs;
   bool test_fail_trial_build = false;
+  AmgKeptAgg kept_agg;            // (what such a rebuild keeps: host copies, taken from the hierarchy before it is destroyed)
   double* d_poses = nullptr;
   int* d_free_id = nullptr;
   EdgeListDev el;
@@ -388,7 +390,7 @@ int do_linearize(sgo_ctx* c);
 int do_spmv(sgo_ctx* c, const double* x, double* y, bool dot, const PcgScalars* S, int* grid_out);
 int run_pcg(sgo_ctx* c);
 void read_call_knobs(sgo_ctx* c);   // the environment knobs of a solve, once per entry-point call
-int build_amg(sgo_ctx* c, bool keep_old = false);
+int build_amg(sgo_ctx* c, bool keep_old = false, bool keep_agg = false);
 int revert_amg(sgo_ctx* c);
 std::string multi_gpu_description(const sgo_ctx* c);
 int build_rows(sgo_ctx* c, const double* poses, const uint8_t* fixed, const int32_t* ei, const int32_t* ej);

@@ -12,6 +12,7 @@
 #include <cstring>
 
 #include "sgo_ctx.h"
+#include "sgo_rules.h"
 
 namespace sgo {
 
@@ -250,7 +251,7 @@ int start_pcg(sgo_ctx* c, int grid) {
 
 // The movement of the level-0 diagonal blocks up to which a solve keeps its coarse operators: what costs this graph's solves four
 // PCG iterations by the slope learned from its kept solves (sgo_ctx.h), at most amg_lag_tau.
-static double lag_allowed(const sgo_ctx* c) { return std::min(c->amg_lag_tau, 4.0 / std::max(c->amg_lag_slope, 1.0)); }
+static double lag_allowed(const sgo_ctx* c) { return rules::lag_allowed(c->amg_lag_tau, c->amg_lag_slope); }
 
 // A solve behind KEPT coarse operators was stopped (its progress probe, or its iteration cap): the operators are refreshed and the
 // solve carries on from its current x and r -- z = M^-1 r with the new cycle, p = z, the recurrence restarts (what the kept
@@ -514,6 +515,7 @@ void read_call_knobs(sgo_ctx* c) {
   if (const char* e = std::getenv("SGO_PCG_STALL_WINDOW")) k.stall_window = std::max(0, std::atoi(e));
   if (const char* e = std::getenv("SGO_FIRST_SOLVE_CAP")) k.first_solve_cap = std::max(1, std::atoi(e));
   if (const char* e = std::getenv("SGO_TEST_FAIL_TRIAL_BUILD")) k.fail_trial_build = std::atoi(e) != 0;
+  if (const char* e = std::getenv("SGO_AMG_KEEP_AGG")) k.keep_agg = std::atoi(e) != 0;
   c->knobs = k;
   c->test_fail_trial_build = k.fail_trial_build;
 }
@@ -664,7 +666,7 @@ std::string multi_gpu_description(const sgo_ctx* c) {
   return "";
 }
 
-int build_amg(sgo_ctx* c, bool keep_old) {
+int build_amg(sgo_ctx* c, bool keep_old, bool keep_agg) {
   // speculative replays of the captured PCG iteration (and the launches queued behind them) may still be
   // in flight: drain the stream before the exec and the old hierarchy's buffers go away
   HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -687,6 +689,8 @@ int build_amg(sgo_ctx* c, bool keep_old) {
     std::swap(c->amg_arena.chunks, c->amg_arena_prev.chunks);
     std::swap(c->amg_arena.next_chunk, c->amg_arena_prev.next_chunk);
   }
+  const bool reuse_agg = keep_agg && !keep_old && c->amg && !c->owner;
+  if (reuse_agg) amg_kept_aggregates(c->amg, &c->kept_agg);
   if (c->amg) {
     amg_destroy(c->amg);
     c->amg = nullptr;
@@ -699,6 +703,7 @@ int build_amg(sgo_ctx* c, bool keep_old) {
   AmgConfig cfg;
   cfg.theta_scale = c->amg_theta_scale;
   cfg.filtered_smoothing = !c->amg_no_filter;
+  cfg.keep_agg = reuse_agg ? &c->kept_agg : nullptr;
   AmgProf prof;
   prof.user = c;
   prof.begin = [](void* u, int kid, double bytes) {
@@ -981,7 +986,7 @@ int optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
     c->amg_lag_tau = std::getenv("SGO_AMG_LAG_TAU") ? std::atof(std::getenv("SGO_AMG_LAG_TAU")) : 0.006;
     c->amg_lag_rows = 32.0;
     if (c->amg_lag_n == 0 || std::abs(c->n - c->amg_lag_n) > c->amg_lag_n / 10) {   // another graph: its sensitivity is not known yet
-      c->amg_lag_slope = 2700.0;
+      c->amg_lag_slope = rules::kLagSlopeStart;
       c->amg_lag_slope_seen = false;
     }
     c->amg_lag_n = c->n;
@@ -1012,18 +1017,18 @@ int optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
     // (a cap on the set-ups redone inside one call, against thrashing: three for a short call, one per three Gauss-Newton
     // iterations for a long one.  Round 5: with three flat, a call whose weights keep changing -- DCS from a dead-reckoned
     // start -- used them up by iteration 6 and then had no safety net left: its 10th solve ground on to pcg_maxit.)
-    const int max_rebuilds = std::max(3, (iters + 2) / 3);
+    const int max_rebuilds = rules::max_rebuilds(iters);
     double its_sum = 0.0;
     for (int it = 0; it < iters; ++it) {
       hipEventRecord(ev[3 * it], c->stream);
-      c->pcg_softcap = (c->amg && c->amg_best > 0 && rebuilds < max_rebuilds && !rebuild_next) ? 4 * c->amg_best + 40 : 0;
+      c->pcg_softcap = (c->amg && c->amg_best > 0 && rebuilds < max_rebuilds && !rebuild_next) ? rules::bail_out_cap(c->amg_best) : 0;
       // A hierarchy that has never solved anything gets 600 iterations (the hardest first solves seen take 200-350: C4 from a
       // dead-reckoned start): one that needs more has a coarse space that does not carry the slow modes, and the set-up is
       // redone with HALF the strength thresholds (larger aggregates, sparser coarse operators) instead of grinding on to
       // pcg_maxit.  (SGO_FIRST_SOLVE_CAP: test hook.)
       const int first_solve_cap = c->knobs.first_solve_cap;
       if (c->amg && c->amg_best == 0 && rebuilds < max_rebuilds && c->amg_theta_scale > 0.2) c->pcg_softcap = first_solve_cap;
-      c->amg_lag_cap = fresh_pcg > 0 ? fresh_pcg + 3 : 0;
+      c->amg_lag_cap = rules::lag_cap(fresh_pcg);
       c->amg_force_keep = force_from >= 0 && it > force_from;
       if (trial == 2) c->amg_ref_valid = false;   // (the trial's solves are fresh ones)
       if (rebuild_next) c->amg_ref_valid = false;
@@ -1037,7 +1042,7 @@ int optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
         // set-up from the current values (same cost as in sgo_set_graph_se2).
         if (rebuilds + 1 >= max_rebuilds) c->amg_no_filter = true;   // (the call's last rebuild: see the abandoned solve below)
         const bool was_trial = trial == 1;
-        rc = build_amg(c, was_trial);
+        rc = build_amg(c, was_trial, c->knobs.keep_agg);
         if (was_trial && c->amg_prev && (rc != SGO_OK || !c->amg) && rc != SGO_ECOMM) {
           // A TRIAL whose set-up did not come about (out of device memory -- a trial holds two hierarchies --, or the graph at its
           // current values cannot be coarsened): the hierarchy that was parked for the comparison is intact and comes back; the
@@ -1074,7 +1079,7 @@ int optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
         // last fresh count its residual was more than half a decade behind that solve's -- or that reached its cap, the
         // fresh count + 3: the operators are refreshed and the solve carries on from where it is.
         const int at = c->h_S->iter;
-        c->pcg_softcap = (c->amg_best > 0 && rebuilds < max_rebuilds) ? 4 * c->amg_best + 40 + at : 0;
+        c->pcg_softcap = (c->amg_best > 0 && rebuilds < max_rebuilds) ? rules::bail_out_cap(c->amg_best) + at : 0;
         const int maxit = c->pcg_softcap > 0 ? std::min(c->pcg_softcap, c->opts.pcg_maxit) : c->opts.pcg_maxit;
         c->pcg_pred = std::max(2, fresh_pcg);
         if ((rc = refresh_and_continue(c, maxit)) || (rc = run_pcg(c))) return rc;
@@ -1082,7 +1087,7 @@ int optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
         const double moved = c->last_dchg[1] > 0.0 ? c->last_dchg[0] / c->last_dchg[1] : 0.0;
         // (counted as sixteen iterations over -- but never past what forbids keeping over 0.01 % of movement: an interruption at next
         // to no movement was not the movement's doing, and a slope that only kept solves can lower must not lock them out)
-        c->amg_lag_slope = std::min(std::max(c->amg_lag_slope, 16.0 / std::max(moved, 1e-6)), 40000.0);
+        c->amg_lag_slope = rules::lag_slope_after_interrupt(c->amg_lag_slope, moved);
         c->amg_lag_slope_seen = true;
         if (c->opts.verbose)
           std::fprintf(stderr, "[sgo] iteration %d: solve behind kept coarse operators interrupted after %d PCG iterations, operators refreshed\n", it, at);
@@ -1103,7 +1108,7 @@ int optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
         // it keeps the tentative transfers, which go stale gracefully -- 190 -> 240 iterations where a stale filtered one can
         // grind on to pcg_maxit (seen with another aggregation threshold from the dead-reckoned start: 11 059, then 20 000)
         if (rebuilds + 1 >= max_rebuilds) c->amg_no_filter = true;
-        if ((rc = build_amg(c)) || (rc = do_linearize(c)) || (rc = run_pcg(c))) return rc;
+        if ((rc = build_amg(c, false, c->knobs.keep_agg && c->amg_best != 0)) || (rc = do_linearize(c)) || (rc = run_pcg(c))) return rc;
         ++rebuilds;
         call_best = 0;   // (another hierarchy: its first solve sets the reference)
         rebuild_next = false;
@@ -1140,23 +1145,22 @@ int optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
         // iterations ~ log(1 / tolerance) -- or the staleness rules below would take every tight solve that follows
         // a loose one for a stale hierarchy.
         const double tol0 = c->opts.pcg_tol * c->tol_scale, tolk = std::sqrt(S.tol2);
-        const int eq_iter = (tolk > tol0 && tolk < 1.0 && tol0 > 0.0) ? (int)std::lround(S.iter * std::log(tol0) / std::log(tolk)) : S.iter;
+        const int eq_iter = rules::equal_tolerance_count(S.iter, tol0, tolk);
         if (kept_interrupted) {
           // (counts of a solve that changed its preconditioner half-way say nothing about either hierarchy state)
         } else if (c->amg_skip_update) {
           ++kept_solves;
           // behind kept coarse operators: judged against the last fresh solve only -- when the lag has cost more than a refresh is
           // worth (~ 8-10 PCG iterations on C2 / C4), the next solve refreshes whatever the blocks' movement says
-          if (eq_iter > fresh_pcg + 8 + fresh_pcg / 4) c->amg_ref_valid = false;
+          if (rules::kept_solve_too_slow(eq_iter, fresh_pcg)) c->amg_ref_valid = false;
           // ... and every kept solve teaches what movement costs on this graph (the first observation replaces the cautious start,
           // later ones raise the slope at once and lower it slowly)
           const double moved = c->last_dchg[1] > 0.0 ? c->last_dchg[0] / c->last_dchg[1] : 0.0;
-          const double obs = std::min(40000.0, std::max(0.5, (double)(eq_iter - fresh_pcg)) / std::max(moved, 1e-5));
-          c->amg_lag_slope = c->amg_lag_slope_seen ? std::max(obs, 0.8 * c->amg_lag_slope) : obs;
+          c->amg_lag_slope = rules::lag_slope_after_kept(c->amg_lag_slope, c->amg_lag_slope_seen, eq_iter - fresh_pcg, moved);
           c->amg_lag_slope_seen = true;
         } else {
         fresh_pcg = eq_iter;
-        if (c->amg_lag_slope > 2700.0) c->amg_lag_slope = std::max(2700.0, 0.95 * c->amg_lag_slope);   // (a high slope is re-examined in time)
+        c->amg_lag_slope = rules::lag_slope_after_fresh(c->amg_lag_slope);   // (a high slope is re-examined in time)
         if (trial == 2) {
           // The re-made hierarchy's first two (fresh, warm-started) solves against the old one's first solve of this call (cold): a
           // hierarchy that is better shows it at once -- 22 / 24 against 33 on the C4-sized session --; one that is not -- the
@@ -1164,7 +1168,7 @@ int optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
           trial_best = trial_seen == 0 ? eq_iter : std::min(trial_best, eq_iter);
           if (++trial_seen == 2) {
             trial = 0;
-            if (100 * trial_best > 85 * trial_old) {
+            if (rules::trial_reverts(trial_best, trial_old)) {
               if ((rc = revert_amg(c))) return rc;
               call_best = 0;
               c->agg_rule_off = true;
@@ -1179,7 +1183,7 @@ int optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
         // the progress probe of the solves that keep these operators: iteration fresh / 3 (at least 4), half a decade of slack
         if (S.probe_k > 0 && S.iter >= S.probe_k && S.probe_rel > 0.0) c->amg_probe_max = 10.0 * S.probe_rel;
         else if (S.probe_k > 0) c->amg_probe_max = 0.0;
-        const int k_new = std::max(4, S.iter / 3);
+        const int k_new = rules::probe_iteration(S.iter);
         if (S.probe_k < 4 || std::abs(k_new - S.probe_k) > 1) {   // (the record was taken at another iteration: the next fresh solve records anew)
           c->amg_probe_k = k_new;
           c->amg_probe_max = 0.0;
@@ -1199,9 +1203,7 @@ int optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
         // start then found useless: 2.2 instead of 1.4 s per call.  Staleness across calls is the movement rule's business, below.)
         if (call_best == 0 || eq_iter < call_best) call_best = eq_iter;
         const int left = iters - it - 1;
-        const bool doubled = eq_iter > 2 * call_best + 10;
-        const bool pays = 4 * eq_iter > 5 * call_best && (long long)(eq_iter - call_best) * left > 150;
-        if (rebuilds < max_rebuilds && (doubled || pays)) rebuild_next = true;
+        if (rebuilds < max_rebuilds && rules::staleness(eq_iter, call_best, left).rebuild()) rebuild_next = true;
         // The aggregation's own staleness, across calls: the hierarchy was aggregated from blocks that have since moved a lot -- a
         // graph set up at poor poses and optimised since -- and this call's first solve needs visibly more iterations than the
         // hierarchy's best.  The count rules above weigh a rebuild against the iterations left in THIS call; the reference calls
@@ -1213,9 +1215,9 @@ int optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
           for (int k = 0; k < 3; ++k)
             for (int i = 0; i < c->agg_grid; ++i) v[k] += h[(size_t)k * kMaxPartials + i];
           c->agg_grid = 0;
-          const bool moved_far = v[1] > 0.0 && (v[0] > 0.05 * v[1] || v[2] > 0.01 * (double)c->n);
+          const bool moved_far = rules::moved_far(v[0], v[1], v[2], c->n);
           if (c->opts.verbose) std::fprintf(stderr, "[sgo] since the aggregation: blocks moved by %.2f %%, %.0f rows by a quarter; first solve %d, best of this aggregation %d\n", v[1] > 0 ? 100.0 * v[0] / v[1] : 0.0, v[2], eq_iter, c->agg_best);
-          if (moved_far && !c->agg_rule_off && iters - it >= 5 && c->agg_best > 0 && 10 * eq_iter > 11 * c->agg_best && rebuilds < max_rebuilds && !rebuild_next) {
+          if (rules::reaggregate(moved_far, c->agg_rule_off, iters - it, c->agg_best, eq_iter, rebuilds, max_rebuilds, rebuild_next)) {
             rebuild_next = true;
             trial = 1;
             trial_old = eq_iter;
