@@ -85,6 +85,10 @@ struct HostLevel {
 Amg* amg_create(hipStream_t s, const BsrDev& A0, const Sym0Dev& S0, const Tile0Dev& T0, const HostLevel& H0, const double* d_poses,
                 const int* d_free_id, const AmgConfig& cfg, const AmgProf& prof, std::string* err,
                 ChunkArena* scratch, DevArena* arena, struct AmgHostL0* pre0 = nullptr, const AmgHalo* halo = nullptr);
+// The same hierarchy set up entirely ON THE DEVICE (sgo_amg_dev.inc; single GPU): parallel aggregation, patterns by sort / scan /
+// compress passes.  What a rebuild inside sgo_optimize_gn uses (build_amg, sgo_solve.cpp).
+Amg* amg_create_dev(hipStream_t s, const BsrDev& A0, const Sym0Dev& S0, const Tile0Dev& T0, const double* d_poses, const int* d_free_id,
+                    const AmgConfig& cfg, const AmgProf& prof, std::string* err, DevArena* arena);
 // Level 0's host analysis (aggregation, patterns and product lists of the transfer, structure of level 1) made ahead
 // of amg_create from the level's logical structure and the strength weights w (Frobenius norms of the slots' blocks
 // at the initial poses, logical slot order): amg_host_l0_run may execute on a helper thread while the caller still

@@ -2239,6 +2239,8 @@ AmgConfig amg_effective_config(const AmgConfig& cfg_in, int n, int nslot) {
   return cfg;
 }
 
+#include "sgo_amg_dev.inc"
+
 // Level 0's host analysis made AHEAD of amg_create: amg_host_l0_run is what a helper thread executes once the
 // strength weights `w` of the level-0 slots (logical order of H0) are on the host; amg_create(..., pre0) then skips its
 // own strength kernel, aggregation and symbolic phase for level 0.  `scratch` is used by the run (and must not be

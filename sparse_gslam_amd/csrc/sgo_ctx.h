@@ -136,8 +136,12 @@ struct sgo_ctx {
     int first_solve_cap = 600;    // SGO_FIRST_SOLVE_CAP (test hook)
     bool fail_trial_build = false;   // SGO_TEST_FAIL_TRIAL_BUILD (test hook: the re-aggregation trial's set-up "fails")
     bool keep_agg = false;           // SGO_AMG_KEEP_AGG: a rebuild inside the call keeps the replaced hierarchy's aggregates
+    int setup_mode = 0;              // SGO_AMG_SETUP: 0 host (every set-up), 1 device for the rebuilds inside sgo_optimize_gn, 2 device
+                                     // for every set-up whose level 0 was not made ahead on the helper thread
+    bool force_rebuild = false;      // SGO_AMG_FORCE_REBUILD (test hook): the hierarchy is re-made before the call's first solve
   } knobs;
   bool test_fail_trial_build = false;
+  bool in_optimize = false;       // inside sgo_optimize_gn (build_amg: which set-up a rebuild takes)
   AmgKeptAgg kept_agg;            // (what such a rebuild keeps: host copies, taken from the hierarchy before it is destroyed)
   double* d_poses = nullptr;
   int* d_free_id = nullptr;

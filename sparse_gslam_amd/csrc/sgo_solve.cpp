@@ -516,6 +516,8 @@ void read_call_knobs(sgo_ctx* c) {
   if (const char* e = std::getenv("SGO_FIRST_SOLVE_CAP")) k.first_solve_cap = std::max(1, std::atoi(e));
   if (const char* e = std::getenv("SGO_TEST_FAIL_TRIAL_BUILD")) k.fail_trial_build = std::atoi(e) != 0;
   if (const char* e = std::getenv("SGO_AMG_KEEP_AGG")) k.keep_agg = std::atoi(e) != 0;
+  if (const char* e = std::getenv("SGO_AMG_SETUP")) k.setup_mode = std::string(e) == "device" ? 2 : (std::string(e) == "host" ? 0 : 1);
+  if (const char* e = std::getenv("SGO_AMG_FORCE_REBUILD")) k.force_rebuild = std::atoi(e) != 0;
   c->knobs = k;
   c->test_fail_trial_build = k.fail_trial_build;
 }
@@ -741,6 +743,13 @@ int build_amg(sgo_ctx* c, bool keep_old, bool keep_agg) {
     ah.reserve = [](void* u, size_t doubles) { return halo_reserve((sgo_ctx*)u, doubles) == SGO_OK; };
     ah.w0 = &w0;
   }
+  // The set-up ON THE DEVICE (sgo_amg_dev.inc): the rebuilds inside sgo_optimize_gn on one GPU (SGO_AMG_SETUP=host: the host
+  // set-up for them too; =device: every set-up, sgo_set_graph_se2's included, whose level 0 the helper thread has not made ahead).
+  const bool pre0_ready = c->l0_pre && amg_host_l0_ready(c->l0_pre);
+  const bool dev_setup = !c->owner && !multi_rank(c) && !pre0_ready && (c->knobs.setup_mode == 2 || (c->knobs.setup_mode == 1 && c->in_optimize));
+  if (dev_setup)
+    c->amg = amg_create_dev(c->stream, c->A, c->S0, c->T0, c->d_poses, c->d_free_id, cfg, prof, &aerr, &c->amg_arena);
+  else
   c->amg = amg_create(c->stream, c->A, c->S0, c->T0, c->H0, c->d_poses, c->d_free_id, cfg, prof, &aerr, &c->amg_scratch,
                       &c->amg_arena, c->l0_pre, c->owner ? &ah : nullptr);
   l0_discard(c);
@@ -978,6 +987,7 @@ int optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
         c->warm_valid = false;
         c->amg_lag_on = false;
         c->amg_skip_update = false;
+        c->in_optimize = false;
       }
     } softcap_guard{c};
     // Lagged refresh of the coarse operators (do_linearize): on by default on one GPU (the sharded modes refresh before every solve:
@@ -1013,7 +1023,8 @@ int optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
     int done = 0;
     bool failed = false;
     int rebuilds = 0;
-    bool rebuild_next = false;
+    bool rebuild_next = c->knobs.force_rebuild && c->amg != nullptr;   // (test hook: the set-up is redone before the call's first solve)
+    c->in_optimize = true;
     // (a cap on the set-ups redone inside one call, against thrashing: three for a short call, one per three Gauss-Newton
     // iterations for a long one.  Round 5: with three flat, a call whose weights keep changing -- DCS from a dead-reckoned
     // start -- used them up by iteration 6 and then had no safety net left: its 10th solve ground on to pcg_maxit.)

@@ -1,0 +1,93 @@
+"""The multigrid set-up ON THE DEVICE (sparse_gslam_amd/csrc/sgo_amg_dev.inc, round 6): what a rebuild of the hierarchy inside
+sgo_optimize_gn runs instead of the host's aggregation and pattern work (sgo_amg_host.cpp) -- g2o's counterpart is the symbolic
+analysis LinearSolverEigen redoes per optimize() (graphs.cpp:19, slc.cpp:286-287).
+
+1. Patterns: with the SAME aggregates (AmgConfig::keep_agg: those of the hierarchy the host made at sgo_set_graph_se2) the device-made
+   hierarchy must be the host-made one bit for bit -- same sizes of P, A P, P^T A P and of every product list (the solver description
+   prints them), the same PCG iteration counts, bitwise the same chi2 history -- on every kind of level: smoothed, smoothed with the
+   filtered operator, tentative (K-cycle), folded level 0.
+2. Aggregation: the device's own (distance-2 independent set by hashed priorities) packs differently from the host's greedy walk
+   along the trajectory; what is checked is what the solver needs from it -- every solve converges, the iterates are the direct-solver
+   goldens' to 1e-6, the PCG counts stay within a factor of the host hierarchy's."""
+import os
+
+import numpy as np
+import pytest
+
+from sparse_gslam_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _run(g, iters, env, monkeypatch, **opts):
+    for k in ("SGO_AMG_FORCE_REBUILD", "SGO_AMG_KEEP_AGG", "SGO_AMG_SETUP"):
+        monkeypatch.delenv(k, raising=False)
+    with capi.Optimizer(0, direct_rows=0, **opts) as opt:
+        opt.set_graph(*g.arrays())          # (the host set-up, as always at sgo_set_graph_se2)
+        d0 = opt.solver_description()
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        done, st = opt.optimize(iters)
+        desc = opt.solver_description()
+    for k in env:
+        monkeypatch.delenv(k, raising=False)
+    return done, st, d0, desc
+
+
+CASES = {
+    "C2": lambda: synth.config("C2"),                                                        # smoothed levels, level 0 folded
+    "C2_odom": lambda: synth.config("C2", init="odom"),                                      # filtered smoothing on level 0
+    "30k_300k": lambda: synth.manhattan(30000, 300000, seed=3, info_mode="full"),           # smoothed, level 0 not folded
+    "20k_random": lambda: synth.manhattan(20000, 100000, seed=5, p_random=0.05),            # tentative levels, K-cycle
+    "chain": lambda: synth.manhattan(8000, 8400, seed=6, info_mode="full"),                 # few closures (multifrontal off below)
+}
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_device_patterns_from_the_hosts_aggregates_are_the_hosts_hierarchy(name, monkeypatch):
+    monkeypatch.setenv("SGO_MFRONT", "0")
+    g = CASES[name]()
+    base = {"SGO_AMG_FORCE_REBUILD": "1", "SGO_AMG_KEEP_AGG": "1"}
+    dh, sh, d0h, desch = _run(g, 4, dict(base, SGO_AMG_SETUP="host"), monkeypatch)
+    dd, sd, d0d, descd = _run(g, 4, dict(base, SGO_AMG_SETUP="device"), monkeypatch)
+    assert dh == 4 and dd == 4
+    strip = lambda d: d.split("; last sgo_optimize_gn")[0]
+    assert d0h == d0d
+    assert strip(desch) == strip(descd), (desch, descd)
+    assert strip(desch).split("; direct path")[0] == strip(d0h).split("; direct path")[0]   # (kept aggregates, same values: the same hierarchy)
+    assert sh["pcg_iters"][:4] == sd["pcg_iters"][:4], (sh["pcg_iters"], sd["pcg_iters"])
+    assert list(sh["chi2"][:5]) == list(sd["chi2"][:5])                                       # bitwise
+    assert list(sh["robust_chi2"][:5]) == list(sd["robust_chi2"][:5])
+
+
+@pytest.mark.parametrize("name", ["C2", "C4"])
+def test_device_aggregation_hierarchy_solves_to_the_goldens(name, monkeypatch):
+    monkeypatch.setenv("SGO_MFRONT", "0")
+    f = np.load(os.path.join(GOLDEN, f"{name}_direct.npz"))
+    g = synth.config(name)
+    dh, sh, _, desch = _run(g, 20, {"SGO_AMG_FORCE_REBUILD": "1", "SGO_AMG_SETUP": "host"}, monkeypatch)
+    dd, sd, _, descd = _run(g, 20, {"SGO_AMG_FORCE_REBUILD": "1", "SGO_AMG_SETUP": "device"}, monkeypatch)
+    assert dh == 20 and dd == 20 and all(sd["pcg_converged"][:20])
+    rel = max(abs(sd["chi2"][k] - f["chi2"][k]) / f["chi2"][k] for k in range(21))
+    assert rel <= 1e-6, rel
+    print(name, "host", desch.split("; direct")[0], sh["pcg_iters"])
+    print(name, "device", descd.split("; direct")[0], sd["pcg_iters"])
+    assert sum(sd["pcg_iters"][:20]) <= 1.5 * sum(sh["pcg_iters"][:20]), (sd["pcg_iters"], sh["pcg_iters"])
+
+
+def test_device_rebuilds_from_the_dead_reckoned_start(monkeypatch, capfd):
+    """BASELINE.md's literal start on C4: the call rebuilds its hierarchy every few iterations; with the rebuilds on the device every
+    solve still converges, and the call is not slower than with the host's rebuilds."""
+    g = synth.config("C4", init="odom")
+    res = {}
+    for mode in ("host", "rebuilds"):
+        monkeypatch.setenv("SGO_AMG_SETUP", mode)
+        with capi.Optimizer(0) as opt:
+            opt.set_graph(*g.arrays())
+            done, st = opt.optimize(20)
+            res[mode] = (done, st, opt.solver_description())
+    for mode, (done, st, desc) in res.items():
+        assert done == 20 and all(st["pcg_converged"][:20]), (mode, st["pcg_iters"])
+        print(mode, "call ms", 1e3 * st["seconds_total"], "pcg", st["pcg_iters"])
+    assert res["rebuilds"][1]["seconds_total"] <= 1.1 * res["host"][1]["seconds_total"]
