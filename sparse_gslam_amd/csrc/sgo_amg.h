@@ -87,8 +87,11 @@ Amg* amg_create(hipStream_t s, const BsrDev& A0, const Sym0Dev& S0, const Tile0D
                 ChunkArena* scratch, DevArena* arena, struct AmgHostL0* pre0 = nullptr, const AmgHalo* halo = nullptr);
 // The same hierarchy set up entirely ON THE DEVICE (sgo_amg_dev.inc; single GPU): parallel aggregation, patterns by sort / scan /
 // compress passes.  What a rebuild inside sgo_optimize_gn uses (build_amg, sgo_solve.cpp).
-Amg* amg_create_dev(hipStream_t s, const BsrDev& A0, const Sym0Dev& S0, const Tile0Dev& T0, const double* d_poses, const int* d_free_id,
-                    const AmgConfig& cfg, const AmgProf& prof, std::string* err, DevArena* arena);
+// aggregate_on_device = false (default of the callers): the aggregation stays the host's greedy walk along the trajectory (its
+// aggregates are the better ones, and it is a fifth of the host set-up's time); everything else on the device.
+Amg* amg_create_dev(hipStream_t s, const BsrDev& A0, const Sym0Dev& S0, const Tile0Dev& T0, const HostLevel& H0, const double* d_poses,
+                    const int* d_free_id, const AmgConfig& cfg, const AmgProf& prof, std::string* err, ChunkArena* scratch, DevArena* arena,
+                    DevArena* tmp_arena, bool aggregate_on_device, const struct AmgHostL0* pre0);
 // Level 0's host analysis (aggregation, patterns and product lists of the transfer, structure of level 1) made ahead
 // of amg_create from the level's logical structure and the strength weights w (Frobenius norms of the slots' blocks
 // at the initial poses, logical slot order): amg_host_l0_run may execute on a helper thread while the caller still
@@ -96,7 +99,9 @@ Amg* amg_create_dev(hipStream_t s, const BsrDev& A0, const Sym0Dev& S0, const Ti
 // amg_create has returned.
 struct AmgHostL0;
 AmgHostL0* amg_host_l0_new();
-void amg_host_l0_run(AmgHostL0* p, const HostLevel& H0, const std::vector<double>& w, const AmgConfig& cfg, ChunkArena* scratch);
+// agg_only: the aggregation alone (the patterns are then made on the device: amg_create_dev(..., pre0))
+void amg_host_l0_run(AmgHostL0* p, const HostLevel& H0, const std::vector<double>& w, const AmgConfig& cfg, ChunkArena* scratch, bool agg_only = false);
+bool amg_host_l0_agg_only(const AmgHostL0* p);
 void amg_host_l0_free(AmgHostL0* p);
 bool amg_host_l0_ready(const AmgHostL0* p);
 AmgConfig amg_effective_config(const AmgConfig& cfg_in, int n, int nslot);

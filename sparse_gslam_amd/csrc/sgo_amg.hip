@@ -1509,7 +1509,7 @@ __global__ __launch_bounds__(kBlock) void k_scan_apply(int* __restrict__ v, int 
 // Wave groups over the segments [ptr[f], ptr[f+1]): whole segments packed up to 64 items, a longer segment its own
 // group -- make_groups' rule, applied independently to chunks of kGroupChunk segments (one thread each: short chunks keep the serial walk short; a chunk starts a new group; the
 // grouping does not change a single sum).  Pass 1 counts a chunk's groups, pass 2 (after a prefix sum) writes them.
-constexpr int kGroupChunk = 256;
+// (kGroupChunk: sgo_amg_host.h -- the host's make_groups applies the same rule to the same chunks)
 template <bool FILL>
 __global__ __launch_bounds__(kBlock) void k_group_chunks(const int* __restrict__ ptr, int nseg, int* __restrict__ cnt_or_off,
                                                          int* __restrict__ grp) {
@@ -2239,23 +2239,33 @@ AmgConfig amg_effective_config(const AmgConfig& cfg_in, int n, int nslot) {
   return cfg;
 }
 
+struct AmgHostL0 {
+  HostCoarse hc;
+  bool ready = false;
+  bool agg_only = false;      // hc holds the aggregation only (agg, visit_c, nc; nc == 0: level 0 cannot be coarsened)
+  double theta_used = 0.0;
+};
+
 #include "sgo_amg_dev.inc"
 
 // Level 0's host analysis made AHEAD of amg_create: amg_host_l0_run is what a helper thread executes once the
 // strength weights `w` of the level-0 slots (logical order of H0) are on the host; amg_create(..., pre0) then skips its
 // own strength kernel, aggregation and symbolic phase for level 0.  `scratch` is used by the run (and must not be
 // touched by anybody else meanwhile).
-struct AmgHostL0 {
-  HostCoarse hc;
-  bool ready = false;
-};
 AmgHostL0* amg_host_l0_new() { return new AmgHostL0(); }
 void amg_host_l0_free(AmgHostL0* p) { delete p; }
 bool amg_host_l0_ready(const AmgHostL0* p) { return p && p->ready; }
-void amg_host_l0_run(AmgHostL0* p, const HostLevel& H0, const std::vector<double>& w, const AmgConfig& cfg_in, ChunkArena* scratch) {
+bool amg_host_l0_agg_only(const AmgHostL0* p) { return p && p->ready && p->agg_only; }
+void amg_host_l0_run(AmgHostL0* p, const HostLevel& H0, const std::vector<double>& w, const AmgConfig& cfg_in, ChunkArena* scratch, bool agg_only) {
   try {
     const AmgConfig cfg = amg_effective_config(cfg_in, H0.n, H0.nslot);
     if (H0.n <= cfg.coarsest_nodes || 1 >= cfg.max_levels) return;   // amg_create will not coarsen level 0 at all
+    if (agg_only) {   // the patterns follow on the device (amg_create_dev)
+      p->hc.nc = host_aggregate(H0, w, cfg, 0, scratch, p->hc.agg, p->hc.visit_c, &p->theta_used);
+      p->agg_only = true;
+      p->ready = true;
+      return;
+    }
     host_coarsen(H0, w, cfg, 0, scratch, p->hc);
     p->ready = p->hc.err.empty();
   } catch (...) {

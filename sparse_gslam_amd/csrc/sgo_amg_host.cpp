@@ -13,25 +13,39 @@
 namespace sgo {
 
 // wave groups over segments [ptr[i], ptr[i+1]): whole segments packed up to 64 items; a longer
-// segment is its own group (same rule as the level-0 row groups in sgo_structure.cpp)
+// segment is its own group (same rule as the level-0 row groups in sgo_structure.cpp).  Round 6: the rule is applied
+// independently to chunks of kGroupChunk segments -- a chunk starts a new group --, literally as the device's list builder does
+// (k_group_chunks, sgo_amg.hip): a hierarchy set up on the device (sgo_amg_dev.inc) then has the SAME groups as one set up here,
+// and with them the same association order inside every wavefront segmented scan (its DPP steps are tied to the lanes' positions):
+// the two are bit-identical, which is what tests/test_gpu_device_setup.py asserts.  The grouping never changes WHICH terms a sum has.
 std::vector<int> make_groups(const std::vector<int>& ptr) {
   std::vector<int> grp;
-  grp.push_back(ptr.empty() ? 0 : ptr[0]);   // (a rank's sub-range of a global list starts at its own first item)
   const int nseg = (int)ptr.size() - 1;
-  int cur = 0;
-  for (int r = 0; r < nseg; ++r) {
-    const int len = ptr[r + 1] - ptr[r];
-    if (cur > 0 && cur + len > 64) {
-      grp.push_back(ptr[r]);
-      cur = 0;
+  for (int s0 = 0; s0 < nseg; s0 += kGroupChunk) {
+    const int s1 = std::min(nseg, s0 + kGroupChunk);
+    int cur = 0, start = ptr[s0];
+    bool open = false;
+    for (int f = s0; f < s1; ++f) {
+      const int b = ptr[f], len = ptr[f + 1] - b;
+      if (open && cur + len > 64) {
+        grp.push_back(start);
+        open = false;
+        cur = 0;
+      }
+      if (!open) {
+        start = b;
+        open = true;
+      }
+      cur += len;
+      if (cur >= 64) {
+        grp.push_back(start);
+        open = false;
+        cur = 0;
+      }
     }
-    cur += len;
-    if (cur >= 64) {
-      grp.push_back(ptr[r + 1]);
-      cur = 0;
-    }
+    if (open) grp.push_back(start);
   }
-  if (grp.back() != ptr[nseg]) grp.push_back(ptr[nseg]);
+  grp.push_back(nseg >= 0 ? ptr[nseg] : 0);   // (the list is closed by the total)
   return grp;
 }
 
@@ -599,6 +613,25 @@ bool sa_symbolic(const HostLevel& H, const std::vector<int>& agg, int nc, const 
 
 
 }  // namespace
+
+// The aggregation alone (what host_coarsen does first): for a set-up that makes the patterns on the device (sgo_amg_dev.inc) from
+// the host's aggregates -- the greedy walk along the trajectory is sequential by nature and its aggregates are visibly better than
+// a parallel independent-set aggregation's (NOTES.md section 28), so it stays here; it is a fifth of the host set-up's time.
+int host_aggregate(const HostLevel& H, const std::vector<double>& w, const AmgConfig& cfg, int l, ChunkArena* scratch, std::vector<int>& agg,
+                   std::vector<int>& visit_c, double* theta_used) {
+  const double theta_l = (l == 0 ? cfg.theta : cfg.theta_coarse) * cfg.theta_scale;
+  if (scratch) scratch->rewind();
+  *theta_used = theta_l;
+  int nc = aggregate(H, w, theta_l, agg, scratch);
+  if (nc > 0.9 * H.n) {   // stalled: treat every connection as strong
+    nc = aggregate(H, w, 0.0, agg, scratch);
+    *theta_used = 0.0;
+  }
+  if (nc > 0.9 * H.n || nc < 1) return 0;   // cannot coarsen further
+  visit_c.clear();
+  if (!H.visit.empty()) renumber_aggregates(agg, nc, visit_c);
+  return nc;
+}
 
 void host_coarsen(const HostLevel& H, const std::vector<double>& w, const AmgConfig& cfg, int l, ChunkArena* scratch, HostCoarse& o) {
   const int n = H.n;

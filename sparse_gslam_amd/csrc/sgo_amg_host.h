@@ -13,6 +13,7 @@ namespace sgo {
 
 // wave groups over segments [ptr[i], ptr[i+1]): whole segments packed up to 64 items; a longer
 // segment is its own group (same rule as the level-0 row groups in sgo_structure.cpp)
+constexpr int kGroupChunk = 256;   // segments per chunk of the grouping rule (host: make_groups; device: k_group_chunks)
 std::vector<int> make_groups(const std::vector<int>& ptr);
 
 // Host side of the smoothed-aggregation set-up: patterns of P, AP = A P and A_c = P^T AP and, for
@@ -80,6 +81,9 @@ struct HostCoarse {
   std::string err;
 };
 
+// nc (0: the level cannot be coarsened further); agg renumbered in order of first appearance when H.visit is set, visit_c as host_coarsen's
+int host_aggregate(const HostLevel& H, const std::vector<double>& w, const AmgConfig& cfg, int l, ChunkArena* scratch, std::vector<int>& agg,
+                   std::vector<int>& visit_c, double* theta_used);
 void host_coarsen(const HostLevel& H, const std::vector<double>& w, const AmgConfig& cfg, int l, ChunkArena* scratch, HostCoarse& o);
 
 }  // namespace sgo

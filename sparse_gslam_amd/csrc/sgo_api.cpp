@@ -111,6 +111,7 @@ void sgo_destroy(sgo_ctx* c) {
   c->graph_arena.release();
   c->amg_arena.release();
   c->amg_arena_prev.release();
+  c->amg_tmp_arena.release();
   c->comm.destroy();
   overlay_release(c->ov);
   for (hipEvent_t e : c->ev_pool) hipEventDestroy(e);
@@ -164,6 +165,7 @@ int sgo_set_graph_se2(sgo_ctx* c, int32_t V, const double* poses, const uint8_t*
       c->err = "sgo_set_graph_se2: graph too large for 32-bit slot indices";
       return SGO_EINVAL;
     }
+    read_call_knobs(c);   // (which set-up the multigrid hierarchy takes is decided here: the helper thread of the pipeline depends on it)
     hipError_t e = hipSetDevice(c->device);
     if (e != hipSuccess) {
       c->err = std::string("hipSetDevice: ") + hipGetErrorString(e);

@@ -125,6 +125,7 @@ struct sgo_ctx {
   // The hierarchy a TRIAL rebuild replaced (optimize_gn's re-aggregation rule): kept with its arena until the trial is decided -- a
   // re-made hierarchy that does not solve visibly faster is dropped for it (revert_amg) -- or until the next rebuild.
   DevArena amg_arena_prev;
+  DevArena amg_tmp_arena;         // temporaries of the device set-up (sgo_amg_dev.inc): rewound per level, kept between set-ups
   Amg* amg_prev = nullptr;
   std::string amg_prev_desc;
   bool agg_rule_off = false;      // a trial was lost on this graph: the rule does not fire again before the next set-up
@@ -138,6 +139,8 @@ struct sgo_ctx {
     bool keep_agg = false;           // SGO_AMG_KEEP_AGG: a rebuild inside the call keeps the replaced hierarchy's aggregates
     int setup_mode = 0;              // SGO_AMG_SETUP: 0 host (every set-up), 1 device for the rebuilds inside sgo_optimize_gn, 2 device
                                      // for every set-up whose level 0 was not made ahead on the helper thread
+    bool dev_aggregation = false;    // SGO_AMG_AGG=device: the device set-up aggregates on the device too (a parallel independent-set
+                                     // aggregation: weaker hierarchies, measured; default: the host's greedy aggregation)
     bool force_rebuild = false;      // SGO_AMG_FORCE_REBUILD (test hook): the hierarchy is re-made before the call's first solve
   } knobs;
   bool test_fail_trial_build = false;

@@ -477,6 +477,19 @@ struct DevArena {
   void rewind() {
     for (Chunk& c : chunks) c.used = 0;
   }
+  // A position to come back to: everything taken after mark() is handed out again after rewind_to(mark) (the device set-up's
+  // refused attempts and per-stage temporaries; stream-ordered reuse: whoever takes the memory next is queued behind its last user)
+  struct Mark {
+    std::vector<size_t> used;
+  };
+  Mark mark() const {
+    Mark m;
+    for (const Chunk& c : chunks) m.used.push_back(c.used);
+    return m;
+  }
+  void rewind_to(const Mark& m) {
+    for (size_t i = 0; i < chunks.size(); ++i) chunks[i].used = i < m.used.size() ? m.used[i] : 0;
+  }
   void release() {
     for (Chunk& c : chunks) hipFree(c.base);
     chunks.clear();

@@ -518,6 +518,7 @@ void read_call_knobs(sgo_ctx* c) {
   if (const char* e = std::getenv("SGO_AMG_KEEP_AGG")) k.keep_agg = std::atoi(e) != 0;
   if (const char* e = std::getenv("SGO_AMG_SETUP")) k.setup_mode = std::string(e) == "device" ? 2 : (std::string(e) == "host" ? 0 : 1);
   if (const char* e = std::getenv("SGO_AMG_FORCE_REBUILD")) k.force_rebuild = std::atoi(e) != 0;
+  if (const char* e = std::getenv("SGO_AMG_AGG")) k.dev_aggregation = std::string(e) == "device";
   c->knobs = k;
   c->test_fail_trial_build = k.fail_trial_build;
 }
@@ -745,14 +746,19 @@ int build_amg(sgo_ctx* c, bool keep_old, bool keep_agg) {
   }
   // The set-up ON THE DEVICE (sgo_amg_dev.inc): the rebuilds inside sgo_optimize_gn on one GPU (SGO_AMG_SETUP=host: the host
   // set-up for them too; =device: every set-up, sgo_set_graph_se2's included, whose level 0 the helper thread has not made ahead).
+  const double t_create0 = wall_s();
   const bool pre0_ready = c->l0_pre && amg_host_l0_ready(c->l0_pre);
-  const bool dev_setup = !c->owner && !multi_rank(c) && !pre0_ready && (c->knobs.setup_mode == 2 || (c->knobs.setup_mode == 1 && c->in_optimize));
+  const bool pre0_agg = pre0_ready && amg_host_l0_agg_only(c->l0_pre);
+  const bool dev_setup = !c->owner && !multi_rank(c) && (pre0_agg || (!pre0_ready && (c->knobs.setup_mode == 2 || (c->knobs.setup_mode == 1 && c->in_optimize))));
   if (dev_setup)
-    c->amg = amg_create_dev(c->stream, c->A, c->S0, c->T0, c->d_poses, c->d_free_id, cfg, prof, &aerr, &c->amg_arena);
+    c->amg = amg_create_dev(c->stream, c->A, c->S0, c->T0, c->H0, c->d_poses, c->d_free_id, cfg, prof, &aerr, &c->amg_scratch, &c->amg_arena,
+                            &c->amg_tmp_arena, c->knobs.dev_aggregation, pre0_agg ? c->l0_pre : nullptr);
   else
   c->amg = amg_create(c->stream, c->A, c->S0, c->T0, c->H0, c->d_poses, c->d_free_id, cfg, prof, &aerr, &c->amg_scratch,
                       &c->amg_arena, c->l0_pre, c->owner ? &ah : nullptr);
   l0_discard(c);
+  if (c->opts.verbose)
+    std::fprintf(stderr, "[sgo] multigrid set-up (%s): %.2f ms\n", dev_setup ? (c->knobs.dev_aggregation ? "aggregation and patterns on the device" : "host aggregation, patterns on the device") : "host", 1e3 * (wall_s() - t_create0));
   if (c->amg && amg_comm_failed(c->amg)) {
     c->err = "collective failed during the multigrid set-up";
     return SGO_ECOMM;

@@ -330,9 +330,11 @@ int build_structure(sgo_ctx* c, int V, const double* poses, const uint8_t* fixed
       const HostLevel* Hp = &c->H0;
       const std::vector<double>* wp = &c->l0_w;
       ChunkArena* scr = &c->amg_scratch;
-      c->l0_thread = std::thread([pre, Hp, wp, scr] {
+      // (one GPU, patterns on the device -- sgo_amg_dev.inc, the default --: the helper thread makes the aggregation only)
+      const bool agg_only = c->knobs.setup_mode == 2 && !c->comm.active();
+      c->l0_thread = std::thread([pre, Hp, wp, scr, agg_only] {
         HostPool::lane() = 1;   // its own worker pool: runs beside this thread's regions instead of queueing with them
-        amg_host_l0_run(pre, *Hp, *wp, AmgConfig(), scr);
+        amg_host_l0_run(pre, *Hp, *wp, AmgConfig(), scr, agg_only);
       });
       lap("early strengths");
     }

@@ -2,13 +2,16 @@
 sgo_optimize_gn runs instead of the host's aggregation and pattern work (sgo_amg_host.cpp) -- g2o's counterpart is the symbolic
 analysis LinearSolverEigen redoes per optimize() (graphs.cpp:19, slc.cpp:286-287).
 
-1. Patterns: with the SAME aggregates (AmgConfig::keep_agg: those of the hierarchy the host made at sgo_set_graph_se2) the device-made
-   hierarchy must be the host-made one bit for bit -- same sizes of P, A P, P^T A P and of every product list (the solver description
-   prints them), the same PCG iteration counts, bitwise the same chi2 history -- on every kind of level: smoothed, smoothed with the
-   filtered operator, tentative (K-cycle), folded level 0.
-2. Aggregation: the device's own (distance-2 independent set by hashed priorities) packs differently from the host's greedy walk
-   along the trajectory; what is checked is what the solver needs from it -- every solve converges, the iterates are the direct-solver
-   goldens' to 1e-6, the PCG counts stay within a factor of the host hierarchy's."""
+1. Patterns (the default device set-up: the host's greedy aggregation, everything else on the device): the device-made hierarchy must
+   be the host-made one bit for bit -- same sizes of P, A P, P^T A P and of every product list (the solver description prints them),
+   the same PCG iteration counts, bitwise the same chi2 history -- on every kind of level: smoothed, smoothed with the filtered
+   operator, tentative (K-cycle), folded level 0; with aggregates made anew and with the aggregates of the replaced hierarchy kept.
+2. Aggregation on the device as well (SGO_AMG_AGG=device, opt-in: a distance-2 independent set by hashed priorities packs less regularly
+   than the host's greedy walk along the trajectory and its hierarchies need 40-50 % more PCG iterations -- measured, NOTES.md section
+   28 --): what is checked is what the solver needs from it -- every solve converges, the iterates are the direct-solver goldens' to
+   1e-6, the PCG counts stay within a factor of two of the host hierarchy's.
+3. The rebuilds inside a call from BASELINE.md's literal dead-reckoned start: the same iterates and counts as with the host's
+   rebuilds, in less time."""
 import os
 
 import numpy as np
@@ -44,11 +47,12 @@ CASES = {
 }
 
 
+@pytest.mark.parametrize("keep", [False, True])
 @pytest.mark.parametrize("name", list(CASES))
-def test_device_patterns_from_the_hosts_aggregates_are_the_hosts_hierarchy(name, monkeypatch):
+def test_device_patterns_from_the_hosts_aggregates_are_the_hosts_hierarchy(name, keep, monkeypatch):
     monkeypatch.setenv("SGO_MFRONT", "0")
     g = CASES[name]()
-    base = {"SGO_AMG_FORCE_REBUILD": "1", "SGO_AMG_KEEP_AGG": "1"}
+    base = {"SGO_AMG_FORCE_REBUILD": "1", "SGO_AMG_KEEP_AGG": "1" if keep else "0"}
     dh, sh, d0h, desch = _run(g, 4, dict(base, SGO_AMG_SETUP="host"), monkeypatch)
     dd, sd, d0d, descd = _run(g, 4, dict(base, SGO_AMG_SETUP="device"), monkeypatch)
     assert dh == 4 and dd == 4
@@ -67,27 +71,31 @@ def test_device_aggregation_hierarchy_solves_to_the_goldens(name, monkeypatch):
     f = np.load(os.path.join(GOLDEN, f"{name}_direct.npz"))
     g = synth.config(name)
     dh, sh, _, desch = _run(g, 20, {"SGO_AMG_FORCE_REBUILD": "1", "SGO_AMG_SETUP": "host"}, monkeypatch)
-    dd, sd, _, descd = _run(g, 20, {"SGO_AMG_FORCE_REBUILD": "1", "SGO_AMG_SETUP": "device"}, monkeypatch)
+    dd, sd, _, descd = _run(g, 20, {"SGO_AMG_FORCE_REBUILD": "1", "SGO_AMG_SETUP": "device", "SGO_AMG_AGG": "device"}, monkeypatch)
+    monkeypatch.delenv("SGO_AMG_AGG", raising=False)
     assert dh == 20 and dd == 20 and all(sd["pcg_converged"][:20])
     rel = max(abs(sd["chi2"][k] - f["chi2"][k]) / f["chi2"][k] for k in range(21))
     assert rel <= 1e-6, rel
     print(name, "host", desch.split("; direct")[0], sh["pcg_iters"])
     print(name, "device", descd.split("; direct")[0], sd["pcg_iters"])
-    assert sum(sd["pcg_iters"][:20]) <= 1.5 * sum(sh["pcg_iters"][:20]), (sd["pcg_iters"], sh["pcg_iters"])
+    assert sum(sd["pcg_iters"][:20]) <= 2.0 * sum(sh["pcg_iters"][:20]), (sd["pcg_iters"], sh["pcg_iters"])
 
 
-def test_device_rebuilds_from_the_dead_reckoned_start(monkeypatch, capfd):
-    """BASELINE.md's literal start on C4: the call rebuilds its hierarchy every few iterations; with the rebuilds on the device every
-    solve still converges, and the call is not slower than with the host's rebuilds."""
+def test_device_rebuilds_from_the_dead_reckoned_start(monkeypatch):
+    """BASELINE.md's literal start on C4: the call rebuilds its hierarchy every few iterations.  With the rebuilds' patterns made on the
+    device the call is the SAME call -- counts and chi2 history bit for bit -- and shorter."""
     g = synth.config("C4", init="odom")
     res = {}
-    for mode in ("host", "rebuilds"):
+    for mode in ("host", "rebuilds", "host", "rebuilds"):
         monkeypatch.setenv("SGO_AMG_SETUP", mode)
         with capi.Optimizer(0) as opt:
             opt.set_graph(*g.arrays())
             done, st = opt.optimize(20)
             res[mode] = (done, st, opt.solver_description())
+    monkeypatch.delenv("SGO_AMG_SETUP")
     for mode, (done, st, desc) in res.items():
         assert done == 20 and all(st["pcg_converged"][:20]), (mode, st["pcg_iters"])
         print(mode, "call ms", 1e3 * st["seconds_total"], "pcg", st["pcg_iters"])
-    assert res["rebuilds"][1]["seconds_total"] <= 1.1 * res["host"][1]["seconds_total"]
+    assert res["rebuilds"][1]["pcg_iters"][:20] == res["host"][1]["pcg_iters"][:20]
+    assert list(res["rebuilds"][1]["chi2"][:21]) == list(res["host"][1]["chi2"][:21])
+    assert res["rebuilds"][1]["seconds_total"] <= 0.9 * res["host"][1]["seconds_total"]
