@@ -111,14 +111,18 @@ typedef struct sgo_opts {
  *     kernel), SGO_PRECOND_F32=0 (fp64 blocks in the preconditioner's level-0 passes)
  *   multigrid set-up: SGO_AMG_THETA (strength threshold), SGO_AMG_THETA_FILTER / SGO_AMG_FILTER=0 (filtered smoothing),
  *     SGO_AMG_SMOOTH=0 (tentative transfers only), SGO_AMG_OMEGA, SGO_AMG_OMEGA_P, SGO_AMG_NU, SGO_AMG_FOLD, SGO_AMG_FOLD0_ROWS,
- *     SGO_AMG_KDEPTH, SGO_AMG_FCG2_DEPTH (cycle shape), SGO_HOST_THREADS (worker pool of the host set-up)
+ *     SGO_AMG_KDEPTH, SGO_AMG_FCG2_DEPTH (cycle shape), SGO_HOST_THREADS (worker pool of the host set-up),
+ *     SGO_AMG_SETUP={device,rebuilds,host} (round 6; default device on one GPU: the hierarchy's patterns -- P, A P, P^T A P, the
+ *     tentative map -- and lists are made on the device from the host's aggregation, bit-identical to the host set-up's; rebuilds:
+ *     only for the rebuilds inside sgo_optimize_gn; host: never), SGO_AMG_AGG=device (opt-in: the aggregation on the device as well --
+ *     a parallel independent-set aggregation, weaker hierarchies: DESIGN.md section 5)
  *   inside sgo_optimize_gn: SGO_AMG_LAG=0 (the hierarchy's coarse operators are refreshed before EVERY solve; default: a solve keeps
  *     those of the solve before while the level-0 diagonal blocks have barely moved, and a hierarchy whose aggregation the blocks
  *     have moved far away from is re-made once inside the next call: DESIGN.md section 5), SGO_AMG_LAG_TAU (the largest relative
  *     movement a solve may keep its coarse operators over, 0.006)
  *   multi-GPU: SGO_COMM_MODE={owner,allreduce}, SGO_COMM_GRAPH (see sgo_comm_init), SGO_OWNER_MIN_ROWS, SGO_RCCL_LIB (library path)
  *   test hooks and A/B switches of scripts/ (not for production): SGO_AMG_LISTS=host, SGO_SETUP_PIPELINE, SGO_TILE_LDS,
- *     SGO_FIRST_SOLVE_CAP, SGO_PCG_STALL_WINDOW, SGO_TEST_FAIL_TRIAL_BUILD, SGO_MIRROR, SGO_LANCZOS (sgo_debug_lanczos), SGO_MFRONT_DEBUG, SGO_AMG_LAG_FORCE / SGO_AMG_LAG_SLOPE
+ *     SGO_FIRST_SOLVE_CAP, SGO_PCG_STALL_WINDOW, SGO_TEST_FAIL_TRIAL_BUILD, SGO_AMG_FORCE_REBUILD, SGO_AMG_KEEP_AGG, SGO_MIRROR, SGO_LANCZOS (sgo_debug_lanczos), SGO_MFRONT_DEBUG, SGO_AMG_LAG_FORCE / SGO_AMG_LAG_SLOPE
  *     (scripts/lag_calib.py, tests/test_gpu_lagged_refresh.py)
  * Removed in round 5 (measured, not kept: NOTES.md sections 9-10): SGO_DEFLATE, SGO_OWNER_XS_EXCHANGE, SGO_MFRONT_FUSED_SOLVE.
  * Of the interface SURVEY.md section 8(b) sketched, three items do not exist, on purpose: SGO_NGPU (one process per GPU: the

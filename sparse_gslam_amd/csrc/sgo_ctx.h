@@ -137,8 +137,10 @@ struct sgo_ctx {
     int first_solve_cap = 600;    // SGO_FIRST_SOLVE_CAP (test hook)
     bool fail_trial_build = false;   // SGO_TEST_FAIL_TRIAL_BUILD (test hook: the re-aggregation trial's set-up "fails")
     bool keep_agg = false;           // SGO_AMG_KEEP_AGG: a rebuild inside the call keeps the replaced hierarchy's aggregates
-    int setup_mode = 0;              // SGO_AMG_SETUP: 0 host (every set-up), 1 device for the rebuilds inside sgo_optimize_gn, 2 device
-                                     // for every set-up whose level 0 was not made ahead on the helper thread
+    int setup_mode = 2;              // SGO_AMG_SETUP: host (0: the host's aggregation, patterns and lists for every set-up, as before round 6),
+                                     // rebuilds (1: the patterns on the device for the rebuilds inside sgo_optimize_gn only), device (2, the
+                                     // default on one GPU: for every set-up; the set-up pipeline's helper thread then makes level 0's
+                                     // aggregation alone).  The multi-GPU modes keep the host set-up.
     bool dev_aggregation = false;    // SGO_AMG_AGG=device: the device set-up aggregates on the device too (a parallel independent-set
                                      // aggregation: weaker hierarchies, measured; default: the host's greedy aggregation)
     bool force_rebuild = false;      // SGO_AMG_FORCE_REBUILD (test hook): the hierarchy is re-made before the call's first solve

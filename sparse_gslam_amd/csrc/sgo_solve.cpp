@@ -516,7 +516,7 @@ void read_call_knobs(sgo_ctx* c) {
   if (const char* e = std::getenv("SGO_FIRST_SOLVE_CAP")) k.first_solve_cap = std::max(1, std::atoi(e));
   if (const char* e = std::getenv("SGO_TEST_FAIL_TRIAL_BUILD")) k.fail_trial_build = std::atoi(e) != 0;
   if (const char* e = std::getenv("SGO_AMG_KEEP_AGG")) k.keep_agg = std::atoi(e) != 0;
-  if (const char* e = std::getenv("SGO_AMG_SETUP")) k.setup_mode = std::string(e) == "device" ? 2 : (std::string(e) == "host" ? 0 : 1);
+  if (const char* e = std::getenv("SGO_AMG_SETUP")) k.setup_mode = std::string(e) == "host" ? 0 : (std::string(e) == "rebuilds" ? 1 : 2);
   if (const char* e = std::getenv("SGO_AMG_FORCE_REBUILD")) k.force_rebuild = std::atoi(e) != 0;
   if (const char* e = std::getenv("SGO_AMG_AGG")) k.dev_aggregation = std::string(e) == "device";
   c->knobs = k;

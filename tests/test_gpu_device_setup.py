@@ -65,6 +65,28 @@ def test_device_patterns_from_the_hosts_aggregates_are_the_hosts_hierarchy(name,
     assert list(sh["robust_chi2"][:5]) == list(sd["robust_chi2"][:5])
 
 
+@pytest.mark.parametrize("name", ["C2", "C2_odom", "C4", "30k_300k", "20k_random"])
+def test_set_graph_with_device_patterns_is_the_host_set_up(name, monkeypatch):
+    """sgo_set_graph_se2 itself (the default since round 6: level 0's aggregation on the set-up pipeline's helper thread where there
+    is one, every pattern and list on the device) against SGO_AMG_SETUP=host: the same hierarchy, bitwise the same optimize(20)."""
+    monkeypatch.setenv("SGO_MFRONT", "0")
+    g = synth.config("C4") if name == "C4" else CASES[name]()
+    out = {}
+    for mode in ("host", "device"):
+        monkeypatch.setenv("SGO_AMG_SETUP", mode)
+        with capi.Optimizer(0, direct_rows=0) as opt:
+            opt.set_graph(*g.arrays())
+            desc = opt.solver_description()
+            done, st = opt.optimize(20)
+            out[mode] = (done, st, desc)
+    monkeypatch.delenv("SGO_AMG_SETUP")
+    assert out["host"][0] == 20 and out["device"][0] == 20
+    assert out["host"][2] == out["device"][2], (out["host"][2], out["device"][2])
+    assert out["host"][1]["pcg_iters"][:20] == out["device"][1]["pcg_iters"][:20]
+    assert list(out["host"][1]["chi2"][:21]) == list(out["device"][1]["chi2"][:21])
+    assert list(out["host"][1]["robust_chi2"][:21]) == list(out["device"][1]["robust_chi2"][:21])
+
+
 @pytest.mark.parametrize("name", ["C2", "C4"])
 def test_device_aggregation_hierarchy_solves_to_the_goldens(name, monkeypatch):
     monkeypatch.setenv("SGO_MFRONT", "0")
