@@ -143,7 +143,10 @@ typedef struct sgo_stats {
   double chi2[SGO_MAX_ITERS + 1];            /* activeChi2 at the START of iteration k; [iters_done] = final */
   double robust_chi2[SGO_MAX_ITERS + 1];     /* activeRobustChi2, same indexing */
   int32_t pcg_iters[SGO_MAX_ITERS];          /* PCG iterations of GN iteration k (0 on the direct small-graph path) */
-  int32_t pcg_converged[SGO_MAX_ITERS];      /* 1 = reached pcg_tol */
+  int32_t pcg_converged[SGO_MAX_ITERS];      /* 1 = reached pcg_tol; 2 (round 6) = stopped without reaching it with x at the floating-point
+                                              * floor of its system (normwise backward error |r| / (|H| |x| + |b|) <= 1e-12): the step WAS
+                                              * applied, as the solution of a backward-stable direct solver (LinearSolverEigen) would be;
+                                              * 0 = failed: the step was not applied, sgo_optimize_gn returned 0 */
   double pcg_relres[SGO_MAX_ITERS];          /* final ||r|| / ||b|| (recurrence residual) */
   double seconds[SGO_MAX_ITERS];             /* device time of GN iteration k (HIP events) */
   double seconds_linearize[SGO_MAX_ITERS];   /* ... of which error/Jacobian/assembly */

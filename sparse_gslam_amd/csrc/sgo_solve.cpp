@@ -903,6 +903,33 @@ int check_graph(sgo_ctx* c) {
   return SGO_OK;
 }
 
+// The normwise backward error of the solve's current x, eta = |r| / (|H| |x| + |b|) with |H| taken as 2 max_i |D_i|_F (an
+// UNDER-estimate for rows of high degree: eta errs on the large side).  A solve that stops making progress with eta at a few
+// thousand units of roundoff has the solution double precision can give for this system -- a backward-stable direct solver
+// (LinearSolverEigen's LDL^T, graphs.cpp:19) returns one of the same quality and g2o applies it --, whatever |r| / |b| says: seen
+// from BASELINE.md's dead-reckoned start on large graphs with full information matrices, where undamped Gauss-Newton + DCS blows up
+// (steps of 10^9 m, |x| / |b| ~ 20, |H| ~ 4 10^9: relative residuals of 10^-5 .. 10^-6 at eta = 10^-16 .. 3 10^-14; restarting the
+// recurrence from b - H x changes nothing there: NOTES.md section 29).  Rare path: x and the diagonal blocks are read on the host.
+static int solve_backward_error(sgo_ctx* c, double* eta) {
+  std::vector<double> hx(3 * (size_t)c->n), hd(6 * (size_t)c->n);
+  HIP_TRY(c, hipMemcpyAsync(hx.data(), c->d_x, sizeof(double) * hx.size(), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(hd.data(), c->S0.dblk, sizeof(double) * hd.size(), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  double xx = 0.0, dmax = 0.0;
+  for (double v : hx) xx += v * v;
+  for (int i = 0; i < c->n; ++i) {
+    const double* d = hd.data() + 6 * (size_t)i;
+    dmax = std::max(dmax, std::sqrt(d[0] * d[0] + 2 * d[1] * d[1] + 2 * d[2] * d[2] + d[3] * d[3] + 2 * d[4] * d[4] + d[5] * d[5]));
+  }
+  const double den = 2.0 * dmax * std::sqrt(xx) + std::sqrt(c->h_S->bb);
+  *eta = (den > 0.0 && std::isfinite(den) && std::isfinite(c->h_S->rr)) ? std::sqrt(c->h_S->rr) / den : 1.0;
+  if (c->opts.verbose)
+    std::fprintf(stderr, "[sgo] solve stopped without reaching pcg_tol: |r| %.3e |b| %.3e |x| %.3e max|D| %.3e: normwise backward error %.2e\n", std::sqrt(c->h_S->rr),
+                 std::sqrt(c->h_S->bb), std::sqrt(xx), dmax, *eta);
+  return SGO_OK;
+}
+constexpr double kFloorEta = 1e-12;   // ~ 4 500 units of roundoff
+
 int optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
     int rc = check_graph(c);
     if (rc) return rc;
@@ -1018,6 +1045,7 @@ int optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
     const int force_from = std::getenv("SGO_AMG_LAG_FORCE") ? std::atoi(std::getenv("SGO_AMG_LAG_FORCE")) : -1;   // (calibration hook, scripts/lag_calib.py)
     int fresh_pcg = 0;   // the count of the last solve behind freshly made coarse operators
     int kept_solves = 0;
+    int floor_solves = 0;   // solves accepted at the floating-point floor of their system (solve_backward_error)
     int call_best = 0;   // the fewest (equal-tolerance) iterations a fresh solve of this call has taken
     std::string agg_note;
     int trial = 0, trial_old = 0, trial_best = 0, trial_seen = 0;   // the re-aggregation rule's trial: 1 = rebuild pending, 2 = judging the new hierarchy's first solves
@@ -1109,7 +1137,24 @@ int optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
         if (c->opts.verbose)
           std::fprintf(stderr, "[sgo] iteration %d: solve behind kept coarse operators interrupted after %d PCG iterations, operators refreshed\n", it, at);
       }
-      if (c->pcg_softcap > 0 && c->h_S->stop == 2 && c->h_S->iter < c->opts.pcg_maxit && c->amg) {
+      // A solve that STAGNATED (run_pcg's guard) or ran out of iterations with x at the floating-point floor of its system: accepted,
+      // like a backward-stable direct solver's solution (solve_backward_error above).  Single GPU (the guard's domain).
+      bool floor_accept = false;
+      auto check_floor = [&]() -> int {
+        if (floor_accept || !(c->h_S->stop == 2 && (c->pcg_stalled || c->h_S->iter >= c->opts.pcg_maxit) && !c->owner && !multi_rank(c))) return SGO_OK;
+        double eta = 1.0;
+        const int r2 = solve_backward_error(c, &eta);
+        if (r2) return r2;
+        floor_accept = eta <= kFloorEta;
+        if (floor_accept) {
+          ++floor_solves;
+          if (c->opts.verbose)
+            std::fprintf(stderr, "[sgo] iteration %d: the solve's x is at the floating-point floor of its system (backward error %.1e <= %.0e): step applied\n", it, eta, kFloorEta);
+        }
+        return SGO_OK;
+      };
+      if ((rc = check_floor())) return rc;
+      if (!floor_accept && c->pcg_softcap > 0 && c->h_S->stop == 2 && c->h_S->iter < c->opts.pcg_maxit && c->amg) {
         // The solve ran into the bail-out cap (4x the best count of this hierarchy): the aggregation no
         // longer fits the re-weighted Hessian.  Redo the set-up from the current values and solve again
         // from x = 0 instead of grinding on (seen: 735 iterations where the rebuilt hierarchy needs 16).
@@ -1131,8 +1176,9 @@ int optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
         rebuild_next = false;
         if (c->opts.verbose)
           std::fprintf(stderr, "[sgo] iteration %d: solve abandoned after %d PCG iterations, hierarchy rebuilt\n", it, wasted);
+        if ((rc = check_floor())) return rc;
       }
-      if (c->h_S->stop == 3 && c->amg && amg_has_filtered(c->amg) && rebuilds < max_rebuilds) {
+      if (!floor_accept && c->h_S->stop == 3 && c->amg && amg_has_filtered(c->amg) && rebuilds < max_rebuilds) {
         // A breakdown (p.Hp <= 0 or a non-finite scalar) behind a hierarchy with FILTERED transfers: the Gauss-Newton Hessian is
         // positive semi-definite by construction, so the first suspect is the preconditioner -- the set-up is redone with the
         // tentative transfers and the solve repeated once; a Hessian that really is indefinite fails again and is reported.
@@ -1145,6 +1191,7 @@ int optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
         rebuild_next = false;
         if (c->opts.verbose)
           std::fprintf(stderr, "[sgo] iteration %d: PCG breakdown behind a filtered hierarchy, rebuilt with tentative transfers and solved again\n", it);
+        if ((rc = check_floor())) return rc;
       }
       if (c->amg_dchg_pending) read_diag_change(c);   // (written before the solve began; the solve's end was waited for)
       if (c->amg_lag_on) {
@@ -1163,8 +1210,9 @@ int optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
         // a loose one for a stale hierarchy.
         const double tol0 = c->opts.pcg_tol * c->tol_scale, tolk = std::sqrt(S.tol2);
         const int eq_iter = rules::equal_tolerance_count(S.iter, tol0, tolk);
-        if (kept_interrupted) {
-          // (counts of a solve that changed its preconditioner half-way say nothing about either hierarchy state)
+        if (kept_interrupted || floor_accept) {
+          // (counts of a solve that changed its preconditioner half-way, or that ended at the floating-point floor, say nothing
+          // about either hierarchy state)
         } else if (c->amg_skip_update) {
           ++kept_solves;
           // behind kept coarse operators: judged against the last fresh solve only -- when the lag has cost more than a refresh is
@@ -1255,10 +1303,10 @@ int optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
       }
       if (out) {
         out->pcg_iters[it] = S.iter + wasted;   // an abandoned solve's iterations count too
-        out->pcg_converged[it] = S.stop == 1;
+        out->pcg_converged[it] = S.stop == 1 ? 1 : (floor_accept ? 2 : 0);
         out->pcg_relres[it] = S.bb > 0 ? std::sqrt(S.rr / S.bb) : 0.0;
       }
-      if (S.stop != 1) {
+      if (S.stop != 1 && !floor_accept) {
         // Solver failure, as LinearSolverEigen::solve returning false (OptimizationAlgorithm::Fail): the
         // step is NOT applied, estimates stay at the last successful update and the call returns 0 like
         // g2o::SparseOptimizer::optimize.  stop == 3: p.Hp <= 0 or non-finite (H not positive definite);
@@ -1302,6 +1350,10 @@ int optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
     if (kept_solves > 0)
       c->lag_note = "last sgo_optimize_gn: " + std::to_string(kept_solves) + " of " + std::to_string(done) + " solves kept the coarse operators of the one before";
     if (!agg_note.empty()) c->lag_note += (c->lag_note.empty() ? "" : "; ") + agg_note;
+    if (floor_solves > 0)
+      c->lag_note += std::string(c->lag_note.empty() ? "last sgo_optimize_gn: " : "; ") + std::to_string(floor_solves) +
+                     " solve(s) stopped at the floating-point floor of their system (normwise backward error <= 1e-12 without reaching pcg_tol): "
+                     "steps applied, as a backward-stable direct solver's would be";
     if ((rc = do_chi2(c, c->d_hist + 2 * done, nullptr))) {
       return rc;
     }
