@@ -1506,6 +1506,29 @@ __global__ __launch_bounds__(kBlock) void k_scan_apply(int* __restrict__ v, int 
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) v[n] = sums[nb];
 }
+// The same in ONE launch of one workgroup for short lists: every thread scans a contiguous piece, the pieces' totals are scanned in LDS.
+constexpr int kScanSmall = 32768;
+__global__ __launch_bounds__(1024) void k_scan_small(int* __restrict__ v, int n) {
+  __shared__ int sm[1024];
+  const int per = (n + 1023) / 1024, b = threadIdx.x * per, e = min(n, b + per);
+  int tot = 0;
+  for (int q = b; q < e; ++q) tot += v[q];
+  sm[threadIdx.x] = tot;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    const int y = (int)threadIdx.x >= off ? sm[threadIdx.x - off] : 0;
+    __syncthreads();
+    sm[threadIdx.x] += y;
+    __syncthreads();
+  }
+  int run = sm[threadIdx.x] - tot;
+  for (int q = b; q < e; ++q) {
+    const int x = v[q];
+    v[q] = run;
+    run += x;
+  }
+  if (threadIdx.x == 1023) v[n] = sm[1023];
+}
 // Wave groups over the segments [ptr[f], ptr[f+1]): whole segments packed up to 64 items, a longer segment its own
 // group -- make_groups' rule, applied independently to chunks of kGroupChunk segments (one thread each: short chunks keep the serial walk short; a chunk starts a new group; the
 // grouping does not change a single sum).  Pass 1 counts a chunk's groups, pass 2 (after a prefix sum) writes them.
@@ -2172,6 +2195,10 @@ int amg_apply(Amg* m, hipStream_t s, const double* r, double* z, const double* d
 
 // v[0..n) counts -> exclusive prefix sums in place, v[n] = total (device, on the stream); `sums` holds n / kScanChunk + 2 ints
 void dev_scan_exclusive(hipStream_t s, int* v, int n, int* sums) {
+  if (n <= kScanSmall) {   // one workgroup, one launch (the set-up's scans are mostly this small: three launches each were a third of its launches)
+    SGO_LAUNCH(k_scan_small, dim3(1), dim3(1024), 0, s, v, n);
+    return;
+  }
   const int nb = (n + kScanChunk - 1) / kScanChunk;
   SGO_LAUNCH(k_scan_sums, dim3(std::max(nb, 1)), dim3(kBlock), 0, s, (const int*)v, n, sums);
   SGO_LAUNCH(k_scan_top, dim3(1), dim3(kBlock), 0, s, sums, nb);
