@@ -19,7 +19,7 @@
 // hierarchy -- a preconditioner for H_base, i.e. for S up to a perturbation of rank <= 3|T| -- as preconditioner.  Per
 // Gauss-Newton iteration: k_ov_lin (the appended edges' linearisation, one thread per overlay row, recompute instead of
 // scatter: no atomics), k_ov_solve (block-tridiagonal LDL^T of H_NN with the 3|T| + 1 right-hand sides [H_NT | b_N] on the
-// lanes of one wave, M and g), k_ov_finish (x_N and the new poses' update).
+// threads of one workgroup, M and g), k_ov_finish (x_N and the new poses' update).
 // The overlay accumulates over successive updates; sgo_update_graph_se2 falls back to the full set-up when the appended
 // part does not have this shape, outgrows the capacities below, or the resident structures cannot take it (multi-GPU,
 // direct path).
@@ -32,7 +32,9 @@
 namespace sgo {
 
 constexpr int kOvMaxRows = 512;      // new rows (poses of the appended chain)
-constexpr int kOvMaxTouched = 16;    // touched base rows + hub rows
+constexpr int kOvMaxTouched = 64;    // touched base rows + hub rows (round 6: 16 before -- the right-hand sides of the chain's elimination
+                                     // sat on the lanes of ONE wave; they now sit on the threads of the workgroup, 3 x 64 + 1 columns)
+constexpr int kOvMaxHubs = 8;        // of which hub rows (their Gauss-Jordan elimination lives in the elimination's LDS tile)
 constexpr int kOvMaxEdges = 4096;    // appended edges
 constexpr int kOvMaxVerts = 4096;    // appended vertices (active or not)
 constexpr int kOvOtherFixed = -(1 << 30);   // entry code: the edge's other endpoint is fixed (no block)

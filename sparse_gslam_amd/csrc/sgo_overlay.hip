@@ -10,9 +10,11 @@
 namespace sgo {
 namespace {
 
-constexpr int kOvTile = 32;          // chain rows per LDS tile of the elimination
+constexpr int kOvTile = 8;           // chain rows per LDS tile of the elimination (3 x 8 x 193 doubles: 37 KB)
 constexpr int kOvThreads = 256;
 constexpr int kOvCols = 3 * kOvMaxTouched + 1;
+static_assert(kOvCols <= kOvThreads, "one right-hand-side column per thread");
+static_assert(3 * kOvMaxHubs * (3 * kOvMaxTouched + 1) <= 3 * kOvTile * kOvCols, "the hubs' Gauss-Jordan tableau lives in the elimination's LDS tile");
 
 // What edge e contributes to the row on its `side` (0: vertices()[0], Jacobian A; 1: vertices()[1], Jacobian B):
 // D += R^T Ow R (symmetric packing), b -= R^T Ow e, blk = R^T Ow C (block towards the other endpoint).  The arithmetic of
@@ -142,16 +144,18 @@ __device__ __forceinline__ bool sym3_inverse(const double (&d)[6], double (&v)[6
 }
 
 // ---------------------------------------------------------------------------- k_ov_solve
-// One workgroup.  Block-tridiagonal LDL^T of H_NN along the chain with the ncol right-hand sides [H_NT | b_N] on the lanes
-// of wave 0 (every lane repeats the 3x3 pivot arithmetic: uniform), the chain walked in LDS tiles of kOvTile rows that all
-// threads load and store; then M = M0 - H_TN Y (symmetrised) and g = bt - H_TN y_b, which is added to the touched rows'
+// One workgroup.  Block-tridiagonal LDL^T of H_NN along the chain with the ncol right-hand sides [H_NT | b_N] on the THREADS
+// of the workgroup (round 6; one wave's lanes before: 16 kept rows at most), one column each; every thread repeats the 3x3
+// pivot arithmetic (uniform: same inputs from LDS, same registers, same order -- no hand-over between the waves inside a tile:
+// a column is private to its thread), the chain walked in LDS tiles of kOvTile rows that all threads load and store; then M = M0 - H_TN Y (symmetrised) and g = bt - H_TN y_b, which is added to the touched rows'
 // right-hand sides in dgb.  A pivot block that is not positive definite (an appended chain that hangs in the air) makes
 // g non-finite: the PCG start then reports a breakdown, as for any Hessian that is not positive definite.
 __global__ __launch_bounds__(kOvThreads) void k_ov_solve(OverlayDev O, double* __restrict__ dgb) {
   __shared__ double Yt[3 * kOvTile * kOvCols];
   __shared__ double Dt[kOvTile * 6], Ut[kOvTile * 9], Sv[kOvTile * 6];
+  __shared__ double fcol[3 * kOvMaxHubs];
   __shared__ int fail, bad_x;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x;
   const int k = O.k, nc = O.ncol, nk3 = 3 * (O.nt + O.nx);
   if (tid == 0) fail = bad_x = 0;
   __syncthreads();
@@ -163,14 +167,14 @@ __global__ __launch_bounds__(kOvThreads) void k_ov_solve(OverlayDev O, double* _
     for (int i = tid; i < 6 * rows; i += kOvThreads) Dt[i] = O.Dn[6 * (size_t)t0 + i];
     for (int i = tid; i < 9 * rows; i += kOvThreads) Ut[i] = O.Un[9 * (size_t)t0 + i];
     __syncthreads();
-    if (wave == 0) {
+    {
       for (int i = 0; i < rows; ++i) {
         double S[6];
 #pragma unroll
         for (int q = 0; q < 6; ++q) S[q] = Dt[6 * i + q];
         double r[3] = {0, 0, 0};
-        if (lane < nc) {
-          r[0] = Yt[(3 * i) * nc + lane]; r[1] = Yt[(3 * i + 1) * nc + lane]; r[2] = Yt[(3 * i + 2) * nc + lane];
+        if (tid < nc) {
+          r[0] = Yt[(3 * i) * nc + tid]; r[1] = Yt[(3 * i + 1) * nc + tid]; r[2] = Yt[(3 * i + 2) * nc + tid];
         }
         if (t0 + i > 0) {
           // L = U_prev^T Sinv_prev ; S -= L U_prev ; r -= L r_prev
@@ -190,10 +194,10 @@ __global__ __launch_bounds__(kOvThreads) void k_ov_solve(OverlayDev O, double* _
           for (int a = 0; a < 3; ++a) r[a] -= L[3 * a] * rpv[0] + L[3 * a + 1] * rpv[1] + L[3 * a + 2] * rpv[2];
         }
         double si[6];
-        if (!sym3_inverse(S, si) && lane == 0) fail = 1;
-        if (lane < 6) Sv[6 * i + lane] = si[lane];
-        if (lane < nc) {
-          Yt[(3 * i) * nc + lane] = r[0]; Yt[(3 * i + 1) * nc + lane] = r[1]; Yt[(3 * i + 2) * nc + lane] = r[2];
+        if (!sym3_inverse(S, si) && tid == 0) fail = 1;
+        if (tid < 6) Sv[6 * i + tid] = si[tid];
+        if (tid < nc) {
+          Yt[(3 * i) * nc + tid] = r[0]; Yt[(3 * i + 1) * nc + tid] = r[1]; Yt[(3 * i + 2) * nc + tid] = r[2];
         }
 #pragma unroll
         for (int q = 0; q < 6; ++q) sp[q] = si[q];
@@ -216,9 +220,9 @@ __global__ __launch_bounds__(kOvThreads) void k_ov_solve(OverlayDev O, double* _
     for (int i = tid; i < 6 * rows; i += kOvThreads) Sv[i] = O.Sinv[6 * (size_t)t0 + i];
     for (int i = tid; i < 9 * rows; i += kOvThreads) Ut[i] = O.Un[9 * (size_t)t0 + i];
     __syncthreads();
-    if (wave == 0 && lane < nc) {
+    if (tid < nc) {
       for (int i = rows - 1; i >= 0; --i) {
-        double r[3] = {Yt[(3 * i) * nc + lane], Yt[(3 * i + 1) * nc + lane], Yt[(3 * i + 2) * nc + lane]};
+        double r[3] = {Yt[(3 * i) * nc + tid], Yt[(3 * i + 1) * nc + tid], Yt[(3 * i + 2) * nc + tid]};
         if (t0 + i < k - 1) {
           const double* U = Ut + 9 * i;
 #pragma unroll
@@ -228,7 +232,7 @@ __global__ __launch_bounds__(kOvThreads) void k_ov_solve(OverlayDev O, double* _
         yn[0] = v[0] * r[0] + v[1] * r[1] + v[2] * r[2];
         yn[1] = v[1] * r[0] + v[3] * r[1] + v[4] * r[2];
         yn[2] = v[2] * r[0] + v[4] * r[1] + v[5] * r[2];
-        Yt[(3 * i) * nc + lane] = yn[0]; Yt[(3 * i + 1) * nc + lane] = yn[1]; Yt[(3 * i + 2) * nc + lane] = yn[2];
+        Yt[(3 * i) * nc + tid] = yn[0]; Yt[(3 * i + 1) * nc + tid] = yn[1]; Yt[(3 * i + 2) * nc + tid] = yn[2];
       }
     }
     __syncthreads();
@@ -267,24 +271,27 @@ __global__ __launch_bounds__(kOvThreads) void k_ov_solve(OverlayDev O, double* _
       G[e] = c2 < nx3 ? O.S[(nt3 + r2) * nk3 + nt3 + c2] : (c2 < nx3 + nt3 ? O.S[(nt3 + r2) * nk3 + (c2 - nx3)] : O.gk[nt3 + r2]);
     }
     __syncthreads();
-    if (wave == 0) {
-      // reduced row echelon form of [S_XX | S_XT | g_X]: lane c owns column c.  Within a step every lane reads what it needs
-      // of the pivot row / the pivot column's factor before the instruction that overwrites it (one instruction stream).
-      for (int pv = 0; pv < nx3; ++pv) {
-        const double piv = G[pv * gw + pv];
-        if (lane == 0 && (!(piv > 0.0) || !isfinite(piv))) bad_x = 1;
-        const double ip = piv != 0.0 ? 1.0 / piv : 0.0;
-        const double prow = lane < gw ? G[pv * gw + lane] * ip : 0.0;
+    // reduced row echelon form of [S_XX | S_XT | g_X]: thread c owns column c (gw <= 3 x 64 + 1 columns: several waves).  Per pivot:
+    // the pivot column's factors are copied aside and the scaled pivot row taken into registers BEFORE anything is overwritten
+    // (a barrier in between: the waves are not in lockstep), then every thread updates its own column.
+    for (int pv = 0; pv < nx3; ++pv) {
+      const double piv = G[pv * gw + pv];
+      if (tid == 0 && (!(piv > 0.0) || !isfinite(piv))) bad_x = 1;
+      const double ip = piv != 0.0 ? 1.0 / piv : 0.0;
+      const double prow = tid < gw ? G[pv * gw + tid] * ip : 0.0;
+      if (tid < nx3) fcol[tid] = G[tid * gw + pv];
+      __syncthreads();
+      if (tid < gw) {
         for (int r2 = 0; r2 < nx3; ++r2) {
           if (r2 == pv) continue;
-          const double f = G[r2 * gw + pv];
-          if (lane < gw) G[r2 * gw + lane] -= f * prow;
+          G[r2 * gw + tid] -= fcol[r2] * prow;
         }
-        if (lane < gw) G[pv * gw + lane] = prow;
+        G[pv * gw + tid] = prow;
       }
-      // W = S_XX^-1 [S_XT | g_X] sits in the columns nx3 .. gw-1
-      for (int e = lane; e < nx3 * (nt3 + 1); e += 64) O.Wx[e] = G[(e / (nt3 + 1)) * gw + nx3 + e % (nt3 + 1)];
+      __syncthreads();
     }
+    // W = S_XX^-1 [S_XT | g_X] sits in the columns nx3 .. gw-1
+    for (int e = tid; e < nx3 * (nt3 + 1); e += kOvThreads) O.Wx[e] = G[(e / (nt3 + 1)) * gw + nx3 + e % (nt3 + 1)];
     __syncthreads();
   }
   const bool failed = bad || bad_x != 0;
@@ -310,10 +317,11 @@ __global__ __launch_bounds__(kOvThreads) void k_ov_solve(OverlayDev O, double* _
 // q_T += M p_T after the base product H_base p; the dot product p . q of the PCG recurrence gets its share added to the
 // product's first partial sum (single writer, after the product kernel: fixed order).  One wave.  The sizes come from the
 // device-resident header so that a captured hipGraph stays valid across updates.
-__global__ __launch_bounds__(64) void k_ov_ax(const int* __restrict__ hdr, const int* __restrict__ trow, const double* __restrict__ M,
-                                              const double* __restrict__ p, double* __restrict__ q, double* __restrict__ partials0,
-                                              const PcgScalars* S) {
+__global__ __launch_bounds__(kOvThreads) void k_ov_ax(const int* __restrict__ hdr, const int* __restrict__ trow, const double* __restrict__ M,
+                                                      const double* __restrict__ p, double* __restrict__ q, double* __restrict__ partials0,
+                                                      const PcgScalars* S) {
   __shared__ double pt[3 * kOvMaxTouched];
+  __shared__ double ws[kOvThreads / 64];
   if (S && S->stop) return;
   const int nt3 = 3 * hdr[1], r = threadIdx.x;
   if (nt3 == 0) return;
@@ -329,9 +337,15 @@ __global__ __launch_bounds__(64) void k_ov_ax(const int* __restrict__ hdr, const
     q[at] += d;
     d *= pt[r];
   }
-  if (partials0) {
+  if (partials0) {   // the waves' sums, added in wave order by one thread (fixed order)
     const double s = wave_sum(d);
-    if (r == 0) partials0[0] += s;
+    if ((r & 63) == 0) ws[r >> 6] = s;
+    __syncthreads();
+    if (r == 0) {
+      double t = ws[0];
+      for (int w = 1; w < kOvThreads / 64; ++w) t += ws[w];
+      partials0[0] += t;
+    }
   }
 }
 
@@ -381,7 +395,7 @@ void launch_ov_solve(hipStream_t s, const OverlayDev& O, double* dgb) {
   if (O.k + O.nt + O.nx > 0) SGO_LAUNCH(k_ov_solve, dim3(1), dim3(kOvThreads), 0, s, O, dgb);
 }
 void launch_ov_ax(hipStream_t s, const OverlayDev& O, const double* p, double* q, double* partials0, const PcgScalars* S) {
-  SGO_LAUNCH(k_ov_ax, dim3(1), dim3(64), 0, s, O.hdr, O.trow, (const double*)O.M, p, q, partials0, S);
+  SGO_LAUNCH(k_ov_ax, dim3(1), dim3(kOvThreads), 0, s, O.hdr, O.trow, (const double*)O.M, p, q, partials0, S);
 }
 void launch_ov_finish(hipStream_t s, const OverlayDev& O, const double* x, double* poses) {
   if (O.k + O.nx > 0) SGO_LAUNCH(k_ov_finish, dim3(std::max(1, (O.k + kOvThreads - 1) / kOvThreads)), dim3(kOvThreads), 0, s, O, x, poses);
@@ -566,6 +580,7 @@ bool overlay_build(Overlay& ov, int V, hipStream_t s, std::string* why, std::str
   const int k = (int)chain_v.size(), nx = (int)hub_v.size(), nk = nt + nx;
   if (nnew > kOvMaxRows) { *why = "more appended poses than the overlay holds"; return false; }
   if (nk > kOvMaxTouched) { *why = "the appended edges end in more resident rows (and hub poses) than the overlay holds"; return false; }
+  if (nx > kOvMaxHubs) { *why = "more hub poses among the appended ones than the overlay holds"; return false; }
   auto code = [&](int v) -> int {   // >= 0 chain row, -1 - t kept row t (touched base rows, then hubs), kOvOtherFixed
     if (ov.fixed[v]) return kOvOtherFixed;
     const int br = base_row(v);

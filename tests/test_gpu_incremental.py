@@ -149,20 +149,37 @@ def test_non_chain_edges_among_appended_poses_become_hubs():
     assert "(2 hubs)" in desc, desc
 
 
+def test_many_touched_rows_and_hubs_stay_incremental():
+    """Round 6: the overlay keeps up to 64 touched + hub rows (16 before: the right-hand sides of the chain's elimination sat on the
+    lanes of one wave; they sit on the threads of the workgroup now, 3 x 64 + 1 columns) and up to 8 hubs.  40 closures into 40
+    different resident poses from poses all along the appended chain + 6 closures inside the chain (6 hubs): 48 kept rows, 145
+    right-hand-side columns -- three waves' worth --; the iterates are a fresh set-up's."""
+    def mutate(st, base):
+        for q in range(40):
+            _add_edge(st, base.V + (q % 16), 50 + 57 * q, phi=1.0)
+        for q in range(6):
+            _add_edge(st, base.V + q, base.V + q + 8, phi=1.0)
+    desc, d = _one_update(mutate, True)
+    assert "(6 hubs), 42 touched rows" in desc, desc   # (40 + the chain's anchor + the step's own closure)
+    assert d == 6
+
+
 def test_changed_prefix_and_too_many_touched_rows_fall_back():
     def mutate(st, base):
-        for q in range(20):                        # 20 closures into 20 different resident poses: more than the overlay's 16 touched rows
-            _add_edge(st, base.V + 8, 50 + 37 * q, phi=1.0)
+        for q in range(70):                        # 70 closures into 70 different resident poses: more than the overlay's 64 kept rows
+            _add_edge(st, base.V + 8, 50 + 31 * q, phi=1.0)
     desc, d = _one_update(mutate, False)
     assert "more resident rows" in desc
 
-    def mutate2(st, base):                         # nine disjoint closures inside the chain + the touched rows: over the 16 kept rows
+    def mutate2(st, base):                         # nine disjoint closures inside the chain: over the 8 hubs
         for q in range(7):
             _add_edge(st, base.V + q, base.V + q + 8, phi=1.0)
+        _add_edge(st, base.V + 7, base.V + 15, phi=1.0)
+        _add_edge(st, base.V + 0, base.V + 7, phi=1.0)
         for q in range(10):
             _add_edge(st, base.V + 3, 60 + 41 * q, phi=1.0)
     desc, d = _one_update(mutate2, False)
-    assert "more resident rows (and hub poses)" in desc
+    assert "more hub poses" in desc, desc
     base, steps, g = synth.append_session(2500, 10000, 1, 16, 5)
     V, fixed, ei, ej, meas, info, phi = _cat(base, steps, 1)
     with capi.Optimizer(0, direct_rows=0) as o:
