@@ -143,6 +143,7 @@ struct sgo_ctx {
                                      // aggregation alone).  The multi-GPU modes keep the host set-up.
     bool dev_aggregation = false;    // SGO_AMG_AGG=device: the device set-up aggregates on the device too (a parallel independent-set
                                      // aggregation: weaker hierarchies, measured; default: the host's greedy aggregation)
+    int rebuild_cost = 150;          // SGO_AMG_REBUILD_COST (sweep knob): what the count rules take a set-up to be worth, in PCG iterations
     bool force_rebuild = false;      // SGO_AMG_FORCE_REBUILD (test hook): the hierarchy is re-made before the call's first solve
   } knobs;
   bool test_fail_trial_build = false;

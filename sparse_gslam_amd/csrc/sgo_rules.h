@@ -29,10 +29,11 @@ struct Staleness {
   bool doubled, pays;
   bool rebuild() const { return doubled || pays; }
 };
-inline Staleness staleness(int eq_iter, int call_best, int iterations_left) {
+constexpr int kRebuildCostIters = 150;   // what a set-up is worth in PCG iterations (swept: NOTES.md sections 27, 30)
+inline Staleness staleness(int eq_iter, int call_best, int iterations_left, int cost_iters = kRebuildCostIters) {
   Staleness s;
   s.doubled = eq_iter > 2 * call_best + 10;
-  s.pays = 4 * eq_iter > 5 * call_best && (long long)(eq_iter - call_best) * iterations_left > 150;
+  s.pays = 4 * eq_iter > 5 * call_best && (long long)(eq_iter - call_best) * iterations_left > cost_iters;
   return s;
 }
 

@@ -519,6 +519,7 @@ void read_call_knobs(sgo_ctx* c) {
   if (const char* e = std::getenv("SGO_AMG_SETUP")) k.setup_mode = std::string(e) == "host" ? 0 : (std::string(e) == "rebuilds" ? 1 : 2);
   if (const char* e = std::getenv("SGO_AMG_FORCE_REBUILD")) k.force_rebuild = std::atoi(e) != 0;
   if (const char* e = std::getenv("SGO_AMG_AGG")) k.dev_aggregation = std::string(e) == "device";
+  if (const char* e = std::getenv("SGO_AMG_REBUILD_COST")) k.rebuild_cost = std::max(1, std::atoi(e));
   c->knobs = k;
   c->test_fail_trial_build = k.fail_trial_build;
 }
@@ -1268,7 +1269,7 @@ int optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
         // start then found useless: 2.2 instead of 1.4 s per call.  Staleness across calls is the movement rule's business, below.)
         if (call_best == 0 || eq_iter < call_best) call_best = eq_iter;
         const int left = iters - it - 1;
-        if (rebuilds < max_rebuilds && rules::staleness(eq_iter, call_best, left).rebuild()) rebuild_next = true;
+        if (rebuilds < max_rebuilds && rules::staleness(eq_iter, call_best, left, c->knobs.rebuild_cost).rebuild()) rebuild_next = true;
         // The aggregation's own staleness, across calls: the hierarchy was aggregated from blocks that have since moved a lot -- a
         // graph set up at poor poses and optimised since -- and this call's first solve needs visibly more iterations than the
         // hierarchy's best.  The count rules above weigh a rebuild against the iterations left in THIS call; the reference calls
