@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define SGO_VERSION 106          /* 0.1.6: sgo_plan_rows takes the measurements (row order of graphs whose poses contradict their closures); 0.1.5: the multifrontal path for mid-size graphs (sgo_mfront_plan; sgo_solver_description names it); 0.1.4: sgo_kernel_profile_samples, sgo_update_graph_se2 (incremental set-up); 0.1.3: row-owner multi-GPU mode (sgo_comm_host_allgather, sgo_debug_level0_bytes); 0.1.2: sgo_comm_init_host; 0.1.1: sgo_opts.direct_rows (took a reserved slot), sgo_solver_description */
+#define SGO_VERSION 107          /* 0.1.7: sgo_stats.pcg_converged may be 2 (a solve accepted at the floating-point floor of its system), the incremental overlay keeps 64 touched + hub rows, SGO_AMG_SETUP (no signature changed); 0.1.6: sgo_plan_rows takes the measurements (row order of graphs whose poses contradict their closures); 0.1.5: the multifrontal path for mid-size graphs (sgo_mfront_plan; sgo_solver_description names it); 0.1.4: sgo_kernel_profile_samples, sgo_update_graph_se2 (incremental set-up); 0.1.3: row-owner multi-GPU mode (sgo_comm_host_allgather, sgo_debug_level0_bytes); 0.1.2: sgo_comm_init_host; 0.1.1: sgo_opts.direct_rows (took a reserved slot), sgo_solver_description */
 #define SGO_MAX_ITERS 256        /* capacity of the per-iteration arrays in sgo_stats */
 
 /* error codes (negative).  -1 mirrors g2o's optimize() "nothing to optimise". */
@@ -122,7 +122,7 @@ typedef struct sgo_opts {
  *     movement a solve may keep its coarse operators over, 0.006)
  *   multi-GPU: SGO_COMM_MODE={owner,allreduce}, SGO_COMM_GRAPH (see sgo_comm_init), SGO_OWNER_MIN_ROWS, SGO_RCCL_LIB (library path)
  *   test hooks and A/B switches of scripts/ (not for production): SGO_AMG_LISTS=host, SGO_SETUP_PIPELINE, SGO_TILE_LDS,
- *     SGO_FIRST_SOLVE_CAP, SGO_PCG_STALL_WINDOW, SGO_TEST_FAIL_TRIAL_BUILD, SGO_AMG_FORCE_REBUILD, SGO_AMG_KEEP_AGG, SGO_MIRROR, SGO_LANCZOS (sgo_debug_lanczos), SGO_MFRONT_DEBUG, SGO_AMG_LAG_FORCE / SGO_AMG_LAG_SLOPE
+ *     SGO_FIRST_SOLVE_CAP, SGO_PCG_STALL_WINDOW, SGO_TEST_FAIL_TRIAL_BUILD, SGO_AMG_FORCE_REBUILD, SGO_AMG_KEEP_AGG, SGO_AMG_REBUILD_COST, SGO_MIRROR, SGO_LANCZOS (sgo_debug_lanczos), SGO_MFRONT_DEBUG, SGO_AMG_LAG_FORCE / SGO_AMG_LAG_SLOPE
  *     (scripts/lag_calib.py, tests/test_gpu_lagged_refresh.py)
  * Removed in round 5 (measured, not kept: NOTES.md sections 9-10): SGO_DEFLATE, SGO_OWNER_XS_EXCHANGE, SGO_MFRONT_FUSED_SOLVE.
  * Of the interface SURVEY.md section 8(b) sketched, three items do not exist, on purpose: SGO_NGPU (one process per GPU: the

@@ -23,7 +23,7 @@ def test_header_and_binding_agree():
 def test_library_exports_every_declared_symbol(sgo_lib):
     for name in _declared_symbols():
         assert hasattr(sgo_lib, name), name
-    assert sgo_lib.sgo_version() == 106
+    assert sgo_lib.sgo_version() == 107
 
 
 def test_struct_sizes_match_header(sgo_lib):
