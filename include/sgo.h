@@ -122,7 +122,7 @@ typedef struct sgo_opts {
  *     movement a solve may keep its coarse operators over, 0.006)
  *   multi-GPU: SGO_COMM_MODE={owner,allreduce}, SGO_COMM_GRAPH (see sgo_comm_init), SGO_OWNER_MIN_ROWS, SGO_RCCL_LIB (library path)
  *   test hooks and A/B switches of scripts/ (not for production): SGO_AMG_LISTS=host, SGO_SETUP_PIPELINE, SGO_TILE_LDS,
- *     SGO_FIRST_SOLVE_CAP, SGO_PCG_STALL_WINDOW, SGO_TEST_FAIL_TRIAL_BUILD, SGO_AMG_FORCE_REBUILD, SGO_AMG_KEEP_AGG, SGO_AMG_REBUILD_COST, SGO_MIRROR, SGO_LANCZOS (sgo_debug_lanczos), SGO_MFRONT_DEBUG, SGO_AMG_LAG_FORCE / SGO_AMG_LAG_SLOPE
+ *     SGO_FIRST_SOLVE_CAP, SGO_PCG_STALL_WINDOW, SGO_TEST_FAIL_TRIAL_BUILD, SGO_TEST_FAIL_DEVICE_SETUP, SGO_AMG_FORCE_REBUILD, SGO_AMG_KEEP_AGG, SGO_AMG_REBUILD_COST, SGO_MIRROR, SGO_LANCZOS (sgo_debug_lanczos), SGO_MFRONT_DEBUG, SGO_AMG_LAG_FORCE / SGO_AMG_LAG_SLOPE
  *     (scripts/lag_calib.py, tests/test_gpu_lagged_refresh.py)
  * Removed in round 5 (measured, not kept: NOTES.md sections 9-10): SGO_DEFLATE, SGO_OWNER_XS_EXCHANGE, SGO_MFRONT_FUSED_SOLVE.
  * Of the interface SURVEY.md section 8(b) sketched, three items do not exist, on purpose: SGO_NGPU (one process per GPU: the

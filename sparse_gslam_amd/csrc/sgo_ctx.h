@@ -136,6 +136,7 @@ struct sgo_ctx {
     int stall_window = -1;        // SGO_PCG_STALL_WINDOW: -1 unset
     int first_solve_cap = 600;    // SGO_FIRST_SOLVE_CAP (test hook)
     bool fail_trial_build = false;   // SGO_TEST_FAIL_TRIAL_BUILD (test hook: the re-aggregation trial's set-up "fails")
+    bool fail_device_setup = false;  // SGO_TEST_FAIL_DEVICE_SETUP (test hook: the device set-up "fails", the host set-up takes over)
     bool keep_agg = false;           // SGO_AMG_KEEP_AGG: a rebuild inside the call keeps the replaced hierarchy's aggregates
     int setup_mode = 2;              // SGO_AMG_SETUP: host (0: the host's aggregation, patterns and lists for every set-up, as before round 6),
                                      // rebuilds (1: the patterns on the device for the rebuilds inside sgo_optimize_gn only), device (2, the

@@ -515,6 +515,7 @@ void read_call_knobs(sgo_ctx* c) {
   if (const char* e = std::getenv("SGO_PCG_STALL_WINDOW")) k.stall_window = std::max(0, std::atoi(e));
   if (const char* e = std::getenv("SGO_FIRST_SOLVE_CAP")) k.first_solve_cap = std::max(1, std::atoi(e));
   if (const char* e = std::getenv("SGO_TEST_FAIL_TRIAL_BUILD")) k.fail_trial_build = std::atoi(e) != 0;
+  if (const char* e = std::getenv("SGO_TEST_FAIL_DEVICE_SETUP")) k.fail_device_setup = std::atoi(e) != 0;
   if (const char* e = std::getenv("SGO_AMG_KEEP_AGG")) k.keep_agg = std::atoi(e) != 0;
   if (const char* e = std::getenv("SGO_AMG_SETUP")) k.setup_mode = std::string(e) == "host" ? 0 : (std::string(e) == "rebuilds" ? 1 : 2);
   if (const char* e = std::getenv("SGO_AMG_FORCE_REBUILD")) k.force_rebuild = std::atoi(e) != 0;
@@ -754,9 +755,21 @@ int build_amg(sgo_ctx* c, bool keep_old, bool keep_agg) {
   if (dev_setup)
     c->amg = amg_create_dev(c->stream, c->A, c->S0, c->T0, c->H0, c->d_poses, c->d_free_id, cfg, prof, &aerr, &c->amg_scratch, &c->amg_arena,
                             &c->amg_tmp_arena, c->knobs.dev_aggregation, pre0_agg ? c->l0_pre : nullptr);
-  else
-  c->amg = amg_create(c->stream, c->A, c->S0, c->T0, c->H0, c->d_poses, c->d_free_id, cfg, prof, &aerr, &c->amg_scratch,
-                      &c->amg_arena, c->l0_pre, c->owner ? &ah : nullptr);
+  if (dev_setup && c->amg && c->knobs.fail_device_setup) {   // test hook (SGO_TEST_FAIL_DEVICE_SETUP): the device set-up "fails"
+    amg_destroy(c->amg);
+    c->amg = nullptr;
+    aerr = "test hook";
+  }
+  if (dev_setup && !c->amg) {
+    // (the device set-up could not be made -- out of device memory for its sort buffers, say --: the host set-up, which needs
+    // none, before the graph is left to block-Jacobi; a helper thread's aggregation-only result is of no use to it)
+    if (c->opts.verbose) std::fprintf(stderr, "[sgo] device set-up failed (%s): host set-up\n", aerr.c_str());
+    c->amg_arena.rewind();
+    aerr.clear();
+  }
+  if (!c->amg)
+    c->amg = amg_create(c->stream, c->A, c->S0, c->T0, c->H0, c->d_poses, c->d_free_id, cfg, prof, &aerr, &c->amg_scratch,
+                        &c->amg_arena, pre0_agg ? nullptr : c->l0_pre, c->owner ? &ah : nullptr);
   l0_discard(c);
   if (c->opts.verbose)
     std::fprintf(stderr, "[sgo] multigrid set-up (%s): %.2f ms\n", dev_setup ? (c->knobs.dev_aggregation ? "aggregation and patterns on the device" : "host aggregation, patterns on the device") : "host", 1e3 * (wall_s() - t_create0));

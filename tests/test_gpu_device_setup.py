@@ -121,3 +121,29 @@ def test_device_rebuilds_from_the_dead_reckoned_start(monkeypatch):
     assert res["rebuilds"][1]["pcg_iters"][:20] == res["host"][1]["pcg_iters"][:20]
     assert list(res["rebuilds"][1]["chi2"][:21]) == list(res["host"][1]["chi2"][:21])
     assert res["rebuilds"][1]["seconds_total"] <= 0.9 * res["host"][1]["seconds_total"]
+
+
+def test_a_device_set_up_that_fails_falls_back_to_the_host_set_up(monkeypatch, capfd):
+    """Out of device memory for the sort buffers, say (here: a test hook): the host set-up, which needs none, takes over -- at
+    sgo_set_graph_se2 (where the helper thread has made level 0's aggregation only, which the host set-up cannot use) and for a
+    rebuild --, and the call is the host call."""
+    monkeypatch.setenv("SGO_MFRONT", "0")
+    g = synth.config("C4")
+    out = {}
+    for mode, fail in (("host", "0"), ("device", "1")):
+        monkeypatch.setenv("SGO_AMG_SETUP", mode)
+        monkeypatch.setenv("SGO_TEST_FAIL_DEVICE_SETUP", fail)
+        monkeypatch.setenv("SGO_AMG_FORCE_REBUILD", "1")
+        monkeypatch.setenv("SGO_VERBOSE", "1")
+        with capi.Optimizer(0, direct_rows=0) as opt:
+            opt.set_graph(*g.arrays())
+            desc = opt.solver_description()
+            done, st = opt.optimize(3)
+            out[mode] = (done, st, desc, capfd.readouterr().err)
+    for k in ("SGO_AMG_SETUP", "SGO_TEST_FAIL_DEVICE_SETUP", "SGO_AMG_FORCE_REBUILD", "SGO_VERBOSE"):
+        monkeypatch.delenv(k)
+    assert out["device"][3].count("device set-up failed (test hook): host set-up") == 2, out["device"][3][-2000:]
+    assert out["device"][2].startswith("pcg_amg") and out["device"][2] == out["host"][2]
+    assert out["device"][0] == 3 and out["host"][0] == 3
+    assert out["host"][1]["pcg_iters"][:3] == out["device"][1]["pcg_iters"][:3]
+    assert list(out["host"][1]["chi2"][:4]) == list(out["device"][1]["chi2"][:4])
