@@ -582,12 +582,22 @@ def main():
             med = kk.get("median_us", 1e3 * kk["ms"] / kk["launches"])
             ach = bpl / (med * 1e-6) / 1e9
             tr, tr_src, ins = None, None, None
+            # (both summaries record the hash of the kernel sources they were taken on: `..._current` says whether those are
+            # the sources of the library this run loaded -- VERDICT round 5: "nothing checks it")
+            sys.path.insert(0, os.path.join(ROOT, "scripts"))
+            from pmc_summary import kernel_source_sha16
+            now_sha = kernel_source_sha16()
+            tr_cur = ins_cur = None
             for cand in sorted(_glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_traffic_{solver_name}_{args.config.lower()}.json"))):
-                e = json.load(open(cand))["kernels"].get(kname)
+                doc = json.load(open(cand))
+                e = doc["kernels"].get(kname)
                 if e:
                     tr, tr_src = e["hbm_bytes_per_launch"], os.path.relpath(cand, ROOT)
+                    tr_cur = doc.get("kernel_source_sha16") == now_sha
             for cand in sorted(_glob.glob(os.path.join(ROOT, "profiles", f"r*_trace_summary_{args.config.lower()}_graph.json"))):
-                e = json.load(open(cand))["kernels"].get(kname)
+                doc = json.load(open(cand))
+                e = doc["kernels"].get(kname)
+                ins_cur = doc.get("kernel_source_sha16") == now_sha if e else ins_cur
                 if e:
                     ins = {"median_us": e["median_us"], "p10_us": e["p10_us"], "p90_us": e["p90_us"],
                            "working_dispatches": e["working"], "dispatches": e["dispatches"],
@@ -597,6 +607,7 @@ def main():
                            "source": os.path.relpath(cand, ROOT)}
             return {"kernel": kname, "achieved": ach, "frac": ach / HBM_PEAK_GBS, "frac_of_measured_copy": ach / HBM_COPY_GBS,
                     "traffic": tr, "traffic_source": tr_src, "traffic_over_algorithmic": (tr / bpl) if tr else None,
+                    "traffic_source_taken_on_these_kernel_sources": tr_cur, "in_solve_source_taken_on_these_kernel_sources": ins_cur,
                     "median_launch_us": med, "p10_launch_us": kk.get("p10_us"), "p90_launch_us": kk.get("p90_us"),
                     "avg_launch_us": 1e3 * kk["ms"] / kk["launches"], "launches": kk["launches"],
                     "algorithmic_bytes_per_launch": bpl, "in_solve": ins}

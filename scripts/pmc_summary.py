@@ -31,6 +31,19 @@ def load(d, counter):
     return out
 
 
+
+def kernel_source_sha16():
+    """sha256 (first 16 hex digits) of the sources the solve's kernels are compiled from (sgo_kernels.hip, sgo_device.h): recorded
+    with every summary so that bench.py can say whether the profile it quotes was taken on the kernels it runs."""
+    import hashlib
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = hashlib.sha256()
+    for f in ("sgo_kernels.hip", "sgo_device.h"):
+        h.update(open(os.path.join(root, "sparse_gslam_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def main():
     fd, wd = sys.argv[1], sys.argv[2]
     F, W = load(fd, "FETCH_SIZE"), load(wd, "WRITE_SIZE")
@@ -43,7 +56,7 @@ def main():
         res[k] = {"launches": n, "fetch_bytes_per_launch": fetch, "write_bytes_per_launch": write,
                   "hbm_bytes_per_launch": fetch + write}
     json.dump({"unit": "bytes per launch (mean over launches)", "corrections": "FETCH_SIZE x2 x1024, WRITE_SIZE x1024",
-               "kernels": res}, sys.stdout, indent=1)
+               "kernel_source_sha16": kernel_source_sha16(), "kernels": res}, sys.stdout, indent=1)
 
 
 if __name__ == "__main__":

@@ -20,6 +20,10 @@ import sys
 import numpy as np
 
 
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__)))
+
+
 def main():
     d, out_json = sys.argv[1], sys.argv[2]
     out_csv = sys.argv[3] if len(sys.argv) > 3 else None
@@ -46,6 +50,7 @@ def main():
     order = sorted(res, key=lambda k: -res[k]["sum_working_ms"])
     json.dump({"unit": "microseconds per dispatch", "rule": "working = duration >= max(3 us, 0.3 x p90) (early-exit launches past "
                "convergence dropped); kernels that never reach 3 us keep all dispatches", "trace_files": len(files),
+               "kernel_source_sha16": __import__("pmc_summary").kernel_source_sha16(),
                "kernels": {k: res[k] for k in order}}, open(out_json, "w"), indent=1)
     if out_csv:
         with open(out_csv, "w") as fh:
