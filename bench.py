@@ -628,6 +628,8 @@ def main():
             "bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "frac_of_measured_copy": achieved / HBM_COPY_GBS, "measured_copy_GBs": HBM_COPY_GBS,
             "traffic": traffic, "traffic_source": traffic_src,
+            "traffic_source_taken_on_these_kernel_sources": dom["traffic_source_taken_on_these_kernel_sources"],
+            "in_solve_source_taken_on_these_kernel_sources": dom["in_solve_source_taken_on_these_kernel_sources"],
             "median_launch_us": med_us, "p10_launch_us": k.get("p10_us"), "p90_launch_us": k.get("p90_us"),
             "avg_launch_us": 1e3 * k["ms"] / k["launches"], "launches": k["launches"],
             "event_bracket_overhead_us": overhead_us,
