@@ -149,6 +149,7 @@ struct sgo_ctx {
   } knobs;
   bool test_fail_trial_build = false;
   bool in_optimize = false;       // inside sgo_optimize_gn (build_amg: which set-up a rebuild takes)
+  bool floor_seen = false;        // a solve of the current call was accepted at the floating-point floor (run_pcg: a shorter stagnation window)
   AmgKeptAgg kept_agg;            // (what such a rebuild keeps: host copies, taken from the hierarchy before it is destroyed)
   double* d_poses = nullptr;
   int* d_free_id = nullptr;

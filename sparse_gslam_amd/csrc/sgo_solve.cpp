@@ -544,6 +544,9 @@ int run_pcg(sgo_ctx* c) {
   // PCG cannot finish in double precision otherwise grind on to pcg_maxit, three times per call.
   c->pcg_stalled = false;
   c->pcg_stall_window = multi_rank(c) ? 0 : std::max(3000, 30 * std::max(1, c->pcg_pred));
+  // (once a solve of this call has been accepted at the floating-point floor of its system -- optimize_gn, solve_backward_error --
+  // the call is at the edge of double precision: its later solves wait a tenth as long before they are looked at)
+  if (c->floor_seen && c->pcg_stall_window > 0) c->pcg_stall_window = std::max(300, 3 * std::max(1, c->pcg_pred));
   if (c->knobs.stall_window >= 0) c->pcg_stall_window = multi_rank(c) ? 0 : c->knobs.stall_window;   // (test hook; 0: no guard)
   double stall_rr = -1.0;
   int stall_it = 0;
@@ -1035,6 +1038,7 @@ int optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
         c->amg_lag_on = false;
         c->amg_skip_update = false;
         c->in_optimize = false;
+        c->floor_seen = false;
       }
     } softcap_guard{c};
     // Lagged refresh of the coarse operators (do_linearize): on by default on one GPU (the sharded modes refresh before every solve:
@@ -1162,6 +1166,7 @@ int optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
         floor_accept = eta <= kFloorEta;
         if (floor_accept) {
           ++floor_solves;
+          c->floor_seen = true;
           if (c->opts.verbose)
             std::fprintf(stderr, "[sgo] iteration %d: the solve's x is at the floating-point floor of its system (backward error %.1e <= %.0e): step applied\n", it, eta, kFloorEta);
         }
