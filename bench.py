@@ -316,10 +316,12 @@ def incremental_session(device: int, V: int, E: int, seed: int, steps: int = 12,
     return {"workload": f"append_session(V={V}, E={E}, seed={seed}): {steps} closures, each {chain} new poses + odometry + 1 closure, "
                         f"optimize({iters}) after each",
             "update_ms_median": med(t_up), "update_ms_min_max": [float(min(t_up)), float(max(t_up))],
-            # (median + median, not the median of the sums: single updates carry the 15-30 ms a stream takes to come back after the
-            # loop's host-side idle -- DESIGN.md section 5b, update_ms_min_max shows them --, and with five or seven of twelve
-            # affected the median of the sums jumps by 10 ms between two runs of the same code)
+            # (both definitions, ADVICE round 5: the sum of the medians -- what rounds 4-5 reported -- and the median of the
+            # per-closure sums; they differ when single updates are outliers, which the in-place arrays removed at the source:
+            # update_ms_min_max)
             "optimize_ms_median": med(t_opt), "setup_plus_optimize_ms": med(t_up) + med(t_opt),
+            "setup_plus_optimize_ms_median_of_sums": med([a + b for a, b in zip(t_up, t_opt)]),
+            "fresh_setup_plus_optimize_ms_median_of_sums": med([a + b for a, b in zip(t_set, t_fopt)]),
             "pcg_iters_per_gn_iter": its,
             "fresh_set_graph_ms_median": med(t_set), "fresh_optimize_ms_median": med(t_fopt),
             "fresh_setup_plus_optimize_ms": med(t_set) + med(t_fopt), "fresh_pcg_iters_per_gn_iter": fits,
