@@ -518,6 +518,8 @@ void read_call_knobs(sgo_ctx* c) {
   if (const char* e = std::getenv("SGO_TEST_FAIL_DEVICE_SETUP")) k.fail_device_setup = std::atoi(e) != 0;
   if (const char* e = std::getenv("SGO_AMG_KEEP_AGG")) k.keep_agg = std::atoi(e) != 0;
   if (const char* e = std::getenv("SGO_AMG_SETUP")) k.setup_mode = std::string(e) == "host" ? 0 : (std::string(e) == "rebuilds" ? 1 : 2);
+  if (const char* e = std::getenv("SGO_AMG_LISTS"))   // (test hook: product lists made on the host -- they belong to the host set-up)
+    if (std::string(e) == "host") k.setup_mode = 0;
   if (const char* e = std::getenv("SGO_AMG_FORCE_REBUILD")) k.force_rebuild = std::atoi(e) != 0;
   if (const char* e = std::getenv("SGO_AMG_AGG")) k.dev_aggregation = std::string(e) == "device";
   if (const char* e = std::getenv("SGO_AMG_REBUILD_COST")) k.rebuild_cost = std::max(1, std::atoi(e));
