@@ -1,6 +1,10 @@
 // sgo_amg_host.h -- host side of the multigrid set-up (sgo_amg_host.cpp): aggregation, patterns of the smoothed transfer
 // and of the Galerkin products, structure of the next level.  No device code; amg_create (sgo_amg.hip) uploads what this
 // produces and makes the product lists on the device from the patterns.
+// Round 6: on one GPU the default set-up takes only the AGGREGATION from here (host_aggregate) and makes everything else on the
+// device (amg_create_dev, sgo_amg_dev.inc), bit-identical to what host_coarsen + amg_create produce; this path stays as the
+// multi-GPU modes' set-up, as SGO_AMG_SETUP=host, as the fallback of a device set-up that cannot be made, and as the reference the
+// device set-up is tested against (tests/test_gpu_device_setup.py).
 #pragma once
 #include <memory>
 #include <string>
