@@ -13,4 +13,9 @@ size_t sort_u64_temp_bytes(size_t n, int bits);
 // no synchronisation.  Returns false when rocPRIM reports an error.
 bool sort_u64(void* tmp, size_t tmp_bytes, const uint64_t* in, uint64_t* out, size_t n, int bits, hipStream_t s);
 
+// The same with a 32-bit value riding along with every key (stable: values of equal keys keep their input order).
+size_t sort_u64_u32_temp_bytes(size_t n, int bits);
+bool sort_u64_u32(void* tmp, size_t tmp_bytes, const uint64_t* keys_in, uint64_t* keys_out, const uint32_t* vals_in, uint32_t* vals_out,
+                  size_t n, int bits, hipStream_t s);
+
 }  // namespace sgo
