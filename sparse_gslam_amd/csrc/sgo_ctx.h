@@ -144,6 +144,10 @@ struct sgo_ctx {
                                      // aggregation alone).  The multi-GPU modes keep the host set-up.
     bool dev_aggregation = false;    // SGO_AMG_AGG=device: the device set-up aggregates on the device too (a parallel independent-set
                                      // aggregation: weaker hierarchies, measured; default: the host's greedy aggregation)
+    bool lag_on = true;              // SGO_AMG_LAG=0: the coarse operators are refreshed before every solve
+    double lag_tau = 0.006;          // SGO_AMG_LAG_TAU
+    double lag_slope = 0.0;          // SGO_AMG_LAG_SLOPE (test hook; 0: unset)
+    int lag_force_from = -1;         // SGO_AMG_LAG_FORCE (calibration hook, scripts/lag_calib.py)
     int rebuild_cost = 150;          // SGO_AMG_REBUILD_COST (sweep knob): what the count rules take a set-up to be worth, in PCG iterations
     bool force_rebuild = false;      // SGO_AMG_FORCE_REBUILD (test hook): the hierarchy is re-made before the call's first solve
   } knobs;

@@ -523,6 +523,10 @@ void read_call_knobs(sgo_ctx* c) {
   if (const char* e = std::getenv("SGO_AMG_FORCE_REBUILD")) k.force_rebuild = std::atoi(e) != 0;
   if (const char* e = std::getenv("SGO_AMG_AGG")) k.dev_aggregation = std::string(e) == "device";
   if (const char* e = std::getenv("SGO_AMG_REBUILD_COST")) k.rebuild_cost = std::max(1, std::atoi(e));
+  if (const char* e = std::getenv("SGO_AMG_LAG")) k.lag_on = std::atoi(e) != 0;
+  if (const char* e = std::getenv("SGO_AMG_LAG_TAU")) k.lag_tau = std::atof(e);
+  if (const char* e = std::getenv("SGO_AMG_LAG_SLOPE")) k.lag_slope = std::atof(e);
+  if (const char* e = std::getenv("SGO_AMG_LAG_FORCE")) k.lag_force_from = std::atoi(e);
   c->knobs = k;
   c->test_fail_trial_build = k.fail_trial_build;
 }
@@ -1046,23 +1050,23 @@ int optimize_gn(sgo_ctx* c, int32_t iters, sgo_stats* out) {
     // Lagged refresh of the coarse operators (do_linearize): on by default on one GPU (the sharded modes refresh before every solve:
     // a decision the ranks must take alike, not exercised on hardware); SGO_AMG_LAG=0 refreshes before every solve.
     // The call's first solve always refreshes (the incremental set-up's staleness rule compares first solves, sgo_ctx.h).
-    c->amg_lag_tau = std::getenv("SGO_AMG_LAG_TAU") ? std::atof(std::getenv("SGO_AMG_LAG_TAU")) : 0.006;
+    c->amg_lag_tau = c->knobs.lag_tau;
     c->amg_lag_rows = 32.0;
     if (c->amg_lag_n == 0 || std::abs(c->n - c->amg_lag_n) > c->amg_lag_n / 10) {   // another graph: its sensitivity is not known yet
       c->amg_lag_slope = rules::kLagSlopeStart;
       c->amg_lag_slope_seen = false;
     }
     c->amg_lag_n = c->n;
-    if (const char* e = std::getenv("SGO_AMG_LAG_SLOPE")) {   // test hook: the sensitivity every call starts from (1: keep whatever SGO_AMG_LAG_TAU allows)
-      c->amg_lag_slope = std::atof(e);
+    if (c->knobs.lag_slope > 0.0) {   // test hook (SGO_AMG_LAG_SLOPE): the sensitivity every call starts from (1: keep whatever SGO_AMG_LAG_TAU allows)
+      c->amg_lag_slope = c->knobs.lag_slope;
       c->amg_lag_slope_seen = false;
     }
-    c->amg_lag_on = !(std::getenv("SGO_AMG_LAG") && std::atoi(std::getenv("SGO_AMG_LAG")) == 0) && !multi_rank(c);   // (replicated ranks: the whole single-GPU computation each)
+    c->amg_lag_on = c->knobs.lag_on && !multi_rank(c);   // (replicated ranks: the whole single-GPU computation each)
     c->amg_ref_valid = false;
     c->amg_probe_max = 0.0;
     c->amg_lag_expect = false;
     if (c->amg_probe_k < 4) c->amg_probe_k = 6;
-    const int force_from = std::getenv("SGO_AMG_LAG_FORCE") ? std::atoi(std::getenv("SGO_AMG_LAG_FORCE")) : -1;   // (calibration hook, scripts/lag_calib.py)
+    const int force_from = c->knobs.lag_force_from;   // (calibration hook, scripts/lag_calib.py)
     int fresh_pcg = 0;   // the count of the last solve behind freshly made coarse operators
     int kept_solves = 0;
     int floor_solves = 0;   // solves accepted at the floating-point floor of their system (solve_backward_error)
